@@ -1,0 +1,296 @@
+/*
+ * ngp_hip.h -- C-ABI of libngp_hip.so, the MI355X (gfx950) replacement for the NeRF
+ * training/rendering hot path of NVlabs/instant-ngp.
+ *
+ * The reference has no C boundary on this path: `ngp::Testbed` calls C++ virtual classes of
+ * tiny-cuda-nn (`Encoding<T>`, `Network<float,T>`, `Trainer`, `Optimizer`) plus its own CUDA
+ * kernels, all on one `cudaStream_t`.  Every entry point below names the reference interface
+ * (file:line under /root/reference) it replaces.  Conventions:
+ *   - plain C: opaque handles, POD structs, raw pointers + sizes; no torch / STL types;
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream); calls enqueue
+ *     work and return, exactly like the reference's `(cudaStream_t stream, ...)` methods;
+ *   - return value: 0 on success, non-zero on failure; `ngp_last_error()` holds the message
+ *     (the C++ host turns it back into the `std::runtime_error` the reference would throw);
+ *   - a handle is thread-compatible (one thread at a time), like `ngp::Testbed`.
+ *   - `ngp_half` is IEEE binary16 stored as uint16_t (== `network_precision_t` = `__half`,
+ *     reference CMakeLists.txt:302).
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t ngp_half;
+
+/* ------------------------------------------------------------------ POD mirrors ---------- */
+
+/* BoundingBox, include/neural-graphics-primitives/bounding_box.cuh:247-248 */
+typedef struct ngp_aabb { float min[3]; float max[3]; } ngp_aabb;
+
+/* Ray {vec3 o, d}; tiny-cuda-nn vec.h (usage common_device.cuh:413-490) */
+typedef struct ngp_ray { float o[3]; float d[3]; } ngp_ray;
+
+/* pcg32 state (tiny-cuda-nn/dependencies/pcg32/pcg32.h; `default_rng_t`, random_val.cuh:26) */
+typedef struct ngp_pcg32 { uint64_t state; uint64_t inc; } ngp_pcg32;
+
+/* ELensMode, common.h:184-192 */
+enum { NGP_LENS_PERSPECTIVE = 0, NGP_LENS_OPENCV = 1, NGP_LENS_FTHETA = 2, NGP_LENS_LATLONG = 3,
+       NGP_LENS_OPENCV_FISHEYE = 4, NGP_LENS_EQUIRECTANGULAR = 5, NGP_LENS_ORTHOGRAPHIC = 6 };
+
+/* EImageDataType, common_device.cuh:764-769 */
+enum { NGP_IMAGE_NONE = 0, NGP_IMAGE_BYTE = 1, NGP_IMAGE_HALF = 2, NGP_IMAGE_FLOAT = 3 };
+
+/* ENerfActivation, common.h (None/ReLU/Logistic/Exponential) */
+enum { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONENTIAL = 3 };
+
+/* ELossType, common.h */
+enum { NGP_LOSS_L2 = 0, NGP_LOSS_L1 = 1, NGP_LOSS_MAPE = 2, NGP_LOSS_SMAPE = 3, NGP_LOSS_HUBER = 4,
+       NGP_LOSS_LOGL1 = 5, NGP_LOSS_RELATIVE_L2 = 6 };
+
+/* TrainingImageMetadata, nerf_device.cuh:45-60 (depth / explicit rays / light_dir: out of scope) */
+typedef struct ngp_image_meta {
+	const void* pixels;        /* device pointer to the image (RGBA8 sRGB, RGBA16F or RGBA32F) */
+	int32_t image_data_type;   /* NGP_IMAGE_* */
+	int32_t lens_mode;         /* NGP_LENS_* */
+	int32_t resolution[2];
+	float principal_point[2];
+	float focal_length[2];
+	float rolling_shutter[4];
+	float lens_params[7];
+	float _pad;
+} ngp_image_meta;
+
+/* TrainingXForm {mat4x3 start, end}, common.h:177-182; mat4x3 = 4 columns of vec3 (col-major) */
+typedef struct ngp_xform { float start[12]; float end[12]; } ngp_xform;
+
+/* Hyper-parameters of NerfNetwork + Trainer (nerf_network.h:81-101, testbed.cu:4160-4412,
+ * configs/nerf/base.json). `ngp_model_config_from_json` fills this from the reference's JSON. */
+typedef struct ngp_model_config {
+	/* "encoding": HashGrid (tiny-cuda-nn encodings/grid.h) */
+	uint32_t n_levels;              /* 8  */
+	uint32_t n_features_per_level;  /* 4  */
+	uint32_t log2_hashmap_size;     /* 19 */
+	uint32_t base_resolution;       /* 16 */
+	float per_level_scale;          /* testbed.cu:4241-4255 */
+	/* "network" / "rgb_network": FullyFusedMLP */
+	uint32_t n_neurons;             /* 64 */
+	uint32_t n_hidden_layers;       /* density net: 1 */
+	uint32_t n_hidden_layers_rgb;   /* rgb net: 2 */
+	uint32_t sh_degree;             /* "dir_encoding": SphericalHarmonics degree 4 */
+	uint32_t n_extra_dims;          /* 0 for lego / fox */
+	/* "optimizer": Ema( ExponentialDecay( Adam ) ) */
+	float learning_rate, beta1, beta2, epsilon, l2_reg;
+	float ema_decay;
+	uint32_t decay_start, decay_interval;
+	float decay_base;
+} ngp_model_config;
+
+/* Run-time options of the NeRF trainer; defaults = the reference's member defaults. */
+typedef struct ngp_nerf_options {
+	int32_t rgb_activation;          /* testbed_nerf.cu:2354  Logistic for LDR data */
+	int32_t density_activation;      /* testbed.h:869         Exponential */
+	int32_t loss_type;               /* configs/nerf/base.json:2-4  Huber */
+	int32_t random_bg_color;         /* testbed.h:793  true  */
+	int32_t snap_to_pixel_centers;   /* testbed.h:797  true  */
+	int32_t linear_colors;           /* testbed.h:794  false */
+	int32_t color_space_srgb;        /* testbed.h:1002 0 = Linear, 1 = SRGB (--nerf_compatibility) */
+	float background_color[3];       /* used when !random_bg_color */
+	float near_distance;             /* testbed.h:817  0.1  */
+	float density_grid_decay;        /* testbed.h:818  0.95 */
+	float cone_angle_constant;       /* testbed_nerf.cu:2440 */
+	uint32_t max_cascade;            /* testbed_nerf.cu:2433-2436 */
+	uint32_t target_batch_size;      /* testbed.h:1089  1<<18 samples */
+	float loss_scale;                /* testbed.h:311   128 */
+	uint64_t seed;                   /* testbed.h:680   1337 */
+	/* data-parallel sharding (new): this rank marches global rays
+	 * [rank*R/world, (rank+1)*R/world) of the same global stream */
+	uint32_t rank, world_size;
+} ngp_nerf_options;
+
+/* Counters read back by the host (NerfCounters, testbed.h / testbed_nerf.cu:2669-2702). */
+typedef struct ngp_nerf_stats {
+	uint32_t training_step;
+	uint32_t rays_per_batch;                        /* R used by the NEXT step */
+	uint32_t n_rays_last;                           /* rays that produced samples in the last step */
+	uint32_t measured_batch_size;                   /* compacted samples in the last step */
+	uint32_t measured_batch_size_before_compaction; /* marched samples in the last step */
+	float loss;                                     /* last loss scalar (every 16 steps in the reference) */
+	uint64_t total_rays;                            /* sum of rays_per_batch over all steps */
+	uint64_t total_samples;                         /* sum of measured_batch_size */
+} ngp_nerf_stats;
+
+typedef struct ngp_model ngp_model;      /* NerfNetwork + Trainer + optimizer state */
+typedef struct ngp_nerf ngp_nerf;        /* Testbed::m_nerf state for training/rendering */
+
+const char* ngp_last_error(void);
+/* 1 when a HIP device is visible to this process. */
+int ngp_device_available(void);
+
+/* ------------------------------------------------------------------ model ---------------- */
+
+/* load_network_config + reset_network hyper-parameter derivation: testbed.cu:86-97, 4160-4412.
+ * `aabb_scale` feeds per_level_scale (testbed.cu:4241-4255). Host-only (no device needed). */
+int ngp_model_config_from_json(const char* json_host, uint32_t aabb_scale, uint32_t n_extra_dims,
+                               ngp_model_config* out_host);
+
+/* NerfNetwork ctor (nerf_network.h:81-101) + Trainer ctor (testbed.cu:4383): allocates
+ * {master f32 | params f16 | inference(EMA) params f16 | gradients f16 | Adam m, v, steps | EMA f32}
+ * and initialises from pcg32{seed} in the order density MLP, rgb MLP, pos enc (nerf_network.h:374-386). */
+int ngp_model_create(const ngp_model_config* cfg_host, uint64_t seed, ngp_model** out);
+void ngp_model_destroy(ngp_model*);
+
+/* n_params (nerf_network.h:388-390); *n_mlp_params = "matrix" params (first in the layout). */
+int ngp_model_n_params(const ngp_model*, uint64_t* n_params, uint64_t* n_mlp_params);
+/* Trainer::params / params_inference / gradients device pointers (for snapshots / all-reduce). */
+int ngp_model_param_ptrs(ngp_model*, float** master, ngp_half** params, ngp_half** inference_params,
+                         ngp_half** gradients);
+/* Per-level offsets (in entries) and hashmap sizes; MultiLevelEncoding::level_params_offset
+ * (testbed.cu:4115-4117). Arrays of n_levels+1 / n_levels uint32 on the host. */
+int ngp_model_grid_layout(const ngp_model*, uint32_t* offsets_host, uint32_t* resolutions_host, float* scales_host);
+/* Trainer::set_params_full_precision (testbed.cu:4407): upload f32 params, refresh f16 copies. */
+int ngp_model_set_params_host(ngp_model*, const float* params_host, uint64_t n);
+int ngp_model_get_params_host(ngp_model*, float* params_host, uint64_t n);
+
+/* Network::inference_mixed_precision (nerf_network.h:105-139; call sites testbed_nerf.cu:3235, 1772).
+ * in: NerfCoordinate AoS, `in_stride` floats per element (7 + n_extra_dims); n_ptr (device uint32,
+ * may be NULL) bounds the element count on-device so no host read-back is needed.
+ * out: rgb logits in [0..2], sigma logit in [3]; `out_stride` halfs per element (>= 4). */
+int ngp_model_inference(ngp_model*, void* stream, const float* in, uint32_t in_stride, uint32_t n_max,
+                        const uint32_t* n_ptr, ngp_half* out, uint32_t out_stride, int use_inference_params);
+
+/* NerfNetwork::density (nerf_network.h:270-280; call site testbed_nerf.cu:2570): grid encoding +
+ * density MLP only; out[i] = raw sigma logit. `pos_stride` floats per position (NerfPosition = 3). */
+int ngp_model_density(ngp_model*, void* stream, const float* pos, uint32_t pos_stride, uint32_t n,
+                      ngp_half* out, uint32_t out_stride, int use_inference_params);
+
+/* Trainer::training_step(stream, input, {}, nullptr, false, dL_dinput, false, Overwrite, &dL_dy)
+ * (testbed_nerf.cu:3313-3323 -> nerf_network.h:145-268): forward + backward with an EXTERNAL output
+ * gradient; parameter gradients are overwritten. dL_dy: `dy_stride` halfs per element, [0..3] used. */
+int ngp_model_training_step(ngp_model*, void* stream, const float* in, uint32_t in_stride, uint32_t n,
+                            const ngp_half* dL_dy, uint32_t dy_stride);
+
+/* Trainer::optimizer_step(stream, loss_scale) (testbed_nerf.cu:2770): Adam -> ExponentialDecay -> EMA. */
+int ngp_model_optimizer_step(ngp_model*, void* stream, float loss_scale);
+/* Optimizer::update_hyperparams (testbed.cu:4617-4623): optimize_matrix_params / non_matrix. */
+int ngp_model_set_trainable(ngp_model*, int train_network, int train_encoding);
+float ngp_model_learning_rate(const ngp_model*);
+uint32_t ngp_model_step(const ngp_model*);
+
+/* Trainer::serialize / deserialize payload (testbed.cu:5289, 5468): params (f32 master), and when
+ * `with_optimizer` Adam m/v/steps + EMA. Layout documented in DESIGN.md. Host buffers. */
+uint64_t ngp_model_serialized_size(const ngp_model*, int with_optimizer);
+int ngp_model_serialize_host(ngp_model*, void* buffer_host, uint64_t size, int with_optimizer);
+int ngp_model_deserialize_host(ngp_model*, const void* buffer_host, uint64_t size);
+
+/* ------------------------------------------------------------------ NeRF kernels --------- */
+/* Stand-alone kernels (each mirrors one reference kernel; used by the parity tests and by
+ * ngp_nerf_* below). All buffers are caller-owned device memory. */
+
+/* generate_training_samples_nerf, testbed_nerf.cu:691-849 (launch :3195).
+ * ray_begin/ray_end: this rank's slice of the global ray range [0, n_rays) (8e). */
+int ngp_k_generate_training_samples(
+	void* stream, uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, const uint32_t* n_rays_ptr,
+	ngp_aabb aabb, uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng,
+	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, ngp_ray* rays_out,
+	uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata,
+	const ngp_xform* xforms, const uint8_t* density_grid_bitfield, uint32_t max_mip,
+	int snap_to_pixel_centers, float cone_angle_constant);
+
+/* compute_loss_kernel_train_nerf, testbed_nerf.cu:852-1180 (launch :3241). */
+int ngp_k_compute_loss(
+	void* stream, uint32_t n_rays, const uint32_t* n_rays_ptr, ngp_aabb aabb, ngp_pcg32 rng,
+	uint32_t max_samples_compacted, const uint32_t* rays_counter, float loss_scale,
+	const float background_color[3], int color_space_srgb, int random_bg_color, int linear_colors,
+	uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_half* network_output,
+	uint32_t output_stride, uint32_t* numsteps_counter_compacted, const uint32_t* ray_indices_in,
+	const ngp_ray* rays_in, uint32_t* numsteps_inout, const float* coords_in, float* coords_out,
+	ngp_half* dloss_doutput, uint32_t dloss_stride, int loss_type, float* loss_output,
+	int rgb_activation, int density_activation, int snap_to_pixel_centers,
+	const float* mean_density_ptr, float near_distance);
+
+/* fill_rollover_and_rescale<T> / fill_rollover<float>, launches testbed_nerf.cu:3298-3306. */
+int ngp_k_fill_rollover(void* stream, uint32_t n_elements, const uint32_t* n_input_ptr,
+                        float* coords_inout, uint32_t coord_stride, ngp_half* dloss_inout, uint32_t dloss_stride);
+
+/* mark_untrained_density_grid, testbed_nerf.cu:87-162 */
+int ngp_k_mark_untrained_density_grid(void* stream, uint32_t n_elements, float* grid,
+	uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_xform* xforms, int clear_visible_voxels);
+/* generate_grid_samples_nerf_nonuniform, testbed_nerf.cu:216-257 */
+int ngp_k_generate_grid_samples(void* stream, uint32_t n_elements, ngp_pcg32 rng, uint32_t step, ngp_aabb aabb,
+	const float* grid_in, float* positions_out, uint32_t* indices_out, uint32_t n_cascades, float thresh);
+/* splat_grid_samples_nerf_max_nearest_neighbor, testbed_nerf.cu:259-284 */
+int ngp_k_splat_grid_samples(void* stream, uint32_t n_elements, const uint32_t* indices,
+	const ngp_half* network_output, uint32_t out_stride, float* grid_out, int density_activation);
+/* ema_grid_samples_nerf, testbed_nerf.cu:316-338 */
+int ngp_k_ema_grid_samples(void* stream, uint32_t n_elements, float decay, float* grid_out, const float* grid_in);
+/* update_density_grid_mean_and_bitfield, testbed_nerf.cu:2594-2633 (reduce_sum + grid_to_bitfield :348
+ * + bitfield_max_pool :376). bitfield: 128^3/8 * 8 bytes; mean: 1 float. */
+int ngp_k_update_mean_and_bitfield(void* stream, const float* grid, uint32_t max_cascade,
+	uint8_t* bitfield, float* mean_out);
+/* grid_to_bitfield + max-pool with a caller-supplied mean (bit-exact test hook). */
+int ngp_k_grid_to_bitfield(void* stream, const float* grid, uint32_t max_cascade, uint8_t* bitfield,
+	const float* mean_ptr);
+
+/* ------------------------------------------------------------------ NeRF trainer --------- */
+
+/* Owns Testbed::m_nerf training state: dataset replicas on device, density grid + bitfield,
+ * counters, rng, scratch arena (train_nerf_step's 11 buffers, testbed_nerf.cu:3014-3040). */
+int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* opts_host, ngp_aabb aabb, ngp_nerf** out);
+void ngp_nerf_destroy(ngp_nerf*);
+/* NerfDataset upload (nerf_loader.cu:749-850 set_training_image; metadata/xforms host arrays;
+ * pixels_host[i] points at resolution.x*resolution.y pixels of the given type). */
+int ngp_nerf_set_dataset_host(ngp_nerf*, uint32_t n_images, const ngp_image_meta* metadata_host,
+                              const ngp_xform* xforms_host, const void* const* pixels_host);
+/* Same, but pixels already live on the device (metadata[i].pixels are device pointers). */
+int ngp_nerf_set_dataset_device(ngp_nerf*, uint32_t n_images, const ngp_image_meta* metadata_host,
+                                const ngp_xform* xforms_host);
+/* Testbed::train(batch_size) (testbed.cu:4561-4647): [training_prep_nerf every clamp(step/16,1,16)
+ * steps] + train_nerf (testbed_nerf.cu:2704) = K1..K6, `n_steps` times, WITHOUT host synchronisation
+ * (rays_per_batch adaptation, testbed_nerf.cu:2698-2699, runs on the device). */
+int ngp_nerf_train(ngp_nerf*, void* stream, uint32_t n_steps);
+/* Pieces of the above, exposed for tests / the multi-GPU driver:
+ *   prep      = training_prep_nerf (testbed_nerf.cu:3385) if due
+ *   forward_backward = train_nerf_step (testbed_nerf.cu:3007) -> gradients ready for all-reduce
+ *   finish    = optimizer_step + counters.update_after_training (testbed_nerf.cu:2770-2778) */
+int ngp_nerf_train_prep(ngp_nerf*, void* stream);
+int ngp_nerf_train_forward_backward(ngp_nerf*, void* stream);
+int ngp_nerf_train_finish(ngp_nerf*, void* stream);
+/* Two uint32 {measured_before_compaction, measured} to all-reduce(sum) across ranks (8e). */
+int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters2);
+/* Blocking read-back (the reference's copy_to_host, testbed_nerf.cu:2681-2682). */
+int ngp_nerf_get_stats(ngp_nerf*, void* stream, ngp_nerf_stats* out_host);
+/* update_density_grid_nerf (testbed_nerf.cu:2476-2592) with explicit sample counts. */
+int ngp_nerf_update_density_grid(ngp_nerf*, void* stream, float decay, uint32_t n_uniform, uint32_t n_nonuniform);
+/* device pointers: density grid (float, 128^3*(max_cascade+1)), bitfield (128^3/8*8), mean (1 float) */
+int ngp_nerf_density_grid_ptrs(ngp_nerf*, float** grid, uint8_t** bitfield, float** mean);
+int ngp_nerf_set_density_grid_host(ngp_nerf*, void* stream, const float* grid_host, uint64_t n);
+
+/* Testbed::render_nerf (testbed_nerf.cu:1894-2149) semantics of the fused per-pixel kernel
+ * fused_kernels/render_nerf.cuh:22-184: frame_buffer = premultiplied linear RGBA float4 per pixel,
+ * depth_buffer float per pixel. camera = mat4x3 col-major (12 floats, host). */
+typedef struct ngp_render_params {
+	int32_t resolution[2];
+	float focal_length[2];
+	float screen_center[2];
+	float camera[12];
+	int32_t lens_mode; float lens_params[7];
+	uint32_t spp_index;              /* sample_index */
+	int32_t snap_to_pixel_centers;
+	float min_transmittance;         /* testbed.h:890 0.01, eval 1e-4 */
+	float near_distance;             /* m_render_near_distance (0 for eval) */
+	int32_t use_inference_params;    /* 1: EMA weights (testbed_nerf.cu:1772) */
+	ngp_aabb render_aabb;
+} ngp_render_params;
+int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_host,
+                    float* frame_buffer, float* depth_buffer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

@@ -1,0 +1,625 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see ora_math.hpp header).  PARITY UNPINNED.
+//
+// ora_nerf.hpp: CPU restatement of the ngp-side NeRF kernels: camera model, K1
+// generate_training_samples_nerf, K3 compute_loss_kernel_train_nerf, the occupancy-grid update chain,
+// the fused per-pixel renderer, and the Testbed::train driver (prep cadence, counters, rng).
+#pragma once
+#include "ora_model.hpp"
+
+namespace ora {
+
+// common_device.cuh:778-793
+inline void image_pos(vec2 pos, const int32_t res[2], int& px, int& py) {
+	px = clampi((int)(pos.x * (float)res[0]), 0, res[0] - 1);
+	py = clampi((int)(pos.y * (float)res[1]), 0, res[1] - 1);
+}
+
+// read_rgba, common_device.cuh:846-872 (host pointer version of `pixels`)
+inline vec4 read_rgba(vec2 uv, const int32_t res[2], const void* pixels, int type) {
+	int px, py; image_pos(uv, res, px, py);
+	size_t idx = (size_t)px + (size_t)py * res[0];
+	switch (type) {
+		case NGP_IMAGE_BYTE: {
+			uint32_t val = ((const uint32_t*)pixels)[idx];
+			if (val == 0x00FF00FFu) return {-1.f, -1.f, -1.f, -1.f};
+			vec4 r = {((val & 0x000000FFu) >> 0) * (1.0f / 255.0f), ((val & 0x0000FF00u) >> 8) * (1.0f / 255.0f),
+			          ((val & 0x00FF0000u) >> 16) * (1.0f / 255.0f), ((val & 0xFF000000u) >> 24) * (1.0f / 255.0f)};
+			r.x = srgb_to_linear(r.x) * r.w; r.y = srgb_to_linear(r.y) * r.w; r.z = srgb_to_linear(r.z) * r.w;
+			return r;
+		}
+		case NGP_IMAGE_HALF: {
+			const uint16_t* p = (const uint16_t*)pixels + idx * 4;
+			return {h2f(p[0]), h2f(p[1]), h2f(p[2]), h2f(p[3])};
+		}
+		case NGP_IMAGE_FLOAT: {
+			const float* p = (const float*)pixels + idx * 4;
+			return {p[0], p[1], p[2], p[3]};
+		}
+		default: return {5.0f, 0.0f, 0.0f, 1.0f};
+	}
+}
+
+// opencv_lens_distortion_delta + iterative_lens_undistortion, common_device.cuh:268-345
+inline void opencv_lens_distortion_delta(const float* p, float u, float v, float* du, float* dv) {
+	const float k1 = p[0], k2 = p[1], p1 = p[2], p2 = p[3];
+	const float u2 = u * u, uv = u * v, v2 = v * v, r2 = u2 + v2;
+	const float radial = k1 * r2 + k2 * r2 * r2;
+	*du = u * radial + 2.f * p1 * uv + p2 * (r2 + 2.f * u2);
+	*dv = v * radial + 2.f * p2 * uv + p1 * (r2 + 2.f * v2);
+}
+inline void iterative_opencv_lens_undistortion(const float* params, float* u, float* v) {
+	const uint32_t kNumIterations = 100;
+	const float kMaxStepNorm = 1e-10f, kRelStepSize = 1e-6f;
+	const float eps = std::numeric_limits<float>::epsilon();
+	const float x0[2] = {*u, *v};
+	float x[2] = {*u, *v};
+	for (uint32_t i = 0; i < kNumIterations; ++i) {
+		const float step0 = std::max(eps, std::fabs(kRelStepSize * x[0]));
+		const float step1 = std::max(eps, std::fabs(kRelStepSize * x[1]));
+		float dx[2], d0b[2], d0f[2], d1b[2], d1f[2];
+		opencv_lens_distortion_delta(params, x[0], x[1], &dx[0], &dx[1]);
+		opencv_lens_distortion_delta(params, x[0] - step0, x[1], &d0b[0], &d0b[1]);
+		opencv_lens_distortion_delta(params, x[0] + step0, x[1], &d0f[0], &d0f[1]);
+		opencv_lens_distortion_delta(params, x[0], x[1] - step1, &d1b[0], &d1b[1]);
+		opencv_lens_distortion_delta(params, x[0], x[1] + step1, &d1f[0], &d1f[1]);
+		// J is column-major: J[c][r]
+		float J00 = 1 + (d0f[0] - d0b[0]) / (2 * step0);
+		float J10 = (d1f[0] - d1b[0]) / (2 * step1);
+		float J01 = (d0f[1] - d0b[1]) / (2 * step0);
+		float J11 = 1 + (d1f[1] - d1b[1]) / (2 * step1);
+		// step_x = inverse(J) * (x + dx - x0); matrix M = [[J00, J10],[J01, J11]] (row r, col c)
+		float r0 = x[0] + dx[0] - x0[0], r1 = x[1] + dx[1] - x0[1];
+		float det = J00 * J11 - J10 * J01;
+		float s0 = (J11 * r0 - J10 * r1) / det;
+		float s1 = (-J01 * r0 + J00 * r1) / det;
+		x[0] -= s0; x[1] -= s1;
+		if (s0 * s0 + s1 * s1 < kMaxStepNorm) break;
+	}
+	*u = x[0]; *v = x[1];
+}
+
+// uv_to_ray, common_device.cuh:413-490, restricted to what the NeRF path uses: Perspective and OpenCV
+// lenses, no foveation / hidden-area mask / distortion map / aperture; parallax_shift = 0.
+inline bool uv_to_ray(vec2 uv, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
+		int lens_mode, const float* lens_params, float near_distance, vec3& o, vec3& d) {
+	vec3 dir = {(uv.x - screen_center[0]) * (float)res[0] / focal[0], (uv.y - screen_center[1]) * (float)res[1] / focal[1], 1.0f};
+	if (lens_mode == NGP_LENS_OPENCV) iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
+	else if (lens_mode != NGP_LENS_PERSPECTIVE) throw std::runtime_error("oracle: lens mode out of scope");
+	dir = mul3(cam, dir);
+	vec3 origin = cam[3];
+	origin += dir * near_distance;
+	o = origin; d = dir;
+	return true;
+}
+
+// image_idx (no cdf), nerf_device.cuh:578-599
+inline uint32_t image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_training_images) {
+	return ((base_idx * n_training_images) / n_rays) % n_training_images; // uint32 arithmetic, as on the device
+}
+// nerf_random_image_pos_training (no cdf), nerf_device.cuh:553-576
+inline vec2 random_image_pos_training(Pcg32& rng, const int32_t res[2], bool snap) {
+	vec2 uv; uv.x = rng.next_float(); uv.y = rng.next_float();
+	if (snap) {
+		uv.x = ((float)clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1) + 0.5f) / (float)res[0];
+		uv.y = ((float)clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1) + 0.5f) / (float)res[1];
+	}
+	return uv;
+}
+
+// losses, nerf_device.cuh:75-143, 601-616
+struct LossAndGradient { vec3 loss, gradient; };
+inline LossAndGradient loss_and_gradient(vec3 target, vec3 pred, int type) {
+	vec3 diff = pred - target;
+	LossAndGradient r;
+	auto cps = [](float mag, float s) { return std::copysign(mag, s); };
+	switch (type) {
+		case NGP_LOSS_RELATIVE_L2: { vec3 den = pred * pred + 1e-2f; r.loss = diff * diff / den; r.gradient = 2.0f * diff / den; break; }
+		case NGP_LOSS_L1: { r.loss = vabs(diff); r.gradient = {cps(1.f, diff.x), cps(1.f, diff.y), cps(1.f, diff.z)}; break; }
+		case NGP_LOSS_MAPE: { vec3 den = vabs(pred) + 1e-2f; r.loss = vabs(diff) / den;
+			r.gradient = {cps(1.f / den.x, diff.x), cps(1.f / den.y, diff.y), cps(1.f / den.z, diff.z)}; break; }
+		case NGP_LOSS_SMAPE: { vec3 den = 0.5f * (vabs(pred) + vabs(target)) + 1e-2f; r.loss = vabs(diff) / den;
+			r.gradient = {cps(1.f / den.x, diff.x), cps(1.f / den.y, diff.y), cps(1.f / den.z, diff.z)}; break; }
+		case NGP_LOSS_HUBER: {
+			const float alpha = 0.1f;
+			for (int k = 0; k < 3; ++k) {
+				float df = diff[k], ad = std::fabs(df), sq = 0.5f / alpha * df * df;
+				r.loss[k] = (ad > alpha ? (ad - 0.5f * alpha) : sq) / 5.0f;
+				r.gradient[k] = (ad > alpha ? (df > 0 ? 1.0f : -1.0f) : (df / alpha)) / 5.0f;
+			}
+			break; }
+		case NGP_LOSS_LOGL1: { vec3 dv = vabs(diff) + 1.0f; r.loss = {std::log(dv.x), std::log(dv.y), std::log(dv.z)};
+			r.gradient = {cps(1.f / dv.x, diff.x), cps(1.f / dv.y, diff.y), cps(1.f / dv.z, diff.z)}; break; }
+		default: { r.loss = diff * diff; r.gradient = 2.0f * diff; break; }
+	}
+	return r;
+}
+
+// -------------------------------------------------------------------------------------------------
+// K1: generate_training_samples_nerf, testbed_nerf.cu:691-849.  Threads (= rays) run in index order,
+// so `base` offsets are deterministic here (the device's atomics order is not).
+// ray range [ray_begin, ray_end) of the global range [0, n_rays) = this rank's shard.
+// -------------------------------------------------------------------------------------------------
+struct K1Out {
+	uint32_t ray_counter = 0, numsteps_counter = 0;
+};
+inline K1Out generate_training_samples(uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, const Aabb& aabb, uint32_t max_samples,
+		const Pcg32& rng_in, uint32_t* ray_indices_out, ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out /* 7 floats each */,
+		uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip,
+		bool snap_to_pixel_centers, float cone_angle_constant) {
+	K1Out k;
+	for (uint32_t i = ray_begin; i < ray_end && i < n_rays; ++i) {
+		uint32_t img = image_idx(i, n_rays, n_images);
+		const ngp_image_meta& m = meta[img];
+		Pcg32 rng = rng_in;
+		rng.advance((int64_t)(i * N_MAX_RANDOM_SAMPLES_PER_RAY));
+		vec2 uv = random_image_pos_training(rng, m.resolution, snap_to_pixel_centers);
+		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) continue; // masked away
+		/* max_level_rand_training = false: max_level = 1, no draw */
+		float motionblur_time = rng.next_float(); (void)motionblur_time;
+		// get_xform_given_rolling_shutter, common_device.cuh:670-674: start == end (no rolling shutter / motion blur data)
+		const mat4x3 xform = M43(xforms[img].start);
+		vec3 ro, rd;
+		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+		vec3 rdn = normalize(rd);
+		vec2 tminmax = aabb.ray_intersect(ro, rdn);
+		float cone_angle = cone_angle_constant; // calc_cone_angle, nerf_device.cuh:370-377
+		tminmax.x = std::fmax(tminmax.x, 0.0f);
+		float startt = advance_n_steps(tminmax.x, cone_angle, rng.next_float());
+		vec3 idir = V3(1.0f) / rdn;
+
+		uint32_t j = 0;
+		float t = startt;
+		vec3 pos;
+		while (aabb.contains(pos = ro + t * rdn) && j < NERF_STEPS) {
+			float dt = calc_dt(t, cone_angle);
+			uint32_t mip = mip_from_dt(dt, pos, max_mip);
+			if (density_grid_occupied_at(pos, bitfield, mip)) { ++j; t += dt; }
+			else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
+		}
+		if (j == 0) continue;
+		uint32_t numsteps = j;
+		uint32_t base = k.numsteps_counter; k.numsteps_counter += numsteps;
+		if (base + numsteps > max_samples) continue;
+		float* co = coords_out + (size_t)base * 7;
+		uint32_t ray_idx = k.ray_counter++;
+		ray_indices_out[ray_idx] = i;
+		rays_out[ray_idx] = {{ro.x, ro.y, ro.z}, {rd.x, rd.y, rd.z}};
+		numsteps_out[ray_idx * 2 + 0] = numsteps;
+		numsteps_out[ray_idx * 2 + 1] = base;
+		vec3 wd = warp_direction(rdn);
+		t = startt; j = 0;
+		while (aabb.contains(pos = ro + t * rdn) && j < numsteps) {
+			float dt = calc_dt(t, cone_angle);
+			uint32_t mip = mip_from_dt(dt, pos, max_mip);
+			if (density_grid_occupied_at(pos, bitfield, mip)) {
+				vec3 wp = warp_position(pos, aabb);
+				float* c = co + (size_t)j * 7;
+				c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+				++j; t += dt;
+			} else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
+		}
+	}
+	return k;
+}
+
+// -------------------------------------------------------------------------------------------------
+// K3: compute_loss_kernel_train_nerf, testbed_nerf.cu:852-1180 (no envmap / depth / error-map /
+// exposure: off by default).  __expf is restated as expf.
+// -------------------------------------------------------------------------------------------------
+struct K3Opts {
+	float loss_scale = 128.f;
+	vec3 background_color = {0, 0, 0};
+	bool color_space_srgb = false, random_bg = true, linear_colors = false, snap = true;
+	int loss_type = NGP_LOSS_HUBER, rgb_act = NGP_ACT_LOGISTIC, density_act = NGP_ACT_EXPONENTIAL;
+	float near_distance = 0.1f;
+};
+inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb& aabb, const Pcg32& rng_in, uint32_t max_samples_compacted,
+		const K3Opts& o, uint32_t n_images, const ngp_image_meta* meta, const uint16_t* network_output, uint32_t out_stride,
+		const uint32_t* ray_indices_in, const ngp_ray* rays_in, uint32_t* numsteps_inout, const float* coords_in, float* coords_out,
+		uint16_t* dloss_doutput, uint32_t dl_stride, float* loss_output, float mean_density) {
+	uint32_t counter = 0;
+	for (uint32_t i = 0; i < rays_counter; ++i) {
+		uint32_t numsteps = numsteps_inout[i * 2 + 0];
+		uint32_t base = numsteps_inout[i * 2 + 1];
+		const float* cin = coords_in + (size_t)base * 7;
+		const uint16_t* no = network_output + (size_t)base * out_stride;
+
+		float T = 1.f;
+		const float EPSILON = 1e-4f;
+		vec3 rgb_ray = V3(0.f);
+		uint32_t compacted_numsteps = 0;
+		vec3 ray_o = V3(rays_in[i].o);
+		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
+			if (T < EPSILON) break;
+			const uint16_t* lo = no + (size_t)compacted_numsteps * out_stride;
+			vec3 rgb = {network_to_rgb(h2f(lo[0]), o.rgb_act), network_to_rgb(h2f(lo[1]), o.rgb_act), network_to_rgb(h2f(lo[2]), o.rgb_act)};
+			const float dt = unwarp_dt(cin[compacted_numsteps * 7 + 3]);
+			float density = network_to_density(h2f(lo[3]), o.density_act);
+			const float alpha = 1.f - std::exp(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray += weight * rgb;
+			T *= (1.f - alpha);
+		}
+
+		uint32_t ray_idx = ray_indices_in[i];
+		Pcg32 rng = rng_in;
+		rng.advance((int64_t)(ray_idx * N_MAX_RANDOM_SAMPLES_PER_RAY));
+		uint32_t img = image_idx(ray_idx, n_rays, n_images);
+		const ngp_image_meta& m = meta[img];
+		vec2 uv = random_image_pos_training(rng, m.resolution, o.snap);
+		rng.advance(1); // motionblur_time
+		vec3 background_color = o.background_color;
+		if (o.random_bg) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
+		background_color = srgb_to_linear(background_color);
+
+		vec4 texsamp = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+		vec3 trgb = {texsamp.x, texsamp.y, texsamp.z};
+		vec3 rgbtarget;
+		if (o.linear_colors || !o.color_space_srgb) {
+			rgbtarget = trgb + (1.0f - texsamp.w) * background_color; // exposure_scale = exp(0) = 1
+			if (!o.linear_colors) {
+				rgbtarget = linear_to_srgb(rgbtarget);
+				background_color = linear_to_srgb(background_color);
+			}
+		} else {
+			background_color = linear_to_srgb(background_color);
+			if (texsamp.w > 0) rgbtarget = linear_to_srgb(trgb / texsamp.w) * texsamp.w + (1.0f - texsamp.w) * background_color;
+			else rgbtarget = background_color;
+		}
+		if (compacted_numsteps == numsteps) rgb_ray += T * background_color;
+
+		uint32_t compacted_base = counter; counter += compacted_numsteps;
+		compacted_numsteps = std::min(max_samples_compacted - std::min(max_samples_compacted, compacted_base), compacted_numsteps);
+		numsteps_inout[i * 2 + 0] = compacted_numsteps;
+		numsteps_inout[i * 2 + 1] = compacted_base;
+		if (compacted_numsteps == 0) continue;
+
+		float* cout = coords_out + (size_t)compacted_base * 7;
+		uint16_t* dl = dloss_doutput + (size_t)compacted_base * dl_stride;
+
+		LossAndGradient lg = loss_and_gradient(rgbtarget, rgb_ray, o.loss_type);
+		float mean_loss = mean(lg.loss);
+		if (loss_output) loss_output[i] = mean_loss / (float)n_rays;
+
+		float loss_scale = o.loss_scale / n_rays;
+		const float output_l2_reg = o.rgb_act == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = mean_density < NERF_MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
+
+		vec3 rgb_ray2 = V3(0.f);
+		T = 1.f;
+		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
+			for (int k = 0; k < 7; ++k) cout[(size_t)j * 7 + k] = cin[(size_t)j * 7 + k];
+			const vec3 pos = unwarp_position(V3(cin + (size_t)j * 7), aabb);
+			float depth = distance(pos, ray_o);
+			float dt = unwarp_dt(cin[(size_t)j * 7 + 3]);
+			const uint16_t* lo = no + (size_t)j * out_stride;
+			float l0 = h2f(lo[0]), l1 = h2f(lo[1]), l2 = h2f(lo[2]), l3 = h2f(lo[3]);
+			const vec3 rgb = {network_to_rgb(l0, o.rgb_act), network_to_rgb(l1, o.rgb_act), network_to_rgb(l2, o.rgb_act)};
+			const float density = network_to_density(l3, o.density_act);
+			const float alpha = 1.f - std::exp(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray2 += weight * rgb;
+			T *= (1.f - alpha);
+			const vec3 suffix = rgb_ray - rgb_ray2;
+			const vec3 dloss_by_drgb = weight * lg.gradient;
+			float d0 = loss_scale * (dloss_by_drgb.x * network_to_rgb_derivative(l0, o.rgb_act) + std::fmax(0.0f, output_l2_reg * l0));
+			float d1 = loss_scale * (dloss_by_drgb.y * network_to_rgb_derivative(l1, o.rgb_act) + std::fmax(0.0f, output_l2_reg * l1));
+			float d2 = loss_scale * (dloss_by_drgb.z * network_to_rgb_derivative(l2, o.rgb_act) + std::fmax(0.0f, output_l2_reg * l2));
+			float density_derivative = network_to_density_derivative(l3, o.density_act);
+			float dloss_by_dmlp = density_derivative * (dt * (dot(lg.gradient, T * rgb - suffix) + 0.0f /* depth supervision off */));
+			float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < o.near_distance ? 1e-4f : 0.0f);
+			uint16_t* d = dl + (size_t)j * dl_stride;
+			d[0] = f2h(d0); d[1] = f2h(d1); d[2] = f2h(d2); d[3] = f2h(d3);
+		}
+	}
+	return counter;
+}
+
+// -------------------------------------------------------------------------------------------------
+// occupancy grid, testbed_nerf.cu:87-396, 2476-2633
+// -------------------------------------------------------------------------------------------------
+// pos_to_uv, common_device.cuh:527-577 (Perspective / OpenCV)
+inline vec2 pos_to_uv(vec3 pos, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
+		int lens_mode, const float* lens_params) {
+	vec3 dir = pos - cam[3];
+	// inverse(mat3(cam)) * dir via cofactors
+	const vec3 &a = cam.c[0], &b = cam.c[1], &c = cam.c[2];
+	float det = a.x * (b.y * c.z - c.y * b.z) - b.x * (a.y * c.z - c.y * a.z) + c.x * (a.y * b.z - b.y * a.z);
+	float id = 1.0f / det;
+	vec3 r0 = {(b.y * c.z - c.y * b.z) * id, -(b.x * c.z - c.x * b.z) * id, (b.x * c.y - c.x * b.y) * id};
+	vec3 r1 = {-(a.y * c.z - c.y * a.z) * id, (a.x * c.z - c.x * a.z) * id, -(a.x * c.y - c.x * a.y) * id};
+	vec3 r2 = {(a.y * b.z - b.y * a.z) * id, -(a.x * b.z - b.x * a.z) * id, (a.x * b.y - b.x * a.y) * id};
+	dir = {dot(r0, dir), dot(r1, dir), dot(r2, dir)};
+	dir /= dir.z;
+	float du = 0.f, dv = 0.f;
+	if (lens_mode == NGP_LENS_OPENCV) opencv_lens_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
+	dir.x += du; dir.y += dv;
+	return {dir.x * focal[0] / (float)res[0] + screen_center[0], dir.y * focal[1] / (float)res[1] + screen_center[1]};
+}
+
+// mark_untrained_density_grid, testbed_nerf.cu:87-162
+inline void mark_untrained_density_grid(uint32_t n_elements, float* grid, uint32_t n_images, const ngp_image_meta* meta,
+		const ngp_xform* xforms, bool clear_visible_voxels) {
+	#pragma omp parallel for schedule(static)
+	for (int64_t ii = 0; ii < (int64_t)n_elements; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		uint32_t level = i / NERF_GRID_N_CELLS, pos_idx = i % NERF_GRID_N_CELLS;
+		uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+		float voxel_size = std::scalbn(1.0f / NERF_GRIDSIZE, (int)level);
+		vec3 pos = (vec3{(float)x, (float)y, (float)z} / (float)NERF_GRIDSIZE - 0.5f) * std::scalbn(1.0f, (int)level) + 0.5f;
+		vec3 corners[8];
+		for (int k = 0; k < 8; ++k) corners[k] = pos + vec3{(k & 1) ? voxel_size : 0.f, (k & 2) ? voxel_size : 0.f, (k & 4) ? voxel_size : 0.f};
+		const uint32_t min_count = 1;
+		uint32_t count = 0;
+		for (uint32_t j = 0; j < n_images && count < min_count; ++j) {
+			const mat4x3 xf = M43(xforms[j].start);
+			const ngp_image_meta& m = meta[j];
+			for (uint32_t k = 0; k < 8; ++k) {
+				vec3 dir = normalize(corners[k] - xf[3]);
+				if (dot(dir, xf[2]) < 1e-4f) continue;
+				vec2 uv = pos_to_uv(corners[k], m.resolution, m.focal_length, xf, m.principal_point, m.lens_mode, m.lens_params);
+				vec3 ro, rd;
+				uv_to_ray(uv, m.resolution, m.focal_length, xf, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+				if (distance(normalize(rd), dir) < 1e-3f && uv.x > 0.0f && uv.y > 0.0f && uv.x < 1.0f && uv.y < 1.0f) { ++count; break; }
+			}
+		}
+		if (clear_visible_voxels || (grid[i] < 0) != (count < min_count)) grid[i] = (count >= min_count) ? 0.f : -1.f;
+	}
+}
+
+// generate_grid_samples_nerf_nonuniform, testbed_nerf.cu:216-257
+inline void generate_grid_samples_nonuniform(uint32_t n_elements, const Pcg32& rng_in, uint32_t step, const Aabb& aabb, const float* grid_in,
+		float* out_pos /* 3 floats */, uint32_t* indices, uint32_t n_cascades, float thresh) {
+	#pragma omp parallel for schedule(static)
+	for (int64_t ii = 0; ii < (int64_t)n_elements; ++ii) {
+		uint32_t i = (uint32_t)ii;
+		Pcg32 rng = rng_in;
+		rng.advance((int64_t)(i * 4u));
+		uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
+		uint32_t idx = 0;
+		for (uint32_t j = 0; j < 10; ++j) {
+			idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % NERF_GRID_N_CELLS;
+			idx += level * NERF_GRID_N_CELLS;
+			if (grid_in[idx] > thresh) break;
+		}
+		uint32_t pos_idx = idx % NERF_GRID_N_CELLS;
+		uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+		vec3 r; r.x = rng.next_float(); r.y = rng.next_float(); r.z = rng.next_float();
+		vec3 pos = ((vec3{(float)x, (float)y, (float)z} + r) / (float)NERF_GRIDSIZE - 0.5f) * std::scalbn(1.0f, (int)level) + 0.5f;
+		vec3 wp = warp_position(pos, aabb);
+		out_pos[(size_t)i * 3 + 0] = wp.x; out_pos[(size_t)i * 3 + 1] = wp.y; out_pos[(size_t)i * 3 + 2] = wp.z;
+		indices[i] = idx;
+	}
+}
+
+// splat_grid_samples_nerf_max_nearest_neighbor, testbed_nerf.cu:259-284 (atomicMax on uint bits of a
+// non-negative float == float max)
+inline void splat_grid_samples(uint32_t n, const uint32_t* indices, const uint16_t* net_out, uint32_t stride, float* grid_out, int density_act) {
+	for (uint32_t i = 0; i < n; ++i) {
+		float mlp = network_to_density(h2f(net_out[(size_t)i * stride]), density_act);
+		float thick = mlp * std::scalbn(MIN_CONE_STEPSIZE, 0);
+		uint32_t a, b; std::memcpy(&a, &grid_out[indices[i]], 4); std::memcpy(&b, &thick, 4);
+		if (b > a) std::memcpy(&grid_out[indices[i]], &b, 4);
+	}
+}
+// ema_grid_samples_nerf, testbed_nerf.cu:316-338
+inline void ema_grid_samples(uint32_t n, float decay, float* grid_out, const float* grid_in) {
+	for (uint32_t i = 0; i < n; ++i) {
+		float prev = grid_out[i];
+		grid_out[i] = (prev < 0.f) ? prev : std::fmax(prev * decay, grid_in[i]);
+	}
+}
+// reduce_sum lambda, testbed_nerf.cu:2602-2608 (summation order differs from the device; compared with tolerance)
+inline float density_grid_mean(const float* grid) {
+	double s = 0;
+	for (uint32_t i = 0; i < NERF_GRID_N_CELLS; ++i) s += (double)(std::fmax(grid[i], 0.f) / (float)NERF_GRID_N_CELLS);
+	return (float)s;
+}
+// grid_to_bitfield :348-374 + bitfield_max_pool :376-396 (launch loop :2621-2630)
+inline void grid_to_bitfield_and_pool(const float* grid, uint32_t max_cascade, uint8_t* bitfield, float mean_density) {
+	const uint32_t n_elements = NERF_GRID_N_CELLS / 8 * NERF_CASCADES;
+	const uint32_t n_nonzero = NERF_GRID_N_CELLS / 8 * (max_cascade + 1);
+	float thresh = std::min(NERF_MIN_OPTICAL_THICKNESS, mean_density);
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		if (i >= n_nonzero) { bitfield[i] = 0; continue; }
+		uint8_t bits = 0;
+		for (uint8_t j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? ((uint8_t)1 << j) : 0;
+		bitfield[i] = bits;
+	}
+	for (uint32_t level = 1; level < NERF_CASCADES; ++level) {
+		const uint8_t* prev = bitfield + grid_mip_offset(level - 1) / 8;
+		uint8_t* next = bitfield + grid_mip_offset(level) / 8;
+		for (uint32_t i = 0; i < NERF_GRID_N_CELLS / 64; ++i) {
+			uint8_t bits = 0;
+			for (uint8_t j = 0; j < 8; ++j) bits |= prev[(size_t)i * 8 + j] > 0 ? ((uint8_t)1 << j) : 0;
+			uint32_t x = morton3D_invert(i >> 0) + NERF_GRIDSIZE / 8;
+			uint32_t y = morton3D_invert(i >> 1) + NERF_GRIDSIZE / 8;
+			uint32_t z = morton3D_invert(i >> 2) + NERF_GRIDSIZE / 8;
+			next[morton3D(x, y, z)] |= bits;
+		}
+	}
+}
+
+// -------------------------------------------------------------------------------------------------
+// Trainer = the NeRF half of ngp::Testbed (train loop: testbed.cu:4561-4647; train_nerf
+// testbed_nerf.cu:2704-2790; train_nerf_step :3007-3382; training_prep_nerf :3385-3398;
+// NerfCounters :2669-2702; reset_network rng plumbing testbed.cu:4163-4178).
+// -------------------------------------------------------------------------------------------------
+struct NerfTrainer {
+	Model* model;
+	ngp_nerf_options opt;
+	Aabb aabb;
+	std::vector<ngp_image_meta> meta;
+	std::vector<ngp_xform> xforms;
+	std::vector<float> density_grid;      // 128^3 * (max_cascade+1)
+	std::vector<uint8_t> bitfield;        // 128^3/8 * 8
+	float mean_density = 0.f;
+	uint32_t ema_step = 0;
+	Pcg32 rng, density_grid_rng;
+	uint32_t training_step = 0;
+	uint32_t rays_per_batch = 1u << 12, n_rays_total = 0;
+	uint32_t measured_batch_size = 0, measured_batch_size_before_compaction = 0;
+	uint32_t n_rays_last = 0;
+	float loss_scalar = 0.f;
+	uint64_t total_rays = 0, total_samples = 0;
+	// scratch kept for inspection by tests
+	std::vector<uint32_t> ray_indices, numsteps;
+	std::vector<ngp_ray> rays;
+	std::vector<float> coords, coords_compacted, loss;
+	std::vector<uint16_t> mlp_out, dloss;
+
+	NerfTrainer(Model* m, const ngp_nerf_options& o, const ngp_aabb& box) : model(m), opt(o), aabb(box) {
+		rng = Pcg32(o.seed);                         // testbed.cu:4163
+		density_grid_rng = Pcg32(rng.next_uint());   // testbed.cu:4178
+		density_grid.assign((size_t)NERF_GRID_N_CELLS * (o.max_cascade + 1), 0.f);
+		bitfield.assign((size_t)NERF_GRID_N_CELLS / 8 * NERF_CASCADES, 0);
+	}
+	void set_dataset(uint32_t n, const ngp_image_meta* m, const ngp_xform* x) { meta.assign(m, m + n); xforms.assign(x, x + n); }
+
+	void update_mean_and_bitfield() {
+		mean_density = density_grid_mean(density_grid.data());
+		grid_to_bitfield_and_pool(density_grid.data(), opt.max_cascade, bitfield.data(), mean_density);
+	}
+
+	// update_density_grid_nerf, testbed_nerf.cu:2476-2592
+	void update_density_grid(float decay, uint32_t n_uniform, uint32_t n_nonuniform) {
+		const uint32_t n_elements = NERF_GRID_N_CELLS * (opt.max_cascade + 1);
+		const uint32_t n_samples = n_uniform + n_nonuniform;
+		if (training_step == 0) {
+			ema_step = 0;
+			mark_untrained_density_grid(n_elements, density_grid.data(), (uint32_t)meta.size(), meta.data(), xforms.data(), true);
+		}
+		std::vector<float> positions((size_t)n_samples * 3), tmp(n_elements, 0.f);
+		std::vector<uint32_t> indices(n_samples);
+		std::vector<uint16_t> out(n_samples);
+		generate_grid_samples_nonuniform(n_uniform, density_grid_rng, ema_step, aabb, density_grid.data(), positions.data(), indices.data(), opt.max_cascade + 1, -0.01f);
+		density_grid_rng.advance();
+		generate_grid_samples_nonuniform(n_nonuniform, density_grid_rng, ema_step, aabb, density_grid.data(), positions.data() + (size_t)n_uniform * 3,
+			indices.data() + n_uniform, opt.max_cascade + 1, NERF_MIN_OPTICAL_THICKNESS);
+		density_grid_rng.advance();
+		model->density(positions.data(), 3, n_samples, out.data(), 1, false);
+		splat_grid_samples(n_samples, indices.data(), out.data(), 1, tmp.data(), opt.density_activation);
+		ema_grid_samples(n_elements, decay, density_grid.data(), tmp.data());
+		++ema_step;
+		update_mean_and_bitfield();
+	}
+
+	// training_prep_nerf, testbed_nerf.cu:3385-3398
+	void training_prep() {
+		uint32_t n_cascades = opt.max_cascade + 1;
+		if (training_step < 256) update_density_grid(opt.density_grid_decay, NERF_GRID_N_CELLS * n_cascades, 0);
+		else update_density_grid(opt.density_grid_decay, NERF_GRID_N_CELLS / 4 * n_cascades, NERF_GRID_N_CELLS / 4 * n_cascades);
+	}
+
+	// train_nerf_step (forward + backward), testbed_nerf.cu:3007-3382
+	void forward_backward() {
+		const uint32_t B = opt.target_batch_size;
+		const uint32_t max_samples = B * 16;
+		uint32_t max_inference;
+		if (measured_batch_size_before_compaction == 0) { measured_batch_size_before_compaction = max_inference = max_samples; }
+		else max_inference = next_multiple(std::min(measured_batch_size_before_compaction, max_samples), 256u);
+		const uint32_t R = rays_per_batch;
+		if (training_step == 0) n_rays_total = 0;
+		n_rays_total += R;
+		ray_indices.assign(R, 0); rays.assign(R, ngp_ray{}); numsteps.assign((size_t)R * 2, 0);
+		coords.assign((size_t)max_inference * 7, 0.f); mlp_out.assign((size_t)max_inference * 4, 0);
+		coords_compacted.assign((size_t)B * 7, 0.f); dloss.assign((size_t)B * 4, 0); loss.assign(R, 0.f);
+		uint32_t rb = (uint32_t)((uint64_t)R * opt.rank / std::max(1u, opt.world_size));
+		uint32_t re = (uint32_t)((uint64_t)R * (opt.rank + 1) / std::max(1u, opt.world_size));
+		K1Out k1 = generate_training_samples(R, rb, re, aabb, max_inference, rng, ray_indices.data(), rays.data(), numsteps.data(), coords.data(),
+			(uint32_t)meta.size(), meta.data(), xforms.data(), bitfield.data(), opt.max_cascade, opt.snap_to_pixel_centers, opt.cone_angle_constant);
+		uint32_t n_inf = std::min(k1.numsteps_counter, max_inference);
+		model->inference(coords.data(), 7, n_inf, mlp_out.data(), 4, false);
+		K3Opts ko;
+		ko.loss_scale = opt.loss_scale; ko.background_color = V3(opt.background_color); ko.color_space_srgb = opt.color_space_srgb;
+		ko.random_bg = opt.random_bg_color; ko.linear_colors = opt.linear_colors; ko.snap = opt.snap_to_pixel_centers;
+		ko.loss_type = opt.loss_type; ko.rgb_act = opt.rgb_activation; ko.density_act = opt.density_activation; ko.near_distance = opt.near_distance;
+		uint32_t compacted = compute_loss(R, k1.ray_counter, aabb, rng, B, ko, (uint32_t)meta.size(), meta.data(), mlp_out.data(), 4,
+			ray_indices.data(), rays.data(), numsteps.data(), coords.data(), coords_compacted.data(), dloss.data(), 4, loss.data(), mean_density);
+		n_rays_last = k1.ray_counter;
+		counter_before = k1.numsteps_counter; counter_compacted = compacted;
+		uint32_t n_valid = std::min(compacted, B);
+		fill_rollover_and_rescale_h(B, 4, n_valid, dloss.data());
+		fill_rollover_f(B, 7, n_valid, coords_compacted.data());
+		model->training_step(coords_compacted.data(), 7, B, dloss.data(), 4);
+		rng.advance();
+	}
+	uint32_t counter_before = 0, counter_compacted = 0;
+
+	// optimizer_step + NerfCounters::update_after_training, testbed_nerf.cu:2770-2778, 2678-2702
+	void finish() {
+		model->optimizer_step(opt.loss_scale);
+		++training_step;
+		total_rays += rays_per_batch;
+		measured_batch_size = 0; measured_batch_size_before_compaction = 0;
+		if (counter_before == 0 || counter_compacted == 0) { loss_scalar = 0.f; return; }
+		measured_batch_size_before_compaction = counter_before;
+		measured_batch_size = counter_compacted;
+		total_samples += measured_batch_size;
+		double s = 0; for (float l : loss) s += l;
+		loss_scalar = (float)s * (float)measured_batch_size / (float)opt.target_batch_size;
+		rays_per_batch = (uint32_t)((float)rays_per_batch * (float)opt.target_batch_size / (float)measured_batch_size);
+		rays_per_batch = std::min(next_multiple(rays_per_batch, 256u), 1u << 18);
+	}
+
+	// Testbed::train, testbed.cu:4561-4647 (one call = one optimizer step)
+	uint32_t training_prep_skip_counter = 0;
+	void train_step() {
+		uint32_t n_prep_to_skip = (uint32_t)clampi((int)training_step / 16, 1, 16);
+		if (training_prep_skip_counter % n_prep_to_skip == 0) training_prep();
+		++training_prep_skip_counter;
+		forward_backward();
+		finish();
+	}
+
+	// fused per-pixel renderer, fused_kernels/render_nerf.cuh:22-184 (Shade mode, no envmap / DoF /
+	// foveation; render_aabb_to_local = identity).
+	void render(const ngp_render_params& rp, float* frame, float* depth) const {
+		const int W = rp.resolution[0], H = rp.resolution[1];
+		Aabb render_aabb(rp.render_aabb);
+		const mat4x3 cam = M43(rp.camera);
+		#pragma omp parallel for schedule(dynamic, 64)
+		for (int64_t idx64 = 0; idx64 < (int64_t)W * H; ++idx64) {
+			uint32_t idx = (uint32_t)idx64, x = idx % W, y = idx / W;
+			vec2 off = ld_random_pixel_offset(rp.snap_to_pixel_centers ? 0 : rp.spp_index);
+			vec2 uv = {((float)x + off.x) / (float)W, ((float)y + off.y) / (float)H};
+			vec3 ro, rd;
+			uv_to_ray(uv, rp.resolution, rp.focal_length, cam, rp.screen_center, rp.lens_mode, rp.lens_params, rp.near_distance, ro, rd);
+			rd = normalize(rd);
+			float t = std::fmax(render_aabb.ray_intersect(ro, rd).x, 0.0f) + 1e-6f;
+			bool alive = render_aabb.contains(ro + rd * t);
+			vec3 idir = V3(1.0f) / rd;
+			float color[4] = {0, 0, 0, 0};
+			vec3 cam_fwd = cam[2], cam_pos = cam[3];
+			float best_depth = MAX_DEPTH, max_weight = 0.f;
+			float cone_angle = opt.cone_angle_constant;
+			t = advance_n_steps(t, cone_angle, ld_random_val(rp.spp_index, idx * 786433u));
+			while (alive) {
+				t = if_unoccupied_advance_to_next_occupied_voxel(t, cone_angle, ro, rd, idir, bitfield.data(), 0, opt.max_cascade, render_aabb);
+				if (t >= MAX_DEPTH) break;
+				vec3 pos = ro + rd * t;
+				float dt = calc_dt(t, cone_angle);
+				vec3 wp = warp_position(pos, aabb), wd = warp_direction(rd);
+				float c[7] = {wp.x, wp.y, wp.z, warp_dt(dt), wd.x, wd.y, wd.z};
+				uint16_t o4[4];
+				model->eval(c, rp.use_inference_params != 0, o4);
+				t += dt;
+				float alpha = 1.f - std::exp(-network_to_density(h2f(o4[3]), opt.density_activation) * dt);
+				float weight = alpha * (1.0f - color[3]);
+				vec3 rgb = {network_to_rgb(h2f(o4[0]), opt.rgb_activation), network_to_rgb(h2f(o4[1]), opt.rgb_activation), network_to_rgb(h2f(o4[2]), opt.rgb_activation)};
+				color[0] += rgb.x * weight; color[1] += rgb.y * weight; color[2] += rgb.z * weight; color[3] += weight;
+				if (weight > max_weight) { max_weight = weight; best_depth = dot(cam_fwd, pos - cam_pos); }
+				if (color[3] > (1.0f - rp.min_transmittance)) {
+					float a = color[3];
+					for (int k = 0; k < 4; ++k) color[k] /= a;
+					break;
+				}
+			}
+			if (!opt.linear_colors) { color[0] = srgb_to_linear(color[0]); color[1] = srgb_to_linear(color[1]); color[2] = srgb_to_linear(color[2]); }
+			depth[idx] = color[3] > 0.2f ? best_depth : MAX_DEPTH;
+			for (int k = 0; k < 4; ++k) frame[(size_t)idx * 4 + k] = color[k];
+		}
+	}
+};
+
+} // namespace ora
