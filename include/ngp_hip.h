@@ -193,9 +193,10 @@ int ngp_model_deserialize_host(ngp_model*, const void* buffer_host, uint64_t siz
  * ngp_nerf_* below). All buffers are caller-owned device memory. */
 
 /* generate_training_samples_nerf, testbed_nerf.cu:691-849 (launch :3195).
- * ray_begin/ray_end: this rank's slice of the global ray range [0, n_rays) (8e). */
+ * rank/world_size: this rank marches the slice [n_rays*rank/world, n_rays*(rank+1)/world) of the
+ * global ray range (8e); n_rays_ptr / max_samples_ptr (device, may be NULL) override the immediates. */
 int ngp_k_generate_training_samples(
-	void* stream, uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, const uint32_t* n_rays_ptr,
+	void* stream, uint32_t n_rays, uint32_t rank, uint32_t world_size, const uint32_t* n_rays_ptr,
 	ngp_aabb aabb, uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng,
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, ngp_ray* rays_out,
 	uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata,
@@ -289,6 +290,14 @@ typedef struct ngp_render_params {
 } ngp_render_params;
 int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_host,
                     float* frame_buffer, float* depth_buffer);
+
+/* ------------------------------------------------------------------ test hooks ----------- */
+/* Not part of the reference's API surface: expose intermediate state to the parity tests. */
+int ngp_model_encode(ngp_model*, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out32);
+int ngp_nerf_scratch_ptrs(ngp_nerf*, uint32_t** ray_indices, ngp_ray** rays, uint32_t** numsteps, float** coords,
+                          ngp_half** mlp_out, float** coords_compacted, ngp_half** dloss, void** counters);
+int ngp_nerf_set_rays_per_batch(ngp_nerf*, uint32_t rays_per_batch);
+int ngp_nerf_get_rng(ngp_nerf*, ngp_pcg32* rng, ngp_pcg32* density_grid_rng);
 
 #ifdef __cplusplus
 }

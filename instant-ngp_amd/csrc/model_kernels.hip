@@ -1,0 +1,843 @@
+// model_kernels.hip -- the fused multiresolution-hash-grid + tiny-MLP kernels for gfx950 (CDNA4).
+//
+// Replaces tiny-cuda-nn's GridEncoding + FullyFusedMLP as consumed by NerfNetwork
+// (reference nerf_network.h:105-139 inference, :145-268 forward/backward, :270-280 density;
+// call sites testbed_nerf.cu:3235, 3313-3323, 2570, 1772) and Trainer::optimizer_step (:2770).
+//
+// Design (MI355X-first, not a translation of tcnn's 32-lane WMMA tiling):
+//  * One 64-lane wavefront owns 64 samples = two 32-column MFMA tiles.  All layers are evaluated in
+//    TRANSPOSED form  H^T = W * X^T  with v_mfma_f32_32x32x16_f16: weights are the A operand (rows =
+//    neurons), samples are the B operand / the lane dimension.  The C/D layout of a 32x32 tile
+//    (lane -> column = sample, register r -> row (r&3)+8*(r>>2)+4*(lane>>5)) is *already* a valid B
+//    operand for the next layer if the contraction index is permuted by
+//        k(s, hi, j) = 16*s + 8*(j>>2) + 4*hi + (j&3)            (s = k-step, hi = lane>>5, j = 0..7)
+//    so activations never leave registers: no LDS round trip, no barrier between layers.  The weights
+//    are kept in HBM/LDS pre-permuted in that "fragment order" (one 16-byte chunk per lane per
+//    fragment, refreshed by the optimizer kernel), so an A operand is a conflict-free ds_read_b128.
+//  * The hash-grid lookup is fused in front: lane (n, hi) gathers the levels whose features land in
+//    its own B-operand slots (levels 4s+2g+hi for F=4), i.e. the encoding is produced directly in MFMA
+//    operand registers.  Features accumulate with packed half FMAs (v_pk_fma_f16), matching the
+//    reference's `fma((T)weight, grid_val, result)`.
+//  * Swapping the MFMA operands yields the transposed product (lane = neuron, registers = samples),
+//    which is exactly the operand layout of the weight-gradient GEMM dW = dY * X^T (contraction over
+//    samples).  The backward therefore needs no LDS transposes either: kernel T1 (forward + dgrad +
+//    hash-grid scatter, latency-bound, low VGPR) and kernel W (recompute + wgrad, MFMA-bound, 1
+//    wave/SIMD with 192 accumulator registers) are separate launches.
+//  * ReLU state is kept as 1 bit per neuron (one VGPR per layer per tile) instead of saved activations.
+//  * Hash-table gradients use packed-half atomics (global_atomic_pk_add_f16) like the reference's
+//    atomicAdd(__half2).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "ngp_kernels.hpp"
+#include <algorithm>
+
+namespace ngp {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define DEV static __device__ __forceinline__
+
+// fragment indices (see header of this file / DESIGN.md)
+constexpr int FW_D1 = 0, FW_D2 = 4, FW_R1 = 8, FW_R2 = 12, FW_R3 = 20;
+constexpr int BW_D1 = 0, BW_D2 = 4, BW_R1 = 6, BW_R2 = 10, BW_R3 = 18;
+
+DEV f16v zero16() { f16v z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
+DEV h8 zero8() { h8 z; for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f; return z; }
+DEV f16v mfma(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+DEV h8 lds_frag(const h8* frags, int idx, int lane) { return frags[idx * 64 + lane]; }
+
+// D tile (fp32, regs 8q..8q+7) -> half fragment, optional ReLU; returns the ReLU bit mask (bit j)
+template <bool RELU>
+DEV h8 to_frag(const f16v& d, int q, uint32_t& mask_bits) {
+	h8 r;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		float v = d[8 * q + j];
+		if (RELU) { bool p = v > 0.f; mask_bits |= (p ? 1u : 0u) << (8 * q + j); v = p ? v : 0.f; }
+		r[j] = (_Float16)v;
+	}
+	return r;
+}
+DEV h8 to_frag_masked(const f16v& d, int q, uint32_t mask16) {
+	h8 r;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) r[j] = ((mask16 >> (8 * q + j)) & 1u) ? (_Float16)d[8 * q + j] : (_Float16)0.f;
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hash grid: one level for one sample.  [tcnn grid.h kernel_grid / grid_index / pos_fract]
+// ---------------------------------------------------------------------------------------------
+struct LevelConst { float scale; uint32_t res, hs, offset; bool hashed; };
+DEV LevelConst level_const(const GridMeta* __restrict__ gmp, int lvl_even, int hi) {
+	const GridMeta& gm = *gmp;
+	// the level index is (compile-time even level) + hi: select between two uniform values
+	LevelConst c;
+	c.scale = hi ? gm.scale[lvl_even + 1] : gm.scale[lvl_even];
+	c.res = hi ? gm.resolution[lvl_even + 1] : gm.resolution[lvl_even];
+	c.hs = hi ? gm.hashmap_size[lvl_even + 1] : gm.hashmap_size[lvl_even];
+	c.offset = hi ? gm.offset[lvl_even + 1] : gm.offset[lvl_even];
+	c.hashed = (uint64_t)c.res * c.res * c.res > (uint64_t)c.hs;
+	return c;
+}
+struct Corners { uint32_t idx[8]; float w[8]; };
+DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners& out) {
+	float p0 = fmaf(lc.scale, x, 0.5f), p1 = fmaf(lc.scale, y, 0.5f), p2 = fmaf(lc.scale, z, 0.5f);
+	float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+	uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+	p0 -= f0; p1 -= f1; p2 -= f2;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		float w = 1.f;
+		uint32_t a0, a1, a2;
+		if ((c & 1) == 0) { w *= 1 - p0; a0 = g0; } else { w *= p0; a0 = g0 + 1; }
+		if ((c & 2) == 0) { w *= 1 - p1; a1 = g1; } else { w *= p1; a1 = g1 + 1; }
+		if ((c & 4) == 0) { w *= 1 - p2; a2 = g2; } else { w *= p2; a2 = g2 + 1; }
+		uint32_t idx;
+		if (lc.hashed) {
+			idx = (a0 * 1u) ^ (a1 * 2654435761u) ^ (a2 * 805459861u);
+			idx = idx & (lc.hs - 1u); // a hashed level always has hs = 2^log2_hashmap_size, so & == %
+		} else {
+			idx = a0 + a1 * lc.res + a2 * lc.res * lc.res; // < 2*hs: one conditional subtract == % hs
+			idx = idx >= lc.hs ? idx - lc.hs : idx;
+		}
+		out.idx[c] = idx; out.w[c] = w;
+	}
+}
+// F = 4: returns the 4 interpolated features of one level (half fma accumulation, corner order 0..7)
+DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, float x, float y, float z) {
+	Corners cr;
+	level_corners(lc, x, y, z, cr);
+	const uint2* t = (const uint2*)table + lc.offset;
+	uint2 v[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) v[c] = t[cr.idx[c]];  // 8 independent 8-byte gathers in flight
+	h2 r0 = {(_Float16)0.f, (_Float16)0.f}, r1 = r0;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		_Float16 wh = (_Float16)cr.w[c];
+		h2 w2 = {wh, wh};
+		h2 a = __builtin_bit_cast(h2, v[c].x), b = __builtin_bit_cast(h2, v[c].y);
+		r0 = __builtin_elementwise_fma(w2, a, r0);
+		r1 = __builtin_elementwise_fma(w2, b, r1);
+	}
+	h4 r = {r0[0], r0[1], r1[0], r1[1]};
+	// keep the scheduler from hoisting the next level's 8 gathers above this point: 8 loads per wave in
+	// flight x 16 waves/CU already exceeds what the memory pipeline tracks, and hoisting all 32-64 gathers
+	// costs >64 VGPRs (= occupancy, which is what actually hides the gather latency).
+	__builtin_amdgcn_sched_barrier(0);
+	return r;
+}
+
+// Encoding of one sample column into the lane's two B-operand fragments (k-steps 0,1), F = 4.
+DEV void encode_sample(const GridMeta* __restrict__ gm, const __half* __restrict__ table, float x, float y, float z, int hi, h8 out[2]) {
+#pragma unroll
+	for (int s = 0; s < 2; ++s) {
+		h4 a = level_features4(table, level_const(gm, 4 * s + 0, hi), x, y, z); // level 4s+hi   -> j = 0..3
+		h4 b = level_features4(table, level_const(gm, 4 * s + 2, hi), x, y, z); // level 4s+2+hi -> j = 4..7
+		h8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+		out[s] = r;
+	}
+}
+
+// [tcnn spherical_harmonics.h] degree 4, d in [0,1]^3; the lane keeps SH indices 8*(j>>2)+4*hi+(j&3)
+DEV h8 sh4_frag(float dx, float dy, float dz, int hi) {
+	const float x = dx * 2.f - 1.f, y = dy * 2.f - 1.f, z = dz * 2.f - 1.f;
+	const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	float o[16];
+	o[0] = 0.28209479177387814f;
+	o[1] = -0.48860251190291987f * y;
+	o[2] = 0.48860251190291987f * z;
+	o[3] = -0.48860251190291987f * x;
+	o[4] = 1.0925484305920792f * xy;
+	o[5] = -1.0925484305920792f * yz;
+	o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+	o[7] = -1.0925484305920792f * xz;
+	o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+	o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+	o[10] = 2.8906114426405538f * xy * z;
+	o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+	o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+	o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+	o[14] = 1.4453057213202769f * z * (x2 - y2);
+	o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+	h8 r;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int lo = 8 * (j >> 2) + (j & 3); // index for hi = 0; hi = 1 adds 4
+		r[j] = (_Float16)(hi ? o[lo + 4] : o[lo]);
+	}
+	return r;
+}
+
+// copy the fragment-ordered weights into LDS (all threads of the block)
+DEV void load_frags_to_lds(h8* dst, const ngp_half* __restrict__ src, int n_frags) {
+	const uint4* s = (const uint4*)src;
+	uint4* d = (uint4*)dst;
+	for (int i = threadIdx.x; i < n_frags * 64; i += blockDim.x) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward chain shared by inference / T1 / W.  CT = number of 32-sample column tiles per wave.
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+struct FwdState {
+	h8 enc[CT][2];      // encoding fragments (k-steps 0,1)
+	h8 rin[CT][2];      // rgb-net input: [0] = density-net output (16), [1] = SH (16)
+	h8 hb[CT][4];       // current 64-wide hidden activation fragments
+	uint32_t m1d[CT], m1r[CT], m2r[CT]; // ReLU bit masks: bit (16*mt + r)
+	float sigma[CT];    // density logit (valid on hi == 0 lanes)
+};
+
+template <int CT>
+DEV void fwd_density_l1(const h8* fw, int lane, FwdState<CT>& st) {
+	f16v acc[2][CT];
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+		for (int c = 0; c < CT; ++c) acc[mt][c] = zero16();
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			h8 a = lds_frag(fw, FW_D1 + mt * 2 + s, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, st.enc[c][s], acc[mt][c]);
+		}
+#pragma unroll
+	for (int c = 0; c < CT; ++c) {
+		st.m1d[c] = 0;
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			uint32_t mb = 0;
+			st.hb[c][2 * mt + 0] = to_frag<true>(acc[mt][c], 0, mb);
+			st.hb[c][2 * mt + 1] = to_frag<true>(acc[mt][c], 1, mb);
+			st.m1d[c] |= mb << (16 * mt);
+		}
+	}
+}
+template <int CT>
+DEV void fwd_density_l2(const h8* fw, int lane, FwdState<CT>& st) {
+	f16v acc[CT];
+#pragma unroll
+	for (int c = 0; c < CT; ++c) acc[c] = zero16();
+#pragma unroll
+	for (int s = 0; s < 4; ++s) {
+		h8 a = lds_frag(fw, FW_D2 + s, lane);
+#pragma unroll
+		for (int c = 0; c < CT; ++c) acc[c] = mfma(a, st.hb[c][s], acc[c]);
+	}
+#pragma unroll
+	for (int c = 0; c < CT; ++c) {
+		uint32_t dummy = 0;
+		st.rin[c][0] = to_frag<false>(acc[c], 0, dummy);
+		st.sigma[c] = (float)st.rin[c][0][0]; // neuron 0 lives in reg 0 of the hi == 0 lanes (half-rounded)
+	}
+}
+template <int CT>
+DEV void fwd_rgb_l1(const h8* fw, int lane, FwdState<CT>& st) {
+	f16v acc[2][CT];
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+		for (int c = 0; c < CT; ++c) acc[mt][c] = zero16();
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			h8 a = lds_frag(fw, FW_R1 + mt * 2 + s, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, st.rin[c][s], acc[mt][c]);
+		}
+#pragma unroll
+	for (int c = 0; c < CT; ++c) {
+		st.m1r[c] = 0;
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			uint32_t mb = 0;
+			st.hb[c][2 * mt + 0] = to_frag<true>(acc[mt][c], 0, mb);
+			st.hb[c][2 * mt + 1] = to_frag<true>(acc[mt][c], 1, mb);
+			st.m1r[c] |= mb << (16 * mt);
+		}
+	}
+}
+template <int CT>
+DEV void fwd_rgb_l2(const h8* fw, int lane, FwdState<CT>& st) {
+	f16v acc[2][CT];
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+		for (int c = 0; c < CT; ++c) acc[mt][c] = zero16();
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+		for (int s = 0; s < 4; ++s) {
+			h8 a = lds_frag(fw, FW_R2 + mt * 4 + s, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, st.hb[c][s], acc[mt][c]);
+		}
+#pragma unroll
+	for (int c = 0; c < CT; ++c) {
+		st.m2r[c] = 0;
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			uint32_t mb = 0;
+			st.hb[c][2 * mt + 0] = to_frag<true>(acc[mt][c], 0, mb);
+			st.hb[c][2 * mt + 1] = to_frag<true>(acc[mt][c], 1, mb);
+			st.m2r[c] |= mb << (16 * mt);
+		}
+	}
+}
+// rgb output layer: returns the D tile (rows 0..2 = rgb logits on hi == 0 lanes, regs 0..2)
+template <int CT>
+DEV void fwd_rgb_l3(const h8* fw, int lane, const FwdState<CT>& st, f16v out[CT]) {
+#pragma unroll
+	for (int c = 0; c < CT; ++c) out[c] = zero16();
+#pragma unroll
+	for (int s = 0; s < 4; ++s) {
+		h8 a = lds_frag(fw, FW_R3 + s, lane);
+#pragma unroll
+		for (int c = 0; c < CT; ++c) out[c] = mfma(a, st.hb[c][s], out[c]);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// inference kernel (K2, density-grid queries, renderer): persistent waves, 64 samples per iteration
+// ---------------------------------------------------------------------------------------------
+template <bool DENSITY_ONLY, int CT>
+__global__ void __launch_bounds__(256, 4) k_inference(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n_max,
+		const uint32_t* __restrict__ n_ptr, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	load_frags_to_lds(fw, mp.fw_frags, DENSITY_ONLY ? 8 : (int)N_FW_FRAGS);
+	__syncthreads();
+	const uint32_t n = n_ptr ? min(*n_ptr, n_max) : n_max;
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const __half* table = (const __half*)mp.grid;
+	constexpr uint32_t TS = 32 * CT; // samples per wave iteration
+	for (uint32_t tile = wave; (uint64_t)tile * TS < n; tile += n_waves) {
+		FwdState<CT> st;
+		uint32_t sidx[CT];
+#pragma unroll
+		for (int c = 0; c < CT; ++c) {
+			const uint32_t s_raw = tile * TS + c * 32 + col;
+			sidx[c] = s_raw;
+			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
+			encode_sample(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
+			if (!DENSITY_ONLY) st.rin[c][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
+		}
+		fwd_density_l1<CT>(fw, lane, st);
+		fwd_density_l2<CT>(fw, lane, st);
+		if (DENSITY_ONLY) {
+#pragma unroll
+			for (int c = 0; c < CT; ++c)
+				if (hi == 0 && sidx[c] < n) out[(size_t)sidx[c] * out_stride] = __float2half(st.sigma[c]);
+			continue;
+		}
+		fwd_rgb_l1<CT>(fw, lane, st);
+		fwd_rgb_l2<CT>(fw, lane, st);
+		f16v o[CT];
+		fwd_rgb_l3<CT>(fw, lane, st, o);
+#pragma unroll
+		for (int c = 0; c < CT; ++c) {
+			if (hi == 0 && sidx[c] < n) {
+				h4 r = {(_Float16)o[c][0], (_Float16)o[c][1], (_Float16)o[c][2], (_Float16)st.sigma[c]};
+				*(uint2*)(out + (size_t)sidx[c] * out_stride) = __builtin_bit_cast(uint2, r);
+			}
+		}
+	}
+}
+
+// encoding only (unit-test hook): out[i][32] halfs in NATURAL feature order (level-major)
+__global__ void __launch_bounds__(256) k_encode_only(const GridMeta* __restrict__ gm, const __half* __restrict__ table, const float* __restrict__ pos, uint32_t stride,
+		uint32_t n, __half* __restrict__ out) {
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t s_raw = wave * 32 + col;
+	if (wave * 32 >= n) return;
+	const float* p = pos + (size_t)min(s_raw, n - 1) * stride;
+	h8 e[2];
+	encode_sample(gm, table, p[0], p[1], p[2], hi, e);
+	if (s_raw >= n) return;
+#pragma unroll
+	for (int s = 0; s < 2; ++s)
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int f = 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3);
+			out[(size_t)s_raw * 32 + f] = __builtin_bit_cast(__half, e[s][j]);
+		}
+}
+
+// ---------------------------------------------------------------------------------------------
+// T1: forward + dgrad + hash-grid scatter; stashes the encoding fragments for kernel W.
+// ---------------------------------------------------------------------------------------------
+DEV void atomic_add_h2(__half* addr, h2 v) {
+	typedef __attribute__((address_space(1))) h2 gh2;
+	__builtin_amdgcn_global_atomic_fadd_v2f16((gh2*)addr, v);
+}
+
+template <int CT>
+__global__ void __launch_bounds__(256, 3) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
+		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	h8* bw = fw + N_FW_FRAGS * 64;
+	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
+	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const __half* table = (const __half*)mp.grid;
+	constexpr uint32_t TS = 32 * CT;
+	for (uint32_t tile = wave; (uint64_t)tile * TS < n; tile += n_waves) {
+		FwdState<CT> st;
+		uint32_t sidx[CT];
+		float px[CT], py[CT], pz[CT];
+#pragma unroll
+		for (int c = 0; c < CT; ++c) {
+			const uint32_t s_raw = tile * TS + c * 32 + col;
+			sidx[c] = s_raw;
+			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
+			px[c] = p[0]; py[c] = p[1]; pz[c] = p[2];
+			encode_sample(gm, table, px[c], py[c], pz[c], hi, st.enc[c]);
+			st.rin[c][1] = sh4_frag(p[4], p[5], p[6], hi);
+			// stash for kernel W: [32-sample tile][s][lane] 16-byte chunks (lane-linear, coalesced)
+			enc_stash[(((size_t)tile * CT + c) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, st.enc[c][0]);
+			enc_stash[(((size_t)tile * CT + c) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, st.enc[c][1]);
+		}
+		fwd_density_l1<CT>(fw, lane, st);
+		fwd_density_l2<CT>(fw, lane, st);
+		fwd_rgb_l1<CT>(fw, lane, st);
+		fwd_rgb_l2<CT>(fw, lane, st);
+
+		// ---- backward (dgrad chain) ----
+		h8 dy0[CT];          // dL/d(rgb output) fragment, k-step 0
+		_Float16 dsig[CT];   // dL/d(sigma logit)
+#pragma unroll
+		for (int c = 0; c < CT; ++c) {
+			dy0[c] = zero8(); dsig[c] = (_Float16)0.f;
+			if (hi == 0 && sidx[c] < n) {
+				const uint2 raw = *(const uint2*)(dL_dy + (size_t)sidx[c] * dy_stride);
+				const h4 g = __builtin_bit_cast(h4, raw);
+				dy0[c][0] = g[0]; dy0[c][1] = g[1]; dy0[c][2] = g[2];
+				dsig[c] = g[3];
+			}
+		}
+		h8 dh[CT][4];
+		// rgb L3^T : d_h2 = W3^T * d_out   (kin tiles mt = 0,1; one k-step)
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			h8 a = lds_frag(bw, BW_R3 + mt, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) {
+				f16v d = mfma(a, dy0[c], zero16());
+				dh[c][2 * mt + 0] = to_frag_masked(d, 0, st.m2r[c] >> (16 * mt));
+				dh[c][2 * mt + 1] = to_frag_masked(d, 1, st.m2r[c] >> (16 * mt));
+			}
+		}
+		// rgb L2^T : d_h1 = W2^T * d_h2
+		{
+			f16v acc[2][CT];
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+				for (int c = 0; c < CT; ++c) acc[mt][c] = zero16();
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+				for (int s = 0; s < 4; ++s) {
+					h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
+#pragma unroll
+					for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, dh[c][s], acc[mt][c]);
+				}
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+				for (int c = 0; c < CT; ++c) {
+					dh[c][2 * mt + 0] = to_frag_masked(acc[mt][c], 0, st.m1r[c] >> (16 * mt));
+					dh[c][2 * mt + 1] = to_frag_masked(acc[mt][c], 1, st.m1r[c] >> (16 * mt));
+				}
+		}
+		// rgb L1^T : d_rin = W1^T * d_h1 ; only rows 0..15 (density-net output) are consumed
+		h8 ddens[CT];
+		{
+			f16v acc[CT];
+#pragma unroll
+			for (int c = 0; c < CT; ++c) acc[c] = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				h8 a = lds_frag(bw, BW_R1 + s, lane);
+#pragma unroll
+				for (int c = 0; c < CT; ++c) acc[c] = mfma(a, dh[c][s], acc[c]);
+			}
+#pragma unroll
+			for (int c = 0; c < CT; ++c) {
+				uint32_t dummy = 0;
+				ddens[c] = to_frag<false>(acc[c], 0, dummy);
+				// add_density_gradient (nerf_network.h:235): half add into density-net output 0
+				if (hi == 0) ddens[c][0] = (_Float16)((float)ddens[c][0] + (float)dsig[c]);
+			}
+		}
+		// density L2^T : d_h1d = W2d^T * d_densout
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			h8 a = lds_frag(bw, BW_D2 + mt, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) {
+				f16v d = mfma(a, ddens[c], zero16());
+				dh[c][2 * mt + 0] = to_frag_masked(d, 0, st.m1d[c] >> (16 * mt));
+				dh[c][2 * mt + 1] = to_frag_masked(d, 1, st.m1d[c] >> (16 * mt));
+			}
+		}
+		// density L1^T : d_enc = W1d^T * d_h1d  (32 features = one row tile)
+		f16v denc[CT];
+#pragma unroll
+		for (int c = 0; c < CT; ++c) denc[c] = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) {
+			h8 a = lds_frag(bw, BW_D1 + s, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) denc[c] = mfma(a, dh[c][s], denc[c]);
+		}
+		// ---- hash-grid scatter: lane (n, hi) owns levels 2*rr + hi (rr = r>>2), features r&3 ----
+#pragma unroll
+		for (int c = 0; c < CT; ++c) {
+			if (sidx[c] >= n) continue;
+#pragma unroll
+			for (int rr = 0; rr < 4; ++rr) {
+				const LevelConst lc = level_const(gm, 2 * rr, hi);
+				Corners cr;
+				level_corners(lc, px[c], py[c], pz[c], cr);
+				// dL/d(enc) is rounded to half first (it is a half matrix in the reference)
+				const float g0 = (float)(_Float16)denc[c][4 * rr + 0], g1 = (float)(_Float16)denc[c][4 * rr + 1];
+				const float g2 = (float)(_Float16)denc[c][4 * rr + 2], g3 = (float)(_Float16)denc[c][4 * rr + 3];
+				__half* gt = grid_grad + (size_t)lc.offset * 4;
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const float w = cr.w[k];
+					h2 v0 = {(_Float16)(g0 * w), (_Float16)(g1 * w)}, v1 = {(_Float16)(g2 * w), (_Float16)(g3 * w)};
+					__half* dst = gt + (size_t)cr.idx[k] * 4;
+					atomic_add_h2(dst, v0);
+					atomic_add_h2(dst + 2, v1);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// W: recompute forward + dgrad in chain AND swapped form, accumulate all weight gradients in registers.
+// One 32-sample column tile per wave iteration; 12 accumulator tiles (192 registers) per wave.
+// ---------------------------------------------------------------------------------------------
+DEV h8 ident_frag(int s, int lane) { // fw_frag(I_32, mt = 0, s): transposes a fragment through the MFMA
+	const int col = lane & 31, hi = lane >> 5;
+	h8 r;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) r[j] = (col == 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3)) ? (_Float16)1.f : (_Float16)0.f;
+	return r;
+}
+// swapped-layout tile (lane = neuron, regs = samples) -> two half operand fragments (q = 0,1)
+DEV void sw_to_frags(const f16v& d, bool relu, h8 out[2]) {
+#pragma unroll
+	for (int q = 0; q < 2; ++q)
+#pragma unroll
+		for (int j = 0; j < 8; ++j) { float v = d[8 * q + j]; if (relu) v = v > 0.f ? v : 0.f; out[q][j] = (_Float16)v; }
+}
+// gradient tile in swapped layout, masked by the sign of the (post-ReLU) forward activation
+DEV void sw_grad_to_frags(const f16v& d, const h8 act[2], h8 out[2]) {
+#pragma unroll
+	for (int q = 0; q < 2; ++q)
+#pragma unroll
+		for (int j = 0; j < 8; ++j) out[q][j] = ((float)act[q][j] > 0.f) ? (_Float16)d[8 * q + j] : (_Float16)0.f;
+}
+
+constexpr int N_DW_TILES = 12; // d1:(0,1) d2:(2,3) r1:(4,5) r2:(6..9) r3:(10,11)
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_wgrad(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n, const __half* __restrict__ dL_dy, uint32_t dy_stride,
+		const uint4* __restrict__ enc_stash, float* __restrict__ partials) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	h8* bw = fw + N_FW_FRAGS * 64;
+	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
+	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6;
+	const uint32_t wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
+	f16v dW[N_DW_TILES];
+#pragma unroll
+	for (int t = 0; t < N_DW_TILES; ++t) dW[t] = zero16();
+	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
+
+	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) { // ct = 32-sample column tile
+		const uint32_t s_raw = ct * 32 + col;
+		const bool valid = s_raw < n;
+		const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
+		FwdState<1> st;
+		st.enc[0][0] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 0) * 64 + lane]);
+		st.enc[0][1] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 1) * 64 + lane]);
+		st.rin[0][1] = sh4_frag(p[4], p[5], p[6], hi);
+		h8 dy0 = zero8(); _Float16 dsig = (_Float16)0.f;
+		if (hi == 0 && valid) {
+			const h4 g = __builtin_bit_cast(h4, *(const uint2*)(dL_dy + (size_t)s_raw * dy_stride));
+			dy0[0] = g[0]; dy0[1] = g[1]; dy0[2] = g[2]; dsig = g[3];
+		}
+		// out-of-range columns must contribute nothing: zero their inputs AND their output gradient
+		// (dy0/dsig are zero already); activations of invalid columns only ever multiply zero gradients.
+
+		// ---- forward chain (ReLU masks) ; swapped activations (lane = neuron, regs = samples) are
+		//      recomputed lazily right before their use to keep the live register set small ----
+		fwd_density_l1<1>(fw, lane, st);
+		fwd_density_l2<1>(fw, lane, st);
+		fwd_rgb_l1<1>(fw, lane, st);
+		h8 h2r_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) t = mfma(st.hb[0][s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
+			sw_to_frags(t, true, h2r_sw[kt]);
+		}
+		fwd_rgb_l2<1>(fw, lane, st); // only the ReLU mask m2r is consumed below
+
+		// ---- backward ----
+		h8 g_sw[2]; // current layer's output gradient in swapped layout
+		// rgb L3: dW = d_out * h2r^T
+		{ f16v t = mfma(dy0, I0, zero16()); sw_to_frags(t, false, g_sw); }
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[10 + kt] = mfma(g_sw[q], h2r_sw[kt][q], dW[10 + kt]);
+		// d_h2 (chain, masked) and swapped
+		h8 dh[4];
+		h8 d2_sw[2][2];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			const h8 a = lds_frag(bw, BW_R3 + mt, lane);
+			f16v d = mfma(a, dy0, zero16());
+			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
+			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+			f16v dsw = mfma(dy0, a, zero16());
+			sw_grad_to_frags(dsw, h2r_sw[mt], d2_sw[mt]);
+		}
+		// h1r swapped (from the rgb-net input), rgb L2: dW[it][kt] = d_h2[it] * h1r[kt]^T
+		h8 h1r_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 2; ++s) t = mfma(st.rin[0][s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
+			sw_to_frags(t, true, h1r_sw[kt]);
+		}
+#pragma unroll
+		for (int it = 0; it < 2; ++it)
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+				for (int q = 0; q < 2; ++q) dW[6 + it * 2 + kt] = mfma(d2_sw[it][q], h1r_sw[kt][q], dW[6 + it * 2 + kt]);
+		// d_h1r
+		h8 dh1[4];
+		h8 d1_sw[2][2];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			f16v d = zero16(), dsw = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				const h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
+				d = mfma(a, dh[s], d);
+				dsw = mfma(dh[s], a, dsw);
+			}
+			dh1[2 * mt + 0] = to_frag_masked(d, 0, st.m1r[0] >> (16 * mt));
+			dh1[2 * mt + 1] = to_frag_masked(d, 1, st.m1r[0] >> (16 * mt));
+			sw_grad_to_frags(dsw, h1r_sw[mt], d1_sw[mt]);
+		}
+		// rgb L1: dW[it][0] = d_h1r[it] * rin^T
+		{
+			h8 rin_sw[2];
+			f16v t = mfma(st.rin[0][0], I0, zero16()); t = mfma(st.rin[0][1], I1, t); sw_to_frags(t, false, rin_sw);
+#pragma unroll
+			for (int it = 0; it < 2; ++it)
+#pragma unroll
+				for (int q = 0; q < 2; ++q) dW[4 + it] = mfma(d1_sw[it][q], rin_sw[q], dW[4 + it]);
+		}
+		// d_rin -> d_densout (+ dsigma on neuron 0)
+		h8 ddens;
+		{
+			f16v d = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) d = mfma(lds_frag(bw, BW_R1 + s, lane), dh1[s], d);
+			uint32_t dummy = 0;
+			ddens = to_frag<false>(d, 0, dummy);
+			if (hi == 0) ddens[0] = (_Float16)((float)ddens[0] + (float)dsig);
+		}
+		{ f16v t = mfma(ddens, I0, zero16()); sw_to_frags(t, false, g_sw); }
+		// h1d swapped (from the encoding); density L2: dW[0][kt] = d_densout * h1d[kt]^T
+		h8 h1d_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 2; ++s) t = mfma(st.enc[0][s], lds_frag(fw, FW_D1 + kt * 2 + s, lane), t);
+			sw_to_frags(t, true, h1d_sw[kt]);
+		}
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[2 + kt] = mfma(g_sw[q], h1d_sw[kt][q], dW[2 + kt]);
+		// d_h1d swapped; density L1: dW[it][0] = d_h1d[it] * enc^T
+		h8 enc_sw[2];
+		{ f16v t = mfma(st.enc[0][0], I0, zero16()); t = mfma(st.enc[0][1], I1, t); sw_to_frags(t, false, enc_sw); }
+#pragma unroll
+		for (int it = 0; it < 2; ++it) {
+			const h8 a = lds_frag(bw, BW_D2 + it, lane);
+			f16v dsw = mfma(ddens, a, zero16());
+			h8 dd_sw[2];
+			sw_grad_to_frags(dsw, h1d_sw[it], dd_sw);
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[0 + it] = mfma(dd_sw[q], enc_sw[q], dW[0 + it]);
+		}
+	}
+
+	// ---- reduce the 4 waves of the block through LDS (re-using the fragment region), 6 tiles at a time ----
+	float* red = (float*)smem; // 6 tiles * 16 regs * 64 lanes * 4 B = 24 KiB <= 44 KiB of fragments
+	float* dstp = partials + (size_t)blockIdx.x * (N_DW_TILES * 16 * 64);
+#pragma unroll
+	for (int half = 0; half < 2; ++half) {
+		__syncthreads();
+		for (int w = 0; w < 4; ++w) {
+			if (wid == w) {
+#pragma unroll
+				for (int t = 0; t < 6; ++t)
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						float* dst = red + ((size_t)t * 16 + r) * 64 + lane;
+						*dst = (w == 0 ? 0.f : *dst) + dW[half * 6 + t][r];
+					}
+			}
+			__syncthreads();
+		}
+		for (int i = threadIdx.x; i < 6 * 16 * 64; i += blockDim.x) dstp[half * 6 * 16 * 64 + i] = red[i];
+	}
+}
+
+// sum the per-block partials, un-permute the D tiles into row-major [out][in] and round to half
+__global__ void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // element of [tile][r][lane]
+	if (e >= N_DW_TILES * 16 * 64) return;
+	float s = 0.f;
+	for (uint32_t g = 0; g < n_partials; ++g) s += partials[(size_t)g * (N_DW_TILES * 16 * 64) + e];
+	const int t = e / (16 * 64), r = (e / 64) % 16, lane = e % 64;
+	int layer_off, R, C, it, kt;
+	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
+	else if (t < 4) { layer_off = 2048; R = 16; C = 64; it = 0; kt = t - 2; }
+	else if (t < 6) { layer_off = 3072; R = 64; C = 32; it = t - 4; kt = 0; }
+	else if (t < 10) { layer_off = 5120; R = 64; C = 64; it = (t - 6) >> 1; kt = (t - 6) & 1; }
+	else { layer_off = 9216; R = 16; C = 64; it = 0; kt = t - 10; }
+	const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+	const int k = kt * 32 + (lane & 31);
+	if (i < R && k < C) mlp_grad[layer_off + i * C + k] = __float2half(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fragment build (after set_params) and the fused Adam + ExponentialDecay + EMA sweep
+// ---------------------------------------------------------------------------------------------
+__global__ void k_build_frags(const __half* __restrict__ mlp_params, uint32_t n_mlp, const uint32_t* __restrict__ fw_perm, const uint32_t* __restrict__ bw_perm,
+		__half* __restrict__ fw, __half* __restrict__ bw) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_mlp) return;
+	const __half v = mlp_params[p];
+	if (fw) fw[fw_perm[p]] = v;
+	if (bw) bw[bw_perm[p]] = v;
+}
+
+// [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters.
+__global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.n_params) return;
+	const bool matrix = i < a.n_mlp;
+	float gradient = __half2float(((const __half*)a.grads)[i]) / a.loss_scale;
+	bool update = matrix ? (a.optimize_matrix != 0) : (a.optimize_non_matrix != 0 && gradient != 0.f);
+	__half w_half = ((__half*)a.params)[i];
+	if (update) {
+		const float weight_fp = a.master[i];
+		if (matrix) gradient += a.l2_reg * weight_fp;
+		const float gradient_sq = gradient * gradient;
+		const float first = a.m[i] = a.beta1 * a.m[i] + (1 - a.beta1) * gradient;
+		const float second = a.v[i] = a.beta2 * a.v[i] + (1 - a.beta2) * gradient_sq;
+		const uint32_t current_step = ++a.steps[i];
+		float lr = a.lr;
+		lr *= sqrtf(1 - powf(a.beta2, (float)current_step)) / (1 - powf(a.beta1, (float)current_step));
+		const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
+		const float new_weight = weight_fp - effective_lr * first;
+		a.master[i] = new_weight;
+		w_half = __float2half(new_weight);
+		((__half*)a.params)[i] = w_half;
+		if (matrix) {
+			((__half*)a.fw_frags)[a.fw_perm[i]] = w_half;
+			((__half*)a.bw_frags)[a.bw_perm[i]] = w_half;
+		}
+	}
+	const float filtered = (a.ema[i] * a.ema_decay * a.ema_debias_old + __half2float(w_half) * (1 - a.ema_decay)) * a.ema_debias_new;
+	a.ema[i] = filtered;
+	const __half fh = __float2half(filtered);
+	((__half*)a.params_inf)[i] = fh;
+	if (matrix) ((__half*)a.fw_frags_inf)[a.fw_perm[i]] = fh;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static int g_num_cus = 0;
+static int num_cus() {
+	if (!g_num_cus) {
+		hipDeviceProp_t prop;
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+		if (g_num_cus <= 0) g_num_cus = 256;
+	}
+	return g_num_cus;
+}
+
+void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
+		ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset) {
+	if (n_max == 0) return;
+	const uint32_t tiles = (n_max + 31) / 32;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 4);
+	if (density_only)
+		hipLaunchKernelGGL((k_inference<true, 1>), dim3(grid), dim3(256), 8 * 1024, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset);
+	else
+		hipLaunchKernelGGL((k_inference<false, 1>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset);
+}
+void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out) {
+	if (n == 0) return;
+	const uint32_t waves = (n + 31) / 32;
+	hipLaunchKernelGGL(k_encode_only, dim3((waves + 3) / 4), dim3(256), 0, s, gm, (const __half*)grid, pos, stride, n, (__half*)out);
+}
+void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw) {
+	hipLaunchKernelGGL(k_build_frags, dim3((n_mlp + 255) / 256), dim3(256), 0, s, (const __half*)mlp_params, n_mlp, fw_perm, bw_perm, (__half*)fw, (__half*)bw);
+}
+uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
+void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {
+	if (n == 0) return;
+	const uint32_t tiles = (n + 31) / 32;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
+	hipLaunchKernelGGL((k_train_fwd_bwd<1>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
+		(__half*)grid_grad, (uint4*)enc_stash);
+	const uint32_t lds = (N_FW_FRAGS + N_BW_FRAGS) * 1024;
+	hipLaunchKernelGGL(k_wgrad, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
+}
+void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad) {
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3((N_DW_TILES * 16 * 64 + 255) / 256), dim3(256), 0, s, partials, n_partials, (__half*)mlp_grad);
+}
+void launch_optimizer_step(hipStream_t s, const AdamArgs& a) {
+	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params + 255) / 256)), dim3(256), 0, s, a);
+}
+
+} // namespace ngp

@@ -1,0 +1,450 @@
+// nerf_kernels.hip -- gfx950 kernels for the ngp-side of the NeRF training step:
+//   K1 ray generation + occupancy-skipping march (reference testbed_nerf.cu:691-849)
+//   K3 compositing, loss, adjoint and sample compaction (testbed_nerf.cu:852-1180)
+//   K4 roll-over padding (launches testbed_nerf.cu:3298-3306)
+//   occupancy-grid maintenance (testbed_nerf.cu:87-396, 2476-2633)
+//   the on-device batch-size controller replacing NerfCounters::update_after_training's host
+//   round-trip (testbed_nerf.cu:2678-2702).
+//
+// MI355X notes: one thread per ray like the reference, but span reservation is done with ONE global
+// atomic per 64-lane wavefront (wave-level exclusive scan of the per-ray sample counts), which also
+// makes a wavefront's samples contiguous in HBM -> the fused encoding kernel that consumes them reads
+// ray-coherent (cache-line sharing) positions.  Compiled with -ffp-contract=off: sample positions and
+// occupancy indices must equal the un-contracted IEEE arithmetic of the oracle bit for bit.
+#include "ngp_device.hpp"
+#include "ngp_kernels.hpp"
+
+namespace ngp {
+
+static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total) {
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t x = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t y = __shfl_up(x, d, 64);
+		if (lane >= (uint32_t)d) x += y;
+	}
+	total = __shfl(x, 63, 64);
+	return x - v;
+}
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
+	// this rank's slice of the global ray range; world_size == 1 -> [0, n_rays)
+	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
+	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
+	const uint32_t i = ray_begin + threadIdx.x + blockIdx.x * blockDim.x;
+	if (blockIdx.x * blockDim.x >= ray_end - ray_begin) return; // whole block out of range (uniform)
+	const Box aabb(a.aabb);
+
+	bool valid = i < ray_end;
+	uint32_t numsteps = 0;
+	f3 ro = mk3(0.f), rd = mk3(0.f), rdn = mk3(0.f, 0.f, 1.f), idir = mk3(1.f);
+	float startt = 0.f, cone_angle = a.cone_angle_constant;
+	if (valid) {
+		uint32_t img = image_idx(i, n_rays, a.n_images);
+		const ngp_image_meta& m = a.metadata[img];
+		Rng rng(a.rng);
+		rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
+		f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) valid = false;
+		if (valid) {
+			(void)rng.next_float(); // motionblur_time
+			const M43 xform = ldm43(a.xforms[img].start);
+			uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+			rdn = normalize3(rd);
+			f2 tminmax = aabb.ray_intersect(ro, rdn);
+			tminmax.x = fmaxf(tminmax.x, 0.0f);
+			startt = advance_n_steps(tminmax.x, cone_angle, rng.next_float());
+			idir = mk3(1.0f) / rdn;
+			uint32_t j = 0;
+			float t = startt;
+			f3 pos;
+			while (aabb.contains(pos = ro + t * rdn) && j < N_STEPS) {
+				float dt = calc_dt(t, cone_angle);
+				uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
+				if (occupied_at(pos, a.bitfield, mip)) { ++j; t += dt; }
+				else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
+			}
+			numsteps = j;
+			if (j == 0) valid = false;
+		}
+	}
+	// one atomic per wavefront reserves the contiguous spans of its 64 rays
+	uint32_t wave_total;
+	uint32_t offset = wave_excl_scan(valid ? numsteps : 0u, wave_total);
+	uint32_t wave_base = 0;
+	if ((threadIdx.x & 63u) == 0 && wave_total) wave_base = atomicAdd(a.numsteps_counter, wave_total);
+	wave_base = __shfl(wave_base, 0, 64);
+	const uint32_t base = wave_base + offset;
+	if (valid && base + numsteps > max_samples) valid = false;
+	uint32_t n_valid_total;
+	uint32_t ray_off = wave_excl_scan(valid ? 1u : 0u, n_valid_total);
+	uint32_t ray_base = 0;
+	if ((threadIdx.x & 63u) == 0 && n_valid_total) ray_base = atomicAdd(a.ray_counter, n_valid_total);
+	ray_base = __shfl(ray_base, 0, 64);
+	if (!valid) return;
+
+	const uint32_t ray_idx = ray_base + ray_off;
+	a.ray_indices_out[ray_idx] = i;
+	ngp_ray r; r.o[0] = ro.x; r.o[1] = ro.y; r.o[2] = ro.z; r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;
+	a.rays_out[ray_idx] = r;
+	a.numsteps_out[ray_idx * 2 + 0] = numsteps;
+	a.numsteps_out[ray_idx * 2 + 1] = base;
+
+	float* co = a.coords_out + (size_t)base * 7;
+	const f3 wd = warp_direction(rdn);
+	float t = startt;
+	uint32_t j = 0;
+	f3 pos;
+	while (aabb.contains(pos = ro + t * rdn) && j < numsteps) {
+		float dt = calc_dt(t, cone_angle);
+		uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
+		if (occupied_at(pos, a.bitfield, mip)) {
+			f3 wp = warp_position(pos, aabb);
+			float* c = co + (size_t)j * 7;
+			c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+			++j; t += dt;
+		} else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t n_active = *a.rays_counter;
+	if (blockIdx.x * blockDim.x >= n_active) return;
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	const bool active = i < n_active;
+	const Box aabb(a.aabb);
+
+	uint32_t numsteps = 0, base = 0, compacted_numsteps = 0;
+	const float* cin = nullptr;
+	const __half* no = nullptr;
+	float T = 1.f;
+	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f);
+	f3 rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
+	if (active) {
+		numsteps = a.numsteps_inout[i * 2 + 0];
+		base = a.numsteps_inout[i * 2 + 1];
+		cin = a.coords_in + (size_t)base * 7;
+		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
+		ray_o = ld3(a.rays_in[i].o);
+		const float EPSILON = 1e-4f;
+		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
+			if (T < EPSILON) break;
+			const __half* lo = no + (size_t)compacted_numsteps * a.output_stride;
+			const f3 rgb = mk3(act_rgb(__half2float(lo[0]), a.rgb_activation), act_rgb(__half2float(lo[1]), a.rgb_activation), act_rgb(__half2float(lo[2]), a.rgb_activation));
+			const float dt = unwarp_dt(cin[(size_t)compacted_numsteps * 7 + 3]);
+			const float density = act_density(__half2float(lo[3]), a.density_activation);
+			const float alpha = 1.f - __expf(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray = rgb_ray + weight * rgb;
+			T *= (1.f - alpha);
+		}
+		const uint32_t ray_idx = a.ray_indices_in[i];
+		Rng rng(a.rng);
+		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
+		const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+		const ngp_image_meta& m = a.metadata[img];
+		const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+		rng.advance(1); // motionblur_time
+		if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
+		background_color = srgb_to_linear3(background_color);
+		const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+		const f3 trgb = mk3(tex.x, tex.y, tex.z);
+		if (a.linear_colors || !a.color_space_srgb) {
+			rgbtarget = trgb + (1.0f - tex.w) * background_color;
+			if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+		} else {
+			background_color = linear_to_srgb3(background_color);
+			if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
+			else rgbtarget = background_color;
+		}
+		if (compacted_numsteps == numsteps) rgb_ray = rgb_ray + T * background_color;
+	}
+
+	// span reservation in the compacted batch: one atomic per wavefront
+	uint32_t wave_total;
+	uint32_t offset = wave_excl_scan(active ? compacted_numsteps : 0u, wave_total);
+	uint32_t wave_base = 0;
+	if ((threadIdx.x & 63u) == 0 && wave_total) wave_base = atomicAdd(a.numsteps_counter_compacted, wave_total);
+	wave_base = __shfl(wave_base, 0, 64);
+	const uint32_t compacted_base = wave_base + offset;
+	float my_loss = 0.f;
+	if (active) {
+		compacted_numsteps = min(a.max_samples_compacted - min(a.max_samples_compacted, compacted_base), compacted_numsteps);
+		a.numsteps_inout[i * 2 + 0] = compacted_numsteps;
+		a.numsteps_inout[i * 2 + 1] = compacted_base;
+	}
+	if (active && compacted_numsteps > 0) {
+		float* cout = a.coords_out + (size_t)compacted_base * 7;
+		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
+		f3 lloss, lgrad;
+		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
+		const float mean_loss = (lloss.x + lloss.y + lloss.z) / 3.0f;
+		my_loss = mean_loss / (float)n_rays;
+		const float loss_scale = a.loss_scale / n_rays;
+		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = *a.mean_density_ptr < MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
+		f3 rgb_ray2 = mk3(0.f);
+		T = 1.f;
+		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
+			const float* ci = cin + (size_t)j * 7;
+			float* cj = cout + (size_t)j * 7;
+			const float c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3];
+			cj[0] = c0; cj[1] = c1; cj[2] = c2; cj[3] = c3; cj[4] = ci[4]; cj[5] = ci[5]; cj[6] = ci[6];
+			const f3 pos = unwarp_position(mk3(c0, c1, c2), aabb);
+			const float depth = dist3(pos, ray_o);
+			const float dt = unwarp_dt(c3);
+			const __half* lo = no + (size_t)j * a.output_stride;
+			const float l0 = __half2float(lo[0]), l1 = __half2float(lo[1]), l2 = __half2float(lo[2]), l3 = __half2float(lo[3]);
+			const f3 rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
+			const float density = act_density(l3, a.density_activation);
+			const float alpha = 1.f - __expf(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray2 = rgb_ray2 + weight * rgb;
+			T *= (1.f - alpha);
+			const f3 suffix = rgb_ray - rgb_ray2;
+			const f3 dloss_by_drgb = weight * lgrad;
+			const float d0 = loss_scale * (dloss_by_drgb.x * act_rgb_d(l0, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l0));
+			const float d1 = loss_scale * (dloss_by_drgb.y * act_rgb_d(l1, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l1));
+			const float d2 = loss_scale * (dloss_by_drgb.z * act_rgb_d(l2, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l2));
+			const float density_derivative = act_density_d(l3, a.density_activation);
+			const float dloss_by_dmlp = density_derivative * (dt * (dot3(lgrad, T * rgb - suffix) + 0.0f));
+			const float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f);
+			__half* d = dl + (size_t)j * a.dloss_stride;
+			d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3);
+		}
+	}
+	if (a.loss_output) {
+		float s = wave_sum(my_loss);
+		if ((threadIdx.x & 63u) == 0 && s != 0.f) atomicAdd(a.loss_output, s);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: fill_rollover<float> on coords + fill_rollover_and_rescale<half> on dL/doutput, one launch.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_rollover(uint32_t n_elements, const uint32_t* __restrict__ n_input_ptr, float* __restrict__ coords, uint32_t cstride,
+		__half* __restrict__ dloss, uint32_t dstride) {
+	const uint32_t n_in = *n_input_ptr;
+	if (n_in == 0 || n_in >= n_elements) return;
+	const uint32_t e = n_in + blockIdx.x * blockDim.x + threadIdx.x; // destination element
+	if (e >= n_elements) return;
+	const uint32_t src = e % n_in;
+	// coords: element-wise wrap is identical to the reference's flat index wrap because
+	// (e*stride + k) % (n_in*stride) == (e % n_in)*stride + k
+	for (uint32_t k = 0; k < cstride; ++k) coords[(size_t)e * cstride + k] = coords[(size_t)src * cstride + k];
+	const float n_input = (float)(n_in * dstride), n_total = (float)(n_elements * dstride);
+	for (uint32_t k = 0; k < dstride; ++k) {
+		float v = __half2float(dloss[(size_t)src * dstride + k]);
+		dloss[(size_t)e * dstride + k] = __float2half(v * n_input / n_total);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// occupancy grid
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mark_untrained(uint32_t n_elements, float* __restrict__ grid, uint32_t n_images, const ngp_image_meta* __restrict__ metadata,
+		const ngp_xform* __restrict__ xforms, int clear_visible) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const uint32_t level = i / GRID_N_CELLS, pos_idx = i % GRID_N_CELLS;
+	const uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+	const float voxel_size = scalbnf(1.0f / GRIDSIZE, (int)level);
+	const f3 pos = (mk3((float)x, (float)y, (float)z) / (float)GRIDSIZE - 0.5f) * scalbnf(1.0f, (int)level) + 0.5f;
+	uint32_t count = 0;
+	for (uint32_t j = 0; j < n_images && count < 1; ++j) {
+		const M43 xf = ldm43(xforms[j].start);
+		const ngp_image_meta& m = metadata[j];
+		for (uint32_t k = 0; k < 8; ++k) {
+			const f3 corner = pos + mk3((k & 1) ? voxel_size : 0.f, (k & 2) ? voxel_size : 0.f, (k & 4) ? voxel_size : 0.f);
+			const f3 dir = normalize3(corner - xf.c[3]);
+			if (dot3(dir, xf.c[2]) < 1e-4f) continue;
+			const f2 uv = pos_to_uv(corner, m.resolution, m.focal_length, xf, m.principal_point, m.lens_mode, m.lens_params);
+			f3 ro, rd;
+			uv_to_ray(uv, m.resolution, m.focal_length, xf, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+			if (dist3(normalize3(rd), dir) < 1e-3f && uv.x > 0.0f && uv.y > 0.0f && uv.x < 1.0f && uv.y < 1.0f) { ++count; break; }
+		}
+	}
+	if (clear_visible || (grid[i] < 0) != (count < 1)) grid[i] = (count >= 1) ? 0.f : -1.f;
+}
+
+__global__ void k_generate_grid_samples(uint32_t n_elements, ngp_pcg32 rng_in, const uint32_t* __restrict__ step_ptr, uint32_t step_imm, ngp_aabb box,
+		const float* __restrict__ grid_in, float* __restrict__ out_pos, uint32_t* __restrict__ indices, uint32_t n_cascades, float thresh) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const uint32_t step = step_ptr ? *step_ptr : step_imm;
+	Rng rng(rng_in);
+	rng.advance((uint64_t)(i * 4u));
+	const uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
+	uint32_t idx = 0;
+	for (uint32_t j = 0; j < 10; ++j) {
+		idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % GRID_N_CELLS;
+		idx += level * GRID_N_CELLS;
+		if (grid_in[idx] > thresh) break;
+	}
+	const uint32_t pos_idx = idx % GRID_N_CELLS;
+	const uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+	f3 r; r.x = rng.next_float(); r.y = rng.next_float(); r.z = rng.next_float();
+	const f3 pos = ((mk3((float)x, (float)y, (float)z) + r) / (float)GRIDSIZE - 0.5f) * scalbnf(1.0f, (int)level) + 0.5f;
+	const f3 wp = warp_position(pos, Box(box));
+	out_pos[(size_t)i * 3 + 0] = wp.x; out_pos[(size_t)i * 3 + 1] = wp.y; out_pos[(size_t)i * 3 + 2] = wp.z;
+	indices[i] = idx;
+}
+
+__global__ void k_splat_grid_samples(uint32_t n, const uint32_t* __restrict__ indices, const __half* __restrict__ net_out, uint32_t stride,
+		float* __restrict__ grid_out, int density_activation) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const float mlp = act_density(__half2float(net_out[(size_t)i * stride]), density_activation);
+	const float optical_thickness = mlp * scalbnf(MIN_CONE_STEP, 0);
+	// positive floats order like their uint bit patterns
+	atomicMax((uint32_t*)&grid_out[indices[i]], __float_as_uint(optical_thickness));
+}
+
+__global__ void k_ema_grid_samples(uint32_t n, float decay, float* __restrict__ grid_out, const float* __restrict__ grid_in) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const float prev = grid_out[i];
+	grid_out[i] = (prev < 0.f) ? prev : fmaxf(prev * decay, grid_in[i]);
+}
+
+// deterministic two-stage mean of max(v,0)/N over cascade 0 (reduce_sum, testbed_nerf.cu:2602-2608)
+constexpr uint32_t MEAN_BLOCKS = 256;
+__global__ void __launch_bounds__(256) k_grid_mean_partial(const float* __restrict__ grid, float* __restrict__ partial) {
+	__shared__ float sm[4];
+	float s = 0.f;
+	const uint32_t per_block = GRID_N_CELLS / MEAN_BLOCKS;
+	const float* g = grid + (size_t)blockIdx.x * per_block;
+	for (uint32_t k = threadIdx.x; k < per_block; k += 256) s += fmaxf(g[k], 0.f) / (float)GRID_N_CELLS;
+	s = wave_sum(s);
+	if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ void __launch_bounds__(64) k_grid_mean_final(const float* __restrict__ partial, float* __restrict__ mean_out) {
+	float s = 0.f;
+	for (uint32_t k = threadIdx.x; k < MEAN_BLOCKS; k += 64) s += partial[k];
+	s = wave_sum(s);
+	if (threadIdx.x == 0) *mean_out = s;
+}
+
+__global__ void k_grid_to_bitfield(uint32_t n_elements, uint32_t n_nonzero, const float* __restrict__ grid, uint8_t* __restrict__ bitfield,
+		const float* __restrict__ mean_ptr) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	if (i >= n_nonzero) { bitfield[i] = 0; return; }
+	const float thresh = fminf(MIN_OPTICAL_THICKNESS, *mean_ptr);
+	const float4 lo = ((const float4*)grid)[(size_t)i * 2], hi = ((const float4*)grid)[(size_t)i * 2 + 1];
+	uint8_t bits = 0;
+	bits |= lo.x > thresh ? 1 : 0; bits |= lo.y > thresh ? 2 : 0; bits |= lo.z > thresh ? 4 : 0; bits |= lo.w > thresh ? 8 : 0;
+	bits |= hi.x > thresh ? 16 : 0; bits |= hi.y > thresh ? 32 : 0; bits |= hi.z > thresh ? 64 : 0; bits |= hi.w > thresh ? 128 : 0;
+	bitfield[i] = bits;
+}
+__global__ void k_bitfield_max_pool(uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const uint64_t p = ((const uint64_t*)prev_level)[i];
+	uint8_t bits = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < 8; ++j) bits |= ((p >> (8 * j)) & 0xffull) ? (uint8_t)(1u << j) : 0;
+	const uint32_t x = morton3D_invert(i >> 0) + GRIDSIZE / 8, y = morton3D_invert(i >> 1) + GRIDSIZE / 8, z = morton3D_invert(i >> 2) + GRIDSIZE / 8;
+	next_level[morton3D(x, y, z)] |= bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// on-device NerfCounters::update_after_training (testbed_nerf.cu:2678-2702) + counter reset
+// (prepare_for_training_steps :2669-2676) for the NEXT step.  c = TrainCounters in device memory.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	const uint32_t before = c->numsteps_counter, compacted = c->numsteps_counter_compacted;
+	c->n_rays_last = c->ray_counter;
+	c->total_rays += c->rays_per_batch;
+	c->training_step += 1;
+	if (before == 0 || compacted == 0) {
+		c->measured_batch_size = 0; c->measured_batch_size_before_compaction = 0; c->loss_scalar = 0.f;
+	} else {
+		c->measured_batch_size_before_compaction = before;
+		c->measured_batch_size = compacted;
+		c->total_samples += compacted;
+		c->loss_scalar = c->loss_sum * (float)compacted / (float)target_batch_size;
+		uint32_t r = (uint32_t)((float)c->rays_per_batch * (float)target_batch_size / (float)compacted);
+		r = ((r + 255u) / 256u) * 256u;
+		c->rays_per_batch = min(r, 1u << 18);
+	}
+	// max_inference for the next step (testbed_nerf.cu:3055-3060)
+	const uint32_t max_samples = target_batch_size * 16u;
+	const uint32_t mb = c->measured_batch_size_before_compaction;
+	c->max_inference = mb == 0 ? max_samples : ((min(mb, max_samples) + 255u) / 256u) * 256u;
+	if (mb == 0) c->measured_batch_size_before_compaction = max_samples;
+	c->numsteps_counter = 0; c->numsteps_counter_compacted = 0; c->ray_counter = 0; c->loss_sum = 0.f;
+	c->n_valid_compacted = 0;
+}
+// clamp the compacted counter to B for K4 / statistics (the reference relies on fill_rollover's guard)
+__global__ void k_clamp_compacted(TrainCounters* c, uint32_t target_batch_size) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	c->n_valid_compacted = min(c->numsteps_counter_compacted, target_batch_size);
+	c->n_inference = min(c->numsteps_counter, c->max_inference);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t blocks(uint32_t n, uint32_t t) { return (n + t - 1) / t; }
+
+void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank) {
+	if (max_rays_this_rank == 0) return;
+	hipLaunchKernelGGL(k_generate_training_samples, dim3(blocks(max_rays_this_rank, 128)), dim3(128), 0, s, a);
+}
+void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
+	if (max_rays == 0) return;
+	hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
+}
+void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
+	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride);
+}
+void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear) {
+	hipLaunchKernelGGL(k_mark_untrained, dim3(blocks(n, 128)), dim3(128), 0, s, n, grid, n_images, m, x, clear);
+}
+void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, const uint32_t* step_ptr, uint32_t step, ngp_aabb box, const float* grid_in,
+		float* pos, uint32_t* idx, uint32_t n_cascades, float thresh) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_generate_grid_samples, dim3(blocks(n, 256)), dim3(256), 0, s, n, rng, step_ptr, step, box, grid_in, pos, idx, n_cascades, thresh);
+}
+void launch_splat_grid_samples(hipStream_t s, uint32_t n, const uint32_t* idx, const ngp_half* out, uint32_t stride, float* grid, int act) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_splat_grid_samples, dim3(blocks(n, 256)), dim3(256), 0, s, n, idx, (const __half*)out, stride, grid, act);
+}
+void launch_ema_grid_samples(hipStream_t s, uint32_t n, float decay, float* grid_out, const float* grid_in) {
+	hipLaunchKernelGGL(k_ema_grid_samples, dim3(blocks(n, 256)), dim3(256), 0, s, n, decay, grid_out, grid_in);
+}
+void launch_grid_mean(hipStream_t s, const float* grid, float* partial256, float* mean_out) {
+	hipLaunchKernelGGL(k_grid_mean_partial, dim3(MEAN_BLOCKS), dim3(256), 0, s, grid, partial256);
+	hipLaunchKernelGGL(k_grid_mean_final, dim3(1), dim3(64), 0, s, partial256, mean_out);
+}
+void launch_grid_to_bitfield(hipStream_t s, const float* grid, uint32_t max_cascade, uint8_t* bitfield, const float* mean_ptr) {
+	const uint32_t n = GRID_N_CELLS / 8 * N_CASCADES, nz = GRID_N_CELLS / 8 * (max_cascade + 1);
+	hipLaunchKernelGGL(k_grid_to_bitfield, dim3(blocks(n, 256)), dim3(256), 0, s, n, nz, grid, bitfield, mean_ptr);
+	for (uint32_t level = 1; level < N_CASCADES; ++level) {
+		hipLaunchKernelGGL(k_bitfield_max_pool, dim3(blocks(GRID_N_CELLS / 64, 256)), dim3(256), 0, s, GRID_N_CELLS / 64,
+			bitfield + grid_mip_offset(level - 1) / 8, bitfield + grid_mip_offset(level) / 8);
+	}
+}
+void launch_update_counters(hipStream_t s, TrainCounters* c, uint32_t B) { hipLaunchKernelGGL(k_update_counters, dim3(1), dim3(64), 0, s, c, B); }
+void launch_clamp_compacted(hipStream_t s, TrainCounters* c, uint32_t B) { hipLaunchKernelGGL(k_clamp_compacted, dim3(1), dim3(64), 0, s, c, B); }
+
+} // namespace ngp

@@ -1,0 +1,674 @@
+// ngp_api.hip -- implementation of the C-ABI declared in include/ngp_hip.h (host side of libngp_hip.so).
+// Owns device memory, derives layouts (hash-grid offset table, MFMA fragment permutations), and
+// sequences the kernels of one training step on one HIP stream without host synchronisation.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ngp_device.hpp"
+#include "ngp_kernels.hpp"
+#include "mini_json.hpp"
+
+using namespace ngp;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define REQUIRE(c, msg) do { if (!(c)) return fail(msg); } while (0)
+
+extern "C" const char* ngp_last_error(void) { return g_err.c_str(); }
+extern "C" int ngp_device_available(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n > 0;
+}
+
+template <typename T> static int dev_alloc(T** p, size_t n) { HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T))); return 0; }
+
+// ------------------------------------------------------------------------------------------------
+// config
+// ------------------------------------------------------------------------------------------------
+extern "C" int ngp_model_config_from_json(const char* json_host, uint32_t aabb_scale, uint32_t n_extra_dims, ngp_model_config* c) {
+	mini_json::Value root;
+	std::string err;
+	if (!mini_json::parse(json_host, root, err)) return fail("config json: " + err);
+	const auto& enc = root["encoding"];
+	const auto& net = root["network"];
+	const auto& rgb = root["rgb_network"];
+	const auto& dir = root["dir_encoding"];
+	std::string otype = enc.str("otype", "HashGrid");
+	for (auto& ch : otype) ch = (char)tolower(ch);
+	REQUIRE(otype == "hashgrid", "only the HashGrid encoding is implemented on this path (got '" + otype + "')");
+	// reset_network, testbed.cu:4218-4255
+	c->n_features_per_level = (uint32_t)enc.num("n_features_per_level", 2);
+	if (enc.has("n_features") && enc.num("n_features", 0) > 0) c->n_levels = (uint32_t)enc.num("n_features", 0) / c->n_features_per_level;
+	else c->n_levels = (uint32_t)enc.num("n_levels", 16);
+	c->log2_hashmap_size = (uint32_t)enc.num("log2_hashmap_size", 15);
+	c->base_resolution = (uint32_t)enc.num("base_resolution", 0);
+	if (!c->base_resolution) c->base_resolution = 1u << (c->log2_hashmap_size / 3);
+	c->per_level_scale = (float)enc.num("per_level_scale", 0.0);
+	if (c->per_level_scale <= 0.0f && c->n_levels > 1) {
+		const float desired_resolution = 2048.0f;
+		c->per_level_scale = std::exp(std::log(desired_resolution * (float)aabb_scale / (float)c->base_resolution) / (c->n_levels - 1));
+	}
+	c->n_neurons = (uint32_t)net.num("n_neurons", 64);
+	c->n_hidden_layers = (uint32_t)net.num("n_hidden_layers", 1);
+	c->n_hidden_layers_rgb = (uint32_t)rgb.num("n_hidden_layers", 2);
+	c->sh_degree = 4;
+	if (dir.has("nested") && dir["nested"].size() > 0) c->sh_degree = (uint32_t)dir["nested"].at(0).num("degree", 4);
+	else if (dir.has("degree")) c->sh_degree = (uint32_t)dir.num("degree", 4);
+	c->n_extra_dims = n_extra_dims;
+	// optimizer: Ema( ExponentialDecay( Adam ) ), configs/nerf/base.json:5-22; walk the nesting
+	c->learning_rate = 1e-2f; c->beta1 = 0.9f; c->beta2 = 0.99f; c->epsilon = 1e-15f; c->l2_reg = 1e-6f;
+	c->ema_decay = 0.0f; c->decay_start = 0; c->decay_interval = 0; c->decay_base = 1.0f;
+	const mini_json::Value* o = &root["optimizer"];
+	for (int depth = 0; depth < 4 && o->is_object(); ++depth) {
+		std::string t = o->str("otype", "");
+		for (auto& ch : t) ch = (char)tolower(ch);
+		if (t == "ema") c->ema_decay = (float)o->num("decay", 0.99);
+		else if (t == "exponentialdecay") {
+			c->decay_start = (uint32_t)o->num("decay_start", 10000); c->decay_interval = (uint32_t)o->num("decay_interval", 10000);
+			c->decay_base = (float)o->num("decay_base", 0.33);
+		} else if (t == "adam") {
+			c->learning_rate = (float)o->num("learning_rate", 1e-3); c->beta1 = (float)o->num("beta1", 0.9); c->beta2 = (float)o->num("beta2", 0.999);
+			c->epsilon = (float)o->num("epsilon", 1e-8); c->l2_reg = (float)o->num("l2_reg", 1e-8);
+		}
+		if (!o->has("nested")) break;
+		o = &(*o)["nested"];
+	}
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct ngp_model {
+	ngp_model_config cfg;
+	GridMeta gm;
+	GridMeta* gm_dev = nullptr;
+	uint64_t n_params = 0, n_mlp = 0;
+	float* master = nullptr; ngp_half* params = nullptr; ngp_half* params_inf = nullptr; ngp_half* grads = nullptr;
+	float* adam_m = nullptr; float* adam_v = nullptr; float* ema = nullptr; uint32_t* adam_steps = nullptr;
+	uint32_t* fw_perm = nullptr; uint32_t* bw_perm = nullptr;
+	ngp_half* fw_frags = nullptr; ngp_half* bw_frags = nullptr; ngp_half* fw_frags_inf = nullptr;
+	ngp_half* enc_stash = nullptr; size_t stash_halfs = 0;
+	float* wgrad_partials = nullptr; uint32_t n_partials = 0;
+	uint32_t step = 0; float lr = 1e-2f;
+	bool train_network = true, train_encoding = true;
+};
+
+// pcg32(initstate, initseq = 1) [tcnn pcg32.h]
+static Rng make_rng(uint64_t seed) { ngp_pcg32 z; z.state = 0; z.inc = 3; Rng r(z); r.next_uint(); r.state += seed; r.next_uint(); return r; }
+static ngp_pcg32 pod(const Rng& r) { ngp_pcg32 p; p.state = r.state; p.inc = r.inc; return p; }
+
+static uint32_t next_multiple_u(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
+
+// [tcnn GridEncodingTemplated ctor] offset table for a Hash grid
+static void build_grid_meta(const ngp_model_config& c, GridMeta& g) {
+	memset(&g, 0, sizeof(g));
+	g.n_levels = c.n_levels; g.F = c.n_features_per_level;
+	const float l2 = std::log2(c.per_level_scale);
+	uint32_t offset = 0;
+	for (uint32_t i = 0; i < c.n_levels; ++i) {
+		const float scale = std::exp2(i * l2) * c.base_resolution - 1.0f;
+		const uint32_t res = (uint32_t)std::ceil(scale) + 1;
+		const uint32_t max_params = 0xFFFFFFFFu / 2;
+		uint32_t params_in_level = std::pow((float)res, 3.0f) > (float)max_params ? max_params : res * res * res;
+		params_in_level = next_multiple_u(params_in_level, 8u);
+		params_in_level = std::min(params_in_level, 1u << c.log2_hashmap_size);
+		g.scale[i] = scale; g.resolution[i] = res; g.hashmap_size[i] = params_in_level; g.offset[i] = offset;
+		offset += params_in_level;
+	}
+	g.offset[c.n_levels] = offset;
+}
+
+// MLP layers in parameter order (nerf_network.h:357-372): density L1, L2, rgb L1, L2, L3; row-major [out][in]
+struct LayerDesc { uint32_t R, C, off, fw_base, bw_base; };
+static const LayerDesc kLayers[5] = {
+	{64, 32, 0, 0, 0}, {16, 64, 2048, 4, 4}, {64, 32, 3072, 8, 6}, {64, 64, 5120, 12, 10}, {16, 64, 9216, 20, 18}};
+
+// position of W[i][k] inside the forward / dgrad fragment buffers (see model_kernels.hip header):
+//   k-index map of a fragment element: k(s, hi, j) = 16 s + 8 (j>>2) + 4 hi + (j&3)
+static void build_perms(std::vector<uint32_t>& fw, std::vector<uint32_t>& bw) {
+	fw.assign(10240, 0xFFFFFFFFu); bw.assign(10240, 0xFFFFFFFFu);
+	for (const LayerDesc& L : kLayers) {
+		for (uint32_t i = 0; i < L.R; ++i) for (uint32_t k = 0; k < L.C; ++k) {
+			const uint32_t p = L.off + i * L.C + k;
+			{ // forward: A[row = i][k]; fragment index = base + (i/32) * (C/16) + s
+				const uint32_t mt = i / 32, s = k / 16, kk = k % 16;
+				const uint32_t j = (kk / 8) * 4 + (kk % 4), hi = (kk % 8) / 4;
+				const uint32_t frag = L.fw_base + mt * (L.C / 16) + s, lane = hi * 32 + (i % 32);
+				fw[p] = (frag * 64 + lane) * 8 + j;
+			}
+			{ // dgrad: A[row = k][i]; fragment index = base + (k/32) * ceil(R/16) + s
+				const uint32_t mt = k / 32, s = i / 16, ii = i % 16;
+				const uint32_t j = (ii / 8) * 4 + (ii % 4), hi = (ii % 8) / 4;
+				const uint32_t frag = L.bw_base + mt * ((L.R + 15) / 16) + s, lane = hi * 32 + (k % 32);
+				bw[p] = (frag * 64 + lane) * 8 + j;
+			}
+		}
+	}
+}
+
+static int model_refresh_half(ngp_model* m, hipStream_t s); // master -> params/params_inf + fragments
+
+extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_model** out) {
+	REQUIRE(cfg && out, "ngp_model_create: null argument");
+	REQUIRE(cfg->n_neurons == 64 && cfg->n_hidden_layers == 1 && cfg->n_hidden_layers_rgb == 2,
+		"this build specialises the fused kernels for configs/nerf/base.json topology (64 neurons, 1+2 hidden layers)");
+	REQUIRE(cfg->n_features_per_level == 4 && cfg->n_levels == 8, "fused kernels are specialised for L=8, F=4 (configs/nerf/base.json)");
+	REQUIRE(cfg->sh_degree == 4 && cfg->n_extra_dims == 0, "only SphericalHarmonics degree 4 without extra dims is implemented");
+	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
+	ngp_model* m = new ngp_model();
+	m->cfg = *cfg;
+	build_grid_meta(*cfg, m->gm);
+	m->n_mlp = 10240;
+	m->n_params = m->n_mlp + (uint64_t)m->gm.offset[cfg->n_levels] * cfg->n_features_per_level;
+	m->lr = cfg->learning_rate;
+	const uint64_t P = m->n_params;
+	if (dev_alloc(&m->gm_dev, 1) || dev_alloc(&m->master, P) || dev_alloc(&m->params, P) || dev_alloc(&m->params_inf, P) || dev_alloc(&m->grads, P) ||
+		dev_alloc(&m->adam_m, P) || dev_alloc(&m->adam_v, P) || dev_alloc(&m->ema, P) || dev_alloc(&m->adam_steps, P) ||
+		dev_alloc(&m->fw_perm, 10240) || dev_alloc(&m->bw_perm, 10240) || dev_alloc(&m->fw_frags, N_FW_FRAGS * FRAG_HALFS) ||
+		dev_alloc(&m->bw_frags, N_BW_FRAGS * FRAG_HALFS) || dev_alloc(&m->fw_frags_inf, N_FW_FRAGS * FRAG_HALFS)) { delete m; return 1; }
+	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(m->grads, 0, P * 2)); HIPCHK(hipMemset(m->adam_m, 0, P * 4)); HIPCHK(hipMemset(m->adam_v, 0, P * 4));
+	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 4));
+	HIPCHK(hipMemset(m->fw_frags, 0, N_FW_FRAGS * FRAG_HALFS * 2)); HIPCHK(hipMemset(m->bw_frags, 0, N_BW_FRAGS * FRAG_HALFS * 2));
+	HIPCHK(hipMemset(m->fw_frags_inf, 0, N_FW_FRAGS * FRAG_HALFS * 2));
+	std::vector<uint32_t> fwp, bwp;
+	build_perms(fwp, bwp);
+	HIPCHK(hipMemcpy(m->fw_perm, fwp.data(), fwp.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(m->bw_perm, bwp.data(), bwp.size() * 4, hipMemcpyHostToDevice));
+	m->n_partials = wgrad_n_partials();
+	if (dev_alloc(&m->wgrad_partials, (size_t)m->n_partials * 12 * 16 * 64)) { delete m; return 1; }
+	// Trainer::initialize_params: pcg32{seed}; Xavier-uniform matrices, U(-1e-4, 1e-4) grid (element j <- draw j)
+	std::vector<float> init(P);
+	Rng rnd = make_rng(seed);
+	size_t p = 0;
+	for (const LayerDesc& L : kLayers) {
+		const float scale = std::sqrt(6.0f / (float)(L.R + L.C));
+		for (uint32_t i = 0; i < L.R * L.C; ++i) init[p++] = rnd.next_float() * 2.0f * scale - scale;
+	}
+	for (; p < P; ++p) init[p] = rnd.next_float() * (1e-4f - (-1e-4f)) + (-1e-4f);
+	HIPCHK(hipMemcpy(m->master, init.data(), P * 4, hipMemcpyHostToDevice));
+	if (model_refresh_half(m, nullptr)) { delete m; return 1; }
+	HIPCHK(hipDeviceSynchronize());
+	*out = m;
+	return 0;
+}
+
+extern "C" void ngp_model_destroy(ngp_model* m) {
+	if (!m) return;
+	void* ptrs[] = {m->gm_dev, m->master, m->params, m->params_inf, m->grads, m->adam_m, m->adam_v, m->ema, m->adam_steps, m->fw_perm, m->bw_perm,
+		m->fw_frags, m->bw_frags, m->fw_frags_inf, m->enc_stash, m->wgrad_partials};
+	for (void* p : ptrs) if (p) (void)hipFree(p);
+	delete m;
+}
+
+__global__ void k_master_to_half(const float* __restrict__ master, __half* __restrict__ params, __half* __restrict__ params_inf, uint64_t n) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const __half h = __float2half(master[i]);
+	params[i] = h; params_inf[i] = h;
+}
+static int model_refresh_half(ngp_model* m, hipStream_t s) {
+	hipLaunchKernelGGL(k_master_to_half, dim3((uint32_t)((m->n_params + 255) / 256)), dim3(256), 0, s, m->master, (__half*)m->params, (__half*)m->params_inf, m->n_params);
+	launch_build_frags(s, m->params, (uint32_t)m->n_mlp, m->fw_perm, m->bw_perm, m->fw_frags, m->bw_frags);
+	launch_build_frags(s, m->params_inf, (uint32_t)m->n_mlp, m->fw_perm, m->bw_perm, m->fw_frags_inf, nullptr);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int ngp_model_n_params(const ngp_model* m, uint64_t* n, uint64_t* n_mlp) { if (n) *n = m->n_params; if (n_mlp) *n_mlp = m->n_mlp; return 0; }
+extern "C" int ngp_model_param_ptrs(ngp_model* m, float** master, ngp_half** params, ngp_half** inf, ngp_half** grads) {
+	if (master) *master = m->master; if (params) *params = m->params; if (inf) *inf = m->params_inf; if (grads) *grads = m->grads; return 0;
+}
+extern "C" int ngp_model_grid_layout(const ngp_model* m, uint32_t* offsets, uint32_t* resolutions, float* scales) {
+	for (uint32_t i = 0; i <= m->gm.n_levels; ++i) offsets[i] = m->gm.offset[i];
+	for (uint32_t i = 0; i < m->gm.n_levels; ++i) { resolutions[i] = m->gm.resolution[i]; scales[i] = m->gm.scale[i]; }
+	return 0;
+}
+extern "C" int ngp_model_set_params_host(ngp_model* m, const float* p, uint64_t n) {
+	REQUIRE(n == m->n_params, "set_params: size mismatch");
+	HIPCHK(hipMemcpy(m->master, p, n * 4, hipMemcpyHostToDevice));
+	if (model_refresh_half(m, nullptr)) return 1;
+	HIPCHK(hipDeviceSynchronize());
+	return 0;
+}
+extern "C" int ngp_model_get_params_host(ngp_model* m, float* p, uint64_t n) {
+	REQUIRE(n == m->n_params, "get_params: size mismatch");
+	HIPCHK(hipMemcpy(p, m->master, n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+static ModelPtrs model_ptrs(const ngp_model* m, bool inference) {
+	ModelPtrs mp;
+	mp.grid = (inference ? m->params_inf : m->params) + m->n_mlp;
+	mp.fw_frags = inference ? m->fw_frags_inf : m->fw_frags;
+	mp.bw_frags = m->bw_frags;
+	return mp;
+}
+
+extern "C" int ngp_model_inference(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
+		ngp_half* out, uint32_t out_stride, int use_inference_params) {
+	REQUIRE(in_stride >= 7 && out_stride >= 4 && out_stride % 4 == 0, "inference: in_stride >= 7, out_stride a multiple of 4 halfs");
+	launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), in, in_stride, n_max, n_ptr, out, out_stride, false, 4);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_model_density(ngp_model* m, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out, uint32_t out_stride, int use_inference_params) {
+	REQUIRE(pos_stride >= 3 && out_stride >= 1, "density: bad strides");
+	launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), pos, pos_stride, n, nullptr, out, out_stride, true, 0);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+// test hook: grid encoding only (natural feature order), not part of the reference API surface
+extern "C" int ngp_model_encode(ngp_model* m, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out32) {
+	launch_encode_only((hipStream_t)stream, m->gm_dev, m->params + m->n_mlp, pos, pos_stride, n, out32);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride) {
+	REQUIRE(in_stride >= 7 && dy_stride >= 4 && dy_stride % 4 == 0, "training_step: in_stride >= 7, dy_stride a multiple of 4 halfs");
+	hipStream_t s = (hipStream_t)stream;
+	const size_t need = (size_t)((n + 31) / 32) * 2 * 64 * 8; // halfs
+	if (need > m->stash_halfs) {
+		HIPCHK(hipStreamSynchronize(s));
+		if (m->enc_stash) HIPCHK(hipFree(m->enc_stash));
+		m->enc_stash = nullptr; m->stash_halfs = 0;
+		if (dev_alloc(&m->enc_stash, need)) return 1;
+		m->stash_halfs = need;
+	}
+	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
+	HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s));
+	launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, m->wgrad_partials, m->n_partials);
+	launch_wgrad_reduce(s, m->wgrad_partials, m->n_partials, m->grads);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
+	++m->step; // Adam::step: ++m_current_step
+	AdamArgs a;
+	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
+	a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.epsilon; a.l2_reg = m->cfg.l2_reg;
+	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
+	const float d = m->cfg.ema_decay;
+	a.ema_decay = d;
+	a.ema_debias_old = 1 - std::pow(d, (float)(m->step - 1));
+	a.ema_debias_new = 1 / (1 - std::pow(d, (float)m->step));
+	a.master = m->master; a.params = m->params; a.params_inf = m->params_inf; a.grads = m->grads;
+	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema;
+	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
+	launch_optimizer_step((hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	// ExponentialDecay::step [tcnn]
+	if (m->cfg.decay_interval > 0 && m->step >= m->cfg.decay_start && m->step % m->cfg.decay_interval == 0) m->lr *= m->cfg.decay_base;
+	return 0;
+}
+extern "C" int ngp_model_set_trainable(ngp_model* m, int net, int enc) { m->train_network = net != 0; m->train_encoding = enc != 0; return 0; }
+extern "C" float ngp_model_learning_rate(const ngp_model* m) { return m->lr; }
+extern "C" uint32_t ngp_model_step(const ngp_model* m) { return m->step; }
+
+struct SerHeader { uint32_t magic, version; uint64_t n_params; uint32_t step, with_optimizer; float lr; uint32_t pad; };
+extern "C" uint64_t ngp_model_serialized_size(const ngp_model* m, int with_optimizer) {
+	return sizeof(SerHeader) + m->n_params * 4 * (with_optimizer ? 5 : 1);
+}
+extern "C" int ngp_model_serialize_host(ngp_model* m, void* buf, uint64_t size, int with_optimizer) {
+	REQUIRE(size >= ngp_model_serialized_size(m, with_optimizer), "serialize: buffer too small");
+	SerHeader h = {0x4E475031u, 1, m->n_params, m->step, (uint32_t)(with_optimizer != 0), m->lr, 0};
+	char* p = (char*)buf;
+	memcpy(p, &h, sizeof(h)); p += sizeof(h);
+	const size_t nb = m->n_params * 4;
+	HIPCHK(hipMemcpy(p, m->master, nb, hipMemcpyDeviceToHost)); p += nb;
+	if (with_optimizer) {
+		HIPCHK(hipMemcpy(p, m->adam_m, nb, hipMemcpyDeviceToHost)); p += nb;
+		HIPCHK(hipMemcpy(p, m->adam_v, nb, hipMemcpyDeviceToHost)); p += nb;
+		HIPCHK(hipMemcpy(p, m->adam_steps, nb, hipMemcpyDeviceToHost)); p += nb;
+		HIPCHK(hipMemcpy(p, m->ema, nb, hipMemcpyDeviceToHost)); p += nb;
+	}
+	return 0;
+}
+__global__ void k_ema_to_inference(const float* __restrict__ ema, __half* __restrict__ inf, uint64_t n) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) inf[i] = __float2half(ema[i]);
+}
+extern "C" int ngp_model_deserialize_host(ngp_model* m, const void* buf, uint64_t size) {
+	REQUIRE(size >= sizeof(SerHeader), "deserialize: truncated");
+	SerHeader h; memcpy(&h, buf, sizeof(h));
+	REQUIRE(h.magic == 0x4E475031u && h.version == 1, "deserialize: bad magic/version");
+	REQUIRE(h.n_params == m->n_params, "deserialize: parameter count mismatch");
+	REQUIRE(size >= sizeof(SerHeader) + m->n_params * 4 * (h.with_optimizer ? 5 : 1), "deserialize: truncated");
+	const char* p = (const char*)buf + sizeof(h);
+	const size_t nb = m->n_params * 4;
+	HIPCHK(hipMemcpy(m->master, p, nb, hipMemcpyHostToDevice)); p += nb;
+	if (model_refresh_half(m, nullptr)) return 1;
+	if (h.with_optimizer) {
+		HIPCHK(hipMemcpy(m->adam_m, p, nb, hipMemcpyHostToDevice)); p += nb;
+		HIPCHK(hipMemcpy(m->adam_v, p, nb, hipMemcpyHostToDevice)); p += nb;
+		HIPCHK(hipMemcpy(m->adam_steps, p, nb, hipMemcpyHostToDevice)); p += nb;
+		HIPCHK(hipMemcpy(m->ema, p, nb, hipMemcpyHostToDevice)); p += nb;
+		m->step = h.step; m->lr = h.lr;
+		if (m->step > 0) {
+			hipLaunchKernelGGL(k_ema_to_inference, dim3((uint32_t)((m->n_params + 255) / 256)), dim3(256), 0, 0, m->ema, (__half*)m->params_inf, m->n_params);
+			launch_build_frags(nullptr, m->params_inf, (uint32_t)m->n_mlp, m->fw_perm, m->bw_perm, m->fw_frags_inf, nullptr);
+		}
+	}
+	HIPCHK(hipDeviceSynchronize());
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone NeRF kernels
+// ------------------------------------------------------------------------------------------------
+extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, uint32_t rank, uint32_t world_size, const uint32_t* n_rays_ptr, ngp_aabb aabb,
+		uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng, uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out,
+		ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_xform* xforms,
+		const uint8_t* bitfield, uint32_t max_mip, int snap_to_pixel_centers, float cone_angle_constant) {
+	REQUIRE(world_size >= 1 && rank < world_size, "generate_training_samples: bad rank/world_size");
+	K1Args a;
+	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.rank = rank; a.world_size = world_size; a.aabb = aabb; a.max_samples = max_samples;
+	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
+	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
+	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
+	launch_generate_training_samples((hipStream_t)stream, a, n_rays / world_size + 1);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t* n_rays_ptr, ngp_aabb aabb, ngp_pcg32 rng, uint32_t max_samples_compacted,
+		const uint32_t* rays_counter, float loss_scale, const float background_color[3], int color_space_srgb, int random_bg_color, int linear_colors,
+		uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_half* network_output, uint32_t output_stride, uint32_t* numsteps_counter_compacted,
+		const uint32_t* ray_indices_in, const ngp_ray* rays_in, uint32_t* numsteps_inout, const float* coords_in, float* coords_out, ngp_half* dloss_doutput,
+		uint32_t dloss_stride, int loss_type, float* loss_output, int rgb_activation, int density_activation, int snap_to_pixel_centers,
+		const float* mean_density_ptr, float near_distance) {
+	K3Args a;
+	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.aabb = aabb; a.rng = rng; a.max_samples_compacted = max_samples_compacted; a.rays_counter = rays_counter;
+	a.loss_scale = loss_scale; for (int k = 0; k < 3; ++k) a.background_color[k] = background_color[k];
+	a.color_space_srgb = color_space_srgb; a.random_bg_color = random_bg_color; a.linear_colors = linear_colors; a.n_images = n_training_images; a.metadata = metadata;
+	a.network_output = network_output; a.output_stride = output_stride; a.numsteps_counter_compacted = numsteps_counter_compacted; a.ray_indices_in = ray_indices_in;
+	a.rays_in = rays_in; a.numsteps_inout = numsteps_inout; a.coords_in = coords_in; a.coords_out = coords_out; a.dloss_doutput = dloss_doutput; a.dloss_stride = dloss_stride;
+	a.loss_type = loss_type; a.loss_output = loss_output; a.rgb_activation = rgb_activation; a.density_activation = density_activation;
+	a.snap_to_pixel_centers = snap_to_pixel_centers; a.mean_density_ptr = mean_density_ptr; a.near_distance = near_distance;
+	launch_compute_loss((hipStream_t)stream, a, n_rays);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_fill_rollover(void* stream, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
+	launch_fill_rollover((hipStream_t)stream, n_elements, n_input_ptr, coords, cstride, dloss, dstride);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_mark_untrained_density_grid(void* stream, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xf, int clear) {
+	launch_mark_untrained((hipStream_t)stream, n, grid, n_images, meta, xf, clear);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_generate_grid_samples(void* stream, uint32_t n, ngp_pcg32 rng, uint32_t step, ngp_aabb aabb, const float* grid_in, float* pos, uint32_t* idx,
+		uint32_t n_cascades, float thresh) {
+	launch_generate_grid_samples((hipStream_t)stream, n, rng, nullptr, step, aabb, grid_in, pos, idx, n_cascades, thresh);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_splat_grid_samples(void* stream, uint32_t n, const uint32_t* idx, const ngp_half* out, uint32_t stride, float* grid, int act) {
+	launch_splat_grid_samples((hipStream_t)stream, n, idx, out, stride, grid, act);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_ema_grid_samples(void* stream, uint32_t n, float decay, float* grid_out, const float* grid_in) {
+	launch_ema_grid_samples((hipStream_t)stream, n, decay, grid_out, grid_in);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+static float* g_mean_partial = nullptr;
+extern "C" int ngp_k_update_mean_and_bitfield(void* stream, const float* grid, uint32_t max_cascade, uint8_t* bitfield, float* mean_out) {
+	if (!g_mean_partial && dev_alloc(&g_mean_partial, 256)) return 1;
+	launch_grid_mean((hipStream_t)stream, grid, g_mean_partial, mean_out);
+	launch_grid_to_bitfield((hipStream_t)stream, grid, max_cascade, bitfield, mean_out);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_grid_to_bitfield(void* stream, const float* grid, uint32_t max_cascade, uint8_t* bitfield, const float* mean_ptr) {
+	launch_grid_to_bitfield((hipStream_t)stream, grid, max_cascade, bitfield, mean_ptr);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NeRF trainer
+// ------------------------------------------------------------------------------------------------
+struct ngp_nerf {
+	ngp_model* model;
+	ngp_nerf_options opt;
+	ngp_aabb aabb;
+	uint32_t n_images = 0;
+	ngp_image_meta* meta_dev = nullptr; ngp_xform* xforms_dev = nullptr;
+	std::vector<void*> owned_pixels;
+	float* density_grid = nullptr; float* density_grid_tmp = nullptr; uint8_t* bitfield = nullptr; float* mean = nullptr; float* mean_partial = nullptr;
+	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
+	TrainCounters* counters = nullptr;
+	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
+	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
+	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
+	// host-side deterministic state (no device read-back needed)
+	Rng rng, density_grid_rng;
+	uint32_t training_step = 0, prep_skip_counter = 0, ema_step = 0;
+	uint32_t max_rays = 1u << 18;
+};
+
+
+extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_aabb aabb, ngp_nerf** out) {
+	REQUIRE(model && o && out, "ngp_nerf_create: null argument");
+	REQUIRE(o->world_size >= 1 && o->rank < o->world_size, "ngp_nerf_create: bad rank/world_size");
+	REQUIRE(o->max_cascade < N_CASCADES, "ngp_nerf_create: max_cascade must be < 8 (NERF_CASCADES)");
+	ngp_nerf* t = new ngp_nerf();
+	t->model = model; t->opt = *o; t->aabb = aabb;
+	t->rng = make_rng(o->seed);                         // testbed.cu:4163
+	t->density_grid_rng = make_rng(t->rng.next_uint()); // testbed.cu:4178
+	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
+	const uint32_t B = o->target_batch_size, max_samples = B * 16;
+	t->grid_sample_cap = n_cells;
+	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
+		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
+		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2)) { delete t; return 1; }
+	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
+	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
+	HIPCHK(hipMemset(t->mean, 0, 4));
+	TrainCounters c; memset(&c, 0, sizeof(c));
+	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
+	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
+	c.measured_batch_size_before_compaction = max_samples;
+	HIPCHK(hipMemcpy(t->counters, &c, sizeof(c), hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(t->sync2, 0, 8));
+	*out = t;
+	return 0;
+}
+extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
+	if (!t) return;
+	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2};
+	for (void* p : ptrs) if (p) (void)hipFree(p);
+	for (void* p : t->owned_pixels) (void)hipFree(p);
+	delete t;
+}
+
+static size_t pixel_bytes(int type) { return type == NGP_IMAGE_BYTE ? 4 : type == NGP_IMAGE_HALF ? 8 : 16; }
+
+static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_image_meta>& meta, const ngp_xform* xforms) {
+	if (t->meta_dev) { (void)hipFree(t->meta_dev); t->meta_dev = nullptr; }
+	if (t->xforms_dev) { (void)hipFree(t->xforms_dev); t->xforms_dev = nullptr; }
+	if (dev_alloc(&t->meta_dev, n) || dev_alloc(&t->xforms_dev, n)) return 1;
+	HIPCHK(hipMemcpy(t->meta_dev, meta.data(), n * sizeof(ngp_image_meta), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->xforms_dev, xforms, n * sizeof(ngp_xform), hipMemcpyHostToDevice));
+	t->n_images = n;
+	return 0;
+}
+extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_image_meta* meta, const ngp_xform* xforms, const void* const* pixels_host) {
+	REQUIRE(n > 0 && meta && xforms && pixels_host, "set_dataset: null/empty");
+	for (void* p : t->owned_pixels) (void)hipFree(p);
+	t->owned_pixels.clear();
+	std::vector<ngp_image_meta> m(meta, meta + n);
+	for (uint32_t i = 0; i < n; ++i) {
+		REQUIRE(m[i].lens_mode == NGP_LENS_PERSPECTIVE || m[i].lens_mode == NGP_LENS_OPENCV, "only Perspective / OpenCV lenses are implemented");
+		const size_t bytes = (size_t)m[i].resolution[0] * m[i].resolution[1] * pixel_bytes(m[i].image_data_type);
+		void* d = nullptr;
+		HIPCHK(hipMalloc(&d, bytes));
+		t->owned_pixels.push_back(d);
+		HIPCHK(hipMemcpy(d, pixels_host[i], bytes, hipMemcpyHostToDevice));
+		m[i].pixels = d;
+	}
+	return set_dataset_common(t, n, m, xforms);
+}
+extern "C" int ngp_nerf_set_dataset_device(ngp_nerf* t, uint32_t n, const ngp_image_meta* meta, const ngp_xform* xforms) {
+	REQUIRE(n > 0 && meta && xforms, "set_dataset: null/empty");
+	std::vector<ngp_image_meta> m(meta, meta + n);
+	for (uint32_t i = 0; i < n; ++i)
+		REQUIRE(m[i].lens_mode == NGP_LENS_PERSPECTIVE || m[i].lens_mode == NGP_LENS_OPENCV, "only Perspective / OpenCV lenses are implemented");
+	return set_dataset_common(t, n, m, xforms);
+}
+
+// update_density_grid_nerf, testbed_nerf.cu:2476-2592
+extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float decay, uint32_t n_uniform, uint32_t n_nonuniform) {
+	REQUIRE(t->n_images > 0, "update_density_grid: no dataset");
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n_elements = GRID_N_CELLS * (t->opt.max_cascade + 1);
+	const uint32_t n_samples = n_uniform + n_nonuniform;
+	REQUIRE(n_samples <= t->grid_sample_cap, "update_density_grid: too many samples");
+	if (t->training_step == 0) {
+		t->ema_step = 0;
+		launch_mark_untrained(s, n_elements, t->density_grid, t->n_images, t->meta_dev, t->xforms_dev, 1);
+	}
+	HIPCHK(hipMemsetAsync(t->density_grid_tmp, 0, (size_t)n_elements * 4, s));
+	launch_generate_grid_samples(s, n_uniform, pod(t->density_grid_rng), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions, t->grid_indices,
+		t->opt.max_cascade + 1, -0.01f);
+	t->density_grid_rng.advance(1ull << 32);
+	launch_generate_grid_samples(s, n_nonuniform, pod(t->density_grid_rng), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions + (size_t)n_uniform * 3,
+		t->grid_indices + n_uniform, t->opt.max_cascade + 1, MIN_OPTICAL_THICKNESS);
+	t->density_grid_rng.advance(1ull << 32);
+	// NerfNetwork::density with the TRAINING params (use_inference_params = false, testbed_nerf.cu:2570)
+	launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->grid_positions, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0);
+	launch_splat_grid_samples(s, n_samples, t->grid_indices, t->grid_mlp_out, 1, t->density_grid_tmp, t->opt.density_activation);
+	launch_ema_grid_samples(s, n_elements, decay, t->density_grid, t->density_grid_tmp);
+	++t->ema_step;
+	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);
+	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// training_prep_nerf (testbed_nerf.cu:3385-3398) at the cadence of Testbed::train (testbed.cu:4596-4613)
+extern "C" int ngp_nerf_train_prep(ngp_nerf* t, void* stream) {
+	const uint32_t n_prep_to_skip = (uint32_t)std::min(std::max((int)t->training_step / 16, 1), 16);
+	int rc = 0;
+	if (t->prep_skip_counter % n_prep_to_skip == 0) {
+		const uint32_t n_cascades = t->opt.max_cascade + 1;
+		if (t->training_step < 256) rc = ngp_nerf_update_density_grid(t, stream, t->opt.density_grid_decay, GRID_N_CELLS * n_cascades, 0);
+		else rc = ngp_nerf_update_density_grid(t, stream, t->opt.density_grid_decay, GRID_N_CELLS / 4 * n_cascades, GRID_N_CELLS / 4 * n_cascades);
+	}
+	++t->prep_skip_counter;
+	return rc;
+}
+
+// train_nerf_step, testbed_nerf.cu:3007-3382 (Nerf train mode: K1, K2, K3, K4, K5)
+extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
+	REQUIRE(t->n_images > 0, "train: no dataset");
+	hipStream_t s = (hipStream_t)stream;
+	const ngp_nerf_options& o = t->opt;
+	const uint32_t B = o.target_batch_size, max_samples = B * 16;
+	TrainCounters* c = t->counters;
+	K1Args k1;
+	k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
+	k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
+	k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
+	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
+	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
+	launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1);
+	launch_clamp_compacted(s, c, B);
+	launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4);
+	K3Args k3;
+	k3.n_rays = 0; k3.n_rays_ptr = &c->rays_per_batch; k3.aabb = t->aabb; k3.rng = pod(t->rng); k3.max_samples_compacted = B; k3.rays_counter = &c->ray_counter;
+	k3.loss_scale = o.loss_scale; for (int k = 0; k < 3; ++k) k3.background_color[k] = o.background_color[k];
+	k3.color_space_srgb = o.color_space_srgb; k3.random_bg_color = o.random_bg_color; k3.linear_colors = o.linear_colors; k3.n_images = t->n_images; k3.metadata = t->meta_dev;
+	k3.network_output = t->mlp_out; k3.output_stride = 4; k3.numsteps_counter_compacted = &c->numsteps_counter_compacted; k3.ray_indices_in = t->ray_indices;
+	k3.rays_in = t->rays; k3.numsteps_inout = t->numsteps; k3.coords_in = t->coords; k3.coords_out = t->coords_compacted; k3.dloss_doutput = t->dloss; k3.dloss_stride = 4;
+	k3.loss_type = o.loss_type; k3.loss_output = &c->loss_sum; k3.rgb_activation = o.rgb_activation; k3.density_activation = o.density_activation;
+	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
+	launch_compute_loss(s, k3, t->max_rays / o.world_size + 1);
+	launch_clamp_compacted(s, c, B);
+	launch_fill_rollover(s, B, &c->n_valid_compacted, t->coords_compacted, 7, t->dloss, 4);
+	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
+	// publish the two counters that every rank must agree on before the controller runs (8e)
+	HIPCHK(hipMemcpyAsync(t->sync2, &c->numsteps_counter, 8, hipMemcpyDeviceToDevice, s));
+	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+__global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t world_size) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	// after an all-reduce(sum) sync2 holds the GLOBAL counts; the controller works on per-rank averages
+	const uint32_t avg_before = (sync2[0] + world_size - 1) / world_size;
+	c->numsteps_counter = avg_before + avg_before / 8; // slack: K1's cap must cover ranks above the average
+	c->numsteps_counter_compacted = (sync2[1] + world_size - 1) / world_size;
+}
+
+// optimizer_step + NerfCounters::update_after_training, testbed_nerf.cu:2770-2778
+extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
+	if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
+	launch_update_counters(s, t->counters, t->opt.target_batch_size);
+	++t->training_step;
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
+	for (uint32_t i = 0; i < n_steps; ++i) {
+		if (ngp_nerf_train_prep(t, stream)) return 1;
+		if (ngp_nerf_train_forward_backward(t, stream)) return 1;
+		if (ngp_nerf_train_finish(t, stream)) return 1;
+	}
+	return 0;
+}
+extern "C" int ngp_nerf_counter_ptrs(ngp_nerf* t, uint32_t** counters2) { *counters2 = t->sync2; return 0; }
+extern "C" int ngp_nerf_get_stats(ngp_nerf* t, void* stream, ngp_nerf_stats* out) {
+	TrainCounters c;
+	HIPCHK(hipMemcpyAsync(&c, t->counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+	out->training_step = c.training_step; out->rays_per_batch = c.rays_per_batch; out->n_rays_last = c.n_rays_last;
+	out->measured_batch_size = c.measured_batch_size; out->measured_batch_size_before_compaction = c.measured_batch_size_before_compaction;
+	out->loss = c.loss_scalar; out->total_rays = c.total_rays; out->total_samples = c.total_samples;
+	return 0;
+}
+extern "C" int ngp_nerf_density_grid_ptrs(ngp_nerf* t, float** grid, uint8_t** bitfield, float** mean) {
+	if (grid) *grid = t->density_grid; if (bitfield) *bitfield = t->bitfield; if (mean) *mean = t->mean; return 0;
+}
+extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const float* grid_host, uint64_t n) {
+	REQUIRE(n == (uint64_t)GRID_N_CELLS * (t->opt.max_cascade + 1), "set_density_grid: size mismatch");
+	HIPCHK(hipMemcpy(t->density_grid, grid_host, n * 4, hipMemcpyHostToDevice));
+	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
+	launch_grid_to_bitfield((hipStream_t)stream, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+// test hooks: scratch buffers of the last train_forward_backward, and state overrides
+extern "C" int ngp_nerf_scratch_ptrs(ngp_nerf* t, uint32_t** ray_indices, ngp_ray** rays, uint32_t** numsteps, float** coords, ngp_half** mlp_out,
+		float** coords_compacted, ngp_half** dloss, void** counters) {
+	*ray_indices = t->ray_indices; *rays = t->rays; *numsteps = t->numsteps; *coords = t->coords; *mlp_out = t->mlp_out; *coords_compacted = t->coords_compacted;
+	*dloss = t->dloss; *counters = t->counters;
+	return 0;
+}
+extern "C" int ngp_nerf_set_rays_per_batch(ngp_nerf* t, uint32_t r) {
+	HIPCHK(hipMemcpy(&t->counters->rays_per_batch, &r, 4, hipMemcpyHostToDevice));
+	return 0;
+}
+extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = pod(t->rng); *grid_rng = pod(t->density_grid_rng); return 0; }
+
+extern "C" int ngp_nerf_render(ngp_nerf*, void*, const ngp_render_params*, float*, float*) { return fail("ngp_nerf_render: not built yet"); }

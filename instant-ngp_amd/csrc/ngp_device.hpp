@@ -1,0 +1,412 @@
+// ngp_device.hpp -- device-side math of the NeRF hot path for gfx950 (wave64).
+//
+// Mirrors the *semantics* of the reference's device headers so that occupancy-grid indices and ray
+// samples are bit-identical to the reference arithmetic (IEEE fp32, no FMA contraction in the
+// translation units that include this for ray marching -- they are compiled with -ffp-contract=off):
+//   nerf_device.cuh   (constants :25-43, activations :204-264, warps :266-315, grid index :317-341,
+//                      stepping :360-460, occupancy skipping :462-495, sampling :553-599, losses :75-143)
+//   common_device.cuh (sRGB :61-103, lens :268-345, uv_to_ray :413-490, pos_to_uv :527-577, read_rgba :846-872)
+//   bounding_box.cuh  (:82-84, :173-227)   random_val.cuh (:60-291)   [tcnn] pcg32, morton3D
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/ngp_hip.h"
+
+namespace ngp {
+
+#define NGP_D __device__ __forceinline__
+#define NGP_HD __host__ __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+struct f4 { float x, y, z, w; };
+
+NGP_HD f3 mk3(float a, float b, float c) { f3 r; r.x = a; r.y = b; r.z = c; return r; }
+NGP_HD f3 mk3(float a) { return mk3(a, a, a); }
+NGP_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+NGP_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+NGP_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+NGP_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+NGP_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+NGP_HD f3 operator+(f3 a, float b) { return mk3(a.x + b, a.y + b, a.z + b); }
+NGP_HD f3 operator-(f3 a, float b) { return mk3(a.x - b, a.y - b, a.z - b); }
+NGP_HD f3 operator*(f3 a, float b) { return mk3(a.x * b, a.y * b, a.z * b); }
+NGP_HD f3 operator*(float b, f3 a) { return mk3(b * a.x, b * a.y, b * a.z); }
+NGP_HD f3 operator/(f3 a, float b) { return mk3(a.x / b, a.y / b, a.z / b); }
+NGP_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NGP_HD float len3(f3 a) { return sqrtf(dot3(a, a)); }
+NGP_HD f3 normalize3(f3 a) { return a / len3(a); }
+NGP_HD float dist3(f3 a, f3 b) { return len3(a - b); }
+NGP_HD float sgn(float x) { return copysignf(1.0f, x); }
+NGP_HD float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+NGP_HD int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+NGP_HD float logisticf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct M43 { f3 c[4]; };
+NGP_HD M43 ldm43(const float* p) { M43 m; m.c[0] = ld3(p); m.c[1] = ld3(p + 3); m.c[2] = ld3(p + 6); m.c[3] = ld3(p + 9); return m; }
+NGP_HD f3 mul3(const M43& m, f3 v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z; }
+
+// ---- pcg32 -----------------------------------------------------------------------------------
+struct Rng {
+	uint64_t state, inc;
+	NGP_HD Rng() {}
+	NGP_HD explicit Rng(ngp_pcg32 p) : state(p.state), inc(p.inc) {}
+	NGP_HD uint32_t next_uint() {
+		uint64_t old = state;
+		state = old * 0x5851f42d4c957f2dULL + inc;
+		uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		uint32_t rot = (uint32_t)(old >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+	}
+	NGP_HD float next_float() {
+		union { uint32_t u; float f; } x;
+		x.u = (next_uint() >> 9) | 0x3f800000u;
+		return x.f - 1.0f;
+	}
+	NGP_HD void advance(uint64_t delta) {
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+		while (delta > 0) {
+			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+			cur_plus = (cur_mult + 1) * cur_plus;
+			cur_mult *= cur_mult;
+			delta >>= 1;
+		}
+		state = acc_mult * state + acc_plus;
+	}
+};
+
+// ---- Morton ----------------------------------------------------------------------------------
+NGP_HD uint32_t expand_bits(uint32_t v) {
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+NGP_HD uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) { return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2); }
+NGP_HD uint32_t morton3D_invert(uint32_t x) {
+	x = x & 0x49249249;
+	x = (x | (x >> 2)) & 0xc30c30c3;
+	x = (x | (x >> 4)) & 0x0f00f00f;
+	x = (x | (x >> 8)) & 0xff0000ff;
+	x = (x | (x >> 16)) & 0x0000ffff;
+	return x;
+}
+
+// ---- colour ----------------------------------------------------------------------------------
+NGP_HD float srgb_to_linear(float s) { return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f); }
+NGP_HD float linear_to_srgb(float l) { return l < 0.0031308f ? 12.92f * l : 1.055f * powf(l, 0.41666f) - 0.055f; }
+NGP_HD f3 srgb_to_linear3(f3 v) { return mk3(srgb_to_linear(v.x), srgb_to_linear(v.y), srgb_to_linear(v.z)); }
+NGP_HD f3 linear_to_srgb3(f3 v) { return mk3(linear_to_srgb(v.x), linear_to_srgb(v.y), linear_to_srgb(v.z)); }
+
+// ---- AABB ------------------------------------------------------------------------------------
+struct Box {
+	f3 mn, mx;
+	NGP_HD Box() {}
+	NGP_HD explicit Box(const ngp_aabb& a) : mn(ld3(a.min)), mx(ld3(a.max)) {}
+	NGP_HD f3 diag() const { return mx - mn; }
+	NGP_HD f3 relative_pos(f3 p) const { return (p - mn) / diag(); }
+	NGP_HD bool contains(f3 p) const { return p.x >= mn.x && p.x <= mx.x && p.y >= mn.y && p.y <= mx.y && p.z >= mn.z && p.z <= mx.z; }
+	NGP_HD f2 ray_intersect(f3 pos, f3 dir) const {
+		const float FMAX = 3.402823466e+38f;
+		float tmin = (mn.x - pos.x) / dir.x, tmax = (mx.x - pos.x) / dir.x;
+		if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
+		float tymin = (mn.y - pos.y) / dir.y, tymax = (mx.y - pos.y) / dir.y;
+		if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
+		if (tmin > tymax || tymin > tmax) return {FMAX, FMAX};
+		if (tymin > tmin) tmin = tymin;
+		if (tymax < tmax) tmax = tymax;
+		float tzmin = (mn.z - pos.z) / dir.z, tzmax = (mx.z - pos.z) / dir.z;
+		if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
+		if (tmin > tzmax || tzmin > tmax) return {FMAX, FMAX};
+		if (tzmin > tmin) tmin = tzmin;
+		if (tzmax < tmax) tmax = tzmax;
+		return {tmin, tmax};
+	}
+};
+
+// ---- constants -------------------------------------------------------------------------------
+constexpr uint32_t GRIDSIZE = 128;
+constexpr uint32_t GRID_N_CELLS = GRIDSIZE * GRIDSIZE * GRIDSIZE;
+constexpr uint32_t N_STEPS = 1024;
+constexpr uint32_t N_CASCADES = 8;
+constexpr float K_SQRT3 = 1.73205080757f;
+constexpr float K_STEPSIZE = K_SQRT3 / N_STEPS;
+constexpr float MIN_CONE_STEP = K_STEPSIZE;
+constexpr float MAX_CONE_STEP = K_STEPSIZE * (1 << (N_CASCADES - 1)) * N_STEPS / GRIDSIZE;
+constexpr uint32_t N_RANDOM_PER_RAY = 16;
+constexpr float MIN_OPTICAL_THICKNESS = 0.01f;
+constexpr float K_MAX_DEPTH = 16384.0f;
+
+NGP_HD float act_rgb(float v, int a) {
+	switch (a) {
+		case NGP_ACT_NONE: return v;
+		case NGP_ACT_RELU: return v > 0.0f ? v : 0.0f;
+		case NGP_ACT_LOGISTIC: return logisticf(v);
+		default: return expf(clampf(v, -10.0f, 10.0f));
+	}
+}
+NGP_HD float act_rgb_d(float v, int a) {
+	switch (a) {
+		case NGP_ACT_NONE: return 1.0f;
+		case NGP_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+		case NGP_ACT_LOGISTIC: { float d = logisticf(v); return d * (1 - d); }
+		default: return expf(clampf(v, -10.0f, 10.0f));
+	}
+}
+NGP_HD float act_density(float v, int a) {
+	switch (a) {
+		case NGP_ACT_NONE: return v;
+		case NGP_ACT_RELU: return v > 0.0f ? v : 0.0f;
+		case NGP_ACT_LOGISTIC: return logisticf(v);
+		default: return expf(v);
+	}
+}
+NGP_HD float act_density_d(float v, int a) {
+	switch (a) {
+		case NGP_ACT_NONE: return 1.0f;
+		case NGP_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+		case NGP_ACT_LOGISTIC: { float d = logisticf(v); return d * (1 - d); }
+		default: return expf(clampf(v, -15.0f, 15.0f));
+	}
+}
+
+NGP_HD f3 warp_position(f3 p, const Box& b) { return b.relative_pos(p); }
+NGP_HD f3 unwarp_position(f3 p, const Box& b) { return b.mn + p * b.diag(); }
+NGP_HD f3 warp_direction(f3 d) { return (d + 1.0f) * 0.5f; }
+NGP_HD float warp_dt(float dt) {
+	float max_stepsize = MIN_CONE_STEP * (1 << (N_CASCADES - 1));
+	return (dt - MIN_CONE_STEP) / (max_stepsize - MIN_CONE_STEP);
+}
+NGP_HD float unwarp_dt(float dt) {
+	float max_stepsize = MIN_CONE_STEP * (1 << (N_CASCADES - 1));
+	return dt * (max_stepsize - MIN_CONE_STEP) + MIN_CONE_STEP;
+}
+
+// ---- occupancy grid index math (bit-exact integer results) ---------------------------------------
+NGP_HD uint32_t cascaded_grid_idx_at(f3 pos, uint32_t mip) {
+	float mip_scale = scalbnf(1.0f, -(int)mip);
+	pos = pos - mk3(0.5f);
+	pos = pos * mip_scale;
+	pos = pos + mk3(0.5f);
+	int ix = (int)(pos.x * (float)GRIDSIZE), iy = (int)(pos.y * (float)GRIDSIZE), iz = (int)(pos.z * (float)GRIDSIZE);
+	if (ix < 0 || ix >= (int)GRIDSIZE || iy < 0 || iy >= (int)GRIDSIZE || iz < 0 || iz >= (int)GRIDSIZE) return 0xFFFFFFFFu;
+	return morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+}
+NGP_HD uint32_t grid_mip_offset(uint32_t mip) { return GRID_N_CELLS * mip; }
+NGP_HD bool occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
+	uint32_t idx = cascaded_grid_idx_at(pos, mip);
+	if (idx == 0xFFFFFFFFu) return false;
+	return bitfield[idx / 8 + grid_mip_offset(mip) / 8] & (1 << (idx % 8));
+}
+
+NGP_HD float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, float res) {
+	f3 p = res * (pos - 0.5f);
+	float tx = (floorf(p.x + 0.5f + 0.5f * sgn(dir.x)) - p.x) * idir.x;
+	float ty = (floorf(p.y + 0.5f + 0.5f * sgn(dir.y)) - p.y) * idir.y;
+	float tz = (floorf(p.z + 0.5f + 0.5f * sgn(dir.z)) - p.z) * idir.z;
+	float t = fminf(fminf(tx, ty), tz);
+	return fmaxf(t / res, 0.0f);
+}
+NGP_HD float to_stepping_space(float t, float cone_angle) {
+	if (cone_angle <= 1e-5f) return t / MIN_CONE_STEP;
+	float log1p_c = logf(1.0f + cone_angle);
+	float a = (logf(MIN_CONE_STEP) - logf(log1p_c)) / log1p_c;
+	float b = (logf(MAX_CONE_STEP) - logf(log1p_c)) / log1p_c;
+	float at = expf(a * log1p_c), bt = expf(b * log1p_c);
+	if (t <= at) return (t - at) / MIN_CONE_STEP + a;
+	else if (t <= bt) return logf(t) / log1p_c;
+	else return (t - bt) / MAX_CONE_STEP + b;
+}
+NGP_HD float from_stepping_space(float n, float cone_angle) {
+	if (cone_angle <= 1e-5f) return n * MIN_CONE_STEP;
+	float log1p_c = logf(1.0f + cone_angle);
+	float a = (logf(MIN_CONE_STEP) - logf(log1p_c)) / log1p_c;
+	float b = (logf(MAX_CONE_STEP) - logf(log1p_c)) / log1p_c;
+	float at = expf(a * log1p_c), bt = expf(b * log1p_c);
+	if (n <= a) return (n - a) * MIN_CONE_STEP + at;
+	else if (n <= b) return expf(n * log1p_c);
+	else return (n - b) * MAX_CONE_STEP + bt;
+}
+NGP_HD float advance_n_steps(float t, float cone_angle, float n) { return from_stepping_space(to_stepping_space(t, cone_angle) + n, cone_angle); }
+NGP_HD float calc_dt(float t, float cone_angle) { return advance_n_steps(t, cone_angle, 1.0f) - t; }
+NGP_HD float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t mip) {
+	float res = scalbnf((float)GRIDSIZE, -(int)mip);
+	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+	t = to_stepping_space(t, cone_angle);
+	t_target = to_stepping_space(t_target, cone_angle);
+	return from_stepping_space(t + ceilf(fmaxf(t_target - t, 0.5f)), cone_angle);
+}
+NGP_HD uint32_t mip_from_pos(f3 pos, uint32_t max_cascade = N_CASCADES - 1) {
+	int exponent;
+	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));
+	frexpf(maxval, &exponent);
+	return (uint32_t)clampi(exponent + 1, 0, (int)max_cascade);
+}
+NGP_HD uint32_t mip_from_dt(float dt, f3 pos, uint32_t max_cascade = N_CASCADES - 1) {
+	uint32_t mip = mip_from_pos(pos, max_cascade);
+	dt *= 2 * GRIDSIZE;
+	if (dt < 1.0f) return mip;
+	int exponent;
+	frexpf(dt, &exponent);
+	return (uint32_t)clampi((int)mip, exponent, (int)max_cascade);
+}
+NGP_D float skip_to_next_occupied(float t, float cone_angle, f3 o, f3 d, f3 idir, const uint8_t* __restrict__ grid,
+		uint32_t min_mip, uint32_t max_mip, const Box& aabb) {
+	while (true) {
+		f3 pos = o + d * t;
+		if (t >= K_MAX_DEPTH || !aabb.contains(pos)) return K_MAX_DEPTH;
+		uint32_t mip = (uint32_t)clampi((int)mip_from_pos(pos), (int)min_mip, (int)max_mip);
+		if (!grid || occupied_at(pos, grid, mip)) return t;
+		while (mip < max_mip && !occupied_at(pos, grid, mip + 1)) ++mip;
+		t = advance_to_next_voxel(t, cone_angle, pos, d, idir, mip);
+	}
+}
+
+// ---- low-discrepancy sampler (Sobol dims 0/1 generated, Owen scrambling) ------------------------
+NGP_HD uint32_t sobol01(uint32_t index, uint32_t dim) {
+	uint32_t X = 0, v = 0x80000000u;
+	for (uint32_t bit = 0; bit < 32; ++bit) {
+		uint32_t dirn = (dim == 0) ? (0x80000000u >> bit) : v;
+		if ((index >> bit) & 1u) X ^= dirn;
+		v = v ^ (v >> 1);
+	}
+	return X;
+}
+NGP_HD uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
+NGP_HD uint32_t reverse_bits32(uint32_t x) {
+	x = (((x & 0xaaaaaaaa) >> 1) | ((x & 0x55555555) << 1));
+	x = (((x & 0xcccccccc) >> 2) | ((x & 0x33333333) << 2));
+	x = (((x & 0xf0f0f0f0) >> 4) | ((x & 0x0f0f0f0f) << 4));
+	x = (((x & 0xff00ff00) >> 8) | ((x & 0x00ff00ff) << 8));
+	return ((x >> 16) | (x << 16));
+}
+NGP_HD uint32_t lk_perm(uint32_t x, uint32_t seed) {
+	x += seed; x ^= x * 0x6c50b47cu; x ^= x * 0xb82f1e52u; x ^= x * 0xc7afe638u; x ^= x * 0x8d22f6e6u; return x;
+}
+NGP_HD uint32_t owen_scramble(uint32_t x, uint32_t seed) { return reverse_bits32(lk_perm(reverse_bits32(x), seed)); }
+NGP_HD float ld_random_val(uint32_t index, uint32_t seed, uint32_t dim = 0) {
+	const float S = (float)(1.0 / 4294967296.0);
+	index = owen_scramble(index, seed);
+	return (float)owen_scramble(sobol01(index, dim), hash_combine(seed, dim)) * S;
+}
+NGP_HD f2 ld_random_pixel_offset(uint32_t spp) {
+	float ax = ld_random_val(0, 0xdeadbeef, 0), ay = ld_random_val(0, 0xdeadbeef, 1);
+	float bx = ld_random_val(spp, 0xdeadbeef, 0), by = ld_random_val(spp, 0xdeadbeef, 1);
+	float ox = 0.5f - ax + bx, oy = 0.5f - ay + by;
+	return {ox - floorf(ox), oy - floorf(oy)};
+}
+
+// ---- camera ----------------------------------------------------------------------------------
+NGP_HD void opencv_distortion_delta(const float* p, float u, float v, float* du, float* dv) {
+	const float k1 = p[0], k2 = p[1], p1 = p[2], p2 = p[3];
+	const float u2 = u * u, uv = u * v, v2 = v * v, r2 = u2 + v2;
+	const float radial = k1 * r2 + k2 * r2 * r2;
+	*du = u * radial + 2.f * p1 * uv + p2 * (r2 + 2.f * u2);
+	*dv = v * radial + 2.f * p2 * uv + p1 * (r2 + 2.f * v2);
+}
+NGP_HD void opencv_undistort(const float* params, float* u, float* v) {
+	const float eps = 1.1920929e-07f;
+	const float x00 = *u, x01 = *v;
+	float x0 = *u, x1 = *v;
+	for (uint32_t i = 0; i < 100; ++i) {
+		const float step0 = fmaxf(eps, fabsf(1e-6f * x0)), step1 = fmaxf(eps, fabsf(1e-6f * x1));
+		float dx0, dx1, b0x, b0y, f0x, f0y, b1x, b1y, f1x, f1y;
+		opencv_distortion_delta(params, x0, x1, &dx0, &dx1);
+		opencv_distortion_delta(params, x0 - step0, x1, &b0x, &b0y);
+		opencv_distortion_delta(params, x0 + step0, x1, &f0x, &f0y);
+		opencv_distortion_delta(params, x0, x1 - step1, &b1x, &b1y);
+		opencv_distortion_delta(params, x0, x1 + step1, &f1x, &f1y);
+		float J00 = 1 + (f0x - b0x) / (2 * step0), J10 = (f1x - b1x) / (2 * step1);
+		float J01 = (f0y - b0y) / (2 * step0), J11 = 1 + (f1y - b1y) / (2 * step1);
+		float r0 = x0 + dx0 - x00, r1 = x1 + dx1 - x01;
+		float det = J00 * J11 - J10 * J01;
+		float s0 = (J11 * r0 - J10 * r1) / det, s1 = (-J01 * r0 + J00 * r1) / det;
+		x0 -= s0; x1 -= s1;
+		if (s0 * s0 + s1 * s1 < 1e-10f) break;
+	}
+	*u = x0; *v = x1;
+}
+// uv_to_ray restricted to Perspective / OpenCV lenses (the lenses of the BASELINE datasets).
+NGP_HD void uv_to_ray(f2 uv, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode,
+		const float* lens_params, float near_distance, f3& o, f3& d) {
+	f3 dir = mk3((uv.x - center[0]) * (float)res[0] / focal[0], (uv.y - center[1]) * (float)res[1] / focal[1], 1.0f);
+	if (lens_mode == NGP_LENS_OPENCV) opencv_undistort(lens_params, &dir.x, &dir.y);
+	dir = mul3(cam, dir);
+	f3 origin = cam.c[3];
+	origin = origin + dir * near_distance;
+	o = origin; d = dir;
+}
+NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode, const float* lens_params) {
+	f3 dir = pos - cam.c[3];
+	const f3 a = cam.c[0], b = cam.c[1], c = cam.c[2];
+	float det = a.x * (b.y * c.z - c.y * b.z) - b.x * (a.y * c.z - c.y * a.z) + c.x * (a.y * b.z - b.y * a.z);
+	float id = 1.0f / det;
+	f3 r0 = mk3((b.y * c.z - c.y * b.z) * id, -(b.x * c.z - c.x * b.z) * id, (b.x * c.y - c.x * b.y) * id);
+	f3 r1 = mk3(-(a.y * c.z - c.y * a.z) * id, (a.x * c.z - c.x * a.z) * id, -(a.x * c.y - c.x * a.y) * id);
+	f3 r2 = mk3((a.y * b.z - b.y * a.z) * id, -(a.x * b.z - b.x * a.z) * id, (a.x * b.y - b.x * a.y) * id);
+	dir = mk3(dot3(r0, dir), dot3(r1, dir), dot3(r2, dir));
+	dir = dir / dir.z;
+	float du = 0.f, dv = 0.f;
+	if (lens_mode == NGP_LENS_OPENCV) opencv_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
+	dir.x += du; dir.y += dv;
+	return {dir.x * focal[0] / (float)res[0] + center[0], dir.y * focal[1] / (float)res[1] + center[1]};
+}
+
+NGP_D f4 read_rgba(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type) {
+	int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1);
+	int py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);
+	size_t idx = (size_t)px + (size_t)py * res[0];
+	if (type == NGP_IMAGE_BYTE) {
+		uint32_t val = ((const uint32_t*)pixels)[idx];
+		if (val == 0x00FF00FFu) return {-1.f, -1.f, -1.f, -1.f};
+		f4 r = {((val & 0x000000FFu) >> 0) * (1.0f / 255.0f), ((val & 0x0000FF00u) >> 8) * (1.0f / 255.0f),
+		        ((val & 0x00FF0000u) >> 16) * (1.0f / 255.0f), ((val & 0xFF000000u) >> 24) * (1.0f / 255.0f)};
+		r.x = srgb_to_linear(r.x) * r.w; r.y = srgb_to_linear(r.y) * r.w; r.z = srgb_to_linear(r.z) * r.w;
+		return r;
+	} else if (type == NGP_IMAGE_HALF) {
+		const __half* p = (const __half*)pixels + idx * 4;
+		return {__half2float(p[0]), __half2float(p[1]), __half2float(p[2]), __half2float(p[3])};
+	} else if (type == NGP_IMAGE_FLOAT) {
+		const float* p = (const float*)pixels + idx * 4;
+		return {p[0], p[1], p[2], p[3]};
+	}
+	return {5.0f, 0.0f, 0.0f, 1.0f};
+}
+
+NGP_HD uint32_t image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_images) { return ((base_idx * n_images) / n_rays) % n_images; }
+NGP_HD f2 random_image_pos_training(Rng& rng, const int32_t res[2], bool snap) {
+	f2 uv; uv.x = rng.next_float(); uv.y = rng.next_float();
+	if (snap) {
+		uv.x = ((float)clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1) + 0.5f) / (float)res[0];
+		uv.y = ((float)clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1) + 0.5f) / (float)res[1];
+	}
+	return uv;
+}
+
+// losses: gradient/loss per channel
+NGP_HD void loss_and_gradient(f3 target, f3 pred, int type, f3& loss, f3& grad) {
+	const float t[3] = {target.x, target.y, target.z}, p[3] = {pred.x, pred.y, pred.z};
+	float lo[3], gr[3];
+	for (int k = 0; k < 3; ++k) {
+		float df = p[k] - t[k];
+		switch (type) {
+			case NGP_LOSS_RELATIVE_L2: { float den = p[k] * p[k] + 1e-2f; lo[k] = df * df / den; gr[k] = 2.0f * df / den; break; }
+			case NGP_LOSS_L1: { lo[k] = fabsf(df); gr[k] = copysignf(1.0f, df); break; }
+			case NGP_LOSS_MAPE: { float den = fabsf(p[k]) + 1e-2f; lo[k] = fabsf(df) / den; gr[k] = copysignf(1.0f / den, df); break; }
+			case NGP_LOSS_SMAPE: { float den = 0.5f * (fabsf(p[k]) + fabsf(t[k])) + 1e-2f; lo[k] = fabsf(df) / den; gr[k] = copysignf(1.0f / den, df); break; }
+			case NGP_LOSS_HUBER: {
+				const float alpha = 0.1f;
+				float ad = fabsf(df), sq = 0.5f / alpha * df * df;
+				lo[k] = (ad > alpha ? (ad - 0.5f * alpha) : sq) / 5.0f;
+				gr[k] = (ad > alpha ? (df > 0 ? 1.0f : -1.0f) : (df / alpha)) / 5.0f;
+				break; }
+			case NGP_LOSS_LOGL1: { float dv = fabsf(df) + 1.0f; lo[k] = logf(dv); gr[k] = copysignf(1.0f / dv, df); break; }
+			default: { lo[k] = df * df; gr[k] = 2.0f * df; break; }
+		}
+	}
+	loss = mk3(lo[0], lo[1], lo[2]); grad = mk3(gr[0], gr[1], gr[2]);
+}
+
+} // namespace ngp

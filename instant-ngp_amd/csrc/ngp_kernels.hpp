@@ -1,0 +1,115 @@
+// ngp_kernels.hpp -- internal (non-ABI) declarations shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ngp_hip.h"
+
+namespace ngp {
+
+// Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
+struct TrainCounters {
+	uint32_t rays_per_batch;                        // R of the current/next step (global, all ranks)
+	uint32_t max_inference;                         // K1 sample cap (testbed_nerf.cu:3055-3060)
+	uint32_t numsteps_counter;                      // K1: marched samples (may overshoot max_inference)
+	uint32_t numsteps_counter_compacted;            // K3: compacted samples (may overshoot B)
+	uint32_t ray_counter;                           // K1: rays that produced samples
+	uint32_t n_inference;                           // min(numsteps_counter, max_inference)
+	uint32_t n_valid_compacted;                     // min(numsteps_counter_compacted, B)
+	uint32_t training_step;
+	uint32_t measured_batch_size;
+	uint32_t measured_batch_size_before_compaction;
+	uint32_t n_rays_last;
+	float loss_sum;                                 // sum over rays of mean_loss / n_rays
+	float loss_scalar;
+	uint32_t ema_step;                              // density_grid_ema_step
+	uint64_t total_rays;
+	uint64_t total_samples;
+};
+
+struct K1Args {
+	uint32_t n_rays; const uint32_t* n_rays_ptr;
+	uint32_t rank, world_size;
+	ngp_aabb aabb;
+	uint32_t max_samples; const uint32_t* max_samples_ptr;
+	ngp_pcg32 rng;
+	uint32_t* ray_counter; uint32_t* numsteps_counter;
+	uint32_t* ray_indices_out; ngp_ray* rays_out; uint32_t* numsteps_out; float* coords_out;
+	uint32_t n_images; const ngp_image_meta* metadata; const ngp_xform* xforms;
+	const uint8_t* bitfield; uint32_t max_mip;
+	int snap_to_pixel_centers; float cone_angle_constant;
+};
+
+struct K3Args {
+	uint32_t n_rays; const uint32_t* n_rays_ptr;
+	ngp_aabb aabb; ngp_pcg32 rng;
+	uint32_t max_samples_compacted; const uint32_t* rays_counter;
+	float loss_scale; float background_color[3];
+	int color_space_srgb, random_bg_color, linear_colors;
+	uint32_t n_images; const ngp_image_meta* metadata;
+	const ngp_half* network_output; uint32_t output_stride;
+	uint32_t* numsteps_counter_compacted;
+	const uint32_t* ray_indices_in; const ngp_ray* rays_in; uint32_t* numsteps_inout;
+	const float* coords_in; float* coords_out;
+	ngp_half* dloss_doutput; uint32_t dloss_stride;
+	int loss_type; float* loss_output; // ONE float accumulator (sum over rays)
+	int rgb_activation, density_activation, snap_to_pixel_centers;
+	const float* mean_density_ptr; float near_distance;
+};
+
+void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
+void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
+void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride);
+void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
+void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, const uint32_t* step_ptr, uint32_t step, ngp_aabb box, const float* grid_in,
+	float* pos, uint32_t* idx, uint32_t n_cascades, float thresh);
+void launch_splat_grid_samples(hipStream_t s, uint32_t n, const uint32_t* idx, const ngp_half* out, uint32_t stride, float* grid, int act);
+void launch_ema_grid_samples(hipStream_t s, uint32_t n, float decay, float* grid_out, const float* grid_in);
+void launch_grid_mean(hipStream_t s, const float* grid, float* partial256, float* mean_out);
+void launch_grid_to_bitfield(hipStream_t s, const float* grid, uint32_t max_cascade, uint8_t* bitfield, const float* mean_ptr);
+void launch_update_counters(hipStream_t s, TrainCounters* c, uint32_t B);
+void launch_clamp_compacted(hipStream_t s, TrainCounters* c, uint32_t B);
+
+// ---- model (model_kernels.hip) ----------------------------------------------------------------
+constexpr uint32_t MAX_LEVELS = 16;
+struct GridMeta {           // per-level constants, passed by value to kernels
+	uint32_t n_levels, F;
+	uint32_t offset[MAX_LEVELS + 1]; // entries
+	uint32_t hashmap_size[MAX_LEVELS];
+	uint32_t resolution[MAX_LEVELS];
+	float scale[MAX_LEVELS];
+};
+
+// MFMA-fragment-ordered copies of the MLP weights (see model_kernels.hip header).
+constexpr uint32_t N_FW_FRAGS = 24;  // forward A-fragments: 4 + 4 + 4 + 8 + 4
+constexpr uint32_t N_BW_FRAGS = 20;  // dgrad A-fragments:   4 + 2 + 4 + 8 + 2
+constexpr uint32_t FRAG_HALFS = 64 * 8;
+
+struct ModelPtrs {
+	const ngp_half* grid;       // hash table (params or inference params)
+	const ngp_half* fw_frags;   // N_FW_FRAGS * 512 halfs
+	const ngp_half* bw_frags;   // N_BW_FRAGS * 512 halfs
+};
+
+void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
+	ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset);
+void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out);
+void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw);
+uint32_t wgrad_n_partials();
+
+void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
+	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
+void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad);
+
+struct AdamArgs {
+	uint64_t n_params, n_mlp;
+	float loss_scale, lr, beta1, beta2, eps, l2_reg;
+	int optimize_matrix, optimize_non_matrix;
+	float ema_decay, ema_debias_old, ema_debias_new;
+	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
+	float* m; float* v; uint32_t* steps; float* ema;
+	const uint32_t* fw_perm; const uint32_t* bw_perm; // n_mlp-entry scatter tables into the fragment buffers (0xFFFFFFFF = none)
+	ngp_half* fw_frags; ngp_half* bw_frags; ngp_half* fw_frags_inf; 
+};
+void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
+
+} // namespace ngp

@@ -1,0 +1,215 @@
+"""GPU parity: ray-march / loss / occupancy-grid kernels (through the C-ABI) vs the CPU oracle.
+
+Bars: integer / index outputs bit-exact (ray indices, sample counts, occupancy bitfield, grid sample cell indices);
+sample coordinates bit-exact (both sides are un-contracted IEEE fp32; cone_angle = 0 => no transcendental in the march);
+float results that go through expf/powf (compositing, sRGB) within 1e-5 relative / half-ulp tolerances stated inline.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ngp_abi as A
+from common import device_meta, dptr, half_to_f32, host_meta, make_small_dataset, ptr
+
+pytestmark = pytest.mark.gpu
+
+N_CELLS = 128 ** 3
+
+
+def _bitfield_from_dataset(ora, M, X, n_img, density=None):
+    """occupancy state to march through: cells seen by a camera, thinned pseudo-randomly so rays hit empty space"""
+    grid = np.zeros(N_CELLS, dtype=np.float32)
+    ora.ora_k_mark_untrained_density_grid(N_CELLS, ptr(grid), n_img, M, X, 1)
+    rng = np.random.default_rng(3)
+    # blobs of occupancy: coarse 16^3 random mask upsampled (in Morton space contiguous runs of 512 cells)
+    mask = (rng.uniform(size=N_CELLS // 512) < 0.35).repeat(512)
+    grid = np.where((grid >= 0) & mask, 0.05, grid).astype(np.float32)
+    bf = np.zeros(N_CELLS // 8 * 8, dtype=np.uint8)
+    mean = ora.ora_k_density_grid_mean(ptr(grid))
+    ora.ora_k_grid_to_bitfield(ptr(grid), 0, ptr(bf), C.c_float(mean))
+    return grid, bf, mean
+
+
+def _rng(ora, seed=1337):
+    s = A.Pcg32()
+    ora.ora_pcg32_seed(C.byref(s), C.c_uint64(seed), C.c_uint64(1))
+    return s
+
+
+@pytest.fixture(scope="module")
+def scene(ora):
+    imgs, xforms, meta = make_small_dataset(6, 48)
+    M, X = host_meta(imgs, xforms, meta)
+    grid, bf, mean = _bitfield_from_dataset(ora, M, X, len(imgs))
+    return dict(imgs=imgs, xforms=xforms, meta=meta, M=M, X=X, grid=grid, bf=bf, mean=mean)
+
+
+def _run_k1(ora, hip, scene, n_rays, max_samples, rank=0, world=1):
+    import torch
+    aabb = A.scene_aabb(1)
+    rng = _rng(ora)
+    n_img = len(scene["imgs"])
+    # oracle
+    o = dict(ray_counter=C.c_uint32(), numsteps_counter=C.c_uint32(), ray_indices=np.zeros(n_rays, np.uint32), rays=np.zeros((n_rays, 6), np.float32),
+             numsteps=np.zeros((n_rays, 2), np.uint32), coords=np.zeros((max_samples, 7), np.float32))
+    rb, re = n_rays * rank // world, n_rays * (rank + 1) // world
+    ora.ora_k_generate_training_samples(n_rays, rb, re, aabb, max_samples, rng, C.byref(o["ray_counter"]), C.byref(o["numsteps_counter"]), ptr(o["ray_indices"]),
+                                        ptr(o["rays"]), ptr(o["numsteps"]), ptr(o["coords"]), n_img, scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, C.c_float(0.0))
+    # device
+    dev_imgs, Mh, Xh, Md, Xd = device_meta(scene["imgs"], scene["xforms"], scene["meta"], torch)
+    bfd = torch.from_numpy(scene["bf"]).cuda()
+    d = dict(counters=torch.zeros(2, dtype=torch.int32, device="cuda"), ray_indices=torch.zeros(n_rays, dtype=torch.int32, device="cuda"),
+             rays=torch.zeros((n_rays, 6), dtype=torch.float32, device="cuda"), numsteps=torch.zeros((n_rays, 2), dtype=torch.int32, device="cuda"),
+             coords=torch.zeros((max_samples, 7), dtype=torch.float32, device="cuda"), keep=(dev_imgs, Md, Xd, bfd))
+    A.check(hip, hip.ngp_k_generate_training_samples(None, n_rays, rank, world, None, aabb, max_samples, None, rng, dptr(d["counters"][0:1]), dptr(d["counters"][1:2]),
+                                                    dptr(d["ray_indices"]), dptr(d["rays"]), dptr(d["numsteps"]), dptr(d["coords"]), n_img, dptr(Md), dptr(Xd),
+                                                    dptr(bfd), 0, 1, C.c_float(0.0)))
+    torch.cuda.synchronize()
+    return o, d
+
+
+@pytest.mark.parametrize("n_rays,rank,world", [(4096, 0, 1), (1000, 0, 1), (4096, 1, 2)])
+def test_k1_sample_generation_bit_exact(ora, hip, scene, n_rays, rank, world):
+    max_samples = 1 << 20
+    o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+    n_o = o["ray_counter"].value
+    cnt = d["counters"].cpu().numpy().astype(np.uint32)
+    assert n_o > 0 and cnt[0] == n_o and cnt[1] == o["numsteps_counter"].value
+    ri = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_o]
+    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_o]
+    rays = d["rays"].cpu().numpy()[:n_o]
+    coords = d["coords"].cpu().numpy()
+    # device order of rays is wave-scheduling dependent: match by global ray index
+    order_d = np.argsort(ri); order_o = np.argsort(o["ray_indices"][:n_o])
+    assert np.array_equal(ri[order_d], o["ray_indices"][:n_o][order_o])
+    assert np.array_equal(ns[order_d, 0], o["numsteps"][:n_o][order_o, 0])
+    assert np.array_equal(rays[order_d].view(np.uint32), o["rays"][:n_o][order_o].view(np.uint32))
+    # spans are disjoint and cover [0, total)
+    spans = sorted((int(b), int(b + k)) for k, b in ns)
+    assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1)) and spans[-1][1] == cnt[1]
+    for a, b in zip(order_d, order_o):
+        k, bd = int(ns[a, 0]), int(ns[a, 1]); bo = int(o["numsteps"][b, 1])
+        assert np.array_equal(coords[bd:bd + k].view(np.uint32), o["coords"][bo:bo + k].view(np.uint32))
+
+
+def test_k1_sample_cap(ora, hip, scene):
+    """rays whose span would exceed max_samples are dropped (testbed_nerf.cu:813-815); which ones is order dependent"""
+    o, d = _run_k1(ora, hip, scene, 4096, 20000)
+    cnt = d["counters"].cpu().numpy().astype(np.uint32)
+    assert cnt[1] == o["numsteps_counter"].value  # the counter still counts every marched sample
+    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:cnt[0]]
+    assert (ns[:, 0] + ns[:, 1] <= 20000).all() and cnt[0] < o["ray_counter"].value + 200
+
+
+def test_k3_loss_and_compaction(ora, hip, scene):
+    import torch
+    n_rays, max_samples, B = 2048, 1 << 19, 1 << 14
+    o, d = _run_k1(ora, hip, scene, n_rays, max_samples)
+    n_act = o["ray_counter"].value
+    total = o["numsteps_counter"].value
+    rngs = np.random.default_rng(1)
+    net = np.zeros((max_samples, 4), np.float16)
+    net[:total, :3] = rngs.normal(0, 1.5, (total, 3)); net[:total, 3] = rngs.normal(-1.0, 2.5, total)
+    net_u = net.view(np.uint16)
+    aabb = A.scene_aabb(1); rng = _rng(ora); n_img = len(scene["imgs"])
+    bg = (C.c_float * 3)(0, 0, 0)
+    # oracle runs on ITS ray order; the device on its own. Compare per ray (matched by ray index).
+    o_ns = o["numsteps"].copy(); o_cc = np.zeros((B, 7), np.float32); o_dl = np.zeros((B, 4), np.uint16); o_loss = np.zeros(n_rays, np.float32); o_cnt = C.c_uint32()
+    ora.ora_k_compute_loss(n_rays, n_act, aabb, rng, B, C.c_float(128.0), bg, 0, 1, 0, n_img, scene["M"], ptr(net_u), 4, C.byref(o_cnt), ptr(o["ray_indices"]), ptr(o["rays"]),
+                           ptr(o_ns), ptr(o["coords"]), ptr(o_cc), ptr(o_dl), 4, A.LOSS_HUBER, ptr(o_loss), A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, C.c_float(scene["mean"]), C.c_float(0.1))
+    # device: network outputs must be laid out by the DEVICE's sample order -> permute per ray
+    ri_d = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_act]; ns_d = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_act]
+    pos_o = {int(r): i for i, r in enumerate(o["ray_indices"][:n_act])}
+    net_d = np.zeros_like(net_u)
+    for i in range(n_act):
+        j = pos_o[int(ri_d[i])]
+        k, bd, bo = int(ns_d[i, 0]), int(ns_d[i, 1]), int(o["numsteps"][j, 1])
+        net_d[bd:bd + k] = net_u[bo:bo + k]
+    netd = torch.from_numpy(net_d.view(np.int16)).cuda()
+    cc = torch.zeros((B, 7), dtype=torch.float32, device="cuda"); dl = torch.zeros((B, 4), dtype=torch.int16, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda"); loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+    mean = torch.tensor([scene["mean"]], dtype=torch.float32, device="cuda")
+    dev_imgs, Md = d["keep"][0], d["keep"][1]
+    A.check(hip, hip.ngp_k_compute_loss(None, n_rays, None, aabb, rng, B, dptr(d["counters"][0:1]), C.c_float(128.0), bg, 0, 1, 0, n_img, dptr(Md), dptr(netd), 4, dptr(cnt),
+                                       dptr(d["ray_indices"]), dptr(d["rays"]), dptr(d["numsteps"]), dptr(d["coords"]), dptr(cc), dptr(dl), 4, A.LOSS_HUBER, dptr(loss),
+                                       A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
+    torch.cuda.synchronize()
+    assert int(cnt.cpu()[0]) == o_cnt.value  # compacted sample count: integer-exact (early-out T < 1e-4 is far from ties here)
+    ns_d2 = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_act]
+    cc_h = cc.cpu().numpy(); dl_h = dl.cpu().numpy().view(np.uint16)
+    n_cmp = 0
+    for i in range(n_act):
+        j = pos_o[int(ri_d[i])]
+        kd, bd = int(ns_d2[i, 0]), int(ns_d2[i, 1]); ko, bo = int(o_ns[j, 0]), int(o_ns[j, 1])
+        if bd + kd >= B or bo + ko >= B:
+            continue  # clamped at the batch end: which ray gets clamped is order dependent
+        assert kd == ko
+        assert np.array_equal(cc_h[bd:bd + kd].view(np.uint32), o_cc[bo:bo + ko].view(np.uint32))  # compacted coords: copies
+        a, b = half_to_f32(dl_h[bd:bd + kd]), half_to_f32(o_dl[bo:bo + ko])
+        # __expf / powf differ from glibc in the last ulps; dL/doutput is a half: allow 2 half-ulps relative + tiny abs
+        assert np.allclose(a, b, rtol=4e-3, atol=2e-6), (i, np.abs(a - b).max())
+        n_cmp += kd
+    assert n_cmp > 1000
+    assert abs(float(loss.cpu()[0]) - float(o_loss.sum())) <= 1e-4 * abs(float(o_loss.sum())) + 1e-7
+
+
+def test_fill_rollover(ora, hip):
+    import torch
+    B, n_in = 4096, 1000
+    rng = np.random.default_rng(0)
+    coords = rng.uniform(size=(B, 7)).astype(np.float32); dl = rng.normal(size=(B, 4)).astype(np.float16).view(np.uint16)
+    c_o, d_o = coords.copy(), dl.copy()
+    ora.ora_k_fill_rollover(B, n_in, ptr(c_o), 7, ptr(d_o), 4)
+    cd = torch.from_numpy(coords).cuda(); dd = torch.from_numpy(dl.view(np.int16)).cuda(); nd = torch.tensor([n_in], dtype=torch.int32, device="cuda")
+    A.check(hip, hip.ngp_k_fill_rollover(None, B, dptr(nd), dptr(cd), 7, dptr(dd), 4))
+    torch.cuda.synchronize()
+    assert np.array_equal(cd.cpu().numpy().view(np.uint32), c_o.view(np.uint32))
+    assert np.array_equal(dd.cpu().numpy().view(np.uint16), d_o)
+
+
+def test_occupancy_grid_chain_bit_exact(ora, hip, scene):
+    import torch
+    n_img = len(scene["imgs"])
+    dev_imgs, Mh, Xh, Md, Xd = device_meta(scene["imgs"], scene["xforms"], scene["meta"], torch)
+    # mark_untrained: float results are exactly 0 / -1
+    g_o = np.full(N_CELLS, 0.5, np.float32)
+    ora.ora_k_mark_untrained_density_grid(N_CELLS, ptr(g_o), n_img, scene["M"], scene["X"], 1)
+    g_d = torch.full((N_CELLS,), 0.5, dtype=torch.float32, device="cuda")
+    A.check(hip, hip.ngp_k_mark_untrained_density_grid(None, N_CELLS, dptr(g_d), n_img, dptr(Md), dptr(Xd), 1))
+    torch.cuda.synchronize()
+    mism = int((g_d.cpu().numpy() != g_o).sum())
+    assert mism <= 8, mism  # projections within 1e-3 of the image border may flip (powf-free, but normalize/div rounding is identical -> expect 0)
+    # grid sample generation: cell indices and positions bit-exact
+    aabb = A.scene_aabb(1); rng = _rng(ora, 4242); n = 200000
+    pos_o = np.zeros((n, 3), np.float32); idx_o = np.zeros(n, np.uint32)
+    ora.ora_k_generate_grid_samples(n, rng, 7, aabb, ptr(scene["grid"]), ptr(pos_o), ptr(idx_o), 1, C.c_float(0.01))
+    gd = torch.from_numpy(scene["grid"]).cuda(); pos_d = torch.zeros((n, 3), dtype=torch.float32, device="cuda"); idx_d = torch.zeros(n, dtype=torch.int32, device="cuda")
+    A.check(hip, hip.ngp_k_generate_grid_samples(None, n, rng, 7, aabb, dptr(gd), dptr(pos_d), dptr(idx_d), 1, C.c_float(0.01)))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx_d.cpu().numpy().astype(np.uint32), idx_o)
+    assert np.array_equal(pos_d.cpu().numpy().view(np.uint32), pos_o.view(np.uint32))
+    # splat (atomicMax) + ema + mean + bitfield + max-pool
+    rs = np.random.default_rng(2)
+    net = rs.normal(-2, 3, n).astype(np.float16).view(np.uint16)
+    tmp_o = np.zeros(N_CELLS, np.float32)
+    ora.ora_k_splat_grid_samples(n, ptr(idx_o), ptr(net), 1, ptr(tmp_o), A.ACT_EXPONENTIAL)
+    tmp_d = torch.zeros(N_CELLS, dtype=torch.float32, device="cuda"); netd = torch.from_numpy(net.view(np.int16)).cuda()
+    A.check(hip, hip.ngp_k_splat_grid_samples(None, n, dptr(idx_d), dptr(netd), 1, dptr(tmp_d), A.ACT_EXPONENTIAL))
+    torch.cuda.synchronize()
+    assert np.allclose(tmp_d.cpu().numpy(), tmp_o, rtol=1e-5, atol=0)  # expf: device vs glibc, <= 2 ulp
+    grid_o = scene["grid"].copy(); ora.ora_k_ema_grid_samples(N_CELLS, C.c_float(0.95), ptr(grid_o), ptr(tmp_o))
+    grid_d = torch.from_numpy(scene["grid"]).cuda(); tmp_same = torch.from_numpy(tmp_o).cuda()
+    A.check(hip, hip.ngp_k_ema_grid_samples(None, N_CELLS, C.c_float(0.95), dptr(grid_d), dptr(tmp_same)))
+    torch.cuda.synchronize()
+    assert np.array_equal(grid_d.cpu().numpy().view(np.uint32), grid_o.view(np.uint32))
+    bf_d = torch.zeros(N_CELLS, dtype=torch.uint8, device="cuda"); mean_d = torch.zeros(1, dtype=torch.float32, device="cuda")
+    A.check(hip, hip.ngp_k_update_mean_and_bitfield(None, dptr(grid_d), 0, dptr(bf_d), dptr(mean_d)))
+    torch.cuda.synchronize()
+    mean_o = ora.ora_k_density_grid_mean(ptr(grid_o))
+    assert abs(float(mean_d.cpu()[0]) - mean_o) <= 2e-6 * abs(mean_o)
+    # bit-exact bitfield given the SAME threshold (the device's own mean)
+    bf_o = np.zeros(N_CELLS, np.uint8)
+    ora.ora_k_grid_to_bitfield(ptr(grid_o), 0, ptr(bf_o), C.c_float(float(mean_d.cpu()[0])))
+    assert np.array_equal(bf_d.cpu().numpy(), bf_o)
+    assert bf_o[N_CELLS // 8:].any()  # the coarser cascades are populated by the max-pool

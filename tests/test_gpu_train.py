@@ -1,0 +1,68 @@
+"""GPU end-to-end: the on-device training loop (no host sync) trains the synthetic scene; loss decreases, counters behave
+like NerfCounters, and the first steps track the CPU oracle's trainer (same seed, same dataset)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ngp_abi as A
+from common import HipModel, OraModel, host_meta, make_small_dataset, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(ora, hip, B, n_images=8, res=64, rays0=0):
+    imgs, xforms, meta = make_small_dataset(n_images, res)
+    M, X = host_meta(imgs, xforms, meta)
+    cfg = A.base_model_config(1)
+    opts = A.default_nerf_options(1, target_batch_size=B)
+    aabb = A.scene_aabb(1)
+    hm = HipModel(hip, cfg)
+    t = C.c_void_p()
+    A.check(hip, hip.ngp_nerf_create(hm.h, C.byref(opts), aabb, C.byref(t)))
+    pix = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+    A.check(hip, hip.ngp_nerf_set_dataset_host(t, len(imgs), M, X, pix))
+    om = OraModel(ora, cfg)
+    ot = C.c_void_p()
+    assert ora.ora_nerf_create(om.h, C.byref(opts), aabb, C.byref(ot)) == 0
+    ora.ora_nerf_set_dataset(ot, len(imgs), M, X)
+    if rays0:
+        # start in a regime where neither K1's sample cap nor K3's batch clamp drops rays (both are order dependent)
+        A.check(hip, hip.ngp_nerf_set_rays_per_batch(t, rays0)); ora.ora_nerf_set_rays_per_batch(ot, rays0)
+    return dict(hm=hm, t=t, om=om, ot=ot, keep=(imgs, M, X, pix), opts=opts)
+
+
+def _stats(hip, t):
+    s = A.NerfStats()
+    A.check(hip, hip.ngp_nerf_get_stats(t, None, C.byref(s)))
+    return s
+
+
+def test_training_loop_tracks_oracle(ora, hip):
+    B = 1 << 17
+    s = _make(ora, hip, B, rays0=256)
+    for step in range(1, 5):
+        A.check(hip, hip.ngp_nerf_train(s["t"], None, 1))
+        assert ora.ora_nerf_train(s["ot"], 1) == 0, ora.ora_last_error()
+        hs = _stats(hip, s["t"]); os_ = A.NerfStats(); ora.ora_nerf_get_stats(s["ot"], C.byref(os_))
+        assert hs.training_step == os_.training_step == step
+        # sample counts come from integer-exact marching through (nearly) the same occupancy grid
+        assert abs(int(hs.measured_batch_size_before_compaction) - int(os_.measured_batch_size_before_compaction)) <= 0.02 * os_.measured_batch_size_before_compaction + 64
+        assert abs(int(hs.measured_batch_size) - int(os_.measured_batch_size)) <= 0.03 * os_.measured_batch_size + 64
+        assert abs(int(hs.rays_per_batch) - int(os_.rays_per_batch)) <= 0.05 * os_.rays_per_batch + 256
+        assert abs(hs.loss - os_.loss) <= 0.05 * abs(os_.loss) + 1e-5, (step, hs.loss, os_.loss)
+    hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
+
+
+def test_training_converges(hip, ora):
+    B = 1 << 16
+    s = _make(ora, hip, B, n_images=12, res=96)
+    A.check(hip, hip.ngp_nerf_train(s["t"], None, 16))
+    l0 = _stats(hip, s["t"]).loss
+    A.check(hip, hip.ngp_nerf_train(s["t"], None, 300))
+    st = _stats(hip, s["t"])
+    assert st.training_step == 316
+    assert np.isfinite(st.loss) and st.loss < 0.5 * l0, (l0, st.loss)
+    assert 0 < st.measured_batch_size <= B * 1.5
+    assert st.rays_per_batch % 256 == 0 and st.rays_per_batch > 4096  # the grid got sparser -> more rays per batch
+    hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
