@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- NeRF training throughput of the MI355X hot path (BASELINE.json: training rays/sec on lego, B = 2^18).
+
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run (one rank per GPU, RCCL).
+A "step" = one Testbed::train(batch) call: occupancy-grid prep at the reference's cadence + K1..K6 (full optimizer step).
+Data: synthetic stand-in for nerf_synthetic/lego (100 views 800x800 RGBA8, same cameras/format; the real set is not
+shipped and there is no network).  Before the W warm-up steps the model is trained for --pretrain steps (untimed setup),
+because rays/step adapts to the occupancy grid: at initialisation one step marches ~500 rays, in steady state tens of
+thousands -- the steady state is the regime the metric is quoted on.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "instant-ngp_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+import ngp_abi as A
+
+# algorithmic bytes per unit, SURVEY.md 8(d) / DESIGN.md "roofline accounting"
+BYTES_PER_SAMPLE_FWD = 28 + 512 + 8          # coords + 8 levels x 8 corners x 8 B gather + rgbsigma half4
+BYTES_PER_SAMPLE_T1 = 28 + 512 + 8 + 1024    # forward gather + dL/dy + scatter as read-modify-write
+BYTES_PER_PARAM_OPT = 38
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
+
+
+class CudaView:
+    """zero-copy torch view of library-owned device memory (for the RCCL all-reduce of gradients / counters)"""
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pretrain", type=int, default=1000, help="untimed training steps that bring the occupancy grid to steady state")
+    ap.add_argument("--images", type=int, default=100)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--batch", type=int, default=1 << 18)
+    ap.add_argument("--profile-steps", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
+
+    lib = A.load_hip()  # raises if libngp_hip.so is missing: no CPU fallback on the product path
+    assert lib.ngp_device_available() == 1
+
+    import synth_scene
+    images, xforms, meta, _ = synth_scene.make_dataset(args.images, args.res, "cuda")
+    n_img = len(images)
+    M = (A.ImageMeta * n_img)(); X = (A.Xform * n_img)()
+    for i in range(n_img):
+        M[i].pixels = images[i].data_ptr(); M[i].image_data_type = A.IMAGE_BYTE; M[i].lens_mode = A.LENS_PERSPECTIVE
+        M[i].resolution[0], M[i].resolution[1] = meta["resolution"]
+        M[i].principal_point[0] = M[i].principal_point[1] = 0.5
+        M[i].focal_length[0], M[i].focal_length[1] = meta["focal_length"]
+        for k in range(12):
+            X[i].start[k] = X[i].end[k] = float(xforms[i][k])
+
+    cfg = A.base_model_config(1)
+    model = C.c_void_p()
+    A.check(lib, lib.ngp_model_create(C.byref(cfg), C.c_uint64(1337), C.byref(model)))
+    opts = A.default_nerf_options(1, target_batch_size=args.batch, rank=rank, world_size=world)
+    nerf = C.c_void_p()
+    A.check(lib, lib.ngp_nerf_create(model, C.byref(opts), A.scene_aabb(1), C.byref(nerf)))
+    A.check(lib, lib.ngp_nerf_set_dataset_device(nerf, n_img, M, X))
+    n_params, n_mlp = C.c_uint64(), C.c_uint64()
+    lib.ngp_model_n_params(model, C.byref(n_params), C.byref(n_mlp))
+
+    grad_view = cnt_view = None
+    if world > 1:
+        g = C.c_void_p(); lib.ngp_model_param_ptrs(model, None, None, None, C.byref(g))
+        grad_view = torch.as_tensor(CudaView(g.value, n_params.value, "<f2"), device="cuda")
+        cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(nerf, C.byref(cp))
+        cnt_view = torch.as_tensor(CudaView(cp.value, 2, "<i4"), device="cuda")
+
+    def step(n=1):
+        if world == 1:
+            A.check(lib, lib.ngp_nerf_train(nerf, None, n))
+            return
+        for _ in range(n):
+            A.check(lib, lib.ngp_nerf_train_prep(nerf, None))
+            A.check(lib, lib.ngp_nerf_train_forward_backward(nerf, None))
+            dist.all_reduce(grad_view)   # RCCL sum of hash-grid + MLP gradients (fp16, 23.4 MB) over xGMI
+            dist.all_reduce(cnt_view)    # two uint32 so that every rank derives the same next rays_per_batch
+            A.check(lib, lib.ngp_nerf_train_finish(nerf, None))
+
+    def stats():
+        s = A.NerfStats()
+        A.check(lib, lib.ngp_nerf_get_stats(nerf, None, C.byref(s)))
+        return s
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    step(args.pretrain)
+    step(args.warmup)
+    barrier()
+    s0 = stats()
+    t0 = time.perf_counter()
+    step(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        dist.barrier()
+    s1 = stats()
+    rays = s1.total_rays - s0.total_rays                # global rays launched over the K steps (all ranks)
+    samples = (s1.total_samples - s0.total_samples) * world
+    value = rays / elapsed
+
+    # ---- roofline leg: per-kernel HIP-event timing over further (untimed) steps --------------------------------
+    lib.ngp_profile_enable(1)
+    s2 = stats()
+    step(args.profile_steps)
+    npf = lib.ngp_profile_count()
+    ms = (C.c_double * npf)(); cnt = (C.c_uint64 * npf)()
+    lib.ngp_profile_read(ms, cnt)
+    lib.ngp_profile_enable(0)
+    s3 = stats()
+    lib.ngp_profile_name.restype = C.c_char_p
+    kern = {lib.ngp_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(npf) if cnt[i]}
+    n_inf_avg = s3.measured_batch_size_before_compaction  # last step's marched samples (steady state)
+    per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd": BYTES_PER_SAMPLE_T1 * args.batch,
+                        "k_optimizer": BYTES_PER_PARAM_OPT * n_params.value}
+    dominant = max((k for k in kern if k in per_launch_bytes), key=lambda k: kern[k][0])
+    avg_ms = kern[dominant][0] / kern[dominant][1]
+    achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
+                "kernel_ms_per_step": {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
+
+    # ---- CPU baseline: the oracle (port) runs ONE bounded step from the same trained state --------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(lib, model, nerf, cfg, opts, images, M, X, n_img, s3, args)
+
+    if rank == 0:
+        out = {
+            "metric": "training rays/sec on nerf_synthetic/lego-format scene, configs/nerf/base.json, B=2^18 samples/step",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "NeRF nerf_synthetic/lego-format synthetic scene (100 views 800x800 RGBA8), configs/nerf/base.json (hash L=8 F=4 T=2^19, MLP 64), "
+                                   "batch 2^18 samples per GPU per step, rays/step adaptive (cap 2^18)", "parallelism": f"dp{world}",
+                       "pretrain_steps": args.pretrain, "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
+                       "samples_per_ray_compacted": samples / max(rays, 1), "loss": s1.loss,
+                       "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(lib, model, nerf, cfg, opts, images, M, X, n_img, st, args):
+    """Time the CPU oracle (a port: the reference has no CPU path) on a bounded sample of the same workload:
+    one training step at B_cpu = 2^15 samples starting from the GPU's trained parameters and occupancy grid."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from common import OraModel, ptr
+    ora = oracle_py.load()
+    B_cpu = 1 << 15
+    om = OraModel(ora, cfg)
+    p = np.empty(om.n, dtype=np.float32)
+    A.check(lib, lib.ngp_model_get_params_host(model, ptr(p), C.c_uint64(p.size)))
+    om.params_fp[:] = p
+    ora.ora_model_sync_half(om.h)
+    o2 = A.default_nerf_options(1, target_batch_size=B_cpu)
+    ot = C.c_void_p()
+    assert ora.ora_nerf_create(om.h, C.byref(o2), A.scene_aabb(1), C.byref(ot)) == 0
+    host_imgs = [im.cpu().numpy() for im in images]
+    Mh = (A.ImageMeta * n_img)()
+    for i in range(n_img):
+        C.memmove(C.byref(Mh[i]), C.byref(M[i]), C.sizeof(A.ImageMeta))
+        Mh[i].pixels = host_imgs[i].ctypes.data
+    ora.ora_nerf_set_dataset(ot, n_img, Mh, X)
+    gp = C.c_void_p(); lib.ngp_nerf_density_grid_ptrs(nerf, C.byref(gp), None, None)
+    grid = torch.as_tensor(CudaView(gp.value, 128 ** 3, "<f4"), device="cuda").cpu().numpy()
+    C.memmove(ora.ora_nerf_density_grid(ot), grid.ctypes.data, grid.nbytes)
+    ora.ora_nerf_update_mean_and_bitfield(ot)
+    rays_cpu = max(256, int(st.rays_per_batch * B_cpu / args.batch) // 256 * 256)
+    ora.ora_nerf_set_rays_per_batch(ot, rays_cpu)
+    t0 = time.perf_counter()
+    assert ora.ora_nerf_train_forward_backward(ot) == 0
+    assert ora.ora_nerf_train_finish(ot) == 0
+    dt = time.perf_counter() - t0
+    s = A.NerfStats(); ora.ora_nerf_get_stats(ot, C.byref(s))
+    ora.ora_nerf_destroy(ot)
+    return {"value": rays_cpu / dt, "unit": "rays/s", "cores": int(ora.ora_num_threads()), "kind": "port",
+            "sample": f"1 training step (K1..K6, occupancy prep excluded) at B=2^15 samples, {rays_cpu} rays, {s.measured_batch_size} compacted samples, "
+                      f"from the GPU's trained state; OpenMP over {ora.ora_num_threads()} threads; {dt:.2f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -291,6 +291,15 @@ typedef struct ngp_render_params {
 int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_host,
                     float* frame_buffer, float* depth_buffer);
 
+/* ------------------------------------------------------------------ profiling ------------ */
+/* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
+ * enable(1) clears the accumulators; read() synchronises the pending events and returns, per kernel
+ * class i < ngp_profile_count(), the summed milliseconds and the number of timed launches. */
+int ngp_profile_enable(int on);
+int ngp_profile_count(void);
+const char* ngp_profile_name(int i);
+int ngp_profile_read(double* ms_sum_host, uint64_t* launches_host);
+
 /* ------------------------------------------------------------------ test hooks ----------- */
 /* Not part of the reference's API surface: expose intermediate state to the parity tests. */
 int ngp_model_encode(ngp_model*, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out32);

@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) k_encode_only(const GridMeta* __restrict_
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			const int f = 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3);
-			out[(size_t)s_raw * 32 + f] = __builtin_bit_cast(__half, e[s][j]);
+			((_Float16*)out)[(size_t)s_raw * 32 + f] = e[s][j];
 		}
 }
 
@@ -824,12 +824,16 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 }
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash) {
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
 	hipLaunchKernelGGL((k_train_fwd_bwd<1>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
 		(__half*)grid_grad, (uint4*)enc_stash);
+}
+void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
+		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {
+	if (n == 0) return;
 	const uint32_t lds = (N_FW_FRAGS + N_BW_FRAGS) * 1024;
 	hipLaunchKernelGGL(k_wgrad, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
 }

@@ -27,6 +27,53 @@ extern "C" int ngp_device_available(void) {
 	return n > 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// optional per-kernel timing with HIP events recorded on the launch stream (off by default)
+// ------------------------------------------------------------------------------------------------
+struct ProfEntry { int id; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+static double g_prof_ms[P_COUNT]; static uint64_t g_prof_n[P_COUNT];
+static const char* kProfNames[P_COUNT] = {"k_generate_training_samples", "k_inference", "k_compute_loss", "k_fill_rollover", "k_train_fwd_bwd", "k_wgrad",
+	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters"};
+static hipEvent_t prof_event() {
+	if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+	hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+	int idx = -1; hipStream_t s;
+	ProfScope(int id, hipStream_t st) : s(st) {
+		if (!g_prof_on) return;
+		ProfEntry e; e.id = id; e.a = prof_event(); e.b = prof_event();
+		(void)hipEventRecord(e.a, s);
+		g_prof.push_back(e); idx = (int)g_prof.size() - 1;
+	}
+	~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s); }
+};
+static void prof_collect() {
+	for (auto& e : g_prof) {
+		(void)hipEventSynchronize(e.b);
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { g_prof_ms[e.id] += ms; g_prof_n[e.id] += 1; }
+		g_event_pool.push_back(e.a); g_event_pool.push_back(e.b);
+	}
+	g_prof.clear();
+}
+extern "C" int ngp_profile_enable(int on) {
+	prof_collect();
+	g_prof_on = on != 0;
+	if (on) { for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; } }
+	return 0;
+}
+extern "C" int ngp_profile_count(void) { return P_COUNT; }
+extern "C" const char* ngp_profile_name(int i) { return (i >= 0 && i < P_COUNT) ? kProfNames[i] : ""; }
+extern "C" int ngp_profile_read(double* ms_sum, uint64_t* launches) {
+	prof_collect();
+	for (int i = 0; i < P_COUNT; ++i) { ms_sum[i] = g_prof_ms[i]; launches[i] = g_prof_n[i]; }
+	return 0;
+}
+
 template <typename T> static int dev_alloc(T** p, size_t n) { HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T))); return 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,13 +303,15 @@ static ModelPtrs model_ptrs(const ngp_model* m, bool inference) {
 extern "C" int ngp_model_inference(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
 		ngp_half* out, uint32_t out_stride, int use_inference_params) {
 	REQUIRE(in_stride >= 7 && out_stride >= 4 && out_stride % 4 == 0, "inference: in_stride >= 7, out_stride a multiple of 4 halfs");
-	launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), in, in_stride, n_max, n_ptr, out, out_stride, false, 4);
+	{ ProfScope ps(P_K2_INFERENCE, (hipStream_t)stream);
+	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), in, in_stride, n_max, n_ptr, out, out_stride, false, 4); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 extern "C" int ngp_model_density(ngp_model* m, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out, uint32_t out_stride, int use_inference_params) {
 	REQUIRE(pos_stride >= 3 && out_stride >= 1, "density: bad strides");
-	launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), pos, pos_stride, n, nullptr, out, out_stride, true, 0);
+	{ ProfScope ps(P_GRID_DENSITY, (hipStream_t)stream);
+	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), pos, pos_stride, n, nullptr, out, out_stride, true, 0); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -285,9 +334,10 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		m->stash_halfs = need;
 	}
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
-	HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s));
-	launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, m->wgrad_partials, m->n_partials);
-	launch_wgrad_reduce(s, m->wgrad_partials, m->n_partials, m->grads);
+	{ ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
+	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash); }
+	{ ProfScope ps(P_W_WGRAD, s); launch_wgrad(s, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
+	{ ProfScope ps(P_WGRAD_REDUCE, s); launch_wgrad_reduce(s, m->wgrad_partials, m->n_partials, m->grads); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -305,7 +355,7 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	a.master = m->master; a.params = m->params; a.params_inf = m->params_inf; a.grads = m->grads;
 	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema;
 	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
-	launch_optimizer_step((hipStream_t)stream, a);
+	{ ProfScope ps(P_OPTIMIZER, (hipStream_t)stream); launch_optimizer_step((hipStream_t)stream, a); }
 	HIPCHK(hipGetLastError());
 	// ExponentialDecay::step [tcnn]
 	if (m->cfg.decay_interval > 0 && m->step >= m->cfg.decay_start && m->step % m->cfg.decay_interval == 0) m->lr *= m->cfg.decay_base;
@@ -544,6 +594,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 		t->ema_step = 0;
 		launch_mark_untrained(s, n_elements, t->density_grid, t->n_images, t->meta_dev, t->xforms_dev, 1);
 	}
+	{ ProfScope ps(P_GRID_MISC, s);
 	HIPCHK(hipMemsetAsync(t->density_grid_tmp, 0, (size_t)n_elements * 4, s));
 	launch_generate_grid_samples(s, n_uniform, pod(t->density_grid_rng), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions, t->grid_indices,
 		t->opt.max_cascade + 1, -0.01f);
@@ -551,8 +602,11 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	launch_generate_grid_samples(s, n_nonuniform, pod(t->density_grid_rng), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions + (size_t)n_uniform * 3,
 		t->grid_indices + n_uniform, t->opt.max_cascade + 1, MIN_OPTICAL_THICKNESS);
 	t->density_grid_rng.advance(1ull << 32);
+	}
 	// NerfNetwork::density with the TRAINING params (use_inference_params = false, testbed_nerf.cu:2570)
-	launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->grid_positions, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0);
+	{ ProfScope ps(P_GRID_DENSITY, s);
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->grid_positions, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0); }
+	ProfScope ps2(P_GRID_MISC, s);
 	launch_splat_grid_samples(s, n_samples, t->grid_indices, t->grid_mlp_out, 1, t->density_grid_tmp, t->opt.density_activation);
 	launch_ema_grid_samples(s, n_elements, decay, t->density_grid, t->density_grid_tmp);
 	++t->ema_step;
@@ -588,9 +642,10 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
 	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
-	launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1);
-	launch_clamp_compacted(s, c, B);
-	launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4);
+	{ ProfScope ps(P_K1, s); launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1); }
+	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
+	{ ProfScope ps(P_K2_INFERENCE, s);
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }
 	K3Args k3;
 	k3.n_rays = 0; k3.n_rays_ptr = &c->rays_per_batch; k3.aabb = t->aabb; k3.rng = pod(t->rng); k3.max_samples_compacted = B; k3.rays_counter = &c->ray_counter;
 	k3.loss_scale = o.loss_scale; for (int k = 0; k < 3; ++k) k3.background_color[k] = o.background_color[k];
@@ -599,9 +654,9 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k3.rays_in = t->rays; k3.numsteps_inout = t->numsteps; k3.coords_in = t->coords; k3.coords_out = t->coords_compacted; k3.dloss_doutput = t->dloss; k3.dloss_stride = 4;
 	k3.loss_type = o.loss_type; k3.loss_output = &c->loss_sum; k3.rgb_activation = o.rgb_activation; k3.density_activation = o.density_activation;
 	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
-	launch_compute_loss(s, k3, t->max_rays / o.world_size + 1);
-	launch_clamp_compacted(s, c, B);
-	launch_fill_rollover(s, B, &c->n_valid_compacted, t->coords_compacted, 7, t->dloss, 4);
+	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays / o.world_size + 1); }
+	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
+	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->n_valid_compacted, t->coords_compacted, 7, t->dloss, 4); }
 	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
 	// publish the two counters that every rank must agree on before the controller runs (8e)
 	HIPCHK(hipMemcpyAsync(t->sync2, &c->numsteps_counter, 8, hipMemcpyDeviceToDevice, s));
@@ -623,7 +678,7 @@ extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 	if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
-	launch_update_counters(s, t->counters, t->opt.target_batch_size);
+	{ ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size); }
 	++t->training_step;
 	HIPCHK(hipGetLastError());
 	return 0;

@@ -97,7 +97,9 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 uint32_t wgrad_n_partials();
 
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
+	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash);
+void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
+	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad);
 
 struct AdamArgs {
@@ -111,5 +113,8 @@ struct AdamArgs {
 	ngp_half* fw_frags; ngp_half* bw_frags; ngp_half* fw_frags_inf; 
 };
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
+
+// ---- optional per-kernel HIP-event timing (bench.py roofline leg) -----------------------------
+enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_COUNT };
 
 } // namespace ngp

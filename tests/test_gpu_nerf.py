@@ -104,7 +104,7 @@ def test_k1_sample_cap(ora, hip, scene):
 
 def test_k3_loss_and_compaction(ora, hip, scene):
     import torch
-    n_rays, max_samples, B = 2048, 1 << 19, 1 << 14
+    n_rays, max_samples, B = 2048, 1 << 19, 1 << 19  # B large enough that no ray is clamped (the clamped set is order dependent)
     o, d = _run_k1(ora, hip, scene, n_rays, max_samples)
     n_act = o["ray_counter"].value
     total = o["numsteps_counter"].value
@@ -142,8 +142,6 @@ def test_k3_loss_and_compaction(ora, hip, scene):
     for i in range(n_act):
         j = pos_o[int(ri_d[i])]
         kd, bd = int(ns_d2[i, 0]), int(ns_d2[i, 1]); ko, bo = int(o_ns[j, 0]), int(o_ns[j, 1])
-        if bd + kd >= B or bo + ko >= B:
-            continue  # clamped at the batch end: which ray gets clamped is order dependent
         assert kd == ko
         assert np.array_equal(cc_h[bd:bd + kd].view(np.uint32), o_cc[bo:bo + ko].view(np.uint32))  # compacted coords: copies
         a, b = half_to_f32(dl_h[bd:bd + kd]), half_to_f32(o_dl[bo:bo + ko])
@@ -152,6 +150,29 @@ def test_k3_loss_and_compaction(ora, hip, scene):
         n_cmp += kd
     assert n_cmp > 1000
     assert abs(float(loss.cpu()[0]) - float(o_loss.sum())) <= 1e-4 * abs(float(o_loss.sum())) + 1e-7
+
+
+def test_k3_batch_clamp(ora, hip, scene):
+    """compacted spans beyond max_samples_compacted are clamped (testbed_nerf.cu:1010-1016); the counter keeps counting"""
+    import torch
+    n_rays, max_samples, B = 2048, 1 << 19, 1 << 12
+    o, d = _run_k1(ora, hip, scene, n_rays, max_samples)
+    total = o["numsteps_counter"].value
+    net = np.zeros((max_samples, 4), np.float16); net[:, 3] = -3.0  # thin medium: no early termination -> compacted == marched
+    netd = torch.from_numpy(net.view(np.int16)).cuda()
+    aabb = A.scene_aabb(1); rng = _rng(ora); n_img = len(scene["imgs"]); bg = (C.c_float * 3)(0, 0, 0)
+    cc = torch.zeros((B, 7), dtype=torch.float32, device="cuda"); dl = torch.zeros((B, 4), dtype=torch.int16, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda"); loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+    mean = torch.tensor([scene["mean"]], dtype=torch.float32, device="cuda")
+    Md = d["keep"][1]
+    A.check(hip, hip.ngp_k_compute_loss(None, n_rays, None, aabb, rng, B, dptr(d["counters"][0:1]), C.c_float(128.0), bg, 0, 1, 0, n_img, dptr(Md), dptr(netd), 4, dptr(cnt),
+                                       dptr(d["ray_indices"]), dptr(d["rays"]), dptr(d["numsteps"]), dptr(d["coords"]), dptr(cc), dptr(dl), 4, A.LOSS_HUBER, dptr(loss),
+                                       A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
+    torch.cuda.synchronize()
+    assert int(cnt.cpu()[0]) == total and total > B
+    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:o["ray_counter"].value]
+    assert int(np.minimum(ns[:, 0] + ns[:, 1], B).max()) == B and (ns[:, 0][ns[:, 1] >= B] == 0).all()
+    assert ((ns[:, 0] + ns[:, 1])[ns[:, 0] > 0] <= B).all()
 
 
 def test_fill_rollover(ora, hip):
