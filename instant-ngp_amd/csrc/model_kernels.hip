@@ -83,12 +83,13 @@ DEV LevelConst level_const(const GridMeta* __restrict__ gmp, int lvl_even, int h
 	c.hashed = (uint64_t)c.res * c.res * c.res > (uint64_t)c.hs;
 	return c;
 }
-struct Corners { uint32_t idx[8]; float w[8]; };
+struct Corners { uint32_t idx[8]; float w[8]; uint32_t cell_xy, cell_z; };
 DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners& out) {
 	float p0 = fmaf(lc.scale, x, 0.5f), p1 = fmaf(lc.scale, y, 0.5f), p2 = fmaf(lc.scale, z, 0.5f);
 	float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
 	uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
 	p0 -= f0; p1 -= f1; p2 -= f2;
+	out.cell_xy = g0 | (g1 << 16); out.cell_z = g2;
 #pragma unroll
 	for (int c = 0; c < 8; ++c) {
 		float w = 1.f;
@@ -382,7 +383,7 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 
 template <int CT>
 __global__ void __launch_bounds__(256, 3) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
-		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash) {
+		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
 	h8* bw = fw + N_FW_FRAGS * 64;
@@ -504,25 +505,62 @@ __global__ void __launch_bounds__(256, 3) k_train_fwd_bwd(const GridMeta* __rest
 			for (int c = 0; c < CT; ++c) denc[c] = mfma(a, dh[c][s], denc[c]);
 		}
 		// ---- hash-grid scatter: lane (n, hi) owns levels 2*rr + hi (rr = r>>2), features r&3 ----
+		// Consecutive lanes of a 32-lane half are consecutive samples of (mostly) one ray; on the coarse
+		// levels whole runs of them fall into the same grid cell and would hit the same 8 table entries.
+		// Runs are found with one ballot per level and summed with a segmented shuffle reduction in
+		// packed half (the same precision class as the table's half atomics), so only the run head
+		// issues global_atomic_pk_add_f16.
+		if (flags & DBG_T1_NO_SCATTER) continue;
 #pragma unroll
 		for (int c = 0; c < CT; ++c) {
-			if (sidx[c] >= n) continue;
+			const bool sv = sidx[c] < n;
 #pragma unroll
 			for (int rr = 0; rr < 4; ++rr) {
+				if ((flags & DBG_T1_NO_COARSE_LEVELS) && rr < 2) continue;
+				if ((flags & DBG_T1_NO_FINE_LEVELS) && rr >= 2) continue;
 				const LevelConst lc = level_const(gm, 2 * rr, hi);
 				Corners cr;
 				level_corners(lc, px[c], py[c], pz[c], cr);
 				// dL/d(enc) is rounded to half first (it is a half matrix in the reference)
-				const float g0 = (float)(_Float16)denc[c][4 * rr + 0], g1 = (float)(_Float16)denc[c][4 * rr + 1];
-				const float g2 = (float)(_Float16)denc[c][4 * rr + 2], g3 = (float)(_Float16)denc[c][4 * rr + 3];
-				__half* gt = grid_grad + (size_t)lc.offset * 4;
+				const float g0 = sv ? (float)(_Float16)denc[c][4 * rr + 0] : 0.f, g1 = sv ? (float)(_Float16)denc[c][4 * rr + 1] : 0.f;
+				const float g2 = sv ? (float)(_Float16)denc[c][4 * rr + 2] : 0.f, g3 = sv ? (float)(_Float16)denc[c][4 * rr + 3] : 0.f;
+				h2 v0[8], v1[8];
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
 					const float w = cr.w[k];
-					h2 v0 = {(_Float16)(g0 * w), (_Float16)(g1 * w)}, v1 = {(_Float16)(g2 * w), (_Float16)(g3 * w)};
-					__half* dst = gt + (size_t)cr.idx[k] * 4;
-					atomic_add_h2(dst, v0);
-					atomic_add_h2(dst + 2, v1);
+					h2 a0 = {(_Float16)(g0 * w), (_Float16)(g1 * w)}, a1 = {(_Float16)(g2 * w), (_Float16)(g3 * w)};
+					v0[k] = a0; v1[k] = a1;
+				}
+				// run detection: same grid cell as the previous lane of this half => all 8 corner indices equal
+				const uint32_t key = cr.cell_xy, key7 = cr.cell_z;
+				const uint32_t pkey = (uint32_t)__shfl_up((int)key, 1, 32), pkey7 = (uint32_t)__shfl_up((int)key7, 1, 32);
+				const bool head = (col == 0) || key != pkey || key7 != pkey7;
+				const uint64_t hm = __ballot(head);
+				bool issue = true;
+				if (!(flags & DBG_T1_NO_MERGE) && __popcll(hm) <= 48) { // wave-uniform: enough followers to pay for the reduction
+					const uint32_t hmask = hi ? (uint32_t)(hm >> 32) : (uint32_t)hm;
+					const uint32_t rest = col == 31 ? 0u : (hmask >> (col + 1));
+					const uint32_t run_right = rest ? (uint32_t)(__ffs((int)rest) - 1) : (uint32_t)(31 - col);
+#pragma unroll
+					for (int d = 1; d < 32; d <<= 1) {
+						const bool take = run_right >= (uint32_t)d;
+#pragma unroll
+						for (int k = 0; k < 8; ++k) {
+							const h2 t0 = __builtin_bit_cast(h2, __shfl_down(__builtin_bit_cast(int, v0[k]), d, 32));
+							const h2 t1 = __builtin_bit_cast(h2, __shfl_down(__builtin_bit_cast(int, v1[k]), d, 32));
+							if (take) { v0[k] += t0; v1[k] += t1; }
+						}
+					}
+					issue = head;
+				}
+				if (issue && sv) {
+					__half* gt = grid_grad + (size_t)lc.offset * 4;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						__half* dst = gt + (size_t)cr.idx[k] * 4;
+						atomic_add_h2(dst, v0[k]);
+						atomic_add_h2(dst + 2, v1[k]);
+					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
@@ -824,12 +862,12 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 }
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash) {
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags) {
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
 	hipLaunchKernelGGL((k_train_fwd_bwd<1>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
-		(__half*)grid_grad, (uint4*)enc_stash);
+		(__half*)grid_grad, (uint4*)enc_stash, flags);
 }
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {

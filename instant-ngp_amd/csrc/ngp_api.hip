@@ -66,6 +66,7 @@ extern "C" int ngp_profile_enable(int on) {
 	if (on) { for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; } }
 	return 0;
 }
+extern "C" int ngp_debug_set_flags(uint32_t flags) { g_debug_flags = flags; return 0; }
 extern "C" int ngp_profile_count(void) { return P_COUNT; }
 extern "C" const char* ngp_profile_name(int i) { return (i >= 0 && i < P_COUNT) ? kProfNames[i] : ""; }
 extern "C" int ngp_profile_read(double* ms_sum, uint64_t* launches) {
@@ -335,7 +336,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	}
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
 	{ ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
-	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash); }
+	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, g_debug_flags); }
 	{ ProfScope ps(P_W_WGRAD, s); launch_wgrad(s, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
 	{ ProfScope ps(P_WGRAD_REDUCE, s); launch_wgrad_reduce(s, m->wgrad_partials, m->n_partials, m->grads); }
 	HIPCHK(hipGetLastError());
@@ -426,7 +427,10 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
-	launch_generate_training_samples((hipStream_t)stream, a, n_rays / world_size + 1);
+	static uint32_t* s_coarse = nullptr;
+	if (!s_coarse && dev_alloc(&s_coarse, 8192)) return 1;
+	launch_build_coarse_mask((hipStream_t)stream, bitfield, s_coarse);
+	launch_generate_training_samples((hipStream_t)stream, a, n_rays / world_size + 1, s_coarse);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -503,6 +507,7 @@ struct ngp_nerf {
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
+	uint32_t* coarse_mask = nullptr; // 64^3 any-occupied mask of cascade 0 for K1 (32 KiB)
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
 	// host-side deterministic state (no device read-back needed)
 	Rng rng, density_grid_rng;
@@ -526,10 +531,11 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2)) { delete t; return 1; }
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192)) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
+	HIPCHK(hipMemset(t->coarse_mask, 0, 8192 * 4));
 	TrainCounters c; memset(&c, 0, sizeof(c));
 	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
 	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
@@ -542,7 +548,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -612,6 +618,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	++t->ema_step;
 	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
+	launch_build_coarse_mask(s, t->bitfield, t->coarse_mask);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -642,7 +649,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
 	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
-	{ ProfScope ps(P_K1, s); launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1); }
+	{ ProfScope ps(P_K1, s); launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1, t->coarse_mask); }
 	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
 	{ ProfScope ps(P_K2_INFERENCE, s);
 	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }
@@ -710,6 +717,7 @@ extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const f
 	HIPCHK(hipMemcpy(t->density_grid, grid_host, n * 4, hipMemcpyHostToDevice));
 	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield((hipStream_t)stream, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
+	launch_build_coarse_mask((hipStream_t)stream, t->bitfield, t->coarse_mask);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

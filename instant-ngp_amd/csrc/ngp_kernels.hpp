@@ -6,6 +6,10 @@
 
 namespace ngp {
 
+// debug / ablation switches (ngp_debug_set_flags); 0 in production
+extern uint32_t g_debug_flags;
+enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16 };
+
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
 struct TrainCounters {
 	uint32_t rays_per_batch;                        // R of the current/next step (global, all ranks)
@@ -56,7 +60,8 @@ struct K3Args {
 	const float* mean_density_ptr; float near_distance;
 };
 
-void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
+void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank, const uint32_t* coarse_mask);
+void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse_8192_words);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride);
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
@@ -97,7 +102,7 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 uint32_t wgrad_n_partials();
 
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash);
+	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad);

@@ -53,7 +53,9 @@ def test_encode_bit_exact(ora, hip, n, coherent):
     A.check(hip, hip.ngp_model_encode(hm.h, None, dptr(cd), 7, n, dptr(out)))
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint16)
-    assert np.array_equal(ref, got), f"{(ref != got).sum()} of {ref.size} encoded halfs differ"
+    bad = np.argwhere(ref != got)
+    msg = [(int(i), int(f), float(half_to_f32(ref[i, f])), float(half_to_f32(got[i, f])), c[i, :3].tolist()) for i, f in bad[:8]]
+    assert len(bad) == 0, f"{len(bad)} of {ref.size} encoded halfs differ: {msg}"
 
 
 @pytest.mark.parametrize("n", [1, 33, 64, 5000, 70001])
