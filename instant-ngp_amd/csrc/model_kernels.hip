@@ -85,6 +85,9 @@ DEV LevelConst level_const(const GridMeta* __restrict__ gmp, int lvl_even, int h
 }
 struct Corners { uint32_t idx[8]; float w[8]; uint32_t cell_xy, cell_z; };
 DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners& out) {
+	// No contraction here: under -ffp-contract=fast LLVM rewrites (1 - p) * w into fma(-p, w, w), which changes the
+	// interpolation weights by an ulp relative to the reference's two-step rounding (only the explicit fmaf is fused).
+#pragma clang fp contract(off)
 	float p0 = fmaf(lc.scale, x, 0.5f), p1 = fmaf(lc.scale, y, 0.5f), p2 = fmaf(lc.scale, z, 0.5f);
 	float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
 	uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;

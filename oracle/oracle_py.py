@@ -38,6 +38,7 @@ def load():
         L.ora_model_optimizer_step.argtypes = [vp, f32]
         L.ora_k_ema_grid_samples.argtypes = [u32, f32, vp, vp]
         L.ora_nerf_update_density_grid.argtypes = [vp, f32, u32, u32]
+        L.ora_sobol.restype = u32; L.ora_morton3D.restype = u32; L.ora_morton3D_invert.restype = u32; L.ora_pcg32_next_uint.restype = u32
         L.ora_hfma.restype = u16; L.ora_hfma.argtypes = [u16, u16, u16]
         for name in ("ora_model_n_params", "ora_model_n_mlp_params"):
             getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]

@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol the header declares; host-only entry points work;
+the synthetic-scene generator follows the reference's NeRF->NGP conventions."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ngp_abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = A.load_hip()
+    header = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ngp_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU the product path must fail loudly instead of computing on the CPU."""
+    lib = A.load_hip()
+    if lib.ngp_device_available():
+        pytest.skip("a GPU is visible here")
+    cfg = A.base_model_config(1)
+    h = C.c_void_p()
+    assert lib.ngp_model_create(C.byref(cfg), C.c_uint64(1337), C.byref(h)) != 0
+    assert b"no HIP device" in lib.ngp_last_error()
+
+
+def test_config_from_json_matches_reference_derivation():
+    lib = A.load_hip()
+    text = open(os.path.join(ROOT, "instant-ngp_amd", "configs", "nerf", "base.json")).read().encode()
+    for aabb_scale, expect in ((1, 2.0), (4, math.exp(math.log(2048 * 4 / 16) / 7)), (16, math.exp(math.log(2048 * 16 / 16) / 7))):
+        cfg = A.ModelConfig()
+        assert lib.ngp_model_config_from_json(text, aabb_scale, 0, C.byref(cfg)) == 0, lib.ngp_last_error()
+        assert (cfg.n_levels, cfg.n_features_per_level, cfg.log2_hashmap_size, cfg.base_resolution) == (8, 4, 19, 16)
+        assert abs(cfg.per_level_scale - expect) < 1e-5  # testbed.cu:4241-4255
+        assert (cfg.n_neurons, cfg.n_hidden_layers, cfg.n_hidden_layers_rgb, cfg.sh_degree) == (64, 1, 2, 4)
+        assert abs(cfg.learning_rate - 1e-2) < 1e-9 and abs(cfg.beta2 - 0.99) < 1e-7 and abs(cfg.epsilon - 1e-15) < 1e-20 and abs(cfg.l2_reg - 1e-6) < 1e-12
+        assert abs(cfg.ema_decay - 0.95) < 1e-7 and (cfg.decay_start, cfg.decay_interval) == (20000, 10000) and abs(cfg.decay_base - 0.33) < 1e-7
+        ref = A.base_model_config(aabb_scale)
+        assert abs(ref.per_level_scale - cfg.per_level_scale) < 1e-6
+    bad = b'{"encoding": {"otype": "Frequency"}}'
+    assert lib.ngp_model_config_from_json(bad, 1, 0, C.byref(A.ModelConfig())) != 0
+    assert b"HashGrid" in lib.ngp_last_error()
+    assert lib.ngp_model_config_from_json(b'{"encoding": ', 1, 0, C.byref(A.ModelConfig())) != 0  # malformed json -> error, not crash
+
+
+def test_struct_sizes_match_the_c_header():
+    # compile-time layout cross-check: sizes as seen by a C compiler
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "ngp_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ngp_image_meta), sizeof(ngp_xform), sizeof(ngp_model_config), sizeof(ngp_nerf_options), sizeof(ngp_nerf_stats), sizeof(ngp_render_params), sizeof(ngp_aabb));}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).split()
+    sizes = [C.sizeof(x) for x in (A.ImageMeta, A.Xform, A.ModelConfig, A.NerfOptions, A.NerfStats, A.RenderParams, A.Aabb)]
+    assert [int(v) for v in out] == sizes
+
+
+def test_synthetic_scene_conventions():
+    import synth_scene
+    poses = synth_scene.camera_poses(5)
+    for c2w in poses:
+        R = c2w[:3, :3]
+        assert np.allclose(R.T @ R, np.eye(3), atol=1e-12)
+        assert abs(np.linalg.norm(c2w[:3, 3]) - synth_scene.RADIUS) < 1e-9
+        fwd = -c2w[:3, 2]
+        assert np.allclose(fwd, -c2w[:3, 3] / np.linalg.norm(c2w[:3, 3]), atol=1e-12)  # looks at the origin
+        m = synth_scene.nerf_matrix_to_ngp(c2w).reshape(4, 3)  # 4 columns of vec3
+        # position: nerf * 0.33 + 0.5 with axes cycled xyz <- yzx (nerf_loader.h:101-120)
+        p = c2w[:3, 3] * 0.33 + 0.5
+        assert np.allclose(m[3], [p[1], p[2], p[0]], atol=1e-6)
+        # ngp column 2 is the view direction (testbed.h:453-456): cycled -(-fwd) = fwd
+        assert np.allclose(m[2], [fwd[1], fwd[2], fwd[0]], atol=1e-6)
+        assert abs(np.linalg.norm(m[3] - 0.5) - synth_scene.RADIUS * 0.33) < 1e-5  # cameras sit outside the unit cube (1.33 from its centre)
+    imgs, xforms, meta, _ = synth_scene.make_dataset(2, 32, "cpu")
+    a = imgs[0].numpy()
+    assert a.shape == (32, 32, 4) and a.dtype == np.uint8
+    cov = (a[..., 3] > 0).mean()
+    assert 0.1 < cov < 0.6 and (a[a[..., 3] == 0][:, :3] == 0).all()  # object in the middle, transparent background

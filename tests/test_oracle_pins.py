@@ -1,0 +1,329 @@
+"""CPU: pins for the oracle that do NOT come from the oracle's own arithmetic.
+
+The reference ships no golden vectors for this path and tiny-cuda-nn is absent, so the oracle is
+"parity unpinned" with respect to the reference; what CAN be pinned independently is pinned here:
+published known-answer values (pcg32 demo stream, Sobol direction numbers), IEEE binary16 semantics (numpy),
+exact rational arithmetic (fused half multiply-add), brute-force definitions (Morton codes, occupancy indices),
+mathematical identities (orthonormality of the SH basis), and independent implementations (numpy float64 trilinear
+interpolation, PyTorch autograd for the network gradients, torch.optim.Adam, finite differences for the compositing adjoint).
+"""
+import ctypes as C
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import ngp_abi as A
+from common import OraModel, half_to_f32, ptr, random_coords
+
+
+def test_pcg32_known_answer(ora):
+    # pcg-c-basic "pcg32-demo" with seed (42, 54): first six outputs of round 1
+    s = A.Pcg32()
+    ora.ora_pcg32_seed(C.byref(s), C.c_uint64(42), C.c_uint64(54))
+    got = [ora.ora_pcg32_next_uint(C.byref(s)) & 0xFFFFFFFF for _ in range(6)]
+    assert got == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+
+
+def test_pcg32_advance_equals_stepping(ora):
+    a, b = A.Pcg32(), A.Pcg32()
+    for delta in (0, 1, 16, 12345, 1 << 20):
+        ora.ora_pcg32_seed(C.byref(a), C.c_uint64(1337), C.c_uint64(1)); ora.ora_pcg32_seed(C.byref(b), C.c_uint64(1337), C.c_uint64(1))
+        ora.ora_pcg32_advance(C.byref(a), C.c_int64(delta))
+        for _ in range(min(delta, 70000)):
+            ora.ora_pcg32_next_uint(C.byref(b))
+        if delta <= 70000:
+            assert (a.state, a.inc) == (b.state, b.inc)
+    ora.ora_pcg32_seed(C.byref(a), C.c_uint64(7), C.c_uint64(1))
+    f = [ora.ora_pcg32_next_float(C.byref(a)) for _ in range(1000)]
+    assert 0.0 <= min(f) and max(f) < 1.0 and 0.4 < np.mean(f) < 0.6
+
+
+def test_half_conversions_match_ieee(ora):
+    allh = np.arange(65536, dtype=np.uint16)
+    out = np.zeros(65536, dtype=np.float32)
+    ora.ora_h2f(ptr(allh), ptr(out), C.c_uint64(65536))
+    ref = allh.view(np.float16).astype(np.float32)
+    ok = (out == ref) | (np.isnan(out) & np.isnan(ref))
+    assert ok.all()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(0, 1, 200000), rng.normal(0, 1e-5, 100000), rng.uniform(-70000, 70000, 100000),
+                        [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-08, 6.1e-5, np.inf, -np.inf]]).astype(np.float32)
+    # exact ties
+    ties = (np.arange(1, 2000, dtype=np.float64) + 0.5) * 2.0 ** -14
+    x = np.concatenate([x, ties.astype(np.float32)])
+    got = np.zeros(x.size, dtype=np.uint16)
+    ora.ora_f2h(ptr(x), ptr(got), C.c_uint64(x.size))
+    with np.errstate(over="ignore"):
+        refh = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, refh)
+
+
+def _round_fraction_to_half(fr):
+    """exact round-to-nearest-even of a rational number to binary16"""
+    if fr == 0:
+        return 0.0
+    sign = -1 if fr < 0 else 1
+    a = abs(fr)
+    e = math.floor(math.log2(float(a))) if a > 0 else 0
+    while Fraction(2) ** e > a:
+        e -= 1
+    while Fraction(2) ** (e + 1) <= a:
+        e += 1
+    ulp = Fraction(2) ** (max(e, -14) - 10)
+    q = a / ulp
+    fl = q.numerator // q.denominator
+    rem = q - fl
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1):
+        fl += 1
+    val = float(fl * ulp)
+    return sign * (val if val < 65520 else float("inf"))
+
+
+def test_fused_half_fma_exact(ora):
+    rng = np.random.default_rng(1)
+    hs = rng.normal(0, 1, (3000, 3)).astype(np.float16)
+    hs[:500] *= np.float16(1e-3)
+    for a, b, c in hs[:1500]:
+        got = np.array([ora.ora_hfma(int(a.view(np.uint16)), int(b.view(np.uint16)), int(c.view(np.uint16)))], dtype=np.uint16).view(np.float16)[0]
+        ref = _round_fraction_to_half(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+        assert float(got) == ref, (a, b, c, got, ref)
+
+
+def test_morton_codes_brute_force(ora):
+    def interleave(x, y, z):
+        r = 0
+        for b in range(10):
+            r |= ((x >> b) & 1) << (3 * b) | ((y >> b) & 1) << (3 * b + 1) | ((z >> b) & 1) << (3 * b + 2)
+        return r
+    rng = np.random.default_rng(2)
+    for x, y, z in rng.integers(0, 1024, (2000, 3)):
+        m = ora.ora_morton3D(int(x), int(y), int(z))
+        assert m == interleave(int(x), int(y), int(z))
+        assert (ora.ora_morton3D_invert(m), ora.ora_morton3D_invert(m >> 1), ora.ora_morton3D_invert(m >> 2)) == (x, y, z)
+
+
+def test_cascaded_grid_index_definition(ora):
+    """idx = Morton(floor(((p-0.5)/2^mip + 0.5)*128)) or 0xFFFFFFFF outside; positions on a dyadic lattice are exact in fp32"""
+    rng = np.random.default_rng(3)
+    for mip in range(0, 4):
+        p = (rng.integers(-3 * 2048, 4 * 2048, (4000, 3)) / 2048.0).astype(np.float32)
+        out = np.zeros(4000, dtype=np.uint32)
+        ora.ora_cascaded_grid_idx_at(ptr(p), 4000, mip, ptr(out))
+        q = (p.astype(np.float64) - 0.5) / 2 ** mip + 0.5
+        cell = np.trunc(q * 128).astype(np.int64)  # C cast truncates toward zero
+        inside = ((cell >= 0) & (cell < 128)).all(axis=1)
+        for k in range(4000):
+            exp = ora.ora_morton3D(int(cell[k, 0]), int(cell[k, 1]), int(cell[k, 2])) if inside[k] else 0xFFFFFFFF
+            assert out[k] == exp
+        mo = np.zeros(4000, dtype=np.uint32)
+        ora.ora_mip_from_pos(ptr(p), 4000, 7, ptr(mo))
+        mx = np.abs(p.astype(np.float64) - 0.5).max(axis=1)
+        exp = np.clip(np.where(mx > 0, np.floor(np.log2(np.maximum(mx, 1e-300))) + 1, -1000) + 1, 0, 7).astype(np.uint32)
+        assert np.array_equal(mo, exp)
+
+
+def test_stepping_space(ora):
+    step = math.sqrt(3) / 1024
+    assert abs(ora.ora_calc_dt(C.c_float(0.37), C.c_float(0.0)) - step) < 1e-7
+    for cone in (0.0, 1.0 / 256.0):
+        for t in (0.01, 0.3, 1.7, 9.0, 100.0):
+            n = ora.ora_to_stepping_space(C.c_float(t), C.c_float(cone))
+            assert abs(ora.ora_from_stepping_space(C.c_float(n), C.c_float(cone)) - t) <= 2e-5 * max(1, t)
+    # exponential stepping: dt grows ~ cone_angle * t in the log region
+    t = 2.0
+    dt = ora.ora_calc_dt(C.c_float(t), C.c_float(1 / 256.0))
+    assert abs(dt / t - 1 / 256.0) < 1e-4
+    assert abs(ora.ora_unwarp_dt(C.c_float(ora.ora_warp_dt(C.c_float(0.01)))) - 0.01) < 1e-7
+
+
+def test_sobol_direction_numbers(ora):
+    # Joe-Kuo / Burley: dimension 0 = van der Corput, dimension 1 first direction numbers
+    assert [ora.ora_sobol(1 << b, 0) for b in range(6)] == [0x80000000 >> b for b in range(6)]
+    assert [ora.ora_sobol(1 << b, 1) for b in range(8)] == [0x80000000, 0xc0000000, 0xa0000000, 0xf0000000, 0x88000000, 0xcc000000, 0xaa000000, 0xff000000]
+    v = [ora.ora_ld_random_val(i, 0xdeadbeef, 0) for i in range(256)]
+    assert 0 <= min(v) and max(v) < 1 and abs(np.mean(v) - 0.5) < 0.01  # stratified: mean of 256 points is tight
+
+
+def test_sh4_orthonormal_basis(ora):
+    """The 16 functions must be an orthonormal basis of the real spherical harmonics of degree <= 3."""
+    from scipy.special import sph_harm
+    n_t, n_p = 64, 128
+    xs, ws = np.polynomial.legendre.leggauss(n_t)
+    theta = np.arccos(xs); phi = (np.arange(n_p) + 0.5) * 2 * np.pi / n_p
+    T, P = np.meshgrid(theta, phi, indexing="ij")
+    W = np.repeat(ws[:, None], n_p, 1) * (2 * np.pi / n_p)
+    d = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], -1).reshape(-1, 3)
+    d01 = ((d + 1) * 0.5).astype(np.float32)
+    out = np.zeros((d01.shape[0], 16), dtype=np.uint16)
+    ora.ora_sh4(ptr(np.ascontiguousarray(d01)), d01.shape[0], ptr(out))
+    Y = half_to_f32(out).astype(np.float64)
+    G = (Y * W.reshape(-1, 1)).T @ Y
+    assert np.abs(G - np.eye(16)).max() < 4e-3  # half-precision outputs
+    # each function lives in the right degree-l subspace (compare with scipy's complex harmonics)
+    for i in range(16):
+        l = int(math.isqrt(i))
+        energy = 0.0
+        for m in range(-l, l + 1):
+            c = np.sum(np.conj(sph_harm(m, l, P.reshape(-1), T.reshape(-1))) * Y[:, i] * W.reshape(-1))
+            energy += abs(c) ** 2
+        assert abs(energy - 1.0) < 1e-2, (i, energy)
+
+
+def _grid_layout(ora, om):
+    offs = (C.c_uint32 * 9)(); res = (C.c_uint32 * 8)(); sc = (C.c_float * 8)()
+    ora.ora_model_grid_layout(om.h, offs, res, sc)
+    return list(offs), list(res), list(sc)
+
+
+def test_grid_layout_and_encode_vs_numpy(ora):
+    cfg = A.base_model_config(1)
+    om = OraModel(ora, cfg)
+    offs, res, sc = _grid_layout(ora, om)
+    assert res == [16, 32, 64, 128, 256, 512, 1024, 2048]
+    assert offs == [0, 4096, 36864, 299008, 823296, 1347584, 1871872, 2396160, 2920448]  # 3 dense + 5 hashed levels
+    assert om.n == 10240 + 2920448 * 4
+    rng = np.random.default_rng(5)
+    om.params_fp[om.n_mlp:] = rng.uniform(-1, 1, om.n - om.n_mlp).astype(np.float32)
+    ora.ora_model_sync_half(om.h)
+    table = half_to_f32(om.params[om.n_mlp:]).astype(np.float64).reshape(-1, 4)
+    pos = rng.uniform(0, 1, (300, 3)).astype(np.float32)
+    got = half_to_f32(om.encode(np.ascontiguousarray(np.pad(pos, ((0, 0), (0, 4)))))).reshape(300, 8, 4)
+    primes = (1, 2654435761, 805459861)
+    for l in range(8):
+        hs = offs[l + 1] - offs[l]
+        p = np.float64(np.float32(sc[l])) * pos.astype(np.float64) + 0.5
+        g = np.floor(p).astype(np.int64); f = p - g
+        acc = np.zeros((300, 4))
+        for c in range(8):
+            w = np.ones(300); idx3 = []
+            for d in range(3):
+                bit = (c >> d) & 1
+                w *= f[:, d] if bit else 1 - f[:, d]
+                idx3.append(g[:, d] + bit)
+            if res[l] ** 3 > hs:
+                idx = ((idx3[0] * primes[0]) & 0xFFFFFFFF) ^ ((idx3[1] * primes[1]) & 0xFFFFFFFF) ^ ((idx3[2] * primes[2]) & 0xFFFFFFFF)
+            else:
+                idx = idx3[0] + idx3[1] * res[l] + idx3[2] * res[l] ** 2
+            acc += w[:, None] * table[offs[l] + idx % hs]
+        assert np.abs(got[:, l] - acc).max() < 6e-3  # 8 half roundings of O(1) values
+
+
+def _torch_reference_grads(om, ora, coords, dl):
+    """independent fp32 autograd implementation of grid + MLPs with the oracle's half-rounded parameters"""
+    import torch
+    offs, res, sc = _grid_layout(ora, om)
+    P = torch.tensor(half_to_f32(om.params), dtype=torch.float64, requires_grad=True)
+    x = torch.tensor(coords[:, :3], dtype=torch.float64)
+    feats = []
+    primes = (1, 2654435761, 805459861)
+    for l in range(8):
+        hs = offs[l + 1] - offs[l]
+        tbl = P[om.n_mlp + offs[l] * 4: om.n_mlp + offs[l + 1] * 4].reshape(-1, 4)
+        p = float(np.float32(sc[l])) * x + 0.5
+        g = torch.floor(p).long(); f = p - g
+        acc = 0
+        for c in range(8):
+            w = torch.ones(x.shape[0], dtype=torch.float64); ids = []
+            for d in range(3):
+                bit = (c >> d) & 1
+                w = w * (f[:, d] if bit else 1 - f[:, d]); ids.append(g[:, d] + bit)
+            if res[l] ** 3 > hs:
+                idx = ((ids[0] * primes[0]) & 0xFFFFFFFF) ^ ((ids[1] * primes[1]) & 0xFFFFFFFF) ^ ((ids[2] * primes[2]) & 0xFFFFFFFF)
+            else:
+                idx = ids[0] + ids[1] * res[l] + ids[2] * res[l] ** 2
+            acc = acc + w[:, None] * tbl[idx % hs]
+        feats.append(acc)
+    enc = torch.cat(feats, 1)
+    W = lambda a, r, c: P[a:a + r * c].reshape(r, c)
+    h = torch.relu(enc @ W(0, 64, 32).T); dens = h @ W(2048, 16, 64).T
+    d01 = torch.tensor(coords[:, 4:7], dtype=torch.float64)
+    sh = np.zeros((coords.shape[0], 16), dtype=np.uint16)
+    ora.ora_sh4(ptr(np.ascontiguousarray(coords[:, 4:7])), coords.shape[0], ptr(sh))
+    rin = torch.cat([dens, torch.tensor(half_to_f32(sh), dtype=torch.float64)], 1)
+    h1 = torch.relu(rin @ W(3072, 64, 32).T); h2 = torch.relu(h1 @ W(5120, 64, 64).T); rgb = h2 @ W(9216, 16, 64).T
+    out = torch.cat([rgb[:, :3], dens[:, :1]], 1)
+    out.backward(torch.tensor(half_to_f32(dl), dtype=torch.float64))
+    return out.detach().numpy(), P.grad.numpy()
+
+
+def test_network_gradients_vs_autograd(ora):
+    cfg = A.base_model_config(1)
+    om = OraModel(ora, cfg)
+    rng = np.random.default_rng(11)
+    om.params_fp[:om.n_mlp] = rng.uniform(-0.3, 0.3, om.n_mlp).astype(np.float32)
+    om.params_fp[om.n_mlp:] = rng.uniform(-1, 1, om.n - om.n_mlp).astype(np.float32)
+    ora.ora_model_sync_half(om.h)
+    n = 512
+    c = random_coords(n, seed=4, ray_coherent=True)
+    dl = (rng.normal(size=(n, 4)) * 0.05).astype(np.float16).view(np.uint16)
+    out_ref, g_ref = _torch_reference_grads(om, ora, c, dl)
+    out = half_to_f32(om.inference(c))
+    assert np.abs(out - out_ref).max() < 2e-2  # half activations vs float64
+    om.training_step(c, dl)
+    g = half_to_f32(om.grads.copy()).astype(np.float64)
+    for name, a, b in (("density_l1", 0, 2048), ("density_l2", 2048, 3072), ("rgb_l1", 3072, 5120), ("rgb_l2", 5120, 9216), ("rgb_l3", 9216, 10240), ("grid", 10240, om.n)):
+        rel = np.linalg.norm(g[a:b] - g_ref[a:b]) / np.linalg.norm(g_ref[a:b])
+        assert rel < 3e-2, (name, rel)  # half-precision pipeline vs float64 autograd
+
+
+def test_adam_vs_torch_optim(ora):
+    import torch
+    cfg = A.base_model_config(1)
+    om = OraModel(ora, cfg)
+    rng = np.random.default_rng(2)
+    w0 = om.params_fp[:om.n_mlp].copy()
+    tw = torch.tensor(w0, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([tw], lr=cfg.learning_rate, betas=(cfg.beta1, cfg.beta2), eps=cfg.epsilon, weight_decay=cfg.l2_reg)
+    for step in range(5):
+        g = (rng.normal(size=om.n_mlp) * 3.0).astype(np.float16)
+        om.grads[:] = 0
+        om.grads[:om.n_mlp] = g.view(np.uint16)
+        ora.ora_model_optimizer_step(om.h, C.c_float(128.0))
+        tw.grad = torch.tensor(g.astype(np.float64) / 128.0)
+        opt.step()
+        assert np.abs(om.params_fp[:om.n_mlp] - tw.detach().numpy()).max() < 2e-6
+    # sparse rule: hash-grid entries with a zero gradient are untouched, EMA follows the debiased recurrence
+    fresh = OraModel(ora, cfg)  # keep the handle alive while its memory is viewed
+    assert np.array_equal(om.params_fp[om.n_mlp:], fresh.params_fp[om.n_mlp:])
+    assert ora.ora_model_step(om.h) == 5
+
+
+def test_compositing_adjoint_finite_differences(ora):
+    """dL/d(network output) from K3 vs central differences of the composited Huber loss (float64 re-implementation)."""
+    from common import host_meta, make_small_dataset
+    imgs, xforms, meta = make_small_dataset(3, 16)
+    M, X = host_meta(imgs, xforms, meta)
+    n_rays, ns = 4, 9
+    rng = np.random.default_rng(0)
+    coords = np.zeros((n_rays * ns, 7), np.float32)
+    coords[:, :3] = rng.uniform(0.3, 0.7, (n_rays * ns, 3)); coords[:, 3] = 0.0
+    net = np.zeros((n_rays * ns, 4), np.float16)
+    net[:, :3] = rng.normal(0, 1, (n_rays * ns, 3)); net[:, 3] = rng.normal(5.0, 1.0, n_rays * ns)  # exp(5)*dt ~ 0.25 optical thickness
+    ray_idx = np.arange(n_rays, dtype=np.uint32)
+    rays = np.zeros((n_rays, 6), np.float32); rays[:, 3:] = (0, 0, 1)
+    numsteps = np.stack([np.full(n_rays, ns), np.arange(n_rays) * ns], 1).astype(np.uint32)
+    aabb = A.scene_aabb(1)
+    rngs = A.Pcg32(); ora.ora_pcg32_seed(C.byref(rngs), C.c_uint64(1337), C.c_uint64(1))
+    bg = (C.c_float * 3)(0.2, 0.4, 0.6)
+
+    def run(net_h):
+        ns2 = numsteps.copy(); cc = np.zeros((64, 7), np.float32); dl = np.zeros((64, 4), np.uint16); loss = np.zeros(n_rays, np.float32); cnt = C.c_uint32()
+        ora.ora_k_compute_loss(n_rays, n_rays, aabb, rngs, 64, C.c_float(1.0), bg, 0, 0, 0, 3, M, ptr(net_h.view(np.uint16)), 4, C.byref(cnt), ptr(ray_idx), ptr(rays), ptr(ns2),
+                               ptr(coords), ptr(cc), ptr(dl), 4, A.LOSS_HUBER, ptr(loss), A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, C.c_float(1.0), C.c_float(0.0))
+        return float(loss.sum()) * 3.0 * n_rays, half_to_f32(dl)[:n_rays * ns], cnt.value  # loss_output = mean(loss)/n_rays ; gradient is of sum over channels /n_rays
+
+    base_loss, dl, cnt = run(net)
+    assert cnt == n_rays * ns
+    eps = 2.0 ** -6  # exactly representable half steps
+    worst = 0.0
+    for k in rng.integers(0, n_rays * ns, 24):
+        for ch in range(4):
+            up, dn = net.copy(), net.copy()
+            up[k, ch] = np.float16(np.float32(net[k, ch]) + eps); dn[k, ch] = np.float16(np.float32(net[k, ch]) - eps)
+            h = float(np.float32(up[k, ch]) - np.float32(dn[k, ch]))
+            fd = (run(up)[0] - run(dn)[0]) / h / n_rays  # loss_scale/n_rays normalisation of the analytic gradient
+            an = dl[k, ch]
+            worst = max(worst, abs(fd - an) / (abs(fd) + 2e-3))
+    assert worst < 0.08, worst
