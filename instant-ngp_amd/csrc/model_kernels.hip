@@ -100,6 +100,9 @@ DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners&
 		if ((c & 1) == 0) { w *= 1 - p0; a0 = g0; } else { w *= p0; a0 = g0 + 1; }
 		if ((c & 2) == 0) { w *= 1 - p1; a1 = g1; } else { w *= p1; a1 = g1 + 1; }
 		if ((c & 4) == 0) { w *= 1 - p2; a2 = g2; } else { w *= p2; a2 = g2 + 1; }
+		// materialise the fp32 weight: otherwise the last multiply is folded into the half conversion
+		// (v_fma_mixlo_f16, one rounding) while the reference rounds to fp32 first and then to half
+		asm volatile("" : "+v"(w));
 		uint32_t idx;
 		if (lc.hashed) {
 			idx = (a0 * 1u) ^ (a1 * 2654435761u) ^ (a2 * 805459861u);

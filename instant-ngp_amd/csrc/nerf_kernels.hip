@@ -247,6 +247,201 @@ __global__ void __launch_bounds__(K1_THREADS) k_generate_training_samples_v2(K1A
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K1, sample-parallel ("lattice") formulation -- the production ray marcher on MI355X.
+//
+// The reference's per-ray loop (testbed_nerf.cu:798-807) is a sequential float recurrence, but its
+// RESULT has a closed form: every visited t is  t_j = from_stepping_space(n' + j),  n' =
+// to_stepping_space(startt), j = 0,1,2,...  (each update is t <- from(to(t) + k), k integer: k = 1
+// for a step through an occupied voxel, k = ceil(...) for a skip to the first lattice point past an
+// empty voxel), and a lattice point is emitted as a sample iff it lies in an occupied voxel: points
+// inside an empty voxel are the ones the skip jumps over, and the landing point of a skip is the first
+// lattice point of the next voxel.  So the samples of a ray are { t_j : occupied(pos(t_j)) } in order
+// of j, cut at NERF_STEPS samples -- all j can be tested independently.
+// One wavefront marches one ray, 64 lattice points per iteration (ballot -> 64-bit occupancy mask);
+// sample spans come from a prefix sum over the per-ray counts, so the output order is deterministic
+// (ray-index order) and needs no atomics.  58k rays x ~16 chunks keep all 256 CUs busy, where the
+// thread-per-ray loop ran < 1 wavefront per SIMD with ~10^3-instruction dependent chains.
+// Numerically the closed form differs from the sequential recurrence only through fp32 double
+// rounding of (n + k1) + k2 vs n + (k1 + k2) and of fl(fl(x*M)/M): the great majority of rays are
+// bit-identical, the rest carry <= 2-ulp offsets in t (tests/test_gpu_nerf.py quantifies both).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
+constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
+
+__global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__ rs) {
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
+	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
+	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
+	const uint32_t i = ray_begin + li;
+	if (i >= ray_end) return;
+	const Box aabb(a.aabb);
+	RaySetup r;
+	r.o[0] = r.o[1] = r.o[2] = 0.f; r.d[0] = r.d[1] = 0.f; r.d[2] = 1.f; r.startt = 0.f; r.nprime = 0.f; r.count = 0; r.flags = 0;
+	uint32_t img = image_idx(i, n_rays, a.n_images);
+	const ngp_image_meta& m = a.metadata[img];
+	Rng rng(a.rng);
+	rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
+	f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+	if (!(read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f)) {
+		(void)rng.next_float(); // motionblur_time
+		const M43 xform = ldm43(a.xforms[img].start);
+		f3 ro, rd;
+		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+		const f3 rdn = normalize3(rd);
+		f2 tminmax = aabb.ray_intersect(ro, rdn);
+		tminmax.x = fmaxf(tminmax.x, 0.0f);
+		const float startt = advance_n_steps(tminmax.x, a.cone_angle_constant, rng.next_float());
+		r.o[0] = ro.x; r.o[1] = ro.y; r.o[2] = ro.z; r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;
+		r.startt = startt;
+		r.nprime = to_stepping_space(startt, a.cone_angle_constant);
+		r.flags = aabb.contains(ro + startt * rdn) ? 1u : 0u;
+	}
+	rs[li] = r;
+}
+
+static __device__ __forceinline__ float lattice_t(const RaySetup& r, uint32_t j, float cone_angle) {
+	return j == 0 ? r.startt : from_stepping_space(r.nprime + (float)j, cone_angle);
+}
+
+__global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__ rs, uint64_t* __restrict__ masks, uint64_t* __restrict__ scan_in) {
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
+	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
+	const uint32_t n_local = ray_end - ray_begin;
+	const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (li >= n_local) return;
+	const RaySetup r = rs[li];
+	uint32_t cnt = 0, n_chunks = 0;
+	if (r.flags) {
+		const Box aabb(a.aabb);
+		const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
+		for (uint32_t ch = 0; ch < LAT_MAX_CHUNKS && cnt < N_STEPS; ++ch) {
+			const float t = lattice_t(r, ch * 64 + lane, a.cone_angle_constant);
+			const f3 pos = ro + t * rdn;
+			const bool inside = aabb.contains(pos);
+			bool occ = false;
+			if (inside) {
+				// 64 consecutive lattice points span ~14 voxels: the byte loads of a wavefront coalesce into a few
+				// L1/L2 lines, and thousands of resident wavefronts hide their latency (no LDS staging needed here)
+				const float dt = calc_dt(t, a.cone_angle_constant);
+				occ = occupied_at(pos, a.bitfield, mip_from_dt(dt, pos, a.max_mip));
+			}
+			const uint64_t m = __ballot(occ);
+			if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch] = m;
+			cnt += (uint32_t)__popcll(m);
+			n_chunks = ch + 1;
+			if (__ballot(inside) == 0ull) break; // the whole chunk is past the box: so is everything after it
+		}
+		cnt = min(cnt, N_STEPS);
+	}
+	if (lane == 0) {
+		rs[li].count = cnt;
+		rs[li].flags = n_chunks;
+		scan_in[li] = (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
+	}
+}
+
+// ---- exclusive prefix sum over packed {samples (low 32), rays (high 32)} ------------------------
+static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], uint64_t* sm /* 4 */, uint64_t& block_total) {
+	// each thread owns 4 consecutive elements; returns the exclusive prefix of the thread's first element
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	uint64_t tsum = v[0] + v[1] + v[2] + v[3];
+	uint64_t x = tsum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint64_t y = __shfl_up((unsigned long long)x, d, 64);
+		if (lane >= (uint32_t)d) x += y;
+	}
+	if (lane == 63) sm[wid] = x;
+	__syncthreads();
+	uint64_t woff = 0;
+	for (uint32_t w = 0; w < wid; ++w) woff += sm[w];
+	block_total = sm[0] + sm[1] + sm[2] + sm[3];
+	return woff + x - tsum;
+}
+__global__ void __launch_bounds__(256) k_scan_partials(const uint64_t* __restrict__ in, uint32_t n_max, const uint32_t* __restrict__ n_ptr, uint32_t rank, uint32_t world,
+		uint64_t* __restrict__ partial) {
+	__shared__ uint64_t sm[4];
+	uint32_t n = n_max;
+	if (n_ptr) { const uint32_t R = *n_ptr; n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world); }
+	uint64_t v[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; v[k] = e < n ? in[e] : 0ull; }
+	uint64_t tot;
+	(void)block_excl_scan_1024(v, sm, tot);
+	if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan_top(uint64_t* __restrict__ partial, uint32_t n_blocks, uint32_t* __restrict__ numsteps_counter, uint32_t* __restrict__ ray_counter) {
+	__shared__ uint64_t sm[4];
+	uint64_t v[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { const uint32_t e = threadIdx.x * 4 + k; v[k] = e < n_blocks ? partial[e] : 0ull; }
+	uint64_t tot;
+	uint64_t pre = block_excl_scan_1024(v, sm, tot);
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { const uint32_t e = threadIdx.x * 4 + k; if (e < n_blocks) partial[e] = pre; pre += v[k]; }
+	if (threadIdx.x == 0) { *numsteps_counter = (uint32_t)tot; *ray_counter = (uint32_t)(tot >> 32); }
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint64_t* __restrict__ in, uint32_t n_max, const uint32_t* __restrict__ n_ptr, uint32_t rank, uint32_t world,
+		const uint64_t* __restrict__ partial, uint64_t* __restrict__ out) {
+	__shared__ uint64_t sm[4];
+	uint32_t n = n_max;
+	if (n_ptr) { const uint32_t R = *n_ptr; n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world); }
+	if (blockIdx.x * SCAN_BLOCK >= n) return;
+	uint64_t v[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; v[k] = e < n ? in[e] : 0ull; }
+	uint64_t tot;
+	uint64_t pre = block_excl_scan_1024(v, sm, tot) + partial[blockIdx.x];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; if (e < n) out[e] = pre; pre += v[k]; }
+}
+
+__global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __restrict__ rs, const uint64_t* __restrict__ masks, const uint64_t* __restrict__ scan_out) {
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
+	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
+	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
+	const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (li >= ray_end - ray_begin) return;
+	const RaySetup r = rs[li];
+	const uint32_t count = r.count;
+	if (count == 0) return;
+	const uint64_t so = scan_out[li];
+	const uint32_t base = (uint32_t)so, slot = (uint32_t)(so >> 32);
+	const bool fits = base + count <= max_samples; // testbed_nerf.cu:813-815: rays past the cap are dropped
+	if (lane == 0) {
+		a.ray_indices_out[slot] = ray_begin + li;
+		ngp_ray rr; rr.o[0] = r.o[0]; rr.o[1] = r.o[1]; rr.o[2] = r.o[2]; rr.d[0] = r.d[0]; rr.d[1] = r.d[1]; rr.d[2] = r.d[2];
+		a.rays_out[slot] = rr;
+		a.numsteps_out[slot * 2 + 0] = fits ? count : 0u;
+		a.numsteps_out[slot * 2 + 1] = base;
+	}
+	if (!fits) return;
+	const Box aabb(a.aabb);
+	const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
+	const f3 wd = warp_direction(rdn);
+	float* co = a.coords_out + (size_t)base * 7;
+	uint32_t written = 0;
+	const uint32_t n_chunks = r.flags;
+	for (uint32_t ch = 0; ch < n_chunks && written < count; ++ch) {
+		const uint64_t m = masks[(size_t)li * LAT_MAX_CHUNKS + ch];
+		const uint32_t k = written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		if (((m >> lane) & 1ull) && k < count) {
+			const float t = lattice_t(r, ch * 64 + lane, a.cone_angle_constant);
+			const f3 pos = ro + t * rdn;
+			const float dt = calc_dt(t, a.cone_angle_constant);
+			const f3 wp = warp_position(pos, aabb);
+			float* c = co + (size_t)k * 7;
+			c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+		}
+		written += (uint32_t)__popcll(m);
+	}
+}
+
 // 64^3 coarse mask of cascade 0: bit b of word w = (fine bitfield byte 32*w + b) != 0
 __global__ void k_build_coarse_mask(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,6 +750,26 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 		hipLaunchKernelGGL(k_generate_training_samples_v2, dim3(blocks(max_rays_this_rank, K1_THREADS)), dim3(K1_THREADS), 0, s, a, coarse_mask);
 	else
 		hipLaunchKernelGGL(k_generate_training_samples, dim3(blocks(max_rays_this_rank, 128)), dim3(128), 0, s, a);
+}
+size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
+	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8 + 8 + 8) + 1024 * 8;
+}
+// K1 as five small launches: setup, count (wave per ray), 3-kernel prefix sum, write (wave per ray)
+void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, const uint32_t* coarse_mask, void* scratch) {
+	if (max_local_rays == 0) return;
+	char* p = (char*)scratch;
+	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
+	uint64_t* masks = (uint64_t*)p; p += (size_t)max_local_rays * LAT_MAX_CHUNKS * 8;
+	uint64_t* scan_in = (uint64_t*)p; p += (size_t)max_local_rays * 8;
+	uint64_t* scan_out = (uint64_t*)p; p += (size_t)max_local_rays * 8;
+	uint64_t* partial = (uint64_t*)p;
+	const uint32_t n_scan_blocks = blocks(max_local_rays, SCAN_BLOCK);
+	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128)), dim3(128), 0, s, a, rs);
+	hipLaunchKernelGGL(k1_count, dim3(blocks(max_local_rays, 4)), dim3(256), 0, s, a, rs, masks, scan_in);
+	hipLaunchKernelGGL(k_scan_partials, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, max_local_rays, a.n_rays_ptr, a.rank, a.world_size, partial);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, partial, n_scan_blocks, a.numsteps_counter, a.ray_counter);
+	hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, max_local_rays, a.n_rays_ptr, a.rank, a.world_size, partial, scan_out);
+	hipLaunchKernelGGL(k1_write, dim3(blocks(max_local_rays, 4)), dim3(256), 0, s, a, rs, masks, scan_out);
 }
 void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse) {
 	hipLaunchKernelGGL(k_build_coarse_mask, dim3(blocks(COARSE_WORDS, 256)), dim3(256), 0, s, bitfield, coarse);

@@ -428,9 +428,25 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
 	static uint32_t* s_coarse = nullptr;
+	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	if (!s_coarse && dev_alloc(&s_coarse, 8192)) return 1;
 	launch_build_coarse_mask((hipStream_t)stream, bitfield, s_coarse);
-	launch_generate_training_samples((hipStream_t)stream, a, n_rays / world_size + 1, s_coarse);
+	const uint32_t max_local = n_rays / world_size + 1;
+	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
+		launch_generate_training_samples((hipStream_t)stream, a, max_local, s_coarse);
+	} else {
+		REQUIRE(n_rays_ptr == nullptr, "stand-alone lattice K1: pass n_rays as an immediate");
+		const size_t need = k1_lattice_scratch_bytes(max_local);
+		if (need > s_scratch_bytes) {
+			HIPCHK(hipDeviceSynchronize());
+			if (s_scratch) HIPCHK(hipFree(s_scratch));
+			s_scratch = nullptr; s_scratch_bytes = 0;
+			if (dev_alloc(&s_scratch, need)) return 1;
+			s_scratch_bytes = need;
+		}
+		// the per-wave atomics of the sequential kernel accumulate into the counters; the scan overwrites them
+		launch_generate_training_samples_lattice((hipStream_t)stream, a, max_local, s_coarse, s_scratch);
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -507,6 +523,7 @@ struct ngp_nerf {
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
+	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
 	uint32_t* coarse_mask = nullptr; // 64^3 any-occupied mask of cascade 0 for K1 (32 KiB)
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
 	// host-side deterministic state (no device read-back needed)
@@ -531,7 +548,8 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192)) { delete t; return 1; }
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192) ||
+		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays / o->world_size + 1))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
@@ -548,7 +566,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->k1_scratch};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -649,7 +667,9 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
 	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
-	{ ProfScope ps(P_K1, s); launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1, t->coarse_mask); }
+	{ ProfScope ps(P_K1, s);
+	  if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1, t->coarse_mask);
+	  else launch_generate_training_samples_lattice(s, k1, t->max_rays / o.world_size + 1, t->coarse_mask, t->k1_scratch); }
 	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
 	{ ProfScope ps(P_K2_INFERENCE, s);
 	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }

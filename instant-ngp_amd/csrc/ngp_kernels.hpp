@@ -8,7 +8,7 @@ namespace ngp {
 
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
-enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16 };
+enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16 };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
 struct TrainCounters {
@@ -61,6 +61,10 @@ struct K3Args {
 };
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank, const uint32_t* coarse_mask);
+// per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
+struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; };
+size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
+void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, const uint32_t* coarse_mask, void* scratch);
 void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse_8192_words);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride);

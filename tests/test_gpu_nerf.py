@@ -69,10 +69,19 @@ def _run_k1(ora, hip, scene, n_rays, max_samples, rank=0, world=1):
     return o, d
 
 
+def _dbg(hip, flags):
+    A.check(hip, hip.ngp_debug_set_flags(flags))
+
+
 @pytest.mark.parametrize("n_rays,rank,world", [(4096, 0, 1), (1000, 0, 1), (4096, 1, 2)])
-def test_k1_sample_generation_bit_exact(ora, hip, scene, n_rays, rank, world):
+def test_k1_sequential_kernel_bit_exact(ora, hip, scene, n_rays, rank, world):
+    """The thread-per-ray kernel replays the reference's float recurrence: bit-exact rays, counts and coordinates."""
     max_samples = 1 << 20
-    o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+    _dbg(hip, 1)  # DBG_K1_REFERENCE_LAYOUT
+    try:
+        o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+    finally:
+        _dbg(hip, 0)
     n_o = o["ray_counter"].value
     cnt = d["counters"].cpu().numpy().astype(np.uint32)
     assert n_o > 0 and cnt[0] == n_o and cnt[1] == o["numsteps_counter"].value
@@ -85,7 +94,6 @@ def test_k1_sample_generation_bit_exact(ora, hip, scene, n_rays, rank, world):
     assert np.array_equal(ri[order_d], o["ray_indices"][:n_o][order_o])
     assert np.array_equal(ns[order_d, 0], o["numsteps"][:n_o][order_o, 0])
     assert np.array_equal(rays[order_d].view(np.uint32), o["rays"][:n_o][order_o].view(np.uint32))
-    # spans are disjoint and cover [0, total)
     spans = sorted((int(b), int(b + k)) for k, b in ns)
     assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1)) and spans[-1][1] == cnt[1]
     for a, b in zip(order_d, order_o):
@@ -93,13 +101,56 @@ def test_k1_sample_generation_bit_exact(ora, hip, scene, n_rays, rank, world):
         assert np.array_equal(coords[bd:bd + k].view(np.uint32), o["coords"][bo:bo + k].view(np.uint32))
 
 
+@pytest.mark.parametrize("n_rays,rank,world", [(4096, 0, 1), (1000, 0, 1), (4096, 1, 2)])
+def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
+    """Production K1 (one wavefront per ray over the closed-form lattice t_j = from_stepping_space(n' + j)).
+    Deterministic output (ray-index order, prefix-sum spans). Versus the sequential recurrence: rays and ray geometry
+    bit-exact; >= 99.5 % of rays with identical sample counts, >= 90 % bit-identical, every matching-count ray within
+    2e-6 absolute of the reference positions (<= 2 ulp of t in [0, 2.5]), total sample count within 0.1 %."""
+    max_samples = 1 << 20
+    o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+    n_o = o["ray_counter"].value
+    cnt = d["counters"].cpu().numpy().astype(np.uint32)
+    n_d = int(cnt[0])
+    ri = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_d]
+    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_d]
+    rays = d["rays"].cpu().numpy()[:n_d]
+    coords = d["coords"].cpu().numpy()
+    assert np.all(np.diff(ri.astype(np.int64)) > 0), "ray slots must be in ray-index order"
+    assert np.array_equal(ns[:, 1], np.concatenate([[0], np.cumsum(ns[:, 0])[:-1]]).astype(np.uint32)), "spans must be the prefix sum of the counts"
+    assert int(ns[:, 0].sum()) == int(cnt[1])
+    ref = {int(r): i for i, r in enumerate(o["ray_indices"][:n_o])}
+    both = [i for i in range(n_d) if int(ri[i]) in ref]
+    assert len(both) >= 0.998 * max(n_o, n_d) and abs(n_d - n_o) <= 0.002 * n_o + 1
+    assert abs(int(cnt[1]) - int(o["numsteps_counter"].value)) <= 1e-3 * o["numsteps_counter"].value
+    same_count = exact = 0
+    for i in both:
+        j = ref[int(ri[i])]
+        assert np.array_equal(rays[i].view(np.uint32), o["rays"][j].view(np.uint32))
+        k, bd = int(ns[i, 0]), int(ns[i, 1]); ko, bo = int(o["numsteps"][j, 0]), int(o["numsteps"][j, 1])
+        if k != ko:
+            assert abs(k - ko) <= 2
+            continue
+        same_count += 1
+        a, b = coords[bd:bd + k], o["coords"][bo:bo + k]
+        if np.array_equal(a.view(np.uint32), b.view(np.uint32)):
+            exact += 1
+        else:
+            assert np.abs(a - b).max() <= 2e-6, (int(ri[i]), np.abs(a - b).max())
+    print(f"rays {len(both)}  same sample count {same_count}  bit-identical {exact}")
+    assert same_count >= 0.995 * len(both) and exact >= 0.90 * len(both)
+
+
 def test_k1_sample_cap(ora, hip, scene):
-    """rays whose span would exceed max_samples are dropped (testbed_nerf.cu:813-815); which ones is order dependent"""
+    """rays whose span would exceed max_samples are dropped (testbed_nerf.cu:813-815) but still counted"""
     o, d = _run_k1(ora, hip, scene, 4096, 20000)
     cnt = d["counters"].cpu().numpy().astype(np.uint32)
-    assert cnt[1] == o["numsteps_counter"].value  # the counter still counts every marched sample
+    assert abs(int(cnt[1]) - int(o["numsteps_counter"].value)) <= 1e-3 * o["numsteps_counter"].value
     ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:cnt[0]]
-    assert (ns[:, 0] + ns[:, 1] <= 20000).all() and cnt[0] < o["ray_counter"].value + 200
+    kept = ns[:, 0] > 0
+    assert (ns[kept, 0] + ns[kept, 1] <= 20000).all() and kept.sum() > 10 and (~kept).sum() > 10
+    # dropped rays form a suffix in ray order (the span base is monotone), exactly like the sequential reference
+    assert not kept[np.argmin(kept):].any()
 
 
 def test_k3_loss_and_compaction(ora, hip, scene):
@@ -119,11 +170,16 @@ def test_k3_loss_and_compaction(ora, hip, scene):
     ora.ora_k_compute_loss(n_rays, n_act, aabb, rng, B, C.c_float(128.0), bg, 0, 1, 0, n_img, scene["M"], ptr(net_u), 4, C.byref(o_cnt), ptr(o["ray_indices"]), ptr(o["rays"]),
                            ptr(o_ns), ptr(o["coords"]), ptr(o_cc), ptr(o_dl), 4, A.LOSS_HUBER, ptr(o_loss), A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, C.c_float(scene["mean"]), C.c_float(0.1))
     # device: network outputs must be laid out by the DEVICE's sample order -> permute per ray
-    ri_d = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_act]; ns_d = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_act]
     pos_o = {int(r): i for i, r in enumerate(o["ray_indices"][:n_act])}
     net_d = np.zeros_like(net_u)
-    for i in range(n_act):
-        j = pos_o[int(ri_d[i])]
+    n_act_d = int(d["counters"].cpu()[0])
+    ri_d = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_act_d]; ns_d = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_act_d]
+    same = np.zeros(n_act_d, bool)
+    for i in range(n_act_d):
+        j = pos_o.get(int(ri_d[i]))
+        if j is None or int(ns_d[i, 0]) != int(o["numsteps"][j, 0]):
+            continue  # the (rare) rays where the closed-form march and the sequential recurrence disagree by a sample
+        same[i] = True
         k, bd, bo = int(ns_d[i, 0]), int(ns_d[i, 1]), int(o["numsteps"][j, 1])
         net_d[bd:bd + k] = net_u[bo:bo + k]
     netd = torch.from_numpy(net_d.view(np.int16)).cuda()
@@ -135,21 +191,23 @@ def test_k3_loss_and_compaction(ora, hip, scene):
                                        dptr(d["ray_indices"]), dptr(d["rays"]), dptr(d["numsteps"]), dptr(d["coords"]), dptr(cc), dptr(dl), 4, A.LOSS_HUBER, dptr(loss),
                                        A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
     torch.cuda.synchronize()
-    assert int(cnt.cpu()[0]) == o_cnt.value  # compacted sample count: integer-exact (early-out T < 1e-4 is far from ties here)
-    ns_d2 = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_act]
+    assert abs(int(cnt.cpu()[0]) - o_cnt.value) <= 2e-3 * o_cnt.value + 8  # compacted sample count (rays with differing march counts excluded below)
+    ns_d2 = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_act_d]
     cc_h = cc.cpu().numpy(); dl_h = dl.cpu().numpy().view(np.uint16)
     n_cmp = 0
-    for i in range(n_act):
+    for i in range(n_act_d):
+        if not same[i]:
+            continue
         j = pos_o[int(ri_d[i])]
         kd, bd = int(ns_d2[i, 0]), int(ns_d2[i, 1]); ko, bo = int(o_ns[j, 0]), int(o_ns[j, 1])
         assert kd == ko
-        assert np.array_equal(cc_h[bd:bd + kd].view(np.uint32), o_cc[bo:bo + ko].view(np.uint32))  # compacted coords: copies
+        assert np.abs(cc_h[bd:bd + kd] - o_cc[bo:bo + ko]).max() <= 2e-6  # compacted coords: copies of the K1 samples
         a, b = half_to_f32(dl_h[bd:bd + kd]), half_to_f32(o_dl[bo:bo + ko])
         # __expf / powf differ from glibc in the last ulps; dL/doutput is a half: allow 2 half-ulps relative + tiny abs
-        assert np.allclose(a, b, rtol=4e-3, atol=2e-6), (i, np.abs(a - b).max())
+        assert np.allclose(a, b, rtol=6e-3, atol=4e-6), (i, np.abs(a - b).max())
         n_cmp += kd
     assert n_cmp > 1000
-    assert abs(float(loss.cpu()[0]) - float(o_loss.sum())) <= 1e-4 * abs(float(o_loss.sum())) + 1e-7
+    assert abs(float(loss.cpu()[0]) - float(o_loss.sum())) <= 5e-3 * abs(float(o_loss.sum())) + 1e-7
 
 
 def test_k3_batch_clamp(ora, hip, scene):
@@ -169,8 +227,9 @@ def test_k3_batch_clamp(ora, hip, scene):
                                        dptr(d["ray_indices"]), dptr(d["rays"]), dptr(d["numsteps"]), dptr(d["coords"]), dptr(cc), dptr(dl), 4, A.LOSS_HUBER, dptr(loss),
                                        A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
     torch.cuda.synchronize()
+    total = int(d["counters"].cpu()[1])
     assert int(cnt.cpu()[0]) == total and total > B
-    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:o["ray_counter"].value]
+    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:int(d["counters"].cpu()[0])]
     assert int(np.minimum(ns[:, 0] + ns[:, 1], B).max()) == B and (ns[:, 0][ns[:, 1] >= B] == 0).all()
     assert ((ns[:, 0] + ns[:, 1])[ns[:, 0] > 0] <= B).all()
 
