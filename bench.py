@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 18)
     ap.add_argument("--profile-steps", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-views", type=int, default=4, help="held-out views rendered (untimed) for PSNR, run.py --test_transforms procedure")
+    ap.add_argument("--eval-res", type=int, default=400)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +159,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
                 "kernel_ms_per_step": {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
 
+    psnr = eval_psnr(lib, nerf, args) if (rank == 0 and args.eval_views > 0) else None
+
     # ---- CPU baseline: the oracle (port) runs ONE bounded step from the same trained state --------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -172,12 +176,41 @@ def main():
                                    "batch 2^18 samples per GPU per step, rays/step adaptive (cap 2^18)", "parallelism": f"dp{world}",
                        "pretrain_steps": args.pretrain, "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
                        "samples_per_ray_compacted": samples / max(rays, 1), "loss": s1.loss,
-                       "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step},
+                       "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
+                       "test_psnr_db": psnr, "test_psnr_at_step": (s3.training_step if psnr is not None else None)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def eval_psnr(lib, nerf, args):
+    """scripts/run.py:257-317: render held-out views (black background, snap_to_pixel_centers, min_transmittance 1e-4,
+    EMA weights), convert to sRGB, clip, PSNR against the ground-truth view composited on black."""
+    import synth_scene
+    res = args.eval_res
+    gts, xforms, meta, _ = synth_scene.make_dataset(args.eval_views, res, "cuda", phase=1.234)
+    mse = []
+    frame = torch.zeros((res * res, 4), dtype=torch.float32, device="cuda")
+    for gt, xf in zip(gts, xforms):
+        rp = A.RenderParams()
+        rp.resolution[0] = rp.resolution[1] = res
+        rp.focal_length[0], rp.focal_length[1] = meta["focal_length"]
+        rp.screen_center[0] = rp.screen_center[1] = 0.5
+        for k in range(12):
+            rp.camera[k] = float(xf[k])
+        rp.lens_mode = 0; rp.spp_index = 0; rp.snap_to_pixel_centers = 1; rp.min_transmittance = 1e-4; rp.near_distance = 0.0
+        rp.use_inference_params = 1
+        rp.render_aabb = A.scene_aabb(1)
+        A.check(lib, lib.ngp_nerf_render(nerf, None, C.byref(rp), C.c_void_p(frame.data_ptr()), None))
+        torch.cuda.synchronize()
+        lin = frame[:, :3].clamp(0, 1)
+        srgb = torch.where(lin < 0.0031308, 12.92 * lin, 1.055 * lin.clamp_min(1e-12) ** (1 / 2.4) - 0.055).clamp(0, 1)
+        g = gt.reshape(-1, 4).float() / 255.0                     # sRGB-encoded, premultiplied by a {0,1} alpha => over black
+        mse.append(float(((srgb - g[:, :3]) ** 2).mean()))
+    m = sum(mse) / len(mse)
+    return -10.0 * math.log10(m) if m > 0 else None
 
 
 def run_cpu_baseline(lib, model, nerf, cfg, opts, images, M, X, n_img, st, args):

@@ -523,6 +523,7 @@ struct ngp_nerf {
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
+	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
 	uint32_t* coarse_mask = nullptr; // 64^3 any-occupied mask of cascade 0 for K1 (32 KiB)
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
@@ -566,7 +567,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->k1_scratch};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -754,4 +755,38 @@ extern "C" int ngp_nerf_set_rays_per_batch(ngp_nerf* t, uint32_t r) {
 }
 extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = pod(t->rng); *grid_rng = pod(t->density_grid_rng); return 0; }
 
-extern "C" int ngp_nerf_render(ngp_nerf*, void*, const ngp_render_params*, float*, float*) { return fail("ngp_nerf_render: not built yet"); }
+// Testbed::render_nerf (testbed_nerf.cu:1894-2149): one spp of a frame into premultiplied linear RGBA + depth
+extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_params* rp, float* frame, float* depth) {
+	REQUIRE(t && rp && frame, "render: null argument");
+	REQUIRE(rp->lens_mode == NGP_LENS_PERSPECTIVE || rp->lens_mode == NGP_LENS_OPENCV, "render: only Perspective / OpenCV lenses are implemented");
+	hipStream_t s = (hipStream_t)stream;
+	constexpr uint32_t TILE = 1u << 18;
+	if (!t->r_rays) {
+		if (dev_alloc(&t->r_rays, TILE) || dev_alloc(&t->r_masks, (size_t)TILE * RENDER_MAX_CHUNKS) || dev_alloc(&t->r_alive, TILE) || dev_alloc(&t->r_n_alive, 1) ||
+			dev_alloc(&t->r_coords, (size_t)TILE * RENDER_STEPS * 7) || dev_alloc(&t->r_out, (size_t)TILE * RENDER_STEPS * 4)) return 1;
+	}
+	RenderArgs a;
+	a.p = *rp; a.train_aabb = t->aabb; a.bitfield = t->bitfield; a.max_mip = t->opt.max_cascade; a.cone_angle = t->opt.cone_angle_constant;
+	a.rgb_activation = t->opt.rgb_activation; a.density_activation = t->opt.density_activation; a.linear_colors = t->opt.linear_colors;
+	a.rays = t->r_rays; a.masks = t->r_masks;
+	const uint64_t n_pix = (uint64_t)rp->resolution[0] * rp->resolution[1];
+	for (uint64_t begin = 0; begin < n_pix; begin += TILE) {
+		const uint32_t n = (uint32_t)std::min<uint64_t>(TILE, n_pix - begin);
+		launch_render_setup(s, a, (uint32_t)begin, n);
+		launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
+		uint32_t n_alive = 0;
+		HIPCHK(hipMemcpyAsync(&n_alive, t->r_n_alive, 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s)); // like the reference's per-compaction sync (testbed_nerf.cu:1735-1736)
+		for (uint32_t round = 0; n_alive > 0 && round < (RENDER_MAX_CHUNKS * 64) / RENDER_STEPS + 1; ++round) {
+			launch_render_emit(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords);
+			launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7, n_alive * RENDER_STEPS, nullptr, t->r_out, 4, false, 4);
+			launch_render_composite(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords, t->r_out);
+			launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
+			HIPCHK(hipMemcpyAsync(&n_alive, t->r_n_alive, 4, hipMemcpyDeviceToHost, s));
+			HIPCHK(hipStreamSynchronize(s));
+		}
+		launch_render_finish(s, a, (uint32_t)begin, n, frame, depth);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}

@@ -123,6 +123,32 @@ struct AdamArgs {
 };
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
 
+// ---- renderer (render_kernels.hip) ------------------------------------------------------------
+constexpr uint32_t RENDER_MAX_CHUNKS = 32; // 2048 lattice points per ray
+constexpr uint32_t RENDER_STEPS = 8;       // samples per live ray between compactions (MAX_STEPS_INBETWEEN_COMPACTION, testbed_nerf.cu:53)
+struct RenderRay {  // NerfPayload (nerf_device.cuh:145-153) + accumulators
+	float o[3], d[3];
+	float startt, nprime;
+	float rgba[4];
+	float depth, max_weight;
+	uint32_t cursor, n_chunks, alive, n_emitted;
+};
+struct RenderArgs {
+	ngp_render_params p;
+	ngp_aabb train_aabb;
+	const uint8_t* bitfield;
+	uint32_t max_mip;
+	float cone_angle;
+	int rgb_activation, density_activation, linear_colors;
+	RenderRay* rays;
+	uint64_t* masks;
+};
+void launch_render_setup(hipStream_t s, const RenderArgs& a, uint32_t pixel_begin, uint32_t n);
+void launch_render_compact(hipStream_t s, const RenderArgs& a, uint32_t n, uint32_t* alive_list, uint32_t* n_alive);
+void launch_render_emit(hipStream_t s, const RenderArgs& a, uint32_t n_alive_host, const uint32_t* alive_list, const uint32_t* n_alive, float* coords);
+void launch_render_composite(hipStream_t s, const RenderArgs& a, uint32_t n_alive_host, const uint32_t* alive_list, const uint32_t* n_alive, const float* coords, const ngp_half* net_out);
+void launch_render_finish(hipStream_t s, const RenderArgs& a, uint32_t pixel_begin, uint32_t n, float* frame, float* depth);
+
 // ---- optional per-kernel HIP-event timing (bench.py roofline leg) -----------------------------
 enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_COUNT };
 

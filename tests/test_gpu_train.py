@@ -69,3 +69,47 @@ def test_training_converges(hip, ora):
     assert 0 < st.measured_batch_size <= B * 1.5
     assert st.rays_per_batch % 256 == 0 and st.rays_per_batch > 4096  # the grid got sparser -> more rays per batch
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
+
+
+def test_render_matches_oracle(ora, hip):
+    """ngp_nerf_render (lattice march + rounds of batched inference + compositing) vs the oracle's per-pixel renderer
+    (fused_kernels/render_nerf.cuh semantics) on the same trained state. Tolerance: 2e-2 abs on premultiplied linear RGBA
+    (half network outputs, different sample-batch boundaries do not change the result), >= 99 % of pixels within 4e-3."""
+    import torch
+    from common import dptr
+    B = 1 << 16
+    s = _make(ora, hip, B, n_images=8, res=64)
+    A.check(hip, hip.ngp_nerf_train(s["t"], None, 200))
+    # copy the trained state into the oracle trainer
+    p = np.empty(s["om"].n, np.float32)
+    A.check(hip, hip.ngp_model_get_params_host(s["hm"].h, ptr(p), C.c_uint64(p.size)))
+    s["om"].params_fp[:] = p; ora.ora_model_sync_half(s["om"].h)
+    gp, bp = C.c_void_p(), C.c_void_p(); hip.ngp_nerf_density_grid_ptrs(s["t"], C.byref(gp), C.byref(bp), None)
+    grid = np.empty(128 ** 3, np.float32); rt = C.CDLL("libamdhip64.so"); torch.cuda.synchronize()
+    assert rt.hipMemcpy(ptr(grid), gp, C.c_size_t(grid.nbytes), 2) == 0
+    C.memmove(ora.ora_nerf_density_grid(s["ot"]), grid.ctypes.data, grid.nbytes)
+    ora.ora_nerf_update_mean_and_bitfield(s["ot"])
+    bf_d = np.empty(128 ** 3, np.uint8); assert rt.hipMemcpy(ptr(bf_d), bp, C.c_size_t(bf_d.nbytes), 2) == 0
+    bf_o = np.ctypeslib.as_array(C.cast(ora.ora_nerf_bitfield(s["ot"]), C.POINTER(C.c_uint8)), shape=(128 ** 3,))
+    assert (bf_d != bf_o).sum() <= 8  # same grid, the mean (threshold) differs by summation order only
+    res = 40
+    rp = A.RenderParams()
+    rp.resolution[0] = rp.resolution[1] = res
+    M = s["keep"][1]; X = s["keep"][2]
+    rp.focal_length[0] = rp.focal_length[1] = M[0].focal_length[0] * res / M[0].resolution[0]
+    rp.screen_center[0] = rp.screen_center[1] = 0.5
+    for k in range(12):
+        rp.camera[k] = X[3].start[k]
+    rp.lens_mode = 0; rp.spp_index = 0; rp.snap_to_pixel_centers = 1; rp.min_transmittance = 1e-4; rp.near_distance = 0.0; rp.use_inference_params = 0
+    rp.render_aabb = A.scene_aabb(1)
+    f_o = np.zeros((res * res, 4), np.float32); d_o = np.zeros(res * res, np.float32)
+    assert ora.ora_nerf_render(s["ot"], C.byref(rp), ptr(f_o), ptr(d_o)) == 0
+    f_d = torch.zeros((res * res, 4), dtype=torch.float32, device="cuda"); d_d = torch.zeros(res * res, dtype=torch.float32, device="cuda")
+    A.check(hip, hip.ngp_nerf_render(s["t"], None, C.byref(rp), dptr(f_d), dptr(d_d)))
+    torch.cuda.synchronize()
+    f = f_d.cpu().numpy()
+    err = np.abs(f - f_o)
+    print("render: coverage", float((f_o[:, 3] > 0.5).mean()), "max err", float(err.max()), "99th pct", float(np.quantile(err, 0.99)))
+    assert (f_o[:, 3] > 0.5).mean() > 0.05  # the object is visible after 200 steps
+    assert np.quantile(err, 0.99) <= 4e-3 and err.max() <= 2e-2
+    hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
