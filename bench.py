@@ -92,14 +92,19 @@ def main():
     lib.ngp_model_n_params(model, C.byref(n_params), C.byref(n_mlp))
 
     grad_view = cnt_view = None
-    if world > 1:
+    force_dp = os.environ.get("NGP_FORCE_DP", "0") == "1"  # exercise the multi-GPU step (all-reduce of size 1) on one GPU
+    if force_dp and dist is None:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    if world > 1 or force_dp:
         g = C.c_void_p(); lib.ngp_model_param_ptrs(model, None, None, None, C.byref(g))
         grad_view = torch.as_tensor(CudaView(g.value, n_params.value, "<f2"), device="cuda")
         cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(nerf, C.byref(cp))
         cnt_view = torch.as_tensor(CudaView(cp.value, 2, "<i4"), device="cuda")
 
     def step(n=1):
-        if world == 1:
+        if world == 1 and not force_dp:
             A.check(lib, lib.ngp_nerf_train(nerf, None, n))
             return
         for _ in range(n):

@@ -244,6 +244,9 @@ int ngp_k_grid_to_bitfield(void* stream, const float* grid, uint32_t max_cascade
  * counters, rng, scratch arena (train_nerf_step's 11 buffers, testbed_nerf.cu:3014-3040). */
 int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* opts_host, ngp_aabb aabb, ngp_nerf** out);
 void ngp_nerf_destroy(ngp_nerf*);
+/* Update the run-time members (python_api.cu:714-853: near_distance, random_bg_color, cone_angle_constant, colour space,
+ * activations, loss ...). Batch size, max_cascade and rank/world_size are fixed at creation. */
+int ngp_nerf_set_options(ngp_nerf*, const ngp_nerf_options* opts_host);
 /* NerfDataset upload (nerf_loader.cu:749-850 set_training_image; metadata/xforms host arrays;
  * pixels_host[i] points at resolution.x*resolution.y pixels of the given type). */
 int ngp_nerf_set_dataset_host(ngp_nerf*, uint32_t n_images, const ngp_image_meta* metadata_host,
@@ -271,6 +274,8 @@ int ngp_nerf_update_density_grid(ngp_nerf*, void* stream, float decay, uint32_t 
 /* device pointers: density grid (float, 128^3*(max_cascade+1)), bitfield (128^3/8*8), mean (1 float) */
 int ngp_nerf_density_grid_ptrs(ngp_nerf*, float** grid, uint8_t** bitfield, float** mean);
 int ngp_nerf_set_density_grid_host(ngp_nerf*, void* stream, const float* grid_host, uint64_t n);
+/* m_training_step restored by load_snapshot (testbed.cu:5400-5403). */
+int ngp_nerf_set_training_step(ngp_nerf*, uint32_t step);
 
 /* Testbed::render_nerf (testbed_nerf.cu:1894-2149) semantics of the fused per-pixel kernel
  * fused_kernels/render_nerf.cuh:22-184: frame_buffer = premultiplied linear RGBA float4 per pixel,

@@ -1,6 +1,7 @@
 // mini_json.hpp -- a small self-contained JSON reader (objects, arrays, numbers, strings, bools, null,
 // // and /* */ comments) for the network-config files (configs/nerf/*.json) and transforms.json.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -116,6 +117,21 @@ inline bool parse(const char* text, Value& out, std::string& err) {
 	if (ps.p != ps.end) { err = "trailing characters"; return false; }
 	return true;
 }
+
+inline void dump_to(const Value& v, std::string& out) {
+	switch (v.type) {
+		case Value::Null: out += "null"; break;
+		case Value::Bool: out += v.b ? "true" : "false"; break;
+		case Value::Number: { char buf[40]; snprintf(buf, sizeof(buf), "%.17g", v.n); out += buf; break; }
+		case Value::String: {
+			out += '"';
+			for (char c : v.s) { if (c == '"' || c == '\\') { out += '\\'; out += c; } else if (c == '\n') out += "\\n"; else out += c; }
+			out += '"'; break; }
+		case Value::Array: { out += '['; for (size_t i = 0; i < v.arr.size(); ++i) { if (i) out += ','; dump_to(v.arr[i], out); } out += ']'; break; }
+		case Value::Object: { out += '{'; for (size_t i = 0; i < v.obj.size(); ++i) { if (i) out += ','; out += '"' + v.obj[i].first + "\":"; dump_to(v.obj[i].second, out); } out += '}'; break; }
+	}
+}
+inline std::string dump(const Value& v) { std::string s; dump_to(v, s); return s; }
 
 // RFC 7386 merge-patch, as used for the "parent" inheritance of network configs (testbed.cu:86-97)
 inline void merge_patch(Value& target, const Value& patch) {

@@ -564,6 +564,14 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	*out = t;
 	return 0;
 }
+// runtime-tunable members of Testbed::m_nerf (python_api.cu:714-853): everything except the sharding and batch size
+extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
+	REQUIRE(t && o, "set_options: null argument");
+	REQUIRE(o->target_batch_size == t->opt.target_batch_size && o->rank == t->opt.rank && o->world_size == t->opt.world_size && o->max_cascade == t->opt.max_cascade,
+		"set_options: batch size, max_cascade and sharding are fixed at creation");
+	t->opt = *o;
+	return 0;
+}
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
@@ -751,6 +759,12 @@ extern "C" int ngp_nerf_scratch_ptrs(ngp_nerf* t, uint32_t** ray_indices, ngp_ra
 }
 extern "C" int ngp_nerf_set_rays_per_batch(ngp_nerf* t, uint32_t r) {
 	HIPCHK(hipMemcpy(&t->counters->rays_per_batch, &r, 4, hipMemcpyHostToDevice));
+	return 0;
+}
+// load_snapshot restores m_training_step (testbed.cu:5400-5403): keeps the prep cadence / step-0 grid marking consistent
+extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
+	t->training_step = step; t->prep_skip_counter = step; t->ema_step = step;
+	HIPCHK(hipMemcpy(&t->counters->training_step, &step, 4, hipMemcpyHostToDevice));
 	return 0;
 }
 extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = pod(t->rng); *grid_rng = pod(t->density_grid_rng); return 0; }

@@ -1,0 +1,125 @@
+// pyngp.cpp -- pybind11 module `pyngp`: the drop-in boundary of scripts/run.py (reference src/python_api.cu:306-968).
+// Property / method / enum names follow the reference binding so that `import pyngp as ngp` scripts keep working for the
+// NeRF path; members that belong to out-of-scope subsystems (GUI, VR, DLSS, SDF, image, volume, mesh export) raise.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+#include <pybind11/eval.h>
+
+#include "testbed.hpp"
+
+namespace py = pybind11;
+using namespace ngp_host;
+
+static py::array_t<float> render_to_numpy(Testbed& t, int w, int h, int spp, bool linear) {
+	std::vector<float> px;
+	{
+		py::gil_scoped_release release;
+		px = t.render(w, h, spp, linear);
+	}
+	py::array_t<float> out({h, w, 4});
+	std::memcpy(out.mutable_data(), px.data(), px.size() * sizeof(float));
+	return out;
+}
+
+PYBIND11_MODULE(pyngp, m) {
+	m.doc() = "MI355X-native instant-ngp NeRF training/rendering (pyngp-compatible API surface)";
+
+	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
+		.value("Volume", ETestbedMode::Volume).value("None", ETestbedMode::None).export_values();
+	py::enum_<ETrainMode>(m, "TrainMode").value("Nerf", ETrainMode::Nerf).value("Rfl", ETrainMode::Rfl).value("RflRelax", ETrainMode::RflRelax).export_values();
+	py::enum_<EColorSpace>(m, "ColorSpace").value("Linear", EColorSpace::Linear).value("SRGB", EColorSpace::SRGB).value("VisPosNeg", EColorSpace::VisPosNeg).export_values();
+	py::enum_<ETonemapCurve>(m, "TonemapCurve").value("Identity", ETonemapCurve::Identity).value("ACES", ETonemapCurve::ACES).value("Hable", ETonemapCurve::Hable)
+		.value("Reinhard", ETonemapCurve::Reinhard).export_values();
+
+	py::class_<Testbed> testbed(m, "Testbed");
+	py::class_<ImageMetadata>(testbed, "TrainingImageMetadata")
+		.def_readonly("resolution", &ImageMetadata::resolution).def_readonly("focal_length", &ImageMetadata::focal_length)
+		.def_readonly("principal_point", &ImageMetadata::principal_point);
+	py::class_<NerfDataset>(testbed, "NerfDataset")
+		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
+		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
+		.def_readonly("scale", &NerfDataset::scale).def_readonly("offset", &NerfDataset::offset).def_readonly("paths", &NerfDataset::paths)
+		.def_readonly("is_hdr", &NerfDataset::is_hdr);
+	py::class_<NerfTraining>(testbed, "NerfTraining")
+		.def_readwrite("near_distance", &NerfTraining::near_distance).def_readwrite("train_mode", &NerfTraining::train_mode)
+		.def_readwrite("random_bg_color", &NerfTraining::random_bg_color).def_readwrite("linear_colors", &NerfTraining::linear_colors)
+		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers).def_readwrite("density_grid_decay", &NerfTraining::density_grid_decay)
+		.def_readonly("dataset", &NerfTraining::dataset);
+	py::class_<Nerf>(testbed, "Nerf")
+		.def_readwrite("sharpen", &Nerf::sharpen).def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
+		.def_readwrite("render_min_transmittance", &Nerf::render_min_transmittance).def_readonly("training", &Nerf::training);
+
+	testbed
+		.def(py::init<>())
+		.def(py::init([](ETestbedMode) { return std::make_unique<Testbed>(); }))
+		.def("load_file", &Testbed::load_file, py::call_guard<py::gil_scoped_release>())
+		.def("load_training_data", &Testbed::load_training_data, "Load training data from a given path.")
+		.def("reload_network_from_file", &Testbed::reload_network_from_file, py::arg("path") = "")
+		.def("reset", &Testbed::reset_network).def("reset_network", &Testbed::reset_network)
+		.def("load_snapshot", &Testbed::load_snapshot).def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
+		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())
+		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>())
+		.def("want_repl", &Testbed::want_repl)
+		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view)
+		.def("set_nerf_camera_matrix", [](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+			if (a.size() < 12) throw std::runtime_error{"set_nerf_camera_matrix expects a 3x4 matrix"};
+			std::array<float, 12> mm; for (int i = 0; i < 12; ++i) mm[i] = a.data()[i];
+			t.set_nerf_camera_matrix(mm);
+		})
+		.def("render", [](Testbed& t, int w, int h, int spp, bool linear, float, float, float, float) { return render_to_numpy(t, w, h, spp, linear); },
+			py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
+			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
+		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error{"init_window: GUI is out of scope of this build (headless MI355X path)"}; },
+			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
+		.def("init_vr", [](Testbed&) { throw std::runtime_error{"init_vr: VR is out of scope of this build"}; })
+		.def("compute_and_save_marching_cubes_mesh", [](Testbed&, py::args, py::kwargs) { throw std::runtime_error{"marching cubes export is out of scope of this build"}; })
+		.def_readwrite("root_dir", &Testbed::root_dir)
+		.def_readwrite("mode", &Testbed::mode)
+		.def_readwrite("shall_train", &Testbed::shall_train)
+		.def_readonly("training_step", &Testbed::training_step)
+		.def_readonly("loss", &Testbed::loss)
+		.def_readwrite("exposure", &Testbed::exposure)
+		.def_readwrite("background_color", &Testbed::background_color)
+		.def_readwrite("snap_to_pixel_centers", &Testbed::snap_to_pixel_centers)
+		.def_readwrite("render_with_lens_distortion", &Testbed::render_with_lens_distortion)
+		.def_readwrite("render_ground_truth", &Testbed::render_ground_truth)
+		.def_readwrite("color_space", &Testbed::color_space)
+		.def_readwrite("tonemap_curve", &Testbed::tonemap_curve)
+		.def_readwrite("fov_axis", &Testbed::fov_axis)
+		.def_property("fov", &Testbed::fov, &Testbed::set_fov)
+		.def_readwrite("training_batch_size", &Testbed::training_batch_size)
+		.def_readwrite("seed", &Testbed::seed)
+		.def_property_readonly("nerf", [](Testbed& t) -> Nerf& { return t.nerf; }, py::return_value_policy::reference_internal)
+		.def_property_readonly("rays_per_batch", [](Testbed& t) { return t.stats().rays_per_batch; })
+		.def_property_readonly("measured_batch_size", [](Testbed& t) { return t.stats().measured_batch_size; });
+
+	// decoder hook for non-PNG images (the fox capture ships JPEGs): Pillow, if importable
+	m.def("_set_image_decoder", [](py::function fn) {
+		Testbed::s_fallback_decoder = [fn](const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
+			py::gil_scoped_acquire gil;
+			py::object r = fn(path);
+			if (r.is_none()) return false;
+			auto arr = r.cast<py::array_t<uint8_t, py::array::c_style | py::array::forcecast>>();
+			if (arr.ndim() != 3 || arr.shape(2) != 4) return false;
+			h = (int)arr.shape(0); w = (int)arr.shape(1);
+			rgba.assign(arr.data(), arr.data() + (size_t)w * h * 4);
+			return true;
+		};
+	});
+	py::exec(R"(
+def _pil_decoder(path):
+    try:
+        from PIL import Image
+        import numpy as np
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGBA'), dtype=np.uint8))
+    except Exception:
+        return None
+)", m.attr("__dict__"));
+	m.attr("_set_image_decoder")(m.attr("_pil_decoder"));
+	// drop the Python callable before the interpreter is finalised (static storage outlives the GIL)
+	py::module_::import("atexit").attr("register")(py::cpp_function([]() { Testbed::s_fallback_decoder = nullptr; }));
+	// root_dir default: the package directory that holds configs/
+	m.attr("__package_dir__") = py::module_::import("os").attr("path").attr("dirname")(m.attr("__file__"));
+	Testbed::s_default_root_dir = m.attr("__package_dir__").cast<std::string>();
+}

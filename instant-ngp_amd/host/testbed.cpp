@@ -1,0 +1,501 @@
+// testbed.cpp -- see testbed.hpp.  Host logic only; every device operation is a C-ABI call.
+#include "testbed.hpp"
+
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace fs = std::filesystem;
+
+namespace ngp_host {
+
+ImageDecoder Testbed::s_fallback_decoder;
+std::string Testbed::s_default_root_dir;
+
+#define NGP_CHECK(x) do { if ((x) != 0) throw std::runtime_error{std::string{ngp_last_error()}}; } while (0)
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error{std::string{#x ": "} + hipGetErrorString(e_)}; } while (0)
+
+static std::string read_text(const fs::path& p) {
+	std::ifstream f{p, std::ios::binary};
+	if (!f) throw std::runtime_error{"File '" + p.string() + "' does not exist."};
+	std::stringstream ss; ss << f.rdbuf();
+	return ss.str();
+}
+static std::string lower(std::string s) { for (auto& c : s) c = (char)tolower(c); return s; }
+
+// ---- minimal PNG reader (8-bit gray / gray+alpha / RGB / RGBA, non-interlaced) on top of zlib ----
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
+	std::ifstream f{path, std::ios::binary};
+	if (!f) return false;
+	std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	if (buf.size() < 33 || memcmp(buf.data(), sig, 8) != 0) return false;
+	size_t pos = 8;
+	int depth = 0, ctype = 0, interlace = 0;
+	std::vector<uint8_t> idat;
+	while (pos + 12 <= buf.size()) {
+		const uint32_t len = be32(&buf[pos]);
+		const std::string type((const char*)&buf[pos + 4], 4);
+		const uint8_t* data = &buf[pos + 8];
+		if (pos + 12 + len > buf.size()) return false;
+		if (type == "IHDR") { w = (int)be32(data); h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+		else if (type == "IDAT") idat.insert(idat.end(), data, data + len);
+		else if (type == "IEND") break;
+		pos += 12 + len;
+	}
+	if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 4 || ctype == 6)) return false;
+	const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : 4;
+	const size_t stride = (size_t)w * ch;
+	std::vector<uint8_t> raw((stride + 1) * h);
+	uLongf out_len = (uLongf)raw.size();
+	if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return false;
+	std::vector<uint8_t> img(stride * h);
+	for (int y = 0; y < h; ++y) {
+		const uint8_t ft = raw[(stride + 1) * y];
+		const uint8_t* src = &raw[(stride + 1) * y + 1];
+		uint8_t* dst = &img[stride * y];
+		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+		for (size_t x = 0; x < stride; ++x) {
+			const int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+			int v = src[x];
+			switch (ft) {
+				case 1: v += a; break;
+				case 2: v += b; break;
+				case 3: v += (a + b) >> 1; break;
+				case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+				default: break;
+			}
+			dst[x] = (uint8_t)v;
+		}
+	}
+	rgba.resize((size_t)w * h * 4);
+	for (size_t i = 0; i < (size_t)w * h; ++i) {
+		const uint8_t* p = &img[i * ch];
+		uint8_t* o = &rgba[i * 4];
+		if (ch == 1) { o[0] = o[1] = o[2] = p[0]; o[3] = 255; }
+		else if (ch == 2) { o[0] = o[1] = o[2] = p[0]; o[3] = p[1]; }
+		else if (ch == 3) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 255; }
+		else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
+	}
+	return true;
+}
+
+// natural (numeric-aware) ordering of frame paths, nerf_loader.cu:347-349
+static bool natural_less(const std::string& a, const std::string& b) {
+	size_t i = 0, j = 0;
+	while (i < a.size() && j < b.size()) {
+		if (isdigit((unsigned char)a[i]) && isdigit((unsigned char)b[j])) {
+			size_t ie = i, je = j;
+			while (ie < a.size() && isdigit((unsigned char)a[ie])) ++ie;
+			while (je < b.size() && isdigit((unsigned char)b[je])) ++je;
+			const std::string na = a.substr(i, ie - i), nb = b.substr(j, je - j);
+			const size_t za = na.find_first_not_of('0'), zb = nb.find_first_not_of('0');
+			const std::string ta = za == std::string::npos ? "0" : na.substr(za), tb = zb == std::string::npos ? "0" : nb.substr(zb);
+			if (ta.size() != tb.size()) return ta.size() < tb.size();
+			if (ta != tb) return ta < tb;
+			i = ie; j = je;
+		} else {
+			if (a[i] != b[j]) return a[i] < b[j];
+			++i; ++j;
+		}
+	}
+	return a.size() - i < b.size() - j;
+}
+
+// ------------------------------------------------------------------------------------------------
+Testbed::Testbed() {
+	root_dir = s_default_root_dir.empty() ? fs::current_path().string() : s_default_root_dir;
+}
+Testbed::~Testbed() {
+	destroy_trainer();
+	if (m_frame_dev) (void)hipFree(m_frame_dev);
+}
+void Testbed::destroy_trainer() {
+	if (m_nerf) { ngp_nerf_destroy(m_nerf); m_nerf = nullptr; }
+	if (m_model) { ngp_model_destroy(m_model); m_model = nullptr; }
+}
+
+// load_network_config with recursive "parent" merge-patch, testbed.cu:86-97, 254-310
+static mini_json::Value load_config_recursive(const fs::path& path, int depth = 0) {
+	if (depth > 8) throw std::runtime_error{"network config: parent chain too deep"};
+	mini_json::Value v; std::string err;
+	if (!mini_json::parse(read_text(path).c_str(), v, err)) throw std::runtime_error{"network config '" + path.string() + "': " + err};
+	if (v.has("parent")) {
+		mini_json::Value parent = load_config_recursive(path.parent_path() / v.str("parent", ""), depth + 1);
+		mini_json::merge_patch(parent, v);
+		return parent;
+	}
+	return v;
+}
+
+void Testbed::reload_network_from_file(const std::string& path_in) {
+	fs::path path = path_in;
+	if (path_in.empty()) path = fs::path(root_dir) / "configs" / "nerf" / "base.json";
+	else if (!fs::exists(path)) {
+		// relative names resolve against configs/<mode>/ (testbed.cu:254-270)
+		fs::path alt = fs::path(root_dir) / "configs" / "nerf" / path_in;
+		if (!fs::exists(alt) && alt.extension().empty()) alt += ".json";
+		if (fs::exists(alt)) path = alt; else throw std::runtime_error{"Network config '" + path_in + "' does not exist."};
+	}
+	m_network_config = load_config_recursive(path);
+	m_network_config_path = path.string();
+	reset_network();
+}
+
+void Testbed::reset_network() {
+	destroy_trainer(); // rebuilt lazily with the current dataset / options
+	training_step = 0;
+	loss = 0.f;
+}
+
+ngp_aabb Testbed::scene_aabb() const { // testbed_nerf.cu:2424-2425
+	const float h = 0.5f * (float)std::min(128, nerf.training.dataset.aabb_scale);
+	return ngp_aabb{{0.5f - h, 0.5f - h, 0.5f - h}, {0.5f + h, 0.5f + h, 0.5f + h}};
+}
+
+ngp_nerf_options Testbed::current_options() const {
+	ngp_nerf_options o; memset(&o, 0, sizeof(o));
+	o.rgb_activation = nerf.training.dataset.is_hdr ? NGP_ACT_EXPONENTIAL : NGP_ACT_LOGISTIC; // testbed_nerf.cu:2354
+	o.density_activation = NGP_ACT_EXPONENTIAL;
+	const std::string lt = lower(m_network_config["loss"].str("otype", "L2")); // string_to_loss_type, testbed.cu:4209
+	o.loss_type = lt == "huber" ? NGP_LOSS_HUBER : lt == "l1" ? NGP_LOSS_L1 : lt == "mape" ? NGP_LOSS_MAPE : lt == "smape" ? NGP_LOSS_SMAPE :
+		lt == "logl1" ? NGP_LOSS_LOGL1 : lt == "relativel2" ? NGP_LOSS_RELATIVE_L2 : NGP_LOSS_L2;
+	o.random_bg_color = nerf.training.random_bg_color;
+	o.snap_to_pixel_centers = nerf.training.snap_to_pixel_centers;
+	o.linear_colors = nerf.training.linear_colors;
+	o.color_space_srgb = color_space == EColorSpace::SRGB;
+	for (int k = 0; k < 3; ++k) o.background_color[k] = background_color[k];
+	o.near_distance = nerf.training.near_distance;
+	o.density_grid_decay = nerf.training.density_grid_decay;
+	o.cone_angle_constant = nerf.cone_angle_constant;
+	o.max_cascade = (uint32_t)nerf.max_cascade;
+	o.target_batch_size = training_batch_size;
+	o.loss_scale = 128.f; // default_loss_scale<__half>, testbed.h:307-311
+	o.seed = seed;
+	o.rank = 0; o.world_size = 1;
+	return o;
+}
+
+void Testbed::ensure_trainer() {
+	if (nerf.training.dataset.n_images == 0) throw std::runtime_error{"No training data loaded."};
+	if (m_network_config.type != mini_json::Value::Object) reload_network_from_file("");
+	if (!m_model) {
+		ngp_model_config cfg;
+		NGP_CHECK(ngp_model_config_from_json(mini_json::dump(m_network_config).c_str(), (uint32_t)nerf.training.dataset.aabb_scale, 0, &cfg));
+		NGP_CHECK(ngp_model_create(&cfg, seed, &m_model));
+	}
+	if (!m_nerf) {
+		ngp_nerf_options o = current_options();
+		NGP_CHECK(ngp_nerf_create(m_model, &o, scene_aabb(), &m_nerf));
+		m_dataset_dirty = true;
+	}
+	if (m_dataset_dirty) {
+		const NerfDataset& d = nerf.training.dataset;
+		std::vector<ngp_image_meta> meta(d.n_images);
+		std::vector<ngp_xform> xf(d.n_images);
+		std::vector<const void*> pix(d.n_images);
+		for (size_t i = 0; i < d.n_images; ++i) {
+			memset(&meta[i], 0, sizeof(ngp_image_meta));
+			meta[i].image_data_type = NGP_IMAGE_BYTE; meta[i].lens_mode = d.metadata[i].lens_mode;
+			for (int k = 0; k < 2; ++k) { meta[i].resolution[k] = d.metadata[i].resolution[k]; meta[i].principal_point[k] = d.metadata[i].principal_point[k]; meta[i].focal_length[k] = d.metadata[i].focal_length[k]; }
+			for (int k = 0; k < 7; ++k) meta[i].lens_params[k] = d.metadata[i].lens_params[k];
+			for (int k = 0; k < 12; ++k) xf[i].start[k] = xf[i].end[k] = d.xforms[i][k];
+			pix[i] = d.pixels[i].data();
+		}
+		NGP_CHECK(ngp_nerf_set_dataset_host(m_nerf, (uint32_t)d.n_images, meta.data(), xf.data(), pix.data()));
+		m_dataset_dirty = false;
+	}
+}
+
+void Testbed::push_options() {
+	if (nerf.training.train_mode != ETrainMode::Nerf) { // RFL modes need the JIT-fused kernel in the reference (testbed_nerf.cu:3091-3094)
+		if (!m_warned_train_mode) { fprintf(stderr, "Warning: JIT fusion is not part of this build, switching to NeRF training mode.\n"); m_warned_train_mode = true; }
+		nerf.training.train_mode = ETrainMode::Nerf;
+	}
+	ngp_nerf_options o = current_options();
+	NGP_CHECK(ngp_nerf_set_options(m_nerf, &o));
+}
+
+// ------------------------------------------------------------------------------------------------
+// dataset: transforms.json (+ images), nerf_loader.cu:273-747
+// ------------------------------------------------------------------------------------------------
+void Testbed::load_training_data(const std::string& path_in) {
+	fs::path path = path_in;
+	if (!fs::exists(path)) throw std::runtime_error{"Data path '" + path_in + "' does not exist."};
+	std::vector<fs::path> jsons;
+	if (fs::is_directory(path)) {
+		for (auto& e : fs::directory_iterator(path)) if (e.is_regular_file() && lower(e.path().extension().string()) == ".json") jsons.push_back(e.path());
+		std::sort(jsons.begin(), jsons.end());
+	} else if (lower(path.extension().string()) == ".json") jsons.push_back(path);
+	else throw std::runtime_error{"NeRF data path must either be a json file or a directory containing json files."};
+	if (jsons.empty()) throw std::runtime_error{"No json files found in '" + path_in + "'."};
+
+	NerfDataset d;
+	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; };
+	std::vector<Frame> frames;
+	for (const fs::path& jp : jsons) {
+		mini_json::Value j; std::string err;
+		if (!mini_json::parse(read_text(jp).c_str(), j, err)) throw std::runtime_error{jp.string() + ": " + err};
+		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
+		if (j.has("scale")) d.scale = (float)j.num("scale", 0.33);
+		if (j.has("offset") && j["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)j["offset"].at(k).n;
+		const auto& fr = j["frames"];
+		for (size_t i = 0; i < fr.size(); ++i) {
+			const auto& f = fr.at(i);
+			Frame F;
+			fs::path ip = jp.parent_path() / f.str("file_path", "");
+			if (!fs::exists(ip) || ip.extension().empty()) {
+				for (const char* ext : {".png", ".jpg", ".jpeg", ".JPG", ".PNG", ".exr"}) { fs::path c = ip; c += ext; if (fs::exists(c)) { ip = c; break; } }
+			}
+			F.image_path = ip.string();
+			// per-frame values override the global ones (nerf_loader.cu:487-535, 697-700)
+			auto get = [&](const char* k, double dflt) { return f.has(k) ? f.num(k, dflt) : j.num(k, dflt); };
+			auto has = [&](const char* k) { return f.has(k) || j.has(k); };
+			F.meta.resolution = {(int)get("w", 0), (int)get("h", 0)};
+			double flx = 0, fly = 0;
+			if (has("fl_x")) flx = get("fl_x", 0);
+			if (has("fl_y")) fly = get("fl_y", 0);
+			F.meta.focal_length = {(float)flx, (float)fly}; // resolved after the image size is known
+			if (has("cx")) F.meta.principal_point[0] = -1.f; // marker, resolved below
+			const auto& tm = f["transform_matrix"];
+			float m[3][4];
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m[r][c] = (float)tm.at(r).at(c).n;
+			// nerf_matrix_to_ngp, nerf_loader.h:101-120
+			for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = m[r][3] * d.scale + d.offset[r]; }
+			float c3[3][4];
+			for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; }
+			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) F.xform[c * 3 + r] = c3[r][c];
+			if (has("k1") || has("k2") || has("p1") || has("p2")) {
+				F.meta.lens_mode = NGP_LENS_OPENCV;
+				F.meta.lens_params[0] = (float)get("k1", 0); F.meta.lens_params[1] = (float)get("k2", 0);
+				F.meta.lens_params[2] = (float)get("p1", 0); F.meta.lens_params[3] = (float)get("p2", 0);
+			}
+			// stash intrinsics needing the resolution
+			F.meta.lens_params[5] = (float)(has("camera_angle_x") ? get("camera_angle_x", 0) : 0);
+			F.meta.lens_params[6] = (float)(has("camera_angle_y") ? get("camera_angle_y", 0) : 0);
+			if (has("cx")) { F.meta.principal_point = {(float)get("cx", 0), (float)get("cy", 0)}; F.meta.lens_params[4] = 1.f; }
+			frames.push_back(F);
+		}
+	}
+	std::sort(frames.begin(), frames.end(), [](const Frame& a, const Frame& b) { return natural_less(a.image_path, b.image_path); });
+	for (Frame& F : frames) {
+		int w = 0, h = 0; std::vector<uint8_t> rgba;
+		bool ok = lower(fs::path(F.image_path).extension().string()) == ".png" && decode_png(F.image_path, w, h, rgba);
+		if (!ok && s_fallback_decoder) ok = s_fallback_decoder(F.image_path, w, h, rgba);
+		if (!ok) throw std::runtime_error{"Could not load image '" + F.image_path + "'"};
+		F.meta.resolution = {w, h};
+		const float ax = F.meta.lens_params[5], ay = F.meta.lens_params[6];
+		float flx = F.meta.focal_length[0], fly = F.meta.focal_length[1];
+		if (flx <= 0 && ax > 0) flx = 0.5f * (float)w / std::tan(0.5f * ax); // nerf_loader.cu:256-263
+		if (fly <= 0 && ay > 0) fly = 0.5f * (float)h / std::tan(0.5f * ay);
+		if (flx <= 0 && fly > 0) flx = fly;
+		if (fly <= 0) fly = flx;
+		if (flx <= 0) throw std::runtime_error{"Couldn't read fov / focal length for '" + F.image_path + "'"};
+		F.meta.focal_length = {flx, fly};
+		if (F.meta.lens_params[4] == 1.f) F.meta.principal_point = {F.meta.principal_point[0] / (float)w, F.meta.principal_point[1] / (float)h};
+		else F.meta.principal_point = {0.5f, 0.5f};
+		F.meta.lens_params[4] = F.meta.lens_params[5] = F.meta.lens_params[6] = 0.f;
+		d.metadata.push_back(F.meta); d.xforms.push_back(F.xform); d.pixels.push_back(std::move(rgba)); d.paths.push_back(F.image_path);
+	}
+	d.n_images = d.metadata.size();
+	if ((d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error{"NeRF dataset's `aabb_scale` must be a power of two."};
+	if (d.aabb_scale > 128) throw std::runtime_error{"NeRF dataset must have `aabb_scale <= 128`."};
+
+	const int prev_scale = nerf.training.dataset.aabb_scale;
+	const bool had = nerf.training.dataset.n_images > 0;
+	nerf.training.dataset = std::move(d);
+	mode = ETestbedMode::Nerf;
+	// load_nerf_post, testbed_nerf.cu:2353-2443
+	nerf.max_cascade = 0;
+	while ((1 << nerf.max_cascade) < nerf.training.dataset.aabb_scale) ++nerf.max_cascade;
+	nerf.cone_angle_constant = nerf.training.dataset.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+	if (had && prev_scale != nerf.training.dataset.aabb_scale) destroy_trainer(); // network size depends on aabb_scale (testbed_nerf.cu:2466-2470)
+	m_dataset_dirty = true;
+	m_render_lens_mode = nerf.training.dataset.metadata[0].lens_mode;
+	m_render_lens_params = nerf.training.dataset.metadata[0].lens_params;
+}
+
+void Testbed::load_file(const std::string& path) {
+	const std::string ext = lower(fs::path(path).extension().string());
+	if (fs::is_directory(path)) { load_training_data(path); return; }
+	if (ext == ".ingp" || ext == ".msgpack" || ext == ".snap") { load_snapshot(path); return; }
+	if (ext == ".json") {
+		mini_json::Value j; std::string err;
+		if (!mini_json::parse(read_text(path).c_str(), j, err)) throw std::runtime_error{path + ": " + err};
+		if (j.has("frames")) load_training_data(path);         // a NeRF scene (mode_from_scene, common_host.cu:144-160)
+		else if (j.has("encoding") || j.has("parent") || j.has("network") || j.has("optimizer")) reload_network_from_file(path);
+		else throw std::runtime_error{"File '" + path + "' is not a recognised scene / config json."};
+		return;
+	}
+	throw std::runtime_error{"File '" + path + "' is not a valid file to load (only NeRF scenes, network configs and snapshots are in scope)."};
+}
+
+// ------------------------------------------------------------------------------------------------
+// training
+// ------------------------------------------------------------------------------------------------
+void Testbed::train(uint32_t batch_size) {
+	if (batch_size != training_batch_size && !m_nerf) training_batch_size = batch_size;
+	ensure_trainer();
+	push_options();
+	NGP_CHECK(ngp_nerf_train(m_nerf, nullptr, 1));
+	++training_step;
+	if (training_step % 16 == 0 || training_step == 1) { // get_loss_scalar cadence, testbed.cu:4625
+		ngp_nerf_stats s = stats();
+		loss = s.loss;
+		if (s.measured_batch_size == 0 && training_step > 1) { fprintf(stderr, "Warning: Nerf training generated 0 samples. Aborting training.\n"); shall_train = false; }
+	}
+}
+ngp_nerf_stats Testbed::stats() {
+	ngp_nerf_stats s; memset(&s, 0, sizeof(s));
+	if (m_nerf) NGP_CHECK(ngp_nerf_get_stats(m_nerf, nullptr, &s));
+	return s;
+}
+bool Testbed::frame() { // headless: one call = one optimizer step when training is on
+	if (shall_train && mode == ETestbedMode::Nerf) train(training_batch_size);
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rendering
+// ------------------------------------------------------------------------------------------------
+static float srgb_to_lin(float s) { return s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f); }
+static float lin_to_srgb(float l) { return l < 0.0031308f ? 12.92f * l : 1.055f * std::pow(l, 0.41666f) - 0.055f; }
+
+void Testbed::set_camera_to_training_view(int i) {
+	const NerfDataset& d = nerf.training.dataset;
+	if (i < 0 || (size_t)i >= d.n_images) throw std::runtime_error{"set_camera_to_training_view: index out of range"};
+	m_camera = d.xforms[i];
+	const auto& m = d.metadata[i];
+	for (int k = 0; k < 2; ++k) m_relative_focal_length[k] = m.focal_length[k] / (float)m.resolution[fov_axis];
+	render_with_lens_distortion = true;
+	m_render_lens_mode = m.lens_mode; m_render_lens_params = m.lens_params;
+	m_screen_center = {1.0f - m.principal_point[0], 1.0f - m.principal_point[1]};
+	m_training_view = i;
+}
+void Testbed::set_nerf_camera_matrix(const std::array<float, 12>& rm) { // 3x4 row-major NeRF-convention matrix (python_api.cu / testbed.cu:463-466)
+	const NerfDataset& d = nerf.training.dataset;
+	float m[3][4];
+	for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m[r][c] = rm[r * 4 + c];
+	for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = m[r][3] * d.scale + d.offset[r]; }
+	float c3[3][4];
+	for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; }
+	for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) m_camera[c * 3 + r] = c3[r][c];
+}
+float Testbed::fov() const { return 2.0f * std::atan(0.5f / m_relative_focal_length[fov_axis]) * 180.0f / 3.14159265358979f; } // testbed.cu focal_length_to_fov
+void Testbed::set_fov(float deg) {
+	const float rf = 0.5f / std::tan(0.5f * deg * 3.14159265358979f / 180.0f);
+	m_relative_focal_length = {rf, rf};
+}
+
+std::vector<float> Testbed::render(int width, int height, int spp, bool linear) {
+	std::vector<float> out((size_t)width * height * 4, 0.f);
+	const float exposure_scale = std::pow(2.0f, exposure);
+	const float bg[4] = {srgb_to_lin(background_color[0]), srgb_to_lin(background_color[1]), srgb_to_lin(background_color[2]), background_color[3]};
+	if (render_ground_truth) {
+		// overlay_image_kernel (render_buffer.cu:344-412): point-sample the training image at pixel centres
+		const NerfDataset& d = nerf.training.dataset;
+		const auto& m = d.metadata[m_training_view];
+		const uint8_t* px = d.pixels[m_training_view].data();
+		for (int y = 0; y < height; ++y) for (int x = 0; x < width; ++x) {
+			const float u = ((float)x + 0.5f) / (float)width, v = ((float)y + 0.5f) / (float)height;
+			const int ix = std::min(std::max((int)(u * m.resolution[0]), 0), m.resolution[0] - 1), iy = std::min(std::max((int)(v * m.resolution[1]), 0), m.resolution[1] - 1);
+			const uint8_t* p = px + ((size_t)iy * m.resolution[0] + ix) * 4;
+			const float a = p[3] / 255.f;
+			float* o = &out[((size_t)y * width + x) * 4];
+			for (int k = 0; k < 3; ++k) o[k] = srgb_to_lin(p[k] / 255.f) * a * exposure_scale + bg[k] * (1.f - a);
+			o[3] = a + bg[3] * (1.f - a);
+		}
+	} else {
+		ensure_trainer();
+		push_options();
+		const size_t n = (size_t)width * height * 4;
+		if (n > m_frame_dev_floats) {
+			if (m_frame_dev) HIP_CHECK(hipFree(m_frame_dev));
+			HIP_CHECK(hipMalloc((void**)&m_frame_dev, n * sizeof(float)));
+			m_frame_dev_floats = n;
+		}
+		std::vector<float> tmp(n);
+		ngp_render_params rp; memset(&rp, 0, sizeof(rp));
+		rp.resolution[0] = width; rp.resolution[1] = height;
+		const int res_axis = fov_axis == 0 ? width : height;
+		rp.focal_length[0] = m_relative_focal_length[0] * (float)res_axis; rp.focal_length[1] = m_relative_focal_length[1] * (float)res_axis; // calc_focal_length, testbed.cu:4649
+		rp.screen_center[0] = (0.5f - m_screen_center[0]) + 0.5f; rp.screen_center[1] = (0.5f - m_screen_center[1]) + 0.5f;                      // render_screen_center, testbed.cu:4653
+		for (int k = 0; k < 12; ++k) rp.camera[k] = m_camera[k];
+		rp.lens_mode = render_with_lens_distortion ? m_render_lens_mode : NGP_LENS_PERSPECTIVE;
+		for (int k = 0; k < 7; ++k) rp.lens_params[k] = m_render_lens_params[k];
+		rp.snap_to_pixel_centers = snap_to_pixel_centers;
+		rp.min_transmittance = nerf.render_min_transmittance;
+		rp.near_distance = 0.f;
+		rp.use_inference_params = 1; // the renderer uses the optimizer's EMA weights (testbed_nerf.cu:1772)
+		rp.render_aabb = scene_aabb();
+		for (int s = 0; s < std::max(spp, 1); ++s) {
+			rp.spp_index = (uint32_t)s;
+			NGP_CHECK(ngp_nerf_render(m_nerf, nullptr, &rp, m_frame_dev, nullptr));
+			HIP_CHECK(hipMemcpy(tmp.data(), m_frame_dev, n * sizeof(float), hipMemcpyDeviceToHost));
+			const float wgt = 1.0f / (float)(s + 1); // accumulate_kernel: running mean over spp (render_buffer.cu:228-260)
+			for (size_t i = 0; i < n; ++i) out[i] += (tmp[i] - out[i]) * wgt;
+		}
+		for (size_t i = 0; i < (size_t)width * height; ++i) { // tonemap_kernel (render_buffer.cu:511-): exposure + background
+			float* o = &out[i * 4];
+			const float a = o[3];
+			for (int k = 0; k < 3; ++k) o[k] = o[k] * exposure_scale + bg[k] * (1.f - a);
+			o[3] = a + bg[3] * (1.f - a);
+		}
+	}
+	if (!linear) for (size_t i = 0; i < (size_t)width * height; ++i) for (int k = 0; k < 3; ++k) out[i * 4 + k] = lin_to_srgb(out[i * 4 + k]);
+	return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// snapshots (own container; the reference's msgpack/.ingp wire format is a "next" item)
+// ------------------------------------------------------------------------------------------------
+struct SnapHeader { char magic[8]; uint32_t version, training_step; uint64_t config_bytes, model_bytes, grid_floats; int32_t aabb_scale, with_optimizer; };
+void Testbed::save_snapshot(const std::string& path, bool include_optimizer_state) {
+	ensure_trainer();
+	const std::string cfg = mini_json::dump(m_network_config);
+	const uint64_t mb = ngp_model_serialized_size(m_model, include_optimizer_state);
+	std::vector<char> blob(mb);
+	NGP_CHECK(ngp_model_serialize_host(m_model, blob.data(), mb, include_optimizer_state));
+	float* grid_dev = nullptr;
+	NGP_CHECK(ngp_nerf_density_grid_ptrs(m_nerf, &grid_dev, nullptr, nullptr));
+	const uint64_t gf = (uint64_t)128 * 128 * 128 * (nerf.max_cascade + 1);
+	std::vector<float> grid(gf);
+	HIP_CHECK(hipMemcpy(grid.data(), grid_dev, gf * 4, hipMemcpyDeviceToHost));
+	SnapHeader h; memset(&h, 0, sizeof(h));
+	memcpy(h.magic, "NGPHIP01", 8); h.version = 1; h.training_step = training_step; h.config_bytes = cfg.size(); h.model_bytes = mb; h.grid_floats = gf;
+	h.aabb_scale = nerf.training.dataset.aabb_scale; h.with_optimizer = include_optimizer_state;
+	std::ofstream f{path, std::ios::binary};
+	if (!f) throw std::runtime_error{"Could not open '" + path + "' for writing."};
+	f.write((const char*)&h, sizeof(h)); f.write(cfg.data(), cfg.size()); f.write(blob.data(), blob.size()); f.write((const char*)grid.data(), gf * 4);
+}
+void Testbed::load_snapshot(const std::string& path) {
+	std::ifstream f{path, std::ios::binary};
+	if (!f) throw std::runtime_error{"Snapshot '" + path + "' does not exist."};
+	SnapHeader h;
+	f.read((char*)&h, sizeof(h));
+	if (!f || memcmp(h.magic, "NGPHIP01", 8) != 0 || h.version != 1) throw std::runtime_error{"File '" + path + "' is not a snapshot of this build (SNAPSHOT_FORMAT_VERSION mismatch)."};
+	std::string cfg(h.config_bytes, '\0'); f.read(cfg.data(), cfg.size());
+	std::vector<char> blob(h.model_bytes); f.read(blob.data(), blob.size());
+	std::vector<float> grid(h.grid_floats); f.read((char*)grid.data(), grid.size() * 4);
+	if (!f) throw std::runtime_error{"Snapshot '" + path + "' is truncated."};
+	std::string err;
+	if (!mini_json::parse(cfg.c_str(), m_network_config, err)) throw std::runtime_error{"snapshot config: " + err};
+	if (nerf.training.dataset.n_images == 0) throw std::runtime_error{"load_snapshot: load the training data first (dataset metadata is not embedded in this container)."};
+	if (h.aabb_scale != nerf.training.dataset.aabb_scale) throw std::runtime_error{"Snapshot aabb_scale differs from the loaded dataset."};
+	destroy_trainer();
+	ensure_trainer();
+	NGP_CHECK(ngp_model_deserialize_host(m_model, blob.data(), blob.size()));
+	NGP_CHECK(ngp_nerf_set_density_grid_host(m_nerf, nullptr, grid.data(), grid.size()));
+	NGP_CHECK(ngp_nerf_set_training_step(m_nerf, h.training_step));
+	training_step = h.training_step;
+}
+
+} // namespace ngp_host

@@ -1,0 +1,131 @@
+// testbed.hpp -- C++ host of the MI355X NeRF path with the member / method names of ngp::Testbed
+// (reference include/neural-graphics-primitives/testbed.h:71-1292) that scripts/run.py and pyngp users touch
+// (python_api.cu:439-853).  All device work goes through the C-ABI of libngp_hip.so (include/ngp_hip.h).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "../../include/ngp_hip.h"
+}
+#include "../csrc/mini_json.hpp"
+
+namespace ngp_host {
+
+enum class ETestbedMode : int { Nerf = 0, Sdf = 1, Image = 2, Volume = 3, None = 4 };   // common.h
+enum class ETrainMode : int { Nerf = 0, Rfl = 1, RflRelax = 2 };                          // common.h:47-51
+enum class EColorSpace : int { Linear = 0, SRGB = 1, VisPosNeg = 2 };
+enum class ETonemapCurve : int { Identity = 0, ACES = 1, Hable = 2, Reinhard = 3 };
+
+struct ImageMetadata {                      // TrainingImageMetadata as seen from Python (python_api.cu:766-779)
+	std::array<int, 2> resolution{0, 0};
+	std::array<float, 2> focal_length{1000.f, 1000.f};
+	std::array<float, 2> principal_point{0.5f, 0.5f};
+	int lens_mode = NGP_LENS_PERSPECTIVE;
+	std::array<float, 7> lens_params{};
+};
+
+struct NerfDataset {                        // nerf_loader.h NerfDataset (subset)
+	size_t n_images = 0;
+	std::vector<ImageMetadata> metadata;
+	std::vector<std::array<float, 12>> xforms;      // ngp convention, column-major mat4x3
+	std::vector<std::vector<uint8_t>> pixels;        // RGBA8 per image (host copy; also feeds render_ground_truth)
+	std::vector<std::string> paths;
+	int aabb_scale = 1;
+	float scale = 0.33f;                             // NERF_SCALE, nerf_loader.h:29
+	std::array<float, 3> offset{0.5f, 0.5f, 0.5f};   // nerf_loader.cu:403-404
+	bool is_hdr = false;
+};
+
+struct NerfTraining {
+	float near_distance = 0.1f;                      // testbed.h:817
+	ETrainMode train_mode = ETrainMode::RflRelax;    // testbed.h:822 (forced to Nerf without JIT, testbed_nerf.cu:3091-3094)
+	bool random_bg_color = true;                     // testbed.h:793
+	bool linear_colors = false;                      // testbed.h:794
+	bool snap_to_pixel_centers = true;               // testbed.h:797
+	float density_grid_decay = 0.95f;                // testbed.h:818
+	NerfDataset dataset;
+};
+
+struct Nerf {
+	float sharpen = 0.f;
+	float cone_angle_constant = 1.f / 256.f;
+	float render_min_transmittance = 0.01f;          // testbed.h:890
+	int max_cascade = 0;
+	NerfTraining training;
+};
+
+using ImageDecoder = std::function<bool(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba)>;
+
+class Testbed {
+public:
+	Testbed();
+	~Testbed();
+	Testbed(const Testbed&) = delete;
+
+	// ---- python_api.cu:439-711 ----
+	void load_file(const std::string& path);                        // testbed.cu:183-252
+	void load_training_data(const std::string& path);               // testbed.cu:156
+	void reload_network_from_file(const std::string& path = "");    // testbed.cu:311
+	void reset_network();                                           // testbed.cu:4160
+	void load_snapshot(const std::string& path);                    // testbed.cu:5357
+	void save_snapshot(const std::string& path, bool include_optimizer_state = false); // testbed.cu:5288
+	bool frame();                                                   // testbed.cu:3908 (headless: train one step)
+	void train(uint32_t batch_size);                                // testbed.cu:4561
+	bool want_repl() const { return false; }
+	void set_camera_to_training_view(int i);                        // testbed.cu:486
+	void set_nerf_camera_matrix(const std::array<float, 12>& m_row_major_3x4);
+	// render_to_cpu (python_api.cu:145-236): premultiplied RGBA float [h][w][4]
+	std::vector<float> render(int width, int height, int spp, bool linear);
+	ngp_nerf_stats stats();
+
+	// public members, same names as the reference
+	std::string root_dir;
+	ETestbedMode mode = ETestbedMode::None;
+	bool shall_train = true;
+	uint32_t training_step = 0;
+	float loss = 0.f;
+	float exposure = 0.f;
+	std::array<float, 4> background_color{0.f, 0.f, 0.f, 0.f};
+	bool snap_to_pixel_centers = false;
+	bool render_with_lens_distortion = false;
+	bool render_ground_truth = false;
+	EColorSpace color_space = EColorSpace::Linear;                   // testbed.h:1002
+	ETonemapCurve tonemap_curve = ETonemapCurve::Identity;
+	int fov_axis = 1;
+	uint32_t training_batch_size = 1u << 18;                         // testbed.h:1089
+	uint64_t seed = 1337;                                            // testbed.h:680
+	Nerf nerf;
+	float fov() const;
+	void set_fov(float degrees);
+
+	static ImageDecoder s_fallback_decoder;
+	static std::string s_default_root_dir;                           // directory that holds configs/ (set by the binding layer)                          // non-PNG images (jpg/exr): provided by the binding layer
+
+private:
+	void ensure_trainer();
+	void destroy_trainer();
+	void push_options();
+	ngp_nerf_options current_options() const;
+	ngp_aabb scene_aabb() const;
+
+	mini_json::Value m_network_config;
+	std::string m_network_config_path;
+	ngp_model* m_model = nullptr;
+	ngp_nerf* m_nerf = nullptr;
+	bool m_dataset_dirty = true;
+	// camera (testbed.h:453-456): column-major mat4x3
+	std::array<float, 12> m_camera{1, 0, 0, 0, 1, 0, 0, 0, 1, 0.5f, 0.5f, 0.5f};
+	std::array<float, 2> m_relative_focal_length{1.f, 1.f};
+	std::array<float, 2> m_screen_center{0.5f, 0.5f};
+	int m_render_lens_mode = NGP_LENS_PERSPECTIVE;
+	std::array<float, 7> m_render_lens_params{};
+	int m_training_view = 0;
+	float* m_frame_dev = nullptr; size_t m_frame_dev_floats = 0;
+	bool m_warned_train_mode = false;
+};
+
+} // namespace ngp_host
