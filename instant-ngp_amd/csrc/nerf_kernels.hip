@@ -572,6 +572,179 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K3, MI355X version: one wavefront per ray, lanes = samples.
+// Transmittance is an exclusive prefix product over the lanes (wave scan), the composited colour a
+// wave reduction, the adjoint's "suffix" an inclusive prefix sum -- so the three sequential per-ray
+// loops of the reference become O(log 64) scans per 64 samples and every ray gets 64 lanes instead of
+// one.  16 rays (waves) share a workgroup and reserve their compacted spans with ONE global atomic.
+// Same arithmetic per sample as k_compute_loss; only the association order of the sums/products
+// differs (prefix scans), i.e. results agree to fp32 round-off.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t K3_RAYS_PER_BLOCK = 16;
+
+static __device__ __forceinline__ float wave_incl_prod(float x, uint32_t lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const float y = __shfl_up(x, d, 64); if (lane >= (uint32_t)d) x *= y; }
+	return x;
+}
+static __device__ __forceinline__ float wave_incl_sum(float x, uint32_t lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const float y = __shfl_up(x, d, 64); if (lane >= (uint32_t)d) x += y; }
+	return x;
+}
+
+__global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
+	__shared__ uint32_t s_cnt[K3_RAYS_PER_BLOCK];
+	__shared__ float s_loss[K3_RAYS_PER_BLOCK];
+	__shared__ uint32_t s_base;
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t n_active = *a.rays_counter;
+	if (blockIdx.x * K3_RAYS_PER_BLOCK >= n_active) return; // uniform
+	const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t i = blockIdx.x * K3_RAYS_PER_BLOCK + wid;
+	const bool active = i < n_active;
+	const Box aabb(a.aabb);
+	const float EPSILON = 1e-4f;
+
+	uint32_t numsteps = 0, base = 0, compacted = 0;
+	const float* cin = nullptr;
+	const __half* no = nullptr;
+	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
+	float T_final = 1.f;
+	if (active) {
+		numsteps = a.numsteps_inout[i * 2 + 0];
+		base = a.numsteps_inout[i * 2 + 1];
+		cin = a.coords_in + (size_t)base * 7;
+		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
+		ray_o = ld3(a.rays_in[i].o);
+		float T_run = 1.f;
+		for (uint32_t c0 = 0; c0 < numsteps; c0 += 64) {
+			const uint32_t s = c0 + lane;
+			const bool valid = s < numsteps;
+			float alpha = 0.f; f3 rgb = mk3(0.f);
+			if (valid) {
+				const __half* lo = no + (size_t)s * a.output_stride;
+				rgb = mk3(act_rgb(__half2float(lo[0]), a.rgb_activation), act_rgb(__half2float(lo[1]), a.rgb_activation), act_rgb(__half2float(lo[2]), a.rgb_activation));
+				const float dt = unwarp_dt(cin[(size_t)s * 7 + 3]);
+				alpha = 1.f - __expf(-act_density(__half2float(lo[3]), a.density_activation) * dt);
+			}
+			const float incl = wave_incl_prod(1.f - alpha, lane);
+			float excl = __shfl_up(incl, 1, 64);
+			if (lane == 0) excl = 1.f;
+			const float T_k = T_run * excl;
+			const uint64_t vm = __ballot(valid), fail = __ballot(valid && !(T_k >= EPSILON)); // `if (T < EPSILON) break;`
+			const uint32_t n_proc = fail ? (uint32_t)(__ffsll((long long)fail) - 1) : (uint32_t)__popcll(vm);
+			const bool proc = lane < n_proc;
+			const float w = proc ? alpha * T_k : 0.f;
+			rgb_ray = rgb_ray + mk3(wave_sum(w * rgb.x), wave_sum(w * rgb.y), wave_sum(w * rgb.z));
+			if (n_proc) T_run = T_run * __shfl(incl, (int)n_proc - 1, 64);
+			compacted += n_proc;
+			if (fail) break;
+		}
+		T_final = T_run;
+		// target colour and background: identical to the sequential kernel (uniform across the wave)
+		const uint32_t ray_idx = a.ray_indices_in[i];
+		Rng rng(a.rng);
+		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
+		const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+		const ngp_image_meta& m = a.metadata[img];
+		const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+		rng.advance(1); // motionblur_time
+		if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
+		background_color = srgb_to_linear3(background_color);
+		const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+		const f3 trgb = mk3(tex.x, tex.y, tex.z);
+		if (a.linear_colors || !a.color_space_srgb) {
+			rgbtarget = trgb + (1.0f - tex.w) * background_color;
+			if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+		} else {
+			background_color = linear_to_srgb3(background_color);
+			if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
+			else rgbtarget = background_color;
+		}
+		if (compacted == numsteps) rgb_ray = rgb_ray + T_final * background_color;
+	}
+	// one global atomic per workgroup reserves the spans of its 16 rays
+	if (lane == 0) s_cnt[wid] = compacted;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) tot += s_cnt[w];
+		s_base = tot ? atomicAdd(a.numsteps_counter_compacted, tot) : 0u;
+	}
+	__syncthreads();
+	uint32_t compacted_base = s_base;
+	for (uint32_t w = 0; w < wid; ++w) compacted_base += s_cnt[w];
+	float my_loss = 0.f;
+	if (active) {
+		compacted = min(a.max_samples_compacted - min(a.max_samples_compacted, compacted_base), compacted);
+		if (lane == 0) { a.numsteps_inout[i * 2 + 0] = compacted; a.numsteps_inout[i * 2 + 1] = compacted_base; }
+	}
+	if (active && compacted > 0) {
+		float* cout = a.coords_out + (size_t)compacted_base * 7;
+		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
+		f3 lloss, lgrad;
+		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
+		my_loss = ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
+		const float loss_scale = a.loss_scale / n_rays;
+		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = *a.mean_density_ptr < MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
+		float T_run = 1.f;
+		f3 ray2_run = mk3(0.f);
+		for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
+			const uint32_t s = c0 + lane;
+			const bool valid = s < compacted;
+			float alpha = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, dt = 0.f, depth = 0.f;
+			f3 rgb = mk3(0.f);
+			float cc[7];
+			if (valid) {
+				const float* ci = cin + (size_t)s * 7;
+#pragma unroll
+				for (int k = 0; k < 7; ++k) cc[k] = ci[k];
+				const __half* lo = no + (size_t)s * a.output_stride;
+				l0 = __half2float(lo[0]); l1 = __half2float(lo[1]); l2 = __half2float(lo[2]); l3 = __half2float(lo[3]);
+				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
+				dt = unwarp_dt(cc[3]);
+				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
+				depth = dist3(unwarp_position(mk3(cc[0], cc[1], cc[2]), aabb), ray_o);
+			}
+			const float incl = wave_incl_prod(1.f - alpha, lane);
+			float excl = __shfl_up(incl, 1, 64);
+			if (lane == 0) excl = 1.f;
+			const float T_k = T_run * excl, T_after = T_run * incl;
+			const float weight = alpha * T_k;
+			const f3 ray2 = ray2_run + mk3(wave_incl_sum(weight * rgb.x, lane), wave_incl_sum(weight * rgb.y, lane), wave_incl_sum(weight * rgb.z, lane));
+			if (valid) {
+				float* cj = cout + (size_t)s * 7;
+#pragma unroll
+				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
+				const f3 suffix = rgb_ray - ray2;
+				const f3 dloss_by_drgb = weight * lgrad;
+				const float d0 = loss_scale * (dloss_by_drgb.x * act_rgb_d(l0, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l0));
+				const float d1 = loss_scale * (dloss_by_drgb.y * act_rgb_d(l1, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l1));
+				const float d2 = loss_scale * (dloss_by_drgb.z * act_rgb_d(l2, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l2));
+				const float dloss_by_dmlp = act_density_d(l3, a.density_activation) * (dt * (dot3(lgrad, T_after * rgb - suffix) + 0.0f));
+				const float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f);
+				__half* d = dl + (size_t)s * a.dloss_stride;
+				d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3);
+			}
+			T_run = T_run * __shfl(incl, 63, 64);
+			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
+		}
+	}
+	if (a.loss_output) {
+		if (lane == 0) s_loss[wid] = my_loss;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			float t = 0.f;
+			for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) t += s_loss[w];
+			if (t != 0.f) atomicAdd(a.loss_output, t);
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: fill_rollover<float> on coords + fill_rollover_and_rescale<half> on dL/doutput, one launch.
 // ------------------------------------------------------------------------------------------------
@@ -776,7 +949,8 @@ void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* 
 }
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
-	hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
+	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
+	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(blocks(max_rays, K3_RAYS_PER_BLOCK)), dim3(1024), 0, s, a);
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
 	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride);

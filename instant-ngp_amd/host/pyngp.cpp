@@ -35,12 +35,19 @@ PYBIND11_MODULE(pyngp, m) {
 	py::class_<Testbed> testbed(m, "Testbed");
 	py::class_<ImageMetadata>(testbed, "TrainingImageMetadata")
 		.def_readonly("resolution", &ImageMetadata::resolution).def_readonly("focal_length", &ImageMetadata::focal_length)
-		.def_readonly("principal_point", &ImageMetadata::principal_point);
+		.def_readonly("principal_point", &ImageMetadata::principal_point).def_readonly("lens_mode", &ImageMetadata::lens_mode)
+		.def_readonly("lens_params", &ImageMetadata::lens_params);
 	py::class_<NerfDataset>(testbed, "NerfDataset")
 		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
 		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
 		.def_readonly("scale", &NerfDataset::scale).def_readonly("offset", &NerfDataset::offset).def_readonly("paths", &NerfDataset::paths)
-		.def_readonly("is_hdr", &NerfDataset::is_hdr);
+		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms)
+		.def("image", [](const NerfDataset& d, size_t i) {
+			if (i >= d.n_images) throw std::runtime_error{"image index out of range"};
+			py::array_t<uint8_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});
+			std::memcpy(out.mutable_data(), d.pixels[i].data(), d.pixels[i].size());
+			return out;
+		}, "RGBA8 pixels of training image i (host copy)");
 	py::class_<NerfTraining>(testbed, "NerfTraining")
 		.def_readwrite("near_distance", &NerfTraining::near_distance).def_readwrite("train_mode", &NerfTraining::train_mode)
 		.def_readwrite("random_bg_color", &NerfTraining::random_bg_color).def_readwrite("linear_colors", &NerfTraining::linear_colors)
