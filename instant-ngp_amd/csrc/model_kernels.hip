@@ -559,8 +559,30 @@ __global__ void __launch_bounds__(256, 3) k_train_fwd_bwd(const GridMeta* __rest
 					}
 					issue = head;
 				}
-				if (issue && sv) {
-					__half* gt = grid_grad + (size_t)lc.offset * 4;
+				__half* gt = grid_grad + (size_t)lc.offset * 4;
+				if (!(flags & DBG_T1_NO_PAIR_HALVES)) {
+					// both 4-byte halves of an 8-byte entry go out in the SAME instruction from a lane pair (L, L^1): the vector
+					// memory pipeline coalesces same-line atomic lanes of one instruction into one memory-side request, like it
+					// does for stores (measured: 1.06 -> 0.59 ms per step, profiles/r01_microbench_ablation2.log)
+					const bool own = issue && sv;
+					const bool odd = (lane & 1) != 0;
+					const bool nb_own = __shfl_xor((int)own, 1, 64) != 0;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const uint32_t idx_nb = (uint32_t)__shfl_xor((int)cr.idx[k], 1, 64);
+						const h2 v0_nb = __builtin_bit_cast(h2, __shfl_xor(__builtin_bit_cast(int, v0[k]), 1, 64));
+						const h2 v1_nb = __builtin_bit_cast(h2, __shfl_xor(__builtin_bit_cast(int, v1[k]), 1, 64));
+						// step A: the even lane's entry; step B: the odd lane's entry
+						{
+							const bool go = odd ? nb_own : own;
+							if (go) atomic_add_h2(gt + (size_t)(odd ? idx_nb : cr.idx[k]) * 4 + (odd ? 2 : 0), odd ? v1_nb : v0[k]);
+						}
+						{
+							const bool go = odd ? own : nb_own;
+							if (go) atomic_add_h2(gt + (size_t)(odd ? cr.idx[k] : idx_nb) * 4 + (odd ? 2 : 0), odd ? v1[k] : v0_nb);
+						}
+					}
+				} else if (issue && sv) {
 #pragma unroll
 					for (int k = 0; k < 8; ++k) {
 						__half* dst = gt + (size_t)cr.idx[k] * 4;
