@@ -560,7 +560,26 @@ __global__ void __launch_bounds__(256, 3) k_train_fwd_bwd(const GridMeta* __rest
 					issue = head;
 				}
 				__half* gt = grid_grad + (size_t)lc.offset * 4;
-				if (!(flags & DBG_T1_NO_PAIR_HALVES)) {
+				if (!(flags & (DBG_T1_NO_PAIR_HALVES | DBG_T1_NO_QUADS))) {
+					// A lane QUAD issues, per instruction, the 16 bytes of one sample's x-adjacent corner pair: {corner 2p: half 0,
+					// half 1; corner 2p+1: half 0, half 1}.  On dense levels (and for even x on hashed ones, prime_x = 1) the two
+					// entries are adjacent, so the four lane-atomics fall into one cache line and leave the CU as ONE request.
+					const bool own = issue && sv;
+					const int r4 = lane & 3;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						const bool go = __shfl((int)own, q, 4) != 0;
+#pragma unroll
+						for (int p = 0; p < 4; ++p) {
+							const uint32_t i0 = (uint32_t)__shfl((int)cr.idx[2 * p], q, 4), i1 = (uint32_t)__shfl((int)cr.idx[2 * p + 1], q, 4);
+							const int a0 = __shfl(__builtin_bit_cast(int, v0[2 * p]), q, 4), a1 = __shfl(__builtin_bit_cast(int, v1[2 * p]), q, 4);
+							const int b0 = __shfl(__builtin_bit_cast(int, v0[2 * p + 1]), q, 4), b1 = __shfl(__builtin_bit_cast(int, v1[2 * p + 1]), q, 4);
+							const uint32_t ix = (r4 & 2) ? i1 : i0;
+							const int val = r4 == 0 ? a0 : r4 == 1 ? a1 : r4 == 2 ? b0 : b1;
+							if (go) atomic_add_h2(gt + (size_t)ix * 4 + (r4 & 1) * 2, __builtin_bit_cast(h2, val));
+						}
+					}
+				} else if (!(flags & DBG_T1_NO_PAIR_HALVES)) {
 					// both 4-byte halves of an 8-byte entry go out in the SAME instruction from a lane pair (L, L^1): the vector
 					// memory pipeline coalesces same-line atomic lanes of one instruction into one memory-side request, like it
 					// does for stores (measured: 1.06 -> 0.59 ms per step, profiles/r01_microbench_ablation2.log)
@@ -791,21 +810,28 @@ k_wgrad(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t
 	}
 }
 
-// sum the per-block partials, un-permute the D tiles into row-major [out][in] and round to half
-__global__ void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
-	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // element of [tile][r][lane]
-	if (e >= N_DW_TILES * 16 * 64) return;
+// sum the per-block partials, un-permute the D tiles into row-major [out][in] and round to half.
+// One block per 64 consecutive elements (= one register row of a tile): 4 waves each sum a quarter of the partials with
+// coalesced 256-byte reads, then combine through LDS in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
+	__shared__ float sm[4][64];
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	const uint32_t e = blockIdx.x * 64 + lane; // element of [tile][r][lane]
 	float s = 0.f;
-	for (uint32_t g = 0; g < n_partials; ++g) s += partials[(size_t)g * (N_DW_TILES * 16 * 64) + e];
-	const int t = e / (16 * 64), r = (e / 64) % 16, lane = e % 64;
+	for (uint32_t g = wid; g < n_partials; g += 4) s += partials[(size_t)g * (N_DW_TILES * 16 * 64) + e];
+	sm[wid][lane] = s;
+	__syncthreads();
+	if (wid != 0) return;
+	s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+	const int t = e / (16 * 64), r = (e / 64) % 16;
 	int layer_off, R, C, it, kt;
 	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
 	else if (t < 4) { layer_off = 2048; R = 16; C = 64; it = 0; kt = t - 2; }
 	else if (t < 6) { layer_off = 3072; R = 64; C = 32; it = t - 4; kt = 0; }
 	else if (t < 10) { layer_off = 5120; R = 64; C = 64; it = (t - 6) >> 1; kt = (t - 6) & 1; }
 	else { layer_off = 9216; R = 16; C = 64; it = 0; kt = t - 10; }
-	const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-	const int k = kt * 32 + (lane & 31);
+	const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((int)lane >> 5);
+	const int k = kt * 32 + ((int)lane & 31);
 	if (i < R && k < C) mlp_grad[layer_off + i * C + k] = __float2half(s);
 }
 
@@ -821,38 +847,64 @@ __global__ void k_build_frags(const __half* __restrict__ mlp_params, uint32_t n_
 	if (bw) bw[bw_perm[p]] = v;
 }
 
-// [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters.
+// [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters, 4 parameters
+// (= one F=4 hash-table entry) per thread: 8-byte gradient / half-parameter accesses, 16-byte fp32 state accesses; the
+// Adam state of an entry is only touched when one of its gradients is non-zero (sparse update of the reference).
+DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint32_t& step) {
+	if (matrix) gradient += a.l2_reg * weight_fp;
+	const float gradient_sq = gradient * gradient;
+	const float first = m = a.beta1 * m + (1 - a.beta1) * gradient;
+	const float second = v = a.beta2 * v + (1 - a.beta2) * gradient_sq;
+	const uint32_t current_step = ++step;
+	float lr = a.lr;
+	lr *= sqrtf(1 - powf(a.beta2, (float)current_step)) / (1 - powf(a.beta1, (float)current_step));
+	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
+	return weight_fp - effective_lr * first;
+}
 __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t i4 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t i = i4 * 4;
 	if (i >= a.n_params) return;
-	const bool matrix = i < a.n_mlp;
-	float gradient = __half2float(((const __half*)a.grads)[i]) / a.loss_scale;
-	bool update = matrix ? (a.optimize_matrix != 0) : (a.optimize_non_matrix != 0 && gradient != 0.f);
-	__half w_half = ((__half*)a.params)[i];
-	if (update) {
-		const float weight_fp = a.master[i];
-		if (matrix) gradient += a.l2_reg * weight_fp;
-		const float gradient_sq = gradient * gradient;
-		const float first = a.m[i] = a.beta1 * a.m[i] + (1 - a.beta1) * gradient;
-		const float second = a.v[i] = a.beta2 * a.v[i] + (1 - a.beta2) * gradient_sq;
-		const uint32_t current_step = ++a.steps[i];
-		float lr = a.lr;
-		lr *= sqrtf(1 - powf(a.beta2, (float)current_step)) / (1 - powf(a.beta1, (float)current_step));
-		const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
-		const float new_weight = weight_fp - effective_lr * first;
-		a.master[i] = new_weight;
-		w_half = __float2half(new_weight);
-		((__half*)a.params)[i] = w_half;
-		if (matrix) {
-			((__half*)a.fw_frags)[a.fw_perm[i]] = w_half;
-			((__half*)a.bw_frags)[a.bw_perm[i]] = w_half;
-		}
+	const bool matrix = i < a.n_mlp; // n_mlp is a multiple of 4
+	const h4 g4 = __builtin_bit_cast(h4, ((const uint2*)a.grads)[i4]);
+	h4 w4 = __builtin_bit_cast(h4, ((const uint2*)a.params)[i4]);
+	float g[4]; bool upd[4]; bool any = false;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		g[k] = (float)g4[k] / a.loss_scale;
+		upd[k] = matrix ? (a.optimize_matrix != 0) : (a.optimize_non_matrix != 0 && g[k] != 0.f);
+		any |= upd[k];
 	}
-	const float filtered = (a.ema[i] * a.ema_decay * a.ema_debias_old + __half2float(w_half) * (1 - a.ema_decay)) * a.ema_debias_new;
-	a.ema[i] = filtered;
-	const __half fh = __float2half(filtered);
-	((__half*)a.params_inf)[i] = fh;
-	if (matrix) ((__half*)a.fw_frags_inf)[a.fw_perm[i]] = fh;
+	if (any) {
+		float4 mw = ((const float4*)a.master)[i4], m4 = ((const float4*)a.m)[i4], v4 = ((const float4*)a.v)[i4];
+		uint4 st = ((const uint4*)a.steps)[i4];
+		float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint32_t* sp = (uint32_t*)&st;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			if (!upd[k]) continue;
+			const float nw = adam_update(a, matrix, g[k], mwp[k], mp[k], vp[k], sp[k]);
+			mwp[k] = nw;
+			w4[k] = (_Float16)nw;
+			if (matrix) {
+				((_Float16*)a.fw_frags)[a.fw_perm[i + k]] = w4[k];
+				((_Float16*)a.bw_frags)[a.bw_perm[i + k]] = w4[k];
+			}
+		}
+		((float4*)a.master)[i4] = mw; ((float4*)a.m)[i4] = m4; ((float4*)a.v)[i4] = v4; ((uint4*)a.steps)[i4] = st;
+		((uint2*)a.params)[i4] = __builtin_bit_cast(uint2, w4);
+	}
+	float4 e4 = ((const float4*)a.ema)[i4];
+	float* ep = (float*)&e4;
+	h4 inf4;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const float filtered = (ep[k] * a.ema_decay * a.ema_debias_old + (float)w4[k] * (1 - a.ema_decay)) * a.ema_debias_new;
+		ep[k] = filtered;
+		inf4[k] = (_Float16)filtered;
+		if (matrix) ((_Float16*)a.fw_frags_inf)[a.fw_perm[i + k]] = inf4[k];
+	}
+	((float4*)a.ema)[i4] = e4;
+	((uint2*)a.params_inf)[i4] = __builtin_bit_cast(uint2, inf4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -904,10 +956,10 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 	hipLaunchKernelGGL(k_wgrad, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
 }
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad) {
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3((N_DW_TILES * 16 * 64 + 255) / 256), dim3(256), 0, s, partials, n_partials, (__half*)mlp_grad);
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(N_DW_TILES * 16), dim3(256), 0, s, partials, n_partials, (__half*)mlp_grad);
 }
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a) {
-	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params + 255) / 256)), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params / 4 + 255) / 256)), dim3(256), 0, s, a);
 }
 
 } // namespace ngp
