@@ -365,8 +365,8 @@ static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], u
 __global__ void __launch_bounds__(256) k_scan_partials(const uint64_t* __restrict__ in, uint32_t n_max, const uint32_t* __restrict__ n_ptr, uint32_t rank, uint32_t world,
 		uint64_t* __restrict__ partial) {
 	__shared__ uint64_t sm[4];
-	uint32_t n = n_max;
-	if (n_ptr) { const uint32_t R = *n_ptr; n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world); }
+	const uint32_t R = n_ptr ? *n_ptr : n_max; // n_max carries the immediate global ray count when there is no device-side count
+	const uint32_t n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world);
 	uint64_t v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; v[k] = e < n ? in[e] : 0ull; }
@@ -388,8 +388,8 @@ __global__ void __launch_bounds__(256) k_scan_top(uint64_t* __restrict__ partial
 __global__ void __launch_bounds__(256) k_scan_apply(const uint64_t* __restrict__ in, uint32_t n_max, const uint32_t* __restrict__ n_ptr, uint32_t rank, uint32_t world,
 		const uint64_t* __restrict__ partial, uint64_t* __restrict__ out) {
 	__shared__ uint64_t sm[4];
-	uint32_t n = n_max;
-	if (n_ptr) { const uint32_t R = *n_ptr; n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world); }
+	const uint32_t R = n_ptr ? *n_ptr : n_max; // n_max carries the immediate global ray count when there is no device-side count
+	const uint32_t n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world);
 	if (blockIdx.x * SCAN_BLOCK >= n) return;
 	uint64_t v[4];
 #pragma unroll
@@ -939,9 +939,9 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	const uint32_t n_scan_blocks = blocks(max_local_rays, SCAN_BLOCK);
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128)), dim3(128), 0, s, a, rs);
 	hipLaunchKernelGGL(k1_count, dim3(blocks(max_local_rays, 4)), dim3(256), 0, s, a, rs, masks, scan_in);
-	hipLaunchKernelGGL(k_scan_partials, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, max_local_rays, a.n_rays_ptr, a.rank, a.world_size, partial);
+	hipLaunchKernelGGL(k_scan_partials, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, a.n_rays, a.n_rays_ptr, a.rank, a.world_size, partial);
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, partial, n_scan_blocks, a.numsteps_counter, a.ray_counter);
-	hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, max_local_rays, a.n_rays_ptr, a.rank, a.world_size, partial, scan_out);
+	hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, a.n_rays, a.n_rays_ptr, a.rank, a.world_size, partial, scan_out);
 	hipLaunchKernelGGL(k1_write, dim3(blocks(max_local_rays, 4)), dim3(256), 0, s, a, rs, masks, scan_out);
 }
 void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse) {
