@@ -114,14 +114,35 @@ DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners&
 		out.idx[c] = idx; out.w[c] = w;
 	}
 }
-// F = 4: returns the 4 interpolated features of one level (half fma accumulation, corner order 0..7)
-DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, float x, float y, float z) {
+// F = 4: returns the 4 interpolated features of one level (half fma accumulation, corner order 0..7).
+// PAIR: the x-adjacent corners (c, c^1) of a sample are neighbouring 8-byte entries on dense levels (and for even x on
+// hashed ones), so a lane pair (L, L^1) loads {L's corner c, L's corner c^1} in ONE instruction and {L^1's c, L^1's c^1}
+// in the next: same-line lanes of an instruction coalesce into one request. The values are handed back with DPP-class
+// shuffles; the accumulation order (and therefore the result) is unchanged.
+template <bool PAIR>
+DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, float x, float y, float z, int lane) {
 	Corners cr;
 	level_corners(lc, x, y, z, cr);
 	const uint2* t = (const uint2*)table + lc.offset;
 	uint2 v[8];
+	if (PAIR) {
+		const bool odd = (lane & 1) != 0;
 #pragma unroll
-	for (int c = 0; c < 8; ++c) v[c] = t[cr.idx[c]];  // 8 independent 8-byte gathers in flight
+		for (int c = 0; c < 8; c += 2) {
+			// what the partner lane needs from me: my idx[c] if I am odd (it loads my corner c), my idx[c+1] if I am even
+			const uint32_t idx_nb = (uint32_t)__shfl_xor((int)(odd ? cr.idx[c] : cr.idx[c + 1]), 1, 64);
+			const uint2 A = t[odd ? idx_nb : cr.idx[c]];       // step A: the even lane's corner pair {c, c+1}
+			const uint2 B = t[odd ? cr.idx[c + 1] : idx_nb];   // step B: the odd lane's corner pair {c, c+1}
+			// even keeps A (own c) and needs own c+1 = partner's A; odd keeps B (own c+1) and needs own c = partner's B
+			const uint32_t sx = odd ? A.x : B.x, sy = odd ? A.y : B.y;
+			const uint32_t rx = (uint32_t)__shfl_xor((int)sx, 1, 64), ry = (uint32_t)__shfl_xor((int)sy, 1, 64);
+			if (odd) { v[c].x = rx; v[c].y = ry; v[c + 1] = B; }
+			else { v[c] = A; v[c + 1].x = rx; v[c + 1].y = ry; }
+		}
+	} else {
+#pragma unroll
+		for (int c = 0; c < 8; ++c) v[c] = t[cr.idx[c]];  // 8 independent 8-byte gathers in flight
+	}
 	h2 r0 = {(_Float16)0.f, (_Float16)0.f}, r1 = r0;
 #pragma unroll
 	for (int c = 0; c < 8; ++c) {
@@ -140,11 +161,13 @@ DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, f
 }
 
 // Encoding of one sample column into the lane's two B-operand fragments (k-steps 0,1), F = 4.
+template <bool PAIR = true>
 DEV void encode_sample(const GridMeta* __restrict__ gm, const __half* __restrict__ table, float x, float y, float z, int hi, h8 out[2]) {
+	const int lane = threadIdx.x & 63;
 #pragma unroll
 	for (int s = 0; s < 2; ++s) {
-		h4 a = level_features4(table, level_const(gm, 4 * s + 0, hi), x, y, z); // level 4s+hi   -> j = 0..3
-		h4 b = level_features4(table, level_const(gm, 4 * s + 2, hi), x, y, z); // level 4s+2+hi -> j = 4..7
+		h4 a = level_features4<PAIR>(table, level_const(gm, 4 * s + 0, hi), x, y, z, lane); // level 4s+hi   -> j = 0..3
+		h4 b = level_features4<PAIR>(table, level_const(gm, 4 * s + 2, hi), x, y, z, lane); // level 4s+2+hi -> j = 4..7
 		h8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 		out[s] = r;
 	}
@@ -314,8 +337,8 @@ DEV void fwd_rgb_l3(const h8* fw, int lane, const FwdState<CT>& st, f16v out[CT]
 // ---------------------------------------------------------------------------------------------
 // inference kernel (K2, density-grid queries, renderer): persistent waves, 64 samples per iteration
 // ---------------------------------------------------------------------------------------------
-template <bool DENSITY_ONLY, int CT>
-__global__ void __launch_bounds__(256, 4) k_inference(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n_max,
+template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW>
+__global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n_max,
 		const uint32_t* __restrict__ n_ptr, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
@@ -334,7 +357,7 @@ __global__ void __launch_bounds__(256, 4) k_inference(const GridMeta* __restrict
 			const uint32_t s_raw = tile * TS + c * 32 + col;
 			sidx[c] = s_raw;
 			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
-			encode_sample(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
+			encode_sample<PAIR>(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
 			if (!DENSITY_ONLY) st.rin[c][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
 		}
 		fwd_density_l1<CT>(fw, lane, st);
@@ -927,10 +950,17 @@ void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, co
 	if (n_max == 0) return;
 	const uint32_t tiles = (n_max + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 4);
-	if (density_only)
-		hipLaunchKernelGGL((k_inference<true, 1>), dim3(grid), dim3(256), 8 * 1024, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset);
-	else
-		hipLaunchKernelGGL((k_inference<false, 1>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset);
+	const bool pair = !(g_debug_flags & DBG_FWD_NO_PAIR_LOADS);
+	const bool occ4 = (g_debug_flags & DBG_FWD_OCC4) != 0; // 4 waves/SIMD (128 VGPRs, spills) instead of 3 (168 VGPRs)
+#define NGP_LAUNCH_INF(D, P, W, LDS) hipLaunchKernelGGL((k_inference<D, 1, P, W>), dim3(grid), dim3(256), LDS, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset)
+	if (density_only) {
+		if (pair) { if (occ4) NGP_LAUNCH_INF(true, true, 4, 8 * 1024); else NGP_LAUNCH_INF(true, true, 3, 8 * 1024); }
+		else { if (occ4) NGP_LAUNCH_INF(true, false, 4, 8 * 1024); else NGP_LAUNCH_INF(true, false, 3, 8 * 1024); }
+	} else {
+		if (pair) { if (occ4) NGP_LAUNCH_INF(false, true, 4, N_FW_FRAGS * 1024); else NGP_LAUNCH_INF(false, true, 3, N_FW_FRAGS * 1024); }
+		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024); }
+	}
+#undef NGP_LAUNCH_INF
 }
 void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out) {
 	if (n == 0) return;

@@ -880,7 +880,7 @@ __global__ void k_bitfield_max_pool(uint32_t n_elements, const uint8_t* __restri
 // on-device NerfCounters::update_after_training (testbed_nerf.cu:2678-2702) + counter reset
 // (prepare_for_training_steps :2669-2676) for the NEXT step.  c = TrainCounters in device memory.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size) {
+__global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size, uint32_t world_size) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	const uint32_t before = c->numsteps_counter, compacted = c->numsteps_counter_compacted;
 	c->n_rays_last = c->ray_counter;
@@ -895,7 +895,8 @@ __global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size) 
 		c->loss_scalar = c->loss_sum * (float)compacted / (float)target_batch_size;
 		uint32_t r = (uint32_t)((float)c->rays_per_batch * (float)target_batch_size / (float)compacted);
 		r = ((r + 255u) / 256u) * 256u;
-		c->rays_per_batch = min(r, 1u << 18);
+		// cap: 2^18 rays per rank (the per-rank ray buffers), i.e. the reference's 1<<18 (testbed_nerf.cu:2699) at world_size 1
+		c->rays_per_batch = min(r, (1u << 18) * world_size);
 	}
 	// max_inference for the next step (testbed_nerf.cu:3055-3060)
 	const uint32_t max_samples = target_batch_size * 16u;
@@ -982,7 +983,7 @@ void launch_grid_to_bitfield(hipStream_t s, const float* grid, uint32_t max_casc
 			bitfield + grid_mip_offset(level - 1) / 8, bitfield + grid_mip_offset(level) / 8);
 	}
 }
-void launch_update_counters(hipStream_t s, TrainCounters* c, uint32_t B) { hipLaunchKernelGGL(k_update_counters, dim3(1), dim3(64), 0, s, c, B); }
+void launch_update_counters(hipStream_t s, TrainCounters* c, uint32_t B, uint32_t world_size) { hipLaunchKernelGGL(k_update_counters, dim3(1), dim3(64), 0, s, c, B, world_size); }
 void launch_clamp_compacted(hipStream_t s, TrainCounters* c, uint32_t B) { hipLaunchKernelGGL(k_clamp_compacted, dim3(1), dim3(64), 0, s, c, B); }
 
 } // namespace ngp

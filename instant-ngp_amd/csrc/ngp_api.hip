@@ -550,7 +550,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192) ||
-		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays / o->world_size + 1))) { delete t; return 1; }
+		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
@@ -677,8 +677,8 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
 	{ ProfScope ps(P_K1, s);
-	  if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays / o.world_size + 1, t->coarse_mask);
-	  else launch_generate_training_samples_lattice(s, k1, t->max_rays / o.world_size + 1, t->coarse_mask, t->k1_scratch); }
+	  if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays, t->coarse_mask);
+	  else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->coarse_mask, t->k1_scratch); }
 	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
 	{ ProfScope ps(P_K2_INFERENCE, s);
 	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }
@@ -690,7 +690,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k3.rays_in = t->rays; k3.numsteps_inout = t->numsteps; k3.coords_in = t->coords; k3.coords_out = t->coords_compacted; k3.dloss_doutput = t->dloss; k3.dloss_stride = 4;
 	k3.loss_type = o.loss_type; k3.loss_output = &c->loss_sum; k3.rgb_activation = o.rgb_activation; k3.density_activation = o.density_activation;
 	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
-	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays / o.world_size + 1); }
+	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
 	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->n_valid_compacted, t->coords_compacted, 7, t->dloss, 4); }
 	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
@@ -714,7 +714,7 @@ extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 	if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
-	{ ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size); }
+	{ ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size, t->opt.world_size); }
 	++t->training_step;
 	HIPCHK(hipGetLastError());
 	return 0;

@@ -8,7 +8,7 @@ namespace ngp {
 
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
-enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
+enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_NO_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
 struct TrainCounters {
@@ -75,7 +75,7 @@ void launch_splat_grid_samples(hipStream_t s, uint32_t n, const uint32_t* idx, c
 void launch_ema_grid_samples(hipStream_t s, uint32_t n, float decay, float* grid_out, const float* grid_in);
 void launch_grid_mean(hipStream_t s, const float* grid, float* partial256, float* mean_out);
 void launch_grid_to_bitfield(hipStream_t s, const float* grid, uint32_t max_cascade, uint8_t* bitfield, const float* mean_ptr);
-void launch_update_counters(hipStream_t s, TrainCounters* c, uint32_t B);
+void launch_update_counters(hipStream_t s, TrainCounters* c, uint32_t B, uint32_t world_size);
 void launch_clamp_compacted(hipStream_t s, TrainCounters* c, uint32_t B);
 
 // ---- model (model_kernels.hip) ----------------------------------------------------------------
