@@ -115,10 +115,10 @@ DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners&
 	}
 }
 // F = 4: returns the 4 interpolated features of one level (half fma accumulation, corner order 0..7).
-// PAIR: the x-adjacent corners (c, c^1) of a sample are neighbouring 8-byte entries on dense levels (and for even x on
-// hashed ones), so a lane pair (L, L^1) loads {L's corner c, L's corner c^1} in ONE instruction and {L^1's c, L^1's c^1}
-// in the next: same-line lanes of an instruction coalesce into one request. The values are handed back with DPP-class
-// shuffles; the accumulation order (and therefore the result) is unchanged.
+// PAIR (ablation, off): the x-adjacent corners (c, c^1) of a sample are neighbouring 8-byte entries on dense levels (and
+// for even x on hashed ones), so a lane pair (L, L^1) can load {L's c, L's c^1} in ONE instruction and hand the values
+// back with shuffles. Unlike for the atomics of the backward pass this does NOT pay for loads (0.262 vs 0.233 ms for K2):
+// the gathers are L2/MALL hits that coalesce well enough, and the shuffles + 40 extra VGPRs cost more than they save.
 template <bool PAIR>
 DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, float x, float y, float z, int lane) {
 	Corners cr;
@@ -161,7 +161,7 @@ DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, f
 }
 
 // Encoding of one sample column into the lane's two B-operand fragments (k-steps 0,1), F = 4.
-template <bool PAIR = true>
+template <bool PAIR = false>
 DEV void encode_sample(const GridMeta* __restrict__ gm, const __half* __restrict__ table, float x, float y, float z, int hi, h8 out[2]) {
 	const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -410,8 +410,8 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 	__builtin_amdgcn_global_atomic_fadd_v2f16((gh2*)addr, v);
 }
 
-template <int CT>
-__global__ void __launch_bounds__(256, 3) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
+template <int CT, int MINW>
+__global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
 		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
@@ -880,7 +880,8 @@ DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weig
 	const float second = v = a.beta2 * v + (1 - a.beta2) * gradient_sq;
 	const uint32_t current_step = ++step;
 	float lr = a.lr;
-	lr *= sqrtf(1 - powf(a.beta2, (float)current_step)) / (1 - powf(a.beta1, (float)current_step));
+	// beta^t as exp(t ln beta): the per-parameter step counters make powf the dominant cost of the sweep otherwise
+	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
 	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
 	return weight_fp - effective_lr * first;
 }
@@ -950,7 +951,7 @@ void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, co
 	if (n_max == 0) return;
 	const uint32_t tiles = (n_max + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 4);
-	const bool pair = !(g_debug_flags & DBG_FWD_NO_PAIR_LOADS);
+	const bool pair = (g_debug_flags & DBG_FWD_PAIR_LOADS) != 0; // measured slower than plain per-lane gathers (profiles/r01_microbench_ablation4_gather.log)
 	const bool occ4 = (g_debug_flags & DBG_FWD_OCC4) != 0; // 4 waves/SIMD (128 VGPRs, spills) instead of 3 (168 VGPRs)
 #define NGP_LAUNCH_INF(D, P, W, LDS) hipLaunchKernelGGL((k_inference<D, 1, P, W>), dim3(grid), dim3(256), LDS, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset)
 	if (density_only) {
@@ -976,8 +977,12 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
-	hipLaunchKernelGGL((k_train_fwd_bwd<1>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
-		(__half*)grid_grad, (uint4*)enc_stash, flags);
+	if (flags & DBG_T1_OCC2)
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
+			(__half*)grid_grad, (uint4*)enc_stash, flags);
+	else
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
+			(__half*)grid_grad, (uint4*)enc_stash, flags);
 }
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {

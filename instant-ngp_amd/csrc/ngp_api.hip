@@ -348,6 +348,7 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	AdamArgs a;
 	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
 	a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.epsilon; a.l2_reg = m->cfg.l2_reg;
+	a.log_beta1 = std::log(m->cfg.beta1); a.log_beta2 = std::log(m->cfg.beta2);
 	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
 	const float d = m->cfg.ema_decay;
 	a.ema_decay = d;

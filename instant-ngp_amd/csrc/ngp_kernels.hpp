@@ -8,7 +8,7 @@ namespace ngp {
 
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
-enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_NO_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
+enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
 struct TrainCounters {
@@ -113,7 +113,7 @@ void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partia
 
 struct AdamArgs {
 	uint64_t n_params, n_mlp;
-	float loss_scale, lr, beta1, beta2, eps, l2_reg;
+	float loss_scale, lr, beta1, beta2, eps, l2_reg, log_beta1, log_beta2;
 	int optimize_matrix, optimize_non_matrix;
 	float ema_decay, ema_debias_old, ema_debias_new;
 	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
