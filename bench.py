@@ -159,8 +159,14 @@ def main():
     dominant = max((k for k in kern if k in per_launch_bytes), key=lambda k: kern[k][0])
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    try:  # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[dominant]["bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw)",
+                "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
                 "kernel_ms_per_step": {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
 
