@@ -318,22 +318,35 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	if (r.flags) {
 		const Box aabb(a.aabb);
 		const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
-		for (uint32_t ch = 0; ch < LAT_MAX_CHUNKS && cnt < N_STEPS; ++ch) {
-			const float t = lattice_t(r, ch * 64 + lane, a.cone_angle_constant);
-			const f3 pos = ro + t * rdn;
-			const bool inside = aabb.contains(pos);
-			bool occ = false;
-			if (inside) {
-				// 64 consecutive lattice points span ~14 voxels: the byte loads of a wavefront coalesce into a few
-				// L1/L2 lines, and thousands of resident wavefronts hide their latency (no LDS staging needed here)
-				const float dt = calc_dt(t, a.cone_angle_constant);
-				occ = occupied_at(pos, a.bitfield, mip_from_dt(dt, pos, a.max_mip));
+		// Four chunks are tested per iteration so that four independent occupancy loads are in flight (the loop is a
+		// chain of dependent ~1 us loads otherwise); the exit tests are then replayed in chunk order, so masks, counts
+		// and n_chunks are exactly those of the one-chunk-at-a-time loop.
+		bool done = false;
+		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += 4) {
+			uint64_t m[4], in[4];
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				const float t = lattice_t(r, (ch0 + u) * 64 + lane, a.cone_angle_constant);
+				const f3 pos = ro + t * rdn;
+				const bool inside = aabb.contains(pos);
+				bool occ = false;
+				if (inside) {
+					// 64 consecutive lattice points span ~14 voxels: the byte loads of a wavefront coalesce into a few
+					// L1/L2 lines, and thousands of resident wavefronts hide their latency (no LDS staging needed here)
+					const float dt = calc_dt(t, a.cone_angle_constant);
+					occ = occupied_at(pos, a.bitfield, mip_from_dt(dt, pos, a.max_mip));
+				}
+				m[u] = __ballot(occ);
+				in[u] = __ballot(inside);
 			}
-			const uint64_t m = __ballot(occ);
-			if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch] = m;
-			cnt += (uint32_t)__popcll(m);
-			n_chunks = ch + 1;
-			if (__ballot(inside) == 0ull) break; // the whole chunk is past the box: so is everything after it
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u) {
+				if (done || cnt >= N_STEPS) { done = true; break; }
+				if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch0 + u] = m[u];
+				cnt += (uint32_t)__popcll(m[u]);
+				n_chunks = ch0 + u + 1;
+				if (in[u] == 0ull) done = true; // the whole chunk is past the box: so is everything after it
+			}
 		}
 		cnt = min(cnt, N_STEPS);
 	}
@@ -583,6 +596,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 // differs (prefix scans), i.e. results agree to fp32 round-off.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t K3_RAYS_PER_BLOCK = 16;
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ float wave_incl_prod(float x, uint32_t lane) {
 #pragma unroll
@@ -613,22 +627,52 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	const __half* no = nullptr;
 	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
 	float T_final = 1.f;
+	// first 64 samples of the ray stay in registers for the adjoint pass (most rays have <= 64 samples)
+	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f, k_cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	const bool vec_out = a.output_stride == 4, vec_dl = a.dloss_stride == 4;
+	auto load_out = [&](const __half* lo, float& l0, float& l1, float& l2, float& l3) {
+		if (vec_out) {
+			const uint2 raw = *(const uint2*)lo;
+			const h4v v = __builtin_bit_cast(h4v, raw);
+			l0 = (float)v[0]; l1 = (float)v[1]; l2 = (float)v[2]; l3 = (float)v[3];
+		} else { l0 = __half2float(lo[0]); l1 = __half2float(lo[1]); l2 = __half2float(lo[2]); l3 = __half2float(lo[3]); }
+	};
 	if (active) {
 		numsteps = a.numsteps_inout[i * 2 + 0];
 		base = a.numsteps_inout[i * 2 + 1];
+		const uint32_t ray_idx = a.ray_indices_in[i];
+		ray_o = ld3(a.rays_in[i].o);
+		// The target-pixel chain (ray index -> image metadata -> texel) is issued BEFORE the sample pass so that its three
+		// dependent memory latencies overlap the sample loads instead of following them (uniform across the wave).
+		Rng rng(a.rng);
+		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
+		const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+		const ngp_image_meta& m = a.metadata[img];
+		const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+		rng.advance(1); // motionblur_time
+		if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
+		const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+
 		cin = a.coords_in + (size_t)base * 7;
 		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
-		ray_o = ld3(a.rays_in[i].o);
 		float T_run = 1.f;
 		for (uint32_t c0 = 0; c0 < numsteps; c0 += 64) {
 			const uint32_t s = c0 + lane;
 			const bool valid = s < numsteps;
 			float alpha = 0.f; f3 rgb = mk3(0.f);
 			if (valid) {
-				const __half* lo = no + (size_t)s * a.output_stride;
-				rgb = mk3(act_rgb(__half2float(lo[0]), a.rgb_activation), act_rgb(__half2float(lo[1]), a.rgb_activation), act_rgb(__half2float(lo[2]), a.rgb_activation));
-				const float dt = unwarp_dt(cin[(size_t)s * 7 + 3]);
-				alpha = 1.f - __expf(-act_density(__half2float(lo[3]), a.density_activation) * dt);
+				float l0, l1, l2, l3, dtw;
+				load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
+				if (c0 == 0) {
+					const float* ci = cin + (size_t)s * 7;
+#pragma unroll
+					for (int k = 0; k < 7; ++k) k_cc[k] = ci[k];
+					k_l0 = l0; k_l1 = l1; k_l2 = l2; k_l3 = l3;
+					dtw = k_cc[3];
+				} else dtw = cin[(size_t)s * 7 + 3];
+				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
+				const float dt = unwarp_dt(dtw);
+				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
 			}
 			const float incl = wave_incl_prod(1.f - alpha, lane);
 			float excl = __shfl_up(incl, 1, 64);
@@ -645,16 +689,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		}
 		T_final = T_run;
 		// target colour and background: identical to the sequential kernel (uniform across the wave)
-		const uint32_t ray_idx = a.ray_indices_in[i];
-		Rng rng(a.rng);
-		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
-		const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
-		const ngp_image_meta& m = a.metadata[img];
-		const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
-		rng.advance(1); // motionblur_time
-		if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 		background_color = srgb_to_linear3(background_color);
-		const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
 		const f3 trgb = mk3(tex.x, tex.y, tex.z);
 		if (a.linear_colors || !a.color_space_srgb) {
 			rgbtarget = trgb + (1.0f - tex.w) * background_color;
@@ -700,11 +735,16 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			f3 rgb = mk3(0.f);
 			float cc[7];
 			if (valid) {
-				const float* ci = cin + (size_t)s * 7;
+				if (c0 == 0) {
 #pragma unroll
-				for (int k = 0; k < 7; ++k) cc[k] = ci[k];
-				const __half* lo = no + (size_t)s * a.output_stride;
-				l0 = __half2float(lo[0]); l1 = __half2float(lo[1]); l2 = __half2float(lo[2]); l3 = __half2float(lo[3]);
+					for (int k = 0; k < 7; ++k) cc[k] = k_cc[k];
+					l0 = k_l0; l1 = k_l1; l2 = k_l2; l3 = k_l3;
+				} else {
+					const float* ci = cin + (size_t)s * 7;
+#pragma unroll
+					for (int k = 0; k < 7; ++k) cc[k] = ci[k];
+					load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
+				}
 				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
 				dt = unwarp_dt(cc[3]);
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
@@ -728,7 +768,10 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				const float dloss_by_dmlp = act_density_d(l3, a.density_activation) * (dt * (dot3(lgrad, T_after * rgb - suffix) + 0.0f));
 				const float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f);
 				__half* d = dl + (size_t)s * a.dloss_stride;
-				d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3);
+				if (vec_dl) {
+					const h4v v = {(_Float16)d0, (_Float16)d1, (_Float16)d2, (_Float16)d3};
+					*(uint2*)d = __builtin_bit_cast(uint2, v);
+				} else { d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3); }
 			}
 			T_run = T_run * __shfl(incl, 63, 64);
 			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
