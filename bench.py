@@ -67,6 +67,8 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
 
     lib = A.load_hip()  # raises if libngp_hip.so is missing: no CPU fallback on the product path
+    if os.environ.get("NGP_DEBUG_FLAGS"):  # ablation switches of ngp_kernels.hpp (default 0 = production path)
+        lib.ngp_debug_set_flags(int(os.environ["NGP_DEBUG_FLAGS"], 0))
     assert lib.ngp_device_available() == 1
 
     import synth_scene
@@ -156,6 +158,11 @@ def main():
     n_inf_avg = s3.measured_batch_size_before_compaction  # last step's marched samples (steady state)
     per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd": BYTES_PER_SAMPLE_T1 * args.batch,
                         "k_optimizer": BYTES_PER_PARAM_OPT * n_params.value}
+    if "k_grad_bin+accumulate" in kern and "k_train_fwd_bwd" in kern:
+        # the hashed levels' scatter runs in two follow-up kernels: one unit of algorithmic work (T1 sample = 1,572 B), one roofline entry
+        t1 = kern.pop("k_train_fwd_bwd"); gb = kern.pop("k_grad_bin+accumulate")
+        kern["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = (t1[0] + gb[0], t1[1])
+        per_launch_bytes["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = per_launch_bytes["k_train_fwd_bwd"]
     dominant = max((k for k in kern if k in per_launch_bytes), key=lambda k: kern[k][0])
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9

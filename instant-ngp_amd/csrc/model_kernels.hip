@@ -412,7 +412,8 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 
 template <int CT, int MINW>
 __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
-		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags) {
+		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags,
+		uint2* __restrict__ denc_lv, uint32_t denc_cap) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
 	h8* bw = fw + N_FW_FRAGS * 64;
@@ -548,11 +549,22 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 				if ((flags & DBG_T1_NO_COARSE_LEVELS) && rr < 2) continue;
 				if ((flags & DBG_T1_NO_FINE_LEVELS) && rr >= 2) continue;
 				const LevelConst lc = level_const(gm, 2 * rr, hi);
+				// Hashed levels (binned mode): the memory side retires only ~14 G atomic requests/s, and hashed corners neither
+				// merge nor coalesce -- they were 85 % of T1's atomic requests.  Their dL/d(enc) goes to memory level-major
+				// (8 bytes per sample and level, coalesced) and k_grad_bin / k_grad_accumulate turn it into table gradients
+				// through LDS accumulators, without global atomics.  Dense levels keep the merged + coalesced atomics below.
+				const bool binned = denc_lv != nullptr && lc.hashed;
+				if (binned && sv) {
+					const h4 g = {(_Float16)denc[c][4 * rr + 0], (_Float16)denc[c][4 * rr + 1], (_Float16)denc[c][4 * rr + 2], (_Float16)denc[c][4 * rr + 3]};
+					denc_lv[(size_t)(2 * rr + hi) * denc_cap + sidx[c]] = __builtin_bit_cast(uint2, g);
+				}
+				if (__ballot(!binned) == 0ull) continue; // both levels of this register group are binned
+				const bool svl = sv && !binned;
 				Corners cr;
 				level_corners(lc, px[c], py[c], pz[c], cr);
 				// dL/d(enc) is rounded to half first (it is a half matrix in the reference)
-				const float g0 = sv ? (float)(_Float16)denc[c][4 * rr + 0] : 0.f, g1 = sv ? (float)(_Float16)denc[c][4 * rr + 1] : 0.f;
-				const float g2 = sv ? (float)(_Float16)denc[c][4 * rr + 2] : 0.f, g3 = sv ? (float)(_Float16)denc[c][4 * rr + 3] : 0.f;
+				const float g0 = svl ? (float)(_Float16)denc[c][4 * rr + 0] : 0.f, g1 = svl ? (float)(_Float16)denc[c][4 * rr + 1] : 0.f;
+				const float g2 = svl ? (float)(_Float16)denc[c][4 * rr + 2] : 0.f, g3 = svl ? (float)(_Float16)denc[c][4 * rr + 3] : 0.f;
 				h2 v0[8], v1[8];
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
@@ -587,7 +599,7 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 					// A lane QUAD issues, per instruction, the 16 bytes of one sample's x-adjacent corner pair: {corner 2p: half 0,
 					// half 1; corner 2p+1: half 0, half 1}.  On dense levels (and for even x on hashed ones, prime_x = 1) the two
 					// entries are adjacent, so the four lane-atomics fall into one cache line and leave the CU as ONE request.
-					const bool own = issue && sv;
+					const bool own = issue && svl;
 					const int r4 = lane & 3;
 #pragma unroll
 					for (int q = 0; q < 4; ++q) {
@@ -606,7 +618,7 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 					// both 4-byte halves of an 8-byte entry go out in the SAME instruction from a lane pair (L, L^1): the vector
 					// memory pipeline coalesces same-line atomic lanes of one instruction into one memory-side request, like it
 					// does for stores (measured: 1.06 -> 0.59 ms per step, profiles/r01_microbench_ablation2.log)
-					const bool own = issue && sv;
+					const bool own = issue && svl;
 					const bool odd = (lane & 1) != 0;
 					const bool nb_own = __shfl_xor((int)own, 1, 64) != 0;
 #pragma unroll
@@ -624,7 +636,7 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 							if (go) atomic_add_h2(gt + (size_t)(odd ? cr.idx[k] : idx_nb) * 4 + (odd ? 2 : 0), odd ? v1[k] : v0_nb);
 						}
 					}
-				} else if (issue && sv) {
+				} else if (issue && svl) {
 #pragma unroll
 					for (int k = 0; k < 8; ++k) {
 						__half* dst = gt + (size_t)cr.idx[k] * 4;
@@ -637,6 +649,147 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 		}
 	}
 }
+
+// ---------------------------------------------------------------------------------------------
+// Binned hash-grid scatter for the HASHED levels (no global atomics).
+//   k_grad_bin:        one block = 512 samples of one level.  The 4096 corner records {value: 4 halfs, index} are counting-
+//                      sorted in LDS by table chunk (4096 entries = 32 KiB of table per chunk), one returning atomic per
+//                      (block, chunk) reserves the slots in the chunk's list, and the sorted records leave the CU as
+//                      contiguous runs (coalesced 8-byte value / 2-byte index streams).
+//   k_grad_accumulate: one block = one chunk x one feature pair.  Records are summed EXACTLY into 64-bit fixed-point LDS
+//                      accumulators (integer ds_add_u64) and the chunk's gradients are written once (the reference sums in
+//                      half with atomicAdd(__half2): one rounding per contribution, order dependent).
+// The hash spreads every sample's corners uniformly over the chunks, so the lists are balanced for any scene; a list that
+// still overflows its capacity (2x the mean) falls back to global atomics on the spot.
+// ---------------------------------------------------------------------------------------------
+DEV LevelConst level_const_uniform(const GridMeta* __restrict__ gm, uint32_t level) {
+	LevelConst lc;
+	lc.scale = gm->scale[level]; lc.res = gm->resolution[level]; lc.hs = gm->hashmap_size[level]; lc.offset = gm->offset[level];
+	lc.hashed = (uint64_t)lc.res * lc.res * lc.res > (uint64_t)lc.hs;
+	return lc;
+}
+
+__global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
+	__shared__ uint32_t s_cnt[GRAD_BIN_MAX_CHUNKS], s_start[GRAD_BIN_MAX_CHUNKS], s_gbase[GRAD_BIN_MAX_CHUNKS];
+	__shared__ uint32_t s_wsum[4];
+	__shared__ uint2 s_val[GRAD_BIN_SAMPLES * 8];
+	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * 8];
+	const uint32_t tid = threadIdx.x, ly = blockIdx.y, level = a.levels[ly];
+	const LevelConst lc = level_const_uniform(a.gm, level);
+	const uint32_t n_chunks = lc.hs >> GRAD_BIN_CHUNK_LOG2;
+	for (uint32_t c = tid; c < GRAD_BIN_MAX_CHUNKS; c += 256) s_cnt[c] = 0;
+	__syncthreads();
+	constexpr int SPT = GRAD_BIN_SAMPLES / 256; // samples per thread
+	uint32_t idx[SPT][8], rank[SPT][8];
+	uint2 val[SPT][8];
+	bool valid[SPT];
+#pragma unroll
+	for (int u = 0; u < SPT; ++u) {
+		const uint32_t s = blockIdx.x * GRAD_BIN_SAMPLES + u * 256 + tid;
+		valid[u] = s < a.n;
+		if (!valid[u]) continue;
+		const float* p = a.in + (size_t)s * a.in_stride;
+		const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + s]);
+		const float g0 = (float)g[0], g1 = (float)g[1], g2 = (float)g[2], g3 = (float)g[3];
+		Corners cr;
+		level_corners(lc, p[0], p[1], p[2], cr);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const float w = cr.w[k];
+			const h4 v = {(_Float16)(g0 * w), (_Float16)(g1 * w), (_Float16)(g2 * w), (_Float16)(g3 * w)};
+			val[u][k] = __builtin_bit_cast(uint2, v);
+			idx[u][k] = cr.idx[k];
+			rank[u][k] = atomicAdd(&s_cnt[cr.idx[k] >> GRAD_BIN_CHUNK_LOG2], 1u);
+		}
+	}
+	__syncthreads();
+	// exclusive prefix of the chunk counts (<= 128 chunks: two wavefronts) + slot reservation in the global lists
+	if (tid < GRAD_BIN_MAX_CHUNKS) {
+		const uint32_t cnt = tid < n_chunks ? s_cnt[tid] : 0u;
+		uint32_t x = cnt;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if ((tid & 63u) >= (uint32_t)d) x += y; }
+		if ((tid & 63u) == 63u) s_wsum[tid >> 6] = x;
+		s_start[tid] = x - cnt;
+		s_gbase[tid] = cnt ? atomicAdd(&a.cursors[ly * GRAD_BIN_MAX_CHUNKS + tid], cnt) : 0u;
+	}
+	__syncthreads();
+	if (tid >= 64 && tid < GRAD_BIN_MAX_CHUNKS) s_start[tid] += s_wsum[0];
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < SPT; ++u) {
+		if (!valid[u]) continue;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t c = idx[u][k] >> GRAD_BIN_CHUNK_LOG2;
+			const uint32_t pos = s_start[c] + rank[u][k];
+			s_val[pos] = val[u][k];
+			s_key[pos] = (c << 16) | (idx[u][k] & ((1u << GRAD_BIN_CHUNK_LOG2) - 1u));
+		}
+	}
+	__syncthreads();
+	const uint32_t total = s_wsum[0] + s_wsum[1];
+	for (uint32_t i = tid; i < total; i += 256) {
+		const uint32_t key = s_key[i], c = key >> 16, local = key & 0xffffu;
+		const uint32_t d = s_gbase[c] + (i - s_start[c]);
+		const uint2 v = s_val[i];
+		if (d < a.cap) {
+			const size_t o = ((size_t)ly * GRAD_BIN_MAX_CHUNKS + c) * a.cap + d;
+			a.vals[o] = v;
+			a.idxs[o] = (uint16_t)local;
+		} else { // list full: straight to the table (k_grad_accumulate adds its sums on top)
+			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + ((size_t)c << GRAD_BIN_CHUNK_LOG2) + local) * 4;
+			atomic_add_h2(dst, __builtin_bit_cast(h2, v.x));
+			atomic_add_h2(dst + 2, __builtin_bit_cast(h2, v.y));
+		}
+	}
+}
+
+// half -> integer multiple of 2^-24 (every finite half is one: subnormal step 2^-24, largest 65504 = 2047 << 29 units)
+DEV long long half_bits_to_fixed(uint32_t hbits) {
+	const uint32_t e = (hbits >> 10) & 31u, m = hbits & 1023u;
+	const long long mag = e ? (long long)(1024u + m) << (e - 1u) : (long long)m; // e == 31 (inf/nan) -> > 65504: converts back to inf
+	return (hbits & 0x8000u) ? -mag : mag;
+}
+__global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
+	// 64-bit FIXED-POINT accumulators (units of 2^-24): sums of halfs are exact, so the result does not depend on the
+	// order in which the records arrive -- the hashed levels' gradients are bitwise reproducible -- and integer LDS atomics
+	// run at full rate where ds_add_f32 / ds_pk_add_f16 do not (measured per step: 0.28 / 0.15 ms vs 0.04 ms for this kernel,
+	// profiles/r01_microbench_ablation7_binning.log).  One block = one chunk x one feature pair: 4096 x 2 x 8 B = 64 KiB.
+	constexpr uint32_t E = 1u << GRAD_BIN_CHUNK_LOG2;
+	__shared__ unsigned long long acc[E * 2];
+	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = blockIdx.z, level = a.levels[ly];
+	const uint32_t hs = a.gm->hashmap_size[level], offset = a.gm->offset[level];
+	if (c >= (hs >> GRAD_BIN_CHUNK_LOG2)) return;
+	const uint32_t n = min(a.cursors[ly * GRAD_BIN_MAX_CHUNKS + c], a.cap);
+	for (uint32_t i = tid; i < E * 2; i += 1024) acc[i] = 0ull;
+	__syncthreads();
+	const size_t base = ((size_t)ly * GRAD_BIN_MAX_CHUNKS + c) * a.cap;
+	const uint32_t* vals32 = (const uint32_t*)(a.vals + base) + fp; // this block's half2 of every 8-byte record
+	const uint16_t* idxs = a.idxs + base;
+	constexpr int U = 8; // records per thread in flight
+	for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+		uint32_t v[U], id[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals32[(size_t)i * 2]; id[u] = idxs[i]; } }
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			if (i0 + u * 1024 >= n) break;
+			atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u] & 0xffffu));
+			atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
+		}
+	}
+	__syncthreads();
+	h2* gt = (h2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << GRAD_BIN_CHUNK_LOG2)) * 4) + fp;
+	for (uint32_t e = tid; e < E; e += 1024) {
+		const h2 old = gt[(size_t)e * 2]; // zero unless a list overflowed
+		const float s0 = (float)(long long)acc[e] * 0x1p-24f, s1 = (float)(long long)acc[E + e] * 0x1p-24f;
+		const h2 r = {(_Float16)((float)old[0] + s0), (_Float16)((float)old[1] + s1)};
+		gt[(size_t)e * 2] = r;
+	}
+}
+// lists are empty again for the next step
+__global__ void k_grad_bin_reset(uint32_t* cursors, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) cursors[i] = 0u; }
 
 // ---------------------------------------------------------------------------------------------
 // W: recompute forward + dgrad in chain AND swapped form, accumulate all weight gradients in registers.
@@ -972,17 +1125,23 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 	hipLaunchKernelGGL(k_build_frags, dim3((n_mlp + 255) / 256), dim3(256), 0, s, (const __half*)mlp_params, n_mlp, fw_perm, bw_perm, (__half*)fw, (__half*)bw);
 }
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
+void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
+	if (a.n == 0 || a.n_hashed == 0) return;
+	hipLaunchKernelGGL(k_grad_bin, dim3((a.n + GRAD_BIN_SAMPLES - 1) / GRAD_BIN_SAMPLES, a.n_hashed), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_grad_accumulate, dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
+	hipLaunchKernelGGL(k_grad_bin_reset, dim3((a.n_hashed * GRAD_BIN_MAX_CHUNKS + 255) / 256), dim3(256), 0, s, a.cursors, a.n_hashed * GRAD_BIN_MAX_CHUNKS);
+}
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags) {
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap) {
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
 	if (flags & DBG_T1_OCC2)
 		hipLaunchKernelGGL((k_train_fwd_bwd<1, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
-			(__half*)grid_grad, (uint4*)enc_stash, flags);
+			(__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
 	else
 		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
-			(__half*)grid_grad, (uint4*)enc_stash, flags);
+			(__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
 }
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {

@@ -36,7 +36,7 @@ static std::vector<ProfEntry> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 static double g_prof_ms[P_COUNT]; static uint64_t g_prof_n[P_COUNT];
 static const char* kProfNames[P_COUNT] = {"k_generate_training_samples", "k_inference", "k_compute_loss", "k_fill_rollover", "k_train_fwd_bwd", "k_wgrad",
-	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters"};
+	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters", "k_grad_bin+accumulate"};
 static hipEvent_t prof_event() {
 	if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
 	hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -145,6 +145,11 @@ struct ngp_model {
 	ngp_half* fw_frags = nullptr; ngp_half* bw_frags = nullptr; ngp_half* fw_frags_inf = nullptr;
 	ngp_half* enc_stash = nullptr; size_t stash_halfs = 0;
 	float* wgrad_partials = nullptr; uint32_t n_partials = 0;
+	// binned scatter of the hashed levels: dL/d(enc) level-major, per-chunk record lists, list cursors
+	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0;
+	GradBinArgs bin_args{};
+	// W (weight gradients, compute bound, 1 wave/SIMD) runs on a side stream next to the hashed levels' bin/accumulate kernels (memory/LDS bound)
+	hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
 };
@@ -252,8 +257,11 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 extern "C" void ngp_model_destroy(ngp_model* m) {
 	if (!m) return;
 	void* ptrs[] = {m->gm_dev, m->master, m->params, m->params_inf, m->grads, m->adam_m, m->adam_v, m->ema, m->adam_steps, m->fw_perm, m->bw_perm,
-		m->fw_frags, m->bw_frags, m->fw_frags_inf, m->enc_stash, m->wgrad_partials};
+		m->fw_frags, m->bw_frags, m->fw_frags_inf, m->enc_stash, m->wgrad_partials, m->denc_lv, m->bin_vals, m->bin_idxs, m->bin_cursors};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
+	if (m->side) (void)hipStreamDestroy(m->side);
+	if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+	if (m->ev_join) (void)hipEventDestroy(m->ev_join);
 	delete m;
 }
 
@@ -334,11 +342,55 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		if (dev_alloc(&m->enc_stash, need)) return 1;
 		m->stash_halfs = need;
 	}
+	// binned scatter: every hashed level must have a power-of-two table of 2^12 .. 2^19 entries (base.json: 2^19)
+	GradBinArgs& ba = m->bin_args;
+	ba.n_hashed = 0; ba.max_chunks = 0;
+	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
+		bool ok = true;
+		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
+			const uint64_t res = m->gm.resolution[l], hs = m->gm.hashmap_size[l];
+			if (res * res * res <= hs) continue;
+			if ((hs & (hs - 1)) || hs < (1u << GRAD_BIN_CHUNK_LOG2) || (hs >> GRAD_BIN_CHUNK_LOG2) > GRAD_BIN_MAX_CHUNKS) { ok = false; break; }
+			ba.levels[ba.n_hashed++] = l;
+			ba.max_chunks = std::max<uint32_t>(ba.max_chunks, (uint32_t)(hs >> GRAD_BIN_CHUNK_LOG2));
+		}
+		if (!ok) ba.n_hashed = 0;
+	}
+	if (ba.n_hashed && n > m->bin_n) {
+		HIPCHK(hipStreamSynchronize(s));
+		for (void* p : {m->denc_lv, m->bin_vals, m->bin_idxs, (void*)m->bin_cursors}) if (p) HIPCHK(hipFree(p));
+		m->denc_lv = m->bin_vals = m->bin_idxs = nullptr; m->bin_cursors = nullptr; m->bin_n = 0;
+		// list capacity: twice the mean number of records per chunk of the SMALLEST chunk count that can occur (>= 1 chunk)
+		const uint32_t cap = std::max<uint32_t>(8192u, (uint32_t)((((uint64_t)n * 8 * 2) / ba.max_chunks + 1023) / 1024 * 1024));
+		const size_t n_lists = (size_t)MAX_LEVELS * GRAD_BIN_MAX_CHUNKS;
+		HIPCHK(hipMalloc(&m->denc_lv, (size_t)MAX_LEVELS * n * 8));
+		HIPCHK(hipMalloc(&m->bin_vals, n_lists * cap * 8));
+		HIPCHK(hipMalloc(&m->bin_idxs, n_lists * cap * 2));
+		HIPCHK(hipMalloc((void**)&m->bin_cursors, n_lists * 4));
+		HIPCHK(hipMemsetAsync(m->bin_cursors, 0, n_lists * 4, s));
+		m->bin_n = n; m->bin_cap = cap;
+	}
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
 	{ ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
-	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, g_debug_flags); }
-	{ ProfScope ps(P_W_WGRAD, s); launch_wgrad(s, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
-	{ ProfScope ps(P_WGRAD_REDUCE, s); launch_wgrad_reduce(s, m->wgrad_partials, m->n_partials, m->grads); }
+	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, g_debug_flags,
+		ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
+	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
+	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
+	hipStream_t sw = s;
+	if (overlap) {
+		if (!m->side) { HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming)); }
+		HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+		sw = m->side;
+	}
+	{ ProfScope ps(P_W_WGRAD, sw); launch_wgrad(sw, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
+	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads); }
+	if (ba.n_hashed) {
+		ProfScope ps(P_GRAD_BIN, s);
+		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = (const uint2*)m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap;
+		ba.vals = (uint2*)m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.grid_grad_ = m->grads + m->n_mlp;
+		launch_grad_bin(s, ba);
+	}
+	if (overlap) { HIPCHK(hipEventRecord(m->ev_join, sw)); HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0)); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }

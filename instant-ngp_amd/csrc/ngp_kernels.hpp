@@ -8,7 +8,7 @@ namespace ngp {
 
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
-enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
+enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
 struct TrainCounters {
@@ -105,8 +105,19 @@ void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* g
 void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw);
 uint32_t wgrad_n_partials();
 
+// binned scatter of the hashed levels (model_kernels.hip)
+constexpr uint32_t GRAD_BIN_CHUNK_LOG2 = 12;   // 4096 table entries per chunk (64 KiB fp32 LDS accumulator)
+constexpr uint32_t GRAD_BIN_MAX_CHUNKS = 128;  // hashmap sizes up to 2^19
+constexpr uint32_t GRAD_BIN_SAMPLES = 512;     // samples per k_grad_bin block
+struct GradBinArgs {
+	const GridMeta* gm; const float* in; uint32_t in_stride, n;
+	const uint2* denc_lv; uint32_t denc_cap;
+	uint32_t levels[MAX_LEVELS]; uint32_t n_hashed, max_chunks, cap;
+	uint2* vals; uint16_t* idxs; uint32_t* cursors; ngp_half* grid_grad_;
+};
+void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags);
+	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad);
@@ -150,6 +161,6 @@ void launch_render_composite(hipStream_t s, const RenderArgs& a, uint32_t n_aliv
 void launch_render_finish(hipStream_t s, const RenderArgs& a, uint32_t pixel_begin, uint32_t n, float* frame, float* depth);
 
 // ---- optional per-kernel HIP-event timing (bench.py roofline leg) -----------------------------
-enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_COUNT };
+enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_GRAD_BIN, P_COUNT };
 
 } // namespace ngp

@@ -33,7 +33,7 @@ def main():
     A.check(lib, lib.ngp_nerf_train(nerf, None, pretrain))
     lib.ngp_profile_name.restype = C.c_char_p
     npf = lib.ngp_profile_count()
-    variants = [("default", 0), ("t1_occ2", 1024), ("default_again", 0), ("t1_occ2_again", 1024), ("fwd_pair_loads", 256), ("fwd_occ4", 512), ("t1_no_quads", 128), ("t1_no_pair_halves", 64), ("k3_thread_per_ray", 32), ("t1_no_merge", 16), ("t1_no_scatter", 2)]
+    variants = [("t1_no_binning", 2048), ("default", 0), ("t1_occ2", 1024), ("default_again", 0), ("t1_occ2_again", 1024), ("fwd_pair_loads", 256), ("fwd_occ4", 512), ("t1_no_quads", 128), ("t1_no_pair_halves", 64), ("k3_thread_per_ray", 32), ("t1_no_merge", 16), ("t1_no_scatter", 2)]
     if len(sys.argv) > 3:
         keep = sys.argv[3].split(",")
         variants = [v for v in variants if v[0] in keep]
