@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_generate_training_samples_v2(K1A
 // rounding of (n + k1) + k2 vs n + (k1 + k2) and of fl(fl(x*M)/M): the great majority of rays are
 // bit-identical, the rest carry <= 2-ulp offsets in t (tests/test_gpu_nerf.py quantifies both).
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t K1_GROUP = 8;          // lattice chunks tested per k1_count iteration
 constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
 constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
 
@@ -280,13 +281,32 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	const Box aabb(a.aabb);
 	RaySetup r;
 	r.o[0] = r.o[1] = r.o[2] = 0.f; r.d[0] = r.d[1] = 0.f; r.d[2] = 1.f; r.startt = 0.f; r.nprime = 0.f; r.count = 0; r.flags = 0;
+	for (int k = 0; k < 6; ++k) r.tgt[k] = 0.f;
 	uint32_t img = image_idx(i, n_rays, a.n_images);
 	const ngp_image_meta& m = a.metadata[img];
 	Rng rng(a.rng);
 	rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
 	f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
-	if (!(read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f)) {
+	const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+	if (!(tex.x < 0.0f)) {
 		(void)rng.next_float(); // motionblur_time
+		if (a.ray_targets_out) { // K3's target colour (testbed_nerf.cu:930-960): same rng stream position, same arithmetic
+			Rng rng_bg = rng;
+			f3 background_color = ld3(a.background_color), rgbtarget;
+			if (a.random_bg_color) { background_color.x = rng_bg.next_float(); background_color.y = rng_bg.next_float(); background_color.z = rng_bg.next_float(); }
+			background_color = srgb_to_linear3(background_color);
+			const f3 trgb = mk3(tex.x, tex.y, tex.z);
+			if (a.linear_colors || !a.color_space_srgb) {
+				rgbtarget = trgb + (1.0f - tex.w) * background_color;
+				if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+			} else {
+				background_color = linear_to_srgb3(background_color);
+				if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
+				else rgbtarget = background_color;
+			}
+			r.tgt[0] = rgbtarget.x; r.tgt[1] = rgbtarget.y; r.tgt[2] = rgbtarget.z;
+			r.tgt[3] = background_color.x; r.tgt[4] = background_color.y; r.tgt[5] = background_color.z;
+		}
 		const M43 xform = ldm43(a.xforms[img].start);
 		f3 ro, rd;
 		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
@@ -311,21 +331,24 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t n_local = ray_end - ray_begin;
-	const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	if (li >= n_local) return;
+	// Persistent grid: the launch is sized for the ray CAP (2^18) while a step marches ~5*10^4 rays, and a kernel of 262k
+	// one-ray wavefronts is bound by the wavefront launch rate (~1-2.5 waves/clk chip-wide, measured 85 us) -- so a fixed
+	// number of wavefronts loops over the rays instead.
+	const uint32_t lane = threadIdx.x & 63u;
+	for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n_local; li += gridDim.x * 4) {
 	const RaySetup r = rs[li];
 	uint32_t cnt = 0, n_chunks = 0;
 	if (r.flags) {
 		const Box aabb(a.aabb);
 		const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
-		// Four chunks are tested per iteration so that four independent occupancy loads are in flight (the loop is a
+		// Eight chunks are tested per iteration so that eight independent occupancy loads are in flight (the loop is a
 		// chain of dependent ~1 us loads otherwise); the exit tests are then replayed in chunk order, so masks, counts
 		// and n_chunks are exactly those of the one-chunk-at-a-time loop.
 		bool done = false;
-		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += 4) {
-			uint64_t m[4], in[4];
+		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
+			uint64_t m[K1_GROUP], in[K1_GROUP];
 #pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) {
+			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				const float t = lattice_t(r, (ch0 + u) * 64 + lane, a.cone_angle_constant);
 				const f3 pos = ro + t * rdn;
 				const bool inside = aabb.contains(pos);
@@ -334,13 +357,14 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 					// 64 consecutive lattice points span ~14 voxels: the byte loads of a wavefront coalesce into a few
 					// L1/L2 lines, and thousands of resident wavefronts hide their latency (no LDS staging needed here)
 					const float dt = calc_dt(t, a.cone_angle_constant);
-					occ = occupied_at(pos, a.bitfield, mip_from_dt(dt, pos, a.max_mip));
+					const uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
+					occ = a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
 				}
 				m[u] = __ballot(occ);
 				in[u] = __ballot(inside);
 			}
 #pragma unroll
-			for (uint32_t u = 0; u < 4; ++u) {
+			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				if (done || cnt >= N_STEPS) { done = true; break; }
 				if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch0 + u] = m[u];
 				cnt += (uint32_t)__popcll(m[u]);
@@ -354,6 +378,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		rs[li].count = cnt;
 		rs[li].flags = n_chunks;
 		scan_in[li] = (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
+	}
 	}
 }
 
@@ -418,11 +443,12 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
-	const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	if (li >= ray_end - ray_begin) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const Box aabb(a.aabb);
+	for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < ray_end - ray_begin; li += gridDim.x * 4) { // persistent grid, see k1_count
 	const RaySetup r = rs[li];
 	const uint32_t count = r.count;
-	if (count == 0) return;
+	if (count == 0) continue;
 	const uint64_t so = scan_out[li];
 	const uint32_t base = (uint32_t)so, slot = (uint32_t)(so >> 32);
 	const bool fits = base + count <= max_samples; // testbed_nerf.cu:813-815: rays past the cap are dropped
@@ -432,9 +458,12 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 		a.rays_out[slot] = rr;
 		a.numsteps_out[slot * 2 + 0] = fits ? count : 0u;
 		a.numsteps_out[slot * 2 + 1] = base;
+		if (a.ray_targets_out) {
+			float4* tg = (float4*)(a.ray_targets_out + (size_t)slot * 8);
+			tg[0] = make_float4(r.tgt[0], r.tgt[1], r.tgt[2], r.tgt[3]); tg[1] = make_float4(r.tgt[4], r.tgt[5], 0.f, 0.f);
+		}
 	}
-	if (!fits) return;
-	const Box aabb(a.aabb);
+	if (!fits) continue;
 	const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
 	const f3 wd = warp_direction(rdn);
 	float* co = a.coords_out + (size_t)base * 7;
@@ -453,8 +482,24 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 		}
 		written += (uint32_t)__popcll(m);
 	}
+	}
 }
 
+// x-major copy of the Morton-ordered bitfield (all cascades): one thread per output byte = 8 x-consecutive cells
+__global__ void k_build_linear_bitfield(const uint8_t* __restrict__ bitfield, uint8_t* __restrict__ linear, uint32_t n_bytes) {
+	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_bytes) return;
+	const uint32_t casc = b / (GRID_N_CELLS / 8), lb = b % (GRID_N_CELLS / 8);
+	const uint32_t cell0 = lb * 8, x0 = cell0 % GRIDSIZE, y = (cell0 / GRIDSIZE) % GRIDSIZE, z = cell0 / (GRIDSIZE * GRIDSIZE);
+	const uint8_t* src = bitfield + grid_mip_offset(casc) / 8;
+	uint32_t out = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 8; ++k) {
+		const uint32_t m = morton3D(x0 + k, y, z);
+		out |= ((src[m >> 3] >> (m & 7u)) & 1u) << k;
+	}
+	linear[b] = (uint8_t)out;
+}
 // 64^3 coarse mask of cascade 0: bit b of word w = (fine bitfield byte 32*w + b) != 0
 __global__ void k_build_coarse_mask(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,12 +660,14 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	__shared__ uint32_t s_base;
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t n_active = *a.rays_counter;
-	if (blockIdx.x * K3_RAYS_PER_BLOCK >= n_active) return; // uniform
-	const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const uint32_t i = blockIdx.x * K3_RAYS_PER_BLOCK + wid;
-	const bool active = i < n_active;
+	const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
 	const Box aabb(a.aabb);
 	const float EPSILON = 1e-4f;
+	float block_loss = 0.f; // thread 0 only
+	// persistent grid (see k1_count): each workgroup loops over groups of 16 rays
+	for (uint32_t grp = blockIdx.x; grp * K3_RAYS_PER_BLOCK < n_active; grp += gridDim.x) {
+	const uint32_t i = grp * K3_RAYS_PER_BLOCK + wid; // wave-uniform (wid is a scalar)
+	const bool active = i < n_active;
 
 	uint32_t numsteps = 0, base = 0, compacted = 0;
 	const float* cin = nullptr;
@@ -638,20 +685,27 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		} else { l0 = __half2float(lo[0]); l1 = __half2float(lo[1]); l2 = __half2float(lo[2]); l3 = __half2float(lo[3]); }
 	};
 	if (active) {
-		numsteps = a.numsteps_inout[i * 2 + 0];
-		base = a.numsteps_inout[i * 2 + 1];
-		const uint32_t ray_idx = a.ray_indices_in[i];
+		// per-ray values are wave-uniform: keep them in scalar registers
+		numsteps = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 0]);
+		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 1]);
 		ray_o = ld3(a.rays_in[i].o);
-		// The target-pixel chain (ray index -> image metadata -> texel) is issued BEFORE the sample pass so that its three
-		// dependent memory latencies overlap the sample loads instead of following them (uniform across the wave).
-		Rng rng(a.rng);
-		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
-		const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
-		const ngp_image_meta& m = a.metadata[img];
-		const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
-		rng.advance(1); // motionblur_time
-		if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
-		const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+		f4 tex = {0.f, 0.f, 0.f, 0.f};
+		if (a.ray_targets) { // computed once per ray by k1_setup
+			const float4 t0 = ((const float4*)(a.ray_targets + (size_t)i * 8))[0], t1 = ((const float4*)(a.ray_targets + (size_t)i * 8))[1];
+			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y);
+		} else {
+			const uint32_t ray_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ray_indices_in[i]);
+			// The target-pixel chain (ray index -> image metadata -> texel) is issued BEFORE the sample pass so that its three
+			// dependent memory latencies overlap the sample loads instead of following them (uniform across the wave).
+			Rng rng(a.rng);
+			rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
+			const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+			const ngp_image_meta& m = a.metadata[img];
+			const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+			rng.advance(1); // motionblur_time
+			if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
+			tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+		}
 
 		cin = a.coords_in + (size_t)base * 7;
 		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
@@ -689,15 +743,17 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		}
 		T_final = T_run;
 		// target colour and background: identical to the sequential kernel (uniform across the wave)
-		background_color = srgb_to_linear3(background_color);
-		const f3 trgb = mk3(tex.x, tex.y, tex.z);
-		if (a.linear_colors || !a.color_space_srgb) {
-			rgbtarget = trgb + (1.0f - tex.w) * background_color;
-			if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
-		} else {
-			background_color = linear_to_srgb3(background_color);
-			if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
-			else rgbtarget = background_color;
+		if (!a.ray_targets) {
+			background_color = srgb_to_linear3(background_color);
+			const f3 trgb = mk3(tex.x, tex.y, tex.z);
+			if (a.linear_colors || !a.color_space_srgb) {
+				rgbtarget = trgb + (1.0f - tex.w) * background_color;
+				if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+			} else {
+				background_color = linear_to_srgb3(background_color);
+				if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
+				else rgbtarget = background_color;
+			}
 		}
 		if (compacted == numsteps) rgb_ray = rgb_ray + T_final * background_color;
 	}
@@ -777,15 +833,11 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
 		}
 	}
-	if (a.loss_output) {
-		if (lane == 0) s_loss[wid] = my_loss;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			float t = 0.f;
-			for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) t += s_loss[w];
-			if (t != 0.f) atomicAdd(a.loss_output, t);
-		}
+	if (lane == 0) s_loss[wid] = my_loss;
+	__syncthreads(); // also protects s_cnt / s_base against the next group
+	if (threadIdx.x == 0) for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) block_loss += s_loss[w];
 	}
+	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -982,11 +1034,16 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	uint64_t* partial = (uint64_t*)p;
 	const uint32_t n_scan_blocks = blocks(max_local_rays, SCAN_BLOCK);
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128)), dim3(128), 0, s, a, rs);
-	hipLaunchKernelGGL(k1_count, dim3(blocks(max_local_rays, 4)), dim3(256), 0, s, a, rs, masks, scan_in);
+	const uint32_t ray_grid = std::min<uint32_t>(blocks(max_local_rays, 4), 256u * 8u); // persistent: 8 workgroups of 4 wavefronts per CU
+	hipLaunchKernelGGL(k1_count, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, scan_in);
 	hipLaunchKernelGGL(k_scan_partials, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, a.n_rays, a.n_rays_ptr, a.rank, a.world_size, partial);
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, partial, n_scan_blocks, a.numsteps_counter, a.ray_counter);
 	hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, a.n_rays, a.n_rays_ptr, a.rank, a.world_size, partial, scan_out);
-	hipLaunchKernelGGL(k1_write, dim3(blocks(max_local_rays, 4)), dim3(256), 0, s, a, rs, masks, scan_out);
+	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, scan_out);
+}
+void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades) {
+	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;
+	hipLaunchKernelGGL(k_build_linear_bitfield, dim3(blocks(n_bytes, 256)), dim3(256), 0, s, bitfield, linear, n_bytes);
 }
 void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse) {
 	hipLaunchKernelGGL(k_build_coarse_mask, dim3(blocks(COARSE_WORDS, 256)), dim3(256), 0, s, bitfield, coarse);
@@ -994,7 +1051,7 @@ void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* 
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
-	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(blocks(max_rays, K3_RAYS_PER_BLOCK)), dim3(1024), 0, s, a);
+	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
 	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride);

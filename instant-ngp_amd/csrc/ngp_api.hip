@@ -476,14 +476,19 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 		const uint8_t* bitfield, uint32_t max_mip, int snap_to_pixel_centers, float cone_angle_constant) {
 	REQUIRE(world_size >= 1 && rank < world_size, "generate_training_samples: bad rank/world_size");
 	K1Args a;
+	a.ray_targets_out = nullptr; a.background_color[0] = a.background_color[1] = a.background_color[2] = 0.f; a.color_space_srgb = a.random_bg_color = a.linear_colors = 0;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.rank = rank; a.world_size = world_size; a.aabb = aabb; a.max_samples = max_samples;
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
 	static uint32_t* s_coarse = nullptr;
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
+	static uint8_t* s_linear = nullptr;
 	if (!s_coarse && dev_alloc(&s_coarse, 8192)) return 1;
+	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
 	launch_build_coarse_mask((hipStream_t)stream, bitfield, s_coarse);
+	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, std::min<uint32_t>(max_mip + 1, N_CASCADES));
+	a.bitfield_linear = s_linear;
 	const uint32_t max_local = n_rays / world_size + 1;
 	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
 		launch_generate_training_samples((hipStream_t)stream, a, max_local, s_coarse);
@@ -510,6 +515,7 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 		uint32_t dloss_stride, int loss_type, float* loss_output, int rgb_activation, int density_activation, int snap_to_pixel_centers,
 		const float* mean_density_ptr, float near_distance) {
 	K3Args a;
+	a.ray_targets = nullptr;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.aabb = aabb; a.rng = rng; a.max_samples_compacted = max_samples_compacted; a.rays_counter = rays_counter;
 	a.loss_scale = loss_scale; for (int k = 0; k < 3; ++k) a.background_color[k] = background_color[k];
 	a.color_space_srgb = color_space_srgb; a.random_bg_color = random_bg_color; a.linear_colors = linear_colors; a.n_images = n_training_images; a.metadata = metadata;
@@ -575,10 +581,12 @@ struct ngp_nerf {
 	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
+	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
 	uint32_t* coarse_mask = nullptr; // 64^3 any-occupied mask of cascade 0 for K1 (32 KiB)
+	uint8_t* bitfield_linear = nullptr; // x-major copy of the bitfield for the lattice marchers
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
 	// host-side deterministic state (no device read-back needed)
 	Rng rng, density_grid_rng;
@@ -601,13 +609,14 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
-		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
 	HIPCHK(hipMemset(t->coarse_mask, 0, 8192 * 4));
+	HIPCHK(hipMemset(t->bitfield_linear, 0, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)));
 	TrainCounters c; memset(&c, 0, sizeof(c));
 	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
 	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
@@ -628,7 +637,7 @@ extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->bitfield_linear, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -699,6 +708,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
 	launch_build_coarse_mask(s, t->bitfield, t->coarse_mask);
+	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -726,6 +736,10 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	K1Args k1;
 	k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 	k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
+	const bool lattice = !(g_debug_flags & DBG_K1_REFERENCE_LAYOUT);
+	k1.bitfield_linear = t->bitfield_linear;
+	k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
+	k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 	k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
 	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
@@ -743,6 +757,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k3.rays_in = t->rays; k3.numsteps_inout = t->numsteps; k3.coords_in = t->coords; k3.coords_out = t->coords_compacted; k3.dloss_doutput = t->dloss; k3.dloss_stride = 4;
 	k3.loss_type = o.loss_type; k3.loss_output = &c->loss_sum; k3.rgb_activation = o.rgb_activation; k3.density_activation = o.density_activation;
 	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
+	k3.ray_targets = lattice ? t->ray_targets : nullptr;
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
 	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->n_valid_compacted, t->coords_compacted, 7, t->dloss, 4); }
@@ -800,6 +815,7 @@ extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const f
 	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield((hipStream_t)stream, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
 	launch_build_coarse_mask((hipStream_t)stream, t->bitfield, t->coarse_mask);
+	launch_build_linear_bitfield((hipStream_t)stream, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

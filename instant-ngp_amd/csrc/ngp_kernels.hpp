@@ -40,7 +40,11 @@ struct K1Args {
 	uint32_t* ray_indices_out; ngp_ray* rays_out; uint32_t* numsteps_out; float* coords_out;
 	uint32_t n_images; const ngp_image_meta* metadata; const ngp_xform* xforms;
 	const uint8_t* bitfield; uint32_t max_mip;
+	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
 	int snap_to_pixel_centers; float cone_angle_constant;
+	// optional (lattice K1 only): per-ray training target {rgbtarget[3], background[3], 0, 0} for K3, computed by the thread-per-ray
+	// setup kernel so that K3's wavefronts do not all repeat it (same arithmetic as compute_loss_kernel_train_nerf)
+	float* ray_targets_out; float background_color[3]; int color_space_srgb, random_bg_color, linear_colors;
 };
 
 struct K3Args {
@@ -58,14 +62,16 @@ struct K3Args {
 	int loss_type; float* loss_output; // ONE float accumulator (sum over rays)
 	int rgb_activation, density_activation, snap_to_pixel_centers;
 	const float* mean_density_ptr; float near_distance;
+	const float* ray_targets; // optional: K1Args::ray_targets_out (8 floats per active ray)
 };
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank, const uint32_t* coarse_mask);
 // per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
-struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; };
+struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[6]; };
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, const uint32_t* coarse_mask, void* scratch);
 void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse_8192_words);
+void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride);
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
