@@ -155,7 +155,7 @@ def main():
     s3 = stats()
     lib.ngp_profile_name.restype = C.c_char_p
     kern = {lib.ngp_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(npf) if cnt[i]}
-    n_inf_avg = s3.measured_batch_size_before_compaction  # last step's marched samples (steady state)
+    n_inf_avg = s3.network_evaluations  # network evaluations of the last step's K2 (lazy K2: fewer than the marched samples)
     per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd": BYTES_PER_SAMPLE_T1 * args.batch,
                         "k_optimizer": BYTES_PER_PARAM_OPT * n_params.value}
     if "k_grad_bin+accumulate" in kern and "k_train_fwd_bwd" in kern:

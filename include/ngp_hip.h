@@ -123,6 +123,8 @@ typedef struct ngp_nerf_stats {
 	float loss;                                     /* last loss scalar (every 16 steps in the reference) */
 	uint64_t total_rays;                            /* sum of rays_per_batch over all steps */
 	uint64_t total_samples;                         /* sum of measured_batch_size */
+	uint32_t network_evaluations;                   /* K2 samples actually evaluated in the last step (== marched samples when eager) */
+	uint32_t reserved;
 } ngp_nerf_stats;
 
 typedef struct ngp_model ngp_model;      /* NerfNetwork + Trainer + optimizer state */
@@ -312,6 +314,9 @@ int ngp_nerf_scratch_ptrs(ngp_nerf*, uint32_t** ray_indices, ngp_ray** rays, uin
                           ngp_half** mlp_out, float** coords_compacted, ngp_half** dloss, void** counters);
 int ngp_nerf_set_rays_per_batch(ngp_nerf*, uint32_t rays_per_batch);
 int ngp_nerf_get_rng(ngp_nerf*, ngp_pcg32* rng, ngp_pcg32* density_grid_rng);
+int ngp_nerf_set_rng(ngp_nerf*, const ngp_pcg32* rng);
+/* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
+int ngp_debug_set_flags(uint32_t flags);
 
 #ifdef __cplusplus
 }

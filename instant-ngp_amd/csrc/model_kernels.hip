@@ -382,6 +382,47 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lazy (front-to-back) K2.  The reference evaluates the network on EVERY marched sample and then discards all samples behind
+// the point where a ray's transmittance drops below 1e-4 (compute_loss_kernel_train_nerf: `if (T < EPSILON) break`).  Samples
+// behind the cut influence nothing, so the network is evaluated in rounds of 32 samples per ray: k_k2_round (nerf_kernels.hip,
+// one thread per ray) composites the densities of the previous round and lists the next 32-sample tile only for rays that are
+// still transparent (with a 1 % safety margin on the threshold, so that K3's own test can never walk into an unevaluated
+// sample); the last round lists everything that is left.  Same results as the eager order (DBG_K2_EAGER),
+// tests/test_gpu_train.py::test_lazy_k2_matches_eager.  One tile = descriptor {first sample, valid lanes}.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
+		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const uint32_t n_tiles = min(la.n_tiles_ptr[la.round], la.tile_cap);
+	if (blockIdx.x * 4 >= n_tiles) return; // uniform: late rounds are small
+	h8* fw = (h8*)smem;
+	load_frags_to_lds(fw, mp.fw_frags, (int)N_FW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const __half* table = (const __half*)mp.grid;
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint2 d = la.tiles[tile];
+		const bool valid = (uint32_t)col < d.y;
+		const uint32_t sample = d.x + (valid ? (uint32_t)col : 0u);
+		FwdState<1> st;
+		const float* p = in + (size_t)sample * in_stride;
+		encode_sample<false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
+		st.rin[0][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
+		fwd_density_l1<1>(fw, lane, st);
+		fwd_density_l2<1>(fw, lane, st);
+		fwd_rgb_l1<1>(fw, lane, st);
+		fwd_rgb_l2<1>(fw, lane, st);
+		f16v o[1];
+		fwd_rgb_l3<1>(fw, lane, st, o);
+		if (hi == 0 && valid) {
+			h4 r = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)st.sigma[0]};
+			*(uint2*)(out + (size_t)sample * out_stride) = __builtin_bit_cast(uint2, r);
+		}
+	}
+}
+
 // encoding only (unit-test hook): out[i][32] halfs in NATURAL feature order (level-major)
 __global__ void __launch_bounds__(256) k_encode_only(const GridMeta* __restrict__ gm, const __half* __restrict__ table, const float* __restrict__ pos, uint32_t stride,
 		uint32_t n, __half* __restrict__ out) {
@@ -1115,6 +1156,18 @@ void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, co
 		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024); }
 	}
 #undef NGP_LAUNCH_INF
+}
+void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
+		ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la_in) {
+	if (max_rays == 0) return;
+	K2LazyArgs la = la_in;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap + 3) / 4, (uint64_t)num_cus() * 3);
+	for (uint32_t r = 0; r < K2_ROUNDS; ++r) {
+		la.round = r;
+		launch_k2_round(s, la, max_rays, out_stride);
+		hipLaunchKernelGGL(k_inference_tiles, dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
+	}
+	(void)max_samples;
 }
 void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out) {
 	if (n == 0) return;

@@ -736,7 +736,8 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const uint32_t n_proc = fail ? (uint32_t)(__ffsll((long long)fail) - 1) : (uint32_t)__popcll(vm);
 			const bool proc = lane < n_proc;
 			const float w = proc ? alpha * T_k : 0.f;
-			rgb_ray = rgb_ray + mk3(wave_sum(w * rgb.x), wave_sum(w * rgb.y), wave_sum(w * rgb.z));
+			// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
+			rgb_ray = rgb_ray + mk3(wave_sum(proc ? w * rgb.x : 0.f), wave_sum(proc ? w * rgb.y : 0.f), wave_sum(proc ? w * rgb.z : 0.f));
 			if (n_proc) T_run = T_run * __shfl(incl, (int)n_proc - 1, 64);
 			compacted += n_proc;
 			if (fail) break;
@@ -838,6 +839,43 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	if (threadIdx.x == 0) for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) block_loss += s_loss[w];
 	}
 	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
+}
+
+// Lazy K2, one thread per active ray: composite the previous round's 32 densities, list the next tile of rays that are still
+// transparent (see k_inference_tiles).  T_run < 0 marks a finished ray.
+__global__ void __launch_bounds__(256) k_k2_round(K2LazyArgs la, uint32_t out_stride) {
+	const uint32_t n_rays = *la.n_rays_ptr;
+	const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t r = la.round, start = 32u * r;
+	const bool last = r + 1 == K2_ROUNDS;
+	uint32_t n_eval = 0;
+	if (ray < n_rays) {
+		const uint2 nb = ((const uint2*)la.numsteps)[ray];
+		const uint32_t count = nb.x, base = nb.y;
+		float T = r == 0 ? 1.f : la.T_run[ray];
+		if (count > start && !(T < 0.f)) {
+			if (r > 0) {
+				for (uint32_t k = start - 32u; k < start; ++k) {
+					const float dt = unwarp_dt(la.coords[(size_t)(base + k) * 7 + 3]);
+					const float sigma = act_density(__half2float(((const __half*)la.mlp_out)[(size_t)(base + k) * out_stride + 3]), la.density_activation);
+					T *= 1.f - (1.f - __expf(-sigma * dt));
+				}
+				if (T < 0.99e-4f) T = -1.f; // opaque (1 % margin below K3's threshold); NaN stays alive
+			}
+			if (!(T < 0.f)) {
+				const uint32_t rest = count - start, n = last ? rest : min(rest, 32u), nt = (n + 31u) / 32u;
+				const uint32_t off = atomicAdd(la.n_tiles_ptr + r, nt);
+				for (uint32_t j = 0; j < nt; ++j)
+					if (off + j < la.tile_cap) la.tiles[off + j] = make_uint2(base + start + 32u * j, min(32u, n - 32u * j));
+				n_eval = n;
+			}
+		} else T = -1.f;
+		if (!last) la.T_run[ray] = T;
+	}
+	// statistics: samples actually evaluated (wave reduction, one atomic per wavefront)
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) n_eval += (uint32_t)__shfl_xor((int)n_eval, d, 64);
+	if ((threadIdx.x & 63u) == 0 && n_eval) atomicAdd(la.n_eval_ptr, n_eval);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -999,7 +1037,7 @@ __global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size, 
 	c->max_inference = mb == 0 ? max_samples : ((min(mb, max_samples) + 255u) / 256u) * 256u;
 	if (mb == 0) c->measured_batch_size_before_compaction = max_samples;
 	c->numsteps_counter = 0; c->numsteps_counter_compacted = 0; c->ray_counter = 0; c->loss_sum = 0.f;
-	c->n_valid_compacted = 0;
+	c->n_valid_compacted = 0; for (int r = 0; r < 4; ++r) c->k2_tiles[r] = 0; c->k2_samples_last = c->k2_samples; c->k2_samples = 0;
 }
 // clamp the compacted counter to B for K4 / statistics (the reference relies on fill_rollover's guard)
 __global__ void k_clamp_compacted(TrainCounters* c, uint32_t target_batch_size) {
@@ -1052,6 +1090,9 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
 	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
+}
+void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride) {
+	hipLaunchKernelGGL(k_k2_round, dim3(blocks(max_rays, 256)), dim3(256), 0, s, la, out_stride);
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
 	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride);

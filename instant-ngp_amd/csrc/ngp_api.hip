@@ -581,6 +581,7 @@ struct ngp_nerf {
 	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
+	float* k2_T = nullptr; uint2* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
@@ -609,7 +610,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
-		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)(t->k2_tile_cap = max_samples / 32 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
@@ -637,7 +638,7 @@ extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->bitfield_linear, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->bitfield_linear, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -748,6 +749,12 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	  else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->coarse_mask, t->k1_scratch); }
 	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
 	{ ProfScope ps(P_K2_INFERENCE, s);
+	  if (!(g_debug_flags & DBG_K2_EAGER)) {
+		K2LazyArgs la;
+		la.numsteps = t->numsteps; la.n_rays_ptr = &c->ray_counter; la.tiles = t->k2_tiles; la.tile_cap = t->k2_tile_cap; la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0;
+		la.n_eval_ptr = &c->k2_samples; la.coords = t->coords; la.mlp_out = t->mlp_out; la.density_activation = o.density_activation;
+		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la);
+	  } else
 	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }
 	K3Args k3;
 	k3.n_rays = 0; k3.n_rays_ptr = &c->rays_per_batch; k3.aabb = t->aabb; k3.rng = pod(t->rng); k3.max_samples_compacted = B; k3.rays_counter = &c->ray_counter;
@@ -804,6 +811,7 @@ extern "C" int ngp_nerf_get_stats(ngp_nerf* t, void* stream, ngp_nerf_stats* out
 	out->training_step = c.training_step; out->rays_per_batch = c.rays_per_batch; out->n_rays_last = c.n_rays_last;
 	out->measured_batch_size = c.measured_batch_size; out->measured_batch_size_before_compaction = c.measured_batch_size_before_compaction;
 	out->loss = c.loss_scalar; out->total_rays = c.total_rays; out->total_samples = c.total_samples;
+	out->network_evaluations = c.k2_samples_last ? c.k2_samples_last : c.measured_batch_size_before_compaction; out->reserved = 0;
 	return 0;
 }
 extern "C" int ngp_nerf_density_grid_ptrs(ngp_nerf* t, float** grid, uint8_t** bitfield, float** mean) {
@@ -836,6 +844,7 @@ extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
 	HIPCHK(hipMemcpy(&t->counters->training_step, &step, 4, hipMemcpyHostToDevice));
 	return 0;
 }
+extern "C" int ngp_nerf_set_rng(ngp_nerf* t, const ngp_pcg32* rng) { t->rng.state = rng->state; t->rng.inc = rng->inc; return 0; }
 extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = pod(t->rng); *grid_rng = pod(t->density_grid_rng); return 0; }
 
 // Testbed::render_nerf (testbed_nerf.cu:1894-2149): one spp of a frame into premultiplied linear RGBA + depth

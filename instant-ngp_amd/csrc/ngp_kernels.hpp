@@ -8,7 +8,7 @@ namespace ngp {
 
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
-enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
+enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
 struct TrainCounters {
@@ -28,6 +28,8 @@ struct TrainCounters {
 	uint32_t ema_step;                              // density_grid_ema_step
 	uint64_t total_rays;
 	uint64_t total_samples;
+	uint32_t k2_tiles[4];                           // lazy K2: number of 32-sample tiles of each round (k_k2_round)
+	uint32_t k2_samples, k2_samples_last;           // network evaluations performed by K2 in this / the previous step (statistics)
 };
 
 struct K1Args {
@@ -105,6 +107,20 @@ struct ModelPtrs {
 	const ngp_half* bw_frags;   // N_BW_FRAGS * 512 halfs
 };
 
+// lazy (front-to-back) K2 in rounds of 32-sample tiles (one tile = 32 consecutive samples of ONE ray): round r evaluates samples
+// [32r, 32r+32) of the rays that are still transparent after round r-1; the last round takes everything that is left
+constexpr uint32_t K2_ROUNDS = 4;
+struct K2LazyArgs {
+	const uint32_t* numsteps;       // per active ray: {count, base}
+	const uint32_t* n_rays_ptr;     // active rays (K1's ray counter)
+	uint2* tiles; uint32_t tile_cap; uint32_t* n_tiles_ptr /* [K2_ROUNDS] */; uint32_t* n_eval_ptr;
+	float* T_run;                   // per active ray: transmittance in front of the current round, < 0 = done
+	const float* coords; const ngp_half* mlp_out; int density_activation;
+	uint32_t round;
+};
+void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride);
+void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
+	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la);
 void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
 	ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset);
 void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out);

@@ -59,7 +59,8 @@ class NerfOptions(C.Structure):
 
 class NerfStats(C.Structure):
     _fields_ = [("training_step", u32), ("rays_per_batch", u32), ("n_rays_last", u32), ("measured_batch_size", u32),
-                ("measured_batch_size_before_compaction", u32), ("loss", f32), ("total_rays", u64), ("total_samples", u64)]
+                ("measured_batch_size_before_compaction", u32), ("loss", f32), ("total_rays", u64), ("total_samples", u64),
+                ("network_evaluations", u32), ("reserved", u32)]
 
 
 class RenderParams(C.Structure):

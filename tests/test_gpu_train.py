@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import ngp_abi as A
-from common import HipModel, OraModel, host_meta, make_small_dataset, ptr
+from common import HipModel, OraModel, half_to_f32, host_meta, make_small_dataset, ptr
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +68,62 @@ def test_training_converges(hip, ora):
     assert np.isfinite(st.loss) and st.loss < 0.5 * l0, (l0, st.loss)
     assert 0 < st.measured_batch_size <= B * 1.5
     assert st.rays_per_batch % 256 == 0 and st.rays_per_batch > 4096  # the grid got sparser -> more rays per batch
+    hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
+
+
+def test_lazy_k2_matches_eager(ora, hip):
+    """Front-to-back (lazy) K2 evaluates only the samples in front of each ray's transmittance cut; the eager order evaluates
+    every marched sample like the reference. From the same trained state, one forward/backward pass must compact exactly the
+    same samples and produce the same gradients (up to the order of the fp16 atomics on the dense levels)."""
+    import torch
+    B = 1 << 17
+    s = _make(ora, hip, B, n_images=12, res=96)
+    A.check(hip, hip.ngp_nerf_train(s["t"], None, 400))
+    st = _stats(hip, s["t"])
+    print("network evaluations", st.network_evaluations, "of", st.measured_batch_size_before_compaction, "marched samples")
+    assert st.network_evaluations < st.measured_batch_size_before_compaction
+    hm = s["hm"]
+    size = hip.ngp_model_serialized_size
+    size.restype = C.c_uint64
+    nbytes = size(hm.h, 0)
+    buf = (C.c_uint8 * nbytes)()
+    A.check(hip, hip.ngp_model_serialize_host(hm.h, buf, C.c_uint64(nbytes), 0))
+    g, bf, mean = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    hip.ngp_nerf_density_grid_ptrs(s["t"], C.byref(g), C.byref(bf), C.byref(mean))
+    n_cells = 128 ** 3
+    grid = np.empty(n_cells, dtype=np.float32)
+    torch.cuda.synchronize()
+    rt = C.CDLL("libamdhip64.so")
+    assert rt.hipMemcpy(ptr(grid), g, C.c_size_t(n_cells * 4), 2) == 0
+    rng, grng = A.Pcg32(), A.Pcg32()
+    hip.ngp_nerf_get_rng(s["t"], C.byref(rng), C.byref(grng))
+    rays = min(st.rays_per_batch, 12000)  # far below K1's sample cap and K3's batch clamp (both order dependent)
+    res = {}
+    for name, flags in (("lazy", 0), ("eager", 8192)):
+        c = _make(ora, hip, B, n_images=12, res=96)
+        A.check(hip, hip.ngp_model_deserialize_host(c["hm"].h, buf, C.c_uint64(nbytes)))
+        A.check(hip, hip.ngp_nerf_set_density_grid_host(c["t"], None, ptr(grid), C.c_uint64(n_cells)))
+        hip.ngp_nerf_set_rng(c["t"], C.byref(rng))
+        A.check(hip, hip.ngp_nerf_set_rays_per_batch(c["t"], rays))
+        hip.ngp_debug_set_flags(flags)
+        try:
+            A.check(hip, hip.ngp_nerf_train_forward_backward(c["t"], None))
+        finally:
+            hip.ngp_debug_set_flags(0)
+        cp = C.POINTER(C.c_uint32)()
+        hip.ngp_nerf_counter_ptrs(c["t"], C.byref(cp))
+        cnt = np.empty(2, dtype=np.uint32)
+        torch.cuda.synchronize()
+        assert rt.hipMemcpy(ptr(cnt), cp, C.c_size_t(8), 2) == 0
+        res[name] = (cnt.copy(), half_to_f32(c["hm"].read("grads", torch)))
+        hip.ngp_nerf_destroy(c["t"]); ora.ora_nerf_destroy(c["ot"])
+    (cl, gl), (ce, ge) = res["lazy"], res["eager"]
+    print("marched, compacted:", cl, ce)
+    assert cl[0] == ce[0] and cl[1] == ce[1] and 0 < cl[1] < B
+    assert cl[1] < 0.7 * cl[0]  # the cut is active in this state
+    err = np.linalg.norm(gl - ge) / np.linalg.norm(ge)
+    print("relative gradient difference", err)
+    assert err < 2e-2  # fill_rollover duplicates the FIRST B - n compacted samples, and their order is atomic-order dependent
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
 
 
