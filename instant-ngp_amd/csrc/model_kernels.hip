@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 // one thread per ray) composites the densities of the previous round and lists the next 32-sample tile only for rays that are
 // still transparent (with a 1 % safety margin on the threshold, so that K3's own test can never walk into an unevaluated
 // sample); the last round lists everything that is left.  Same results as the eager order (DBG_K2_EAGER),
-// tests/test_gpu_train.py::test_lazy_k2_matches_eager.  One tile = descriptor {first sample, valid lanes}.
+// tests/test_gpu_train.py::test_lazy_k2_matches_eager.  One tile = descriptor {first sample, valid lanes, ray}.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
 	const __half* table = (const __half*)mp.grid;
 	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-		const uint2 d = la.tiles[tile];
+		const uint4 d = la.tiles[tile];
 		const bool valid = (uint32_t)col < d.y;
 		const uint32_t sample = d.x + (valid ? (uint32_t)col : 0u);
 		FwdState<1> st;
@@ -419,6 +419,20 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		if (hi == 0 && valid) {
 			h4 r = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)st.sigma[0]};
 			*(uint2*)(out + (size_t)sample * out_stride) = __builtin_bit_cast(uint2, r);
+		}
+		// transmittance of this tile (product over its samples of exp(-sigma dt)): k_k2_round decides from it whether the ray
+		// needs its next tile.  An estimate with a safety margin -- K3 recomputes the exact compositing.
+		if (la.round + 1 < K2_ROUNDS) {
+			float od = 0.f; // optical depth of the lane's sample
+			if (hi == 0 && valid) {
+				const float x = st.sigma[0];
+				const float sg = la.density_activation == NGP_ACT_NONE ? x : la.density_activation == NGP_ACT_RELU ? fmaxf(x, 0.f)
+					: la.density_activation == NGP_ACT_LOGISTIC ? 1.f / (1.f + __expf(-x)) : __expf(x);
+				od = sg * (p[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
+			}
+#pragma unroll
+			for (int dd = 16; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64);
+			if (lane == 0) la.T_run[d.z] *= __expf(-od);
 		}
 	}
 }

@@ -841,9 +841,9 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
 }
 
-// Lazy K2, one thread per active ray: composite the previous round's 32 densities, list the next tile of rays that are still
-// transparent (see k_inference_tiles).  T_run < 0 marks a finished ray.
-__global__ void __launch_bounds__(256) k_k2_round(K2LazyArgs la, uint32_t out_stride) {
+// Lazy K2, one thread per active ray: list the next 32-sample tile of the rays that are still transparent (k_inference_tiles
+// keeps T_run = transmittance behind the samples evaluated so far).  T_run < 0 marks a finished ray.
+__global__ void __launch_bounds__(256) k_k2_round(K2LazyArgs la) {
 	const uint32_t n_rays = *la.n_rays_ptr;
 	const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t r = la.round, start = 32u * r;
@@ -853,22 +853,13 @@ __global__ void __launch_bounds__(256) k_k2_round(K2LazyArgs la, uint32_t out_st
 		const uint2 nb = ((const uint2*)la.numsteps)[ray];
 		const uint32_t count = nb.x, base = nb.y;
 		float T = r == 0 ? 1.f : la.T_run[ray];
+		if (T < 0.99e-4f) T = -1.f; // opaque (1 % margin below K3's threshold) or already finished; NaN stays alive
 		if (count > start && !(T < 0.f)) {
-			if (r > 0) {
-				for (uint32_t k = start - 32u; k < start; ++k) {
-					const float dt = unwarp_dt(la.coords[(size_t)(base + k) * 7 + 3]);
-					const float sigma = act_density(__half2float(((const __half*)la.mlp_out)[(size_t)(base + k) * out_stride + 3]), la.density_activation);
-					T *= 1.f - (1.f - __expf(-sigma * dt));
-				}
-				if (T < 0.99e-4f) T = -1.f; // opaque (1 % margin below K3's threshold); NaN stays alive
-			}
-			if (!(T < 0.f)) {
-				const uint32_t rest = count - start, n = last ? rest : min(rest, 32u), nt = (n + 31u) / 32u;
-				const uint32_t off = atomicAdd(la.n_tiles_ptr + r, nt);
-				for (uint32_t j = 0; j < nt; ++j)
-					if (off + j < la.tile_cap) la.tiles[off + j] = make_uint2(base + start + 32u * j, min(32u, n - 32u * j));
-				n_eval = n;
-			}
+			const uint32_t rest = count - start, n = last ? rest : min(rest, 32u), nt = (n + 31u) / 32u;
+			const uint32_t off = atomicAdd(la.n_tiles_ptr + r, nt);
+			for (uint32_t j = 0; j < nt; ++j)
+				if (off + j < la.tile_cap) la.tiles[off + j] = make_uint4(base + start + 32u * j, min(32u, n - 32u * j), ray, 0u);
+			n_eval = n;
 		} else T = -1.f;
 		if (!last) la.T_run[ray] = T;
 	}
@@ -1092,7 +1083,7 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
 }
 void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride) {
-	hipLaunchKernelGGL(k_k2_round, dim3(blocks(max_rays, 256)), dim3(256), 0, s, la, out_stride);
+	hipLaunchKernelGGL(k_k2_round, dim3(blocks(max_rays, 256)), dim3(256), 0, s, la); (void)out_stride;
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
 	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride);

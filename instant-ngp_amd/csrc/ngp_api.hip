@@ -581,7 +581,7 @@ struct ngp_nerf {
 	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
-	float* k2_T = nullptr; uint2* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
+	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
@@ -752,7 +752,8 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	  if (!(g_debug_flags & DBG_K2_EAGER)) {
 		K2LazyArgs la;
 		la.numsteps = t->numsteps; la.n_rays_ptr = &c->ray_counter; la.tiles = t->k2_tiles; la.tile_cap = t->k2_tile_cap; la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0;
-		la.n_eval_ptr = &c->k2_samples; la.coords = t->coords; la.mlp_out = t->mlp_out; la.density_activation = o.density_activation;
+		la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
+		{ const float max_stepsize = MIN_CONE_STEP * (float)(1 << (N_CASCADES - 1)); la.dt_unwarp_scale = max_stepsize - MIN_CONE_STEP; la.dt_unwarp_offset = MIN_CONE_STEP; } // unwarp_dt
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la);
 	  } else
 	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }

@@ -113,9 +113,9 @@ constexpr uint32_t K2_ROUNDS = 4;
 struct K2LazyArgs {
 	const uint32_t* numsteps;       // per active ray: {count, base}
 	const uint32_t* n_rays_ptr;     // active rays (K1's ray counter)
-	uint2* tiles; uint32_t tile_cap; uint32_t* n_tiles_ptr /* [K2_ROUNDS] */; uint32_t* n_eval_ptr;
-	float* T_run;                   // per active ray: transmittance in front of the current round, < 0 = done
-	const float* coords; const ngp_half* mlp_out; int density_activation;
+	uint4* tiles /* {first sample, valid lanes, ray, 0} */; uint32_t tile_cap; uint32_t* n_tiles_ptr /* [K2_ROUNDS] */; uint32_t* n_eval_ptr;
+	float* T_run;                   // per active ray: transmittance behind the evaluated samples (updated by k_inference_tiles), < 0 = done
+	int density_activation; float dt_unwarp_scale, dt_unwarp_offset; // dt = warped * scale + offset (unwarp_dt)
 	uint32_t round;
 };
 void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride);

@@ -76,7 +76,7 @@ def test_lazy_k2_matches_eager(ora, hip):
     every marched sample like the reference. From the same trained state, one forward/backward pass must compact exactly the
     same samples and produce the same gradients (up to the order of the fp16 atomics on the dense levels)."""
     import torch
-    B = 1 << 17
+    B = 1 << 18
     s = _make(ora, hip, B, n_images=12, res=96)
     A.check(hip, hip.ngp_nerf_train(s["t"], None, 400))
     st = _stats(hip, s["t"])
