@@ -190,6 +190,32 @@ uint64_t ngp_model_serialized_size(const ngp_model*, int with_optimizer);
 int ngp_model_serialize_host(ngp_model*, void* buffer_host, uint64_t size, int with_optimizer);
 int ngp_model_deserialize_host(ngp_model*, const void* buffer_host, uint64_t size);
 
+/* ------------------------------------------------------------------ encoding + MLP ------ */
+/* The image and SDF primitives' model (configs/image/base.json, configs/sdf/base.json): a HashGrid encoding of a 2-D / 3-D
+ * position feeding one FullyFusedMLP -- tcnn::NetworkWithInputEncoding, created at testbed.cu:4354-4363 and queried through
+ * Network::inference at testbed_image.cu:383,541 and testbed_sdf.cu:1658.  Forward (inference) path only in this round:
+ * the fused kernel is specialised for L*F = 32 encoded features (L = 16, F = 2), 64 neurons, 2 hidden layers, <= 16 outputs.
+ * Parameter order: MLP weights (row-major [out][in] per layer, output layer padded to 16 rows), then the grid [tcnn]. */
+typedef struct ngp_encmlp_config {
+	uint32_t n_pos_dims;            /* 2 (image uv) or 3 (SDF position), inputs in [0,1]^D */
+	uint32_t n_levels;              /* 16 */
+	uint32_t n_features_per_level;  /* 2  */
+	uint32_t log2_hashmap_size;     /* 19 in BASELINE.json's configs (24 in configs/image/base.json) */
+	uint32_t base_resolution;       /* 16 */
+	float per_level_scale;          /* testbed.cu:4241-4255: image 1.25992 (max res 512 from 16), SDF 1.3819 */
+	uint32_t n_neurons;             /* 64 */
+	uint32_t n_hidden_layers;       /* 2  */
+	uint32_t n_output_dims;         /* 3 (rgb) / 1 (distance) */
+} ngp_encmlp_config;
+typedef struct ngp_encmlp ngp_encmlp;
+int ngp_encmlp_create(const ngp_encmlp_config*, uint64_t seed, ngp_encmlp** out);
+void ngp_encmlp_destroy(ngp_encmlp*);
+int ngp_encmlp_n_params(const ngp_encmlp*, uint64_t* n_params, uint64_t* n_mlp_params);
+int ngp_encmlp_set_params_host(ngp_encmlp*, const float* params_host, uint64_t n);
+int ngp_encmlp_get_params_host(ngp_encmlp*, float* params_host, uint64_t n);
+/* Network::inference: in = n positions (D floats each, `in_stride` floats apart), out = n x n_output_dims halfs, `out_stride` halfs apart */
+int ngp_encmlp_inference(ngp_encmlp*, void* stream, const float* in, uint32_t in_stride, uint32_t n, ngp_half* out, uint32_t out_stride);
+
 /* ------------------------------------------------------------------ NeRF kernels --------- */
 /* Stand-alone kernels (each mirrors one reference kernel; used by the parity tests and by
  * ngp_nerf_* below). All buffers are caller-owned device memory. */

@@ -437,6 +437,101 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Image / SDF primitives' model (tcnn::NetworkWithInputEncoding: HashGrid L = 16, F = 2 over a 2-D or 3-D position, then a
+// FullyFusedMLP 32 -> 64 -> 64 -> 16): forward only.  The MLP has exactly the shape of the NeRF colour network, so the
+// fragment layout (FW_R1 / FW_R2 / FW_R3) and the register-resident chain are shared; the encoding again lands directly in the
+// lane's B-operand registers: with F = 2, fragment element (s, hi, j) is feature j & 1 of level 8 s + 4 (j >> 2) + 2 hi + ((j & 3) >> 1).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+DEV h2 level_features2(const __half* __restrict__ table, const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x) {
+#pragma clang fp contract(off)
+	const float scale = gm->scale[level];
+	const uint32_t res = gm->resolution[level], hs = gm->hashmap_size[level];
+	uint32_t g[D]; float p[D];
+	uint64_t cells = 1; bool dense = true; // dense iff res^D <= hs
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		const float q = fmaf(scale, x[d], 0.5f), f = floorf(q);
+		g[d] = (uint32_t)(int)f; p[d] = q - f;
+		cells *= res; if (cells > hs) dense = false;
+	}
+	const uint32_t* t = (const uint32_t*)table + gm->offset[level];
+	constexpr int NC = 1 << D;
+	uint32_t v[NC]; float w[NC];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		float wc = 1.f;
+		uint32_t a[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) { if ((c & (1 << d)) == 0) { wc *= 1 - p[d]; a[d] = g[d]; } else { wc *= p[d]; a[d] = g[d] + 1; } }
+		asm volatile("" : "+v"(wc)); // keep the fp32 rounding of the weight before the half conversion (see level_corners)
+		uint32_t idx;
+		if (dense) {
+			uint32_t stride = 1; idx = 0;
+#pragma unroll
+			for (int d = 0; d < D; ++d) { idx += a[d] * stride; stride *= res; }
+			idx = idx % hs; // [tcnn] the dense index can exceed the (8-aligned) level size only by wrapping at the last cell row
+		} else {
+			const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+			idx = 0;
+#pragma unroll
+			for (int d = 0; d < D; ++d) idx ^= a[d] * primes[d];
+			idx = idx % hs;
+		}
+		v[c] = t[idx]; w[c] = wc;
+	}
+	h2 r = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const _Float16 wh = (_Float16)w[c];
+		const h2 w2 = {wh, wh};
+		r = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, v[c]), r);
+	}
+	__builtin_amdgcn_sched_barrier(0);
+	return r;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 3) k_encmlp_inference(const GridMeta* __restrict__ gm, const __half* __restrict__ table, const ngp_half* __restrict__ frags,
+		const float* __restrict__ in, uint32_t in_stride, uint32_t n, __half* __restrict__ out, uint32_t out_stride, uint32_t n_out) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	load_frags_to_lds(fw, frags, (int)N_FW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	for (uint32_t tile = wave; (uint64_t)tile * 32 < n; tile += n_waves) {
+		const uint32_t s_raw = tile * 32 + col;
+		const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
+		float x[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) x[d] = p[d];
+		FwdState<1> st;
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			h8 e;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const h2 f = level_features2<D>(table, gm, (uint32_t)(8 * s + 4 * (q >> 1) + 2 * hi + (q & 1)), x);
+				e[2 * q] = f[0]; e[2 * q + 1] = f[1];
+			}
+			st.rin[0][s] = e;
+		}
+		fwd_rgb_l1<1>(fw, lane, st);
+		fwd_rgb_l2<1>(fw, lane, st);
+		f16v o[1];
+		fwd_rgb_l3<1>(fw, lane, st, o);
+		if (s_raw < n) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * hi);
+				if (row < n_out) out[(size_t)s_raw * out_stride + row] = __float2half(o[0][r]);
+			}
+		}
+	}
+}
+
 // encoding only (unit-test hook): out[i][32] halfs in NATURAL feature order (level-major)
 __global__ void __launch_bounds__(256) k_encode_only(const GridMeta* __restrict__ gm, const __half* __restrict__ table, const float* __restrict__ pos, uint32_t stride,
 		uint32_t n, __half* __restrict__ out) {
@@ -1182,6 +1277,16 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 		hipLaunchKernelGGL(k_inference_tiles, dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
 	}
 	(void)max_samples;
+}
+void launch_encmlp_inference(hipStream_t s, const GridMeta* gm, uint32_t n_pos_dims, const ngp_half* grid, const ngp_half* fw_frags, const float* in, uint32_t in_stride,
+		uint32_t n, ngp_half* out, uint32_t out_stride, uint32_t n_out) {
+	if (n == 0) return;
+	const uint32_t tiles = (n + 31) / 32;
+	const uint32_t grid_dim = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 4);
+	if (n_pos_dims == 2)
+		hipLaunchKernelGGL((k_encmlp_inference<2>), dim3(grid_dim), dim3(256), N_FW_FRAGS * 1024, s, gm, (const __half*)grid, fw_frags, in, in_stride, n, (__half*)out, out_stride, n_out);
+	else
+		hipLaunchKernelGGL((k_encmlp_inference<3>), dim3(grid_dim), dim3(256), N_FW_FRAGS * 1024, s, gm, (const __half*)grid, fw_frags, in, in_stride, n, (__half*)out, out_stride, n_out);
 }
 void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out) {
 	if (n == 0) return;

@@ -873,8 +873,10 @@ __global__ void __launch_bounds__(256) k_k2_round(K2LazyArgs la) {
 // K4: fill_rollover<float> on coords + fill_rollover_and_rescale<half> on dL/doutput, one launch.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_fill_rollover(uint32_t n_elements, const uint32_t* __restrict__ n_input_ptr, float* __restrict__ coords, uint32_t cstride,
-		__half* __restrict__ dloss, uint32_t dstride) {
-	const uint32_t n_in = *n_input_ptr;
+		__half* __restrict__ dloss, uint32_t dstride, const uint32_t* __restrict__ publish_src2, uint32_t* __restrict__ publish_dst2) {
+	// the two counters every rank must agree on (8e) are published here instead of by a separate copy
+	if (publish_dst2 && blockIdx.x == 0 && threadIdx.x == 0) { publish_dst2[0] = publish_src2[0]; publish_dst2[1] = publish_src2[1]; }
+	const uint32_t n_in = min(*n_input_ptr, n_elements); // K3's counter may overshoot the batch (its spans are clamped)
 	if (n_in == 0 || n_in >= n_elements) return;
 	const uint32_t e = n_in + blockIdx.x * blockDim.x + threadIdx.x; // destination element
 	if (e >= n_elements) return;
@@ -1085,8 +1087,9 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride) {
 	hipLaunchKernelGGL(k_k2_round, dim3(blocks(max_rays, 256)), dim3(256), 0, s, la); (void)out_stride;
 }
-void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride) {
-	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride);
+void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
+		const uint32_t* publish_src2, uint32_t* publish_dst2) {
+	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride, publish_src2, publish_dst2);
 }
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear) {
 	hipLaunchKernelGGL(k_mark_untrained, dim3(blocks(n, 128)), dim3(128), 0, s, n, grid, n_images, m, x, clear);

@@ -395,6 +395,101 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// encoding + MLP model of the image / SDF primitives (forward only): tcnn::NetworkWithInputEncoding, testbed.cu:4354-4363
+// ------------------------------------------------------------------------------------------------
+struct ngp_encmlp {
+	ngp_encmlp_config cfg{};
+	GridMeta gm{}; GridMeta* gm_dev = nullptr;
+	uint64_t n_params = 0, n_mlp = 0;
+	std::vector<float> master;          // fp32 parameters (host; this round has no optimizer for this model)
+	ngp_half* params = nullptr;         // device: grid table in half (the MLP lives in fw_frags)
+	ngp_half* fw_frags = nullptr;       // device: N_FW_FRAGS fragments, only the FW_R1/R2/R3 slots are used
+};
+static void build_grid_meta_nd(const ngp_encmlp_config& c, GridMeta& g) {
+	memset(&g, 0, sizeof(g));
+	g.n_levels = c.n_levels; g.F = c.n_features_per_level;
+	const float l2 = std::log2(c.per_level_scale);
+	uint32_t offset = 0;
+	for (uint32_t i = 0; i < c.n_levels; ++i) {
+		const float scale = std::exp2(i * l2) * c.base_resolution - 1.0f;
+		const uint32_t res = (uint32_t)std::ceil(scale) + 1;
+		const uint32_t max_params = 0xFFFFFFFFu / 2;
+		uint32_t params_in_level = std::pow((float)res, (float)c.n_pos_dims) > (float)max_params ? max_params : (uint32_t)std::pow((float)res, (float)c.n_pos_dims);
+		params_in_level = next_multiple_u(params_in_level, 8u);
+		params_in_level = std::min(params_in_level, 1u << c.log2_hashmap_size);
+		g.scale[i] = scale; g.resolution[i] = res; g.hashmap_size[i] = params_in_level; g.offset[i] = offset;
+		offset += params_in_level;
+	}
+	g.offset[c.n_levels] = offset;
+}
+static int encmlp_upload(ngp_encmlp* m) {
+	// MLP -> forward fragments (same element permutation as the NeRF colour network, build_perms), grid -> half table
+	static const LayerDesc layers[3] = {{64, 32, 0, 8, 0}, {64, 64, 2048, 12, 0}, {16, 64, 6144, 20, 0}};
+	std::vector<__half> frags((size_t)N_FW_FRAGS * FRAG_HALFS, __float2half(0.f));
+	for (const LayerDesc& L : layers)
+		for (uint32_t i = 0; i < L.R; ++i) for (uint32_t k = 0; k < L.C; ++k) {
+			const uint32_t mt = i / 32, s = k / 16, kk = k % 16, j = (kk / 8) * 4 + (kk % 4), hi = (kk % 8) / 4;
+			const uint32_t frag = L.fw_base + mt * (L.C / 16) + s, lane = hi * 32 + (i % 32);
+			frags[(size_t)(frag * 64 + lane) * 8 + j] = __float2half(m->master[L.off + i * L.C + k]);
+		}
+	HIPCHK(hipMemcpy(m->fw_frags, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
+	const uint64_t n_grid = m->n_params - m->n_mlp;
+	std::vector<__half> table(n_grid);
+	for (uint64_t i = 0; i < n_grid; ++i) table[i] = __float2half(m->master[m->n_mlp + i]);
+	HIPCHK(hipMemcpy(m->params, table.data(), n_grid * 2, hipMemcpyHostToDevice));
+	return 0;
+}
+extern "C" int ngp_encmlp_create(const ngp_encmlp_config* cfg, uint64_t seed, ngp_encmlp** out) {
+	REQUIRE(cfg && out, "ngp_encmlp_create: null argument");
+	REQUIRE(cfg->n_pos_dims == 2 || cfg->n_pos_dims == 3, "encmlp: n_pos_dims must be 2 (image) or 3 (SDF)");
+	REQUIRE(cfg->n_levels == 16 && cfg->n_features_per_level == 2, "encmlp: the fused kernel is specialised for L = 16, F = 2 (configs/image|sdf/base.json)");
+	REQUIRE(cfg->n_neurons == 64 && cfg->n_hidden_layers == 2 && cfg->n_output_dims >= 1 && cfg->n_output_dims <= 16, "encmlp: 64 neurons, 2 hidden layers, 1..16 outputs");
+	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
+	ngp_encmlp* m = new ngp_encmlp();
+	m->cfg = *cfg;
+	build_grid_meta_nd(*cfg, m->gm);
+	m->n_mlp = 64 * 32 + 64 * 64 + 16 * 64;
+	m->n_params = m->n_mlp + (uint64_t)m->gm.offset[cfg->n_levels] * cfg->n_features_per_level;
+	m->master.resize(m->n_params);
+	// Trainer::initialize_params [tcnn]: Xavier-uniform matrices, then U(-1e-4, 1e-4) for the grid, one pcg32{seed} stream
+	Rng rnd = make_rng(seed);
+	uint64_t p = 0;
+	const uint32_t shapes[3][2] = {{64, 32}, {64, 64}, {16, 64}};
+	for (const auto& sh : shapes) {
+		const float scale = std::sqrt(6.0f / (float)(sh[0] + sh[1]));
+		for (uint32_t i = 0; i < sh[0] * sh[1]; ++i) m->master[p++] = rnd.next_float() * 2.0f * scale - scale;
+	}
+	for (; p < m->n_params; ++p) m->master[p] = rnd.next_float() * (1e-4f - (-1e-4f)) + (-1e-4f);
+	if (dev_alloc(&m->gm_dev, 1) || dev_alloc(&m->params, m->n_params - m->n_mlp) || dev_alloc(&m->fw_frags, N_FW_FRAGS * FRAG_HALFS)) { delete m; return 1; }
+	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
+	if (encmlp_upload(m)) return 1;
+	*out = m;
+	return 0;
+}
+extern "C" void ngp_encmlp_destroy(ngp_encmlp* m) {
+	if (!m) return;
+	for (void* p : {(void*)m->gm_dev, (void*)m->params, (void*)m->fw_frags}) if (p) (void)hipFree(p);
+	delete m;
+}
+extern "C" int ngp_encmlp_n_params(const ngp_encmlp* m, uint64_t* n_params, uint64_t* n_mlp) { if (n_params) *n_params = m->n_params; if (n_mlp) *n_mlp = m->n_mlp; return 0; }
+extern "C" int ngp_encmlp_set_params_host(ngp_encmlp* m, const float* p, uint64_t n) {
+	REQUIRE(n == m->n_params, "encmlp set_params: size mismatch");
+	std::copy(p, p + n, m->master.begin());
+	return encmlp_upload(m);
+}
+extern "C" int ngp_encmlp_get_params_host(ngp_encmlp* m, float* p, uint64_t n) {
+	REQUIRE(n == m->n_params, "encmlp get_params: size mismatch");
+	std::copy(m->master.begin(), m->master.end(), p);
+	return 0;
+}
+extern "C" int ngp_encmlp_inference(ngp_encmlp* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, ngp_half* out, uint32_t out_stride) {
+	REQUIRE(in_stride >= m->cfg.n_pos_dims && out_stride >= m->cfg.n_output_dims, "encmlp inference: strides too small");
+	launch_encmlp_inference((hipStream_t)stream, m->gm_dev, m->cfg.n_pos_dims, m->params, m->fw_frags, in, in_stride, n, out, out_stride, m->cfg.n_output_dims);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
 	++m->step; // Adam::step: ++m_current_step
 	AdamArgs a;
@@ -747,7 +842,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	{ ProfScope ps(P_K1, s);
 	  if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays, t->coarse_mask);
 	  else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->coarse_mask, t->k1_scratch); }
-	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
+	if (g_debug_flags & DBG_K2_EAGER) { ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); } // n_inference for the eager K2
 	{ ProfScope ps(P_K2_INFERENCE, s);
 	  if (!(g_debug_flags & DBG_K2_EAGER)) {
 		K2LazyArgs la;
@@ -767,11 +862,10 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
 	k3.ray_targets = lattice ? t->ray_targets : nullptr;
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
-	{ ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); }
-	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->n_valid_compacted, t->coords_compacted, 7, t->dloss, 4); }
+	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
+	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2); }
 	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
 	// publish the two counters that every rank must agree on before the controller runs (8e)
-	HIPCHK(hipMemcpyAsync(t->sync2, &c->numsteps_counter, 8, hipMemcpyDeviceToDevice, s));
 	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
 	HIPCHK(hipGetLastError());
 	return 0;

@@ -75,7 +75,8 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse_8192_words);
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
-void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride);
+void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
+	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr);
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
 void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, const uint32_t* step_ptr, uint32_t step, ngp_aabb box, const float* grid_in,
 	float* pos, uint32_t* idx, uint32_t n_cascades, float thresh);
@@ -123,6 +124,9 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtr
 	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la);
 void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
 	ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset);
+// encoding (D = 2 / 3, L = 16, F = 2) + MLP 32 -> 64 -> 64 -> 16, forward only (image / SDF primitives' model)
+void launch_encmlp_inference(hipStream_t s, const GridMeta* gm_dev, uint32_t n_pos_dims, const ngp_half* grid, const ngp_half* fw_frags, const float* in, uint32_t in_stride,
+	uint32_t n, ngp_half* out, uint32_t out_stride, uint32_t n_out);
 void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out);
 void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw);
 uint32_t wgrad_n_partials();

@@ -49,6 +49,27 @@ class ModelConfig(C.Structure):
                 ("ema_decay", f32), ("decay_start", u32), ("decay_interval", u32), ("decay_base", f32)]
 
 
+class EncMlpConfig(C.Structure):
+    _fields_ = [("n_pos_dims", u32), ("n_levels", u32), ("n_features_per_level", u32), ("log2_hashmap_size", u32),
+                ("base_resolution", u32), ("per_level_scale", f32), ("n_neurons", u32), ("n_hidden_layers", u32), ("n_output_dims", u32)]
+
+
+def _auto_per_level_scale(desired_resolution, base_resolution, n_levels):
+    """testbed.cu:4249-4253 in the reference's float arithmetic: std::exp(std::log(desired / base) / (n_levels - 1))"""
+    import numpy as np
+    return float(np.exp(np.log(np.float32(desired_resolution) / np.float32(base_resolution)) / np.float32(n_levels - 1)))
+
+
+def image_encmlp_config(log2_hashmap_size=19, image_resolution=1024):
+    """BASELINE.json config 0 (configs/image/base.json with T = 2^19): 2-D grid, desired finest resolution = max(image res) / 2."""
+    return EncMlpConfig(2, 16, 2, log2_hashmap_size, 16, _auto_per_level_scale(image_resolution / 2.0, 16, 16), 64, 2, 3)
+
+
+def sdf_encmlp_config(log2_hashmap_size=19):
+    """BASELINE.json config 4 (configs/sdf/base.json): 3-D grid, desired finest resolution 2048 => per_level_scale 1.3819."""
+    return EncMlpConfig(3, 16, 2, log2_hashmap_size, 16, _auto_per_level_scale(2048.0, 16, 16), 64, 2, 1)
+
+
 class NerfOptions(C.Structure):
     _fields_ = [("rgb_activation", i32), ("density_activation", i32), ("loss_type", i32), ("random_bg_color", i32),
                 ("snap_to_pixel_centers", i32), ("linear_colors", i32), ("color_space_srgb", i32),

@@ -1,6 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ora_math.hpp header).  PARITY UNPINNED.
 // C entry points of liboracle.so for ctypes (tests/, smoke(), bench.py cpu_baseline). All pointers are HOST pointers.
 #include "ora_nerf.hpp"
+#include "ora_encmlp.hpp"
 #include <omp.h>
 
 using namespace ora;
@@ -152,4 +153,24 @@ API uint32_t ora_nerf_scratch(void* tt, uint32_t** ray_indices, ngp_ray** rays, 
 	*ray_indices = t->ray_indices.data(); *rays = t->rays.data(); *numsteps = t->numsteps.data(); *coords = t->coords.data(); *mlp_out = t->mlp_out.data();
 	*coords_compacted = t->coords_compacted.data(); *dloss = t->dloss.data(); *counter_before = t->counter_before; *counter_compacted = t->counter_compacted;
 	return t->n_rays_last;
+}
+
+// ---- encoding + MLP (image / SDF primitives' model), forward only --------------------------------
+API int ora_encmlp_create(const ngp_encmlp_config* cfg, uint64_t seed, void** out) { TRY(*out = new EncMlp(*cfg, seed)) }
+API void ora_encmlp_destroy(void* h) { delete (EncMlp*)h; }
+API uint64_t ora_encmlp_n_params(void* h) { return ((EncMlp*)h)->n_params; }
+API uint64_t ora_encmlp_n_mlp(void* h) { return ((EncMlp*)h)->n_mlp; }
+API float* ora_encmlp_params_fp(void* h) { return ((EncMlp*)h)->params_fp.data(); }
+API void ora_encmlp_sync_half(void* h) { ((EncMlp*)h)->sync_half(); }
+API void ora_encmlp_grid_layout(void* h, uint32_t* offsets, uint32_t* resolutions, float* scales) {
+	const GridLayoutND& g = ((EncMlp*)h)->grid;
+	for (uint32_t l = 0; l <= g.n_levels; ++l) offsets[l] = g.offsets[l];
+	for (uint32_t l = 0; l < g.n_levels; ++l) { resolutions[l] = g.resolutions[l]; scales[l] = g.scales[l]; }
+}
+API int ora_encmlp_encode(void* h, const float* in, uint32_t stride, uint32_t n, uint16_t* out) {
+	const EncMlp& m = *(EncMlp*)h;
+	TRY(for (uint32_t i = 0; i < n; ++i) grid_encode_nd(m.grid, m.params.data() + m.n_mlp, in + (size_t)i * stride, out + (size_t)i * m.net.in))
+}
+API int ora_encmlp_inference(void* h, const float* in, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride) {
+	TRY(((EncMlp*)h)->inference(in, stride, n, out, out_stride))
 }

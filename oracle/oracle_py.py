@@ -45,6 +45,10 @@ def load():
         for name in ("ora_model_params_fp", "ora_model_params", "ora_model_params_inference", "ora_model_gradients", "ora_model_adam_m",
                      "ora_model_adam_v", "ora_nerf_density_grid", "ora_nerf_bitfield"):
             getattr(L, name).restype = vp; getattr(L, name).argtypes = [vp]
+        for name in ("ora_encmlp_n_params", "ora_encmlp_n_mlp"):
+            getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]
+        L.ora_encmlp_params_fp.restype = vp; L.ora_encmlp_params_fp.argtypes = [vp]
+        L.ora_encmlp_destroy.argtypes = [vp]; L.ora_encmlp_sync_half.argtypes = [vp]
         for name in ("ora_model_destroy", "ora_nerf_destroy", "ora_model_sync_half", "ora_nerf_update_mean_and_bitfield"):
             getattr(L, name).argtypes = [vp]
         _lib = L
