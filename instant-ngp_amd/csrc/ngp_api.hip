@@ -676,6 +676,9 @@ struct ngp_nerf {
 	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
+	// K1 of step n+1 does not depend on the parameters: it is launched on its own stream as soon as step n's controller has run and
+	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
+	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
@@ -723,7 +726,13 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	return 0;
 }
 // runtime-tunable members of Testbed::m_nerf (python_api.cu:714-853): everything except the sharding and batch size
+// Anything K1 depends on is about to change through the API: wait for a pre-launched K1 and make sure it is not consumed.
+static void invalidate_k1(ngp_nerf* t) {
+	if (t->k1_prelaunched && t->k1_stream) (void)hipStreamSynchronize(t->k1_stream);
+	++t->state_version;
+}
 extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
+	if (t) invalidate_k1(t);
 	REQUIRE(t && o, "set_options: null argument");
 	REQUIRE(o->target_batch_size == t->opt.target_batch_size && o->rank == t->opt.rank && o->world_size == t->opt.world_size && o->max_cascade == t->opt.max_cascade,
 		"set_options: batch size, max_cascade and sharding are fixed at creation");
@@ -732,6 +741,10 @@ extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
 }
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
+	(void)hipDeviceSynchronize();
+	if (t->k1_stream) (void)hipStreamDestroy(t->k1_stream);
+	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
+	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->bitfield_linear, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -751,6 +764,7 @@ static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_ima
 	return 0;
 }
 extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_image_meta* meta, const ngp_xform* xforms, const void* const* pixels_host) {
+	invalidate_k1(t);
 	REQUIRE(n > 0 && meta && xforms && pixels_host, "set_dataset: null/empty");
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	t->owned_pixels.clear();
@@ -767,6 +781,7 @@ extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_imag
 	return set_dataset_common(t, n, m, xforms);
 }
 extern "C" int ngp_nerf_set_dataset_device(ngp_nerf* t, uint32_t n, const ngp_image_meta* meta, const ngp_xform* xforms) {
+	invalidate_k1(t);
 	REQUIRE(n > 0 && meta && xforms, "set_dataset: null/empty");
 	std::vector<ngp_image_meta> m(meta, meta + n);
 	for (uint32_t i = 0; i < n; ++i)
@@ -776,6 +791,7 @@ extern "C" int ngp_nerf_set_dataset_device(ngp_nerf* t, uint32_t n, const ngp_im
 
 // update_density_grid_nerf, testbed_nerf.cu:2476-2592
 extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float decay, uint32_t n_uniform, uint32_t n_nonuniform) {
+	invalidate_k1(t);
 	REQUIRE(t->n_images > 0, "update_density_grid: no dataset");
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n_elements = GRID_N_CELLS * (t->opt.max_cascade + 1);
@@ -823,25 +839,43 @@ extern "C" int ngp_nerf_train_prep(ngp_nerf* t, void* stream) {
 }
 
 // train_nerf_step, testbed_nerf.cu:3007-3382 (Nerf train mode: K1, K2, K3, K4, K5)
+// will the NEXT ngp_nerf_train_prep update the occupancy grid? (same arithmetic, one step ahead: training_step is incremented by
+// ngp_nerf_train_finish, prep_skip_counter was already incremented by this step's prep)
+static bool next_prep_updates_grid(const ngp_nerf* t) {
+	const uint32_t n_prep_to_skip = (uint32_t)std::min(std::max((int)(t->training_step + 1) / 16, 1), 16);
+	return t->prep_skip_counter % n_prep_to_skip == 0;
+}
 extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	REQUIRE(t->n_images > 0, "train: no dataset");
 	hipStream_t s = (hipStream_t)stream;
 	const ngp_nerf_options& o = t->opt;
 	const uint32_t B = o.target_batch_size, max_samples = B * 16;
 	TrainCounters* c = t->counters;
-	K1Args k1;
-	k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
-	k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
 	const bool lattice = !(g_debug_flags & DBG_K1_REFERENCE_LAYOUT);
-	k1.bitfield_linear = t->bitfield_linear;
-	k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
-	k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
-	k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
-	k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
-	k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
-	{ ProfScope ps(P_K1, s);
-	  if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays, t->coarse_mask);
-	  else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->coarse_mask, t->k1_scratch); }
+	auto make_k1 = [&]() {
+		K1Args k1;
+		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
+		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
+		k1.bitfield_linear = t->bitfield_linear;
+		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
+		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
+		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
+		k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
+		k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
+		return k1;
+	};
+	bool have_k1 = false;
+	if (t->k1_prelaunched) { // launched by the previous step: valid if nothing it depends on was changed through the API since
+		HIPCHK(hipStreamWaitEvent(s, t->ev_k1, 0));
+		have_k1 = t->k1_version == t->state_version && t->k1_for_stream == s && lattice;
+		t->k1_prelaunched = false; // a stale one is simply overwritten: the lattice K1 writes (never accumulates) its counters
+	}
+	if (!have_k1) {
+		ProfScope ps(P_K1, s);
+		const K1Args k1 = make_k1();
+		if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays, t->coarse_mask);
+		else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->coarse_mask, t->k1_scratch);
+	}
 	if (g_debug_flags & DBG_K2_EAGER) { ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); } // n_inference for the eager K2
 	{ ProfScope ps(P_K2_INFERENCE, s);
 	  if (!(g_debug_flags & DBG_K2_EAGER)) {
@@ -864,9 +898,23 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2); }
+	// Single rank: the batch-size controller only needs K1's / K3's counters, so it runs here instead of after the optimizer and
+	// the next step's K1 can start behind it (multi-rank: after the counters' all-reduce, ngp_nerf_train_finish).
+	const bool early_ctl = o.world_size == 1;
+	if (early_ctl) { ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, B, 1); }
+	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t);
+	if (prelaunch) {
+		if (!t->k1_stream) { HIPCHK(hipStreamCreateWithFlags(&t->k1_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
+		HIPCHK(hipEventRecord(t->ev_ctl, s));
+	}
 	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
-	// publish the two counters that every rank must agree on before the controller runs (8e)
 	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
+	if (prelaunch) { // K1 of the NEXT step (its rng position), concurrent with this step's backward pass and optimizer
+		HIPCHK(hipStreamWaitEvent(t->k1_stream, t->ev_ctl, 0));
+		launch_generate_training_samples_lattice(t->k1_stream, make_k1(), t->max_rays, t->coarse_mask, t->k1_scratch);
+		HIPCHK(hipEventRecord(t->ev_k1, t->k1_stream));
+		t->k1_prelaunched = true; t->k1_version = t->state_version; t->k1_for_stream = s;
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -883,8 +931,10 @@ __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t 
 extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
-	if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
-	{ ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size, t->opt.world_size); }
+	if (t->opt.world_size > 1) { // single rank: the controller already ran behind K3 (ngp_nerf_train_forward_backward)
+		hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
+		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size, t->opt.world_size);
+	}
 	++t->training_step;
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -913,6 +963,7 @@ extern "C" int ngp_nerf_density_grid_ptrs(ngp_nerf* t, float** grid, uint8_t** b
 	if (grid) *grid = t->density_grid; if (bitfield) *bitfield = t->bitfield; if (mean) *mean = t->mean; return 0;
 }
 extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const float* grid_host, uint64_t n) {
+	invalidate_k1(t);
 	REQUIRE(n == (uint64_t)GRID_N_CELLS * (t->opt.max_cascade + 1), "set_density_grid: size mismatch");
 	HIPCHK(hipMemcpy(t->density_grid, grid_host, n * 4, hipMemcpyHostToDevice));
 	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
@@ -930,16 +981,18 @@ extern "C" int ngp_nerf_scratch_ptrs(ngp_nerf* t, uint32_t** ray_indices, ngp_ra
 	return 0;
 }
 extern "C" int ngp_nerf_set_rays_per_batch(ngp_nerf* t, uint32_t r) {
+	invalidate_k1(t);
 	HIPCHK(hipMemcpy(&t->counters->rays_per_batch, &r, 4, hipMemcpyHostToDevice));
 	return 0;
 }
 // load_snapshot restores m_training_step (testbed.cu:5400-5403): keeps the prep cadence / step-0 grid marking consistent
 extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
+	invalidate_k1(t);
 	t->training_step = step; t->prep_skip_counter = step; t->ema_step = step;
 	HIPCHK(hipMemcpy(&t->counters->training_step, &step, 4, hipMemcpyHostToDevice));
 	return 0;
 }
-extern "C" int ngp_nerf_set_rng(ngp_nerf* t, const ngp_pcg32* rng) { t->rng.state = rng->state; t->rng.inc = rng->inc; return 0; }
+extern "C" int ngp_nerf_set_rng(ngp_nerf* t, const ngp_pcg32* rng) { invalidate_k1(t); t->rng.state = rng->state; t->rng.inc = rng->inc; return 0; }
 extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = pod(t->rng); *grid_rng = pod(t->density_grid_rng); return 0; }
 
 // Testbed::render_nerf (testbed_nerf.cu:1894-2149): one spp of a frame into premultiplied linear RGBA + depth

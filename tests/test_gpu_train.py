@@ -133,6 +133,47 @@ def test_lazy_k2_matches_eager(ora, hip):
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
 
 
+def test_prelaunched_k1_is_the_same_k1(ora, hip):
+    """K1 of step n+1 is launched on a side stream behind step n's controller (it does not depend on the parameters). Its output
+    must be bit-identical to a K1 launched the normal way from the same state."""
+    import torch
+    B = 1 << 14
+    s = _make(ora, hip, B, n_images=8, res=64)
+    t = s["t"]
+    A.check(hip, hip.ngp_nerf_train(t, None, 70))  # step 71 has no grid update pending (prep every 4th step) -> K1(71) is in flight
+    torch.cuda.synchronize()
+    ri, rays, ns, co, mo, cc, dl, cn = (C.c_void_p() for _ in range(8))
+    A.check(hip, hip.ngp_nerf_scratch_ptrs(t, C.byref(ri), C.byref(rays), C.byref(ns), C.byref(co), C.byref(mo), C.byref(cc), C.byref(dl), C.byref(cn)))
+    rt = C.CDLL("libamdhip64.so")
+    n_rays_cap, n_samples = 1 << 18, B * 16
+
+    def grab():
+        torch.cuda.synchronize()
+        a = np.empty(n_rays_cap, np.uint32); b = np.empty(n_rays_cap * 6, np.float32); c = np.empty(n_samples * 7, np.float32)
+        assert rt.hipMemcpy(ptr(a), ri, C.c_size_t(a.nbytes), 2) == 0
+        assert rt.hipMemcpy(ptr(b), rays, C.c_size_t(b.nbytes), 2) == 0
+        assert rt.hipMemcpy(ptr(c), co, C.c_size_t(c.nbytes), 2) == 0
+        return a, b, c
+    pre = grab()
+    rng, grng = A.Pcg32(), A.Pcg32()
+    hip.ngp_nerf_get_rng(t, C.byref(rng), C.byref(grng))
+    hip.ngp_nerf_set_rng(t, C.byref(rng))  # same state, but the pre-launched K1 is now considered stale -> K1 runs again in-line
+    A.check(hip, hip.ngp_nerf_train_prep(t, None))
+    hip.ngp_debug_set_flags(4096)  # DBG_NO_STREAM_OVERLAP: this step must not pre-launch K1(72) over the buffers we compare
+    try:
+        A.check(hip, hip.ngp_nerf_train_forward_backward(t, None))
+    finally:
+        hip.ngp_debug_set_flags(0)
+    post = grab()
+    for name, x, y in zip(("ray_indices", "rays", "coords"), pre, post):
+        bad = np.flatnonzero(x.view(np.uint32) != y.view(np.uint32))
+        assert bad.size == 0, (name, bad.size, bad[:8].tolist(), x[bad[:4]].tolist(), y[bad[:4]].tolist())
+    A.check(hip, hip.ngp_nerf_train_finish(t, None))
+    st = _stats(hip, t)
+    assert st.training_step == 71 and st.measured_batch_size > 0
+    hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
+
+
 def test_render_matches_oracle(ora, hip):
     """ngp_nerf_render (lattice march + rounds of batched inference + compositing) vs the oracle's per-pixel renderer
     (fused_kernels/render_nerf.cuh semantics) on the same trained state. Tolerance: 2e-2 abs on premultiplied linear RGBA
