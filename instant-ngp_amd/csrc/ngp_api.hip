@@ -904,7 +904,8 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	if (early_ctl) { ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, B, 1); }
 	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t);
 	if (prelaunch) {
-		if (!t->k1_stream) { HIPCHK(hipStreamCreateWithFlags(&t->k1_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
+		if (!t->k1_stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
+			HIPCHK(hipStreamCreateWithPriority(&t->k1_stream, hipStreamNonBlocking, hi)); HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(t->ev_ctl, s));
 	}
 	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
