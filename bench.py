@@ -259,15 +259,33 @@ def run_cpu_baseline(lib, model, nerf, cfg, opts, images, M, X, n_img, st, args)
     ora.ora_nerf_update_mean_and_bitfield(ot)
     rays_cpu = max(256, int(st.rays_per_batch * B_cpu / args.batch) // 256 * 256)
     ora.ora_nerf_set_rays_per_batch(ot, rays_cpu)
-    t0 = time.perf_counter()
-    assert ora.ora_nerf_train_forward_backward(ot) == 0
-    assert ora.ora_nerf_train_finish(ot) == 0
+    # repeat the step until ~10 s of wall time are spent (bounded: at most 32 steps); the controller adapts rays/step like on the GPU
+    n_steps, rays_total, t0 = 0, 0, time.perf_counter()
+    while n_steps < 32 and (n_steps == 0 or time.perf_counter() - t0 < 10.0):
+        s = A.NerfStats(); ora.ora_nerf_get_stats(ot, C.byref(s))
+        rays_total += s.rays_per_batch if n_steps else rays_cpu
+        assert ora.ora_nerf_train_forward_backward(ot) == 0
+        assert ora.ora_nerf_train_finish(ot) == 0
+        n_steps += 1
     dt = time.perf_counter() - t0
     s = A.NerfStats(); ora.ora_nerf_get_stats(ot, C.byref(s))
     ora.ora_nerf_destroy(ot)
-    return {"value": rays_cpu / dt, "unit": "rays/s", "cores": int(ora.ora_num_threads()), "kind": "port",
-            "sample": f"1 training step (K1..K6, occupancy prep excluded) at B=2^15 samples, {rays_cpu} rays, {s.measured_batch_size} compacted samples, "
-                      f"from the GPU's trained state; OpenMP over {ora.ora_num_threads()} threads; {dt:.2f} s"}
+    # forward-only legs of SURVEY.md 8(d): NeRF network on 2^18 ray-coherent samples, image model (config 0) on its 65,536-sample batch
+    legs = {}
+    from common import random_coords
+    c = random_coords(1 << 18, seed=1, ray_coherent=True)
+    t1 = time.perf_counter(); om.inference(c); d1 = time.perf_counter() - t1
+    legs["nerf_forward"] = {"value": (1 << 18) / d1, "unit": "samples/s", "sample": f"2^18 samples, {d1:.2f} s"}
+    ic = A.image_encmlp_config(); ih = C.c_void_p()
+    if ora.ora_encmlp_create(C.byref(ic), C.c_uint64(1337), C.byref(ih)) == 0:
+        uv = np.random.default_rng(1).random((65536, 2), dtype=np.float32); o16 = np.zeros((65536, 3), np.uint16)
+        t2 = time.perf_counter(); ora.ora_encmlp_inference(ih, ptr(uv), 2, 65536, ptr(o16), 3); d2 = time.perf_counter() - t2
+        legs["image_forward"] = {"value": 65536 / d2, "unit": "samples/s", "sample": f"config 0 model (2-D HashGrid L16 F2 T=2^19 + MLP 2x64), 65,536 samples, {d2:.3f} s"}
+        ora.ora_encmlp_destroy(ih)
+    return {"value": rays_total / dt, "unit": "rays/s", "cores": int(ora.ora_num_threads()), "kind": "port",
+            "sample": f"{n_steps} training steps (K1..K6, occupancy prep excluded) at B=2^15 samples, {rays_total} rays, last step {s.measured_batch_size} compacted samples, "
+                      f"from the GPU's trained state; OpenMP over {ora.ora_num_threads()} threads; {dt:.2f} s",
+            "legs": legs}
 
 
 if __name__ == "__main__":

@@ -122,133 +122,6 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// K1, MI355X version.  Identical march semantics (same sequence of t values, same occupancy answers),
-// restructured around the two latency chains that bound the per-ray loops at < 1 wave / SIMD:
-//  * a 64^3 "any fine cell occupied" mask of cascade 0 (1 bit per bitfield byte = per 2x2x2 Morton
-//    block, 32 KiB) lives in LDS: a step through empty space is answered from LDS (~100 cycles)
-//    instead of a dependent global byte load (~500+ cycles under load); only steps inside a non-empty
-//    coarse cell touch the 256 KiB fine bitfield.
-//  * the first CACHE_N sample parameters t found by the counting pass are kept in LDS, so rays with
-//    <= CACHE_N samples (the steady-state majority) write their samples without marching twice.
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t K1_THREADS = 128;
-constexpr uint32_t K1_CACHE_N = 24;
-constexpr uint32_t COARSE_WORDS = GRID_N_CELLS / 8 / 32; // 8192 words = 32 KiB
-
-static __device__ __forceinline__ bool occupied_lds(f3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* coarse, uint32_t mip) {
-	const uint32_t idx = cascaded_grid_idx_at(pos, mip);
-	if (idx == 0xFFFFFFFFu) return false;
-	if (mip == 0) {
-		const uint32_t cb = idx >> 3;
-		if (!((coarse[cb >> 5] >> (cb & 31u)) & 1u)) return false; // whole 2x2x2 block empty
-	}
-	return bitfield[idx / 8 + grid_mip_offset(mip) / 8] & (1 << (idx % 8));
-}
-
-__global__ void __launch_bounds__(K1_THREADS) k_generate_training_samples_v2(K1Args a, const uint32_t* __restrict__ coarse_mask) {
-	__shared__ uint32_t coarse[COARSE_WORDS];
-	__shared__ float tcache[K1_CACHE_N][K1_THREADS];
-	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
-	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
-	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
-	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
-	const uint32_t i = ray_begin + threadIdx.x + blockIdx.x * blockDim.x;
-	if (blockIdx.x * blockDim.x >= ray_end - ray_begin) return; // whole block out of range (uniform)
-	{
-		const uint4* src = (const uint4*)coarse_mask;
-		uint4* dst = (uint4*)coarse;
-		for (uint32_t k = threadIdx.x; k < COARSE_WORDS / 4; k += K1_THREADS) dst[k] = src[k];
-	}
-	__syncthreads();
-	const Box aabb(a.aabb);
-
-	bool valid = i < ray_end;
-	uint32_t numsteps = 0;
-	f3 ro = mk3(0.f), rd = mk3(0.f), rdn = mk3(0.f, 0.f, 1.f), idir = mk3(1.f);
-	float startt = 0.f, cone_angle = a.cone_angle_constant;
-	if (valid) {
-		uint32_t img = image_idx(i, n_rays, a.n_images);
-		const ngp_image_meta& m = a.metadata[img];
-		Rng rng(a.rng);
-		rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
-		f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
-		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) valid = false;
-		if (valid) {
-			(void)rng.next_float(); // motionblur_time
-			const M43 xform = ldm43(a.xforms[img].start);
-			uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
-			rdn = normalize3(rd);
-			f2 tminmax = aabb.ray_intersect(ro, rdn);
-			tminmax.x = fmaxf(tminmax.x, 0.0f);
-			startt = advance_n_steps(tminmax.x, cone_angle, rng.next_float());
-			idir = mk3(1.0f) / rdn;
-			uint32_t j = 0;
-			float t = startt;
-			f3 pos;
-			while (aabb.contains(pos = ro + t * rdn) && j < N_STEPS) {
-				float dt = calc_dt(t, cone_angle);
-				uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
-				if (occupied_lds(pos, a.bitfield, coarse, mip)) {
-					if (j < K1_CACHE_N) tcache[j][threadIdx.x] = t;
-					++j; t += dt;
-				} else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
-			}
-			numsteps = j;
-			if (j == 0) valid = false;
-		}
-	}
-	uint32_t wave_total;
-	uint32_t offset = wave_excl_scan(valid ? numsteps : 0u, wave_total);
-	uint32_t wave_base = 0;
-	if ((threadIdx.x & 63u) == 0 && wave_total) wave_base = atomicAdd(a.numsteps_counter, wave_total);
-	wave_base = __shfl(wave_base, 0, 64);
-	const uint32_t base = wave_base + offset;
-	if (valid && base + numsteps > max_samples) valid = false;
-	uint32_t n_valid_total;
-	uint32_t ray_off = wave_excl_scan(valid ? 1u : 0u, n_valid_total);
-	uint32_t ray_base = 0;
-	if ((threadIdx.x & 63u) == 0 && n_valid_total) ray_base = atomicAdd(a.ray_counter, n_valid_total);
-	ray_base = __shfl(ray_base, 0, 64);
-	if (!valid) return;
-
-	const uint32_t ray_idx = ray_base + ray_off;
-	a.ray_indices_out[ray_idx] = i;
-	ngp_ray r; r.o[0] = ro.x; r.o[1] = ro.y; r.o[2] = ro.z; r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;
-	a.rays_out[ray_idx] = r;
-	a.numsteps_out[ray_idx * 2 + 0] = numsteps;
-	a.numsteps_out[ray_idx * 2 + 1] = base;
-
-	float* co = a.coords_out + (size_t)base * 7;
-	const f3 wd = warp_direction(rdn);
-	if (numsteps <= K1_CACHE_N) {
-		// replay the cached sample parameters: pos / dt are recomputed with the very same expressions
-		for (uint32_t j = 0; j < numsteps; ++j) {
-			const float t = tcache[j][threadIdx.x];
-			const f3 pos = ro + t * rdn;
-			const float dt = calc_dt(t, cone_angle);
-			const f3 wp = warp_position(pos, aabb);
-			float* c = co + (size_t)j * 7;
-			c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
-		}
-		return;
-	}
-	float t = startt;
-	uint32_t j = 0;
-	f3 pos;
-	while (aabb.contains(pos = ro + t * rdn) && j < numsteps) {
-		float dt = calc_dt(t, cone_angle);
-		uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
-		if (occupied_lds(pos, a.bitfield, coarse, mip)) {
-			f3 wp = warp_position(pos, aabb);
-			float* c = co + (size_t)j * 7;
-			c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
-			++j; t += dt;
-		} else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
-	}
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // K1, sample-parallel ("lattice") formulation -- the production ray marcher on MI355X.
 //
 // The reference's per-ray loop (testbed_nerf.cu:798-807) is a sequential float recurrence, but its
@@ -499,19 +372,6 @@ __global__ void k_build_linear_bitfield(const uint8_t* __restrict__ bitfield, ui
 		out |= ((src[m >> 3] >> (m & 7u)) & 1u) << k;
 	}
 	linear[b] = (uint8_t)out;
-}
-// 64^3 coarse mask of cascade 0: bit b of word w = (fine bitfield byte 32*w + b) != 0
-__global__ void k_build_coarse_mask(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
-	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	if (w >= COARSE_WORDS) return;
-	const uint4 a = ((const uint4*)bitfield)[(size_t)w * 2], b = ((const uint4*)bitfield)[(size_t)w * 2 + 1];
-	const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-	uint32_t bits = 0;
-#pragma unroll
-	for (uint32_t k = 0; k < 8; ++k)
-#pragma unroll
-		for (uint32_t q = 0; q < 4; ++q) bits |= ((v[k] >> (8 * q)) & 0xffu) ? (1u << (4 * k + q)) : 0u;
-	coarse[w] = bits;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,18 +904,15 @@ __global__ void k_clamp_compacted(TrainCounters* c, uint32_t target_batch_size) 
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t blocks(uint32_t n, uint32_t t) { return (n + t - 1) / t; }
 
-void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank, const uint32_t* coarse_mask) {
+void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank) {
 	if (max_rays_this_rank == 0) return;
-	if (coarse_mask && !(g_debug_flags & DBG_K1_REFERENCE_LAYOUT))
-		hipLaunchKernelGGL(k_generate_training_samples_v2, dim3(blocks(max_rays_this_rank, K1_THREADS)), dim3(K1_THREADS), 0, s, a, coarse_mask);
-	else
-		hipLaunchKernelGGL(k_generate_training_samples, dim3(blocks(max_rays_this_rank, 128)), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_generate_training_samples, dim3(blocks(max_rays_this_rank, 128)), dim3(128), 0, s, a);
 }
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
 	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8 + 8 + 8) + 1024 * 8;
 }
 // K1 as five small launches: setup, count (wave per ray), 3-kernel prefix sum, write (wave per ray)
-void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, const uint32_t* coarse_mask, void* scratch) {
+void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch) {
 	if (max_local_rays == 0) return;
 	char* p = (char*)scratch;
 	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
@@ -1075,9 +932,6 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades) {
 	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;
 	hipLaunchKernelGGL(k_build_linear_bitfield, dim3(blocks(n_bytes, 256)), dim3(256), 0, s, bitfield, linear, n_bytes);
-}
-void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse) {
-	hipLaunchKernelGGL(k_build_coarse_mask, dim3(blocks(COARSE_WORDS, 256)), dim3(256), 0, s, bitfield, coarse);
 }
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;

@@ -576,17 +576,14 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
-	static uint32_t* s_coarse = nullptr;
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
-	if (!s_coarse && dev_alloc(&s_coarse, 8192)) return 1;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
-	launch_build_coarse_mask((hipStream_t)stream, bitfield, s_coarse);
 	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, std::min<uint32_t>(max_mip + 1, N_CASCADES));
 	a.bitfield_linear = s_linear;
 	const uint32_t max_local = n_rays / world_size + 1;
 	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
-		launch_generate_training_samples((hipStream_t)stream, a, max_local, s_coarse);
+		launch_generate_training_samples((hipStream_t)stream, a, max_local);
 	} else {
 		REQUIRE(n_rays_ptr == nullptr, "stand-alone lattice K1: pass n_rays as an immediate");
 		const size_t need = k1_lattice_scratch_bytes(max_local);
@@ -598,7 +595,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 			s_scratch_bytes = need;
 		}
 		// the per-wave atomics of the sequential kernel accumulate into the counters; the scan overwrites them
-		launch_generate_training_samples_lattice((hipStream_t)stream, a, max_local, s_coarse, s_scratch);
+		launch_generate_training_samples_lattice((hipStream_t)stream, a, max_local, s_scratch);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -684,7 +681,6 @@ struct ngp_nerf {
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
-	uint32_t* coarse_mask = nullptr; // 64^3 any-occupied mask of cascade 0 for K1 (32 KiB)
 	uint8_t* bitfield_linear = nullptr; // x-major copy of the bitfield for the lattice marchers
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
 	// host-side deterministic state (no device read-back needed)
@@ -709,12 +705,11 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)(t->k2_tile_cap = max_samples / 32 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->coarse_mask, 8192) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
-	HIPCHK(hipMemset(t->coarse_mask, 0, 8192 * 4));
 	HIPCHK(hipMemset(t->bitfield_linear, 0, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)));
 	TrainCounters c; memset(&c, 0, sizeof(c));
 	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
@@ -746,7 +741,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->coarse_mask, t->bitfield_linear, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->k1_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -819,7 +814,6 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	++t->ema_step;
 	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
-	launch_build_coarse_mask(s, t->bitfield, t->coarse_mask);
 	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1);
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -873,8 +867,8 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	if (!have_k1) {
 		ProfScope ps(P_K1, s);
 		const K1Args k1 = make_k1();
-		if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays, t->coarse_mask);
-		else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->coarse_mask, t->k1_scratch);
+		if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays);
+		else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->k1_scratch);
 	}
 	if (g_debug_flags & DBG_K2_EAGER) { ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); } // n_inference for the eager K2
 	{ ProfScope ps(P_K2_INFERENCE, s);
@@ -912,7 +906,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
 	if (prelaunch) { // K1 of the NEXT step (its rng position), concurrent with this step's backward pass and optimizer
 		HIPCHK(hipStreamWaitEvent(t->k1_stream, t->ev_ctl, 0));
-		launch_generate_training_samples_lattice(t->k1_stream, make_k1(), t->max_rays, t->coarse_mask, t->k1_scratch);
+		launch_generate_training_samples_lattice(t->k1_stream, make_k1(), t->max_rays, t->k1_scratch);
 		HIPCHK(hipEventRecord(t->ev_k1, t->k1_stream));
 		t->k1_prelaunched = true; t->k1_version = t->state_version; t->k1_for_stream = s;
 	}
@@ -969,7 +963,6 @@ extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const f
 	HIPCHK(hipMemcpy(t->density_grid, grid_host, n * 4, hipMemcpyHostToDevice));
 	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield((hipStream_t)stream, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
-	launch_build_coarse_mask((hipStream_t)stream, t->bitfield, t->coarse_mask);
 	launch_build_linear_bitfield((hipStream_t)stream, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1);
 	HIPCHK(hipGetLastError());
 	return 0;

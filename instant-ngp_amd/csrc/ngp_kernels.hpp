@@ -67,12 +67,11 @@ struct K3Args {
 	const float* ray_targets; // optional: K1Args::ray_targets_out (8 floats per active ray)
 };
 
-void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank, const uint32_t* coarse_mask);
+void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
 // per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
 struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[6]; };
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
-void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, const uint32_t* coarse_mask, void* scratch);
-void launch_build_coarse_mask(hipStream_t s, const uint8_t* bitfield, uint32_t* coarse_8192_words);
+void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch);
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,

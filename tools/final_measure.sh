@@ -1,13 +1,15 @@
 #!/bin/bash
-# Round-end measurement batch on the GPU box: tests, ablations, bench, rocprofv3 kernel stats of the bench command, PMC traffic.
+# Round-end measurement batch on the GPU box: smoke, tests, bench (full JSON line), rocprofv3 kernel stats of the bench command,
+# PMC traffic passes.  usage: tools/final_measure.sh <tag>
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
 TAG=${1:-r01}
+timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee gpurun_out/${TAG}_smoke.log
 timeout 800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_gpu.log | tail -4
-timeout 300 python tools/microbench.py 600 32 default,t1_occ2,default_again,t1_occ2_again 2>&1 | tee gpurun_out/${TAG}_microbench.log | cut -c1-260
-timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -2 gpurun_out/${TAG}_bench.err; cut -c1-600 gpurun_out/${TAG}_bench.json
+timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -2 gpurun_out/${TAG}_bench.err; cut -c1-700 gpurun_out/${TAG}_bench.json
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_bench
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $R/bench.py --no-cpu-baseline --eval-views 0 > $R/gpurun_out/${TAG}_rocprof_bench.log 2>&1
-ls -la /tmp/prof_bench/* | head; for f in $(find /tmp/prof_bench -name "*kernel_stats.csv" -o -name "*domain_stats.csv"); do cp $f $R/gpurun_out/${TAG}_$(basename $f); done
+# stream overlap off (NGP_DEBUG_FLAGS=4096) so that the per-kernel durations are those of isolated kernels, like the HIP-event leg of bench.py
+NGP_DEBUG_FLAGS=4096 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $R/bench.py --no-cpu-baseline --eval-views 0 > $R/gpurun_out/${TAG}_rocprof_bench.log 2>&1
+for f in $(find /tmp/prof_bench -name "*kernel_stats.csv" -o -name "*domain_stats.csv"); do cp $f $R/gpurun_out/${TAG}_$(basename $f); done
 rm -rf /tmp/prof_bench
-$R/tools/pmc_traffic.sh $R/gpurun_out/${TAG}_pmc > /dev/null 2>&1; tail -n 30 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt | cut -c1-160
+$R/tools/pmc_traffic.sh $R/gpurun_out/${TAG}_pmc > /dev/null 2>&1; grep -A3 "k_train_fwd_bwd\|k_grad_bin\|k_grad_accumulate\|k_inference_tiles" $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt | cut -c1-170 | head -40
