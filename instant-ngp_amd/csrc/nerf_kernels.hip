@@ -503,16 +503,25 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 constexpr uint32_t K3_RAYS_PER_BLOCK = 16;
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
-static __device__ __forceinline__ float wave_incl_prod(float x, uint32_t lane) {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { const float y = __shfl_up(x, d, 64); if (lane >= (uint32_t)d) x *= y; }
-	return x;
+// Wave-wide inclusive scans with DPP (row_shr within the 16-lane rows, then row_bcast:15 / row_bcast:31 across rows): 7 data-parallel
+// moves + 7 operations per scan instead of 6 ds_bpermute round trips.  `ident` fills the lanes that have no source.
+#define NGP_DPP(old_f, src_f, ctrl, row_mask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_f), __builtin_bit_cast(int, src_f), ctrl, row_mask, 0xf, false))
+template <bool PROD>
+static __device__ __forceinline__ float wave_incl_scan(float x) {
+	const float ident = PROD ? 1.f : 0.f;
+	auto op = [](float a, float b) { return PROD ? a * b : a + b; };
+	float a = op(x, NGP_DPP(ident, x, 0x111, 0xf)); // row_shr:1
+	a = op(a, NGP_DPP(ident, x, 0x112, 0xf));       // row_shr:2 (of x)
+	a = op(a, NGP_DPP(ident, x, 0x113, 0xf));       // row_shr:3 (of x)
+	a = op(a, NGP_DPP(ident, a, 0x114, 0xf));       // row_shr:4
+	a = op(a, NGP_DPP(ident, a, 0x118, 0xf));       // row_shr:8  -> inclusive scan of every row
+	a = op(a, NGP_DPP(ident, a, 0x142, 0xa));       // row_bcast:15 into rows 1 and 3
+	a = op(a, NGP_DPP(ident, a, 0x143, 0xc));       // row_bcast:31 into rows 2 and 3
+	return a;
 }
-static __device__ __forceinline__ float wave_incl_sum(float x, uint32_t lane) {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { const float y = __shfl_up(x, d, 64); if (lane >= (uint32_t)d) x += y; }
-	return x;
-}
+static __device__ __forceinline__ float wave_incl_prod(float x, uint32_t) { return wave_incl_scan<true>(x); }
+static __device__ __forceinline__ float wave_incl_sum(float x, uint32_t) { return wave_incl_scan<false>(x); }
+static __device__ __forceinline__ float wave_total(float x) { return __shfl(wave_incl_scan<false>(x), 63, 64); } // sum of all 64 lanes, in every lane
 
 __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	__shared__ uint32_t s_cnt[K3_RAYS_PER_BLOCK];
@@ -597,7 +606,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const bool proc = lane < n_proc;
 			const float w = proc ? alpha * T_k : 0.f;
 			// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
-			rgb_ray = rgb_ray + mk3(wave_sum(proc ? w * rgb.x : 0.f), wave_sum(proc ? w * rgb.y : 0.f), wave_sum(proc ? w * rgb.z : 0.f));
+			rgb_ray = rgb_ray + mk3(wave_total(proc ? w * rgb.x : 0.f), wave_total(proc ? w * rgb.y : 0.f), wave_total(proc ? w * rgb.z : 0.f));
 			if (n_proc) T_run = T_run * __shfl(incl, (int)n_proc - 1, 64);
 			compacted += n_proc;
 			if (fail) break;
