@@ -7,6 +7,7 @@ TAG=${1:-r01}
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee gpurun_out/${TAG}_smoke.log
 timeout 800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_gpu.log | tail -4
 timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -2 gpurun_out/${TAG}_bench.err; cut -c1-700 gpurun_out/${TAG}_bench.json
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 NGP_FORCE_DP=1 timeout 200 python bench.py --no-cpu-baseline --eval-views 0 --pretrain 300 --steps 50 > gpurun_out/${TAG}_bench_forced_dp1.json 2> gpurun_out/${TAG}_bench_forced_dp1.err; cut -c1-300 gpurun_out/${TAG}_bench_forced_dp1.json; tail -1 gpurun_out/${TAG}_bench_forced_dp1.err
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_bench
 # stream overlap off (NGP_DEBUG_FLAGS=4096) so that the per-kernel durations are those of isolated kernels, like the HIP-event leg of bench.py
 NGP_DEBUG_FLAGS=4096 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $R/bench.py --no-cpu-baseline --eval-views 0 > $R/gpurun_out/${TAG}_rocprof_bench.log 2>&1
