@@ -385,16 +385,17 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 // ---------------------------------------------------------------------------------------------
 // Lazy (front-to-back) K2.  The reference evaluates the network on EVERY marched sample and then discards all samples behind
 // the point where a ray's transmittance drops below 1e-4 (compute_loss_kernel_train_nerf: `if (T < EPSILON) break`).  Samples
-// behind the cut influence nothing, so the network is evaluated in rounds of 32 samples per ray: k_k2_round (nerf_kernels.hip,
-// one thread per ray) composites the densities of the previous round and lists the next 32-sample tile only for rays that are
-// still transparent (with a 1 % safety margin on the threshold, so that K3's own test can never walk into an unevaluated
-// sample); the last round lists everything that is left.  Same results as the eager order (DBG_K2_EAGER),
-// tests/test_gpu_train.py::test_lazy_k2_matches_eager.  One tile = descriptor {first sample, valid lanes, ray}.
+// behind the cut influence nothing, so the network is evaluated in rounds of 32-sample tiles (one tile = 32 consecutive samples of
+// ONE ray).  K1 writes the round-0 list (the first tile of every active ray); a tile that leaves its ray still transparent appends
+// the ray's next tile to the next round's list (the last round takes everything that is left), with a 1 % safety margin on the
+// threshold so that K3's own test can never walk into an unevaluated sample.  Same results as the eager order (DBG_K2_EAGER),
+// tests/test_gpu_train.py::test_lazy_k2_matches_eager.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const uint32_t n_tiles = min(la.n_tiles_ptr[la.round], la.tile_cap);
+	const uint32_t r = la.round;
+	const uint32_t n_tiles = min(r == 0 ? *la.n_rays_ptr : la.n_tiles_ptr[r], la.tile_cap);
 	if (blockIdx.x * 4 >= n_tiles) return; // uniform: late rounds are small
 	h8* fw = (h8*)smem;
 	load_frags_to_lds(fw, mp.fw_frags, (int)N_FW_FRAGS);
@@ -402,8 +403,13 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
 	const __half* table = (const __half*)mp.grid;
+	const uint4* __restrict__ tiles = la.tiles[r & 1u];
+	uint4* __restrict__ next = la.tiles[(r + 1u) & 1u];
+	const bool next_is_last = r + 2 == K2_ROUNDS;
+	uint32_t n_eval = 0; // lane 0: samples evaluated by this wavefront (statistics)
 	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-		const uint4 d = la.tiles[tile];
+		const uint4 d = tiles[tile];
+		if (d.y == 0u) continue; // a ray K1 dropped at its sample cap: nothing to evaluate (its base may lie outside the buffers)
 		const bool valid = (uint32_t)col < d.y;
 		const uint32_t sample = d.x + (valid ? (uint32_t)col : 0u);
 		FwdState<1> st;
@@ -417,12 +423,14 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		f16v o[1];
 		fwd_rgb_l3<1>(fw, lane, st, o);
 		if (hi == 0 && valid) {
-			h4 r = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)st.sigma[0]};
-			*(uint2*)(out + (size_t)sample * out_stride) = __builtin_bit_cast(uint2, r);
+			h4 rr = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)st.sigma[0]};
+			*(uint2*)(out + (size_t)sample * out_stride) = __builtin_bit_cast(uint2, rr);
 		}
-		// transmittance of this tile (product over its samples of exp(-sigma dt)): k_k2_round decides from it whether the ray
-		// needs its next tile.  An estimate with a safety margin -- K3 recomputes the exact compositing.
-		if (la.round + 1 < K2_ROUNDS) {
+		n_eval += d.y;
+		// Transmittance behind this tile (an estimate with a safety margin: K3 recomputes the exact compositing).  A ray that is
+		// still transparent gets its next tile -- or, if the next round is the last one, all its remaining tiles -- appended to the
+		// next round's list: 1 % below K3's threshold, so K3's own test can never walk into an unevaluated sample; NaN stays alive.
+		if (d.w != 0u && r + 1 < K2_ROUNDS) {
 			float od = 0.f; // optical depth of the lane's sample
 			if (hi == 0 && valid) {
 				const float x = st.sigma[0];
@@ -432,9 +440,19 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 			}
 #pragma unroll
 			for (int dd = 16; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64);
-			if (lane == 0) la.T_run[d.z] *= __expf(-od);
+			if (lane == 0) {
+				const float T = (r == 0 ? 1.f : la.T_run[d.z]) * __expf(-od);
+				if (!(T < 0.99e-4f)) {
+					la.T_run[d.z] = T;
+					const uint32_t rest = d.w, n = next_is_last ? rest : min(rest, 32u), nt = (n + 31u) / 32u;
+					const uint32_t off = atomicAdd(la.n_tiles_ptr + r + 1, nt);
+					for (uint32_t j = 0; j < nt; ++j)
+						if (off + j < la.tile_cap) next[off + j] = make_uint4(d.x + 32u * (j + 1u), min(32u, n - 32u * j), d.z, rest - min(rest, 32u * (j + 1u)));
+				}
+			}
 		}
 	}
+	if (lane == 0 && n_eval) atomicAdd(la.n_eval_ptr, n_eval);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1273,7 +1291,6 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap + 3) / 4, (uint64_t)num_cus() * 3);
 	for (uint32_t r = 0; r < K2_ROUNDS; ++r) {
 		la.round = r;
-		launch_k2_round(s, la, max_rays, out_stride);
 		hipLaunchKernelGGL(k_inference_tiles, dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
 	}
 	(void)max_samples;

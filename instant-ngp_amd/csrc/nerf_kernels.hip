@@ -331,6 +331,10 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 		a.rays_out[slot] = rr;
 		a.numsteps_out[slot * 2 + 0] = fits ? count : 0u;
 		a.numsteps_out[slot * 2 + 1] = base;
+		if (a.k2_tiles0_out) { // lazy K2, round 0: the first 32 samples of this ray (dropped rays: an empty tile)
+			const uint32_t c0 = fits ? count : 0u;
+			a.k2_tiles0_out[slot] = make_uint4(base, min(c0, 32u), slot, c0 - min(c0, 32u));
+		}
 		if (a.ray_targets_out) {
 			float4* tg = (float4*)(a.ray_targets_out + (size_t)slot * 8);
 			tg[0] = make_float4(r.tgt[0], r.tgt[1], r.tgt[2], r.tgt[3]); tg[1] = make_float4(r.tgt[4], r.tgt[5], 0.f, 0.f);
@@ -710,34 +714,6 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
 }
 
-// Lazy K2, one thread per active ray: list the next 32-sample tile of the rays that are still transparent (k_inference_tiles
-// keeps T_run = transmittance behind the samples evaluated so far).  T_run < 0 marks a finished ray.
-__global__ void __launch_bounds__(256) k_k2_round(K2LazyArgs la) {
-	const uint32_t n_rays = *la.n_rays_ptr;
-	const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t r = la.round, start = 32u * r;
-	const bool last = r + 1 == K2_ROUNDS;
-	uint32_t n_eval = 0;
-	if (ray < n_rays) {
-		const uint2 nb = ((const uint2*)la.numsteps)[ray];
-		const uint32_t count = nb.x, base = nb.y;
-		float T = r == 0 ? 1.f : la.T_run[ray];
-		if (T < 0.99e-4f) T = -1.f; // opaque (1 % margin below K3's threshold) or already finished; NaN stays alive
-		if (count > start && !(T < 0.f)) {
-			const uint32_t rest = count - start, n = last ? rest : min(rest, 32u), nt = (n + 31u) / 32u;
-			const uint32_t off = atomicAdd(la.n_tiles_ptr + r, nt);
-			for (uint32_t j = 0; j < nt; ++j)
-				if (off + j < la.tile_cap) la.tiles[off + j] = make_uint4(base + start + 32u * j, min(32u, n - 32u * j), ray, 0u);
-			n_eval = n;
-		} else T = -1.f;
-		if (!last) la.T_run[ray] = T;
-	}
-	// statistics: samples actually evaluated (wave reduction, one atomic per wavefront)
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) n_eval += (uint32_t)__shfl_xor((int)n_eval, d, 64);
-	if ((threadIdx.x & 63u) == 0 && n_eval) atomicAdd(la.n_eval_ptr, n_eval);
-}
-
 // ------------------------------------------------------------------------------------------------
 // K4: fill_rollover<float> on coords + fill_rollover_and_rescale<half> on dL/doutput, one launch.
 // ------------------------------------------------------------------------------------------------
@@ -946,9 +922,6 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
 	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
-}
-void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride) {
-	hipLaunchKernelGGL(k_k2_round, dim3(blocks(max_rays, 256)), dim3(256), 0, s, la); (void)out_stride;
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
 		const uint32_t* publish_src2, uint32_t* publish_dst2) {

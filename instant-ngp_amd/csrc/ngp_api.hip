@@ -571,7 +571,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 		const uint8_t* bitfield, uint32_t max_mip, int snap_to_pixel_centers, float cone_angle_constant) {
 	REQUIRE(world_size >= 1 && rank < world_size, "generate_training_samples: bad rank/world_size");
 	K1Args a;
-	a.ray_targets_out = nullptr; a.background_color[0] = a.background_color[1] = a.background_color[2] = 0.f; a.color_space_srgb = a.random_bg_color = a.linear_colors = 0;
+	a.k2_tiles0_out = nullptr; a.ray_targets_out = nullptr; a.background_color[0] = a.background_color[1] = a.background_color[2] = 0.f; a.color_space_srgb = a.random_bg_color = a.linear_colors = 0;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.rank = rank; a.world_size = world_size; a.aabb = aabb; a.max_samples = max_samples;
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
@@ -704,7 +704,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
-		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)(t->k2_tile_cap = max_samples / 32 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 32 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
@@ -850,7 +850,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.bitfield_linear = t->bitfield_linear;
+		k1.bitfield_linear = t->bitfield_linear; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
@@ -870,12 +870,13 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 		if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays);
 		else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->k1_scratch);
 	}
-	if (g_debug_flags & DBG_K2_EAGER) { ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); } // n_inference for the eager K2
+	const bool lazy_k2 = lattice && !(g_debug_flags & DBG_K2_EAGER); // the round-0 tile list comes from the lattice K1
+	if (!lazy_k2) { ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); } // n_inference for the eager K2
 	{ ProfScope ps(P_K2_INFERENCE, s);
-	  if (!(g_debug_flags & DBG_K2_EAGER)) {
+	  if (lazy_k2) {
 		K2LazyArgs la;
-		la.numsteps = t->numsteps; la.n_rays_ptr = &c->ray_counter; la.tiles = t->k2_tiles; la.tile_cap = t->k2_tile_cap; la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0;
-		la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
+		la.n_rays_ptr = &c->ray_counter; la.tiles[0] = t->k2_tiles; la.tiles[1] = t->k2_tiles + t->k2_tile_cap; la.tile_cap = t->k2_tile_cap;
+		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
 		{ const float max_stepsize = MIN_CONE_STEP * (float)(1 << (N_CASCADES - 1)); la.dt_unwarp_scale = max_stepsize - MIN_CONE_STEP; la.dt_unwarp_offset = MIN_CONE_STEP; } // unwarp_dt
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la);
 	  } else

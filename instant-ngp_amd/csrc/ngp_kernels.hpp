@@ -28,7 +28,7 @@ struct TrainCounters {
 	uint32_t ema_step;                              // density_grid_ema_step
 	uint64_t total_rays;
 	uint64_t total_samples;
-	uint32_t k2_tiles[4];                           // lazy K2: number of 32-sample tiles of each round (k_k2_round)
+	uint32_t k2_tiles[4];                           // lazy K2: number of 32-sample tiles of rounds 1..3 ([0] unused: round 0 = one tile per active ray)
 	uint32_t k2_samples, k2_samples_last;           // network evaluations performed by K2 in this / the previous step (statistics)
 };
 
@@ -43,6 +43,7 @@ struct K1Args {
 	uint32_t n_images; const ngp_image_meta* metadata; const ngp_xform* xforms;
 	const uint8_t* bitfield; uint32_t max_mip;
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
+	uint4* k2_tiles0_out;           // optional: round-0 tile list of the lazy K2 (one descriptor per active ray)
 	int snap_to_pixel_centers; float cone_angle_constant;
 	// optional (lattice K1 only): per-ray training target {rgbtarget[3], background[3], 0, 0} for K3, computed by the thread-per-ray
 	// setup kernel so that K3's wavefronts do not all repeat it (same arithmetic as compute_loss_kernel_train_nerf)
@@ -108,17 +109,18 @@ struct ModelPtrs {
 };
 
 // lazy (front-to-back) K2 in rounds of 32-sample tiles (one tile = 32 consecutive samples of ONE ray): round r evaluates samples
-// [32r, 32r+32) of the rays that are still transparent after round r-1; the last round takes everything that is left
+// [32r, 32r+32) of the rays that are still transparent after round r-1; the last round takes everything that is left.
+// Tile descriptor = {first sample, valid lanes, ray, samples of the ray behind this tile}.  Round 0's list is written by K1
+// (one tile per active ray, tile index = ray slot); a tile of round r appends its ray's next tile(s) to round r+1's list.
 constexpr uint32_t K2_ROUNDS = 4;
 struct K2LazyArgs {
-	const uint32_t* numsteps;       // per active ray: {count, base}
-	const uint32_t* n_rays_ptr;     // active rays (K1's ray counter)
-	uint4* tiles /* {first sample, valid lanes, ray, 0} */; uint32_t tile_cap; uint32_t* n_tiles_ptr /* [K2_ROUNDS] */; uint32_t* n_eval_ptr;
-	float* T_run;                   // per active ray: transmittance behind the evaluated samples (updated by k_inference_tiles), < 0 = done
+	const uint32_t* n_rays_ptr;     // active rays (K1's ray counter) = number of round-0 tiles
+	uint4* tiles[2]; uint32_t tile_cap; // ping-pong lists: round r reads tiles[r & 1] and appends to tiles[(r + 1) & 1]
+	uint32_t* n_tiles_ptr /* [K2_ROUNDS], [0] unused */; uint32_t* n_eval_ptr;
+	float* T_run;                   // per active ray: transmittance behind the evaluated samples
 	int density_activation; float dt_unwarp_scale, dt_unwarp_offset; // dt = warped * scale + offset (unwarp_dt)
 	uint32_t round;
 };
-void launch_k2_round(hipStream_t s, const K2LazyArgs& la, uint32_t max_rays, uint32_t out_stride);
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
 	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la);
 void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
