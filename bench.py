@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-views", type=int, default=4, help="held-out views rendered (untimed) for PSNR, run.py --test_transforms procedure")
     ap.add_argument("--eval-res", type=int, default=400)
+    ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the held-out PSNR after the timed region (untimed), e.g. 5000,10000,35000")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,6 +180,17 @@ def main():
 
     psnr = eval_psnr(lib, nerf, args) if (rank == 0 and args.eval_views > 0) else None
 
+    # optional PSNR@step curve (BASELINE.json's second metric): keep training, untimed, and evaluate at the requested steps
+    psnr_curve = {}
+    if rank == 0 and world == 1 and args.psnr_steps:
+        if psnr is not None:
+            psnr_curve[str(stats().training_step)] = round(psnr, 3)
+        for target in sorted(int(x) for x in args.psnr_steps.split(",") if x):
+            cur = stats().training_step
+            if target > cur:
+                step(target - cur)
+            psnr_curve[str(stats().training_step)] = round(eval_psnr(lib, nerf, args), 3)
+
     # ---- CPU baseline: the oracle (port) runs ONE bounded step from the same trained state --------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -195,7 +207,8 @@ def main():
                        "pretrain_steps": args.pretrain, "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
                        "samples_per_ray_compacted": samples / max(rays, 1), "loss": s1.loss,
                        "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
-                       "test_psnr_db": psnr, "test_psnr_at_step": (s3.training_step if psnr is not None else None)},
+                       "test_psnr_db": psnr, "test_psnr_at_step": (s3.training_step if psnr is not None else None),
+                       **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {})},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
