@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	const __half* table = (const __half*)mp.grid;
 	const uint4* __restrict__ tiles = la.tiles[r & 1u];
 	uint4* __restrict__ next = la.tiles[(r + 1u) & 1u];
-	const bool next_is_last = r + 2 == K2_ROUNDS;
+	const bool next_is_last = r + 2 == la.n_rounds;
 	uint32_t n_eval = 0; // lane 0: samples evaluated by this wavefront (statistics)
 	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
 		const uint4 d = tiles[tile];
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		// Transmittance behind this tile (an estimate with a safety margin: K3 recomputes the exact compositing).  A ray that is
 		// still transparent gets its next tile -- or, if the next round is the last one, all its remaining tiles -- appended to the
 		// next round's list: 1 % below K3's threshold, so K3's own test can never walk into an unevaluated sample; NaN stays alive.
-		if (d.w != 0u && r + 1 < K2_ROUNDS) {
+		if (d.w != 0u && r + 1 < la.n_rounds) {
 			float od = 0.f; // optical depth of the lane's sample
 			if (hi == 0 && valid) {
 				const float x = st.sigma[0];
@@ -1289,7 +1289,7 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	if (max_rays == 0) return;
 	K2LazyArgs la = la_in;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap + 3) / 4, (uint64_t)num_cus() * 3);
-	for (uint32_t r = 0; r < K2_ROUNDS; ++r) {
+	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
 		hipLaunchKernelGGL(k_inference_tiles, dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
 	}

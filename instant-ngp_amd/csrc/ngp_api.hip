@@ -676,6 +676,7 @@ struct ngp_nerf {
 	// K1 of step n+1 does not depend on the parameters: it is launched on its own stream as soon as step n's controller has run and
 	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
 	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
+	uint32_t k2_rounds = 3; // measured best of 2..4 (0.168 / 0.178 / 0.180 ms for 3 / 4 / 2 rounds); NGP_K2_ROUNDS=2..4 overrides (tuning knob; round 0 is always the first 32 samples of every ray)
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
@@ -700,6 +701,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	t->density_grid_rng = make_rng(t->rng.next_uint()); // testbed.cu:4178
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
+	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 2), K2_ROUNDS);
 	t->grid_sample_cap = n_cells;
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
@@ -876,7 +878,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	  if (lazy_k2) {
 		K2LazyArgs la;
 		la.n_rays_ptr = &c->ray_counter; la.tiles[0] = t->k2_tiles; la.tiles[1] = t->k2_tiles + t->k2_tile_cap; la.tile_cap = t->k2_tile_cap;
-		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
+		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_rounds = t->k2_rounds; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
 		{ const float max_stepsize = MIN_CONE_STEP * (float)(1 << (N_CASCADES - 1)); la.dt_unwarp_scale = max_stepsize - MIN_CONE_STEP; la.dt_unwarp_offset = MIN_CONE_STEP; } // unwarp_dt
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la);
 	  } else

@@ -112,14 +112,14 @@ struct ModelPtrs {
 // [32r, 32r+32) of the rays that are still transparent after round r-1; the last round takes everything that is left.
 // Tile descriptor = {first sample, valid lanes, ray, samples of the ray behind this tile}.  Round 0's list is written by K1
 // (one tile per active ray, tile index = ray slot); a tile of round r appends its ray's next tile(s) to round r+1's list.
-constexpr uint32_t K2_ROUNDS = 4;
+constexpr uint32_t K2_ROUNDS = 4; // maximum / default number of rounds
 struct K2LazyArgs {
 	const uint32_t* n_rays_ptr;     // active rays (K1's ray counter) = number of round-0 tiles
 	uint4* tiles[2]; uint32_t tile_cap; // ping-pong lists: round r reads tiles[r & 1] and appends to tiles[(r + 1) & 1]
 	uint32_t* n_tiles_ptr /* [K2_ROUNDS], [0] unused */; uint32_t* n_eval_ptr;
 	float* T_run;                   // per active ray: transmittance behind the evaluated samples
 	int density_activation; float dt_unwarp_scale, dt_unwarp_offset; // dt = warped * scale + offset (unwarp_dt)
-	uint32_t round;
+	uint32_t round, n_rounds;
 };
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
 	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la);
