@@ -11,10 +11,11 @@
 namespace mini_json {
 
 struct Value {
-	enum Type { Null, Bool, Number, String, Array, Object } type = Null;
+	enum Type { Null, Bool, Number, String, Array, Object, Binary } type = Null; // Binary: msgpack bin (snapshots), dumped as null in JSON text
 	bool b = false;
 	double n = 0;
 	std::string s;
+	std::vector<unsigned char> bin;
 	std::vector<Value> arr;
 	std::vector<std::pair<std::string, Value>> obj; // insertion-ordered
 
@@ -120,7 +121,7 @@ inline bool parse(const char* text, Value& out, std::string& err) {
 
 inline void dump_to(const Value& v, std::string& out) {
 	switch (v.type) {
-		case Value::Null: out += "null"; break;
+		case Value::Null: case Value::Binary: out += "null"; break;
 		case Value::Bool: out += v.b ? "true" : "false"; break;
 		case Value::Number: { char buf[40]; snprintf(buf, sizeof(buf), "%.17g", v.n); out += buf; break; }
 		case Value::String: {

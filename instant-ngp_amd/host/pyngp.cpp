@@ -24,6 +24,9 @@ static py::array_t<float> render_to_numpy(Testbed& t, int w, int h, int spp, boo
 
 PYBIND11_MODULE(pyngp, m) {
 	m.doc() = "MI355X-native instant-ngp NeRF training/rendering (pyngp-compatible API surface)";
+	// not part of the reference API: msgpack (optionally zlib-framed) -> document -> msgpack, used by the snapshot wire-format tests
+	m.def("_msgpack_repack", [](py::bytes data, bool input_compressed, bool output_compressed) { return py::bytes(msgpack_repack(std::string(data), input_compressed, output_compressed)); },
+		py::arg("data"), py::arg("input_compressed") = false, py::arg("output_compressed") = false);
 
 	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
 		.value("Volume", ETestbedMode::Volume).value("None", ETestbedMode::None).export_values();

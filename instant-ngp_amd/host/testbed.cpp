@@ -1,5 +1,6 @@
 // testbed.cpp -- see testbed.hpp.  Host logic only; every device operation is a C-ABI call.
 #include "testbed.hpp"
+#include "msgpack_lite.hpp"
 
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
@@ -455,47 +456,195 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// snapshots (own container; the reference's msgpack/.ingp wire format is a "next" item)
+// snapshots in the reference's wire format (testbed.cu:5288-5514): nlohmann::json::to_msgpack of the network config with a
+// "snapshot" object, `.ingp` = the same bytes through zlib (zstr).  ngp-side fields and the vector / bounding-box / dataset
+// encodings follow testbed.cu:5288-5343 and json_binding.h; the tcnn-side fields (Trainer::serialize: "n_params", "params_type",
+// "params_binary" = inference parameters in half, optional "optimizer") are restated from memory of the public tiny-cuda-nn
+// [tcnn, unverifiable here: the submodule is absent and the mount holds no snapshot file].  The optimizer state is stored under
+// "optimizer" in THIS library's own binary form ("otype": "ngp_hip"), which a real instant-ngp build would not accept.
 // ------------------------------------------------------------------------------------------------
-struct SnapHeader { char magic[8]; uint32_t version, training_step; uint64_t config_bytes, model_bytes, grid_floats; int32_t aabb_scale, with_optimizer; };
+namespace {
+using mini_json::Value;
+Value jnum(double d) { Value v; v.type = Value::Number; v.n = d; return v; }
+Value jbool(bool b) { Value v; v.type = Value::Bool; v.b = b; return v; }
+Value jstr(const std::string& s) { Value v; v.type = Value::String; v.s = s; return v; }
+Value jobj() { Value v; v.type = Value::Object; return v; }
+template <typename T> Value jvec(const T* p, size_t n) { Value v; v.type = Value::Array; for (size_t i = 0; i < n; ++i) v.arr.push_back(jnum((double)p[i])); return v; }
+Value jmat_cols(const float* p, size_t n_cols, size_t n_rows) { Value v; v.type = Value::Array; for (size_t c = 0; c < n_cols; ++c) v.arr.push_back(jvec(p + c * n_rows, n_rows)); return v; } // [tcnn vec_json.h] array of columns
+Value jbox(const ngp_aabb& b) { Value v = jobj(); v.set("min", jvec(b.min, 3)); v.set("max", jvec(b.max, 3)); return v; }
+uint16_t f32_to_f16(float f) { // round to nearest even
+	uint32_t x; memcpy(&x, &f, 4);
+	const uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+	if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+	if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                        // overflow -> inf
+	if (x < 0x38800000u) {                                                            // subnormal half (or zero)
+		if (x < 0x33000000u) return (uint16_t)sign;
+		const uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u, shift = 126u - e; // value = m * 2^(e-150); half subnormal unit 2^-24
+		uint32_t h = m >> shift; const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+		if (rem > half || (rem == half && (h & 1u))) ++h;
+		return (uint16_t)(sign | h);
+	}
+	uint32_t h = ((x - 0x38000000u) >> 13); const uint32_t rem = x & 0x1fffu;
+	if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+	return (uint16_t)(sign | h);
+}
+float f16_to_f32(uint16_t h) {
+	const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+	uint32_t x;
+	if (e == 0) { if (m == 0) x = sign; else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++sh; } x = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13); } }
+	else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+	else x = sign | ((e + 112u) << 23) | (m << 13);
+	float f; memcpy(&f, &x, 4); return f;
+}
+bool ends_with_ci(const std::string& s, const char* ext) { const size_t n = strlen(ext); if (s.size() < n) return false; for (size_t i = 0; i < n; ++i) if (tolower((unsigned char)s[s.size() - n + i]) != ext[i]) return false; return true; }
+} // namespace
+
 void Testbed::save_snapshot(const std::string& path, bool include_optimizer_state) {
 	ensure_trainer();
-	const std::string cfg = mini_json::dump(m_network_config);
-	const uint64_t mb = ngp_model_serialized_size(m_model, include_optimizer_state);
-	std::vector<char> blob(mb);
-	NGP_CHECK(ngp_model_serialize_host(m_model, blob.data(), mb, include_optimizer_state));
+	Value root = m_network_config.type == Value::Object ? m_network_config : jobj();
+	Value snap = jobj();
+	// ---- tcnn Trainer::serialize ----
+	uint64_t n_params = 0, n_mlp = 0;
+	NGP_CHECK(ngp_model_n_params(m_model, &n_params, &n_mlp));
+	float* master = nullptr; ngp_half* params = nullptr; ngp_half* inference = nullptr; ngp_half* grads = nullptr;
+	NGP_CHECK(ngp_model_param_ptrs(m_model, &master, &params, &inference, &grads));
+	HIP_CHECK(hipDeviceSynchronize());
+	Value pb; pb.type = Value::Binary; pb.bin.resize(n_params * 2);
+	HIP_CHECK(hipMemcpy(pb.bin.data(), inference, n_params * 2, hipMemcpyDeviceToHost));
+	snap.set("n_params", jnum((double)n_params)); snap.set("params_type", jstr("__half")); snap.set("params_binary", pb);
+	if (include_optimizer_state) {
+		Value opt = jobj(); opt.set("otype", jstr("ngp_hip"));
+		Value blob; blob.type = Value::Binary; blob.bin.resize(ngp_model_serialized_size(m_model, 1));
+		NGP_CHECK(ngp_model_serialize_host(m_model, blob.bin.data(), blob.bin.size(), 1));
+		opt.set("state_binary", blob);
+		snap.set("optimizer", opt);
+	}
+	// ---- Testbed::save_snapshot, testbed.cu:5291-5343 ----
+	snap.set("version", jnum(1)); snap.set("mode", jstr("nerf"));
+	snap.set("density_grid_size", jnum(128));
 	float* grid_dev = nullptr;
 	NGP_CHECK(ngp_nerf_density_grid_ptrs(m_nerf, &grid_dev, nullptr, nullptr));
 	const uint64_t gf = (uint64_t)128 * 128 * 128 * (nerf.max_cascade + 1);
 	std::vector<float> grid(gf);
 	HIP_CHECK(hipMemcpy(grid.data(), grid_dev, gf * 4, hipMemcpyDeviceToHost));
-	SnapHeader h; memset(&h, 0, sizeof(h));
-	memcpy(h.magic, "NGPHIP01", 8); h.version = 1; h.training_step = training_step; h.config_bytes = cfg.size(); h.model_bytes = mb; h.grid_floats = gf;
-	h.aabb_scale = nerf.training.dataset.aabb_scale; h.with_optimizer = include_optimizer_state;
+	Value gb; gb.type = Value::Binary; gb.bin.resize(gf * 2);
+	for (uint64_t i = 0; i < gf; ++i) { const uint16_t h = f32_to_f16(grid[i]); memcpy(&gb.bin[i * 2], &h, 2); }
+	snap.set("density_grid_binary", gb);
+	const ngp_nerf_stats st = stats();
+	Value jn = jobj();
+	jn.set("aabb_scale", jnum(nerf.training.dataset.aabb_scale));
+	{ Value e; e.type = Value::Array; jn.set("cam_pos_offset", e); jn.set("cam_rot_offset", e); jn.set("extra_dims_opt", e); } // camera / extra-dims optimisation is not part of this build
+	Value rgb = jobj(); rgb.set("rays_per_batch", jnum(st.rays_per_batch)); rgb.set("measured_batch_size", jnum(st.measured_batch_size));
+	rgb.set("measured_batch_size_before_compaction", jnum(st.measured_batch_size_before_compaction));
+	jn.set("rgb", rgb);
+	{ // to_json(NerfDataset), json_binding.h:114-139
+		const NerfDataset& d = nerf.training.dataset;
+		Value jd = jobj(); jd.set("n_images", jnum((double)d.n_images));
+		Value paths; paths.type = Value::Array; for (const auto& p : d.paths) paths.arr.push_back(jstr(p)); jd.set("paths", paths);
+		Value metas; metas.type = Value::Array; Value xfs; xfs.type = Value::Array;
+		for (size_t i = 0; i < d.n_images; ++i) {
+			const ImageMetadata& m = d.metadata[i];
+			Value jm = jobj(); jm.set("focal_length", jvec(m.focal_length.data(), 2));
+			Value lens = jobj();
+			if (m.lens_mode == NGP_LENS_OPENCV) { lens.set("is_fisheye", jbool(false)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("p1", jnum(m.lens_params[2])); lens.set("p2", jnum(m.lens_params[3])); }
+			jm.set("lens", lens); jm.set("principal_point", jvec(m.principal_point.data(), 2));
+			const float rs[4] = {0.f, 0.f, 0.f, 0.f}; jm.set("rolling_shutter", jvec(rs, 4)); jm.set("resolution", jvec(m.resolution.data(), 2));
+			metas.arr.push_back(jm);
+			Value x = jobj(); x.set("start", jmat_cols(d.xforms[i].data(), 4, 3)); x.set("end", jmat_cols(d.xforms[i].data(), 4, 3)); xfs.arr.push_back(x);
+		}
+		jd.set("metadata", metas); jd.set("xforms", xfs);
+		const ngp_aabb box = scene_aabb(); jd.set("render_aabb", jbox(box));
+		const float eye3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; jd.set("render_aabb_to_local", jmat_cols(eye3, 3, 3));
+		const float up[3] = {0.f, 1.f, 0.f}; jd.set("up", jvec(up, 3)); jd.set("offset", jvec(d.offset.data(), 3));
+		const int env[2] = {0, 0}; jd.set("envmap_resolution", jvec(env, 2)); jd.set("scale", jnum(d.scale)); jd.set("aabb_scale", jnum(d.aabb_scale));
+		jd.set("from_mitsuba", jbool(false)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(0));
+		jn.set("dataset", jd);
+	}
+	snap.set("nerf", jn);
+	snap.set("training_step", jnum(training_step)); snap.set("loss", jnum(loss));
+	const ngp_aabb box = scene_aabb();
+	snap.set("aabb", jbox(box)); snap.set("bounding_radius", jnum(1.0));
+	{ const float eye3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; snap.set("render_aabb_to_local", jmat_cols(eye3, 3, 3)); }
+	snap.set("render_aabb", jbox(box));
+	{ const float up[3] = {0.f, 1.f, 0.f}, sun[3] = {0.577f, 0.577f, 0.577f}; snap.set("up_dir", jvec(up, 3)); snap.set("sun_dir", jvec(sun, 3)); }
+	snap.set("exposure", jnum(exposure)); snap.set("background_color", jvec(background_color.data(), 4));
+	Value cam = jobj();
+	cam.set("matrix", jmat_cols(m_camera.data(), 4, 3)); cam.set("fov_axis", jnum(fov_axis));
+	cam.set("relative_focal_length", jvec(m_relative_focal_length.data(), 2)); cam.set("screen_center", jvec(m_screen_center.data(), 2));
+	cam.set("zoom", jnum(1.0)); cam.set("scale", jnum(1.5)); cam.set("aperture_size", jnum(0.0)); cam.set("autofocus", jbool(false));
+	{ const float t[3] = {0.5f, 0.5f, 0.5f}; cam.set("autofocus_target", jvec(t, 3)); } cam.set("autofocus_depth", jnum(0.5));
+	snap.set("camera", cam);
+	root.set("snapshot", snap);
+
+	std::string bytes;
+	msgpack_lite::pack(root, bytes);
+	if (ends_with_ci(path, ".ingp")) bytes = msgpack_lite::zlib_compress(bytes);
 	std::ofstream f{path, std::ios::binary};
 	if (!f) throw std::runtime_error{"Could not open '" + path + "' for writing."};
-	f.write((const char*)&h, sizeof(h)); f.write(cfg.data(), cfg.size()); f.write(blob.data(), blob.size()); f.write((const char*)grid.data(), gf * 4);
+	f.write(bytes.data(), (std::streamsize)bytes.size());
+	m_network_config_path = path;
 }
+
 void Testbed::load_snapshot(const std::string& path) {
 	std::ifstream f{path, std::ios::binary};
 	if (!f) throw std::runtime_error{"Snapshot '" + path + "' does not exist."};
-	SnapHeader h;
-	f.read((char*)&h, sizeof(h));
-	if (!f || memcmp(h.magic, "NGPHIP01", 8) != 0 || h.version != 1) throw std::runtime_error{"File '" + path + "' is not a snapshot of this build (SNAPSHOT_FORMAT_VERSION mismatch)."};
-	std::string cfg(h.config_bytes, '\0'); f.read(cfg.data(), cfg.size());
-	std::vector<char> blob(h.model_bytes); f.read(blob.data(), blob.size());
-	std::vector<float> grid(h.grid_floats); f.read((char*)grid.data(), grid.size() * 4);
-	if (!f) throw std::runtime_error{"Snapshot '" + path + "' is truncated."};
-	std::string err;
-	if (!mini_json::parse(cfg.c_str(), m_network_config, err)) throw std::runtime_error{"snapshot config: " + err};
-	if (nerf.training.dataset.n_images == 0) throw std::runtime_error{"load_snapshot: load the training data first (dataset metadata is not embedded in this container)."};
-	if (h.aabb_scale != nerf.training.dataset.aabb_scale) throw std::runtime_error{"Snapshot aabb_scale differs from the loaded dataset."};
+	std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	if (ends_with_ci(path, ".ingp")) bytes = msgpack_lite::zlib_decompress(bytes.data(), bytes.size());
+	Value root = msgpack_lite::unpack(bytes.data(), bytes.size());
+	if (!root.is_object() || !root.has("snapshot")) throw std::runtime_error{"File '" + path + "' does not contain a snapshot."};
+	const Value& snap = root["snapshot"];
+	if (snap.num("version", 0) < 1) throw std::runtime_error{"Snapshot uses an old format and can not be loaded."};
+	if (snap.has("mode") && snap.str("mode", "") != "nerf") throw std::runtime_error{"Only NeRF snapshots are supported by this build."};
+	if ((int)snap.num("density_grid_size", 0) != 128) throw std::runtime_error{"Incompatible grid size."};
+	const Value& jn = snap["nerf"];
+	const int aabb_scale = (int)jn.num("aabb_scale", nerf.training.dataset.aabb_scale);
+	if (nerf.training.dataset.n_images == 0) throw std::runtime_error{"load_snapshot: load the training data first (rendering from the snapshot's embedded dataset metadata alone is not implemented)."};
+	if (aabb_scale != nerf.training.dataset.aabb_scale) throw std::runtime_error{"Snapshot aabb_scale differs from the loaded dataset."};
+	m_network_config = root;
 	destroy_trainer();
 	ensure_trainer();
-	NGP_CHECK(ngp_model_deserialize_host(m_model, blob.data(), blob.size()));
-	NGP_CHECK(ngp_nerf_set_density_grid_host(m_nerf, nullptr, grid.data(), grid.size()));
-	NGP_CHECK(ngp_nerf_set_training_step(m_nerf, h.training_step));
-	training_step = h.training_step;
+	uint64_t n_params = 0, n_mlp = 0;
+	NGP_CHECK(ngp_model_n_params(m_model, &n_params, &n_mlp));
+	const Value& opt = snap["optimizer"];
+	if (opt.is_object() && opt.str("otype", "") == "ngp_hip" && opt["state_binary"].type == Value::Binary) {
+		NGP_CHECK(ngp_model_deserialize_host(m_model, opt["state_binary"].bin.data(), opt["state_binary"].bin.size()));
+	} else { // Trainer::deserialize without optimizer state: parameters only, in the precision named by "params_type"
+		const Value& pb = snap["params_binary"];
+		if (pb.type != Value::Binary || (uint64_t)snap.num("n_params", 0) != n_params) throw std::runtime_error{"Snapshot parameters do not match the network config."};
+		std::vector<float> p(n_params);
+		if (snap.str("params_type", "__half") == "float") { if (pb.bin.size() != n_params * 4) throw std::runtime_error{"Snapshot params_binary has the wrong size."}; memcpy(p.data(), pb.bin.data(), n_params * 4); }
+		else { if (pb.bin.size() != n_params * 2) throw std::runtime_error{"Snapshot params_binary has the wrong size."}; for (uint64_t i = 0; i < n_params; ++i) { uint16_t h; memcpy(&h, &pb.bin[i * 2], 2); p[i] = f16_to_f32(h); } }
+		NGP_CHECK(ngp_model_set_params_host(m_model, p.data(), n_params));
+	}
+	const Value& gb = snap["density_grid_binary"];
+	const uint64_t gf = (uint64_t)128 * 128 * 128 * (nerf.max_cascade + 1);
+	if (gb.type == Value::Binary && gb.bin.size() == gf * 2) {
+		std::vector<float> grid(gf);
+		for (uint64_t i = 0; i < gf; ++i) { uint16_t h; memcpy(&h, &gb.bin[i * 2], 2); grid[i] = f16_to_f32(h); }
+		NGP_CHECK(ngp_nerf_set_density_grid_host(m_nerf, nullptr, grid.data(), grid.size()));
+	} else if (gb.type == Value::Binary && !gb.bin.empty()) throw std::runtime_error{"Incompatible number of grid cascades."};
+	training_step = (uint32_t)snap.num("training_step", 0);
+	loss = (float)snap.num("loss", 0.0);
+	NGP_CHECK(ngp_nerf_set_training_step(m_nerf, training_step));
+	if (jn["rgb"].is_object() && jn["rgb"].num("rays_per_batch", 0) > 0) NGP_CHECK(ngp_nerf_set_rays_per_batch(m_nerf, (uint32_t)jn["rgb"].num("rays_per_batch", 4096)));
+	exposure = (float)snap.num("exposure", exposure);
+	if (snap["background_color"].is_array() && snap["background_color"].size() == 4) for (int k = 0; k < 4; ++k) background_color[k] = (float)snap["background_color"].at(k).n;
+	const Value& cam = snap["camera"];
+	if (cam.is_object()) {
+		if (cam["matrix"].is_array() && cam["matrix"].size() == 4) for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) m_camera[c * 3 + r] = (float)cam["matrix"].at(c).at(r).n;
+		fov_axis = (int)cam.num("fov_axis", fov_axis);
+		if (cam["relative_focal_length"].size() == 2) for (int k = 0; k < 2; ++k) m_relative_focal_length[k] = (float)cam["relative_focal_length"].at(k).n;
+		if (cam["screen_center"].size() == 2) for (int k = 0; k < 2; ++k) m_screen_center[k] = (float)cam["screen_center"].at(k).n;
+	}
+	m_network_config_path = path;
+}
+
+// test / tooling hook: msgpack (optionally zlib-framed) -> Value -> msgpack, exercising reader and writer on arbitrary documents
+std::string msgpack_repack(const std::string& data, bool input_compressed, bool output_compressed) {
+	const std::string raw = input_compressed ? msgpack_lite::zlib_decompress(data.data(), data.size()) : data;
+	const mini_json::Value v = msgpack_lite::unpack(raw.data(), raw.size());
+	std::string out; msgpack_lite::pack(v, out);
+	return output_compressed ? msgpack_lite::zlib_compress(out) : out;
 }
 
 } // namespace ngp_host

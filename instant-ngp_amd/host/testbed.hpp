@@ -128,4 +128,6 @@ private:
 	bool m_warned_train_mode = false;
 };
 
+std::string msgpack_repack(const std::string& data, bool input_compressed, bool output_compressed); // msgpack_lite round trip (tests)
+
 } // namespace ngp_host

@@ -70,6 +70,37 @@ def test_network_config_parent_inheritance(scene_dir):
         t.reload_network_from_file(os.path.join(d, "missing.json"))
 
 
+def test_msgpack_wire_format_against_reference_implementation():
+    """msgpack_lite (the snapshot reader / writer) against the `msgpack` Python package in both directions, incl. binary blobs,
+    nested maps / arrays, the integer and float width classes and the zlib framing of .ingp files."""
+    import zlib
+    import msgpack
+    ngp = _ngp()
+    doc = {
+        "encoding": {"otype": "HashGrid", "n_levels": 8, "per_level_scale": 2.0, "log2_hashmap_size": 19},
+        "snapshot": {
+            "version": 1, "mode": "nerf", "loss": 0.00123456789, "neg": -5, "i8": -100, "i16": -30000, "i32": -2000000000, "i64": -9000000000,
+            "u8": 200, "u16": 60000, "u32": 4000000000, "u64": 1 << 40, "f32": 0.5, "f64": 0.1, "flag": True, "nothing": None,
+            "params_binary": bytes(range(256)) * 300, "small_bin": b"\x00\x01\x02", "aabb": {"min": [0.0, 0.0, 0.0], "max": [1.0, 1.0, 1.0]},
+            "long_string": "x" * 70000, "str8": "y" * 100, "array16": list(range(70)), "empty": [], "empty_map": {},
+            "matrix": [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.5, 0.5, 0.5]],
+        },
+    }
+    packed = msgpack.packb(doc, use_bin_type=True)
+    ours = ngp._msgpack_repack(packed, False, False)
+    assert msgpack.unpackb(ours, raw=False) == doc                        # reader + writer preserve the document
+    z = ngp._msgpack_repack(packed, False, True)
+    assert msgpack.unpackb(zlib.decompress(z), raw=False) == doc          # .ingp framing is plain zlib
+    back = ngp._msgpack_repack(zlib.compress(packed), True, False)
+    assert msgpack.unpackb(back, raw=False) == doc
+    # width classes follow nlohmann::json::to_msgpack: smallest integer type, float32 when exact
+    assert ngp._msgpack_repack(msgpack.packb(200), False, False) == b"\xcc\xc8"
+    assert ngp._msgpack_repack(msgpack.packb(0.5), False, False) == b"\xca\x3f\x00\x00\x00"
+    assert ngp._msgpack_repack(msgpack.packb(0.1), False, False)[0] == 0xcb
+    with pytest.raises(RuntimeError):
+        ngp._msgpack_repack(packed[:-3], False, False)                     # truncated input
+
+
 @pytest.mark.gpu
 def test_run_py_flow_train_eval_snapshot(scene_dir):
     ngp = _ngp()
@@ -88,8 +119,24 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     t.snap_to_pixel_centers = True
     t.nerf.render_min_transmittance = 1e-4
     t.shall_train = False
-    snap = os.path.join(tempfile.mkdtemp(), "model.snap")
+    snap = os.path.join(tempfile.mkdtemp(), "model.ingp")
     t.save_snapshot(snap, True)  # with optimizer state: the EMA (inference) weights used by the renderer are restored too
+    snap_plain = os.path.join(os.path.dirname(snap), "weights_only.msgpack")
+    t.save_snapshot(snap_plain, False)
+    # the files are the reference's wire format: zlib(msgpack(config + "snapshot")) (testbed.cu:5288-5352) -- read them with an
+    # independent msgpack implementation
+    import zlib
+    import msgpack
+    doc = msgpack.unpackb(zlib.decompress(open(snap, "rb").read()), raw=False)
+    sn = doc["snapshot"]
+    assert "encoding" in doc and "network" in doc and sn["version"] == 1 and sn["mode"] == "nerf" and sn["training_step"] == 400
+    assert sn["params_type"] == "__half" and len(sn["params_binary"]) == 2 * sn["n_params"] and sn["n_params"] == 10240 + 2920448 * 4
+    assert sn["density_grid_size"] == 128 and len(sn["density_grid_binary"]) == 2 * 128 ** 3
+    assert sn["nerf"]["aabb_scale"] == 1 and sn["nerf"]["rgb"]["rays_per_batch"] % 256 == 0 and sn["nerf"]["dataset"]["n_images"] == len(sn["nerf"]["dataset"]["xforms"])
+    assert len(sn["camera"]["matrix"]) == 4 and len(sn["camera"]["matrix"][0]) == 3 and sn["aabb"]["min"] == [0.0, 0.0, 0.0]
+    assert sn["optimizer"]["otype"] == "ngp_hip"
+    doc2 = msgpack.unpackb(open(snap_plain, "rb").read(), raw=False)
+    assert "optimizer" not in doc2["snapshot"] and doc2["snapshot"]["params_binary"] == sn["params_binary"]
     t.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
     t.render_with_lens_distortion = True
     psnrs = []
@@ -114,3 +161,11 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     t2.set_camera_to_training_view(1); t.set_camera_to_training_view(1)
     a, b = t.render(64, 64, 1, True), t2.render(64, 64, 1, True)
     assert np.abs(a - b).max() < 2e-3
+    # parameters-only snapshot (what Trainer::deserialize restores without optimizer state): same inference weights -> same image
+    t3 = ngp.Testbed()
+    t3.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
+    t3.load_snapshot(snap_plain)
+    t3.background_color = [0.0, 0.0, 0.0, 1.0]; t3.snap_to_pixel_centers = True; t3.nerf.render_min_transmittance = 1e-4
+    t3.set_camera_to_training_view(1)
+    c = t3.render(64, 64, 1, True)
+    assert t3.training_step == 400 and np.abs(a - c).max() < 2e-3
