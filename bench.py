@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the held-out PSNR after the timed region (untimed), e.g. 5000,10000,35000")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL's version block at init) go to stderr
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,16 +109,29 @@ def main():
         cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(nerf, C.byref(cp))
         cnt_view = torch.as_tensor(CudaView(cp.value, 2, "<i4"), device="cuda")
 
+    host_s = {}  # multi-rank path: host-side enqueue time per call (to tell a host-bound loop from a device-bound one)
+
     def step(n=1):
         if world == 1 and not force_dp:
             A.check(lib, lib.ngp_nerf_train(nerf, None, n))
             return
+        pc = time.perf_counter
         for _ in range(n):
+            t0 = pc()
             A.check(lib, lib.ngp_nerf_train_prep(nerf, None))
-            A.check(lib, lib.ngp_nerf_train_forward_backward(nerf, None))
-            dist.all_reduce(grad_view)   # RCCL sum of hash-grid + MLP gradients (fp16, 23.4 MB) over xGMI
+            A.check(lib, lib.ngp_nerf_train_forward(nerf, None))    # K1 (unless pre-launched) .. K4
+            t1 = pc()
             dist.all_reduce(cnt_view)    # two uint32 so that every rank derives the same next rays_per_batch
-            A.check(lib, lib.ngp_nerf_train_finish(nerf, None))
+            t2 = pc()
+            A.check(lib, lib.ngp_nerf_train_backward(nerf, None))   # controller, next step's K1 on its own stream, T1 / scatter / W
+            t3 = pc()
+            dist.all_reduce(grad_view)   # RCCL sum of hash-grid + MLP gradients (fp16, 23.4 MB) over xGMI, overlapped by the next K1
+            t4 = pc()
+            A.check(lib, lib.ngp_nerf_train_finish(nerf, None))     # optimizer
+            t5 = pc()
+            for k, v in (("prep+forward", t1 - t0), ("allreduce_counters", t2 - t1), ("backward", t3 - t2), ("allreduce_gradients", t4 - t3), ("finish", t5 - t4)):
+                host_s[k] = host_s.get(k, 0.0) + v
+            host_s["steps"] = host_s.get("steps", 0) + 1
 
     def stats():
         s = A.NerfStats()
@@ -130,9 +146,11 @@ def main():
     step(args.pretrain)
     step(args.warmup)
     barrier()
+    host_s.clear()
     s0 = stats()
     t0 = time.perf_counter()
     step(args.steps)
+    host_ms = {k: round(1e3 * v / max(host_s.get("steps", 1), 1), 4) for k, v in host_s.items() if k != "steps"}  # snapshot of the timed region only
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -208,10 +226,12 @@ def main():
                        "samples_per_ray_compacted": samples / max(rays, 1), "loss": s1.loss,
                        "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
                        "test_psnr_db": psnr, "test_psnr_at_step": (s3.training_step if psnr is not None else None),
+                       **({"dp_host_enqueue_ms_per_step": host_ms} if host_ms else {}),
                        **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {})},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 

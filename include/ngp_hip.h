@@ -293,6 +293,11 @@ int ngp_nerf_train(ngp_nerf*, void* stream, uint32_t n_steps);
 int ngp_nerf_train_prep(ngp_nerf*, void* stream);
 int ngp_nerf_train_forward_backward(ngp_nerf*, void* stream);
 int ngp_nerf_train_finish(ngp_nerf*, void* stream);
+/* Multi-rank order that lets the controller and the next step's ray marching start before the backward pass:
+ * train_forward -> all-reduce(sum) of ngp_nerf_counter_ptrs' two words -> train_backward -> all-reduce(sum) of the gradients ->
+ * train_finish.  (train_forward_backward + both all-reduces + train_finish stays valid.) */
+int ngp_nerf_train_forward(ngp_nerf*, void* stream);
+int ngp_nerf_train_backward(ngp_nerf*, void* stream);
 /* Two uint32 {measured_before_compaction, measured} to all-reduce(sum) across ranks (8e). */
 int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters2);
 /* Blocking read-back (the reference's copy_to_host, testbed_nerf.cu:2681-2682). */

@@ -675,6 +675,7 @@ struct ngp_nerf {
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
 	// K1 of step n+1 does not depend on the parameters: it is launched on its own stream as soon as step n's controller has run and
 	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
+	bool ctl_done = false; // the batch-size controller of the current step has run
 	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
 	uint32_t k2_rounds = 3; // measured best of 2..4 (0.168 / 0.178 / 0.180 ms for 3 / 4 / 2 rounds); NGP_K2_ROUNDS=2..4 overrides (tuning knob; round 0 is always the first 32 samples of every ray)
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
@@ -841,7 +842,10 @@ static bool next_prep_updates_grid(const ngp_nerf* t) {
 	const uint32_t n_prep_to_skip = (uint32_t)std::min(std::max((int)(t->training_step + 1) / 16, 1), 16);
 	return t->prep_skip_counter % n_prep_to_skip == 0;
 }
-extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
+__global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t world_size);
+// phase bit 1: K1..K4 (forward, loss, compaction); bit 2: controller, T1 / W / scatter (backward).  `global_counters`: the caller has
+// all-reduced the published counters (multi-rank), so the controller may run before the backward pass.
+static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_counters) {
 	REQUIRE(t->n_images > 0, "train: no dataset");
 	hipStream_t s = (hipStream_t)stream;
 	const ngp_nerf_options& o = t->opt;
@@ -860,6 +864,7 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 		k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
 		return k1;
 	};
+	if (phase & 1) {
 	bool have_k1 = false;
 	if (t->k1_prelaunched) { // launched by the previous step: valid if nothing it depends on was changed through the API since
 		HIPCHK(hipStreamWaitEvent(s, t->ev_k1, 0));
@@ -895,10 +900,16 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2); }
-	// Single rank: the batch-size controller only needs K1's / K3's counters, so it runs here instead of after the optimizer and
-	// the next step's K1 can start behind it (multi-rank: after the counters' all-reduce, ngp_nerf_train_finish).
-	const bool early_ctl = o.world_size == 1;
-	if (early_ctl) { ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, B, 1); }
+	}
+	if (phase & 2) {
+	// The batch-size controller only needs K1's / K3's counters (multi-rank: their all-reduced values), so it runs here instead of after
+	// the optimizer and the next step's K1 can start behind it.
+	const bool early_ctl = o.world_size == 1 || global_counters;
+	if (early_ctl) {
+		if (o.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, o.world_size);
+		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, B, o.world_size);
+		t->ctl_done = true;
+	}
 	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t);
 	if (prelaunch) {
 		if (!t->k1_stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
@@ -913,9 +924,17 @@ extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) {
 		HIPCHK(hipEventRecord(t->ev_k1, t->k1_stream));
 		t->k1_prelaunched = true; t->k1_version = t->state_version; t->k1_for_stream = s;
 	}
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+
+extern "C" int ngp_nerf_train_forward_backward(ngp_nerf* t, void* stream) { return nerf_step_impl(t, stream, 3, false); }
+// Multi-rank order: ngp_nerf_train_forward -> all-reduce(sum) of the two ngp_nerf_counter_ptrs words -> ngp_nerf_train_backward ->
+// all-reduce(sum) of the gradients -> ngp_nerf_train_finish.  The controller then runs before the backward pass and the next
+// step's K1 overlaps the backward pass AND the gradient all-reduce.
+extern "C" int ngp_nerf_train_forward(ngp_nerf* t, void* stream) { return nerf_step_impl(t, stream, 1, false); }
+extern "C" int ngp_nerf_train_backward(ngp_nerf* t, void* stream) { return nerf_step_impl(t, stream, 2, true); }
 
 __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t world_size) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -929,10 +948,11 @@ __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t 
 extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
-	if (t->opt.world_size > 1) { // single rank: the controller already ran behind K3 (ngp_nerf_train_forward_backward)
-		hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
+	if (!t->ctl_done) { // the controller has not run behind K3 (multi-rank caller using ngp_nerf_train_forward_backward)
+		if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
 		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size, t->opt.world_size);
 	}
+	t->ctl_done = false;
 	++t->training_step;
 	HIPCHK(hipGetLastError());
 	return 0;
