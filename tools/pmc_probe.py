@@ -20,7 +20,7 @@ GROUPS = {
     "tcc2": ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_ATOMIC_sum", "TCC_READ_sum"],
     "grbm": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
 }
-KERNELS = "k_train_fwd_bwd|k_inference|k_optimizer|k_wgrad|k_compute_loss_v2|k1_count|k1_write|k1_setup"
+KERNELS = "k_train_fwd_bwd|k_grad_bin|k_grad_accumulate|k_inference|k_optimizer|k_wgrad|k_compute_loss_v2|k1_count|k1_write|k1_setup"
 
 
 def main():
