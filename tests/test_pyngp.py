@@ -101,6 +101,37 @@ def test_msgpack_wire_format_against_reference_implementation():
         ngp._msgpack_repack(packed[:-3], False, False)                     # truncated input
 
 
+def test_load_snapshot_validates_before_touching_the_gpu():
+    """Testbed::load_snapshot (testbed.cu:5357-5395): version / mode / grid-size checks and the error texts, on documents written
+    with the `msgpack` package (plain .msgpack and zlib-framed .ingp)."""
+    import zlib
+    import msgpack
+    ngp = _ngp()
+    d = tempfile.mkdtemp()
+
+    def write(name, doc, compress=False):
+        b = msgpack.packb(doc, use_bin_type=True)
+        path = os.path.join(d, name)
+        open(path, "wb").write(zlib.compress(b) if compress else b)
+        return path
+    good = {"version": 1, "mode": "nerf", "density_grid_size": 128, "nerf": {"aabb_scale": 1}, "n_params": 0, "params_type": "__half", "params_binary": b""}
+    t = ngp.Testbed()
+    with pytest.raises(RuntimeError, match="does not exist"):
+        t.load_snapshot(os.path.join(d, "nope.ingp"))
+    with pytest.raises(RuntimeError, match="does not contain a snapshot"):
+        t.load_snapshot(write("a.msgpack", {"encoding": {}}))
+    with pytest.raises(RuntimeError, match="old format"):
+        t.load_snapshot(write("b.msgpack", {"snapshot": dict(good, version=0)}))
+    with pytest.raises(RuntimeError, match="Only NeRF snapshots"):
+        t.load_snapshot(write("c.ingp", {"snapshot": dict(good, mode="sdf")}, compress=True))
+    with pytest.raises(RuntimeError, match="Incompatible grid size"):
+        t.load_snapshot(write("d.ingp", {"snapshot": dict(good, density_grid_size=64)}, compress=True))
+    with pytest.raises(RuntimeError, match="load the training data first"):
+        t.load_snapshot(write("e.ingp", {"snapshot": good}, compress=True))
+    with pytest.raises(RuntimeError):
+        t.load_snapshot(write("f.ingp", {"snapshot": good}))  # .ingp must be zlib framed
+
+
 @pytest.mark.gpu
 def test_run_py_flow_train_eval_snapshot(scene_dir):
     ngp = _ngp()
