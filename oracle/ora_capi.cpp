@@ -174,3 +174,11 @@ API int ora_encmlp_encode(void* h, const float* in, uint32_t stride, uint32_t n,
 API int ora_encmlp_inference(void* h, const float* in, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride) {
 	TRY(((EncMlp*)h)->inference(in, stride, n, out, out_stride))
 }
+API int ora_encmlp_training_step(void* h, const float* in, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
+	TRY(((EncMlp*)h)->training_step(in, stride, n, dL_dy, dy_stride))
+}
+API uint16_t* ora_encmlp_gradients(void* h) { return ((EncMlp*)h)->grads.data(); }
+API float ora_encmlp_loss_and_gradient(void* h, int mape, const uint16_t* pred, uint32_t pred_stride, const float* target, uint32_t target_stride, uint32_t n, float loss_scale,
+		uint16_t* dL_dy) {
+	return ((EncMlp*)h)->loss_and_gradient(mape != 0, pred, pred_stride, target, target_stride, n, loss_scale, dL_dy);
+}

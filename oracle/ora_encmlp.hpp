@@ -86,6 +86,78 @@ struct EncMlp {
 		sync_half();
 	}
 	void sync_half() { for (size_t i = 0; i < n_params; ++i) params[i] = f2h(params_fp[i]); }
+	std::vector<uint16_t> grads; // Trainer::gradients, written by training_step (GradientMode::Overwrite)
+
+	// Trainer::training_step with an external dL/dy (n x 16 halfs, only the first n_output_dims used): forward with saved activations,
+	// FullyFusedMLP backward (fp32 weight-gradient accumulation, half dL/dx), GridEncoding backward (half atomicAdd per contribution,
+	// here in sample order) -- the same scheme as Model::training_step, for general D / F.  [tcnn]
+	void training_step(const float* in, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
+		const uint32_t n_enc = net.in, D = grid.D, NC = 1u << D;
+		std::vector<float> dW(n_mlp, 0.f);
+		std::vector<uint16_t> dL_denc((size_t)n * n_enc);
+		#pragma omp parallel
+		{
+			std::vector<float> dWt(n_mlp, 0.f);
+			std::vector<uint16_t> enc(n_enc), acts(net.n_hidden * net.width);
+			#pragma omp for schedule(static)
+			for (int64_t i = 0; i < (int64_t)n; ++i) {
+				uint16_t o[16], dout[16] = {0};
+				grid_encode_nd(grid, params.data() + n_mlp, in + (size_t)i * stride, enc.data());
+				mlp_forward(net, params.data(), enc.data(), acts.data(), o);
+				for (uint32_t k = 0; k < cfg.n_output_dims; ++k) dout[k] = dL_dy[(size_t)i * dy_stride + k];
+				mlp_backward(net, params.data(), enc.data(), acts.data(), dout, dWt.data(), dL_denc.data() + (size_t)i * n_enc);
+			}
+			#pragma omp critical
+			for (size_t k = 0; k < n_mlp; ++k) dW[k] += dWt[k];
+		}
+		grads.assign(n_params, 0);
+		for (size_t k = 0; k < n_mlp; ++k) grads[k] = f2h(dW[k]);
+		uint16_t* gg = grads.data() + n_mlp;
+		#pragma omp parallel for schedule(dynamic, 1)
+		for (int64_t l = 0; l < (int64_t)grid.n_levels; ++l) {
+			const float scale = grid.scales[l];
+			const uint32_t res = grid.resolutions[l], hashmap_size = grid.offsets[l + 1] - grid.offsets[l];
+			uint16_t* lvl = gg + (size_t)grid.offsets[l] * grid.F;
+			for (uint32_t i = 0; i < n; ++i) {
+				const float* x = in + (size_t)i * stride;
+				float pos[4]; uint32_t pg[4];
+				for (uint32_t d = 0; d < D; ++d) { const float p = std::fma(scale, x[d], 0.5f), tmp = std::floor(p); pg[d] = (uint32_t)(int)tmp; pos[d] = p - tmp; }
+				for (uint32_t c = 0; c < NC; ++c) {
+					float w = 1; uint32_t pl[4];
+					for (uint32_t d = 0; d < D; ++d) { if ((c & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; } else { w *= pos[d]; pl[d] = pg[d] + 1; } }
+					const uint32_t idx = grid_index_nd(D, hashmap_size, res, pl);
+					for (uint32_t f = 0; f < grid.F; ++f) {
+						const uint16_t v = f2h(h2f(dL_denc[(size_t)i * n_enc + l * grid.F + f]) * w);
+						uint16_t& dst = lvl[(size_t)idx * grid.F + f];
+						dst = f2h(h2f(dst) + h2f(v));
+					}
+				}
+			}
+		}
+	}
+
+	// [tcnn losses/l2.h, mape.h] per-element loss value and loss_scale-d gradient in half; n_total = n * n_output_dims.
+	// L2 (configs/image/base.json): (p - t)^2 / n_total, gradient 2 (p - t) / n_total.  MAPE (configs/sdf/base.json):
+	// |p - t| / (|t| + 0.01) / n_total, gradient sign(p - t) / (|t| + 0.01) / n_total.
+	float loss_and_gradient(bool mape, const uint16_t* pred, uint32_t pred_stride, const float* target, uint32_t target_stride, uint32_t n, float loss_scale,
+			uint16_t* dL_dy /* n x 16 halfs */) const {
+		const uint32_t no = cfg.n_output_dims;
+		const float n_total = (float)n * (float)no;
+		double total = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			for (uint32_t k = 0; k < 16; ++k) dL_dy[(size_t)i * 16 + k] = 0;
+			for (uint32_t k = 0; k < no; ++k) {
+				const float p = h2f(pred[(size_t)i * pred_stride + k]), t = target[(size_t)i * target_stride + k], diff = p - t;
+				float value, grad;
+				if (mape) { const float scale = 1.0f / (std::fabs(t) + 0.01f); value = std::fabs(diff) * scale / n_total; grad = (diff > 0 ? 1.f : diff < 0 ? -1.f : 0.f) * scale / n_total; }
+				else { value = diff * diff / n_total; grad = 2 * diff / n_total; }
+				total += value;
+				dL_dy[(size_t)i * 16 + k] = f2h(loss_scale * grad);
+			}
+		}
+		return (float)total;
+	}
+
 	void inference(const float* in, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride) const {
 		#pragma omp parallel for schedule(static)
 		for (int64_t i = 0; i < (int64_t)n; ++i) {

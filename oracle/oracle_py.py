@@ -48,6 +48,8 @@ def load():
         for name in ("ora_encmlp_n_params", "ora_encmlp_n_mlp"):
             getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]
         L.ora_encmlp_params_fp.restype = vp; L.ora_encmlp_params_fp.argtypes = [vp]
+        L.ora_encmlp_gradients.restype = vp; L.ora_encmlp_gradients.argtypes = [vp]
+        L.ora_encmlp_loss_and_gradient.restype = f32; L.ora_encmlp_loss_and_gradient.argtypes = [vp, C.c_int, vp, u32, vp, u32, u32, f32, vp]
         L.ora_encmlp_destroy.argtypes = [vp]; L.ora_encmlp_sync_half.argtypes = [vp]
         for name in ("ora_model_destroy", "ora_nerf_destroy", "ora_model_sync_half", "ora_nerf_update_mean_and_bitfield"):
             getattr(L, name).argtypes = [vp]

@@ -101,6 +101,71 @@ def test_encode_3d_agrees_with_nerf_grid_oracle(ora):
     ora.ora_encmlp_destroy(h)
 
 
+@pytest.mark.parametrize("which", ["image", "sdf"])
+def test_encmlp_gradients_vs_autograd(ora, which):
+    """Oracle training step of the image / SDF model (next-round groundwork for ngp_encmlp training): MLP and grid gradients against a
+    float64 PyTorch autograd implementation, L2 / MAPE loss gradients against autograd of the loss definitions."""
+    import torch
+    cfg = A.image_encmlp_config(log2_hashmap_size=14) if which == "image" else A.sdf_encmlp_config(log2_hashmap_size=14)
+    D, no = cfg.n_pos_dims, cfg.n_output_dims
+    h, n_params, nm, p = _ora_model(ora, cfg)
+    rng = np.random.default_rng(2)
+    p[:nm] = rng.uniform(-0.3, 0.3, nm).astype(np.float32); p[nm:] = rng.uniform(-1, 1, n_params - nm).astype(np.float32)
+    ora.ora_encmlp_sync_half(h)
+    off, res, sc = _layout(ora, h)
+    n = 400
+    x = rng.random((n, D), dtype=np.float32)
+    pred16 = np.zeros((n, no), np.uint16)
+    assert ora.ora_encmlp_inference(h, ptr(x), D, n, ptr(pred16), no) == 0
+    target = rng.normal(size=(n, no)).astype(np.float32) * 0.3
+    dl = np.zeros((n, 16), np.uint16)
+    loss = ora.ora_encmlp_loss_and_gradient(h, 1 if which == "sdf" else 0, ptr(pred16), no, ptr(target), no, n, 128.0, ptr(dl))
+    # --- loss definitions under autograd ---
+    pt = torch.tensor(half_to_f32(pred16), dtype=torch.float64, requires_grad=True); tt = torch.tensor(target, dtype=torch.float64)
+    lt = ((pt - tt).abs() / (tt.abs() + 0.01)).sum() / (n * no) if which == "sdf" else ((pt - tt) ** 2).sum() / (n * no)
+    lt.backward()
+    assert abs(loss - float(lt)) < 1e-4 * abs(float(lt))
+    gl = half_to_f32(dl)[:, :no]
+    assert np.abs(gl - 128.0 * pt.grad.numpy()).max() < 2e-3 * np.abs(128.0 * pt.grad.numpy()).max() + 1e-6
+    assert not half_to_f32(dl)[:, no:].any()
+    # --- network gradients ---
+    assert ora.ora_encmlp_training_step(h, ptr(x), D, n, ptr(dl), 16) == 0
+    g = half_to_f32(np.ctypeslib.as_array(C.cast(ora.ora_encmlp_gradients(h), C.POINTER(C.c_uint16)), shape=(n_params,)).copy()).astype(np.float64)
+    ph = np.empty(n_params, np.uint16); ora.ora_f2h(ptr(np.ascontiguousarray(p)), ptr(ph), C.c_uint64(n_params))
+    P = torch.tensor(half_to_f32(ph), dtype=torch.float64, requires_grad=True)
+    X = torch.tensor(x, dtype=torch.float64)
+    primes = (1, 2654435761, 805459861)
+    feats = []
+    for l in range(16):
+        hs = int(off[l + 1] - off[l]); r = int(res[l])
+        tbl = P[nm + int(off[l]) * 2: nm + int(off[l + 1]) * 2].reshape(-1, 2)
+        q = float(np.float32(sc[l])) * X + 0.5
+        gi = torch.floor(q).long(); f = q - gi
+        acc = 0
+        for c in range(1 << D):
+            w = torch.ones(n, dtype=torch.float64); ids = []
+            for d in range(D):
+                bit = (c >> d) & 1
+                w = w * (f[:, d] if bit else 1 - f[:, d]); ids.append(gi[:, d] + bit)
+            if r ** D > hs:
+                idx = 0
+                for d in range(D):
+                    idx = idx ^ ((ids[d] * primes[d]) & 0xFFFFFFFF)
+            else:
+                idx = sum(ids[d] * r ** d for d in range(D))
+            acc = acc + w[:, None] * tbl[idx % hs]
+        feats.append(acc)
+    enc = torch.cat(feats, 1)
+    W = lambda a, rr, cc: P[a:a + rr * cc].reshape(rr, cc)
+    out = torch.relu(torch.relu(enc @ W(0, 64, 32).T) @ W(2048, 64, 64).T) @ W(6144, 16, 64).T
+    out.backward(torch.tensor(half_to_f32(dl), dtype=torch.float64))
+    gref = P.grad.numpy()
+    for name, a, b in (("l1", 0, 2048), ("l2", 2048, 6144), ("l3", 6144, 7168), ("grid", nm, n_params)):
+        rel = np.linalg.norm(g[a:b] - gref[a:b]) / np.linalg.norm(gref[a:b])
+        assert rel < 3e-2, (which, name, rel)
+    ora.ora_encmlp_destroy(h)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,n", [("image", 65536), ("image", 77), ("sdf", 50021)])
 def test_encmlp_inference_parity(ora, hip, which, n):
