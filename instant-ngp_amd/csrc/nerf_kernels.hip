@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n_local; li += gridDim.x * 4) {
 	const RaySetup r = rs[li];
 	uint32_t cnt = 0, n_chunks = 0;
+	const bool exact_skip = a.exact_skip != 0;
 	if (r.flags) {
 		const Box aabb(a.aabb);
 		const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
@@ -218,20 +219,30 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		// chain of dependent ~1 us loads otherwise); the exit tests are then replayed in chunk order, so masks, counts
 		// and n_chunks are exactly those of the one-chunk-at-a-time loop.
 		bool done = false;
+		const f3 idir = mk3(1.0f) / rdn;
+		uint32_t jnext = 0; // next lattice point the reference's loop visits (wave-uniform)
 		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
 			uint64_t m[K1_GROUP], in[K1_GROUP];
+			uint32_t skip[K1_GROUP]; // empty lattice points: length of the reference's skip, in lattice units
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				const float t = lattice_t(r, (ch0 + u) * 64 + lane, a.cone_angle_constant);
 				const f3 pos = ro + t * rdn;
 				const bool inside = aabb.contains(pos);
 				bool occ = false;
+				skip[u] = 1u;
 				if (inside) {
 					// 64 consecutive lattice points span ~14 voxels: the byte loads of a wavefront coalesce into a few
 					// L1/L2 lines, and thousands of resident wavefronts hide their latency (no LDS staging needed here)
 					const float dt = calc_dt(t, a.cone_angle_constant);
 					const uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
 					occ = a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
+					if (exact_skip && !occ) {
+						// advance_to_next_voxel (nerf_device.cuh:431-441) lands on lattice point j + ceil(max(to(t_target) - to(t), 0.5))
+						const float res = scalbnf((float)GRIDSIZE, -(int)mip);
+						const float t_target = t + distance_to_next_voxel(pos, rdn, idir, res);
+						skip[u] = (uint32_t)ceilf(fmaxf(to_stepping_space(t_target, a.cone_angle_constant) - to_stepping_space(t, a.cone_angle_constant), 0.5f));
+					}
 				}
 				m[u] = __ballot(occ);
 				in[u] = __ballot(inside);
@@ -239,8 +250,27 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				if (done || cnt >= N_STEPS) { done = true; break; }
-				if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch0 + u] = m[u];
-				cnt += (uint32_t)__popcll(m[u]);
+				uint64_t sm = m[u];
+				if (exact_skip) {
+					// The orbit of the reference's update rule over this chunk: runs of occupied points are taken whole (j -> j + 1),
+					// an empty point jumps by its own skip length (one v_readlane); everything stays in scalar registers.
+					const uint32_t base = (ch0 + u) * 64;
+					sm = 0ull;
+					uint32_t j = jnext > base ? jnext - base : 0u;
+					while (j < 64u) {
+						if (!((in[u] >> j) & 1ull)) { done = true; break; } // the march left the box
+						const uint64_t rest = ~(m[u] >> j); // bit 0 = 1 <=> point j is empty
+						const uint32_t run = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
+						if (run) {
+							const uint32_t len = min(run, 64u - j);
+							sm |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << j;
+							j += len;
+						} else j += (uint32_t)__builtin_amdgcn_readlane((int)skip[u], (int)__builtin_amdgcn_readfirstlane((int)j));
+					}
+					jnext = base + j;
+				}
+				if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch0 + u] = sm;
+				cnt += (uint32_t)__popcll(sm);
 				n_chunks = ch0 + u + 1;
 				if (in[u] == 0ull) done = true; // the whole chunk is past the box: so is everything after it
 			}

@@ -576,6 +576,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
+	a.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
@@ -862,6 +863,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
 		k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 		k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
+		k1.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
 		return k1;
 	};
 	if (phase & 1) {

@@ -95,6 +95,11 @@ API void ora_k_generate_training_samples(uint32_t n_rays, uint32_t ray_begin, ui
 		n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant);
 	*ray_counter = k.ray_counter; *numsteps_counter = k.numsteps_counter;
 }
+// CPU model of the production (sample-parallel) marcher, see ora_nerf.hpp lattice_march_counts; mode 0 = independent test, 1 = exact-skip walk
+API void ora_k1_lattice_counts(int mode, uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, ngp_aabb aabb, ngp_pcg32 rng, uint32_t n_images, const ngp_image_meta* meta,
+		const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip, int snap, float cone_angle_constant, uint32_t* out_counts, uint32_t max_lattice_points) {
+	lattice_march_counts(mode, n_rays, ray_begin, ray_end, Aabb(aabb), Pcg32(rng), n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant, out_counts, max_lattice_points);
+}
 API void ora_k_compute_loss(uint32_t n_rays, uint32_t rays_counter, ngp_aabb aabb, ngp_pcg32 rng, uint32_t max_samples_compacted, float loss_scale,
 		const float* background_color, int color_space_srgb, int random_bg, int linear_colors, uint32_t n_images, const ngp_image_meta* meta,
 		const uint16_t* network_output, uint32_t out_stride, uint32_t* numsteps_counter_compacted, const uint32_t* ray_indices_in, const ngp_ray* rays_in,

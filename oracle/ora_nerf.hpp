@@ -203,6 +203,60 @@ inline K1Out generate_training_samples(uint32_t n_rays, uint32_t ray_begin, uint
 }
 
 // -------------------------------------------------------------------------------------------------
+// CPU model of the PRODUCTION ray marcher of libngp_hip (csrc/nerf_kernels.hip k1_setup / k1_count): NOT a restatement of a
+// reference function but of this repo's sample-parallel reformulation of testbed_nerf.cu:798-807, kept here so that the tests can
+// (i) quantify on the CPU how the reformulation differs from the sequential loop above and (ii) compare the device kernel with the
+// same algorithm on the host.  Every visited march parameter of the reference loop is a lattice point t_j = from_stepping_space(n'+j),
+// n' = to_stepping_space(startt): a step through an occupied voxel is j -> j+1 (`t += dt`, dt = from(to(t)+1) - t), and a skip
+// is j -> j + ceil(max(to(t_target) - to(t), 0.5)) (advance_to_next_voxel, nerf_device.cuh:431-441).
+//   mode 0 ("independent"): lattice point j is a sample iff it lies in an occupied voxel at ITS OWN mip (exact while the mip is
+//                           constant along a skipped voxel, i.e. cone_angle == 0);
+//   mode 1 ("walk"):        the orbit of j = 0 under the reference's own update rule, evaluated on the lattice.
+// out_counts[i - ray_begin] = number of samples of global ray i (0 for masked / empty rays).
+// -------------------------------------------------------------------------------------------------
+inline void lattice_march_counts(int mode, uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, const Aabb& aabb, const Pcg32& rng_in, uint32_t n_images,
+		const ngp_image_meta* meta, const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip, bool snap_to_pixel_centers, float cone_angle,
+		uint32_t* out_counts, uint32_t max_lattice_points) {
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t ii = ray_begin; ii < (int64_t)std::min(ray_end, n_rays); ++ii) {
+		const uint32_t i = (uint32_t)ii;
+		out_counts[i - ray_begin] = 0;
+		uint32_t img = image_idx(i, n_rays, n_images);
+		const ngp_image_meta& m = meta[img];
+		Pcg32 rng = rng_in;
+		rng.advance((int64_t)(i * N_MAX_RANDOM_SAMPLES_PER_RAY));
+		vec2 uv = random_image_pos_training(rng, m.resolution, snap_to_pixel_centers);
+		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) continue;
+		(void)rng.next_float();
+		const mat4x3 xform = M43(xforms[img].start);
+		vec3 ro, rd;
+		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+		vec3 rdn = normalize(rd);
+		vec2 tminmax = aabb.ray_intersect(ro, rdn);
+		tminmax.x = std::fmax(tminmax.x, 0.0f);
+		const float startt = advance_n_steps(tminmax.x, cone_angle, rng.next_float());
+		const float nprime = to_stepping_space(startt, cone_angle);
+		const vec3 idir = V3(1.0f) / rdn;
+		uint32_t cnt = 0, j = 0;
+		while (j < max_lattice_points && cnt < NERF_STEPS) {
+			const float t = j == 0 ? startt : from_stepping_space(nprime + (float)j, cone_angle);
+			const vec3 pos = ro + t * rdn;
+			if (!aabb.contains(pos)) break;
+			const float dt = calc_dt(t, cone_angle);
+			const uint32_t mip = mip_from_dt(dt, pos, max_mip);
+			if (density_grid_occupied_at(pos, bitfield, mip)) { ++cnt; ++j; continue; }
+			if (mode == 0) { ++j; continue; }
+			// the reference's skip, in lattice units
+			const float res = scalbnf((float)NERF_GRIDSIZE, -(int)mip);
+			const float t_target = t + distance_to_next_voxel(pos, rdn, idir, res);
+			const float k = ceilf(std::fmax(to_stepping_space(t_target, cone_angle) - to_stepping_space(t, cone_angle), 0.5f));
+			j += (uint32_t)k;
+		}
+		out_counts[i - ray_begin] = cnt;
+	}
+}
+
+// -------------------------------------------------------------------------------------------------
 // K3: compute_loss_kernel_train_nerf, testbed_nerf.cu:852-1180 (no envmap / depth / error-map /
 // exposure: off by default).  __expf is restated as expf.
 // -------------------------------------------------------------------------------------------------
