@@ -4,9 +4,14 @@
 `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run (one rank per GPU, RCCL).
 A "step" = one Testbed::train(batch) call: occupancy-grid prep at the reference's cadence + K1..K6 (full optimizer step).
 Data: synthetic stand-in for nerf_synthetic/lego (100 views 800x800 RGBA8, same cameras/format; the real set is not
-shipped and there is no network).  Before the W warm-up steps the model is trained for --pretrain steps (untimed setup),
-because rays/step adapts to the occupancy grid: at initialisation one step marches ~500 rays, in steady state tens of
+shipped and there is no network), or `--scene fox` = the reference's shipped real capture (50 JPEGs 1080x1920, staged under
+_ref_data/ by tools/stage_reference_data.py).  Before the W warm-up steps the model is trained for --pretrain steps (untimed
+setup), because rays/step adapts to the occupancy grid: at initialisation one step marches ~500 rays, in steady state tens of
 thousands -- the steady state is the regime the metric is quoted on.  Prints ONE JSON line on rank 0.
+
+Untimed legs after the timed region: per-kernel HIP-event profile (roofline), held-out PSNR (scripts/run.py procedure),
+`--psnr-steps` PSNR@step curve, `--ab-psnr` equal-step PSNR of the production path vs the reference-order path
+(sequential K1 / K3, half atomics, eager K2: ngp_debug_set_flags(1|32|2048|8192)), CPU baseline (the oracle, a port).
 """
 import argparse
 import ctypes as C
@@ -25,17 +30,160 @@ import torch
 
 import ngp_abi as A
 
-# algorithmic bytes per unit, SURVEY.md 8(d) / DESIGN.md "roofline accounting"
+# algorithmic work per unit, SURVEY.md 8(d) / DESIGN.md "roofline accounting"
 BYTES_PER_SAMPLE_FWD = 28 + 512 + 8          # coords + 8 levels x 8 corners x 8 B gather + rgbsigma half4
 BYTES_PER_SAMPLE_T1 = 28 + 512 + 8 + 1024    # forward gather + dL/dy + scatter as read-modify-write
 BYTES_PER_PARAM_OPT = 38
+FLOP_PER_SAMPLE_FWD = 2 * (3072 + 7168)      # both MLPs, one sample, forward
+FLOP_PER_SAMPLE_TRAIN = 3 * FLOP_PER_SAMPLE_FWD  # forward + dgrad + wgrad
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
+MFMA_PEAK_TFLOPS = 2500.0                    # dense fp16 MFMA peak (no sparsity)
+REFERENCE_ORDER_FLAGS = 1 | 32 | 2048 | 8192  # sequential K1, sequential K3, half atomics for every level, eager K2
 
 
 class CudaView:
-    """zero-copy torch view of library-owned device memory (for the RCCL all-reduce of gradients / counters)"""
+    """zero-copy torch view of library-owned device memory (for the all-reduce of gradients / counters through torch.distributed)"""
     def __init__(self, ptr, n, typestr):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# scenes
+# ------------------------------------------------------------------------------------------------------------------------
+def load_scene(args):
+    """-> dict(images=[cuda uint8 HxWx4], M, X (ctypes arrays with device pixel pointers), n, aabb_scale, eval=[(gt cuda uint8, RenderParams)], eval_kind)"""
+    if args.scene == "synthetic":
+        import synth_scene
+        images, xforms, meta, _ = synth_scene.make_dataset(args.images, args.res, "cuda")
+        n = len(images)
+        M = (A.ImageMeta * n)(); X = (A.Xform * n)()
+        for i in range(n):
+            M[i].pixels = images[i].data_ptr(); M[i].image_data_type = A.IMAGE_BYTE; M[i].lens_mode = A.LENS_PERSPECTIVE
+            M[i].resolution[0], M[i].resolution[1] = meta["resolution"]
+            M[i].principal_point[0] = M[i].principal_point[1] = 0.5
+            M[i].focal_length[0], M[i].focal_length[1] = meta["focal_length"]
+            for k in range(12):
+                X[i].start[k] = X[i].end[k] = float(xforms[i][k])
+        ev = []
+        if args.eval_views > 0:
+            res = args.eval_res
+            gts, exf, emeta, _ = synth_scene.make_dataset(args.eval_views, res, "cuda", phase=1.234)
+            for gt, xf in zip(gts, exf):
+                rp = A.RenderParams()
+                rp.resolution[0] = rp.resolution[1] = res
+                rp.focal_length[0], rp.focal_length[1] = emeta["focal_length"]
+                rp.screen_center[0] = rp.screen_center[1] = 0.5
+                for k in range(12):
+                    rp.camera[k] = float(xf[k])
+                rp.lens_mode = 0
+                ev.append((gt, rp))
+        return dict(images=images, M=M, X=X, n=n, aabb_scale=1, eval=ev, eval_kind="held-out views (synthetic test cameras)",
+                    name=f"NeRF nerf_synthetic/lego-format synthetic scene ({n} views {args.res}x{args.res} RGBA8)")
+    # fox: the reference's real capture, through this repo's C++ loader (host/testbed.cpp load_training_data; JPEG decode by Pillow)
+    path = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
+    if not os.path.exists(path):
+        raise RuntimeError("--scene fox needs _ref_data/data/nerf/fox (tools/stage_reference_data.py copies it from /root/reference at build time)")
+    import pyngp as ngp
+    t = ngp.Testbed()
+    t.load_training_data(path)
+    d = t.nerf.training.dataset
+    n = d.n_images
+    images = [torch.from_numpy(np.ascontiguousarray(d.image(i))).cuda() for i in range(n)]
+    M = (A.ImageMeta * n)(); X = (A.Xform * n)()
+    for i in range(n):
+        m = d.metadata[i]
+        M[i].pixels = images[i].data_ptr(); M[i].image_data_type = A.IMAGE_BYTE; M[i].lens_mode = m.lens_mode
+        M[i].resolution[0], M[i].resolution[1] = m.resolution
+        M[i].principal_point[0], M[i].principal_point[1] = m.principal_point
+        M[i].focal_length[0], M[i].focal_length[1] = m.focal_length
+        for k in range(7):
+            M[i].lens_params[k] = m.lens_params[k]
+        for k in range(12):
+            X[i].start[k] = X[i].end[k] = d.xforms[i][k]
+    ev = []
+    for i in [int(round(k * (n - 1) / max(args.eval_views - 1, 1))) for k in range(args.eval_views)] if args.eval_views > 0 else []:
+        # Testbed::set_camera_to_training_view (testbed.cu:486-505): camera = xform, screen_center = 1 - principal point, lens of the view
+        rp = A.RenderParams()
+        rp.resolution[0], rp.resolution[1] = M[i].resolution[0], M[i].resolution[1]
+        rp.focal_length[0], rp.focal_length[1] = M[i].focal_length[0], M[i].focal_length[1]
+        rp.screen_center[0] = 1.0 - (1.0 - M[i].principal_point[0]); rp.screen_center[1] = 1.0 - (1.0 - M[i].principal_point[1])
+        for k in range(12):
+            rp.camera[k] = X[i].start[k]
+        rp.lens_mode = M[i].lens_mode
+        for k in range(7):
+            rp.lens_params[k] = M[i].lens_params[k]
+        ev.append((images[i], rp))
+    return dict(images=images, M=M, X=X, n=n, aabb_scale=int(d.aabb_scale), eval=ev, eval_kind="TRAINING views (the capture has no test split)",
+                name=f"NeRF data/nerf/fox real capture ({n} JPEGs {M[0].resolution[0]}x{M[0].resolution[1]}, OpenCV lens, aabb_scale {int(d.aabb_scale)})", keep=t)
+
+
+def make_trainer(lib, scene, batch, rank=0, world=1):
+    cfg = A.base_model_config(scene["aabb_scale"])
+    model = C.c_void_p()
+    A.check(lib, lib.ngp_model_create(C.byref(cfg), C.c_uint64(1337), C.byref(model)))
+    opts = A.default_nerf_options(scene["aabb_scale"], target_batch_size=batch, rank=rank, world_size=world)
+    nerf = C.c_void_p()
+    A.check(lib, lib.ngp_nerf_create(model, C.byref(opts), A.scene_aabb(scene["aabb_scale"]), C.byref(nerf)))
+    A.check(lib, lib.ngp_nerf_set_dataset_device(nerf, scene["n"], scene["M"], scene["X"]))
+    return cfg, opts, model, nerf
+
+
+def get_stats(lib, nerf):
+    s = A.NerfStats()
+    A.check(lib, lib.ngp_nerf_get_stats(nerf, None, C.byref(s)))
+    return s
+
+
+def eval_psnr(lib, nerf, scene, spp=1):
+    """scripts/run.py:257-317: render the evaluation views (black background, snap_to_pixel_centers, min_transmittance 1e-4, EMA
+    weights, `spp` samples per pixel averaged in linear space), convert to sRGB, clip, PSNR against the view composited on black."""
+    if not scene["eval"]:
+        return None
+    mse = []
+    for gt, rp0 in scene["eval"]:
+        w, h = rp0.resolution[0], rp0.resolution[1]
+        frame = torch.zeros((w * h, 4), dtype=torch.float32, device="cuda")
+        acc = torch.zeros_like(frame)
+        rp = A.RenderParams(); C.memmove(C.byref(rp), C.byref(rp0), C.sizeof(A.RenderParams))
+        rp.snap_to_pixel_centers = 1; rp.min_transmittance = 1e-4; rp.near_distance = 0.0; rp.use_inference_params = 1
+        rp.render_aabb = A.scene_aabb(scene["aabb_scale"])
+        for s in range(max(spp, 1)):
+            rp.spp_index = s
+            A.check(lib, lib.ngp_nerf_render(nerf, None, C.byref(rp), C.c_void_p(frame.data_ptr()), None))
+            torch.cuda.synchronize()
+            acc += (frame - acc) / float(s + 1)  # accumulate_kernel: running mean over spp (render_buffer.cu:228-260)
+        lin = acc[:, :3].clamp(0, 1)
+        srgb = torch.where(lin < 0.0031308, 12.92 * lin, 1.055 * lin.clamp_min(1e-12) ** (1 / 2.4) - 0.055).clamp(0, 1)
+        g = gt.reshape(-1, 4).float() / 255.0
+        a = g[:, 3:4]
+        glin = torch.where(g[:, :3] <= 0.04045, g[:, :3] / 12.92, ((g[:, :3] + 0.055) / 1.055) ** 2.4) * a  # read_image + composite on black
+        gs = torch.where(glin < 0.0031308, 12.92 * glin, 1.055 * glin.clamp_min(1e-12) ** (1 / 2.4) - 0.055).clamp(0, 1)
+        mse.append(float(((srgb - gs) ** 2).mean()))
+    m = sum(mse) / len(mse)
+    return -10.0 * math.log10(m) if m > 0 else None
+
+
+def run_ab_psnr(lib, scene, args, steps):
+    """north_star parity proxy (the CUDA reference cannot run here): train the same scene / seed / ray stream with the production
+    path and with the reference-order path, evaluate PSNR at equal step counts with the run.py procedure."""
+    out = {"eval": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "steps": steps, "production": {}, "reference_order": {},
+           "reference_order_flags": REFERENCE_ORDER_FLAGS}
+    for name, flags in (("production", 0), ("reference_order", REFERENCE_ORDER_FLAGS)):
+        lib.ngp_debug_set_flags(flags)
+        try:
+            _, _, model, nerf = make_trainer(lib, scene, args.batch)
+            done = 0
+            t0 = time.perf_counter()
+            for target in steps:
+                A.check(lib, lib.ngp_nerf_train(nerf, None, target - done)); done = target
+                out[name][str(target)] = round(eval_psnr(lib, nerf, scene, args.eval_spp), 4)
+            out[name + "_wall_s"] = round(time.perf_counter() - t0, 2)
+            lib.ngp_nerf_destroy(nerf); lib.ngp_model_destroy(model)
+        finally:
+            lib.ngp_debug_set_flags(0)
+    out["delta_db"] = {k: round(out["production"][k] - out["reference_order"][k], 4) for k in out["production"]}
+    out["max_abs_delta_db"] = max(abs(v) for v in out["delta_db"].values())
+    return out
 
 
 def main():
@@ -44,14 +192,18 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pretrain", type=int, default=1000, help="untimed training steps that bring the occupancy grid to steady state")
+    ap.add_argument("--scene", choices=["synthetic", "fox"], default="synthetic")
     ap.add_argument("--images", type=int, default=100)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--batch", type=int, default=1 << 18)
     ap.add_argument("--profile-steps", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eval-views", type=int, default=4, help="held-out views rendered (untimed) for PSNR, run.py --test_transforms procedure")
+    ap.add_argument("--eval-views", type=int, default=4, help="views rendered (untimed) for PSNR, run.py --test_transforms procedure")
     ap.add_argument("--eval-res", type=int, default=400)
-    ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the held-out PSNR after the timed region (untimed), e.g. 5000,10000,35000")
+    ap.add_argument("--eval-spp", type=int, default=1)
+    ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the PSNR after the timed region (untimed), e.g. 5000,10000,35000")
+    ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
+    ap.add_argument("--dp-backend", choices=["auto", "rccl", "torch"], default="auto", help="N > 1: gradient / counter all-reduce inside libngp_hip (RCCL, ngp_comm_*) or through torch.distributed")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL's version block at init) go to stderr
@@ -61,9 +213,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("NGP_FORCE_DP", "0") == "1"  # exercise the multi-GPU step (all-reduce of size 1) on one GPU
+    if world > 1 or force_dp:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     else:
@@ -75,45 +228,41 @@ def main():
         lib.ngp_debug_set_flags(int(os.environ["NGP_DEBUG_FLAGS"], 0))
     assert lib.ngp_device_available() == 1
 
-    import synth_scene
-    images, xforms, meta, _ = synth_scene.make_dataset(args.images, args.res, "cuda")
-    n_img = len(images)
-    M = (A.ImageMeta * n_img)(); X = (A.Xform * n_img)()
-    for i in range(n_img):
-        M[i].pixels = images[i].data_ptr(); M[i].image_data_type = A.IMAGE_BYTE; M[i].lens_mode = A.LENS_PERSPECTIVE
-        M[i].resolution[0], M[i].resolution[1] = meta["resolution"]
-        M[i].principal_point[0] = M[i].principal_point[1] = 0.5
-        M[i].focal_length[0], M[i].focal_length[1] = meta["focal_length"]
-        for k in range(12):
-            X[i].start[k] = X[i].end[k] = float(xforms[i][k])
-
-    cfg = A.base_model_config(1)
-    model = C.c_void_p()
-    A.check(lib, lib.ngp_model_create(C.byref(cfg), C.c_uint64(1337), C.byref(model)))
-    opts = A.default_nerf_options(1, target_batch_size=args.batch, rank=rank, world_size=world)
-    nerf = C.c_void_p()
-    A.check(lib, lib.ngp_nerf_create(model, C.byref(opts), A.scene_aabb(1), C.byref(nerf)))
-    A.check(lib, lib.ngp_nerf_set_dataset_device(nerf, n_img, M, X))
+    scene = load_scene(args)
+    cfg, opts, model, nerf = make_trainer(lib, scene, args.batch, rank, world)
     n_params, n_mlp = C.c_uint64(), C.c_uint64()
     lib.ngp_model_n_params(model, C.byref(n_params), C.byref(n_mlp))
 
+    # ---- data-parallel step: inside the library over RCCL (ngp_comm_*), or through torch.distributed on zero-copy views -------------
+    dp = world > 1 or force_dp
+    dp_backend = None
     grad_view = cnt_view = None
-    force_dp = os.environ.get("NGP_FORCE_DP", "0") == "1"  # exercise the multi-GPU step (all-reduce of size 1) on one GPU
-    if force_dp and dist is None:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=0, world_size=1)
-    if world > 1 or force_dp:
-        g = C.c_void_p(); lib.ngp_model_param_ptrs(model, None, None, None, C.byref(g))
-        grad_view = torch.as_tensor(CudaView(g.value, n_params.value, "<f2"), device="cuda")
-        cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(nerf, C.byref(cp))
-        cnt_view = torch.as_tensor(CudaView(cp.value, 2, "<i4"), device="cuda")
+    if dp:
+        if args.dp_backend in ("auto", "rccl") and hasattr(lib, "ngp_comm_init"):
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_uint8 * 128)()
+                A.check(lib, lib.ngp_comm_unique_id(buf))
+                uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            uid = uid.cuda(); dist.broadcast(uid, 0); uid = uid.cpu()
+            rc = lib.ngp_comm_init(nerf, rank, world, (C.c_uint8 * 128)(*uid.tolist()))
+            ok = torch.tensor([1 if rc == 0 else 0], device="cuda"); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                dp_backend = "rccl-in-library"
+            elif args.dp_backend == "rccl":
+                raise RuntimeError("ngp_comm_init failed: " + lib.ngp_last_error().decode())
+        if dp_backend is None:
+            dp_backend = "torch.distributed"
+            g = C.c_void_p(); lib.ngp_model_param_ptrs(model, None, None, None, C.byref(g))
+            grad_view = torch.as_tensor(CudaView(g.value, n_params.value, "<f2"), device="cuda")
+            cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(nerf, C.byref(cp))
+            cnt_view = torch.as_tensor(CudaView(cp.value, 2, "<i4"), device="cuda")
 
-    host_s = {}  # multi-rank path: host-side enqueue time per call (to tell a host-bound loop from a device-bound one)
+    host_s = {}  # torch.distributed path: host-side enqueue time per call (to tell a host-bound loop from a device-bound one)
 
     def step(n=1):
-        if world == 1 and not force_dp:
-            A.check(lib, lib.ngp_nerf_train(nerf, None, n))
+        if not dp or dp_backend == "rccl-in-library":
+            A.check(lib, lib.ngp_nerf_train(nerf, None, n))  # multi-rank: the library all-reduces counters and gradient buckets itself
             return
         pc = time.perf_counter
         for _ in range(n):
@@ -133,11 +282,6 @@ def main():
                 host_s[k] = host_s.get(k, 0.0) + v
             host_s["steps"] = host_s.get("steps", 0) + 1
 
-    def stats():
-        s = A.NerfStats()
-        A.check(lib, lib.ngp_nerf_get_stats(nerf, None, C.byref(s)))
-        return s
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -147,7 +291,7 @@ def main():
     step(args.warmup)
     barrier()
     host_s.clear()
-    s0 = stats()
+    s0 = get_stats(lib, nerf)
     t0 = time.perf_counter()
     step(args.steps)
     host_ms = {k: round(1e3 * v / max(host_s.get("steps", 1), 1), 4) for k, v in host_s.items() if k != "steps"}  # snapshot of the timed region only
@@ -158,20 +302,19 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         dist.barrier()
-    s1 = stats()
+    s1 = get_stats(lib, nerf)
     rays = s1.total_rays - s0.total_rays                # global rays launched over the K steps (all ranks)
     samples = (s1.total_samples - s0.total_samples) * world
     value = rays / elapsed
 
     # ---- roofline leg: per-kernel HIP-event timing over further (untimed) steps --------------------------------
     lib.ngp_profile_enable(1)
-    s2 = stats()
     step(args.profile_steps)
     npf = lib.ngp_profile_count()
     ms = (C.c_double * npf)(); cnt = (C.c_uint64 * npf)()
     lib.ngp_profile_read(ms, cnt)
     lib.ngp_profile_enable(0)
-    s3 = stats()
+    s3 = get_stats(lib, nerf)
     lib.ngp_profile_name.restype = C.c_char_p
     kern = {lib.ngp_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(npf) if cnt[i]}
     n_inf_avg = s3.network_evaluations  # network evaluations of the last step's K2 (lazy K2: fewer than the marched samples)
@@ -182,52 +325,74 @@ def main():
         t1 = kern.pop("k_train_fwd_bwd"); gb = kern.pop("k_grad_bin+accumulate")
         kern["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = (t1[0] + gb[0], t1[1])
         per_launch_bytes["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = per_launch_bytes["k_train_fwd_bwd"]
+    kern_ms = {k: v[0] / args.profile_steps for k, v in kern.items()}
     dominant = max((k for k in kern if k in per_launch_bytes), key=lambda k: kern[k][0])
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    try:  # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[dominant]["bytes_per_launch"]
-    except Exception:
-        pass
+    traffic = traffic_src = None
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", fn)))[dominant]["bytes_per_launch"]
+            traffic_src = f"profiles/{fn} (separate rocprofv3 --pmc passes of this command; see the file for the correction applied)"
+            break
+        except Exception:
+            pass
+    ms_step = 1e3 * elapsed / args.steps
+    flop_step = FLOP_PER_SAMPLE_FWD * n_inf_avg + FLOP_PER_SAMPLE_TRAIN * args.batch
+    wg = kern.get("k_wgrad")
+    mfma = {"flop_per_step": int(flop_step), "achieved_tflops": round(flop_step / (ms_step * 1e-3) / 1e12, 2), "peak_tflops": MFMA_PEAK_TFLOPS,
+            "frac_of_2.5PF": round(flop_step / (ms_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "k_wgrad": ({"algorithmic_flop": int(FLOP_PER_SAMPLE_FWD * args.batch), "avg_launch_ms": round(wg[0] / wg[1], 4),
+                         "achieved_tflops": round(FLOP_PER_SAMPLE_FWD * args.batch / (wg[0] / wg[1] * 1e-3) / 1e12, 2),
+                         "frac_of_2.5PF": round(FLOP_PER_SAMPLE_FWD * args.batch / (wg[0] / wg[1] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)} if wg else None),
+            "note": "the path is gather / scatter bound: MFMA is a minor term (SURVEY 8d); counter-based MFMA busy fractions: profiles/r02_pmc_mfma*.txt"}
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw)",
-                "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
-                "kernel_ms_per_step": {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
+                "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}, "mfma": mfma}
 
-    psnr = eval_psnr(lib, nerf, args) if (rank == 0 and args.eval_views > 0) else None
+    psnr = eval_psnr(lib, nerf, scene, args.eval_spp) if (rank == 0 and args.eval_views > 0) else None
+    psnr_step = get_stats(lib, nerf).training_step
 
     # optional PSNR@step curve (BASELINE.json's second metric): keep training, untimed, and evaluate at the requested steps
     psnr_curve = {}
     if rank == 0 and world == 1 and args.psnr_steps:
         if psnr is not None:
-            psnr_curve[str(stats().training_step)] = round(psnr, 3)
+            psnr_curve[str(psnr_step)] = round(psnr, 3)
         for target in sorted(int(x) for x in args.psnr_steps.split(",") if x):
-            cur = stats().training_step
+            cur = get_stats(lib, nerf).training_step
             if target > cur:
                 step(target - cur)
-            psnr_curve[str(stats().training_step)] = round(eval_psnr(lib, nerf, args), 3)
+            psnr_curve[str(get_stats(lib, nerf).training_step)] = round(eval_psnr(lib, nerf, scene, args.eval_spp), 3)
 
-    # ---- CPU baseline: the oracle (port) runs ONE bounded step from the same trained state --------------------
+    # ---- CPU baseline: the oracle (port) runs bounded steps from the same trained state --------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(lib, model, nerf, cfg, opts, images, M, X, n_img, s3, args)
+        cpu_baseline = run_cpu_baseline(lib, model, nerf, cfg, scene, s3, args)
+
+    ab = None
+    if rank == 0 and world == 1 and args.ab_psnr:
+        ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x))
 
     if rank == 0:
+        lego = args.scene == "synthetic"
         out = {
-            "metric": "training rays/sec on nerf_synthetic/lego-format scene, configs/nerf/base.json, B=2^18 samples/step",
+            "metric": ("training rays/sec on nerf_synthetic/lego-format scene" if lego else "training rays/sec on data/nerf/fox") + ", configs/nerf/base.json, B=2^18 samples/step",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "NeRF nerf_synthetic/lego-format synthetic scene (100 views 800x800 RGBA8), configs/nerf/base.json (hash L=8 F=4 T=2^19, MLP 64), "
-                                   "batch 2^18 samples per GPU per step, rays/step adaptive (cap 2^18)", "parallelism": f"dp{world}",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic" if lego else "reference-shipped capture (data/nerf/fox)",
+            "config": {"workload": scene["name"] + ", configs/nerf/base.json (hash L=8 F=4 T=2^19, MLP 64), batch 2^18 samples per GPU per step, rays/step adaptive (cap 2^18)",
+                       "parallelism": f"dp{world}", **({"dp_backend": dp_backend} if dp_backend else {}),
                        "pretrain_steps": args.pretrain, "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
-                       "samples_per_ray_compacted": samples / max(rays, 1), "loss": s1.loss,
-                       "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
-                       "test_psnr_db": psnr, "test_psnr_at_step": (s3.training_step if psnr is not None else None),
+                       "samples_per_ray_compacted": samples / max(rays, 1),
+                       "ray_hit_fraction": s1.n_rays_last / max(s1.rays_per_batch, 1), "rays_hit_last_step": s1.n_rays_last, "rays_per_batch_last_step": s1.rays_per_batch,
+                       "marched_samples_last_step": s1.measured_batch_size_before_compaction, "network_evaluations_last_step": s1.network_evaluations,
+                       "loss": s1.loss, "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
+                       "test_psnr_db": psnr, "test_psnr_at_step": (psnr_step if psnr is not None else None),
+                       "test_psnr_views": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}",
                        **({"dp_host_enqueue_ms_per_step": host_ms} if host_ms else {}),
-                       **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {})},
+                       **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {}),
+                       **({"ab_psnr": ab} if ab else {})},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         result_out.write(json.dumps(out) + "\n")
@@ -236,58 +401,32 @@ def main():
         dist.destroy_process_group()
 
 
-def eval_psnr(lib, nerf, args):
-    """scripts/run.py:257-317: render held-out views (black background, snap_to_pixel_centers, min_transmittance 1e-4,
-    EMA weights), convert to sRGB, clip, PSNR against the ground-truth view composited on black."""
-    import synth_scene
-    res = args.eval_res
-    gts, xforms, meta, _ = synth_scene.make_dataset(args.eval_views, res, "cuda", phase=1.234)
-    mse = []
-    frame = torch.zeros((res * res, 4), dtype=torch.float32, device="cuda")
-    for gt, xf in zip(gts, xforms):
-        rp = A.RenderParams()
-        rp.resolution[0] = rp.resolution[1] = res
-        rp.focal_length[0], rp.focal_length[1] = meta["focal_length"]
-        rp.screen_center[0] = rp.screen_center[1] = 0.5
-        for k in range(12):
-            rp.camera[k] = float(xf[k])
-        rp.lens_mode = 0; rp.spp_index = 0; rp.snap_to_pixel_centers = 1; rp.min_transmittance = 1e-4; rp.near_distance = 0.0
-        rp.use_inference_params = 1
-        rp.render_aabb = A.scene_aabb(1)
-        A.check(lib, lib.ngp_nerf_render(nerf, None, C.byref(rp), C.c_void_p(frame.data_ptr()), None))
-        torch.cuda.synchronize()
-        lin = frame[:, :3].clamp(0, 1)
-        srgb = torch.where(lin < 0.0031308, 12.92 * lin, 1.055 * lin.clamp_min(1e-12) ** (1 / 2.4) - 0.055).clamp(0, 1)
-        g = gt.reshape(-1, 4).float() / 255.0                     # sRGB-encoded, premultiplied by a {0,1} alpha => over black
-        mse.append(float(((srgb - g[:, :3]) ** 2).mean()))
-    m = sum(mse) / len(mse)
-    return -10.0 * math.log10(m) if m > 0 else None
-
-
-def run_cpu_baseline(lib, model, nerf, cfg, opts, images, M, X, n_img, st, args):
+def run_cpu_baseline(lib, model, nerf, cfg, scene, st, args):
     """Time the CPU oracle (a port: the reference has no CPU path) on a bounded sample of the same workload:
-    one training step at B_cpu = 2^15 samples starting from the GPU's trained parameters and occupancy grid."""
+    training steps at B_cpu = 2^15 samples starting from the GPU's trained parameters and occupancy grid."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     from common import OraModel, ptr
     ora = oracle_py.load()
     B_cpu = 1 << 15
+    n_img, M, X = scene["n"], scene["M"], scene["X"]
     om = OraModel(ora, cfg)
     p = np.empty(om.n, dtype=np.float32)
     A.check(lib, lib.ngp_model_get_params_host(model, ptr(p), C.c_uint64(p.size)))
     om.params_fp[:] = p
     ora.ora_model_sync_half(om.h)
-    o2 = A.default_nerf_options(1, target_batch_size=B_cpu)
+    o2 = A.default_nerf_options(scene["aabb_scale"], target_batch_size=B_cpu)
     ot = C.c_void_p()
-    assert ora.ora_nerf_create(om.h, C.byref(o2), A.scene_aabb(1), C.byref(ot)) == 0
-    host_imgs = [im.cpu().numpy() for im in images]
+    assert ora.ora_nerf_create(om.h, C.byref(o2), A.scene_aabb(scene["aabb_scale"]), C.byref(ot)) == 0
+    host_imgs = [im.cpu().numpy() for im in scene["images"]]
     Mh = (A.ImageMeta * n_img)()
     for i in range(n_img):
         C.memmove(C.byref(Mh[i]), C.byref(M[i]), C.sizeof(A.ImageMeta))
         Mh[i].pixels = host_imgs[i].ctypes.data
     ora.ora_nerf_set_dataset(ot, n_img, Mh, X)
+    n_casc = int(o2.max_cascade) + 1
     gp = C.c_void_p(); lib.ngp_nerf_density_grid_ptrs(nerf, C.byref(gp), None, None)
-    grid = torch.as_tensor(CudaView(gp.value, 128 ** 3, "<f4"), device="cuda").cpu().numpy()
+    grid = torch.as_tensor(CudaView(gp.value, 128 ** 3 * n_casc, "<f4"), device="cuda").cpu().numpy()
     C.memmove(ora.ora_nerf_density_grid(ot), grid.ctypes.data, grid.nbytes)
     ora.ora_nerf_update_mean_and_bitfield(ot)
     rays_cpu = max(256, int(st.rays_per_batch * B_cpu / args.batch) // 256 * 256)

@@ -346,8 +346,14 @@ int ngp_nerf_scratch_ptrs(ngp_nerf*, uint32_t** ray_indices, ngp_ray** rays, uin
 int ngp_nerf_set_rays_per_batch(ngp_nerf*, uint32_t rays_per_batch);
 int ngp_nerf_get_rng(ngp_nerf*, ngp_pcg32* rng, ngp_pcg32* density_grid_rng);
 int ngp_nerf_set_rng(ngp_nerf*, const ngp_pcg32* rng);
+/* lazy (front-to-back) K2: number of rounds (2..8) and samples per tile (16 | 32); defaults 4 x 16 (csrc/model_kernels.hip k_inference_tiles) */
+int ngp_nerf_set_k2_params(ngp_nerf*, uint32_t rounds, uint32_t tile_w);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);
+/* layout of the hashed levels' binned gradient scatter (csrc/model_kernels.hip k_grad_bin / k_grad_accumulate): table entries per
+ * chunk = 2^chunk_log2 (11 or 12), one block per chunk (split = 0) or per (chunk, feature pair) (split = 1), list capacity override
+ * in records (0 = twice the mean; a small value forces the list-overflow path for the tests); process-wide */
+int ngp_debug_set_bin_params(uint32_t chunk_log2, uint32_t split, uint32_t cap_override);
 
 #ifdef __cplusplus
 }

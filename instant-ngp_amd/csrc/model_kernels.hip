@@ -391,27 +391,35 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 // threshold so that K3's own test can never walk into an unevaluated sample.  Same results as the eager order (DBG_K2_EAGER),
 // tests/test_gpu_train.py::test_lazy_k2_matches_eager.
 // ---------------------------------------------------------------------------------------------
+// TW = tile width in samples: 32 (one tile per wavefront) or 16 (two tiles of two different rays share the wavefront's 32 MFMA
+// columns -- rays end after ~12 compacted samples, so 16-wide tiles evaluate fewer samples behind the cut and fill the columns).
+template <uint32_t TW>
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	constexpr uint32_t TPW = 32u / TW; // tiles per wavefront
 	const uint32_t r = la.round;
 	const uint32_t n_tiles = min(r == 0 ? *la.n_rays_ptr : la.n_tiles_ptr[r], la.tile_cap);
-	if (blockIdx.x * 4 >= n_tiles) return; // uniform: late rounds are small
+	if (blockIdx.x * 4 * TPW >= n_tiles) return; // uniform: late rounds are small
 	h8* fw = (h8*)smem;
 	load_frags_to_lds(fw, mp.fw_frags, (int)N_FW_FRAGS);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t slot = (uint32_t)col / TW, tcol = (uint32_t)col % TW; // which of the wavefront's tiles, column inside it
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
 	const __half* table = (const __half*)mp.grid;
 	const uint4* __restrict__ tiles = la.tiles[r & 1u];
 	uint4* __restrict__ next = la.tiles[(r + 1u) & 1u];
 	const bool next_is_last = r + 2 == la.n_rounds;
-	uint32_t n_eval = 0; // lane 0: samples evaluated by this wavefront (statistics)
-	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-		const uint4 d = tiles[tile];
-		if (d.y == 0u) continue; // a ray K1 dropped at its sample cap: nothing to evaluate (its base may lie outside the buffers)
-		const bool valid = (uint32_t)col < d.y;
-		const uint32_t sample = d.x + (valid ? (uint32_t)col : 0u);
+	uint32_t n_eval = 0; // tile leaders: samples evaluated (statistics)
+	for (uint32_t wt = wave; wt * TPW < n_tiles; wt += n_waves) {
+		const uint32_t tile = wt * TPW + slot;
+		uint4 d = make_uint4(0u, 0u, 0u, 0u);
+		if (tile < n_tiles) d = tiles[tile];
+		// d.y == 0: a ray K1 dropped at its sample cap (its base may lie outside the buffers) or no tile in this slot: nothing to evaluate
+		const bool valid = tcol < d.y;
+		const uint32_t sample = valid ? d.x + tcol : 0u;
+		if (__ballot(valid) == 0ull) continue;
 		FwdState<1> st;
 		const float* p = in + (size_t)sample * in_stride;
 		encode_sample<false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
@@ -426,11 +434,12 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 			h4 rr = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)st.sigma[0]};
 			*(uint2*)(out + (size_t)sample * out_stride) = __builtin_bit_cast(uint2, rr);
 		}
-		n_eval += d.y;
+		const bool leader = hi == 0 && tcol == 0;
+		if (leader) n_eval += d.y;
 		// Transmittance behind this tile (an estimate with a safety margin: K3 recomputes the exact compositing).  A ray that is
 		// still transparent gets its next tile -- or, if the next round is the last one, all its remaining tiles -- appended to the
 		// next round's list: 1 % below K3's threshold, so K3's own test can never walk into an unevaluated sample; NaN stays alive.
-		if (d.w != 0u && r + 1 < la.n_rounds) {
+		if (r + 1 < la.n_rounds && __ballot(d.w != 0u) != 0ull) {
 			float od = 0.f; // optical depth of the lane's sample
 			if (hi == 0 && valid) {
 				const float x = st.sigma[0];
@@ -439,20 +448,20 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 				od = sg * (p[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
 			}
 #pragma unroll
-			for (int dd = 16; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64);
-			if (lane == 0) {
+			for (int dd = (int)TW / 2; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64); // sum over the tile's TW lanes (hi == 0 half)
+			if (leader && d.w != 0u) {
 				const float T = (r == 0 ? 1.f : la.T_run[d.z]) * __expf(-od);
 				if (!(T < 0.99e-4f)) {
 					la.T_run[d.z] = T;
-					const uint32_t rest = d.w, n = next_is_last ? rest : min(rest, 32u), nt = (n + 31u) / 32u;
+					const uint32_t rest = d.w, n = next_is_last ? rest : min(rest, TW), nt = (n + TW - 1u) / TW;
 					const uint32_t off = atomicAdd(la.n_tiles_ptr + r + 1, nt);
 					for (uint32_t j = 0; j < nt; ++j)
-						if (off + j < la.tile_cap) next[off + j] = make_uint4(d.x + 32u * (j + 1u), min(32u, n - 32u * j), d.z, rest - min(rest, 32u * (j + 1u)));
+						if (off + j < la.tile_cap) next[off + j] = make_uint4(d.x + TW * (j + 1u), min(TW, n - TW * j), d.z, rest - min(rest, TW * (j + 1u)));
 				}
 			}
 		}
 	}
-	if (lane == 0 && n_eval) atomicAdd(la.n_eval_ptr, n_eval);
+	if (hi == 0 && tcol == 0 && n_eval) atomicAdd(la.n_eval_ptr, n_eval);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -837,15 +846,17 @@ DEV LevelConst level_const_uniform(const GridMeta* __restrict__ gm, uint32_t lev
 	return lc;
 }
 
+template <uint32_t CL2>
 __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
-	__shared__ uint32_t s_cnt[GRAD_BIN_MAX_CHUNKS], s_start[GRAD_BIN_MAX_CHUNKS], s_gbase[GRAD_BIN_MAX_CHUNKS];
+	constexpr uint32_t NCH = (1u << GRAD_BIN_MAX_TABLE_LOG2) >> CL2; // most chunks a level can have (128 / 256)
+	__shared__ uint32_t s_cnt[NCH], s_start[NCH], s_gbase[NCH];
 	__shared__ uint32_t s_wsum[4];
 	__shared__ uint2 s_val[GRAD_BIN_SAMPLES * 8];
 	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * 8];
 	const uint32_t tid = threadIdx.x, ly = blockIdx.y, level = a.levels[ly];
 	const LevelConst lc = level_const_uniform(a.gm, level);
-	const uint32_t n_chunks = lc.hs >> GRAD_BIN_CHUNK_LOG2;
-	for (uint32_t c = tid; c < GRAD_BIN_MAX_CHUNKS; c += 256) s_cnt[c] = 0;
+	const uint32_t n_chunks = lc.hs >> CL2;
+	for (uint32_t c = tid; c < NCH; c += 256) s_cnt[c] = 0;
 	__syncthreads();
 	constexpr int SPT = GRAD_BIN_SAMPLES / 256; // samples per thread
 	uint32_t idx[SPT][8], rank[SPT][8];
@@ -867,46 +878,49 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 			const h4 v = {(_Float16)(g0 * w), (_Float16)(g1 * w), (_Float16)(g2 * w), (_Float16)(g3 * w)};
 			val[u][k] = __builtin_bit_cast(uint2, v);
 			idx[u][k] = cr.idx[k];
-			rank[u][k] = atomicAdd(&s_cnt[cr.idx[k] >> GRAD_BIN_CHUNK_LOG2], 1u);
+			rank[u][k] = atomicAdd(&s_cnt[cr.idx[k] >> CL2], 1u);
 		}
 	}
 	__syncthreads();
-	// exclusive prefix of the chunk counts (<= 128 chunks: two wavefronts) + slot reservation in the global lists
-	if (tid < GRAD_BIN_MAX_CHUNKS) {
-		const uint32_t cnt = tid < n_chunks ? s_cnt[tid] : 0u;
+	// exclusive prefix of the chunk counts (<= 256 chunks: one per thread) + slot reservation in the global lists
+	{
+		const uint32_t cnt = tid < n_chunks ? s_cnt[tid < NCH ? tid : 0u] : 0u;
 		uint32_t x = cnt;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if ((tid & 63u) >= (uint32_t)d) x += y; }
 		if ((tid & 63u) == 63u) s_wsum[tid >> 6] = x;
-		s_start[tid] = x - cnt;
-		s_gbase[tid] = cnt ? atomicAdd(&a.cursors[ly * GRAD_BIN_MAX_CHUNKS + tid], cnt) : 0u;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (uint32_t w = 0; w < (tid >> 6); ++w) woff += s_wsum[w];
+		if (tid < NCH) {
+			s_start[tid] = woff + x - cnt;
+			s_gbase[tid] = cnt ? atomicAdd(&a.cursors[ly * a.max_chunks + tid], cnt) : 0u;
+		}
 	}
-	__syncthreads();
-	if (tid >= 64 && tid < GRAD_BIN_MAX_CHUNKS) s_start[tid] += s_wsum[0];
 	__syncthreads();
 #pragma unroll
 	for (int u = 0; u < SPT; ++u) {
 		if (!valid[u]) continue;
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			const uint32_t c = idx[u][k] >> GRAD_BIN_CHUNK_LOG2;
+			const uint32_t c = idx[u][k] >> CL2;
 			const uint32_t pos = s_start[c] + rank[u][k];
 			s_val[pos] = val[u][k];
-			s_key[pos] = (c << 16) | (idx[u][k] & ((1u << GRAD_BIN_CHUNK_LOG2) - 1u));
+			s_key[pos] = (c << 16) | (idx[u][k] & ((1u << CL2) - 1u));
 		}
 	}
 	__syncthreads();
-	const uint32_t total = s_wsum[0] + s_wsum[1];
+	const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
 	for (uint32_t i = tid; i < total; i += 256) {
 		const uint32_t key = s_key[i], c = key >> 16, local = key & 0xffffu;
 		const uint32_t d = s_gbase[c] + (i - s_start[c]);
 		const uint2 v = s_val[i];
 		if (d < a.cap) {
-			const size_t o = ((size_t)ly * GRAD_BIN_MAX_CHUNKS + c) * a.cap + d;
+			const size_t o = ((size_t)ly * a.max_chunks + c) * a.cap + d;
 			a.vals[o] = v;
 			a.idxs[o] = (uint16_t)local;
 		} else { // list full: straight to the table (k_grad_accumulate adds its sums on top)
-			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + ((size_t)c << GRAD_BIN_CHUNK_LOG2) + local) * 4;
+			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + ((size_t)c << CL2) + local) * 4;
 			atomic_add_h2(dst, __builtin_bit_cast(h2, v.x));
 			atomic_add_h2(dst + 2, __builtin_bit_cast(h2, v.y));
 		}
@@ -919,45 +933,82 @@ DEV long long half_bits_to_fixed(uint32_t hbits) {
 	const long long mag = e ? (long long)(1024u + m) << (e - 1u) : (long long)m; // e == 31 (inf/nan) -> > 65504: converts back to inf
 	return (hbits & 0x8000u) ? -mag : mag;
 }
+// 64-bit FIXED-POINT accumulators (units of 2^-24): sums of halfs are exact, so the result does not depend on the order in
+// which the records arrive -- the hashed levels' gradients are bitwise reproducible -- and integer LDS atomics run at full
+// rate where ds_add_f32 / ds_pk_add_f16 do not (measured per step: 0.28 / 0.15 ms vs 0.04 ms for this kernel,
+// profiles/r01_microbench_ablation7_binning.log).
+//   SPLIT = false: one block = one chunk, all four features of an entry (2^CL2 x 4 x 8 B of LDS: 128 KiB at CL2 = 12, 64 KiB at 11):
+//                  every record byte is fetched once;
+//   SPLIT = true:  one block = one chunk x one feature pair (round-1 layout: half the LDS, but both blocks fetch every record).
+// The block also empties its list for the next step (no separate reset launch).
+template <uint32_t CL2, bool SPLIT>
 __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
-	// 64-bit FIXED-POINT accumulators (units of 2^-24): sums of halfs are exact, so the result does not depend on the
-	// order in which the records arrive -- the hashed levels' gradients are bitwise reproducible -- and integer LDS atomics
-	// run at full rate where ds_add_f32 / ds_pk_add_f16 do not (measured per step: 0.28 / 0.15 ms vs 0.04 ms for this kernel,
-	// profiles/r01_microbench_ablation7_binning.log).  One block = one chunk x one feature pair: 4096 x 2 x 8 B = 64 KiB.
-	constexpr uint32_t E = 1u << GRAD_BIN_CHUNK_LOG2;
-	__shared__ unsigned long long acc[E * 2];
-	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = blockIdx.z, level = a.levels[ly];
+	constexpr uint32_t E = 1u << CL2, NF = SPLIT ? 2u : 4u;
+	__shared__ unsigned long long acc[E * NF];
+	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = SPLIT ? blockIdx.z : 0u, level = a.levels[ly];
 	const uint32_t hs = a.gm->hashmap_size[level], offset = a.gm->offset[level];
-	if (c >= (hs >> GRAD_BIN_CHUNK_LOG2)) return;
-	const uint32_t n = min(a.cursors[ly * GRAD_BIN_MAX_CHUNKS + c], a.cap);
-	for (uint32_t i = tid; i < E * 2; i += 1024) acc[i] = 0ull;
-	__syncthreads();
-	const size_t base = ((size_t)ly * GRAD_BIN_MAX_CHUNKS + c) * a.cap;
-	const uint32_t* vals32 = (const uint32_t*)(a.vals + base) + fp; // this block's half2 of every 8-byte record
+	if (c >= (hs >> CL2)) return;
+	uint32_t* cursor = a.cursors + ly * a.max_chunks + c;
+	const uint32_t n = min(*cursor, a.cap);
+	for (uint32_t i = tid; i < E * NF; i += 1024) acc[i] = 0ull;
+	__syncthreads(); // every thread has read the cursor
+	if (tid == 0) { // the list is empty again for the next step; SPLIT: the second of the two blocks that share it does that
+		uint32_t* done = a.cursor_done + ly * a.max_chunks + c;
+		if (!SPLIT) *cursor = 0u;
+		else if (atomicAdd(done, 1u) == 1u) { *cursor = 0u; *done = 0u; }
+	}
+	const size_t base = ((size_t)ly * a.max_chunks + c) * a.cap;
 	const uint16_t* idxs = a.idxs + base;
 	constexpr int U = 8; // records per thread in flight
-	for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
-		uint32_t v[U], id[U];
+	if (SPLIT) {
+		const uint32_t* vals32 = (const uint32_t*)(a.vals + base) + fp; // this block's half2 of every 8-byte record
+		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+			uint32_t v[U], id[U];
 #pragma unroll
-		for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals32[(size_t)i * 2]; id[u] = idxs[i]; } }
+			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals32[(size_t)i * 2]; id[u] = idxs[i]; } }
 #pragma unroll
-		for (int u = 0; u < U; ++u) {
-			if (i0 + u * 1024 >= n) break;
-			atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u] & 0xffffu));
-			atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
+			for (int u = 0; u < U; ++u) {
+				if (i0 + u * 1024 >= n) break;
+				atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u] & 0xffffu));
+				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
+			}
+		}
+	} else {
+		const uint2* vals = a.vals + base;
+		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+			uint2 v[U]; uint32_t id[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals[i]; id[u] = idxs[i]; } }
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (i0 + u * 1024 >= n) break;
+				atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u].x & 0xffffu));
+				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u].x >> 16));
+				atomicAdd(&acc[2 * E + id[u]], (unsigned long long)half_bits_to_fixed(v[u].y & 0xffffu));
+				atomicAdd(&acc[3 * E + id[u]], (unsigned long long)half_bits_to_fixed(v[u].y >> 16));
+			}
 		}
 	}
 	__syncthreads();
-	h2* gt = (h2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << GRAD_BIN_CHUNK_LOG2)) * 4) + fp;
-	for (uint32_t e = tid; e < E; e += 1024) {
-		const h2 old = gt[(size_t)e * 2]; // zero unless a list overflowed
-		const float s0 = (float)(long long)acc[e] * 0x1p-24f, s1 = (float)(long long)acc[E + e] * 0x1p-24f;
-		const h2 r = {(_Float16)((float)old[0] + s0), (_Float16)((float)old[1] + s1)};
-		gt[(size_t)e * 2] = r;
+	if (SPLIT) {
+		h2* gt = (h2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << CL2)) * 4) + fp;
+		for (uint32_t e = tid; e < E; e += 1024) {
+			const h2 old = gt[(size_t)e * 2]; // zero unless a list overflowed
+			const float s0 = (float)(long long)acc[e] * 0x1p-24f, s1 = (float)(long long)acc[E + e] * 0x1p-24f;
+			const h2 r = {(_Float16)((float)old[0] + s0), (_Float16)((float)old[1] + s1)};
+			gt[(size_t)e * 2] = r;
+		}
+	} else {
+		uint2* gt = (uint2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << CL2)) * 4);
+		for (uint32_t e = tid; e < E; e += 1024) {
+			const h4 old = __builtin_bit_cast(h4, gt[e]); // zero unless a list overflowed
+			h4 r;
+#pragma unroll
+			for (int f = 0; f < 4; ++f) r[f] = (_Float16)((float)old[f] + (float)(long long)acc[f * E + e] * 0x1p-24f);
+			gt[e] = __builtin_bit_cast(uint2, r);
+		}
 	}
 }
-// lists are empty again for the next step
-__global__ void k_grad_bin_reset(uint32_t* cursors, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) cursors[i] = 0u; }
 
 // ---------------------------------------------------------------------------------------------
 // W: recompute forward + dgrad in chain AND swapped form, accumulate all weight gradients in registers.
@@ -1288,10 +1339,12 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 		ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la_in) {
 	if (max_rays == 0) return;
 	K2LazyArgs la = la_in;
-	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap + 3) / 4, (uint64_t)num_cus() * 3);
+	const uint32_t tpw = 32u / la.tile_w;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
-		hipLaunchKernelGGL(k_inference_tiles, dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
+		if (la.tile_w == 16) hipLaunchKernelGGL((k_inference_tiles<16>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
+		else hipLaunchKernelGGL((k_inference_tiles<32>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
 	}
 	(void)max_samples;
 }
@@ -1316,9 +1369,16 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	if (a.n == 0 || a.n_hashed == 0) return;
-	hipLaunchKernelGGL(k_grad_bin, dim3((a.n + GRAD_BIN_SAMPLES - 1) / GRAD_BIN_SAMPLES, a.n_hashed), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(k_grad_accumulate, dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
-	hipLaunchKernelGGL(k_grad_bin_reset, dim3((a.n_hashed * GRAD_BIN_MAX_CHUNKS + 255) / 256), dim3(256), 0, s, a.cursors, a.n_hashed * GRAD_BIN_MAX_CHUNKS);
+	const dim3 gb((a.n + GRAD_BIN_SAMPLES - 1) / GRAD_BIN_SAMPLES, a.n_hashed);
+	if (a.chunk_log2 == 11) {
+		hipLaunchKernelGGL((k_grad_bin<11>), gb, dim3(256), 0, s, a);
+		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
+		else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+	} else {
+		hipLaunchKernelGGL((k_grad_bin<12>), gb, dim3(256), 0, s, a);
+		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
+		else hipLaunchKernelGGL((k_grad_accumulate<12, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+	}
 }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
 		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap) {

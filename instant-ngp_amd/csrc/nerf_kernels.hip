@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 		a.numsteps_out[slot * 2 + 1] = base;
 		if (a.k2_tiles0_out) { // lazy K2, round 0: the first 32 samples of this ray (dropped rays: an empty tile)
 			const uint32_t c0 = fits ? count : 0u;
-			a.k2_tiles0_out[slot] = make_uint4(base, min(c0, 32u), slot, c0 - min(c0, 32u));
+			a.k2_tiles0_out[slot] = make_uint4(base, min(c0, a.k2_tile_w), slot, c0 - min(c0, a.k2_tile_w));
 		}
 		if (a.ray_targets_out) {
 			float4* tg = (float4*)(a.ray_targets_out + (size_t)slot * 8);
@@ -905,7 +905,7 @@ __global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size, 
 	c->max_inference = mb == 0 ? max_samples : ((min(mb, max_samples) + 255u) / 256u) * 256u;
 	if (mb == 0) c->measured_batch_size_before_compaction = max_samples;
 	c->numsteps_counter = 0; c->numsteps_counter_compacted = 0; c->ray_counter = 0; c->loss_sum = 0.f;
-	c->n_valid_compacted = 0; for (int r = 0; r < 4; ++r) c->k2_tiles[r] = 0; c->k2_samples_last = c->k2_samples; c->k2_samples = 0;
+	c->n_valid_compacted = 0; for (int r = 0; r < 8; ++r) c->k2_tiles[r] = 0; c->k2_samples_last = c->k2_samples; c->k2_samples = 0;
 }
 // clamp the compacted counter to B for K4 / statistics (the reference relies on fill_rollover's guard)
 __global__ void k_clamp_compacted(TrainCounters* c, uint32_t target_batch_size) {

@@ -67,6 +67,16 @@ extern "C" int ngp_profile_enable(int on) {
 	return 0;
 }
 extern "C" int ngp_debug_set_flags(uint32_t flags) { g_debug_flags = flags; return 0; }
+// layout of the hashed levels' binned scatter (tuning / test hook): table entries per chunk (2^11 or 2^12), one block per chunk
+// (split = 0) or per (chunk, feature pair) (split = 1), and a list-capacity override (0 = twice the mean; small values force the
+// overflow path of k_grad_bin).  NGP_BIN_CHUNK_LOG2 / NGP_BIN_SPLIT / NGP_BIN_CAP in the environment set the defaults.
+static uint32_t env_u32(const char* name, uint32_t dflt) { const char* e = getenv(name); return e ? (uint32_t)strtoul(e, nullptr, 0) : dflt; }
+static uint32_t g_bin_chunk_log2 = env_u32("NGP_BIN_CHUNK_LOG2", 12) == 11 ? 11 : 12, g_bin_split = env_u32("NGP_BIN_SPLIT", 0) ? 1 : 0, g_bin_cap_override = env_u32("NGP_BIN_CAP", 0);
+extern "C" int ngp_debug_set_bin_params(uint32_t chunk_log2, uint32_t split, uint32_t cap_override) {
+	if (chunk_log2 != 11 && chunk_log2 != 12) { g_err = "ngp_debug_set_bin_params: chunk_log2 must be 11 or 12"; return 1; }
+	g_bin_chunk_log2 = chunk_log2; g_bin_split = split ? 1 : 0; g_bin_cap_override = cap_override;
+	return 0;
+}
 extern "C" int ngp_profile_count(void) { return P_COUNT; }
 extern "C" const char* ngp_profile_name(int i) { return (i >= 0 && i < P_COUNT) ? kProfNames[i] : ""; }
 extern "C" int ngp_profile_read(double* ms_sum, uint64_t* launches) {
@@ -146,7 +156,7 @@ struct ngp_model {
 	ngp_half* enc_stash = nullptr; size_t stash_halfs = 0;
 	float* wgrad_partials = nullptr; uint32_t n_partials = 0;
 	// binned scatter of the hashed levels: dL/d(enc) level-major, per-chunk record lists, list cursors
-	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0;
+	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0, bin_lists = 0;
 	GradBinArgs bin_args{};
 	// W (weight gradients, compute bound, 1 wave/SIMD) runs on a side stream next to the hashed levels' bin/accumulate kernels (memory/LDS bound)
 	hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -342,33 +352,36 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		if (dev_alloc(&m->enc_stash, need)) return 1;
 		m->stash_halfs = need;
 	}
-	// binned scatter: every hashed level must have a power-of-two table of 2^12 .. 2^19 entries (base.json: 2^19)
+	// binned scatter: every hashed level must have a power-of-two table of 2^chunk_log2 .. 2^19 entries (base.json: 2^19)
 	GradBinArgs& ba = m->bin_args;
-	ba.n_hashed = 0; ba.max_chunks = 0;
+	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split;
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
 			const uint64_t res = m->gm.resolution[l], hs = m->gm.hashmap_size[l];
 			if (res * res * res <= hs) continue;
-			if ((hs & (hs - 1)) || hs < (1u << GRAD_BIN_CHUNK_LOG2) || (hs >> GRAD_BIN_CHUNK_LOG2) > GRAD_BIN_MAX_CHUNKS) { ok = false; break; }
+			if ((hs & (hs - 1)) || hs < (1u << ba.chunk_log2) || hs > (1u << GRAD_BIN_MAX_TABLE_LOG2)) { ok = false; break; }
 			ba.levels[ba.n_hashed++] = l;
-			ba.max_chunks = std::max<uint32_t>(ba.max_chunks, (uint32_t)(hs >> GRAD_BIN_CHUNK_LOG2));
+			ba.max_chunks = std::max<uint32_t>(ba.max_chunks, (uint32_t)(hs >> ba.chunk_log2));
 		}
 		if (!ok) ba.n_hashed = 0;
 	}
-	if (ba.n_hashed && n > m->bin_n) {
+	// lists: n_hashed x max_chunks of `cap` records (8-byte values + 2-byte local indices); capacity = twice the mean number of
+	// records per chunk.  Re-allocated when the batch grows or the layout (chunk size, capacity override) changes.
+	const uint32_t cap_want = !ba.n_hashed ? 0u : g_bin_cap_override ? g_bin_cap_override
+		: std::max<uint32_t>(2048u, (uint32_t)((((uint64_t)n * 8 * 2) / ba.max_chunks + 1023) / 1024 * 1024));
+	if (ba.n_hashed && (n > m->bin_n || cap_want != m->bin_cap || ba.n_hashed * ba.max_chunks != m->bin_lists)) {
 		HIPCHK(hipStreamSynchronize(s));
 		for (void* p : {m->denc_lv, m->bin_vals, m->bin_idxs, (void*)m->bin_cursors}) if (p) HIPCHK(hipFree(p));
+		const uint32_t n_alloc = std::max(n, m->bin_n);
 		m->denc_lv = m->bin_vals = m->bin_idxs = nullptr; m->bin_cursors = nullptr; m->bin_n = 0;
-		// list capacity: twice the mean number of records per chunk of the SMALLEST chunk count that can occur (>= 1 chunk)
-		const uint32_t cap = std::max<uint32_t>(8192u, (uint32_t)((((uint64_t)n * 8 * 2) / ba.max_chunks + 1023) / 1024 * 1024));
-		const size_t n_lists = (size_t)MAX_LEVELS * GRAD_BIN_MAX_CHUNKS;
-		HIPCHK(hipMalloc(&m->denc_lv, (size_t)MAX_LEVELS * n * 8));
-		HIPCHK(hipMalloc(&m->bin_vals, n_lists * cap * 8));
-		HIPCHK(hipMalloc(&m->bin_idxs, n_lists * cap * 2));
-		HIPCHK(hipMalloc((void**)&m->bin_cursors, n_lists * 4));
-		HIPCHK(hipMemsetAsync(m->bin_cursors, 0, n_lists * 4, s));
-		m->bin_n = n; m->bin_cap = cap;
+		const size_t n_lists = (size_t)ba.n_hashed * ba.max_chunks;
+		HIPCHK(hipMalloc(&m->denc_lv, (size_t)m->gm.n_levels * n_alloc * 8));
+		HIPCHK(hipMalloc(&m->bin_vals, n_lists * cap_want * 8));
+		HIPCHK(hipMalloc(&m->bin_idxs, n_lists * cap_want * 2));
+		HIPCHK(hipMalloc((void**)&m->bin_cursors, n_lists * 2 * 4)); // cursors + the split variant's arrival counters
+		HIPCHK(hipMemsetAsync(m->bin_cursors, 0, n_lists * 2 * 4, s));
+		m->bin_n = n_alloc; m->bin_cap = cap_want; m->bin_lists = (uint32_t)n_lists;
 	}
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
 	{ ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
@@ -387,7 +400,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	if (ba.n_hashed) {
 		ProfScope ps(P_GRAD_BIN, s);
 		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = (const uint2*)m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap;
-		ba.vals = (uint2*)m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.grid_grad_ = m->grads + m->n_mlp;
+		ba.vals = (uint2*)m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
 		launch_grad_bin(s, ba);
 	}
 	if (overlap) { HIPCHK(hipEventRecord(m->ev_join, sw)); HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0)); }
@@ -571,7 +584,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 		const uint8_t* bitfield, uint32_t max_mip, int snap_to_pixel_centers, float cone_angle_constant) {
 	REQUIRE(world_size >= 1 && rank < world_size, "generate_training_samples: bad rank/world_size");
 	K1Args a;
-	a.k2_tiles0_out = nullptr; a.ray_targets_out = nullptr; a.background_color[0] = a.background_color[1] = a.background_color[2] = 0.f; a.color_space_srgb = a.random_bg_color = a.linear_colors = 0;
+	a.k2_tiles0_out = nullptr; a.k2_tile_w = 32; a.ray_targets_out = nullptr; a.background_color[0] = a.background_color[1] = a.background_color[2] = 0.f; a.color_space_srgb = a.random_bg_color = a.linear_colors = 0;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.rank = rank; a.world_size = world_size; a.aabb = aabb; a.max_samples = max_samples;
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
@@ -678,7 +691,7 @@ struct ngp_nerf {
 	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
 	bool ctl_done = false; // the batch-size controller of the current step has run
 	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
-	uint32_t k2_rounds = 3; // measured best of 2..4 (0.168 / 0.178 / 0.180 ms for 3 / 4 / 2 rounds); NGP_K2_ROUNDS=2..4 overrides (tuning knob; round 0 is always the first 32 samples of every ray)
+	uint32_t k2_rounds = 4, k2_tile_w = 16; // NGP_K2_ROUNDS=2..8 / NGP_K2_TILE=16|32 override (tuning knobs; round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest)
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
@@ -704,11 +717,12 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
 	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 2), K2_ROUNDS);
+	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : 16u;
 	t->grid_sample_cap = n_cells;
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
-		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 32 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
@@ -731,8 +745,9 @@ static void invalidate_k1(ngp_nerf* t) {
 	++t->state_version;
 }
 extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
-	if (t) invalidate_k1(t);
 	REQUIRE(t && o, "set_options: null argument");
+	if (memcmp(&t->opt, o, sizeof(*o)) == 0) return 0; // nothing changes: a pre-launched K1 of the next step stays valid (Testbed pushes its options every frame)
+	invalidate_k1(t);
 	REQUIRE(o->target_batch_size == t->opt.target_batch_size && o->rank == t->opt.rank && o->world_size == t->opt.world_size && o->max_cascade == t->opt.max_cascade,
 		"set_options: batch size, max_cascade and sharding are fixed at creation");
 	t->opt = *o;
@@ -857,7 +872,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.bitfield_linear = t->bitfield_linear; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr;
+		k1.bitfield_linear = t->bitfield_linear; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
@@ -885,7 +900,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	  if (lazy_k2) {
 		K2LazyArgs la;
 		la.n_rays_ptr = &c->ray_counter; la.tiles[0] = t->k2_tiles; la.tiles[1] = t->k2_tiles + t->k2_tile_cap; la.tile_cap = t->k2_tile_cap;
-		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_rounds = t->k2_rounds; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
+		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_rounds = t->k2_rounds; la.tile_w = t->k2_tile_w; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
 		{ const float max_stepsize = MIN_CONE_STEP * (float)(1 << (N_CASCADES - 1)); la.dt_unwarp_scale = max_stepsize - MIN_CONE_STEP; la.dt_unwarp_offset = MIN_CONE_STEP; } // unwarp_dt
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la);
 	  } else
@@ -1009,6 +1024,13 @@ extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
 	invalidate_k1(t);
 	t->training_step = step; t->prep_skip_counter = step; t->ema_step = step;
 	HIPCHK(hipMemcpy(&t->counters->training_step, &step, 4, hipMemcpyHostToDevice));
+	return 0;
+}
+// lazy K2 tuning knobs (test / ablation hook): number of front-to-back rounds (2..8) and samples per tile (16 | 32)
+extern "C" int ngp_nerf_set_k2_params(ngp_nerf* t, uint32_t rounds, uint32_t tile_w) {
+	REQUIRE(rounds >= 2 && rounds <= K2_ROUNDS && (tile_w == 16 || tile_w == 32), "set_k2_params: rounds in 2..8, tile width 16 or 32");
+	invalidate_k1(t); // a pre-launched K1 wrote its round-0 tiles with the old width
+	t->k2_rounds = rounds; t->k2_tile_w = tile_w;
 	return 0;
 }
 extern "C" int ngp_nerf_set_rng(ngp_nerf* t, const ngp_pcg32* rng) { invalidate_k1(t); t->rng.state = rng->state; t->rng.inc = rng->inc; return 0; }

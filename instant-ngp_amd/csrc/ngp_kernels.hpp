@@ -29,7 +29,7 @@ struct TrainCounters {
 	uint32_t ema_step;                              // density_grid_ema_step
 	uint64_t total_rays;
 	uint64_t total_samples;
-	uint32_t k2_tiles[4];                           // lazy K2: number of 32-sample tiles of rounds 1..3 ([0] unused: round 0 = one tile per active ray)
+	uint32_t k2_tiles[8];                           // lazy K2: number of tiles of rounds 1..7 ([0] unused: round 0 = one tile per active ray)
 	uint32_t k2_samples, k2_samples_last;           // network evaluations performed by K2 in this / the previous step (statistics)
 };
 
@@ -44,7 +44,7 @@ struct K1Args {
 	uint32_t n_images; const ngp_image_meta* metadata; const ngp_xform* xforms;
 	const uint8_t* bitfield; uint32_t max_mip;
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
-	uint4* k2_tiles0_out;           // optional: round-0 tile list of the lazy K2 (one descriptor per active ray)
+	uint4* k2_tiles0_out; uint32_t k2_tile_w; // optional: round-0 tile list of the lazy K2 (one descriptor per active ray: its first k2_tile_w samples)
 	int snap_to_pixel_centers; float cone_angle_constant;
 	int exact_skip; // lattice K1: follow the reference's skip rule (advance_to_next_voxel) over the lattice instead of testing every point on its own
 	// optional (lattice K1 only): per-ray training target {rgbtarget[3], background[3], 0, 0} for K3, computed by the thread-per-ray
@@ -114,7 +114,7 @@ struct ModelPtrs {
 // [32r, 32r+32) of the rays that are still transparent after round r-1; the last round takes everything that is left.
 // Tile descriptor = {first sample, valid lanes, ray, samples of the ray behind this tile}.  Round 0's list is written by K1
 // (one tile per active ray, tile index = ray slot); a tile of round r appends its ray's next tile(s) to round r+1's list.
-constexpr uint32_t K2_ROUNDS = 4; // maximum / default number of rounds
+constexpr uint32_t K2_ROUNDS = 8; // maximum number of rounds
 struct K2LazyArgs {
 	const uint32_t* n_rays_ptr;     // active rays (K1's ray counter) = number of round-0 tiles
 	uint4* tiles[2]; uint32_t tile_cap; // ping-pong lists: round r reads tiles[r & 1] and appends to tiles[(r + 1) & 1]
@@ -122,6 +122,7 @@ struct K2LazyArgs {
 	float* T_run;                   // per active ray: transmittance behind the evaluated samples
 	int density_activation; float dt_unwarp_scale, dt_unwarp_offset; // dt = warped * scale + offset (unwarp_dt)
 	uint32_t round, n_rounds;
+	uint32_t tile_w;                // samples per tile: 16 (two rays' tiles per wavefront) or 32
 };
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
 	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la);
@@ -135,14 +136,16 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 uint32_t wgrad_n_partials();
 
 // binned scatter of the hashed levels (model_kernels.hip)
-constexpr uint32_t GRAD_BIN_CHUNK_LOG2 = 12;   // 4096 table entries per chunk (64 KiB fp32 LDS accumulator)
-constexpr uint32_t GRAD_BIN_MAX_CHUNKS = 128;  // hashmap sizes up to 2^19
-constexpr uint32_t GRAD_BIN_SAMPLES = 512;     // samples per k_grad_bin block
+constexpr uint32_t GRAD_BIN_MAX_TABLE_LOG2 = 19; // hashmap sizes up to 2^19 (2^12 .. 2^19)
+constexpr uint32_t GRAD_BIN_SAMPLES = 512;       // samples per k_grad_bin block
+// chunk_log2: table entries per chunk (2^12: 128 KiB of 64-bit accumulators for the four features of an entry, one block per CU;
+// 2^11: 64 KiB, two blocks per CU).  split: round-1 layout, one block per (chunk, feature pair) -- both blocks fetch every record.
 struct GradBinArgs {
 	const GridMeta* gm; const float* in; uint32_t in_stride, n;
 	const uint2* denc_lv; uint32_t denc_cap;
 	uint32_t levels[MAX_LEVELS]; uint32_t n_hashed, max_chunks, cap;
-	uint2* vals; uint16_t* idxs; uint32_t* cursors; ngp_half* grid_grad_;
+	uint32_t chunk_log2, split;
+	uint2* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
 };
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,

@@ -198,3 +198,78 @@ def test_optimizer_step_parity(ora, hip):
         # keep both models identical for the next iteration
         hm.set_params(ref.copy()) if False else None
     assert hip.ngp_model_step(hm.h) == 3
+
+
+def _captured_batch(hip, B, steps):
+    """one compacted training batch of the NeRF trainer (K1-marched, K3-compacted, K4-padded coordinates and loss gradients) and the
+    trained parameters it was computed with"""
+    import torch
+    from common import host_meta, make_small_dataset
+    imgs, xforms, meta = make_small_dataset(12, 96)
+    M, X = host_meta(imgs, xforms, meta)
+    cfg = A.base_model_config(1)
+    hm = HipModel(hip, cfg)
+    t = C.c_void_p()
+    opts = A.default_nerf_options(1, target_batch_size=B)
+    A.check(hip, hip.ngp_nerf_create(hm.h, C.byref(opts), A.scene_aabb(1), C.byref(t)))
+    pix = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+    A.check(hip, hip.ngp_nerf_set_dataset_host(t, len(imgs), M, X, pix))
+    A.check(hip, hip.ngp_nerf_train(t, None, steps))
+    A.check(hip, hip.ngp_nerf_train_prep(t, None))
+    A.check(hip, hip.ngp_nerf_train_forward(t, None))  # K1..K4: the batch of step `steps`, not yet consumed
+    torch.cuda.synchronize()
+    ri, rays, ns, co, mo, cc, dl, cnt = (C.c_void_p() for _ in range(8))
+    A.check(hip, hip.ngp_nerf_scratch_ptrs(t, C.byref(ri), C.byref(rays), C.byref(ns), C.byref(co), C.byref(mo), C.byref(cc), C.byref(dl), C.byref(cnt)))
+    coords = np.empty((B, 7), np.float32); dloss = np.empty((B, 4), np.uint16)
+    rt = C.CDLL("libamdhip64.so")
+    assert rt.hipMemcpy(ptr(coords), cc, C.c_size_t(coords.nbytes), 2) == 0 and rt.hipMemcpy(ptr(dloss), dl, C.c_size_t(dloss.nbytes), 2) == 0
+    params = np.empty(hm.n, np.float32)
+    A.check(hip, hip.ngp_model_get_params_host(hm.h, ptr(params), C.c_uint64(params.size)))
+    st = A.NerfStats(); A.check(hip, hip.ngp_nerf_get_stats(t, None, C.byref(st)))
+    hip.ngp_nerf_destroy(t)
+    return cfg, hm, params, coords, dloss, st
+
+
+def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
+    """Gradient parity at the benchmark's batch size (B = 2^18 samples) on a batch captured from the NeRF trainer: HIP vs oracle per
+    parameter block, for every layout of the hashed levels' binned scatter (chunk 2^11 / 2^12, one block per chunk or per (chunk,
+    feature pair)), with the list capacity forced small (the overflow path: most records then take global atomics), and for the
+    atomics-only path.  The binned layouts sum the same multiset of half contributions exactly => bit-identical among themselves."""
+    import torch
+    B = 1 << 18
+    cfg, hm, params, coords, dloss, st = _captured_batch(hip, B, 48)
+    assert st.measured_batch_size > 0 and np.isfinite(coords).all()
+    om = OraModel(ora, cfg)
+    om.params_fp[:] = params
+    ora.ora_model_sync_half(om.h)
+    om.training_step(coords, dloss)
+    gref = half_to_f32(om.grads.copy())
+    cd = torch.from_numpy(coords).cuda(); dld = torch.from_numpy(dloss.view(np.int16)).cuda()
+    offs = (C.c_uint32 * 9)(); res = (C.c_uint32 * 8)(); sc = (C.c_float * 8)()
+    hip.ngp_model_grid_layout(hm.h, offs, res, sc)
+    blocks = {"density_l1": (0, 2048), "density_l2": (2048, 3072), "rgb_l1": (3072, 5120), "rgb_l2": (5120, 9216), "rgb_l3": (9216, 9216 + 3 * 64)}
+    for l in range(8):
+        blocks[f"grid_level_{l}"] = (10240 + offs[l] * 4, 10240 + offs[l + 1] * 4)
+    hashed = [l for l in range(8) if int(res[l]) ** 3 > offs[l + 1] - offs[l]]
+    variants = [("chunk12", 12, 0, 0, 0), ("chunk12_split", 12, 1, 0, 0), ("chunk11", 11, 0, 0, 0), ("chunk11_split", 11, 1, 0, 0),
+                ("chunk12_overflow", 12, 0, 2048, 0), ("chunk11_split_overflow", 11, 1, 1024, 0), ("atomics_only", 12, 0, 0, 2048)]
+    got = {}
+    try:
+        for name, cl2, split, cap, flags in variants:
+            A.check(hip, hip.ngp_debug_set_bin_params(cl2, split, cap)); hip.ngp_debug_set_flags(flags)
+            A.check(hip, hip.ngp_model_training_step(hm.h, None, dptr(cd), 7, B, dptr(dld), 4))
+            torch.cuda.synchronize()
+            g = hm.read("grads", torch).copy()
+            got[name] = g
+            gf = half_to_f32(g)
+            report = {k: _rel_l2(gf[a:b], gref[a:b]) for k, (a, b) in blocks.items()}
+            print(name, {k: f"{v:.2e}" for k, v in report.items()})
+            assert np.isfinite(gf).all()
+            for k, v in report.items():
+                assert v < (2e-2 if not k.startswith("grid") else 5e-2), (name, k, v)
+    finally:
+        A.check(hip, hip.ngp_debug_set_bin_params(12, 0, 0)); hip.ngp_debug_set_flags(0)
+    for l in hashed:
+        lo, hi_ = blocks[f"grid_level_{l}"]
+        for name in ("chunk12_split", "chunk11", "chunk11_split"):
+            assert np.array_equal(got["chunk12"][lo:hi_], got[name][lo:hi_]), (name, l)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Ablation micro-benchmark (GPU box): per-kernel HIP-event timings of the training step under debug switches."""
+"""Ablation micro-benchmark (GPU box): per-kernel HIP-event timings of the training step under debug switches and layout knobs.
+usage: microbench.py [pretrain] [steps] [comma separated variant names]"""
 import ctypes as C
 import json
 import os
@@ -10,6 +11,23 @@ sys.path[:0] = [os.path.join(ROOT, "instant-ngp_amd"), os.path.join(ROOT, "tests
 import torch
 import ngp_abi as A
 import synth_scene
+
+# name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
+VARIANTS = [
+    ("default", 0, (12, 0, 0), (4, 16)),
+    ("bin_chunk12_split", 0, (12, 1, 0), (4, 16)),   # round-1 layout
+    ("bin_chunk11", 0, (11, 0, 0), (4, 16)),
+    ("bin_chunk11_split", 0, (11, 1, 0), (4, 16)),
+    ("k2_tile32_r3", 0, (12, 0, 0), (3, 32)),         # round-1 K2
+    ("k2_tile16_r3", 0, (12, 0, 0), (3, 16)),
+    ("k2_tile16_r5", 0, (12, 0, 0), (5, 16)),
+    ("k2_tile16_r6", 0, (12, 0, 0), (6, 16)),
+    ("k2_eager", 8192, (12, 0, 0), (4, 16)),
+    ("k1_independent_lattice", 16384, (12, 0, 0), (4, 16)),
+    ("default_again", 0, (12, 0, 0), (4, 16)),
+    ("t1_no_binning", 2048, (12, 0, 0), (4, 16)),
+    ("t1_no_scatter", 2, (12, 0, 0), (4, 16)),
+]
 
 
 def main():
@@ -33,23 +51,34 @@ def main():
     A.check(lib, lib.ngp_nerf_train(nerf, None, pretrain))
     lib.ngp_profile_name.restype = C.c_char_p
     npf = lib.ngp_profile_count()
-    variants = [("t1_no_binning", 2048), ("default", 0), ("t1_occ2", 1024), ("default_again", 0), ("t1_occ2_again", 1024), ("fwd_pair_loads", 256), ("fwd_occ4", 512), ("t1_no_quads", 128), ("t1_no_pair_halves", 64), ("k3_thread_per_ray", 32), ("t1_no_merge", 16), ("t1_no_scatter", 2)]
+    variants = VARIANTS
     if len(sys.argv) > 3:
         keep = sys.argv[3].split(",")
         variants = [v for v in variants if v[0] in keep]
-    res = {}
-    for name, flags in variants:
+    for name, flags, (cl2, split, cap), (rounds, tw) in variants:
         lib.ngp_debug_set_flags(flags)
+        A.check(lib, lib.ngp_debug_set_bin_params(cl2, split, cap))
+        A.check(lib, lib.ngp_nerf_set_k2_params(nerf, rounds, tw))
         A.check(lib, lib.ngp_nerf_train(nerf, None, 4))
+        # (a) un-profiled wall time per step (helper streams on), (b) per-kernel HIP-event times (everything on one stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        import time
+        t0 = time.perf_counter()
+        A.check(lib, lib.ngp_nerf_train(nerf, None, nsteps))
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / nsteps * 1e3
         lib.ngp_profile_enable(1)
         A.check(lib, lib.ngp_nerf_train(nerf, None, nsteps))
         ms = (C.c_double * npf)(); cnt = (C.c_uint64 * npf)()
         lib.ngp_profile_read(ms, cnt); lib.ngp_profile_enable(0)
         s = A.NerfStats(); lib.ngp_nerf_get_stats(nerf, None, C.byref(s))
-        res[name] = {lib.ngp_profile_name(i).decode(): round(ms[i] / nsteps, 4) for i in range(npf) if cnt[i]}
-        res[name]["_rays_per_batch"] = s.rays_per_batch; res[name]["_before"] = s.measured_batch_size_before_compaction; res[name]["_loss"] = s.loss
-        print(name, json.dumps(res[name]), flush=True)
-    lib.ngp_debug_set_flags(0)
+        r = {lib.ngp_profile_name(i).decode(): round(ms[i] / nsteps, 4) for i in range(npf) if cnt[i]}
+        r["_sum"] = round(sum(r.values()), 4); r["_wall_ms_per_step"] = round(wall, 4)
+        r["_rays_per_batch"] = s.rays_per_batch; r["_rays_hit"] = s.n_rays_last; r["_before"] = s.measured_batch_size_before_compaction
+        r["_k2_evals"] = s.network_evaluations; r["_loss"] = s.loss
+        print(name, json.dumps(r), flush=True)
+    lib.ngp_debug_set_flags(0); lib.ngp_debug_set_bin_params(12, 0, 0)
 
 
 if __name__ == "__main__":
