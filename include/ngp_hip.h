@@ -298,6 +298,17 @@ int ngp_nerf_train_finish(ngp_nerf*, void* stream);
  * train_finish.  (train_forward_backward + both all-reduces + train_finish stays valid.) */
 int ngp_nerf_train_forward(ngp_nerf*, void* stream);
 int ngp_nerf_train_backward(ngp_nerf*, void* stream);
+/* Data-parallel training inside the library (new; SURVEY 8b "ngp_comm_init / ngp_allreduce_gradients", 8e): one process per GPU,
+ * RCCL over xGMI (librccl is resolved at run time).  Rank 0 calls ngp_comm_unique_id (ncclGetUniqueId) and hands the 128 bytes to
+ * every rank by any side channel; every rank calls ngp_comm_init with the rank / world_size its trainer was created with.  From
+ * then on ngp_nerf_train runs  forward -> all-reduce(sum) of the two counters -> backward -> all-reduce(sum) of the fp16
+ * gradients in two buckets (hashed levels | MLP + dense levels) on the communicator's own stream -> optimizer.
+ * ngp_allreduce_gradients / ngp_allreduce_counters are the un-bucketed collectives for callers that sequence the step themselves. */
+int ngp_comm_unique_id(uint8_t id_out_host[128]);
+int ngp_comm_init(ngp_nerf*, uint32_t rank, uint32_t world_size, const uint8_t id_host[128]);
+int ngp_comm_destroy(ngp_nerf*);
+int ngp_allreduce_gradients(ngp_nerf*, void* stream);
+int ngp_allreduce_counters(ngp_nerf*, void* stream);
 /* Two uint32 {measured_before_compaction, measured} to all-reduce(sum) across ranks (8e). */
 int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters2);
 /* Blocking read-back (the reference's copy_to_host, testbed_nerf.cu:2681-2682). */

@@ -211,63 +211,81 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n_local; li += gridDim.x * 4) {
 	const RaySetup r = rs[li];
 	uint32_t cnt = 0, n_chunks = 0;
-	const bool exact_skip = a.exact_skip != 0;
+	// The reference's skip rule differs from "every lattice point on its own" only where the mip changes along a skipped voxel, and the
+	// mip of a lattice point depends on dt only when cone_angle > 0 (mip_from_dt): with cone_angle == 0 both are the same algorithm.
+	const bool exact_skip = a.exact_skip != 0 && a.cone_angle_constant > 1e-5f;
 	if (r.flags) {
 		const Box aabb(a.aabb);
 		const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
+		const f3 idir = mk3(1.0f) / rdn;
+		// one lattice point per lane: inside the box? occupied at its own mip? (64 consecutive lattice points span ~14 voxels: the byte
+		// loads of a wavefront coalesce into a few L1/L2 lines, and thousands of resident wavefronts hide their latency)
+		auto eval_point = [&](uint32_t j, bool want_skip, bool& inside, bool& occ, uint32_t& mip, uint32_t& skip) {
+			const float t = lattice_t(r, j, a.cone_angle_constant);
+			const f3 pos = ro + t * rdn;
+			inside = aabb.contains(pos);
+			occ = false; mip = 0u; skip = 1u;
+			if (inside) {
+				const float dt = calc_dt(t, a.cone_angle_constant);
+				mip = mip_from_dt(dt, pos, a.max_mip);
+				occ = a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
+				if (want_skip && !occ) {
+					// advance_to_next_voxel (nerf_device.cuh:431-441) lands on lattice point j + ceil(max(to(t_target) - to(t), 0.5))
+					const float res = scalbnf((float)GRIDSIZE, -(int)mip);
+					const float t_target = t + distance_to_next_voxel(pos, rdn, idir, res);
+					skip = (uint32_t)ceilf(fmaxf(to_stepping_space(t_target, a.cone_angle_constant) - to_stepping_space(t, a.cone_angle_constant), 0.5f));
+				}
+			}
+		};
 		// Eight chunks are tested per iteration so that eight independent occupancy loads are in flight (the loop is a
 		// chain of dependent ~1 us loads otherwise); the exit tests are then replayed in chunk order, so masks, counts
 		// and n_chunks are exactly those of the one-chunk-at-a-time loop.
-		bool done = false;
-		const f3 idir = mk3(1.0f) / rdn;
-		uint32_t jnext = 0; // next lattice point the reference's loop visits (wave-uniform)
+		bool done = false, prev_walked = false;
+		uint32_t jnext = 0;        // exact skip: next lattice point the reference's loop visits (valid while prev_walked)
+		uint32_t prev_mip = 0xffu; // mip of the previous chunk if it was uniform
 		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
 			uint64_t m[K1_GROUP], in[K1_GROUP];
-			uint32_t skip[K1_GROUP]; // empty lattice points: length of the reference's skip, in lattice units
+			uint32_t mip0[K1_GROUP]; bool uni[K1_GROUP]; // exact skip: the chunk's mip (of its first point) / is it the same for all points inside the box?
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
-				const float t = lattice_t(r, (ch0 + u) * 64 + lane, a.cone_angle_constant);
-				const f3 pos = ro + t * rdn;
-				const bool inside = aabb.contains(pos);
-				bool occ = false;
-				skip[u] = 1u;
-				if (inside) {
-					// 64 consecutive lattice points span ~14 voxels: the byte loads of a wavefront coalesce into a few
-					// L1/L2 lines, and thousands of resident wavefronts hide their latency (no LDS staging needed here)
-					const float dt = calc_dt(t, a.cone_angle_constant);
-					const uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
-					occ = a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
-					if (exact_skip && !occ) {
-						// advance_to_next_voxel (nerf_device.cuh:431-441) lands on lattice point j + ceil(max(to(t_target) - to(t), 0.5))
-						const float res = scalbnf((float)GRIDSIZE, -(int)mip);
-						const float t_target = t + distance_to_next_voxel(pos, rdn, idir, res);
-						skip[u] = (uint32_t)ceilf(fmaxf(to_stepping_space(t_target, a.cone_angle_constant) - to_stepping_space(t, a.cone_angle_constant), 0.5f));
-					}
-				}
+				bool inside, occ; uint32_t mip, skip;
+				eval_point((ch0 + u) * 64 + lane, false, inside, occ, mip, skip);
 				m[u] = __ballot(occ);
 				in[u] = __ballot(inside);
+				mip0[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mip);
+				uni[u] = __ballot(inside && mip != mip0[u]) == 0ull;
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				if (done || cnt >= N_STEPS) { done = true; break; }
 				uint64_t sm = m[u];
 				if (exact_skip) {
-					// The orbit of the reference's update rule over this chunk: runs of occupied points are taken whole (j -> j + 1),
-					// an empty point jumps by its own skip length (one v_readlane); everything stays in scalar registers.
-					const uint32_t base = (ch0 + u) * 64;
-					sm = 0ull;
-					uint32_t j = jnext > base ? jnext - base : 0u;
-					while (j < 64u) {
-						if (!((in[u] >> j) & 1ull)) { done = true; break; } // the march left the box
-						const uint64_t rest = ~(m[u] >> j); // bit 0 = 1 <=> point j is empty
-						const uint32_t run = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
-						if (run) {
-							const uint32_t len = min(run, 64u - j);
-							sm |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << j;
-							j += len;
-						} else j += (uint32_t)__builtin_amdgcn_readlane((int)skip[u], (int)__builtin_amdgcn_readfirstlane((int)j));
+					// A chunk whose points all share one mip, between neighbours of that same mip, is "plain": whatever the reference's loop
+					// skips there is empty at that mip anyway, so the independent test is exact and no skip has to be followed.  Around a mip
+					// change (and at the end of a group, where the next chunk is not known yet) the orbit of the reference's update rule is
+					// walked: runs of occupied points are taken whole (j -> j + 1), an empty point jumps by its own skip length.
+					const bool next_same = u + 1 < K1_GROUP && (in[u + 1 < K1_GROUP ? u + 1 : u] == 0ull || (uni[u + 1 < K1_GROUP ? u + 1 : u] && mip0[u + 1 < K1_GROUP ? u + 1 : u] == mip0[u]));
+					const bool plain = uni[u] && prev_mip == mip0[u] && next_same;
+					if (!plain) {
+						bool inside, occ; uint32_t mip, skip;
+						eval_point((ch0 + u) * 64 + lane, true, inside, occ, mip, skip);
+						const uint32_t base = (ch0 + u) * 64;
+						sm = 0ull;
+						uint32_t j = (prev_walked && jnext > base) ? jnext - base : 0u; // behind a plain chunk of the same mip the entry point is immaterial
+						while (j < 64u) {
+							if (!((in[u] >> j) & 1ull)) { done = true; break; } // the march left the box
+							const uint64_t rest = ~(m[u] >> j); // bit 0 = 1 <=> point j is empty
+							const uint32_t run = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
+							if (run) {
+								const uint32_t len = min(run, 64u - j);
+								sm |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << j;
+								j += len;
+							} else j += (uint32_t)__builtin_amdgcn_readlane((int)skip, (int)__builtin_amdgcn_readfirstlane((int)j));
+						}
+						jnext = base + j;
 					}
-					jnext = base + j;
+					prev_walked = !plain;
+					prev_mip = uni[u] ? mip0[u] : 0xffu;
 				}
 				if (lane == 0) masks[(size_t)li * LAT_MAX_CHUNKS + ch0 + u] = sm;
 				cnt += (uint32_t)__popcll(sm);

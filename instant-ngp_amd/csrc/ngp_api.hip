@@ -2,6 +2,7 @@
 // Owns device memory, derives layouts (hash-grid offset table, MFMA fragment permutations), and
 // sequences the kernels of one training step on one HIP stream without host synchronisation.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -160,6 +161,8 @@ struct ngp_model {
 	GradBinArgs bin_args{};
 	// W (weight gradients, compute bound, 1 wave/SIMD) runs on a side stream next to the hashed levels' bin/accumulate kernels (memory/LDS bound)
 	hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// data-parallel step: events that mark the two gradient buckets final (recorded when record_bucket_events is set, see ngp_comm_*)
+	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
 };
@@ -272,6 +275,8 @@ extern "C" void ngp_model_destroy(ngp_model* m) {
 	if (m->side) (void)hipStreamDestroy(m->side);
 	if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
 	if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+	if (m->ev_hashed_ready) (void)hipEventDestroy(m->ev_hashed_ready);
+	if (m->ev_mlp_ready) (void)hipEventDestroy(m->ev_mlp_ready);
 	delete m;
 }
 
@@ -402,6 +407,10 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = (const uint2*)m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap;
 		ba.vals = (uint2*)m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
 		launch_grad_bin(s, ba);
+	}
+	if (m->record_bucket_events) { // bucket B (hashed levels) is final behind k_grad_accumulate, bucket A (MLP + dense levels) behind T1 and k_wgrad_reduce
+		if (!m->ev_hashed_ready) { HIPCHK(hipEventCreateWithFlags(&m->ev_hashed_ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&m->ev_mlp_ready, hipEventDisableTiming)); }
+		HIPCHK(hipEventRecord(m->ev_hashed_ready, s)); HIPCHK(hipEventRecord(m->ev_mlp_ready, sw));
 	}
 	if (overlap) { HIPCHK(hipEventRecord(m->ev_join, sw)); HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0)); }
 	HIPCHK(hipGetLastError());
@@ -699,6 +708,8 @@ struct ngp_nerf {
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
 	uint8_t* bitfield_linear = nullptr; // x-major copy of the bitfield for the lattice marchers
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
+	// in-library data-parallel step over RCCL (ngp_comm_init): communicator, its stream, bucket-reduced events
+	void* comm = nullptr; hipStream_t comm_stream = nullptr; hipEvent_t ev_red_a = nullptr, ev_red_b = nullptr; bool grads_pending = false;
 	// host-side deterministic state (no device read-back needed)
 	Rng rng, density_grid_rng;
 	uint32_t training_step = 0, prep_skip_counter = 0, ema_step = 0;
@@ -756,6 +767,7 @@ extern "C" int ngp_nerf_set_options(ngp_nerf* t, const ngp_nerf_options* o) {
 extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
+	if (t->comm) (void)ngp_comm_destroy(t);
 	if (t->k1_stream) (void)hipStreamDestroy(t->k1_stream);
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
@@ -964,6 +976,7 @@ __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t 
 // optimizer_step + NerfCounters::update_after_training, testbed_nerf.cu:2770-2778
 extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
+	if (t->grads_pending) { HIPCHK(hipStreamWaitEvent(s, t->ev_red_a, 0)); HIPCHK(hipStreamWaitEvent(s, t->ev_red_b, 0)); t->grads_pending = false; }
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 	if (!t->ctl_done) { // the controller has not run behind K3 (multi-rank caller using ngp_nerf_train_forward_backward)
 		if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
@@ -975,10 +988,105 @@ extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// data-parallel step inside the library: RCCL over xGMI, one process per GPU.  librccl is resolved at run time
+// (dlopen; the copy a host process has already loaded -- e.g. PyTorch's -- is reused), so libngp_hip.so has no link-time dependency.
+// ------------------------------------------------------------------------------------------------
+struct NcclId { char internal[128]; };
+struct RcclApi {
+	void* lib = nullptr;
+	int (*GetUniqueId)(NcclId*) = nullptr;
+	int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+	int (*CommDestroy)(void*) = nullptr;
+	int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+	if (g_rccl.lib) return 0;
+	void* h = nullptr;
+	for (const char* name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break; // already in the process
+	if (!h) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+	if (!h) return fail(std::string("librccl not found: ") + dlerror());
+	g_rccl.GetUniqueId = (int (*)(NcclId*))dlsym(h, "ncclGetUniqueId");
+	g_rccl.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(h, "ncclCommInitRank");
+	g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+	g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+	g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+	if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) return fail("librccl: missing symbols");
+	g_rccl.lib = h;
+	return 0;
+}
+#define RCCLCHK(x) do { int r_ = (x); if (r_ != 0) return fail(std::string(#x) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); } while (0)
+constexpr int kNcclUint32 = 3, kNcclHalf = 6, kNcclSum = 0; // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+extern "C" int ngp_comm_unique_id(uint8_t id_out_host[128]) {
+	REQUIRE(id_out_host, "ngp_comm_unique_id: null argument");
+	if (rccl_load()) return 1;
+	NcclId id; RCCLCHK(g_rccl.GetUniqueId(&id));
+	memcpy(id_out_host, id.internal, 128);
+	return 0;
+}
+extern "C" int ngp_comm_init(ngp_nerf* t, uint32_t rank, uint32_t world_size, const uint8_t id_host[128]) {
+	REQUIRE(t && id_host, "ngp_comm_init: null argument");
+	REQUIRE(rank == t->opt.rank && world_size == t->opt.world_size, "ngp_comm_init: rank / world_size differ from the trainer's sharding (ngp_nerf_options)");
+	REQUIRE(!t->comm, "ngp_comm_init: communicator already initialised");
+	if (rccl_load()) return 1;
+	NcclId id; memcpy(id.internal, id_host, 128);
+	RCCLCHK(g_rccl.CommInitRank(&t->comm, (int)world_size, id, (int)rank));
+	int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+	HIPCHK(hipStreamCreateWithPriority(&t->comm_stream, hipStreamNonBlocking, hi));
+	HIPCHK(hipEventCreateWithFlags(&t->ev_red_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_red_b, hipEventDisableTiming));
+	t->model->record_bucket_events = true;
+	return 0;
+}
+extern "C" int ngp_comm_destroy(ngp_nerf* t) {
+	if (!t || !t->comm) return 0;
+	(void)hipDeviceSynchronize();
+	RCCLCHK(g_rccl.CommDestroy(t->comm));
+	t->comm = nullptr; t->model->record_bucket_events = false;
+	if (t->comm_stream) { (void)hipStreamDestroy(t->comm_stream); t->comm_stream = nullptr; }
+	if (t->ev_red_a) { (void)hipEventDestroy(t->ev_red_a); (void)hipEventDestroy(t->ev_red_b); t->ev_red_a = t->ev_red_b = nullptr; }
+	return 0;
+}
+// all-reduce(sum) of the whole fp16 gradient buffer on `stream` (the un-bucketed form; tests / callers that sequence the step themselves)
+extern "C" int ngp_allreduce_gradients(ngp_nerf* t, void* stream) {
+	REQUIRE(t && t->comm, "ngp_allreduce_gradients: ngp_comm_init has not been called");
+	RCCLCHK(g_rccl.AllReduce(t->model->grads, t->model->grads, t->model->n_params, kNcclHalf, kNcclSum, t->comm, (hipStream_t)stream));
+	return 0;
+}
+extern "C" int ngp_allreduce_counters(ngp_nerf* t, void* stream) {
+	REQUIRE(t && t->comm, "ngp_allreduce_counters: ngp_comm_init has not been called");
+	RCCLCHK(g_rccl.AllReduce(t->sync2, t->sync2, 2, kNcclUint32, kNcclSum, t->comm, (hipStream_t)stream));
+	return 0;
+}
+// Bucketed gradient all-reduce behind ngp_nerf_train_backward: bucket B = the hashed levels (final behind k_grad_accumulate), bucket A =
+// MLP + dense levels (final behind T1 / k_wgrad_reduce); both on the communicator's own stream, so B's ring runs next to the tail of
+// the backward pass (W, the next step's K1).  ngp_nerf_train_finish makes the optimizer wait for both.
+static int dp_reduce_buckets(ngp_nerf* t) {
+	ngp_model* m = t->model;
+	const GradBinArgs& ba = m->bin_args;
+	size_t split = m->n_params; // first parameter of bucket B
+	if (ba.n_hashed) split = m->n_mlp + (size_t)m->gm.offset[ba.levels[0]] * m->gm.F; // hashed levels are the finest ones: contiguous tail of the layout
+	HIPCHK(hipStreamWaitEvent(t->comm_stream, m->ev_hashed_ready, 0));
+	if (split < m->n_params) RCCLCHK(g_rccl.AllReduce(m->grads + split, m->grads + split, m->n_params - split, kNcclHalf, kNcclSum, t->comm, t->comm_stream));
+	HIPCHK(hipEventRecord(t->ev_red_b, t->comm_stream));
+	HIPCHK(hipStreamWaitEvent(t->comm_stream, m->ev_mlp_ready, 0));
+	RCCLCHK(g_rccl.AllReduce(m->grads, m->grads, split, kNcclHalf, kNcclSum, t->comm, t->comm_stream));
+	HIPCHK(hipEventRecord(t->ev_red_a, t->comm_stream));
+	t->grads_pending = true;
+	return 0;
+}
+
 extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 	for (uint32_t i = 0; i < n_steps; ++i) {
 		if (ngp_nerf_train_prep(t, stream)) return 1;
-		if (ngp_nerf_train_forward_backward(t, stream)) return 1;
+		if (t->comm) { // data-parallel: forward -> all-reduce(counters) -> backward + bucketed all-reduce(gradients) -> optimizer
+			if (ngp_nerf_train_forward(t, stream)) return 1;
+			if (ngp_allreduce_counters(t, stream)) return 1;
+			if (ngp_nerf_train_backward(t, stream)) return 1;
+			if (dp_reduce_buckets(t)) return 1;
+		} else if (ngp_nerf_train_forward_backward(t, stream)) return 1;
 		if (ngp_nerf_train_finish(t, stream)) return 1;
 	}
 	return 0;

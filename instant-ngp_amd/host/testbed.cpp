@@ -249,14 +249,37 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (j.has("scale")) d.scale = (float)j.num("scale", 0.33);
 		if (j.has("offset") && j["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)j["offset"].at(k).n;
 		const auto& fr = j["frames"];
-		for (size_t i = 0; i < fr.size(); ++i) {
-			const auto& f = fr.at(i);
-			Frame F;
+		auto resolve = [&](const mini_json::Value& f) { // resolve_path, nerf_loader.cu:314-330: try the supported extensions when none is given
 			fs::path ip = jp.parent_path() / f.str("file_path", "");
 			if (!fs::exists(ip) || ip.extension().empty()) {
 				for (const char* ext : {".png", ".jpg", ".jpeg", ".JPG", ".PNG", ".exr"}) { fs::path c = ip; c += ext; if (fs::exists(c)) { ip = c; break; } }
 			}
-			F.image_path = ip.string();
+			return ip;
+		};
+		// frame selection, nerf_loader.cu:352-388: natural sort by file_path, optional "n_frames" cull, and -- when the frames carry a
+		// "sharpness" value (colmap2nerf.py) -- frames whose image is missing or blurrier than `sharpness_discard_threshold` x the mean
+		// of their neighbourhood are dropped (fox: transforms.json lists 67 frames, 50 images are shipped)
+		std::vector<const mini_json::Value*> sel;
+		for (size_t i = 0; i < fr.size(); ++i) sel.push_back(&fr.at(i));
+		std::stable_sort(sel.begin(), sel.end(), [](const mini_json::Value* a, const mini_json::Value* b) { return natural_less(a->str("file_path", ""), b->str("file_path", "")); });
+		if (j.has("n_frames")) sel.resize(std::min(sel.size(), (size_t)j.num("n_frames", 0)));
+		if (!sel.empty() && sel[0]->has("sharpness")) {
+			const float thresh = (float)j.num("sharpness_discard_threshold", 0.0);
+			std::vector<const mini_json::Value*> kept;
+			const int nb = 3, n = (int)sel.size();
+			for (int i = 0; i < n; ++i) {
+				const int b = std::max(0, i - nb), e = std::min(i + nb, n - 1);
+				float mean = 0.f;
+				for (int k = b; k < e; ++k) mean += (float)sel[k]->num("sharpness", 1.0);
+				mean /= (float)(e - b);
+				if (fs::exists(resolve(*sel[i])) && (float)sel[i]->num("sharpness", 1.0) > thresh * mean) kept.push_back(sel[i]);
+			}
+			sel.swap(kept);
+		}
+		for (const mini_json::Value* fp : sel) {
+			const auto& f = *fp;
+			Frame F;
+			F.image_path = resolve(f).string();
 			// per-frame values override the global ones (nerf_loader.cu:487-535, 697-700)
 			auto get = [&](const char* k, double dflt) { return f.has(k) ? f.num(k, dflt) : j.num(k, dflt); };
 			auto has = [&](const char* k) { return f.has(k) || j.has(k); };

@@ -143,11 +143,12 @@ def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
     # 99.7 % of rays with identical counts, worst position delta 2.1e-6 ~ 9 ulp of t; almost no ray is bit-identical)
     assert worst <= 5e-6
     assert same_count >= 0.995 * len(both)
-    # The device kernel IS the lattice algorithm of oracle/ora_nerf.hpp::lattice_march_counts (mode 1: the reference's skip rule
-    # evaluated on the lattice); with cone_angle = 0 there is no transcendental on either side, so the sample counts agree exactly.
+    # The device kernel IS the lattice algorithm of oracle/ora_nerf.hpp::lattice_march_counts; with cone_angle = 0 the mip is constant
+    # along every skipped voxel, the reference's skip rule and the independent test coincide (tests/test_k1_lattice_model.py) and the
+    # kernel runs the latter (mode 0); no transcendental on either side, so the sample counts agree exactly.
     rb, re = n_rays * rank // world, n_rays * (rank + 1) // world
     model = np.zeros(re - rb, np.uint32)
-    ora.ora_k1_lattice_counts(1, n_rays, rb, re, A.scene_aabb(1), _rng(ora), len(scene["imgs"]), scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, C.c_float(0.0), ptr(model), 2048)
+    ora.ora_k1_lattice_counts(0, n_rays, rb, re, A.scene_aabb(1), _rng(ora), len(scene["imgs"]), scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, C.c_float(0.0), ptr(model), 2048)
     dev = np.zeros(re - rb, np.uint32); dev[ri - rb] = ns[:, 0]
     assert np.array_equal(dev, model), f"device lattice K1 vs its CPU model: {(dev != model).sum()} rays differ"
 
