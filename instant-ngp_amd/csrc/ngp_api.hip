@@ -700,7 +700,7 @@ struct ngp_nerf {
 	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
 	bool ctl_done = false; // the batch-size controller of the current step has run
 	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
-	uint32_t k2_rounds = 4, k2_tile_w = 16; // NGP_K2_ROUNDS=2..8 / NGP_K2_TILE=16|32 override (tuning knobs; round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest)
+	uint32_t k2_rounds = 3, k2_tile_w = 32; // measured (profiles/r02_microbench_k2.log): 3 x 32 = 0.157 ms, 4 x 16 = 0.18 ms although it evaluates 30 % fewer samples (per-round wave quantisation + one more launch); NGP_K2_ROUNDS=2..8 / NGP_K2_TILE=16|32 override (tuning knobs; round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest)
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;

@@ -83,6 +83,11 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error{"init_window: GUI is out of scope of this build (headless MI355X path)"}; },
 			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
 		.def("init_vr", [](Testbed&) { throw std::runtime_error{"init_vr: VR is out of scope of this build"}; })
+		.def("load_camera_path", [](Testbed&, const std::string&) { throw std::runtime_error{"load_camera_path: camera-path video rendering is out of scope of this build (python_api.cu:563)"}; })
+		.def_property("camera_smoothing", [](Testbed&) { return false; }, [](Testbed&, bool v) { if (v) throw std::runtime_error{"camera_smoothing: camera-path video rendering is out of scope of this build"}; })
+		// data-parallel training (new): rank 0 creates the id, every rank passes the same 128 bytes
+		.def_static("comm_unique_id", []() { return py::bytes(Testbed::comm_unique_id()); })
+		.def("comm_init", [](Testbed& t, uint32_t rank, uint32_t world, py::bytes id) { t.comm_init(rank, world, std::string(id)); }, py::arg("rank"), py::arg("world_size"), py::arg("unique_id"))
 		.def("compute_and_save_marching_cubes_mesh", [](Testbed&, py::args, py::kwargs) { throw std::runtime_error{"marching cubes export is out of scope of this build"}; })
 		.def_readwrite("root_dir", &Testbed::root_dir)
 		.def_readwrite("mode", &Testbed::mode)

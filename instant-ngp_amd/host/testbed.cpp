@@ -181,7 +181,7 @@ ngp_nerf_options Testbed::current_options() const {
 	o.target_batch_size = training_batch_size;
 	o.loss_scale = 128.f; // default_loss_scale<__half>, testbed.h:307-311
 	o.seed = seed;
-	o.rank = 0; o.world_size = 1;
+	o.rank = m_rank; o.world_size = m_world_size;
 	return o;
 }
 
@@ -197,6 +197,11 @@ void Testbed::ensure_trainer() {
 		ngp_nerf_options o = current_options();
 		NGP_CHECK(ngp_nerf_create(m_model, &o, scene_aabb(), &m_nerf));
 		m_dataset_dirty = true;
+		m_comm_up = false;
+	}
+	if (m_world_size > 1 && !m_comm_up) {
+		NGP_CHECK(ngp_comm_init(m_nerf, m_rank, m_world_size, (const uint8_t*)m_comm_id.data()));
+		m_comm_up = true;
 	}
 	if (m_dataset_dirty) {
 		const NerfDataset& d = nerf.training.dataset;
@@ -210,6 +215,10 @@ void Testbed::ensure_trainer() {
 			for (int k = 0; k < 7; ++k) meta[i].lens_params[k] = d.metadata[i].lens_params[k];
 			for (int k = 0; k < 12; ++k) xf[i].start[k] = xf[i].end[k] = d.xforms[i][k];
 			pix[i] = d.pixels[i].data();
+			if (d.pixels[i].empty()) { // metadata restored from a snapshot: a 1x1 transparent stand-in keeps the device arrays well formed (render-only)
+				static const uint32_t k_no_pixel = 0u;
+				pix[i] = &k_no_pixel; meta[i].resolution[0] = meta[i].resolution[1] = 1;
+			}
 		}
 		NGP_CHECK(ngp_nerf_set_dataset_host(m_nerf, (uint32_t)d.n_images, meta.data(), xf.data(), pix.data()));
 		m_dataset_dirty = false;
@@ -366,6 +375,8 @@ void Testbed::load_file(const std::string& path) {
 // training
 // ------------------------------------------------------------------------------------------------
 void Testbed::train(uint32_t batch_size) {
+	if (nerf.training.dataset.n_images > 0 && nerf.training.dataset.pixels[0].empty())
+		throw std::runtime_error{"Cannot train: the dataset was restored from a snapshot's metadata only. Load the training data first."};
 	if (batch_size != training_batch_size && !m_nerf) training_batch_size = batch_size;
 	ensure_trainer();
 	push_options();
@@ -376,6 +387,17 @@ void Testbed::train(uint32_t batch_size) {
 		loss = s.loss;
 		if (s.measured_batch_size == 0 && training_step > 1) { fprintf(stderr, "Warning: Nerf training generated 0 samples. Aborting training.\n"); shall_train = false; }
 	}
+}
+std::string Testbed::comm_unique_id() {
+	uint8_t id[128];
+	NGP_CHECK(ngp_comm_unique_id(id));
+	return std::string((const char*)id, 128);
+}
+void Testbed::comm_init(uint32_t rank, uint32_t world_size, const std::string& id) {
+	if (world_size < 1 || rank >= world_size) throw std::runtime_error{"comm_init: bad rank / world_size"};
+	if (id.size() != 128) throw std::runtime_error{"comm_init: the unique id must be the 128 bytes of Testbed.comm_unique_id()"};
+	if (m_rank != rank || m_world_size != world_size) destroy_trainer(); // the sharding is fixed when the trainer is created
+	m_rank = rank; m_world_size = world_size; m_comm_id = id; m_comm_up = false;
 }
 ngp_nerf_stats Testbed::stats() {
 	ngp_nerf_stats s; memset(&s, 0, sizeof(s));
@@ -540,7 +562,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 		Value blob; blob.type = Value::Binary; blob.bin.resize(ngp_model_serialized_size(m_model, 1));
 		NGP_CHECK(ngp_model_serialize_host(m_model, blob.bin.data(), blob.bin.size(), 1));
 		opt.set("state_binary", blob);
-		snap.set("optimizer", opt);
+		snap.set("ngp_hip_optimizer", opt); // NOT under "optimizer": a real instant-ngp build would try to deserialise that key with tcnn's Adam / EMA layout
 	}
 	// ---- Testbed::save_snapshot, testbed.cu:5291-5343 ----
 	snap.set("version", jnum(1)); snap.set("mode", jstr("nerf"));
@@ -621,14 +643,44 @@ void Testbed::load_snapshot(const std::string& path) {
 	if ((int)snap.num("density_grid_size", 0) != 128) throw std::runtime_error{"Incompatible grid size."};
 	const Value& jn = snap["nerf"];
 	const int aabb_scale = (int)jn.num("aabb_scale", nerf.training.dataset.aabb_scale);
-	if (nerf.training.dataset.n_images == 0) throw std::runtime_error{"load_snapshot: load the training data first (rendering from the snapshot's embedded dataset metadata alone is not implemented)."};
+	if (nerf.training.dataset.n_images == 0) {
+		// No training data loaded: restore the dataset METADATA embedded in the snapshot (from_json(NerfDataset), json_binding.h:141-190;
+		// testbed.cu:5386-5400), enough to render / evaluate (`run.py --load_snapshot x.ingp` without --scene).  There are no pixels:
+		// training stays off until load_training_data is called.
+		const Value& jd = jn["dataset"];
+		if (!jd.is_object() || !jd["metadata"].is_array()) throw std::runtime_error{"Snapshot holds no dataset metadata and no training data is loaded."};
+		NerfDataset d;
+		d.aabb_scale = (int)jd.num("aabb_scale", aabb_scale); d.scale = (float)jd.num("scale", 0.33); d.is_hdr = jd["is_hdr"].type == Value::Bool && jd["is_hdr"].b;
+		if (jd["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)jd["offset"].at(k).n;
+		const size_t n = jd["metadata"].size();
+		for (size_t i = 0; i < n; ++i) {
+			const Value& jm = jd["metadata"].at(i);
+			ImageMetadata m;
+			for (int k = 0; k < 2; ++k) { m.resolution[k] = (int)jm["resolution"].at(k).n; m.focal_length[k] = (float)jm["focal_length"].at(k).n; m.principal_point[k] = (float)jm["principal_point"].at(k).n; }
+			const Value& lens = jm["lens"];
+			if (lens.is_object() && lens.has("k1")) { m.lens_mode = NGP_LENS_OPENCV; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("p1", 0); m.lens_params[3] = (float)lens.num("p2", 0); }
+			std::array<float, 12> x{};
+			const Value& xs = jd["xforms"].at(i)["start"];
+			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) x[c * 3 + r] = (float)xs.at(c).at(r).n;
+			d.metadata.push_back(m); d.xforms.push_back(x); d.pixels.emplace_back(); // no pixels
+			d.paths.push_back(jd["paths"].is_array() && i < jd["paths"].size() ? jd["paths"].at(i).s : std::string());
+		}
+		d.n_images = n;
+		nerf.training.dataset = std::move(d);
+		mode = ETestbedMode::Nerf;
+		nerf.max_cascade = 0;
+		while ((1 << nerf.max_cascade) < nerf.training.dataset.aabb_scale) ++nerf.max_cascade;
+		nerf.cone_angle_constant = nerf.training.dataset.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+		m_render_lens_mode = nerf.training.dataset.metadata[0].lens_mode; m_render_lens_params = nerf.training.dataset.metadata[0].lens_params;
+		m_dataset_dirty = true; shall_train = false;
+	}
 	if (aabb_scale != nerf.training.dataset.aabb_scale) throw std::runtime_error{"Snapshot aabb_scale differs from the loaded dataset."};
 	m_network_config = root;
 	destroy_trainer();
 	ensure_trainer();
 	uint64_t n_params = 0, n_mlp = 0;
 	NGP_CHECK(ngp_model_n_params(m_model, &n_params, &n_mlp));
-	const Value& opt = snap["optimizer"];
+	const Value& opt = snap.has("ngp_hip_optimizer") ? snap["ngp_hip_optimizer"] : snap["optimizer"]; // ("optimizer": files written by round 1 of this library)
 	if (opt.is_object() && opt.str("otype", "") == "ngp_hip" && opt["state_binary"].type == Value::Binary) {
 		NGP_CHECK(ngp_model_deserialize_host(m_model, opt["state_binary"].bin.data(), opt["state_binary"].bin.size()));
 	} else { // Trainer::deserialize without optimizer state: parameters only, in the precision named by "params_type"

@@ -81,6 +81,9 @@ public:
 	// render_to_cpu (python_api.cu:145-236): premultiplied RGBA float [h][w][4]
 	std::vector<float> render(int width, int height, int spp, bool linear);
 	ngp_nerf_stats stats();
+	// data-parallel training (new): one process per GPU, ngp_comm_* of libngp_hip (RCCL); call before the first train()
+	static std::string comm_unique_id();
+	void comm_init(uint32_t rank, uint32_t world_size, const std::string& unique_id_128_bytes);
 
 	// public members, same names as the reference
 	std::string root_dir;
@@ -89,7 +92,7 @@ public:
 	uint32_t training_step = 0;
 	float loss = 0.f;
 	float exposure = 0.f;
-	std::array<float, 4> background_color{0.f, 0.f, 0.f, 0.f};
+	std::array<float, 4> background_color{0.f, 0.f, 0.f, 1.f};          // testbed.h:1031
 	bool snap_to_pixel_centers = false;
 	bool render_with_lens_distortion = false;
 	bool render_ground_truth = false;
@@ -126,6 +129,7 @@ private:
 	int m_training_view = 0;
 	float* m_frame_dev = nullptr; size_t m_frame_dev_floats = 0;
 	bool m_warned_train_mode = false;
+	uint32_t m_rank = 0, m_world_size = 1; std::string m_comm_id; bool m_comm_up = false;
 };
 
 std::string msgpack_repack(const std::string& data, bool input_compressed, bool output_compressed); // msgpack_lite round trip (tests)

@@ -19,7 +19,8 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-B_GLOBAL = 1 << 17
+B_GLOBAL = 1 << 18
+RAYS0 = 256  # start where neither K1's sample cap nor K3's batch clamp drops rays (both are order dependent): ~500 samples per ray at initialisation
 N_STEPS = 40
 
 
@@ -39,6 +40,7 @@ def _setup(A, lib, rank, world, batch):
     A.check(lib, lib.ngp_nerf_create(hm.h, C.byref(opts), A.scene_aabb(1), C.byref(t)))
     pix = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
     A.check(lib, lib.ngp_nerf_set_dataset_host(t, len(imgs), M, X, pix))
+    A.check(lib, lib.ngp_nerf_set_rays_per_batch(t, RAYS0))
     return hm, t, (imgs, M, X, pix)
 
 
@@ -46,11 +48,13 @@ def _scratch(A, lib, t, batch):
     ri, rays, ns, co, mo, cc, dl, cnt = (C.c_void_p() for _ in range(8))
     A.check(lib, lib.ngp_nerf_scratch_ptrs(t, C.byref(ri), C.byref(rays), C.byref(ns), C.byref(co), C.byref(mo), C.byref(cc), C.byref(dl), C.byref(cnt)))
     return dict(ray_indices=torch.as_tensor(_View(ri.value, 1 << 18, "<u4".replace("u", "i")), device="cuda"), numsteps=torch.as_tensor(_View(ns.value, 2 << 18, "<i4"), device="cuda"),
-                coords_compacted=torch.as_tensor(_View(cc.value, batch * 7, "<f4"), device="cuda"), dloss=torch.as_tensor(_View(dl.value, batch * 4, "<i2"), device="cuda"))
+                coords_compacted=torch.as_tensor(_View(cc.value, batch * 7, "<f4"), device="cuda"), dloss=torch.as_tensor(_View(dl.value, batch * 4, "<i2"), device="cuda"),
+                counters=torch.as_tensor(_View(cnt.value, 8, "<i4"), device="cuda"))  # TrainCounters: [4] = ray_counter (active rays of the step in flight)
 
 
-def _rows(sc, n_rays_active):
+def _rows(sc):
     """per global ray index: the bytes of its compacted coordinate / loss-gradient rows (valid rows only, before K4's padding)"""
+    n_rays_active = int(sc["counters"].cpu()[4])
     ri = sc["ray_indices"].cpu().numpy().astype(np.uint32)[:n_rays_active]
     ns = sc["numsteps"].cpu().numpy().astype(np.uint32).reshape(-1, 2)[:n_rays_active]
     cc = sc["coords_compacted"].cpu().numpy().reshape(-1, 7); dl = sc["dloss"].cpu().numpy().reshape(-1, 4)
@@ -87,7 +91,7 @@ def _worker(rank, world, port, q):
         A.check(lib, lib.ngp_nerf_train_forward(t, None))
         torch.cuda.synchronize()
         c_host = cnt.cpu().to(torch.int64)
-        rows = _rows(sc, int(1 << 18)) if step in (0, 5) else None  # numsteps beyond the active rays are stale -> filter below
+        rows = _rows(sc) if step == 0 else None
         dist.all_reduce(c_host)
         cnt.copy_(c_host.to(torch.int32).cuda())
         A.check(lib, lib.ngp_nerf_train_backward(t, None))
@@ -106,7 +110,7 @@ def _worker(rank, world, port, q):
             A.check(lib, lib.ngp_nerf_train_prep(t1, None))
             A.check(lib, lib.ngp_nerf_train_forward(t1, None))
             torch.cuda.synchronize()
-            rows1 = _rows(sc1, int(1 << 18)) if step in (0, 5) else None
+            rows1 = _rows(sc1) if step == 0 else None
             A.check(lib, lib.ngp_nerf_train_backward(t1, None))
             torch.cuda.synchronize()
             g_one = grads1.float().cpu()
@@ -125,15 +129,12 @@ def _worker(rank, world, port, q):
                     assert not (set(d) & set(union)), "shards overlap"
                     union.update(d)
                 one = rows1
-                # numsteps slots beyond the active-ray count hold stale entries: compare the rays both sides report
-                assert sum(n_act) == ref[0]["n_rays"], (n_act, ref[0])
-                common = set(union) & set(one)
-                assert len(common) >= ref[0]["n_rays"], (len(common), ref[0])
-                assert all(union[k] == one[k] for k in common), "per-ray compacted rows differ between 1 and 2 ranks"
+                assert sum(n_act) == ref[0]["n_rays"] and set(union) == set(one), (n_act, ref[0], len(union), len(one))
+                assert all(union[k] == one[k] for k in one), "per-ray compacted rows differ between 1 and 2 ranks"
                 # (ii) the all-reduced gradient is the single-rank gradient up to K4's padding (each rank wraps ITS rows to B/G: not linear) and fp16 order
                 a, b = g_sum.numpy().astype(np.float64), g_one.numpy().astype(np.float64)
                 rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
-                print(f"step 0: {len(common)} rays, summed-gradient rel-L2 vs single rank {rel:.3e}")
+                print(f"step 0: {len(one)} rays, summed-gradient rel-L2 vs single rank {rel:.3e}")
                 assert rel < 0.25, rel
     # (iv) replicated optimizer on identical reduced gradients: both ranks hold bit-identical parameters after N steps
     p = np.empty(hm.n, np.float32)
@@ -181,7 +182,8 @@ def test_rccl_in_library_world1(hip):
         torch.cuda.synchronize()
     sa, sb = A.NerfStats(), A.NerfStats()
     A.check(hip, hip.ngp_nerf_get_stats(t_a, None, C.byref(sa))); A.check(hip, hip.ngp_nerf_get_stats(t_b, None, C.byref(sb)))
-    assert sa.training_step == sb.training_step == 30 and sa.rays_per_batch == sb.rays_per_batch and sa.measured_batch_size == sb.measured_batch_size
+    # two trainings differ by the arrival order of the dense levels' half atomics: counters agree statistically, not bit for bit
+    assert sa.training_step == sb.training_step == 30 and abs(int(sa.rays_per_batch) - int(sb.rays_per_batch)) <= 512 and abs(int(sa.measured_batch_size) - int(sb.measured_batch_size)) <= 0.1 * sa.measured_batch_size
     pa, pb = hm_a.read("master", torch), hm_b.read("master", torch)
     # the dense levels' half atomics arrive in a different order from run to run: compare statistically, the hashed levels + MLP tightly
     rel = float(np.linalg.norm(pa - pb) / np.linalg.norm(pa))

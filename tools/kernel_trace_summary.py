@@ -31,6 +31,23 @@ def main():
     print(f"{'kernel':70s} {'count':>8s} {'avg us':>9s} {'total ms':>9s} {'%':>6s}")
     for n, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         print(f"{n:70s} {len(v):8d} {sum(v) / len(v):9.2f} {sum(v) / 1e3:9.2f} {100 * sum(v) / total:6.2f}")
+    # timeline of the last 60 % of the trace (steady state): union of busy intervals vs wall time, overlap, gaps between consecutive kernels
+    tail = rows[int(0.4 * len(rows)):]
+    if tail:
+        t0, t1 = tail[0][0], max(e for _, e, _ in tail)
+        busy, cur_s, cur_e, ksum, gaps = 0, tail[0][0], tail[0][1], 0, []
+        for s, e, n in tail:
+            ksum += e - s
+            if s > cur_e:
+                busy += cur_e - cur_s; gaps.append((s - cur_e) / 1e3); cur_s, cur_e = s, e
+            else:
+                cur_e = max(cur_e, e)
+        busy += cur_e - cur_s
+        n_opt = sum(1 for _, _, n in tail if "k_optimizer" in n)
+        gaps.sort()
+        print(f"steady-state timeline: wall {(t1 - t0) / 1e6:.2f} ms, union busy {busy / 1e6:.2f} ms ({100 * busy / (t1 - t0):.1f} %), sum of kernel durations {ksum / 1e6:.2f} ms, "
+              f"{len(gaps)} idle gaps: total {sum(gaps) / 1e3:.2f} ms, median {gaps[len(gaps) // 2] if gaps else 0:.2f} us, p90 {gaps[int(0.9 * len(gaps))] if gaps else 0:.2f} us; "
+              f"{n_opt} optimizer steps -> {(t1 - t0) / 1e3 / max(n_opt, 1):.1f} us wall, {busy / 1e3 / max(n_opt, 1):.1f} us busy, {ksum / 1e3 / max(n_opt, 1):.1f} us kernel time per step")
     # K2 rounds: consecutive runs of the same tiles kernel = one step's rounds
     for key in [k for k in by if "k_inference_tiles" in k]:
         runs, cur = [], []

@@ -14,19 +14,19 @@ import synth_scene
 
 # name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
 VARIANTS = [
-    ("default", 0, (12, 0, 0), (4, 16)),
-    ("bin_chunk12_split", 0, (12, 1, 0), (4, 16)),   # round-1 layout
-    ("bin_chunk11", 0, (11, 0, 0), (4, 16)),
-    ("bin_chunk11_split", 0, (11, 1, 0), (4, 16)),
-    ("k2_tile32_r3", 0, (12, 0, 0), (3, 32)),         # round-1 K2
+    ("default", 0, (12, 0, 0), (3, 32)),
+    ("bin_chunk12_split", 0, (12, 1, 0), (3, 32)),   # round-1 layout
+    ("bin_chunk11", 0, (11, 0, 0), (3, 32)),
+    ("bin_chunk11_split", 0, (11, 1, 0), (3, 32)),
+    ("k2_tile16_r4", 0, (12, 0, 0), (4, 16)),
     ("k2_tile16_r3", 0, (12, 0, 0), (3, 16)),
     ("k2_tile16_r5", 0, (12, 0, 0), (5, 16)),
     ("k2_tile16_r6", 0, (12, 0, 0), (6, 16)),
-    ("k2_eager", 8192, (12, 0, 0), (4, 16)),
-    ("k1_independent_lattice", 16384, (12, 0, 0), (4, 16)),
-    ("default_again", 0, (12, 0, 0), (4, 16)),
-    ("t1_no_binning", 2048, (12, 0, 0), (4, 16)),
-    ("t1_no_scatter", 2, (12, 0, 0), (4, 16)),
+    ("k2_eager", 8192, (12, 0, 0), (3, 32)),
+    ("k1_independent_lattice", 16384, (12, 0, 0), (3, 32)),
+    ("default_again", 0, (12, 0, 0), (3, 32)),
+    ("t1_no_binning", 2048, (12, 0, 0), (3, 32)),
+    ("t1_no_scatter", 2, (12, 0, 0), (3, 32)),
 ]
 
 

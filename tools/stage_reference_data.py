@@ -10,6 +10,7 @@ gpurun-ignored, so `bench.py --scene fox`, the full-resolution fox test, the ima
   data/nerf/fox          50 JPEGs 1080x1920 + transforms.json   (BASELINE.json config 2)
   data/image/albert.exr  1024^2 RGBA float32                     (config 0)
   data/sdf/armadillo.obj 49,990 vertices                         (config 4)
+  configs/{nerf,image,sdf}/*.json             the reference's network configs (run.py resolves them against ROOT_DIR = the parent of scripts/)
   scripts/{run,common,scenes,constants}.py   executed UNMODIFIED by tests/test_run_py_dropin.py against this repo's pyngp
 """
 import os
@@ -20,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("NGP_REFERENCE_DIR", "/root/reference")
 DST = os.path.join(ROOT, "_ref_data")
 
-ITEMS = ["data/nerf/fox", "data/image/albert.exr", "data/sdf/armadillo.obj", "scripts/run.py", "scripts/common.py", "scripts/scenes.py", "scripts/constants.py"]
+ITEMS = ["configs/nerf", "configs/image", "configs/sdf", "data/nerf/fox", "data/image/albert.exr", "data/sdf/armadillo.obj", "scripts/run.py", "scripts/common.py", "scripts/scenes.py", "scripts/constants.py"]
 
 
 def stage(verbose=False):
