@@ -412,6 +412,29 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	uint4* __restrict__ next = la.tiles[(r + 1u) & 1u];
 	const bool next_is_last = r + 2 == la.n_rounds;
 	uint32_t n_eval = 0; // tile leaders: samples evaluated (statistics)
+	// Continuations are collected per wavefront and appended to the next round's list in bulk: one returning atomic per flush instead of one
+	// per surviving tile (a single counter word retires only ~90 returning atomics per microsecond chip-wide -- MI355X_MICROARCH.md
+	// "dequeue" -- which bounded round 0 at ~24k rays: 114 us for 16-wide and 32-wide tiles alike, profiles/r02_kernel_trace_summary_*.txt).
+	constexpr uint32_t PEND_CAP = 32;
+	__shared__ volatile uint32_t s_pend[4][PEND_CAP][3]; // {first sample of the continuation, samples left, ray}
+	const uint32_t wid = threadIdx.x >> 6;
+	uint32_t n_pend = 0; // wave-uniform
+	auto flush = [&]() {
+		const uint32_t e = (uint32_t)lane;
+		uint32_t first = 0, rest = 0, ray = 0, nt = 0;
+		if (e < n_pend) { first = s_pend[wid][e][0]; rest = s_pend[wid][e][1]; ray = s_pend[wid][e][2]; nt = next_is_last ? (rest + TW - 1u) / TW : 1u; }
+		uint32_t incl = nt;
+#pragma unroll
+		for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, dd, 64); if (lane >= dd) incl += y; }
+		const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+		uint32_t off = 0;
+		if (lane == 0) off = atomicAdd(la.n_tiles_ptr + r + 1, total);
+		off = (uint32_t)__shfl((int)off, 0, 64) + incl - nt;
+		const uint32_t n = next_is_last ? rest : min(rest, TW);
+		for (uint32_t j = 0; j < nt; ++j)
+			if (off + j < la.tile_cap) next[off + j] = make_uint4(first + TW * j, min(TW, n - TW * j), ray, rest - min(rest, TW * (j + 1u)));
+		n_pend = 0;
+	};
 	for (uint32_t wt = wave; wt * TPW < n_tiles; wt += n_waves) {
 		const uint32_t tile = wt * TPW + slot;
 		uint4 d = make_uint4(0u, 0u, 0u, 0u);
@@ -449,18 +472,23 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 			}
 #pragma unroll
 			for (int dd = (int)TW / 2; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64); // sum over the tile's TW lanes (hi == 0 half)
+			bool cont = false;
 			if (leader && d.w != 0u) {
 				const float T = (r == 0 ? 1.f : la.T_run[d.z]) * __expf(-od);
-				if (!(T < 0.99e-4f)) {
-					la.T_run[d.z] = T;
-					const uint32_t rest = d.w, n = next_is_last ? rest : min(rest, TW), nt = (n + TW - 1u) / TW;
-					const uint32_t off = atomicAdd(la.n_tiles_ptr + r + 1, nt);
-					for (uint32_t j = 0; j < nt; ++j)
-						if (off + j < la.tile_cap) next[off + j] = make_uint4(d.x + TW * (j + 1u), min(TW, n - TW * j), d.z, rest - min(rest, TW * (j + 1u)));
+				if (!(T < 0.99e-4f)) { la.T_run[d.z] = T; cont = true; }
+			}
+			const uint64_t cm = __ballot(cont);
+			if (cm) {
+				if (cont) {
+					const uint32_t e = n_pend + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+					s_pend[wid][e][0] = d.x + TW; s_pend[wid][e][1] = d.w; s_pend[wid][e][2] = d.z;
 				}
+				n_pend += (uint32_t)__popcll(cm);
+				if (n_pend + TPW > PEND_CAP) flush();
 			}
 		}
 	}
+	if (n_pend) flush();
 	if (hi == 0 && tcol == 0 && n_eval) atomicAdd(la.n_eval_ptr, n_eval);
 }
 
