@@ -192,10 +192,11 @@ int ngp_model_deserialize_host(ngp_model*, const void* buffer_host, uint64_t siz
 
 /* ------------------------------------------------------------------ encoding + MLP ------ */
 /* The image and SDF primitives' model (configs/image/base.json, configs/sdf/base.json): a HashGrid encoding of a 2-D / 3-D
- * position feeding one FullyFusedMLP -- tcnn::NetworkWithInputEncoding, created at testbed.cu:4354-4363 and queried through
- * Network::inference at testbed_image.cu:383,541 and testbed_sdf.cu:1658.  Forward (inference) path only in this round:
- * the fused kernel is specialised for L*F = 32 encoded features (L = 16, F = 2), 64 neurons, 2 hidden layers, <= 16 outputs.
- * Parameter order: MLP weights (row-major [out][in] per layer, output layer padded to 16 rows), then the grid [tcnn]. */
+ * position feeding one FullyFusedMLP -- tcnn::NetworkWithInputEncoding + Trainer, created at testbed.cu:4354-4383, queried through
+ * Network::inference at testbed_image.cu:383,541 / testbed_sdf.cu:1658 and trained through Trainer::training_step at
+ * testbed_image.cu:289 / testbed_sdf.cu:1557.  The fused kernels are specialised for L*F = 32 encoded features (L = 16, F = 2),
+ * 64 neurons, 2 hidden layers, <= 16 outputs (training: <= 4).  Parameter order: MLP weights (row-major [out][in] per layer,
+ * output layer padded to 16 rows), then the grid [tcnn]. */
 typedef struct ngp_encmlp_config {
 	uint32_t n_pos_dims;            /* 2 (image uv) or 3 (SDF position), inputs in [0,1]^D */
 	uint32_t n_levels;              /* 16 */
@@ -207,14 +208,58 @@ typedef struct ngp_encmlp_config {
 	uint32_t n_hidden_layers;       /* 2  */
 	uint32_t n_output_dims;         /* 3 (rgb) / 1 (distance) */
 } ngp_encmlp_config;
+/* "optimizer" block of a network config: [Ema(] ExponentialDecay( Adam ) [)]; ema_decay = 0 <=> no Ema wrapper
+ * (configs/image/base.json:5-22, configs/sdf/base.json) */
+typedef struct ngp_optimizer_config {
+	float learning_rate, beta1, beta2, epsilon, l2_reg;
+	float ema_decay;
+	uint32_t decay_start, decay_interval;
+	float decay_base;
+} ngp_optimizer_config;
 typedef struct ngp_encmlp ngp_encmlp;
 int ngp_encmlp_create(const ngp_encmlp_config*, uint64_t seed, ngp_encmlp** out);
 void ngp_encmlp_destroy(ngp_encmlp*);
 int ngp_encmlp_n_params(const ngp_encmlp*, uint64_t* n_params, uint64_t* n_mlp_params);
+int ngp_encmlp_param_ptrs(ngp_encmlp*, float** master, ngp_half** params, ngp_half** inference_params, ngp_half** gradients);
 int ngp_encmlp_set_params_host(ngp_encmlp*, const float* params_host, uint64_t n);
 int ngp_encmlp_get_params_host(ngp_encmlp*, float* params_host, uint64_t n);
-/* Network::inference: in = n positions (D floats each, `in_stride` floats apart), out = n x n_output_dims halfs, `out_stride` halfs apart */
+int ngp_encmlp_set_optimizer(ngp_encmlp*, const ngp_optimizer_config* host);   /* defaults: configs/image/base.json */
+/* Network::inference (inference parameters): in = n positions (D floats each, `in_stride` floats apart), out = n x n_output_dims halfs */
 int ngp_encmlp_inference(ngp_encmlp*, void* stream, const float* in, uint32_t in_stride, uint32_t n, ngp_half* out, uint32_t out_stride);
+/* Trainer::training_step(stream, input, target): forward, loss (NGP_LOSS_L2 | L1 | MAPE | RELATIVE_L2, tcnn losses/...: value and gradient
+ * normalised by n * n_output_dims, gradient times loss_scale), backward; parameter gradients overwritten.  loss_sum (device float,
+ * may be NULL) receives the sum of the per-element loss values; pred_out (may be NULL) the network outputs (n_output_dims halfs). */
+int ngp_encmlp_training_step(ngp_encmlp*, void* stream, const float* in, uint32_t in_stride, uint32_t n, const float* target, uint32_t target_stride,
+                             int loss_type, float loss_scale, float* loss_sum, ngp_half* pred_out, uint32_t pred_stride);
+/* the same with an external output gradient dL/dy (n_output_dims halfs per element used), like ngp_model_training_step */
+int ngp_encmlp_training_step_external(ngp_encmlp*, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride);
+int ngp_encmlp_optimizer_step(ngp_encmlp*, void* stream, float loss_scale);    /* Trainer::optimizer_step */
+float ngp_encmlp_learning_rate(const ngp_encmlp*);
+uint32_t ngp_encmlp_step(const ngp_encmlp*);
+
+/* ------------------------------------------------------------------ image trainer -------- */
+/* Testbed::m_image + train_image (testbed_image.cu:231-302) and compute_image_mse (:490-547): the image lives on the device as RGBA
+ * float32 (EDataType::Float) or half; a training batch is `batch_size` uv positions from pcg32{seed} (stratified over a
+ * sqrt(batch) x sqrt(batch) grid, stratify2_kernel :66-82) and their targets (eval_image_kernel_and_snap :175-229: nearest pixel
+ * when snap_to_pixel_centers, else bilinear; sRGB-encoded unless linear_colors). */
+typedef struct ngp_image_options {
+	int32_t snap_to_pixel_centers;   /* testbed.h:966 true  */
+	int32_t linear_colors;           /* testbed.h:967 false */
+	int32_t stratified;              /* testbed.h:970 ERandomMode::Stratified */
+	int32_t loss_type;               /* configs/image/base.json: L2 */
+	float loss_scale;                /* 128 */
+	uint32_t batch_size;             /* Testbed::m_training_batch_size; BASELINE config 0: 65536 */
+	uint64_t seed;                   /* 1337 */
+} ngp_image_options;
+typedef struct ngp_image ngp_image;
+int ngp_image_create(ngp_encmlp* model, const void* pixels_rgba_host, int32_t image_data_type /* NGP_IMAGE_HALF | NGP_IMAGE_FLOAT */, int32_t width, int32_t height,
+                     const ngp_image_options* opts_host, ngp_image** out);
+void ngp_image_destroy(ngp_image*);
+int ngp_image_train(ngp_image*, void* stream, uint32_t n_steps);               /* train_image + optimizer_step, n times, no host sync */
+int ngp_image_loss(ngp_image*, void* stream, float* loss_host);               /* loss of the last step (blocking read-back) */
+int ngp_image_mse(ngp_image*, int quantize_to_byte, float* mse_host);         /* compute_image_mse (blocking) */
+/* device pointers of the last training batch: positions (vec2) and targets (vec3); test hook */
+int ngp_image_batch_ptrs(ngp_image*, float** positions, float** targets);
 
 /* ------------------------------------------------------------------ NeRF kernels --------- */
 /* Stand-alone kernels (each mirrors one reference kernel; used by the parity tests and by

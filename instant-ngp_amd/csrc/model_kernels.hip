@@ -498,8 +498,10 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 // fragment layout (FW_R1 / FW_R2 / FW_R3) and the register-resident chain are shared; the encoding again lands directly in the
 // lane's B-operand registers: with F = 2, fragment element (s, hi, j) is feature j & 1 of level 8 s + 4 (j >> 2) + 2 hi + ((j & 3) >> 1).
 // ---------------------------------------------------------------------------------------------
+template <int D> struct CornersND { uint32_t idx[1 << D]; float w[1 << D]; };
+// [tcnn grid.h] grid_index + interpolation weights of one level for a D-dimensional position (F = 2 tables)
 template <int D>
-DEV h2 level_features2(const __half* __restrict__ table, const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x) {
+DEV void level_corners_nd(const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x, CornersND<D>& out) {
 #pragma clang fp contract(off)
 	const float scale = gm->scale[level];
 	const uint32_t res = gm->resolution[level], hs = gm->hashmap_size[level];
@@ -511,9 +513,7 @@ DEV h2 level_features2(const __half* __restrict__ table, const GridMeta* __restr
 		g[d] = (uint32_t)(int)f; p[d] = q - f;
 		cells *= res; if (cells > hs) dense = false;
 	}
-	const uint32_t* t = (const uint32_t*)table + gm->offset[level];
 	constexpr int NC = 1 << D;
-	uint32_t v[NC]; float w[NC];
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
 		float wc = 1.f;
@@ -534,12 +534,22 @@ DEV h2 level_features2(const __half* __restrict__ table, const GridMeta* __restr
 			for (int d = 0; d < D; ++d) idx ^= a[d] * primes[d];
 			idx = idx % hs;
 		}
-		v[c] = t[idx]; w[c] = wc;
+		out.idx[c] = idx; out.w[c] = wc;
 	}
+}
+template <int D>
+DEV h2 level_features2(const __half* __restrict__ table, const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x) {
+	CornersND<D> cr;
+	level_corners_nd<D>(gm, level, x, cr);
+	const uint32_t* t = (const uint32_t*)table + gm->offset[level];
+	constexpr int NC = 1 << D;
+	uint32_t v[NC];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) v[c] = t[cr.idx[c]];
 	h2 r = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
-		const _Float16 wh = (_Float16)w[c];
+		const _Float16 wh = (_Float16)cr.w[c];
 		const h2 w2 = {wh, wh};
 		r = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, v[c]), r);
 	}
@@ -1259,6 +1269,243 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Training step of the image / SDF primitives' model (Trainer::training_step, reference call sites testbed_image.cu:289,
+// testbed_sdf.cu:1557): forward with ReLU masks, loss + loss gradient [tcnn losses/l2.h, mape.h, relative_l2.h] (or an external
+// dL/dy), dgrad chain, GridEncoding backward with atomicAdd(__half2) into the gradient table -- one launch; the encoding fragments
+// and dL/dy are stashed for the weight-gradient kernel.  Lane (n, hi) owns levels 4q + 2hi + b (q = 0..3, b = 0,1), both features.
+// ---------------------------------------------------------------------------------------------
+template <int D, bool EXTERNAL_DY>
+__global__ void __launch_bounds__(256, 3) k_encmlp_train_fwd_bwd(EncTrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	h8* bw = fw + N_FW_FRAGS * 64;
+	load_frags_to_lds(fw, a.fw_frags, N_FW_FRAGS);
+	load_frags_to_lds(bw, a.bw_frags, N_BW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const uint32_t n = a.n;
+	const float n_total = (float)n * (float)a.n_out;
+	float loss_acc = 0.f;
+	for (uint32_t tile = wave; (uint64_t)tile * 32 < n; tile += n_waves) {
+		const uint32_t s_raw = tile * 32 + col;
+		const bool sv = s_raw < n;
+		const float* p = a.in + (size_t)min(s_raw, n - 1) * a.in_stride;
+		float x[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) x[d] = p[d];
+		FwdState<1> st;
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			h8 e;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const h2 f = level_features2<D>(a.table, a.gm, (uint32_t)(8 * s + 4 * (q >> 1) + 2 * hi + (q & 1)), x);
+				e[2 * q] = f[0]; e[2 * q + 1] = f[1];
+			}
+			st.rin[0][s] = e;
+			a.enc_stash[((size_t)tile * 2 + s) * 64 + lane] = __builtin_bit_cast(uint4, e);
+		}
+		fwd_rgb_l1<1>(fw, lane, st);
+		fwd_rgb_l2<1>(fw, lane, st);
+		f16v o[1];
+		fwd_rgb_l3<1>(fw, lane, st, o);
+		// ---- loss and dL/dy: outputs 0..3 live in registers 0..3 of the hi == 0 lanes ----
+		h8 dy0 = zero8();
+		if (hi == 0 && sv) {
+			h4 dy4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+			if (EXTERNAL_DY) {
+				const _Float16* g = (const _Float16*)a.dy_in + (size_t)s_raw * a.dy_stride;
+				for (uint32_t k = 0; k < a.n_out; ++k) dy4[k] = g[k];
+			} else {
+				const float* t = a.target + (size_t)s_raw * a.target_stride;
+				for (uint32_t k = 0; k < a.n_out; ++k) {
+					const float pr = (float)(_Float16)o[0][k], tg = t[k], diff = pr - tg; // the prediction is the network's half output
+					float value, grad;
+					if (a.loss_type == NGP_LOSS_MAPE) { const float sc = 1.0f / (fabsf(tg) + 0.01f); value = fabsf(diff) * sc / n_total; grad = (diff > 0.f ? 1.f : diff < 0.f ? -1.f : 0.f) * sc / n_total; }
+					else if (a.loss_type == NGP_LOSS_RELATIVE_L2) { const float sc = 1.0f / (pr * pr + 0.01f); value = diff * diff * sc / n_total; grad = 2 * diff * sc / n_total; }
+					else if (a.loss_type == NGP_LOSS_L1) { value = fabsf(diff) / n_total; grad = (diff > 0.f ? 1.f : diff < 0.f ? -1.f : 0.f) / n_total; }
+					else { value = diff * diff / n_total; grad = 2 * diff / n_total; }
+					loss_acc += value;
+					dy4[k] = (_Float16)(a.loss_scale * grad);
+				}
+				if (a.pred_out) for (uint32_t k = 0; k < a.n_out; ++k) ((_Float16*)a.pred_out)[(size_t)s_raw * a.pred_stride + k] = (_Float16)o[0][k];
+			}
+			dy0[0] = dy4[0]; dy0[1] = dy4[1]; dy0[2] = dy4[2]; dy0[3] = dy4[3];
+			a.dy_stash[s_raw] = __builtin_bit_cast(uint2, dy4);
+		}
+		// ---- dgrad chain ----
+		h8 dh[4];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			const h8 aa = lds_frag(bw, BW_R3 + mt, lane);
+			const f16v d = mfma(aa, dy0, zero16());
+			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
+			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+		}
+		h8 dh1[4];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			f16v acc = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) acc = mfma(lds_frag(bw, BW_R2 + mt * 4 + s, lane), dh[s], acc);
+			dh1[2 * mt + 0] = to_frag_masked(acc, 0, st.m1r[0] >> (16 * mt));
+			dh1[2 * mt + 1] = to_frag_masked(acc, 1, st.m1r[0] >> (16 * mt));
+		}
+		f16v denc = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) denc = mfma(lds_frag(bw, BW_R1 + s, lane), dh1[s], denc);
+		// ---- GridEncoding backward: register pair (2m, 2m+1) = features 0,1 of level (m & 1) + 4 (m >> 1) + 2 hi ----
+		if (a.grid_grad && sv) {
+#pragma unroll
+			for (int m = 0; m < 8; ++m) {
+				const uint32_t level = (uint32_t)((m & 1) + 4 * (m >> 1) + 2 * hi);
+				const float g0 = (float)(_Float16)denc[2 * m], g1 = (float)(_Float16)denc[2 * m + 1]; // dL/d(enc) is a half matrix in the reference
+				CornersND<D> cr;
+				level_corners_nd<D>(a.gm, level, x, cr);
+				__half* gt = a.grid_grad + (size_t)a.gm->offset[level] * 2;
+#pragma unroll
+				for (int c = 0; c < (1 << D); ++c) {
+					const h2 v = {(_Float16)(g0 * cr.w[c]), (_Float16)(g1 * cr.w[c])};
+					atomic_add_h2(gt + (size_t)cr.idx[c] * 2, v);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+	if (!EXTERNAL_DY && a.loss_sum) {
+#pragma unroll
+		for (int dd = 32; dd >= 1; dd >>= 1) loss_acc += __shfl_xor(loss_acc, dd, 64);
+		if (lane == 0 && loss_acc != 0.f) atomicAdd(a.loss_sum, loss_acc);
+	}
+}
+
+// Weight gradients of the 32 -> 64 -> 64 -> 16 MLP: the colour-network part of k_wgrad (same swapped-operand scheme), 8 dW tiles
+// r1:(0,1) r2:(2..5) r3:(6,7) = 128 accumulator registers per wave.
+constexpr int N_EDW_TILES = 8;
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_encmlp_wgrad(const ngp_half* __restrict__ fw_frags, const ngp_half* __restrict__ bw_frags, uint32_t n, const uint2* __restrict__ dy_stash,
+		const uint4* __restrict__ enc_stash, float* __restrict__ partials) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	h8* bw = fw + N_FW_FRAGS * 64;
+	load_frags_to_lds(fw, fw_frags, N_FW_FRAGS);
+	load_frags_to_lds(bw, bw_frags, N_BW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6;
+	const uint32_t wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
+	f16v dW[N_EDW_TILES];
+#pragma unroll
+	for (int t = 0; t < N_EDW_TILES; ++t) dW[t] = zero16();
+	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
+	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) {
+		const uint32_t s_raw = ct * 32 + col;
+		FwdState<1> st;
+		st.rin[0][0] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 0) * 64 + lane]);
+		st.rin[0][1] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 1) * 64 + lane]);
+		h8 dy0 = zero8();
+		if (hi == 0 && s_raw < n) { // out-of-range columns contribute nothing: their output gradient is zero
+			const h4 g = __builtin_bit_cast(h4, dy_stash[s_raw]);
+			dy0[0] = g[0]; dy0[1] = g[1]; dy0[2] = g[2]; dy0[3] = g[3];
+		}
+		fwd_rgb_l1<1>(fw, lane, st);
+		h8 h2_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) t = mfma(st.hb[0][s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
+			sw_to_frags(t, true, h2_sw[kt]);
+		}
+		fwd_rgb_l2<1>(fw, lane, st); // only the ReLU mask m2r is consumed below
+		h8 g_sw[2];
+		{ f16v t = mfma(dy0, I0, zero16()); sw_to_frags(t, false, g_sw); }
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[6 + kt] = mfma(g_sw[q], h2_sw[kt][q], dW[6 + kt]);
+		h8 dh[4];
+		h8 d2_sw[2][2];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			const h8 aa = lds_frag(bw, BW_R3 + mt, lane);
+			f16v d = mfma(aa, dy0, zero16());
+			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
+			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+			f16v dsw = mfma(dy0, aa, zero16());
+			sw_grad_to_frags(dsw, h2_sw[mt], d2_sw[mt]);
+		}
+		h8 h1_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 2; ++s) t = mfma(st.rin[0][s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
+			sw_to_frags(t, true, h1_sw[kt]);
+		}
+#pragma unroll
+		for (int it = 0; it < 2; ++it)
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+				for (int q = 0; q < 2; ++q) dW[2 + it * 2 + kt] = mfma(d2_sw[it][q], h1_sw[kt][q], dW[2 + it * 2 + kt]);
+		h8 d1_sw[2][2];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			f16v dsw = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) dsw = mfma(dh[s], lds_frag(bw, BW_R2 + mt * 4 + s, lane), dsw);
+			sw_grad_to_frags(dsw, h1_sw[mt], d1_sw[mt]);
+		}
+		h8 rin_sw[2];
+		{ f16v t = mfma(st.rin[0][0], I0, zero16()); t = mfma(st.rin[0][1], I1, t); sw_to_frags(t, false, rin_sw); }
+#pragma unroll
+		for (int it = 0; it < 2; ++it)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[0 + it] = mfma(d1_sw[it][q], rin_sw[q], dW[0 + it]);
+	}
+	// reduce the 4 waves of the block through LDS (re-using the fragment region), 4 tiles at a time
+	float* red = (float*)smem; // 4 tiles * 16 regs * 64 lanes * 4 B = 16 KiB
+	float* dstp = partials + (size_t)blockIdx.x * (N_EDW_TILES * 16 * 64);
+#pragma unroll
+	for (int half = 0; half < 2; ++half) {
+		__syncthreads();
+		for (int w = 0; w < 4; ++w) {
+			if (wid == w) {
+#pragma unroll
+				for (int t = 0; t < 4; ++t)
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						float* dst = red + ((size_t)t * 16 + r) * 64 + lane;
+						*dst = (w == 0 ? 0.f : *dst) + dW[half * 4 + t][r];
+					}
+			}
+			__syncthreads();
+		}
+		for (int i = threadIdx.x; i < 4 * 16 * 64; i += blockDim.x) dstp[half * 4 * 16 * 64 + i] = red[i];
+	}
+}
+__global__ void __launch_bounds__(256) k_encmlp_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
+	__shared__ float sm[4][64];
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	const uint32_t e = blockIdx.x * 64 + lane; // element of [tile][r][lane]
+	float s = 0.f;
+	for (uint32_t g = wid; g < n_partials; g += 4) s += partials[(size_t)g * (N_EDW_TILES * 16 * 64) + e];
+	sm[wid][lane] = s;
+	__syncthreads();
+	if (wid != 0) return;
+	s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+	const int t = e / (16 * 64), r = (e / 64) % 16;
+	int layer_off, R, C, it, kt;
+	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
+	else if (t < 6) { layer_off = 2048; R = 64; C = 64; it = (t - 2) >> 1; kt = (t - 2) & 1; }
+	else { layer_off = 6144; R = 16; C = 64; it = 0; kt = t - 6; }
+	const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((int)lane >> 5);
+	const int k = kt * 32 + ((int)lane & 31);
+	if (i < R && k < C) mlp_grad[layer_off + i * C + k] = __float2half(s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // fragment build (after set_params) and the fused Adam + ExponentialDecay + EMA sweep
 // ---------------------------------------------------------------------------------------------
 __global__ void k_build_frags(const __half* __restrict__ mlp_params, uint32_t n_mlp, const uint32_t* __restrict__ fw_perm, const uint32_t* __restrict__ bw_perm,
@@ -1385,6 +1632,21 @@ void launch_encmlp_inference(hipStream_t s, const GridMeta* gm, uint32_t n_pos_d
 		hipLaunchKernelGGL((k_encmlp_inference<2>), dim3(grid_dim), dim3(256), N_FW_FRAGS * 1024, s, gm, (const __half*)grid, fw_frags, in, in_stride, n, (__half*)out, out_stride, n_out);
 	else
 		hipLaunchKernelGGL((k_encmlp_inference<3>), dim3(grid_dim), dim3(256), N_FW_FRAGS * 1024, s, gm, (const __half*)grid, fw_frags, in, in_stride, n, (__half*)out, out_stride, n_out);
+}
+void launch_encmlp_train(hipStream_t s, const EncTrainArgs& a, uint32_t n_pos_dims, bool external_dy, float* wgrad_partials, uint32_t n_partials, ngp_half* mlp_grad) {
+	if (a.n == 0) return;
+	const uint32_t tiles = (a.n + 31) / 32;
+	const uint32_t grid_dim = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
+	const uint32_t lds = (N_FW_FRAGS + N_BW_FRAGS) * 1024;
+	if (n_pos_dims == 2) {
+		if (external_dy) hipLaunchKernelGGL((k_encmlp_train_fwd_bwd<2, true>), dim3(grid_dim), dim3(256), lds, s, a);
+		else hipLaunchKernelGGL((k_encmlp_train_fwd_bwd<2, false>), dim3(grid_dim), dim3(256), lds, s, a);
+	} else {
+		if (external_dy) hipLaunchKernelGGL((k_encmlp_train_fwd_bwd<3, true>), dim3(grid_dim), dim3(256), lds, s, a);
+		else hipLaunchKernelGGL((k_encmlp_train_fwd_bwd<3, false>), dim3(grid_dim), dim3(256), lds, s, a);
+	}
+	hipLaunchKernelGGL(k_encmlp_wgrad, dim3(n_partials), dim3(256), lds, s, a.fw_frags, a.bw_frags, a.n, (const uint2*)a.dy_stash, (const uint4*)a.enc_stash, wgrad_partials);
+	hipLaunchKernelGGL(k_encmlp_wgrad_reduce, dim3(N_EDW_TILES * 16), dim3(256), 0, s, wgrad_partials, n_partials, (__half*)mlp_grad);
 }
 void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out) {
 	if (n == 0) return;

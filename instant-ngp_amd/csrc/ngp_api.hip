@@ -422,11 +422,18 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 // ------------------------------------------------------------------------------------------------
 struct ngp_encmlp {
 	ngp_encmlp_config cfg{};
+	ngp_optimizer_config opt{};
 	GridMeta gm{}; GridMeta* gm_dev = nullptr;
 	uint64_t n_params = 0, n_mlp = 0;
-	std::vector<float> master;          // fp32 parameters (host; this round has no optimizer for this model)
-	ngp_half* params = nullptr;         // device: grid table in half (the MLP lives in fw_frags)
-	ngp_half* fw_frags = nullptr;       // device: N_FW_FRAGS fragments, only the FW_R1/R2/R3 slots are used
+	// Trainer state on the device, same layout conventions as ngp_model: MLP (row-major [out][in] per layer) then the grid [tcnn]
+	float* master = nullptr; ngp_half* params = nullptr; ngp_half* params_inf = nullptr; ngp_half* grads = nullptr;
+	float* adam_m = nullptr; float* adam_v = nullptr; float* ema = nullptr; uint32_t* adam_steps = nullptr;
+	uint32_t* fw_perm = nullptr; uint32_t* bw_perm = nullptr;
+	ngp_half* fw_frags = nullptr; ngp_half* bw_frags = nullptr; ngp_half* fw_frags_inf = nullptr; // only the FW_R* / BW_R* slots are used
+	ngp_half* enc_stash = nullptr; void* dy_stash = nullptr; uint32_t stash_n = 0;
+	float* wgrad_partials = nullptr; uint32_t n_partials = 0;
+	uint32_t step = 0; float lr = 1e-2f;
+	bool train_network = true, train_encoding = true;
 };
 static void build_grid_meta_nd(const ngp_encmlp_config& c, GridMeta& g) {
 	memset(&g, 0, sizeof(g));
@@ -445,21 +452,24 @@ static void build_grid_meta_nd(const ngp_encmlp_config& c, GridMeta& g) {
 	}
 	g.offset[c.n_levels] = offset;
 }
-static int encmlp_upload(ngp_encmlp* m) {
-	// MLP -> forward fragments (same element permutation as the NeRF colour network, build_perms), grid -> half table
-	static const LayerDesc layers[3] = {{64, 32, 0, 8, 0}, {64, 64, 2048, 12, 0}, {16, 64, 6144, 20, 0}};
-	std::vector<__half> frags((size_t)N_FW_FRAGS * FRAG_HALFS, __float2half(0.f));
-	for (const LayerDesc& L : layers)
+// the three layers of the 32 -> 64 -> 64 -> 16 network sit in the fragment slots of the NeRF colour network (FW_R* / BW_R*)
+static const LayerDesc kEncLayers[3] = {{64, 32, 0, 8, 6}, {64, 64, 2048, 12, 10}, {16, 64, 6144, 20, 18}};
+static void build_enc_perms(std::vector<uint32_t>& fw, std::vector<uint32_t>& bw) {
+	fw.assign(7168, 0xFFFFFFFFu); bw.assign(7168, 0xFFFFFFFFu);
+	for (const LayerDesc& L : kEncLayers)
 		for (uint32_t i = 0; i < L.R; ++i) for (uint32_t k = 0; k < L.C; ++k) {
-			const uint32_t mt = i / 32, s = k / 16, kk = k % 16, j = (kk / 8) * 4 + (kk % 4), hi = (kk % 8) / 4;
-			const uint32_t frag = L.fw_base + mt * (L.C / 16) + s, lane = hi * 32 + (i % 32);
-			frags[(size_t)(frag * 64 + lane) * 8 + j] = __float2half(m->master[L.off + i * L.C + k]);
+			const uint32_t p = L.off + i * L.C + k;
+			{ const uint32_t mt = i / 32, s = k / 16, kk = k % 16, j = (kk / 8) * 4 + (kk % 4), hi = (kk % 8) / 4;
+			  fw[p] = ((L.fw_base + mt * (L.C / 16) + s) * 64 + hi * 32 + (i % 32)) * 8 + j; }
+			{ const uint32_t mt = k / 32, s = i / 16, ii = i % 16, j = (ii / 8) * 4 + (ii % 4), hi = (ii % 8) / 4;
+			  bw[p] = ((L.bw_base + mt * ((L.R + 15) / 16) + s) * 64 + hi * 32 + (k % 32)) * 8 + j; }
 		}
-	HIPCHK(hipMemcpy(m->fw_frags, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
-	const uint64_t n_grid = m->n_params - m->n_mlp;
-	std::vector<__half> table(n_grid);
-	for (uint64_t i = 0; i < n_grid; ++i) table[i] = __float2half(m->master[m->n_mlp + i]);
-	HIPCHK(hipMemcpy(m->params, table.data(), n_grid * 2, hipMemcpyHostToDevice));
+}
+static int encmlp_refresh_half(ngp_encmlp* m, hipStream_t s) { // master -> params / params_inf + fragments
+	hipLaunchKernelGGL(k_master_to_half, dim3((uint32_t)((m->n_params + 255) / 256)), dim3(256), 0, s, m->master, (__half*)m->params, (__half*)m->params_inf, m->n_params);
+	launch_build_frags(s, m->params, (uint32_t)m->n_mlp, m->fw_perm, m->bw_perm, m->fw_frags, m->bw_frags);
+	launch_build_frags(s, m->params_inf, (uint32_t)m->n_mlp, m->fw_perm, m->bw_perm, m->fw_frags_inf, nullptr);
+	HIPCHK(hipGetLastError());
 	return 0;
 }
 extern "C" int ngp_encmlp_create(const ngp_encmlp_config* cfg, uint64_t seed, ngp_encmlp** out) {
@@ -470,47 +480,215 @@ extern "C" int ngp_encmlp_create(const ngp_encmlp_config* cfg, uint64_t seed, ng
 	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
 	ngp_encmlp* m = new ngp_encmlp();
 	m->cfg = *cfg;
+	// configs/image/base.json, configs/sdf/base.json: ExponentialDecay(Adam), no EMA
+	m->opt.learning_rate = 1e-2f; m->opt.beta1 = 0.9f; m->opt.beta2 = 0.99f; m->opt.epsilon = 1e-15f; m->opt.l2_reg = 1e-6f;
+	m->opt.ema_decay = 0.f; m->opt.decay_start = 20000; m->opt.decay_interval = 10000; m->opt.decay_base = 0.33f;
+	m->lr = m->opt.learning_rate;
 	build_grid_meta_nd(*cfg, m->gm);
 	m->n_mlp = 64 * 32 + 64 * 64 + 16 * 64;
 	m->n_params = m->n_mlp + (uint64_t)m->gm.offset[cfg->n_levels] * cfg->n_features_per_level;
-	m->master.resize(m->n_params);
+	const uint64_t P = m->n_params;
+	if (dev_alloc(&m->gm_dev, 1) || dev_alloc(&m->master, P) || dev_alloc(&m->params, P) || dev_alloc(&m->params_inf, P) || dev_alloc(&m->grads, P) ||
+		dev_alloc(&m->adam_m, P) || dev_alloc(&m->adam_v, P) || dev_alloc(&m->ema, P) || dev_alloc(&m->adam_steps, P) ||
+		dev_alloc(&m->fw_perm, 7168) || dev_alloc(&m->bw_perm, 7168) || dev_alloc(&m->fw_frags, N_FW_FRAGS * FRAG_HALFS) ||
+		dev_alloc(&m->bw_frags, N_BW_FRAGS * FRAG_HALFS) || dev_alloc(&m->fw_frags_inf, N_FW_FRAGS * FRAG_HALFS)) { delete m; return 1; }
+	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(m->grads, 0, P * 2)); HIPCHK(hipMemset(m->adam_m, 0, P * 4)); HIPCHK(hipMemset(m->adam_v, 0, P * 4));
+	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 4));
+	HIPCHK(hipMemset(m->fw_frags, 0, N_FW_FRAGS * FRAG_HALFS * 2)); HIPCHK(hipMemset(m->bw_frags, 0, N_BW_FRAGS * FRAG_HALFS * 2));
+	HIPCHK(hipMemset(m->fw_frags_inf, 0, N_FW_FRAGS * FRAG_HALFS * 2));
+	std::vector<uint32_t> fwp, bwp;
+	build_enc_perms(fwp, bwp);
+	HIPCHK(hipMemcpy(m->fw_perm, fwp.data(), fwp.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(m->bw_perm, bwp.data(), bwp.size() * 4, hipMemcpyHostToDevice));
+	m->n_partials = wgrad_n_partials();
+	if (dev_alloc(&m->wgrad_partials, (size_t)m->n_partials * 8 * 16 * 64)) { delete m; return 1; }
 	// Trainer::initialize_params [tcnn]: Xavier-uniform matrices, then U(-1e-4, 1e-4) for the grid, one pcg32{seed} stream
+	std::vector<float> init(P);
 	Rng rnd = make_rng(seed);
 	uint64_t p = 0;
-	const uint32_t shapes[3][2] = {{64, 32}, {64, 64}, {16, 64}};
-	for (const auto& sh : shapes) {
-		const float scale = std::sqrt(6.0f / (float)(sh[0] + sh[1]));
-		for (uint32_t i = 0; i < sh[0] * sh[1]; ++i) m->master[p++] = rnd.next_float() * 2.0f * scale - scale;
+	for (const LayerDesc& L : kEncLayers) {
+		const float scale = std::sqrt(6.0f / (float)(L.R + L.C));
+		for (uint32_t i = 0; i < L.R * L.C; ++i) init[p++] = rnd.next_float() * 2.0f * scale - scale;
 	}
-	for (; p < m->n_params; ++p) m->master[p] = rnd.next_float() * (1e-4f - (-1e-4f)) + (-1e-4f);
-	if (dev_alloc(&m->gm_dev, 1) || dev_alloc(&m->params, m->n_params - m->n_mlp) || dev_alloc(&m->fw_frags, N_FW_FRAGS * FRAG_HALFS)) { delete m; return 1; }
-	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
-	if (encmlp_upload(m)) return 1;
+	for (; p < P; ++p) init[p] = rnd.next_float() * (1e-4f - (-1e-4f)) + (-1e-4f);
+	HIPCHK(hipMemcpy(m->master, init.data(), P * 4, hipMemcpyHostToDevice));
+	if (encmlp_refresh_half(m, nullptr)) { delete m; return 1; }
+	HIPCHK(hipDeviceSynchronize());
 	*out = m;
 	return 0;
 }
 extern "C" void ngp_encmlp_destroy(ngp_encmlp* m) {
 	if (!m) return;
-	for (void* p : {(void*)m->gm_dev, (void*)m->params, (void*)m->fw_frags}) if (p) (void)hipFree(p);
+	void* ptrs[] = {m->gm_dev, m->master, m->params, m->params_inf, m->grads, m->adam_m, m->adam_v, m->ema, m->adam_steps, m->fw_perm, m->bw_perm, m->fw_frags, m->bw_frags,
+		m->fw_frags_inf, m->enc_stash, m->dy_stash, m->wgrad_partials};
+	for (void* p : ptrs) if (p) (void)hipFree(p);
 	delete m;
 }
 extern "C" int ngp_encmlp_n_params(const ngp_encmlp* m, uint64_t* n_params, uint64_t* n_mlp) { if (n_params) *n_params = m->n_params; if (n_mlp) *n_mlp = m->n_mlp; return 0; }
+extern "C" int ngp_encmlp_param_ptrs(ngp_encmlp* m, float** master, ngp_half** params, ngp_half** inf, ngp_half** grads) {
+	if (master) *master = m->master; if (params) *params = m->params; if (inf) *inf = m->params_inf; if (grads) *grads = m->grads; return 0;
+}
 extern "C" int ngp_encmlp_set_params_host(ngp_encmlp* m, const float* p, uint64_t n) {
 	REQUIRE(n == m->n_params, "encmlp set_params: size mismatch");
-	std::copy(p, p + n, m->master.begin());
-	return encmlp_upload(m);
+	HIPCHK(hipMemcpy(m->master, p, n * 4, hipMemcpyHostToDevice));
+	if (encmlp_refresh_half(m, nullptr)) return 1;
+	HIPCHK(hipDeviceSynchronize());
+	return 0;
 }
 extern "C" int ngp_encmlp_get_params_host(ngp_encmlp* m, float* p, uint64_t n) {
 	REQUIRE(n == m->n_params, "encmlp get_params: size mismatch");
-	std::copy(m->master.begin(), m->master.end(), p);
+	HIPCHK(hipMemcpy(p, m->master, n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+extern "C" int ngp_encmlp_set_optimizer(ngp_encmlp* m, const ngp_optimizer_config* o) {
+	REQUIRE(m && o, "encmlp set_optimizer: null argument");
+	m->opt = *o; m->lr = o->learning_rate;
 	return 0;
 }
 extern "C" int ngp_encmlp_inference(ngp_encmlp* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, ngp_half* out, uint32_t out_stride) {
 	REQUIRE(in_stride >= m->cfg.n_pos_dims && out_stride >= m->cfg.n_output_dims, "encmlp inference: strides too small");
-	launch_encmlp_inference((hipStream_t)stream, m->gm_dev, m->cfg.n_pos_dims, m->params, m->fw_frags, in, in_stride, n, out, out_stride, m->cfg.n_output_dims);
+	launch_encmlp_inference((hipStream_t)stream, m->gm_dev, m->cfg.n_pos_dims, m->params_inf + m->n_mlp, m->fw_frags_inf, in, in_stride, n, out, out_stride, m->cfg.n_output_dims);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+// Trainer::training_step(stream, input, target) (testbed_image.cu:289, testbed_sdf.cu:1557): forward, loss [tcnn l2 / mape / relative_l2 / l1],
+// backward, gradients overwritten.  `external`: dL/dy is given instead of targets (parity tests / callers with their own loss).
+static int encmlp_training_step(ngp_encmlp* m, hipStream_t s, const float* in, uint32_t in_stride, uint32_t n, const float* target, uint32_t target_stride,
+		int loss_type, float loss_scale, const ngp_half* dy, uint32_t dy_stride, float* loss_sum_dev, ngp_half* pred_out, uint32_t pred_stride) {
+	REQUIRE(m->cfg.n_output_dims <= 4, "encmlp training: at most 4 output dims (image: 3, SDF: 1)");
+	REQUIRE(in_stride >= m->cfg.n_pos_dims, "encmlp training: in_stride too small");
+	if (n > m->stash_n) {
+		HIPCHK(hipStreamSynchronize(s));
+		if (m->enc_stash) HIPCHK(hipFree(m->enc_stash)); if (m->dy_stash) HIPCHK(hipFree(m->dy_stash));
+		m->enc_stash = nullptr; m->dy_stash = nullptr; m->stash_n = 0;
+		if (dev_alloc(&m->enc_stash, (size_t)((n + 31) / 32) * 2 * 64 * 8)) return 1;
+		HIPCHK(hipMalloc(&m->dy_stash, (size_t)((n + 31) / 32) * 32 * 8));
+		m->stash_n = n;
+	}
+	HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); // GradientMode::Overwrite
+	if (loss_sum_dev) HIPCHK(hipMemsetAsync(loss_sum_dev, 0, 4, s));
+	EncTrainArgs a;
+	a.gm = m->gm_dev; a.table = (const __half*)(m->params + m->n_mlp); a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags;
+	a.in = in; a.in_stride = in_stride; a.n = n; a.target = target; a.target_stride = target_stride; a.n_out = m->cfg.n_output_dims;
+	a.loss_type = loss_type; a.loss_scale = loss_scale; a.dy_in = dy; a.dy_stride = dy_stride;
+	a.grid_grad = m->train_encoding ? (__half*)(m->grads + m->n_mlp) : nullptr;
+	a.enc_stash = (uint4*)m->enc_stash; a.dy_stash = (uint2*)m->dy_stash; a.loss_sum = loss_sum_dev; a.pred_out = pred_out; a.pred_stride = pred_stride;
+	launch_encmlp_train(s, a, m->cfg.n_pos_dims, dy != nullptr, m->wgrad_partials, m->n_partials, m->grads);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_encmlp_training_step(ngp_encmlp* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const float* target, uint32_t target_stride,
+		int loss_type, float loss_scale, float* loss_sum, ngp_half* pred_out, uint32_t pred_stride) {
+	REQUIRE(target && target_stride >= m->cfg.n_output_dims, "encmlp training_step: targets missing / stride too small");
+	REQUIRE(loss_type == NGP_LOSS_L2 || loss_type == NGP_LOSS_L1 || loss_type == NGP_LOSS_MAPE || loss_type == NGP_LOSS_RELATIVE_L2, "encmlp training_step: loss must be L2, L1, MAPE or RelativeL2");
+	return encmlp_training_step(m, (hipStream_t)stream, in, in_stride, n, target, target_stride, loss_type, loss_scale, nullptr, 0, loss_sum, pred_out, pred_stride);
+}
+extern "C" int ngp_encmlp_training_step_external(ngp_encmlp* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride) {
+	REQUIRE(dL_dy && dy_stride >= m->cfg.n_output_dims, "encmlp training_step_external: dL/dy missing / stride too small");
+	return encmlp_training_step(m, (hipStream_t)stream, in, in_stride, n, nullptr, 0, NGP_LOSS_L2, 1.f, dL_dy, dy_stride, nullptr, nullptr, 0);
+}
+extern "C" int ngp_encmlp_optimizer_step(ngp_encmlp* m, void* stream, float loss_scale) {
+	++m->step;
+	AdamArgs a;
+	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
+	a.beta1 = m->opt.beta1; a.beta2 = m->opt.beta2; a.eps = m->opt.epsilon; a.l2_reg = m->opt.l2_reg;
+	a.log_beta1 = std::log(m->opt.beta1); a.log_beta2 = std::log(m->opt.beta2);
+	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
+	const float d = m->opt.ema_decay; // 0 without an Ema wrapper: the inference parameters then equal the parameters
+	a.ema_decay = d;
+	a.ema_debias_old = 1 - std::pow(d, (float)(m->step - 1));
+	a.ema_debias_new = 1 / (1 - std::pow(d, (float)m->step));
+	a.master = m->master; a.params = m->params; a.params_inf = m->params_inf; a.grads = m->grads;
+	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema;
+	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
+	launch_optimizer_step((hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	if (m->opt.decay_interval > 0 && m->step >= m->opt.decay_start && m->step % m->opt.decay_interval == 0) m->lr *= m->opt.decay_base;
+	return 0;
+}
+extern "C" float ngp_encmlp_learning_rate(const ngp_encmlp* m) { return m->lr; }
+extern "C" uint32_t ngp_encmlp_step(const ngp_encmlp* m) { return m->step; }
+
+// ------------------------------------------------------------------------------------------------
+// image trainer: Testbed::m_image, train_image (testbed_image.cu:231-302), compute_image_mse (:490-547)
+// ------------------------------------------------------------------------------------------------
+struct ngp_image {
+	ngp_encmlp* model = nullptr;
+	ngp_image_options opt{};
+	void* pixels = nullptr; int type = NGP_IMAGE_FLOAT; int width = 0, height = 0;
+	float* positions = nullptr; float* targets = nullptr; uint32_t batch_cap = 0;
+	float* loss_sum = nullptr; double* mse_sum = nullptr; ngp_half* pred = nullptr;
+	Rng rng; uint32_t training_step = 0;
+};
+extern "C" int ngp_image_create(ngp_encmlp* model, const void* pixels_host, int32_t type, int32_t w, int32_t h, const ngp_image_options* o, ngp_image** out) {
+	REQUIRE(model && pixels_host && o && out, "ngp_image_create: null argument");
+	REQUIRE(model->cfg.n_pos_dims == 2 && model->cfg.n_output_dims == 3, "ngp_image_create: the model must map 2-D positions to 3 outputs (network_dims_image, testbed_image.cu:30-36)");
+	REQUIRE((type == NGP_IMAGE_FLOAT || type == NGP_IMAGE_HALF) && w > 1 && h > 1, "ngp_image_create: RGBA float32 / half images of at least 2x2 pixels");
+	REQUIRE(o->batch_size > 0 && o->batch_size % 32 == 0, "ngp_image_create: batch size must be a positive multiple of 32");
+	ngp_image* t = new ngp_image();
+	t->model = model; t->opt = *o; t->type = type; t->width = w; t->height = h;
+	t->rng = make_rng(o->seed);
+	const size_t bytes = (size_t)w * h * 4 * (type == NGP_IMAGE_FLOAT ? 4 : 2);
+	t->batch_cap = std::max<uint32_t>(o->batch_size, 1u << 20); // compute_image_mse evaluates batches of 2^20 pixels
+	if (dev_alloc((char**)&t->pixels, bytes) || dev_alloc(&t->positions, (size_t)t->batch_cap * 2) || dev_alloc(&t->targets, (size_t)t->batch_cap * 3) ||
+		dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->mse_sum, 1) || dev_alloc(&t->pred, (size_t)t->batch_cap * 4)) { delete t; return 1; }
+	HIPCHK(hipMemcpy(t->pixels, pixels_host, bytes, hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(t->loss_sum, 0, 4));
+	*out = t;
+	return 0;
+}
+extern "C" void ngp_image_destroy(ngp_image* t) {
+	if (!t) return;
+	(void)hipDeviceSynchronize();
+	for (void* p : {t->pixels, (void*)t->positions, (void*)t->targets, (void*)t->loss_sum, (void*)t->mse_sum, (void*)t->pred}) if (p) (void)hipFree(p);
+	delete t;
+}
+static ImageBatchArgs image_args(ngp_image* t, uint32_t n) {
+	ImageBatchArgs a;
+	a.pixels = t->pixels; a.image_data_type = t->type; a.width = t->width; a.height = t->height; a.n = n; a.rng = pod(t->rng); a.stratify_log2 = 0;
+	a.snap_to_pixel_centers = t->opt.snap_to_pixel_centers; a.linear_colors = t->opt.linear_colors; a.positions = t->positions; a.targets = t->targets;
+	return a;
+}
+extern "C" int ngp_image_train(ngp_image* t, void* stream, uint32_t n_steps) {
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n = t->opt.batch_size;
+	for (uint32_t i = 0; i < n_steps; ++i) {
+		ImageBatchArgs a = image_args(t, n);
+		if (t->opt.stratified) { // "Can't stratify a non-pot / non-square batch size" (testbed_image.cu:252-259): plain uniform positions then
+			uint32_t l2 = 0; while ((1u << l2) < n) ++l2;
+			if ((1u << l2) == n && l2 % 2 == 0) a.stratify_log2 = l2;
+		}
+		launch_image_generate_batch(s, a);
+		t->rng.advance((uint64_t)n * 2ull); // generate_random_uniform advances the generator by the number of elements [tcnn]
+		if (encmlp_training_step(t->model, s, t->positions, 2, n, t->targets, 3, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
+		if (ngp_encmlp_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
+		++t->training_step;
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_image_loss(ngp_image* t, void* stream, float* loss_host) {
+	HIPCHK(hipMemcpyAsync(loss_host, t->loss_sum, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+	return 0;
+}
+extern "C" int ngp_image_mse(ngp_image* t, int quantize_to_byte, float* mse_host) {
+	const uint32_t n_elements = (uint32_t)t->width * (uint32_t)t->height, max_batch = 1u << 20;
+	HIPCHK(hipMemsetAsync(t->mse_sum, 0, 8, nullptr));
+	for (uint32_t offset = 0; offset < n_elements; offset += max_batch) {
+		const uint32_t n = std::min(max_batch, n_elements - offset);
+		ImageBatchArgs a = image_args(t, n);
+		launch_image_pixel_batch(nullptr, a, offset);
+		if (ngp_encmlp_inference(t->model, nullptr, t->positions, 2, n, t->pred, 4)) return 1;
+		launch_image_mse(nullptr, n, t->targets, t->pred, 4, quantize_to_byte, t->mse_sum);
+	}
+	double sum = 0;
+	HIPCHK(hipMemcpy(&sum, t->mse_sum, 8, hipMemcpyDeviceToHost));
+	*mse_host = (float)(sum / (double)n_elements);
+	return 0;
+}
+extern "C" int ngp_image_batch_ptrs(ngp_image* t, float** positions, float** targets) { if (positions) *positions = t->positions; if (targets) *targets = t->targets; return 0; }
 
 extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
 	++m->step; // Adam::step: ++m_current_step

@@ -131,6 +131,18 @@ void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp
 // encoding (D = 2 / 3, L = 16, F = 2) + MLP 32 -> 64 -> 64 -> 16, forward only (image / SDF primitives' model)
 void launch_encmlp_inference(hipStream_t s, const GridMeta* gm_dev, uint32_t n_pos_dims, const ngp_half* grid, const ngp_half* fw_frags, const float* in, uint32_t in_stride,
 	uint32_t n, ngp_half* out, uint32_t out_stride, uint32_t n_out);
+// training step of the image / SDF model (k_encmlp_train_fwd_bwd -> k_encmlp_wgrad -> k_encmlp_wgrad_reduce)
+struct EncTrainArgs {
+	const GridMeta* gm; const __half* table; const ngp_half* fw_frags; const ngp_half* bw_frags;
+	const float* in; uint32_t in_stride, n;
+	const float* target; uint32_t target_stride, n_out;     // internal loss: targets (n_out floats per sample) ...
+	int loss_type; float loss_scale;
+	const ngp_half* dy_in; uint32_t dy_stride;              // ... or an external dL/dy (n_out halfs per sample used)
+	__half* grid_grad;                                      // encoding gradient table (nullptr: the encoding is not trained)
+	uint4* enc_stash; uint2* dy_stash;                      // for the weight-gradient kernel
+	float* loss_sum; ngp_half* pred_out; uint32_t pred_stride; // optional: sum of the per-element loss values, network outputs
+};
+void launch_encmlp_train(hipStream_t s, const EncTrainArgs& a, uint32_t n_pos_dims, bool external_dy, float* wgrad_partials, uint32_t n_partials, ngp_half* mlp_grad);
 void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out);
 void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw);
 uint32_t wgrad_n_partials();
@@ -165,6 +177,17 @@ struct AdamArgs {
 	ngp_half* fw_frags; ngp_half* bw_frags; ngp_half* fw_frags_inf; 
 };
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
+
+// ---- image primitive (image_kernels.hip) ------------------------------------------------------
+struct ImageBatchArgs {
+	const void* pixels; int image_data_type; int width, height;
+	uint32_t n; ngp_pcg32 rng; uint32_t stratify_log2; // 0 = plain uniform positions
+	int snap_to_pixel_centers, linear_colors;
+	float* positions; float* targets; // vec2 / vec3 per sample
+};
+void launch_image_generate_batch(hipStream_t s, const ImageBatchArgs& a);
+void launch_image_pixel_batch(hipStream_t s, const ImageBatchArgs& a, uint32_t offset);
+void launch_image_mse(hipStream_t s, uint32_t n, const float* targets, const ngp_half* pred, uint32_t pred_stride, int quantize, double* sum);
 
 // ---- renderer (render_kernels.hip) ------------------------------------------------------------
 constexpr uint32_t RENDER_MAX_CHUNKS = 32; // 2048 lattice points per ray

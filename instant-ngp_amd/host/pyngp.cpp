@@ -7,6 +7,7 @@
 #include <pybind11/eval.h>
 
 #include "testbed.hpp"
+#include "exr_lite.hpp"
 
 namespace py = pybind11;
 using namespace ngp_host;
@@ -28,6 +29,14 @@ PYBIND11_MODULE(pyngp, m) {
 	m.def("_msgpack_repack", [](py::bytes data, bool input_compressed, bool output_compressed) { return py::bytes(msgpack_repack(std::string(data), input_compressed, output_compressed)); },
 		py::arg("data"), py::arg("input_compressed") = false, py::arg("output_compressed") = false);
 
+	// not part of the reference API: the host's EXR reader (image primitive data path), RGBA float32 [h][w][4]
+	m.def("read_exr", [](const std::string& path) {
+		int w = 0, h = 0; std::vector<float> px;
+		exr_lite::read_rgba(path, w, h, px);
+		py::array_t<float> out({h, w, 4});
+		std::memcpy(out.mutable_data(), px.data(), px.size() * sizeof(float));
+		return out;
+	});
 	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
 		.value("Volume", ETestbedMode::Volume).value("None", ETestbedMode::None).export_values();
 	py::enum_<ETrainMode>(m, "TrainMode").value("Nerf", ETrainMode::Nerf).value("Rfl", ETrainMode::Rfl).value("RflRelax", ETrainMode::RflRelax).export_values();

@@ -54,6 +54,24 @@ class EncMlpConfig(C.Structure):
                 ("base_resolution", u32), ("per_level_scale", f32), ("n_neurons", u32), ("n_hidden_layers", u32), ("n_output_dims", u32)]
 
 
+class OptimizerConfig(C.Structure):
+    _fields_ = [("learning_rate", f32), ("beta1", f32), ("beta2", f32), ("epsilon", f32), ("l2_reg", f32), ("ema_decay", f32),
+                ("decay_start", u32), ("decay_interval", u32), ("decay_base", f32)]
+
+
+class ImageOptions(C.Structure):
+    _fields_ = [("snap_to_pixel_centers", i32), ("linear_colors", i32), ("stratified", i32), ("loss_type", i32), ("loss_scale", f32),
+                ("batch_size", u32), ("seed", u64)]
+
+
+def default_image_options(**kw):
+    """Testbed::m_image.training defaults (testbed.h:966-970), configs/image/base.json loss, BASELINE config 0 batch"""
+    o = ImageOptions(snap_to_pixel_centers=1, linear_colors=0, stratified=1, loss_type=LOSS_L2, loss_scale=128.0, batch_size=1 << 16, seed=1337)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 def _auto_per_level_scale(desired_resolution, base_resolution, n_levels):
     """testbed.cu:4249-4253 in the reference's float arithmetic: std::exp(std::log(desired / base) / (n_levels - 1))"""
     import numpy as np
@@ -139,6 +157,8 @@ def load_hip():
         _lib.ngp_model_learning_rate.restype = f32
         _lib.ngp_model_step.restype = u32
         _lib.ngp_model_serialized_size.restype = u64
+        _lib.ngp_encmlp_learning_rate.restype = f32
+        _lib.ngp_encmlp_step.restype = u32
     return _lib
 
 

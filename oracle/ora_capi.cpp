@@ -182,6 +182,12 @@ API int ora_encmlp_inference(void* h, const float* in, uint32_t stride, uint32_t
 API int ora_encmlp_training_step(void* h, const float* in, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
 	TRY(((EncMlp*)h)->training_step(in, stride, n, dL_dy, dy_stride))
 }
+API int ora_encmlp_optimizer_step(void* h, float loss_scale) { TRY(((EncMlp*)h)->optimizer_step(loss_scale)) }
+API void ora_encmlp_set_optimizer(void* h, const ngp_optimizer_config* o) { ((EncMlp*)h)->opt = *o; ((EncMlp*)h)->lr = o->learning_rate; }
+API uint16_t* ora_encmlp_params(void* h) { return ((EncMlp*)h)->params.data(); }
+API void ora_image_generate_batch(const float* rgba, int w, int h, uint32_t n, ngp_pcg32 rng, int stratified, int snap, int linear_colors, float* positions, float* targets) {
+	image_generate_batch(rgba, w, h, n, Pcg32(rng), stratified != 0, snap != 0, linear_colors != 0, positions, targets);
+}
 API uint16_t* ora_encmlp_gradients(void* h) { return ((EncMlp*)h)->grads.data(); }
 API float ora_encmlp_loss_and_gradient(void* h, int mape, const uint16_t* pred, uint32_t pred_stride, const float* target, uint32_t target_stride, uint32_t n, float loss_scale,
 		uint16_t* dL_dy) {

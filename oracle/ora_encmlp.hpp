@@ -86,6 +86,33 @@ struct EncMlp {
 		sync_half();
 	}
 	void sync_half() { for (size_t i = 0; i < n_params; ++i) params[i] = f2h(params_fp[i]); }
+	// Trainer::optimizer_step: ExponentialDecay( Adam ) of configs/image|sdf/base.json (no Ema wrapper) -- the same per-parameter
+	// arithmetic as Model::optimizer_step [tcnn optimizers/adam.h, exponential_decay.h]
+	ngp_optimizer_config opt{1e-2f, 0.9f, 0.99f, 1e-15f, 1e-6f, 0.f, 20000, 10000, 0.33f};
+	std::vector<float> adam_m, adam_v; std::vector<uint32_t> adam_steps; uint32_t step = 0; float lr = 1e-2f;
+	void optimizer_step(float loss_scale) {
+		if (adam_m.empty()) { adam_m.assign(n_params, 0.f); adam_v.assign(n_params, 0.f); adam_steps.assign(n_params, 0); lr = opt.learning_rate; }
+		++step;
+		const float beta1 = opt.beta1, beta2 = opt.beta2, eps = opt.epsilon, l2 = opt.l2_reg;
+		#pragma omp parallel for schedule(static)
+		for (int64_t i = 0; i < (int64_t)n_params; ++i) {
+			float gradient = h2f(grads[i]) / loss_scale;
+			const bool matrix = (size_t)i < n_mlp;
+			if (!matrix && gradient == 0) continue;
+			const float weight_fp = params_fp[i];
+			if (matrix) gradient += l2 * weight_fp;
+			const float gradient_sq = gradient * gradient;
+			const float first = adam_m[i] = beta1 * adam_m[i] + (1 - beta1) * gradient;
+			const float second = adam_v[i] = beta2 * adam_v[i] + (1 - beta2) * gradient_sq;
+			float learning_rate = lr;
+			const uint32_t current_step = ++adam_steps[i];
+			learning_rate *= std::sqrt(1 - std::pow(beta2, (float)current_step)) / (1 - std::pow(beta1, (float)current_step));
+			const float effective_lr = std::fmin(std::fmax(learning_rate / (std::sqrt(second) + eps), 0.0f), std::numeric_limits<float>::max());
+			params_fp[i] = weight_fp - effective_lr * first;
+			params[i] = f2h(params_fp[i]);
+		}
+		if (opt.decay_interval > 0 && step >= opt.decay_start && step % opt.decay_interval == 0) lr *= opt.decay_base;
+	}
 	std::vector<uint16_t> grads; // Trainer::gradients, written by training_step (GradientMode::Overwrite)
 
 	// Trainer::training_step with an external dL/dy (n x 16 halfs, only the first n_output_dims used): forward with saved activations,
@@ -169,5 +196,51 @@ struct EncMlp {
 		}
 	}
 };
+
+// -------------------------------------------------------------------------------------------------
+// image primitive: training batch of train_image (testbed_image.cu:231-302): uniform positions from the pcg32 stream (element e <-
+// draw e [tcnn generate_random_uniform, mapping from memory]), stratify2_kernel (:66-82), eval_image_kernel_and_snap<float, 3> (:175-229)
+// -------------------------------------------------------------------------------------------------
+inline void image_eval_and_snap(const float* rgba, int w, int h, bool snap, bool linear_colors, float& px, float& py, float* rgb) {
+	auto read_val = [&](int x, int y, float* o) {
+		const float* p = rgba + ((size_t)y * w + x) * 4;
+		for (int k = 0; k < 4; ++k) o[k] = p[k];
+		if (!linear_colors) for (int k = 0; k < 3; ++k) o[k] = linear_to_srgb(o[k]);
+	};
+	const float rx = (float)w, ry = (float)h;
+	float v[4];
+	if (snap) {
+		const int ix = (int)std::floor(px * rx), iy = (int)std::floor(py * ry);
+		px = ((float)ix + 0.5f) / rx; py = ((float)iy + 0.5f) / ry;
+		read_val(clampi(ix, 0, w - 1), clampi(iy, 0, h - 1), v);
+	} else {
+		const float fx = std::fmin(std::fmax(px * rx - 0.5f, 0.0f), rx - (1.0f + 1e-4f)), fy = std::fmin(std::fmax(py * ry - 0.5f, 0.0f), ry - (1.0f + 1e-4f));
+		const int ix = (int)fx, iy = (int)fy;
+		const float wx = fx - (float)ix, wy = fy - (float)iy;
+		const int x0 = clampi(ix, 0, w - 2), y0 = clampi(iy, 0, h - 2);
+		float v00[4], v10[4], v01[4], v11[4];
+		read_val(x0, y0, v00); read_val(x0 + 1, y0, v10); read_val(x0, y0 + 1, v01); read_val(x0 + 1, y0 + 1, v11);
+		for (int k = 0; k < 4; ++k) v[k] = (1 - wx) * (1 - wy) * v00[k] + (wx) * (1 - wy) * v10[k] + (1 - wx) * (wy) * v01[k] + (wx) * (wy) * v11[k];
+	}
+	rgb[0] = v[0]; rgb[1] = v[1]; rgb[2] = v[2];
+}
+inline void image_generate_batch(const float* rgba, int w, int h, uint32_t n, const Pcg32& rng_in, bool stratified, bool snap, bool linear_colors, float* positions, float* targets) {
+	uint32_t l2 = 0; while ((1u << l2) < n) ++l2;
+	const bool strat = stratified && (1u << l2) == n && l2 % 2 == 0;
+	#pragma omp parallel for schedule(static)
+	for (int64_t ii = 0; ii < (int64_t)n; ++ii) {
+		const uint32_t i = (uint32_t)ii;
+		Pcg32 rng = rng_in;
+		rng.advance((int64_t)i * 2);
+		float px = rng.next_float(), py = rng.next_float();
+		if (strat) {
+			const uint32_t log2_size = l2 / 2, size = 1u << log2_size, in_batch = i & ((1u << l2) - 1u);
+			const uint32_t x = in_batch & (size - 1u), y = in_batch >> log2_size;
+			px = px / (float)size + ((float)x / (float)size); py = py / (float)size + ((float)y / (float)size);
+		}
+		image_eval_and_snap(rgba, w, h, snap, linear_colors, px, py, targets + (size_t)i * 3);
+		positions[(size_t)i * 2] = px; positions[(size_t)i * 2 + 1] = py;
+	}
+}
 
 } // namespace ora

@@ -51,6 +51,7 @@ def load():
         L.ora_encmlp_gradients.restype = vp; L.ora_encmlp_gradients.argtypes = [vp]
         L.ora_encmlp_loss_and_gradient.restype = f32; L.ora_encmlp_loss_and_gradient.argtypes = [vp, C.c_int, vp, u32, vp, u32, u32, f32, vp]
         L.ora_encmlp_destroy.argtypes = [vp]; L.ora_encmlp_sync_half.argtypes = [vp]
+        L.ora_encmlp_optimizer_step.argtypes = [vp, f32]; L.ora_encmlp_params.restype = vp; L.ora_encmlp_params.argtypes = [vp]
         for name in ("ora_model_destroy", "ora_nerf_destroy", "ora_model_sync_half", "ora_nerf_update_mean_and_bitfield"):
             getattr(L, name).argtypes = [vp]
         _lib = L
