@@ -126,7 +126,7 @@ def test_load_snapshot_validates_before_touching_the_gpu():
         t.load_snapshot(write("c.ingp", {"snapshot": dict(good, mode="sdf")}, compress=True))
     with pytest.raises(RuntimeError, match="Incompatible grid size"):
         t.load_snapshot(write("d.ingp", {"snapshot": dict(good, density_grid_size=64)}, compress=True))
-    with pytest.raises(RuntimeError, match="load the training data first"):
+    with pytest.raises(RuntimeError, match="no dataset metadata and no training data"):
         t.load_snapshot(write("e.ingp", {"snapshot": good}, compress=True))
     with pytest.raises(RuntimeError):
         t.load_snapshot(write("f.ingp", {"snapshot": good}))  # .ingp must be zlib framed
