@@ -19,6 +19,9 @@ GROUPS = {
     "tcc": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_ATOMIC_sum"],
     "tcc2": ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_ATOMIC_sum", "TCC_READ_sum"],
     "grbm": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
+    # memory-side request sizes (calibrates FETCH_SIZE / WRITE_SIZE, which tally every request at 64 B: MI355X_MICROARCH.md "HBM")
+    "rdsize": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
+    "wrsize": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_ATOMIC_sum"],
     # MFMA utilisation (north_star: "evidenced by rocprof HBM GB/s and MFMA utilisation"): busy cycles of the matrix pipe vs the SQ's, MFMA instruction / op counts
     "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"],
 }
