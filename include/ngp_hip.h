@@ -111,6 +111,9 @@ typedef struct ngp_nerf_options {
 	/* data-parallel sharding (new): this rank marches global rays
 	 * [rank*R/world, (rank+1)*R/world) of the same global stream */
 	uint32_t rank, world_size;
+	/* ETrainMode (testbed.h:822; python_api.cu TrainMode): 0 Nerf, 1 Rfl, 2 RflRelax -- the radiance-field-loss gradients of
+	 * fused_kernels/train_nerf.cuh:391-410, here evaluated by the unfused K1/K2/K3 pipeline (no JIT needed) */
+	int32_t train_mode;
 } ngp_nerf_options;
 
 /* Counters read back by the host (NerfCounters, testbed.h / testbed_nerf.cu:2669-2702). */
@@ -406,6 +409,8 @@ int ngp_nerf_set_rng(ngp_nerf*, const ngp_pcg32* rng);
 int ngp_nerf_set_k2_params(ngp_nerf*, uint32_t rounds, uint32_t tile_w);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);
+/* train mode of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options) */
+int ngp_debug_set_train_mode(int mode);
 /* layout of the hashed levels' binned gradient scatter (csrc/model_kernels.hip k_grad_bin / k_grad_accumulate): table entries per
  * chunk = 2^chunk_log2 (11 or 12), one block per chunk (split = 0) or per (chunk, feature pair) (split = 1), list capacity override
  * in records (0 = twice the mean; a small value forces the list-overflow path for the tests); process-wide */

@@ -144,15 +144,23 @@ constexpr uint32_t K1_GROUP = 8;          // lattice chunks tested per k1_count 
 constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
 constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
 
+static __device__ __forceinline__ uint32_t k1_slot_to_ray(uint32_t li, uint32_t n_local) { return (uint32_t)(((uint64_t)li * K1_SCRAMBLE_PRIME) % n_local); }
+
 __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__ rs) {
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
-	const uint32_t i = ray_begin + li;
-	if (i >= ray_end) return;
+	if (li >= ray_end - ray_begin) return;
+	// Slot li marches global ray ray_begin + pi(li), pi = a fixed bijection of [0, n_local) (multiplication by a prime > 2^18 x world):
+	// slots are filled in slot order, so the rays that K1's sample cap (testbed_nerf.cu:813-815) and K3's batch clamp drop -- the LAST
+	// slots -- are spread evenly over the ray range.  In plain index order they were always the rays of the last image(s)
+	// (img = i * n_img / R): the reference drops whichever rays reserve their spans last (atomic order), i.e. a random subset, and the
+	// index-ordered variant cost 0.2 - 0.35 dB of held-out PSNR at 5k - 20k steps (profiles/r02_bench_ab_psnr_before_scramble.json).
+	const uint32_t i = ray_begin + k1_slot_to_ray(li, ray_end - ray_begin);
 	const Box aabb(a.aabb);
 	RaySetup r;
+	r.ray_index = i;
 	r.o[0] = r.o[1] = r.o[2] = 0.f; r.d[0] = r.d[1] = 0.f; r.d[2] = 1.f; r.startt = 0.f; r.nprime = 0.f; r.count = 0; r.flags = 0;
 	for (int k = 0; k < 6; ++k) r.tgt[k] = 0.f;
 	uint32_t img = image_idx(i, n_rays, a.n_images);
@@ -441,7 +449,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 	const float* cin = nullptr;
 	const __half* no = nullptr;
 	float T = 1.f;
-	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f);
+	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), loss_bg = mk3(0.f);
 	f3 rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
 	if (active) {
 		numsteps = a.numsteps_inout[i * 2 + 0];
@@ -449,18 +457,6 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		cin = a.coords_in + (size_t)base * 7;
 		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
 		ray_o = ld3(a.rays_in[i].o);
-		const float EPSILON = 1e-4f;
-		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
-			if (T < EPSILON) break;
-			const __half* lo = no + (size_t)compacted_numsteps * a.output_stride;
-			const f3 rgb = mk3(act_rgb(__half2float(lo[0]), a.rgb_activation), act_rgb(__half2float(lo[1]), a.rgb_activation), act_rgb(__half2float(lo[2]), a.rgb_activation));
-			const float dt = unwarp_dt(cin[(size_t)compacted_numsteps * 7 + 3]);
-			const float density = act_density(__half2float(lo[3]), a.density_activation);
-			const float alpha = 1.f - __expf(-density * dt);
-			const float weight = alpha * T;
-			rgb_ray = rgb_ray + weight * rgb;
-			T *= (1.f - alpha);
-		}
 		const uint32_t ray_idx = a.ray_indices_in[i];
 		Rng rng(a.rng);
 		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
@@ -480,7 +476,23 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
 			else rgbtarget = background_color;
 		}
-		if (compacted_numsteps == numsteps) rgb_ray = rgb_ray + T * background_color;
+		const float EPSILON = 1e-4f;
+		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
+			if (T < EPSILON) break;
+			const __half* lo = no + (size_t)compacted_numsteps * a.output_stride;
+			const f3 rgb = mk3(act_rgb(__half2float(lo[0]), a.rgb_activation), act_rgb(__half2float(lo[1]), a.rgb_activation), act_rgb(__half2float(lo[2]), a.rgb_activation));
+			const float dt = unwarp_dt(cin[(size_t)compacted_numsteps * 7 + 3]);
+			const float density = act_density(__half2float(lo[3]), a.density_activation);
+			const float alpha = 1.f - __expf(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray = rgb_ray + weight * rgb;
+			if (a.train_mode == 1) { f3 ll, lg2; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lg2); loss_bg = loss_bg + weight * ll; }
+			T *= (1.f - alpha);
+		}
+		if (compacted_numsteps == numsteps) {
+			rgb_ray = rgb_ray + T * background_color;
+			if (a.train_mode == 1) { f3 ll, lg2; loss_and_gradient(rgbtarget, background_color, a.loss_type, ll, lg2); loss_bg = loss_bg + T * ll; }
+		}
 	}
 
 	// span reservation in the compacted batch: one atomic per wavefront
@@ -505,8 +517,8 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		my_loss = mean_loss / (float)n_rays;
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
-		const float output_l1_reg_density = *a.mean_density_ptr < MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
-		f3 rgb_ray2 = mk3(0.f);
+		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
+		f3 rgb_ray2 = mk3(0.f), loss_bg2 = mk3(0.f);
 		T = 1.f;
 		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
 			const float* ci = cin + (size_t)j * 7;
@@ -525,12 +537,25 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			rgb_ray2 = rgb_ray2 + weight * rgb;
 			T *= (1.f - alpha);
 			const f3 suffix = rgb_ray - rgb_ray2;
-			const f3 dloss_by_drgb = weight * lgrad;
+			f3 dloss_by_drgb = weight * lgrad;
+			const float density_derivative = act_density_d(l3, a.density_activation);
+			float dloss_by_dmlp = density_derivative * (dt * (dot3(lgrad, T * rgb - suffix) + 0.0f));
+			if (a.train_mode == 1) { // Rfl, fused_kernels/train_nerf.cuh:391-396
+				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
+				loss_bg2 = loss_bg2 + weight * ll;
+				dloss_by_drgb = weight * lgl;
+				const f3 v = T * ll - (loss_bg - loss_bg2);
+				dloss_by_dmlp = density_derivative * (dt * (v.x + v.y + v.z));
+			} else if (a.train_mode == 2) { // RflRelax, train_nerf.cuh:397-405
+				const f3 rgb_bg = suffix / fmaxf(1e-6f, T);
+				const f3 rgb_lerp = (1 - alpha) * rgb_bg + alpha * rgb;
+				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb_lerp, a.loss_type, ll, lgl);
+				dloss_by_drgb = weight * lgl;
+				dloss_by_dmlp = density_derivative * (dt * (dot3(lgl, T * rgb - suffix) + 0.0f));
+			}
 			const float d0 = loss_scale * (dloss_by_drgb.x * act_rgb_d(l0, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l0));
 			const float d1 = loss_scale * (dloss_by_drgb.y * act_rgb_d(l1, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l1));
 			const float d2 = loss_scale * (dloss_by_drgb.z * act_rgb_d(l2, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l2));
-			const float density_derivative = act_density_d(l3, a.density_activation);
-			const float dloss_by_dmlp = density_derivative * (dt * (dot3(lgrad, T * rgb - suffix) + 0.0f));
 			const float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f);
 			__half* d = dl + (size_t)j * a.dloss_stride;
 			d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3);
@@ -593,7 +618,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	uint32_t numsteps = 0, base = 0, compacted = 0;
 	const float* cin = nullptr;
 	const __half* no = nullptr;
-	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
+	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color), loss_bg = mk3(0.f);
 	float T_final = 1.f;
 	// first 64 samples of the ray stay in registers for the adjoint pass (most rays have <= 64 samples)
 	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f, k_cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -626,6 +651,17 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			rng.advance(1); // motionblur_time
 			if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 			tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+			// target colour and background: identical to the sequential kernel (uniform across the wave); needed BEFORE the sample pass by the Rfl mode
+			background_color = srgb_to_linear3(background_color);
+			const f3 trgb = mk3(tex.x, tex.y, tex.z);
+			if (a.linear_colors || !a.color_space_srgb) {
+				rgbtarget = trgb + (1.0f - tex.w) * background_color;
+				if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+			} else {
+				background_color = linear_to_srgb3(background_color);
+				if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
+				else rgbtarget = background_color;
+			}
 		}
 
 		cin = a.coords_in + (size_t)base * 7;
@@ -659,25 +695,19 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const float w = proc ? alpha * T_k : 0.f;
 			// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
 			rgb_ray = rgb_ray + mk3(wave_total(proc ? w * rgb.x : 0.f), wave_total(proc ? w * rgb.y : 0.f), wave_total(proc ? w * rgb.z : 0.f));
+			if (a.train_mode == 1) { // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
+				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
+				loss_bg = loss_bg + mk3(wave_total(proc ? w * ll.x : 0.f), wave_total(proc ? w * ll.y : 0.f), wave_total(proc ? w * ll.z : 0.f));
+			}
 			if (n_proc) T_run = T_run * __shfl(incl, (int)n_proc - 1, 64);
 			compacted += n_proc;
 			if (fail) break;
 		}
 		T_final = T_run;
-		// target colour and background: identical to the sequential kernel (uniform across the wave)
-		if (!a.ray_targets) {
-			background_color = srgb_to_linear3(background_color);
-			const f3 trgb = mk3(tex.x, tex.y, tex.z);
-			if (a.linear_colors || !a.color_space_srgb) {
-				rgbtarget = trgb + (1.0f - tex.w) * background_color;
-				if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
-			} else {
-				background_color = linear_to_srgb3(background_color);
-				if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
-				else rgbtarget = background_color;
-			}
+		if (compacted == numsteps) {
+			rgb_ray = rgb_ray + T_final * background_color;
+			if (a.train_mode == 1) { f3 ll, lgl; loss_and_gradient(rgbtarget, background_color, a.loss_type, ll, lgl); loss_bg = loss_bg + T_final * ll; }
 		}
-		if (compacted == numsteps) rgb_ray = rgb_ray + T_final * background_color;
 	}
 	// one global atomic per workgroup reserves the spans of its 16 rays
 	if (lane == 0) s_cnt[wid] = compacted;
@@ -703,9 +733,9 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		my_loss = ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
-		const float output_l1_reg_density = *a.mean_density_ptr < MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
 		float T_run = 1.f;
-		f3 ray2_run = mk3(0.f);
+		f3 ray2_run = mk3(0.f), lb2_run = mk3(0.f);
 		for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
 			const uint32_t s = c0 + lane;
 			const bool valid = s < compacted;
@@ -734,16 +764,33 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const float T_k = T_run * excl, T_after = T_run * incl;
 			const float weight = alpha * T_k;
 			const f3 ray2 = ray2_run + mk3(wave_incl_sum(weight * rgb.x, lane), wave_incl_sum(weight * rgb.y, lane), wave_incl_sum(weight * rgb.z, lane));
+			f3 lloc = mk3(0.f), gloc = mk3(0.f), lb2 = lb2_run;
+			if (a.train_mode == 1) { // Rfl: per-sample loss against the target and its running (inclusive) weighted sum
+				loss_and_gradient(rgbtarget, rgb, a.loss_type, lloc, gloc);
+				lb2 = lb2_run + mk3(wave_incl_sum(weight * lloc.x, lane), wave_incl_sum(weight * lloc.y, lane), wave_incl_sum(weight * lloc.z, lane));
+			}
 			if (valid) {
 				float* cj = cout + (size_t)s * 7;
 #pragma unroll
 				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
 				const f3 suffix = rgb_ray - ray2;
-				const f3 dloss_by_drgb = weight * lgrad;
+				f3 dloss_by_drgb = weight * lgrad;
+				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + 0.0f;
+				if (a.train_mode == 1) { // fused_kernels/train_nerf.cuh:391-396
+					dloss_by_drgb = weight * gloc;
+					const f3 v = T_after * lloc - (loss_bg - lb2);
+					dmlp_inner = v.x + v.y + v.z;
+				} else if (a.train_mode == 2) { // train_nerf.cuh:397-405
+					const f3 rgb_bg = suffix / fmaxf(1e-6f, T_after);
+					const f3 rgb_lerp = (1 - alpha) * rgb_bg + alpha * rgb;
+					f3 ll, lgl; loss_and_gradient(rgbtarget, rgb_lerp, a.loss_type, ll, lgl);
+					dloss_by_drgb = weight * lgl;
+					dmlp_inner = dot3(lgl, T_after * rgb - suffix) + 0.0f;
+				}
 				const float d0 = loss_scale * (dloss_by_drgb.x * act_rgb_d(l0, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l0));
 				const float d1 = loss_scale * (dloss_by_drgb.y * act_rgb_d(l1, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l1));
 				const float d2 = loss_scale * (dloss_by_drgb.z * act_rgb_d(l2, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l2));
-				const float dloss_by_dmlp = act_density_d(l3, a.density_activation) * (dt * (dot3(lgrad, T_after * rgb - suffix) + 0.0f));
+				const float dloss_by_dmlp = act_density_d(l3, a.density_activation) * (dt * dmlp_inner);
 				const float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f);
 				__half* d = dl + (size_t)s * a.dloss_stride;
 				if (vec_dl) {
@@ -753,6 +800,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			}
 			T_run = T_run * __shfl(incl, 63, 64);
 			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
+			if (a.train_mode == 1) lb2_run = mk3(__shfl(lb2.x, 63, 64), __shfl(lb2.y, 63, 64), __shfl(lb2.z, 63, 64));
 		}
 	}
 	if (lane == 0) s_loss[wid] = my_loss;

@@ -801,6 +801,8 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+static int g_k3_train_mode = 0; // stand-alone ngp_k_compute_loss only (test hook): ETrainMode
+extern "C" int ngp_debug_set_train_mode(int mode) { g_k3_train_mode = mode; return 0; }
 extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t* n_rays_ptr, ngp_aabb aabb, ngp_pcg32 rng, uint32_t max_samples_compacted,
 		const uint32_t* rays_counter, float loss_scale, const float background_color[3], int color_space_srgb, int random_bg_color, int linear_colors,
 		uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_half* network_output, uint32_t output_stride, uint32_t* numsteps_counter_compacted,
@@ -808,7 +810,7 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 		uint32_t dloss_stride, int loss_type, float* loss_output, int rgb_activation, int density_activation, int snap_to_pixel_centers,
 		const float* mean_density_ptr, float near_distance) {
 	K3Args a;
-	a.ray_targets = nullptr;
+	a.ray_targets = nullptr; a.train_mode = g_k3_train_mode;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.aabb = aabb; a.rng = rng; a.max_samples_compacted = max_samples_compacted; a.rays_counter = rays_counter;
 	a.loss_scale = loss_scale; for (int k = 0; k < 3; ++k) a.background_color[k] = background_color[k];
 	a.color_space_srgb = color_space_srgb; a.random_bg_color = random_bg_color; a.linear_colors = linear_colors; a.n_images = n_training_images; a.metadata = metadata;
@@ -1103,7 +1105,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	k3.rays_in = t->rays; k3.numsteps_inout = t->numsteps; k3.coords_in = t->coords; k3.coords_out = t->coords_compacted; k3.dloss_doutput = t->dloss; k3.dloss_stride = 4;
 	k3.loss_type = o.loss_type; k3.loss_output = &c->loss_sum; k3.rgb_activation = o.rgb_activation; k3.density_activation = o.density_activation;
 	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
-	k3.ray_targets = lattice ? t->ray_targets : nullptr;
+	k3.ray_targets = lattice ? t->ray_targets : nullptr; k3.train_mode = o.train_mode;
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2); }

@@ -68,11 +68,13 @@ struct K3Args {
 	int rgb_activation, density_activation, snap_to_pixel_centers;
 	const float* mean_density_ptr; float near_distance;
 	const float* ray_targets; // optional: K1Args::ray_targets_out (8 floats per active ray)
+	int train_mode;           // ETrainMode: 0 Nerf, 1 Rfl, 2 RflRelax (fused_kernels/train_nerf.cuh:391-410)
 };
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
 // per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
-struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[6]; };
+struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[6]; uint32_t ray_index; };
+constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multiplicative-hash constant), larger than every ray count => coprime to it, and well mixed modulo powers of two; see k1_setup
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch);
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades);

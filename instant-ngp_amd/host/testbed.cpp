@@ -182,6 +182,8 @@ ngp_nerf_options Testbed::current_options() const {
 	o.loss_scale = 128.f; // default_loss_scale<__half>, testbed.h:307-311
 	o.seed = seed;
 	o.rank = m_rank; o.world_size = m_world_size;
+	// Rfl / RflRelax: the reference needs its JIT-fused kernel for these (testbed_nerf.cu:3091-3094); here K3 evaluates their gradients
+	o.train_mode = nerf.training.train_mode == ETrainMode::Rfl ? 1 : nerf.training.train_mode == ETrainMode::RflRelax ? 2 : 0;
 	return o;
 }
 
@@ -226,10 +228,6 @@ void Testbed::ensure_trainer() {
 }
 
 void Testbed::push_options() {
-	if (nerf.training.train_mode != ETrainMode::Nerf) { // RFL modes need the JIT-fused kernel in the reference (testbed_nerf.cu:3091-3094)
-		if (!m_warned_train_mode) { fprintf(stderr, "Warning: JIT fusion is not part of this build, switching to NeRF training mode.\n"); m_warned_train_mode = true; }
-		nerf.training.train_mode = ETrainMode::Nerf;
-	}
 	ngp_nerf_options o = current_options();
 	NGP_CHECK(ngp_nerf_set_options(m_nerf, &o));
 }

@@ -93,7 +93,7 @@ class NerfOptions(C.Structure):
                 ("snap_to_pixel_centers", i32), ("linear_colors", i32), ("color_space_srgb", i32),
                 ("background_color", f32 * 3), ("near_distance", f32), ("density_grid_decay", f32),
                 ("cone_angle_constant", f32), ("max_cascade", u32), ("target_batch_size", u32), ("loss_scale", f32),
-                ("seed", u64), ("rank", u32), ("world_size", u32)]
+                ("seed", u64), ("rank", u32), ("world_size", u32), ("train_mode", i32)]
 
 
 class NerfStats(C.Structure):
@@ -131,7 +131,7 @@ def default_nerf_options(aabb_scale=1, **kw):
     o = NerfOptions(rgb_activation=ACT_LOGISTIC, density_activation=ACT_EXPONENTIAL, loss_type=LOSS_HUBER, random_bg_color=1,
                     snap_to_pixel_centers=1, linear_colors=0, color_space_srgb=0, near_distance=0.1, density_grid_decay=0.95,
                     cone_angle_constant=0.0 if aabb_scale <= 1 else 1.0 / 256.0, max_cascade=max_cascade,
-                    target_batch_size=1 << 18, loss_scale=128.0, seed=1337, rank=0, world_size=1)
+                    target_batch_size=1 << 18, loss_scale=128.0, seed=1337, rank=0, world_size=1, train_mode=0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -266,6 +266,7 @@ struct K3Opts {
 	bool color_space_srgb = false, random_bg = true, linear_colors = false, snap = true;
 	int loss_type = NGP_LOSS_HUBER, rgb_act = NGP_ACT_LOGISTIC, density_act = NGP_ACT_EXPONENTIAL;
 	float near_distance = 0.1f;
+	int train_mode = 0; // ETrainMode: 0 Nerf, 1 Rfl, 2 RflRelax (fused_kernels/train_nerf.cuh:391-410)
 };
 inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb& aabb, const Pcg32& rng_in, uint32_t max_samples_compacted,
 		const K3Opts& o, uint32_t n_images, const ngp_image_meta* meta, const uint16_t* network_output, uint32_t out_stride,
@@ -277,23 +278,6 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 		uint32_t base = numsteps_inout[i * 2 + 1];
 		const float* cin = coords_in + (size_t)base * 7;
 		const uint16_t* no = network_output + (size_t)base * out_stride;
-
-		float T = 1.f;
-		const float EPSILON = 1e-4f;
-		vec3 rgb_ray = V3(0.f);
-		uint32_t compacted_numsteps = 0;
-		vec3 ray_o = V3(rays_in[i].o);
-		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
-			if (T < EPSILON) break;
-			const uint16_t* lo = no + (size_t)compacted_numsteps * out_stride;
-			vec3 rgb = {network_to_rgb(h2f(lo[0]), o.rgb_act), network_to_rgb(h2f(lo[1]), o.rgb_act), network_to_rgb(h2f(lo[2]), o.rgb_act)};
-			const float dt = unwarp_dt(cin[compacted_numsteps * 7 + 3]);
-			float density = network_to_density(h2f(lo[3]), o.density_act);
-			const float alpha = 1.f - std::exp(-density * dt);
-			const float weight = alpha * T;
-			rgb_ray += weight * rgb;
-			T *= (1.f - alpha);
-		}
 
 		uint32_t ray_idx = ray_indices_in[i];
 		Pcg32 rng = rng_in;
@@ -320,7 +304,26 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 			if (texsamp.w > 0) rgbtarget = linear_to_srgb(trgb / texsamp.w) * texsamp.w + (1.0f - texsamp.w) * background_color;
 			else rgbtarget = background_color;
 		}
-		if (compacted_numsteps == numsteps) rgb_ray += T * background_color;
+		vec3 loss_bg = V3(0.f); // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
+		float T = 1.f;
+		const float EPSILON = 1e-4f;
+		vec3 rgb_ray = V3(0.f);
+		uint32_t compacted_numsteps = 0;
+		vec3 ray_o = V3(rays_in[i].o);
+		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
+			if (T < EPSILON) break;
+			const uint16_t* lo = no + (size_t)compacted_numsteps * out_stride;
+			vec3 rgb = {network_to_rgb(h2f(lo[0]), o.rgb_act), network_to_rgb(h2f(lo[1]), o.rgb_act), network_to_rgb(h2f(lo[2]), o.rgb_act)};
+			const float dt = unwarp_dt(cin[compacted_numsteps * 7 + 3]);
+			float density = network_to_density(h2f(lo[3]), o.density_act);
+			const float alpha = 1.f - std::exp(-density * dt);
+			const float weight = alpha * T;
+			rgb_ray += weight * rgb;
+			if (o.train_mode == 1) loss_bg += weight * loss_and_gradient(rgbtarget, rgb, o.loss_type).loss;
+			T *= (1.f - alpha);
+		}
+
+		if (compacted_numsteps == numsteps) { rgb_ray += T * background_color; if (o.train_mode == 1) loss_bg += T * loss_and_gradient(rgbtarget, background_color, o.loss_type).loss; }
 
 		uint32_t compacted_base = counter; counter += compacted_numsteps;
 		compacted_numsteps = std::min(max_samples_compacted - std::min(max_samples_compacted, compacted_base), compacted_numsteps);
@@ -337,9 +340,10 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 
 		float loss_scale = o.loss_scale / n_rays;
 		const float output_l2_reg = o.rgb_act == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
-		const float output_l1_reg_density = mean_density < NERF_MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
+		// the fused kernel (the only one with Rfl modes in the reference) has this regulariser switched off (train_nerf.cuh:307)
+		const float output_l1_reg_density = (o.train_mode == 0 && mean_density < NERF_MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
 
-		vec3 rgb_ray2 = V3(0.f);
+		vec3 rgb_ray2 = V3(0.f), loss_bg2 = V3(0.f);
 		T = 1.f;
 		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
 			for (int k = 0; k < 7; ++k) cout[(size_t)j * 7 + k] = cin[(size_t)j * 7 + k];
@@ -355,12 +359,25 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 			rgb_ray2 += weight * rgb;
 			T *= (1.f - alpha);
 			const vec3 suffix = rgb_ray - rgb_ray2;
-			const vec3 dloss_by_drgb = weight * lg.gradient;
+			vec3 dloss_by_drgb = weight * lg.gradient;
+			float density_derivative = network_to_density_derivative(l3, o.density_act);
+			float dloss_by_dmlp = density_derivative * (dt * (dot(lg.gradient, T * rgb - suffix) + 0.0f /* depth supervision off */));
+			if (o.train_mode == 1) { // radiance field loss, train_nerf.cuh:391-396
+				LossAndGradient local_lg = loss_and_gradient(rgbtarget, rgb, o.loss_type);
+				loss_bg2 += weight * local_lg.loss;
+				dloss_by_drgb = weight * local_lg.gradient;
+				const vec3 v = T * local_lg.loss - (loss_bg - loss_bg2);
+				dloss_by_dmlp = density_derivative * (dt * (v.x + v.y + v.z));
+			} else if (o.train_mode == 2) { // relaxation between volume and surface reconstruction, train_nerf.cuh:397-405
+				const vec3 rgb_bg = suffix / std::fmax(1e-6f, T);
+				const vec3 rgb_lerp = (1 - alpha) * rgb_bg + alpha * rgb;
+				LossAndGradient local_lg = loss_and_gradient(rgbtarget, rgb_lerp, o.loss_type);
+				dloss_by_drgb = weight * local_lg.gradient;
+				dloss_by_dmlp = density_derivative * (dt * (dot(local_lg.gradient, T * rgb - suffix) + 0.0f));
+			}
 			float d0 = loss_scale * (dloss_by_drgb.x * network_to_rgb_derivative(l0, o.rgb_act) + std::fmax(0.0f, output_l2_reg * l0));
 			float d1 = loss_scale * (dloss_by_drgb.y * network_to_rgb_derivative(l1, o.rgb_act) + std::fmax(0.0f, output_l2_reg * l1));
 			float d2 = loss_scale * (dloss_by_drgb.z * network_to_rgb_derivative(l2, o.rgb_act) + std::fmax(0.0f, output_l2_reg * l2));
-			float density_derivative = network_to_density_derivative(l3, o.density_act);
-			float dloss_by_dmlp = density_derivative * (dt * (dot(lg.gradient, T * rgb - suffix) + 0.0f /* depth supervision off */));
 			float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < o.near_distance ? 1e-4f : 0.0f);
 			uint16_t* d = dl + (size_t)j * dl_stride;
 			d[0] = f2h(d0); d[1] = f2h(d1); d[2] = f2h(d2); d[3] = f2h(d3);
@@ -588,6 +605,7 @@ struct NerfTrainer {
 		ko.loss_scale = opt.loss_scale; ko.background_color = V3(opt.background_color); ko.color_space_srgb = opt.color_space_srgb;
 		ko.random_bg = opt.random_bg_color; ko.linear_colors = opt.linear_colors; ko.snap = opt.snap_to_pixel_centers;
 		ko.loss_type = opt.loss_type; ko.rgb_act = opt.rgb_activation; ko.density_act = opt.density_activation; ko.near_distance = opt.near_distance;
+		ko.train_mode = opt.train_mode;
 		uint32_t compacted = compute_loss(R, k1.ray_counter, aabb, rng, B, ko, (uint32_t)meta.size(), meta.data(), mlp_out.data(), 4,
 			ray_indices.data(), rays.data(), numsteps.data(), coords.data(), coords_compacted.data(), dloss.data(), 4, loss.data(), mean_density);
 		n_rays_last = k1.ray_counter;

@@ -116,7 +116,11 @@ def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
     ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_d]
     rays = d["rays"].cpu().numpy()[:n_d]
     coords = d["coords"].cpu().numpy()
-    assert np.all(np.diff(ri.astype(np.int64)) > 0), "ray slots must be in ray-index order"
+    # slots follow a FIXED scramble of the rank's ray range (slot s <-> ray rb + (s * 2654435761) % n_local, csrc/nerf_kernels.hip k1_setup), so that
+    # the rays dropped by the sample cap / batch clamp (the last slots) are spread over all images: deterministic, but not index order
+    rb_, re_ = n_rays * rank // world, n_rays * (rank + 1) // world
+    slot_of = np.empty(re_ - rb_, np.int64); slot_of[(np.arange(re_ - rb_, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(re_ - rb_)).astype(np.int64)] = np.arange(re_ - rb_)
+    assert np.all(np.diff(slot_of[ri.astype(np.int64) - rb_]) > 0), "ray slots must follow the slot scramble"
     assert np.array_equal(ns[:, 1], np.concatenate([[0], np.cumsum(ns[:, 0])[:-1]]).astype(np.uint32)), "spans must be the prefix sum of the counts"
     assert int(ns[:, 0].sum()) == int(cnt[1])
     ref = {int(r): i for i, r in enumerate(o["ray_indices"][:n_o])}
@@ -165,7 +169,19 @@ def test_k1_sample_cap(ora, hip, scene):
     assert not kept[np.argmin(kept):].any()
 
 
-def test_k3_loss_and_compaction(ora, hip, scene):
+@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (1, 32), (2, 32)])
+def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
+    """K3 vs the oracle per ray, for the three train modes (0 Nerf, 1 Rfl, 2 RflRelax: fused_kernels/train_nerf.cuh:391-410) and for both device
+    kernels (wave per ray; flag 32 = the reference's sequential per-ray loops)."""
+    import torch
+    ora.ora_set_train_mode(train_mode); hip.ngp_debug_set_train_mode(train_mode); hip.ngp_debug_set_flags(k3_flags)
+    try:
+        _k3_loss_and_compaction(ora, hip, scene)
+    finally:
+        ora.ora_set_train_mode(0); hip.ngp_debug_set_train_mode(0); hip.ngp_debug_set_flags(0)
+
+
+def _k3_loss_and_compaction(ora, hip, scene):
     import torch
     n_rays, max_samples, B = 2048, 1 << 19, 1 << 19  # B large enough that no ray is clamped (the clamped set is order dependent)
     o, d = _run_k1(ora, hip, scene, n_rays, max_samples)

@@ -219,3 +219,23 @@ def test_render_matches_oracle(ora, hip):
     assert (f_o[:, 3] > 0.5).mean() > 0.05  # the object is visible after 200 steps
     assert np.quantile(err, 0.99) <= 4e-3 and err.max() <= 2e-2
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
+
+
+@pytest.mark.parametrize("train_mode", [1, 2])
+def test_rfl_train_modes_converge(hip, ora, train_mode):
+    """ngp_nerf_options::train_mode = Rfl / RflRelax (fused_kernels/train_nerf.cuh:391-410, evaluated by the unfused K3): the run.py schedule
+    (Nerf first, then the Rfl mode, run.py:229-242) trains, and the loss stays in the range of the Nerf-mode run."""
+    B = 1 << 16
+    res = {}
+    for mode in (0, train_mode):
+        s = _make(ora, hip, B, n_images=12, res=96)
+        A.check(hip, hip.ngp_nerf_train(s["t"], None, 150))  # warm-up in Nerf mode, like run.py's --rfl_warmup_steps
+        o = s["opts"]; o.train_mode = mode
+        A.check(hip, hip.ngp_nerf_set_options(s["t"], C.byref(o)))
+        A.check(hip, hip.ngp_nerf_train(s["t"], None, 250))
+        st = _stats(hip, s["t"])
+        res[mode] = st.loss
+        assert st.training_step == 400 and np.isfinite(st.loss) and st.measured_batch_size > 0
+        hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
+    print(f"train_mode {train_mode}: loss {res[train_mode]:.5f} vs Nerf mode {res[0]:.5f}")
+    assert res[train_mode] < 4 * res[0] + 1e-4
