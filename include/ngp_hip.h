@@ -264,6 +264,29 @@ int ngp_image_mse(ngp_image*, int quantize_to_byte, float* mse_host);         /*
 /* device pointers of the last training batch: positions (vec2) and targets (vec3); test hook */
 int ngp_image_batch_ptrs(ngp_image*, float** positions, float** targets);
 
+/* ------------------------------------------------------------------ SDF trainer ---------- */
+/* Testbed::m_sdf: load_mesh normalisation (testbed_sdf.cu:1380-1410), triangle BVH (triangle_bvh.cu) with EMeshSdfMode::Raystab
+ * signed distances (32 Fibonacci stab rays, :631-650), generate_training_samples_sdf (:1449-1544: 4/8 of a batch on the surface, 3/8
+ * surface + logistic offset of sigma = |(0.5,0.5,0.5)| / 1024, 1/8 uniform in the box), train_sdf (:1580-1622, MAPE loss),
+ * calculate_iou (:1636-1680).  Triangles: 9 floats each (a, b, c), already normalised into the unit cube. */
+typedef struct ngp_sdf_options {
+	int32_t loss_type;               /* configs/sdf/base.json: MAPE */
+	float loss_scale;                /* 128 */
+	uint32_t batch_size;             /* 1 << 18 */
+	uint64_t seed;                   /* 1337 */
+	float surface_offset_scale;      /* testbed.h:938  1.0 */
+	float zero_offset;               /* testbed.h:925  0   */
+} ngp_sdf_options;
+typedef struct ngp_sdf ngp_sdf;
+int ngp_sdf_normalize_mesh_host(float* vertices_inout_host, uint64_t n_vertices, ngp_aabb* aabb_out_host, float* mesh_scale_out_host);
+int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, uint32_t n_triangles, ngp_aabb aabb, const ngp_sdf_options* opts_host, ngp_sdf** out);
+void ngp_sdf_destroy(ngp_sdf*);
+int ngp_sdf_train(ngp_sdf*, void* stream, uint32_t n_steps);                 /* training_prep_sdf + train_sdf + optimizer_step, n times */
+int ngp_sdf_loss(ngp_sdf*, void* stream, float* loss_host);
+int ngp_sdf_iou(ngp_sdf*, uint32_t n_samples, double* iou_host);             /* calculate_iou(n_samples, 0, blocking) */
+int ngp_sdf_batch_ptrs(ngp_sdf*, float** positions, float** distances);      /* last generated batch (device); test hook */
+int ngp_sdf_signed_distance(ngp_sdf*, void* stream, const float* positions, uint32_t n, float* distances_out); /* TriangleBvh::signed_distance_gpu (Raystab) */
+
 /* ------------------------------------------------------------------ NeRF kernels --------- */
 /* Stand-alone kernels (each mirrors one reference kernel; used by the parity tests and by
  * ngp_nerf_* below). All buffers are caller-owned device memory. */

@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 	const uint32_t base = (uint32_t)so, slot = (uint32_t)(so >> 32);
 	const bool fits = base + count <= max_samples; // testbed_nerf.cu:813-815: rays past the cap are dropped
 	if (lane == 0) {
-		a.ray_indices_out[slot] = ray_begin + li;
+		a.ray_indices_out[slot] = r.ray_index;
 		ngp_ray rr; rr.o[0] = r.o[0]; rr.o[1] = r.o[1]; rr.o[2] = r.o[2]; rr.d[0] = r.d[0]; rr.d[1] = r.d[1]; rr.d[2] = r.d[2];
 		a.rays_out[slot] = rr;
 		a.numsteps_out[slot * 2 + 0] = fits ? count : 0u;

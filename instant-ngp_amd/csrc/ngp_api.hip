@@ -690,6 +690,162 @@ extern "C" int ngp_image_mse(ngp_image* t, int quantize_to_byte, float* mse_host
 }
 extern "C" int ngp_image_batch_ptrs(ngp_image* t, float** positions, float** targets) { if (positions) *positions = t->positions; if (targets) *targets = t->targets; return 0; }
 
+// ------------------------------------------------------------------------------------------------
+// SDF trainer: Testbed::m_sdf, load_mesh (testbed_sdf.cu:1363-1447), generate_training_samples_sdf (:1449-1544), train_sdf (:1580-1622),
+// calculate_iou (:1636-1680); TriangleBvh::build (triangle_bvh.cu:757-840) as a binary tree
+// ------------------------------------------------------------------------------------------------
+struct ngp_sdf {
+	ngp_encmlp* model = nullptr;
+	ngp_sdf_options opt{};
+	ngp_aabb aabb{};
+	uint32_t n_triangles = 0;
+	SdfTriangle* tris = nullptr; SdfBvhNode* nodes = nullptr; float* cdf = nullptr;
+	float* positions = nullptr; float* distances = nullptr; ngp_half* pred = nullptr; uint32_t cap = 0;
+	float* loss_sum = nullptr; uint32_t* iou_counters = nullptr;
+	Rng rng; uint32_t training_step = 0;
+};
+// load_mesh's normalisation (testbed_sdf.cu:1380-1410): raw box inflated by 0.5 % of its diagonal, scaled by its largest extent and centred in the unit cube
+extern "C" int ngp_sdf_normalize_mesh_host(float* v, uint64_t n_vertices, ngp_aabb* aabb_out, float* mesh_scale_out) {
+	REQUIRE(v && n_vertices >= 3 && aabb_out, "ngp_sdf_normalize_mesh_host: null / empty");
+	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+	for (uint64_t i = 0; i < n_vertices; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[i * 3 + k]); mx[k] = std::max(mx[k], v[i * 3 + k]); }
+	const float inflation = 0.005f;
+	auto diag_len = [&]() { const float d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]}; return std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); };
+	float amt = diag_len() * inflation;
+	for (int k = 0; k < 3; ++k) { mn[k] -= amt; mx[k] += amt; }
+	const float scale = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+	for (uint64_t i = 0; i < n_vertices; ++i) for (int k = 0; k < 3; ++k) v[i * 3 + k] = (v[i * 3 + k] - mn[k] - 0.5f * (mx[k] - mn[k])) / scale + 0.5f;
+	for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+	for (uint64_t i = 0; i < n_vertices; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[i * 3 + k]); mx[k] = std::max(mx[k], v[i * 3 + k]); }
+	amt = diag_len() * inflation;
+	for (int k = 0; k < 3; ++k) { aabb_out->min[k] = std::max(mn[k] - amt, 0.0f); aabb_out->max[k] = std::min(mx[k] + amt, 1.0f); } // intersection with the unit cube
+	if (mesh_scale_out) *mesh_scale_out = scale;
+	return 0;
+}
+static void sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode>& nodes, uint32_t leaf_size) {
+	struct Job { int node; size_t begin, end; };
+	auto bounds = [&](size_t b, size_t e, SdfBvhNode& n) {
+		for (int k = 0; k < 3; ++k) { n.bmin[k] = INFINITY; n.bmax[k] = -INFINITY; }
+		for (size_t i = b; i < e; ++i) for (const float* p : {tris[i].a, tris[i].b, tris[i].c}) for (int k = 0; k < 3; ++k) { n.bmin[k] = std::min(n.bmin[k], p[k]); n.bmax[k] = std::max(n.bmax[k], p[k]); }
+	};
+	auto centroid = [](const SdfTriangle& t, int k) { return (t.a[k] + t.b[k] + t.c[k]) / 3; };
+	nodes.clear(); nodes.emplace_back();
+	bounds(0, tris.size(), nodes[0]);
+	std::vector<Job> stack{{0, 0, tris.size()}};
+	while (!stack.empty()) {
+		const Job j = stack.back(); stack.pop_back();
+		if (j.end - j.begin <= leaf_size) { nodes[j.node].left = -(int)j.begin - 1; nodes[j.node].right = -(int)j.end - 1; continue; }
+		// axis of maximum centroid variance, median split (triangle_bvh.cu:788-809)
+		double mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
+		for (size_t i = j.begin; i < j.end; ++i) for (int k = 0; k < 3; ++k) mean[k] += centroid(tris[i], k);
+		for (int k = 0; k < 3; ++k) mean[k] /= (double)(j.end - j.begin);
+		for (size_t i = j.begin; i < j.end; ++i) for (int k = 0; k < 3; ++k) { const double d = centroid(tris[i], k) - mean[k]; var[k] += d * d; }
+		const int axis = var[0] >= var[1] && var[0] >= var[2] ? 0 : (var[1] >= var[2] ? 1 : 2);
+		const size_t mid = j.begin + (j.end - j.begin) / 2;
+		std::nth_element(tris.begin() + j.begin, tris.begin() + mid, tris.begin() + j.end, [&](const SdfTriangle& x, const SdfTriangle& y) { return centroid(x, axis) < centroid(y, axis); });
+		const int l = (int)nodes.size(); nodes.emplace_back(); nodes.emplace_back();
+		nodes[j.node].left = l; nodes[j.node].right = l + 1;
+		bounds(j.begin, mid, nodes[l]); bounds(mid, j.end, nodes[l + 1]);
+		stack.push_back({l, j.begin, mid}); stack.push_back({l + 1, mid, j.end});
+	}
+}
+extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, uint32_t n_triangles, ngp_aabb aabb, const ngp_sdf_options* o, ngp_sdf** out) {
+	REQUIRE(model && triangles_host && o && out && n_triangles > 0, "ngp_sdf_create: null / empty argument");
+	REQUIRE(model->cfg.n_pos_dims == 3 && model->cfg.n_output_dims == 1, "ngp_sdf_create: the model must map 3-D positions to 1 output (network_dims_sdf)");
+	REQUIRE(o->batch_size >= 256 && o->batch_size % 32 == 0, "ngp_sdf_create: batch size must be a multiple of 32, at least 256");
+	ngp_sdf* t = new ngp_sdf();
+	t->model = model; t->opt = *o; t->aabb = aabb; t->n_triangles = n_triangles;
+	t->rng = make_rng(o->seed);
+	std::vector<SdfTriangle> tris(n_triangles);
+	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
+	std::vector<SdfBvhNode> nodes;
+	sdf_build_bvh(tris, nodes, 8); // m_sdf.triangle_bvh->build(triangles_cpu, 8); reorders the triangles
+	// DiscreteDistribution::build over the surface areas (discrete_distribution.h:21-38) -- of the REORDERED triangles, like the reference
+	std::vector<float> cdf(n_triangles);
+	{
+		std::vector<float> w(n_triangles);
+		float total = 0;
+		for (uint32_t i = 0; i < n_triangles; ++i) {
+			const SdfTriangle& q = tris[i];
+			const float e1[3] = {q.b[0] - q.a[0], q.b[1] - q.a[1], q.b[2] - q.a[2]}, e2[3] = {q.c[0] - q.a[0], q.c[1] - q.a[1], q.c[2] - q.a[2]};
+			const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+			w[i] = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
+			total += w[i];
+		}
+		const float inv = 1 / total;
+		float acc = 0;
+		for (uint32_t i = 0; i < n_triangles; ++i) { acc += w[i] * inv; cdf[i] = acc; }
+		cdf.back() = 1.0f;
+	}
+	t->cap = std::max<uint32_t>(o->batch_size, 1u << 21); // calculate_iou works in batches of 128^3 = 2^21
+	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
+		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8)) { delete t; return 1; }
+	HIPCHK(hipMemcpy(t->tris, tris.data(), tris.size() * sizeof(SdfTriangle), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->nodes, nodes.data(), nodes.size() * sizeof(SdfBvhNode), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(t->loss_sum, 0, 4));
+	*out = t;
+	return 0;
+}
+extern "C" void ngp_sdf_destroy(ngp_sdf* t) {
+	if (!t) return;
+	(void)hipDeviceSynchronize();
+	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters}) if (p) (void)hipFree(p);
+	delete t;
+}
+// generate_training_samples_sdf: fills positions / distances for `n` samples and advances m_rng like the reference
+static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only) {
+	const uint32_t base = n / 8;
+	SdfSampleArgs a;
+	a.n = n; a.n_exact = uniform_only ? 0 : base * 4; a.n_surface = uniform_only ? 0 : base * 7;
+	a.rng = pod(t->rng);
+	a.stddev = std::sqrt(0.75f) / 1024.0f * t->opt.surface_offset_scale; // m_bounding_radius = length(vec3(0.5)) (testbed_sdf.cu:1424)
+	a.aabb = t->aabb;
+	for (int k = 0; k < 3; ++k) { a.aabb.min[k] -= t->opt.zero_offset; a.aabb.max[k] += t->opt.zero_offset; } // sdf_aabb.inflate(zero_offset)
+	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = t->positions; a.distances = t->distances;
+	launch_sdf_generate_positions(s, a);
+	t->rng.advance((uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull); // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
+	launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->tris, 1);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_sdf_train(ngp_sdf* t, void* stream, uint32_t n_steps) {
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n = t->opt.batch_size;
+	for (uint32_t i = 0; i < n_steps; ++i) {
+		if (sdf_generate(t, s, n, false)) return 1; // training_prep_sdf with generate_sdf_data_online (the shuffle of train_sdf permutes a full batch: no effect on its sum)
+		if (encmlp_training_step(t->model, s, t->positions, 3, n, t->distances, 1, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
+		if (ngp_encmlp_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
+		++t->training_step;
+	}
+	return 0;
+}
+extern "C" int ngp_sdf_loss(ngp_sdf* t, void* stream, float* loss_host) {
+	HIPCHK(hipMemcpyAsync(loss_host, t->loss_sum, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+	return 0;
+}
+extern "C" int ngp_sdf_iou(ngp_sdf* t, uint32_t n_samples, double* iou_host) {
+	HIPCHK(hipMemsetAsync(t->iou_counters, 0, 32, nullptr));
+	while (n_samples > 0) {
+		const uint32_t n = std::min<uint32_t>(128u * 128u * 128u, n_samples);
+		n_samples -= n;
+		if (sdf_generate(t, nullptr, n, true)) return 1;
+		if (ngp_encmlp_inference(t->model, nullptr, t->positions, 3, n, t->pred, 1)) return 1;
+		launch_sdf_compare_signs(nullptr, n, t->distances, t->pred, 1, t->iou_counters);
+	}
+	uint32_t c[8];
+	HIPCHK(hipMemcpy(c, t->iou_counters, 32, hipMemcpyDeviceToHost));
+	*iou_host = c[5] ? (double)c[4] / (double)c[5] : 0.0;
+	return 0;
+}
+extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distances) { if (positions) *positions = t->positions; if (distances) *distances = t->distances; return 0; }
+extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* positions, uint32_t n, float* out) {
+	launch_sdf_signed_distance((hipStream_t)stream, n, positions, out, t->nodes, t->tris, 0);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
 	++m->step; // Adam::step: ++m_current_step
 	AdamArgs a;

@@ -191,6 +191,19 @@ void launch_image_generate_batch(hipStream_t s, const ImageBatchArgs& a);
 void launch_image_pixel_batch(hipStream_t s, const ImageBatchArgs& a, uint32_t offset);
 void launch_image_mse(hipStream_t s, uint32_t n, const float* targets, const ngp_half* pred, uint32_t pred_stride, int quantize, double* sum);
 
+// ---- SDF primitive (sdf_kernels.hip) -----------------------------------------------------------
+struct SdfTriangle { float a[3], b[3], c[3]; };                       // Triangle, triangle.cuh:37
+struct SdfBvhNode { float bmin[3], bmax[3]; int left, right; };        // inner node: child indices; leaf: left = -first - 1, right = -end - 1 (TriangleBvhNode convention)
+struct SdfSampleArgs {
+	uint32_t n, n_exact, n_surface;   // samples [0, n_exact) on the surface, [n_exact, n_surface) surface + offset, [n_surface, n) uniform
+	ngp_pcg32 rng; float stddev; ngp_aabb aabb;
+	const float* cdf; uint32_t n_triangles; const SdfTriangle* triangles;
+	float* positions; float* distances;
+};
+void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a);
+void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds);
+void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters);
+
 // ---- renderer (render_kernels.hip) ------------------------------------------------------------
 constexpr uint32_t RENDER_MAX_CHUNKS = 32; // 2048 lattice points per ray
 constexpr uint32_t RENDER_STEPS = 8;       // samples per live ray between compactions (MAX_STEPS_INBETWEEN_COMPACTION, testbed_nerf.cu:53)

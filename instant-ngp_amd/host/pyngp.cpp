@@ -8,6 +8,7 @@
 
 #include "testbed.hpp"
 #include "exr_lite.hpp"
+#include "mesh_lite.hpp"
 
 namespace py = pybind11;
 using namespace ngp_host;
@@ -35,6 +36,13 @@ PYBIND11_MODULE(pyngp, m) {
 		exr_lite::read_rgba(path, w, h, px);
 		py::array_t<float> out({h, w, 4});
 		std::memcpy(out.mutable_data(), px.data(), px.size() * sizeof(float));
+		return out;
+	});
+	// not part of the reference API: the host's OBJ reader (SDF primitive data path), float32 [n_triangles][3][3]
+	m.def("read_obj", [](const std::string& path) {
+		const std::vector<float> v = mesh_lite::load_obj(path);
+		py::array_t<float> out({(py::ssize_t)(v.size() / 9), (py::ssize_t)3, (py::ssize_t)3});
+		std::memcpy(out.mutable_data(), v.data(), v.size() * sizeof(float));
 		return out;
 	});
 	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)

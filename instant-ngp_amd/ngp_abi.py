@@ -72,6 +72,18 @@ def default_image_options(**kw):
     return o
 
 
+class SdfOptions(C.Structure):
+    _fields_ = [("loss_type", i32), ("loss_scale", f32), ("batch_size", u32), ("seed", u64), ("surface_offset_scale", f32), ("zero_offset", f32)]
+
+
+def default_sdf_options(**kw):
+    """Testbed::m_sdf defaults (testbed.h:909-938), configs/sdf/base.json loss (MAPE), m_training_batch_size"""
+    o = SdfOptions(loss_type=LOSS_MAPE, loss_scale=128.0, batch_size=1 << 18, seed=1337, surface_offset_scale=1.0, zero_offset=0.0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 def _auto_per_level_scale(desired_resolution, base_resolution, n_levels):
     """testbed.cu:4249-4253 in the reference's float arithmetic: std::exp(std::log(desired / base) / (n_levels - 1))"""
     import numpy as np

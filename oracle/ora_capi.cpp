@@ -2,6 +2,7 @@
 // C entry points of liboracle.so for ctypes (tests/, smoke(), bench.py cpu_baseline). All pointers are HOST pointers.
 #include "ora_nerf.hpp"
 #include "ora_encmlp.hpp"
+#include "ora_sdf.hpp"
 #include <omp.h>
 
 using namespace ora;
@@ -195,4 +196,13 @@ API uint16_t* ora_encmlp_gradients(void* h) { return ((EncMlp*)h)->grads.data();
 API float ora_encmlp_loss_and_gradient(void* h, int mape, const uint16_t* pred, uint32_t pred_stride, const float* target, uint32_t target_stride, uint32_t n, float loss_scale,
 		uint16_t* dL_dy) {
 	return ((EncMlp*)h)->loss_and_gradient(mape != 0, pred, pred_stride, target, target_stride, n, loss_scale, dL_dy);
+}
+
+// ---- SDF data path (brute force, no BVH) ------------------------------------------------------
+API void ora_sdf_signed_distance(const float* tris9, uint32_t n_tris, const float* positions, uint32_t n, const float* max_dist, float* out) {
+	sdf_signed_distance_brute((const Tri*)tris9, n_tris, positions, n, max_dist, out);
+}
+API void ora_sdf_generate_positions(const float* tris9, uint32_t n_tris, const float* cdf, uint32_t n, uint32_t n_exact, uint32_t n_surface, ngp_pcg32 rng, float stddev,
+		ngp_aabb box, float* positions, float* distances) {
+	sdf_generate_positions((const Tri*)tris9, n_tris, cdf, n, n_exact, n_surface, Pcg32(rng), stddev, box, positions, distances);
 }
