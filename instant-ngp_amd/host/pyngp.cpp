@@ -88,6 +88,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())
 		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>())
 		.def("want_repl", &Testbed::want_repl)
+		.def("compute_image_mse", &Testbed::compute_image_mse, py::arg("quantize") = false)
+		.def("calculate_iou", &Testbed::calculate_iou, py::arg("n_samples") = 128u * 128u * 128u * 4u, py::arg("scale_existing_results_factor") = 0.0f, py::arg("blocking") = true, py::arg("force_use_octree") = false)
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view)
 		.def("set_nerf_camera_matrix", [](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
 			if (a.size() < 12) throw std::runtime_error{"set_nerf_camera_matrix expects a 3x4 matrix"};

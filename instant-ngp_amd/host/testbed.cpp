@@ -1,5 +1,7 @@
 // testbed.cpp -- see testbed.hpp.  Host logic only; every device operation is a C-ABI call.
 #include "testbed.hpp"
+#include "exr_lite.hpp"
+#include "mesh_lite.hpp"
 #include "msgpack_lite.hpp"
 
 #include <hip/hip_runtime_api.h>
@@ -120,6 +122,9 @@ Testbed::~Testbed() {
 	if (m_frame_dev) (void)hipFree(m_frame_dev);
 }
 void Testbed::destroy_trainer() {
+	if (m_image) { ngp_image_destroy(m_image); m_image = nullptr; }
+	if (m_sdf) { ngp_sdf_destroy(m_sdf); m_sdf = nullptr; }
+	if (m_encmlp) { ngp_encmlp_destroy(m_encmlp); m_encmlp = nullptr; }
 	if (m_nerf) { ngp_nerf_destroy(m_nerf); m_nerf = nullptr; }
 	if (m_model) { ngp_model_destroy(m_model); m_model = nullptr; }
 }
@@ -139,10 +144,11 @@ static mini_json::Value load_config_recursive(const fs::path& path, int depth = 
 
 void Testbed::reload_network_from_file(const std::string& path_in) {
 	fs::path path = path_in;
-	if (path_in.empty()) path = fs::path(root_dir) / "configs" / "nerf" / "base.json";
+	const char* mode_dir = mode == ETestbedMode::Image ? "image" : mode == ETestbedMode::Sdf ? "sdf" : "nerf"; // get_filename_in_data_path_with_suffix / to_string(mode), testbed.cu:254-270
+	if (path_in.empty()) { path = fs::path(root_dir) / "configs" / mode_dir / "base.json"; if (!fs::exists(path)) path = fs::path(s_default_root_dir) / "configs" / mode_dir / "base.json"; }
 	else if (!fs::exists(path)) {
 		// relative names resolve against configs/<mode>/ (testbed.cu:254-270)
-		fs::path alt = fs::path(root_dir) / "configs" / "nerf" / path_in;
+		fs::path alt = fs::path(root_dir) / "configs" / mode_dir / path_in;
 		if (!fs::exists(alt) && alt.extension().empty()) alt += ".json";
 		if (fs::exists(alt)) path = alt; else throw std::runtime_error{"Network config '" + path_in + "' does not exist."};
 	}
@@ -238,6 +244,32 @@ void Testbed::push_options() {
 void Testbed::load_training_data(const std::string& path_in) {
 	fs::path path = path_in;
 	if (!fs::exists(path)) throw std::runtime_error{"Data path '" + path_in + "' does not exist."};
+	// mode_from_scene, common_host.cu:144-160: directory / json -> NeRF, obj / stl -> SDF, nvdb -> volume, anything else -> image
+	const std::string ext = lower(path.extension().string());
+	if (!fs::is_directory(path) && ext != ".json") {
+		if (ext == ".nvdb") throw std::runtime_error{"Volume (.nvdb) scenes are out of scope of this build."};
+		destroy_trainer();
+		m_network_config = mini_json::Value{};
+		if (ext == ".obj" || ext == ".stl") { // load_mesh, testbed_sdf.cu:1363-1447
+			if (ext == ".stl") throw std::runtime_error{"Binary .stl meshes are not implemented; convert to ascii .obj."};
+			m_mesh = mesh_lite::load_obj(path.string());
+			NGP_CHECK(ngp_sdf_normalize_mesh_host(m_mesh.data(), m_mesh.size() / 3, &m_mesh_aabb, nullptr));
+			mode = ETestbedMode::Sdf;
+		} else { // load_image, testbed_image.cu: EXR natively, 8-bit formats through the decoder hook (sRGB -> linear)
+			if (ext == ".exr") exr_lite::read_rgba(path.string(), m_image_w, m_image_h, m_image_pixels);
+			else {
+				std::vector<uint8_t> rgba;
+				bool ok = ext == ".png" && decode_png(path.string(), m_image_w, m_image_h, rgba);
+				if (!ok && s_fallback_decoder) ok = s_fallback_decoder(path.string(), m_image_w, m_image_h, rgba);
+				if (!ok) throw std::runtime_error{"Could not load image '" + path.string() + "'"};
+				m_image_pixels.resize(rgba.size());
+				for (size_t i = 0; i < rgba.size(); ++i) { const float v = rgba[i] / 255.f; m_image_pixels[i] = (i & 3) == 3 ? v : (v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f)); }
+			}
+			mode = ETestbedMode::Image;
+		}
+		training_step = 0; loss = 0.f;
+		return;
+	}
 	std::vector<fs::path> jsons;
 	if (fs::is_directory(path)) {
 		for (auto& e : fs::directory_iterator(path)) if (e.is_regular_file() && lower(e.path().extension().string()) == ".json") jsons.push_back(e.path());
@@ -366,13 +398,75 @@ void Testbed::load_file(const std::string& path) {
 		else throw std::runtime_error{"File '" + path + "' is not a recognised scene / config json."};
 		return;
 	}
-	throw std::runtime_error{"File '" + path + "' is not a valid file to load (only NeRF scenes, network configs and snapshots are in scope)."};
+	if (fs::exists(path)) { load_training_data(path); return; } // a mesh (SDF) or an image: mode_from_scene, common_host.cu:144-160
+	throw std::runtime_error{"File '" + path + "' does not exist."};
 }
 
 // ------------------------------------------------------------------------------------------------
 // training
 // ------------------------------------------------------------------------------------------------
+// NetworkWithInputEncoding + Trainer of the image / SDF modes from the network config (reset_network, testbed.cu:4160-4412)
+void Testbed::ensure_encmlp_trainer() {
+	if (m_image || m_sdf) return;
+	if (m_network_config.type != mini_json::Value::Object) reload_network_from_file("");
+	const bool image = mode == ETestbedMode::Image;
+	const auto& enc = m_network_config["encoding"]; const auto& net = m_network_config["network"];
+	ngp_encmlp_config c; memset(&c, 0, sizeof(c));
+	c.n_pos_dims = image ? 2 : 3; c.n_output_dims = image ? 3 : 1;
+	c.n_features_per_level = (uint32_t)enc.num("n_features_per_level", 2); c.n_levels = (uint32_t)enc.num("n_levels", 16);
+	c.log2_hashmap_size = (uint32_t)enc.num("log2_hashmap_size", 15); c.base_resolution = (uint32_t)enc.num("base_resolution", 16);
+	c.per_level_scale = (float)enc.num("per_level_scale", 0.0);
+	if (c.per_level_scale <= 0.f && c.n_levels > 1) { // testbed.cu:4241-4255: finest level = half the image's larger side / 2048 for a unit-cube SDF
+		const float desired = image ? (float)std::max(m_image_w, m_image_h) / 2.0f : 2048.0f;
+		c.per_level_scale = std::exp(std::log(desired / (float)c.base_resolution) / (float)(c.n_levels - 1));
+	}
+	c.n_neurons = (uint32_t)net.num("n_neurons", 64); c.n_hidden_layers = (uint32_t)net.num("n_hidden_layers", 2);
+	NGP_CHECK(ngp_encmlp_create(&c, seed, &m_encmlp));
+	ngp_optimizer_config oc{1e-3f, 0.9f, 0.999f, 1e-8f, 1e-8f, 0.f, 0, 0, 1.f};
+	const mini_json::Value* o = &m_network_config["optimizer"];
+	for (int depth = 0; depth < 4 && o->is_object(); ++depth) {
+		const std::string t = lower(o->str("otype", ""));
+		if (t == "ema") oc.ema_decay = (float)o->num("decay", 0.99);
+		else if (t == "exponentialdecay") { oc.decay_start = (uint32_t)o->num("decay_start", 10000); oc.decay_interval = (uint32_t)o->num("decay_interval", 10000); oc.decay_base = (float)o->num("decay_base", 0.33); }
+		else if (t == "adam") { oc.learning_rate = (float)o->num("learning_rate", 1e-3); oc.beta1 = (float)o->num("beta1", 0.9); oc.beta2 = (float)o->num("beta2", 0.999); oc.epsilon = (float)o->num("epsilon", 1e-8); oc.l2_reg = (float)o->num("l2_reg", 1e-8); }
+		if (!o->has("nested")) break;
+		o = &(*o)["nested"];
+	}
+	NGP_CHECK(ngp_encmlp_set_optimizer(m_encmlp, &oc));
+	const std::string lt = lower(m_network_config["loss"].str("otype", "L2"));
+	const int loss_type = lt == "mape" ? NGP_LOSS_MAPE : lt == "l1" ? NGP_LOSS_L1 : lt == "relativel2" ? NGP_LOSS_RELATIVE_L2 : NGP_LOSS_L2;
+	if (image) {
+		ngp_image_options io; memset(&io, 0, sizeof(io));
+		io.snap_to_pixel_centers = 1; io.linear_colors = 0; io.stratified = 1; io.loss_type = loss_type; io.loss_scale = 128.f; io.batch_size = training_batch_size; io.seed = seed;
+		NGP_CHECK(ngp_image_create(m_encmlp, m_image_pixels.data(), NGP_IMAGE_FLOAT, m_image_w, m_image_h, &io, &m_image));
+	} else {
+		ngp_sdf_options so; memset(&so, 0, sizeof(so));
+		so.loss_type = loss_type; so.loss_scale = 128.f; so.batch_size = training_batch_size; so.seed = seed; so.surface_offset_scale = 1.f; so.zero_offset = 0.f;
+		NGP_CHECK(ngp_sdf_create(m_encmlp, m_mesh.data(), (uint32_t)(m_mesh.size() / 9), m_mesh_aabb, &so, &m_sdf));
+	}
+}
+float Testbed::compute_image_mse(bool quantize_to_byte) {
+	if (mode != ETestbedMode::Image) throw std::runtime_error{"compute_image_mse: no image loaded"};
+	ensure_encmlp_trainer();
+	float mse = 0.f; NGP_CHECK(ngp_image_mse(m_image, quantize_to_byte ? 1 : 0, &mse));
+	return mse;
+}
+double Testbed::calculate_iou(uint32_t n_samples, float, bool, bool) {
+	if (mode != ETestbedMode::Sdf) throw std::runtime_error{"calculate_iou: no mesh loaded"};
+	ensure_encmlp_trainer();
+	double iou = 0; NGP_CHECK(ngp_sdf_iou(m_sdf, n_samples, &iou));
+	return iou;
+}
+
 void Testbed::train(uint32_t batch_size) {
+	if (mode == ETestbedMode::Image || mode == ETestbedMode::Sdf) { // train_image (testbed_image.cu:231) / training_prep_sdf + train_sdf (testbed_sdf.cu:1580-1635) + optimizer_step
+		if (batch_size != training_batch_size && !m_image && !m_sdf) training_batch_size = batch_size;
+		ensure_encmlp_trainer();
+		if (m_image) NGP_CHECK(ngp_image_train(m_image, nullptr, 1)); else NGP_CHECK(ngp_sdf_train(m_sdf, nullptr, 1));
+		++training_step;
+		if (training_step % 16 == 0 || training_step == 1) { if (m_image) NGP_CHECK(ngp_image_loss(m_image, nullptr, &loss)); else NGP_CHECK(ngp_sdf_loss(m_sdf, nullptr, &loss)); }
+		return;
+	}
 	if (nerf.training.dataset.n_images > 0 && nerf.training.dataset.pixels[0].empty())
 		throw std::runtime_error{"Cannot train: the dataset was restored from a snapshot's metadata only. Load the training data first."};
 	if (batch_size != training_batch_size && !m_nerf) training_batch_size = batch_size;
@@ -403,7 +497,7 @@ ngp_nerf_stats Testbed::stats() {
 	return s;
 }
 bool Testbed::frame() { // headless: one call = one optimizer step when training is on
-	if (shall_train && mode == ETestbedMode::Nerf) train(training_batch_size);
+	if (shall_train && (mode == ETestbedMode::Nerf || mode == ETestbedMode::Image || mode == ETestbedMode::Sdf)) train(training_batch_size);
 	return true;
 }
 

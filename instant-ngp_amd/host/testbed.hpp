@@ -81,6 +81,9 @@ public:
 	// render_to_cpu (python_api.cu:145-236): premultiplied RGBA float [h][w][4]
 	std::vector<float> render(int width, int height, int spp, bool linear);
 	ngp_nerf_stats stats();
+	// image / SDF primitives (testbed_image.cu, testbed_sdf.cu): same entry points (load_training_data, train / frame, loss), plus
+	float compute_image_mse(bool quantize_to_byte = false);                    // testbed_image.cu:490
+	double calculate_iou(uint32_t n_samples = 128u * 128u * 128u * 4u, float scale_existing_results_factor = 0.f, bool blocking = true, bool force_use_octree = false); // testbed_sdf.cu:1636
 	// data-parallel training (new): one process per GPU, ngp_comm_* of libngp_hip (RCCL); call before the first train()
 	static std::string comm_unique_id();
 	void comm_init(uint32_t rank, uint32_t world_size, const std::string& unique_id_128_bytes);
@@ -119,6 +122,11 @@ private:
 	std::string m_network_config_path;
 	ngp_model* m_model = nullptr;
 	ngp_nerf* m_nerf = nullptr;
+	// image / SDF modes: the NetworkWithInputEncoding model + its trainer state
+	ngp_encmlp* m_encmlp = nullptr; ngp_image* m_image = nullptr; ngp_sdf* m_sdf = nullptr;
+	std::vector<float> m_image_pixels; int m_image_w = 0, m_image_h = 0; // RGBA float32, linear
+	std::vector<float> m_mesh; ngp_aabb m_mesh_aabb{};                   // 9 floats per triangle, normalised into the unit cube (load_mesh)
+	void ensure_encmlp_trainer();
 	bool m_dataset_dirty = true;
 	// camera (testbed.h:453-456): column-major mat4x3
 	std::array<float, 12> m_camera{1, 0, 0, 0, 1, 0, 0, 0, 1, 0.5f, 0.5f, 0.5f};

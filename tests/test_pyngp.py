@@ -200,3 +200,33 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     t3.set_camera_to_training_view(1)
     c = t3.render(64, 64, 1, True)
     assert t3.training_step == 400 and np.abs(a - c).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_pyngp_image_and_sdf_modes():
+    """The other two primitives BASELINE.json names, through the same drop-in API: load_training_data picks the mode from the file
+    (mode_from_scene, common_host.cu:144-160), frame() trains (train_image / train_sdf), compute_image_mse / calculate_iou evaluate."""
+    ngp = _ngp()
+    data = os.path.join(ROOT, "_ref_data", "data")
+    exr, obj = os.path.join(data, "image", "albert.exr"), os.path.join(data, "sdf", "armadillo.obj")
+    if not (os.path.exists(exr) and os.path.exists(obj)):
+        pytest.skip("_ref_data not staged")
+    t = ngp.Testbed()
+    t.load_training_data(exr)
+    assert t.mode == ngp.TestbedMode.Image
+    t.training_batch_size = 1 << 16
+    mse0 = t.compute_image_mse()
+    for _ in range(500):
+        t.frame()
+    mse = t.compute_image_mse()
+    print(f"image: mse {mse0:.4f} -> {mse:.2e} ({-10 * math.log10(mse):.2f} dB) after {t.training_step} steps, loss {t.loss:.2e}")
+    assert t.training_step == 500 and mse < 0.02 * mse0 and -10 * math.log10(mse) > 30
+    t2 = ngp.Testbed()
+    t2.load_file(obj)
+    assert t2.mode == ngp.TestbedMode.Sdf
+    t2.training_batch_size = 1 << 16
+    for _ in range(1500):
+        t2.frame()
+    iou = t2.calculate_iou(1 << 20)
+    print(f"sdf: IoU {iou:.4f} after {t2.training_step} steps (configs/sdf/base.json: Adam lr 1e-4 + EMA), MAPE {t2.loss:.4f}")
+    assert iou > 0.9
