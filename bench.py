@@ -309,7 +309,8 @@ def main():
 
     # ---- roofline leg: per-kernel HIP-event timing over further (untimed) steps --------------------------------
     lib.ngp_profile_enable(1)
-    step(args.profile_steps)
+    step(max(args.profile_steps, 1))
+    args.profile_steps = max(args.profile_steps, 1)
     npf = lib.ngp_profile_count()
     ms = (C.c_double * npf)(); cnt = (C.c_uint64 * npf)()
     lib.ngp_profile_read(ms, cnt)
@@ -351,7 +352,9 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}, "mfma": mfma}
 
+    t_eval = time.perf_counter()
     psnr = eval_psnr(lib, nerf, scene, args.eval_spp) if (rank == 0 and args.eval_views > 0) else None
+    t_eval = time.perf_counter() - t_eval
     psnr_step = get_stats(lib, nerf).training_step
 
     # optional PSNR@step curve (BASELINE.json's second metric): keep training, untimed, and evaluate at the requested steps
@@ -389,7 +392,7 @@ def main():
                        "marched_samples_last_step": s1.measured_batch_size_before_compaction, "network_evaluations_last_step": s1.network_evaluations,
                        "loss": s1.loss, "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
                        "test_psnr_db": psnr, "test_psnr_at_step": (psnr_step if psnr is not None else None),
-                       "test_psnr_views": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}",
+                       "test_psnr_views": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "test_psnr_eval_seconds": round(t_eval, 3),
                        **({"dp_host_enqueue_ms_per_step": host_ms} if host_ms else {}),
                        **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {}),
                        **({"ab_psnr": ab} if ab else {})},

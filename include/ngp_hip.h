@@ -411,6 +411,11 @@ typedef struct ngp_render_params {
 int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_host,
                     float* frame_buffer, float* depth_buffer);
 
+/* CudaRenderBuffer::accumulate (running mean over spp, render_buffer.cu:228-260) and tonemap (Identity curve: 2^exposure, background behind
+ * the premultiplied colour, optional linear -> sRGB; :511-560) on device buffers of RGBA float32 */
+int ngp_render_accumulate(void* stream, const float* frame, float* accum, uint64_t n_floats, uint32_t sample_index);
+int ngp_render_tonemap(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb);
+
 /* ------------------------------------------------------------------ profiling ------------ */
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * enable(1) clears the accumulators; read() synchronises the pending events and returns, per kernel

@@ -1040,7 +1040,7 @@ struct ngp_nerf {
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
-	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
+	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; uint32_t* r_n_inf = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
 	uint8_t* bitfield_linear = nullptr; // x-major copy of the bitfield for the lattice marchers
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
@@ -1487,9 +1487,10 @@ extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_param
 	hipStream_t s = (hipStream_t)stream;
 	constexpr uint32_t TILE = 1u << 18;
 	if (!t->r_rays) {
-		if (dev_alloc(&t->r_rays, TILE) || dev_alloc(&t->r_masks, (size_t)TILE * RENDER_MAX_CHUNKS) || dev_alloc(&t->r_alive, TILE) || dev_alloc(&t->r_n_alive, 1) ||
+		if (dev_alloc(&t->r_rays, TILE) || dev_alloc(&t->r_masks, (size_t)TILE * RENDER_MAX_CHUNKS) || dev_alloc(&t->r_alive, TILE) || dev_alloc(&t->r_n_alive, 2) ||
 			dev_alloc(&t->r_coords, (size_t)TILE * RENDER_STEPS * 7) || dev_alloc(&t->r_out, (size_t)TILE * RENDER_STEPS * 4)) return 1;
 	}
+	t->r_n_inf = t->r_n_alive + 1; // live rays x RENDER_STEPS: the inference kernel's device-side element count
 	RenderArgs a;
 	a.p = *rp; a.train_aabb = t->aabb; a.bitfield = t->bitfield; a.max_mip = t->opt.max_cascade; a.cone_angle = t->opt.cone_angle_constant;
 	a.rgb_activation = t->opt.rgb_activation; a.density_activation = t->opt.density_activation; a.linear_colors = t->opt.linear_colors;
@@ -1501,17 +1502,38 @@ extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_param
 		launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
 		uint32_t n_alive = 0;
 		HIPCHK(hipMemcpyAsync(&n_alive, t->r_n_alive, 4, hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s)); // like the reference's per-compaction sync (testbed_nerf.cu:1735-1736)
-		for (uint32_t round = 0; n_alive > 0 && round < (RENDER_MAX_CHUNKS * 64) / RENDER_STEPS + 1; ++round) {
-			launch_render_emit(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords);
-			launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7, n_alive * RENDER_STEPS, nullptr, t->r_out, 4, false, 4);
-			launch_render_composite(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords, t->r_out);
-			launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
+		HIPCHK(hipStreamSynchronize(s));
+		// The reference synchronises after every compaction (testbed_nerf.cu:1735-1736).  Here the live-ray count stays on the device:
+		// emit / inference / composite take it from r_n_alive (grids sized for the last count the host has seen, an upper bound since rays
+		// only die), and the host looks at it after groups of 2, 4, 8, ... rounds -- a few read-backs per tile instead of one per round.
+		const uint32_t max_rounds = (RENDER_MAX_CHUNKS * 64) / RENDER_STEPS + 1;
+		for (uint32_t round = 0, group = 2; n_alive > 0 && round < max_rounds; group = std::min(group * 2, 16u)) {
+			for (uint32_t g = 0; g < group && round < max_rounds; ++g, ++round) {
+				launch_render_emit(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords);
+				launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7, n_alive * RENDER_STEPS, t->r_n_inf, t->r_out, 4, false, 4);
+				launch_render_composite(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords, t->r_out);
+				launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
+			}
 			HIPCHK(hipMemcpyAsync(&n_alive, t->r_n_alive, 4, hipMemcpyDeviceToHost, s));
 			HIPCHK(hipStreamSynchronize(s));
 		}
 		launch_render_finish(s, a, (uint32_t)begin, n, frame, depth);
 	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// CudaRenderBuffer::accumulate / tonemap (render_buffer.cu:228-260, 511-560; Identity tonemap curve): device-side so that a multi-spp
+// render leaves the GPU once, as the finished frame
+extern "C" int ngp_render_accumulate(void* stream, const float* frame, float* accum, uint64_t n_floats, uint32_t sample_index) {
+	REQUIRE(frame && accum, "ngp_render_accumulate: null argument");
+	launch_render_accumulate((hipStream_t)stream, (uint32_t)n_floats, frame, accum, 1.0f / (float)(sample_index + 1));
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_render_tonemap(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb) {
+	REQUIRE(rgba && background_linear, "ngp_render_tonemap: null argument");
+	launch_render_tonemap((hipStream_t)stream, (uint32_t)n_pixels, rgba, std::pow(2.0f, exposure), background_linear, to_srgb);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_render_compact(RenderArgs a, uint32_t n
 	const bool alive = li < n_pixels && a.rays[li].alive;
 	const uint64_t m = __ballot(alive);
 	uint32_t base = 0;
-	if ((threadIdx.x & 63u) == 0 && m) base = atomicAdd(n_alive, (uint32_t)__popcll(m));
+	if ((threadIdx.x & 63u) == 0 && m) { base = atomicAdd(n_alive, (uint32_t)__popcll(m)); atomicAdd(n_alive + 1, (uint32_t)__popcll(m) * RENDER_STEPS); } // [1] = network queries of the next round
 	base = __shfl(base, 0, 64);
 	if (alive) alive_list[base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull))] = li;
 }
@@ -162,13 +162,35 @@ __global__ void __launch_bounds__(256) k_render_finish(RenderArgs a, uint32_t pi
 	if (depth) depth[idx] = r.rgba[3] > 0.2f ? r.depth : K_MAX_DEPTH;
 }
 
+// accumulate_kernel (render_buffer.cu:228-260): running mean of the per-spp frames; tonemap_kernel (:511-560, Identity curve): exposure,
+// background behind the premultiplied colour, optional linear -> sRGB
+__global__ void __launch_bounds__(256) k_render_accumulate(uint32_t n_floats, const float* __restrict__ frame, float* __restrict__ accum, float weight) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i < n_floats) { const float a = accum[i]; accum[i] = a + (frame[i] - a) * weight; }
+}
+__global__ void __launch_bounds__(256) k_render_tonemap(uint32_t n_pixels, float* __restrict__ rgba, float exposure_scale, float bg0, float bg1, float bg2, float bg3, int to_srgb) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_pixels) return;
+	float4 c = ((float4*)rgba)[i];
+	const float a = c.w;
+	c.x = c.x * exposure_scale + bg0 * (1.f - a); c.y = c.y * exposure_scale + bg1 * (1.f - a); c.z = c.z * exposure_scale + bg2 * (1.f - a); c.w = a + bg3 * (1.f - a);
+	if (to_srgb) { c.x = linear_to_srgb(c.x); c.y = linear_to_srgb(c.y); c.z = linear_to_srgb(c.z); }
+	((float4*)rgba)[i] = c;
+}
+void launch_render_accumulate(hipStream_t s, uint32_t n_floats, const float* frame, float* accum, float weight) {
+	if (n_floats) hipLaunchKernelGGL(k_render_accumulate, dim3((n_floats + 255) / 256), dim3(256), 0, s, n_floats, frame, accum, weight);
+}
+void launch_render_tonemap(hipStream_t s, uint32_t n_pixels, float* rgba, float exposure_scale, const float bg[4], int to_srgb) {
+	if (n_pixels) hipLaunchKernelGGL(k_render_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, s, n_pixels, rgba, exposure_scale, bg[0], bg[1], bg[2], bg[3], to_srgb);
+}
+
 static inline uint32_t nblk(uint32_t n, uint32_t t) { return (n + t - 1) / t; }
 void launch_render_setup(hipStream_t s, const RenderArgs& a, uint32_t pixel_begin, uint32_t n) {
 	hipLaunchKernelGGL(k_render_setup, dim3(nblk(n, 128)), dim3(128), 0, s, a, pixel_begin, n);
 	hipLaunchKernelGGL(k_render_masks, dim3(nblk(n, 4)), dim3(256), 0, s, a, n);
 }
 void launch_render_compact(hipStream_t s, const RenderArgs& a, uint32_t n, uint32_t* alive_list, uint32_t* n_alive) {
-	(void)hipMemsetAsync(n_alive, 0, 4, s);
+	(void)hipMemsetAsync(n_alive, 0, 8, s);
 	hipLaunchKernelGGL(k_render_compact, dim3(nblk(n, 256)), dim3(256), 0, s, a, n, alive_list, n_alive);
 }
 void launch_render_emit(hipStream_t s, const RenderArgs& a, uint32_t n_alive_host, const uint32_t* alive_list, const uint32_t* n_alive, float* coords) {

@@ -555,12 +555,13 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 		ensure_trainer();
 		push_options();
 		const size_t n = (size_t)width * height * 4;
-		if (n > m_frame_dev_floats) {
+		if (2 * n > m_frame_dev_floats) { // [frame of one spp | accumulated frame]
 			if (m_frame_dev) HIP_CHECK(hipFree(m_frame_dev));
-			HIP_CHECK(hipMalloc((void**)&m_frame_dev, n * sizeof(float)));
-			m_frame_dev_floats = n;
+			HIP_CHECK(hipMalloc((void**)&m_frame_dev, 2 * n * sizeof(float)));
+			m_frame_dev_floats = 2 * n;
 		}
-		std::vector<float> tmp(n);
+		float* accum = m_frame_dev + n;
+		HIP_CHECK(hipMemsetAsync(accum, 0, n * sizeof(float), nullptr));
 		ngp_render_params rp; memset(&rp, 0, sizeof(rp));
 		rp.resolution[0] = width; rp.resolution[1] = height;
 		const int res_axis = fov_axis == 0 ? width : height;
@@ -574,19 +575,13 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 		rp.near_distance = 0.f;
 		rp.use_inference_params = 1; // the renderer uses the optimizer's EMA weights (testbed_nerf.cu:1772)
 		rp.render_aabb = scene_aabb();
-		for (int s = 0; s < std::max(spp, 1); ++s) {
+		for (int s = 0; s < std::max(spp, 1); ++s) { // accumulate + tonemap stay on the device (render_buffer.cu:228-260, 511-560): one read-back per frame
 			rp.spp_index = (uint32_t)s;
 			NGP_CHECK(ngp_nerf_render(m_nerf, nullptr, &rp, m_frame_dev, nullptr));
-			HIP_CHECK(hipMemcpy(tmp.data(), m_frame_dev, n * sizeof(float), hipMemcpyDeviceToHost));
-			const float wgt = 1.0f / (float)(s + 1); // accumulate_kernel: running mean over spp (render_buffer.cu:228-260)
-			for (size_t i = 0; i < n; ++i) out[i] += (tmp[i] - out[i]) * wgt;
+			NGP_CHECK(ngp_render_accumulate(nullptr, m_frame_dev, accum, n, (uint32_t)s));
 		}
-		for (size_t i = 0; i < (size_t)width * height; ++i) { // tonemap_kernel (render_buffer.cu:511-): exposure + background
-			float* o = &out[i * 4];
-			const float a = o[3];
-			for (int k = 0; k < 3; ++k) o[k] = o[k] * exposure_scale + bg[k] * (1.f - a);
-			o[3] = a + bg[3] * (1.f - a);
-		}
+		NGP_CHECK(ngp_render_tonemap(nullptr, accum, (uint64_t)width * height, exposure, bg, 0));
+		HIP_CHECK(hipMemcpy(out.data(), accum, n * sizeof(float), hipMemcpyDeviceToHost));
 	}
 	if (!linear) for (size_t i = 0; i < (size_t)width * height; ++i) for (int k = 0; k < 3; ++k) out[i * 4 + k] = lin_to_srgb(out[i * 4 + k]);
 	return out;
