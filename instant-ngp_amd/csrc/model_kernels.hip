@@ -900,21 +900,58 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	uint32_t idx[SPT][8], rank[SPT][8];
 	uint2 val[SPT][8];
 	bool valid[SPT];
+	const uint32_t lane = tid & 63u;
 #pragma unroll
 	for (int u = 0; u < SPT; ++u) {
 		const uint32_t s = blockIdx.x * GRAD_BIN_SAMPLES + u * 256 + tid;
 		valid[u] = s < a.n;
-		if (!valid[u]) continue;
-		const float* p = a.in + (size_t)s * a.in_stride;
-		const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + s]);
-		const float g0 = (float)g[0], g1 = (float)g[1], g2 = (float)g[2], g3 = (float)g[3];
+		float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
 		Corners cr;
-		level_corners(lc, p[0], p[1], p[2], cr);
+		{
+			const uint32_t sc = valid[u] ? s : a.n - 1; // every lane takes part in the shuffles below
+			const float* p = a.in + (size_t)sc * a.in_stride;
+			level_corners(lc, p[0], p[1], p[2], cr);
+			if (valid[u]) { const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + sc]); g0 = (float)g[0]; g1 = (float)g[1]; g2 = (float)g[2]; g3 = (float)g[3]; }
+		}
+		// Consecutive lanes are consecutive samples of (mostly) one ray; on the coarser hashed levels runs of them share a grid cell, i.e. all
+		// eight table entries.  Such runs are summed here (fp32, segmented shuffle reduction like T1's) and only the run head emits records:
+		// 20-25 % fewer records to sort, write, read and accumulate.  Wave-uniform decision: worth it when >= 1/4 of the lanes are followers.
+		const uint32_t key_xy = cr.cell_xy, key_z = cr.cell_z;
+		const uint32_t pxy = (uint32_t)__shfl_up((int)key_xy, 1, 64), pz = (uint32_t)__shfl_up((int)key_z, 1, 64);
+		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;
+		const bool head = lane == 0 || key_xy != pxy || key_z != pz || !valid[u] || !pvalid;
+		const uint64_t hm = __ballot(head);
+		const bool merge = a.merge_runs && __popcll(hm) <= 48;
+		bool emit = valid[u];
+		if (merge) {
+			const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
+			const uint32_t run_right = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : (63u - lane); // followers to my right that belong to my run
+			float v[8][4];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { const float w = cr.w[k]; v[k][0] = g0 * w; v[k][1] = g1 * w; v[k][2] = g2 * w; v[k][3] = g3 * w; }
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const bool take = run_right >= (uint32_t)d;
+#pragma unroll
+				for (int k = 0; k < 8; ++k)
+#pragma unroll
+					for (int f = 0; f < 4; ++f) { const float t = __shfl_down(v[k][f], d, 64); if (take) v[k][f] += t; }
+			}
+			emit = valid[u] && head;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { const h4 hv = {(_Float16)v[k][0], (_Float16)v[k][1], (_Float16)v[k][2], (_Float16)v[k][3]}; val[u][k] = __builtin_bit_cast(uint2, hv); }
+		} else {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const float w = cr.w[k];
+				const h4 hv = {(_Float16)(g0 * w), (_Float16)(g1 * w), (_Float16)(g2 * w), (_Float16)(g3 * w)};
+				val[u][k] = __builtin_bit_cast(uint2, hv);
+			}
+		}
+		valid[u] = emit;
+		if (!emit) continue;
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			const float w = cr.w[k];
-			const h4 v = {(_Float16)(g0 * w), (_Float16)(g1 * w), (_Float16)(g2 * w), (_Float16)(g3 * w)};
-			val[u][k] = __builtin_bit_cast(uint2, v);
 			idx[u][k] = cr.idx[k];
 			rank[u][k] = atomicAdd(&s_cnt[cr.idx[k] >> CL2], 1u);
 		}
@@ -1243,6 +1280,176 @@ k_wgrad(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// W, two roles per workgroup (round 2).  k_wgrad keeps all 12 dW tiles in one wavefront: 192 accumulators + the working set spill 104
+// VGPRs to scratch, the wave owns its SIMD's whole register file (nothing else can run there) and has nobody to hide its LDS / scratch /
+// global latencies behind (matrix pipe busy 7.7 % of the kernel, profiles/r02_pmc_mfma_tcc.txt).  Here a workgroup has 8 waves:
+// waves 0-3 (role A) accumulate the density-net tiles and the colour net's first layer  (d1, d2, r1: 6 tiles),
+// waves 4-7 (role B) the colour net's second and third layer (r2, r3: 6 tiles);
+// wave w and wave w+4 land on the same SIMD and work on the SAME 32-sample tiles, each recomputing the part of the forward / dgrad chain
+// it needs (~16 % more MFMA work in total) with 96 accumulators and no spills, two waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+template <int ROLE>
+DEV void wgrad_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, const float* __restrict__ p, const uint4* __restrict__ enc_stash, uint32_t ct,
+		const __half* __restrict__ dL_dy, uint32_t dy_stride, uint32_t s_raw, const h8& I0, const h8& I1, f16v dW[6]) {
+	FwdState<1> st;
+	st.enc[0][0] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 0) * 64 + lane]);
+	st.enc[0][1] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 1) * 64 + lane]);
+	st.rin[0][1] = sh4_frag(p[4], p[5], p[6], hi);
+	h8 dy0 = zero8(); _Float16 dsig = (_Float16)0.f;
+	if (hi == 0 && valid) {
+		const h4 g = __builtin_bit_cast(h4, *(const uint2*)(dL_dy + (size_t)s_raw * dy_stride));
+		dy0[0] = g[0]; dy0[1] = g[1]; dy0[2] = g[2]; dsig = g[3];
+	}
+	fwd_density_l1<1>(fw, lane, st);
+	fwd_density_l2<1>(fw, lane, st);
+	fwd_rgb_l1<1>(fw, lane, st);
+	// swapped activations of the colour net's first hidden layer: both roles mask gradients with them
+	h8 h1r_sw[2][2];
+#pragma unroll
+	for (int kt = 0; kt < 2; ++kt) {
+		f16v t = zero16();
+#pragma unroll
+		for (int s = 0; s < 2; ++s) t = mfma(st.rin[0][s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
+		sw_to_frags(t, true, h1r_sw[kt]);
+	}
+	if (ROLE == 1) {
+		// ---- role B: r3 = d_out x h2r^T, r2 = d_h2 x h1r^T ----
+		h8 h2r_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) t = mfma(st.hb[0][s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
+			sw_to_frags(t, true, h2r_sw[kt]);
+		}
+		h8 g_sw[2];
+		{ f16v t = mfma(dy0, I0, zero16()); sw_to_frags(t, false, g_sw); }
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[4 + kt] = mfma(g_sw[q], h2r_sw[kt][q], dW[4 + kt]);
+#pragma unroll
+		for (int it = 0; it < 2; ++it) {
+			const h8 a = lds_frag(bw, BW_R3 + it, lane);
+			f16v dsw = mfma(dy0, a, zero16());
+			h8 d2_sw[2];
+			sw_grad_to_frags(dsw, h2r_sw[it], d2_sw);
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+				for (int q = 0; q < 2; ++q) dW[it * 2 + kt] = mfma(d2_sw[q], h1r_sw[kt][q], dW[it * 2 + kt]);
+		}
+		return;
+	}
+	// ---- role A: r1 = d_h1r x rin^T, d2 = d_densout x h1d^T, d1 = d_h1d x enc^T ----
+	fwd_rgb_l2<1>(fw, lane, st); // only the ReLU mask m2r is consumed below
+	h8 dh[4];
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt) {
+		f16v d = mfma(lds_frag(bw, BW_R3 + mt, lane), dy0, zero16());
+		dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
+		dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+	}
+	h8 dh1[4];
+	{
+		h8 rin_sw[2];
+		{ f16v t = mfma(st.rin[0][0], I0, zero16()); t = mfma(st.rin[0][1], I1, t); sw_to_frags(t, false, rin_sw); }
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			f16v d = zero16(), dsw = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				const h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
+				d = mfma(a, dh[s], d);
+				dsw = mfma(dh[s], a, dsw);
+			}
+			dh1[2 * mt + 0] = to_frag_masked(d, 0, st.m1r[0] >> (16 * mt));
+			dh1[2 * mt + 1] = to_frag_masked(d, 1, st.m1r[0] >> (16 * mt));
+			h8 d1_sw[2];
+			sw_grad_to_frags(dsw, h1r_sw[mt], d1_sw);
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[4 + mt] = mfma(d1_sw[q], rin_sw[q], dW[4 + mt]);
+		}
+	}
+	h8 ddens;
+	{
+		f16v d = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) d = mfma(lds_frag(bw, BW_R1 + s, lane), dh1[s], d);
+		uint32_t dummy = 0;
+		ddens = to_frag<false>(d, 0, dummy);
+		if (hi == 0) ddens[0] = (_Float16)((float)ddens[0] + (float)dsig);
+	}
+	h8 g_sw[2];
+	{ f16v t = mfma(ddens, I0, zero16()); sw_to_frags(t, false, g_sw); }
+	h8 h1d_sw[2][2];
+#pragma unroll
+	for (int kt = 0; kt < 2; ++kt) {
+		f16v t = zero16();
+#pragma unroll
+		for (int s = 0; s < 2; ++s) t = mfma(st.enc[0][s], lds_frag(fw, FW_D1 + kt * 2 + s, lane), t);
+		sw_to_frags(t, true, h1d_sw[kt]);
+	}
+#pragma unroll
+	for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+		for (int q = 0; q < 2; ++q) dW[2 + kt] = mfma(g_sw[q], h1d_sw[kt][q], dW[2 + kt]);
+	h8 enc_sw[2];
+	{ f16v t = mfma(st.enc[0][0], I0, zero16()); t = mfma(st.enc[0][1], I1, t); sw_to_frags(t, false, enc_sw); }
+#pragma unroll
+	for (int it = 0; it < 2; ++it) {
+		f16v dsw = mfma(ddens, lds_frag(bw, BW_D2 + it, lane), zero16());
+		h8 dd_sw[2];
+		sw_grad_to_frags(dsw, h1d_sw[it], dd_sw);
+#pragma unroll
+		for (int q = 0; q < 2; ++q) dW[0 + it] = mfma(dd_sw[q], enc_sw[q], dW[0 + it]);
+	}
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_wgrad2(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n, const __half* __restrict__ dL_dy, uint32_t dy_stride,
+		const uint4* __restrict__ enc_stash, float* __restrict__ partials) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	h8* bw = fw + N_FW_FRAGS * 64;
+	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
+	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6, role = wid >> 2, w4 = wid & 3;
+	const uint32_t wave = blockIdx.x * 4 + w4, n_waves = gridDim.x * 4; // the two roles walk the same tiles
+	f16v dW[6]; // role A: d1 (0,1), d2 (2,3), r1 (4,5) = tiles 0..5; role B: r2 (0..3), r3 (4,5) = tiles 6..11
+#pragma unroll
+	for (int t = 0; t < 6; ++t) dW[t] = zero16();
+	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
+	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) {
+		const uint32_t s_raw = ct * 32 + col;
+		const bool valid = s_raw < n;
+		const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
+		if (role == 0) wgrad_tile<0>(fw, bw, lane, hi, valid, p, enc_stash, ct, dL_dy, dy_stride, s_raw, I0, I1, dW);
+		else wgrad_tile<1>(fw, bw, lane, hi, valid, p, enc_stash, ct, dL_dy, dy_stride, s_raw, I0, I1, dW);
+	}
+	// reduce the 4 waves of each role through LDS (re-using the fragment region: 6 tiles * 16 regs * 64 lanes * 4 B = 24 KiB), one role at a time
+	float* red = (float*)smem;
+	float* dstp = partials + (size_t)blockIdx.x * (N_DW_TILES * 16 * 64);
+	for (int r = 0; r < 2; ++r) {
+		__syncthreads();
+		for (int w = 0; w < 4; ++w) {
+			if (role == r && w4 == w) {
+#pragma unroll
+				for (int t = 0; t < 6; ++t)
+#pragma unroll
+					for (int q = 0; q < 16; ++q) {
+						float* dst = red + ((size_t)t * 16 + q) * 64 + lane;
+						*dst = (w == 0 ? 0.f : *dst) + dW[t][q];
+					}
+			}
+			__syncthreads();
+		}
+		for (int i = threadIdx.x; i < 6 * 16 * 64; i += blockDim.x) dstp[r * 6 * 16 * 64 + i] = red[i];
+	}
+}
+
 // sum the per-block partials, un-permute the D tiles into row-major [out][in] and round to half.
 // One block per 64 consecutive elements (= one register row of a tile): 4 waves each sum a quarter of the partials with
 // coalesced 256-byte reads, then combine through LDS in a fixed order (deterministic).
@@ -1538,6 +1745,7 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 	if (i >= a.n_params) return;
 	const bool matrix = i < a.n_mlp; // n_mlp is a multiple of 4
 	const h4 g4 = __builtin_bit_cast(h4, ((const uint2*)a.grads)[i4]);
+	if (a.zero_grid_grads && !matrix) ((uint2*)a.grads)[i4] = make_uint2(0u, 0u); // consumed: the next step's scatter starts from zero
 	h4 w4 = __builtin_bit_cast(h4, ((const uint2*)a.params)[i4]);
 	float g[4]; bool upd[4]; bool any = false;
 #pragma unroll
@@ -1686,7 +1894,8 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {
 	if (n == 0) return;
 	const uint32_t lds = (N_FW_FRAGS + N_BW_FRAGS) * 1024;
-	hipLaunchKernelGGL(k_wgrad, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
+	if (g_debug_flags & DBG_W_SINGLE_ROLE) hipLaunchKernelGGL(k_wgrad, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
+	else hipLaunchKernelGGL(k_wgrad2, dim3(n_partials), dim3(512), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
 }
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad) {
 	hipLaunchKernelGGL(k_wgrad_reduce, dim3(N_DW_TILES * 16), dim3(256), 0, s, partials, n_partials, (__half*)mlp_grad);

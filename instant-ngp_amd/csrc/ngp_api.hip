@@ -165,6 +165,7 @@ struct ngp_model {
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
+	bool grads_clean = true; // the hash-grid part of `grads` is all zero (after creation / after an optimizer sweep that zeroed it)
 };
 
 // pcg32(initstate, initseq = 1) [tcnn pcg32.h]
@@ -359,7 +360,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	}
 	// binned scatter: every hashed level must have a power-of-two table of 2^chunk_log2 .. 2^19 entries (base.json: 2^19)
 	GradBinArgs& ba = m->bin_args;
-	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split;
+	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = !(g_debug_flags & DBG_BIN_NO_MERGE);
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
@@ -389,7 +390,8 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		m->bin_n = n_alloc; m->bin_cap = cap_want; m->bin_lists = (uint32_t)n_lists;
 	}
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
-	{ ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
+	if (!m->grads_clean) { ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
+	m->grads_clean = false;
 	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, g_debug_flags,
 		ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
@@ -594,7 +596,7 @@ extern "C" int ngp_encmlp_optimizer_step(ngp_encmlp* m, void* stream, float loss
 	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
 	a.beta1 = m->opt.beta1; a.beta2 = m->opt.beta2; a.eps = m->opt.epsilon; a.l2_reg = m->opt.l2_reg;
 	a.log_beta1 = std::log(m->opt.beta1); a.log_beta2 = std::log(m->opt.beta2);
-	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
+	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding; a.zero_grid_grads = 0;
 	const float d = m->opt.ema_decay; // 0 without an Ema wrapper: the inference parameters then equal the parameters
 	a.ema_decay = d;
 	a.ema_debias_old = 1 - std::pow(d, (float)(m->step - 1));
@@ -853,6 +855,7 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.epsilon; a.l2_reg = m->cfg.l2_reg;
 	a.log_beta1 = std::log(m->cfg.beta1); a.log_beta2 = std::log(m->cfg.beta2);
 	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
+	a.zero_grid_grads = !(g_debug_flags & DBG_NO_GRAD_ZERO_IN_OPTIMIZER);
 	const float d = m->cfg.ema_decay;
 	a.ema_decay = d;
 	a.ema_debias_old = 1 - std::pow(d, (float)(m->step - 1));
@@ -861,6 +864,7 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema;
 	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
 	{ ProfScope ps(P_OPTIMIZER, (hipStream_t)stream); launch_optimizer_step((hipStream_t)stream, a); }
+	m->grads_clean = a.zero_grid_grads != 0;
 	HIPCHK(hipGetLastError());
 	// ExponentialDecay::step [tcnn]
 	if (m->cfg.decay_interval > 0 && m->step >= m->cfg.decay_start && m->step % m->cfg.decay_interval == 0) m->lr *= m->cfg.decay_base;

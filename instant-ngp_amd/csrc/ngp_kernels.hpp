@@ -9,6 +9,8 @@ namespace ngp {
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
+	DBG_BIN_NO_MERGE = 65536 /* k_grad_bin without the same-cell run merging */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
+	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
 	DBG_K1_INDEPENDENT_LATTICE = 16384 /* lattice K1 without the exact skip rule: every lattice point tested on its own (round-1 behaviour; exact only for cone_angle == 0) */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
@@ -158,7 +160,7 @@ struct GradBinArgs {
 	const GridMeta* gm; const float* in; uint32_t in_stride, n;
 	const uint2* denc_lv; uint32_t denc_cap;
 	uint32_t levels[MAX_LEVELS]; uint32_t n_hashed, max_chunks, cap;
-	uint32_t chunk_log2, split;
+	uint32_t chunk_log2, split, merge_runs;
 	uint2* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
 };
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
@@ -172,6 +174,7 @@ struct AdamArgs {
 	uint64_t n_params, n_mlp;
 	float loss_scale, lr, beta1, beta2, eps, l2_reg, log_beta1, log_beta2;
 	int optimize_matrix, optimize_non_matrix;
+	int zero_grid_grads; // leave the hash-grid gradients zeroed for the next step's scatter (GradientMode::Overwrite without a memset launch)
 	float ema_decay, ema_debias_old, ema_debias_new;
 	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
 	float* m; float* v; uint32_t* steps; float* ema;

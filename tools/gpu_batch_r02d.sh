@@ -9,7 +9,7 @@ echo "== pytest" ; date
 timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc $?"
 grep -v "^$" gpurun_out/${TAG}_pytest_gpu.log | tail -12 | cut -c1-300
 echo "== microbench" ; date
-timeout 420 python tools/microbench.py 1000 32 default,k2_tile16_r4,k2_tile16_r3,k2_tile16_r5,default_again > gpurun_out/${TAG}_microbench.log 2> gpurun_out/${TAG}_microbench.err; echo "microbench rc $?"
+timeout 420 python tools/microbench.py 1000 32 default,w_single_role,bin_no_merge,separate_grad_memset,round1_backward,default_again > gpurun_out/${TAG}_microbench.log 2> gpurun_out/${TAG}_microbench.err; echo "microbench rc $?"
 cut -c1-700 gpurun_out/${TAG}_microbench.log
 prof() { # tag, env...
   tag=$1; shift
@@ -23,5 +23,5 @@ prof() { # tag, env...
 }
 echo "== rocprof traces" ; date
 prof nooverlap NGP_DEBUG_FLAGS=4096
-prof k2tile16 NGP_K2_TILE=16 NGP_K2_ROUNDS=4 NGP_DEBUG_FLAGS=4096
+prof overlap NGP_X=1
 date
