@@ -433,7 +433,8 @@ int ngp_nerf_scratch_ptrs(ngp_nerf*, uint32_t** ray_indices, ngp_ray** rays, uin
 int ngp_nerf_set_rays_per_batch(ngp_nerf*, uint32_t rays_per_batch);
 int ngp_nerf_get_rng(ngp_nerf*, ngp_pcg32* rng, ngp_pcg32* density_grid_rng);
 int ngp_nerf_set_rng(ngp_nerf*, const ngp_pcg32* rng);
-/* lazy (front-to-back) K2: number of rounds (2..8) and samples per tile (16 | 32); defaults 3 x 32 (csrc/model_kernels.hip k_inference_tiles) */
+/* lazy (front-to-back) K2: rounds = 1 (default): one launch, every wavefront follows its ray tile by tile; rounds = 2..8: list-driven rounds;
+   samples per tile 32 (or 16 with >= 2 rounds) (csrc/model_kernels.hip k_inference_tiles) */
 int ngp_nerf_set_k2_params(ngp_nerf*, uint32_t rounds, uint32_t tile_w);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);

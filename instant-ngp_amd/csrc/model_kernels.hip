@@ -439,10 +439,12 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		const uint32_t tile = wt * TPW + slot;
 		uint4 d = make_uint4(0u, 0u, 0u, 0u);
 		if (tile < n_tiles) d = tiles[tile];
+		float T_wave = 1.f; // n_rounds == 1: transmittance behind the tiles this wavefront has evaluated of its ray
+		for (;;) {
 		// d.y == 0: a ray K1 dropped at its sample cap (its base may lie outside the buffers) or no tile in this slot: nothing to evaluate
 		const bool valid = tcol < d.y;
 		const uint32_t sample = valid ? d.x + tcol : 0u;
-		if (__ballot(valid) == 0ull) continue;
+		if (__ballot(valid) == 0ull) break;
 		FwdState<1> st;
 		const float* p = in + (size_t)sample * in_stride;
 		encode_sample<false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
@@ -459,6 +461,27 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		}
 		const bool leader = hi == 0 && tcol == 0;
 		if (leader) n_eval += d.y;
+		if (TW == 32 && la.n_rounds == 1) {
+			// One launch, no lists: the wavefront that evaluated a tile of a still transparent ray goes on with the ray's next tile itself
+			// (one tile per wavefront, so the descriptor and the decision are wave-uniform).  Strictly lazier than the round scheme, whose last
+			// round takes everything that is left, and two launches + their ramps and gaps shorter.
+			if (d.w == 0u) break;
+			float od = 0.f;
+			if (hi == 0 && valid) {
+				const float x = st.sigma[0];
+				const float sg = la.density_activation == NGP_ACT_NONE ? x : la.density_activation == NGP_ACT_RELU ? fmaxf(x, 0.f)
+					: la.density_activation == NGP_ACT_LOGISTIC ? 1.f / (1.f + __expf(-x)) : __expf(x);
+				od = sg * (p[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
+			}
+#pragma unroll
+			for (int dd = 16; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64);
+			T_wave *= __expf(-od);
+			const float T0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, T_wave)));
+			if (T0 < 0.99e-4f) break; // NaN stays alive, like in K3
+			const uint32_t take = min(d.w, TW);
+			d = make_uint4(d.x + TW, take, d.z, d.w - take);
+			continue;
+		}
 		// Transmittance behind this tile (an estimate with a safety margin: K3 recomputes the exact compositing).  A ray that is
 		// still transparent gets its next tile -- or, if the next round is the last one, all its remaining tiles -- appended to the
 		// next round's list: 1 % below K3's threshold, so K3's own test can never walk into an unevaluated sample; NaN stays alive.
@@ -486,6 +509,8 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 				n_pend += (uint32_t)__popcll(cm);
 				if (n_pend + TPW > PEND_CAP) flush();
 			}
+		}
+		break;
 		}
 	}
 	if (n_pend) flush();
@@ -767,8 +792,9 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 				// Hashed levels (binned mode): the memory side retires only ~14 G atomic requests/s, and hashed corners neither
 				// merge nor coalesce -- they were 85 % of T1's atomic requests.  Their dL/d(enc) goes to memory level-major
 				// (8 bytes per sample and level, coalesced) and k_grad_bin / k_grad_accumulate turn it into table gradients
-				// through LDS accumulators, without global atomics.  Dense levels keep the merged + coalesced atomics below.
-				const bool binned = denc_lv != nullptr && lc.hashed;
+				// through LDS accumulators, without global atomics.  Dense levels: merged + coalesced atomics, either below or (T1_DENSE_EXTERNAL,
+				// production) in k_grad_dense, which runs beside k_grad_bin / k_grad_accumulate / W on its own stream.
+				const bool binned = denc_lv != nullptr && (lc.hashed || (flags & T1_DENSE_EXTERNAL));
 				if (binned && sv) {
 					const h4 g = {(_Float16)denc[c][4 * rr + 0], (_Float16)denc[c][4 * rr + 1], (_Float16)denc[c][4 * rr + 2], (_Float16)denc[c][4 * rr + 3]};
 					denc_lv[(size_t)(2 * rr + hi) * denc_cap + sidx[c]] = __builtin_bit_cast(uint2, g);
@@ -1081,6 +1107,72 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 #pragma unroll
 			for (int f = 0; f < 4; ++f) r[f] = (_Float16)((float)old[f] + (float)(long long)acc[f * E + e] * 0x1p-24f);
 			gt[e] = __builtin_bit_cast(uint2, r);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense levels' scatter (the levels whose grid fits the table: 16^3 .. 64^3 in base.json), from the level-major dL/d(enc) that T1
+// leaves in memory.  One lane = one sample, 64 consecutive samples (mostly of one ray) per wavefront: runs of samples in the same
+// grid cell are summed in packed half by a segmented shuffle reduction and only the run head issues atomics; a lane QUAD issues the
+// 16 bytes of an x-adjacent corner pair in one instruction (one memory-side request).  The memory side retires ~14 G atomic requests
+// per second whatever the kernel around them does, so these requests are issued from a small kernel that shares the chip with the
+// LDS-bound k_grad_bin / k_grad_accumulate and the MFMA-bound W instead of from T1's critical path (T1: 170 -> 65 us).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_grad_dense(GradDenseArgs a) {
+	const uint32_t level = a.levels[blockIdx.y];
+	const LevelConst lc = level_const_uniform(a.gm, level);
+	const int lane = threadIdx.x & 63;
+	const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+	if ((s & ~63u) >= a.n) return; // whole wavefront past the end
+	const bool sv = s < a.n;
+	const uint32_t sc = sv ? s : a.n - 1;
+	const float* p = a.in + (size_t)sc * a.in_stride;
+	Corners cr;
+	level_corners(lc, p[0], p[1], p[2], cr);
+	float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+	if (sv) { const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + sc]); g0 = (float)g[0]; g1 = (float)g[1]; g2 = (float)g[2]; g3 = (float)g[3]; }
+	h2 v0[8], v1[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const float w = cr.w[k];
+		h2 a0 = {(_Float16)(g0 * w), (_Float16)(g1 * w)}, a1 = {(_Float16)(g2 * w), (_Float16)(g3 * w)};
+		v0[k] = a0; v1[k] = a1;
+	}
+	const uint32_t key = cr.cell_xy, key7 = cr.cell_z;
+	const uint32_t pkey = (uint32_t)__shfl_up((int)key, 1, 64), pkey7 = (uint32_t)__shfl_up((int)key7, 1, 64);
+	const bool head = lane == 0 || key != pkey || key7 != pkey7;
+	const uint64_t hm = __ballot(head);
+	bool issue = true;
+	if (a.merge_runs && __popcll(hm) <= 48) {
+		const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
+		const uint32_t run_right = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : (uint32_t)(63 - lane);
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const bool take = run_right >= (uint32_t)d;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const h2 t0 = __builtin_bit_cast(h2, __shfl_down(__builtin_bit_cast(int, v0[k]), d, 64));
+				const h2 t1 = __builtin_bit_cast(h2, __shfl_down(__builtin_bit_cast(int, v1[k]), d, 64));
+				if (take) { v0[k] += t0; v1[k] += t1; }
+			}
+		}
+		issue = head;
+	}
+	__half* gt = (__half*)a.grid_grad_ + (size_t)lc.offset * 4;
+	const bool own = issue && sv;
+	const int r4 = lane & 3;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const bool go = __shfl((int)own, q, 4) != 0;
+#pragma unroll
+		for (int pp = 0; pp < 4; ++pp) {
+			const uint32_t i0 = (uint32_t)__shfl((int)cr.idx[2 * pp], q, 4), i1 = (uint32_t)__shfl((int)cr.idx[2 * pp + 1], q, 4);
+			const int a0 = __shfl(__builtin_bit_cast(int, v0[2 * pp]), q, 4), a1 = __shfl(__builtin_bit_cast(int, v1[2 * pp]), q, 4);
+			const int b0 = __shfl(__builtin_bit_cast(int, v0[2 * pp + 1]), q, 4), b1 = __shfl(__builtin_bit_cast(int, v1[2 * pp + 1]), q, 4);
+			const uint32_t ix = (r4 & 2) ? i1 : i0;
+			const int val = r4 == 0 ? a0 : r4 == 1 ? a1 : r4 == 2 ? b0 : b1;
+			if (go) atomic_add_h2(gt + (size_t)ix * 4 + (r4 & 1) * 2, __builtin_bit_cast(h2, val));
 		}
 	}
 }
@@ -1889,6 +1981,10 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 	else
 		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
 			(__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
+}
+void launch_grad_dense(hipStream_t s, const GradDenseArgs& a) {
+	if (a.n == 0 || a.n_levels == 0) return;
+	hipLaunchKernelGGL(k_grad_dense, dim3((a.n + 255) / 256, a.n_levels), dim3(256), 0, s, a);
 }
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {

@@ -160,7 +160,7 @@ struct ngp_model {
 	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0, bin_lists = 0;
 	GradBinArgs bin_args{};
 	// W (weight gradients, compute bound, 1 wave/SIMD) runs on a side stream next to the hashed levels' bin/accumulate kernels (memory/LDS bound)
-	hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t side = nullptr, side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 	// data-parallel step: events that mark the two gradient buckets final (recorded when record_bucket_events is set, see ngp_comm_*)
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
 	uint32_t step = 0; float lr = 1e-2f;
@@ -274,6 +274,8 @@ extern "C" void ngp_model_destroy(ngp_model* m) {
 		m->fw_frags, m->bw_frags, m->fw_frags_inf, m->enc_stash, m->wgrad_partials, m->denc_lv, m->bin_vals, m->bin_idxs, m->bin_cursors};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	if (m->side) (void)hipStreamDestroy(m->side);
+	if (m->side2) (void)hipStreamDestroy(m->side2);
+	if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
 	if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
 	if (m->ev_join) (void)hipEventDestroy(m->ev_join);
 	if (m->ev_hashed_ready) (void)hipEventDestroy(m->ev_hashed_ready);
@@ -392,8 +394,13 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
 	if (!m->grads_clean) { ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
 	m->grads_clean = false;
-	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash, g_debug_flags,
-		ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
+	// dense levels: T1 leaves their dL/d(enc) in denc_lv as well and k_grad_dense issues the atomics beside the kernels below
+	GradDenseArgs da;
+	da.n_levels = 0;
+	if (ba.n_hashed && !(g_debug_flags & (DBG_T1_DENSE_INLINE | DBG_T1_NO_SCATTER)))
+		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
+	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
+		g_debug_flags | (da.n_levels ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
 	hipStream_t sw = s;
@@ -402,6 +409,16 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
 		sw = m->side;
 	}
+	if (da.n_levels) {
+		da.gm = m->gm_dev; da.in = in; da.in_stride = in_stride; da.n = n; da.denc_lv = (const uint2*)m->denc_lv; da.denc_cap = m->bin_n;
+		da.merge_runs = !(g_debug_flags & DBG_T1_NO_MERGE); da.grid_grad_ = m->grads + m->n_mlp;
+		if (overlap) {
+			if (!m->side2) { HIPCHK(hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming)); }
+			HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork, 0));
+			launch_grad_dense(m->side2, da);
+			HIPCHK(hipEventRecord(m->ev_join2, m->side2));
+		}
+	}
 	{ ProfScope ps(P_W_WGRAD, sw); launch_wgrad(sw, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
 	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads); }
 	if (ba.n_hashed) {
@@ -409,7 +426,9 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = (const uint2*)m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap;
 		ba.vals = (uint2*)m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
 		launch_grad_bin(s, ba);
+		if (da.n_levels && !overlap) launch_grad_dense(s, da); // profiling / single-stream mode: part of the same scope (one unit of algorithmic work)
 	}
+	if (da.n_levels && overlap) HIPCHK(hipStreamWaitEvent(sw, m->ev_join2, 0)); // bucket A (MLP + dense levels) is final behind W's stream from here on
 	if (m->record_bucket_events) { // bucket B (hashed levels) is final behind k_grad_accumulate, bucket A (MLP + dense levels) behind T1 and k_wgrad_reduce
 		if (!m->ev_hashed_ready) { HIPCHK(hipEventCreateWithFlags(&m->ev_hashed_ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&m->ev_mlp_ready, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(m->ev_hashed_ready, s)); HIPCHK(hipEventRecord(m->ev_mlp_ready, sw));
@@ -1040,7 +1059,7 @@ struct ngp_nerf {
 	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
 	bool ctl_done = false; // the batch-size controller of the current step has run
 	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
-	uint32_t k2_rounds = 3, k2_tile_w = 32; // measured (profiles/r02_microbench_k2.log): 3 x 32 = 0.157 ms, 4 x 16 = 0.18 ms although it evaluates 30 % fewer samples (per-round wave quantisation + one more launch); NGP_K2_ROUNDS=2..8 / NGP_K2_TILE=16|32 override (tuning knobs; round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest)
+	uint32_t k2_rounds = 1, k2_tile_w = 32; // 1 = one launch, every wavefront follows its ray front to back (default); 2..8 = list-driven rounds (round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest): 3 x 32 = 0.157 ms, 4 x 16 = 0.18 ms (profiles/r02_microbench_k2.log).  NGP_K2_ROUNDS / NGP_K2_TILE override.
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
@@ -1067,8 +1086,9 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	t->density_grid_rng = make_rng(t->rng.next_uint()); // testbed.cu:4178
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
-	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 2), K2_ROUNDS);
+	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 1), K2_ROUNDS);
 	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : 16u;
+	if (t->k2_tile_w == 16 && t->k2_rounds < 2) t->k2_rounds = 2;
 	t->grid_sample_cap = n_cells;
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
@@ -1474,9 +1494,9 @@ extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
 	HIPCHK(hipMemcpy(&t->counters->training_step, &step, 4, hipMemcpyHostToDevice));
 	return 0;
 }
-// lazy K2 tuning knobs (test / ablation hook): number of front-to-back rounds (2..8) and samples per tile (16 | 32)
+// lazy K2 tuning knobs (test / ablation hook): 1 = single launch with in-wave continuation, 2..8 = list-driven front-to-back rounds; samples per tile (16 | 32)
 extern "C" int ngp_nerf_set_k2_params(ngp_nerf* t, uint32_t rounds, uint32_t tile_w) {
-	REQUIRE(rounds >= 2 && rounds <= K2_ROUNDS && (tile_w == 16 || tile_w == 32), "set_k2_params: rounds in 2..8, tile width 16 or 32");
+	REQUIRE(rounds >= 1 && rounds <= K2_ROUNDS && (tile_w == 32 || (tile_w == 16 && rounds >= 2)), "set_k2_params: rounds in 1..8 (1 = one launch, wavefronts follow their rays), tile width 32, or 16 with >= 2 rounds");
 	invalidate_k1(t); // a pre-launched K1 wrote its round-0 tiles with the old width
 	t->k2_rounds = rounds; t->k2_tile_w = tile_w;
 	return 0;

@@ -10,6 +10,7 @@ namespace ngp {
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_NO_MERGE = 65536 /* k_grad_bin without the same-cell run merging */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
+	DBG_T1_DENSE_INLINE = 262144 /* dense levels' atomics issued by T1 itself instead of k_grad_dense on its own stream (round-1 behaviour) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
 	DBG_K1_INDEPENDENT_LATTICE = 16384 /* lattice K1 without the exact skip rule: every lattice point tested on its own (round-1 behaviour; exact only for cone_angle == 0) */ };
 
@@ -164,6 +165,14 @@ struct GradBinArgs {
 	uint2* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
 };
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
+struct GradDenseArgs { // k_grad_dense: the dense levels' scatter from T1's level-major dL/d(enc)
+	const GridMeta* gm; const float* in; uint32_t in_stride, n;
+	const uint2* denc_lv; uint32_t denc_cap;
+	uint32_t levels[MAX_LEVELS]; uint32_t n_levels, merge_runs;
+	ngp_half* grid_grad_;
+};
+void launch_grad_dense(hipStream_t s, const GradDenseArgs& a);
+constexpr uint32_t T1_DENSE_EXTERNAL = 1u << 31; // launch_train_fwd_bwd flag (not a debug flag): dense levels' dL/d(enc) goes to denc_lv too, no scatter in T1
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
 	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
