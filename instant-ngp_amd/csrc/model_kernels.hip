@@ -792,8 +792,8 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 				// Hashed levels (binned mode): the memory side retires only ~14 G atomic requests/s, and hashed corners neither
 				// merge nor coalesce -- they were 85 % of T1's atomic requests.  Their dL/d(enc) goes to memory level-major
 				// (8 bytes per sample and level, coalesced) and k_grad_bin / k_grad_accumulate turn it into table gradients
-				// through LDS accumulators, without global atomics.  Dense levels: merged + coalesced atomics, either below or (T1_DENSE_EXTERNAL,
-				// production) in k_grad_dense, which runs beside k_grad_bin / k_grad_accumulate / W on its own stream.
+				// through LDS accumulators, without global atomics.  Dense levels: merged + coalesced atomics, either below (production) or (T1_DENSE_EXTERNAL,
+				// ablation) in k_grad_dense, which runs beside k_grad_bin / k_grad_accumulate / W on its own stream.
 				const bool binned = denc_lv != nullptr && (lc.hashed || (flags & T1_DENSE_EXTERNAL));
 				if (binned && sv) {
 					const h4 g = {(_Float16)denc[c][4 * rr + 0], (_Float16)denc[c][4 * rr + 1], (_Float16)denc[c][4 * rr + 2], (_Float16)denc[c][4 * rr + 3]};
@@ -940,8 +940,9 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 			if (valid[u]) { const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + sc]); g0 = (float)g[0]; g1 = (float)g[1]; g2 = (float)g[2]; g3 = (float)g[3]; }
 		}
 		// Consecutive lanes are consecutive samples of (mostly) one ray; on the coarser hashed levels runs of them share a grid cell, i.e. all
-		// eight table entries.  Such runs are summed here (fp32, segmented shuffle reduction like T1's) and only the run head emits records:
-		// 20-25 % fewer records to sort, write, read and accumulate.  Wave-uniform decision: worth it when >= 1/4 of the lanes are followers.
+		// eight table entries.  With merge_runs (ablation DBG_BIN_MERGE_RUNS) such runs are summed here (fp32, segmented shuffle reduction like
+		// T1's) and only the run head emits records: 20-25 % fewer records to sort, write, read and accumulate -- but the 192 shuffles per sample
+		// cost this kernel more (57 -> 78 us) than k_grad_accumulate gains (55 -> 44 us), so production emits every record.
 		const uint32_t key_xy = cr.cell_xy, key_z = cr.cell_z;
 		const uint32_t pxy = (uint32_t)__shfl_up((int)key_xy, 1, 64), pz = (uint32_t)__shfl_up((int)key_z, 1, 64);
 		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;
@@ -1117,7 +1118,8 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 // grid cell are summed in packed half by a segmented shuffle reduction and only the run head issues atomics; a lane QUAD issues the
 // 16 bytes of an x-adjacent corner pair in one instruction (one memory-side request).  The memory side retires ~14 G atomic requests
 // per second whatever the kernel around them does, so these requests are issued from a small kernel that shares the chip with the
-// LDS-bound k_grad_bin / k_grad_accumulate and the MFMA-bound W instead of from T1's critical path (T1: 170 -> 65 us).
+// LDS-bound k_grad_bin / k_grad_accumulate and the MFMA-bound W instead of from T1's critical path.  Measured: T1 189 -> 90 us, this
+// kernel 117 us, step time unchanged (the chip is throughput bound, not critical-path bound) -- kept as ablation DBG_T1_DENSE_EXTERNAL.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_grad_dense(GradDenseArgs a) {
 	const uint32_t level = a.levels[blockIdx.y];

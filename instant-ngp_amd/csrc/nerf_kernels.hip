@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 constexpr uint32_t K1_GROUP = 8;          // lattice chunks tested per k1_count iteration
 constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
 constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
+constexpr uint32_t K1_MAX_RANGE = 256;    // most slots a k1_count / k1_write workgroup owns (grid >= ceil(max rays / 256))
 
 static __device__ __forceinline__ uint32_t k1_slot_to_ray(uint32_t li, uint32_t n_local) { return (uint32_t)(((uint64_t)li * K1_SCRAMBLE_PRIME) % n_local); }
 
@@ -207,7 +208,32 @@ static __device__ __forceinline__ float lattice_t(const RaySetup& r, uint32_t j,
 	return j == 0 ? r.startt : from_stepping_space(r.nprime + (float)j, cone_angle);
 }
 
-__global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__ rs, uint64_t* __restrict__ masks, uint64_t* __restrict__ scan_in) {
+// ---- exclusive prefix sum over packed {samples (low 32), rays (high 32)} ------------------------
+static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], uint64_t* sm /* 4 */, uint64_t& block_total) {
+	// each thread owns 4 consecutive elements; returns the exclusive prefix of the thread's first element
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	uint64_t tsum = v[0] + v[1] + v[2] + v[3];
+	uint64_t x = tsum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint64_t y = __shfl_up((unsigned long long)x, d, 64);
+		if (lane >= (uint32_t)d) x += y;
+	}
+	if (lane == 63) sm[wid] = x;
+	__syncthreads();
+	uint64_t woff = 0;
+	for (uint32_t w = 0; w < wid; ++w) woff += sm[w];
+	block_total = sm[0] + sm[1] + sm[2] + sm[3];
+	return woff + x - tsum;
+}
+// Prefix sum over the per-ray counts without scan launches: workgroup b owns the CONTIGUOUS slot range [b n / G, (b + 1) n / G) (slots are
+// scrambled rays, so the ranges are statistically equal), publishes the packed {samples, rays} total of its range, and the last workgroup to
+// finish (ticket counter) turns the G totals into exclusive offsets + the two global counters.  k1_write, launched with the same G, re-scans
+// the <= 128 counts of its own range in LDS.  Same slot-ordered spans as a global scan: deterministic, no atomics on the sample buffer.
+__global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__ rs, uint64_t* __restrict__ masks, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
+	__shared__ uint64_t s_tot[4];
+	__shared__ uint64_t s_scan[4];
+	__shared__ uint32_t s_ticket;
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
@@ -216,7 +242,9 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	// one-ray wavefronts is bound by the wavefront launch rate (~1-2.5 waves/clk chip-wide, measured 85 us) -- so a fixed
 	// number of wavefronts loops over the rays instead.
 	const uint32_t lane = threadIdx.x & 63u;
-	for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n_local; li += gridDim.x * 4) {
+	const uint32_t li_begin = (uint32_t)(((uint64_t)n_local * blockIdx.x) / gridDim.x), li_end = (uint32_t)(((uint64_t)n_local * (blockIdx.x + 1)) / gridDim.x);
+	uint64_t wave_total = 0ull; // packed {samples (low 32), rays with samples (high 32)} of this wavefront's rays
+	for (uint32_t li = li_begin + (threadIdx.x >> 6); li < li_end; li += 4) {
 	const RaySetup r = rs[li];
 	uint32_t cnt = 0, n_chunks = 0;
 	// The reference's skip rule differs from "every lattice point on its own" only where the mip changes along a skipped voxel, and the
@@ -306,79 +334,59 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	if (lane == 0) {
 		rs[li].count = cnt;
 		rs[li].flags = n_chunks;
-		scan_in[li] = (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
 	}
+	wave_total += (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
 	}
-}
-
-// ---- exclusive prefix sum over packed {samples (low 32), rays (high 32)} ------------------------
-static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], uint64_t* sm /* 4 */, uint64_t& block_total) {
-	// each thread owns 4 consecutive elements; returns the exclusive prefix of the thread's first element
-	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	uint64_t tsum = v[0] + v[1] + v[2] + v[3];
-	uint64_t x = tsum;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		uint64_t y = __shfl_up((unsigned long long)x, d, 64);
-		if (lane >= (uint32_t)d) x += y;
-	}
-	if (lane == 63) sm[wid] = x;
+	if (lane == 0) s_tot[threadIdx.x >> 6] = wave_total;
 	__syncthreads();
-	uint64_t woff = 0;
-	for (uint32_t w = 0; w < wid; ++w) woff += sm[w];
-	block_total = sm[0] + sm[1] + sm[2] + sm[3];
-	return woff + x - tsum;
-}
-__global__ void __launch_bounds__(256) k_scan_partials(const uint64_t* __restrict__ in, uint32_t n_max, const uint32_t* __restrict__ n_ptr, uint32_t rank, uint32_t world,
-		uint64_t* __restrict__ partial) {
-	__shared__ uint64_t sm[4];
-	const uint32_t R = n_ptr ? *n_ptr : n_max; // n_max carries the immediate global ray count when there is no device-side count
-	const uint32_t n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world);
-	uint64_t v[4];
+	if (threadIdx.x == 0) {
+		partial[blockIdx.x] = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+		__threadfence(); // the total is visible device-wide before the ticket is
+		s_ticket = atomicAdd(done, 1u);
+	}
+	__syncthreads();
+	if (s_ticket != gridDim.x - 1) return;
+	__threadfence(); // last workgroup: every other workgroup's total is visible now
+	uint64_t run = 0ull;
+	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
+		uint64_t v[4];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; v[k] = e < n ? in[e] : 0ull; }
-	uint64_t tot;
-	(void)block_excl_scan_1024(v, sm, tot);
-	if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-__global__ void __launch_bounds__(256) k_scan_top(uint64_t* __restrict__ partial, uint32_t n_blocks, uint32_t* __restrict__ numsteps_counter, uint32_t* __restrict__ ray_counter) {
-	__shared__ uint64_t sm[4];
-	uint64_t v[4];
+		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? __hip_atomic_load(partial + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }
+		uint64_t tot;
+		uint64_t pre = run + block_excl_scan_1024(v, s_scan, tot);
 #pragma unroll
-	for (int k = 0; k < 4; ++k) { const uint32_t e = threadIdx.x * 4 + k; v[k] = e < n_blocks ? partial[e] : 0ull; }
-	uint64_t tot;
-	uint64_t pre = block_excl_scan_1024(v, sm, tot);
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { const uint32_t e = threadIdx.x * 4 + k; if (e < n_blocks) partial[e] = pre; pre += v[k]; }
-	if (threadIdx.x == 0) { *numsteps_counter = (uint32_t)tot; *ray_counter = (uint32_t)(tot >> 32); }
-}
-__global__ void __launch_bounds__(256) k_scan_apply(const uint64_t* __restrict__ in, uint32_t n_max, const uint32_t* __restrict__ n_ptr, uint32_t rank, uint32_t world,
-		const uint64_t* __restrict__ partial, uint64_t* __restrict__ out) {
-	__shared__ uint64_t sm[4];
-	const uint32_t R = n_ptr ? *n_ptr : n_max; // n_max carries the immediate global ray count when there is no device-side count
-	const uint32_t n = (uint32_t)(((uint64_t)R * (rank + 1)) / world) - (uint32_t)(((uint64_t)R * rank) / world);
-	if (blockIdx.x * SCAN_BLOCK >= n) return;
-	uint64_t v[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; v[k] = e < n ? in[e] : 0ull; }
-	uint64_t tot;
-	uint64_t pre = block_excl_scan_1024(v, sm, tot) + partial[blockIdx.x];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { const uint32_t e = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4 + k; if (e < n) out[e] = pre; pre += v[k]; }
+		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; if (e < gridDim.x) partial[e] = pre; pre += v[k]; }
+		run += tot;
+		__syncthreads(); // s_scan is reused by the next round
+	}
+	if (threadIdx.x == 0) { *a.numsteps_counter = (uint32_t)run; *a.ray_counter = (uint32_t)(run >> 32); *done = 0u; }
 }
 
-__global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __restrict__ rs, const uint64_t* __restrict__ masks, const uint64_t* __restrict__ scan_out) {
+__global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __restrict__ rs, const uint64_t* __restrict__ masks, const uint64_t* __restrict__ partial) {
+	__shared__ uint64_t s_scan[4];
+	__shared__ uint64_t s_off[K1_MAX_RANGE];
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t lane = threadIdx.x & 63u;
 	const Box aabb(a.aabb);
-	for (uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6); li < ray_end - ray_begin; li += gridDim.x * 4) { // persistent grid, see k1_count
+	// this workgroup's slot range (the same split as k1_count's) and the spans of its rays: offset of the range + exclusive scan inside it
+	const uint32_t n_local = ray_end - ray_begin;
+	const uint32_t li_begin = (uint32_t)(((uint64_t)n_local * blockIdx.x) / gridDim.x), li_end = (uint32_t)(((uint64_t)n_local * (blockIdx.x + 1)) / gridDim.x);
+	{
+		uint64_t v[4] = {0ull, 0ull, 0ull, 0ull};
+		if (li_begin + threadIdx.x < li_end) { const uint32_t c = rs[li_begin + threadIdx.x].count; v[0] = (uint64_t)c | ((uint64_t)(c > 0 ? 1u : 0u) << 32); }
+		uint64_t tot;
+		const uint64_t pre = block_excl_scan_1024(v, s_scan, tot);
+		if (threadIdx.x < K1_MAX_RANGE) s_off[threadIdx.x] = partial[blockIdx.x] + pre;
+		__syncthreads();
+	}
+	for (uint32_t li = li_begin + (threadIdx.x >> 6); li < li_end; li += 4) { // persistent grid, see k1_count
 	const RaySetup r = rs[li];
 	const uint32_t count = r.count;
 	if (count == 0) continue;
-	const uint64_t so = scan_out[li];
+	const uint64_t so = s_off[li - li_begin];
 	const uint32_t base = (uint32_t)so, slot = (uint32_t)(so >> 32);
 	const bool fits = base + count <= max_samples; // testbed_nerf.cu:813-815: rays past the cap are dropped
 	if (lane == 0) {
@@ -810,26 +818,64 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
 }
 
+// NerfCounters::update_after_training (testbed_nerf.cu:2669-2702) on the device-resident counters: one thread
+static __device__ __forceinline__ void update_counters_body(TrainCounters* c, uint32_t target_batch_size, uint32_t world_size) {
+	const uint32_t before = c->numsteps_counter, compacted = c->numsteps_counter_compacted;
+	c->n_rays_last = c->ray_counter;
+	c->total_rays += c->rays_per_batch;
+	c->training_step += 1;
+	if (before == 0 || compacted == 0) {
+		c->measured_batch_size = 0; c->measured_batch_size_before_compaction = 0; c->loss_scalar = 0.f;
+	} else {
+		c->measured_batch_size_before_compaction = before;
+		c->measured_batch_size = compacted;
+		c->total_samples += compacted;
+		c->loss_scalar = c->loss_sum * (float)compacted / (float)target_batch_size;
+		uint32_t r = (uint32_t)((float)c->rays_per_batch * (float)target_batch_size / (float)compacted);
+		r = ((r + 255u) / 256u) * 256u;
+		// cap: 2^18 rays per rank (the per-rank ray buffers), i.e. the reference's 1<<18 (testbed_nerf.cu:2699) at world_size 1
+		c->rays_per_batch = min(r, (1u << 18) * world_size);
+	}
+	// max_inference for the next step (testbed_nerf.cu:3055-3060)
+	const uint32_t max_samples = target_batch_size * 16u;
+	const uint32_t mb = c->measured_batch_size_before_compaction;
+	c->max_inference = mb == 0 ? max_samples : ((min(mb, max_samples) + 255u) / 256u) * 256u;
+	if (mb == 0) c->measured_batch_size_before_compaction = max_samples;
+	c->numsteps_counter = 0; c->numsteps_counter_compacted = 0; c->ray_counter = 0; c->loss_sum = 0.f;
+	c->n_valid_compacted = 0; for (int r = 0; r < 8; ++r) c->k2_tiles[r] = 0; c->k2_samples_last = c->k2_samples; c->k2_samples = 0;
+}
 // ------------------------------------------------------------------------------------------------
 // K4: fill_rollover<float> on coords + fill_rollover_and_rescale<half> on dL/doutput, one launch.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_fill_rollover(uint32_t n_elements, const uint32_t* __restrict__ n_input_ptr, float* __restrict__ coords, uint32_t cstride,
-		__half* __restrict__ dloss, uint32_t dstride, const uint32_t* __restrict__ publish_src2, uint32_t* __restrict__ publish_dst2) {
+// With `ctl` the batch-size controller (k_update_counters) rides along: the last workgroup to finish -- a ticket counter; every read of
+// K3's counter precedes the workgroup's ticket -- runs it, so the step has one launch (and one inter-kernel gap) less on its critical path.
+__global__ void __launch_bounds__(256) k_fill_rollover(uint32_t n_elements, const uint32_t* __restrict__ n_input_ptr, float* __restrict__ coords, uint32_t cstride,
+		__half* __restrict__ dloss, uint32_t dstride, const uint32_t* __restrict__ publish_src2, uint32_t* __restrict__ publish_dst2,
+		TrainCounters* ctl, uint32_t ctl_world_size) {
 	// the two counters every rank must agree on (8e) are published here instead of by a separate copy
 	if (publish_dst2 && blockIdx.x == 0 && threadIdx.x == 0) { publish_dst2[0] = publish_src2[0]; publish_dst2[1] = publish_src2[1]; }
 	const uint32_t n_in = min(*n_input_ptr, n_elements); // K3's counter may overshoot the batch (its spans are clamped)
-	if (n_in == 0 || n_in >= n_elements) return;
-	const uint32_t e = n_in + blockIdx.x * blockDim.x + threadIdx.x; // destination element
-	if (e >= n_elements) return;
-	const uint32_t src = e % n_in;
-	// coords: element-wise wrap is identical to the reference's flat index wrap because
-	// (e*stride + k) % (n_in*stride) == (e % n_in)*stride + k
-	for (uint32_t k = 0; k < cstride; ++k) coords[(size_t)e * cstride + k] = coords[(size_t)src * cstride + k];
-	const float n_input = (float)(n_in * dstride), n_total = (float)(n_elements * dstride);
-	for (uint32_t k = 0; k < dstride; ++k) {
-		float v = __half2float(dloss[(size_t)src * dstride + k]);
-		dloss[(size_t)e * dstride + k] = __float2half(v * n_input / n_total);
+	if (n_in != 0 && n_in < n_elements) {
+		const float n_input = (float)(n_in * dstride), n_total = (float)(n_elements * dstride);
+		for (uint32_t e = n_in + blockIdx.x * blockDim.x + threadIdx.x; e < n_elements; e += gridDim.x * blockDim.x) { // destination element
+			const uint32_t src = e % n_in;
+			// coords: element-wise wrap is identical to the reference's flat index wrap because
+			// (e*stride + k) % (n_in*stride) == (e % n_in)*stride + k
+			for (uint32_t k = 0; k < cstride; ++k) coords[(size_t)e * cstride + k] = coords[(size_t)src * cstride + k];
+			for (uint32_t k = 0; k < dstride; ++k) {
+				float v = __half2float(dloss[(size_t)src * dstride + k]);
+				dloss[(size_t)e * dstride + k] = __float2half(v * n_input / n_total);
+			}
+		}
 	}
+	if (!ctl) return;
+	__syncthreads(); // every thread of the workgroup has read the counter
+	if (threadIdx.x != 0) return;
+	__threadfence();
+	if (atomicAdd(&ctl->k4_ticket, 1u) != gridDim.x - 1) return;
+	__threadfence();
+	ctl->k4_ticket = 0u;
+	update_counters_body(ctl, n_elements, ctl_world_size);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -949,29 +995,7 @@ __global__ void k_bitfield_max_pool(uint32_t n_elements, const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ void k_update_counters(TrainCounters* c, uint32_t target_batch_size, uint32_t world_size) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	const uint32_t before = c->numsteps_counter, compacted = c->numsteps_counter_compacted;
-	c->n_rays_last = c->ray_counter;
-	c->total_rays += c->rays_per_batch;
-	c->training_step += 1;
-	if (before == 0 || compacted == 0) {
-		c->measured_batch_size = 0; c->measured_batch_size_before_compaction = 0; c->loss_scalar = 0.f;
-	} else {
-		c->measured_batch_size_before_compaction = before;
-		c->measured_batch_size = compacted;
-		c->total_samples += compacted;
-		c->loss_scalar = c->loss_sum * (float)compacted / (float)target_batch_size;
-		uint32_t r = (uint32_t)((float)c->rays_per_batch * (float)target_batch_size / (float)compacted);
-		r = ((r + 255u) / 256u) * 256u;
-		// cap: 2^18 rays per rank (the per-rank ray buffers), i.e. the reference's 1<<18 (testbed_nerf.cu:2699) at world_size 1
-		c->rays_per_batch = min(r, (1u << 18) * world_size);
-	}
-	// max_inference for the next step (testbed_nerf.cu:3055-3060)
-	const uint32_t max_samples = target_batch_size * 16u;
-	const uint32_t mb = c->measured_batch_size_before_compaction;
-	c->max_inference = mb == 0 ? max_samples : ((min(mb, max_samples) + 255u) / 256u) * 256u;
-	if (mb == 0) c->measured_batch_size_before_compaction = max_samples;
-	c->numsteps_counter = 0; c->numsteps_counter_compacted = 0; c->ray_counter = 0; c->loss_sum = 0.f;
-	c->n_valid_compacted = 0; for (int r = 0; r < 8; ++r) c->k2_tiles[r] = 0; c->k2_samples_last = c->k2_samples; c->k2_samples = 0;
+	update_counters_body(c, target_batch_size, world_size);
 }
 // clamp the compacted counter to B for K4 / statistics (the reference relies on fill_rollover's guard)
 __global__ void k_clamp_compacted(TrainCounters* c, uint32_t target_batch_size) {
@@ -989,26 +1013,28 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 	if (max_rays_this_rank == 0) return;
 	hipLaunchKernelGGL(k_generate_training_samples, dim3(blocks(max_rays_this_rank, 128)), dim3(128), 0, s, a);
 }
+// persistent grid: up to 8 workgroups of 4 wavefronts per CU; every workgroup owns at most K1_MAX_RANGE consecutive slots
+static uint32_t k1_grid(uint32_t max_local_rays) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * 8u), blocks(max_local_rays, K1_MAX_RANGE)); }
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
-	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8 + 8 + 8) + 1024 * 8;
+	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + (size_t)k1_grid(max_local_rays) * 8 + 64;
 }
-// K1 as five small launches: setup, count (wave per ray), 3-kernel prefix sum, write (wave per ray)
+// the ticket counter behind the workgroup totals must start at zero (k1_count's last workgroup leaves it at zero again)
+int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays) {
+	char* p = (char*)scratch + (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8);
+	return hipMemsetAsync(p, 0, (size_t)k1_grid(max_local_rays) * 8 + 64, s) == hipSuccess ? 0 : 1;
+}
+// K1 as three launches: setup (thread per ray), count (wave per ray + the prefix sum over workgroup totals), write (wave per ray)
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch) {
 	if (max_local_rays == 0) return;
 	char* p = (char*)scratch;
 	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
 	uint64_t* masks = (uint64_t*)p; p += (size_t)max_local_rays * LAT_MAX_CHUNKS * 8;
-	uint64_t* scan_in = (uint64_t*)p; p += (size_t)max_local_rays * 8;
-	uint64_t* scan_out = (uint64_t*)p; p += (size_t)max_local_rays * 8;
-	uint64_t* partial = (uint64_t*)p;
-	const uint32_t n_scan_blocks = blocks(max_local_rays, SCAN_BLOCK);
+	const uint32_t ray_grid = k1_grid(max_local_rays);
+	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
+	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128)), dim3(128), 0, s, a, rs);
-	const uint32_t ray_grid = std::min<uint32_t>(blocks(max_local_rays, 4), 256u * 8u); // persistent: 8 workgroups of 4 wavefronts per CU
-	hipLaunchKernelGGL(k1_count, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, scan_in);
-	hipLaunchKernelGGL(k_scan_partials, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, a.n_rays, a.n_rays_ptr, a.rank, a.world_size, partial);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, partial, n_scan_blocks, a.numsteps_counter, a.ray_counter);
-	hipLaunchKernelGGL(k_scan_apply, dim3(n_scan_blocks), dim3(256), 0, s, scan_in, a.n_rays, a.n_rays_ptr, a.rank, a.world_size, partial, scan_out);
-	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, scan_out);
+	hipLaunchKernelGGL(k1_count, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial, done);
+	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades) {
 	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;
@@ -1020,8 +1046,10 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
-		const uint32_t* publish_src2, uint32_t* publish_dst2) {
-	hipLaunchKernelGGL(k_fill_rollover, dim3(blocks(n_elements, 256)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride, publish_src2, publish_dst2);
+		const uint32_t* publish_src2, uint32_t* publish_dst2, TrainCounters* ctl, uint32_t ctl_world_size) {
+	// grid-stride over the padding (typically 5 - 15 % of the batch); few workgroups keep the controller's ticket cheap
+	hipLaunchKernelGGL(k_fill_rollover, dim3(std::min<uint32_t>(blocks(n_elements, 256), 128u)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride,
+		publish_src2, publish_dst2, ctl, ctl_world_size);
 }
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear) {
 	hipLaunchKernelGGL(k_mark_untrained, dim3(blocks(n, 128)), dim3(128), 0, s, n, grid, n_images, m, x, clear);

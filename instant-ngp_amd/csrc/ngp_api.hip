@@ -362,7 +362,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	}
 	// binned scatter: every hashed level must have a power-of-two table of 2^chunk_log2 .. 2^19 entries (base.json: 2^19)
 	GradBinArgs& ba = m->bin_args;
-	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = !(g_debug_flags & DBG_BIN_NO_MERGE);
+	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = (g_debug_flags & DBG_BIN_MERGE_RUNS) != 0;
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
@@ -394,10 +394,10 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	// GradientMode::Overwrite: clear the hash-grid gradient table (the MLP part is fully rewritten)
 	if (!m->grads_clean) { ProfScope ps(P_GRAD_MEMSET, s); HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); }
 	m->grads_clean = false;
-	// dense levels: T1 leaves their dL/d(enc) in denc_lv as well and k_grad_dense issues the atomics beside the kernels below
+	// dense levels (ablation DBG_T1_DENSE_EXTERNAL): T1 leaves their dL/d(enc) in denc_lv as well and k_grad_dense issues the atomics beside the kernels below
 	GradDenseArgs da;
 	da.n_levels = 0;
-	if (ba.n_hashed && !(g_debug_flags & (DBG_T1_DENSE_INLINE | DBG_T1_NO_SCATTER)))
+	if (ba.n_hashed && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !(g_debug_flags & DBG_T1_NO_SCATTER))
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
 	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
 		g_debug_flags | (da.n_levels ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
@@ -974,6 +974,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 			if (dev_alloc(&s_scratch, need)) return 1;
 			s_scratch_bytes = need;
 		}
+		if (k1_lattice_scratch_init((hipStream_t)stream, s_scratch, max_local)) return fail("k1 scratch init");
 		// the per-wave atomics of the sequential kernel accumulate into the counters; the scan overwrites them
 		launch_generate_training_samples_lattice((hipStream_t)stream, a, max_local, s_scratch);
 	}
@@ -1096,6 +1097,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays))) { delete t; return 1; }
+	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
@@ -1288,13 +1290,16 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	k3.ray_targets = lattice ? t->ray_targets : nullptr; k3.train_mode = o.train_mode;
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
-	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2); }
+	// single rank, forward and backward in one call: the controller rides on K4's last workgroup (no launch of its own)
+	const bool fuse_ctl = (phase & 2) && o.world_size == 1 && !(g_debug_flags & DBG_SEPARATE_CONTROLLER);
+	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2, fuse_ctl ? c : nullptr, o.world_size); }
+	if (fuse_ctl) t->ctl_done = true;
 	}
 	if (phase & 2) {
 	// The batch-size controller only needs K1's / K3's counters (multi-rank: their all-reduced values), so it runs here instead of after
 	// the optimizer and the next step's K1 can start behind it.
 	const bool early_ctl = o.world_size == 1 || global_counters;
-	if (early_ctl) {
+	if (early_ctl && !t->ctl_done) {
 		if (o.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, o.world_size);
 		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, B, o.world_size);
 		t->ctl_done = true;

@@ -9,8 +9,9 @@ namespace ngp {
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
-	DBG_BIN_NO_MERGE = 65536 /* k_grad_bin without the same-cell run merging */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
-	DBG_T1_DENSE_INLINE = 262144 /* dense levels' atomics issued by T1 itself instead of k_grad_dense on its own stream (round-1 behaviour) */,
+	DBG_BIN_MERGE_RUNS = 65536 /* k_grad_bin sums same-cell runs before the sort: 20 % fewer records, k_grad_accumulate 55 -> 44 us, k_grad_bin 57 -> 78 us: not worth it (profiles/r02_microbench_final.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
+	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
+	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
 	DBG_K1_INDEPENDENT_LATTICE = 16384 /* lattice K1 without the exact skip rule: every lattice point tested on its own (round-1 behaviour; exact only for cone_angle == 0) */ };
 
@@ -34,6 +35,7 @@ struct TrainCounters {
 	uint64_t total_samples;
 	uint32_t k2_tiles[8];                           // lazy K2: number of tiles of rounds 1..7 ([0] unused: round 0 = one tile per active ray)
 	uint32_t k2_samples, k2_samples_last;           // network evaluations performed by K2 in this / the previous step (statistics)
+	uint32_t k4_ticket;                             // K4's workgroup ticket (the last one runs the controller); zero between launches
 };
 
 struct K1Args {
@@ -79,11 +81,12 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[6]; uint32_t ray_index; };
 constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multiplicative-hash constant), larger than every ray count => coprime to it, and well mixed modulo powers of two; see k1_setup
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
+int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays); // once per allocation (and whenever max_local_rays changes)
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch);
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
-	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr);
+	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr, TrainCounters* ctl = nullptr /* run the batch-size controller behind the fill */, uint32_t ctl_world_size = 1);
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
 void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, const uint32_t* step_ptr, uint32_t step, ngp_aabb box, const float* grid_in,
 	float* pos, uint32_t* idx, uint32_t n_cascades, float thresh);

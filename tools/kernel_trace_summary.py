@@ -48,6 +48,29 @@ def main():
         print(f"steady-state timeline: wall {(t1 - t0) / 1e6:.2f} ms, union busy {busy / 1e6:.2f} ms ({100 * busy / (t1 - t0):.1f} %), sum of kernel durations {ksum / 1e6:.2f} ms, "
               f"{len(gaps)} idle gaps: total {sum(gaps) / 1e3:.2f} ms, median {gaps[len(gaps) // 2] if gaps else 0:.2f} us, p90 {gaps[int(0.9 * len(gaps))] if gaps else 0:.2f} us; "
               f"{n_opt} optimizer steps -> {(t1 - t0) / 1e3 / max(n_opt, 1):.1f} us wall, {busy / 1e3 / max(n_opt, 1):.1f} us busy, {ksum / 1e3 / max(n_opt, 1):.1f} us kernel time per step")
+    # average step timeline: a step = (end of the previous k_optimizer, end of this k_optimizer]; kernels are placed by their START; steps that
+    # contain occupancy-grid kernels are left out.  Offsets are relative to the previous optimizer's end.
+    opt_ends = [e for _, e, n in tail if "k_optimizer" in n]
+    if len(opt_ends) > 10:
+        import bisect
+        steps = defaultdict(list)
+        for s, e, n in tail:
+            k = bisect.bisect_left(opt_ends, e)  # this kernel ends inside step k (ends at or before opt_ends[k])
+            if 0 < k < len(opt_ends):
+                steps[k].append((s - opt_ends[k - 1], e - opt_ends[k - 1], n))
+        clean = [v for v in steps.values() if not any("grid" in n or "bitfield" in n or "density_only" in n or "true, 1, false" in n for _, _, n in v)]
+        if clean:
+            agg = defaultdict(lambda: [0.0, 0.0, 0])
+            for v in clean:
+                seen = defaultdict(int)
+                for s, e, n in v:
+                    seen[n] += 1
+                    key = f"{n}#{seen[n]}" if seen[n] > 1 else n
+                    a = agg[key]; a[0] += s / 1e3; a[1] += e / 1e3; a[2] += 1
+            print(f"average step timeline over {len(clean)} steps without occupancy-grid update (us after the previous optimizer's end): start .. end")
+            for key, a in sorted(agg.items(), key=lambda kv: kv[1][0] / kv[1][2]):
+                if a[2] >= len(clean) // 2:
+                    print(f"  {key:60s} {a[0] / a[2]:8.1f} .. {a[1] / a[2]:8.1f}   ({(a[1] - a[0]) / a[2]:6.1f} us)")
     # K2 rounds: consecutive runs of the same tiles kernel = one step's rounds
     for key in [k for k in by if "k_inference_tiles" in k]:
         runs, cur = [], []

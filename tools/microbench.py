@@ -16,11 +16,11 @@ import synth_scene
 VARIANTS = [
     ("default", 0, (12, 0, 0), (1, 32)),
     ("k2_rounds3", 0, (12, 0, 0), (3, 32)),
-    ("t1_dense_inline", 262144, (12, 0, 0), (1, 32)),   # dense levels' atomics issued from T1 (round 1) instead of k_grad_dense
+    ("t1_dense_external", 262144, (12, 0, 0), (1, 32)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
     ("w_single_role", 32768, (12, 0, 0), (1, 32)),       # round-1 weight-gradient kernel
-    ("bin_no_merge", 65536, (12, 0, 0), (1, 32)),        # k_grad_bin without same-cell run merging
+    ("bin_merge_runs", 65536, (12, 0, 0), (1, 32)),      # k_grad_bin with same-cell run merging
     ("separate_grad_memset", 131072, (12, 0, 0), (1, 32)),
-    ("round1_backward", 32768 | 65536 | 131072, (12, 1, 0), (1, 32)),
+    ("round1_backward", 32768 | 131072, (12, 1, 0), (1, 32)),
     ("bin_chunk12_split", 0, (12, 1, 0), (1, 32)),   # round-1 layout
     ("bin_chunk11", 0, (11, 0, 0), (1, 32)),
     ("k2_tile16_r4", 0, (12, 0, 0), (4, 16)),
