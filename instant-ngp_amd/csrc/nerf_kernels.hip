@@ -140,68 +140,78 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 // rounding of (n + k1) + k2 vs n + (k1 + k2) and of fl(fl(x*M)/M): the great majority of rays are
 // bit-identical, the rest carry <= 2-ulp offsets in t (tests/test_gpu_nerf.py quantifies both).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t K1_GROUP = 8;          // lattice chunks tested per k1_count iteration
 constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
 constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
+constexpr uint32_t K1_TICKET_CLASSES = 32; // sub-counters of k1_count's workgroup ticket
 constexpr uint32_t K1_MAX_RANGE = 256;    // most slots a k1_count / k1_write workgroup owns (grid >= ceil(max rays / 256))
 
 static __device__ __forceinline__ uint32_t k1_slot_to_ray(uint32_t li, uint32_t n_local) { return (uint32_t)(((uint64_t)li * K1_SCRAMBLE_PRIME) % n_local); }
 
+// Thread per (ray, role).  The per-ray work is a long dependent chain of scalar arithmetic (twelve powf of the sRGB conversions of the
+// target colour, normalisation, box intersection, stepping-space conversion) on fewer threads than the chip has lanes, so it is split
+// into four independent roles on separate wavefronts (blockIdx.y): role 0 = ray geometry, roles 1..3 = one colour channel of the
+// target / background each (the conversions are component-wise: same arithmetic, same results).  Measured: 48 -> see DESIGN 8.
 __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__ rs) {
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
 	if (li >= ray_end - ray_begin) return;
+	const uint32_t role = blockIdx.y;
 	// Slot li marches global ray ray_begin + pi(li), pi = a fixed bijection of [0, n_local) (multiplication by a prime > 2^18 x world):
 	// slots are filled in slot order, so the rays that K1's sample cap (testbed_nerf.cu:813-815) and K3's batch clamp drop -- the LAST
 	// slots -- are spread evenly over the ray range.  In plain index order they were always the rays of the last image(s)
 	// (img = i * n_img / R): the reference drops whichever rays reserve their spans last (atomic order), i.e. a random subset, and the
 	// index-ordered variant cost 0.2 - 0.35 dB of held-out PSNR at 5k - 20k steps (profiles/r02_bench_ab_psnr_before_scramble.json).
 	const uint32_t i = ray_begin + k1_slot_to_ray(li, ray_end - ray_begin);
-	const Box aabb(a.aabb);
-	RaySetup r;
-	r.ray_index = i;
-	r.o[0] = r.o[1] = r.o[2] = 0.f; r.d[0] = r.d[1] = 0.f; r.d[2] = 1.f; r.startt = 0.f; r.nprime = 0.f; r.count = 0; r.flags = 0;
-	for (int k = 0; k < 6; ++k) r.tgt[k] = 0.f;
 	uint32_t img = image_idx(i, n_rays, a.n_images);
 	const ngp_image_meta& m = a.metadata[img];
 	Rng rng(a.rng);
 	rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
 	f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
 	const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
-	if (!(tex.x < 0.0f)) {
-		(void)rng.next_float(); // motionblur_time
-		if (a.ray_targets_out) { // K3's target colour (testbed_nerf.cu:930-960): same rng stream position, same arithmetic
-			Rng rng_bg = rng;
-			f3 background_color = ld3(a.background_color), rgbtarget;
-			if (a.random_bg_color) { background_color.x = rng_bg.next_float(); background_color.y = rng_bg.next_float(); background_color.z = rng_bg.next_float(); }
-			background_color = srgb_to_linear3(background_color);
-			const f3 trgb = mk3(tex.x, tex.y, tex.z);
+	const bool masked = tex.x < 0.0f; // masked-away pixel: the ray is not marched
+	RaySetup& out = rs[li];
+	if (role != 0) {
+		// K3's target colour (testbed_nerf.cu:930-960): same rng stream position, same arithmetic -- channel c of every 3-vector
+		const uint32_t c = role - 1;
+		float tgt = 0.f, bg = 0.f;
+		if (!masked) {
+			(void)rng.next_float(); // motionblur_time
+			bg = a.background_color[c];
+			if (a.random_bg_color) { for (uint32_t k = 0; k <= c; ++k) bg = rng.next_float(); }
+			bg = srgb_to_linear(bg);
+			const float tc = c == 0 ? tex.x : c == 1 ? tex.y : tex.z;
 			if (a.linear_colors || !a.color_space_srgb) {
-				rgbtarget = trgb + (1.0f - tex.w) * background_color;
-				if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+				tgt = tc + (1.0f - tex.w) * bg;
+				if (!a.linear_colors) { tgt = linear_to_srgb(tgt); bg = linear_to_srgb(bg); }
 			} else {
-				background_color = linear_to_srgb3(background_color);
-				if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
-				else rgbtarget = background_color;
+				bg = linear_to_srgb(bg);
+				if (tex.w > 0) tgt = linear_to_srgb(tc / tex.w) * tex.w + (1.0f - tex.w) * bg;
+				else tgt = bg;
 			}
-			r.tgt[0] = rgbtarget.x; r.tgt[1] = rgbtarget.y; r.tgt[2] = rgbtarget.z;
-			r.tgt[3] = background_color.x; r.tgt[4] = background_color.y; r.tgt[5] = background_color.z;
 		}
+		out.tgt[c] = tgt; out.tgt[3 + c] = bg;
+		return;
+	}
+	const Box aabb(a.aabb);
+	float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f}, startt = 0.f, nprime = 0.f; uint32_t flags = 0;
+	if (!masked) {
+		(void)rng.next_float(); // motionblur_time
 		const M43 xform = ldm43(a.xforms[img].start);
 		f3 ro, rd;
 		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
 		const f3 rdn = normalize3(rd);
 		f2 tminmax = aabb.ray_intersect(ro, rdn);
 		tminmax.x = fmaxf(tminmax.x, 0.0f);
-		const float startt = advance_n_steps(tminmax.x, a.cone_angle_constant, rng.next_float());
-		r.o[0] = ro.x; r.o[1] = ro.y; r.o[2] = ro.z; r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;
-		r.startt = startt;
-		r.nprime = to_stepping_space(startt, a.cone_angle_constant);
-		r.flags = aabb.contains(ro + startt * rdn) ? 1u : 0u;
+		startt = advance_n_steps(tminmax.x, a.cone_angle_constant, rng.next_float());
+		o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; d[0] = rd.x; d[1] = rd.y; d[2] = rd.z;
+		nprime = to_stepping_space(startt, a.cone_angle_constant);
+		flags = aabb.contains(ro + startt * rdn) ? 1u : 0u;
 	}
-	rs[li] = r;
+	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2];
+	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = flags; out.ray_index = i;
+	if (!a.ray_targets_out) for (int k = 0; k < 6; ++k) out.tgt[k] = 0.f;
 }
 
 static __device__ __forceinline__ float lattice_t(const RaySetup& r, uint32_t j, float cone_angle) {
@@ -230,6 +240,7 @@ static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], u
 // scrambled rays, so the ranges are statistically equal), publishes the packed {samples, rays} total of its range, and the last workgroup to
 // finish (ticket counter) turns the G totals into exclusive offsets + the two global counters.  k1_write, launched with the same G, re-scans
 // the <= 128 counts of its own range in LDS.  Same slot-ordered spans as a global scan: deterministic, no atomics on the sample buffer.
+template <uint32_t K1_GROUP> // lattice chunks tested (= occupancy loads in flight) per iteration
 __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__ rs, uint64_t* __restrict__ masks, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
 	__shared__ uint64_t s_tot[4];
 	__shared__ uint64_t s_scan[4];
@@ -342,10 +353,19 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	if (threadIdx.x == 0) {
 		partial[blockIdx.x] = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
 		__threadfence(); // the total is visible device-wide before the ticket is
-		s_ticket = atomicAdd(done, 1u);
+		// two-level ticket: one counter word retires only ~90 returning atomics per microsecond (2048 workgroups on one word: +45 us),
+		// so workgroup b draws from sub-counter b % 32 and only the last of each residue class draws from the top counter
+		const uint32_t cls = blockIdx.x % K1_TICKET_CLASSES, n_cls = (gridDim.x - cls + K1_TICKET_CLASSES - 1) / K1_TICKET_CLASSES;
+		uint32_t last = 0u;
+		if (atomicAdd(done + 1 + cls, 1u) == n_cls - 1) {
+			done[1 + cls] = 0u;
+			__threadfence();
+			last = atomicAdd(done, 1u) == min(gridDim.x, K1_TICKET_CLASSES) - 1 ? 1u : 0u;
+		}
+		s_ticket = last;
 	}
 	__syncthreads();
-	if (s_ticket != gridDim.x - 1) return;
+	if (!s_ticket) return;
 	__threadfence(); // last workgroup: every other workgroup's total is visible now
 	uint64_t run = 0ull;
 	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
@@ -410,8 +430,10 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 	float* co = a.coords_out + (size_t)base * 7;
 	uint32_t written = 0;
 	const uint32_t n_chunks = r.flags;
+	// all chunk masks of the ray with ONE load (lane = chunk), then broadcast from registers: the loop has no memory latency in it
+	const uint64_t my_mask = lane < n_chunks ? masks[(size_t)li * LAT_MAX_CHUNKS + lane] : 0ull;
 	for (uint32_t ch = 0; ch < n_chunks && written < count; ++ch) {
-		const uint64_t m = masks[(size_t)li * LAT_MAX_CHUNKS + ch];
+		const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_mask >> 32), (int)ch) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_mask, (int)ch);
 		const uint32_t k = written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 		if (((m >> lane) & 1ull) && k < count) {
 			const float t = lattice_t(r, ch * 64 + lane, a.cone_angle_constant);
@@ -1016,12 +1038,12 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 // persistent grid: up to 8 workgroups of 4 wavefronts per CU; every workgroup owns at most K1_MAX_RANGE consecutive slots
 static uint32_t k1_grid(uint32_t max_local_rays) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * 8u), blocks(max_local_rays, K1_MAX_RANGE)); }
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
-	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + (size_t)k1_grid(max_local_rays) * 8 + 64;
+	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + (size_t)k1_grid(max_local_rays) * 8 + 256;
 }
 // the ticket counter behind the workgroup totals must start at zero (k1_count's last workgroup leaves it at zero again)
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays) {
 	char* p = (char*)scratch + (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8);
-	return hipMemsetAsync(p, 0, (size_t)k1_grid(max_local_rays) * 8 + 64, s) == hipSuccess ? 0 : 1;
+	return hipMemsetAsync(p, 0, (size_t)k1_grid(max_local_rays) * 8 + 256, s) == hipSuccess ? 0 : 1;
 }
 // K1 as three launches: setup (thread per ray), count (wave per ray + the prefix sum over workgroup totals), write (wave per ray)
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch) {
@@ -1032,8 +1054,9 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	const uint32_t ray_grid = k1_grid(max_local_rays);
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
-	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128)), dim3(128), 0, s, a, rs);
-	hipLaunchKernelGGL(k1_count, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial, done);
+	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
+	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
+	hipLaunchKernelGGL((k1_count<8>), dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial, done);
 	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades) {

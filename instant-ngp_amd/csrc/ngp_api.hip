@@ -67,7 +67,10 @@ extern "C" int ngp_profile_enable(int on) {
 	if (on) { for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; } }
 	return 0;
 }
-extern "C" int ngp_debug_set_flags(uint32_t flags) { g_debug_flags = flags; return 0; }
+// NGP_DEBUG_FLAGS_OR (environment, ablation runs of unmodified callers): bits that stay set whatever ngp_debug_set_flags is given
+static uint32_t env_debug_or() { static const uint32_t v = getenv("NGP_DEBUG_FLAGS_OR") ? (uint32_t)strtoul(getenv("NGP_DEBUG_FLAGS_OR"), nullptr, 0) : 0u; return v; }
+static const bool g_debug_env_applied = [] { g_debug_flags |= env_debug_or(); return true; }();
+extern "C" int ngp_debug_set_flags(uint32_t flags) { g_debug_flags = flags | env_debug_or(); return 0; }
 // layout of the hashed levels' binned scatter (tuning / test hook): table entries per chunk (2^11 or 2^12), one block per chunk
 // (split = 0) or per (chunk, feature pair) (split = 1), and a list-capacity override (0 = twice the mean; small values force the
 // overflow path of k_grad_bin).  NGP_BIN_CHUNK_LOG2 / NGP_BIN_SPLIT / NGP_BIN_CAP in the environment set the defaults.
