@@ -351,27 +351,28 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	if (lane == 0) s_tot[threadIdx.x >> 6] = wave_total;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		partial[blockIdx.x] = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
-		__threadfence(); // the total is visible device-wide before the ticket is
-		// two-level ticket: one counter word retires only ~90 returning atomics per microsecond (2048 workgroups on one word: +45 us),
-		// so workgroup b draws from sub-counter b % 32 and only the last of each residue class draws from the top counter
+		// The total is published with a RETURNING device-scope atomic (performed at the coherence point; its return value is awaited before the
+		// ticket is drawn) instead of store + __threadfence(): an agent-scope release fence writes back the XCD's whole L2 on this multi-XCD
+		// part, and 2048 of them made this kernel 47 us slower (profiles/r02_k1_experiments.txt).
+		const uint64_t prev = atomicExch((unsigned long long*)(partial + blockIdx.x), (unsigned long long)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3])));
+		// two-level ticket: one counter word retires only ~90 returning atomics per microsecond, so workgroup b draws from sub-counter
+		// b % 32 and only the last of each residue class draws from the top counter
 		const uint32_t cls = blockIdx.x % K1_TICKET_CLASSES, n_cls = (gridDim.x - cls + K1_TICKET_CLASSES - 1) / K1_TICKET_CLASSES;
 		uint32_t last = 0u;
-		if (atomicAdd(done + 1 + cls, 1u) == n_cls - 1) {
-			done[1 + cls] = 0u;
-			__threadfence();
+		if (atomicAdd(done + 1 + cls, (uint32_t)(prev >> 63) + 1u) == n_cls - 1) { // (prev >> 63 == 0: the data dependence orders the ticket behind the exchange)
+			atomicExch(done + 1 + cls, 0u);
 			last = atomicAdd(done, 1u) == min(gridDim.x, K1_TICKET_CLASSES) - 1 ? 1u : 0u;
 		}
 		s_ticket = last;
 	}
 	__syncthreads();
 	if (!s_ticket) return;
-	__threadfence(); // last workgroup: every other workgroup's total is visible now
+	// last workgroup: every total has been exchanged in; read them at the coherence point as well (atomic RMW with 0)
 	uint64_t run = 0ull;
 	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
 		uint64_t v[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? __hip_atomic_load(partial + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }
+		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? (uint64_t)atomicAdd((unsigned long long*)(partial + e), 0ull) : 0ull; }
 		uint64_t tot;
 		uint64_t pre = run + block_excl_scan_1024(v, s_scan, tot);
 #pragma unroll
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		run += tot;
 		__syncthreads(); // s_scan is reused by the next round
 	}
-	if (threadIdx.x == 0) { *a.numsteps_counter = (uint32_t)run; *a.ray_counter = (uint32_t)(run >> 32); *done = 0u; }
+	if (threadIdx.x == 0) { *a.numsteps_counter = (uint32_t)run; *a.ray_counter = (uint32_t)(run >> 32); atomicExch(done, 0u); }
 }
 
 __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __restrict__ rs, const uint64_t* __restrict__ masks, const uint64_t* __restrict__ partial) {
@@ -840,6 +841,242 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3 in two passes (production): PASS 0 composites every active ray front to back (wave per ray) and leaves a 16-float record per
+// ray {compacted count, rgb_ray, loss_bg (Rfl), target, background}; the workgroups' totals are scanned by the last workgroup (same
+// scheme as k1_count).  PASS 1 places every ray's compacted samples at its slot-ordered offset and writes the adjoint.
+// Against the one-pass kernel above: no __syncthreads / span atomic per 16 rays, 256-thread workgroups at <= 64 registers (twice the
+// rays in flight per CU; the kernel is a chain of dependent loads per ray), and the compacted order is DETERMINISTIC (ray-slot order
+// instead of the order in which workgroups win the span atomic) -- two runs from the same state produce the same batch bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t K3_REC = 16; // floats per ray record
+template <int PASS>
+__global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __restrict__ rec, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
+	__shared__ uint64_t s_tot[4];
+	__shared__ uint64_t s_scan[4];
+	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_off[K1_MAX_RANGE];
+	__shared__ float s_loss[4];
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t n_active = *a.rays_counter;
+	const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+	const Box aabb(a.aabb);
+	const float EPSILON = 1e-4f;
+	const bool vec_out = a.output_stride == 4, vec_dl = a.dloss_stride == 4;
+	auto load_out = [&](const __half* lo, float& l0, float& l1, float& l2, float& l3) {
+		if (vec_out) {
+			const uint2 raw = *(const uint2*)lo;
+			const h4v v = __builtin_bit_cast(h4v, raw);
+			l0 = (float)v[0]; l1 = (float)v[1]; l2 = (float)v[2]; l3 = (float)v[3];
+		} else { l0 = __half2float(lo[0]); l1 = __half2float(lo[1]); l2 = __half2float(lo[2]); l3 = __half2float(lo[3]); }
+	};
+	const uint32_t r_begin = (uint32_t)(((uint64_t)n_active * blockIdx.x) / gridDim.x), r_end = (uint32_t)(((uint64_t)n_active * (blockIdx.x + 1)) / gridDim.x);
+	if (PASS == 0) {
+		uint64_t wtot = 0ull;
+		for (uint32_t i = r_begin + wid; i < r_end; i += 4) {
+			const uint32_t numsteps = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 0]);
+			const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 1]);
+			f3 rgb_ray = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color), loss_bg = mk3(0.f);
+			if (a.ray_targets) { // computed once per ray by k1_setup
+				const float4 t0 = ((const float4*)(a.ray_targets + (size_t)i * 8))[0], t1 = ((const float4*)(a.ray_targets + (size_t)i * 8))[1];
+				rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y);
+			} else {
+				const uint32_t ray_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ray_indices_in[i]);
+				Rng rng(a.rng);
+				rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
+				const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+				const ngp_image_meta& m = a.metadata[img];
+				const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+				rng.advance(1); // motionblur_time
+				if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
+				const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+				background_color = srgb_to_linear3(background_color);
+				const f3 trgb = mk3(tex.x, tex.y, tex.z);
+				if (a.linear_colors || !a.color_space_srgb) {
+					rgbtarget = trgb + (1.0f - tex.w) * background_color;
+					if (!a.linear_colors) { rgbtarget = linear_to_srgb3(rgbtarget); background_color = linear_to_srgb3(background_color); }
+				} else {
+					background_color = linear_to_srgb3(background_color);
+					if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
+					else rgbtarget = background_color;
+				}
+			}
+			const float* cin = a.coords_in + (size_t)base * 7;
+			const __half* no = (const __half*)a.network_output + (size_t)base * a.output_stride;
+			float T_run = 1.f;
+			uint32_t compacted = 0;
+			for (uint32_t c0 = 0; c0 < numsteps; c0 += 64) {
+				const uint32_t s = c0 + lane;
+				const bool valid = s < numsteps;
+				float alpha = 0.f; f3 rgb = mk3(0.f);
+				if (valid) {
+					float l0, l1, l2, l3;
+					load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
+					const float dtw = cin[(size_t)s * 7 + 3];
+					rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
+					const float dt = unwarp_dt(dtw);
+					alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
+				}
+				const float incl = wave_incl_prod(1.f - alpha, lane);
+				float excl = __shfl_up(incl, 1, 64);
+				if (lane == 0) excl = 1.f;
+				const float T_k = T_run * excl;
+				const uint64_t vm = __ballot(valid), fail = __ballot(valid && !(T_k >= EPSILON)); // `if (T < EPSILON) break;`
+				const uint32_t n_proc = fail ? (uint32_t)(__ffsll((long long)fail) - 1) : (uint32_t)__popcll(vm);
+				const bool proc = lane < n_proc;
+				const float w = proc ? alpha * T_k : 0.f;
+				// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
+				rgb_ray = rgb_ray + mk3(wave_total(proc ? w * rgb.x : 0.f), wave_total(proc ? w * rgb.y : 0.f), wave_total(proc ? w * rgb.z : 0.f));
+				if (a.train_mode == 1) { // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
+					f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
+					loss_bg = loss_bg + mk3(wave_total(proc ? w * ll.x : 0.f), wave_total(proc ? w * ll.y : 0.f), wave_total(proc ? w * ll.z : 0.f));
+				}
+				if (n_proc) T_run = T_run * __shfl(incl, (int)n_proc - 1, 64);
+				compacted += n_proc;
+				if (fail) break;
+			}
+			if (compacted == numsteps) {
+				rgb_ray = rgb_ray + T_run * background_color;
+				if (a.train_mode == 1) { f3 ll, lgl; loss_and_gradient(rgbtarget, background_color, a.loss_type, ll, lgl); loss_bg = loss_bg + T_run * ll; }
+			}
+			if (lane == 0) {
+				float4* r4 = (float4*)(rec + (size_t)i * K3_REC);
+				r4[0] = make_float4(__uint_as_float(compacted), rgb_ray.x, rgb_ray.y, rgb_ray.z);
+				r4[1] = make_float4(loss_bg.x, loss_bg.y, loss_bg.z, 0.f);
+				r4[2] = make_float4(rgbtarget.x, rgbtarget.y, rgbtarget.z, 0.f);
+				r4[3] = make_float4(background_color.x, background_color.y, background_color.z, 0.f);
+			}
+			wtot += compacted;
+		}
+		if (lane == 0) s_tot[wid] = wtot;
+		__syncthreads();
+		if (threadIdx.x == 0) { // see k1_count: returning exchange + two-level ticket, no fence
+			const uint64_t prev = atomicExch((unsigned long long*)(partial + blockIdx.x), (unsigned long long)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3])));
+			const uint32_t cls = blockIdx.x % K1_TICKET_CLASSES, n_cls = (gridDim.x - cls + K1_TICKET_CLASSES - 1) / K1_TICKET_CLASSES;
+			uint32_t last = 0u;
+			if (atomicAdd(done + 1 + cls, (uint32_t)(prev >> 63) + 1u) == n_cls - 1) {
+				atomicExch(done + 1 + cls, 0u);
+				last = atomicAdd(done, 1u) == min(gridDim.x, K1_TICKET_CLASSES) - 1 ? 1u : 0u;
+			}
+			s_ticket = last;
+		}
+		__syncthreads();
+		if (!s_ticket) return;
+		uint64_t run = *a.numsteps_counter_compacted; // the spans start behind whatever the counter holds (0 in the training loop)
+		for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
+			uint64_t v[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? (uint64_t)atomicAdd((unsigned long long*)(partial + e), 0ull) : 0ull; }
+			uint64_t tot;
+			uint64_t pre = run + block_excl_scan_1024(v, s_scan, tot);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; if (e < gridDim.x) partial[e] = pre; pre += v[k]; }
+			run += tot;
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) { *a.numsteps_counter_compacted = (uint32_t)min(run, (uint64_t)0xffffffffu); atomicExch(done, 0u); }
+		return;
+	}
+	// ---- PASS 1 ----
+	{
+		uint64_t v[4] = {0ull, 0ull, 0ull, 0ull};
+		if (r_begin + threadIdx.x < r_end) v[0] = __float_as_uint(rec[(size_t)(r_begin + threadIdx.x) * K3_REC]);
+		uint64_t tot;
+		const uint64_t pre = block_excl_scan_1024(v, s_scan, tot) + partial[blockIdx.x];
+		if (threadIdx.x < K1_MAX_RANGE) s_off[threadIdx.x] = (uint32_t)min(pre, (uint64_t)0xffffffffu);
+		__syncthreads();
+	}
+	float wave_loss = 0.f;
+	for (uint32_t i = r_begin + wid; i < r_end; i += 4) {
+		const float4* r4 = (const float4*)(rec + (size_t)i * K3_REC);
+		const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+		const uint32_t compacted_base = s_off[i - r_begin];
+		uint32_t compacted = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q0.x));
+		const f3 rgb_ray = mk3(q0.y, q0.z, q0.w), loss_bg = mk3(q1.x, q1.y, q1.z), rgbtarget = mk3(q2.x, q2.y, q2.z);
+		const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 1]);
+		const f3 ray_o = ld3(a.rays_in[i].o);
+		compacted = min(a.max_samples_compacted - min(a.max_samples_compacted, compacted_base), compacted);
+		if (lane == 0) { a.numsteps_inout[i * 2 + 0] = compacted; a.numsteps_inout[i * 2 + 1] = compacted_base; }
+		if (compacted == 0) continue;
+		const float* cin = a.coords_in + (size_t)base * 7;
+		const __half* no = (const __half*)a.network_output + (size_t)base * a.output_stride;
+		float* cout = a.coords_out + (size_t)compacted_base * 7;
+		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
+		f3 lloss, lgrad;
+		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
+		wave_loss += ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
+		const float loss_scale = a.loss_scale / n_rays;
+		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
+		float T_run = 1.f;
+		f3 ray2_run = mk3(0.f), lb2_run = mk3(0.f);
+		for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
+			const uint32_t s = c0 + lane;
+			const bool valid = s < compacted;
+			float alpha = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, dt = 0.f, depth = 0.f;
+			f3 rgb = mk3(0.f);
+			float cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+			if (valid) {
+				const float* ci = cin + (size_t)s * 7;
+#pragma unroll
+				for (int k = 0; k < 7; ++k) cc[k] = ci[k];
+				load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
+				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
+				dt = unwarp_dt(cc[3]);
+				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
+				depth = dist3(unwarp_position(mk3(cc[0], cc[1], cc[2]), aabb), ray_o);
+			}
+			const float incl = wave_incl_prod(1.f - alpha, lane);
+			float excl = __shfl_up(incl, 1, 64);
+			if (lane == 0) excl = 1.f;
+			const float T_k = T_run * excl, T_after = T_run * incl;
+			const float weight = alpha * T_k;
+			const f3 ray2 = ray2_run + mk3(wave_incl_sum(weight * rgb.x, lane), wave_incl_sum(weight * rgb.y, lane), wave_incl_sum(weight * rgb.z, lane));
+			f3 lloc = mk3(0.f), gloc = mk3(0.f), lb2 = lb2_run;
+			if (a.train_mode == 1) { // Rfl: per-sample loss against the target and its running (inclusive) weighted sum
+				loss_and_gradient(rgbtarget, rgb, a.loss_type, lloc, gloc);
+				lb2 = lb2_run + mk3(wave_incl_sum(weight * lloc.x, lane), wave_incl_sum(weight * lloc.y, lane), wave_incl_sum(weight * lloc.z, lane));
+			}
+			if (valid) {
+				float* cj = cout + (size_t)s * 7;
+#pragma unroll
+				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
+				const f3 suffix = rgb_ray - ray2;
+				f3 dloss_by_drgb = weight * lgrad;
+				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + 0.0f;
+				if (a.train_mode == 1) { // fused_kernels/train_nerf.cuh:391-396
+					dloss_by_drgb = weight * gloc;
+					const f3 v = T_after * lloc - (loss_bg - lb2);
+					dmlp_inner = v.x + v.y + v.z;
+				} else if (a.train_mode == 2) { // train_nerf.cuh:397-405
+					const f3 rgb_bg = suffix / fmaxf(1e-6f, T_after);
+					const f3 rgb_lerp = (1 - alpha) * rgb_bg + alpha * rgb;
+					f3 ll, lgl; loss_and_gradient(rgbtarget, rgb_lerp, a.loss_type, ll, lgl);
+					dloss_by_drgb = weight * lgl;
+					dmlp_inner = dot3(lgl, T_after * rgb - suffix) + 0.0f;
+				}
+				const float d0 = loss_scale * (dloss_by_drgb.x * act_rgb_d(l0, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l0));
+				const float d1 = loss_scale * (dloss_by_drgb.y * act_rgb_d(l1, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l1));
+				const float d2 = loss_scale * (dloss_by_drgb.z * act_rgb_d(l2, a.rgb_activation) + fmaxf(0.0f, output_l2_reg * l2));
+				const float dloss_by_dmlp = act_density_d(l3, a.density_activation) * (dt * dmlp_inner);
+				const float d3 = loss_scale * dloss_by_dmlp + (l3 < 0.0f ? -output_l1_reg_density : 0.0f) + (l3 > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f);
+				__half* d = dl + (size_t)s * a.dloss_stride;
+				if (vec_dl) {
+					const h4v v = {(_Float16)d0, (_Float16)d1, (_Float16)d2, (_Float16)d3};
+					*(uint2*)d = __builtin_bit_cast(uint2, v);
+				} else { d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3); }
+			}
+			T_run = T_run * __shfl(incl, 63, 64);
+			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
+			if (a.train_mode == 1) lb2_run = mk3(__shfl(lb2.x, 63, 64), __shfl(lb2.y, 63, 64), __shfl(lb2.z, 63, 64));
+		}
+		(void)q3;
+	}
+	if (lane == 0) s_loss[wid] = wave_loss;
+	__syncthreads();
+	if (a.loss_output && threadIdx.x == 0) { const float bl = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]); if (bl != 0.f) atomicAdd(a.loss_output, bl); }
+}
+
 // NerfCounters::update_after_training (testbed_nerf.cu:2669-2702) on the device-resident counters: one thread
 static __device__ __forceinline__ void update_counters_body(TrainCounters* c, uint32_t target_batch_size, uint32_t world_size) {
 	const uint32_t before = c->numsteps_counter, compacted = c->numsteps_counter_compacted;
@@ -893,10 +1130,10 @@ __global__ void __launch_bounds__(256) k_fill_rollover(uint32_t n_elements, cons
 	if (!ctl) return;
 	__syncthreads(); // every thread of the workgroup has read the counter
 	if (threadIdx.x != 0) return;
-	__threadfence();
+	// no fence: the counters the controller reads were written by earlier kernels, and this workgroup's own read of K3's counter has
+	// completed (its value was used above) before the ticket is drawn
 	if (atomicAdd(&ctl->k4_ticket, 1u) != gridDim.x - 1) return;
-	__threadfence();
-	ctl->k4_ticket = 0u;
+	atomicExch(&ctl->k4_ticket, 0u);
 	update_counters_body(ctl, n_elements, ctl_world_size);
 }
 
@@ -1045,6 +1282,11 @@ int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_ray
 	char* p = (char*)scratch + (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8);
 	return hipMemsetAsync(p, 0, (size_t)k1_grid(max_local_rays) * 8 + 256, s) == hipSuccess ? 0 : 1;
 }
+// two-pass K3: per-ray records + workgroup totals + ticket counters (zeroed once, like K1's)
+size_t k3_scratch_bytes(uint32_t max_rays) { return (size_t)max_rays * K3_REC * 4 + (size_t)k1_grid(max_rays) * 8 + 256; }
+int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays) {
+	return hipMemsetAsync((char*)scratch + (size_t)max_rays * K3_REC * 4, 0, (size_t)k1_grid(max_rays) * 8 + 256, s) == hipSuccess ? 0 : 1;
+}
 // K1 as three launches: setup (thread per ray), count (wave per ray + the prefix sum over workgroup totals), write (wave per ray)
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch) {
 	if (max_local_rays == 0) return;
@@ -1066,7 +1308,13 @@ void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
-	else hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
+	else if (!a.k3_scratch || (g_debug_flags & DBG_K3_ONE_PASS)) hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
+	else {
+		const uint32_t grid = k1_grid(max_rays);
+		float* rec = (float*)a.k3_scratch; uint64_t* partial = (uint64_t*)(rec + (size_t)max_rays * K3_REC); uint32_t* done = (uint32_t*)(partial + grid);
+		hipLaunchKernelGGL((k_compute_loss_v3<0>), dim3(grid), dim3(256), 0, s, a, rec, partial, done);
+		hipLaunchKernelGGL((k_compute_loss_v3<1>), dim3(grid), dim3(256), 0, s, a, rec, partial, done);
+	}
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
 		const uint32_t* publish_src2, uint32_t* publish_dst2, TrainCounters* ctl, uint32_t ctl_world_size) {

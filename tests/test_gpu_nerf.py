@@ -169,10 +169,10 @@ def test_k1_sample_cap(ora, hip, scene):
     assert not kept[np.argmin(kept):].any()
 
 
-@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (1, 32), (2, 32)])
+@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (1, 32), (2, 32), (0, 1048576), (1, 1048576), (2, 1048576)])
 def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
-    """K3 vs the oracle per ray, for the three train modes (0 Nerf, 1 Rfl, 2 RflRelax: fused_kernels/train_nerf.cuh:391-410) and for both device
-    kernels (wave per ray; flag 32 = the reference's sequential per-ray loops)."""
+    """K3 vs the oracle per ray, for the three train modes (0 Nerf, 1 Rfl, 2 RflRelax: fused_kernels/train_nerf.cuh:391-410) and for the three device
+    kernels (two-pass wave per ray = production; flag 1048576 = one pass with span atomics; flag 32 = the reference's sequential per-ray loops)."""
     import torch
     ora.ora_set_train_mode(train_mode); hip.ngp_debug_set_train_mode(train_mode); hip.ngp_debug_set_flags(k3_flags)
     try:
@@ -236,6 +236,38 @@ def _k3_loss_and_compaction(ora, hip, scene):
         n_cmp += kd
     assert n_cmp > 1000
     assert abs(float(loss.cpu()[0]) - float(o_loss.sum())) <= 5e-3 * abs(float(o_loss.sum())) + 1e-7
+
+
+def test_k3_compaction_order_is_the_slot_order(ora, hip, scene):
+    """The two-pass K3 places the rays' compacted spans in ray-slot order (prefix sum, no span atomics): base[i + 1] = base[i] + count[i],
+    and two runs on the same input give bit-identical outputs."""
+    import torch
+    n_rays, max_samples, B = 2048, 1 << 19, 1 << 19
+    o, d = _run_k1(ora, hip, scene, n_rays, max_samples)
+    rngs = np.random.default_rng(2)
+    net = np.zeros((max_samples, 4), np.float16)
+    net[:, :3] = rngs.normal(0, 1.5, (max_samples, 3)); net[:, 3] = rngs.normal(-1.0, 2.5, max_samples)
+    netd = torch.from_numpy(net.view(np.int16)).cuda()
+    aabb = A.scene_aabb(1); rng = _rng(ora); n_img = len(scene["imgs"]); bg = (C.c_float * 3)(0, 0, 0)
+    mean = torch.tensor([scene["mean"]], dtype=torch.float32, device="cuda")
+    Md = d["keep"][1]
+    n_act = int(d["counters"].cpu()[0])
+    ns0 = d["numsteps"].clone()
+    outs = []
+    for _ in range(2):
+        ns = ns0.clone()
+        cc = torch.zeros((B, 7), dtype=torch.float32, device="cuda"); dl = torch.zeros((B, 4), dtype=torch.int16, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda"); loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+        A.check(hip, hip.ngp_k_compute_loss(None, n_rays, None, aabb, rng, B, dptr(d["counters"][0:1]), C.c_float(128.0), bg, 0, 1, 0, n_img, dptr(Md), dptr(netd), 4, dptr(cnt),
+                                           dptr(d["ray_indices"]), dptr(d["rays"]), dptr(ns), dptr(d["coords"]), dptr(cc), dptr(dl), 4, A.LOSS_HUBER, dptr(loss),
+                                           A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
+        torch.cuda.synchronize()
+        outs.append((ns.cpu().numpy().astype(np.int64)[:n_act], cc.cpu().numpy(), dl.cpu().numpy(), int(cnt.cpu()[0])))
+    ns1, cc1, dl1, c1 = outs[0]
+    assert c1 > 1000 and ns1[0, 1] == 0 and c1 == ns1[-1, 0] + ns1[-1, 1]
+    assert np.array_equal(ns1[1:, 1], ns1[:-1, 1] + ns1[:-1, 0])
+    ns2, cc2, dl2, c2 = outs[1]
+    assert c1 == c2 and np.array_equal(ns1, ns2) and np.array_equal(cc1, cc2) and np.array_equal(dl1, dl2)
 
 
 def test_k3_batch_clamp(ora, hip, scene):
