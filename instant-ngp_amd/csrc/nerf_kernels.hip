@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3 in two passes (production): PASS 0 composites every active ray front to back (wave per ray) and leaves a 16-float record per
+// K3 in two passes (ablation DBG_K3_TWO_PASS; the one-pass kernel above is faster: 72 us against 34 + 57 us): PASS 0 composites every active ray front to back (wave per ray) and leaves a 16-float record per
 // ray {compacted count, rgb_ray, loss_bg (Rfl), target, background}; the workgroups' totals are scanned by the last workgroup (same
 // scheme as k1_count).  PASS 1 places every ray's compacted samples at its slot-ordered offset and writes the adjoint.
 // Against the one-pass kernel above: no __syncthreads / span atomic per 16 rays, 256-thread workgroups at <= 64 registers (twice the
@@ -1274,12 +1274,14 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 }
 // persistent grid: up to 8 workgroups of 4 wavefronts per CU; every workgroup owns at most K1_MAX_RANGE consecutive slots
 static uint32_t k1_grid(uint32_t max_local_rays) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * 8u), blocks(max_local_rays, K1_MAX_RANGE)); }
+// byte offset of the workgroup totals behind the RaySetup and mask arrays (64-bit atomics: naturally aligned)
+static size_t k1_partial_offset(uint32_t max_local_rays) { return ((size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + 15) / 16 * 16; }
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
-	return (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + (size_t)k1_grid(max_local_rays) * 8 + 256;
+	return k1_partial_offset(max_local_rays) + (size_t)k1_grid(max_local_rays) * 8 + 256;
 }
 // the ticket counter behind the workgroup totals must start at zero (k1_count's last workgroup leaves it at zero again)
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays) {
-	char* p = (char*)scratch + (size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8);
+	char* p = (char*)scratch + k1_partial_offset(max_local_rays);
 	return hipMemsetAsync(p, 0, (size_t)k1_grid(max_local_rays) * 8 + 256, s) == hipSuccess ? 0 : 1;
 }
 // two-pass K3: per-ray records + workgroup totals + ticket counters (zeroed once, like K1's)
@@ -1292,8 +1294,9 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	if (max_local_rays == 0) return;
 	char* p = (char*)scratch;
 	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
-	uint64_t* masks = (uint64_t*)p; p += (size_t)max_local_rays * LAT_MAX_CHUNKS * 8;
+	uint64_t* masks = (uint64_t*)p;
 	const uint32_t ray_grid = k1_grid(max_local_rays);
+	p = (char*)scratch + k1_partial_offset(max_local_rays);
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
@@ -1308,7 +1311,7 @@ void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
-	else if (!a.k3_scratch || (g_debug_flags & DBG_K3_ONE_PASS)) hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
+	else if (!a.k3_scratch || !(g_debug_flags & DBG_K3_TWO_PASS)) hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
 	else {
 		const uint32_t grid = k1_grid(max_rays);
 		float* rec = (float*)a.k3_scratch; uint64_t* partial = (uint64_t*)(rec + (size_t)max_rays * K3_REC); uint32_t* done = (uint32_t*)(partial + grid);

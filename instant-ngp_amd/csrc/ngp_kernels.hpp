@@ -10,7 +10,7 @@ namespace ngp {
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_MERGE_RUNS = 65536 /* k_grad_bin sums same-cell runs before the sort: 20 % fewer records, k_grad_accumulate 55 -> 44 us, k_grad_bin 57 -> 78 us: not worth it (profiles/r02_microbench_final.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
-	DBG_K3_ONE_PASS = 1048576 /* K3 as one kernel with a span atomic per 16 rays (round-1 behaviour; compaction order depends on the atomics) */,
+	DBG_K3_TWO_PASS = 1048576 /* K3 as composite pass + prefix sum + adjoint pass: deterministic (slot-ordered) compaction without span atomics, but 34 + 57 us against 72 us for the one-pass kernel (profiles/r02_k3_two_pass.txt) */,
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
 	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
@@ -75,7 +75,7 @@ struct K3Args {
 	const float* mean_density_ptr; float near_distance;
 	const float* ray_targets; // optional: K1Args::ray_targets_out (8 floats per active ray)
 	int train_mode;           // ETrainMode: 0 Nerf, 1 Rfl, 2 RflRelax (fused_kernels/train_nerf.cuh:391-410)
-	void* k3_scratch = nullptr; // k3_scratch_bytes(max_rays), initialised by k3_scratch_init: selects the two-pass kernel (deterministic compaction order)
+	void* k3_scratch = nullptr; // k3_scratch_bytes(max_rays), initialised by k3_scratch_init: needed by the two-pass kernel (DBG_K3_TWO_PASS)
 };
 size_t k3_scratch_bytes(uint32_t max_rays);
 int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays);

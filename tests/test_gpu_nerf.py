@@ -172,7 +172,8 @@ def test_k1_sample_cap(ora, hip, scene):
 @pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (1, 32), (2, 32), (0, 1048576), (1, 1048576), (2, 1048576)])
 def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
     """K3 vs the oracle per ray, for the three train modes (0 Nerf, 1 Rfl, 2 RflRelax: fused_kernels/train_nerf.cuh:391-410) and for the three device
-    kernels (two-pass wave per ray = production; flag 1048576 = one pass with span atomics; flag 32 = the reference's sequential per-ray loops)."""
+    kernels (one pass, wave per ray, span atomic per 16 rays = production; flag 1048576 = two passes with a prefix sum, deterministic order; flag 32 = the
+    reference's sequential per-ray loops)."""
     import torch
     ora.ora_set_train_mode(train_mode); hip.ngp_debug_set_train_mode(train_mode); hip.ngp_debug_set_flags(k3_flags)
     try:
@@ -239,7 +240,7 @@ def _k3_loss_and_compaction(ora, hip, scene):
 
 
 def test_k3_compaction_order_is_the_slot_order(ora, hip, scene):
-    """The two-pass K3 places the rays' compacted spans in ray-slot order (prefix sum, no span atomics): base[i + 1] = base[i] + count[i],
+    """The two-pass K3 (ablation flag 1048576) places the rays' compacted spans in ray-slot order (prefix sum, no span atomics): base[i + 1] = base[i] + count[i],
     and two runs on the same input give bit-identical outputs."""
     import torch
     n_rays, max_samples, B = 2048, 1 << 19, 1 << 19
@@ -254,6 +255,7 @@ def test_k3_compaction_order_is_the_slot_order(ora, hip, scene):
     n_act = int(d["counters"].cpu()[0])
     ns0 = d["numsteps"].clone()
     outs = []
+    hip.ngp_debug_set_flags(1048576)
     for _ in range(2):
         ns = ns0.clone()
         cc = torch.zeros((B, 7), dtype=torch.float32, device="cuda"); dl = torch.zeros((B, 4), dtype=torch.int16, device="cuda")
@@ -263,6 +265,7 @@ def test_k3_compaction_order_is_the_slot_order(ora, hip, scene):
                                            A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
         torch.cuda.synchronize()
         outs.append((ns.cpu().numpy().astype(np.int64)[:n_act], cc.cpu().numpy(), dl.cpu().numpy(), int(cnt.cpu()[0])))
+    hip.ngp_debug_set_flags(0)
     ns1, cc1, dl1, c1 = outs[0]
     assert c1 > 1000 and ns1[0, 1] == 0 and c1 == ns1[-1, 0] + ns1[-1, 1]
     assert np.array_equal(ns1[1:, 1], ns1[:-1, 1] + ns1[:-1, 0])
