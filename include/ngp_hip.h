@@ -434,7 +434,7 @@ int ngp_nerf_set_rays_per_batch(ngp_nerf*, uint32_t rays_per_batch);
 int ngp_nerf_get_rng(ngp_nerf*, ngp_pcg32* rng, ngp_pcg32* density_grid_rng);
 int ngp_nerf_set_rng(ngp_nerf*, const ngp_pcg32* rng);
 /* lazy (front-to-back) K2: rounds = 1 (default): one launch, every wavefront follows its ray tile by tile; rounds = 2..8: list-driven rounds;
-   samples per tile 32 (or 16 with >= 2 rounds) (csrc/model_kernels.hip k_inference_tiles) */
+   samples per tile 16 (default: two rays per wavefront) or 32 (csrc/model_kernels.hip k_inference_tiles) */
 int ngp_nerf_set_k2_params(ngp_nerf*, uint32_t rounds, uint32_t tile_w);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);

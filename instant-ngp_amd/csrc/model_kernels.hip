@@ -461,11 +461,11 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		}
 		const bool leader = hi == 0 && tcol == 0;
 		if (leader) n_eval += d.y;
-		if (TW == 32 && la.n_rounds == 1) {
-			// One launch, no lists: the wavefront that evaluated a tile of a still transparent ray goes on with the ray's next tile itself
-			// (one tile per wavefront, so the descriptor and the decision are wave-uniform).  Strictly lazier than the round scheme, whose last
-			// round takes everything that is left, and two launches + their ramps and gaps shorter.
-			if (d.w == 0u) break;
+		if (la.n_rounds == 1) {
+			// One launch, no lists: the wavefront that evaluated a tile of a still transparent ray goes on with the ray's next tile itself.
+			// Strictly lazier than the round scheme, whose last round takes everything that is left, and two launches + their ramps and gaps
+			// shorter.  TW == 16: the two tiles of the wavefront belong to different rays and continue (or end) independently -- the slot of a
+			// finished ray idles (its lanes issue no gathers) until the other one is done.
 			float od = 0.f;
 			if (hi == 0 && valid) {
 				const float x = st.sigma[0];
@@ -474,11 +474,12 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 				od = sg * (p[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
 			}
 #pragma unroll
-			for (int dd = 16; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64);
+			for (int dd = (int)TW / 2; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64); // sum over the tile's TW lanes (hi == 0 half)
 			T_wave *= __expf(-od);
-			const float T0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, T_wave)));
-			if (T0 < 0.99e-4f) break; // NaN stays alive, like in K3
-			const uint32_t take = min(d.w, TW);
+			const bool cont_l = d.w != 0u && !(T_wave < 0.99e-4f); // meaningful in the tile's leader lane; NaN stays alive, like in K3
+			const bool cont = __shfl((int)cont_l, (int)(slot * TW), 64) != 0;
+			if (__ballot(cont) == 0ull) break;
+			const uint32_t take = cont ? min(d.w, TW) : 0u;
 			d = make_uint4(d.x + TW, take, d.z, d.w - take);
 			continue;
 		}

@@ -1076,7 +1076,7 @@ struct ngp_nerf {
 	// overlaps step n's backward pass / optimizer (single-rank training, no grid update pending, no per-kernel profiling)
 	bool ctl_done = false; // the batch-size controller of the current step has run
 	hipStream_t k1_stream = nullptr; hipEvent_t ev_ctl = nullptr, ev_k1 = nullptr; bool k1_prelaunched = false; uint64_t state_version = 0, k1_version = 0; hipStream_t k1_for_stream = nullptr;
-	uint32_t k2_rounds = 1, k2_tile_w = 32; // 1 = one launch, every wavefront follows its ray front to back (default); 2..8 = list-driven rounds (round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest): 3 x 32 = 0.157 ms, 4 x 16 = 0.18 ms (profiles/r02_microbench_k2.log).  NGP_K2_ROUNDS / NGP_K2_TILE override.
+	uint32_t k2_rounds = 1, k2_tile_w = 16; // rounds 1 = one launch, every wavefront follows its rays front to back (default); 2..8 = list-driven rounds (round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest).  Tile width 16: two rays per wavefront, 383k instead of 556k evaluations per step.  Measured per step (profiles/r02_microbench_k2.log, r02_microbench_final.log): 3 rounds x 32 = 0.171 ms, 1 x 32 = 0.131 ms, 1 x 16 = 0.112 ms.  NGP_K2_ROUNDS / NGP_K2_TILE override.
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
@@ -1106,7 +1106,6 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
 	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 1), K2_ROUNDS);
 	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : 16u;
-	if (t->k2_tile_w == 16 && t->k2_rounds < 2) t->k2_rounds = 2;
 	t->grid_sample_cap = n_cells;
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
@@ -1518,7 +1517,7 @@ extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
 }
 // lazy K2 tuning knobs (test / ablation hook): 1 = single launch with in-wave continuation, 2..8 = list-driven front-to-back rounds; samples per tile (16 | 32)
 extern "C" int ngp_nerf_set_k2_params(ngp_nerf* t, uint32_t rounds, uint32_t tile_w) {
-	REQUIRE(rounds >= 1 && rounds <= K2_ROUNDS && (tile_w == 32 || (tile_w == 16 && rounds >= 2)), "set_k2_params: rounds in 1..8 (1 = one launch, wavefronts follow their rays), tile width 32, or 16 with >= 2 rounds");
+	REQUIRE(rounds >= 1 && rounds <= K2_ROUNDS && (tile_w == 32 || tile_w == 16), "set_k2_params: rounds in 1..8 (1 = one launch, wavefronts follow their rays), tile width 16 or 32");
 	invalidate_k1(t); // a pre-launched K1 wrote its round-0 tiles with the old width
 	t->k2_rounds = rounds; t->k2_tile_w = tile_w;
 	return 0;

@@ -14,21 +14,22 @@ import synth_scene
 
 # name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
 VARIANTS = [
-    ("default", 0, (12, 0, 0), (1, 32)),
+    ("default", 0, (12, 0, 0), (1, 16)),
+    ("k2_tile32", 0, (12, 0, 0), (1, 32)),
     ("k2_rounds3", 0, (12, 0, 0), (3, 32)),
-    ("t1_dense_external", 262144, (12, 0, 0), (1, 32)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
-    ("w_single_role", 32768, (12, 0, 0), (1, 32)),       # round-1 weight-gradient kernel
-    ("bin_merge_runs", 65536, (12, 0, 0), (1, 32)),      # k_grad_bin with same-cell run merging
-    ("separate_grad_memset", 131072, (12, 0, 0), (1, 32)),
-    ("round1_backward", 32768 | 131072, (12, 1, 0), (1, 32)),
-    ("bin_chunk12_split", 0, (12, 1, 0), (1, 32)),   # round-1 layout
-    ("bin_chunk11", 0, (11, 0, 0), (1, 32)),
+    ("t1_dense_external", 262144, (12, 0, 0), (1, 16)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
+    ("w_single_role", 32768, (12, 0, 0), (1, 16)),       # round-1 weight-gradient kernel
+    ("bin_merge_runs", 65536, (12, 0, 0), (1, 16)),      # k_grad_bin with same-cell run merging
+    ("separate_grad_memset", 131072, (12, 0, 0), (1, 16)),
+    ("round1_backward", 32768 | 131072, (12, 1, 0), (1, 16)),
+    ("bin_chunk12_split", 0, (12, 1, 0), (1, 16)),   # round-1 layout
+    ("bin_chunk11", 0, (11, 0, 0), (1, 16)),
     ("k2_tile16_r4", 0, (12, 0, 0), (4, 16)),
-    ("k2_eager", 8192, (12, 0, 0), (1, 32)),
-    ("k1_independent_lattice", 16384, (12, 0, 0), (1, 32)),
-    ("default_again", 0, (12, 0, 0), (1, 32)),
-    ("t1_no_binning", 2048, (12, 0, 0), (1, 32)),
-    ("t1_no_scatter", 2, (12, 0, 0), (1, 32)),
+    ("k2_eager", 8192, (12, 0, 0), (1, 16)),
+    ("k1_independent_lattice", 16384, (12, 0, 0), (1, 16)),
+    ("default_again", 0, (12, 0, 0), (1, 16)),
+    ("t1_no_binning", 2048, (12, 0, 0), (1, 16)),
+    ("t1_no_scatter", 2, (12, 0, 0), (1, 16)),
 ]
 
 
