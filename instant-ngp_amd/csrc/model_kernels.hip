@@ -1921,7 +1921,8 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
-		if (la.tile_w == 16) hipLaunchKernelGGL((k_inference_tiles<16>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
+		if (la.tile_w == 8) hipLaunchKernelGGL((k_inference_tiles<8>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
+		else if (la.tile_w == 16) hipLaunchKernelGGL((k_inference_tiles<16>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
 		else hipLaunchKernelGGL((k_inference_tiles<32>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
 	}
 	(void)max_samples;

@@ -254,6 +254,12 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	// number of wavefronts loops over the rays instead.
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t li_begin = (uint32_t)(((uint64_t)n_local * blockIdx.x) / gridDim.x), li_end = (uint32_t)(((uint64_t)n_local * (blockIdx.x + 1)) / gridDim.x);
+	// coarse occupancy (one bit per 4x4x4 cells) of every cascade in LDS: most lattice points lie in empty space and are rejected without a memory
+	// access, and a chunk without any coarse hit costs no memory latency at all
+	extern __shared__ uint32_t s_coarse[];
+	const bool prefilter = a.bitfield_coarse != nullptr && a.bitfield_linear != nullptr;
+	if (prefilter && li_begin < li_end) for (uint32_t w = threadIdx.x; w < (a.max_mip + 1) * COARSE_WORDS; w += blockDim.x) s_coarse[w] = a.bitfield_coarse[w];
+	__syncthreads();
 	uint64_t wave_total = 0ull; // packed {samples (low 32), rays with samples (high 32)} of this wavefront's rays
 	for (uint32_t li = li_begin + (threadIdx.x >> 6); li < li_end; li += 4) {
 	const RaySetup r = rs[li];
@@ -275,7 +281,8 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 			if (inside) {
 				const float dt = calc_dt(t, a.cone_angle_constant);
 				mip = mip_from_dt(dt, pos, a.max_mip);
-				occ = a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
+				occ = prefilter ? occupied_at_linear_prefiltered(pos, a.bitfield_linear, s_coarse, mip)
+					: a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
 				if (want_skip && !occ) {
 					// advance_to_next_voxel (nerf_device.cuh:431-441) lands on lattice point j + ceil(max(to(t_target) - to(t), 0.5))
 					const float res = scalbnf((float)GRIDSIZE, -(int)mip);
@@ -463,6 +470,25 @@ __global__ void k_build_linear_bitfield(const uint8_t* __restrict__ bitfield, ui
 		out |= ((src[m >> 3] >> (m & 7u)) & 1u) << k;
 	}
 	linear[b] = (uint8_t)out;
+}
+
+// one bit per 4x4x4 block of cells of the x-major copy: one thread per coarse cell, 32 coarse cells (one word) per 32 threads
+__global__ void __launch_bounds__(256) k_build_coarse_bitfield(const uint8_t* __restrict__ linear, uint32_t* __restrict__ coarse, uint32_t n_cascades) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t per = COARSE_SIZE * COARSE_SIZE * COARSE_SIZE;
+	const uint32_t casc = t / per, c = t % per;
+	bool any = false;
+	if (casc < n_cascades) {
+		const uint32_t cx = c % COARSE_SIZE, cy = (c / COARSE_SIZE) % COARSE_SIZE, cz = c / (COARSE_SIZE * COARSE_SIZE);
+		const uint8_t* src = linear + (size_t)casc * (GRID_N_CELLS / 8);
+		for (uint32_t dz = 0; dz < 4; ++dz)
+			for (uint32_t dy = 0; dy < 4; ++dy) {
+				const uint32_t cell0 = 4 * cx + GRIDSIZE * ((4 * cy + dy) + GRIDSIZE * (4 * cz + dz)); // 4 x-consecutive cells: one nibble
+				any |= ((src[cell0 >> 3] >> (cell0 & 7u)) & 0xfu) != 0u;
+			}
+	}
+	const uint64_t m = __ballot(any);
+	if (casc < n_cascades && (threadIdx.x & 31u) == 0) coarse[t >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1301,12 +1327,13 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
-	hipLaunchKernelGGL((k1_count<8>), dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial, done);
+	hipLaunchKernelGGL((k1_count<8>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? (a.max_mip + 1) * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
-void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades) {
+void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {
 	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;
 	hipLaunchKernelGGL(k_build_linear_bitfield, dim3(blocks(n_bytes, 256)), dim3(256), 0, s, bitfield, linear, n_bytes);
+	if (coarse) hipLaunchKernelGGL(k_build_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, linear, coarse, n_cascades);
 }
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;

@@ -962,8 +962,10 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
-	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, std::min<uint32_t>(max_mip + 1, N_CASCADES));
-	a.bitfield_linear = s_linear;
+	static uint32_t* s_coarse = nullptr;
+	if (!s_coarse && dev_alloc(&s_coarse, (size_t)COARSE_WORDS * N_CASCADES)) return 1;
+	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, std::min<uint32_t>(max_mip + 1, N_CASCADES), s_coarse);
+	a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse;
 	const uint32_t max_local = n_rays / world_size + 1;
 	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
 		launch_generate_training_samples((hipStream_t)stream, a, max_local);
@@ -1084,6 +1086,7 @@ struct ngp_nerf {
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
 	char* k3_scratch = nullptr; // per-ray records / workgroup totals of the two-pass K3
 	uint8_t* bitfield_linear = nullptr; // x-major copy of the bitfield for the lattice marchers
+	uint32_t* bitfield_coarse = nullptr; // one bit per 4x4x4 cells of it (k1_count's prefilter)
 	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
 	// in-library data-parallel step over RCCL (ngp_comm_init): communicator, its stream, bucket-reduced events
 	void* comm = nullptr; hipStream_t comm_stream = nullptr; hipEvent_t ev_red_a = nullptr, ev_red_b = nullptr; bool grads_pending = false;
@@ -1105,19 +1108,21 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
 	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 1), K2_ROUNDS);
-	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : 16u;
+	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : atoi(e) == 8 ? 8u : 16u;
+	if (t->k2_tile_w == 8) t->k2_rounds = 1;
 	t->grid_sample_cap = n_cells;
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * (o->max_cascade + 1)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays)) || dev_alloc(&t->k3_scratch, k3_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || k3_scratch_init(nullptr, t->k3_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
 	HIPCHK(hipMemset(t->bitfield_linear, 0, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)));
+	HIPCHK(hipMemset(t->bitfield_coarse, 0, (size_t)COARSE_WORDS * 4 * (o->max_cascade + 1)));
 	TrainCounters c; memset(&c, 0, sizeof(c));
 	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
 	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
@@ -1150,7 +1155,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
-		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
+		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
@@ -1223,7 +1228,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	++t->ema_step;
 	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
-	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1);
+	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1, t->bitfield_coarse);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1262,7 +1267,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.bitfield_linear = t->bitfield_linear; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
+		k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
@@ -1492,7 +1497,7 @@ extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const f
 	HIPCHK(hipMemcpy(t->density_grid, grid_host, n * 4, hipMemcpyHostToDevice));
 	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield((hipStream_t)stream, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
-	launch_build_linear_bitfield((hipStream_t)stream, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1);
+	launch_build_linear_bitfield((hipStream_t)stream, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1, t->bitfield_coarse);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1517,7 +1522,7 @@ extern "C" int ngp_nerf_set_training_step(ngp_nerf* t, uint32_t step) {
 }
 // lazy K2 tuning knobs (test / ablation hook): 1 = single launch with in-wave continuation, 2..8 = list-driven front-to-back rounds; samples per tile (16 | 32)
 extern "C" int ngp_nerf_set_k2_params(ngp_nerf* t, uint32_t rounds, uint32_t tile_w) {
-	REQUIRE(rounds >= 1 && rounds <= K2_ROUNDS && (tile_w == 32 || tile_w == 16), "set_k2_params: rounds in 1..8 (1 = one launch, wavefronts follow their rays), tile width 16 or 32");
+	REQUIRE(rounds >= 1 && rounds <= K2_ROUNDS && (tile_w == 32 || tile_w == 16 || (tile_w == 8 && rounds == 1)), "set_k2_params: rounds in 1..8 (1 = one launch, wavefronts follow their rays), tile width 16 or 32 (8 with rounds = 1)");
 	invalidate_k1(t); // a pre-launched K1 wrote its round-0 tiles with the old width
 	t->k2_rounds = rounds; t->k2_tile_w = tile_w;
 	return 0;

@@ -208,6 +208,22 @@ NGP_HD bool occupied_at_linear(f3 pos, const uint8_t* __restrict__ bitfield_line
 	const uint32_t idx = (uint32_t)ix + GRIDSIZE * ((uint32_t)iy + GRIDSIZE * (uint32_t)iz);
 	return bitfield_linear[idx / 8 + grid_mip_offset(mip) / 8] & (1 << (idx % 8));
 }
+// The same test behind a conservative prefilter: `coarse` (LDS) holds one bit per 4x4x4 block of cells (OR of its 64 cells; 32^3 bits =
+// 1024 words per cascade, built by k_build_coarse_bitfield from the linear copy), so a clear coarse bit proves the cell empty without a
+// memory access.  Identical result to occupied_at_linear by construction.
+constexpr uint32_t COARSE_SIZE = GRIDSIZE / 4, COARSE_WORDS = COARSE_SIZE * COARSE_SIZE * COARSE_SIZE / 32;
+NGP_D bool occupied_at_linear_prefiltered(f3 pos, const uint8_t* __restrict__ bitfield_linear, const uint32_t* coarse, uint32_t mip) {
+	float mip_scale = scalbnf(1.0f, -(int)mip);
+	pos = pos - mk3(0.5f);
+	pos = pos * mip_scale;
+	pos = pos + mk3(0.5f);
+	int ix = (int)(pos.x * (float)GRIDSIZE), iy = (int)(pos.y * (float)GRIDSIZE), iz = (int)(pos.z * (float)GRIDSIZE);
+	if (ix < 0 || ix >= (int)GRIDSIZE || iy < 0 || iy >= (int)GRIDSIZE || iz < 0 || iz >= (int)GRIDSIZE) return false;
+	const uint32_t cidx = ((uint32_t)ix >> 2) + COARSE_SIZE * (((uint32_t)iy >> 2) + COARSE_SIZE * ((uint32_t)iz >> 2));
+	if (!((coarse[mip * COARSE_WORDS + (cidx >> 5)] >> (cidx & 31u)) & 1u)) return false;
+	const uint32_t idx = (uint32_t)ix + GRIDSIZE * ((uint32_t)iy + GRIDSIZE * (uint32_t)iz);
+	return bitfield_linear[idx / 8 + grid_mip_offset(mip) / 8] & (1 << (idx % 8));
+}
 NGP_HD bool occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
 	uint32_t idx = cascaded_grid_idx_at(pos, mip);
 	if (idx == 0xFFFFFFFFu) return false;

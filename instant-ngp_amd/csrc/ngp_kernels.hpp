@@ -10,6 +10,7 @@ namespace ngp {
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_MERGE_RUNS = 65536 /* k_grad_bin sums same-cell runs before the sort: 20 % fewer records, k_grad_accumulate 55 -> 44 us, k_grad_bin 57 -> 78 us: not worth it (profiles/r02_microbench_final.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
+	DBG_K1_NO_PREFILTER = 2097152 /* k1_count without the coarse-occupancy prefilter in LDS */,
 	DBG_K3_TWO_PASS = 1048576 /* K3 as composite pass + prefix sum + adjoint pass: deterministic (slot-ordered) compaction without span atomics, but 34 + 57 us against 72 us for the one-pass kernel (profiles/r02_k3_two_pass.txt) */,
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
 	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
@@ -50,6 +51,7 @@ struct K1Args {
 	uint32_t n_images; const ngp_image_meta* metadata; const ngp_xform* xforms;
 	const uint8_t* bitfield; uint32_t max_mip;
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
+	const uint32_t* bitfield_coarse = nullptr; // optional: one bit per 4x4x4 cells of the x-major copy (same launcher), k1_count's LDS prefilter
 	uint4* k2_tiles0_out; uint32_t k2_tile_w; // optional: round-0 tile list of the lazy K2 (one descriptor per active ray: its first k2_tile_w samples)
 	int snap_to_pixel_centers; float cone_angle_constant;
 	int exact_skip; // lattice K1: follow the reference's skip rule (advance_to_next_voxel) over the lattice instead of testing every point on its own
@@ -87,7 +89,7 @@ constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multipli
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays); // once per allocation (and whenever max_local_rays changes)
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch);
-void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades);
+void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse = nullptr);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
 	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr, TrainCounters* ctl = nullptr /* run the batch-size controller behind the fill */, uint32_t ctl_world_size = 1);

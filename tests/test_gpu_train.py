@@ -103,7 +103,7 @@ def test_lazy_k2_matches_eager(ora, hip):
     hip.ngp_nerf_get_rng(s["t"], C.byref(rng), C.byref(grng))
     rays = min(st.rays_per_batch, 12000)  # far below K1's sample cap and K3's batch clamp (both order dependent)
     res = {}
-    for name, flags in (("lazy", 0), ("lazy_rounds", 0), ("lazy_tile16", 0), ("lazy_tile32", 0), ("eager", 8192)):
+    for name, flags in (("lazy", 0), ("lazy_rounds", 0), ("lazy_tile16", 0), ("lazy_tile32", 0), ("lazy_tile8", 0), ("eager", 8192)):
         c = _make(ora, hip, B, n_images=12, res=96)
         if name == "lazy_rounds":  # list-driven rounds instead of the default single launch whose wavefronts follow their rays
             A.check(hip, hip.ngp_nerf_set_k2_params(c["t"], 3, 32))
@@ -111,6 +111,8 @@ def test_lazy_k2_matches_eager(ora, hip):
             A.check(hip, hip.ngp_nerf_set_k2_params(c["t"], 1, 16))
         if name == "lazy_tile32":
             A.check(hip, hip.ngp_nerf_set_k2_params(c["t"], 1, 32))
+        if name == "lazy_tile8":
+            A.check(hip, hip.ngp_nerf_set_k2_params(c["t"], 1, 8))
         A.check(hip, hip.ngp_model_deserialize_host(c["hm"].h, buf, C.c_uint64(nbytes)))
         A.check(hip, hip.ngp_nerf_set_density_grid_host(c["t"], None, ptr(grid), C.c_uint64(n_cells)))
         hip.ngp_nerf_set_rng(c["t"], C.byref(rng))
@@ -129,7 +131,7 @@ def test_lazy_k2_matches_eager(ora, hip):
         A.check(hip, hip.ngp_nerf_train_finish(c["t"], None))
         res[name] = (cnt.copy(), grads, _stats(hip, c["t"]).loss)
         hip.ngp_nerf_destroy(c["t"]); ora.ora_nerf_destroy(c["ot"])
-    for variant in ("lazy_rounds", "lazy_tile16", "lazy_tile32"):
+    for variant in ("lazy_rounds", "lazy_tile16", "lazy_tile32", "lazy_tile8"):
         (cr, gr, lr), (ce, ge, le) = res[variant], res["eager"]
         assert abs(lr - le) <= 1e-4 * abs(le) and cr[0] == ce[0] and cr[1] == ce[1], variant
         assert np.linalg.norm(gr - ge) / np.linalg.norm(ge) < 0.1, variant

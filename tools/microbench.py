@@ -15,6 +15,8 @@ import synth_scene
 # name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
 VARIANTS = [
     ("default", 0, (12, 0, 0), (1, 16)),
+    ("k1_no_prefilter", 2097152, (12, 0, 0), (1, 16)),   # k1_count without the coarse-occupancy prefilter in LDS
+    ("k2_tile8", 0, (12, 0, 0), (1, 8)),
     ("k2_tile32", 0, (12, 0, 0), (1, 32)),
     ("k2_rounds3", 0, (12, 0, 0), (3, 32)),
     ("t1_dense_external", 262144, (12, 0, 0), (1, 16)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
