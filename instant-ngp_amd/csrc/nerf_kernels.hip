@@ -240,7 +240,10 @@ static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], u
 // scrambled rays, so the ranges are statistically equal), publishes the packed {samples, rays} total of its range, and the last workgroup to
 // finish (ticket counter) turns the G totals into exclusive offsets + the two global counters.  k1_write, launched with the same G, re-scans
 // the <= 128 counts of its own range in LDS.  Same slot-ordered spans as a global scan: deterministic, no atomics on the sample buffer.
-template <uint32_t K1_GROUP> // lattice chunks tested (= occupancy loads in flight) per iteration
+// K1_GROUP = lattice chunks tested (= occupancy loads in flight) per iteration.  SINGLE_CASCADE (aabb_scale 1: max_mip == 0): every point's mip
+// is 0 (mip_from_dt clamps to max_cascade), so dt, both frexp chains and the mip scaling drop out -- the kernel is VALU bound (~110
+// instructions per lattice point, 4 cycles each per wavefront), this removes a third of them.
+template <uint32_t K1_GROUP, bool SINGLE_CASCADE>
 __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__ rs, uint64_t* __restrict__ masks, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
 	__shared__ uint64_t s_tot[4];
 	__shared__ uint64_t s_scan[4];
@@ -279,8 +282,10 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 			inside = aabb.contains(pos);
 			occ = false; mip = 0u; skip = 1u;
 			if (inside) {
-				const float dt = calc_dt(t, a.cone_angle_constant);
-				mip = mip_from_dt(dt, pos, a.max_mip);
+				if (!SINGLE_CASCADE) {
+					const float dt = calc_dt(t, a.cone_angle_constant);
+					mip = mip_from_dt(dt, pos, a.max_mip);
+				}
 				occ = prefilter ? occupied_at_linear_prefiltered(pos, a.bitfield_linear, s_coarse, mip)
 					: a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
 				if (want_skip && !occ) {
@@ -1327,7 +1332,8 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
-	hipLaunchKernelGGL((k1_count<8>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? (a.max_mip + 1) * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	if (a.max_mip == 0) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? (a.max_mip + 1) * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {
