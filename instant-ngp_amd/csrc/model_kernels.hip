@@ -1548,16 +1548,34 @@ k_wgrad2(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_
 // sum the per-block partials, un-permute the D tiles into row-major [out][in] and round to half.
 // One block per 64 consecutive elements (= one register row of a tile): 4 waves each sum a quarter of the partials with
 // coalesced 256-byte reads, then combine through LDS in a fixed order (deterministic).
-__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
-	__shared__ float sm[4][64];
+// 16 wavefronts per 64 elements (each sums every 16th partial, 4 independent loads in flight), then a fixed-order tree over the 16 sums:
+// the 12.6 MB of partials stream at memory speed instead of as 64 dependent loads per wavefront (17.7 -> see DESIGN 8).
+__global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
+	__shared__ float sm[16][64];
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	const uint32_t e = blockIdx.x * 64 + lane; // element of [tile][r][lane]
-	float s = 0.f;
-	for (uint32_t g = wid; g < n_partials; g += 4) s += partials[(size_t)g * (N_DW_TILES * 16 * 64) + e];
-	sm[wid][lane] = s;
+	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+	constexpr size_t PS = (size_t)N_DW_TILES * 16 * 64;
+	uint32_t g = wid;
+	for (; g + 48 < n_partials; g += 64) {
+		s0 += partials[(size_t)g * PS + e]; s1 += partials[(size_t)(g + 16) * PS + e];
+		s2 += partials[(size_t)(g + 32) * PS + e]; s3 += partials[(size_t)(g + 48) * PS + e];
+	}
+	for (; g < n_partials; g += 16) s0 += partials[(size_t)g * PS + e];
+	sm[wid][lane] = (s0 + s1) + (s2 + s3);
 	__syncthreads();
 	if (wid != 0) return;
-	s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+	float s;
+	{
+		float t[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) t[k] = sm[k][lane];
+#pragma unroll
+		for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+			for (int k = 0; k < w; ++k) t[k] = t[k] + t[k + w];
+		s = t[0];
+	}
 	const int t = e / (16 * 64), r = (e / 64) % 16;
 	int layer_off, R, C, it, kt;
 	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
@@ -1998,7 +2016,7 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 	else hipLaunchKernelGGL(k_wgrad2, dim3(n_partials), dim3(512), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
 }
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad) {
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(N_DW_TILES * 16), dim3(256), 0, s, partials, n_partials, (__half*)mlp_grad);
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(N_DW_TILES * 16), dim3(1024), 0, s, partials, n_partials, (__half*)mlp_grad);
 }
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a) {
 	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params / 4 + 255) / 256)), dim3(256), 0, s, a);

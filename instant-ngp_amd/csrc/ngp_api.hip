@@ -1072,6 +1072,7 @@ struct ngp_nerf {
 	std::vector<void*> owned_pixels;
 	float* density_grid = nullptr; float* density_grid_tmp = nullptr; uint8_t* bitfield = nullptr; float* mean = nullptr; float* mean_partial = nullptr;
 	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
+	float* grid_positions_sorted = nullptr; uint32_t* grid_indices_sorted = nullptr; char* grid_sort_temp = nullptr; size_t grid_sort_temp_bytes = 0;
 	TrainCounters* counters = nullptr;
 	uint32_t* ray_indices = nullptr; ngp_ray* rays = nullptr; uint32_t* numsteps = nullptr;
 	// K1 of step n+1 does not depend on the parameters: it is launched on its own stream as soon as step n's controller has run and
@@ -1113,6 +1114,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	t->grid_sample_cap = n_cells;
 	if (dev_alloc(&t->density_grid, n_cells) || dev_alloc(&t->density_grid_tmp, n_cells) || dev_alloc(&t->bitfield, GRID_N_CELLS / 8 * N_CASCADES) ||
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
+		dev_alloc(&t->grid_positions_sorted, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices_sorted, n_cells) || dev_alloc(&t->grid_sort_temp, t->grid_sort_temp_bytes = grid_sample_sort_temp_bytes(n_cells)) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * (o->max_cascade + 1)) ||
@@ -1154,7 +1156,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (t->k1_stream) (void)hipStreamDestroy(t->k1_stream);
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
-	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices,
+	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
@@ -1219,11 +1221,20 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 		t->grid_indices + n_uniform, t->opt.max_cascade + 1, MIN_OPTICAL_THICKNESS);
 	t->density_grid_rng.advance(1ull << 32);
 	}
+	// evaluation order = (cascade, Morton cell) order: spatially coherent like the samples of a ray (sort_util.hip); the result is order independent
+	const float* eval_pos = t->grid_positions; const uint32_t* eval_idx = t->grid_indices;
+	if (!(g_debug_flags & DBG_GRID_NO_SORT)) {
+		ProfScope ps(P_GRID_MISC, s);
+		uint32_t key_bits = 21; for (uint32_t c = t->opt.max_cascade; c; c >>= 1) ++key_bits; // 3 x 7 Morton bits + the cascade
+		if (grid_sample_sort(s, t->grid_sort_temp, t->grid_sort_temp_bytes, t->grid_indices, t->grid_indices_sorted, t->grid_positions, t->grid_positions_sorted, n_samples, key_bits))
+			return fail("update_density_grid: sort failed");
+		eval_pos = t->grid_positions_sorted; eval_idx = t->grid_indices_sorted;
+	}
 	// NerfNetwork::density with the TRAINING params (use_inference_params = false, testbed_nerf.cu:2570)
 	{ ProfScope ps(P_GRID_DENSITY, s);
-	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->grid_positions, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0); }
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), eval_pos, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0); }
 	ProfScope ps2(P_GRID_MISC, s);
-	launch_splat_grid_samples(s, n_samples, t->grid_indices, t->grid_mlp_out, 1, t->density_grid_tmp, t->opt.density_activation);
+	launch_splat_grid_samples(s, n_samples, eval_idx, t->grid_mlp_out, 1, t->density_grid_tmp, t->opt.density_activation);
 	launch_ema_grid_samples(s, n_elements, decay, t->density_grid, t->density_grid_tmp);
 	++t->ema_step;
 	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);

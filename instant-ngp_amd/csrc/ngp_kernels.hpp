@@ -10,6 +10,7 @@ namespace ngp {
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_MERGE_RUNS = 65536 /* k_grad_bin sums same-cell runs before the sort: 20 % fewer records, k_grad_accumulate 55 -> 44 us, k_grad_bin 57 -> 78 us: not worth it (profiles/r02_microbench_final.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
+	DBG_GRID_NO_SORT = 4194304 /* occupancy-grid update evaluates its samples in generation order (round-1 behaviour) */,
 	DBG_K1_NO_PREFILTER = 2097152 /* k1_count without the coarse-occupancy prefilter in LDS */,
 	DBG_K3_TWO_PASS = 1048576 /* K3 as composite pass + prefix sum + adjoint pass: deterministic (slot-ordered) compaction without span atomics, but 34 + 57 us against 72 us for the one-pass kernel (profiles/r02_k3_two_pass.txt) */,
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
@@ -96,6 +97,9 @@ void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
 void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, const uint32_t* step_ptr, uint32_t step, ngp_aabb box, const float* grid_in,
 	float* pos, uint32_t* idx, uint32_t n_cascades, float thresh);
+// sort_util.hip: the update's samples sorted by (cascade, Morton cell) so that the density network sees spatially coherent positions
+size_t grid_sample_sort_temp_bytes(uint32_t n);
+int grid_sample_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* idx_in, uint32_t* idx_out, const float* pos_in, float* pos_out, uint32_t n, uint32_t key_bits);
 void launch_splat_grid_samples(hipStream_t s, uint32_t n, const uint32_t* idx, const ngp_half* out, uint32_t stride, float* grid, int act);
 void launch_ema_grid_samples(hipStream_t s, uint32_t n, float decay, float* grid_out, const float* grid_in);
 void launch_grid_mean(hipStream_t s, const float* grid, float* partial256, float* mean_out);
