@@ -99,7 +99,7 @@ void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, cons
 	float* pos, uint32_t* idx, uint32_t n_cascades, float thresh);
 // sort_util.hip: the update's samples sorted by (cascade, Morton cell) so that the density network sees spatially coherent positions
 size_t grid_sample_sort_temp_bytes(uint32_t n);
-int grid_sample_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* idx_in, uint32_t* idx_out, const float* pos_in, float* pos_out, uint32_t n, uint32_t key_bits);
+int grid_sample_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* idx_in, uint32_t* idx_out, const float* pos_in, float* pos_out, uint32_t n, uint32_t begin_bit, uint32_t end_bit);
 void launch_splat_grid_samples(hipStream_t s, uint32_t n, const uint32_t* idx, const ngp_half* out, uint32_t stride, float* grid, int act);
 void launch_ema_grid_samples(hipStream_t s, uint32_t n, float decay, float* grid_out, const float* grid_in);
 void launch_grid_mean(hipStream_t s, const float* grid, float* partial256, float* mean_out);

@@ -16,9 +16,9 @@ size_t grid_sample_sort_temp_bytes(uint32_t n) {
 	(void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const GridSamplePos*)nullptr, (GridSamplePos*)nullptr, (int)n, 0, 32, (hipStream_t)nullptr);
 	return bytes;
 }
-int grid_sample_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* idx_in, uint32_t* idx_out, const float* pos_in, float* pos_out, uint32_t n, uint32_t key_bits) {
+int grid_sample_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* idx_in, uint32_t* idx_out, const float* pos_in, float* pos_out, uint32_t n, uint32_t begin_bit, uint32_t end_bit) {
 	if (n == 0) return 0;
-	return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, idx_in, idx_out, (const GridSamplePos*)pos_in, (GridSamplePos*)pos_out, (int)n, 0, (int)key_bits, s) == hipSuccess ? 0 : 1;
+	return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, idx_in, idx_out, (const GridSamplePos*)pos_in, (GridSamplePos*)pos_out, (int)n, (int)begin_bit, (int)end_bit, s) == hipSuccess ? 0 : 1;
 }
 
 } // namespace ngp
