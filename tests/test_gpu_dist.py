@@ -184,7 +184,7 @@ def test_rccl_in_library_world1(hip):
     sa, sb = A.NerfStats(), A.NerfStats()
     A.check(hip, hip.ngp_nerf_get_stats(t_a, None, C.byref(sa))); A.check(hip, hip.ngp_nerf_get_stats(t_b, None, C.byref(sb)))
     # two trainings differ by the arrival order of the dense levels' half atomics: counters agree statistically, not bit for bit
-    assert sa.training_step == sb.training_step == 30 and abs(int(sa.rays_per_batch) - int(sb.rays_per_batch)) <= 512 and abs(int(sa.measured_batch_size) - int(sb.measured_batch_size)) <= 0.1 * sa.measured_batch_size
+    assert sa.training_step == sb.training_step == 30 and abs(int(sa.rays_per_batch) - int(sb.rays_per_batch)) <= 512 + 0.1 * sa.rays_per_batch and abs(int(sa.measured_batch_size) - int(sb.measured_batch_size)) <= 0.1 * sa.measured_batch_size
     # Adam turns every non-zero gradient into a step of ~lr, so the arrival order of the dense levels' half atomics decorrelates individual
     # table entries between ANY two runs within tens of steps: compare the training signal, not the parameter vectors
     print(f"rccl world-1 vs plain: loss {sb.loss:.6f} vs {sa.loss:.6f}")
