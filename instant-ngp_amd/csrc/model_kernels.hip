@@ -920,7 +920,14 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * 8];
 	const uint32_t tid = threadIdx.x, ly = blockIdx.y, level = a.levels[ly];
 	const LevelConst lc = level_const_uniform(a.gm, level);
-	const uint32_t n_chunks = lc.hs >> CL2;
+	// Chunk of a table entry.  Hashed level: 2^CL2 consecutive entries (the hash spreads every sample's corners over all chunks).  Dense level
+	// (a.dense_too): entries are INTERLEAVED over all NCH chunks (chunk = index mod NCH, local = index / NCH), so that the spatially clustered
+	// samples of a scene still fill the lists evenly; a dense level has at most 2^19 entries, i.e. local < 2^CL2.
+	constexpr uint32_t NCH_LOG2 = GRAD_BIN_MAX_TABLE_LOG2 - CL2;
+	const bool dense = !lc.hashed;
+	auto chunk_of = [&](uint32_t idx) { return dense ? idx & (NCH - 1u) : idx >> CL2; };
+	auto local_of = [&](uint32_t idx) { return dense ? idx >> NCH_LOG2 : idx & ((1u << CL2) - 1u); };
+	const uint32_t n_chunks = dense ? NCH : lc.hs >> CL2;
 	for (uint32_t c = tid; c < NCH; c += 256) s_cnt[c] = 0;
 	__syncthreads();
 	constexpr int SPT = GRAD_BIN_SAMPLES / 256; // samples per thread
@@ -949,7 +956,7 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;
 		const bool head = lane == 0 || key_xy != pxy || key_z != pz || !valid[u] || !pvalid;
 		const uint64_t hm = __ballot(head);
-		const bool merge = a.merge_runs && __popcll(hm) <= 48;
+		const bool merge = (a.merge_runs || dense) && __popcll(hm) <= 48; // dense (coarse) levels: most lanes are followers
 		bool emit = valid[u];
 		if (merge) {
 			const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
@@ -981,7 +988,7 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
 			idx[u][k] = cr.idx[k];
-			rank[u][k] = atomicAdd(&s_cnt[cr.idx[k] >> CL2], 1u);
+			rank[u][k] = atomicAdd(&s_cnt[chunk_of(cr.idx[k])], 1u);
 		}
 	}
 	__syncthreads();
@@ -1006,10 +1013,10 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 		if (!valid[u]) continue;
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			const uint32_t c = idx[u][k] >> CL2;
+			const uint32_t c = chunk_of(idx[u][k]);
 			const uint32_t pos = s_start[c] + rank[u][k];
 			s_val[pos] = val[u][k];
-			s_key[pos] = (c << 16) | (idx[u][k] & ((1u << CL2) - 1u));
+			s_key[pos] = (c << 16) | local_of(idx[u][k]);
 		}
 	}
 	__syncthreads();
@@ -1023,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 			a.vals[o] = v;
 			a.idxs[o] = (uint16_t)local;
 		} else { // list full: straight to the table (k_grad_accumulate adds its sums on top)
-			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + ((size_t)c << CL2) + local) * 4;
+			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + (dense ? ((size_t)local << NCH_LOG2) + c : ((size_t)c << CL2) + local)) * 4;
 			atomic_add_h2(dst, __builtin_bit_cast(h2, v.x));
 			atomic_add_h2(dst + 2, __builtin_bit_cast(h2, v.y));
 		}
@@ -1050,7 +1057,10 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	__shared__ unsigned long long acc[E * NF];
 	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = SPLIT ? blockIdx.z : 0u, level = a.levels[ly];
 	const uint32_t hs = a.gm->hashmap_size[level], offset = a.gm->offset[level];
-	if (c >= (hs >> CL2)) return;
+	constexpr uint32_t NCH_LOG2 = GRAD_BIN_MAX_TABLE_LOG2 - CL2;
+	const uint64_t res = a.gm->resolution[level];
+	const bool dense = res * res * res <= (uint64_t)hs; // interleaved chunks: entry = local * NCH + chunk (see k_grad_bin)
+	if (c >= (dense ? (1u << NCH_LOG2) : (hs >> CL2))) return;
 	uint32_t* cursor = a.cursors + ly * a.max_chunks + c;
 	const uint32_t n = min(*cursor, a.cap);
 	for (uint32_t i = tid; i < E * NF; i += 1024) acc[i] = 0ull;
@@ -1102,13 +1112,15 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 			gt[(size_t)e * 2] = r;
 		}
 	} else {
-		uint2* gt = (uint2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << CL2)) * 4);
-		for (uint32_t e = tid; e < E; e += 1024) {
-			const h4 old = __builtin_bit_cast(h4, gt[e]); // zero unless a list overflowed
+		uint2* gt = (uint2*)((__half*)a.grid_grad_ + ((size_t)offset + (dense ? (size_t)c : ((size_t)c << CL2))) * 4);
+		const uint32_t n_local = dense ? (hs > c ? (hs - c + (1u << NCH_LOG2) - 1u) >> NCH_LOG2 : 0u) : E; // dense: entries c, c + NCH, c + 2 NCH, ... < hs
+		for (uint32_t e = tid; e < n_local; e += 1024) {
+			const size_t o = dense ? ((size_t)e << NCH_LOG2) : (size_t)e;
+			const h4 old = __builtin_bit_cast(h4, gt[o]); // zero unless a list overflowed
 			h4 r;
 #pragma unroll
 			for (int f = 0; f < 4; ++f) r[f] = (_Float16)((float)old[f] + (float)(long long)acc[f * E + e] * 0x1p-24f);
-			gt[e] = __builtin_bit_cast(uint2, r);
+			gt[o] = __builtin_bit_cast(uint2, r);
 		}
 	}
 }

@@ -163,6 +163,7 @@ struct ngp_model {
 	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0, bin_lists = 0;
 	GradBinArgs bin_args{};
 	// W (weight gradients, compute bound, 1 wave/SIMD) runs on a side stream next to the hashed levels' bin/accumulate kernels (memory/LDS bound)
+	bool bin_dense = false; // the dense levels are scattered through the bin lists as well (DBG_BIN_DENSE_LEVELS)
 	hipStream_t side = nullptr, side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 	// data-parallel step: events that mark the two gradient buckets final (recorded when record_bucket_events is set, see ngp_comm_*)
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
@@ -368,14 +369,25 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = (g_debug_flags & DBG_BIN_MERGE_RUNS) != 0;
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
+		// DBG_BIN_DENSE_LEVELS: the dense levels go through the lists as well (entries interleaved over all 2^(19 - chunk_log2) chunks, see
+		// k_grad_bin), T1 issues no atomics at all; needs the one-block-per-chunk layout
+		const bool dense_too = (g_debug_flags & DBG_BIN_DENSE_LEVELS) && !ba.split;
+		uint32_t n_dense = 0;
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
 			const uint64_t res = m->gm.resolution[l], hs = m->gm.hashmap_size[l];
-			if (res * res * res <= hs) continue;
+			if (res * res * res <= hs) {
+				if (!dense_too) continue;
+				if (hs > (1u << GRAD_BIN_MAX_TABLE_LOG2)) { ok = false; break; }
+				ba.levels[ba.n_hashed++] = l; ++n_dense;
+				ba.max_chunks = std::max<uint32_t>(ba.max_chunks, (1u << GRAD_BIN_MAX_TABLE_LOG2) >> ba.chunk_log2);
+				continue;
+			}
 			if ((hs & (hs - 1)) || hs < (1u << ba.chunk_log2) || hs > (1u << GRAD_BIN_MAX_TABLE_LOG2)) { ok = false; break; }
 			ba.levels[ba.n_hashed++] = l;
 			ba.max_chunks = std::max<uint32_t>(ba.max_chunks, (uint32_t)(hs >> ba.chunk_log2));
 		}
 		if (!ok) ba.n_hashed = 0;
+		m->bin_dense = ok && n_dense > 0;
 	}
 	// lists: n_hashed x max_chunks of `cap` records (8-byte values + 2-byte local indices); capacity = twice the mean number of
 	// records per chunk.  Re-allocated when the batch grows or the layout (chunk size, capacity override) changes.
@@ -400,10 +412,10 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	// dense levels (ablation DBG_T1_DENSE_EXTERNAL): T1 leaves their dL/d(enc) in denc_lv as well and k_grad_dense issues the atomics beside the kernels below
 	GradDenseArgs da;
 	da.n_levels = 0;
-	if (ba.n_hashed && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !(g_debug_flags & DBG_T1_NO_SCATTER))
+	if (ba.n_hashed && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !m->bin_dense && !(g_debug_flags & DBG_T1_NO_SCATTER))
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
 	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
-		g_debug_flags | (da.n_levels ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
+		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
 	hipStream_t sw = s;

@@ -15,6 +15,7 @@ import synth_scene
 # name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
 VARIANTS = [
     ("default", 0, (12, 0, 0), (1, 16)),
+    ("bin_dense_levels", 8388608, (12, 0, 0), (1, 16)),   # dense levels through the bin lists, no atomics in T1
     ("grid_no_sort", 4194304, (12, 0, 0), (1, 16)),   # occupancy-grid update in generation order
     ("k1_no_prefilter", 2097152, (12, 0, 0), (1, 16)),   # k1_count without the coarse-occupancy prefilter in LDS
     ("k2_tile8", 0, (12, 0, 0), (1, 8)),
