@@ -163,7 +163,7 @@ struct ngp_model {
 	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0, bin_lists = 0;
 	GradBinArgs bin_args{};
 	// W (weight gradients, compute bound, 1 wave/SIMD) runs on a side stream next to the hashed levels' bin/accumulate kernels (memory/LDS bound)
-	bool bin_dense = false; // the dense levels are scattered through the bin lists as well (DBG_BIN_DENSE_LEVELS)
+	bool bin_dense = false; // the dense levels are scattered through the bin lists as well (production; see ngp_model_training_step)
 	hipStream_t side = nullptr, side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 	// data-parallel step: events that mark the two gradient buckets final (recorded when record_bucket_events is set, see ngp_comm_*)
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
@@ -369,9 +369,16 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = (g_debug_flags & DBG_BIN_MERGE_RUNS) != 0;
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
-		// DBG_BIN_DENSE_LEVELS: the dense levels go through the lists as well (entries interleaved over all 2^(19 - chunk_log2) chunks, see
-		// k_grad_bin), T1 issues no atomics at all; needs the one-block-per-chunk layout
-		const bool dense_too = (g_debug_flags & DBG_BIN_DENSE_LEVELS) && !ba.split;
+		// The dense levels go through the lists as well (entries interleaved over all 2^(19 - chunk_log2) chunks, see k_grad_bin): T1 issues no
+		// atomics at all -- the memory side retires only ~14 G four-byte atomic operations per second, and the dense levels needed 1.9 M of them
+		// per step (~100 us of T1).  Needs the one-block-per-chunk layout; DBG_T1_DENSE_ATOMICS restores the atomics.
+		// (and every hashed level must have the full 2^19-entry table, base.json's size: the dense levels always spread over 2^(19 - chunk_log2)
+		// lists and all lists share one capacity, so smaller tables would overflow theirs)
+		bool dense_too = !(g_debug_flags & DBG_T1_DENSE_ATOMICS) && !ba.split;
+		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
+			const uint64_t res = m->gm.resolution[l], hs = m->gm.hashmap_size[l];
+			if (res * res * res > hs && hs != (1ull << GRAD_BIN_MAX_TABLE_LOG2)) dense_too = false;
+		}
 		uint32_t n_dense = 0;
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
 			const uint64_t res = m->gm.resolution[l], hs = m->gm.hashmap_size[l];

@@ -15,13 +15,13 @@ import synth_scene
 # name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
 VARIANTS = [
     ("default", 0, (12, 0, 0), (1, 16)),
-    ("bin_dense_levels", 8388608, (12, 0, 0), (1, 16)),   # dense levels through the bin lists, no atomics in T1
+    ("t1_dense_atomics", 8388608, (12, 0, 0), (1, 16)),   # dense levels as half atomics from T1 instead of through the bin lists
     ("grid_no_sort", 4194304, (12, 0, 0), (1, 16)),   # occupancy-grid update in generation order
     ("k1_no_prefilter", 2097152, (12, 0, 0), (1, 16)),   # k1_count without the coarse-occupancy prefilter in LDS
     ("k2_tile8", 0, (12, 0, 0), (1, 8)),
     ("k2_tile32", 0, (12, 0, 0), (1, 32)),
     ("k2_rounds3", 0, (12, 0, 0), (3, 32)),
-    ("t1_dense_external", 262144, (12, 0, 0), (1, 16)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
+    ("t1_dense_external", 262144 | 8388608, (12, 0, 0), (1, 16)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
     ("w_single_role", 32768, (12, 0, 0), (1, 16)),       # round-1 weight-gradient kernel
     ("bin_merge_runs", 65536, (12, 0, 0), (1, 16)),      # k_grad_bin with same-cell run merging
     ("separate_grad_memset", 131072, (12, 0, 0), (1, 16)),
