@@ -651,7 +651,9 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 	__builtin_amdgcn_global_atomic_fadd_v2f16((gh2*)addr, v);
 }
 
-template <int CT, int MINW>
+// SCATTER = false: every level's dL/d(enc) goes to denc_lv and the kernel issues no atomics (production: all levels through the bin lists);
+// compiled separately so that the scatter code's registers do not limit the occupancy of the gather-latency-bound forward / dgrad part.
+template <int CT, int MINW, bool SCATTER>
 __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
 		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags,
 		uint2* __restrict__ denc_lv, uint32_t denc_cap) {
@@ -782,6 +784,18 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 		// packed half (the same precision class as the table's half atomics), so only the run head
 		// issues global_atomic_pk_add_f16.
 		if (flags & DBG_T1_NO_SCATTER) continue;
+		if (!SCATTER) {
+#pragma unroll
+			for (int c = 0; c < CT; ++c) {
+				if (sidx[c] >= n) continue;
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr) {
+					const h4 g = {(_Float16)denc[c][4 * rr + 0], (_Float16)denc[c][4 * rr + 1], (_Float16)denc[c][4 * rr + 2], (_Float16)denc[c][4 * rr + 3]};
+					denc_lv[(size_t)(2 * rr + hi) * denc_cap + sidx[c]] = __builtin_bit_cast(uint2, g);
+				}
+			}
+			continue;
+		}
 #pragma unroll
 		for (int c = 0; c < CT; ++c) {
 			const bool sv = sidx[c] < n;
@@ -911,7 +925,7 @@ DEV LevelConst level_const_uniform(const GridMeta* __restrict__ gm, uint32_t lev
 	return lc;
 }
 
-template <uint32_t CL2>
+template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */>
 __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	constexpr uint32_t NCH = (1u << GRAD_BIN_MAX_TABLE_LOG2) >> CL2; // most chunks a level can have (128 / 256)
 	__shared__ uint32_t s_cnt[NCH], s_start[NCH], s_gbase[NCH];
@@ -1993,13 +2007,16 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	if (a.n == 0 || a.n_hashed == 0) return;
-	const dim3 gb((a.n + GRAD_BIN_SAMPLES - 1) / GRAD_BIN_SAMPLES, a.n_hashed);
+	static const uint32_t ns = getenv("NGP_BIN_SAMPLES") ? (uint32_t)atoi(getenv("NGP_BIN_SAMPLES")) : 512u;
+	const dim3 gb((a.n + ns - 1) / ns, a.n_hashed);
 	if (a.chunk_log2 == 11) {
-		hipLaunchKernelGGL((k_grad_bin<11>), gb, dim3(256), 0, s, a);
+		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<11, 256>), gb, dim3(256), 0, s, a);
+		else hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
 		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
 	} else {
-		hipLaunchKernelGGL((k_grad_bin<12>), gb, dim3(256), 0, s, a);
+		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<12, 256>), gb, dim3(256), 0, s, a);
+		else hipLaunchKernelGGL((k_grad_bin<12, 512>), gb, dim3(256), 0, s, a);
 		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_accumulate<12, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
 	}
@@ -2009,11 +2026,18 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
-	if (flags & DBG_T1_OCC2)
-		hipLaunchKernelGGL((k_train_fwd_bwd<1, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
+	static const int t1_occ = getenv("NGP_T1_OCC") ? atoi(getenv("NGP_T1_OCC")) : 4;
+	if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3)
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
+			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
+	else if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2)) // no atomics in T1: every level's dL/d(enc) goes to denc_lv
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 4, false>), dim3(std::min<uint32_t>((tiles + 3) / 4, (uint32_t)num_cus() * 4)), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
+			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
+	else if (flags & DBG_T1_OCC2)
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 2, true>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
 			(__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
 	else
-		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, true>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride,
 			(__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
 }
 void launch_grad_dense(hipStream_t s, const GradDenseArgs& a) {

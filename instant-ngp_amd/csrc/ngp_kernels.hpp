@@ -168,7 +168,6 @@ uint32_t wgrad_n_partials();
 
 // binned scatter of the hashed levels (model_kernels.hip)
 constexpr uint32_t GRAD_BIN_MAX_TABLE_LOG2 = 19; // hashmap sizes up to 2^19 (2^12 .. 2^19)
-constexpr uint32_t GRAD_BIN_SAMPLES = 512;       // samples per k_grad_bin block
 // chunk_log2: table entries per chunk (2^12: 128 KiB of 64-bit accumulators for the four features of an entry, one block per CU;
 // 2^11: 64 KiB, two blocks per CU).  split: round-1 layout, one block per (chunk, feature pair) -- both blocks fetch every record.
 struct GradBinArgs {
