@@ -2026,7 +2026,8 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
-	static const int t1_occ = getenv("NGP_T1_OCC") ? atoi(getenv("NGP_T1_OCC")) : 4;
+	// 3 wavefronts per SIMD without spills (164 registers) beat 4 with 36 spilled registers: T1 + bin + accumulate 0.219 vs 0.244 ms (profiles/r02_t1_occupancy.txt)
+	static const int t1_occ = getenv("NGP_T1_OCC") ? atoi(getenv("NGP_T1_OCC")) : 3;
 	if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3)
 		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
 			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);

@@ -273,7 +273,12 @@ def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
                 assert v < (2e-2 if not k.startswith("grid") else 5e-2), (name, k, v)
     finally:
         A.check(hip, hip.ngp_debug_set_bin_params(12, 0, 0)); hip.ngp_debug_set_flags(0)
-    for l in hashed:
+    # Bit-identical sums within one instantiation of T1 (the layouts with one block per chunk run the T1 without scatter code, the split ones
+    # the T1 that issues the dense levels' atomics: the compiler contracts the MLP's fp operations differently in the two, so dL/d(enc)
+    # differs in the last bit between them); in the one-block-per-chunk layouts the DENSE levels are exact sums as well.
+    for l in range(8):
         lo, hi_ = blocks[f"grid_level_{l}"]
-        for name in ("chunk12_split", "chunk11", "chunk11_split"):
-            assert np.array_equal(got["chunk12"][lo:hi_], got[name][lo:hi_]), (name, l)
+        assert np.array_equal(got["chunk12"][lo:hi_], got["chunk11"][lo:hi_]), ("chunk11", l)
+        if l in hashed:
+            assert np.array_equal(got["chunk12_split"][lo:hi_], got["chunk11_split"][lo:hi_]), ("chunk11_split", l)
+            assert np.array_equal(got["t1_dense_atomics"][lo:hi_], got["t1_dense_atomics_chunk11"][lo:hi_]), ("t1_dense_atomics_chunk11", l)
