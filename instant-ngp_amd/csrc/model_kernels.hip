@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;
 		const bool head = lane == 0 || key_xy != pxy || key_z != pz || !valid[u] || !pvalid;
 		const uint64_t hm = __ballot(head);
-		const bool merge = (a.merge_runs || dense) && __popcll(hm) <= 48; // dense (coarse) levels: most lanes are followers
+		const bool merge = (a.merge_runs || (dense && !a.no_dense_merge)) && __popcll(hm) <= 48; // dense (coarse) levels: most lanes are followers
 		bool emit = valid[u];
 		if (merge) {
 			const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
@@ -981,6 +981,7 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
 				const bool take = run_right >= (uint32_t)d;
+				if (__ballot(take) == 0ull) break; // no run reaches this far (wave-uniform): runs are a ray's samples in one cell, rarely longer than 8 - 16
 #pragma unroll
 				for (int k = 0; k < 8; ++k)
 #pragma unroll
