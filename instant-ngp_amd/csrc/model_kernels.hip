@@ -962,9 +962,9 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 			if (valid[u]) { const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + sc]); g0 = (float)g[0]; g1 = (float)g[1]; g2 = (float)g[2]; g3 = (float)g[3]; }
 		}
 		// Consecutive lanes are consecutive samples of (mostly) one ray; on the coarser hashed levels runs of them share a grid cell, i.e. all
-		// eight table entries.  With merge_runs (ablation DBG_BIN_MERGE_RUNS) such runs are summed here (fp32, segmented shuffle reduction like
-		// T1's) and only the run head emits records: 20-25 % fewer records to sort, write, read and accumulate -- but the 192 shuffles per sample
-		// cost this kernel more (57 -> 78 us) than k_grad_accumulate gains (55 -> 44 us), so production emits every record.
+		// eight table entries.  Such runs are summed here (fp32, segmented shuffle reduction like T1's, stopped at the longest run of the
+		// wavefront) and only the run head emits records: 20-25 % fewer records of the hashed levels and ~60 % fewer of the dense ones to sort,
+		// write, read and accumulate (without it the dense levels' lists overflow).  Wave-uniform decision: worth it when >= 1/4 of the lanes are followers.
 		const uint32_t key_xy = cr.cell_xy, key_z = cr.cell_z;
 		const uint32_t pxy = (uint32_t)__shfl_up((int)key_xy, 1, 64), pz = (uint32_t)__shfl_up((int)key_z, 1, 64);
 		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;

@@ -366,7 +366,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	}
 	// binned scatter: every hashed level must have a power-of-two table of 2^chunk_log2 .. 2^19 entries (base.json: 2^19)
 	GradBinArgs& ba = m->bin_args;
-	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = (g_debug_flags & DBG_BIN_MERGE_RUNS) != 0; ba.no_dense_merge = (g_debug_flags & DBG_BIN_NO_DENSE_MERGE) != 0;
+	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = !(g_debug_flags & DBG_BIN_NO_HASHED_MERGE); ba.no_dense_merge = (g_debug_flags & DBG_BIN_NO_DENSE_MERGE) != 0;
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
 		// The dense levels go through the lists as well (entries interleaved over all 2^(19 - chunk_log2) chunks, see k_grad_bin): T1 issues no

@@ -9,8 +9,8 @@ namespace ngp {
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
-	DBG_BIN_MERGE_RUNS = 65536 /* k_grad_bin sums same-cell runs before the sort: 20 % fewer records, k_grad_accumulate 55 -> 44 us, k_grad_bin 57 -> 78 us: not worth it (profiles/r02_microbench_final.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
-	DBG_BIN_NO_DENSE_MERGE = 16777216 /* k_grad_bin emits one record per sample and corner on the dense levels too (no same-cell run merging) */,
+	DBG_BIN_NO_HASHED_MERGE = 65536 /* k_grad_bin sums same-cell runs before the sort on the dense levels only (hashed levels: one record per sample and corner): bin + accumulate 150 -> 161 us (profiles/r02_microbench_bin_merge.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
+	DBG_BIN_NO_DENSE_MERGE = 16777216 /* no run merging on the dense levels either: their lists overflow into the atomics fallback (0.16 -> 0.81 ms) */,
 	DBG_T1_DENSE_ATOMICS = 8388608 /* dense levels' gradients as merged half atomics issued by T1 (rounds 1-2a) instead of through k_grad_bin / k_grad_accumulate: T1 183 -> 89 us, bin + accumulate 123 -> 173 us (profiles/r02_microbench_dense_bins.log) */,
 	DBG_GRID_NO_SORT = 4194304 /* occupancy-grid update evaluates its samples in generation order (round-1 behaviour) */,
 	DBG_K1_NO_PREFILTER = 2097152 /* k1_count without the coarse-occupancy prefilter in LDS */,

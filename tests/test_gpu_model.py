@@ -254,7 +254,7 @@ def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
     variants = [("chunk12", 12, 0, 0, 0), ("chunk12_split", 12, 1, 0, 0), ("chunk11", 11, 0, 0, 0), ("chunk11_split", 11, 1, 0, 0),
                 ("chunk12_overflow", 12, 0, 2048, 0), ("chunk11_split_overflow", 11, 1, 1024, 0), ("atomics_only", 12, 0, 0, 2048),
                 # ablation variants of ngp_kernels.hpp: run merging in k_grad_bin, dense levels through k_grad_dense, one-role weight-gradient kernel
-                ("bin_merge_runs", 12, 0, 0, 65536), ("w_single_role", 12, 0, 0, 32768),
+                ("bin_no_hashed_merge", 12, 0, 0, 65536), ("w_single_role", 12, 0, 0, 32768),
                 # dense levels as half atomics from T1 (rounds 1-2a) / from k_grad_dense instead of through the bin lists
                 ("t1_dense_atomics", 12, 0, 0, 8388608), ("t1_dense_atomics_chunk11", 11, 0, 0, 8388608), ("dense_external", 12, 0, 0, 262144 | 8388608)]
     got = {}

@@ -24,7 +24,7 @@ VARIANTS = [
     ("k2_rounds3", 0, (12, 0, 0), (3, 32)),
     ("t1_dense_external", 262144 | 8388608, (12, 0, 0), (1, 16)),   # dense levels' atomics issued by k_grad_dense on its own stream instead of by T1
     ("w_single_role", 32768, (12, 0, 0), (1, 16)),       # round-1 weight-gradient kernel
-    ("bin_merge_runs", 65536, (12, 0, 0), (1, 16)),      # k_grad_bin with same-cell run merging
+    ("bin_no_hashed_merge", 65536, (12, 0, 0), (1, 16)), # k_grad_bin merges same-cell runs on the dense levels only
     ("separate_grad_memset", 131072, (12, 0, 0), (1, 16)),
     ("round1_backward", 32768 | 131072, (12, 1, 0), (1, 16)),
     ("bin_chunk12_split", 0, (12, 1, 0), (1, 16)),   # round-1 layout
