@@ -261,7 +261,14 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	// access, and a chunk without any coarse hit costs no memory latency at all
 	extern __shared__ uint32_t s_coarse[];
 	const bool prefilter = a.bitfield_coarse != nullptr && a.bitfield_linear != nullptr;
-	if (prefilter && li_begin < li_end) for (uint32_t w = threadIdx.x; w < (a.max_mip + 1) * COARSE_WORDS; w += blockDim.x) s_coarse[w] = a.bitfield_coarse[w];
+	// single cascade + constant step (cone_angle 0): 8-point lattice segments (7 steps = 0.012 < one coarse cell = 0.031) are rejected by ONE test
+	// of their midpoint against the DILATED coarse grid (second half of the LDS copy), whole chunks without a hit are not evaluated at all
+	const bool group_skip = SINGLE_CASCADE && prefilter && a.segment_skip && a.cone_angle_constant <= 1e-5f;
+	if (prefilter && li_begin < li_end) {
+		const uint32_t n_words = (a.max_mip + 1) * COARSE_WORDS;
+		for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) s_coarse[w] = a.bitfield_coarse[w];
+		if (group_skip) for (uint32_t w = threadIdx.x; w < COARSE_WORDS; w += blockDim.x) s_coarse[COARSE_WORDS + w] = a.bitfield_coarse[n_words + w];
+	}
 	__syncthreads();
 	uint64_t wave_total = 0ull; // packed {samples (low 32), rays with samples (high 32)} of this wavefront's rays
 	for (uint32_t li = li_begin + (threadIdx.x >> 6); li < li_end; li += 4) {
@@ -305,8 +312,25 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
 			uint64_t m[K1_GROUP], in[K1_GROUP];
 			uint32_t mip0[K1_GROUP]; bool uni[K1_GROUP]; // exact skip: the chunk's mip (of its first point) / is it the same for all points inside the box?
+			uint64_t seg_hit = ~0ull, seg_in = ~0ull; // lane l <-> the 8 lattice points ch0 * 64 + 8 l .. + 7 (chunk u = lanes 8 u .. 8 u + 7)
+			if (group_skip) {
+				const uint32_t j0 = ch0 * 64 + 8 * lane;
+				const float tm = (r.nprime + ((float)j0 + 3.5f)) * MIN_CONE_STEP; // from_stepping_space at cone_angle 0
+				const f3 pm = ro + tm * rdn;
+				const uint32_t cx = (uint32_t)clampi((int)floorf(pm.x * (float)COARSE_SIZE), 0, (int)COARSE_SIZE - 1), cy = (uint32_t)clampi((int)floorf(pm.y * (float)COARSE_SIZE), 0, (int)COARSE_SIZE - 1),
+					cz = (uint32_t)clampi((int)floorf(pm.z * (float)COARSE_SIZE), 0, (int)COARSE_SIZE - 1);
+				const uint32_t cidx = cx + COARSE_SIZE * (cy + COARSE_SIZE * cz);
+				seg_hit = __ballot(((s_coarse[COARSE_WORDS + (cidx >> 5)] >> (cidx & 31u)) & 1u) != 0u);
+				// the march is inside the box from its first point up to its exit: a chunk lies wholly outside iff its FIRST point does (exact test)
+				const float t0 = lattice_t(r, j0, a.cone_angle_constant);
+				seg_in = __ballot(aabb.contains(ro + t0 * rdn));
+			}
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
+				if (group_skip && !((seg_hit >> (8 * u)) & 0xffull)) { // no occupied cell anywhere near the chunk's 64 points
+					m[u] = 0ull; in[u] = ((seg_in >> (8 * u)) & 1ull) ? ~0ull : 0ull; mip0[u] = 0u; uni[u] = true;
+					continue;
+				}
 				bool inside, occ; uint32_t mip, skip;
 				eval_point((ch0 + u) * 64 + lane, false, inside, occ, mip, skip);
 				m[u] = __ballot(occ);
@@ -494,6 +518,29 @@ __global__ void __launch_bounds__(256) k_build_coarse_bitfield(const uint8_t* __
 	}
 	const uint64_t m = __ballot(any);
 	if (casc < n_cascades && (threadIdx.x & 31u) == 0) coarse[t >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
+}
+// dilation of the coarse grid by one coarse cell in every direction (OR over the 3x3x3 neighbourhood), stored behind it: a clear bit proves
+// that every cell within one coarse-cell edge (4 fine cells) of ANY position inside that coarse cell is empty -- k1_count skips whole
+// 8-point lattice segments with one test of their midpoint
+__global__ void __launch_bounds__(256) k_dilate_coarse_bitfield(const uint32_t* __restrict__ coarse, uint32_t* __restrict__ dilated, uint32_t n_cascades) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t per = COARSE_SIZE * COARSE_SIZE * COARSE_SIZE;
+	const uint32_t casc = t / per, c = t % per;
+	bool any = false;
+	if (casc < n_cascades) {
+		const int cx = (int)(c % COARSE_SIZE), cy = (int)((c / COARSE_SIZE) % COARSE_SIZE), cz = (int)(c / (COARSE_SIZE * COARSE_SIZE));
+		const uint32_t* src = coarse + (size_t)casc * COARSE_WORDS;
+		for (int dz = -1; dz <= 1; ++dz)
+			for (int dy = -1; dy <= 1; ++dy)
+				for (int dx = -1; dx <= 1; ++dx) {
+					const int x = cx + dx, y = cy + dy, z = cz + dz;
+					if (x < 0 || y < 0 || z < 0 || x >= (int)COARSE_SIZE || y >= (int)COARSE_SIZE || z >= (int)COARSE_SIZE) continue;
+					const uint32_t n = (uint32_t)x + COARSE_SIZE * ((uint32_t)y + COARSE_SIZE * (uint32_t)z);
+					any |= ((src[n >> 5] >> (n & 31u)) & 1u) != 0u;
+				}
+	}
+	const uint64_t m = __ballot(any);
+	if (casc < n_cascades && (threadIdx.x & 31u) == 0) dilated[t >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1332,14 +1379,17 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
-	if (a.max_mip == 0) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	if (a.max_mip == 0) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? 2 * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? (a.max_mip + 1) * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {
 	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;
 	hipLaunchKernelGGL(k_build_linear_bitfield, dim3(blocks(n_bytes, 256)), dim3(256), 0, s, bitfield, linear, n_bytes);
-	if (coarse) hipLaunchKernelGGL(k_build_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, linear, coarse, n_cascades);
+	if (coarse) { // [n_cascades x COARSE_WORDS coarse][n_cascades x COARSE_WORDS dilated]
+		hipLaunchKernelGGL(k_build_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, linear, coarse, n_cascades);
+		hipLaunchKernelGGL(k_dilate_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, coarse, coarse + (size_t)COARSE_WORDS * n_cascades, n_cascades);
+	}
 }
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;

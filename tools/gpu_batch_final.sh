@@ -40,6 +40,6 @@ if has ab; then echo "== A/B psnr full scale"; date
   timeout 1500 python bench.py --pretrain 200 --steps 20 --warmup 5 --no-cpu-baseline --eval-views 8 --eval-res 800 --eval-spp 8 --ab-psnr 1000,5000,20000 --profile-steps 4 > gpurun_out/${TAG}_bench_ab.json 2> gpurun_out/${TAG}_bench_ab.err; echo "ab rc $?"
   python -c "import json;d=json.load(open('gpurun_out/${TAG}_bench_ab.json'));print(json.dumps(d['config'].get('ab_psnr')))"; fi
 if has ablation; then echo "== ablation table"; date
-  timeout 600 python tools/microbench.py 1000 32 default,k2_tile32,k2_rounds3,grid_no_sort,k1_no_prefilter,w_single_role,separate_grad_memset,t1_dense_external,bin_merge_runs,bin_chunk12_split,k2_eager,t1_no_binning,t1_no_scatter,default_again > gpurun_out/${TAG}_microbench.log 2> gpurun_out/${TAG}_microbench.err; echo "microbench rc $?"
+  timeout 600 python tools/microbench.py 1000 32 default,k2_tile32,k2_rounds3,grid_no_sort,k1_no_prefilter,w_single_role,separate_grad_memset,t1_dense_atomics,t1_dense_external,bin_no_hashed_merge,bin_chunk12_split,k2_eager,t1_no_binning,t1_no_scatter,default_again > gpurun_out/${TAG}_microbench.log 2> gpurun_out/${TAG}_microbench.err; echo "microbench rc $?"
   cut -c1-700 gpurun_out/${TAG}_microbench.log; fi
 date
