@@ -157,6 +157,25 @@ def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
     assert np.array_equal(dev, model), f"device lattice K1 vs its CPU model: {(dev != model).sum()} rays differ"
 
 
+@pytest.mark.parametrize("flags", [2097152, 33554432])
+def test_k1_ablation_variants_are_the_same_marcher(ora, hip, scene, flags):
+    """k1_count without the coarse-occupancy prefilter (flag 2097152) and with the midpoint test of 8-point segments against the dilated coarse
+    grid (flag 33554432): both are exact accelerations, so the per-ray sample counts equal the CPU lattice model's exactly."""
+    n_rays = 4096
+    hip.ngp_debug_set_flags(flags)
+    try:
+        o, d = _run_k1(ora, hip, scene, n_rays, 1 << 20)
+    finally:
+        hip.ngp_debug_set_flags(0)
+    n_d = int(d["counters"].cpu().numpy().astype(np.uint32)[0])
+    ri = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_d]
+    ns = d["numsteps"].cpu().numpy().astype(np.uint32)[:n_d]
+    model = np.zeros(n_rays, np.uint32)
+    ora.ora_k1_lattice_counts(0, n_rays, 0, n_rays, A.scene_aabb(1), _rng(ora), len(scene["imgs"]), scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, C.c_float(0.0), ptr(model), 2048)
+    dev = np.zeros(n_rays, np.uint32); dev[ri] = ns[:, 0]
+    assert n_d > 100 and np.array_equal(dev, model), f"{(dev != model).sum()} rays differ"
+
+
 def test_k1_sample_cap(ora, hip, scene):
     """rays whose span would exceed max_samples are dropped (testbed_nerf.cu:813-815) but still counted"""
     o, d = _run_k1(ora, hip, scene, 4096, 20000)
