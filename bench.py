@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--eval-spp", type=int, default=1)
     ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the PSNR after the timed region (untimed), e.g. 5000,10000,35000")
     ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = --batch samples per GPU per step (default, the driver's mode); strong = --batch samples per step in total (B / N per GPU)")
     ap.add_argument("--dp-backend", choices=["auto", "rccl", "torch"], default="auto", help="N > 1: gradient / counter all-reduce inside libngp_hip (RCCL, ngp_comm_*) or through torch.distributed")
     args = ap.parse_args()
 
@@ -229,6 +230,8 @@ def main():
     assert lib.ngp_device_available() == 1
 
     scene = load_scene(args)
+    if args.scaling == "strong":  # total work fixed: every rank trains B / N samples per step (the library needs a multiple of 256)
+        args.batch = max(256, args.batch // world // 256 * 256)
     cfg, opts, model, nerf = make_trainer(lib, scene, args.batch, rank, world)
     n_params, n_mlp = C.c_uint64(), C.c_uint64()
     lib.ngp_model_n_params(model, C.byref(n_params), C.byref(n_mlp))
@@ -382,9 +385,9 @@ def main():
         out = {
             "metric": ("training rays/sec on nerf_synthetic/lego-format scene" if lego else "training rays/sec on data/nerf/fox") + ", configs/nerf/base.json, B=2^18 samples/step",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16", "data": "synthetic" if lego else "reference-shipped capture (data/nerf/fox)",
-            "config": {"workload": scene["name"] + ", configs/nerf/base.json (hash L=8 F=4 T=2^19, MLP 64), batch 2^18 samples per GPU per step, rays/step adaptive (cap 2^18)",
+            "config": {"workload": scene["name"] + ", configs/nerf/base.json (hash L=8 F=4 T=2^19, MLP 64), batch " + (f"2^{int(math.log2(args.batch))}" if args.batch & (args.batch - 1) == 0 else str(args.batch)) + " samples per GPU per step, rays/step adaptive (cap 2^18)",
                        "parallelism": f"dp{world}", **({"dp_backend": dp_backend} if dp_backend else {}),
                        "pretrain_steps": args.pretrain, "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
                        "samples_per_ray_compacted": samples / max(rays, 1),

@@ -108,8 +108,8 @@ DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners&
 			idx = (a0 * 1u) ^ (a1 * 2654435761u) ^ (a2 * 805459861u);
 			idx = idx & (lc.hs - 1u); // a hashed level always has hs = 2^log2_hashmap_size, so & == %
 		} else {
-			idx = a0 + a1 * lc.res + a2 * lc.res * lc.res; // < 2*hs: one conditional subtract == % hs
-			idx = idx >= lc.hs ? idx - lc.hs : idx;
+			idx = a0 + a1 * lc.res + a2 * lc.res * lc.res; // positions in [0, 1]: < 2*hs, one conditional subtract == % hs
+			if (idx >= lc.hs) { idx -= lc.hs; if (idx >= lc.hs) idx %= lc.hs; } // anything else (out-of-range / NaN input) wraps like tcnn's `% hashmap_size`: never out of bounds
 		}
 		out.idx[c] = idx; out.w[c] = w;
 	}

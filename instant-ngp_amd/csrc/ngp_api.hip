@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "ngp_device.hpp"
@@ -964,12 +965,15 @@ extern "C" int ngp_model_deserialize_host(ngp_model* m, const void* buf, uint64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// stand-alone NeRF kernels
+// stand-alone NeRF kernels (test hooks).  The three hooks that need scratch memory keep it in function-static buffers on the current
+// device: they are serialised by one mutex and must be used from one device / one stream at a time (the trainer handles own theirs).
 // ------------------------------------------------------------------------------------------------
+static std::mutex g_hook_mutex;
 extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, uint32_t rank, uint32_t world_size, const uint32_t* n_rays_ptr, ngp_aabb aabb,
 		uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng, uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out,
 		ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_xform* xforms,
 		const uint8_t* bitfield, uint32_t max_mip, int snap_to_pixel_centers, float cone_angle_constant) {
+	std::lock_guard<std::mutex> hook_lock(g_hook_mutex);
 	REQUIRE(world_size >= 1 && rank < world_size, "generate_training_samples: bad rank/world_size");
 	K1Args a;
 	a.k2_tiles0_out = nullptr; a.k2_tile_w = 32; a.ray_targets_out = nullptr; a.background_color[0] = a.background_color[1] = a.background_color[2] = 0.f; a.color_space_srgb = a.random_bg_color = a.linear_colors = 0;
@@ -1022,7 +1026,8 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 	a.rays_in = rays_in; a.numsteps_inout = numsteps_inout; a.coords_in = coords_in; a.coords_out = coords_out; a.dloss_doutput = dloss_doutput; a.dloss_stride = dloss_stride;
 	a.loss_type = loss_type; a.loss_output = loss_output; a.rgb_activation = rgb_activation; a.density_activation = density_activation;
 	a.snap_to_pixel_centers = snap_to_pixel_centers; a.mean_density_ptr = mean_density_ptr; a.near_distance = near_distance;
-	{ // scratch of the two-pass kernel (production path); static like the other stand-alone hooks' scratch
+	std::lock_guard<std::mutex> hook_lock(g_hook_mutex);
+	{ // scratch of the two-pass kernel (ablation DBG_K3_TWO_PASS); static like the other stand-alone hooks' scratch
 		static char* s_k3 = nullptr; static size_t s_k3_bytes = 0;
 		const size_t need = k3_scratch_bytes(n_rays);
 		if (need > s_k3_bytes) {
@@ -1067,6 +1072,7 @@ extern "C" int ngp_k_ema_grid_samples(void* stream, uint32_t n, float decay, flo
 }
 static float* g_mean_partial = nullptr;
 extern "C" int ngp_k_update_mean_and_bitfield(void* stream, const float* grid, uint32_t max_cascade, uint8_t* bitfield, float* mean_out) {
+	std::lock_guard<std::mutex> hook_lock(g_hook_mutex);
 	if (!g_mean_partial && dev_alloc(&g_mean_partial, 256)) return 1;
 	launch_grid_mean((hipStream_t)stream, grid, g_mean_partial, mean_out);
 	launch_grid_to_bitfield((hipStream_t)stream, grid, max_cascade, bitfield, mean_out);
