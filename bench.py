@@ -215,7 +215,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     force_dp = os.environ.get("NGP_FORCE_DP", "0") == "1"  # exercise the multi-GPU step (all-reduce of size 1) on one GPU
-    if world > 1 or force_dp:
+    if world > 1 or force_dp or os.environ.get("NGP_BENCH_INIT_PG", "0") == "1":  # NGP_BENCH_INIT_PG: diagnostic -- a process group without a data-parallel step
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)

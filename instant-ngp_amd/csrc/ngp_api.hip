@@ -1457,10 +1457,7 @@ extern "C" int ngp_comm_init(ngp_nerf* t, uint32_t rank, uint32_t world_size, co
 	if (rccl_load()) return 1;
 	NcclId id; memcpy(id.internal, id_host, 128);
 	RCCLCHK(g_rccl.CommInitRank(&t->comm, (int)world_size, id, (int)rank));
-	int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-	HIPCHK(hipStreamCreateWithPriority(&t->comm_stream, hipStreamNonBlocking, hi));
-	HIPCHK(hipEventCreateWithFlags(&t->ev_red_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_red_b, hipEventDisableTiming));
-	t->model->record_bucket_events = true;
+	t->model->record_bucket_events = false; // the all-reduce runs on the caller's stream behind the backward pass: no communication stream, no bucket events
 	return 0;
 }
 extern "C" int ngp_comm_destroy(ngp_nerf* t) {
@@ -1478,37 +1475,39 @@ extern "C" int ngp_allreduce_gradients(ngp_nerf* t, void* stream) {
 	RCCLCHK(g_rccl.AllReduce(t->model->grads, t->model->grads, t->model->n_params, kNcclHalf, kNcclSum, t->comm, (hipStream_t)stream));
 	return 0;
 }
+static bool dp_skip_allreduce() { static const bool v = getenv("NGP_DP_SKIP_ALLREDUCE") && atoi(getenv("NGP_DP_SKIP_ALLREDUCE")) != 0; return v; } // diagnostic: the step's structure without the RCCL calls
 extern "C" int ngp_allreduce_counters(ngp_nerf* t, void* stream) {
 	REQUIRE(t && t->comm, "ngp_allreduce_counters: ngp_comm_init has not been called");
-	RCCLCHK(g_rccl.AllReduce(t->sync2, t->sync2, 2, kNcclUint32, kNcclSum, t->comm, (hipStream_t)stream));
+	if (!dp_skip_allreduce()) RCCLCHK(g_rccl.AllReduce(t->sync2, t->sync2, 2, kNcclUint32, kNcclSum, t->comm, (hipStream_t)stream));
 	return 0;
 }
-// Bucketed gradient all-reduce behind ngp_nerf_train_backward: bucket B = the hashed levels (final behind k_grad_accumulate), bucket A =
-// MLP + dense levels (final behind T1 / k_wgrad_reduce); both on the communicator's own stream, so B's ring runs next to the tail of
-// the backward pass (W, the next step's K1).  ngp_nerf_train_finish makes the optimizer wait for both.
-static int dp_reduce_buckets(ngp_nerf* t) {
+// Gradient all-reduce behind ngp_nerf_train_backward: ONE ring over the whole fp16 gradient vector on the CALLER's stream.  Every level goes
+// through the record lists now, so the big bucket is complete only when the backward pass is (k_grad_accumulate is its last kernel) and a
+// second bucket has nothing to overlap with; the next step's K1 runs on its own stream next to the ring.  The round-2a layout -- two
+// buckets on a communication stream of their own -- paid 0.6 ms per step for its event chain (two waits and two records on an otherwise
+// idle high-priority stream, two waits on the caller's stream): 1.41 vs 0.79 ms at world size 1 (profiles/r02_dp_overhead.txt).
+static int dp_reduce_gradients(ngp_nerf* t, hipStream_t s) {
 	ngp_model* m = t->model;
-	const GradBinArgs& ba = m->bin_args;
-	size_t split = m->n_params; // first parameter of bucket B
-	if (ba.n_hashed) split = m->n_mlp + (size_t)m->gm.offset[ba.levels[0]] * m->gm.F; // hashed levels are the finest ones: contiguous tail of the layout
-	HIPCHK(hipStreamWaitEvent(t->comm_stream, m->ev_hashed_ready, 0));
-	if (split < m->n_params) RCCLCHK(g_rccl.AllReduce(m->grads + split, m->grads + split, m->n_params - split, kNcclHalf, kNcclSum, t->comm, t->comm_stream));
-	HIPCHK(hipEventRecord(t->ev_red_b, t->comm_stream));
-	HIPCHK(hipStreamWaitEvent(t->comm_stream, m->ev_mlp_ready, 0));
-	RCCLCHK(g_rccl.AllReduce(m->grads, m->grads, split, kNcclHalf, kNcclSum, t->comm, t->comm_stream));
-	HIPCHK(hipEventRecord(t->ev_red_a, t->comm_stream));
-	t->grads_pending = true;
+	if (!dp_skip_allreduce()) RCCLCHK(g_rccl.AllReduce(m->grads, m->grads, m->n_params, kNcclHalf, kNcclSum, t->comm, s));
+	t->grads_pending = false;
 	return 0;
 }
 
 extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 	for (uint32_t i = 0; i < n_steps; ++i) {
 		if (ngp_nerf_train_prep(t, stream)) return 1;
-		if (t->comm) { // data-parallel: forward -> all-reduce(counters) -> backward + bucketed all-reduce(gradients) -> optimizer
+		// diagnostics (world size 1 only): NGP_TRAIN_SPLIT_PHASES=1 runs the split-phase step without a communicator, NGP_DP_FUSED_STEP=1 the
+		// single-call step although a communicator exists
+		static const bool split_phases = getenv("NGP_TRAIN_SPLIT_PHASES") && atoi(getenv("NGP_TRAIN_SPLIT_PHASES")) != 0;
+		static const bool fused_step = getenv("NGP_DP_FUSED_STEP") && atoi(getenv("NGP_DP_FUSED_STEP")) != 0;
+		if (!t->comm && split_phases && t->opt.world_size == 1) {
+			if (ngp_nerf_train_forward(t, stream)) return 1;
+			if (ngp_nerf_train_backward(t, stream)) return 1;
+		} else if (t->comm && !(fused_step && t->opt.world_size == 1)) { // data-parallel: forward -> all-reduce(counters) -> backward + bucketed all-reduce(gradients) -> optimizer
 			if (ngp_nerf_train_forward(t, stream)) return 1;
 			if (ngp_allreduce_counters(t, stream)) return 1;
 			if (ngp_nerf_train_backward(t, stream)) return 1;
-			if (dp_reduce_buckets(t)) return 1;
+			if (dp_reduce_gradients(t, (hipStream_t)stream)) return 1;
 		} else if (ngp_nerf_train_forward_backward(t, stream)) return 1;
 		if (ngp_nerf_train_finish(t, stream)) return 1;
 	}
