@@ -373,8 +373,8 @@ int ngp_nerf_train_backward(ngp_nerf*, void* stream);
  * RCCL over xGMI (librccl is resolved at run time).  Rank 0 calls ngp_comm_unique_id (ncclGetUniqueId) and hands the 128 bytes to
  * every rank by any side channel; every rank calls ngp_comm_init with the rank / world_size its trainer was created with.  From
  * then on ngp_nerf_train runs  forward -> all-reduce(sum) of the two counters -> backward -> all-reduce(sum) of the fp16
- * gradients in two buckets (hashed levels | MLP + dense levels) on the communicator's own stream -> optimizer.
- * ngp_allreduce_gradients / ngp_allreduce_counters are the un-bucketed collectives for callers that sequence the step themselves. */
+ * gradient vector on the caller's stream (the next step's ray marching runs beside it on its own stream) -> optimizer.
+ * ngp_allreduce_gradients / ngp_allreduce_counters are the same collectives for callers that sequence the step themselves. */
 int ngp_comm_unique_id(uint8_t id_out_host[128]);
 int ngp_comm_init(ngp_nerf*, uint32_t rank, uint32_t world_size, const uint8_t id_host[128]);
 int ngp_comm_destroy(ngp_nerf*);
