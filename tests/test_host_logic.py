@@ -86,3 +86,25 @@ def test_synthetic_scene_conventions():
     assert a.shape == (32, 32, 4) and a.dtype == np.uint8
     cov = (a[..., 3] > 0).mean()
     assert 0.1 < cov < 0.6 and (a[a[..., 3] == 0][:, :3] == 0).all()  # object in the middle, transparent background
+
+
+@pytest.mark.parametrize("chunk_log2", [11, 12])
+def test_dense_level_list_interleaving_is_a_bijection(chunk_log2):
+    """Index arithmetic of the scatter lists for DENSE levels (csrc/model_kernels.hip k_grad_bin / k_grad_accumulate): entry e of a level
+    with hs <= 2^19 entries goes to list e mod NCH at local slot e div NCH (NCH = 2^(19 - chunk_log2) lists per level); the accumulate block
+    of list c writes back the entries c, c + NCH, ... < hs.  Every entry must land in exactly one (list, slot) with slot < 2^chunk_log2, and
+    the write-back count per list must be the number of entries the list owns."""
+    nch_log2 = 19 - chunk_log2
+    nch = 1 << nch_log2
+    for res in (16, 17, 33, 65, 80):  # tcnn grid resolutions of base.json's dense levels (+ one that nearly fills 2^19)
+        hs = (res ** 3 + 7) // 8 * 8  # params_in_level: rounded up to a multiple of 8
+        assert hs <= 1 << 19
+        e = np.arange(hs, dtype=np.uint32)
+        c, local = e & (nch - 1), e >> nch_log2
+        assert int(local.max()) < (1 << chunk_log2)
+        assert len(set(zip(c.tolist(), local.tolist()))) == hs  # bijection onto (list, slot)
+        back = (local.astype(np.uint64) << nch_log2) | c        # the accumulate kernel's entry index
+        assert np.array_equal(back, e)
+        owned = np.bincount(c, minlength=nch)
+        n_local = np.array([((hs - k + nch - 1) >> nch_log2) if hs > k else 0 for k in range(nch)])
+        assert np.array_equal(owned, n_local)
