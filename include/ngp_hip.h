@@ -436,6 +436,10 @@ int ngp_nerf_set_rng(ngp_nerf*, const ngp_pcg32* rng);
 /* lazy (front-to-back) K2: rounds = 1 (default): one launch, every wavefront follows its ray tile by tile; rounds = 2..8: list-driven rounds;
    samples per tile 16 (default: two rays per wavefront) or 32 (csrc/model_kernels.hip k_inference_tiles) */
 int ngp_nerf_set_k2_params(ngp_nerf*, uint32_t rounds, uint32_t tile_w);
+/* host-side evaluation of the device's camera model (the same source, csrc/ngp_device.hpp uv_to_ray / pos_to_uv, compiled for the host):
+   all seven lens modes of common_device.cuh:413-577.  Test hooks: no GPU needed.  uv_to_ray returns 0 where the lens has no ray. */
+int ngp_host_uv_to_ray(const ngp_image_meta* meta, const float xform12[12], const float uv[2], float origin_out[3], float dir_out[3]);
+int ngp_host_pos_to_uv(const ngp_image_meta* meta, const float xform12[12], const float pos[3], float uv_out[2]);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);
 /* train mode of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options) */

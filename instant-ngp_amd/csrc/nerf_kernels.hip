@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 		if (valid) {
 			(void)rng.next_float(); // motionblur_time
 			const M43 xform = ldm43(a.xforms[img].start);
-			uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+			if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform.c[3]; rd = xform.c[2]; } // testbed_nerf.cu:776-778
 			rdn = normalize3(rd);
 			f2 tminmax = aabb.ray_intersect(ro, rdn);
 			tminmax.x = fmaxf(tminmax.x, 0.0f);
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 		(void)rng.next_float(); // motionblur_time
 		const M43 xform = ldm43(a.xforms[img].start);
 		f3 ro, rd;
-		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform.c[3]; rd = xform.c[2]; } // testbed_nerf.cu:776-778
 		const f3 rdn = normalize3(rd);
 		f2 tminmax = aabb.ray_intersect(ro, rdn);
 		tminmax.x = fmaxf(tminmax.x, 0.0f);
@@ -1230,6 +1230,8 @@ __global__ void k_mark_untrained(uint32_t n_elements, float* __restrict__ grid, 
 	for (uint32_t j = 0; j < n_images && count < 1; ++j) {
 		const M43 xf = ldm43(xforms[j].start);
 		const ngp_image_meta& m = metadata[j];
+		// f-theta lenses have no forward mapping and are assumed to see everything; lat-long / equirectangular ones do (testbed_nerf.cu:131-136)
+		if (m.lens_mode == NGP_LENS_FTHETA || lens_is_360(m.lens_mode)) { ++count; continue; }
 		for (uint32_t k = 0; k < 8; ++k) {
 			const f3 corner = pos + mk3((k & 1) ? voxel_size : 0.f, (k & 2) ? voxel_size : 0.f, (k & 4) ? voxel_size : 0.f);
 			const f3 dir = normalize3(corner - xf.c[3]);

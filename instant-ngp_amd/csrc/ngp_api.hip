@@ -68,6 +68,18 @@ extern "C" int ngp_profile_enable(int on) {
 	if (on) { for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; } }
 	return 0;
 }
+// host-side evaluation of the camera model of csrc/ngp_device.hpp (test hooks; the functions are __host__ __device__)
+extern "C" int ngp_host_uv_to_ray(const ngp_image_meta* m, const float xform12[12], const float uv[2], float o_out[3], float d_out[3]) {
+	f3 o, d; const f2 u = {uv[0], uv[1]};
+	const bool ok = uv_to_ray(u, m->resolution, m->focal_length, ldm43(xform12), m->principal_point, m->lens_mode, m->lens_params, 0.0f, o, d);
+	o_out[0] = o.x; o_out[1] = o.y; o_out[2] = o.z; d_out[0] = d.x; d_out[1] = d.y; d_out[2] = d.z;
+	return ok ? 1 : 0;
+}
+extern "C" int ngp_host_pos_to_uv(const ngp_image_meta* m, const float xform12[12], const float pos[3], float uv_out[2]) {
+	const f2 uv = pos_to_uv(mk3(pos[0], pos[1], pos[2]), m->resolution, m->focal_length, ldm43(xform12), m->principal_point, m->lens_mode, m->lens_params);
+	uv_out[0] = uv.x; uv_out[1] = uv.y;
+	return 0;
+}
 // NGP_DEBUG_FLAGS_OR (environment, ablation runs of unmodified callers): bits that stay set whatever ngp_debug_set_flags is given
 static uint32_t env_debug_or() { static const uint32_t v = getenv("NGP_DEBUG_FLAGS_OR") ? (uint32_t)strtoul(getenv("NGP_DEBUG_FLAGS_OR"), nullptr, 0) : 0u; return v; }
 static const bool g_debug_env_applied = [] { g_debug_flags |= env_debug_or(); return true; }();
@@ -1206,7 +1218,7 @@ extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_imag
 	t->owned_pixels.clear();
 	std::vector<ngp_image_meta> m(meta, meta + n);
 	for (uint32_t i = 0; i < n; ++i) {
-		REQUIRE(m[i].lens_mode == NGP_LENS_PERSPECTIVE || m[i].lens_mode == NGP_LENS_OPENCV, "only Perspective / OpenCV lenses are implemented");
+		REQUIRE(m[i].lens_mode >= NGP_LENS_PERSPECTIVE && m[i].lens_mode <= NGP_LENS_ORTHOGRAPHIC, "set_dataset: unknown lens mode");
 		const size_t bytes = (size_t)m[i].resolution[0] * m[i].resolution[1] * pixel_bytes(m[i].image_data_type);
 		void* d = nullptr;
 		HIPCHK(hipMalloc(&d, bytes));
@@ -1221,7 +1233,7 @@ extern "C" int ngp_nerf_set_dataset_device(ngp_nerf* t, uint32_t n, const ngp_im
 	REQUIRE(n > 0 && meta && xforms, "set_dataset: null/empty");
 	std::vector<ngp_image_meta> m(meta, meta + n);
 	for (uint32_t i = 0; i < n; ++i)
-		REQUIRE(m[i].lens_mode == NGP_LENS_PERSPECTIVE || m[i].lens_mode == NGP_LENS_OPENCV, "only Perspective / OpenCV lenses are implemented");
+		REQUIRE(m[i].lens_mode >= NGP_LENS_PERSPECTIVE && m[i].lens_mode <= NGP_LENS_ORTHOGRAPHIC, "set_dataset: unknown lens mode");
 	return set_dataset_common(t, n, m, xforms);
 }
 
@@ -1569,7 +1581,7 @@ extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng
 // Testbed::render_nerf (testbed_nerf.cu:1894-2149): one spp of a frame into premultiplied linear RGBA + depth
 extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_params* rp, float* frame, float* depth) {
 	REQUIRE(t && rp && frame, "render: null argument");
-	REQUIRE(rp->lens_mode == NGP_LENS_PERSPECTIVE || rp->lens_mode == NGP_LENS_OPENCV, "render: only Perspective / OpenCV lenses are implemented");
+	REQUIRE(rp->lens_mode >= NGP_LENS_PERSPECTIVE && rp->lens_mode <= NGP_LENS_ORTHOGRAPHIC, "render: unknown lens mode");
 	hipStream_t s = (hipStream_t)stream;
 	constexpr uint32_t TILE = 1u << 18;
 	if (!t->r_rays) {

@@ -357,16 +357,99 @@ NGP_HD void opencv_undistort(const float* params, float* u, float* v) {
 	}
 	*u = x0; *v = x1;
 }
-// uv_to_ray restricted to Perspective / OpenCV lenses (the lenses of the BASELINE datasets).
-NGP_HD void uv_to_ray(f2 uv, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode,
+// ---- the other lens models of common_device.cuh:283-411 (own restatement; the Perspective / OpenCV arithmetic above is untouched) ----
+NGP_HD void opencv_fisheye_distortion_delta(const float* p, float u, float v, float* du, float* dv) {
+	const float r = sqrtf(u * u + v * v);
+	*du = 0.f; *dv = 0.f;
+	if (r > 2.220446049250313e-16f) { // (T)std::numeric_limits<double>::epsilon() in the reference
+		const float theta = atanf(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+		const float thetad = theta * (1.f + p[0] * t2 + p[1] * t4 + p[2] * t6 + p[3] * t8);
+		*du = u * thetad / r - u;
+		*dv = v * thetad / r - v;
+	}
+}
+// Newton iteration with central differences, the reference's iterative_lens_undistortion for the fisheye distortion function
+NGP_HD void opencv_fisheye_undistort(const float* params, float* u, float* v) {
+	const float eps = 1.1920929e-07f;
+	const float x00 = *u, x01 = *v;
+	float x0 = *u, x1 = *v;
+	for (uint32_t i = 0; i < 100; ++i) {
+		const float step0 = fmaxf(eps, fabsf(1e-6f * x0)), step1 = fmaxf(eps, fabsf(1e-6f * x1));
+		float dx0, dx1, b0x, b0y, f0x, f0y, b1x, b1y, f1x, f1y;
+		opencv_fisheye_distortion_delta(params, x0, x1, &dx0, &dx1);
+		opencv_fisheye_distortion_delta(params, x0 - step0, x1, &b0x, &b0y);
+		opencv_fisheye_distortion_delta(params, x0 + step0, x1, &f0x, &f0y);
+		opencv_fisheye_distortion_delta(params, x0, x1 - step1, &b1x, &b1y);
+		opencv_fisheye_distortion_delta(params, x0, x1 + step1, &f1x, &f1y);
+		float J00 = 1 + (f0x - b0x) / (2 * step0), J10 = (f1x - b1x) / (2 * step1);
+		float J01 = (f0y - b0y) / (2 * step0), J11 = 1 + (f1y - b1y) / (2 * step1);
+		float r0 = x0 + dx0 - x00, r1 = x1 + dx1 - x01;
+		float det = J00 * J11 - J10 * J01;
+		float s0 = (J11 * r0 - J10 * r1) / det, s1 = (-J01 * r0 + J00 * r1) / det;
+		x0 -= s0; x1 -= s1;
+		if (s0 * s0 + s1 * s1 < 1e-10f) break;
+	}
+	*u = x0; *v = x1;
+}
+// f-theta: params = polynomial r0..r4 in the pixel radius, then the resolution the intrinsics refer to; (0,0,0) = no ray
+NGP_HD f3 f_theta_direction(float u, float v, const float* params) {
+	const float xpix = u * params[5], ypix = v * params[6];
+	const float norm = sqrtf(xpix * xpix + ypix * ypix);
+	const float alpha = params[0] + norm * (params[1] + norm * (params[2] + norm * (params[3] + norm * params[4])));
+	float sa = sinf(alpha), ca = cosf(alpha);
+	if (ca <= 1.17549435e-38f || norm == 0.f) return mk3(0.f);
+	sa *= 1.f / norm;
+	return mk3(sa * xpix, sa * ypix, ca);
+}
+constexpr float NGP_PI = 3.14159265358979323846f;
+NGP_HD f3 latlong_to_dir(f2 uv) {
+	const float theta = (uv.y - 0.5f) * NGP_PI, phi = (uv.x - 0.5f) * NGP_PI * 2.0f;
+	const float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+	return mk3(sp * ct, st, cp * ct);
+}
+NGP_HD f3 equirectangular_to_dir(f2 uv) {
+	const float ct = (uv.y - 0.5f) * 2.0f, st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f)), phi = (uv.x - 0.5f) * NGP_PI * 2.0f;
+	return mk3(sinf(phi) * st, ct, cosf(phi) * st);
+}
+NGP_HD f2 dir_to_latlong(f3 dir) { return {atan2f(dir.x, dir.z) / (NGP_PI * 2.0f) + 0.5f, asinf(dir.y) / NGP_PI + 0.5f}; }
+NGP_HD f2 dir_to_equirectangular(f3 dir) { return {atan2f(dir.x, dir.z) / (NGP_PI * 2.0f) + 0.5f, dir.y / 2.0f + 0.5f}; }
+NGP_HD bool lens_is_360(int lens_mode) { return lens_mode == NGP_LENS_LATLONG || lens_mode == NGP_LENS_EQUIRECTANGULAR; }
+
+// uv_to_ray, common_device.cuh:413-490 without foveation / hidden-area mask / distortion map / aperture, parallax_shift = 0.
+// Returns false where the lens has no ray for this uv (f-theta outside its field of view): the caller drops the ray / pixel.
+NGP_HD bool uv_to_ray(f2 uv, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode,
 		const float* lens_params, float near_distance, f3& o, f3& d) {
-	f3 dir = mk3((uv.x - center[0]) * (float)res[0] / focal[0], (uv.y - center[1]) * (float)res[1] / focal[1], 1.0f);
-	if (lens_mode == NGP_LENS_OPENCV) opencv_undistort(lens_params, &dir.x, &dir.y);
+	f3 dir, head = mk3(0.f);
+	if (lens_mode == NGP_LENS_PERSPECTIVE || lens_mode == NGP_LENS_OPENCV) { // the lenses of the BASELINE datasets: arithmetic unchanged since round 1
+		dir = mk3((uv.x - center[0]) * (float)res[0] / focal[0], (uv.y - center[1]) * (float)res[1] / focal[1], 1.0f);
+		if (lens_mode == NGP_LENS_OPENCV) opencv_undistort(lens_params, &dir.x, &dir.y);
+		dir = mul3(cam, dir);
+		f3 origin = cam.c[3];
+		origin = origin + dir * near_distance;
+		o = origin; d = dir;
+		return true;
+	}
+	if (lens_mode == NGP_LENS_FTHETA) {
+		dir = f_theta_direction(uv.x - center[0], uv.y - center[1], lens_params);
+		if (dir.x == 0.f && dir.y == 0.f && dir.z == 0.f) { o = cam.c[3]; d = dir; return false; }
+	} else if (lens_mode == NGP_LENS_LATLONG) {
+		dir = latlong_to_dir(uv);
+	} else if (lens_mode == NGP_LENS_EQUIRECTANGULAR) {
+		dir = equirectangular_to_dir(uv);
+	} else if (lens_mode == NGP_LENS_ORTHOGRAPHIC) {
+		dir = mk3(0.f, 0.f, 1.f);
+		head = mk3((uv.x - center[0]) * (float)res[0] / focal[0], (uv.y - center[1]) * (float)res[1] / focal[1], 0.0f);
+	} else { // NGP_LENS_OPENCV_FISHEYE
+		dir = mk3((uv.x - center[0]) * (float)res[0] / focal[0], (uv.y - center[1]) * (float)res[1] / focal[1], 1.0f);
+		opencv_fisheye_undistort(lens_params, &dir.x, &dir.y);
+	}
 	dir = mul3(cam, dir);
-	f3 origin = cam.c[3];
+	f3 origin = mul3(cam, head) + cam.c[3];
 	origin = origin + dir * near_distance;
 	o = origin; d = dir;
+	return true;
 }
+// pos_to_uv, common_device.cuh:527-577 (f-theta has no forward mapping: treated like Perspective, as the reference's release build does)
 NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode, const float* lens_params) {
 	f3 dir = pos - cam.c[3];
 	const f3 a = cam.c[0], b = cam.c[1], c = cam.c[2];
@@ -376,9 +459,15 @@ NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M4
 	f3 r1 = mk3(-(a.y * c.z - c.y * a.z) * id, (a.x * c.z - c.x * a.z) * id, -(a.x * c.y - c.x * a.y) * id);
 	f3 r2 = mk3((a.y * b.z - b.y * a.z) * id, -(a.x * b.z - b.x * a.z) * id, (a.x * b.y - b.x * a.y) * id);
 	dir = mk3(dot3(r0, dir), dot3(r1, dir), dot3(r2, dir));
+	if (lens_mode == NGP_LENS_ORTHOGRAPHIC) return {dir.x * focal[0] / (float)res[0] + center[0], dir.y * focal[1] / (float)res[1] + center[1]};
+	if (lens_is_360(lens_mode)) {
+		dir = dir / sqrtf(dot3(dir, dir));
+		return lens_mode == NGP_LENS_EQUIRECTANGULAR ? dir_to_equirectangular(dir) : dir_to_latlong(dir);
+	}
 	dir = dir / dir.z;
 	float du = 0.f, dv = 0.f;
 	if (lens_mode == NGP_LENS_OPENCV) opencv_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
+	else if (lens_mode == NGP_LENS_OPENCV_FISHEYE) opencv_fisheye_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
 	dir.x += du; dir.y += dv;
 	return {dir.x * focal[0] / (float)res[0] + center[0], dir.y * focal[1] / (float)res[1] + center[1]};
 }

@@ -30,11 +30,12 @@ __global__ void __launch_bounds__(128) k_render_setup(RenderArgs a, uint32_t pix
 	const f2 uv = {((float)x + off.x) / (float)a.p.resolution[0], ((float)y + off.y) / (float)a.p.resolution[1]};
 	const M43 cam = ldm43(a.p.camera);
 	f3 ro, rd;
-	uv_to_ray(uv, a.p.resolution, a.p.focal_length, cam, a.p.screen_center, a.p.lens_mode, a.p.lens_params, a.p.near_distance, ro, rd);
+	const bool has_ray = uv_to_ray(uv, a.p.resolution, a.p.focal_length, cam, a.p.screen_center, a.p.lens_mode, a.p.lens_params, a.p.near_distance, ro, rd);
+	if (!has_ray) rd = cam.c[2]; // outside the lens' field of view (f-theta): the pixel stays empty (init_rays_with_payload: payload.alive = false)
 	rd = normalize3(rd);
 	const Box box(a.p.render_aabb);
 	float t = fmaxf(box.ray_intersect(ro, rd).x, 0.0f) + 1e-6f;
-	const bool alive = box.contains(ro + rd * t);
+	const bool alive = has_ray && box.contains(ro + rd * t);
 	t = advance_n_steps(t, a.cone_angle, ld_random_val(a.p.spp_index, idx * 786433u));
 	RenderRay r;
 	r.o[0] = ro.x; r.o[1] = ro.y; r.o[2] = ro.z; r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;

@@ -279,7 +279,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 	if (jsons.empty()) throw std::runtime_error{"No json files found in '" + path_in + "'."};
 
 	NerfDataset d;
-	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; };
+	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; float angle_x = 0.f, angle_y = 0.f; bool principal_in_pixels = false; };
 	std::vector<Frame> frames;
 	for (const fs::path& jp : jsons) {
 		mini_json::Value j; std::string err;
@@ -336,15 +336,23 @@ void Testbed::load_training_data(const std::string& path_in) {
 			float c3[3][4];
 			for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; }
 			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) F.xform[c * 3 + r] = c3[r][c];
-			if (has("k1") || has("k2") || has("p1") || has("p2")) {
-				F.meta.lens_mode = NGP_LENS_OPENCV;
-				F.meta.lens_params[0] = (float)get("k1", 0); F.meta.lens_params[1] = (float)get("k2", 0);
-				F.meta.lens_params[2] = (float)get("p1", 0); F.meta.lens_params[3] = (float)get("p2", 0);
+			{ // read_lens, nerf_loader.cu:175-241: OpenCV / OpenCV-fisheye coefficients select their mode only when one of them is non-zero
+				const int opencv_mode = (has("is_fisheye") && get("is_fisheye", 0) != 0) ? NGP_LENS_OPENCV_FISHEYE : NGP_LENS_OPENCV;
+				auto coeff = [&](const char* name, int idx) { if (has(name)) { F.meta.lens_params[idx] = (float)get(name, 0); if (F.meta.lens_params[idx] != 0.f) F.meta.lens_mode = opencv_mode; } };
+				coeff("k1", 0); coeff("k2", 1); coeff("k3", 2); coeff("k4", 3); coeff("p1", 2); coeff("p2", 3);
+				if (has("ftheta_p0")) { // polynomial in the pixel radius + the resolution the intrinsics refer to (stored behind the coefficients)
+					for (int k = 0; k < 5; ++k) F.meta.lens_params[k] = (float)get((std::string("ftheta_p") + char('0' + k)).c_str(), 0);
+					F.meta.lens_params[5] = (float)get("w", 0); F.meta.lens_params[6] = (float)get("h", 0);
+					F.meta.lens_mode = NGP_LENS_FTHETA;
+				}
+				if (has("latlong")) F.meta.lens_mode = NGP_LENS_LATLONG;
+				else if (has("equirectangular")) F.meta.lens_mode = NGP_LENS_EQUIRECTANGULAR;
+				else if (has("orthographic")) F.meta.lens_mode = NGP_LENS_ORTHOGRAPHIC;
 			}
 			// stash intrinsics needing the resolution
-			F.meta.lens_params[5] = (float)(has("camera_angle_x") ? get("camera_angle_x", 0) : 0);
-			F.meta.lens_params[6] = (float)(has("camera_angle_y") ? get("camera_angle_y", 0) : 0);
-			if (has("cx")) { F.meta.principal_point = {(float)get("cx", 0), (float)get("cy", 0)}; F.meta.lens_params[4] = 1.f; }
+			F.angle_x = (float)(has("camera_angle_x") ? get("camera_angle_x", 0) : 0);
+			F.angle_y = (float)(has("camera_angle_y") ? get("camera_angle_y", 0) : 0);
+			if (has("cx")) { F.meta.principal_point = {(float)get("cx", 0), (float)get("cy", 0)}; F.principal_in_pixels = true; }
 			frames.push_back(F);
 		}
 	}
@@ -355,7 +363,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (!ok && s_fallback_decoder) ok = s_fallback_decoder(F.image_path, w, h, rgba);
 		if (!ok) throw std::runtime_error{"Could not load image '" + F.image_path + "'"};
 		F.meta.resolution = {w, h};
-		const float ax = F.meta.lens_params[5], ay = F.meta.lens_params[6];
+		const float ax = F.angle_x, ay = F.angle_y;
 		float flx = F.meta.focal_length[0], fly = F.meta.focal_length[1];
 		if (flx <= 0 && ax > 0) flx = 0.5f * (float)w / std::tan(0.5f * ax); // nerf_loader.cu:256-263
 		if (fly <= 0 && ay > 0) fly = 0.5f * (float)h / std::tan(0.5f * ay);
@@ -363,9 +371,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (fly <= 0) fly = flx;
 		if (flx <= 0) throw std::runtime_error{"Couldn't read fov / focal length for '" + F.image_path + "'"};
 		F.meta.focal_length = {flx, fly};
-		if (F.meta.lens_params[4] == 1.f) F.meta.principal_point = {F.meta.principal_point[0] / (float)w, F.meta.principal_point[1] / (float)h};
+		if (F.principal_in_pixels) F.meta.principal_point = {F.meta.principal_point[0] / (float)w, F.meta.principal_point[1] / (float)h};
 		else F.meta.principal_point = {0.5f, 0.5f};
-		F.meta.lens_params[4] = F.meta.lens_params[5] = F.meta.lens_params[6] = 0.f;
 		d.metadata.push_back(F.meta); d.xforms.push_back(F.xform); d.pixels.push_back(std::move(rgba)); d.paths.push_back(F.image_path);
 	}
 	d.n_images = d.metadata.size();
@@ -678,7 +685,13 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 			const ImageMetadata& m = d.metadata[i];
 			Value jm = jobj(); jm.set("focal_length", jvec(m.focal_length.data(), 2));
 			Value lens = jobj();
+			// to_json(Lens), json_binding.h:37-65
 			if (m.lens_mode == NGP_LENS_OPENCV) { lens.set("is_fisheye", jbool(false)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("p1", jnum(m.lens_params[2])); lens.set("p2", jnum(m.lens_params[3])); }
+			else if (m.lens_mode == NGP_LENS_OPENCV_FISHEYE) { lens.set("is_fisheye", jbool(true)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("k3", jnum(m.lens_params[2])); lens.set("k4", jnum(m.lens_params[3])); }
+			else if (m.lens_mode == NGP_LENS_FTHETA) { for (int k = 0; k < 5; ++k) lens.set(std::string("ftheta_p") + char('0' + k), jnum(m.lens_params[k])); lens.set("w", jnum(m.lens_params[5])); lens.set("h", jnum(m.lens_params[6])); }
+			else if (m.lens_mode == NGP_LENS_LATLONG) lens.set("latlong", jbool(true));
+			else if (m.lens_mode == NGP_LENS_EQUIRECTANGULAR) lens.set("equirectangular", jbool(true));
+			else if (m.lens_mode == NGP_LENS_ORTHOGRAPHIC) lens.set("orthographic", jbool(true));
 			jm.set("lens", lens); jm.set("principal_point", jvec(m.principal_point.data(), 2));
 			const float rs[4] = {0.f, 0.f, 0.f, 0.f}; jm.set("rolling_shutter", jvec(rs, 4)); jm.set("resolution", jvec(m.resolution.data(), 2));
 			metas.arr.push_back(jm);
@@ -745,7 +758,15 @@ void Testbed::load_snapshot(const std::string& path) {
 			ImageMetadata m;
 			for (int k = 0; k < 2; ++k) { m.resolution[k] = (int)jm["resolution"].at(k).n; m.focal_length[k] = (float)jm["focal_length"].at(k).n; m.principal_point[k] = (float)jm["principal_point"].at(k).n; }
 			const Value& lens = jm["lens"];
-			if (lens.is_object() && lens.has("k1")) { m.lens_mode = NGP_LENS_OPENCV; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("p1", 0); m.lens_params[3] = (float)lens.num("p2", 0); }
+			if (lens.is_object()) { // from_json(Lens), json_binding.h:67-100
+				if (lens.has("k1")) {
+					if (lens.boolean("is_fisheye", false)) { m.lens_mode = NGP_LENS_OPENCV_FISHEYE; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("k3", 0); m.lens_params[3] = (float)lens.num("k4", 0); }
+					else { m.lens_mode = NGP_LENS_OPENCV; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("p1", 0); m.lens_params[3] = (float)lens.num("p2", 0); }
+				} else if (lens.has("ftheta_p0")) { m.lens_mode = NGP_LENS_FTHETA; for (int k = 0; k < 5; ++k) m.lens_params[k] = (float)lens.num(std::string("ftheta_p") + char('0' + k), 0); m.lens_params[5] = (float)lens.num("w", 0); m.lens_params[6] = (float)lens.num("h", 0); }
+				else if (lens.has("latlong")) m.lens_mode = NGP_LENS_LATLONG;
+				else if (lens.has("equirectangular")) m.lens_mode = NGP_LENS_EQUIRECTANGULAR;
+				else if (lens.has("orthographic")) m.lens_mode = NGP_LENS_ORTHOGRAPHIC;
+			}
 			std::array<float, 12> x{};
 			const Value& xs = jd["xforms"].at(i)["start"];
 			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) x[c * 3 + r] = (float)xs.at(c).at(r).n;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libngp_hip.so")
 u32, i32, f32, u64, u8, u16 = C.c_uint32, C.c_int32, C.c_float, C.c_uint64, C.c_uint8, C.c_uint16
 vp = C.c_void_p
 
-LENS_PERSPECTIVE, LENS_OPENCV = 0, 1
+LENS_PERSPECTIVE, LENS_OPENCV, LENS_FTHETA, LENS_LATLONG, LENS_OPENCV_FISHEYE, LENS_EQUIRECTANGULAR, LENS_ORTHOGRAPHIC = 0, 1, 2, 3, 4, 5, 6
 IMAGE_BYTE, IMAGE_HALF, IMAGE_FLOAT = 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
 LOSS_L2, LOSS_L1, LOSS_MAPE, LOSS_SMAPE, LOSS_HUBER, LOSS_LOGL1, LOSS_RELATIVE_L2 = range(7)

@@ -47,9 +47,14 @@ API void ora_loss_and_gradient(const float* target, const float* pred, int type,
 	LossAndGradient lg = loss_and_gradient(V3(target), V3(pred), type);
 	for (int k = 0; k < 3; ++k) { loss3[k] = lg.loss[k]; grad3[k] = lg.gradient[k]; }
 }
-API void ora_uv_to_ray(const float* uv, const ngp_image_meta* m, const float* xform12, float* o3, float* d3) {
-	vec3 o, d; uv_to_ray({uv[0], uv[1]}, m->resolution, m->focal_length, M43(xform12), m->principal_point, m->lens_mode, m->lens_params, 0.f, o, d);
+API int ora_uv_to_ray(const float* uv, const ngp_image_meta* m, const float* xform12, float* o3, float* d3) {
+	vec3 o, d; const bool ok = uv_to_ray({uv[0], uv[1]}, m->resolution, m->focal_length, M43(xform12), m->principal_point, m->lens_mode, m->lens_params, 0.f, o, d);
 	for (int k = 0; k < 3; ++k) { o3[k] = o[k]; d3[k] = d[k]; }
+	return ok ? 1 : 0;
+}
+API void ora_pos_to_uv(const float* pos3, const ngp_image_meta* m, const float* xform12, float* uv2) {
+	const vec2 uv = pos_to_uv(V3(pos3), m->resolution, m->focal_length, M43(xform12), m->principal_point, m->lens_mode, m->lens_params);
+	uv2[0] = uv.x; uv2[1] = uv.y;
 }
 
 // ---- model -----------------------------------------------------------------------------------

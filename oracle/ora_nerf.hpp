@@ -78,15 +78,86 @@ inline void iterative_opencv_lens_undistortion(const float* params, float* u, fl
 	*u = x[0]; *v = x[1];
 }
 
-// uv_to_ray, common_device.cuh:413-490, restricted to what the NeRF path uses: Perspective and OpenCV
-// lenses, no foveation / hidden-area mask / distortion map / aperture; parallax_shift = 0.
+// opencv_fisheye_lens_distortion_delta, common_device.cuh:283-305
+inline void opencv_fisheye_lens_distortion_delta(const float* p, float u, float v, float* du, float* dv) {
+	const float r = std::sqrt(u * u + v * v);
+	if (r > (float)std::numeric_limits<double>::epsilon()) {
+		const float theta = std::atan(r);
+		const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+		const float thetad = theta * (1.f + p[0] * theta2 + p[1] * theta4 + p[2] * theta6 + p[3] * theta8);
+		*du = u * thetad / r - u;
+		*dv = v * thetad / r - v;
+	} else { *du = 0.f; *dv = 0.f; }
+}
+// iterative_lens_undistortion (common_device.cuh:307-345) for an arbitrary distortion function
+template <typename F> inline void iterative_lens_undistortion(const float* params, float* u, float* v, F distortion_fun) {
+	const float eps = std::numeric_limits<float>::epsilon();
+	const float x0[2] = {*u, *v};
+	float x[2] = {*u, *v};
+	for (uint32_t i = 0; i < 100; ++i) {
+		const float step0 = std::max(eps, std::fabs(1e-6f * x[0])), step1 = std::max(eps, std::fabs(1e-6f * x[1]));
+		float dx[2], d0b[2], d0f[2], d1b[2], d1f[2];
+		distortion_fun(params, x[0], x[1], &dx[0], &dx[1]);
+		distortion_fun(params, x[0] - step0, x[1], &d0b[0], &d0b[1]);
+		distortion_fun(params, x[0] + step0, x[1], &d0f[0], &d0f[1]);
+		distortion_fun(params, x[0], x[1] - step1, &d1b[0], &d1b[1]);
+		distortion_fun(params, x[0], x[1] + step1, &d1f[0], &d1f[1]);
+		const float J00 = 1 + (d0f[0] - d0b[0]) / (2 * step0), J10 = (d1f[0] - d1b[0]) / (2 * step1);
+		const float J01 = (d0f[1] - d0b[1]) / (2 * step0), J11 = 1 + (d1f[1] - d1b[1]) / (2 * step1);
+		const float r0 = x[0] + dx[0] - x0[0], r1 = x[1] + dx[1] - x0[1];
+		const float det = J00 * J11 - J10 * J01;
+		const float s0 = (J11 * r0 - J10 * r1) / det, s1 = (-J01 * r0 + J00 * r1) / det;
+		x[0] -= s0; x[1] -= s1;
+		if (s0 * s0 + s1 * s1 < 1e-10f) break;
+	}
+	*u = x[0]; *v = x[1];
+}
+// f_theta_undistortion, latlong / equirectangular mappings, common_device.cuh:368-411
+inline vec3 f_theta_undistortion(vec2 uv, const float* params, vec3 error_direction) {
+	const float xpix = uv.x * params[5], ypix = uv.y * params[6];
+	const float norm = std::sqrt(xpix * xpix + ypix * ypix);
+	const float alpha = params[0] + norm * (params[1] + norm * (params[2] + norm * (params[3] + norm * params[4])));
+	float sin_alpha = std::sin(alpha), cos_alpha = std::cos(alpha);
+	if (cos_alpha <= std::numeric_limits<float>::min() || norm == 0.f) return error_direction;
+	sin_alpha *= 1.f / norm;
+	return {sin_alpha * xpix, sin_alpha * ypix, cos_alpha};
+}
+constexpr float ORA_PI = 3.14159265358979323846f;
+inline vec3 latlong_to_dir(vec2 uv) {
+	const float theta = (uv.y - 0.5f) * ORA_PI, phi = (uv.x - 0.5f) * ORA_PI * 2.0f;
+	return {std::sin(phi) * std::cos(theta), std::sin(theta), std::cos(phi) * std::cos(theta)};
+}
+inline vec3 equirectangular_to_dir(vec2 uv) {
+	const float ct = (uv.y - 0.5f) * 2.0f, st = std::sqrt(std::max(1.0f - ct * ct, 0.0f)), phi = (uv.x - 0.5f) * ORA_PI * 2.0f;
+	return {std::sin(phi) * st, ct, std::cos(phi) * st};
+}
+inline vec2 dir_to_latlong(vec3 dir) { return {std::atan2(dir.x, dir.z) / (ORA_PI * 2.0f) + 0.5f, std::asin(dir.y) / ORA_PI + 0.5f}; }
+inline vec2 dir_to_equirectangular(vec3 dir) { return {std::atan2(dir.x, dir.z) / (ORA_PI * 2.0f) + 0.5f, dir.y / 2.0f + 0.5f}; }
+
+// uv_to_ray, common_device.cuh:413-490: all seven lens modes; no foveation / hidden-area mask / distortion map / aperture;
+// parallax_shift = 0.  Returns false for Ray::invalid() (f-theta outside its field of view).
 inline bool uv_to_ray(vec2 uv, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
 		int lens_mode, const float* lens_params, float near_distance, vec3& o, vec3& d) {
-	vec3 dir = {(uv.x - screen_center[0]) * (float)res[0] / focal[0], (uv.y - screen_center[1]) * (float)res[1] / focal[1], 1.0f};
-	if (lens_mode == NGP_LENS_OPENCV) iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
-	else if (lens_mode != NGP_LENS_PERSPECTIVE) throw std::runtime_error("oracle: lens mode out of scope");
+	vec3 head_pos = {0.f, 0.f, 0.f};
+	vec3 dir;
+	if (lens_mode == NGP_LENS_FTHETA) {
+		dir = f_theta_undistortion({uv.x - screen_center[0], uv.y - screen_center[1]}, lens_params, {0.f, 0.f, 0.f});
+		if (dir.x == 0.f && dir.y == 0.f && dir.z == 0.f) { o = cam[3]; d = dir; return false; }
+	} else if (lens_mode == NGP_LENS_LATLONG) {
+		dir = latlong_to_dir(uv);
+	} else if (lens_mode == NGP_LENS_EQUIRECTANGULAR) {
+		dir = equirectangular_to_dir(uv);
+	} else if (lens_mode == NGP_LENS_ORTHOGRAPHIC) {
+		dir = {0.0f, 0.0f, 1.0f};
+		head_pos += vec3{(uv.x - screen_center[0]) * (float)res[0] / focal[0], (uv.y - screen_center[1]) * (float)res[1] / focal[1], 0.0f};
+	} else {
+		dir = {(uv.x - screen_center[0]) * (float)res[0] / focal[0], (uv.y - screen_center[1]) * (float)res[1] / focal[1], 1.0f};
+		if (lens_mode == NGP_LENS_OPENCV) iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
+		else if (lens_mode == NGP_LENS_OPENCV_FISHEYE) iterative_lens_undistortion(lens_params, &dir.x, &dir.y, opencv_fisheye_lens_distortion_delta);
+		else if (lens_mode != NGP_LENS_PERSPECTIVE) throw std::runtime_error("oracle: unknown lens mode");
+	}
 	dir = mul3(cam, dir);
-	vec3 origin = cam[3];
+	vec3 origin = mul3(cam, head_pos) + cam[3];
 	origin += dir * near_distance;
 	o = origin; d = dir;
 	return true;
@@ -159,7 +230,7 @@ inline K1Out generate_training_samples(uint32_t n_rays, uint32_t ray_begin, uint
 		// get_xform_given_rolling_shutter, common_device.cuh:670-674: start == end (no rolling shutter / motion blur data)
 		const mat4x3 xform = M43(xforms[img].start);
 		vec3 ro, rd;
-		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform[3]; rd = xform[2]; } // testbed_nerf.cu:776-778
 		vec3 rdn = normalize(rd);
 		vec2 tminmax = aabb.ray_intersect(ro, rdn);
 		float cone_angle = cone_angle_constant; // calc_cone_angle, nerf_device.cuh:370-377
@@ -230,7 +301,7 @@ inline void lattice_march_counts(int mode, uint32_t n_rays, uint32_t ray_begin, 
 		(void)rng.next_float();
 		const mat4x3 xform = M43(xforms[img].start);
 		vec3 ro, rd;
-		uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd);
+		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform[3]; rd = xform[2]; }
 		vec3 rdn = normalize(rd);
 		vec2 tminmax = aabb.ray_intersect(ro, rdn);
 		tminmax.x = std::fmax(tminmax.x, 0.0f);
@@ -389,7 +460,8 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 // -------------------------------------------------------------------------------------------------
 // occupancy grid, testbed_nerf.cu:87-396, 2476-2633
 // -------------------------------------------------------------------------------------------------
-// pos_to_uv, common_device.cuh:527-577 (Perspective / OpenCV)
+// pos_to_uv, common_device.cuh:527-577 (f-theta has no forward mapping: the reference asserts in debug builds and falls through to the
+// undistorted perspective mapping otherwise)
 inline vec2 pos_to_uv(vec3 pos, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
 		int lens_mode, const float* lens_params) {
 	vec3 dir = pos - cam[3];
@@ -401,9 +473,15 @@ inline vec2 pos_to_uv(vec3 pos, const int32_t res[2], const float focal[2], cons
 	vec3 r1 = {-(a.y * c.z - c.y * a.z) * id, (a.x * c.z - c.x * a.z) * id, -(a.x * c.y - c.x * a.y) * id};
 	vec3 r2 = {(a.y * b.z - b.y * a.z) * id, -(a.x * b.z - b.x * a.z) * id, (a.x * b.y - b.x * a.y) * id};
 	dir = {dot(r0, dir), dot(r1, dir), dot(r2, dir)};
+	if (lens_mode == NGP_LENS_ORTHOGRAPHIC) return {dir.x * focal[0] / (float)res[0] + screen_center[0], dir.y * focal[1] / (float)res[1] + screen_center[1]};
+	if (lens_mode == NGP_LENS_LATLONG || lens_mode == NGP_LENS_EQUIRECTANGULAR) { // lens.is_360(): normalise by the length
+		dir /= std::sqrt(dot(dir, dir));
+		return lens_mode == NGP_LENS_EQUIRECTANGULAR ? dir_to_equirectangular(dir) : dir_to_latlong(dir);
+	}
 	dir /= dir.z;
 	float du = 0.f, dv = 0.f;
 	if (lens_mode == NGP_LENS_OPENCV) opencv_lens_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
+	else if (lens_mode == NGP_LENS_OPENCV_FISHEYE) opencv_fisheye_lens_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
 	dir.x += du; dir.y += dv;
 	return {dir.x * focal[0] / (float)res[0] + screen_center[0], dir.y * focal[1] / (float)res[1] + screen_center[1]};
 }
@@ -425,6 +503,8 @@ inline void mark_untrained_density_grid(uint32_t n_elements, float* grid, uint32
 		for (uint32_t j = 0; j < n_images && count < min_count; ++j) {
 			const mat4x3 xf = M43(xforms[j].start);
 			const ngp_image_meta& m = meta[j];
+			// testbed_nerf.cu:131-136: f-theta lenses have no forward mapping and are assumed to see everything; 360 lenses do
+			if (m.lens_mode == NGP_LENS_FTHETA || m.lens_mode == NGP_LENS_LATLONG || m.lens_mode == NGP_LENS_EQUIRECTANGULAR) { ++count; continue; }
 			for (uint32_t k = 0; k < 8; ++k) {
 				vec3 dir = normalize(corners[k] - xf[3]);
 				if (dot(dir, xf[2]) < 1e-4f) continue;
@@ -656,10 +736,11 @@ struct NerfTrainer {
 			vec2 off = ld_random_pixel_offset(rp.snap_to_pixel_centers ? 0 : rp.spp_index);
 			vec2 uv = {((float)x + off.x) / (float)W, ((float)y + off.y) / (float)H};
 			vec3 ro, rd;
-			uv_to_ray(uv, rp.resolution, rp.focal_length, cam, rp.screen_center, rp.lens_mode, rp.lens_params, rp.near_distance, ro, rd);
+			const bool has_ray = uv_to_ray(uv, rp.resolution, rp.focal_length, cam, rp.screen_center, rp.lens_mode, rp.lens_params, rp.near_distance, ro, rd);
+			if (!has_ray) rd = cam[2];
 			rd = normalize(rd);
 			float t = std::fmax(render_aabb.ray_intersect(ro, rd).x, 0.0f) + 1e-6f;
-			bool alive = render_aabb.contains(ro + rd * t);
+			bool alive = has_ray && render_aabb.contains(ro + rd * t);
 			vec3 idir = V3(1.0f) / rd;
 			float color[4] = {0, 0, 0, 0};
 			vec3 cam_fwd = cam[2], cam_pos = cam[3];
