@@ -67,7 +67,14 @@ PYBIND11_MODULE(pyngp, m) {
 			py::array_t<uint8_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});
 			std::memcpy(out.mutable_data(), d.pixels[i].data(), d.pixels[i].size());
 			return out;
-		}, "RGBA8 pixels of training image i (host copy)");
+		}, "RGBA8 pixels of training image i (host copy)")
+		.def_readonly("sharpen_amount", &NerfDataset::sharpen_amount)
+		.def("image_half", [](const NerfDataset& d, size_t i) {
+			if (i >= d.n_images || i >= d.pixels_half.size() || d.pixels_half[i].empty()) throw std::runtime_error{"image_half: no sharpened image (nerf.sharpen == 0?)"};
+			py::array_t<uint16_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});
+			std::memcpy(out.mutable_data(), d.pixels_half[i].data(), d.pixels_half[i].size() * 2);
+			return out;
+		}, "sharpened training image i as IEEE binary16 bit patterns [h, w, 4] (view as float16): linear premultiplied RGBA, what the trainer samples when nerf.sharpen > 0");
 	py::class_<NerfTraining>(testbed, "NerfTraining")
 		.def_readwrite("near_distance", &NerfTraining::near_distance).def_readwrite("train_mode", &NerfTraining::train_mode)
 		.def_readwrite("random_bg_color", &NerfTraining::random_bg_color).def_readwrite("linear_colors", &NerfTraining::linear_colors)

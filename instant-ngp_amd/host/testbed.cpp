@@ -223,6 +223,7 @@ void Testbed::ensure_trainer() {
 			for (int k = 0; k < 7; ++k) meta[i].lens_params[k] = d.metadata[i].lens_params[k];
 			for (int k = 0; k < 12; ++k) xf[i].start[k] = xf[i].end[k] = d.xforms[i][k];
 			pix[i] = d.pixels[i].data();
+			if (i < d.pixels_half.size() && !d.pixels_half[i].empty()) { meta[i].image_data_type = NGP_IMAGE_HALF; pix[i] = d.pixels_half[i].data(); } // sharpened at load time
 			if (d.pixels[i].empty()) { // metadata restored from a snapshot: a 1x1 transparent stand-in keeps the device arrays well formed (render-only)
 				static const uint32_t k_no_pixel = 0u;
 				pix[i] = &k_no_pixel; meta[i].resolution[0] = meta[i].resolution[1] = 1;
@@ -241,6 +242,36 @@ void Testbed::push_options() {
 // ------------------------------------------------------------------------------------------------
 // dataset: transforms.json (+ images), nerf_loader.cu:273-747
 // ------------------------------------------------------------------------------------------------
+namespace { uint16_t f32_to_f16(float f); float f16_to_f32(uint16_t h); }
+// NerfDataset::set_training_image's sharpening (nerf_loader.cu:85-105, 805-827): the RGBA8 image becomes linear premultiplied halfs
+// (from_rgba32, common_device.cuh:699-731) and is filtered with the 5-point stencil {center_w, -1, -1, -1, -1} / (center_w - 4),
+// center_w = 4 + 1 / amount, on the FLAT pixel index (left / up neighbours clamp at 0, right / down ones wrap) -- on the host here,
+// the reference runs it on the device at load time.  The trainer then samples the half image (EImageDataType::Half).
+std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int h, float amount) {
+	const int64_t n = (int64_t)w * h;
+	std::vector<uint16_t> src((size_t)n * 4), dst((size_t)n * 4);
+	auto s2l = [](float s) { return s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f); };
+	for (int64_t i = 0; i < n; ++i) {
+		const float alpha = rgba[i * 4 + 3] * (1.0f / 255.0f);
+		for (int c = 0; c < 3; ++c) src[i * 4 + c] = f32_to_f16(s2l(rgba[i * 4 + c] * (1.0f / 255.0f)) * alpha);
+		src[i * 4 + 3] = f32_to_f16(alpha);
+	}
+	const float center_w = 4.f + 1.f / amount, inv_totalw = 1.f / (center_w - 4.f);
+	for (int64_t i = 0; i < n; ++i) {
+		int64_t nb[4] = {i - 1, i - w, i + 1, i + w};
+		if (nb[0] < 0) nb[0] = 0;
+		if (nb[1] < 0) nb[1] = 0;
+		if (nb[2] >= n) nb[2] -= n;
+		if (nb[3] >= n) nb[3] -= n;
+		for (int c = 0; c < 4; ++c) {
+			float v = f16_to_f32(src[i * 4 + c]) * center_w;
+			for (int k = 0; k < 4; ++k) v -= f16_to_f32(src[nb[k] * 4 + c]);
+			dst[i * 4 + c] = f32_to_f16(std::max(0.f, v * inv_totalw));
+		}
+	}
+	return dst;
+}
+
 void Testbed::load_training_data(const std::string& path_in) {
 	fs::path path = path_in;
 	if (!fs::exists(path)) throw std::runtime_error{"Data path '" + path_in + "' does not exist."};
@@ -279,12 +310,14 @@ void Testbed::load_training_data(const std::string& path_in) {
 	if (jsons.empty()) throw std::runtime_error{"No json files found in '" + path_in + "'."};
 
 	NerfDataset d;
+	d.sharpen_amount = nerf.sharpen;
 	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; float angle_x = 0.f, angle_y = 0.f; bool principal_in_pixels = false; };
 	std::vector<Frame> frames;
 	for (const fs::path& jp : jsons) {
 		mini_json::Value j; std::string err;
 		if (!mini_json::parse(read_text(jp).c_str(), j, err)) throw std::runtime_error{jp.string() + ": " + err};
 		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
+		if (j.has("sharpen")) d.sharpen_amount = (float)j.num("sharpen", 0);
 		if (j.has("scale")) d.scale = (float)j.num("scale", 0.33);
 		if (j.has("offset") && j["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)j["offset"].at(k).n;
 		const auto& fr = j["frames"];
@@ -373,6 +406,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 		F.meta.focal_length = {flx, fly};
 		if (F.principal_in_pixels) F.meta.principal_point = {F.meta.principal_point[0] / (float)w, F.meta.principal_point[1] / (float)h};
 		else F.meta.principal_point = {0.5f, 0.5f};
+		d.pixels_half.emplace_back();
+		if (d.sharpen_amount > 0.f) d.pixels_half.back() = sharpen_rgba8(rgba, w, h, d.sharpen_amount);
 		d.metadata.push_back(F.meta); d.xforms.push_back(F.xform); d.pixels.push_back(std::move(rgba)); d.paths.push_back(F.image_path);
 	}
 	d.n_images = d.metadata.size();
@@ -770,7 +805,7 @@ void Testbed::load_snapshot(const std::string& path) {
 			std::array<float, 12> x{};
 			const Value& xs = jd["xforms"].at(i)["start"];
 			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) x[c * 3 + r] = (float)xs.at(c).at(r).n;
-			d.metadata.push_back(m); d.xforms.push_back(x); d.pixels.emplace_back(); // no pixels
+			d.metadata.push_back(m); d.xforms.push_back(x); d.pixels.emplace_back(); d.pixels_half.emplace_back(); // no pixels
 			d.paths.push_back(jd["paths"].is_array() && i < jd["paths"].size() ? jd["paths"].at(i).s : std::string());
 		}
 		d.n_images = n;

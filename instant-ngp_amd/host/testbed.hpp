@@ -33,6 +33,8 @@ struct NerfDataset {                        // nerf_loader.h NerfDataset (subset
 	std::vector<ImageMetadata> metadata;
 	std::vector<std::array<float, 12>> xforms;      // ngp convention, column-major mat4x3
 	std::vector<std::vector<uint8_t>> pixels;        // RGBA8 per image (host copy; also feeds render_ground_truth)
+	std::vector<std::vector<uint16_t>> pixels_half;  // sharpened images (nerf.sharpen > 0): linear premultiplied RGBA halfs, what the trainer then samples
+	float sharpen_amount = 0.f;                      // what the images were loaded with (json "sharpen" overrides nerf.sharpen, nerf_loader.cu:462)
 	std::vector<std::string> paths;
 	int aabb_scale = 1;
 	float scale = 0.33f;                             // NERF_SCALE, nerf_loader.h:29

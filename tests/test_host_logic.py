@@ -108,3 +108,41 @@ def test_dense_level_list_interleaving_is_a_bijection(chunk_log2):
         owned = np.bincount(c, minlength=nch)
         n_local = np.array([((hs - k + nch - 1) >> nch_log2) if hs > k else 0 for k in range(nch)])
         assert np.array_equal(owned, n_local)
+
+
+def test_sharpen_at_load_time_matches_a_numpy_model():
+    """`testbed.nerf.sharpen` (run.py --sharpen): NerfDataset::set_training_image's sharpening (nerf_loader.cu:85-105, 805-827) runs in this
+    repo's host loader; the result -- linear premultiplied RGBA halfs, what the trainer then samples -- equals a numpy model of
+    from_rgba32 + the 5-point stencil on the flat pixel index, bit for bit up to the last place of the sRGB powf."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    t = ngp.Testbed()
+    t.nerf.sharpen = 0.5
+    t.load_training_data(os.path.join(ROOT, "tests", "golden", "fox_small", "transforms.json"))
+    d = t.nerf.training.dataset
+    assert d.sharpen_amount == 0.5
+    rgba = d.image(2).astype(np.float32)
+    h, w, _ = rgba.shape
+    got = d.image_half(2).view(np.float16).reshape(-1, 4)
+    s = rgba[..., :3] / np.float32(255)
+    lin = np.where(s <= 0.04045, s / np.float32(12.92), ((s + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4)).astype(np.float32)
+    alpha = (rgba[..., 3:] * np.float32(1 / 255)).astype(np.float32)
+    src = np.concatenate([lin * alpha, alpha], axis=-1).astype(np.float16).reshape(-1, 4).astype(np.float32)
+    n = h * w
+    i = np.arange(n)
+    nb = [np.maximum(i - 1, 0), np.maximum(i - w, 0), np.where(i + 1 >= n, i + 1 - n, i + 1), np.where(i + w >= n, i + w - n, i + w)]
+    center_w = np.float32(4.0) + np.float32(1.0) / np.float32(0.5)
+    v = src * center_w
+    for k in nb:
+        v = v - src[k]
+    want = np.maximum(np.float32(0), v * (np.float32(1) / (center_w - np.float32(4)))).astype(np.float16)
+    # the sRGB -> linear powf may differ in the last float32 place between libm and numpy: allow one half ulp of the inputs to propagate
+    diff = np.abs(got.astype(np.float32) - want.astype(np.float32))
+    assert float(diff.max()) <= 6e-3 and float((diff > 0).mean()) < 0.02, (float(diff.max()), float((diff > 0).mean()))
+    assert got.astype(np.float32).max() > 0.2 and (got.astype(np.float32) >= 0).all()
+    # sharpening off: no half images
+    t2 = ngp.Testbed()
+    t2.load_training_data(os.path.join(ROOT, "tests", "golden", "fox_small", "transforms.json"))
+    with pytest.raises(RuntimeError):
+        t2.nerf.training.dataset.image_half(0)
