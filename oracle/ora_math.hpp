@@ -9,7 +9,9 @@
 // github.com/NVlabs/tiny-cuda-nn (API generation >= 2.0, pinned SHA unknown) and is anchored on
 // the reference's call sites.  Independent pins used by tests/: the pcg32 reference stream
 // (pcg-c-basic demo values), closed-form spherical harmonics (scipy), finite-difference gradients,
-// and brute-force definitions of Morton / occupancy indices.
+// and brute-force definitions of Morton / occupancy indices.  Two results the reference itself logged (notebooks/instant_ngp.ipynb: the hash
+// grid's parameter count for a 16 x 2 configuration, the fox cameras' bounding box after loading) are pinned in tests/test_oracle_pins.py and
+// tests/test_host_logic.py; nothing else is.
 //
 // ora_math.hpp: half, pcg32, vec3, Morton codes, colour transfer, AABB, ray stepping and
 // occupancy-grid index math.

@@ -146,3 +146,30 @@ def test_sharpen_at_load_time_matches_a_numpy_model():
     t2.load_training_data(os.path.join(ROOT, "tests", "golden", "fox_small", "transforms.json"))
     with pytest.raises(RuntimeError):
         t2.nerf.training.dataset.image_half(0)
+
+
+def test_fox_loader_matches_the_reference_log():
+    """notebooks/instant_ngp.ipynb (shipped with the reference) keeps the console output of the REFERENCE loading data/nerf/fox:
+    "Loaded 50 images" and "cam_aabb=[min=[1.0229,-1.33309,-0.378748], max=[2.46175,1.00721,1.41295]]" -- the bounding box of the
+    camera positions p * scale + offset (nerf_loader.cu:516-527, NeRF axis order) of the frames it kept.  transforms.json lists 67 frames
+    (their box would be [0.98359, ...] .. [..., 1.43941]); this repo's loader must keep the same 50 and apply the same scale / offset."""
+    import sys
+    path = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
+    if not os.path.exists(path):
+        pytest.skip("_ref_data/ not staged (tools/stage_reference_data.py copies the reference's datasets at build time)")
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    t = ngp.Testbed()
+    try:
+        t.load_training_data(path)
+    except RuntimeError as e:  # JPEG decoding needs Pillow through the fallback decoder
+        pytest.skip(f"cannot decode the fox JPEGs here: {e}")
+    d = t.nerf.training.dataset
+    assert d.n_images == 50
+    # xforms are stored in the NGP convention (nerf_matrix_to_ngp cycles the axes: ngp = (y, z, x) of the scaled + offset NeRF position)
+    pos_ngp = np.array([x[9:12] for x in d.xforms], dtype=np.float32)
+    pos_nerf = pos_ngp[:, [2, 0, 1]]
+    lo, hi = pos_nerf.min(0), pos_nerf.max(0)
+    want_lo, want_hi = ["1.0229", "-1.33309", "-0.378748"], ["2.46175", "1.00721", "1.41295"]
+    assert [f"{v:.6g}" for v in lo] == want_lo, lo
+    assert [f"{v:.6g}" for v in hi] == want_hi, hi
