@@ -1,6 +1,7 @@
-// mesh_lite.hpp -- minimal Wavefront OBJ reader for the SDF primitive's data path (reference: load_obj via tinyobjloader,
+// mesh_lite.hpp -- minimal Wavefront OBJ and binary STL readers for the SDF primitive's data path (reference: load_obj via tinyobjloader,
 // src/tinyobj_loader_wrapper.cpp; dependencies/tinyobjloader is not used).  Output: 3 vertices per triangle, faces with more than three
 // corners fan-triangulated like tinyobjloader's `triangulate` default; texture / normal indices, groups and materials are ignored.
+// load_stl: testbed_sdf.cu:1328-1361 (binary only: 80-byte header, uint32 face count, 50-byte faces = normal, 3 vertices, attribute word).
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,31 @@ inline std::vector<float> load_obj(const std::string& path) {
 		}
 	}
 	if (out.empty()) throw std::runtime_error{"obj: no faces in '" + path + "'"};
+	return out;
+}
+
+// binary STL: 3 vertices per triangle in file order (the face normals are not used by the SDF path); a truncated file yields the complete
+// faces that were read, an ASCII file ("solid ...") or a zero face count is refused -- as the reference does
+inline std::vector<float> load_stl(const std::string& path) {
+	std::ifstream f{path, std::ios::in | std::ios::binary};
+	if (!f) throw std::runtime_error{"Mesh file '" + path + "' not found"};
+	unsigned char head[84] = {};
+	f.read((char*)head, 84);
+	if (f.gcount() < 84) throw std::runtime_error{"Mesh file '" + path + "' too small for STL header"};
+	uint32_t n_faces = 0;
+	std::memcpy(&n_faces, head + 80, 4);
+	if (std::memcmp(head, "solid", 5) == 0 || n_faces == 0) throw std::runtime_error{"ASCII STL file '" + path + "' not supported"};
+	std::vector<float> out;
+	out.reserve((size_t)n_faces * 9);
+	unsigned char face[50];
+	for (uint32_t i = 0; i < n_faces; ++i) {
+		f.read((char*)face, 50);
+		if (f.gcount() < 50) break;
+		float v[9];
+		std::memcpy(v, face + 12, 36); // behind the 12-byte normal
+		out.insert(out.end(), v, v + 9);
+	}
+	if (out.empty()) throw std::runtime_error{"stl: no faces in '" + path + "'"};
 	return out;
 }
 

@@ -45,6 +45,12 @@ PYBIND11_MODULE(pyngp, m) {
 		std::memcpy(out.mutable_data(), v.data(), v.size() * sizeof(float));
 		return out;
 	});
+	m.def("read_stl", [](const std::string& path) { // binary STL (testbed_sdf.cu:1328-1361), float32 [n_triangles][3][3]
+		const std::vector<float> v = mesh_lite::load_stl(path);
+		py::array_t<float> out({(py::ssize_t)(v.size() / 9), (py::ssize_t)3, (py::ssize_t)3});
+		std::memcpy(out.mutable_data(), v.data(), v.size() * sizeof(float));
+		return out;
+	});
 	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
 		.value("Volume", ETestbedMode::Volume).value("None", ETestbedMode::None).export_values();
 	py::enum_<ETrainMode>(m, "TrainMode").value("Nerf", ETrainMode::Nerf).value("Rfl", ETrainMode::Rfl).value("RflRelax", ETrainMode::RflRelax).export_values();

@@ -282,8 +282,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 		destroy_trainer();
 		m_network_config = mini_json::Value{};
 		if (ext == ".obj" || ext == ".stl") { // load_mesh, testbed_sdf.cu:1363-1447
-			if (ext == ".stl") throw std::runtime_error{"Binary .stl meshes are not implemented; convert to ascii .obj."};
-			m_mesh = mesh_lite::load_obj(path.string());
+			m_mesh = ext == ".stl" ? mesh_lite::load_stl(path.string()) : mesh_lite::load_obj(path.string());
 			NGP_CHECK(ngp_sdf_normalize_mesh_host(m_mesh.data(), m_mesh.size() / 3, &m_mesh_aabb, nullptr));
 			mode = ETestbedMode::Sdf;
 		} else { // load_image, testbed_image.cu: EXR natively, 8-bit formats through the decoder hook (sRGB -> linear)

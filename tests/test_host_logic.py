@@ -173,3 +173,28 @@ def test_fox_loader_matches_the_reference_log():
     want_lo, want_hi = ["1.0229", "-1.33309", "-0.378748"], ["2.46175", "1.00721", "1.41295"]
     assert [f"{v:.6g}" for v in lo] == want_lo, lo
     assert [f"{v:.6g}" for v in hi] == want_hi, hi
+
+
+def test_binary_stl_reader(tmp_path):
+    """load_stl (testbed_sdf.cu:1328-1361): binary STL = 80-byte header, uint32 face count, 50-byte faces; ASCII and empty files are refused,
+    a truncated file yields the complete faces."""
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    rng = np.random.default_rng(9)
+    tris = rng.normal(size=(37, 3, 3)).astype(np.float32)
+    blob = b"binary stl written by the test".ljust(80, b"\0") + struct.pack("<I", len(tris))
+    for t in tris:
+        blob += struct.pack("<3f", 0, 0, 1) + t.tobytes() + b"\0\0"
+    p = tmp_path / "mesh.stl"
+    p.write_bytes(blob)
+    got = ngp.read_stl(str(p))
+    assert got.shape == (37, 3, 3) and np.array_equal(got, tris)
+    (tmp_path / "cut.stl").write_bytes(blob[:84 + 50 * 10 + 17])
+    assert np.array_equal(ngp.read_stl(str(tmp_path / "cut.stl")), tris[:10])
+    (tmp_path / "ascii.stl").write_bytes(b"solid x\n" + b" " * 200)
+    with pytest.raises(RuntimeError):
+        ngp.read_stl(str(tmp_path / "ascii.stl"))
+    with pytest.raises(RuntimeError):
+        ngp.read_stl(str(tmp_path / "missing.stl"))
