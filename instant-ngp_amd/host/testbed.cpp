@@ -247,15 +247,9 @@ namespace { uint16_t f32_to_f16(float f); float f16_to_f32(uint16_t h); }
 // (from_rgba32, common_device.cuh:699-731) and is filtered with the 5-point stencil {center_w, -1, -1, -1, -1} / (center_w - 4),
 // center_w = 4 + 1 / amount, on the FLAT pixel index (left / up neighbours clamp at 0, right / down ones wrap) -- on the host here,
 // the reference runs it on the device at load time.  The trainer then samples the half image (EImageDataType::Half).
-std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int h, float amount) {
+std::vector<uint16_t> sharpen_half(const std::vector<uint16_t>& src, int w, int h, float amount) {
 	const int64_t n = (int64_t)w * h;
-	std::vector<uint16_t> src((size_t)n * 4), dst((size_t)n * 4);
-	auto s2l = [](float s) { return s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f); };
-	for (int64_t i = 0; i < n; ++i) {
-		const float alpha = rgba[i * 4 + 3] * (1.0f / 255.0f);
-		for (int c = 0; c < 3; ++c) src[i * 4 + c] = f32_to_f16(s2l(rgba[i * 4 + c] * (1.0f / 255.0f)) * alpha);
-		src[i * 4 + 3] = f32_to_f16(alpha);
-	}
+	std::vector<uint16_t> dst((size_t)n * 4);
 	const float center_w = 4.f + 1.f / amount, inv_totalw = 1.f / (center_w - 4.f);
 	for (int64_t i = 0; i < n; ++i) {
 		int64_t nb[4] = {i - 1, i - w, i + 1, i + w};
@@ -270,6 +264,17 @@ std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int
 		}
 	}
 	return dst;
+}
+std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int h, float amount) {
+	const int64_t n = (int64_t)w * h;
+	std::vector<uint16_t> src((size_t)n * 4);
+	auto s2l = [](float s) { return s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f); };
+	for (int64_t i = 0; i < n; ++i) {
+		const float alpha = rgba[i * 4 + 3] * (1.0f / 255.0f);
+		for (int c = 0; c < 3; ++c) src[i * 4 + c] = f32_to_f16(s2l(rgba[i * 4 + c] * (1.0f / 255.0f)) * alpha);
+		src[i * 4 + 3] = f32_to_f16(alpha);
+	}
+	return sharpen_half(src, w, h, amount);
 }
 
 void Testbed::load_training_data(const std::string& path_in) {
@@ -310,6 +315,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 
 	NerfDataset d;
 	d.sharpen_amount = nerf.sharpen;
+	bool fix_premult = false; // json "fix_premult" (nerf_loader.cu:448-450): EXR colours are multiplied by their alpha at load time
 	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; float angle_x = 0.f, angle_y = 0.f; bool principal_in_pixels = false; };
 	std::vector<Frame> frames;
 	for (const fs::path& jp : jsons) {
@@ -317,6 +323,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (!mini_json::parse(read_text(jp).c_str(), j, err)) throw std::runtime_error{jp.string() + ": " + err};
 		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
 		if (j.has("sharpen")) d.sharpen_amount = (float)j.num("sharpen", 0);
+		if (j.has("fix_premult")) fix_premult = j.boolean("fix_premult", false);
 		if (j.has("scale")) d.scale = (float)j.num("scale", 0.33);
 		if (j.has("offset") && j["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)j["offset"].at(k).n;
 		const auto& fr = j["frames"];
@@ -391,7 +398,27 @@ void Testbed::load_training_data(const std::string& path_in) {
 	std::sort(frames.begin(), frames.end(), [](const Frame& a, const Frame& b) { return natural_less(a.image_path, b.image_path); });
 	for (Frame& F : frames) {
 		int w = 0, h = 0; std::vector<uint8_t> rgba;
-		bool ok = lower(fs::path(F.image_path).extension().string()) == ".png" && decode_png(F.image_path, w, h, rgba);
+		std::vector<uint16_t> hdr_half; // EXR frames: linear RGBA halfs (EImageDataType::Half), nerf_loader.cu:569-573 + tinyexr_wrapper.cu:39-53
+		const std::string ext_l = lower(fs::path(F.image_path).extension().string());
+		bool ok = false;
+		if (ext_l == ".exr") {
+			std::vector<float> f;
+			exr_lite::read_rgba(F.image_path, w, h, f);
+			hdr_half.resize((size_t)w * h * 4); rgba.resize((size_t)w * h * 4);
+			for (size_t i = 0; i < (size_t)w * h; ++i) {
+				const float alpha = f[i * 4 + 3], fix = fix_premult ? alpha : 1.0f;
+				for (int c = 0; c < 3; ++c) {
+					const float v = f[i * 4 + c] * fix;
+					hdr_half[i * 4 + c] = f32_to_f16(v);
+					const float s8 = v < 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 0.41666f) - 0.055f; // 8-bit sRGB preview for render_ground_truth
+					rgba[i * 4 + c] = (uint8_t)std::lround(255.f * std::min(std::max(s8, 0.f), 1.f));
+				}
+				hdr_half[i * 4 + 3] = f32_to_f16(alpha);
+				rgba[i * 4 + 3] = (uint8_t)std::lround(255.f * std::min(std::max(alpha, 0.f), 1.f));
+			}
+			d.is_hdr = true; ok = true;
+		}
+		if (!ok) ok = ext_l == ".png" && decode_png(F.image_path, w, h, rgba);
 		if (!ok && s_fallback_decoder) ok = s_fallback_decoder(F.image_path, w, h, rgba);
 		if (!ok) throw std::runtime_error{"Could not load image '" + F.image_path + "'"};
 		F.meta.resolution = {w, h};
@@ -406,7 +433,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (F.principal_in_pixels) F.meta.principal_point = {F.meta.principal_point[0] / (float)w, F.meta.principal_point[1] / (float)h};
 		else F.meta.principal_point = {0.5f, 0.5f};
 		d.pixels_half.emplace_back();
-		if (d.sharpen_amount > 0.f) d.pixels_half.back() = sharpen_rgba8(rgba, w, h, d.sharpen_amount);
+		if (!hdr_half.empty()) d.pixels_half.back() = d.sharpen_amount > 0.f ? sharpen_half(hdr_half, w, h, d.sharpen_amount) : std::move(hdr_half);
+		else if (d.sharpen_amount > 0.f) d.pixels_half.back() = sharpen_rgba8(rgba, w, h, d.sharpen_amount);
 		d.metadata.push_back(F.meta); d.xforms.push_back(F.xform); d.pixels.push_back(std::move(rgba)); d.paths.push_back(F.image_path);
 	}
 	d.n_images = d.metadata.size();

@@ -198,3 +198,32 @@ def test_binary_stl_reader(tmp_path):
         ngp.read_stl(str(tmp_path / "ascii.stl"))
     with pytest.raises(RuntimeError):
         ngp.read_stl(str(tmp_path / "missing.stl"))
+
+
+def test_exr_training_images_load_as_hdr_halfs(tmp_path):
+    """NeRF frames stored as OpenEXR (nerf_loader.cu:569-573, tinyexr_wrapper.cu:39-53): linear RGBA halfs for the trainer (optionally
+    multiplied by alpha: json "fix_premult"), the dataset is flagged HDR (=> exponential rgb activation, testbed_nerf.cu:2354)."""
+    import json
+    import shutil
+    import sys
+    src = os.path.join(ROOT, "_ref_data", "data", "image", "albert.exr")
+    if not os.path.exists(src):
+        pytest.skip("_ref_data/ not staged")
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    shutil.copy(src, tmp_path / "frame0.exr")
+    tf = {"camera_angle_x": 0.7, "aabb_scale": 1, "frames": [{"file_path": "frame0.exr", "transform_matrix": [[1, 0, 0, 0.1], [0, 1, 0, 0.2], [0, 0, 1, 3.0], [0, 0, 0, 1]]}]}
+    (tmp_path / "transforms.json").write_text(json.dumps(tf))
+    ref = ngp.read_exr(src)  # float32 [h, w, 4] by the same reader the image primitive uses
+    t = ngp.Testbed()
+    t.load_training_data(str(tmp_path / "transforms.json"))
+    d = t.nerf.training.dataset
+    assert d.n_images == 1 and d.is_hdr and d.metadata[0].resolution == [ref.shape[1], ref.shape[0]]
+    got = d.image_half(0).view(np.float16)
+    assert np.array_equal(got, ref.astype(np.float16))
+    tf["fix_premult"] = True
+    (tmp_path / "transforms.json").write_text(json.dumps(tf))
+    t2 = ngp.Testbed()
+    t2.load_training_data(str(tmp_path / "transforms.json"))
+    want = ref.copy(); want[..., :3] *= want[..., 3:]
+    assert np.array_equal(t2.nerf.training.dataset.image_half(0).view(np.float16), want.astype(np.float16))
