@@ -67,7 +67,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
 		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
 		.def_readonly("scale", &NerfDataset::scale).def_readonly("offset", &NerfDataset::offset).def_readonly("paths", &NerfDataset::paths)
-		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms)
+		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms).def_readonly("from_mitsuba", &NerfDataset::from_mitsuba)
 		.def("image", [](const NerfDataset& d, size_t i) {
 			if (i >= d.n_images) throw std::runtime_error{"image index out of range"};
 			py::array_t<uint8_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});

@@ -315,6 +315,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 
 	NerfDataset d;
 	d.sharpen_amount = nerf.sharpen;
+	bool white_transparent = false, black_transparent = false; // json flags (NSVF-style datasets): pure white / black pixels become transparent (convert_rgba32)
 	bool fix_premult = false; // json "fix_premult" (nerf_loader.cu:448-450): EXR colours are multiplied by their alpha at load time
 	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; float angle_x = 0.f, angle_y = 0.f; bool principal_in_pixels = false; };
 	std::vector<Frame> frames;
@@ -324,8 +325,25 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
 		if (j.has("sharpen")) d.sharpen_amount = (float)j.num("sharpen", 0);
 		if (j.has("fix_premult")) fix_premult = j.boolean("fix_premult", false);
+		// nerf_loader.cu:439-514, in the reference's order: Mitsuba convention (its own default scale / offset), then explicit scale / offset, then an
+		// "aabb" [[min],[max]] that is mapped isotropically onto the unit cube
+		if (j.has("normal_mts_args")) d.from_mitsuba = true;
+		if (j.has("from_mitsuba")) d.from_mitsuba = j.boolean("from_mitsuba", false);
+		if (d.from_mitsuba) { d.scale = 0.66f; d.offset = {0.25f * d.scale, 0.25f * d.scale, 0.25f * d.scale}; }
+		if (j.has("white_transparent")) white_transparent = j.boolean("white_transparent", false);
+		if (j.has("black_transparent")) black_transparent = j.boolean("black_transparent", false);
 		if (j.has("scale")) d.scale = (float)j.num("scale", 0.33);
-		if (j.has("offset") && j["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)j["offset"].at(k).n;
+		if (j.has("offset")) {
+			if (j["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)j["offset"].at(k).n;
+			else if (j["offset"].type == mini_json::Value::Number) d.offset = {(float)j["offset"].n, (float)j["offset"].n, (float)j["offset"].n};
+		}
+		if (j.has("aabb") && j["aabb"].size() == 2) {
+			const auto& ab = j["aabb"];
+			float len = 0.000001f, lo[3], hi[3];
+			for (int k = 0; k < 3; ++k) { lo[k] = (float)ab.at(0).at(k).n; hi[k] = (float)ab.at(1).at(k).n; len = std::max(len, std::fabs(hi[k] - lo[k])); }
+			d.scale = 1.f / len;
+			for (int k = 0; k < 3; ++k) d.offset[k] = ((hi[k] + lo[k]) * 0.5f) * -d.scale + 0.5f;
+		}
 		const auto& fr = j["frames"];
 		auto resolve = [&](const mini_json::Value& f) { // resolve_path, nerf_loader.cu:314-330: try the supported extensions when none is given
 			fs::path ip = jp.parent_path() / f.str("file_path", "");
@@ -373,7 +391,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 			// nerf_matrix_to_ngp, nerf_loader.h:101-120
 			for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = m[r][3] * d.scale + d.offset[r]; }
 			float c3[3][4];
-			for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; }
+			if (d.from_mitsuba) { for (int r = 0; r < 3; ++r) { m[r][0] *= -1.f; m[r][2] *= -1.f; } for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) c3[r][c] = m[r][c]; }
+			else for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; } // cycle the axes xyz <- yzx
 			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) F.xform[c * 3 + r] = c3[r][c];
 			{ // read_lens, nerf_loader.cu:175-241: OpenCV / OpenCV-fisheye coefficients select their mode only when one of them is non-zero
 				const int opencv_mode = (has("is_fisheye") && get("is_fisheye", 0) != 0) ? NGP_LENS_OPENCV_FISHEYE : NGP_LENS_OPENCV;
@@ -421,6 +440,33 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (!ok) ok = ext_l == ".png" && decode_png(F.image_path, w, h, rgba);
 		if (!ok && s_fallback_decoder) ok = s_fallback_decoder(F.image_path, w, h, rgba);
 		if (!ok) throw std::runtime_error{"Could not load image '" + F.image_path + "'"};
+		if (hdr_half.empty()) { // 8-bit images (nerf_loader.cu:581-620, convert_rgba32 :41-63)
+			const fs::path ip = F.image_path;
+			auto decode_any = [&](const fs::path& p, int& ww, int& hh, std::vector<uint8_t>& px) {
+				bool good = lower(p.extension().string()) == ".png" && decode_png(p.string(), ww, hh, px);
+				if (!good && s_fallback_decoder) good = s_fallback_decoder(p.string(), ww, hh, px);
+				return good;
+			};
+			const fs::path alpha_path = ip.parent_path() / (ip.stem().string() + ".alpha" + ip.extension().string());
+			if (fs::exists(alpha_path)) { // red channel of <name>.alpha.<ext> (sRGB -> linear) replaces the alpha channel
+				int wa = 0, ha = 0; std::vector<uint8_t> a;
+				if (!decode_any(alpha_path, wa, ha, a)) throw std::runtime_error{"Could not load alpha image " + alpha_path.string()};
+				if (wa != w || ha != h) throw std::runtime_error{"Alpha image " + alpha_path.string() + " has wrong resolution."};
+				for (size_t i = 0; i < (size_t)w * h; ++i) { const float s = a[i * 4] * (1.f / 255.f); rgba[i * 4 + 3] = (uint8_t)(255.0f * (s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f))); }
+			}
+			const fs::path mask_path = ip.parent_path() / ("dynamic_mask_" + ip.stem().string() + ".png");
+			if (fs::exists(mask_path)) { // masked pixels become "hot pink" 0x00FF00FF, which read_rgba reports as "no pixel": such rays are not trained
+				int wa = 0, ha = 0; std::vector<uint8_t> mk;
+				if (!decode_any(mask_path, wa, ha, mk)) throw std::runtime_error{"Dynamic mask " + mask_path.string() + " could not be loaded."};
+				if (wa != w || ha != h) throw std::runtime_error{"Dynamic mask " + mask_path.string() + " has wrong resolution."};
+				for (size_t i = 0; i < (size_t)w * h; ++i) if (mk[i * 4] || mk[i * 4 + 1] || mk[i * 4 + 2]) { rgba[i * 4] = 0xFF; rgba[i * 4 + 1] = 0x00; rgba[i * 4 + 2] = 0xFF; rgba[i * 4 + 3] = 0x00; }
+			}
+			if (white_transparent || black_transparent)
+				for (size_t i = 0; i < (size_t)w * h; ++i) {
+					const uint8_t* q = &rgba[i * 4];
+					if ((white_transparent && q[0] == 255 && q[1] == 255 && q[2] == 255) || (black_transparent && q[0] == 0 && q[1] == 0 && q[2] == 0)) rgba[i * 4 + 3] = 0;
+				}
+		}
 		F.meta.resolution = {w, h};
 		const float ax = F.angle_x, ay = F.angle_y;
 		float flx = F.meta.focal_length[0], fly = F.meta.focal_length[1];
@@ -764,7 +810,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 		const float eye3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; jd.set("render_aabb_to_local", jmat_cols(eye3, 3, 3));
 		const float up[3] = {0.f, 1.f, 0.f}; jd.set("up", jvec(up, 3)); jd.set("offset", jvec(d.offset.data(), 3));
 		const int env[2] = {0, 0}; jd.set("envmap_resolution", jvec(env, 2)); jd.set("scale", jnum(d.scale)); jd.set("aabb_scale", jnum(d.aabb_scale));
-		jd.set("from_mitsuba", jbool(false)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(0));
+		jd.set("from_mitsuba", jbool(d.from_mitsuba)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(0));
 		jn.set("dataset", jd);
 	}
 	snap.set("nerf", jn);
@@ -812,7 +858,7 @@ void Testbed::load_snapshot(const std::string& path) {
 		const Value& jd = jn["dataset"];
 		if (!jd.is_object() || !jd["metadata"].is_array()) throw std::runtime_error{"Snapshot holds no dataset metadata and no training data is loaded."};
 		NerfDataset d;
-		d.aabb_scale = (int)jd.num("aabb_scale", aabb_scale); d.scale = (float)jd.num("scale", 0.33); d.is_hdr = jd["is_hdr"].type == Value::Bool && jd["is_hdr"].b;
+		d.aabb_scale = (int)jd.num("aabb_scale", aabb_scale); d.scale = (float)jd.num("scale", 0.33); d.is_hdr = jd["is_hdr"].type == Value::Bool && jd["is_hdr"].b; d.from_mitsuba = jd.boolean("from_mitsuba", false);
 		if (jd["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)jd["offset"].at(k).n;
 		const size_t n = jd["metadata"].size();
 		for (size_t i = 0; i < n; ++i) {

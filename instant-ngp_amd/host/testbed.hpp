@@ -40,6 +40,7 @@ struct NerfDataset {                        // nerf_loader.h NerfDataset (subset
 	float scale = 0.33f;                             // NERF_SCALE, nerf_loader.h:29
 	std::array<float, 3> offset{0.5f, 0.5f, 0.5f};   // nerf_loader.cu:403-404
 	bool is_hdr = false;
+	bool from_mitsuba = false;                       // json "from_mitsuba" / "normal_mts_args": Mitsuba axis convention (nerf_loader.h:101-120)
 };
 
 struct NerfTraining {

@@ -227,3 +227,64 @@ def test_exr_training_images_load_as_hdr_halfs(tmp_path):
     t2.load_training_data(str(tmp_path / "transforms.json"))
     want = ref.copy(); want[..., :3] *= want[..., 3:]
     assert np.array_equal(t2.nerf.training.dataset.image_half(0).view(np.float16), want.astype(np.float16))
+
+
+def _write_png(path, rgba):
+    from PIL import Image
+    Image.fromarray(rgba, "RGBA").save(path)
+
+
+def test_loader_conventions_aabb_mitsuba_masks(tmp_path):
+    """Host loader vs nerf_loader.cu / nerf_loader.h arithmetic restated in numpy: the "aabb" key (isotropic map onto the unit cube),
+    the Mitsuba convention (scale 0.66, offset 0.165, no axis cycle), <name>.alpha.<ext> companions, dynamic_mask_<name>.png (masked pixels
+    become 0x00FF00FF = "no pixel" for the trainer) and white_transparent."""
+    import json
+    import sys
+    pytest.importorskip("PIL")
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    rng = np.random.default_rng(4)
+    img = rng.integers(1, 255, (6, 8, 4), dtype=np.uint8); img[..., 3] = 255
+    img[0, 0, :3] = 255  # a pure white pixel
+    _write_png(tmp_path / "f0.png", img)
+    alpha = np.zeros((6, 8, 4), np.uint8); alpha[..., 0] = np.arange(48, dtype=np.uint8).reshape(6, 8) * 5; alpha[..., 3] = 255
+    _write_png(tmp_path / "f0.alpha.png", alpha)
+    mask = np.zeros((6, 8, 4), np.uint8); mask[2, 3, 1] = 9; mask[..., 3] = 255
+    _write_png(tmp_path / "dynamic_mask_f0.png", mask)
+    M = np.array([[0.9, 0.1, -0.2, 1.5], [-0.1, 0.95, 0.3, -0.5], [0.25, -0.28, 0.92, 2.0], [0, 0, 0, 1]], dtype=np.float32)
+    base = {"camera_angle_x": 0.8, "frames": [{"file_path": "f0.png", "transform_matrix": M.tolist()}]}
+
+    def load(extra):
+        (tmp_path / "transforms.json").write_text(json.dumps({**base, **extra}))
+        t = ngp.Testbed()
+        t.load_training_data(str(tmp_path / "transforms.json"))
+        return t.nerf.training.dataset
+
+    def ngp_matrix(scale, offset, mitsuba):  # nerf_matrix_to_ngp, nerf_loader.h:101-120; returns columns (4 x 3)
+        cols = [M[:3, 0].copy(), -M[:3, 1], -M[:3, 2], M[:3, 3] * np.float32(scale) + np.asarray(offset, np.float32)]
+        if mitsuba:
+            cols[0] = -cols[0]; cols[2] = -cols[2]
+            return np.stack(cols)
+        return np.stack([c[[1, 2, 0]] for c in cols])  # cycle the axes xyz <- yzx
+
+    # 1. "aabb": length = largest extent, scale = 1 / length, offset = -centre * scale + 0.5
+    d = load({"aabb": [[-1.0, -2.0, 0.0], [3.0, 1.0, 2.0]], "white_transparent": True})
+    assert abs(d.scale - 0.25) < 1e-7 and np.allclose(d.offset, [-1.0 * 0.25 + 0.5, 0.5 * 0.25 + 0.5, -1.0 * 0.25 + 0.5])
+    assert np.allclose(np.array(d.xforms[0]).reshape(4, 3), ngp_matrix(d.scale, d.offset, False), atol=1e-6)
+    px = d.image(0)
+    # alpha companion: red channel, sRGB -> linear, times 255 truncated
+    s = alpha[..., 0].astype(np.float32) / np.float32(255)
+    lin = np.where(s <= 0.04045, s / np.float32(12.92), ((s + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4))
+    want_alpha = (np.float32(255) * lin).astype(np.uint8)
+    want_alpha[2, 3] = 0          # masked pixel: hot pink with alpha 0
+    want_alpha[0, 0] = 0          # white_transparent
+    assert np.abs(px[..., 3].astype(int) - want_alpha.astype(int)).max() <= 1  # (powf vs numpy ** at a truncation boundary)
+    assert tuple(px[2, 3]) == (255, 0, 255, 0)
+    assert np.array_equal(px[1, 1, :3], img[1, 1, :3])
+    # 2. Mitsuba convention
+    d = load({"from_mitsuba": True})
+    assert d.from_mitsuba and abs(d.scale - 0.66) < 1e-7 and np.allclose(d.offset, [0.165] * 3)
+    assert np.allclose(np.array(d.xforms[0]).reshape(4, 3), ngp_matrix(0.66, [0.165] * 3, True), atol=1e-6)
+    # 3. default convention: scale 0.33, offset 0.5
+    d = load({})
+    assert not d.from_mitsuba and np.allclose(np.array(d.xforms[0]).reshape(4, 3), ngp_matrix(0.33, [0.5] * 3, False), atol=1e-6)
