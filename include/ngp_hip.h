@@ -415,6 +415,10 @@ int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_hos
  * the premultiplied colour, optional linear -> sRGB; :511-560) on device buffers of RGBA float32 */
 int ngp_render_accumulate(void* stream, const float* frame, float* accum, uint64_t n_floats, uint32_t sample_index);
 int ngp_render_tonemap(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb);
+/* the same with a tonemapping curve (ETonemapCurve, render_buffer.cu:264-321): 0 Identity, 1 ACES, 2 Hable, 3 Reinhard; and its per-pixel
+ * arithmetic evaluated on the host (test hook, no GPU needed) */
+int ngp_render_tonemap_curve(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb, int curve);
+int ngp_host_tonemap_pixel(const float rgba[4], float exposure, const float background_linear[4], int to_srgb, int curve, float out[4]);
 
 /* ------------------------------------------------------------------ profiling ------------ */
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).

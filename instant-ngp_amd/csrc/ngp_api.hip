@@ -1629,9 +1629,19 @@ extern "C" int ngp_render_accumulate(void* stream, const float* frame, float* ac
 	HIPCHK(hipGetLastError());
 	return 0;
 }
-extern "C" int ngp_render_tonemap(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb) {
+extern "C" int ngp_render_tonemap_curve(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb, int curve) {
 	REQUIRE(rgba && background_linear, "ngp_render_tonemap: null argument");
-	launch_render_tonemap((hipStream_t)stream, (uint32_t)n_pixels, rgba, std::pow(2.0f, exposure), background_linear, to_srgb);
+	REQUIRE(curve >= 0 && curve <= 3, "ngp_render_tonemap: curve = 0 Identity, 1 ACES, 2 Hable, 3 Reinhard");
+	launch_render_tonemap((hipStream_t)stream, (uint32_t)n_pixels, rgba, std::pow(2.0f, exposure), background_linear, to_srgb, curve);
 	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_render_tonemap(void* stream, float* rgba, uint64_t n_pixels, float exposure, const float background_linear[4], int to_srgb) {
+	return ngp_render_tonemap_curve(stream, rgba, n_pixels, exposure, background_linear, to_srgb, 0);
+}
+// host-side evaluation of the device's tonemapping (csrc/ngp_device.hpp tonemap_pixel, compiled for the host): test hook, no GPU needed
+extern "C" int ngp_host_tonemap_pixel(const float rgba[4], float exposure, const float background_linear[4], int to_srgb, int curve, float out[4]) {
+	const f4 r = tonemap_pixel({rgba[0], rgba[1], rgba[2], rgba[3]}, std::pow(2.0f, exposure), background_linear[0], background_linear[1], background_linear[2], background_linear[3], to_srgb, curve);
+	out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 	return 0;
 }

@@ -472,6 +472,39 @@ NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M4
 	return {dir.x * focal[0] / (float)res[0] + center[0], dir.y * focal[1] / (float)res[1] + center[1]};
 }
 
+// tonemap(vec3, ETonemapCurve), render_buffer.cu:264-321: Identity 0, ACES 1 (Narkowicz fit incl. the 0.6 pre-exposure), Hable 2 (Uncharted-2
+// operator with exposure bias 2 and white point 11.2 folded into the coefficients), Reinhard 3 (luminance based)
+NGP_HD f3 tonemap_curve(f3 x, int curve) {
+	if (curve == 0) return x;
+	x = mk3(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f));
+	float k0, k1, k2, k3, k4, k5;
+	if (curve == 1) {
+		k0 = 0.6f * 0.6f * 2.51f; k1 = 0.6f * 0.03f; k2 = 0.0f; k3 = 0.6f * 0.6f * 2.43f; k4 = 0.6f * 0.59f; k5 = 0.14f;
+	} else if (curve == 2) {
+		const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+		k0 = A * F - A * E; k1 = C * B * F - B * E; k2 = 0.0f; k3 = A * F; k4 = B * F; k5 = D * F * F;
+		const float W = 11.2f;
+		const float nom = k0 * (W * W) + k1 * W + k2, denom = k3 * (W * W) + k4 * W + k5;
+		const float white_scale = denom / nom;
+		k0 = 4.0f * k0 * white_scale; k1 = 2.0f * k1 * white_scale; k2 = k2 * white_scale; k3 = 4.0f * k3; k4 = 2.0f * k4;
+	} else {
+		const float Y = 0.2126f * x.x + 0.7152f * x.y + 0.0722f * x.z;
+		return x * (1.f / (Y + 1.0f));
+	}
+	const f3 sq = x * x;
+	const f3 nom = sq * k0 + x * k1 + mk3(k2), denom = sq * k3 + x * k4 + mk3(k5);
+	return nom / denom;
+}
+// tonemap_kernel (render_buffer.cu:511-548) for one pixel of the accumulated linear frame: background behind the premultiplied colour
+// (weight (1 - a) * bg.a), exposure, curve, optional linear -> sRGB.  `bg` is linear here (the host converts the sRGB background colour).
+NGP_HD f4 tonemap_pixel(f4 c, float exposure_scale, float bg0, float bg1, float bg2, float bg3, int to_srgb, int curve) {
+	const float weight = (1.f - c.w) * bg3;
+	f3 rgb = mk3(c.x + bg0 * weight, c.y + bg1 * weight, c.z + bg2 * weight);
+	rgb = tonemap_curve(rgb * exposure_scale, curve);
+	if (to_srgb) rgb = mk3(linear_to_srgb(rgb.x), linear_to_srgb(rgb.y), linear_to_srgb(rgb.z));
+	return {rgb.x, rgb.y, rgb.z, c.w + weight};
+}
+
 NGP_D f4 read_rgba(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type) {
 	int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1);
 	int py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);

@@ -258,7 +258,7 @@ void launch_render_emit(hipStream_t s, const RenderArgs& a, uint32_t n_alive_hos
 void launch_render_composite(hipStream_t s, const RenderArgs& a, uint32_t n_alive_host, const uint32_t* alive_list, const uint32_t* n_alive, const float* coords, const ngp_half* net_out);
 void launch_render_finish(hipStream_t s, const RenderArgs& a, uint32_t pixel_begin, uint32_t n, float* frame, float* depth);
 void launch_render_accumulate(hipStream_t s, uint32_t n_floats, const float* frame, float* accum, float weight);
-void launch_render_tonemap(hipStream_t s, uint32_t n_pixels, float* rgba, float exposure_scale, const float bg[4], int to_srgb);
+void launch_render_tonemap(hipStream_t s, uint32_t n_pixels, float* rgba, float exposure_scale, const float bg[4], int to_srgb, int curve);
 
 // ---- optional per-kernel HIP-event timing (bench.py roofline leg) -----------------------------
 enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_GRAD_BIN, P_COUNT };

@@ -169,20 +169,18 @@ __global__ void __launch_bounds__(256) k_render_accumulate(uint32_t n_floats, co
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i < n_floats) { const float a = accum[i]; accum[i] = a + (frame[i] - a) * weight; }
 }
-__global__ void __launch_bounds__(256) k_render_tonemap(uint32_t n_pixels, float* __restrict__ rgba, float exposure_scale, float bg0, float bg1, float bg2, float bg3, int to_srgb) {
+__global__ void __launch_bounds__(256) k_render_tonemap(uint32_t n_pixels, float* __restrict__ rgba, float exposure_scale, float bg0, float bg1, float bg2, float bg3, int to_srgb, int curve) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_pixels) return;
-	float4 c = ((float4*)rgba)[i];
-	const float a = c.w;
-	c.x = c.x * exposure_scale + bg0 * (1.f - a); c.y = c.y * exposure_scale + bg1 * (1.f - a); c.z = c.z * exposure_scale + bg2 * (1.f - a); c.w = a + bg3 * (1.f - a);
-	if (to_srgb) { c.x = linear_to_srgb(c.x); c.y = linear_to_srgb(c.y); c.z = linear_to_srgb(c.z); }
-	((float4*)rgba)[i] = c;
+	const float4 c = ((float4*)rgba)[i];
+	const f4 r = tonemap_pixel({c.x, c.y, c.z, c.w}, exposure_scale, bg0, bg1, bg2, bg3, to_srgb, curve); // ngp_device.hpp (host-testable)
+	((float4*)rgba)[i] = make_float4(r.x, r.y, r.z, r.w);
 }
 void launch_render_accumulate(hipStream_t s, uint32_t n_floats, const float* frame, float* accum, float weight) {
 	if (n_floats) hipLaunchKernelGGL(k_render_accumulate, dim3((n_floats + 255) / 256), dim3(256), 0, s, n_floats, frame, accum, weight);
 }
-void launch_render_tonemap(hipStream_t s, uint32_t n_pixels, float* rgba, float exposure_scale, const float bg[4], int to_srgb) {
-	if (n_pixels) hipLaunchKernelGGL(k_render_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, s, n_pixels, rgba, exposure_scale, bg[0], bg[1], bg[2], bg[3], to_srgb);
+void launch_render_tonemap(hipStream_t s, uint32_t n_pixels, float* rgba, float exposure_scale, const float bg[4], int to_srgb, int curve) {
+	if (n_pixels) hipLaunchKernelGGL(k_render_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, s, n_pixels, rgba, exposure_scale, bg[0], bg[1], bg[2], bg[3], to_srgb, curve);
 }
 
 static inline uint32_t nblk(uint32_t n, uint32_t t) { return (n + t - 1) / t; }

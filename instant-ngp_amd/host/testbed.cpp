@@ -695,7 +695,7 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 			NGP_CHECK(ngp_nerf_render(m_nerf, nullptr, &rp, m_frame_dev, nullptr));
 			NGP_CHECK(ngp_render_accumulate(nullptr, m_frame_dev, accum, n, (uint32_t)s));
 		}
-		NGP_CHECK(ngp_render_tonemap(nullptr, accum, (uint64_t)width * height, exposure, bg, 0));
+		NGP_CHECK(ngp_render_tonemap_curve(nullptr, accum, (uint64_t)width * height, exposure, bg, 0, (int)tonemap_curve));
 		HIP_CHECK(hipMemcpy(out.data(), accum, n * sizeof(float), hipMemcpyDeviceToHost));
 	}
 	if (!linear) for (size_t i = 0; i < (size_t)width * height; ++i) for (int k = 0; k < 3; ++k) out[i * 4 + k] = lin_to_srgb(out[i * 4 + k]);

@@ -288,3 +288,52 @@ def test_loader_conventions_aabb_mitsuba_masks(tmp_path):
     # 3. default convention: scale 0.33, offset 0.5
     d = load({})
     assert not d.from_mitsuba and np.allclose(np.array(d.xforms[0]).reshape(4, 3), ngp_matrix(0.33, [0.5] * 3, False), atol=1e-6)
+
+
+def test_tonemap_pixel_matches_the_reference_formulas():
+    """CudaRenderBuffer::tonemap per pixel (render_buffer.cu:264-341, 511-548) as the device evaluates it -- csrc/ngp_device.hpp tonemap_pixel
+    compiled for the host -- against the formulas in float64: background behind the premultiplied colour with weight (1 - a) * bg.a,
+    exposure 2^e, curve (Identity / ACES / Hable / Reinhard), optional linear -> sRGB."""
+    lib = A.load_hip()
+
+    def curve64(x, curve):
+        if curve == 0:
+            return x
+        x = np.maximum(x, 0)
+        if curve == 3:
+            return x / (1 + 0.2126 * x[0] + 0.7152 * x[1] + 0.0722 * x[2])
+        if curve == 1:
+            k = [0.6 * 0.6 * 2.51, 0.6 * 0.03, 0.0, 0.6 * 0.6 * 2.43, 0.6 * 0.59, 0.14]
+        else:
+            a, b, c, d, e, f, w = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30, 11.2
+            k = [a * f - a * e, c * b * f - b * e, 0.0, a * f, b * f, d * f * f]
+            ws = (k[3] * w * w + k[4] * w + k[5]) / (k[0] * w * w + k[1] * w + k[2])
+            k = [4 * k[0] * ws, 2 * k[1] * ws, k[2] * ws, 4 * k[3], 2 * k[4], k[5]]
+        return (x * x * k[0] + x * k[1] + k[2]) / (x * x * k[3] + x * k[4] + k[5])
+
+    def srgb64(v):
+        return np.where(v < 0.0031308, 12.92 * v, 1.055 * np.maximum(v, 0) ** 0.41666 - 0.055)
+
+    rng = np.random.default_rng(12)
+    out = (C.c_float * 4)()
+    for curve in range(4):
+        for _ in range(60):
+            a = float(rng.uniform(0, 1))
+            rgba = np.append(rng.uniform(0, 3, 3) * a, a).astype(np.float32)
+            bg = rng.uniform(0, 1, 4).astype(np.float32)
+            exposure = float(rng.uniform(-2, 2))
+            for to_srgb in (0, 1):
+                assert lib.ngp_host_tonemap_pixel((C.c_float * 4)(*rgba), C.c_float(exposure), (C.c_float * 4)(*bg), to_srgb, curve, out) == 0
+                w = (1 - float(rgba[3])) * float(bg[3])
+                rgb = (rgba[:3].astype(np.float64) + bg[:3].astype(np.float64) * w) * 2.0 ** exposure
+                want = curve64(rgb, curve)
+                if to_srgb:
+                    want = srgb64(want)
+                assert np.allclose(np.array(out[:3]), want, rtol=3e-5, atol=3e-6), (curve, to_srgb, out[:], want)
+                assert abs(out[3] - (float(rgba[3]) + w)) <= 1e-6
+    # defining points of the curves: Hable maps its white point (11.2, with the exposure bias of 2 folded in: 5.6) to 1; ACES(1) = 0.6733
+    one = (C.c_float * 4)(5.6, 5.6, 5.6, 1.0)
+    lib.ngp_host_tonemap_pixel(one, C.c_float(0.0), (C.c_float * 4)(0, 0, 0, 1), 0, 2, out)
+    assert abs(out[0] - 1.0) < 1e-5
+    lib.ngp_host_tonemap_pixel((C.c_float * 4)(1, 1, 1, 1), C.c_float(0.0), (C.c_float * 4)(0, 0, 0, 1), 0, 1, out)
+    assert abs(out[0] - 0.9216 / 1.3688) < 1e-5
