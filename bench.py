@@ -117,11 +117,11 @@ def load_scene(args):
                 name=f"NeRF data/nerf/fox real capture ({n} JPEGs {M[0].resolution[0]}x{M[0].resolution[1]}, OpenCV lens, aabb_scale {int(d.aabb_scale)})", keep=t)
 
 
-def make_trainer(lib, scene, batch, rank=0, world=1):
-    cfg = A.base_model_config(scene["aabb_scale"])
+def make_trainer(lib, scene, batch, rank=0, world=1, seed=1337, model_kw=None):
+    cfg = A.base_model_config(scene["aabb_scale"], **(model_kw or {}))
     model = C.c_void_p()
-    A.check(lib, lib.ngp_model_create(C.byref(cfg), C.c_uint64(1337), C.byref(model)))
-    opts = A.default_nerf_options(scene["aabb_scale"], target_batch_size=batch, rank=rank, world_size=world)
+    A.check(lib, lib.ngp_model_create(C.byref(cfg), C.c_uint64(seed), C.byref(model)))
+    opts = A.default_nerf_options(scene["aabb_scale"], target_batch_size=batch, rank=rank, world_size=world, seed=seed)
     nerf = C.c_void_p()
     A.check(lib, lib.ngp_nerf_create(model, C.byref(opts), A.scene_aabb(scene["aabb_scale"]), C.byref(nerf)))
     A.check(lib, lib.ngp_nerf_set_dataset_device(nerf, scene["n"], scene["M"], scene["X"]))
@@ -163,26 +163,42 @@ def eval_psnr(lib, nerf, scene, spp=1):
     return -10.0 * math.log10(m) if m > 0 else None
 
 
-def run_ab_psnr(lib, scene, args, steps):
+def run_ab_psnr(lib, scene, args, steps, seeds=(1337,)):
     """north_star parity proxy (the CUDA reference cannot run here): train the same scene / seed / ray stream with the production
-    path and with the reference-order path, evaluate PSNR at equal step counts with the run.py procedure."""
-    out = {"eval": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "steps": steps, "production": {}, "reference_order": {},
+    path and with the reference-order path, evaluate PSNR at equal step counts with the run.py procedure.  Several seeds (parameter
+    initialisation AND ray stream): per path mean and standard deviation, and the PAIRED difference production - reference_order with its
+    standard error -- single pairs vary by +-0.15 dB per path, so only the mean over seeds can resolve the north-star tolerance of 0.1 dB."""
+    out = {"eval": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "steps": steps, "seeds": list(seeds), "production": {}, "reference_order": {},
            "reference_order_flags": REFERENCE_ORDER_FLAGS}
-    for name, flags in (("production", 0), ("reference_order", REFERENCE_ORDER_FLAGS)):
-        lib.ngp_debug_set_flags(flags)
-        try:
-            _, _, model, nerf = make_trainer(lib, scene, args.batch)
-            done = 0
-            t0 = time.perf_counter()
-            for target in steps:
-                A.check(lib, lib.ngp_nerf_train(nerf, None, target - done)); done = target
-                out[name][str(target)] = round(eval_psnr(lib, nerf, scene, args.eval_spp), 4)
-            out[name + "_wall_s"] = round(time.perf_counter() - t0, 2)
-            lib.ngp_nerf_destroy(nerf); lib.ngp_model_destroy(model)
-        finally:
-            lib.ngp_debug_set_flags(0)
-    out["delta_db"] = {k: round(out["production"][k] - out["reference_order"][k], 4) for k in out["production"]}
+    per = {"production": {str(k): [] for k in steps}, "reference_order": {str(k): [] for k in steps}}
+    wall = {"production": 0.0, "reference_order": 0.0}
+    for seed in seeds:
+        for name, flags in (("production", 0), ("reference_order", REFERENCE_ORDER_FLAGS)):
+            lib.ngp_debug_set_flags(flags)
+            try:
+                _, _, model, nerf = make_trainer(lib, scene, args.batch, seed=seed)
+                done = 0
+                t0 = time.perf_counter()
+                for target in steps:
+                    A.check(lib, lib.ngp_nerf_train(nerf, None, target - done)); done = target
+                    per[name][str(target)].append(round(eval_psnr(lib, nerf, scene, args.eval_spp), 4))
+                wall[name] += time.perf_counter() - t0
+                lib.ngp_nerf_destroy(nerf); lib.ngp_model_destroy(model)
+            finally:
+                lib.ngp_debug_set_flags(0)
+    n = len(seeds)
+    for name in ("production", "reference_order"):
+        out[name] = {k: round(float(np.mean(v)), 4) for k, v in per[name].items()}
+        out[name + "_per_seed"] = per[name]
+        out[name + "_std_db"] = {k: round(float(np.std(v, ddof=1)), 4) if n > 1 else None for k, v in per[name].items()}
+        out[name + "_wall_s"] = round(wall[name], 2)
+    d = {k: np.array(per["production"][k]) - np.array(per["reference_order"][k]) for k in per["production"]}
+    out["delta_db"] = {k: round(float(v.mean()), 4) for k, v in d.items()}                       # mean paired difference
+    out["delta_db_per_seed"] = {k: [round(float(x), 4) for x in v] for k, v in d.items()}
+    out["delta_db_stderr"] = {k: round(float(v.std(ddof=1) / math.sqrt(n)), 4) if n > 1 else None for k, v in d.items()}
     out["max_abs_delta_db"] = max(abs(v) for v in out["delta_db"].values())
+    # done-criterion of the round-2 review: |mean delta| <= 0.1 dB with the +-2 standard-error interval inside +-0.1
+    out["within_0p1_db"] = {k: (abs(out["delta_db"][k]) + 2 * out["delta_db_stderr"][k] <= 0.1) if n > 1 else None for k in out["delta_db"]}
     return out
 
 
@@ -203,6 +219,7 @@ def main():
     ap.add_argument("--eval-spp", type=int, default=1)
     ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the PSNR after the timed region (untimed), e.g. 5000,10000,35000")
     ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
+    ap.add_argument("--ab-seeds", type=int, default=1, help="--ab-psnr: number of seeds (1337, 1338, ...) per path; mean, standard deviation and the paired difference with its standard error are reported")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = --batch samples per GPU per step (default, the driver's mode); strong = --batch samples per step in total (B / N per GPU)")
     ap.add_argument("--dp-backend", choices=["auto", "rccl", "torch"], default="auto", help="N > 1: gradient / counter all-reduce inside libngp_hip (RCCL, ngp_comm_*) or through torch.distributed")
     args = ap.parse_args()
@@ -252,14 +269,17 @@ def main():
             ok = torch.tensor([1 if rc == 0 else 0], device="cuda"); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 dp_backend = "rccl-in-library"
-            elif args.dp_backend == "rccl":
-                raise RuntimeError("ngp_comm_init failed: " + lib.ngp_last_error().decode())
+            else:
+                if rc == 0:
+                    lib.ngp_comm_destroy(nerf)  # another rank failed: no rank may keep a communicator while the torch.distributed path runs the step
+                if args.dp_backend == "rccl":
+                    raise RuntimeError("ngp_comm_init failed on some rank: " + lib.ngp_last_error().decode())
         if dp_backend is None:
             dp_backend = "torch.distributed"
             g = C.c_void_p(); lib.ngp_model_param_ptrs(model, None, None, None, C.byref(g))
             grad_view = torch.as_tensor(CudaView(g.value, n_params.value, "<f2"), device="cuda")
             cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(nerf, C.byref(cp))
-            cnt_view = torch.as_tensor(CudaView(cp.value, 2, "<i4"), device="cuda")
+            cnt_view = torch.as_tensor(CudaView(cp.value, 3, "<i4"), device="cuda")  # {marched, compacted, loss sum in units of 2^-24}
 
     host_s = {}  # torch.distributed path: host-side enqueue time per call (to tell a host-bound loop from a device-bound one)
 
@@ -273,7 +293,7 @@ def main():
             A.check(lib, lib.ngp_nerf_train_prep(nerf, None))
             A.check(lib, lib.ngp_nerf_train_forward(nerf, None))    # K1 (unless pre-launched) .. K4
             t1 = pc()
-            dist.all_reduce(cnt_view)    # two uint32 so that every rank derives the same next rays_per_batch
+            dist.all_reduce(cnt_view)    # three uint32 so that every rank derives the same next rays_per_batch and reports the union batch's loss
             t2 = pc()
             A.check(lib, lib.ngp_nerf_train_backward(nerf, None))   # controller, next step's K1 on its own stream, T1 / scatter / W
             t3 = pc()
@@ -378,7 +398,7 @@ def main():
 
     ab = None
     if rank == 0 and world == 1 and args.ab_psnr:
-        ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x))
+        ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[1337 + i for i in range(max(args.ab_seeds, 1))])
 
     if rank == 0:
         lego = args.scene == "synthetic"

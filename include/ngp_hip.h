@@ -365,14 +365,14 @@ int ngp_nerf_train_prep(ngp_nerf*, void* stream);
 int ngp_nerf_train_forward_backward(ngp_nerf*, void* stream);
 int ngp_nerf_train_finish(ngp_nerf*, void* stream);
 /* Multi-rank order that lets the controller and the next step's ray marching start before the backward pass:
- * train_forward -> all-reduce(sum) of ngp_nerf_counter_ptrs' two words -> train_backward -> all-reduce(sum) of the gradients ->
+ * train_forward -> all-reduce(sum) of ngp_nerf_counter_ptrs' three words -> train_backward -> all-reduce(sum) of the gradients ->
  * train_finish.  (train_forward_backward + both all-reduces + train_finish stays valid.) */
 int ngp_nerf_train_forward(ngp_nerf*, void* stream);
 int ngp_nerf_train_backward(ngp_nerf*, void* stream);
 /* Data-parallel training inside the library (new; SURVEY 8b "ngp_comm_init / ngp_allreduce_gradients", 8e): one process per GPU,
  * RCCL over xGMI (librccl is resolved at run time).  Rank 0 calls ngp_comm_unique_id (ncclGetUniqueId) and hands the 128 bytes to
  * every rank by any side channel; every rank calls ngp_comm_init with the rank / world_size its trainer was created with.  From
- * then on ngp_nerf_train runs  forward -> all-reduce(sum) of the two counters -> backward -> all-reduce(sum) of the fp16
+ * then on ngp_nerf_train runs  forward -> all-reduce(sum) of the three counter words -> backward -> all-reduce(sum) of the fp16
  * gradient vector on the caller's stream (the next step's ray marching runs beside it on its own stream) -> optimizer.
  * ngp_allreduce_gradients / ngp_allreduce_counters are the same collectives for callers that sequence the step themselves. */
 int ngp_comm_unique_id(uint8_t id_out_host[128]);
@@ -380,8 +380,9 @@ int ngp_comm_init(ngp_nerf*, uint32_t rank, uint32_t world_size, const uint8_t i
 int ngp_comm_destroy(ngp_nerf*);
 int ngp_allreduce_gradients(ngp_nerf*, void* stream);
 int ngp_allreduce_counters(ngp_nerf*, void* stream);
-/* Two uint32 {measured_before_compaction, measured} to all-reduce(sum) across ranks (8e). */
-int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters2);
+/* Three uint32 {measured_before_compaction, measured, this rank's loss sum in units of 2^-24} to all-reduce(sum) across ranks (8e):
+ * every rank then derives the same next rays_per_batch and reports the loss of the union batch. */
+int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters3);
 /* Blocking read-back (the reference's copy_to_host, testbed_nerf.cu:2681-2682). */
 int ngp_nerf_get_stats(ngp_nerf*, void* stream, ngp_nerf_stats* out_host);
 /* update_density_grid_nerf (testbed_nerf.cu:2476-2592) with explicit sample counts. */

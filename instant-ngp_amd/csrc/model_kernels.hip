@@ -72,17 +72,18 @@ DEV h8 to_frag_masked(const f16v& d, int q, uint32_t mask16) {
 // hash grid: one level for one sample.  [tcnn grid.h kernel_grid / grid_index / pos_fract]
 // ---------------------------------------------------------------------------------------------
 struct LevelConst { float scale; uint32_t res, hs, offset; bool hashed; };
-DEV LevelConst level_const(const GridMeta* __restrict__ gmp, int lvl_even, int hi) {
+// the lane's level is one of two compile-time levels, selected by hi (= lane >> 5): a select between two uniform values
+DEV LevelConst level_const2(const GridMeta* __restrict__ gmp, int lvl_lo, int lvl_hi, int hi) {
 	const GridMeta& gm = *gmp;
-	// the level index is (compile-time even level) + hi: select between two uniform values
 	LevelConst c;
-	c.scale = hi ? gm.scale[lvl_even + 1] : gm.scale[lvl_even];
-	c.res = hi ? gm.resolution[lvl_even + 1] : gm.resolution[lvl_even];
-	c.hs = hi ? gm.hashmap_size[lvl_even + 1] : gm.hashmap_size[lvl_even];
-	c.offset = hi ? gm.offset[lvl_even + 1] : gm.offset[lvl_even];
+	c.scale = hi ? gm.scale[lvl_hi] : gm.scale[lvl_lo];
+	c.res = hi ? gm.resolution[lvl_hi] : gm.resolution[lvl_lo];
+	c.hs = hi ? gm.hashmap_size[lvl_hi] : gm.hashmap_size[lvl_lo];
+	c.offset = hi ? gm.offset[lvl_hi] : gm.offset[lvl_lo];
 	c.hashed = (uint64_t)c.res * c.res * c.res > (uint64_t)c.hs;
 	return c;
 }
+DEV LevelConst level_const(const GridMeta* __restrict__ gmp, int lvl_even, int hi) { return level_const2(gmp, lvl_even, lvl_even + 1, hi); }
 struct Corners { uint32_t idx[8]; float w[8]; uint32_t cell_xy, cell_z; };
 DEV void level_corners(const LevelConst& lc, float x, float y, float z, Corners& out) {
 	// No contraction here: under -ffp-contract=fast LLVM rewrites (1 - p) * w into fma(-p, w, w), which changes the
@@ -160,16 +161,50 @@ DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, f
 	return r;
 }
 
-// Encoding of one sample column into the lane's two B-operand fragments (k-steps 0,1), F = 4.
-template <bool PAIR = false>
+// F = 2 (L = 16: the reference's 2022 configs/nerf/base.json, notebooks/instant_ngp.ipynb): 4-byte entries, same corner order and half fma chain
+DEV h2 level_features2_3d(const __half* __restrict__ table, const LevelConst& lc, float x, float y, float z) {
+	Corners cr;
+	level_corners(lc, x, y, z, cr);
+	const uint32_t* t = (const uint32_t*)table + lc.offset;
+	uint32_t v[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) v[c] = t[cr.idx[c]];
+	h2 r = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		const _Float16 wh = (_Float16)cr.w[c];
+		const h2 w2 = {wh, wh};
+		r = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, v[c]), r);
+	}
+	__builtin_amdgcn_sched_barrier(0); // see level_features4
+	return r;
+}
+
+// Encoding of one sample column into the lane's two B-operand fragments (k-steps 0,1).  Fragment element (s, hi, j) is input feature
+// k = 16 s + 8 (j >> 2) + 4 hi + (j & 3):  F = 4: feature j & 3 of level 4 s + 2 (j >> 2) + hi;  F = 2: feature j & 1 of level 8 s + 4 (j >> 2) + 2 hi + ((j & 3) >> 1).
+template <int F = 4, bool PAIR = false>
 DEV void encode_sample(const GridMeta* __restrict__ gm, const __half* __restrict__ table, float x, float y, float z, int hi, h8 out[2]) {
 	const int lane = threadIdx.x & 63;
 #pragma unroll
 	for (int s = 0; s < 2; ++s) {
-		h4 a = level_features4<PAIR>(table, level_const(gm, 4 * s + 0, hi), x, y, z, lane); // level 4s+hi   -> j = 0..3
-		h4 b = level_features4<PAIR>(table, level_const(gm, 4 * s + 2, hi), x, y, z, lane); // level 4s+2+hi -> j = 4..7
-		h8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-		out[s] = r;
+		if (F == 4) {
+			h4 a = level_features4<PAIR>(table, level_const(gm, 4 * s + 0, hi), x, y, z, lane); // level 4s+hi   -> j = 0..3
+			h4 b = level_features4<PAIR>(table, level_const(gm, 4 * s + 2, hi), x, y, z, lane); // level 4s+2+hi -> j = 4..7
+			h8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+			out[s] = r;
+		} else {
+			h8 r;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { // q = j >> 1
+				const int l0 = 8 * s + 4 * (q >> 1) + (q & 1);
+				// 16 levels x 4 per-lane constants would stay live across the whole sample loop (they are loop invariant: 32 VGPRs, spills);
+				// an opaque copy of `hi` makes the four selects of a level part of the level's own code instead
+				int hi_l = hi; asm volatile("" : "+v"(hi_l));
+				const h2 f = level_features2_3d(table, level_const2(gm, l0, l0 + 2, hi_l), x, y, z);
+				r[2 * q] = f[0]; r[2 * q + 1] = f[1];
+			}
+			out[s] = r;
+		}
 	}
 }
 
@@ -337,7 +372,7 @@ DEV void fwd_rgb_l3(const h8* fw, int lane, const FwdState<CT>& st, f16v out[CT]
 // ---------------------------------------------------------------------------------------------
 // inference kernel (K2, density-grid queries, renderer): persistent waves, 64 samples per iteration
 // ---------------------------------------------------------------------------------------------
-template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW>
+template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW, int F = 4>
 __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n_max,
 		const uint32_t* __restrict__ n_ptr, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -357,7 +392,7 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 			const uint32_t s_raw = tile * TS + c * 32 + col;
 			sidx[c] = s_raw;
 			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
-			encode_sample<PAIR>(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
+			encode_sample<F, PAIR>(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
 			if (!DENSITY_ONLY) st.rin[c][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
 		}
 		fwd_density_l1<CT>(fw, lane, st);
@@ -393,7 +428,7 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 // ---------------------------------------------------------------------------------------------
 // TW = tile width in samples: 32 (one tile per wavefront) or 16 (two tiles of two different rays share the wavefront's 32 MFMA
 // columns -- rays end after ~12 compacted samples, so 16-wide tiles evaluate fewer samples behind the cut and fill the columns).
-template <uint32_t TW>
+template <uint32_t TW, int F = 4>
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -447,7 +482,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		if (__ballot(valid) == 0ull) break;
 		FwdState<1> st;
 		const float* p = in + (size_t)sample * in_stride;
-		encode_sample<false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
+		encode_sample<F, false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
 		st.rin[0][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
 		fwd_density_l1<1>(fw, lane, st);
 		fwd_density_l2<1>(fw, lane, st);
@@ -624,6 +659,7 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_inference(const GridMeta* __r
 }
 
 // encoding only (unit-test hook): out[i][32] halfs in NATURAL feature order (level-major)
+template <int F>
 __global__ void __launch_bounds__(256) k_encode_only(const GridMeta* __restrict__ gm, const __half* __restrict__ table, const float* __restrict__ pos, uint32_t stride,
 		uint32_t n, __half* __restrict__ out) {
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
@@ -632,7 +668,7 @@ __global__ void __launch_bounds__(256) k_encode_only(const GridMeta* __restrict_
 	if (wave * 32 >= n) return;
 	const float* p = pos + (size_t)min(s_raw, n - 1) * stride;
 	h8 e[2];
-	encode_sample(gm, table, p[0], p[1], p[2], hi, e);
+	encode_sample<F>(gm, table, p[0], p[1], p[2], hi, e);
 	if (s_raw >= n) return;
 #pragma unroll
 	for (int s = 0; s < 2; ++s)
@@ -653,7 +689,7 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 
 // SCATTER = false: every level's dL/d(enc) goes to denc_lv and the kernel issues no atomics (production: all levels through the bin lists);
 // compiled separately so that the scatter code's registers do not limit the occupancy of the gather-latency-bound forward / dgrad part.
-template <int CT, int MINW, bool SCATTER>
+template <int CT, int MINW, bool SCATTER, int F = 4>
 __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
 		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags,
 		uint2* __restrict__ denc_lv, uint32_t denc_cap) {
@@ -677,7 +713,7 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 			sidx[c] = s_raw;
 			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
 			px[c] = p[0]; py[c] = p[1]; pz[c] = p[2];
-			encode_sample(gm, table, px[c], py[c], pz[c], hi, st.enc[c]);
+			encode_sample<F>(gm, table, px[c], py[c], pz[c], hi, st.enc[c]);
 			st.rin[c][1] = sh4_frag(p[4], p[5], p[6], hi);
 			// stash for kernel W: [32-sample tile][s][lane] 16-byte chunks (lane-linear, coalesced)
 			enc_stash[(((size_t)tile * CT + c) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, st.enc[c][0]);
@@ -784,6 +820,39 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 		// packed half (the same precision class as the table's half atomics), so only the run head
 		// issues global_atomic_pk_add_f16.
 		if (flags & DBG_T1_NO_SCATTER) continue;
+		if (F == 2) {
+			// F = 2, L = 16: register pair (2m, 2m+1) of the dL/d(enc) tile = features 0,1 of level (m & 1) + 4 (m >> 1) + 2 hi.  Levels that go through the
+			// record lists (all of them in production) leave their 4 bytes per sample level-major in denc_lv; the others (no lists: table sizes the
+			// binning does not cover, DBG_T1_NO_BINNING) are scattered here with one packed-half atomic per corner like the reference's atomicAdd(__half2).
+			uint32_t* __restrict__ denc32 = (uint32_t*)denc_lv;
+#pragma unroll
+			for (int c = 0; c < CT; ++c) {
+				const bool sv = sidx[c] < n;
+#pragma unroll
+				for (int m = 0; m < 8; ++m) {
+					const int l0 = (m & 1) + 4 * (m >> 1);
+					const h2 g = {(_Float16)denc[c][2 * m], (_Float16)denc[c][2 * m + 1]}; // dL/d(enc) is a half matrix in the reference
+					if (!SCATTER) { if (sv) denc32[(size_t)(l0 + 2 * hi) * denc_cap + sidx[c]] = __builtin_bit_cast(uint32_t, g); continue; }
+					const LevelConst lc = level_const2(gm, l0, l0 + 2, hi);
+					const bool binned = denc_lv != nullptr && (lc.hashed || (flags & T1_DENSE_EXTERNAL));
+					if (binned) { if (sv) denc32[(size_t)(l0 + 2 * hi) * denc_cap + sidx[c]] = __builtin_bit_cast(uint32_t, g); }
+					if (__ballot(!binned) == 0ull) continue;
+					if (sv && !binned) {
+						Corners cr;
+						level_corners(lc, px[c], py[c], pz[c], cr);
+						const float g0 = (float)g[0], g1 = (float)g[1];
+						__half* gt = grid_grad + (size_t)lc.offset * 2;
+#pragma unroll
+						for (int k = 0; k < 8; ++k) {
+							const h2 v = {(_Float16)(g0 * cr.w[k]), (_Float16)(g1 * cr.w[k])};
+							atomic_add_h2(gt + (size_t)cr.idx[k] * 2, v);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			continue;
+		}
 		if (!SCATTER) {
 #pragma unroll
 			for (int c = 0; c < CT; ++c) {
@@ -925,12 +994,21 @@ DEV LevelConst level_const_uniform(const GridMeta* __restrict__ gm, uint32_t lev
 	return lc;
 }
 
-template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */>
+// record value of one corner: the F halfs of the entry's gradient contribution (F = 4: 8 bytes, F = 2: 4 bytes)
+template <int F> struct BinVal;
+template <> struct BinVal<4> { typedef uint2 type; };
+template <> struct BinVal<2> { typedef uint32_t type; };
+template <int F> DEV typename BinVal<F>::type pack_halfs(const float* v);
+template <> __device__ __forceinline__ uint2 pack_halfs<4>(const float* v) { const h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; return __builtin_bit_cast(uint2, hv); }
+template <> __device__ __forceinline__ uint32_t pack_halfs<2>(const float* v) { const h2 hv = {(_Float16)v[0], (_Float16)v[1]}; return __builtin_bit_cast(uint32_t, hv); }
+
+template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */, int F = 4>
 __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
+	typedef typename BinVal<F>::type val_t;
 	constexpr uint32_t NCH = (1u << GRAD_BIN_MAX_TABLE_LOG2) >> CL2; // most chunks a level can have (128 / 256)
 	__shared__ uint32_t s_cnt[NCH], s_start[NCH], s_gbase[NCH];
 	__shared__ uint32_t s_wsum[4];
-	__shared__ uint2 s_val[GRAD_BIN_SAMPLES * 8];
+	__shared__ val_t s_val[GRAD_BIN_SAMPLES * 8];
 	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * 8];
 	const uint32_t tid = threadIdx.x, ly = blockIdx.y, level = a.levels[ly];
 	const LevelConst lc = level_const_uniform(a.gm, level);
@@ -946,20 +1024,27 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	__syncthreads();
 	constexpr int SPT = GRAD_BIN_SAMPLES / 256; // samples per thread
 	uint32_t idx[SPT][8], rank[SPT][8];
-	uint2 val[SPT][8];
+	val_t val[SPT][8];
 	bool valid[SPT];
 	const uint32_t lane = tid & 63u;
 #pragma unroll
 	for (int u = 0; u < SPT; ++u) {
 		const uint32_t s = blockIdx.x * GRAD_BIN_SAMPLES + u * 256 + tid;
 		valid[u] = s < a.n;
-		float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+		float g[F];
+#pragma unroll
+		for (int f = 0; f < F; ++f) g[f] = 0.f;
 		Corners cr;
 		{
 			const uint32_t sc = valid[u] ? s : a.n - 1; // every lane takes part in the shuffles below
 			const float* p = a.in + (size_t)sc * a.in_stride;
 			level_corners(lc, p[0], p[1], p[2], cr);
-			if (valid[u]) { const h4 g = __builtin_bit_cast(h4, a.denc_lv[(size_t)level * a.denc_cap + sc]); g0 = (float)g[0]; g1 = (float)g[1]; g2 = (float)g[2]; g3 = (float)g[3]; }
+			if (valid[u]) {
+				const val_t raw = ((const val_t*)a.denc_lv)[(size_t)level * a.denc_cap + sc];
+				const _Float16* gh = (const _Float16*)&raw;
+#pragma unroll
+				for (int f = 0; f < F; ++f) g[f] = (float)gh[f];
+			}
 		}
 		// Consecutive lanes are consecutive samples of (mostly) one ray; on the coarser hashed levels runs of them share a grid cell, i.e. all
 		// eight table entries.  Such runs are summed here (fp32, segmented shuffle reduction like T1's, stopped at the longest run of the
@@ -975,9 +1060,11 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 		if (merge) {
 			const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
 			const uint32_t run_right = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : (63u - lane); // followers to my right that belong to my run
-			float v[8][4];
+			float v[8][F];
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { const float w = cr.w[k]; v[k][0] = g0 * w; v[k][1] = g1 * w; v[k][2] = g2 * w; v[k][3] = g3 * w; }
+			for (int k = 0; k < 8; ++k) { const float w = cr.w[k];
+#pragma unroll
+				for (int f = 0; f < F; ++f) v[k][f] = g[f] * w; }
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
 				const bool take = run_right >= (uint32_t)d;
@@ -985,17 +1072,19 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 #pragma unroll
 				for (int k = 0; k < 8; ++k)
 #pragma unroll
-					for (int f = 0; f < 4; ++f) { const float t = __shfl_down(v[k][f], d, 64); if (take) v[k][f] += t; }
+					for (int f = 0; f < F; ++f) { const float t = __shfl_down(v[k][f], d, 64); if (take) v[k][f] += t; }
 			}
 			emit = valid[u] && head;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { const h4 hv = {(_Float16)v[k][0], (_Float16)v[k][1], (_Float16)v[k][2], (_Float16)v[k][3]}; val[u][k] = __builtin_bit_cast(uint2, hv); }
+			for (int k = 0; k < 8; ++k) val[u][k] = pack_halfs<F>(v[k]);
 		} else {
 #pragma unroll
 			for (int k = 0; k < 8; ++k) {
 				const float w = cr.w[k];
-				const h4 hv = {(_Float16)(g0 * w), (_Float16)(g1 * w), (_Float16)(g2 * w), (_Float16)(g3 * w)};
-				val[u][k] = __builtin_bit_cast(uint2, hv);
+				float v[F];
+#pragma unroll
+				for (int f = 0; f < F; ++f) v[f] = g[f] * w;
+				val[u][k] = pack_halfs<F>(v);
 			}
 		}
 		valid[u] = emit;
@@ -1039,15 +1128,15 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	for (uint32_t i = tid; i < total; i += 256) {
 		const uint32_t key = s_key[i], c = key >> 16, local = key & 0xffffu;
 		const uint32_t d = s_gbase[c] + (i - s_start[c]);
-		const uint2 v = s_val[i];
+		const val_t v = s_val[i];
 		if (d < a.cap) {
 			const size_t o = ((size_t)ly * a.max_chunks + c) * a.cap + d;
-			a.vals[o] = v;
+			((val_t*)a.vals)[o] = v;
 			a.idxs[o] = (uint16_t)local;
 		} else { // list full: straight to the table (k_grad_accumulate adds its sums on top)
-			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + (dense ? ((size_t)local << NCH_LOG2) + c : ((size_t)c << CL2) + local)) * 4;
-			atomic_add_h2(dst, __builtin_bit_cast(h2, v.x));
-			atomic_add_h2(dst + 2, __builtin_bit_cast(h2, v.y));
+			__half* dst = (__half*)a.grid_grad_ + ((size_t)lc.offset + (dense ? ((size_t)local << NCH_LOG2) + c : ((size_t)c << CL2) + local)) * F;
+			if constexpr (F == 4) { atomic_add_h2(dst, __builtin_bit_cast(h2, v.x)); atomic_add_h2(dst + 2, __builtin_bit_cast(h2, v.y)); }
+			else atomic_add_h2(dst, __builtin_bit_cast(h2, v));
 		}
 	}
 }
@@ -1066,9 +1155,10 @@ DEV long long half_bits_to_fixed(uint32_t hbits) {
 //                  every record byte is fetched once;
 //   SPLIT = true:  one block = one chunk x one feature pair (round-1 layout: half the LDS, but both blocks fetch every record).
 // The block also empties its list for the next step (no separate reset launch).
-template <uint32_t CL2, bool SPLIT>
+template <uint32_t CL2, bool SPLIT, int F = 4>
 __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
-	constexpr uint32_t E = 1u << CL2, NF = SPLIT ? 2u : 4u;
+	static_assert(F == 4 || !SPLIT, "the split layout exists for F = 4 only");
+	constexpr uint32_t E = 1u << CL2, NF = SPLIT ? 2u : (uint32_t)F;
 	__shared__ unsigned long long acc[E * NF];
 	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = SPLIT ? blockIdx.z : 0u, level = a.levels[ly];
 	const uint32_t hs = a.gm->hashmap_size[level], offset = a.gm->offset[level];
@@ -1088,8 +1178,8 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	const size_t base = ((size_t)ly * a.max_chunks + c) * a.cap;
 	const uint16_t* idxs = a.idxs + base;
 	constexpr int U = 8; // records per thread in flight
-	if (SPLIT) {
-		const uint32_t* vals32 = (const uint32_t*)(a.vals + base) + fp; // this block's half2 of every 8-byte record
+	if constexpr (SPLIT) {
+		const uint32_t* vals32 = (const uint32_t*)((const uint2*)a.vals + base) + fp; // this block's half2 of every 8-byte record
 		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
 			uint32_t v[U], id[U];
 #pragma unroll
@@ -1101,8 +1191,8 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
 			}
 		}
-	} else {
-		const uint2* vals = a.vals + base;
+	} else if constexpr (F == 4) {
+		const uint2* vals = (const uint2*)a.vals + base;
 		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
 			uint2 v[U]; uint32_t id[U];
 #pragma unroll
@@ -1116,9 +1206,22 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 				atomicAdd(&acc[3 * E + id[u]], (unsigned long long)half_bits_to_fixed(v[u].y >> 16));
 			}
 		}
+	} else {
+		const uint32_t* vals = (const uint32_t*)a.vals + base;
+		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+			uint32_t v[U], id[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals[i]; id[u] = idxs[i]; } }
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (i0 + u * 1024 >= n) break;
+				atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u] & 0xffffu));
+				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
+			}
+		}
 	}
 	__syncthreads();
-	if (SPLIT) {
+	if constexpr (SPLIT) {
 		h2* gt = (h2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << CL2)) * 4) + fp;
 		for (uint32_t e = tid; e < E; e += 1024) {
 			const h2 old = gt[(size_t)e * 2]; // zero unless a list overflowed
@@ -1127,15 +1230,17 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 			gt[(size_t)e * 2] = r;
 		}
 	} else {
-		uint2* gt = (uint2*)((__half*)a.grid_grad_ + ((size_t)offset + (dense ? (size_t)c : ((size_t)c << CL2))) * 4);
+		typedef typename BinVal<F>::type val_t;
+		val_t* gt = (val_t*)((__half*)a.grid_grad_ + ((size_t)offset + (dense ? (size_t)c : ((size_t)c << CL2))) * F);
 		const uint32_t n_local = dense ? (hs > c ? (hs - c + (1u << NCH_LOG2) - 1u) >> NCH_LOG2 : 0u) : E; // dense: entries c, c + NCH, c + 2 NCH, ... < hs
 		for (uint32_t e = tid; e < n_local; e += 1024) {
 			const size_t o = dense ? ((size_t)e << NCH_LOG2) : (size_t)e;
-			const h4 old = __builtin_bit_cast(h4, gt[o]); // zero unless a list overflowed
-			h4 r;
+			const val_t oldv = gt[o]; // zero unless a list overflowed
+			const _Float16* old = (const _Float16*)&oldv;
+			float r[F];
 #pragma unroll
-			for (int f = 0; f < 4; ++f) r[f] = (_Float16)((float)old[f] + (float)(long long)acc[f * E + e] * 0x1p-24f);
-			gt[o] = __builtin_bit_cast(uint2, r);
+			for (int f = 0; f < F; ++f) r[f] = (float)old[f] + (float)(long long)acc[f * E + e] * 0x1p-24f;
+			gt[o] = pack_halfs<F>(r);
 		}
 	}
 }
@@ -1942,34 +2047,37 @@ static int num_cus() {
 }
 
 void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
-		ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset) {
+		ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset, uint32_t F) {
 	if (n_max == 0) return;
 	const uint32_t tiles = (n_max + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 4);
 	const bool pair = (g_debug_flags & DBG_FWD_PAIR_LOADS) != 0; // measured slower than plain per-lane gathers (profiles/r01_microbench_ablation4_gather.log)
 	const bool occ4 = (g_debug_flags & DBG_FWD_OCC4) != 0; // 4 waves/SIMD (128 VGPRs, spills) instead of 3 (168 VGPRs)
-#define NGP_LAUNCH_INF(D, P, W, LDS) hipLaunchKernelGGL((k_inference<D, 1, P, W>), dim3(grid), dim3(256), LDS, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset)
-	if (density_only) {
-		if (pair) { if (occ4) NGP_LAUNCH_INF(true, true, 4, 8 * 1024); else NGP_LAUNCH_INF(true, true, 3, 8 * 1024); }
-		else { if (occ4) NGP_LAUNCH_INF(true, false, 4, 8 * 1024); else NGP_LAUNCH_INF(true, false, 3, 8 * 1024); }
+#define NGP_LAUNCH_INF(D, P, W, LDS, FF) hipLaunchKernelGGL((k_inference<D, 1, P, W, FF>), dim3(grid), dim3(256), LDS, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset)
+	if (F == 2) { // L = 16, F = 2 (no ablation variants)
+		if (density_only) NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 2); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024, 2);
+	} else if (density_only) {
+		if (pair) { if (occ4) NGP_LAUNCH_INF(true, true, 4, 8 * 1024, 4); else NGP_LAUNCH_INF(true, true, 3, 8 * 1024, 4); }
+		else { if (occ4) NGP_LAUNCH_INF(true, false, 4, 8 * 1024, 4); else NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 4); }
 	} else {
-		if (pair) { if (occ4) NGP_LAUNCH_INF(false, true, 4, N_FW_FRAGS * 1024); else NGP_LAUNCH_INF(false, true, 3, N_FW_FRAGS * 1024); }
-		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024); }
+		if (pair) { if (occ4) NGP_LAUNCH_INF(false, true, 4, N_FW_FRAGS * 1024, 4); else NGP_LAUNCH_INF(false, true, 3, N_FW_FRAGS * 1024, 4); }
+		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024, 4); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024, 4); }
 	}
 #undef NGP_LAUNCH_INF
 }
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
-		ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la_in) {
+		ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la_in, uint32_t F) {
 	if (max_rays == 0) return;
 	K2LazyArgs la = la_in;
 	const uint32_t tpw = 32u / la.tile_w;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
+#define NGP_LAUNCH_TILES(TW, FF) hipLaunchKernelGGL((k_inference_tiles<TW, FF>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
-		if (la.tile_w == 8) hipLaunchKernelGGL((k_inference_tiles<8>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
-		else if (la.tile_w == 16) hipLaunchKernelGGL((k_inference_tiles<16>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
-		else hipLaunchKernelGGL((k_inference_tiles<32>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset);
+		if (F == 2) { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, 2); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, 2); else NGP_LAUNCH_TILES(32, 2); }
+		else { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, 4); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, 4); else NGP_LAUNCH_TILES(32, 4); }
 	}
+#undef NGP_LAUNCH_TILES
 	(void)max_samples;
 }
 void launch_encmlp_inference(hipStream_t s, const GridMeta* gm, uint32_t n_pos_dims, const ngp_half* grid, const ngp_half* fw_frags, const float* in, uint32_t in_stride,
@@ -1997,10 +2105,11 @@ void launch_encmlp_train(hipStream_t s, const EncTrainArgs& a, uint32_t n_pos_di
 	hipLaunchKernelGGL(k_encmlp_wgrad, dim3(n_partials), dim3(256), lds, s, a.fw_frags, a.bw_frags, a.n, (const uint2*)a.dy_stash, (const uint4*)a.enc_stash, wgrad_partials);
 	hipLaunchKernelGGL(k_encmlp_wgrad_reduce, dim3(N_EDW_TILES * 16), dim3(256), 0, s, wgrad_partials, n_partials, (__half*)mlp_grad);
 }
-void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out) {
+void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out, uint32_t F) {
 	if (n == 0) return;
 	const uint32_t waves = (n + 31) / 32;
-	hipLaunchKernelGGL(k_encode_only, dim3((waves + 3) / 4), dim3(256), 0, s, gm, (const __half*)grid, pos, stride, n, (__half*)out);
+	if (F == 2) hipLaunchKernelGGL(k_encode_only<2>, dim3((waves + 3) / 4), dim3(256), 0, s, gm, (const __half*)grid, pos, stride, n, (__half*)out);
+	else hipLaunchKernelGGL(k_encode_only<4>, dim3((waves + 3) / 4), dim3(256), 0, s, gm, (const __half*)grid, pos, stride, n, (__half*)out);
 }
 void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw) {
 	hipLaunchKernelGGL(k_build_frags, dim3((n_mlp + 255) / 256), dim3(256), 0, s, (const __half*)mlp_params, n_mlp, fw_perm, bw_perm, (__half*)fw, (__half*)bw);
@@ -2010,6 +2119,16 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	if (a.n == 0 || a.n_hashed == 0) return;
 	static const uint32_t ns = getenv("NGP_BIN_SAMPLES") ? (uint32_t)atoi(getenv("NGP_BIN_SAMPLES")) : 512u;
 	const dim3 gb((a.n + ns - 1) / ns, a.n_hashed);
+	if (a.n_features == 2) { // L = 16, F = 2: one block per chunk, both features (4-byte record values)
+		if (a.chunk_log2 == 11) {
+			hipLaunchKernelGGL((k_grad_bin<11, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
+			hipLaunchKernelGGL((k_grad_accumulate<11, false, 2>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		} else {
+			hipLaunchKernelGGL((k_grad_bin<12, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
+			hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		}
+		return;
+	}
 	if (a.chunk_log2 == 11) {
 		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<11, 256>), gb, dim3(256), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
@@ -2023,10 +2142,19 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	}
 }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap) {
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t F) {
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
+	if (F == 2) { // L = 16, F = 2: every level through the lists (no atomics in T1) or, without lists, per-corner atomics
+		if ((flags & T1_DENSE_EXTERNAL) && denc_lv)
+			hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
+				(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
+		else
+			hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, true, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
+				(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
+		return;
+	}
 	// 3 wavefronts per SIMD without spills (164 registers) beat 4 with 36 spilled registers: T1 + bin + accumulate 0.219 vs 0.244 ms (profiles/r02_t1_occupancy.txt)
 	static const int t1_occ = getenv("NGP_T1_OCC") ? atoi(getenv("NGP_T1_OCC")) : 3;
 	if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3)

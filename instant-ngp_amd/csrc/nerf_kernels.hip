@@ -1187,10 +1187,15 @@ static __device__ __forceinline__ void update_counters_body(TrainCounters* c, ui
 // With `ctl` the batch-size controller (k_update_counters) rides along: the last workgroup to finish -- a ticket counter; every read of
 // K3's counter precedes the workgroup's ticket -- runs it, so the step has one launch (and one inter-kernel gap) less on its critical path.
 __global__ void __launch_bounds__(256) k_fill_rollover(uint32_t n_elements, const uint32_t* __restrict__ n_input_ptr, float* __restrict__ coords, uint32_t cstride,
-		__half* __restrict__ dloss, uint32_t dstride, const uint32_t* __restrict__ publish_src2, uint32_t* __restrict__ publish_dst2,
-		TrainCounters* ctl, uint32_t ctl_world_size) {
-	// the two counters every rank must agree on (8e) are published here instead of by a separate copy
-	if (publish_dst2 && blockIdx.x == 0 && threadIdx.x == 0) { publish_dst2[0] = publish_src2[0]; publish_dst2[1] = publish_src2[1]; }
+		__half* __restrict__ dloss, uint32_t dstride, const uint32_t* __restrict__ publish_src2, uint32_t* __restrict__ publish_dst2, const float* __restrict__ publish_loss,
+		TrainCounters* ctl, uint32_t ctl_world_size, int zero_padding) {
+	// the words every rank must agree on (8e) are published here instead of by a separate copy: {marched, compacted} samples and this rank's
+	// share of the loss (K3 normalises by the GLOBAL ray count, so the sum over ranks is the loss of the union batch) as unsigned fixed point
+	// in units of 2^-24 -- one integer all-reduce(sum) covers all three
+	if (publish_dst2 && blockIdx.x == 0 && threadIdx.x == 0) {
+		publish_dst2[0] = publish_src2[0]; publish_dst2[1] = publish_src2[1];
+		if (publish_loss) { const float l = *publish_loss; publish_dst2[2] = l > 0.f ? (uint32_t)(fminf(l, 16.f) * 16777216.f) : 0u; } // NaN -> 0
+	}
 	const uint32_t n_in = min(*n_input_ptr, n_elements); // K3's counter may overshoot the batch (its spans are clamped)
 	if (n_in != 0 && n_in < n_elements) {
 		const float n_input = (float)(n_in * dstride), n_total = (float)(n_elements * dstride);
@@ -1201,7 +1206,7 @@ __global__ void __launch_bounds__(256) k_fill_rollover(uint32_t n_elements, cons
 			for (uint32_t k = 0; k < cstride; ++k) coords[(size_t)e * cstride + k] = coords[(size_t)src * cstride + k];
 			for (uint32_t k = 0; k < dstride; ++k) {
 				float v = __half2float(dloss[(size_t)src * dstride + k]);
-				dloss[(size_t)e * dstride + k] = __float2half(v * n_input / n_total);
+				dloss[(size_t)e * dstride + k] = __float2half(zero_padding ? 0.f : v * n_input / n_total);
 			}
 		}
 	}
@@ -1405,10 +1410,10 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	}
 }
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
-		const uint32_t* publish_src2, uint32_t* publish_dst2, TrainCounters* ctl, uint32_t ctl_world_size) {
+		const uint32_t* publish_src2, uint32_t* publish_dst2, TrainCounters* ctl, uint32_t ctl_world_size, const float* publish_loss) {
 	// grid-stride over the padding (typically 5 - 15 % of the batch); few workgroups keep the controller's ticket cheap
 	hipLaunchKernelGGL(k_fill_rollover, dim3(std::min<uint32_t>(blocks(n_elements, 256), 128u)), dim3(256), 0, s, n_elements, n_input_ptr, coords, cstride, (__half*)dloss, dstride,
-		publish_src2, publish_dst2, ctl, ctl_world_size);
+		publish_src2, publish_dst2, publish_loss, ctl, ctl_world_size, (g_debug_flags & DBG_K4_ZERO_PADDING) ? 1 : 0);
 }
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear) {
 	hipLaunchKernelGGL(k_mark_untrained, dim3(blocks(n, 128)), dim3(128), 0, s, n, grid, n_images, m, x, clear);

@@ -102,6 +102,21 @@ extern "C" int ngp_profile_read(double* ms_sum, uint64_t* launches) {
 	return 0;
 }
 
+// Helper streams are created with the object that uses them, and one tiny command makes HIP create the stream's hardware queue right away.  Created lazily
+// (inside the first training step) they used to come into existence AFTER a data-parallel caller's RCCL communicator, and in that order every kernel of the
+// step ran 1.3 - 2x longer (+20 us even for one-wavefront kernels): 1.12 ms per step against 0.66 ms with the communicator created after the first steps
+// (profiles/r03_dp_overhead.txt).  NGP_LAZY_STREAMS=1 restores the old order (diagnostic).
+static bool lazy_streams() { static const bool v = getenv("NGP_LAZY_STREAMS") && atoi(getenv("NGP_LAZY_STREAMS")) != 0; return v; }
+static int create_helper_stream(hipStream_t* st, bool high_priority) {
+	if (*st) return 0;
+	if (high_priority) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi)); }
+	else HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+	static uint32_t* scratch = nullptr;
+	if (!scratch) HIPCHK(hipMalloc((void**)&scratch, 256));
+	HIPCHK(hipMemsetAsync(scratch, 0, 4, *st));
+	HIPCHK(hipStreamSynchronize(*st));
+	return 0;
+}
 template <typename T> static int dev_alloc(T** p, size_t n) { HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T))); return 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,7 +259,10 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 	REQUIRE(cfg && out, "ngp_model_create: null argument");
 	REQUIRE(cfg->n_neurons == 64 && cfg->n_hidden_layers == 1 && cfg->n_hidden_layers_rgb == 2,
 		"this build specialises the fused kernels for configs/nerf/base.json topology (64 neurons, 1+2 hidden layers)");
-	REQUIRE(cfg->n_features_per_level == 4 && cfg->n_levels == 8, "fused kernels are specialised for L=8, F=4 (configs/nerf/base.json)");
+	// the encoding feeds the 32-wide first layer directly in MFMA operand registers: L x F = 8 x 4 (configs/nerf/base.json) or 16 x 2 (the reference's 2022
+	// base.json, notebooks/instant_ngp.ipynb:5838); any log2_hashmap_size (base_14, small, big: table sizes the record lists do not cover fall back to half atomics)
+	REQUIRE((cfg->n_features_per_level == 4 && cfg->n_levels == 8) || (cfg->n_features_per_level == 2 && cfg->n_levels == 16), "the fused kernels take the hash grid as L = 8, F = 4 or L = 16, F = 2");
+	REQUIRE(cfg->log2_hashmap_size >= 12 && cfg->log2_hashmap_size <= 24 && cfg->base_resolution >= 2 && cfg->per_level_scale >= 1.0f, "hash grid: log2_hashmap_size in [12, 24], base_resolution >= 2, per_level_scale >= 1");
 	REQUIRE(cfg->sh_degree == 4 && cfg->n_extra_dims == 0, "only SphericalHarmonics degree 4 without extra dims is implemented");
 	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
 	ngp_model* m = new ngp_model();
@@ -281,6 +299,7 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 	HIPCHK(hipMemcpy(m->master, init.data(), P * 4, hipMemcpyHostToDevice));
 	if (model_refresh_half(m, nullptr)) { delete m; return 1; }
 	HIPCHK(hipDeviceSynchronize());
+	if (!lazy_streams() && create_helper_stream(&m->side, false)) { delete m; return 1; } // W's stream (see create_helper_stream)
 	*out = m;
 	return 0;
 }
@@ -348,20 +367,20 @@ extern "C" int ngp_model_inference(ngp_model* m, void* stream, const float* in, 
 		ngp_half* out, uint32_t out_stride, int use_inference_params) {
 	REQUIRE(in_stride >= 7 && out_stride >= 4 && out_stride % 4 == 0, "inference: in_stride >= 7, out_stride a multiple of 4 halfs");
 	{ ProfScope ps(P_K2_INFERENCE, (hipStream_t)stream);
-	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), in, in_stride, n_max, n_ptr, out, out_stride, false, 4); }
+	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), in, in_stride, n_max, n_ptr, out, out_stride, false, 4, m->gm.F); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 extern "C" int ngp_model_density(ngp_model* m, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out, uint32_t out_stride, int use_inference_params) {
 	REQUIRE(pos_stride >= 3 && out_stride >= 1, "density: bad strides");
 	{ ProfScope ps(P_GRID_DENSITY, (hipStream_t)stream);
-	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), pos, pos_stride, n, nullptr, out, out_stride, true, 0); }
+	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), pos, pos_stride, n, nullptr, out, out_stride, true, 0, m->gm.F); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 // test hook: grid encoding only (natural feature order), not part of the reference API surface
 extern "C" int ngp_model_encode(ngp_model* m, void* stream, const float* pos, uint32_t pos_stride, uint32_t n, ngp_half* out32) {
-	launch_encode_only((hipStream_t)stream, m->gm_dev, m->params + m->n_mlp, pos, pos_stride, n, out32);
+	launch_encode_only((hipStream_t)stream, m->gm_dev, m->params + m->n_mlp, pos, pos_stride, n, out32, m->gm.F);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -379,7 +398,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	}
 	// binned scatter: every hashed level must have a power-of-two table of 2^chunk_log2 .. 2^19 entries (base.json: 2^19)
 	GradBinArgs& ba = m->bin_args;
-	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split; ba.merge_runs = !(g_debug_flags & DBG_BIN_NO_HASHED_MERGE); ba.no_dense_merge = (g_debug_flags & DBG_BIN_NO_DENSE_MERGE) != 0;
+	ba.n_hashed = 0; ba.max_chunks = 0; ba.chunk_log2 = g_bin_chunk_log2; ba.split = g_bin_split && m->gm.F == 4; ba.merge_runs = !(g_debug_flags & DBG_BIN_NO_HASHED_MERGE); ba.no_dense_merge = (g_debug_flags & DBG_BIN_NO_DENSE_MERGE) != 0;
 	if (!(g_debug_flags & DBG_T1_NO_BINNING)) {
 		bool ok = true;
 		// The dense levels go through the lists as well (entries interleaved over all 2^(19 - chunk_log2) chunks, see k_grad_bin): T1 issues no
@@ -419,8 +438,8 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		const uint32_t n_alloc = std::max(n, m->bin_n);
 		m->denc_lv = m->bin_vals = m->bin_idxs = nullptr; m->bin_cursors = nullptr; m->bin_n = 0;
 		const size_t n_lists = (size_t)ba.n_hashed * ba.max_chunks;
-		HIPCHK(hipMalloc(&m->denc_lv, (size_t)m->gm.n_levels * n_alloc * 8));
-		HIPCHK(hipMalloc(&m->bin_vals, n_lists * cap_want * 8));
+		HIPCHK(hipMalloc(&m->denc_lv, (size_t)m->gm.n_levels * n_alloc * m->gm.F * 2));
+		HIPCHK(hipMalloc(&m->bin_vals, n_lists * cap_want * m->gm.F * 2));
 		HIPCHK(hipMalloc(&m->bin_idxs, n_lists * cap_want * 2));
 		HIPCHK(hipMalloc((void**)&m->bin_cursors, n_lists * 2 * 4)); // cursors + the split variant's arrival counters
 		HIPCHK(hipMemsetAsync(m->bin_cursors, 0, n_lists * 2 * 4, s));
@@ -432,15 +451,16 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	// dense levels (ablation DBG_T1_DENSE_EXTERNAL): T1 leaves their dL/d(enc) in denc_lv as well and k_grad_dense issues the atomics beside the kernels below
 	GradDenseArgs da;
 	da.n_levels = 0;
-	if (ba.n_hashed && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !m->bin_dense && !(g_debug_flags & DBG_T1_NO_SCATTER))
+	if (ba.n_hashed && m->gm.F == 4 && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !m->bin_dense && !(g_debug_flags & DBG_T1_NO_SCATTER))
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
 	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
-		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n); }
+		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n, m->gm.F); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
 	hipStream_t sw = s;
 	if (overlap) {
-		if (!m->side) { HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming)); }
+		if (!m->side) { if (create_helper_stream(&m->side, false)) return 1; }
+		if (!m->ev_fork) { HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
 		sw = m->side;
 	}
@@ -448,7 +468,8 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		da.gm = m->gm_dev; da.in = in; da.in_stride = in_stride; da.n = n; da.denc_lv = (const uint2*)m->denc_lv; da.denc_cap = m->bin_n;
 		da.merge_runs = !(g_debug_flags & DBG_T1_NO_MERGE); da.grid_grad_ = m->grads + m->n_mlp;
 		if (overlap) {
-			if (!m->side2) { HIPCHK(hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming)); }
+			if (!m->side2) { if (create_helper_stream(&m->side2, false)) return 1; }
+			if (!m->ev_join2) HIPCHK(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming));
 			HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork, 0));
 			launch_grad_dense(m->side2, da);
 			HIPCHK(hipEventRecord(m->ev_join2, m->side2));
@@ -458,8 +479,8 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads); }
 	if (ba.n_hashed) {
 		ProfScope ps(P_GRAD_BIN, s);
-		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = (const uint2*)m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap;
-		ba.vals = (uint2*)m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
+		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap; ba.n_features = m->gm.F;
+		ba.vals = m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
 		launch_grad_bin(s, ba);
 		if (da.n_levels && !overlap) launch_grad_dense(s, da); // profiling / single-stream mode: part of the same scope (one unit of algorithmic work)
 	}
@@ -778,8 +799,10 @@ extern "C" int ngp_sdf_normalize_mesh_host(float* v, uint64_t n_vertices, ngp_aa
 	if (mesh_scale_out) *mesh_scale_out = scale;
 	return 0;
 }
-static void sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode>& nodes, uint32_t leaf_size) {
-	struct Job { int node; size_t begin, end; };
+// returns the depth of the tree (root = 0): the device traversals keep at most depth + 1 nodes on their 64-entry stacks
+static uint32_t sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode>& nodes, uint32_t leaf_size) {
+	struct Job { int node; size_t begin, end; uint32_t depth; };
+	uint32_t max_depth = 0;
 	auto bounds = [&](size_t b, size_t e, SdfBvhNode& n) {
 		for (int k = 0; k < 3; ++k) { n.bmin[k] = INFINITY; n.bmax[k] = -INFINITY; }
 		for (size_t i = b; i < e; ++i) for (const float* p : {tris[i].a, tris[i].b, tris[i].c}) for (int k = 0; k < 3; ++k) { n.bmin[k] = std::min(n.bmin[k], p[k]); n.bmax[k] = std::max(n.bmax[k], p[k]); }
@@ -787,9 +810,10 @@ static void sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode
 	auto centroid = [](const SdfTriangle& t, int k) { return (t.a[k] + t.b[k] + t.c[k]) / 3; };
 	nodes.clear(); nodes.emplace_back();
 	bounds(0, tris.size(), nodes[0]);
-	std::vector<Job> stack{{0, 0, tris.size()}};
+	std::vector<Job> stack{{0, 0, tris.size(), 0u}};
 	while (!stack.empty()) {
 		const Job j = stack.back(); stack.pop_back();
+		max_depth = std::max(max_depth, j.depth);
 		if (j.end - j.begin <= leaf_size) { nodes[j.node].left = -(int)j.begin - 1; nodes[j.node].right = -(int)j.end - 1; continue; }
 		// axis of maximum centroid variance, median split (triangle_bvh.cu:788-809)
 		double mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
@@ -802,8 +826,9 @@ static void sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode
 		const int l = (int)nodes.size(); nodes.emplace_back(); nodes.emplace_back();
 		nodes[j.node].left = l; nodes[j.node].right = l + 1;
 		bounds(j.begin, mid, nodes[l]); bounds(mid, j.end, nodes[l + 1]);
-		stack.push_back({l, j.begin, mid}); stack.push_back({l + 1, mid, j.end});
+		stack.push_back({l, j.begin, mid, j.depth + 1}); stack.push_back({l + 1, mid, j.end, j.depth + 1});
 	}
+	return max_depth;
 }
 extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, uint32_t n_triangles, ngp_aabb aabb, const ngp_sdf_options* o, ngp_sdf** out) {
 	REQUIRE(model && triangles_host && o && out && n_triangles > 0, "ngp_sdf_create: null / empty argument");
@@ -815,7 +840,8 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	std::vector<SdfTriangle> tris(n_triangles);
 	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
 	std::vector<SdfBvhNode> nodes;
-	sdf_build_bvh(tris, nodes, 8); // m_sdf.triangle_bvh->build(triangles_cpu, 8); reorders the triangles
+	const uint32_t bvh_depth = sdf_build_bvh(tris, nodes, 8); // m_sdf.triangle_bvh->build(triangles_cpu, 8); reorders the triangles
+	if (bvh_depth + 2 > 64) { delete t; return fail("ngp_sdf_create: BVH deeper than the device traversal stack (64 entries)"); } // median split: depth = ceil(log2(n / 8)) <= 29
 	// DiscreteDistribution::build over the surface areas (discrete_distribution.h:21-38) -- of the REORDERED triangles, like the reference
 	std::vector<float> cdf(n_triangles);
 	{
@@ -1125,7 +1151,7 @@ struct ngp_nerf {
 	char* k3_scratch = nullptr; // per-ray records / workgroup totals of the two-pass K3
 	uint8_t* bitfield_linear = nullptr; // x-major copy of the bitfield for the lattice marchers
 	uint32_t* bitfield_coarse = nullptr; // one bit per 4x4x4 cells of it (k1_count's prefilter)
-	uint32_t* sync2 = nullptr; // {measured_before, measured} for the cross-rank all-reduce
+	uint32_t* sync2 = nullptr; // {measured_before, measured, loss sum in units of 2^-24} for the cross-rank all-reduce (4 words allocated)
 	// in-library data-parallel step over RCCL (ngp_comm_init): communicator, its stream, bucket-reduced events
 	void* comm = nullptr; hipStream_t comm_stream = nullptr; hipEvent_t ev_red_a = nullptr, ev_red_b = nullptr; bool grads_pending = false;
 	// host-side deterministic state (no device read-back needed)
@@ -1154,7 +1180,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->grid_positions_sorted, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices_sorted, n_cells) || dev_alloc(&t->grid_sort_temp, t->grid_sort_temp_bytes = grid_sample_sort_temp_bytes(n_cells)) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 2) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * (o->max_cascade + 1) * 2) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * (o->max_cascade + 1) * 2) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays)) || dev_alloc(&t->k3_scratch, k3_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || k3_scratch_init(nullptr, t->k3_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
@@ -1167,7 +1193,8 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
 	c.measured_batch_size_before_compaction = max_samples;
 	HIPCHK(hipMemcpy(t->counters, &c, sizeof(c), hipMemcpyHostToDevice));
-	HIPCHK(hipMemset(t->sync2, 0, 8));
+	HIPCHK(hipMemset(t->sync2, 0, 16));
+	if (!lazy_streams() && create_helper_stream(&t->k1_stream, true)) { delete t; return 1; } // the pre-launched K1's stream (see create_helper_stream)
 	*out = t;
 	return 0;
 }
@@ -1270,7 +1297,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	}
 	// NerfNetwork::density with the TRAINING params (use_inference_params = false, testbed_nerf.cu:2570)
 	{ ProfScope ps(P_GRID_DENSITY, s);
-	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), eval_pos, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0); }
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), eval_pos, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0, t->model->gm.F); }
 	ProfScope ps2(P_GRID_MISC, s);
 	launch_splat_grid_samples(s, n_samples, eval_idx, t->grid_mlp_out, 1, t->density_grid_tmp, t->opt.density_activation);
 	launch_ema_grid_samples(s, n_elements, decay, t->density_grid, t->density_grid_tmp);
@@ -1346,9 +1373,9 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		la.n_rays_ptr = &c->ray_counter; la.tiles[0] = t->k2_tiles; la.tiles[1] = t->k2_tiles + t->k2_tile_cap; la.tile_cap = t->k2_tile_cap;
 		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_rounds = t->k2_rounds; la.tile_w = t->k2_tile_w; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
 		{ const float max_stepsize = MIN_CONE_STEP * (float)(1 << (N_CASCADES - 1)); la.dt_unwarp_scale = max_stepsize - MIN_CONE_STEP; la.dt_unwarp_offset = MIN_CONE_STEP; } // unwarp_dt
-		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la);
+		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la, t->model->gm.F);
 	  } else
-	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4); }
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4, t->model->gm.F); }
 	K3Args k3;
 	k3.n_rays = 0; k3.n_rays_ptr = &c->rays_per_batch; k3.aabb = t->aabb; k3.rng = pod(t->rng); k3.max_samples_compacted = B; k3.rays_counter = &c->ray_counter;
 	k3.loss_scale = o.loss_scale; for (int k = 0; k < 3; ++k) k3.background_color[k] = o.background_color[k];
@@ -1362,7 +1389,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	// single rank, forward and backward in one call: the controller rides on K4's last workgroup (no launch of its own)
 	const bool fuse_ctl = (phase & 2) && o.world_size == 1 && !(g_debug_flags & DBG_SEPARATE_CONTROLLER);
-	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2, fuse_ctl ? c : nullptr, o.world_size); }
+	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2, fuse_ctl ? c : nullptr, o.world_size, &c->loss_sum); }
 	if (fuse_ctl) t->ctl_done = true;
 	}
 	if (phase & 2) {
@@ -1376,8 +1403,8 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	}
 	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t);
 	if (prelaunch) {
-		if (!t->k1_stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
-			HIPCHK(hipStreamCreateWithPriority(&t->k1_stream, hipStreamNonBlocking, hi)); HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
+		if (!t->k1_stream) { if (create_helper_stream(&t->k1_stream, true)) return 1; } // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
+		if (!t->ev_ctl) { HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(t->ev_ctl, s));
 	}
 	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
@@ -1406,6 +1433,8 @@ __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t 
 	const uint32_t avg_before = (sync2[0] + world_size - 1) / world_size;
 	c->numsteps_counter = avg_before + avg_before / 8; // slack: K1's cap must cover ranks above the average
 	c->numsteps_counter_compacted = (sync2[1] + world_size - 1) / world_size;
+	// K3 normalises every ray's loss by the GLOBAL ray count, so the sum over ranks is the loss of the union batch (Testbed.loss under data parallelism)
+	c->loss_sum = (float)sync2[2] * (1.0f / 16777216.f);
 }
 
 // optimizer_step + NerfCounters::update_after_training, testbed_nerf.cu:2770-2778
@@ -1490,7 +1519,7 @@ extern "C" int ngp_allreduce_gradients(ngp_nerf* t, void* stream) {
 static bool dp_skip_allreduce() { static const bool v = getenv("NGP_DP_SKIP_ALLREDUCE") && atoi(getenv("NGP_DP_SKIP_ALLREDUCE")) != 0; return v; } // diagnostic: the step's structure without the RCCL calls
 extern "C" int ngp_allreduce_counters(ngp_nerf* t, void* stream) {
 	REQUIRE(t && t->comm, "ngp_allreduce_counters: ngp_comm_init has not been called");
-	if (!dp_skip_allreduce()) RCCLCHK(g_rccl.AllReduce(t->sync2, t->sync2, 2, kNcclUint32, kNcclSum, t->comm, (hipStream_t)stream));
+	if (!dp_skip_allreduce()) RCCLCHK(g_rccl.AllReduce(t->sync2, t->sync2, 3, kNcclUint32, kNcclSum, t->comm, (hipStream_t)stream));
 	return 0;
 }
 // Gradient all-reduce behind ngp_nerf_train_backward: ONE ring over the whole fp16 gradient vector on the CALLER's stream.  Every level goes
@@ -1608,7 +1637,7 @@ extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_param
 		for (uint32_t round = 0, group = 2; n_alive > 0 && round < max_rounds; group = std::min(group * 2, 16u)) {
 			for (uint32_t g = 0; g < group && round < max_rounds; ++g, ++round) {
 				launch_render_emit(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords);
-				launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7, n_alive * RENDER_STEPS, t->r_n_inf, t->r_out, 4, false, 4);
+				launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7, n_alive * RENDER_STEPS, t->r_n_inf, t->r_out, 4, false, 4, t->model->gm.F);
 				launch_render_composite(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords, t->r_out);
 				launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
 			}

@@ -335,18 +335,21 @@ NGP_HD void opencv_distortion_delta(const float* p, float u, float v, float* du,
 	*du = u * radial + 2.f * p1 * uv + p2 * (r2 + 2.f * u2);
 	*dv = v * radial + 2.f * p2 * uv + p1 * (r2 + 2.f * v2);
 }
-NGP_HD void opencv_undistort(const float* params, float* u, float* v) {
+// Inverse of x -> x + delta(x) by Newton's method with a central-difference Jacobian (the reference's iterative_lens_undistortion,
+// common_device.cuh:307-345), one loop for every distortion function
+template <typename Delta>
+NGP_HD void newton_undistort(const Delta& delta, const float* params, float* u, float* v) {
 	const float eps = 1.1920929e-07f;
 	const float x00 = *u, x01 = *v;
 	float x0 = *u, x1 = *v;
 	for (uint32_t i = 0; i < 100; ++i) {
 		const float step0 = fmaxf(eps, fabsf(1e-6f * x0)), step1 = fmaxf(eps, fabsf(1e-6f * x1));
 		float dx0, dx1, b0x, b0y, f0x, f0y, b1x, b1y, f1x, f1y;
-		opencv_distortion_delta(params, x0, x1, &dx0, &dx1);
-		opencv_distortion_delta(params, x0 - step0, x1, &b0x, &b0y);
-		opencv_distortion_delta(params, x0 + step0, x1, &f0x, &f0y);
-		opencv_distortion_delta(params, x0, x1 - step1, &b1x, &b1y);
-		opencv_distortion_delta(params, x0, x1 + step1, &f1x, &f1y);
+		delta(params, x0, x1, &dx0, &dx1);
+		delta(params, x0 - step0, x1, &b0x, &b0y);
+		delta(params, x0 + step0, x1, &f0x, &f0y);
+		delta(params, x0, x1 - step1, &b1x, &b1y);
+		delta(params, x0, x1 + step1, &f1x, &f1y);
 		float J00 = 1 + (f0x - b0x) / (2 * step0), J10 = (f1x - b1x) / (2 * step1);
 		float J01 = (f0y - b0y) / (2 * step0), J11 = 1 + (f1y - b1y) / (2 * step1);
 		float r0 = x0 + dx0 - x00, r1 = x1 + dx1 - x01;
@@ -357,6 +360,8 @@ NGP_HD void opencv_undistort(const float* params, float* u, float* v) {
 	}
 	*u = x0; *v = x1;
 }
+struct OpencvDelta { NGP_HD void operator()(const float* p, float u, float v, float* du, float* dv) const { opencv_distortion_delta(p, u, v, du, dv); } };
+NGP_HD void opencv_undistort(const float* params, float* u, float* v) { newton_undistort(OpencvDelta{}, params, u, v); }
 // ---- the other lens models of common_device.cuh:283-411 (own restatement; the Perspective / OpenCV arithmetic above is untouched) ----
 NGP_HD void opencv_fisheye_distortion_delta(const float* p, float u, float v, float* du, float* dv) {
 	const float r = sqrtf(u * u + v * v);
@@ -368,29 +373,8 @@ NGP_HD void opencv_fisheye_distortion_delta(const float* p, float u, float v, fl
 		*dv = v * thetad / r - v;
 	}
 }
-// Newton iteration with central differences, the reference's iterative_lens_undistortion for the fisheye distortion function
-NGP_HD void opencv_fisheye_undistort(const float* params, float* u, float* v) {
-	const float eps = 1.1920929e-07f;
-	const float x00 = *u, x01 = *v;
-	float x0 = *u, x1 = *v;
-	for (uint32_t i = 0; i < 100; ++i) {
-		const float step0 = fmaxf(eps, fabsf(1e-6f * x0)), step1 = fmaxf(eps, fabsf(1e-6f * x1));
-		float dx0, dx1, b0x, b0y, f0x, f0y, b1x, b1y, f1x, f1y;
-		opencv_fisheye_distortion_delta(params, x0, x1, &dx0, &dx1);
-		opencv_fisheye_distortion_delta(params, x0 - step0, x1, &b0x, &b0y);
-		opencv_fisheye_distortion_delta(params, x0 + step0, x1, &f0x, &f0y);
-		opencv_fisheye_distortion_delta(params, x0, x1 - step1, &b1x, &b1y);
-		opencv_fisheye_distortion_delta(params, x0, x1 + step1, &f1x, &f1y);
-		float J00 = 1 + (f0x - b0x) / (2 * step0), J10 = (f1x - b1x) / (2 * step1);
-		float J01 = (f0y - b0y) / (2 * step0), J11 = 1 + (f1y - b1y) / (2 * step1);
-		float r0 = x0 + dx0 - x00, r1 = x1 + dx1 - x01;
-		float det = J00 * J11 - J10 * J01;
-		float s0 = (J11 * r0 - J10 * r1) / det, s1 = (-J01 * r0 + J00 * r1) / det;
-		x0 -= s0; x1 -= s1;
-		if (s0 * s0 + s1 * s1 < 1e-10f) break;
-	}
-	*u = x0; *v = x1;
-}
+struct OpencvFisheyeDelta { NGP_HD void operator()(const float* p, float u, float v, float* du, float* dv) const { opencv_fisheye_distortion_delta(p, u, v, du, dv); } };
+NGP_HD void opencv_fisheye_undistort(const float* params, float* u, float* v) { newton_undistort(OpencvFisheyeDelta{}, params, u, v); }
 // f-theta: params = polynomial r0..r4 in the pixel radius, then the resolution the intrinsics refer to; (0,0,0) = no ray
 NGP_HD f3 f_theta_direction(float u, float v, const float* params) {
 	const float xpix = u * params[5], ypix = v * params[6];

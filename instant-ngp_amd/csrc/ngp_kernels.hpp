@@ -19,6 +19,7 @@ enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
 	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
+	DBG_K4_ZERO_PADDING = 67108864 /* test hook: the rows K4 pads the compacted batch with carry a zero loss gradient instead of the rescaled copy (the padding is the only part of a step that is not linear in the set of rays: tests/test_gpu_dist.py compares the 2-rank sum with the 1-rank gradient without it) */,
 	DBG_K1_INDEPENDENT_LATTICE = 16384 /* lattice K1 without the exact skip rule: every lattice point tested on its own (round-1 behaviour; exact only for cone_angle == 0) */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
@@ -97,7 +98,8 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse = nullptr);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
-	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr, TrainCounters* ctl = nullptr /* run the batch-size controller behind the fill */, uint32_t ctl_world_size = 1);
+	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr, TrainCounters* ctl = nullptr /* run the batch-size controller behind the fill */, uint32_t ctl_world_size = 1,
+	const float* publish_loss = nullptr /* this rank's loss sum -> publish_dst2[2], unsigned fixed point in units of 2^-24 */);
 void launch_mark_untrained(hipStream_t s, uint32_t n, float* grid, uint32_t n_images, const ngp_image_meta* m, const ngp_xform* x, int clear);
 void launch_generate_grid_samples(hipStream_t s, uint32_t n, ngp_pcg32 rng, const uint32_t* step_ptr, uint32_t step, ngp_aabb box, const float* grid_in,
 	float* pos, uint32_t* idx, uint32_t n_cascades, float thresh);
@@ -147,9 +149,9 @@ struct K2LazyArgs {
 	uint32_t tile_w;                // samples per tile: 16 (two rays' tiles per wavefront) or 32
 };
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
-	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la);
+	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la, uint32_t n_features = 4);
 void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
-	ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset);
+	ngp_half* out, uint32_t out_stride, bool density_only, uint32_t dir_offset, uint32_t n_features = 4 /* F: 4 (L = 8) or 2 (L = 16) */);
 // encoding (D = 2 / 3, L = 16, F = 2) + MLP 32 -> 64 -> 64 -> 16, forward only (image / SDF primitives' model)
 void launch_encmlp_inference(hipStream_t s, const GridMeta* gm_dev, uint32_t n_pos_dims, const ngp_half* grid, const ngp_half* fw_frags, const float* in, uint32_t in_stride,
 	uint32_t n, ngp_half* out, uint32_t out_stride, uint32_t n_out);
@@ -165,7 +167,7 @@ struct EncTrainArgs {
 	float* loss_sum; ngp_half* pred_out; uint32_t pred_stride; // optional: sum of the per-element loss values, network outputs
 };
 void launch_encmlp_train(hipStream_t s, const EncTrainArgs& a, uint32_t n_pos_dims, bool external_dy, float* wgrad_partials, uint32_t n_partials, ngp_half* mlp_grad);
-void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out);
+void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out, uint32_t n_features = 4);
 void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_mlp, const uint32_t* fw_perm, const uint32_t* bw_perm, ngp_half* fw, ngp_half* bw);
 uint32_t wgrad_n_partials();
 
@@ -175,10 +177,11 @@ constexpr uint32_t GRAD_BIN_MAX_TABLE_LOG2 = 19; // hashmap sizes up to 2^19 (2^
 // 2^11: 64 KiB, two blocks per CU).  split: round-1 layout, one block per (chunk, feature pair) -- both blocks fetch every record.
 struct GradBinArgs {
 	const GridMeta* gm; const float* in; uint32_t in_stride, n;
-	const uint2* denc_lv; uint32_t denc_cap;
+	const void* denc_lv; uint32_t denc_cap; // level-major dL/d(enc): F halfs per (level, sample)
 	uint32_t levels[MAX_LEVELS]; uint32_t n_hashed, max_chunks, cap;
 	uint32_t chunk_log2, split, merge_runs, no_dense_merge;
-	uint2* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
+	uint32_t n_features; // F: 4 (8-byte record values) or 2 (4-byte)
+	void* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
 };
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
 struct GradDenseArgs { // k_grad_dense: the dense levels' scatter from T1's level-major dL/d(enc)
@@ -190,7 +193,7 @@ struct GradDenseArgs { // k_grad_dense: the dense levels' scatter from T1's leve
 void launch_grad_dense(hipStream_t s, const GradDenseArgs& a);
 constexpr uint32_t T1_DENSE_EXTERNAL = 1u << 31; // launch_train_fwd_bwd flag (not a debug flag): dense levels' dL/d(enc) goes to denc_lv too, no scatter in T1
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap);
+	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t n_features = 4);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad);

@@ -67,18 +67,22 @@ static __device__ __forceinline__ float bb_ray_entry(const SdfBvhNode& n, f3 o, 
 
 // closest_triangle(...).second: distance to the nearest triangle, bounded above by sqrt(max_distance_sq)
 static __device__ float bvh_unsigned_distance(f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance_sq) {
-	int stack[64]; int sp = 0;
-	stack[sp++] = 0;
+	// stack depth: ngp_sdf_create checks the tree's depth against the 64 entries.  An entry carries its box distance, so a node that became
+	// farther than the best hit while it waited on the stack is dropped when it is popped.
+	int stack[64]; float sdist[64]; int sp = 0;
+	stack[sp] = 0; sdist[sp++] = 0.f;
 	float best = max_distance_sq; bool found = false;
 	while (sp > 0) {
-		const SdfBvhNode& n = nodes[stack[--sp]];
+		--sp;
+		if (sdist[sp] > best) continue;
+		const SdfBvhNode& n = nodes[stack[sp]];
 		if (n.left < 0) {
 			for (int i = -n.left - 1; i < -n.right - 1; ++i) { const float d = tri_distance_sq(tris[i], p); if (d <= best) { best = d; found = true; } }
 		} else {
 			const float dl = bb_distance_sq(nodes[n.left], p), dr = bb_distance_sq(nodes[n.right], p);
 			// far child first onto the stack, so the near one is popped next
-			if (dl <= dr) { if (dr <= best && sp < 63) stack[sp++] = n.right; if (dl <= best && sp < 63) stack[sp++] = n.left; }
-			else { if (dl <= best && sp < 63) stack[sp++] = n.left; if (dr <= best && sp < 63) stack[sp++] = n.right; }
+			if (dl <= dr) { if (dr <= best) { stack[sp] = n.right; sdist[sp++] = dr; } if (dl <= best) { stack[sp] = n.left; sdist[sp++] = dl; } }
+			else { if (dl <= best) { stack[sp] = n.left; sdist[sp++] = dl; } if (dr <= best) { stack[sp] = n.right; sdist[sp++] = dr; } }
 		}
 	}
 	return found ? sqrtf(best) : 0.0f; // "No closest triangle found": the reference returns 0 as well (triangle_bvh.cu:562-566)
@@ -92,8 +96,8 @@ static __device__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode* __res
 		if (n.left < 0) {
 			for (int i = -n.left - 1; i < -n.right - 1; ++i) if (tri_ray_intersect(tris[i], o, d) < SDF_MAX_DIST) return true;
 		} else {
-			if (bb_ray_entry(nodes[n.right], o, d) < SDF_MAX_DIST && sp < 63) stack[sp++] = n.right;
-			if (bb_ray_entry(nodes[n.left], o, d) < SDF_MAX_DIST && sp < 63) stack[sp++] = n.left;
+			if (bb_ray_entry(nodes[n.right], o, d) < SDF_MAX_DIST) stack[sp++] = n.right; // depth checked at creation (ngp_sdf_create)
+			if (bb_ray_entry(nodes[n.left], o, d) < SDF_MAX_DIST) stack[sp++] = n.left;
 		}
 	}
 	return false;

@@ -31,7 +31,9 @@ inline void read_rgba(const std::string& path, int& width, int& height, std::vec
 	std::ifstream f{path, std::ios::binary};
 	if (!f) throw std::runtime_error{"exr: could not open '" + path + "'"};
 	std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-	auto need = [&](size_t p, size_t n) { if (p + n > b.size()) throw std::runtime_error{"exr: truncated file '" + path + "'"}; };
+	// every size and offset below comes from the file: checked without wrap-around before anything is read
+	auto need = [&](size_t p, size_t n) { if (n > b.size() || p > b.size() - n) throw std::runtime_error{"exr: truncated or malformed file '" + path + "'"}; };
+	auto bad = [&](const char* what) { return std::runtime_error{std::string("exr: ") + what + " in '" + path + "'"}; };
 	need(0, 8);
 	uint32_t magic, version; std::memcpy(&magic, &b[0], 4); std::memcpy(&version, &b[4], 4);
 	if (magic != 20000630u) throw std::runtime_error{"exr: bad magic in '" + path + "'"};
@@ -44,18 +46,28 @@ inline void read_rgba(const std::string& path, int& width, int& height, std::vec
 		const std::string name = cstr(p);
 		if (name.empty()) break;
 		const std::string type = cstr(p);
-		need(p, 4); int32_t size; std::memcpy(&size, &b[p], 4); p += 4; need(p, (size_t)size);
+		need(p, 4); int32_t size; std::memcpy(&size, &b[p], 4); p += 4;
+		if (size < 0) throw bad("negative attribute size");
+		need(p, (size_t)size);
 		const size_t v = p; p += (size_t)size;
 		if (name == "channels") {
 			size_t q = v;
-			while (q < v + (size_t)size && b[q]) { Channel c; c.name = cstr(q); need(q, 16); int32_t t; std::memcpy(&t, &b[q], 4); c.type = t; q += 16; channels.push_back(c); }
-		} else if (name == "compression") compression = b[v];
-		else if (name == "dataWindow") { int32_t w[4]; std::memcpy(w, &b[v], 16); xmin = w[0]; ymin = w[1]; xmax = w[2]; ymax = w[3]; }
-		else if (name == "lineOrder") line_order = b[v];
+			while (q < v + (size_t)size && b[q]) {
+				Channel c; c.name = cstr(q); need(q, 16); if (q + 16 > v + (size_t)size) throw bad("channel list overruns its attribute");
+				int32_t t; std::memcpy(&t, &b[q], 4); c.type = t; q += 16;
+				if (t < 0 || t > 2) throw bad("unknown channel type");
+				channels.push_back(c);
+				if (channels.size() > 64) throw bad("too many channels");
+			}
+		} else if (name == "compression") { if (size < 1) throw bad("short compression attribute"); compression = b[v]; }
+		else if (name == "dataWindow") { if (size < 16) throw bad("short dataWindow attribute"); int32_t w[4]; std::memcpy(w, &b[v], 16); xmin = w[0]; ymin = w[1]; xmax = w[2]; ymax = w[3]; }
+		else if (name == "lineOrder") { if (size < 1) throw bad("short lineOrder attribute"); line_order = b[v]; }
 	}
 	if (channels.empty() || xmax < xmin || ymax < ymin) throw std::runtime_error{"exr: missing channels / dataWindow in '" + path + "'"};
 	if (compression != 0 && compression != 2 && compression != 3) throw std::runtime_error{"exr: only NO / ZIPS / ZIP compression is supported ('" + path + "')"};
-	width = xmax - xmin + 1; height = ymax - ymin + 1;
+	const int64_t w64 = (int64_t)xmax - xmin + 1, h64 = (int64_t)ymax - ymin + 1;
+	if (w64 > (1 << 16) || h64 > (1 << 16) || w64 * h64 > (int64_t)1 << 28) throw bad("dataWindow too large (limit 2^28 pixels)"); // 4 GiB of RGBA floats
+	width = (int)w64; height = (int)h64;
 	const int lines_per_block = compression == 3 ? 16 : 1;
 	const int n_blocks = (height + lines_per_block - 1) / lines_per_block;
 	size_t line_bytes = 0;
@@ -71,14 +83,18 @@ inline void read_rgba(const std::string& path, int& width, int& height, std::vec
 	std::vector<uint8_t> raw, tmp;
 	for (int blk = 0; blk < n_blocks; ++blk) {
 		uint64_t off; std::memcpy(&off, &b[p + (size_t)blk * 8], 8);
+		if (off > b.size()) throw bad("block offset outside the file");
 		need((size_t)off, 8);
 		int32_t y0, csize; std::memcpy(&y0, &b[off], 4); std::memcpy(&csize, &b[off + 4], 4);
+		if (csize < 0) throw bad("negative block size");
 		need((size_t)off + 8, (size_t)csize);
+		if (y0 < ymin || y0 > ymax) throw bad("block outside the dataWindow");
 		const int n_lines = std::min(lines_per_block, ymax - y0 + 1);
-		if (n_lines <= 0 || y0 < ymin) throw std::runtime_error{"exr: bad block in '" + path + "'"};
 		const size_t usize = line_bytes * (size_t)n_lines;
+		if (compression == 0 && (size_t)csize != usize) throw bad("uncompressed block of the wrong size");
+		if ((size_t)csize > usize) throw bad("block larger than its scan lines");
 		raw.resize(usize);
-		if (compression == 0 || (size_t)csize == usize) std::memcpy(raw.data(), &b[off + 8], usize);
+		if ((size_t)csize == usize) std::memcpy(raw.data(), &b[off + 8], usize); // stored raw (NO compression, or a block zlib could not shrink)
 		else {
 			tmp.resize(usize);
 			uLongf dl = (uLongf)usize;

@@ -122,6 +122,9 @@ Testbed::~Testbed() {
 	if (m_frame_dev) (void)hipFree(m_frame_dev);
 }
 void Testbed::destroy_trainer() {
+	// ngp_nerf_destroy tears the RCCL communicator down with the trainer, and a unique id creates ONE communicator: the next trainer needs a fresh
+	// comm_unique_id() / comm_init() on every rank (ensure_trainer says so instead of handing RCCL a consumed id, which hangs or fails on all ranks)
+	if (m_comm_up) { m_comm_up = false; m_comm_id.clear(); }
 	if (m_image) { ngp_image_destroy(m_image); m_image = nullptr; }
 	if (m_sdf) { ngp_sdf_destroy(m_sdf); m_sdf = nullptr; }
 	if (m_encmlp) { ngp_encmlp_destroy(m_encmlp); m_encmlp = nullptr; }
@@ -208,6 +211,9 @@ void Testbed::ensure_trainer() {
 		m_comm_up = false;
 	}
 	if (m_world_size > 1 && !m_comm_up) {
+		if (m_comm_id.size() != 128)
+			throw std::runtime_error{"The data-parallel communicator went away with the trainer it belonged to (load_snapshot / reload_network_from_file / new training data): "
+				"call comm_unique_id() on rank 0 and comm_init(rank, world_size, id) on every rank again before training resumes."};
 		NGP_CHECK(ngp_comm_init(m_nerf, m_rank, m_world_size, (const uint8_t*)m_comm_id.data()));
 		m_comm_up = true;
 	}
@@ -523,6 +529,7 @@ void Testbed::load_file(const std::string& path) {
 // NetworkWithInputEncoding + Trainer of the image / SDF modes from the network config (reset_network, testbed.cu:4160-4412)
 void Testbed::ensure_encmlp_trainer() {
 	if (m_image || m_sdf) return;
+	if (m_encmlp) { ngp_encmlp_destroy(m_encmlp); m_encmlp = nullptr; } // left over from a creation that failed after the model was built (bad batch size, out of memory): never stack a second model on it
 	if (m_network_config.type != mini_json::Value::Object) reload_network_from_file("");
 	const bool image = mode == ETestbedMode::Image;
 	const auto& enc = m_network_config["encoding"]; const auto& net = m_network_config["network"];
@@ -604,6 +611,7 @@ void Testbed::comm_init(uint32_t rank, uint32_t world_size, const std::string& i
 	if (world_size < 1 || rank >= world_size) throw std::runtime_error{"comm_init: bad rank / world_size"};
 	if (id.size() != 128) throw std::runtime_error{"comm_init: the unique id must be the 128 bytes of Testbed.comm_unique_id()"};
 	if (m_rank != rank || m_world_size != world_size) destroy_trainer(); // the sharding is fixed when the trainer is created
+	else if (m_nerf && m_comm_up) { NGP_CHECK(ngp_comm_destroy(m_nerf)); m_comm_up = false; } // same sharding, live trainer: the new id replaces the communicator
 	m_rank = rank; m_world_size = world_size; m_comm_id = id; m_comm_up = false;
 }
 ngp_nerf_stats Testbed::stats() {
@@ -650,7 +658,6 @@ void Testbed::set_fov(float deg) {
 
 std::vector<float> Testbed::render(int width, int height, int spp, bool linear) {
 	std::vector<float> out((size_t)width * height * 4, 0.f);
-	const float exposure_scale = std::pow(2.0f, exposure);
 	const float bg[4] = {srgb_to_lin(background_color[0]), srgb_to_lin(background_color[1]), srgb_to_lin(background_color[2]), background_color[3]};
 	if (render_ground_truth) {
 		// overlay_image_kernel (render_buffer.cu:344-412): point-sample the training image at pixel centres
@@ -662,9 +669,10 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 			const int ix = std::min(std::max((int)(u * m.resolution[0]), 0), m.resolution[0] - 1), iy = std::min(std::max((int)(v * m.resolution[1]), 0), m.resolution[1] - 1);
 			const uint8_t* p = px + ((size_t)iy * m.resolution[0] + ix) * 4;
 			const float a = p[3] / 255.f;
-			float* o = &out[((size_t)y * width + x) * 4];
-			for (int k = 0; k < 3; ++k) o[k] = srgb_to_lin(p[k] / 255.f) * a * exposure_scale + bg[k] * (1.f - a);
-			o[3] = a + bg[3] * (1.f - a);
+			// the reference draws the overlay into the frame buffer BEFORE tonemap_kernel (testbed.cu:5076-5091, render_buffer.cu:511-560): the texel, as
+			// premultiplied linear RGBA, goes through the same background / exposure / curve arithmetic as a rendered pixel
+			const float texel[4] = {srgb_to_lin(p[0] / 255.f) * a, srgb_to_lin(p[1] / 255.f) * a, srgb_to_lin(p[2] / 255.f) * a, a};
+			NGP_CHECK(ngp_host_tonemap_pixel(texel, exposure, bg, 0, (int)tonemap_curve, &out[((size_t)y * width + x) * 4]));
 		}
 	} else {
 		ensure_trainer();

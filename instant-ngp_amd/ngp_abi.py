@@ -16,6 +16,7 @@ vp = C.c_void_p
 LENS_PERSPECTIVE, LENS_OPENCV, LENS_FTHETA, LENS_LATLONG, LENS_OPENCV_FISHEYE, LENS_EQUIRECTANGULAR, LENS_ORTHOGRAPHIC = 0, 1, 2, 3, 4, 5, 6
 IMAGE_BYTE, IMAGE_HALF, IMAGE_FLOAT = 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
+DBG_K4_ZERO_PADDING = 1 << 26  # ngp_debug_set_flags test hook (csrc/ngp_kernels.hpp)
 LOSS_L2, LOSS_L1, LOSS_MAPE, LOSS_SMAPE, LOSS_HUBER, LOSS_LOGL1, LOSS_RELATIVE_L2 = range(7)
 
 

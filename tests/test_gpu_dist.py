@@ -2,7 +2,7 @@
 
 gpurun hands out ONE GPU, and RCCL refuses two ranks on one device, so the world-size-2 test lets two processes share the GPU and
 exchanges the two collectives' payloads through host memory over gloo -- everything else is the product path:
-ngp_nerf_train_forward (K1 on this rank's slice of the global ray stream .. K4) -> all-reduce(sum) of the two counters ->
+ngp_nerf_train_forward (K1 on this rank's slice of the global ray stream .. K4) -> all-reduce(sum) of the three counter words ->
 ngp_nerf_train_backward (k_import_sync, controller, next K1, T1 / scatter / W) -> all-reduce(sum) of the fp16 gradients ->
 ngp_nerf_train_finish (optimizer).  The RCCL calls themselves (ngp_comm_*, bucketed all-reduce inside ngp_nerf_train) run in the
 second test with a communicator of one rank.
@@ -76,7 +76,7 @@ def _worker(rank, world, port, q):
     g = C.c_void_p(); lib.ngp_model_param_ptrs(hm.h, None, None, None, C.byref(g))
     grads = torch.as_tensor(_View(g.value, hm.n, "<f2"), device="cuda")
     cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(t, C.byref(cp))
-    cnt = torch.as_tensor(_View(cp.value, 2, "<i4"), device="cuda")
+    cnt = torch.as_tensor(_View(cp.value, 3, "<i4"), device="cuda")  # {marched, compacted, loss sum in units of 2^-24}
     sc = _scratch(A, lib, t, B_GLOBAL // world)
     ref = None
     if rank == 0:  # the single-rank trainer on the same GPU, same seed
@@ -143,11 +143,63 @@ def _worker(rank, world, port, q):
     digests = [None] * world; dist.all_gather_object(digests, hashlib.sha1(p.tobytes()).hexdigest())  # (hash() of bytes is salted per process)
     assert len(set(digests)) == 1, "ranks diverged"
     if rank == 0:
-        # (v) the 2-rank run trains like the 1-rank run (same global batch, same ray stream)
+        # (v) the 2-rank run trains like the 1-rank run (same global batch, same ray stream); Testbed.loss is the loss of the UNION batch on
+        #     every rank (the third all-reduced word).  Two trajectories of 40 noisy steps: same order of magnitude is all that can be asked here,
+        #     the tight comparison is (vi)
         l2, l1 = losses[-1], ref[N_STEPS - 1]["loss"]
         print(f"loss after {N_STEPS} steps: 2 ranks {l2:.5f}, 1 rank {l1:.5f}; rays/batch {rpb[0]} vs {ref[N_STEPS - 1]['rpb']}")
-        assert np.isfinite(l2) and l2 < 0.5 * losses[0] and l1 < 0.5 * ref[0]["loss"] and 1 / 3 < l2 / l1 < 3  # per-batch loss at step 40 is noisy: same order of magnitude, both trained
+        assert np.isfinite(l2) and l2 < 0.5 * losses[0] and l1 < 0.5 * ref[0]["loss"] and 0.6 < l2 / l1 < 1 / 0.6
         assert abs(rpb[0] - ref[N_STEPS - 1]["rpb"]) <= 0.15 * ref[N_STEPS - 1]["rpb"] + 256
+    # (vi) steady state (n_in ~ B): every trainer takes ONE step from the single-rank trainer's state after N steps -- same parameters, occupancy
+    #      grid, ray stream and rays per batch (slightly below the controller's value so that neither K1's sample cap nor K3's batch clamp, which
+    #      drop order-dependent rays, binds).  The loss of the union batch must agree to fp32 summation order and the summed gradient to fp16
+    #      rounding; K4's padding (each rank wraps ITS rows to B / G) is the only non-linear term and is measured separately.
+    grid_n = 128 ** 3
+    state = [None]
+    if rank == 0:
+        p1 = np.empty(hm1.n, np.float32)
+        A.check(lib, lib.ngp_model_get_params_host(hm1.h, p1.ctypes.data_as(C.c_void_p), C.c_uint64(p1.size)))
+        gp = C.c_void_p(); A.check(lib, lib.ngp_nerf_density_grid_ptrs(t1, C.byref(gp), None, None))
+        grid1 = torch.as_tensor(_View(gp.value, grid_n, "<f4"), device="cuda").cpu().numpy().copy()
+        r1, r1g = A.Pcg32(), A.Pcg32(); A.check(lib, lib.ngp_nerf_get_rng(t1, C.byref(r1), C.byref(r1g)))
+        state[0] = dict(params=p1, grid=grid1, rng=(int(r1.state), int(r1.inc)), rays=int(ref[N_STEPS - 1]["rpb"] * 0.97) // 256 * 256)
+    dist.broadcast_object_list(state, 0)
+    st0 = state[0]
+    results = {}
+    for zero_pad in (0, 1):
+        lib.ngp_debug_set_flags(A.DBG_K4_ZERO_PADDING if zero_pad else 0)
+        trainers = [(hm, t, grads, cnt, world)] + ([(hm1, t1, grads1, None, 1)] if rank == 0 else [])
+        for (m_, t_, g_, c_, w_) in trainers:
+            A.check(lib, lib.ngp_model_set_params_host(m_.h, st0["params"].ctypes.data_as(C.c_void_p), C.c_uint64(st0["params"].size)))
+            A.check(lib, lib.ngp_nerf_set_density_grid_host(t_, None, st0["grid"].ctypes.data_as(C.c_void_p), C.c_uint64(grid_n)))
+            rr = A.Pcg32(st0["rng"][0], st0["rng"][1]); A.check(lib, lib.ngp_nerf_set_rng(t_, C.byref(rr)))
+            A.check(lib, lib.ngp_nerf_set_rays_per_batch(t_, st0["rays"]))
+            A.check(lib, lib.ngp_nerf_train_forward(t_, None))
+            torch.cuda.synchronize()
+            if w_ > 1:
+                c_host = c_.cpu().to(torch.int64); dist.all_reduce(c_host); c_.copy_(c_host.to(torch.int32).cuda())
+            A.check(lib, lib.ngp_nerf_train_backward(t_, None))
+            torch.cuda.synchronize()
+            gl = g_.float().cpu()
+            if w_ > 1:
+                dist.all_reduce(gl)
+                g_.copy_(gl.half().cuda())
+            A.check(lib, lib.ngp_nerf_train_finish(t_, None))
+            torch.cuda.synchronize()
+            st_ = A.NerfStats(); A.check(lib, lib.ngp_nerf_get_stats(t_, None, C.byref(st_)))
+            results[(zero_pad, w_)] = (gl.numpy().astype(np.float64), float(st_.loss), int(st_.measured_batch_size), int(st_.n_rays_last))
+    lib.ngp_debug_set_flags(0)
+    if rank == 0:
+        for zero_pad in (0, 1):
+            (g2, l2, m2, n2), (g1, l1, m1, n1) = results[(zero_pad, world)], results[(zero_pad, 1)]
+            rel = float(np.linalg.norm(g2 - g1) / np.linalg.norm(g1))
+            print(f"steady state, padding {'zeroed' if zero_pad else 'as in production'}: loss 2 ranks {l2:.6f} vs 1 rank {l1:.6f}; compacted per rank {m2} vs {m1} of {B_GLOBAL}; "
+                  f"summed-gradient rel-L2 {rel:.3e}")
+            assert m1 > 0.9 * B_GLOBAL and m1 < B_GLOBAL and m2 < B_GLOBAL // world, "the check must run below the batch clamp"
+            assert abs(l2 - l1) <= 0.02 * l1, (l2, l1)   # the loss of the union batch (Testbed.loss) on every rank
+            # without the padding rows the step is linear in the set of rays: 2-rank sum == 1-rank gradient up to half rounding of the partial sums;
+            # with them the difference is the wrap of each rank's first rows (a few per cent of the batch at n_in ~ 0.97 B)
+            assert rel < (0.02 if zero_pad else 0.10), rel
         q.put("ok")
     dist.barrier()
     lib.ngp_nerf_destroy(t)

@@ -337,3 +337,65 @@ def test_tonemap_pixel_matches_the_reference_formulas():
     assert abs(out[0] - 1.0) < 1e-5
     lib.ngp_host_tonemap_pixel((C.c_float * 4)(1, 1, 1, 1), C.c_float(0.0), (C.c_float * 4)(0, 0, 0, 1), 0, 1, out)
     assert abs(out[0] - 0.9216 / 1.3688) < 1e-5
+
+
+def _tiny_exr(width=4, height=3, compression=0, zip_payload=None):
+    """a scan-line OpenEXR written by hand (the published file layout): RGBA float32, NO compression (or a caller-supplied block payload)"""
+    import struct
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in ("A", "B", "G", "R")) + b"\0"
+    box = struct.pack("<4i", 0, 0, width - 1, height - 1)
+    head = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression])) + \
+        attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+        attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    px = np.arange(width * height * 4, dtype=np.float32).reshape(height, width, 4) / 7.0  # [y][x][rgba]
+    blocks = []
+    for y in range(height):
+        line = b"".join(px[y, :, k].tobytes() for k in (3, 2, 1, 0))  # channels in file order A, B, G, R
+        blocks.append(struct.pack("<ii", y, len(line)) + line if zip_payload is None else struct.pack("<ii", y, len(zip_payload)) + zip_payload)
+    table_at = len(head)
+    offs, pos = [], table_at + 8 * height
+    for b in blocks:
+        offs.append(pos); pos += len(b)
+    return head + struct.pack(f"<{height}Q", *offs) + b"".join(blocks), px, table_at
+
+
+def test_exr_reader_rejects_malformed_files(tmp_path):
+    """The reader is reachable from load_training_data / load_file / pyngp.read_exr on arbitrary user files: every size and offset taken from
+    the file is checked before it is used (round-2 advisor finding: negative attribute sizes, short fixed-size attributes, csize < usize in an
+    uncompressed block, a hostile dataWindow)."""
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    good, px, table_at = _tiny_exr()
+    f = tmp_path / "good.exr"; f.write_bytes(good)
+    img = ngp.read_exr(str(f))
+    assert img.shape == (3, 4, 4) and np.array_equal(img, px)
+
+    def expect_error(data, what):
+        g = tmp_path / "bad.exr"; g.write_bytes(data)
+        with pytest.raises(RuntimeError):
+            ngp.read_exr(str(g))
+
+    # (1) negative attribute size: first attribute is "channels\0chlist\0<size>"
+    i = good.index(b"chlist\0") + 7
+    expect_error(good[:i] + struct.pack("<i", -8) + good[i + 4:], "negative size")
+    # (2) dataWindow / compression attributes shorter than their fixed-size payload
+    i = good.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0")
+    expect_error(good[:i] + struct.pack("<i", 4) + good[i + 4:i + 8] + good[i + 20:], "short dataWindow")
+    # (3) uncompressed block whose stored size is smaller than its scan line (the old reader copied usize bytes regardless)
+    first_block = struct.unpack("<Q", good[table_at:table_at + 8])[0]
+    expect_error(good[:first_block + 4] + struct.pack("<i", 8) + good[first_block + 8:], "csize < usize")
+    # (4) hostile dataWindow: 2^31 - 1 pixels wide
+    expect_error(good[:i + 4] + struct.pack("<4i", 0, 0, 2**31 - 2, 2**31 - 2) + good[i + 20:], "huge window")
+    # (5) block offset outside the file, (6) truncated file, (7) negative block size
+    expect_error(good[:table_at] + struct.pack("<Q", 1 << 40) + good[table_at + 8:], "offset")
+    expect_error(good[:len(good) - 20], "truncated")
+    expect_error(good[:first_block + 4] + struct.pack("<i", -1) + good[first_block + 8:], "negative csize")
+    # (8) a ZIP block that inflates to the wrong size
+    import zlib
+    bad_zip, _, _ = _tiny_exr(compression=2, zip_payload=zlib.compress(b"\0" * 10))
+    expect_error(bad_zip, "zip size")
