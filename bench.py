@@ -202,6 +202,57 @@ def run_ab_psnr(lib, scene, args, steps, seeds=(1337,)):
     return out
 
 
+def calibrate():
+    """Two seconds of box calibration, printed in `config.calibration`: boxes of this pool differ by 15-35 % on the same binary, so a line carries the
+    means to tell a slow box from a regression -- device-to-device copy rate of a 1 GiB buffer (read + write bytes) and the rate of a fixed fp16 GEMM
+    (8192^3 through the library GEMM: MFMA clocks)."""
+    a = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)
+    b.copy_(a); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    copy_gbs = 8 * 2 * a.numel() * 4 / (1e6 * e0.elapsed_time(e1))
+    del a, b
+    x = torch.randn(8192, 8192, dtype=torch.float16, device="cuda"); y = torch.randn(8192, 8192, dtype=torch.float16, device="cuda")
+    torch.matmul(x, y); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        torch.matmul(x, y)
+    e1.record(); torch.cuda.synchronize()
+    gemm_tflops = 4 * 2 * 8192 ** 3 / (1e9 * e0.elapsed_time(e1))
+    del x, y
+    torch.cuda.empty_cache()
+    return {"d2d_copy_GBps": round(copy_gbs, 1), "fp16_gemm_8192_TFLOPs": round(gemm_tflops, 1),
+            "reference_fast_box": {"d2d_copy_GBps": 5800.0, "note": "profiles/r03_dp_diag2_comm_after_training.txt: 5.77-5.80 TB/s read+write on the box that ran 0.65 ms per step"}}
+
+
+def run_fox_leg(lib, args):
+    """Secondary leg of the default line (BASELINE.json config 2: data/nerf/fox, same network config, 1 GPU): untimed load + pretrain, then the same
+    barrier-bracketed timing as the headline."""
+    import copy
+    a2 = copy.copy(args); a2.scene = "fox"; a2.eval_views = 0
+    t0 = time.perf_counter()
+    scene = load_scene(a2)
+    load_s = time.perf_counter() - t0
+    _, _, model, nerf = make_trainer(lib, scene, args.batch)
+    A.check(lib, lib.ngp_nerf_train(nerf, None, 2000 + 20))
+    torch.cuda.synchronize()
+    s0 = get_stats(lib, nerf)
+    n = 100
+    t0 = time.perf_counter()
+    A.check(lib, lib.ngp_nerf_train(nerf, None, n))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    s1 = get_stats(lib, nerf)
+    out = {"workload": scene["name"] + ", configs/nerf/base.json, batch 2^18 samples per step", "pretrain_steps": 2020, "steps": n, "ms_per_step": round(1e3 * el / n, 4),
+           "rays_per_s": (s1.total_rays - s0.total_rays) / el, "samples_per_s": (s1.total_samples - s0.total_samples) / el,
+           "rays_per_step": (s1.total_rays - s0.total_rays) / n, "loss": s1.loss, "load_seconds": round(load_s, 2)}
+    lib.ngp_nerf_destroy(nerf); lib.ngp_model_destroy(model)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +265,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 18)
     ap.add_argument("--profile-steps", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fox-leg", action="store_true", help="skip the secondary data/nerf/fox leg of the default line")
+    ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--eval-views", type=int, default=4, help="views rendered (untimed) for PSNR, run.py --test_transforms procedure")
     ap.add_argument("--eval-res", type=int, default=400)
     ap.add_argument("--eval-spp", type=int, default=1)
@@ -246,6 +299,7 @@ def main():
         lib.ngp_debug_set_flags(int(os.environ["NGP_DEBUG_FLAGS"], 0))
     assert lib.ngp_device_available() == 1
 
+    calibration = None if args.no_calibration else calibrate()
     scene = load_scene(args)
     if args.scaling == "strong":  # total work fixed: every rank trains B / N samples per step (the library needs a multiple of 256)
         args.batch = max(256, args.batch // world // 256 * 256)
@@ -396,6 +450,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(lib, model, nerf, cfg, scene, s3, args)
 
+    fox_leg = None
+    if rank == 0 and world == 1 and args.scene == "synthetic" and not args.no_fox_leg:
+        try:
+            fox_leg = run_fox_leg(lib, args)
+        except Exception as e:  # the capture is staged from /root/reference at build time; a box without it still reports the headline
+            fox_leg = {"skipped": str(e)[:200]}
+
     ab = None
     if rank == 0 and world == 1 and args.ab_psnr:
         ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[1337 + i for i in range(max(args.ab_seeds, 1))])
@@ -416,10 +477,12 @@ def main():
                        "loss": s1.loss, "train_psnr_estimate_db": (-10 * math.log10(s1.loss) if s1.loss > 0 else None), "training_step_end": s1.training_step,
                        "test_psnr_db": psnr, "test_psnr_at_step": (psnr_step if psnr is not None else None),
                        "test_psnr_views": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "test_psnr_eval_seconds": round(t_eval, 3),
+                       **({"calibration": calibration} if calibration else {}),
                        **({"dp_host_enqueue_ms_per_step": host_ms} if host_ms else {}),
                        **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {}),
                        **({"ab_psnr": ab} if ab else {})},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+            **({"legs": {"fox": fox_leg}} if fox_leg else {}),
         }
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()

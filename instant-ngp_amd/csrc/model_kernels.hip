@@ -41,8 +41,14 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #define DEV static __device__ __forceinline__
 
 // fragment indices (see header of this file / DESIGN.md)
+// density net: D1 (32 -> 64), D2 (64 -> 16); colour net: R1 (32 -> 64), NR - 1 layers R2 (64 -> 64, 8 fragments each), R3 (64 -> 16).
+// FW_R3 / BW_R3 are the positions for NR = 2 hidden colour layers (configs/nerf/base.json); fw_r3(NR) / bw_r3(NR) in general.
 constexpr int FW_D1 = 0, FW_D2 = 4, FW_R1 = 8, FW_R2 = 12, FW_R3 = 20;
 constexpr int BW_D1 = 0, BW_D2 = 4, BW_R1 = 6, BW_R2 = 10, BW_R3 = 18;
+constexpr int fw_r3(int nr) { return FW_R2 + 8 * (nr - 1); }
+constexpr int bw_r3(int nr) { return BW_R2 + 8 * (nr - 1); }
+constexpr int n_fw(int nr) { return fw_r3(nr) + 4; }
+constexpr int n_bw(int nr) { return bw_r3(nr) + 2; }
 
 DEV f16v zero16() { f16v z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
 DEV h8 zero8() { h8 z; for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.f; return z; }
@@ -253,7 +259,7 @@ struct FwdState {
 	h8 enc[CT][2];      // encoding fragments (k-steps 0,1)
 	h8 rin[CT][2];      // rgb-net input: [0] = density-net output (16), [1] = SH (16)
 	h8 hb[CT][4];       // current 64-wide hidden activation fragments
-	uint32_t m1d[CT], m1r[CT], m2r[CT]; // ReLU bit masks: bit (16*mt + r)
+	uint32_t m1d[CT], m1r[CT], m2r[2][CT]; // ReLU bit masks: bit (16*mt + r); m2r[k] = the k-th 64 x 64 colour layer
 	float sigma[CT];    // density logit (valid on hi == 0 lanes)
 };
 
@@ -330,7 +336,7 @@ DEV void fwd_rgb_l1(const h8* fw, int lane, FwdState<CT>& st) {
 	}
 }
 template <int CT>
-DEV void fwd_rgb_l2(const h8* fw, int lane, FwdState<CT>& st) {
+DEV void fwd_rgb_l2(const h8* fw, int lane, FwdState<CT>& st, const int k = 0 /* which of the 64 x 64 layers */) {
 	f16v acc[2][CT];
 #pragma unroll
 	for (int mt = 0; mt < 2; ++mt)
@@ -340,44 +346,52 @@ DEV void fwd_rgb_l2(const h8* fw, int lane, FwdState<CT>& st) {
 	for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
 		for (int s = 0; s < 4; ++s) {
-			h8 a = lds_frag(fw, FW_R2 + mt * 4 + s, lane);
+			h8 a = lds_frag(fw, FW_R2 + 8 * k + mt * 4 + s, lane);
 #pragma unroll
 			for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, st.hb[c][s], acc[mt][c]);
 		}
 #pragma unroll
 	for (int c = 0; c < CT; ++c) {
-		st.m2r[c] = 0;
+		st.m2r[k][c] = 0;
 #pragma unroll
 		for (int mt = 0; mt < 2; ++mt) {
 			uint32_t mb = 0;
 			st.hb[c][2 * mt + 0] = to_frag<true>(acc[mt][c], 0, mb);
 			st.hb[c][2 * mt + 1] = to_frag<true>(acc[mt][c], 1, mb);
-			st.m2r[c] |= mb << (16 * mt);
+			st.m2r[k][c] |= mb << (16 * mt);
 		}
 	}
 }
 // rgb output layer: returns the D tile (rows 0..2 = rgb logits on hi == 0 lanes, regs 0..2)
 template <int CT>
-DEV void fwd_rgb_l3(const h8* fw, int lane, const FwdState<CT>& st, f16v out[CT]) {
+DEV void fwd_rgb_l3(const h8* fw, int lane, const FwdState<CT>& st, f16v out[CT], const int base = FW_R3) {
 #pragma unroll
 	for (int c = 0; c < CT; ++c) out[c] = zero16();
 #pragma unroll
 	for (int s = 0; s < 4; ++s) {
-		h8 a = lds_frag(fw, FW_R3 + s, lane);
+		h8 a = lds_frag(fw, base + s, lane);
 #pragma unroll
 		for (int c = 0; c < CT; ++c) out[c] = mfma(a, st.hb[c][s], out[c]);
 	}
 }
 
+// the colour network with NR hidden layers (configs/nerf/base_1layer / base(_2layer) / base_3layer.json): hidden activations only
+template <int CT, int NR>
+DEV void fwd_rgb_hidden(const h8* fw, int lane, FwdState<CT>& st) {
+	fwd_rgb_l1<CT>(fw, lane, st);
+#pragma unroll
+	for (int k = 0; k < NR - 1; ++k) fwd_rgb_l2<CT>(fw, lane, st, k);
+}
+
 // ---------------------------------------------------------------------------------------------
 // inference kernel (K2, density-grid queries, renderer): persistent waves, 64 samples per iteration
 // ---------------------------------------------------------------------------------------------
-template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW, int F = 4>
+template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW, int F = 4, int NR = 2>
 __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n_max,
 		const uint32_t* __restrict__ n_ptr, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
-	load_frags_to_lds(fw, mp.fw_frags, DENSITY_ONLY ? 8 : (int)N_FW_FRAGS);
+	load_frags_to_lds(fw, mp.fw_frags, DENSITY_ONLY ? 8 : n_fw(NR));
 	__syncthreads();
 	const uint32_t n = n_ptr ? min(*n_ptr, n_max) : n_max;
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
@@ -403,10 +417,9 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 				if (hi == 0 && sidx[c] < n) out[(size_t)sidx[c] * out_stride] = __float2half(st.sigma[c]);
 			continue;
 		}
-		fwd_rgb_l1<CT>(fw, lane, st);
-		fwd_rgb_l2<CT>(fw, lane, st);
+		fwd_rgb_hidden<CT, NR>(fw, lane, st);
 		f16v o[CT];
-		fwd_rgb_l3<CT>(fw, lane, st, o);
+		fwd_rgb_l3<CT>(fw, lane, st, o, fw_r3(NR));
 #pragma unroll
 		for (int c = 0; c < CT; ++c) {
 			if (hi == 0 && sidx[c] < n) {
@@ -428,7 +441,7 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 // ---------------------------------------------------------------------------------------------
 // TW = tile width in samples: 32 (one tile per wavefront) or 16 (two tiles of two different rays share the wavefront's 32 MFMA
 // columns -- rays end after ~12 compacted samples, so 16-wide tiles evaluate fewer samples behind the cut and fill the columns).
-template <uint32_t TW, int F = 4>
+template <uint32_t TW, int F = 4, int NR = 2>
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -437,7 +450,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	const uint32_t n_tiles = min(r == 0 ? *la.n_rays_ptr : la.n_tiles_ptr[r], la.tile_cap);
 	if (blockIdx.x * 4 * TPW >= n_tiles) return; // uniform: late rounds are small
 	h8* fw = (h8*)smem;
-	load_frags_to_lds(fw, mp.fw_frags, (int)N_FW_FRAGS);
+	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
 	const uint32_t slot = (uint32_t)col / TW, tcol = (uint32_t)col % TW; // which of the wavefront's tiles, column inside it
@@ -486,10 +499,9 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		st.rin[0][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
 		fwd_density_l1<1>(fw, lane, st);
 		fwd_density_l2<1>(fw, lane, st);
-		fwd_rgb_l1<1>(fw, lane, st);
-		fwd_rgb_l2<1>(fw, lane, st);
+		fwd_rgb_hidden<1, NR>(fw, lane, st);
 		f16v o[1];
-		fwd_rgb_l3<1>(fw, lane, st, o);
+		fwd_rgb_l3<1>(fw, lane, st, o, fw_r3(NR));
 		if (hi == 0 && valid) {
 			h4 rr = {(_Float16)o[0][0], (_Float16)o[0][1], (_Float16)o[0][2], (_Float16)st.sigma[0]};
 			*(uint2*)(out + (size_t)sample * out_stride) = __builtin_bit_cast(uint2, rr);
@@ -689,15 +701,15 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 
 // SCATTER = false: every level's dL/d(enc) goes to denc_lv and the kernel issues no atomics (production: all levels through the bin lists);
 // compiled separately so that the scatter code's registers do not limit the occupancy of the gather-latency-bound forward / dgrad part.
-template <int CT, int MINW, bool SCATTER, int F = 4>
+template <int CT, int MINW, bool SCATTER, int F = 4, int NR = 2>
 __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
 		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags,
 		uint2* __restrict__ denc_lv, uint32_t denc_cap) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
-	h8* bw = fw + N_FW_FRAGS * 64;
-	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
-	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
+	h8* bw = fw + n_fw(NR) * 64;
+	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
+	load_frags_to_lds(bw, mp.bw_frags, n_bw(NR));
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
@@ -721,8 +733,7 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 		}
 		fwd_density_l1<CT>(fw, lane, st);
 		fwd_density_l2<CT>(fw, lane, st);
-		fwd_rgb_l1<CT>(fw, lane, st);
-		fwd_rgb_l2<CT>(fw, lane, st);
+		fwd_rgb_hidden<CT, NR>(fw, lane, st);
 
 		// ---- backward (dgrad chain) ----
 		h8 dy0[CT];          // dL/d(rgb output) fragment, k-step 0
@@ -738,19 +749,21 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 			}
 		}
 		h8 dh[CT][4];
-		// rgb L3^T : d_h2 = W3^T * d_out   (kin tiles mt = 0,1; one k-step)
+		// rgb L3^T : d_h = W3^T * d_out   (kin tiles mt = 0,1; one k-step), masked by the last hidden layer's ReLU state
 #pragma unroll
 		for (int mt = 0; mt < 2; ++mt) {
-			h8 a = lds_frag(bw, BW_R3 + mt, lane);
+			h8 a = lds_frag(bw, bw_r3(NR) + mt, lane);
 #pragma unroll
 			for (int c = 0; c < CT; ++c) {
 				f16v d = mfma(a, dy0[c], zero16());
-				dh[c][2 * mt + 0] = to_frag_masked(d, 0, st.m2r[c] >> (16 * mt));
-				dh[c][2 * mt + 1] = to_frag_masked(d, 1, st.m2r[c] >> (16 * mt));
+				const uint32_t mask = NR == 1 ? st.m1r[c] : st.m2r[NR >= 2 ? NR - 2 : 0][c];
+				dh[c][2 * mt + 0] = to_frag_masked(d, 0, mask >> (16 * mt));
+				dh[c][2 * mt + 1] = to_frag_masked(d, 1, mask >> (16 * mt));
 			}
 		}
-		// rgb L2^T : d_h1 = W2^T * d_h2
-		{
+		// the 64 x 64 layers, last to first: d_h(k) = W2(k)^T * d_h(k+1), masked by the ReLU state of the layer below
+#pragma unroll
+		for (int k = NR - 2; k >= 0; --k) {
 			f16v acc[2][CT];
 #pragma unroll
 			for (int mt = 0; mt < 2; ++mt)
@@ -760,7 +773,7 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 			for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
 				for (int s = 0; s < 4; ++s) {
-					h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
+					h8 a = lds_frag(bw, BW_R2 + 8 * k + mt * 4 + s, lane);
 #pragma unroll
 					for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, dh[c][s], acc[mt][c]);
 				}
@@ -768,8 +781,9 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 			for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
 				for (int c = 0; c < CT; ++c) {
-					dh[c][2 * mt + 0] = to_frag_masked(acc[mt][c], 0, st.m1r[c] >> (16 * mt));
-					dh[c][2 * mt + 1] = to_frag_masked(acc[mt][c], 1, st.m1r[c] >> (16 * mt));
+					const uint32_t mask = k == 0 ? st.m1r[c] : st.m2r[k >= 1 ? k - 1 : 0][c];
+					dh[c][2 * mt + 0] = to_frag_masked(acc[mt][c], 0, mask >> (16 * mt));
+					dh[c][2 * mt + 1] = to_frag_masked(acc[mt][c], 1, mask >> (16 * mt));
 				}
 		}
 		// rgb L1^T : d_rin = W1^T * d_h1 ; only rows 0..15 (density-net output) are consumed
@@ -1338,25 +1352,33 @@ DEV void sw_grad_to_frags(const f16v& d, const h8 act[2], h8 out[2]) {
 		for (int j = 0; j < 8; ++j) out[q][j] = ((float)act[q][j] > 0.f) ? (_Float16)d[8 * q + j] : (_Float16)0.f;
 }
 
-constexpr int N_DW_TILES = 12; // d1:(0,1) d2:(2,3) r1:(4,5) r2:(6..9) r3:(10,11)
+constexpr int N_DW_TILES = 12; // NR = 2: d1:(0,1) d2:(2,3) r1:(4,5) r2:(6..9) r3:(10,11)
+constexpr int n_dw_tiles(int nr) { return 8 + 4 * (nr - 1); } // d1:(0,1) d2:(2,3) r1:(4,5) r2_k:(6+4k .. 9+4k) r3: the last two
 
+// One wavefront keeps all dW tiles (128 / 192 / 256 accumulator registers for NR = 1 / 2 / 3 hidden colour layers) and owns its SIMD's register file.
+// NR = 2 is the round-1 kernel (ablation DBG_W_SINGLE_ROLE; production runs the two-role k_wgrad2 below); NR = 1 and 3 (configs/nerf/base_1layer.json,
+// base_3layer.json) run this one.  Per 32-sample tile: forward chain with the SWAPPED activations (lane = neuron, registers = samples) of every hidden
+// colour layer kept for the weight-gradient products, then the dgrad chain in both layouts, layer by layer from the output.
+template <int NR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_wgrad(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n, const __half* __restrict__ dL_dy, uint32_t dy_stride,
+k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n, const __half* __restrict__ dL_dy, uint32_t dy_stride,
 		const uint4* __restrict__ enc_stash, float* __restrict__ partials) {
+	constexpr int NT = n_dw_tiles(NR);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
-	h8* bw = fw + N_FW_FRAGS * 64;
-	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
-	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
+	h8* bw = fw + n_fw(NR) * 64;
+	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
+	load_frags_to_lds(bw, mp.bw_frags, n_bw(NR));
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6;
 	const uint32_t wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
-	f16v dW[N_DW_TILES];
+	f16v dW[NT];
 #pragma unroll
-	for (int t = 0; t < N_DW_TILES; ++t) dW[t] = zero16();
+	for (int t = 0; t < NT; ++t) dW[t] = zero16();
 	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
 
 	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) { // ct = 32-sample column tile
+		asm volatile("" ::: "memory"); // the weight fragments in LDS are loop invariant: without this the compiler hoists their loads into (spilled) registers
 		const uint32_t s_raw = ct * 32 + col;
 		const bool valid = s_raw < n;
 		const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
@@ -1365,94 +1387,99 @@ k_wgrad(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t
 		st.enc[0][1] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 1) * 64 + lane]);
 		st.rin[0][1] = sh4_frag(p[4], p[5], p[6], hi);
 		h8 dy0 = zero8(); _Float16 dsig = (_Float16)0.f;
-		if (hi == 0 && valid) {
+		if (hi == 0 && valid) { // out-of-range columns contribute nothing: their output gradient is zero
 			const h4 g = __builtin_bit_cast(h4, *(const uint2*)(dL_dy + (size_t)s_raw * dy_stride));
 			dy0[0] = g[0]; dy0[1] = g[1]; dy0[2] = g[2]; dsig = g[3];
 		}
-		// out-of-range columns must contribute nothing: zero their inputs AND their output gradient
-		// (dy0/dsig are zero already); activations of invalid columns only ever multiply zero gradients.
-
-		// ---- forward chain (ReLU masks) ; swapped activations (lane = neuron, regs = samples) are
-		//      recomputed lazily right before their use to keep the live register set small ----
+		// ---- forward chain (ReLU masks) + swapped activations of the hidden colour layers ----
 		fwd_density_l1<1>(fw, lane, st);
 		fwd_density_l2<1>(fw, lane, st);
-		fwd_rgb_l1<1>(fw, lane, st);
-		h8 h2r_sw[2][2];
-#pragma unroll
-		for (int kt = 0; kt < 2; ++kt) {
-			f16v t = zero16();
-#pragma unroll
-			for (int s = 0; s < 4; ++s) t = mfma(st.hb[0][s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
-			sw_to_frags(t, true, h2r_sw[kt]);
-		}
-		fwd_rgb_l2<1>(fw, lane, st); // only the ReLU mask m2r is consumed below
-
-		// ---- backward ----
-		h8 g_sw[2]; // current layer's output gradient in swapped layout
-		// rgb L3: dW = d_out * h2r^T
-		{ f16v t = mfma(dy0, I0, zero16()); sw_to_frags(t, false, g_sw); }
-#pragma unroll
-		for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-			for (int q = 0; q < 2; ++q) dW[10 + kt] = mfma(g_sw[q], h2r_sw[kt][q], dW[10 + kt]);
-		// d_h2 (chain, masked) and swapped
-		h8 dh[4];
-		h8 d2_sw[2][2];
-#pragma unroll
-		for (int mt = 0; mt < 2; ++mt) {
-			const h8 a = lds_frag(bw, BW_R3 + mt, lane);
-			f16v d = mfma(a, dy0, zero16());
-			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
-			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
-			f16v dsw = mfma(dy0, a, zero16());
-			sw_grad_to_frags(dsw, h2r_sw[mt], d2_sw[mt]);
-		}
-		// h1r swapped (from the rgb-net input), rgb L2: dW[it][kt] = d_h2[it] * h1r[kt]^T
-		h8 h1r_sw[2][2];
+		h8 H_sw[NR][2][2]; // [layer][32-neuron tile][16-sample half]
 #pragma unroll
 		for (int kt = 0; kt < 2; ++kt) {
 			f16v t = zero16();
 #pragma unroll
 			for (int s = 0; s < 2; ++s) t = mfma(st.rin[0][s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
-			sw_to_frags(t, true, h1r_sw[kt]);
+			sw_to_frags(t, true, H_sw[0][kt]);
 		}
+		fwd_rgb_l1<1>(fw, lane, st);
 #pragma unroll
-		for (int it = 0; it < 2; ++it)
+		for (int k = 0; k < NR - 1; ++k) {
 #pragma unroll
-			for (int kt = 0; kt < 2; ++kt)
+			for (int kt = 0; kt < 2; ++kt) {
+				f16v t = zero16();
 #pragma unroll
-				for (int q = 0; q < 2; ++q) dW[6 + it * 2 + kt] = mfma(d2_sw[it][q], h1r_sw[kt][q], dW[6 + it * 2 + kt]);
-		// d_h1r
-		h8 dh1[4];
-		h8 d1_sw[2][2];
+				for (int s = 0; s < 4; ++s) t = mfma(st.hb[0][s], lds_frag(fw, FW_R2 + 8 * k + kt * 4 + s, lane), t);
+				sw_to_frags(t, true, H_sw[k + 1][kt]);
+			}
+			fwd_rgb_l2<1>(fw, lane, st, k);
+		}
+		// ---- backward ----
+		h8 g_sw[2]; // an output gradient in swapped layout
+		// output layer: dW = d_out * H_last^T
+		{ f16v t = mfma(dy0, I0, zero16()); sw_to_frags(t, false, g_sw); }
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[NT - 2 + kt] = mfma(g_sw[q], H_sw[NR - 1][kt][q], dW[NT - 2 + kt]);
+		// gradient at the last hidden layer, chain form (masked by the ReLU bits) and swapped (masked by the activation's sign)
+		h8 dh[4];
+		h8 d_sw[2][2];
 #pragma unroll
 		for (int mt = 0; mt < 2; ++mt) {
-			f16v d = zero16(), dsw = zero16();
-#pragma unroll
-			for (int s = 0; s < 4; ++s) {
-				const h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
-				d = mfma(a, dh[s], d);
-				dsw = mfma(dh[s], a, dsw);
-			}
-			dh1[2 * mt + 0] = to_frag_masked(d, 0, st.m1r[0] >> (16 * mt));
-			dh1[2 * mt + 1] = to_frag_masked(d, 1, st.m1r[0] >> (16 * mt));
-			sw_grad_to_frags(dsw, h1r_sw[mt], d1_sw[mt]);
+			const h8 a = lds_frag(bw, bw_r3(NR) + mt, lane);
+			const uint32_t mask = NR == 1 ? st.m1r[0] : st.m2r[NR >= 2 ? NR - 2 : 0][0];
+			f16v d = mfma(a, dy0, zero16());
+			dh[2 * mt + 0] = to_frag_masked(d, 0, mask >> (16 * mt));
+			dh[2 * mt + 1] = to_frag_masked(d, 1, mask >> (16 * mt));
+			f16v dsw = mfma(dy0, a, zero16());
+			sw_grad_to_frags(dsw, H_sw[NR - 1][mt], d_sw[mt]);
 		}
-		// rgb L1: dW[it][0] = d_h1r[it] * rin^T
+		// the 64 x 64 layers, last to first: dW(k)[it][kt] = d_H(k+2)[it] * H(k+1)[kt]^T, then the gradient at H(k+1)
+#pragma unroll
+		for (int k = NR - 2; k >= 0; --k) {
+#pragma unroll
+			for (int it = 0; it < 2; ++it)
+#pragma unroll
+				for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+					for (int q = 0; q < 2; ++q) dW[6 + 4 * k + it * 2 + kt] = mfma(d_sw[it][q], H_sw[k][kt][q], dW[6 + 4 * k + it * 2 + kt]);
+			h8 dhn[4];
+			h8 dn_sw[2][2];
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt) {
+				f16v d = zero16(), dsw = zero16();
+#pragma unroll
+				for (int s = 0; s < 4; ++s) {
+					const h8 a = lds_frag(bw, BW_R2 + 8 * k + mt * 4 + s, lane);
+					d = mfma(a, dh[s], d);
+					dsw = mfma(dh[s], a, dsw);
+				}
+				const uint32_t mask = k == 0 ? st.m1r[0] : st.m2r[k >= 1 ? k - 1 : 0][0];
+				dhn[2 * mt + 0] = to_frag_masked(d, 0, mask >> (16 * mt));
+				dhn[2 * mt + 1] = to_frag_masked(d, 1, mask >> (16 * mt));
+				sw_grad_to_frags(dsw, H_sw[k][mt], dn_sw[mt]);
+			}
+#pragma unroll
+			for (int x = 0; x < 4; ++x) dh[x] = dhn[x];
+#pragma unroll
+			for (int x = 0; x < 2; ++x) { d_sw[x][0] = dn_sw[x][0]; d_sw[x][1] = dn_sw[x][1]; }
+		}
+		// first colour layer: dW[it][0] = d_H1[it] * rin^T
 		{
 			h8 rin_sw[2];
 			f16v t = mfma(st.rin[0][0], I0, zero16()); t = mfma(st.rin[0][1], I1, t); sw_to_frags(t, false, rin_sw);
 #pragma unroll
 			for (int it = 0; it < 2; ++it)
 #pragma unroll
-				for (int q = 0; q < 2; ++q) dW[4 + it] = mfma(d1_sw[it][q], rin_sw[q], dW[4 + it]);
+				for (int q = 0; q < 2; ++q) dW[4 + it] = mfma(d_sw[it][q], rin_sw[q], dW[4 + it]);
 		}
 		// d_rin -> d_densout (+ dsigma on neuron 0)
 		h8 ddens;
 		{
 			f16v d = zero16();
 #pragma unroll
-			for (int s = 0; s < 4; ++s) d = mfma(lds_frag(bw, BW_R1 + s, lane), dh1[s], d);
+			for (int s = 0; s < 4; ++s) d = mfma(lds_frag(bw, BW_R1 + s, lane), dh[s], d);
 			uint32_t dummy = 0;
 			ddens = to_frag<false>(d, 0, dummy);
 			if (hi == 0) ddens[0] = (_Float16)((float)ddens[0] + (float)dsig);
@@ -1485,25 +1512,25 @@ k_wgrad(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t
 		}
 	}
 
-	// ---- reduce the 4 waves of the block through LDS (re-using the fragment region), 6 tiles at a time ----
-	float* red = (float*)smem; // 6 tiles * 16 regs * 64 lanes * 4 B = 24 KiB <= 44 KiB of fragments
-	float* dstp = partials + (size_t)blockIdx.x * (N_DW_TILES * 16 * 64);
+	// ---- reduce the 4 waves of the block through LDS (re-using the fragment region), 4 tiles at a time: 16 KiB <= the 28 KiB of fragments at NR = 1 ----
+	float* red = (float*)smem;
+	float* dstp = partials + (size_t)blockIdx.x * (NT * 16 * 64);
 #pragma unroll
-	for (int half = 0; half < 2; ++half) {
+	for (int part = 0; part < NT / 4; ++part) {
 		__syncthreads();
 		for (int w = 0; w < 4; ++w) {
 			if (wid == w) {
 #pragma unroll
-				for (int t = 0; t < 6; ++t)
+				for (int t = 0; t < 4; ++t)
 #pragma unroll
 					for (int r = 0; r < 16; ++r) {
 						float* dst = red + ((size_t)t * 16 + r) * 64 + lane;
-						*dst = (w == 0 ? 0.f : *dst) + dW[half * 6 + t][r];
+						*dst = (w == 0 ? 0.f : *dst) + dW[part * 4 + t][r];
 					}
 			}
 			__syncthreads();
 		}
-		for (int i = threadIdx.x; i < 6 * 16 * 64; i += blockDim.x) dstp[half * 6 * 16 * 64 + i] = red[i];
+		for (int i = threadIdx.x; i < 4 * 16 * 64; i += blockDim.x) dstp[part * 4 * 16 * 64 + i] = red[i];
 	}
 }
 
@@ -1575,8 +1602,8 @@ DEV void wgrad_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, co
 #pragma unroll
 	for (int mt = 0; mt < 2; ++mt) {
 		f16v d = mfma(lds_frag(bw, BW_R3 + mt, lane), dy0, zero16());
-		dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
-		dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+		dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0][0] >> (16 * mt));
+		dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0][0] >> (16 * mt));
 	}
 	h8 dh1[4];
 	{
@@ -1682,12 +1709,13 @@ k_wgrad2(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_
 // coalesced 256-byte reads, then combine through LDS in a fixed order (deterministic).
 // 16 wavefronts per 64 elements (each sums every 16th partial, 4 independent loads in flight), then a fixed-order tree over the 16 sums:
 // the 12.6 MB of partials stream at memory speed instead of as 64 dependent loads per wavefront (17.7 -> see DESIGN 8).
-__global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
+__global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad, uint32_t nr /* hidden colour layers */) {
 	__shared__ float sm[16][64];
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	const uint32_t e = blockIdx.x * 64 + lane; // element of [tile][r][lane]
 	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-	constexpr size_t PS = (size_t)N_DW_TILES * 16 * 64;
+	const uint32_t n_tiles = 8 + 4 * (nr - 1);
+	const size_t PS = (size_t)n_tiles * 16 * 64;
 	uint32_t g = wid;
 	for (; g + 48 < n_partials; g += 64) {
 		s0 += partials[(size_t)g * PS + e]; s1 += partials[(size_t)(g + 16) * PS + e];
@@ -1713,8 +1741,8 @@ __global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__
 	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
 	else if (t < 4) { layer_off = 2048; R = 16; C = 64; it = 0; kt = t - 2; }
 	else if (t < 6) { layer_off = 3072; R = 64; C = 32; it = t - 4; kt = 0; }
-	else if (t < 10) { layer_off = 5120; R = 64; C = 64; it = (t - 6) >> 1; kt = (t - 6) & 1; }
-	else { layer_off = 9216; R = 16; C = 64; it = 0; kt = t - 10; }
+	else if (t < (int)n_tiles - 2) { const int k = (t - 6) >> 2, u = (t - 6) & 3; layer_off = 5120 + 4096 * k; R = 64; C = 64; it = u >> 1; kt = u & 1; }
+	else { layer_off = 5120 + 4096 * ((int)nr - 1); R = 16; C = 64; it = 0; kt = t - ((int)n_tiles - 2); }
 	const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((int)lane >> 5);
 	const int k = kt * 32 + ((int)lane & 31);
 	if (i < R && k < C) mlp_grad[layer_off + i * C + k] = __float2half(s);
@@ -1792,8 +1820,8 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_train_fwd_bwd(EncTrainArgs a)
 		for (int mt = 0; mt < 2; ++mt) {
 			const h8 aa = lds_frag(bw, BW_R3 + mt, lane);
 			const f16v d = mfma(aa, dy0, zero16());
-			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
-			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0][0] >> (16 * mt));
+			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0][0] >> (16 * mt));
 		}
 		h8 dh1[4];
 #pragma unroll
@@ -1882,8 +1910,8 @@ k_encmlp_wgrad(const ngp_half* __restrict__ fw_frags, const ngp_half* __restrict
 		for (int mt = 0; mt < 2; ++mt) {
 			const h8 aa = lds_frag(bw, BW_R3 + mt, lane);
 			f16v d = mfma(aa, dy0, zero16());
-			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0] >> (16 * mt));
-			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0] >> (16 * mt));
+			dh[2 * mt + 0] = to_frag_masked(d, 0, st.m2r[0][0] >> (16 * mt));
+			dh[2 * mt + 1] = to_frag_masked(d, 1, st.m2r[0][0] >> (16 * mt));
 			f16v dsw = mfma(dy0, aa, zero16());
 			sw_grad_to_frags(dsw, h2_sw[mt], d2_sw[mt]);
 		}
@@ -2053,15 +2081,18 @@ void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, co
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 4);
 	const bool pair = (g_debug_flags & DBG_FWD_PAIR_LOADS) != 0; // measured slower than plain per-lane gathers (profiles/r01_microbench_ablation4_gather.log)
 	const bool occ4 = (g_debug_flags & DBG_FWD_OCC4) != 0; // 4 waves/SIMD (128 VGPRs, spills) instead of 3 (168 VGPRs)
-#define NGP_LAUNCH_INF(D, P, W, LDS, FF) hipLaunchKernelGGL((k_inference<D, 1, P, W, FF>), dim3(grid), dim3(256), LDS, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset)
-	if (F == 2) { // L = 16, F = 2 (no ablation variants)
-		if (density_only) NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 2); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024, 2);
-	} else if (density_only) {
-		if (pair) { if (occ4) NGP_LAUNCH_INF(true, true, 4, 8 * 1024, 4); else NGP_LAUNCH_INF(true, true, 3, 8 * 1024, 4); }
-		else { if (occ4) NGP_LAUNCH_INF(true, false, 4, 8 * 1024, 4); else NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 4); }
+	const uint32_t nr = mp.n_rgb_hidden;
+#define NGP_LAUNCH_INF(D, P, W, LDS, FF, NRR) hipLaunchKernelGGL((k_inference<D, 1, P, W, FF, NRR>), dim3(grid), dim3(256), LDS, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset)
+	if (density_only) { // the density network is the same for every colour-network depth
+		if (F == 2) NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 2, 2);
+		else if (pair) { if (occ4) NGP_LAUNCH_INF(true, true, 4, 8 * 1024, 4, 2); else NGP_LAUNCH_INF(true, true, 3, 8 * 1024, 4, 2); }
+		else { if (occ4) NGP_LAUNCH_INF(true, false, 4, 8 * 1024, 4, 2); else NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 4, 2); }
+	} else if (F == 2 || nr != 2) { // L = 16, F = 2 and / or 1 or 3 hidden colour layers (no ablation variants)
+		if (F == 2) { if (nr == 1) NGP_LAUNCH_INF(false, false, 3, n_fw(1) * 1024, 2, 1); else if (nr == 3) NGP_LAUNCH_INF(false, false, 3, n_fw(3) * 1024, 2, 3); else NGP_LAUNCH_INF(false, false, 3, n_fw(2) * 1024, 2, 2); }
+		else { if (nr == 1) NGP_LAUNCH_INF(false, false, 3, n_fw(1) * 1024, 4, 1); else NGP_LAUNCH_INF(false, false, 3, n_fw(3) * 1024, 4, 3); }
 	} else {
-		if (pair) { if (occ4) NGP_LAUNCH_INF(false, true, 4, N_FW_FRAGS * 1024, 4); else NGP_LAUNCH_INF(false, true, 3, N_FW_FRAGS * 1024, 4); }
-		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024, 4); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024, 4); }
+		if (pair) { if (occ4) NGP_LAUNCH_INF(false, true, 4, N_FW_FRAGS * 1024, 4, 2); else NGP_LAUNCH_INF(false, true, 3, N_FW_FRAGS * 1024, 4, 2); }
+		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024, 4, 2); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024, 4, 2); }
 	}
 #undef NGP_LAUNCH_INF
 }
@@ -2071,12 +2102,15 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	K2LazyArgs la = la_in;
 	const uint32_t tpw = 32u / la.tile_w;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
-#define NGP_LAUNCH_TILES(TW, FF) hipLaunchKernelGGL((k_inference_tiles<TW, FF>), dim3(grid), dim3(256), N_FW_FRAGS * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
+	const uint32_t nr = mp.n_rgb_hidden;
+#define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
+#define NGP_LAUNCH_TILES_W(FF, NRR) do { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, FF, NRR); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, FF, NRR); else NGP_LAUNCH_TILES(32, FF, NRR); } while (0)
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
-		if (F == 2) { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, 2); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, 2); else NGP_LAUNCH_TILES(32, 2); }
-		else { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, 4); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, 4); else NGP_LAUNCH_TILES(32, 4); }
+		if (F == 2) { if (nr == 1) NGP_LAUNCH_TILES_W(2, 1); else if (nr == 3) NGP_LAUNCH_TILES_W(2, 3); else NGP_LAUNCH_TILES_W(2, 2); }
+		else { if (nr == 1) NGP_LAUNCH_TILES_W(4, 1); else if (nr == 3) NGP_LAUNCH_TILES_W(4, 3); else NGP_LAUNCH_TILES_W(4, 2); }
 	}
+#undef NGP_LAUNCH_TILES_W
 #undef NGP_LAUNCH_TILES
 	(void)max_samples;
 }
@@ -2146,13 +2180,16 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
-	if (F == 2) { // L = 16, F = 2: every level through the lists (no atomics in T1) or, without lists, per-corner atomics
-		if ((flags & T1_DENSE_EXTERNAL) && denc_lv)
-			hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
-				(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
-		else
-			hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, true, 2>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
-				(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
+	const uint32_t nr = mp.n_rgb_hidden;
+	if (F == 2 || nr != 2) { // L = 16, F = 2 and / or 1 or 3 hidden colour layers: every level through the lists (no atomics in T1) or, without lists, atomics
+		const bool no_scatter = (flags & T1_DENSE_EXTERNAL) && denc_lv;
+#define NGP_LAUNCH_T1(SC, FF, NRR) hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, SC, FF, NRR>), dim3(grid), dim3(256), (n_fw(NRR) + n_bw(NRR)) * 1024, s, gm, mp, in, in_stride, n, \
+			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap)
+#define NGP_LAUNCH_T1_SC(FF, NRR) do { if (no_scatter) NGP_LAUNCH_T1(false, FF, NRR); else NGP_LAUNCH_T1(true, FF, NRR); } while (0)
+		if (F == 2) { if (nr == 1) NGP_LAUNCH_T1_SC(2, 1); else if (nr == 3) NGP_LAUNCH_T1_SC(2, 3); else NGP_LAUNCH_T1_SC(2, 2); }
+		else { if (nr == 1) NGP_LAUNCH_T1_SC(4, 1); else NGP_LAUNCH_T1_SC(4, 3); }
+#undef NGP_LAUNCH_T1_SC
+#undef NGP_LAUNCH_T1
 		return;
 	}
 	// 3 wavefronts per SIMD without spills (164 registers) beat 4 with 36 spilled registers: T1 + bin + accumulate 0.219 vs 0.244 ms (profiles/r02_t1_occupancy.txt)
@@ -2177,12 +2214,16 @@ void launch_grad_dense(hipStream_t s, const GradDenseArgs& a) {
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 		const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials) {
 	if (n == 0) return;
-	const uint32_t lds = (N_FW_FRAGS + N_BW_FRAGS) * 1024;
-	if (g_debug_flags & DBG_W_SINGLE_ROLE) hipLaunchKernelGGL(k_wgrad, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
+	const uint32_t nr = mp.n_rgb_hidden, lds = (uint32_t)(n_fw((int)nr) + n_bw((int)nr)) * 1024;
+#define NGP_LAUNCH_W(NRR) hipLaunchKernelGGL(k_wgrad_nr<NRR>, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials)
+	if (nr == 1) NGP_LAUNCH_W(1);
+	else if (nr == 3) NGP_LAUNCH_W(3);
+	else if (g_debug_flags & DBG_W_SINGLE_ROLE) NGP_LAUNCH_W(2);
 	else hipLaunchKernelGGL(k_wgrad2, dim3(n_partials), dim3(512), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
+#undef NGP_LAUNCH_W
 }
-void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad) {
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(N_DW_TILES * 16), dim3(1024), 0, s, partials, n_partials, (__half*)mlp_grad);
+void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden) {
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_dw_tiles((int)n_rgb_hidden) * 16), dim3(1024), 0, s, partials, n_partials, (__half*)mlp_grad, n_rgb_hidden);
 }
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a) {
 	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params / 4 + 255) / 256)), dim3(256), 0, s, a);

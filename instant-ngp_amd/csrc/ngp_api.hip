@@ -225,16 +225,21 @@ static void build_grid_meta(const ngp_model_config& c, GridMeta& g) {
 	g.offset[c.n_levels] = offset;
 }
 
-// MLP layers in parameter order (nerf_network.h:357-372): density L1, L2, rgb L1, L2, L3; row-major [out][in]
+// MLP layers in parameter order (nerf_network.h:357-372): density L1, L2, then the colour network's L1, its NR - 1 layers of 64 x 64, and its output
+// layer; row-major [out][in].  Fragment bases as in model_kernels.hip (FW_* / BW_*, fw_r3 / bw_r3).
 struct LayerDesc { uint32_t R, C, off, fw_base, bw_base; };
-static const LayerDesc kLayers[5] = {
-	{64, 32, 0, 0, 0}, {16, 64, 2048, 4, 4}, {64, 32, 3072, 8, 6}, {64, 64, 5120, 12, 10}, {16, 64, 9216, 20, 18}};
+static std::vector<LayerDesc> nerf_layers(uint32_t n_rgb_hidden) {
+	std::vector<LayerDesc> L = {{64, 32, 0, 0, 0}, {16, 64, 2048, 4, 4}, {64, 32, 3072, 8, 6}};
+	for (uint32_t k = 0; k + 1 < n_rgb_hidden; ++k) L.push_back({64, 64, 5120 + 4096 * k, 12 + 8 * k, 10 + 8 * k});
+	L.push_back({16, 64, 5120 + 4096 * (n_rgb_hidden - 1), 12 + 8 * (n_rgb_hidden - 1), 10 + 8 * (n_rgb_hidden - 1)});
+	return L;
+}
 
 // position of W[i][k] inside the forward / dgrad fragment buffers (see model_kernels.hip header):
 //   k-index map of a fragment element: k(s, hi, j) = 16 s + 8 (j>>2) + 4 hi + (j&3)
-static void build_perms(std::vector<uint32_t>& fw, std::vector<uint32_t>& bw) {
-	fw.assign(10240, 0xFFFFFFFFu); bw.assign(10240, 0xFFFFFFFFu);
-	for (const LayerDesc& L : kLayers) {
+static void build_perms(const std::vector<LayerDesc>& layers, uint32_t n_mlp, std::vector<uint32_t>& fw, std::vector<uint32_t>& bw) {
+	fw.assign(n_mlp, 0xFFFFFFFFu); bw.assign(n_mlp, 0xFFFFFFFFu);
+	for (const LayerDesc& L : layers) {
 		for (uint32_t i = 0; i < L.R; ++i) for (uint32_t k = 0; k < L.C; ++k) {
 			const uint32_t p = L.off + i * L.C + k;
 			{ // forward: A[row = i][k]; fragment index = base + (i/32) * (C/16) + s
@@ -257,8 +262,8 @@ static int model_refresh_half(ngp_model* m, hipStream_t s); // master -> params/
 
 extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_model** out) {
 	REQUIRE(cfg && out, "ngp_model_create: null argument");
-	REQUIRE(cfg->n_neurons == 64 && cfg->n_hidden_layers == 1 && cfg->n_hidden_layers_rgb == 2,
-		"this build specialises the fused kernels for configs/nerf/base.json topology (64 neurons, 1+2 hidden layers)");
+	REQUIRE(cfg->n_neurons == 64 && cfg->n_hidden_layers == 1 && cfg->n_hidden_layers_rgb >= 1 && cfg->n_hidden_layers_rgb <= 3,
+		"the fused kernels cover the FullyFusedMLP topologies of configs/nerf/base*.json: 64 neurons, density network with 1 hidden layer, colour network with 1, 2 or 3");
 	// the encoding feeds the 32-wide first layer directly in MFMA operand registers: L x F = 8 x 4 (configs/nerf/base.json) or 16 x 2 (the reference's 2022
 	// base.json, notebooks/instant_ngp.ipynb:5838); any log2_hashmap_size (base_14, small, big: table sizes the record lists do not cover fall back to half atomics)
 	REQUIRE((cfg->n_features_per_level == 4 && cfg->n_levels == 8) || (cfg->n_features_per_level == 2 && cfg->n_levels == 16), "the fused kernels take the hash grid as L = 8, F = 4 or L = 16, F = 2");
@@ -268,30 +273,32 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 	ngp_model* m = new ngp_model();
 	m->cfg = *cfg;
 	build_grid_meta(*cfg, m->gm);
-	m->n_mlp = 10240;
+	const uint32_t nr = cfg->n_hidden_layers_rgb, n_fw_halfs = n_fw_frags(nr) * FRAG_HALFS, n_bw_halfs = n_bw_frags(nr) * FRAG_HALFS;
+	const std::vector<LayerDesc> layers = nerf_layers(nr);
+	m->n_mlp = n_mlp_params(nr);
 	m->n_params = m->n_mlp + (uint64_t)m->gm.offset[cfg->n_levels] * cfg->n_features_per_level;
 	m->lr = cfg->learning_rate;
 	const uint64_t P = m->n_params;
 	if (dev_alloc(&m->gm_dev, 1) || dev_alloc(&m->master, P) || dev_alloc(&m->params, P) || dev_alloc(&m->params_inf, P) || dev_alloc(&m->grads, P) ||
 		dev_alloc(&m->adam_m, P) || dev_alloc(&m->adam_v, P) || dev_alloc(&m->ema, P) || dev_alloc(&m->adam_steps, P) ||
-		dev_alloc(&m->fw_perm, 10240) || dev_alloc(&m->bw_perm, 10240) || dev_alloc(&m->fw_frags, N_FW_FRAGS * FRAG_HALFS) ||
-		dev_alloc(&m->bw_frags, N_BW_FRAGS * FRAG_HALFS) || dev_alloc(&m->fw_frags_inf, N_FW_FRAGS * FRAG_HALFS)) { delete m; return 1; }
+		dev_alloc(&m->fw_perm, m->n_mlp) || dev_alloc(&m->bw_perm, m->n_mlp) || dev_alloc(&m->fw_frags, n_fw_halfs) ||
+		dev_alloc(&m->bw_frags, n_bw_halfs) || dev_alloc(&m->fw_frags_inf, n_fw_halfs)) { delete m; return 1; }
 	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(m->grads, 0, P * 2)); HIPCHK(hipMemset(m->adam_m, 0, P * 4)); HIPCHK(hipMemset(m->adam_v, 0, P * 4));
 	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 4));
-	HIPCHK(hipMemset(m->fw_frags, 0, N_FW_FRAGS * FRAG_HALFS * 2)); HIPCHK(hipMemset(m->bw_frags, 0, N_BW_FRAGS * FRAG_HALFS * 2));
-	HIPCHK(hipMemset(m->fw_frags_inf, 0, N_FW_FRAGS * FRAG_HALFS * 2));
+	HIPCHK(hipMemset(m->fw_frags, 0, n_fw_halfs * 2)); HIPCHK(hipMemset(m->bw_frags, 0, n_bw_halfs * 2));
+	HIPCHK(hipMemset(m->fw_frags_inf, 0, n_fw_halfs * 2));
 	std::vector<uint32_t> fwp, bwp;
-	build_perms(fwp, bwp);
+	build_perms(layers, (uint32_t)m->n_mlp, fwp, bwp);
 	HIPCHK(hipMemcpy(m->fw_perm, fwp.data(), fwp.size() * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(m->bw_perm, bwp.data(), bwp.size() * 4, hipMemcpyHostToDevice));
 	m->n_partials = wgrad_n_partials();
-	if (dev_alloc(&m->wgrad_partials, (size_t)m->n_partials * 12 * 16 * 64)) { delete m; return 1; }
+	if (dev_alloc(&m->wgrad_partials, (size_t)m->n_partials * (8 + 4 * (nr - 1)) * 16 * 64)) { delete m; return 1; }
 	// Trainer::initialize_params: pcg32{seed}; Xavier-uniform matrices, U(-1e-4, 1e-4) grid (element j <- draw j)
 	std::vector<float> init(P);
 	Rng rnd = make_rng(seed);
 	size_t p = 0;
-	for (const LayerDesc& L : kLayers) {
+	for (const LayerDesc& L : layers) {
 		const float scale = std::sqrt(6.0f / (float)(L.R + L.C));
 		for (uint32_t i = 0; i < L.R * L.C; ++i) init[p++] = rnd.next_float() * 2.0f * scale - scale;
 	}
@@ -360,6 +367,7 @@ static ModelPtrs model_ptrs(const ngp_model* m, bool inference) {
 	mp.grid = (inference ? m->params_inf : m->params) + m->n_mlp;
 	mp.fw_frags = inference ? m->fw_frags_inf : m->fw_frags;
 	mp.bw_frags = m->bw_frags;
+	mp.n_rgb_hidden = m->cfg.n_hidden_layers_rgb;
 	return mp;
 }
 
@@ -476,7 +484,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		}
 	}
 	{ ProfScope ps(P_W_WGRAD, sw); launch_wgrad(sw, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
-	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads); }
+	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads, m->cfg.n_hidden_layers_rgb); }
 	if (ba.n_hashed) {
 		ProfScope ps(P_GRAD_BIN, s);
 		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap; ba.n_features = m->gm.F;

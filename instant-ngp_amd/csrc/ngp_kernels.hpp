@@ -124,14 +124,18 @@ struct GridMeta {           // per-level constants, passed by value to kernels
 };
 
 // MFMA-fragment-ordered copies of the MLP weights (see model_kernels.hip header).
-constexpr uint32_t N_FW_FRAGS = 24;  // forward A-fragments: 4 + 4 + 4 + 8 + 4
+constexpr uint32_t N_FW_FRAGS = 24;  // forward A-fragments: 4 + 4 + 4 + 8 + 4   (two hidden colour layers: configs/nerf/base.json, and the image / SDF model)
 constexpr uint32_t N_BW_FRAGS = 20;  // dgrad A-fragments:   4 + 2 + 4 + 8 + 2
+constexpr uint32_t n_fw_frags(uint32_t n_rgb_hidden) { return 16 + 8 * (n_rgb_hidden - 1); } // NR hidden colour layers: NR - 1 layers of 64 x 64 (8 fragments each)
+constexpr uint32_t n_bw_frags(uint32_t n_rgb_hidden) { return 12 + 8 * (n_rgb_hidden - 1); }
+constexpr uint32_t n_mlp_params(uint32_t n_rgb_hidden) { return 64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 * (n_rgb_hidden - 1) + 16 * 64; }
 constexpr uint32_t FRAG_HALFS = 64 * 8;
 
 struct ModelPtrs {
 	const ngp_half* grid;       // hash table (params or inference params)
-	const ngp_half* fw_frags;   // N_FW_FRAGS * 512 halfs
-	const ngp_half* bw_frags;   // N_BW_FRAGS * 512 halfs
+	const ngp_half* fw_frags;   // n_fw_frags(n_rgb_hidden) * 512 halfs
+	const ngp_half* bw_frags;   // n_bw_frags(n_rgb_hidden) * 512 halfs
+	uint32_t n_rgb_hidden = 2;  // hidden layers of the colour network: 1, 2 (base.json) or 3
 };
 
 // lazy (front-to-back) K2 in rounds of 32-sample tiles (one tile = 32 consecutive samples of ONE ray): round r evaluates samples
@@ -196,7 +200,7 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs
 	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t n_features = 4);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
-void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad);
+void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden = 2);
 
 struct AdamArgs {
 	uint64_t n_params, n_mlp;

@@ -20,7 +20,21 @@ SHAPES = {
     "l8f4_t15": (1, dict(log2_hashmap_size=15)),                                          # configs/nerf/small.json
     "l8f4_t21": (1, dict(log2_hashmap_size=21)),                                          # configs/nerf/big.json
     "l16f2_t15": (1, dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=15)),
+    "l8f4_rgb1": (1, dict(n_hidden_layers_rgb=1)),                                        # configs/nerf/base_1layer.json
+    "l8f4_rgb3": (1, dict(n_hidden_layers_rgb=3)),                                        # configs/nerf/base_3layer.json
+    "l16f2_rgb3_t15": (1, dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=15, n_hidden_layers_rgb=3)),
 }
+
+
+def _mlp_blocks(cfg):
+    """parameter blocks of the two MLPs in tcnn order (nerf_network.h:357-372) and the total"""
+    nr = cfg.n_hidden_layers_rgb
+    b = {"density_l1": (0, 2048), "density_l2": (2048, 3072), "rgb_l1": (3072, 5120)}
+    for k in range(nr - 1):
+        b[f"rgb_l2_{k}"] = (5120 + 4096 * k, 5120 + 4096 * (k + 1))
+    o = 5120 + 4096 * (nr - 1)
+    b["rgb_out"] = (o, o + 3 * 64)  # rows 3..15 of the padded output layer receive no gradient
+    return b, o + 1024
 
 
 def _cfg(name):
@@ -58,10 +72,11 @@ def test_init_and_layout(ora, hip, name):
     cfg = _cfg(name)
     om = OraModel(ora, cfg, seed=1337)
     hm = HipModel(hip, cfg, seed=1337)
-    assert om.n == hm.n and om.n_mlp == hm.n_mlp == 10240
+    n_mlp = _mlp_blocks(cfg)[1]
+    assert om.n == hm.n and om.n_mlp == hm.n_mlp == n_mlp
     assert np.array_equal(om.params_fp, hm.read("master", torch))
     L, F, offs, res, sc = _layout(hip, hm, cfg)
-    assert hm.n == 10240 + offs[L] * F
+    assert hm.n == n_mlp + offs[L] * F
     if name == "l16f2_t19_aabb4":  # the reference's own log: `GridEncoding: Nmin=16 b=1.51572 F=2 T=2^19 L=16`, total_encoding_params=13074912
         assert offs[L] * F == 13074912 and abs(cfg.per_level_scale - 1.51572) < 5e-6
 
@@ -121,12 +136,12 @@ def test_training_step_gradients_all_scatter_layouts(ora, hip, name):
     gref = half_to_f32(om.grads.copy())
     cd = torch.from_numpy(c).cuda(); dld = torch.from_numpy(dl.view(np.int16)).cuda()
     L, F, offs, res, sc = _layout(hip, hm, cfg)
-    blocks = {"density_l1": (0, 2048), "density_l2": (2048, 3072), "rgb_l1": (3072, 5120), "rgb_l2": (5120, 9216), "rgb_l3": (9216, 9216 + 3 * 64)}
+    blocks, n_mlp = _mlp_blocks(cfg)
     for l in range(L):
-        blocks[f"grid_level_{l}"] = (10240 + offs[l] * F, 10240 + offs[l + 1] * F)
+        blocks[f"grid_level_{l}"] = (n_mlp + offs[l] * F, n_mlp + offs[l + 1] * F)
     got = {}
     try:
-        for vname, cl2, cap, flags in [("chunk12", 12, 0, 0), ("chunk11", 11, 0, 0), ("chunk12_overflow", 12, 2048, 0), ("atomics_only", 12, 0, 2048)]:
+        for vname, cl2, cap, flags in [("chunk12", 12, 0, 0), ("chunk11", 11, 0, 0), ("chunk12_overflow", 12, 2048, 0), ("atomics_only", 12, 0, 2048), ("w_single_role", 12, 0, 32768)]:
             A.check(hip, hip.ngp_debug_set_bin_params(cl2, 0, cap)); hip.ngp_debug_set_flags(flags)
             A.check(hip, hip.ngp_model_training_step(hm.h, None, dptr(cd), 7, n, dptr(dld), 4))
             torch.cuda.synchronize()
@@ -138,9 +153,9 @@ def test_training_step_gradients_all_scatter_layouts(ora, hip, name):
             print(name, vname, {k: f"{v:.1e}" for k, v in report.items()})
             for k, v in report.items():
                 assert v < (2e-2 if not k.startswith("grid") else 5e-2), (name, vname, k, v)
-        assert np.all(half_to_f32(got["chunk12"])[9216 + 3 * 64:10240] == 0)  # rgb_l3 rows 3..15 receive no gradient
-        big = np.abs(gref[10240:]) > 1e-4
-        assert np.all(got["chunk12"][10240:][big] != 0)
+        assert np.all(half_to_f32(got["chunk12"])[blocks["rgb_out"][1]:n_mlp] == 0)  # output-layer rows 3..15 receive no gradient
+        big = np.abs(gref[n_mlp:]) > 1e-4
+        assert np.all(got["chunk12"][n_mlp:][big] != 0)
         # the hashed levels of every list layout hold the exact sum of the same records
         for l in range(L):
             lo, hi_ = blocks[f"grid_level_{l}"]
@@ -150,7 +165,7 @@ def test_training_step_gradients_all_scatter_layouts(ora, hip, name):
         A.check(hip, hip.ngp_debug_set_bin_params(12, 0, 0)); hip.ngp_debug_set_flags(0)
 
 
-@pytest.mark.parametrize("name", ["l16f2_t19", "l8f4_t15", "l8f4_t21", "l16f2_t15"])
+@pytest.mark.parametrize("name", ["l16f2_t19", "l8f4_t15", "l8f4_t21", "l16f2_t15", "l8f4_rgb1", "l8f4_rgb3", "l16f2_rgb3_t15"])
 def test_short_training_run(hip, name):
     """each shape creates, trains and learns: the per-batch loss falls below a third of its initial value within 150 steps of the small synthetic scene"""
     import torch
