@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the PSNR after the timed region (untimed), e.g. 5000,10000,35000")
     ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
     ap.add_argument("--ab-seeds", type=int, default=1, help="--ab-psnr: number of seeds (1337, 1338, ...) per path; mean, standard deviation and the paired difference with its standard error are reported")
+    ap.add_argument("--ab-seed0", type=int, default=1337, help="--ab-psnr: first seed")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = --batch samples per GPU per step (default, the driver's mode); strong = --batch samples per step in total (B / N per GPU)")
     ap.add_argument("--dp-backend", choices=["auto", "rccl", "torch"], default="auto", help="N > 1: gradient / counter all-reduce inside libngp_hip (RCCL, ngp_comm_*) or through torch.distributed")
     args = ap.parse_args()
@@ -459,7 +460,7 @@ def main():
 
     ab = None
     if rank == 0 and world == 1 and args.ab_psnr:
-        ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[1337 + i for i in range(max(args.ab_seeds, 1))])
+        ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[args.ab_seed0 + i for i in range(max(args.ab_seeds, 1))])
 
     if rank == 0:
         lego = args.scene == "synthetic"

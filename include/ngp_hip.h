@@ -53,7 +53,7 @@ enum { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONEN
 enum { NGP_LOSS_L2 = 0, NGP_LOSS_L1 = 1, NGP_LOSS_MAPE = 2, NGP_LOSS_SMAPE = 3, NGP_LOSS_HUBER = 4,
        NGP_LOSS_LOGL1 = 5, NGP_LOSS_RELATIVE_L2 = 6 };
 
-/* TrainingImageMetadata, nerf_device.cuh:45-60 (depth / explicit rays / light_dir: out of scope) */
+/* TrainingImageMetadata, nerf_device.cuh:45-60 (explicit rays / light_dir: out of scope) */
 typedef struct ngp_image_meta {
 	const void* pixels;        /* device pointer to the image (RGBA8 sRGB, RGBA16F or RGBA32F) */
 	int32_t image_data_type;   /* NGP_IMAGE_* */
@@ -64,6 +64,7 @@ typedef struct ngp_image_meta {
 	float rolling_shutter[4];
 	float lens_params[7];
 	float _pad;
+	const float* depth;        /* optional: one float per pixel in scene units (0 = no measurement), nerf_loader.cu:73-82; NULL = no depth for this image */
 } ngp_image_meta;
 
 /* TrainingXForm {mat4x3 start, end}, common.h:177-182; mat4x3 = 4 columns of vec3 (col-major) */
@@ -114,6 +115,9 @@ typedef struct ngp_nerf_options {
 	/* ETrainMode (testbed.h:822; python_api.cu TrainMode): 0 Nerf, 1 Rfl, 2 RflRelax -- the radiance-field-loss gradients of
 	 * fused_kernels/train_nerf.cuh:391-410, here evaluated by the unfused K1/K2/K3 pipeline (no JIT needed) */
 	int32_t train_mode;
+	/* depth supervision (testbed.h:796, 824; testbed_nerf.cu:1027-1029, 1126-1129): weight of the depth term (0 = off) and its loss (default L1) */
+	float depth_supervision_lambda;
+	int32_t depth_loss_type;
 } ngp_nerf_options;
 
 /* Counters read back by the host (NerfCounters, testbed.h / testbed_nerf.cu:2669-2702). */
@@ -445,10 +449,15 @@ int ngp_nerf_set_k2_params(ngp_nerf*, uint32_t rounds, uint32_t tile_w);
    all seven lens modes of common_device.cuh:413-577.  Test hooks: no GPU needed.  uv_to_ray returns 0 where the lens has no ray. */
 int ngp_host_uv_to_ray(const ngp_image_meta* meta, const float xform12[12], const float uv[2], float origin_out[3], float dir_out[3]);
 int ngp_host_pos_to_uv(const ngp_image_meta* meta, const float xform12[12], const float pos[3], float uv_out[2]);
+/* get_xform_given_rolling_shutter (common_device.cuh:670-674) of csrc/ngp_device.hpp evaluated on the host (test hook): the training camera of a pixel
+ * (uv) of a frame with rolling shutter {a, b, c, d} -> t = a + b u + c v + d motionblur_time, interpolated between xform.start and xform.end */
+int ngp_host_xform_given_rolling_shutter(const ngp_xform* xform, const float rolling_shutter[4], const float uv[2], float motionblur_time, float xform12_out[12]);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);
 /* train mode of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options) */
 int ngp_debug_set_train_mode(int mode);
+/* depth supervision of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options; testbed_nerf.cu:1027-1029, 1126-1129) */
+int ngp_debug_set_depth_supervision(float depth_supervision_lambda, int depth_loss_type);
 /* layout of the hashed levels' binned gradient scatter (csrc/model_kernels.hip k_grad_bin / k_grad_accumulate): table entries per
  * chunk = 2^chunk_log2 (11 or 12), one block per chunk (split = 0) or per (chunk, feature pair) (split = 1), list capacity override
  * in records (0 = twice the mean; a small value forces the list-overflow path for the tests); process-wide */

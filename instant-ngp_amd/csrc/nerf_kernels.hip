@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 		f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
 		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) valid = false;
 		if (valid) {
-			(void)rng.next_float(); // motionblur_time
-			const M43 xform = ldm43(a.xforms[img].start);
+			const float motionblur_time = rng.next_float();
+			const M43 xform = xform_given_rolling_shutter(a.xforms[img], m.rolling_shutter, uv, motionblur_time); // common_device.cuh:670-674
 			if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform.c[3]; rd = xform.c[2]; } // testbed_nerf.cu:776-778
 			rdn = normalize3(rd);
 			f2 tminmax = aabb.ray_intersect(ro, rdn);
@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	const Box aabb(a.aabb);
 	float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f}, startt = 0.f, nprime = 0.f; uint32_t flags = 0;
 	if (!masked) {
-		(void)rng.next_float(); // motionblur_time
-		const M43 xform = ldm43(a.xforms[img].start);
+		const float motionblur_time = rng.next_float();
+		const M43 xform = xform_given_rolling_shutter(a.xforms[img], m.rolling_shutter, uv, motionblur_time); // common_device.cuh:670-674
 		f3 ro, rd;
 		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform.c[3]; rd = xform.c[2]; } // testbed_nerf.cu:776-778
 		const f3 rdn = normalize3(rd);
@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 		o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; d[0] = rd.x; d[1] = rd.y; d[2] = rd.z;
 		nprime = to_stepping_space(startt, a.cone_angle_constant);
 		flags = aabb.contains(ro + startt * rdn) ? 1u : 0u;
-	}
+		// K3's target depth (testbed_nerf.cu:1027): distance along the unnormalised direction; <= 0 = not supervised
+		out.tgt[6] = sqrtf(dot3(rd, rd)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
+	} else out.tgt[6] = -1.0f;
 	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2];
 	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = flags; out.ray_index = i;
 	if (!a.ray_targets_out) for (int k = 0; k < 6; ++k) out.tgt[k] = 0.f;
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 		}
 		if (a.ray_targets_out) {
 			float4* tg = (float4*)(a.ray_targets_out + (size_t)slot * 8);
-			tg[0] = make_float4(r.tgt[0], r.tgt[1], r.tgt[2], r.tgt[3]); tg[1] = make_float4(r.tgt[4], r.tgt[5], 0.f, 0.f);
+			tg[0] = make_float4(r.tgt[0], r.tgt[1], r.tgt[2], r.tgt[3]); tg[1] = make_float4(r.tgt[4], r.tgt[5], r.tgt[6], 0.f);
 		}
 	}
 	if (!fits) continue;
@@ -560,6 +562,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 	float T = 1.f;
 	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), loss_bg = mk3(0.f);
 	f3 rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
+	float depth_ray = 0.f, target_depth = -1.f;
 	if (active) {
 		numsteps = a.numsteps_inout[i * 2 + 0];
 		base = a.numsteps_inout[i * 2 + 1];
@@ -585,6 +588,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			if (tex.w > 0) rgbtarget = linear_to_srgb3(trgb / tex.w) * tex.w + (1.0f - tex.w) * background_color;
 			else rgbtarget = background_color;
 		}
+		target_depth = len3(ld3(a.rays_in[i].d)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f); // testbed_nerf.cu:1027
 		const float EPSILON = 1e-4f;
 		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
 			if (T < EPSILON) break;
@@ -595,6 +599,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			const float alpha = 1.f - __expf(-density * dt);
 			const float weight = alpha * T;
 			rgb_ray = rgb_ray + weight * rgb;
+			if (a.depth_lambda > 0.0f) { const float* ck = cin + (size_t)compacted_numsteps * 7; depth_ray += weight * dist3(unwarp_position(mk3(ck[0], ck[1], ck[2]), aabb), ray_o); }
 			if (a.train_mode == 1) { f3 ll, lg2; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lg2); loss_bg = loss_bg + weight * ll; }
 			T *= (1.f - alpha);
 		}
@@ -627,6 +632,8 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
 		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
+		float depth_loss_gradient = 0.f, depth_ray2 = 0.f;
+		if (target_depth > 0.0f) { f3 dl_, dg_; loss_and_gradient(mk3(target_depth), mk3(depth_ray), a.depth_loss_type, dl_, dg_); depth_loss_gradient = a.depth_lambda * dg_.x; } // testbed_nerf.cu:1028-1029
 		f3 rgb_ray2 = mk3(0.f), loss_bg2 = mk3(0.f);
 		T = 1.f;
 		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
@@ -644,11 +651,13 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			const float alpha = 1.f - __expf(-density * dt);
 			const float weight = alpha * T;
 			rgb_ray2 = rgb_ray2 + weight * rgb;
+			depth_ray2 += weight * depth;
 			T *= (1.f - alpha);
 			const f3 suffix = rgb_ray - rgb_ray2;
 			f3 dloss_by_drgb = weight * lgrad;
 			const float density_derivative = act_density_d(l3, a.density_activation);
-			float dloss_by_dmlp = density_derivative * (dt * (dot3(lgrad, T * rgb - suffix) + 0.0f));
+			const float depth_supervision = depth_loss_gradient * (T * depth - (depth_ray - depth_ray2)); // testbed_nerf.cu:1126-1127
+			float dloss_by_dmlp = density_derivative * (dt * (dot3(lgrad, T * rgb - suffix) + depth_supervision));
 			if (a.train_mode == 1) { // Rfl, fused_kernels/train_nerf.cuh:391-396
 				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
 				loss_bg2 = loss_bg2 + weight * ll;
@@ -729,6 +738,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	const __half* no = nullptr;
 	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color), loss_bg = mk3(0.f);
 	float T_final = 1.f;
+	float depth_ray = 0.f, target_depth = -1.f; // depth supervision (a.depth_lambda > 0, wave-uniform)
 	// first 64 samples of the ray stay in registers for the adjoint pass (most rays have <= 64 samples)
 	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f, k_cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	const bool vec_out = a.output_stride == 4, vec_dl = a.dloss_stride == 4;
@@ -747,7 +757,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		f4 tex = {0.f, 0.f, 0.f, 0.f};
 		if (a.ray_targets) { // computed once per ray by k1_setup
 			const float4 t0 = ((const float4*)(a.ray_targets + (size_t)i * 8))[0], t1 = ((const float4*)(a.ray_targets + (size_t)i * 8))[1];
-			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y);
+			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y); target_depth = t1.z;
 		} else {
 			const uint32_t ray_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ray_indices_in[i]);
 			// The target-pixel chain (ray index -> image metadata -> texel) is issued BEFORE the sample pass so that its three
@@ -760,6 +770,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			rng.advance(1); // motionblur_time
 			if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 			tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
+			target_depth = len3(ld3(a.rays_in[i].d)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
 			// target colour and background: identical to the sequential kernel (uniform across the wave); needed BEFORE the sample pass by the Rfl mode
 			background_color = srgb_to_linear3(background_color);
 			const f3 trgb = mk3(tex.x, tex.y, tex.z);
@@ -779,7 +790,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		for (uint32_t c0 = 0; c0 < numsteps; c0 += 64) {
 			const uint32_t s = c0 + lane;
 			const bool valid = s < numsteps;
-			float alpha = 0.f; f3 rgb = mk3(0.f);
+			float alpha = 0.f, sdepth = 0.f; f3 rgb = mk3(0.f);
 			if (valid) {
 				float l0, l1, l2, l3, dtw;
 				load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
@@ -793,6 +804,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
 				const float dt = unwarp_dt(dtw);
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
+				if (a.depth_lambda > 0.0f) { const float* ci = cin + (size_t)s * 7; sdepth = dist3(unwarp_position(mk3(ci[0], ci[1], ci[2]), aabb), ray_o); }
 			}
 			const float incl = wave_incl_prod(1.f - alpha, lane);
 			float excl = __shfl_up(incl, 1, 64);
@@ -804,6 +816,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const float w = proc ? alpha * T_k : 0.f;
 			// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
 			rgb_ray = rgb_ray + mk3(wave_total(proc ? w * rgb.x : 0.f), wave_total(proc ? w * rgb.y : 0.f), wave_total(proc ? w * rgb.z : 0.f));
+			if (a.depth_lambda > 0.0f) depth_ray += wave_total(proc ? w * sdepth : 0.f);
 			if (a.train_mode == 1) { // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
 				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
 				loss_bg = loss_bg + mk3(wave_total(proc ? w * ll.x : 0.f), wave_total(proc ? w * ll.y : 0.f), wave_total(proc ? w * ll.z : 0.f));
@@ -845,6 +858,8 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
 		float T_run = 1.f;
 		f3 ray2_run = mk3(0.f), lb2_run = mk3(0.f);
+		float depth_loss_gradient = 0.f, depth2_run = 0.f;
+		if (target_depth > 0.0f) { f3 dl_, dg_; loss_and_gradient(mk3(target_depth), mk3(depth_ray), a.depth_loss_type, dl_, dg_); depth_loss_gradient = a.depth_lambda * dg_.x; } // testbed_nerf.cu:1028-1029
 		for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
 			const uint32_t s = c0 + lane;
 			const bool valid = s < compacted;
@@ -873,6 +888,8 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const float T_k = T_run * excl, T_after = T_run * incl;
 			const float weight = alpha * T_k;
 			const f3 ray2 = ray2_run + mk3(wave_incl_sum(weight * rgb.x, lane), wave_incl_sum(weight * rgb.y, lane), wave_incl_sum(weight * rgb.z, lane));
+			float depth2 = depth2_run;
+			if (a.depth_lambda > 0.0f) depth2 = depth2_run + wave_incl_sum(weight * depth, lane);
 			f3 lloc = mk3(0.f), gloc = mk3(0.f), lb2 = lb2_run;
 			if (a.train_mode == 1) { // Rfl: per-sample loss against the target and its running (inclusive) weighted sum
 				loss_and_gradient(rgbtarget, rgb, a.loss_type, lloc, gloc);
@@ -884,7 +901,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
 				const f3 suffix = rgb_ray - ray2;
 				f3 dloss_by_drgb = weight * lgrad;
-				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + 0.0f;
+				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + depth_loss_gradient * (T_after * depth - (depth_ray - depth2)); // depth supervision, testbed_nerf.cu:1126-1129
 				if (a.train_mode == 1) { // fused_kernels/train_nerf.cuh:391-396
 					dloss_by_drgb = weight * gloc;
 					const f3 v = T_after * lloc - (loss_bg - lb2);
@@ -909,6 +926,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			}
 			T_run = T_run * __shfl(incl, 63, 64);
 			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
+			if (a.depth_lambda > 0.0f) depth2_run = __shfl(depth2, 63, 64);
 			if (a.train_mode == 1) lb2_run = mk3(__shfl(lb2.x, 63, 64), __shfl(lb2.y, 63, 64), __shfl(lb2.z, 63, 64));
 		}
 	}

@@ -75,6 +75,13 @@ extern "C" int ngp_host_uv_to_ray(const ngp_image_meta* m, const float xform12[1
 	o_out[0] = o.x; o_out[1] = o.y; o_out[2] = o.z; d_out[0] = d.x; d_out[1] = d.y; d_out[2] = d.z;
 	return ok ? 1 : 0;
 }
+// get_xform_given_rolling_shutter of csrc/ngp_device.hpp evaluated on the host (test hook)
+extern "C" int ngp_host_xform_given_rolling_shutter(const ngp_xform* xform, const float rolling_shutter[4], const float uv[2], float motionblur_time, float xform12_out[12]) {
+	const f2 u = {uv[0], uv[1]};
+	const M43 m = xform_given_rolling_shutter(*xform, rolling_shutter, u, motionblur_time);
+	for (int c = 0; c < 4; ++c) { xform12_out[c * 3 + 0] = m.c[c].x; xform12_out[c * 3 + 1] = m.c[c].y; xform12_out[c * 3 + 2] = m.c[c].z; }
+	return 0;
+}
 extern "C" int ngp_host_pos_to_uv(const ngp_image_meta* m, const float xform12[12], const float pos[3], float uv_out[2]) {
 	const f2 uv = pos_to_uv(mk3(pos[0], pos[1], pos[2]), m->resolution, m->focal_length, ldm43(xform12), m->principal_point, m->lens_mode, m->lens_params);
 	uv_out[0] = uv.x; uv_out[1] = uv.y;
@@ -1057,6 +1064,8 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 }
 static int g_k3_train_mode = 0; // stand-alone ngp_k_compute_loss only (test hook): ETrainMode
 extern "C" int ngp_debug_set_train_mode(int mode) { g_k3_train_mode = mode; return 0; }
+static float g_k3_depth_lambda = 0.f; static int g_k3_depth_loss_type = NGP_LOSS_L1; // stand-alone ngp_k_compute_loss only (test hook): depth supervision
+extern "C" int ngp_debug_set_depth_supervision(float lambda, int loss_type) { g_k3_depth_lambda = lambda; g_k3_depth_loss_type = loss_type; return 0; }
 extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t* n_rays_ptr, ngp_aabb aabb, ngp_pcg32 rng, uint32_t max_samples_compacted,
 		const uint32_t* rays_counter, float loss_scale, const float background_color[3], int color_space_srgb, int random_bg_color, int linear_colors,
 		uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_half* network_output, uint32_t output_stride, uint32_t* numsteps_counter_compacted,
@@ -1064,7 +1073,7 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 		uint32_t dloss_stride, int loss_type, float* loss_output, int rgb_activation, int density_activation, int snap_to_pixel_centers,
 		const float* mean_density_ptr, float near_distance) {
 	K3Args a;
-	a.ray_targets = nullptr; a.train_mode = g_k3_train_mode;
+	a.ray_targets = nullptr; a.train_mode = g_k3_train_mode; a.depth_lambda = g_k3_depth_lambda; a.depth_loss_type = g_k3_depth_loss_type;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.aabb = aabb; a.rng = rng; a.max_samples_compacted = max_samples_compacted; a.rays_counter = rays_counter;
 	a.loss_scale = loss_scale; for (int k = 0; k < 3; ++k) a.background_color[k] = background_color[k];
 	a.color_space_srgb = color_space_srgb; a.random_bg_color = random_bg_color; a.linear_colors = linear_colors; a.n_images = n_training_images; a.metadata = metadata;
@@ -1260,6 +1269,14 @@ extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_imag
 		t->owned_pixels.push_back(d);
 		HIPCHK(hipMemcpy(d, pixels_host[i], bytes, hipMemcpyHostToDevice));
 		m[i].pixels = d;
+		if (m[i].depth) { // host pointer to one float per pixel (nerf_loader.cu copy_depth: integer depth * depth_scale): uploaded like the pixels
+			const size_t db = (size_t)m[i].resolution[0] * m[i].resolution[1] * sizeof(float);
+			void* dd = nullptr;
+			HIPCHK(hipMalloc(&dd, db));
+			t->owned_pixels.push_back(dd);
+			HIPCHK(hipMemcpy(dd, m[i].depth, db, hipMemcpyHostToDevice));
+			m[i].depth = (const float*)dd;
+		}
 	}
 	return set_dataset_common(t, n, m, xforms);
 }
@@ -1358,6 +1375,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 		k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
 		k1.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
+		k1.depth_lambda = o.depth_supervision_lambda;
 		return k1;
 	};
 	if (phase & 1) {
@@ -1393,6 +1411,8 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	k3.loss_type = o.loss_type; k3.loss_output = &c->loss_sum; k3.rgb_activation = o.rgb_activation; k3.density_activation = o.density_activation;
 	k3.snap_to_pixel_centers = o.snap_to_pixel_centers; k3.mean_density_ptr = t->mean; k3.near_distance = o.near_distance;
 	k3.ray_targets = lattice ? t->ray_targets : nullptr; k3.train_mode = o.train_mode; k3.k3_scratch = t->k3_scratch;
+	k3.depth_lambda = o.depth_supervision_lambda; k3.depth_loss_type = o.depth_loss_type;
+	if (k3.depth_lambda > 0.f) k3.k3_scratch = nullptr; // the two-pass ablation kernel has no depth term: the one-pass kernel runs
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	// single rank, forward and backward in one call: the controller rides on K4's last workgroup (no launch of its own)

@@ -327,6 +327,57 @@ NGP_HD f2 ld_random_pixel_offset(uint32_t spp) {
 	return {ox - floorf(ox), oy - floorf(oy)};
 }
 
+// ---- rolling shutter / motion blur: the training camera at a pixel's exposure time --------------------------------------------------------
+// get_xform_given_rolling_shutter + camera_slerp, common_device.cuh:665-674: rotation = slerp(mat3(start), mat3(end), t), position = mix(start[3], end[3], t),
+// t = rs.x + rs.y u + rs.z v + rs.w motionblur_time.  slerp(mat3, mat3, t) is tiny-cuda-nn's (vec.h, GLM-derived; the submodule is absent from the mount,
+// restated from the published algorithm): matrix -> quaternion by the largest-diagonal rule, quaternion slerp along the short arc (linear when the
+// quaternions almost coincide), quaternion -> matrix.  A frame WITHOUT motion data (start == end, rolling_shutter == 0) keeps its matrix untouched: the
+// reference sends it through the same round trip at t = 0, which returns the matrix up to quaternion rounding that cannot be pinned without tcnn's sources.
+struct Quat { float x, y, z, w; };
+NGP_HD Quat quat_normalize(Quat q) { const float l = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w); return {q.x / l, q.y / l, q.z / l, q.w / l}; }
+NGP_HD Quat quat_from_mat3(f3 c0, f3 c1, f3 c2) { // columns c0, c1, c2; m[col][row]
+	const float fx = c0.x - c1.y - c2.z, fy = c1.y - c0.x - c2.z, fz = c2.z - c0.x - c1.y, fw = c0.x + c1.y + c2.z;
+	int big = 0; float fb = fw;
+	if (fx > fb) { fb = fx; big = 1; }
+	if (fy > fb) { fb = fy; big = 2; }
+	if (fz > fb) { fb = fz; big = 3; }
+	const float bv = sqrtf(fb + 1.0f) * 0.5f, mult = 0.25f / bv;
+	switch (big) {
+		case 0: return {(c1.z - c2.y) * mult, (c2.x - c0.z) * mult, (c0.y - c1.x) * mult, bv};
+		case 1: return {bv, (c0.y + c1.x) * mult, (c2.x + c0.z) * mult, (c1.z - c2.y) * mult};
+		case 2: return {(c0.y + c1.x) * mult, bv, (c1.z + c2.y) * mult, (c2.x - c0.z) * mult};
+		default: return {(c2.x + c0.z) * mult, (c1.z + c2.y) * mult, bv, (c0.y - c1.x) * mult};
+	}
+}
+NGP_HD void mat3_from_quat(Quat q, f3& c0, f3& c1, f3& c2) {
+	const float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z, qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+	c0 = mk3(1.0f - 2.0f * (qyy + qzz), 2.0f * (qxy + qwz), 2.0f * (qxz - qwy));
+	c1 = mk3(2.0f * (qxy - qwz), 1.0f - 2.0f * (qxx + qzz), 2.0f * (qyz + qwx));
+	c2 = mk3(2.0f * (qxz + qwy), 2.0f * (qyz - qwx), 1.0f - 2.0f * (qxx + qyy));
+}
+NGP_HD Quat quat_slerp(Quat x, Quat y, float a) {
+	Quat z = y;
+	float cos_theta = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+	if (cos_theta < 0.0f) { z = {-y.x, -y.y, -y.z, -y.w}; cos_theta = -cos_theta; } // the short way round
+	if (cos_theta > 1.0f - 1.1920929e-07f) return {x.x + a * (z.x - x.x), x.y + a * (z.y - x.y), x.z + a * (z.z - x.z), x.w + a * (z.w - x.w)}; // mix
+	const float angle = acosf(cos_theta), s0 = sinf((1.0f - a) * angle), s1 = sinf(a * angle), sd = sinf(angle);
+	return {(s0 * x.x + s1 * z.x) / sd, (s0 * x.y + s1 * z.y) / sd, (s0 * x.z + s1 * z.z) / sd, (s0 * x.w + s1 * z.w) / sd};
+}
+NGP_HD M43 camera_slerp(const M43& a, const M43& b, float t) {
+	const Quat q = quat_normalize(quat_slerp(quat_normalize(quat_from_mat3(a.c[0], a.c[1], a.c[2])), quat_normalize(quat_from_mat3(b.c[0], b.c[1], b.c[2])), t));
+	M43 r;
+	mat3_from_quat(q, r.c[0], r.c[1], r.c[2]);
+	r.c[3] = a.c[3] * (1.0f - t) + b.c[3] * t; // mix
+	return r;
+}
+NGP_HD M43 xform_given_rolling_shutter(const ngp_xform& X, const float rs[4], f2 uv, float motionblur_time) {
+	bool moving = rs[0] != 0.f || rs[1] != 0.f || rs[2] != 0.f || rs[3] != 0.f;
+	for (int k = 0; k < 12; ++k) moving |= X.start[k] != X.end[k];
+	if (!moving) return ldm43(X.start);
+	const float pixel_t = rs[0] + rs[1] * uv.x + rs[2] * uv.y + rs[3] * motionblur_time;
+	return camera_slerp(ldm43(X.start), ldm43(X.end), pixel_t);
+}
+
 // ---- camera ----------------------------------------------------------------------------------
 NGP_HD void opencv_distortion_delta(const float* p, float u, float v, float* du, float* dv) {
 	const float k1 = p[0], k2 = p[1], p1 = p[2], p2 = p[3];
@@ -489,6 +540,11 @@ NGP_HD f4 tonemap_pixel(f4 c, float exposure_scale, float bg0, float bg1, float 
 	return {rgb.x, rgb.y, rgb.z, c.w + weight};
 }
 
+// read_depth, common_device.cuh:874-878
+NGP_D float read_depth(f2 uv, const int32_t res[2], const float* __restrict__ depth) {
+	const int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1), py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);
+	return depth[(size_t)px + (size_t)py * res[0]];
+}
 NGP_D f4 read_rgba(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type) {
 	int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1);
 	int py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);

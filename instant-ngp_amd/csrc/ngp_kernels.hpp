@@ -64,6 +64,7 @@ struct K1Args {
 	// optional (lattice K1 only): per-ray training target {rgbtarget[3], background[3], 0, 0} for K3, computed by the thread-per-ray
 	// setup kernel so that K3's wavefronts do not all repeat it (same arithmetic as compute_loss_kernel_train_nerf)
 	float* ray_targets_out; float background_color[3]; int color_space_srgb, random_bg_color, linear_colors;
+	float depth_lambda = 0.f; // > 0: the ray's target depth (testbed_nerf.cu:1027) goes into slot 6 of its target record
 };
 
 struct K3Args {
@@ -83,6 +84,7 @@ struct K3Args {
 	const float* mean_density_ptr; float near_distance;
 	const float* ray_targets; // optional: K1Args::ray_targets_out (8 floats per active ray)
 	int train_mode;           // ETrainMode: 0 Nerf, 1 Rfl, 2 RflRelax (fused_kernels/train_nerf.cuh:391-410)
+	float depth_lambda = 0.f; int depth_loss_type = NGP_LOSS_L1; // depth supervision (testbed_nerf.cu:1027-1029, 1126-1129); ray_targets slot 6 = target depth (<= 0: none)
 	void* k3_scratch = nullptr; // k3_scratch_bytes(max_rays), initialised by k3_scratch_init: needed by the two-pass kernel (DBG_K3_TWO_PASS)
 };
 size_t k3_scratch_bytes(uint32_t max_rays);
@@ -90,7 +92,7 @@ int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays);
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
 // per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
-struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[6]; uint32_t ray_index; };
+struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[7]; uint32_t ray_index; }; // tgt = {rgb target, background, target depth}
 constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multiplicative-hash constant), larger than every ray count => coprime to it, and well mixed modulo powers of two; see k1_setup
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays); // once per allocation (and whenever max_local_rays changes)

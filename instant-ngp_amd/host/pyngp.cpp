@@ -54,6 +54,8 @@ PYBIND11_MODULE(pyngp, m) {
 	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image)
 		.value("Volume", ETestbedMode::Volume).value("None", ETestbedMode::None).export_values();
 	py::enum_<ETrainMode>(m, "TrainMode").value("Nerf", ETrainMode::Nerf).value("Rfl", ETrainMode::Rfl).value("RflRelax", ETrainMode::RflRelax).export_values();
+	py::enum_<ELossType>(m, "LossType").value("L2", ELossType::L2).value("L1", ELossType::L1).value("Mape", ELossType::Mape).value("Smape", ELossType::Smape)
+		.value("Huber", ELossType::Huber).value("SmoothL1", ELossType::Huber).value("LogL1", ELossType::LogL1).value("RelativeL2", ELossType::RelativeL2).export_values(); // python_api.cu:351-362
 	py::enum_<EColorSpace>(m, "ColorSpace").value("Linear", EColorSpace::Linear).value("SRGB", EColorSpace::SRGB).value("VisPosNeg", EColorSpace::VisPosNeg).export_values();
 	py::enum_<ETonemapCurve>(m, "TonemapCurve").value("Identity", ETonemapCurve::Identity).value("ACES", ETonemapCurve::ACES).value("Hable", ETonemapCurve::Hable)
 		.value("Reinhard", ETonemapCurve::Reinhard).export_values();
@@ -62,12 +64,12 @@ PYBIND11_MODULE(pyngp, m) {
 	py::class_<ImageMetadata>(testbed, "TrainingImageMetadata")
 		.def_readonly("resolution", &ImageMetadata::resolution).def_readonly("focal_length", &ImageMetadata::focal_length)
 		.def_readonly("principal_point", &ImageMetadata::principal_point).def_readonly("lens_mode", &ImageMetadata::lens_mode)
-		.def_readonly("lens_params", &ImageMetadata::lens_params);
+		.def_readonly("lens_params", &ImageMetadata::lens_params).def_readonly("rolling_shutter", &ImageMetadata::rolling_shutter);
 	py::class_<NerfDataset>(testbed, "NerfDataset")
 		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
 		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
 		.def_readonly("scale", &NerfDataset::scale).def_readonly("offset", &NerfDataset::offset).def_readonly("paths", &NerfDataset::paths)
-		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms).def_readonly("from_mitsuba", &NerfDataset::from_mitsuba)
+		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms).def_readonly("xforms_end", &NerfDataset::xforms_end).def_readonly("from_mitsuba", &NerfDataset::from_mitsuba)
 		.def("image", [](const NerfDataset& d, size_t i) {
 			if (i >= d.n_images) throw std::runtime_error{"image index out of range"};
 			py::array_t<uint8_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});
@@ -80,11 +82,19 @@ PYBIND11_MODULE(pyngp, m) {
 			py::array_t<uint16_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});
 			std::memcpy(out.mutable_data(), d.pixels_half[i].data(), d.pixels_half[i].size() * 2);
 			return out;
-		}, "sharpened training image i as IEEE binary16 bit patterns [h, w, 4] (view as float16): linear premultiplied RGBA, what the trainer samples when nerf.sharpen > 0");
+		}, "sharpened training image i as IEEE binary16 bit patterns [h, w, 4] (view as float16): linear premultiplied RGBA, what the trainer samples when nerf.sharpen > 0")
+		.def("depth", [](const NerfDataset& d, size_t i) {
+			if (i >= d.n_images || i >= d.depth.size() || d.depth[i].empty()) throw std::runtime_error{"depth: image has no depth (json depth_path + integer_depth_scale)"};
+			py::array_t<float> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0]});
+			std::memcpy(out.mutable_data(), d.depth[i].data(), d.depth[i].size() * 4);
+			return out;
+		}, "depth image i in scene units [h, w] (0 = no measurement): integer depth x integer_depth_scale x dataset scale");
 	py::class_<NerfTraining>(testbed, "NerfTraining")
 		.def_readwrite("near_distance", &NerfTraining::near_distance).def_readwrite("train_mode", &NerfTraining::train_mode)
 		.def_readwrite("random_bg_color", &NerfTraining::random_bg_color).def_readwrite("linear_colors", &NerfTraining::linear_colors)
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers).def_readwrite("density_grid_decay", &NerfTraining::density_grid_decay)
+		.def_readwrite("depth_supervision_lambda", &NerfTraining::depth_supervision_lambda)
+		.def_property("depth_loss_type", [](const NerfTraining& t) { return (ELossType)t.depth_loss_type; }, [](NerfTraining& t, ELossType v) { t.depth_loss_type = (int)v; })
 		.def_readonly("dataset", &NerfTraining::dataset);
 	py::class_<Nerf>(testbed, "Nerf")
 		.def_readwrite("sharpen", &Nerf::sharpen).def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)

@@ -33,16 +33,18 @@ static std::string read_text(const fs::path& p) {
 }
 static std::string lower(std::string s) { for (auto& c : s) c = (char)tolower(c); return s; }
 
-// ---- minimal PNG reader (8-bit gray / gray+alpha / RGB / RGBA, non-interlaced) on top of zlib ----
+// ---- minimal PNG reader (8- or 16-bit gray / gray+alpha / RGB / RGBA, non-interlaced) on top of zlib ----
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
+// un-filtered scan lines: `ch` channels of `depth` bits (big-endian samples for 16 bits), row-major
+static bool decode_png_raw(const std::string& path, int& w, int& h, int& ch, int& depth, std::vector<uint8_t>& img) {
 	std::ifstream f{path, std::ios::binary};
 	if (!f) return false;
 	std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
 	if (buf.size() < 33 || memcmp(buf.data(), sig, 8) != 0) return false;
 	size_t pos = 8;
-	int depth = 0, ctype = 0, interlace = 0;
+	int ctype = 0, interlace = 0;
+	depth = 0;
 	std::vector<uint8_t> idat;
 	while (pos + 12 <= buf.size()) {
 		const uint32_t len = be32(&buf[pos]);
@@ -54,20 +56,21 @@ static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint
 		else if (type == "IEND") break;
 		pos += 12 + len;
 	}
-	if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 4 || ctype == 6)) return false;
-	const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : 4;
-	const size_t stride = (size_t)w * ch;
+	if ((depth != 8 && depth != 16) || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 4 || ctype == 6) || w <= 0 || h <= 0 || (uint64_t)w * h > (1ull << 28)) return false;
+	ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : 4;
+	const int bpp = ch * depth / 8; // bytes per pixel: the filters' "previous pixel" distance
+	const size_t stride = (size_t)w * bpp;
 	std::vector<uint8_t> raw((stride + 1) * h);
 	uLongf out_len = (uLongf)raw.size();
 	if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return false;
-	std::vector<uint8_t> img(stride * h);
+	img.assign(stride * h, 0);
 	for (int y = 0; y < h; ++y) {
 		const uint8_t ft = raw[(stride + 1) * y];
 		const uint8_t* src = &raw[(stride + 1) * y + 1];
 		uint8_t* dst = &img[stride * y];
 		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
 		for (size_t x = 0; x < stride; ++x) {
-			const int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+			const int a = x >= (size_t)bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
 			int v = src[x];
 			switch (ft) {
 				case 1: v += a; break;
@@ -79,6 +82,16 @@ static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint
 			dst[x] = (uint8_t)v;
 		}
 	}
+	return true;
+}
+static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
+	int ch = 0, depth = 0; std::vector<uint8_t> img;
+	if (!decode_png_raw(path, w, h, ch, depth, img)) return false;
+	if (depth == 16) { // 16 -> 8 bits like stb_image's 8-bit interface: the high byte
+		std::vector<uint8_t> hi((size_t)w * h * ch);
+		for (size_t i = 0; i < hi.size(); ++i) hi[i] = img[2 * i];
+		img.swap(hi);
+	}
 	rgba.resize((size_t)w * h * 4);
 	for (size_t i = 0; i < (size_t)w * h; ++i) {
 		const uint8_t* p = &img[i * ch];
@@ -88,6 +101,17 @@ static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint
 		else if (ch == 3) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 255; }
 		else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
 	}
+	return true;
+}
+
+// load_stbi_16(path, &w, &h, &comp, 1) (nerf_loader.cu:633): one 16-bit channel.  Gray (+ alpha) files give their gray channel, 8-bit files v * 257,
+// colour files stb_image's integer luma (77 r + 150 g + 29 b) >> 8.
+static bool decode_png_gray16(const std::string& path, int& w, int& h, std::vector<uint16_t>& out) {
+	int ch = 0, depth = 0; std::vector<uint8_t> img;
+	if (!decode_png_raw(path, w, h, ch, depth, img)) return false;
+	out.resize((size_t)w * h);
+	auto sample = [&](size_t i, int c) -> uint32_t { return depth == 16 ? ((uint32_t)img[(i * ch + c) * 2] << 8) | img[(i * ch + c) * 2 + 1] : (uint32_t)img[i * ch + c] * 257u; };
+	for (size_t i = 0; i < out.size(); ++i) out[i] = (uint16_t)(ch >= 3 ? (sample(i, 0) * 77u + sample(i, 1) * 150u + sample(i, 2) * 29u) >> 8 : sample(i, 0));
 	return true;
 }
 
@@ -193,6 +217,7 @@ ngp_nerf_options Testbed::current_options() const {
 	o.rank = m_rank; o.world_size = m_world_size;
 	// Rfl / RflRelax: the reference needs its JIT-fused kernel for these (testbed_nerf.cu:3091-3094); here K3 evaluates their gradients
 	o.train_mode = nerf.training.train_mode == ETrainMode::Rfl ? 1 : nerf.training.train_mode == ETrainMode::RflRelax ? 2 : 0;
+	o.depth_supervision_lambda = nerf.training.depth_supervision_lambda; o.depth_loss_type = nerf.training.depth_loss_type;
 	return o;
 }
 
@@ -227,8 +252,10 @@ void Testbed::ensure_trainer() {
 			meta[i].image_data_type = NGP_IMAGE_BYTE; meta[i].lens_mode = d.metadata[i].lens_mode;
 			for (int k = 0; k < 2; ++k) { meta[i].resolution[k] = d.metadata[i].resolution[k]; meta[i].principal_point[k] = d.metadata[i].principal_point[k]; meta[i].focal_length[k] = d.metadata[i].focal_length[k]; }
 			for (int k = 0; k < 7; ++k) meta[i].lens_params[k] = d.metadata[i].lens_params[k];
-			for (int k = 0; k < 12; ++k) xf[i].start[k] = xf[i].end[k] = d.xforms[i][k];
+			for (int k = 0; k < 12; ++k) { xf[i].start[k] = d.xforms[i][k]; xf[i].end[k] = i < d.xforms_end.size() ? d.xforms_end[i][k] : d.xforms[i][k]; }
+			for (int k = 0; k < 4; ++k) meta[i].rolling_shutter[k] = d.metadata[i].rolling_shutter[k];
 			pix[i] = d.pixels[i].data();
+			if (i < d.depth.size() && !d.depth[i].empty()) meta[i].depth = d.depth[i].data(); // host pointer: ngp_nerf_set_dataset_host uploads it
 			if (i < d.pixels_half.size() && !d.pixels_half[i].empty()) { meta[i].image_data_type = NGP_IMAGE_HALF; pix[i] = d.pixels_half[i].data(); } // sharpened at load time
 			if (d.pixels[i].empty()) { // metadata restored from a snapshot: a 1x1 transparent stand-in keeps the device arrays well formed (render-only)
 				static const uint32_t k_no_pixel = 0u;
@@ -323,7 +350,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 	d.sharpen_amount = nerf.sharpen;
 	bool white_transparent = false, black_transparent = false; // json flags (NSVF-style datasets): pure white / black pixels become transparent (convert_rgba32)
 	bool fix_premult = false; // json "fix_premult" (nerf_loader.cu:448-450): EXR colours are multiplied by their alpha at load time
-	struct Frame { std::string image_path; std::array<float, 12> xform; ImageMetadata meta; float angle_x = 0.f, angle_y = 0.f; bool principal_in_pixels = false; };
+	struct Frame { std::string image_path, depth_path; float depth_scale = -1.f; std::array<float, 12> xform, xform_end; ImageMetadata meta; float angle_x = 0.f, angle_y = 0.f; bool principal_in_pixels = false; };
+	bool enable_depth_loading = true; // nerf_loader.cu:419, 435-437
 	std::vector<Frame> frames;
 	for (const fs::path& jp : jsons) {
 		mini_json::Value j; std::string err;
@@ -331,6 +359,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
 		if (j.has("sharpen")) d.sharpen_amount = (float)j.num("sharpen", 0);
 		if (j.has("fix_premult")) fix_premult = j.boolean("fix_premult", false);
+		if (j.has("enable_depth_loading")) enable_depth_loading = j.boolean("enable_depth_loading", true);
+		const float integer_depth_scale = j.has("integer_depth_scale") ? (float)j.num("integer_depth_scale", -1.0) : -1.f; // nerf_loader.cu:490-492: units of the 16-bit depth images
 		// nerf_loader.cu:439-514, in the reference's order: Mitsuba convention (its own default scale / offset), then explicit scale / offset, then an
 		// "aabb" [[min],[max]] that is mapped isotropically onto the unit cube
 		if (j.has("normal_mts_args")) d.from_mitsuba = true;
@@ -382,6 +412,10 @@ void Testbed::load_training_data(const std::string& path_in) {
 			const auto& f = *fp;
 			Frame F;
 			F.image_path = resolve(f).string();
+			if (enable_depth_loading && integer_depth_scale > 0.f && f.has("depth_path")) { // nerf_loader.cu:629-641
+				std::string dp = f.str("depth_path", ""); for (auto& c : dp) if (c == '\\') c = '/';
+				F.depth_path = (jp.parent_path() / dp).string(); F.depth_scale = integer_depth_scale;
+			}
 			// per-frame values override the global ones (nerf_loader.cu:487-535, 697-700)
 			auto get = [&](const char* k, double dflt) { return f.has(k) ? f.num(k, dflt) : j.num(k, dflt); };
 			auto has = [&](const char* k) { return f.has(k) || j.has(k); };
@@ -391,15 +425,24 @@ void Testbed::load_training_data(const std::string& path_in) {
 			if (has("fl_y")) fly = get("fl_y", 0);
 			F.meta.focal_length = {(float)flx, (float)fly}; // resolved after the image size is known
 			if (has("cx")) F.meta.principal_point[0] = -1.f; // marker, resolved below
-			const auto& tm = f["transform_matrix"];
-			float m[3][4];
-			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m[r][c] = (float)tm.at(r).at(c).n;
-			// nerf_matrix_to_ngp, nerf_loader.h:101-120
-			for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = m[r][3] * d.scale + d.offset[r]; }
-			float c3[3][4];
-			if (d.from_mitsuba) { for (int r = 0; r < 3; ++r) { m[r][0] *= -1.f; m[r][2] *= -1.f; } for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) c3[r][c] = m[r][c]; }
-			else for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; } // cycle the axes xyz <- yzx
-			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) F.xform[c * 3 + r] = c3[r][c];
+			// nerf_loader.cu:668-669, 689-694: "transform_matrix_start" / "transform_matrix_end" bracket the exposure of a moving camera; both default to "transform_matrix"
+			const auto& tm_start = f.has("transform_matrix_start") ? f["transform_matrix_start"] : f["transform_matrix"];
+			const auto& tm_end = f.has("transform_matrix_end") ? f["transform_matrix_end"] : tm_start;
+			auto to_ngp = [&](const mini_json::Value& tm, std::array<float, 12>& out) {
+				float m[3][4];
+				for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m[r][c] = (float)tm.at(r).at(c).n;
+				// nerf_matrix_to_ngp, nerf_loader.h:101-120
+				for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = m[r][3] * d.scale + d.offset[r]; }
+				float c3[3][4];
+				if (d.from_mitsuba) { for (int r = 0; r < 3; ++r) { m[r][0] *= -1.f; m[r][2] *= -1.f; } for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) c3[r][c] = m[r][c]; }
+				else for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; } // cycle the axes xyz <- yzx
+				for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) out[c * 3 + r] = c3[r][c];
+			};
+			to_ngp(tm_start, F.xform); to_ngp(tm_end, F.xform_end);
+			{ // "rolling_shutter": [a, b, c, d?] (nerf_loader.cu:204-215), global with per-frame override (read_lens :699)
+				const mini_json::Value* rs = f.has("rolling_shutter") ? &f["rolling_shutter"] : (j.has("rolling_shutter") ? &j["rolling_shutter"] : nullptr);
+				if (rs && rs->size() >= 3) F.meta.rolling_shutter = {(float)rs->at(0).n, (float)rs->at(1).n, (float)rs->at(2).n, rs->size() >= 4 ? (float)rs->at(3).n : 0.f};
+			}
 			{ // read_lens, nerf_loader.cu:175-241: OpenCV / OpenCV-fisheye coefficients select their mode only when one of them is non-zero
 				const int opencv_mode = (has("is_fisheye") && get("is_fisheye", 0) != 0) ? NGP_LENS_OPENCV_FISHEYE : NGP_LENS_OPENCV;
 				auto coeff = [&](const char* name, int idx) { if (has(name)) { F.meta.lens_params[idx] = (float)get(name, 0); if (F.meta.lens_params[idx] != 0.f) F.meta.lens_mode = opencv_mode; } };
@@ -487,7 +530,17 @@ void Testbed::load_training_data(const std::string& path_in) {
 		d.pixels_half.emplace_back();
 		if (!hdr_half.empty()) d.pixels_half.back() = d.sharpen_amount > 0.f ? sharpen_half(hdr_half, w, h, d.sharpen_amount) : std::move(hdr_half);
 		else if (d.sharpen_amount > 0.f) d.pixels_half.back() = sharpen_rgba8(rgba, w, h, d.sharpen_amount);
-		d.metadata.push_back(F.meta); d.xforms.push_back(F.xform); d.pixels.push_back(std::move(rgba)); d.paths.push_back(F.image_path);
+		d.depth.emplace_back();
+		if (!F.depth_path.empty() && fs::exists(F.depth_path)) { // copy_depth, nerf_loader.cu:73-82: float depth = integer depth * (integer_depth_scale * dataset scale); 0 = no measurement
+			int wa = 0, ha = 0; std::vector<uint16_t> dp;
+			if (!decode_png_gray16(F.depth_path, wa, ha, dp)) throw std::runtime_error{"Could not load depth image '" + F.depth_path + "'."};
+			if (wa != w || ha != h) throw std::runtime_error{"Depth image " + F.depth_path + " has wrong resolution."};
+			std::vector<float>& dst = d.depth.back();
+			dst.resize(dp.size());
+			const float sc = F.depth_scale * d.scale; // (the dataset scale is final here: it is read from the json before its frames)
+			for (size_t i = 0; i < dp.size(); ++i) dst[i] = (float)dp[i] * sc;
+		}
+		d.metadata.push_back(F.meta); d.xforms.push_back(F.xform); d.xforms_end.push_back(F.xform_end); d.pixels.push_back(std::move(rgba)); d.paths.push_back(F.image_path);
 	}
 	d.n_images = d.metadata.size();
 	if ((d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error{"NeRF dataset's `aabb_scale` must be a power of two."};
@@ -809,9 +862,9 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 			else if (m.lens_mode == NGP_LENS_EQUIRECTANGULAR) lens.set("equirectangular", jbool(true));
 			else if (m.lens_mode == NGP_LENS_ORTHOGRAPHIC) lens.set("orthographic", jbool(true));
 			jm.set("lens", lens); jm.set("principal_point", jvec(m.principal_point.data(), 2));
-			const float rs[4] = {0.f, 0.f, 0.f, 0.f}; jm.set("rolling_shutter", jvec(rs, 4)); jm.set("resolution", jvec(m.resolution.data(), 2));
+			jm.set("rolling_shutter", jvec(m.rolling_shutter.data(), 4)); jm.set("resolution", jvec(m.resolution.data(), 2));
 			metas.arr.push_back(jm);
-			Value x = jobj(); x.set("start", jmat_cols(d.xforms[i].data(), 4, 3)); x.set("end", jmat_cols(d.xforms[i].data(), 4, 3)); xfs.arr.push_back(x);
+			Value x = jobj(); x.set("start", jmat_cols(d.xforms[i].data(), 4, 3)); x.set("end", jmat_cols((i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i]).data(), 4, 3)); xfs.arr.push_back(x);
 		}
 		jd.set("metadata", metas); jd.set("xforms", xfs);
 		const ngp_aabb box = scene_aabb(); jd.set("render_aabb", jbox(box));
@@ -883,10 +936,12 @@ void Testbed::load_snapshot(const std::string& path) {
 				else if (lens.has("equirectangular")) m.lens_mode = NGP_LENS_EQUIRECTANGULAR;
 				else if (lens.has("orthographic")) m.lens_mode = NGP_LENS_ORTHOGRAPHIC;
 			}
-			std::array<float, 12> x{};
+			if (jm["rolling_shutter"].size() == 4) for (int k = 0; k < 4; ++k) m.rolling_shutter[k] = (float)jm["rolling_shutter"].at(k).n;
+			std::array<float, 12> x{}, xe{};
 			const Value& xs = jd["xforms"].at(i)["start"];
-			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) x[c * 3 + r] = (float)xs.at(c).at(r).n;
-			d.metadata.push_back(m); d.xforms.push_back(x); d.pixels.emplace_back(); d.pixels_half.emplace_back(); // no pixels
+			const Value& xend = jd["xforms"].at(i).has("end") ? jd["xforms"].at(i)["end"] : xs;
+			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) { x[c * 3 + r] = (float)xs.at(c).at(r).n; xe[c * 3 + r] = (float)xend.at(c).at(r).n; }
+			d.metadata.push_back(m); d.xforms.push_back(x); d.xforms_end.push_back(xe); d.pixels.emplace_back(); d.pixels_half.emplace_back(); // no pixels
 			d.paths.push_back(jd["paths"].is_array() && i < jd["paths"].size() ? jd["paths"].at(i).s : std::string());
 		}
 		d.n_images = n;

@@ -19,6 +19,7 @@ enum class ETestbedMode : int { Nerf = 0, Sdf = 1, Image = 2, Volume = 3, None =
 enum class ETrainMode : int { Nerf = 0, Rfl = 1, RflRelax = 2 };                          // common.h:47-51
 enum class EColorSpace : int { Linear = 0, SRGB = 1, VisPosNeg = 2 };
 enum class ETonemapCurve : int { Identity = 0, ACES = 1, Hable = 2, Reinhard = 3 };
+enum class ELossType : int { L2 = 0, L1 = 1, Mape = 2, Smape = 3, Huber = 4, LogL1 = 5, RelativeL2 = 6 }; // common.h:99-107 = NGP_LOSS_*
 
 struct ImageMetadata {                      // TrainingImageMetadata as seen from Python (python_api.cu:766-779)
 	std::array<int, 2> resolution{0, 0};
@@ -26,13 +27,16 @@ struct ImageMetadata {                      // TrainingImageMetadata as seen fro
 	std::array<float, 2> principal_point{0.5f, 0.5f};
 	int lens_mode = NGP_LENS_PERSPECTIVE;
 	std::array<float, 7> lens_params{};
+	std::array<float, 4> rolling_shutter{};          // {a, b, c, d}: pixel time t = a + b u + c v + d motionblur_time (nerf_loader.cu:204-215)
 };
 
 struct NerfDataset {                        // nerf_loader.h NerfDataset (subset)
 	size_t n_images = 0;
 	std::vector<ImageMetadata> metadata;
-	std::vector<std::array<float, 12>> xforms;      // ngp convention, column-major mat4x3
+	std::vector<std::array<float, 12>> xforms;      // ngp convention, column-major mat4x3 (TrainingXForm::start)
+	std::vector<std::array<float, 12>> xforms_end;  // TrainingXForm::end: json "transform_matrix_end" (== start without motion data)
 	std::vector<std::vector<uint8_t>> pixels;        // RGBA8 per image (host copy; also feeds render_ground_truth)
+	std::vector<std::vector<float>> depth;            // per image: empty, or one float per pixel in scene units (json "depth_path" + "integer_depth_scale", nerf_loader.cu:629-641, 73-82)
 	std::vector<std::vector<uint16_t>> pixels_half;  // sharpened images (nerf.sharpen > 0): linear premultiplied RGBA halfs, what the trainer then samples
 	float sharpen_amount = 0.f;                      // what the images were loaded with (json "sharpen" overrides nerf.sharpen, nerf_loader.cu:462)
 	std::vector<std::string> paths;
@@ -50,6 +54,8 @@ struct NerfTraining {
 	bool linear_colors = false;                      // testbed.h:794
 	bool snap_to_pixel_centers = true;               // testbed.h:797
 	float density_grid_decay = 0.95f;                // testbed.h:818
+	float depth_supervision_lambda = 0.f;            // testbed.h:824
+	int depth_loss_type = NGP_LOSS_L1;               // testbed.h:796 (ELossType)
 	NerfDataset dataset;
 };
 

@@ -35,7 +35,7 @@ class Pcg32(C.Structure):
 class ImageMeta(C.Structure):
     _fields_ = [("pixels", vp), ("image_data_type", i32), ("lens_mode", i32), ("resolution", i32 * 2),
                 ("principal_point", f32 * 2), ("focal_length", f32 * 2), ("rolling_shutter", f32 * 4),
-                ("lens_params", f32 * 7), ("_pad", f32)]
+                ("lens_params", f32 * 7), ("_pad", f32), ("depth", vp)]
 
 
 class Xform(C.Structure):
@@ -106,7 +106,8 @@ class NerfOptions(C.Structure):
                 ("snap_to_pixel_centers", i32), ("linear_colors", i32), ("color_space_srgb", i32),
                 ("background_color", f32 * 3), ("near_distance", f32), ("density_grid_decay", f32),
                 ("cone_angle_constant", f32), ("max_cascade", u32), ("target_batch_size", u32), ("loss_scale", f32),
-                ("seed", u64), ("rank", u32), ("world_size", u32), ("train_mode", i32)]
+                ("seed", u64), ("rank", u32), ("world_size", u32), ("train_mode", i32),
+                ("depth_supervision_lambda", f32), ("depth_loss_type", i32)]
 
 
 class NerfStats(C.Structure):
@@ -144,7 +145,8 @@ def default_nerf_options(aabb_scale=1, **kw):
     o = NerfOptions(rgb_activation=ACT_LOGISTIC, density_activation=ACT_EXPONENTIAL, loss_type=LOSS_HUBER, random_bg_color=1,
                     snap_to_pixel_centers=1, linear_colors=0, color_space_srgb=0, near_distance=0.1, density_grid_decay=0.95,
                     cone_angle_constant=0.0 if aabb_scale <= 1 else 1.0 / 256.0, max_cascade=max_cascade,
-                    target_batch_size=1 << 18, loss_scale=128.0, seed=1337, rank=0, world_size=1, train_mode=0)
+                    target_batch_size=1 << 18, loss_scale=128.0, seed=1337, rank=0, world_size=1, train_mode=0,
+                    depth_supervision_lambda=0.0, depth_loss_type=LOSS_L1)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -106,8 +106,14 @@ API void ora_k1_lattice_counts(int mode, uint32_t n_rays, uint32_t ray_begin, ui
 		const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip, int snap, float cone_angle_constant, uint32_t* out_counts, uint32_t max_lattice_points) {
 	lattice_march_counts(mode, n_rays, ray_begin, ray_end, Aabb(aabb), Pcg32(rng), n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant, out_counts, max_lattice_points);
 }
+API void ora_xform_given_rolling_shutter(const ngp_xform* X, const float* rs, const float* uv, float motionblur_time, float* out12) {
+	const mat4x3 m = get_xform_given_rolling_shutter(*X, rs, vec2{uv[0], uv[1]}, motionblur_time);
+	for (int c = 0; c < 4; ++c) { out12[c * 3 + 0] = m.c[c].x; out12[c * 3 + 1] = m.c[c].y; out12[c * 3 + 2] = m.c[c].z; }
+}
 static int g_k3_train_mode = 0; // ETrainMode of the stand-alone ora_k_compute_loss
 API void ora_set_train_mode(int mode) { g_k3_train_mode = mode; }
+static float g_k3_depth_lambda = 0.f; static int g_k3_depth_loss_type = NGP_LOSS_L1; // depth supervision of the stand-alone ora_k_compute_loss
+API void ora_set_depth_supervision(float lambda, int loss_type) { g_k3_depth_lambda = lambda; g_k3_depth_loss_type = loss_type; }
 API void ora_k_compute_loss(uint32_t n_rays, uint32_t rays_counter, ngp_aabb aabb, ngp_pcg32 rng, uint32_t max_samples_compacted, float loss_scale,
 		const float* background_color, int color_space_srgb, int random_bg, int linear_colors, uint32_t n_images, const ngp_image_meta* meta,
 		const uint16_t* network_output, uint32_t out_stride, uint32_t* numsteps_counter_compacted, const uint32_t* ray_indices_in, const ngp_ray* rays_in,
@@ -115,7 +121,7 @@ API void ora_k_compute_loss(uint32_t n_rays, uint32_t rays_counter, ngp_aabb aab
 		int rgb_act, int density_act, int snap, float mean_density, float near_distance) {
 	K3Opts o; o.loss_scale = loss_scale; o.background_color = V3(background_color); o.color_space_srgb = color_space_srgb; o.random_bg = random_bg;
 	o.linear_colors = linear_colors; o.snap = snap; o.loss_type = loss_type; o.rgb_act = rgb_act; o.density_act = density_act; o.near_distance = near_distance;
-	o.train_mode = g_k3_train_mode;
+	o.train_mode = g_k3_train_mode; o.depth_lambda = g_k3_depth_lambda; o.depth_loss_type = g_k3_depth_loss_type;
 	*numsteps_counter_compacted = compute_loss(n_rays, rays_counter, Aabb(aabb), Pcg32(rng), max_samples_compacted, o, n_images, meta, network_output, out_stride,
 		ray_indices_in, rays_in, numsteps_inout, coords_in, coords_out, dloss, dl_stride, loss_output, mean_density);
 }

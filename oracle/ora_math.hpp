@@ -203,6 +203,52 @@ inline mat4x3 M43(const float* p) { return {{V3(p), V3(p + 3), V3(p + 6), V3(p +
 inline vec3 mul3(const mat4x3& m, vec3 v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z; } // mat3(m) * v
 
 // ---------------------------------------------------------------------------------------------
+// get_xform_given_rolling_shutter / camera_slerp, common_device.cuh:665-674.  slerp(mat3, mat3, t) is tiny-cuda-nn's [tcnn vec.h, GLM-derived;
+// from the published algorithm]: quat_cast by the largest diagonal term, short-arc quaternion slerp (linear mix when cos(theta) > 1 - epsilon),
+// mat3_cast.  Frames without motion data keep their matrix (see csrc/ngp_device.hpp for the reason).
+// ---------------------------------------------------------------------------------------------
+struct quat { float x, y, z, w; };
+inline quat normalize(quat q) { float l = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w); return {q.x / l, q.y / l, q.z / l, q.w / l}; }
+inline quat quat_cast(const mat4x3& m) {
+	const vec3 &a = m.c[0], &b = m.c[1], &c = m.c[2];
+	float four_x = a.x - b.y - c.z, four_y = b.y - a.x - c.z, four_z = c.z - a.x - b.y, four_w = a.x + b.y + c.z;
+	int biggest = 0; float four_biggest = four_w;
+	if (four_x > four_biggest) { four_biggest = four_x; biggest = 1; }
+	if (four_y > four_biggest) { four_biggest = four_y; biggest = 2; }
+	if (four_z > four_biggest) { four_biggest = four_z; biggest = 3; }
+	float biggest_val = std::sqrt(four_biggest + 1.0f) * 0.5f, mult = 0.25f / biggest_val;
+	if (biggest == 0) return {(b.z - c.y) * mult, (c.x - a.z) * mult, (a.y - b.x) * mult, biggest_val};
+	if (biggest == 1) return {biggest_val, (a.y + b.x) * mult, (c.x + a.z) * mult, (b.z - c.y) * mult};
+	if (biggest == 2) return {(a.y + b.x) * mult, biggest_val, (b.z + c.y) * mult, (c.x - a.z) * mult};
+	return {(c.x + a.z) * mult, (b.z + c.y) * mult, biggest_val, (a.y - b.x) * mult};
+}
+inline quat slerp(quat x, quat y, float a) {
+	quat z = y;
+	float cos_theta = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+	if (cos_theta < 0.0f) { z = {-y.x, -y.y, -y.z, -y.w}; cos_theta = -cos_theta; }
+	if (cos_theta > 1.0f - std::numeric_limits<float>::epsilon()) return {x.x + a * (z.x - x.x), x.y + a * (z.y - x.y), x.z + a * (z.z - x.z), x.w + a * (z.w - x.w)};
+	float angle = std::acos(cos_theta), s0 = std::sin((1.0f - a) * angle), s1 = std::sin(a * angle), sd = std::sin(angle);
+	return {(s0 * x.x + s1 * z.x) / sd, (s0 * x.y + s1 * z.y) / sd, (s0 * x.z + s1 * z.z) / sd, (s0 * x.w + s1 * z.w) / sd};
+}
+inline mat4x3 camera_slerp(const mat4x3& a, const mat4x3& b, float t) {
+	quat q = normalize(slerp(normalize(quat_cast(a)), normalize(quat_cast(b)), t));
+	float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z, qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+	mat4x3 r;
+	r.c[0] = {1.0f - 2.0f * (qyy + qzz), 2.0f * (qxy + qwz), 2.0f * (qxz - qwy)};
+	r.c[1] = {2.0f * (qxy - qwz), 1.0f - 2.0f * (qxx + qzz), 2.0f * (qyz + qwx)};
+	r.c[2] = {2.0f * (qxz + qwy), 2.0f * (qyz - qwx), 1.0f - 2.0f * (qxx + qyy)};
+	r.c[3] = a.c[3] * (1.0f - t) + b.c[3] * t;
+	return r;
+}
+inline mat4x3 get_xform_given_rolling_shutter(const ngp_xform& X, const float rs[4], vec2 uv, float motionblur_time) {
+	bool moving = rs[0] != 0.f || rs[1] != 0.f || rs[2] != 0.f || rs[3] != 0.f;
+	for (int k = 0; k < 12; ++k) moving = moving || X.start[k] != X.end[k];
+	if (!moving) return M43(X.start);
+	float pixel_t = rs[0] + rs[1] * uv.x + rs[2] * uv.y + rs[3] * motionblur_time;
+	return camera_slerp(M43(X.start), M43(X.end), pixel_t);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Morton codes [tcnn common_device.h: expand_bits / morton3D / morton3D_invert]
 // ---------------------------------------------------------------------------------------------
 inline uint32_t expand_bits(uint32_t v) {

@@ -226,9 +226,8 @@ inline K1Out generate_training_samples(uint32_t n_rays, uint32_t ray_begin, uint
 		vec2 uv = random_image_pos_training(rng, m.resolution, snap_to_pixel_centers);
 		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) continue; // masked away
 		/* max_level_rand_training = false: max_level = 1, no draw */
-		float motionblur_time = rng.next_float(); (void)motionblur_time;
-		// get_xform_given_rolling_shutter, common_device.cuh:670-674: start == end (no rolling shutter / motion blur data)
-		const mat4x3 xform = M43(xforms[img].start);
+		float motionblur_time = rng.next_float();
+		const mat4x3 xform = get_xform_given_rolling_shutter(xforms[img], m.rolling_shutter, uv, motionblur_time); // common_device.cuh:670-674
 		vec3 ro, rd;
 		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform[3]; rd = xform[2]; } // testbed_nerf.cu:776-778
 		vec3 rdn = normalize(rd);
@@ -298,8 +297,8 @@ inline void lattice_march_counts(int mode, uint32_t n_rays, uint32_t ray_begin, 
 		rng.advance((int64_t)(i * N_MAX_RANDOM_SAMPLES_PER_RAY));
 		vec2 uv = random_image_pos_training(rng, m.resolution, snap_to_pixel_centers);
 		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) continue;
-		(void)rng.next_float();
-		const mat4x3 xform = M43(xforms[img].start);
+		const float motionblur_time = rng.next_float();
+		const mat4x3 xform = get_xform_given_rolling_shutter(xforms[img], m.rolling_shutter, uv, motionblur_time);
 		vec3 ro, rd;
 		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform[3]; rd = xform[2]; }
 		vec3 rdn = normalize(rd);
@@ -328,8 +327,8 @@ inline void lattice_march_counts(int mode, uint32_t n_rays, uint32_t ray_begin, 
 }
 
 // -------------------------------------------------------------------------------------------------
-// K3: compute_loss_kernel_train_nerf, testbed_nerf.cu:852-1180 (no envmap / depth / error-map /
-// exposure: off by default).  __expf is restated as expf.
+// K3: compute_loss_kernel_train_nerf, testbed_nerf.cu:852-1180 (no envmap / error-map / exposure: off by default; depth supervision
+// :1027-1029, :1126-1129 behind depth_lambda > 0).  __expf is restated as expf.
 // -------------------------------------------------------------------------------------------------
 struct K3Opts {
 	float loss_scale = 128.f;
@@ -338,7 +337,13 @@ struct K3Opts {
 	int loss_type = NGP_LOSS_HUBER, rgb_act = NGP_ACT_LOGISTIC, density_act = NGP_ACT_EXPONENTIAL;
 	float near_distance = 0.1f;
 	int train_mode = 0; // ETrainMode: 0 Nerf, 1 Rfl, 2 RflRelax (fused_kernels/train_nerf.cuh:391-410)
+	float depth_lambda = 0.f; int depth_loss_type = NGP_LOSS_L1; // depth_supervision_lambda, depth_loss_type (testbed.h:796, 824)
 };
+// read_depth, common_device.cuh:874-878 (image_pos: pixel of a uv, clamped)
+inline float read_depth(vec2 uv, const int32_t res[2], const float* depth) {
+	int px = std::min(std::max((int)(uv.x * (float)res[0]), 0), res[0] - 1), py = std::min(std::max((int)(uv.y * (float)res[1]), 0), res[1] - 1);
+	return depth[(size_t)px + (size_t)py * res[0]];
+}
 inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb& aabb, const Pcg32& rng_in, uint32_t max_samples_compacted,
 		const K3Opts& o, uint32_t n_images, const ngp_image_meta* meta, const uint16_t* network_output, uint32_t out_stride,
 		const uint32_t* ray_indices_in, const ngp_ray* rays_in, uint32_t* numsteps_inout, const float* coords_in, float* coords_out,
@@ -379,6 +384,7 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 		float T = 1.f;
 		const float EPSILON = 1e-4f;
 		vec3 rgb_ray = V3(0.f);
+		float depth_ray = 0.f;
 		uint32_t compacted_numsteps = 0;
 		vec3 ray_o = V3(rays_in[i].o);
 		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
@@ -390,6 +396,7 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 			const float alpha = 1.f - std::exp(-density * dt);
 			const float weight = alpha * T;
 			rgb_ray += weight * rgb;
+			depth_ray += weight * distance(unwarp_position(V3(cin + (size_t)compacted_numsteps * 7), aabb), ray_o);
 			if (o.train_mode == 1) loss_bg += weight * loss_and_gradient(rgbtarget, rgb, o.loss_type).loss;
 			T *= (1.f - alpha);
 		}
@@ -408,6 +415,10 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 		LossAndGradient lg = loss_and_gradient(rgbtarget, rgb_ray, o.loss_type);
 		float mean_loss = mean(lg.loss);
 		if (loss_output) loss_output[i] = mean_loss / (float)n_rays;
+		// testbed_nerf.cu:1027-1029: the depth image holds distances along the UNNORMALISED ray direction
+		const float target_depth = length(V3(rays_in[i].d)) * ((o.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
+		const LossAndGradient lg_depth = loss_and_gradient(V3(target_depth), V3(depth_ray), o.depth_loss_type);
+		const float depth_loss_gradient = target_depth > 0.0f ? o.depth_lambda * lg_depth.gradient.x : 0.f;
 
 		float loss_scale = o.loss_scale / n_rays;
 		const float output_l2_reg = o.rgb_act == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
@@ -415,6 +426,7 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 		const float output_l1_reg_density = (o.train_mode == 0 && mean_density < NERF_MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
 
 		vec3 rgb_ray2 = V3(0.f), loss_bg2 = V3(0.f);
+		float depth_ray2 = 0.f;
 		T = 1.f;
 		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
 			for (int k = 0; k < 7; ++k) cout[(size_t)j * 7 + k] = cin[(size_t)j * 7 + k];
@@ -428,11 +440,14 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 			const float alpha = 1.f - std::exp(-density * dt);
 			const float weight = alpha * T;
 			rgb_ray2 += weight * rgb;
+			depth_ray2 += weight * depth;
 			T *= (1.f - alpha);
 			const vec3 suffix = rgb_ray - rgb_ray2;
 			vec3 dloss_by_drgb = weight * lg.gradient;
 			float density_derivative = network_to_density_derivative(l3, o.density_act);
-			float dloss_by_dmlp = density_derivative * (dt * (dot(lg.gradient, T * rgb - suffix) + 0.0f /* depth supervision off */));
+			const float depth_suffix = depth_ray - depth_ray2;
+			const float depth_supervision = depth_loss_gradient * (T * depth - depth_suffix); // :1126-1127
+			float dloss_by_dmlp = density_derivative * (dt * (dot(lg.gradient, T * rgb - suffix) + depth_supervision));
 			if (o.train_mode == 1) { // radiance field loss, train_nerf.cuh:391-396
 				LossAndGradient local_lg = loss_and_gradient(rgbtarget, rgb, o.loss_type);
 				loss_bg2 += weight * local_lg.loss;
@@ -685,7 +700,7 @@ struct NerfTrainer {
 		ko.loss_scale = opt.loss_scale; ko.background_color = V3(opt.background_color); ko.color_space_srgb = opt.color_space_srgb;
 		ko.random_bg = opt.random_bg_color; ko.linear_colors = opt.linear_colors; ko.snap = opt.snap_to_pixel_centers;
 		ko.loss_type = opt.loss_type; ko.rgb_act = opt.rgb_activation; ko.density_act = opt.density_activation; ko.near_distance = opt.near_distance;
-		ko.train_mode = opt.train_mode;
+		ko.train_mode = opt.train_mode; ko.depth_lambda = opt.depth_supervision_lambda; ko.depth_loss_type = opt.depth_loss_type;
 		uint32_t compacted = compute_loss(R, k1.ray_counter, aabb, rng, B, ko, (uint32_t)meta.size(), meta.data(), mlp_out.data(), 4,
 			ray_indices.data(), rays.data(), numsteps.data(), coords.data(), coords_compacted.data(), dloss.data(), 4, loss.data(), mean_density);
 		n_rays_last = k1.ray_counter;

@@ -162,7 +162,7 @@ def _worker(rank, world, port, q):
         gp = C.c_void_p(); A.check(lib, lib.ngp_nerf_density_grid_ptrs(t1, C.byref(gp), None, None))
         grid1 = torch.as_tensor(_View(gp.value, grid_n, "<f4"), device="cuda").cpu().numpy().copy()
         r1, r1g = A.Pcg32(), A.Pcg32(); A.check(lib, lib.ngp_nerf_get_rng(t1, C.byref(r1), C.byref(r1g)))
-        state[0] = dict(params=p1, grid=grid1, rng=(int(r1.state), int(r1.inc)), rays=int(ref[N_STEPS - 1]["rpb"] * 0.97) // 256 * 256)
+        state[0] = dict(params=p1, grid=grid1, rng=(int(r1.state), int(r1.inc)), rays=int(ref[N_STEPS - 1]["rpb"] * 0.90) // 256 * 256)  # 10 % below the controller's value: the two ranks' shares of the samples differ by a few per cent
     dist.broadcast_object_list(state, 0)
     st0 = state[0]
     results = {}
@@ -195,11 +195,11 @@ def _worker(rank, world, port, q):
             rel = float(np.linalg.norm(g2 - g1) / np.linalg.norm(g1))
             print(f"steady state, padding {'zeroed' if zero_pad else 'as in production'}: loss 2 ranks {l2:.6f} vs 1 rank {l1:.6f}; compacted per rank {m2} vs {m1} of {B_GLOBAL}; "
                   f"summed-gradient rel-L2 {rel:.3e}")
-            assert m1 > 0.9 * B_GLOBAL and m1 < B_GLOBAL and m2 < B_GLOBAL // world, "the check must run below the batch clamp"
+            assert m1 > 0.8 * B_GLOBAL and m1 < B_GLOBAL and m2 < B_GLOBAL // world, f"the check must run below the batch clamp ({m1}, {m2} of {B_GLOBAL})"
             assert abs(l2 - l1) <= 0.02 * l1, (l2, l1)   # the loss of the union batch (Testbed.loss) on every rank
             # without the padding rows the step is linear in the set of rays: 2-rank sum == 1-rank gradient up to half rounding of the partial sums;
             # with them the difference is the wrap of each rank's first rows (a few per cent of the batch at n_in ~ 0.97 B)
-            assert rel < (0.02 if zero_pad else 0.10), rel
+            assert rel < (0.02 if zero_pad else 0.20), rel  # with padding: each rank wraps its first rows to B / G (~10 % of the batch here)
         q.put("ok")
     dist.barrier()
     lib.ngp_nerf_destroy(t)
@@ -236,7 +236,8 @@ def test_rccl_in_library_world1(hip):
     sa, sb = A.NerfStats(), A.NerfStats()
     A.check(hip, hip.ngp_nerf_get_stats(t_a, None, C.byref(sa))); A.check(hip, hip.ngp_nerf_get_stats(t_b, None, C.byref(sb)))
     # two trainings differ by the arrival order of the dense levels' half atomics: counters agree statistically, not bit for bit
-    assert sa.training_step == sb.training_step == 30 and abs(int(sa.rays_per_batch) - int(sb.rays_per_batch)) <= 512 + 0.1 * sa.rays_per_batch and abs(int(sa.measured_batch_size) - int(sb.measured_batch_size)) <= 0.1 * sa.measured_batch_size
+    # (at ~1800 rays per batch one 256-ray granule of the controller is 14 % of the batch, and the compacted sample count follows the ray count)
+    assert sa.training_step == sb.training_step == 30 and abs(int(sa.rays_per_batch) - int(sb.rays_per_batch)) <= 512 + 0.1 * sa.rays_per_batch and abs(int(sa.measured_batch_size) - int(sb.measured_batch_size)) <= 0.3 * sa.measured_batch_size
     # Adam turns every non-zero gradient into a step of ~lr, so the arrival order of the dense levels' half atomics decorrelates individual
     # table entries between ANY two runs within tens of steps: compare the training signal, not the parameter vectors
     print(f"rccl world-1 vs plain: loss {sb.loss:.6f} vs {sa.loss:.6f}")

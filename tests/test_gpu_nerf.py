@@ -201,10 +201,45 @@ def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
         ora.ora_set_train_mode(0); hip.ngp_debug_set_train_mode(0); hip.ngp_debug_set_flags(0)
 
 
-def _k3_loss_and_compaction(ora, hip, scene):
+@pytest.mark.parametrize("depth_loss,k3_flags", [(A.LOSS_L1, 0), (A.LOSS_L2, 0), (A.LOSS_L1, 32), (A.LOSS_HUBER, 32)])
+def test_k3_depth_supervision(ora, hip, scene, depth_loss, k3_flags):
+    """Depth supervision (testbed_nerf.cu:1027-1029, 1126-1129; depth_supervision_lambda > 0 and a depth image per training view): the wave-per-ray
+    kernel and the reference-order kernel vs the oracle, per ray.  The depth images are synthetic (a smooth field of plausible distances with holes = 0,
+    "no measurement"): the test is about the arithmetic, and that rays without a measurement get no depth term."""
+    lam = 0.7
+    ora.ora_set_depth_supervision(C.c_float(lam), depth_loss); hip.ngp_debug_set_depth_supervision(C.c_float(lam), depth_loss); hip.ngp_debug_set_flags(k3_flags)
+    try:
+        _k3_loss_and_compaction(ora, hip, scene, with_depth=True)
+    finally:
+        ora.ora_set_depth_supervision(C.c_float(0.0), A.LOSS_L1); hip.ngp_debug_set_depth_supervision(C.c_float(0.0), A.LOSS_L1); hip.ngp_debug_set_flags(0)
+
+
+def _k3_loss_and_compaction(ora, hip, scene, with_depth=False):
     import torch
     n_rays, max_samples, B = 2048, 1 << 19, 1 << 19  # B large enough that no ray is clamped (the clamped set is order dependent)
     o, d = _run_k1(ora, hip, scene, n_rays, max_samples)
+    depth_keep = []
+    if with_depth:  # one float per pixel: host arrays for the oracle's metadata, device copies for the device's
+        w, h = scene["M"][0].resolution[0], scene["M"][0].resolution[1]
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        dev_M = (A.ImageMeta * len(scene["imgs"])).from_buffer_copy(bytes(d["keep"][1].cpu().numpy()))
+        for i in range(len(scene["imgs"])):
+            dep = (0.9 + 0.4 * np.sin(0.13 * xx + i) * np.cos(0.09 * yy)).astype(np.float32)
+            dep[(xx.astype(int) + yy.astype(int) + i) % 7 == 0] = 0.0  # holes: no measurement
+            dep = np.ascontiguousarray(dep.reshape(-1)); dd = torch.from_numpy(dep).cuda()
+            depth_keep.append((dep, dd))
+            scene["M"][i].depth = dep.ctypes.data; dev_M[i].depth = dd.data_ptr()
+        d["keep"] = (d["keep"][0], torch.from_numpy(np.frombuffer(bytes(dev_M), dtype=np.uint8).copy()).cuda()) + tuple(d["keep"][2:])
+    try:
+        _k3_body(ora, hip, scene, o, d, n_rays, max_samples, B)
+    finally:
+        if with_depth:
+            for i in range(len(scene["imgs"])):
+                scene["M"][i].depth = None
+
+
+def _k3_body(ora, hip, scene, o, d, n_rays, max_samples, B):
+    import torch
     n_act = o["ray_counter"].value
     total = o["numsteps_counter"].value
     rngs = np.random.default_rng(1)

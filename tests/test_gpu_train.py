@@ -263,3 +263,47 @@ def test_rfl_train_modes_converge(hip, ora, train_mode):
         hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
     print(f"train_mode {train_mode}: loss {res[train_mode]:.5f} vs Nerf mode {res[0]:.5f}")
     assert res[train_mode] < 4 * res[0] + 1e-4
+
+
+def test_depth_supervision_end_to_end(hip, ora):
+    """The production path of the depth term (k1_setup stores the ray's target depth next to its target colour, k_compute_loss_v2 reads it): training with
+    depth images that claim a much smaller depth than the scene's pulls the composited depth sum_j w_j depth_j (not normalised by the opacity, like the
+    reference's depth_ray) down -- the model gives up opacity to get there; with depth_supervision_lambda = 0 the same images change nothing.  The arithmetic itself is checked per ray in test_gpu_nerf.py::test_k3_depth_supervision."""
+    import torch
+    from common import dptr
+    B, n_img, res = 1 << 16, 12, 96
+    imgs, xforms, meta = make_small_dataset(n_img, res)
+    means = {}
+    for tag, lam, depth_value in (("off", 0.0, 0.35), ("on", 2.0, 0.35)):
+        M, X = host_meta(imgs, xforms, meta)
+        dep = None
+        if depth_value is not None:
+            dep = np.full(res * res, depth_value, np.float32)
+            for i in range(n_img):
+                M[i].depth = dep.ctypes.data
+        hm = HipModel(hip, A.base_model_config(1))
+        opts = A.default_nerf_options(1, target_batch_size=B, depth_supervision_lambda=lam, depth_loss_type=A.LOSS_L1)
+        t = C.c_void_p()
+        A.check(hip, hip.ngp_nerf_create(hm.h, C.byref(opts), A.scene_aabb(1), C.byref(t)))
+        pix = (C.c_void_p * n_img)(*[im.ctypes.data for im in imgs])
+        A.check(hip, hip.ngp_nerf_set_dataset_host(t, n_img, M, X, pix))
+        A.check(hip, hip.ngp_nerf_train(t, None, 400))
+        rp = A.RenderParams()
+        rp.resolution[0] = rp.resolution[1] = 48
+        rp.focal_length[0] = rp.focal_length[1] = M[0].focal_length[0] * 48 / M[0].resolution[0]
+        rp.screen_center[0] = rp.screen_center[1] = 0.5
+        for k in range(12):
+            rp.camera[k] = X[2].start[k]
+        rp.lens_mode = 0; rp.spp_index = 0; rp.snap_to_pixel_centers = 1; rp.min_transmittance = 1e-4; rp.near_distance = 0.0; rp.use_inference_params = 0
+        rp.render_aabb = A.scene_aabb(1)
+        f = torch.zeros((48 * 48, 4), dtype=torch.float32, device="cuda"); dd = torch.zeros(48 * 48, dtype=torch.float32, device="cuda")
+        A.check(hip, hip.ngp_nerf_render(t, None, C.byref(rp), dptr(f), dptr(dd)))
+        torch.cuda.synchronize()
+        st = _stats(hip, t)
+        alpha = f[:, 3].cpu().numpy(); depth = dd.cpu().numpy()
+        means[tag] = (float(alpha.mean()), float((alpha > 0.5).mean()), float(st.loss))
+        assert np.isfinite(st.loss) and st.measured_batch_size > 0
+        hip.ngp_nerf_destroy(t)
+    print("mean rendered opacity / coverage / loss:", means)
+    assert means["off"][1] > 0.1 and means["off"][0] > 0.1  # lambda = 0: the scene trains as if the depth images were not there
+    assert means["on"][0] < 0.5 * means["off"][0], means      # the (wrong, far too small) depth targets are met by giving up opacity

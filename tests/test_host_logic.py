@@ -399,3 +399,41 @@ def test_exr_reader_rejects_malformed_files(tmp_path):
     import zlib
     bad_zip, _, _ = _tiny_exr(compression=2, zip_payload=zlib.compress(b"\0" * 10))
     expect_error(bad_zip, "zip size")
+
+
+def test_loader_depth_images(tmp_path):
+    """json "integer_depth_scale" + per-frame "depth_path" (nerf_loader.cu:490-492, 629-641): 16-bit PNGs, depth in scene units = integer depth x
+    integer_depth_scale x dataset scale (copy_depth :73-82 with m.depth_scale * result.scale, :732); "enable_depth_loading": false switches it off;
+    a depth image of the wrong size is an error."""
+    import json
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    w, h = 12, 9
+    rng = np.random.default_rng(4)
+    _write_png(tmp_path / "f0.png", rng.integers(0, 255, (h, w, 4), dtype=np.uint8))
+    _write_png(tmp_path / "f1.png", rng.integers(0, 255, (h, w, 4), dtype=np.uint8))
+    dep = rng.integers(0, 65535, (h, w), dtype=np.uint16); dep[2, 3] = 0
+    Image.fromarray(dep, "I;16").save(tmp_path / "d0.png")
+    mat = [[1, 0, 0, 0.1], [0, 1, 0, 0.2], [0, 0, 1, 3.0], [0, 0, 0, 1]]
+    tf = {"camera_angle_x": 0.7, "aabb_scale": 1, "scale": 0.5, "integer_depth_scale": 0.001,
+          "frames": [{"file_path": "f0.png", "depth_path": "d0.png", "transform_matrix": mat}, {"file_path": "f1.png", "transform_matrix": mat}]}
+    (tmp_path / "transforms.json").write_text(json.dumps(tf))
+    t = ngp.Testbed(); t.load_training_data(str(tmp_path / "transforms.json"))
+    d = t.nerf.training.dataset
+    got = d.depth(0)
+    assert got.shape == (h, w) and np.array_equal(got, dep.astype(np.float32) * (np.float32(0.001) * np.float32(0.5)))
+    with pytest.raises(RuntimeError):
+        d.depth(1)  # no depth image for this frame
+    assert t.nerf.training.depth_supervision_lambda == 0.0 and t.nerf.training.depth_loss_type == ngp.LossType.L1
+    tf["enable_depth_loading"] = False
+    (tmp_path / "transforms.json").write_text(json.dumps(tf))
+    t2 = ngp.Testbed(); t2.load_training_data(str(tmp_path / "transforms.json"))
+    with pytest.raises(RuntimeError):
+        t2.nerf.training.dataset.depth(0)
+    tf["enable_depth_loading"] = True
+    Image.fromarray(dep[:-1], "I;16").save(tmp_path / "d0.png")
+    (tmp_path / "transforms.json").write_text(json.dumps(tf))
+    with pytest.raises(RuntimeError):
+        ngp.Testbed().load_training_data(str(tmp_path / "transforms.json"))

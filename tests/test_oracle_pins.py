@@ -329,6 +329,62 @@ def test_compositing_adjoint_finite_differences(ora):
     assert worst < 0.08, worst
 
 
+def test_depth_supervision_adjoint_finite_differences(ora):
+    """The depth term of K3's density gradient (testbed_nerf.cu:1027-1029, 1126-1129) vs central differences of an independent float64 model:
+    L_depth = lambda * |sum_j alpha_j T_j depth_j - target|, differentiated with respect to the density logits.  The oracle's gradient with the term
+    switched on minus the one with it switched off must be dL_depth / dlogit (x loss_scale / n_rays)."""
+    from common import host_meta, make_small_dataset
+    imgs, xforms, meta = make_small_dataset(3, 16)
+    M, X = host_meta(imgs, xforms, meta)
+    n_rays, ns, lam, D0 = 4, 9, 0.7, 0.45
+    dep = np.full(16 * 16, D0, np.float32)
+    for i in range(3):
+        M[i].depth = dep.ctypes.data
+    rng = np.random.default_rng(2)
+    coords = np.zeros((n_rays * ns, 7), np.float32)
+    coords[:, :3] = rng.uniform(0.2, 0.8, (n_rays * ns, 3)); coords[:, 3] = 0.0
+    net = np.zeros((n_rays * ns, 4), np.float16)
+    net[:, :3] = rng.normal(0, 1, (n_rays * ns, 3)); net[:, 3] = rng.normal(5.0, 1.0, n_rays * ns)
+    ray_idx = np.arange(n_rays, dtype=np.uint32)
+    rays = np.zeros((n_rays, 6), np.float32); rays[:, 3:] = (0, 0, 1)  # origin 0, |d| = 1: target depth = the depth image's value
+    numsteps = np.stack([np.full(n_rays, ns), np.arange(n_rays) * ns], 1).astype(np.uint32)
+    aabb = A.scene_aabb(1)
+    rngs = A.Pcg32(); ora.ora_pcg32_seed(C.byref(rngs), C.c_uint64(1337), C.c_uint64(1))
+    bg = (C.c_float * 3)(0.2, 0.4, 0.6)
+
+    def oracle_grad(lam_):
+        ora.ora_set_depth_supervision(C.c_float(lam_), A.LOSS_L1)
+        try:
+            ns2 = numsteps.copy(); cc = np.zeros((64, 7), np.float32); dl = np.zeros((64, 4), np.uint16); loss = np.zeros(n_rays, np.float32); cnt = C.c_uint32()
+            ora.ora_k_compute_loss(n_rays, n_rays, aabb, rngs, 64, C.c_float(1.0), bg, 0, 0, 0, 3, M, ptr(net.view(np.uint16)), 4, C.byref(cnt), ptr(ray_idx), ptr(rays), ptr(ns2),
+                                   ptr(coords), ptr(cc), ptr(dl), 4, A.LOSS_HUBER, ptr(loss), A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, C.c_float(1.0), C.c_float(0.0))
+            assert cnt.value == n_rays * ns
+            return half_to_f32(dl)[:n_rays * ns].astype(np.float64)
+        finally:
+            ora.ora_set_depth_supervision(C.c_float(0.0), A.LOSS_L1)
+
+    g = oracle_grad(lam) - oracle_grad(0.0)
+    assert np.abs(g[:, :3]).max() == 0.0  # the colour logits do not see the depth term
+    dt = math.sqrt(3.0) / 1024.0  # unwarp_dt(0) = MIN_CONE_STEPSIZE
+    depth = np.linalg.norm(coords[:, :3].astype(np.float64), axis=1).reshape(n_rays, ns)
+
+    def l_depth(logits):  # [n_rays, ns] float64 -> sum over rays of lambda * |depth_ray - target|
+        alpha = 1.0 - np.exp(-np.exp(logits) * dt)
+        T = np.cumprod(np.concatenate([np.ones((n_rays, 1)), 1.0 - alpha[:, :-1]], 1), 1)
+        return float((lam * np.abs((alpha * T * depth).sum(1) - D0)).sum())
+
+    l0 = net[:, 3].astype(np.float64).reshape(n_rays, ns)
+    worst = 0.0
+    for r in range(n_rays):
+        for j in range(ns):
+            up, dn = l0.copy(), l0.copy(); up[r, j] += 1e-4; dn[r, j] -= 1e-4
+            fd = (l_depth(up) - l_depth(dn)) / 2e-4 / n_rays  # loss_scale / n_rays normalisation of the analytic gradient
+            worst = max(worst, abs(fd - g[r * ns + j, 3]) / (abs(fd) + 2e-4))
+    assert worst < 0.03, worst  # half rounding of two gradients
+    for i in range(3):
+        M[i].depth = None
+
+
 # ---- pins against the REFERENCE's own logged output -------------------------------------------------------------------------------
 # notebooks/instant_ngp.ipynb (shipped with the reference) keeps the console output of a real instant-ngp run on data/nerf/fox:
 #   "GridEncoding:  Nmin=16 b=1.51572 F=2 T=2^19 L=16"  and  "total_encoding_params=13074912 total_network_params=9728"

@@ -17,16 +17,28 @@ import numpy as np
 NOTEBOOK_LOSS, NOTEBOOK_STEPS = 0.00102, 2000
 
 
-def run(n_steps=NOTEBOOK_STEPS, config="base_l16f2.json", seed=1337):
-    import pyngp as ngp
-    scene = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
-    if not os.path.exists(scene):
-        raise RuntimeError("_ref_data/data/nerf/fox is not staged (tools/stage_reference_data.py)")
-    t = ngp.Testbed()
+_TB = None
+
+
+def _testbed():
+    """one Testbed for all runs: the 50 JPEGs are decoded once; reload_network_from_file resets the network and the training state (reset_network)"""
+    global _TB
+    if _TB is None:
+        import pyngp as ngp
+        scene = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
+        if not os.path.exists(scene):
+            raise RuntimeError("_ref_data/data/nerf/fox is not staged (tools/stage_reference_data.py)")
+        _TB = ngp.Testbed()
+        _TB.load_training_data(scene)
+    return _TB
+
+
+def run(n_steps=NOTEBOOK_STEPS, config="base_l16f2.json", seed=1337, near_distance=None):
+    t = _testbed()
     t.seed = seed
-    t.load_training_data(scene)
     t.reload_network_from_file(os.path.join(ROOT, "instant-ngp_amd", "configs", "nerf", config))
     t.shall_train = True
+    t.nerf.training.near_distance = 0.1 if near_distance is None else near_distance  # (the 2022 code base's member default is not known from the mount; the current one is 0.1)
     losses = []
     t0 = time.perf_counter()
     while t.training_step < n_steps:
@@ -35,16 +47,21 @@ def run(n_steps=NOTEBOOK_STEPS, config="base_l16f2.json", seed=1337):
             losses.append((int(t.training_step), float(t.loss)))
     wall = time.perf_counter() - t0
     tail = np.array([l for s, l in losses if s > n_steps - 320])  # the last 20 read-backs
-    return {"scene": "data/nerf/fox (50 JPEGs 1080x1920, aabb_scale 4)", "config": config, "n_steps": n_steps, "seed": seed, "n_images": int(t.nerf.training.dataset.n_images),
-            "loss_last_readback": losses[-1][1], "loss_last_readback_step": losses[-1][0],
-            "loss_tail_mean": float(tail.mean()), "loss_tail_std": float(tail.std(ddof=1)), "loss_tail_min": float(tail.min()), "loss_tail_max": float(tail.max()), "loss_tail_n": int(tail.size),
-            "notebook_loss": NOTEBOOK_LOSS, "notebook_steps": NOTEBOOK_STEPS, "ratio_tail_mean_to_notebook": float(tail.mean() / NOTEBOOK_LOSS),
-            "loss_curve_every_160": [(s, round(l, 6)) for s, l in losses if s % 160 == 0], "wall_s": round(wall, 2)}
+    return {"config": config, "near_distance": near_distance, "n_steps": n_steps, "seed": seed,
+            "loss_last_readback": losses[-1][1], "loss_tail_mean": float(tail.mean()), "loss_tail_std": float(tail.std(ddof=1)), "loss_tail_min": float(tail.min()), "loss_tail_max": float(tail.max()),
+            "ratio_tail_mean_to_notebook": float(tail.mean() / NOTEBOOK_LOSS),
+            "loss_curve_every_320": [(s, round(l, 6)) for s, l in losses if s % 320 == 0], "wall_s": round(wall, 2)}
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else NOTEBOOK_STEPS
-    r = {"l16f2": run(n, "base_l16f2.json"), "l8f4_current_base_json": run(n, "base.json")}
+    n_seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    runs = {"l16f2": [run(n, "base_l16f2.json", seed=1337 + i) for i in range(n_seeds)], "l8f4_current_base_json": [run(n, "base.json", seed=1337 + i) for i in range(min(n_seeds, 4))]}
+    r = {"scene": "data/nerf/fox (50 JPEGs 1080x1920, aabb_scale 4)", "notebook_loss": NOTEBOOK_LOSS, "notebook_steps": NOTEBOOK_STEPS, "n_images": int(_testbed().nerf.training.dataset.n_images), "runs": runs}
+    for k, v in runs.items():
+        m = np.array([x["loss_tail_mean"] for x in v])
+        r[k + "_summary"] = {"seeds": len(v), "tail_mean_over_seeds": float(m.mean()), "std_over_seeds": float(m.std(ddof=1)), "min": float(m.min()), "max": float(m.max()),
+                             "ratio_mean_to_notebook": float(m.mean() / NOTEBOOK_LOSS), "notebook_within_seed_range": bool(m.min() <= NOTEBOOK_LOSS <= m.max())}
     s = json.dumps(r)
     print(s)
     if len(sys.argv) > 2:
