@@ -2000,12 +2000,14 @@ __global__ void k_build_frags(const __half* __restrict__ mlp_params, uint32_t n_
 // [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters, 4 parameters
 // (= one F=4 hash-table entry) per thread: 8-byte gradient / half-parameter accesses, 16-byte fp32 state accesses; the
 // Adam state of an entry is only touched when one of its gradients is non-zero (sparse update of the reference).
-DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint32_t& step) {
+DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint16_t& step) {
 	if (matrix) gradient += a.l2_reg * weight_fp;
 	const float gradient_sq = gradient * gradient;
 	const float first = m = a.beta1 * m + (1 - a.beta1) * gradient;
 	const float second = v = a.beta2 * v + (1 - a.beta2) * gradient_sq;
-	const uint32_t current_step = ++step;
+	// per-parameter step counter, 16 bits SATURATING: it only feeds the two debias factors, and 1 - beta^t is exactly 1.0f in fp32 long before
+	// t = 65,535 (beta2 = 0.99: t > 1,700; beta2 = 0.999: t > 17,000) -- the result is the one of a 32-bit counter, at half the bytes per updated entry
+	const uint32_t current_step = step == 0xFFFFu ? 0xFFFFu : (uint32_t)(++step);
 	float lr = a.lr;
 	// beta^t as exp(t ln beta): the per-parameter step counters make powf the dominant cost of the sweep otherwise
 	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
@@ -2029,8 +2031,8 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 	}
 	if (any) {
 		float4 mw = ((const float4*)a.master)[i4], m4 = ((const float4*)a.m)[i4], v4 = ((const float4*)a.v)[i4];
-		uint4 st = ((const uint4*)a.steps)[i4];
-		float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint32_t* sp = (uint32_t*)&st;
+		uint2 st = ((const uint2*)a.steps)[i4];
+		float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			if (!upd[k]) continue;
@@ -2042,7 +2044,7 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 				((_Float16*)a.bw_frags)[a.bw_perm[i + k]] = w4[k];
 			}
 		}
-		((float4*)a.master)[i4] = mw; ((float4*)a.m)[i4] = m4; ((float4*)a.v)[i4] = v4; ((uint4*)a.steps)[i4] = st;
+		((float4*)a.master)[i4] = mw; ((float4*)a.m)[i4] = m4; ((float4*)a.v)[i4] = v4; ((uint2*)a.steps)[i4] = st;
 		((uint2*)a.params)[i4] = __builtin_bit_cast(uint2, w4);
 	}
 	float4 e4 = ((const float4*)a.ema)[i4];

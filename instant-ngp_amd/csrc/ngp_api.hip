@@ -189,7 +189,7 @@ struct ngp_model {
 	GridMeta* gm_dev = nullptr;
 	uint64_t n_params = 0, n_mlp = 0;
 	float* master = nullptr; ngp_half* params = nullptr; ngp_half* params_inf = nullptr; ngp_half* grads = nullptr;
-	float* adam_m = nullptr; float* adam_v = nullptr; float* ema = nullptr; uint32_t* adam_steps = nullptr;
+	float* adam_m = nullptr; float* adam_v = nullptr; float* ema = nullptr; uint16_t* adam_steps = nullptr;
 	uint32_t* fw_perm = nullptr; uint32_t* bw_perm = nullptr;
 	ngp_half* fw_frags = nullptr; ngp_half* bw_frags = nullptr; ngp_half* fw_frags_inf = nullptr;
 	ngp_half* enc_stash = nullptr; size_t stash_halfs = 0;
@@ -292,7 +292,7 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 		dev_alloc(&m->bw_frags, n_bw_halfs) || dev_alloc(&m->fw_frags_inf, n_fw_halfs)) { delete m; return 1; }
 	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(m->grads, 0, P * 2)); HIPCHK(hipMemset(m->adam_m, 0, P * 4)); HIPCHK(hipMemset(m->adam_v, 0, P * 4));
-	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 4));
+	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 2));
 	HIPCHK(hipMemset(m->fw_frags, 0, n_fw_halfs * 2)); HIPCHK(hipMemset(m->bw_frags, 0, n_bw_halfs * 2));
 	HIPCHK(hipMemset(m->fw_frags_inf, 0, n_fw_halfs * 2));
 	std::vector<uint32_t> fwp, bwp;
@@ -519,7 +519,7 @@ struct ngp_encmlp {
 	uint64_t n_params = 0, n_mlp = 0;
 	// Trainer state on the device, same layout conventions as ngp_model: MLP (row-major [out][in] per layer) then the grid [tcnn]
 	float* master = nullptr; ngp_half* params = nullptr; ngp_half* params_inf = nullptr; ngp_half* grads = nullptr;
-	float* adam_m = nullptr; float* adam_v = nullptr; float* ema = nullptr; uint32_t* adam_steps = nullptr;
+	float* adam_m = nullptr; float* adam_v = nullptr; float* ema = nullptr; uint16_t* adam_steps = nullptr;
 	uint32_t* fw_perm = nullptr; uint32_t* bw_perm = nullptr;
 	ngp_half* fw_frags = nullptr; ngp_half* bw_frags = nullptr; ngp_half* fw_frags_inf = nullptr; // only the FW_R* / BW_R* slots are used
 	ngp_half* enc_stash = nullptr; void* dy_stash = nullptr; uint32_t stash_n = 0;
@@ -586,7 +586,7 @@ extern "C" int ngp_encmlp_create(const ngp_encmlp_config* cfg, uint64_t seed, ng
 		dev_alloc(&m->bw_frags, N_BW_FRAGS * FRAG_HALFS) || dev_alloc(&m->fw_frags_inf, N_FW_FRAGS * FRAG_HALFS)) { delete m; return 1; }
 	HIPCHK(hipMemcpy(m->gm_dev, &m->gm, sizeof(GridMeta), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(m->grads, 0, P * 2)); HIPCHK(hipMemset(m->adam_m, 0, P * 4)); HIPCHK(hipMemset(m->adam_v, 0, P * 4));
-	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 4));
+	HIPCHK(hipMemset(m->ema, 0, P * 4)); HIPCHK(hipMemset(m->adam_steps, 0, P * 2));
 	HIPCHK(hipMemset(m->fw_frags, 0, N_FW_FRAGS * FRAG_HALFS * 2)); HIPCHK(hipMemset(m->bw_frags, 0, N_BW_FRAGS * FRAG_HALFS * 2));
 	HIPCHK(hipMemset(m->fw_frags_inf, 0, N_FW_FRAGS * FRAG_HALFS * 2));
 	std::vector<uint32_t> fwp, bwp;
@@ -686,6 +686,7 @@ extern "C" int ngp_encmlp_optimizer_step(ngp_encmlp* m, void* stream, float loss
 	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
 	a.beta1 = m->opt.beta1; a.beta2 = m->opt.beta2; a.eps = m->opt.epsilon; a.l2_reg = m->opt.l2_reg;
 	a.log_beta1 = std::log(m->opt.beta1); a.log_beta2 = std::log(m->opt.beta2);
+	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
 	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding; a.zero_grid_grads = 0;
 	const float d = m->opt.ema_decay; // 0 without an Ema wrapper: the inference parameters then equal the parameters
 	a.ema_decay = d;
@@ -949,6 +950,7 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
 	a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.epsilon; a.l2_reg = m->cfg.l2_reg;
 	a.log_beta1 = std::log(m->cfg.beta1); a.log_beta2 = std::log(m->cfg.beta2);
+	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
 	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
 	a.zero_grid_grads = !(g_debug_flags & DBG_NO_GRAD_ZERO_IN_OPTIMIZER);
 	const float d = m->cfg.ema_decay;
@@ -983,7 +985,13 @@ extern "C" int ngp_model_serialize_host(ngp_model* m, void* buf, uint64_t size, 
 	if (with_optimizer) {
 		HIPCHK(hipMemcpy(p, m->adam_m, nb, hipMemcpyDeviceToHost)); p += nb;
 		HIPCHK(hipMemcpy(p, m->adam_v, nb, hipMemcpyDeviceToHost)); p += nb;
-		HIPCHK(hipMemcpy(p, m->adam_steps, nb, hipMemcpyDeviceToHost)); p += nb;
+		{ // the blob keeps 32-bit counters (format version 1); the device holds 16-bit saturating ones
+			std::vector<uint16_t> st16(m->n_params);
+			HIPCHK(hipMemcpy(st16.data(), m->adam_steps, m->n_params * 2, hipMemcpyDeviceToHost));
+			uint32_t* dst = (uint32_t*)p;
+			for (uint64_t i = 0; i < m->n_params; ++i) dst[i] = st16[i];
+			p += nb;
+		}
 		HIPCHK(hipMemcpy(p, m->ema, nb, hipMemcpyDeviceToHost)); p += nb;
 	}
 	return 0;
@@ -1005,7 +1013,13 @@ extern "C" int ngp_model_deserialize_host(ngp_model* m, const void* buf, uint64_
 	if (h.with_optimizer) {
 		HIPCHK(hipMemcpy(m->adam_m, p, nb, hipMemcpyHostToDevice)); p += nb;
 		HIPCHK(hipMemcpy(m->adam_v, p, nb, hipMemcpyHostToDevice)); p += nb;
-		HIPCHK(hipMemcpy(m->adam_steps, p, nb, hipMemcpyHostToDevice)); p += nb;
+		{
+			std::vector<uint16_t> st16(m->n_params);
+			const uint32_t* src = (const uint32_t*)p;
+			for (uint64_t i = 0; i < m->n_params; ++i) st16[i] = (uint16_t)std::min<uint32_t>(src[i], 0xFFFFu);
+			HIPCHK(hipMemcpy(m->adam_steps, st16.data(), m->n_params * 2, hipMemcpyHostToDevice));
+			p += nb;
+		}
 		HIPCHK(hipMemcpy(m->ema, p, nb, hipMemcpyHostToDevice)); p += nb;
 		m->step = h.step; m->lr = h.lr;
 		if (m->step > 0) {

@@ -211,7 +211,7 @@ struct AdamArgs {
 	int zero_grid_grads; // leave the hash-grid gradients zeroed for the next step's scatter (GradientMode::Overwrite without a memset launch)
 	float ema_decay, ema_debias_old, ema_debias_new;
 	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
-	float* m; float* v; uint32_t* steps; float* ema;
+	float* m; float* v; uint16_t* steps /* per-parameter Adam step counters, saturating */; float* ema;
 	const uint32_t* fw_perm; const uint32_t* bw_perm; // n_mlp-entry scatter tables into the fragment buffers (0xFFFFFFFF = none)
 	ngp_half* fw_frags; ngp_half* bw_frags; ngp_half* fw_frags_inf; 
 };

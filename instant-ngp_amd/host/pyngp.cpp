@@ -151,7 +151,21 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("rays_per_batch", [](Testbed& t) { return t.stats().rays_per_batch; })
 		.def_property_readonly("measured_batch_size", [](Testbed& t) { return t.stats().measured_batch_size; });
 
-	// decoder hook for non-PNG images (the fox capture ships JPEGs): Pillow, if importable
+	m.def("read_image", [](const std::string& path) {
+		int w = 0, h = 0; std::vector<uint8_t> px;
+		if (!Testbed::read_image_builtin(path, w, h, px)) throw std::runtime_error{"read_image: '" + path + "' is not a PNG / baseline JPEG the built-in readers decode"};
+		py::array_t<uint8_t> out({h, w, 4});
+		std::memcpy(out.mutable_data(), px.data(), px.size());
+		return out;
+	}, "RGBA8 [h, w, 4] by the loader's built-in PNG / baseline-JPEG readers (no Pillow)");
+	m.def("read_depth_png", [](const std::string& path) {
+		int w = 0, h = 0; std::vector<uint16_t> px;
+		if (!Testbed::read_depth_png16(path, w, h, px)) throw std::runtime_error{"read_depth_png: could not decode '" + path + "'"};
+		py::array_t<uint16_t> out({h, w});
+		std::memcpy(out.mutable_data(), px.data(), px.size() * 2);
+		return out;
+	}, "one 16-bit channel [h, w] of a PNG, as the loader reads depth images");
+	// decoder hook for images the built-in readers do not decode (progressive JPEG, ...): Pillow, if importable
 	m.def("_set_image_decoder", [](py::function fn) {
 		Testbed::s_fallback_decoder = [fn](const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
 			py::gil_scoped_acquire gil;

@@ -1,6 +1,7 @@
 // testbed.cpp -- see testbed.hpp.  Host logic only; every device operation is a C-ABI call.
 #include "testbed.hpp"
 #include "exr_lite.hpp"
+#include "jpeg_lite.hpp"
 #include "mesh_lite.hpp"
 #include "msgpack_lite.hpp"
 
@@ -104,16 +105,31 @@ static bool decode_png(const std::string& path, int& w, int& h, std::vector<uint
 	return true;
 }
 
-// load_stbi_16(path, &w, &h, &comp, 1) (nerf_loader.cu:633): one 16-bit channel.  Gray (+ alpha) files give their gray channel, 8-bit files v * 257,
-// colour files stb_image's integer luma (77 r + 150 g + 29 b) >> 8.
+// load_stbi_16(path, &w, &h, &comp, 1) (nerf_loader.cu:633): one 16-bit channel.  Gray (+ alpha) files give their gray channel, colour files stb_image's
+// integer luma (77 r + 150 g + 29 b) >> 8, 8-bit files are widened by v * 257 (tests/test_jpeg.py: bit-exact against stb_image itself).
 static bool decode_png_gray16(const std::string& path, int& w, int& h, std::vector<uint16_t>& out) {
 	int ch = 0, depth = 0; std::vector<uint8_t> img;
 	if (!decode_png_raw(path, w, h, ch, depth, img)) return false;
 	out.resize((size_t)w * h);
-	auto sample = [&](size_t i, int c) -> uint32_t { return depth == 16 ? ((uint32_t)img[(i * ch + c) * 2] << 8) | img[(i * ch + c) * 2 + 1] : (uint32_t)img[i * ch + c] * 257u; };
-	for (size_t i = 0; i < out.size(); ++i) out[i] = (uint16_t)(ch >= 3 ? (sample(i, 0) * 77u + sample(i, 1) * 150u + sample(i, 2) * 29u) >> 8 : sample(i, 0));
+	// stb_image converts to the requested channel count in the file's own bit depth and widens afterwards: the luma of an 8-bit colour file is taken in 8 bits
+	auto sample = [&](size_t i, int c) -> uint32_t { return depth == 16 ? ((uint32_t)img[(i * ch + c) * 2] << 8) | img[(i * ch + c) * 2 + 1] : (uint32_t)img[i * ch + c]; };
+	for (size_t i = 0; i < out.size(); ++i) {
+		const uint32_t y = ch >= 3 ? (sample(i, 0) * 77u + sample(i, 1) * 150u + sample(i, 2) * 29u) >> 8 : sample(i, 0);
+		out[i] = (uint16_t)(depth == 16 ? y : y * 257u);
+	}
 	return true;
 }
+
+// load_stbi (nerf_loader.cu:570-603) with the built-in readers: PNG and baseline JPEG decode natively in C++ (host/jpeg_lite.hpp); anything else
+// (progressive JPEG, ...) is left to the decoder hook a Python host may register
+static bool decode_builtin(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
+	const std::string ext = lower(fs::path(path).extension().string());
+	if (ext == ".png") return decode_png(path, w, h, rgba);
+	if (ext == ".jpg" || ext == ".jpeg") return jpeg_lite::decode_file(path, w, h, rgba);
+	return false;
+}
+bool Testbed::read_image_builtin(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) { return decode_builtin(path, w, h, rgba); }
+bool Testbed::read_depth_png16(const std::string& path, int& w, int& h, std::vector<uint16_t>& gray) { return decode_png_gray16(path, w, h, gray); }
 
 // natural (numeric-aware) ordering of frame paths, nerf_loader.cu:347-349
 static bool natural_less(const std::string& a, const std::string& b) {
@@ -486,13 +502,13 @@ void Testbed::load_training_data(const std::string& path_in) {
 			}
 			d.is_hdr = true; ok = true;
 		}
-		if (!ok) ok = ext_l == ".png" && decode_png(F.image_path, w, h, rgba);
+		if (!ok) ok = decode_builtin(F.image_path, w, h, rgba);
 		if (!ok && s_fallback_decoder) ok = s_fallback_decoder(F.image_path, w, h, rgba);
 		if (!ok) throw std::runtime_error{"Could not load image '" + F.image_path + "'"};
 		if (hdr_half.empty()) { // 8-bit images (nerf_loader.cu:581-620, convert_rgba32 :41-63)
 			const fs::path ip = F.image_path;
 			auto decode_any = [&](const fs::path& p, int& ww, int& hh, std::vector<uint8_t>& px) {
-				bool good = lower(p.extension().string()) == ".png" && decode_png(p.string(), ww, hh, px);
+				bool good = decode_builtin(p.string(), ww, hh, px);
 				if (!good && s_fallback_decoder) good = s_fallback_decoder(p.string(), ww, hh, px);
 				return good;
 			};

@@ -437,3 +437,35 @@ def test_loader_depth_images(tmp_path):
     (tmp_path / "transforms.json").write_text(json.dumps(tf))
     with pytest.raises(RuntimeError):
         ngp.Testbed().load_training_data(str(tmp_path / "transforms.json"))
+
+
+def test_loader_rolling_shutter_and_motion(tmp_path):
+    """json "rolling_shutter" [a, b, c, d] (global, per-frame override; three values = no motion-blur term) and per-frame "transform_matrix_start" /
+    "transform_matrix_end" (nerf_loader.cu:204-215, 668-669, 689-694): both matrices go through the NeRF -> NGP convention; without them start == end."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    rng = np.random.default_rng(8)
+    for k in range(3):
+        _write_png(tmp_path / f"f{k}.png", rng.integers(0, 255, (6, 8, 4), dtype=np.uint8))
+    m0 = [[1, 0, 0, 0.1], [0, 1, 0, 0.2], [0, 0, 1, 3.0], [0, 0, 0, 1]]
+    m1 = [[0, -1, 0, 0.4], [1, 0, 0, 0.1], [0, 0, 1, 2.5], [0, 0, 0, 1]]
+    tf = {"camera_angle_x": 0.7, "aabb_scale": 1, "rolling_shutter": [0.1, 0.0, 0.8, 0.05],
+          "frames": [{"file_path": "f0.png", "transform_matrix": m0},
+                     {"file_path": "f1.png", "transform_matrix_start": m0, "transform_matrix_end": m1, "rolling_shutter": [0.0, 1.0, 0.0]},
+                     {"file_path": "f2.png", "transform_matrix": m1, "transform_matrix_end": m0}]}
+    (tmp_path / "transforms.json").write_text(json.dumps(tf))
+    t = ngp.Testbed(); t.load_training_data(str(tmp_path / "transforms.json"))
+    d = t.nerf.training.dataset
+
+    def to_ngp(m):  # nerf_matrix_to_ngp with the default scale 0.33 / offset 0.5, column-major 4x3
+        m = np.array(m, np.float32)[:3].copy()
+        m[:, 1] *= -1; m[:, 2] *= -1; m[:, 3] = m[:, 3] * np.float32(0.33) + np.float32(0.5)
+        c = m[[1, 2, 0], :]
+        return c.T.reshape(-1)
+
+    assert np.allclose(d.metadata[0].rolling_shutter, [0.1, 0.0, 0.8, 0.05]) and np.allclose(d.metadata[1].rolling_shutter, [0.0, 1.0, 0.0, 0.0])
+    assert np.array_equal(np.array(d.xforms[0], np.float32), to_ngp(m0)) and np.array_equal(np.array(d.xforms_end[0], np.float32), to_ngp(m0))
+    assert np.array_equal(np.array(d.xforms[1], np.float32), to_ngp(m0)) and np.array_equal(np.array(d.xforms_end[1], np.float32), to_ngp(m1))
+    assert np.array_equal(np.array(d.xforms[2], np.float32), to_ngp(m1)) and np.array_equal(np.array(d.xforms_end[2], np.float32), to_ngp(m0))

@@ -148,3 +148,49 @@ def test_pos_to_uv_inverts_uv_to_ray(ora, name):
         assert abs(back_h[0] - back_o[0]) <= 2e-6 and abs(back_h[1] - back_o[1]) <= 2e-6
         worst = max(worst, abs(back_h[0] - uv[0]), abs(back_h[1] - uv[1]))
     assert worst <= 2e-5, (name, worst)
+
+
+def test_rolling_shutter_camera_interpolation(ora):
+    """get_xform_given_rolling_shutter / camera_slerp (common_device.cuh:665-674; slerp(mat3, mat3, t) from tiny-cuda-nn's published vec.h): the device
+    header compiled for the host vs the oracle's restatement vs scipy's quaternion slerp in float64.  t = a + b u + c v + d motionblur_time; the rotation
+    follows the short great arc, the position is interpolated linearly; a frame without motion data keeps its matrix bit for bit."""
+    from scipy.spatial.transform import Rotation, Slerp
+    lib = A.load_hip()
+    rng = np.random.default_rng(11)
+    worst_dev_ora = worst_model = 0.0
+    for trial in range(40):
+        r0 = Rotation.from_rotvec(rng.normal(size=3) * 1.5)
+        r1 = r0 * Rotation.from_rotvec(rng.normal(size=3) * (0.02 if trial % 2 else 1.0))  # small and large camera motion
+        p0, p1 = rng.uniform(-1, 2, 3), rng.uniform(-1, 2, 3)
+        X = A.Xform()
+        for c in range(3):
+            for r in range(3):
+                X.start[c * 3 + r] = float(r0.as_matrix()[r, c]); X.end[c * 3 + r] = float(r1.as_matrix()[r, c])
+        for r in range(3):
+            X.start[9 + r] = float(p0[r]); X.end[9 + r] = float(p1[r])
+        rs = (C.c_float * 4)(*rng.uniform(-0.2, 0.5, 4).astype(np.float32))
+        uv = (C.c_float * 2)(*rng.uniform(0, 1, 2).astype(np.float32))
+        mb = float(np.float32(rng.uniform(0, 1)))
+        t = float(np.float32(rs[0]) + np.float32(rs[1]) * np.float32(uv[0]) + np.float32(rs[2]) * np.float32(uv[1]) + np.float32(rs[3]) * np.float32(mb))
+        dev = (C.c_float * 12)(); orc = (C.c_float * 12)()
+        assert lib.ngp_host_xform_given_rolling_shutter(C.byref(X), rs, uv, C.c_float(mb), dev) == 0
+        ora.ora_xform_given_rolling_shutter(C.byref(X), rs, uv, C.c_float(mb), orc)
+        d, o = np.array(dev[:]), np.array(orc[:])
+        worst_dev_ora = max(worst_dev_ora, float(np.abs(d - o).max()))
+        # float64 model: scipy's slerp extrapolates outside [0, 1] the same way (angle * t along the same arc)
+        rot = (r0 * Rotation.from_rotvec((r0.inv() * r1).as_rotvec() * t)).as_matrix()
+        pos = p0 * (1 - t) + p1 * t
+        model = np.concatenate([rot[:, 0], rot[:, 1], rot[:, 2], pos])
+        worst_model = max(worst_model, float(np.abs(d - model).max()))
+        R = d[:9].reshape(3, 3).T
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5
+    assert worst_dev_ora <= 1e-6, worst_dev_ora   # same arithmetic, two implementations (acosf / sinf of the same libm here)
+    assert worst_model <= 5e-6, worst_model       # fp32 vs the float64 model
+    # no motion data: the matrix comes back untouched (csrc/ngp_device.hpp explains the deviation from the reference's quaternion round trip)
+    X = A.Xform()
+    vals = rng.normal(size=12).astype(np.float32)
+    for k in range(12):
+        X.start[k] = X.end[k] = float(vals[k])
+    out = (C.c_float * 12)()
+    lib.ngp_host_xform_given_rolling_shutter(C.byref(X), (C.c_float * 4)(0, 0, 0, 0), (C.c_float * 2)(0.3, 0.7), C.c_float(0.5), out)
+    assert np.array_equal(np.array(out[:], np.float32).view(np.uint32), vals.view(np.uint32))
