@@ -327,8 +327,14 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 				const float t0 = lattice_t(r, j0, a.cone_angle_constant);
 				seg_in = __ballot(aabb.contains(ro + t0 * rdn));
 			}
+			// The in-box lattice points of a ray are a contiguous range (every coordinate of ro + t * rdn is monotonic in t, in fp32 as well, and so is t in
+			// j), so a chunk whose FIRST point is outside the box lies wholly outside: one test per chunk (lane u = chunk u of the group) instead of 64 point
+			// evaluations.  A ray crosses ~9 chunks, the groups are 8 wide: this skips the ~6 chunks behind the exit that the last group used to evaluate
+			// (same masks: a chunk evaluated outside the box yields exactly these values).
+			const uint32_t first_in = (uint32_t)(__ballot(lane < K1_GROUP && aabb.contains(ro + lattice_t(r, (ch0 + (lane < K1_GROUP ? lane : 0u)) * 64u, a.cone_angle_constant) * rdn)) & ((1ull << K1_GROUP) - 1ull));
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
+				if (!((first_in >> u) & 1u) && !a.no_first_point_skip) { m[u] = 0ull; in[u] = 0ull; mip0[u] = 0u; uni[u] = true; continue; }
 				if (group_skip && !((seg_hit >> (8 * u)) & 0xffull)) { // no occupied cell anywhere near the chunk's 64 points
 					m[u] = 0ull; in[u] = ((seg_in >> (8 * u)) & 1ull) ? ~0ull : 0ull; mip0[u] = 0u; uni[u] = true;
 					continue;
@@ -718,19 +724,45 @@ static __device__ __forceinline__ float wave_incl_prod(float x, uint32_t) { retu
 static __device__ __forceinline__ float wave_incl_sum(float x, uint32_t) { return wave_incl_scan<false>(x); }
 static __device__ __forceinline__ float wave_total(float x) { return __shfl(wave_incl_scan<false>(x), 63, 64); } // sum of all 64 lanes, in every lane
 
+// Segmented variants of the wave scans for the two-rays-per-wavefront kernel: inclusive scan inside each 32-lane half (the DPP row operations stay inside
+// 16-lane rows, row_bcast:15 carries row 0 -> 1 and row 2 -> 3; without row_bcast:31 nothing crosses the halves).
+template <bool PROD>
+static __device__ __forceinline__ float half_incl_scan(float x) {
+	const float ident = PROD ? 1.f : 0.f;
+	auto op = [](float a, float b) { return PROD ? a * b : a + b; };
+	float a = op(x, NGP_DPP(ident, x, 0x111, 0xf));
+	a = op(a, NGP_DPP(ident, x, 0x112, 0xf));
+	a = op(a, NGP_DPP(ident, x, 0x113, 0xf));
+	a = op(a, NGP_DPP(ident, a, 0x114, 0xf));
+	a = op(a, NGP_DPP(ident, a, 0x118, 0xf));
+	a = op(a, NGP_DPP(ident, a, 0x142, 0xa)); // row_bcast:15 into rows 1 and 3
+	return a;
+}
+
+// RPW = rays per wavefront.  1: one wavefront per ray (64 samples per pass iteration).  2 (production): the two 32-lane halves of a wavefront work on two rays --
+// a trained scene keeps ~10 samples per ray, so a 64-lane wavefront per ray wastes 5/6 of every instruction (the kernel is VALU-issue bound);
+// the per-ray values move from scalar to per-lane registers, the scans become segmented, and both halves iterate until the longer ray is done.
+template <int RPW>
 __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
-	__shared__ uint32_t s_cnt[K3_RAYS_PER_BLOCK];
-	__shared__ float s_loss[K3_RAYS_PER_BLOCK];
+	constexpr uint32_t LPR = 64u / RPW, RPB = K3_RAYS_PER_BLOCK * RPW; // lanes per ray, rays per workgroup (16 wavefronts)
+	__shared__ uint32_t s_cnt[RPB];
+	__shared__ float s_loss[RPB];
 	__shared__ uint32_t s_base;
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t n_active = *a.rays_counter;
 	const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+	const uint32_t sub = lane / LPR, sl = lane % LPR, seg0 = sub * LPR; // which ray of the wavefront, lane inside the ray's segment, the segment's first lane
+	auto uni = [&](uint32_t v) { return RPW == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; }; // per-ray values: scalar when the wavefront has one ray
+	auto seg_prod = [&](float x) { return RPW == 1 ? wave_incl_scan<true>(x) : half_incl_scan<true>(x); };
+	auto seg_sum = [&](float x) { return RPW == 1 ? wave_incl_scan<false>(x) : half_incl_scan<false>(x); };
+	auto seg_total = [&](float x) { return __shfl(seg_sum(x), (int)(seg0 + LPR - 1u), 64); };       // sum over the ray's segment, in every lane of it
+	auto seg_mask = [&](bool pred) { const uint64_t m = __ballot(pred); return RPW == 1 ? m : (m >> seg0) & 0xffffffffull; }; // ballot restricted to the segment
 	const Box aabb(a.aabb);
 	const float EPSILON = 1e-4f;
 	float block_loss = 0.f; // thread 0 only
-	// persistent grid (see k1_count): each workgroup loops over groups of 16 rays
-	for (uint32_t grp = blockIdx.x; grp * K3_RAYS_PER_BLOCK < n_active; grp += gridDim.x) {
-	const uint32_t i = grp * K3_RAYS_PER_BLOCK + wid; // wave-uniform (wid is a scalar)
+	// persistent grid (see k1_count): each workgroup loops over groups of RPB rays
+	for (uint32_t grp = blockIdx.x; grp * RPB < n_active; grp += gridDim.x) {
+	const uint32_t i = grp * RPB + wid * RPW + sub; // the lane's ray (wave-uniform for RPW == 1)
 	const bool active = i < n_active;
 
 	uint32_t numsteps = 0, base = 0, compacted = 0;
@@ -739,7 +771,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color), loss_bg = mk3(0.f);
 	float T_final = 1.f;
 	float depth_ray = 0.f, target_depth = -1.f; // depth supervision (a.depth_lambda > 0, wave-uniform)
-	// first 64 samples of the ray stay in registers for the adjoint pass (most rays have <= 64 samples)
+	// the first LPR samples of the ray stay in registers for the adjoint pass (most rays keep fewer)
 	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f, k_cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	const bool vec_out = a.output_stride == 4, vec_dl = a.dloss_stride == 4;
 	auto load_out = [&](const __half* lo, float& l0, float& l1, float& l2, float& l3) {
@@ -750,18 +782,18 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		} else { l0 = __half2float(lo[0]); l1 = __half2float(lo[1]); l2 = __half2float(lo[2]); l3 = __half2float(lo[3]); }
 	};
 	if (active) {
-		// per-ray values are wave-uniform: keep them in scalar registers
-		numsteps = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 0]);
-		base = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.numsteps_inout[i * 2 + 1]);
+		// per-ray values: uniform across the ray's lanes (scalar registers when the wavefront has one ray)
+		numsteps = uni(a.numsteps_inout[i * 2 + 0]);
+		base = uni(a.numsteps_inout[i * 2 + 1]);
 		ray_o = ld3(a.rays_in[i].o);
 		f4 tex = {0.f, 0.f, 0.f, 0.f};
 		if (a.ray_targets) { // computed once per ray by k1_setup
 			const float4 t0 = ((const float4*)(a.ray_targets + (size_t)i * 8))[0], t1 = ((const float4*)(a.ray_targets + (size_t)i * 8))[1];
 			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y); target_depth = t1.z;
 		} else {
-			const uint32_t ray_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ray_indices_in[i]);
+			const uint32_t ray_idx = uni(a.ray_indices_in[i]);
 			// The target-pixel chain (ray index -> image metadata -> texel) is issued BEFORE the sample pass so that its three
-			// dependent memory latencies overlap the sample loads instead of following them (uniform across the wave).
+			// dependent memory latencies overlap the sample loads instead of following them (uniform across the ray's lanes).
 			Rng rng(a.rng);
 			rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
 			const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
@@ -771,7 +803,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 			tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
 			target_depth = len3(ld3(a.rays_in[i].d)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
-			// target colour and background: identical to the sequential kernel (uniform across the wave); needed BEFORE the sample pass by the Rfl mode
+			// target colour and background: identical to the sequential kernel; needed BEFORE the sample pass by the Rfl mode
 			background_color = srgb_to_linear3(background_color);
 			const f3 trgb = mk3(tex.x, tex.y, tex.z);
 			if (a.linear_colors || !a.color_space_srgb) {
@@ -783,13 +815,17 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				else rgbtarget = background_color;
 			}
 		}
-
 		cin = a.coords_in + (size_t)base * 7;
 		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
+	}
+	{ // ---- pass 1: composite front to back until the transmittance cut; every lane of the wavefront takes part in the scans ----
 		float T_run = 1.f;
-		for (uint32_t c0 = 0; c0 < numsteps; c0 += 64) {
-			const uint32_t s = c0 + lane;
-			const bool valid = s < numsteps;
+		bool fin = !active; // this ray's pass is over (cut found / all samples seen / no ray)
+		for (uint32_t c0 = 0; ; c0 += LPR) {
+			const bool on = !fin && c0 < numsteps;
+			if (__ballot(on) == 0ull) break;
+			const uint32_t s = c0 + sl;
+			const bool valid = on && s < numsteps;
 			float alpha = 0.f, sdepth = 0.f; f3 rgb = mk3(0.f);
 			if (valid) {
 				float l0, l1, l2, l3, dtw;
@@ -806,53 +842,56 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
 				if (a.depth_lambda > 0.0f) { const float* ci = cin + (size_t)s * 7; sdepth = dist3(unwarp_position(mk3(ci[0], ci[1], ci[2]), aabb), ray_o); }
 			}
-			const float incl = wave_incl_prod(1.f - alpha, lane);
+			const float incl = seg_prod(1.f - alpha);
 			float excl = __shfl_up(incl, 1, 64);
-			if (lane == 0) excl = 1.f;
+			if (sl == 0) excl = 1.f;
 			const float T_k = T_run * excl;
-			const uint64_t vm = __ballot(valid), fail = __ballot(valid && !(T_k >= EPSILON)); // `if (T < EPSILON) break;`
+			const uint64_t vm = seg_mask(valid), fail = seg_mask(valid && !(T_k >= EPSILON)); // `if (T < EPSILON) break;`
 			const uint32_t n_proc = fail ? (uint32_t)(__ffsll((long long)fail) - 1) : (uint32_t)__popcll(vm);
-			const bool proc = lane < n_proc;
+			const bool proc = sl < n_proc;
 			const float w = proc ? alpha * T_k : 0.f;
 			// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
-			rgb_ray = rgb_ray + mk3(wave_total(proc ? w * rgb.x : 0.f), wave_total(proc ? w * rgb.y : 0.f), wave_total(proc ? w * rgb.z : 0.f));
-			if (a.depth_lambda > 0.0f) depth_ray += wave_total(proc ? w * sdepth : 0.f);
+			rgb_ray = rgb_ray + mk3(seg_total(proc ? w * rgb.x : 0.f), seg_total(proc ? w * rgb.y : 0.f), seg_total(proc ? w * rgb.z : 0.f));
+			if (a.depth_lambda > 0.0f) depth_ray += seg_total(proc ? w * sdepth : 0.f);
 			if (a.train_mode == 1) { // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
 				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
-				loss_bg = loss_bg + mk3(wave_total(proc ? w * ll.x : 0.f), wave_total(proc ? w * ll.y : 0.f), wave_total(proc ? w * ll.z : 0.f));
+				loss_bg = loss_bg + mk3(seg_total(proc ? w * ll.x : 0.f), seg_total(proc ? w * ll.y : 0.f), seg_total(proc ? w * ll.z : 0.f));
 			}
-			if (n_proc) T_run = T_run * __shfl(incl, (int)n_proc - 1, 64);
-			compacted += n_proc;
-			if (fail) break;
+			const float T_last = __shfl(incl, (int)(seg0 + (n_proc ? n_proc - 1u : 0u)), 64);
+			if (on) {
+				if (n_proc) T_run = T_run * T_last;
+				compacted += n_proc;
+				if (fail) fin = true;
+			}
 		}
 		T_final = T_run;
-		if (compacted == numsteps) {
+		if (active && compacted == numsteps) {
 			rgb_ray = rgb_ray + T_final * background_color;
 			if (a.train_mode == 1) { f3 ll, lgl; loss_and_gradient(rgbtarget, background_color, a.loss_type, ll, lgl); loss_bg = loss_bg + T_final * ll; }
 		}
 	}
-	// one global atomic per workgroup reserves the spans of its 16 rays
-	if (lane == 0) s_cnt[wid] = compacted;
+	// one global atomic per workgroup reserves the spans of its rays
+	if (sl == 0) s_cnt[wid * RPW + sub] = active ? compacted : 0u;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint32_t tot = 0;
-		for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) tot += s_cnt[w];
+		for (uint32_t w = 0; w < RPB; ++w) tot += s_cnt[w];
 		s_base = tot ? atomicAdd(a.numsteps_counter_compacted, tot) : 0u;
 	}
 	__syncthreads();
 	uint32_t compacted_base = s_base;
-	for (uint32_t w = 0; w < wid; ++w) compacted_base += s_cnt[w];
+	for (uint32_t w = 0; w < wid * RPW + sub; ++w) compacted_base += s_cnt[w];
 	float my_loss = 0.f;
 	if (active) {
 		compacted = min(a.max_samples_compacted - min(a.max_samples_compacted, compacted_base), compacted);
-		if (lane == 0) { a.numsteps_inout[i * 2 + 0] = compacted; a.numsteps_inout[i * 2 + 1] = compacted_base; }
-	}
-	if (active && compacted > 0) {
+		if (sl == 0) { a.numsteps_inout[i * 2 + 0] = compacted; a.numsteps_inout[i * 2 + 1] = compacted_base; }
+	} else compacted = 0;
+	{ // ---- pass 2: adjoint + compaction ----
 		float* cout = a.coords_out + (size_t)compacted_base * 7;
 		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
-		f3 lloss, lgrad;
+		f3 lloss = mk3(0.f), lgrad = mk3(0.f);
 		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
-		my_loss = ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
+		if (compacted > 0) my_loss = ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
 		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
@@ -860,8 +899,9 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		f3 ray2_run = mk3(0.f), lb2_run = mk3(0.f);
 		float depth_loss_gradient = 0.f, depth2_run = 0.f;
 		if (target_depth > 0.0f) { f3 dl_, dg_; loss_and_gradient(mk3(target_depth), mk3(depth_ray), a.depth_loss_type, dl_, dg_); depth_loss_gradient = a.depth_lambda * dg_.x; } // testbed_nerf.cu:1028-1029
-		for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
-			const uint32_t s = c0 + lane;
+		for (uint32_t c0 = 0; ; c0 += LPR) {
+			if (__ballot(c0 < compacted) == 0ull) break;
+			const uint32_t s = c0 + sl;
 			const bool valid = s < compacted;
 			float alpha = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, dt = 0.f, depth = 0.f;
 			f3 rgb = mk3(0.f);
@@ -882,18 +922,18 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
 				depth = dist3(unwarp_position(mk3(cc[0], cc[1], cc[2]), aabb), ray_o);
 			}
-			const float incl = wave_incl_prod(1.f - alpha, lane);
+			const float incl = seg_prod(1.f - alpha);
 			float excl = __shfl_up(incl, 1, 64);
-			if (lane == 0) excl = 1.f;
+			if (sl == 0) excl = 1.f;
 			const float T_k = T_run * excl, T_after = T_run * incl;
 			const float weight = alpha * T_k;
-			const f3 ray2 = ray2_run + mk3(wave_incl_sum(weight * rgb.x, lane), wave_incl_sum(weight * rgb.y, lane), wave_incl_sum(weight * rgb.z, lane));
+			const f3 ray2 = ray2_run + mk3(seg_sum(weight * rgb.x), seg_sum(weight * rgb.y), seg_sum(weight * rgb.z));
 			float depth2 = depth2_run;
-			if (a.depth_lambda > 0.0f) depth2 = depth2_run + wave_incl_sum(weight * depth, lane);
+			if (a.depth_lambda > 0.0f) depth2 = depth2_run + seg_sum(weight * depth);
 			f3 lloc = mk3(0.f), gloc = mk3(0.f), lb2 = lb2_run;
 			if (a.train_mode == 1) { // Rfl: per-sample loss against the target and its running (inclusive) weighted sum
 				loss_and_gradient(rgbtarget, rgb, a.loss_type, lloc, gloc);
-				lb2 = lb2_run + mk3(wave_incl_sum(weight * lloc.x, lane), wave_incl_sum(weight * lloc.y, lane), wave_incl_sum(weight * lloc.z, lane));
+				lb2 = lb2_run + mk3(seg_sum(weight * lloc.x), seg_sum(weight * lloc.y), seg_sum(weight * lloc.z));
 			}
 			if (valid) {
 				float* cj = cout + (size_t)s * 7;
@@ -924,15 +964,16 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 					*(uint2*)d = __builtin_bit_cast(uint2, v);
 				} else { d[0] = __float2half(d0); d[1] = __float2half(d1); d[2] = __float2half(d2); d[3] = __float2half(d3); }
 			}
-			T_run = T_run * __shfl(incl, 63, 64);
-			ray2_run = mk3(__shfl(ray2.x, 63, 64), __shfl(ray2.y, 63, 64), __shfl(ray2.z, 63, 64));
-			if (a.depth_lambda > 0.0f) depth2_run = __shfl(depth2, 63, 64);
-			if (a.train_mode == 1) lb2_run = mk3(__shfl(lb2.x, 63, 64), __shfl(lb2.y, 63, 64), __shfl(lb2.z, 63, 64));
+			const int last = (int)(seg0 + LPR - 1u);
+			T_run = T_run * __shfl(incl, last, 64);
+			ray2_run = mk3(__shfl(ray2.x, last, 64), __shfl(ray2.y, last, 64), __shfl(ray2.z, last, 64));
+			if (a.depth_lambda > 0.0f) depth2_run = __shfl(depth2, last, 64);
+			if (a.train_mode == 1) lb2_run = mk3(__shfl(lb2.x, last, 64), __shfl(lb2.y, last, 64), __shfl(lb2.z, last, 64));
 		}
 	}
-	if (lane == 0) s_loss[wid] = my_loss;
+	if (sl == 0) s_loss[wid * RPW + sub] = my_loss;
 	__syncthreads(); // also protects s_cnt / s_base against the next group
-	if (threadIdx.x == 0) for (uint32_t w = 0; w < K3_RAYS_PER_BLOCK; ++w) block_loss += s_loss[w];
+	if (threadIdx.x == 0) for (uint32_t w = 0; w < RPB; ++w) block_loss += s_loss[w];
 	}
 	if (a.loss_output && threadIdx.x == 0 && block_loss != 0.f) atomicAdd(a.loss_output, block_loss);
 }
@@ -1419,7 +1460,10 @@ void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
-	else if (!a.k3_scratch || !(g_debug_flags & DBG_K3_TWO_PASS)) hipLaunchKernelGGL(k_compute_loss_v2, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
+	else if (!a.k3_scratch || !(g_debug_flags & DBG_K3_TWO_PASS)) {
+		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) hipLaunchKernelGGL(k_compute_loss_v2<1>, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
+		else hipLaunchKernelGGL(k_compute_loss_v2<2>, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK * 2), 256u * 2u)), dim3(1024), 0, s, a);
+	}
 	else {
 		const uint32_t grid = k1_grid(max_rays);
 		float* rec = (float*)a.k3_scratch; uint64_t* partial = (uint64_t*)(rec + (size_t)max_rays * K3_REC); uint32_t* done = (uint32_t*)(partial + grid);

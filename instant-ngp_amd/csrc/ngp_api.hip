@@ -1055,7 +1055,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	static uint32_t* s_coarse = nullptr;
 	if (!s_coarse && dev_alloc(&s_coarse, (size_t)COARSE_WORDS * N_CASCADES * 2)) return 1;
 	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, std::min<uint32_t>(max_mip + 1, N_CASCADES), s_coarse);
-	a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse; a.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0;
+	a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse; a.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; a.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0;
 	const uint32_t max_local = n_rays / world_size + 1;
 	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
 		launch_generate_training_samples((hipStream_t)stream, a, max_local);
@@ -1382,7 +1382,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
+		k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;

@@ -19,6 +19,8 @@ enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
 	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
+	DBG_K1_NO_FIRST_POINT_SKIP = 268435456 /* k1_count without the one-test-per-chunk rejection of the chunks behind the ray's exit */,
+	DBG_K3_ONE_RAY_PER_WAVE = 134217728 /* K3 with one wavefront per ray (rounds 1-2) instead of two rays per wavefront */,
 	DBG_K4_ZERO_PADDING = 67108864 /* test hook: the rows K4 pads the compacted batch with carry a zero loss gradient instead of the rescaled copy (the padding is the only part of a step that is not linear in the set of rays: tests/test_gpu_dist.py compares the 2-rank sum with the 1-rank gradient without it) */,
 	DBG_K1_INDEPENDENT_LATTICE = 16384 /* lattice K1 without the exact skip rule: every lattice point tested on its own (round-1 behaviour; exact only for cone_angle == 0) */ };
 
@@ -57,6 +59,7 @@ struct K1Args {
 	const uint8_t* bitfield; uint32_t max_mip;
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
 	const uint32_t* bitfield_coarse = nullptr; // optional: one bit per 4x4x4 cells of the x-major copy, followed by its one-cell dilation (same launcher): k1_count's LDS prefilters
+	uint32_t no_first_point_skip = 0;          // ablation DBG_K1_NO_FIRST_POINT_SKIP: k1_count evaluates every chunk of a group, also those behind the ray's exit from the box (rounds 1-2)
 	uint32_t segment_skip = 0;                 // ablation DBG_K1_SEGMENT_SKIP: k1_count rejects 8-point lattice segments by their midpoint (single cascade, cone_angle 0)
 	uint4* k2_tiles0_out; uint32_t k2_tile_w; // optional: round-0 tile list of the lazy K2 (one descriptor per active ray: its first k2_tile_w samples)
 	int snap_to_pixel_centers; float cone_angle_constant;

@@ -157,7 +157,7 @@ def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
     assert np.array_equal(dev, model), f"device lattice K1 vs its CPU model: {(dev != model).sum()} rays differ"
 
 
-@pytest.mark.parametrize("flags", [2097152, 33554432])
+@pytest.mark.parametrize("flags", [2097152, 33554432, 268435456])
 def test_k1_ablation_variants_are_the_same_marcher(ora, hip, scene, flags):
     """k1_count without the coarse-occupancy prefilter (flag 2097152) and with the midpoint test of 8-point segments against the dilated coarse
     grid (flag 33554432): both are exact accelerations, so the per-ray sample counts equal the CPU lattice model's exactly."""
@@ -188,11 +188,11 @@ def test_k1_sample_cap(ora, hip, scene):
     assert not kept[np.argmin(kept):].any()
 
 
-@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (1, 32), (2, 32), (0, 1048576), (1, 1048576), (2, 1048576)])
+@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (0, 134217728), (1, 134217728), (2, 134217728), (1, 32), (2, 32), (0, 1048576), (1, 1048576), (2, 1048576)])
 def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
     """K3 vs the oracle per ray, for the three train modes (0 Nerf, 1 Rfl, 2 RflRelax: fused_kernels/train_nerf.cuh:391-410) and for the three device
-    kernels (one pass, wave per ray, span atomic per 16 rays = production; flag 1048576 = two passes with a prefix sum, deterministic order; flag 32 = the
-    reference's sequential per-ray loops)."""
+    kernels (one pass, two rays per wavefront, span atomic per 32 rays = production; flag 134217728 = the same kernel with one ray per wavefront; flag
+    1048576 = two passes with a prefix sum, deterministic order; flag 32 = the reference's sequential per-ray loops)."""
     import torch
     ora.ora_set_train_mode(train_mode); hip.ngp_debug_set_train_mode(train_mode); hip.ngp_debug_set_flags(k3_flags)
     try:
@@ -201,7 +201,7 @@ def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
         ora.ora_set_train_mode(0); hip.ngp_debug_set_train_mode(0); hip.ngp_debug_set_flags(0)
 
 
-@pytest.mark.parametrize("depth_loss,k3_flags", [(A.LOSS_L1, 0), (A.LOSS_L2, 0), (A.LOSS_L1, 32), (A.LOSS_HUBER, 32)])
+@pytest.mark.parametrize("depth_loss,k3_flags", [(A.LOSS_L1, 0), (A.LOSS_L2, 0), (A.LOSS_L1, 134217728), (A.LOSS_L1, 32), (A.LOSS_HUBER, 32)])
 def test_k3_depth_supervision(ora, hip, scene, depth_loss, k3_flags):
     """Depth supervision (testbed_nerf.cu:1027-1029, 1126-1129; depth_supervision_lambda > 0 and a depth image per training view): the wave-per-ray
     kernel and the reference-order kernel vs the oracle, per ray.  The depth images are synthetic (a smooth field of plausible distances with holes = 0,

@@ -32,6 +32,8 @@ VARIANTS = [
     ("bin_chunk11", 0, (11, 0, 0), (1, 16)),
     ("k2_tile16_r4", 0, (12, 0, 0), (4, 16)),
     ("k2_eager", 8192, (12, 0, 0), (1, 16)),
+    ("k1_no_first_point_skip", 268435456, (12, 0, 0), (1, 16)),   # k1_count evaluates the chunks behind the ray's exit as well (rounds 1-2)
+    ("k3_one_ray_per_wave", 134217728, (12, 0, 0), (1, 16)),   # K3 with a whole wavefront per ray (rounds 1-2)
     ("k1_independent_lattice", 16384, (12, 0, 0), (1, 16)),
     ("default_again", 0, (12, 0, 0), (1, 16)),
     ("t1_no_binning", 2048, (12, 0, 0), (1, 16)),
