@@ -296,6 +296,7 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
 
     lib = A.load_hip()  # raises if libngp_hip.so is missing: no CPU fallback on the product path
+    A.check(lib, lib.ngp_init())  # the library's helper streams exist before the first collective creates an RCCL communicator
     if os.environ.get("NGP_DEBUG_FLAGS"):  # ablation switches of ngp_kernels.hpp (default 0 = production path)
         lib.ngp_debug_set_flags(int(os.environ["NGP_DEBUG_FLAGS"], 0))
     assert lib.ngp_device_available() == 1
@@ -409,7 +410,7 @@ def main():
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
     traffic = traffic_src = None
-    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", fn)))[dominant]["bytes_per_launch"]
             traffic_src = f"profiles/{fn} (separate rocprofv3 --pmc passes of this command; see the file for the correction applied)"

@@ -140,6 +140,10 @@ typedef struct ngp_nerf ngp_nerf;        /* Testbed::m_nerf state for training/r
 const char* ngp_last_error(void);
 /* 1 when a HIP device is visible to this process. */
 int ngp_device_available(void);
+/* Optional: create the library's process-wide helper streams now (they are created with the first model / trainer otherwise).  A host that sets up
+ * communication (RCCL / torch.distributed "nccl") BEFORE its first model calls this first: on ROCm 7.0 streams that come into existence after an RCCL
+ * communicator run their kernels 1.3 - 2x slower (profiles/r03_dp_overhead.txt).  New; no counterpart in the reference. */
+int ngp_init(void);
 
 /* ------------------------------------------------------------------ model ---------------- */
 

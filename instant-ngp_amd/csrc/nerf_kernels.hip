@@ -311,6 +311,10 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		bool done = false, prev_walked = false;
 		uint32_t jnext = 0;        // exact skip: next lattice point the reference's loop visits (valid while prev_walked)
 		uint32_t prev_mip = 0xffu; // mip of the previous chunk if it was uniform
+		// (Round 3 also tried a per-ray bracket: <= 31 points along the ray tested against the dilated coarse grid, only the chunks between the first and the
+		// last hit evaluated, rays without a hit rejected outright.  Exact -- all K1 tests passed with it -- but worth nothing on the bench scene: 0.188 vs 0.190 ms
+		// for K1, profiles/r03_microbench_k1_coarse_bracket_no_gain.log: a ray that misses every occupied cell still passes within one coarse cell of the
+		// dilated occupancy almost always.  Removed again.)
 		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
 			uint64_t m[K1_GROUP], in[K1_GROUP];
 			uint32_t mip0[K1_GROUP]; bool uni[K1_GROUP]; // exact skip: the chunk's mip (of its first point) / is it the same for all points inside the box?

@@ -124,6 +124,17 @@ static int create_helper_stream(hipStream_t* st, bool high_priority) {
 	HIPCHK(hipStreamSynchronize(*st));
 	return 0;
 }
+// The helper streams are PROCESS-WIDE (one W stream, one for the dense-level ablation, one high-priority stream for the pre-launched K1) and live until the
+// process ends: every model / trainer uses the same three, so a second trainer (bench.py's fox leg, a Testbed rebuilding its trainer after load_snapshot)
+// neither adds hardware queues -- two trainers with their own streams ran the second one at 1.17 instead of 0.78 ms per step,
+// profiles/r03_bench_n1_slow_box.json -- nor creates streams behind a communicator that exists by then.  ngp_init() creates them explicitly for hosts
+// that set up communication before their first model.
+static hipStream_t g_side_stream = nullptr, g_side2_stream = nullptr, g_k1_stream = nullptr;
+static int ensure_helper_streams() { return create_helper_stream(&g_side_stream, false) || create_helper_stream(&g_k1_stream, true); }
+extern "C" int ngp_init(void) {
+	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
+	return ensure_helper_streams();
+}
 template <typename T> static int dev_alloc(T** p, size_t n) { HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T))); return 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,7 +324,7 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 	HIPCHK(hipMemcpy(m->master, init.data(), P * 4, hipMemcpyHostToDevice));
 	if (model_refresh_half(m, nullptr)) { delete m; return 1; }
 	HIPCHK(hipDeviceSynchronize());
-	if (!lazy_streams() && create_helper_stream(&m->side, false)) { delete m; return 1; } // W's stream (see create_helper_stream)
+	if (!lazy_streams()) { if (ensure_helper_streams()) { delete m; return 1; } m->side = g_side_stream; } // W's stream (see create_helper_stream)
 	*out = m;
 	return 0;
 }
@@ -323,8 +334,7 @@ extern "C" void ngp_model_destroy(ngp_model* m) {
 	void* ptrs[] = {m->gm_dev, m->master, m->params, m->params_inf, m->grads, m->adam_m, m->adam_v, m->ema, m->adam_steps, m->fw_perm, m->bw_perm,
 		m->fw_frags, m->bw_frags, m->fw_frags_inf, m->enc_stash, m->wgrad_partials, m->denc_lv, m->bin_vals, m->bin_idxs, m->bin_cursors};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	if (m->side) (void)hipStreamDestroy(m->side);
-	if (m->side2) (void)hipStreamDestroy(m->side2);
+	// (the helper streams are process-wide: not destroyed with the model)
 	if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
 	if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
 	if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -474,7 +484,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
 	hipStream_t sw = s;
 	if (overlap) {
-		if (!m->side) { if (create_helper_stream(&m->side, false)) return 1; }
+		if (!m->side) { if (create_helper_stream(&g_side_stream, false)) return 1; m->side = g_side_stream; }
 		if (!m->ev_fork) { HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(m->ev_fork, s)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
 		sw = m->side;
@@ -483,7 +493,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 		da.gm = m->gm_dev; da.in = in; da.in_stride = in_stride; da.n = n; da.denc_lv = (const uint2*)m->denc_lv; da.denc_cap = m->bin_n;
 		da.merge_runs = !(g_debug_flags & DBG_T1_NO_MERGE); da.grid_grad_ = m->grads + m->n_mlp;
 		if (overlap) {
-			if (!m->side2) { if (create_helper_stream(&m->side2, false)) return 1; }
+			if (!m->side2) { if (create_helper_stream(&g_side2_stream, false)) return 1; m->side2 = g_side2_stream; }
 			if (!m->ev_join2) HIPCHK(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming));
 			HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork, 0));
 			launch_grad_dense(m->side2, da);
@@ -1225,7 +1235,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	c.measured_batch_size_before_compaction = max_samples;
 	HIPCHK(hipMemcpy(t->counters, &c, sizeof(c), hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(t->sync2, 0, 16));
-	if (!lazy_streams() && create_helper_stream(&t->k1_stream, true)) { delete t; return 1; } // the pre-launched K1's stream (see create_helper_stream)
+	if (!lazy_streams()) { if (ensure_helper_streams()) { delete t; return 1; } t->k1_stream = g_k1_stream; } // the pre-launched K1's stream (see create_helper_stream)
 	*out = t;
 	return 0;
 }
@@ -1248,7 +1258,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
 	if (t->comm) (void)ngp_comm_destroy(t);
-	if (t->k1_stream) (void)hipStreamDestroy(t->k1_stream);
+	if (t->k1_prelaunched && t->k1_stream) (void)hipStreamSynchronize(t->k1_stream); // (process-wide stream: not destroyed with the trainer)
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
@@ -1445,7 +1455,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	}
 	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t);
 	if (prelaunch) {
-		if (!t->k1_stream) { if (create_helper_stream(&t->k1_stream, true)) return 1; } // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
+		if (!t->k1_stream) { if (create_helper_stream(&g_k1_stream, true)) return 1; t->k1_stream = g_k1_stream; } // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
 		if (!t->ev_ctl) { HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(t->ev_ctl, s));
 	}

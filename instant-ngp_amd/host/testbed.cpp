@@ -156,6 +156,7 @@ static bool natural_less(const std::string& a, const std::string& b) {
 // ------------------------------------------------------------------------------------------------
 Testbed::Testbed() {
 	root_dir = s_default_root_dir.empty() ? fs::current_path().string() : s_default_root_dir;
+	if (ngp_device_available()) (void)ngp_init(); // helper streams before any communicator the host may create later (include/ngp_hip.h)
 }
 Testbed::~Testbed() {
 	destroy_trainer();
