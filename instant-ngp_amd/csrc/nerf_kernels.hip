@@ -38,6 +38,30 @@ static __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------
+// The training pixel of global ray i (testbed_nerf.cu:726-730 in K1 = :955-961 in K3): image, uv and the density the pair was drawn with
+// (1 without CDFs); leaves rng behind the two uv draws.
+static __device__ __forceinline__ f2 training_pixel(const ErrorCdf& cdf, Rng& rng, uint32_t i, uint32_t n_rays, uint32_t n_images, const ngp_image_meta* __restrict__ metadata,
+		int snap, uint32_t& img, float& pdf) {
+	float img_pdf = 1.0f, uv_pdf = 1.0f;
+	img = cdf.img ? image_idx_cdf(i, n_images, cdf.img, &img_pdf) : image_idx(i, n_rays, n_images);
+	const f2 uv = cdf.x_cond_y ? random_image_pos_training_cdf(rng, metadata[img].resolution, snap != 0, cdf.x_cond_y, cdf.y, cdf.res, img, &uv_pdf)
+	                           : random_image_pos_training(rng, metadata[img].resolution, snap != 0);
+	pdf = img_pdf * uv_pdf;
+	return uv;
+}
+// testbed_nerf.cu:1042-1071 (no sharpness data): the ray's mean loss goes into the four cells around its pixel
+static __device__ __forceinline__ void deposit_error(float* __restrict__ error_map, const int32_t emres[2], const int32_t resolution[2], uint32_t img, f2 uv, float mean_loss) {
+	const float px = fminf(fmaxf(uv.x * (float)emres[0] - 0.5f, 0.0f), (float)emres[0] - (1.0f + 1e-4f));
+	const float py = fminf(fmaxf(uv.y * (float)emres[1] - 0.5f, 0.0f), (float)emres[1] - (1.0f + 1e-4f));
+	const int ix = (int)px, iy = (int)py;
+	const float wx = px - (float)ix, wy = py - (float)iy;
+	const int x = clampi(ix, 0, resolution[0] - 2), y = clampi(iy, 0, resolution[1] - 2); // (the reference clamps against the IMAGE resolution, :1047)
+	float* e = error_map + (size_t)img * emres[0] * emres[1];
+	atomicAdd(&e[y * emres[0] + x], (1 - wx) * (1 - wy) * mean_loss);
+	atomicAdd(&e[y * emres[0] + x + 1], wx * (1 - wy) * mean_loss);
+	atomicAdd(&e[(y + 1) * emres[0] + x], (1 - wx) * wy * mean_loss);
+	atomicAdd(&e[(y + 1) * emres[0] + x + 1], wx * wy * mean_loss);
+}
 __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
@@ -53,11 +77,11 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 	f3 ro = mk3(0.f), rd = mk3(0.f), rdn = mk3(0.f, 0.f, 1.f), idir = mk3(1.f);
 	float startt = 0.f, cone_angle = a.cone_angle_constant;
 	if (valid) {
-		uint32_t img = image_idx(i, n_rays, a.n_images);
-		const ngp_image_meta& m = a.metadata[img];
 		Rng rng(a.rng);
 		rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
-		f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+		uint32_t img; float pix_pdf;
+		f2 uv = training_pixel(a.cdf, rng, i, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
+		const ngp_image_meta& m = a.metadata[img];
 		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) valid = false;
 		if (valid) {
 			const float motionblur_time = rng.next_float();
@@ -164,11 +188,11 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	// (img = i * n_img / R): the reference drops whichever rays reserve their spans last (atomic order), i.e. a random subset, and the
 	// index-ordered variant cost 0.2 - 0.35 dB of held-out PSNR at 5k - 20k steps (profiles/r02_bench_ab_psnr_before_scramble.json).
 	const uint32_t i = ray_begin + k1_slot_to_ray(li, ray_end - ray_begin);
-	uint32_t img = image_idx(i, n_rays, a.n_images);
-	const ngp_image_meta& m = a.metadata[img];
 	Rng rng(a.rng);
 	rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
-	f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
+	uint32_t img; float pix_pdf;
+	f2 uv = training_pixel(a.cdf, rng, i, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
+	const ngp_image_meta& m = a.metadata[img];
 	const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
 	const bool masked = tex.x < 0.0f; // masked-away pixel: the ray is not marched
 	RaySetup& out = rs[li];
@@ -573,6 +597,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), loss_bg = mk3(0.f);
 	f3 rgbtarget = mk3(0.f), background_color = ld3(a.background_color);
 	float depth_ray = 0.f, target_depth = -1.f;
+	uint32_t pix_img = 0; float pix_pdf = 1.0f; f2 pix_uv = {0.f, 0.f};
 	if (active) {
 		numsteps = a.numsteps_inout[i * 2 + 0];
 		base = a.numsteps_inout[i * 2 + 1];
@@ -582,9 +607,10 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		const uint32_t ray_idx = a.ray_indices_in[i];
 		Rng rng(a.rng);
 		rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
-		const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+		uint32_t img;
+		const f2 uv = training_pixel(a.cdf, rng, ray_idx, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
+		pix_img = img; pix_uv = uv;
 		const ngp_image_meta& m = a.metadata[img];
-		const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
 		rng.advance(1); // motionblur_time
 		if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 		background_color = srgb_to_linear3(background_color);
@@ -637,8 +663,10 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
 		f3 lloss, lgrad;
 		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
+		if (a.cdf.x_cond_y || a.cdf.img) lloss = lloss / pix_pdf; // testbed_nerf.cu:1024 (the gradient is deliberately NOT divided, :1031-1035)
 		const float mean_loss = (lloss.x + lloss.y + lloss.z) / 3.0f;
 		my_loss = mean_loss / (float)n_rays;
+		if (a.error_map) deposit_error(a.error_map, a.error_map_res, a.metadata[pix_img].resolution, pix_img, pix_uv, mean_loss);
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
 		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
@@ -746,7 +774,8 @@ static __device__ __forceinline__ float half_incl_scan(float x) {
 // RPW = rays per wavefront.  1: one wavefront per ray (64 samples per pass iteration).  2 (production): the two 32-lane halves of a wavefront work on two rays --
 // a trained scene keeps ~10 samples per ray, so a 64-lane wavefront per ray wastes 5/6 of every instruction (the kernel is VALU-issue bound);
 // the per-ray values move from scalar to per-lane registers, the scans become segmented, and both halves iterate until the longer ray is done.
-template <int RPW>
+// ERR: error-proportional pixel sampling / error-map accumulation compiled in (off in the production instance: the extra live values cost it 16 bytes of scratch).
+template <int RPW, bool ERR>
 __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	constexpr uint32_t LPR = 64u / RPW, RPB = K3_RAYS_PER_BLOCK * RPW; // lanes per ray, rays per workgroup (16 wavefronts)
 	__shared__ uint32_t s_cnt[RPB];
@@ -800,9 +829,9 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			// dependent memory latencies overlap the sample loads instead of following them (uniform across the ray's lanes).
 			Rng rng(a.rng);
 			rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
-			const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+			uint32_t img; float pdf_unused;
+			const f2 uv = training_pixel(ERR ? a.cdf : ErrorCdf{}, rng, ray_idx, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pdf_unused);
 			const ngp_image_meta& m = a.metadata[img];
-			const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
 			rng.advance(1); // motionblur_time
 			if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 			tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
@@ -895,6 +924,17 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
 		f3 lloss = mk3(0.f), lgrad = mk3(0.f);
 		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
+		if (ERR && (a.error_map || a.cdf.x_cond_y || a.cdf.img) && compacted > 0) {
+			// error-proportional sampling (off by default): the ray's pixel is re-derived from its index, as the reference's K3 does (testbed_nerf.cu:955-961),
+			// the loss is divided by the density it was drawn with (:1024) and splatted into the error map (:1042-1071)
+			Rng rng(a.rng);
+			const uint32_t ray_idx = a.ray_indices_in[i];
+			rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
+			uint32_t img; float pdf;
+			const f2 uv = training_pixel(a.cdf, rng, ray_idx, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pdf);
+			if (a.cdf.x_cond_y || a.cdf.img) lloss = lloss / pdf;
+			if (a.error_map && sl == 0) deposit_error(a.error_map, a.error_map_res, a.metadata[img].resolution, img, uv, (lloss.x + lloss.y + lloss.z) / 3.0f);
+		}
 		if (compacted > 0) my_loss = ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
@@ -1025,9 +1065,9 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 				const uint32_t ray_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.ray_indices_in[i]);
 				Rng rng(a.rng);
 				rng.advance((uint64_t)(ray_idx * N_RANDOM_PER_RAY));
-				const uint32_t img = image_idx(ray_idx, n_rays, a.n_images);
+				uint32_t img; float pdf_unused;
+				const f2 uv = training_pixel(a.cdf, rng, ray_idx, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pdf_unused);
 				const ngp_image_meta& m = a.metadata[img];
-				const f2 uv = random_image_pos_training(rng, m.resolution, a.snap_to_pixel_centers);
 				rng.advance(1); // motionblur_time
 				if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 				const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
@@ -1461,12 +1501,55 @@ void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_
 		hipLaunchKernelGGL(k_dilate_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, coarse, coarse + (size_t)COARSE_WORDS * n_cascades, n_cascades);
 	}
 }
+// ---- CDFs of the accumulated error (testbed_nerf.cu:1530-1580, 2795-2847) ----
+// construct_cdf_2d: one thread per (row, image): running sum along x (+1e-10 per cell), the row total goes to cdf_y, the row is normalised and mixed with 1 % uniform
+__global__ void __launch_bounds__(128) k_construct_cdf_2d(uint32_t n_images, uint32_t height, uint32_t width, const float* __restrict__ data, float* __restrict__ cdf_x_cond_y, float* __restrict__ cdf_y) {
+	const uint32_t y = threadIdx.x + blockIdx.x * blockDim.x, img = blockIdx.y;
+	if (y >= height || img >= n_images) return;
+	const size_t offset_xy = ((size_t)img * height + y) * width;
+	data += offset_xy; cdf_x_cond_y += offset_xy;
+	const float MIN_PDF = 0.01f;
+	float cum = 0;
+	for (uint32_t x = 0; x < width; ++x) { cum += data[x] + 1e-10f; cdf_x_cond_y[x] = cum; }
+	cdf_y[img * height + y] = cum;
+	const float norm = 1.0f / cum; // __frcp_rn: correctly rounded, like this division
+	for (uint32_t x = 0; x < width; ++x) cdf_x_cond_y[x] = (1.0f - MIN_PDF) * cdf_x_cond_y[x] * norm + MIN_PDF * (float)(x + 1) / (float)width;
+}
+// construct_cdf_1d: one thread per image over its rows; the image total goes to cdf_img
+__global__ void __launch_bounds__(64) k_construct_cdf_1d(uint32_t n_images, uint32_t height, float* __restrict__ cdf_y, float* __restrict__ cdf_img) {
+	const uint32_t img = threadIdx.x + blockIdx.x * blockDim.x;
+	if (img >= n_images) return;
+	cdf_y += (size_t)img * height;
+	const float MIN_PDF = 0.01f;
+	float cum = 0;
+	for (uint32_t y = 0; y < height; ++y) { cum += cdf_y[y]; cdf_y[y] = cum; }
+	cdf_img[img] = cum;
+	const float norm = 1.0f / cum;
+	for (uint32_t y = 0; y < height; ++y) cdf_y[y] = (1.0f - MIN_PDF) * cdf_y[y] * norm + MIN_PDF * (float)(y + 1) / (float)height;
+}
+// testbed_nerf.cu:2832-2847 (a host loop in the reference: "single-threaded anyway"): same order of additions, one lane, no round trip to the host
+__global__ void k_construct_cdf_img(uint32_t n_images, float* __restrict__ cdf_img) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	const float MIN_PMF = 0.1f;
+	float cum = 0;
+	for (uint32_t i = 0; i < n_images; ++i) { cum += cdf_img[i]; cdf_img[i] = cum; }
+	const float norm = 1.0f / cum;
+	for (uint32_t i = 0; i < n_images; ++i) cdf_img[i] = (1.0f - MIN_PMF) * cdf_img[i] * norm + MIN_PMF * (float)(i + 1) / (float)n_images;
+}
+void launch_construct_error_cdfs(hipStream_t s, uint32_t n_images, uint32_t width, uint32_t height, const float* error_map, float* cdf_x_cond_y, float* cdf_y, float* cdf_img) {
+	hipLaunchKernelGGL(k_construct_cdf_2d, dim3(blocks(height, 128), n_images), dim3(128), 0, s, n_images, height, width, error_map, cdf_x_cond_y, cdf_y);
+	hipLaunchKernelGGL(k_construct_cdf_1d, dim3(blocks(n_images, 64)), dim3(64), 0, s, n_images, height, cdf_y, cdf_img);
+	hipLaunchKernelGGL(k_construct_cdf_img, dim3(1), dim3(64), 0, s, n_images, cdf_img);
+}
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	if (max_rays == 0) return;
 	if (g_debug_flags & DBG_K3_THREAD_PER_RAY) hipLaunchKernelGGL(k_compute_loss, dim3(blocks(max_rays, 128)), dim3(128), 0, s, a);
 	else if (!a.k3_scratch || !(g_debug_flags & DBG_K3_TWO_PASS)) {
-		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) hipLaunchKernelGGL(k_compute_loss_v2<1>, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), dim3(1024), 0, s, a);
-		else hipLaunchKernelGGL(k_compute_loss_v2<2>, dim3(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK * 2), 256u * 2u)), dim3(1024), 0, s, a);
+		const bool err = a.error_map || a.cdf.x_cond_y || a.cdf.img;
+		const dim3 g1(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), g2(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK * 2), 256u * 2u));
+		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) { if (err) hipLaunchKernelGGL((k_compute_loss_v2<1, true>), g1, dim3(1024), 0, s, a); else hipLaunchKernelGGL((k_compute_loss_v2<1, false>), g1, dim3(1024), 0, s, a); }
+		else if (err) hipLaunchKernelGGL((k_compute_loss_v2<2, true>), g2, dim3(1024), 0, s, a);
+		else hipLaunchKernelGGL((k_compute_loss_v2<2, false>), g2, dim3(1024), 0, s, a);
 	}
 	else {
 		const uint32_t grid = k1_grid(max_rays);

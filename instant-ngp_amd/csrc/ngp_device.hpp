@@ -576,6 +576,55 @@ NGP_HD f2 random_image_pos_training(Rng& rng, const int32_t res[2], bool snap) {
 	return uv;
 }
 
+// ---- training pixels drawn in proportion to the accumulated error (nerf_device.cuh:497-599; the CDFs: testbed_nerf.cu:1530-1580, 2795-2855) ----
+// binary_search, common.h:207-230: first element >= val, clamped to the last one
+NGP_HD uint32_t cdf_lower_bound(float val, const float* data, uint32_t length) {
+	if (length == 0) return 0;
+	uint32_t first = 0, count = length;
+	while (count > 0) {
+		const uint32_t step = count / 2, it = first + step;
+		if (data[it] < val) { first = it + 1; count -= step + 1; } else count = step;
+	}
+	return first < length - 1 ? first : length - 1;
+}
+// sample_cdf_2d, nerf_device.cuh:499-528: half of the draws stay uniform (UNIFORM_SAMPLING_FRACTION; *pdf is left untouched for them, as in the reference)
+NGP_HD f2 sample_cdf_2d(f2 sample, uint32_t img, const int32_t res[2], const float* cdf_x_cond_y, const float* cdf_y, float* pdf) {
+	const float UNIFORM_SAMPLING_FRACTION = 0.5f;
+	if (sample.x < UNIFORM_SAMPLING_FRACTION) { sample.x /= UNIFORM_SAMPLING_FRACTION; return sample; }
+	sample.x = (sample.x - UNIFORM_SAMPLING_FRACTION) / (1.0f - UNIFORM_SAMPLING_FRACTION);
+	cdf_y += (size_t)img * res[1];
+	const uint32_t y = cdf_lower_bound(sample.y, cdf_y, (uint32_t)res[1]);
+	float prev = y > 0 ? cdf_y[y - 1] : 0.0f;
+	const float pmf_y = cdf_y[y] - prev;
+	sample.y = (sample.y - prev) / pmf_y;
+	cdf_x_cond_y += (size_t)img * res[1] * res[0] + (size_t)y * res[0];
+	const uint32_t x = cdf_lower_bound(sample.x, cdf_x_cond_y, (uint32_t)res[0]);
+	prev = x > 0 ? cdf_x_cond_y[x - 1] : 0.0f;
+	const float pmf_x = cdf_x_cond_y[x] - prev;
+	sample.x = (sample.x - prev) / pmf_x;
+	if (pdf) *pdf = pmf_x * pmf_y * (float)(res[0] * res[1]);
+	f2 r; r.x = ((float)x + sample.x) / (float)res[0]; r.y = ((float)y + sample.y) / (float)res[1];
+	return r;
+}
+// image_idx with an image CDF, nerf_device.cuh:578-591: one Owen-scrambled Sobol draw per ray index
+NGP_HD uint32_t image_idx_cdf(uint32_t base_idx, uint32_t n_images, const float* cdf, float* pdf) {
+	const float sample = ld_random_val(base_idx, 0xdeadbeefu);
+	const uint32_t img = cdf_lower_bound(sample, cdf, n_images);
+	if (pdf) { const float prev = img > 0 ? cdf[img - 1] : 0.0f; *pdf = (cdf[img] - prev) * (float)n_images; }
+	return img;
+}
+// nerf_random_image_pos_training with the pixel CDFs, nerf_device.cuh:553-576
+NGP_HD f2 random_image_pos_training_cdf(Rng& rng, const int32_t res[2], bool snap, const float* cdf_x_cond_y, const float* cdf_y, const int32_t cdf_res[2], uint32_t img, float* pdf) {
+	f2 uv; uv.x = rng.next_float(); uv.y = rng.next_float();
+	if (cdf_x_cond_y) uv = sample_cdf_2d(uv, img, cdf_res, cdf_x_cond_y, cdf_y, pdf);
+	else if (pdf) *pdf = 1.0f;
+	if (snap) {
+		uv.x = ((float)clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1) + 0.5f) / (float)res[0];
+		uv.y = ((float)clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1) + 0.5f) / (float)res[1];
+	}
+	return uv;
+}
+
 // losses: gradient/loss per channel
 NGP_HD void loss_and_gradient(f3 target, f3 pred, int type, f3& loss, f3& grad) {
 	const float t[3] = {target.x, target.y, target.z}, p[3] = {pred.x, pred.y, pred.z};

@@ -47,6 +47,8 @@ struct TrainCounters {
 	uint32_t k4_ticket;                             // K4's workgroup ticket (the last one runs the controller); zero between launches
 };
 
+// error-proportional sampling of the training pixels (testbed.h:756 error_map; nerf_device.cuh:497-599): all null = the uniform stream
+struct ErrorCdf { const float* x_cond_y = nullptr; const float* y = nullptr; const float* img = nullptr; int32_t res[2] = {0, 0}; };
 struct K1Args {
 	uint32_t n_rays; const uint32_t* n_rays_ptr;
 	uint32_t rank, world_size;
@@ -68,6 +70,7 @@ struct K1Args {
 	// setup kernel so that K3's wavefronts do not all repeat it (same arithmetic as compute_loss_kernel_train_nerf)
 	float* ray_targets_out; float background_color[3]; int color_space_srgb, random_bg_color, linear_colors;
 	float depth_lambda = 0.f; // > 0: the ray's target depth (testbed_nerf.cu:1027) goes into slot 6 of its target record
+	ErrorCdf cdf;             // testbed_nerf.cu:3152-3155: x_cond_y / y set = sample_focal_plane_proportional_to_error, img set = sample_image_proportional_to_error
 };
 
 struct K3Args {
@@ -88,6 +91,8 @@ struct K3Args {
 	const float* ray_targets; // optional: K1Args::ray_targets_out (8 floats per active ray)
 	int train_mode;           // ETrainMode: 0 Nerf, 1 Rfl, 2 RflRelax (fused_kernels/train_nerf.cuh:391-410)
 	float depth_lambda = 0.f; int depth_loss_type = NGP_LOSS_L1; // depth supervision (testbed_nerf.cu:1027-1029, 1126-1129); ray_targets slot 6 = target depth (<= 0: none)
+	ErrorCdf cdf;             // must equal K1's: the ray's pixel is re-derived from its index (testbed_nerf.cu:955-961); the loss is divided by the pixel's density (:1024)
+	float* error_map = nullptr; int32_t error_map_res[2] = {0, 0}; // testbed_nerf.cu:1042-1071: every ray's mean loss, splatted bilinearly into its image's error map (float atomics)
 	void* k3_scratch = nullptr; // k3_scratch_bytes(max_rays), initialised by k3_scratch_init: needed by the two-pass kernel (DBG_K3_TWO_PASS)
 };
 size_t k3_scratch_bytes(uint32_t max_rays);
@@ -102,6 +107,8 @@ int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_ray
 void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch);
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse = nullptr);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
+// testbed_nerf.cu:2795-2847: error map (n_images x height x width) -> cdf_x_cond_y (same shape), cdf_y (n_images x height), cdf_img (n_images)
+void launch_construct_error_cdfs(hipStream_t s, uint32_t n_images, uint32_t width, uint32_t height, const float* error_map, float* cdf_x_cond_y, float* cdf_y, float* cdf_img);
 void launch_fill_rollover(hipStream_t s, uint32_t n_elements, const uint32_t* n_input_ptr, float* coords, uint32_t cstride, ngp_half* dloss, uint32_t dstride,
 	const uint32_t* publish_src2 = nullptr, uint32_t* publish_dst2 = nullptr, TrainCounters* ctl = nullptr /* run the batch-size controller behind the fill */, uint32_t ctl_world_size = 1,
 	const float* publish_loss = nullptr /* this rank's loss sum -> publish_dst2[2], unsigned fixed point in units of 2^-24 */);
