@@ -118,6 +118,12 @@ typedef struct ngp_nerf_options {
 	/* depth supervision (testbed.h:796, 824; testbed_nerf.cu:1027-1029, 1126-1129): weight of the depth term (0 = off) and its loss (default L1) */
 	float depth_supervision_lambda;
 	int32_t depth_loss_type;
+	/* training pixels drawn in proportion to the accumulated error (testbed.h:810-811; python_api.cu:795-796; nerf_device.cuh:497-599). The reference
+	 * ALWAYS accumulates the error map (testbed_nerf.cu:2793 `accumulate_error = true`, for its GUI); here the map is accumulated while one of the two
+	 * switches is on, or always with accumulate_error_map = 1, so that the default step does not pay for atomics nothing reads. */
+	int32_t sample_focal_plane_proportional_to_error;
+	int32_t sample_image_proportional_to_error;
+	int32_t accumulate_error_map;
 } ngp_nerf_options;
 
 /* Counters read back by the host (NerfCounters, testbed.h / testbed_nerf.cu:2669-2702). */
@@ -321,7 +327,9 @@ int ngp_k_compute_loss(
 	ngp_half* dloss_doutput, uint32_t dloss_stride, int loss_type, float* loss_output,
 	int rgb_activation, int density_activation, int snap_to_pixel_centers,
 	const float* mean_density_ptr, float near_distance);
-
+/* construct_cdf_2d + construct_cdf_1d + the image CDF (testbed_nerf.cu:1530-1580, 2795-2847): error map (n_images x height x width, device) ->
+ * cdf_x_cond_y (same shape), cdf_y (n_images x height), cdf_img (n_images). */
+int ngp_k_construct_error_cdfs(void* stream, uint32_t n_images, uint32_t width, uint32_t height, const float* error_map, float* cdf_x_cond_y, float* cdf_y, float* cdf_img);
 /* fill_rollover_and_rescale<T> / fill_rollover<float>, launches testbed_nerf.cu:3298-3306. */
 int ngp_k_fill_rollover(void* stream, uint32_t n_elements, const uint32_t* n_input_ptr,
                         float* coords_inout, uint32_t coord_stride, ngp_half* dloss_inout, uint32_t dloss_stride);
@@ -391,6 +399,14 @@ int ngp_allreduce_counters(ngp_nerf*, void* stream);
 /* Three uint32 {measured_before_compaction, measured, this rank's loss sum in units of 2^-24} to all-reduce(sum) across ranks (8e):
  * every rank then derives the same next rays_per_batch and reports the loss of the union batch. */
 int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters3);
+/* Error map and its CDFs (Testbed::Nerf::Training::error_map, testbed.h:745-756; built every n_steps_between_error_map_updates steps, x 1.5 per cycle,
+ * testbed_nerf.cu:2753-2759, 2791-2855). Device pointers (null before the first cycle), resolutions {x, y}; any out pointer may be null. */
+int ngp_nerf_error_map_ptrs(ngp_nerf*, float** error_map, int32_t error_map_res[2], float** cdf_x_cond_y, float** cdf_y, float** cdf_img, int32_t cdf_res[2],
+	int* cdf_valid, uint32_t* n_steps_between_updates, uint32_t* n_steps_since_update);
+/* n_steps_between_error_map_updates (testbed.h:813): 128 after a reset, multiplied by 1.5 after every CDF update; only between cycles. */
+int ngp_nerf_set_error_map_interval(ngp_nerf*, uint32_t n_steps);
+/* Test / tooling hook: install CDFs computed elsewhere (n_images x res[1] x res[0], n_images x res[1], n_images floats on the host). */
+int ngp_nerf_set_error_cdfs_host(ngp_nerf*, const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t cdf_res[2]);
 /* Blocking read-back (the reference's copy_to_host, testbed_nerf.cu:2681-2682). */
 int ngp_nerf_get_stats(ngp_nerf*, void* stream, ngp_nerf_stats* out_host);
 /* update_density_grid_nerf (testbed_nerf.cu:2476-2592) with explicit sample counts. */
@@ -462,6 +478,8 @@ int ngp_debug_set_flags(uint32_t flags);
 int ngp_debug_set_train_mode(int mode);
 /* depth supervision of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options; testbed_nerf.cu:1027-1029, 1126-1129) */
 int ngp_debug_set_depth_supervision(float depth_supervision_lambda, int depth_loss_type);
+/* Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only: CDFs (device; null = uniform) and the error map K3 splats into (device; null = none). */
+int ngp_debug_set_error_sampling(const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t cdf_res[2], float* error_map, const int32_t error_map_res[2]);
 /* layout of the hashed levels' binned gradient scatter (csrc/model_kernels.hip k_grad_bin / k_grad_accumulate): table entries per
  * chunk = 2^chunk_log2 (11 or 12), one block per chunk (split = 0) or per (chunk, feature pair) (split = 1), list capacity override
  * in records (0 = twice the mean; a small value forces the list-overflow path for the tests); process-wide */

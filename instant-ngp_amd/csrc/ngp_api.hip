@@ -1046,6 +1046,16 @@ extern "C" int ngp_model_deserialize_host(ngp_model* m, const void* buf, uint64_
 // device: they are serialised by one mutex and must be used from one device / one stream at a time (the trainer handles own theirs).
 // ------------------------------------------------------------------------------------------------
 static std::mutex g_hook_mutex;
+// stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only (test hook): CDFs for error-proportional pixel sampling and the error map K3 splats into (device pointers; null = off)
+static ErrorCdf g_hook_cdf; static float* g_hook_error_map = nullptr; static int32_t g_hook_error_map_res[2] = {0, 0};
+extern "C" int ngp_debug_set_error_sampling(const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t cdf_res[2], float* error_map, const int32_t error_map_res[2]) {
+	g_hook_cdf = ErrorCdf();
+	g_hook_cdf.x_cond_y = cdf_x_cond_y; g_hook_cdf.y = cdf_y; g_hook_cdf.img = cdf_img;
+	if (cdf_res) { g_hook_cdf.res[0] = cdf_res[0]; g_hook_cdf.res[1] = cdf_res[1]; }
+	g_hook_error_map = error_map;
+	if (error_map_res) { g_hook_error_map_res[0] = error_map_res[0]; g_hook_error_map_res[1] = error_map_res[1]; }
+	return 0;
+}
 extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, uint32_t rank, uint32_t world_size, const uint32_t* n_rays_ptr, ngp_aabb aabb,
 		uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng, uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out,
 		ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_xform* xforms,
@@ -1059,6 +1069,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
 	a.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
+	a.cdf = g_hook_cdf;
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
@@ -1105,6 +1116,7 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 	a.rays_in = rays_in; a.numsteps_inout = numsteps_inout; a.coords_in = coords_in; a.coords_out = coords_out; a.dloss_doutput = dloss_doutput; a.dloss_stride = dloss_stride;
 	a.loss_type = loss_type; a.loss_output = loss_output; a.rgb_activation = rgb_activation; a.density_activation = density_activation;
 	a.snap_to_pixel_centers = snap_to_pixel_centers; a.mean_density_ptr = mean_density_ptr; a.near_distance = near_distance;
+	a.cdf = g_hook_cdf; a.error_map = g_hook_error_map; a.error_map_res[0] = g_hook_error_map_res[0]; a.error_map_res[1] = g_hook_error_map_res[1];
 	std::lock_guard<std::mutex> hook_lock(g_hook_mutex);
 	{ // scratch of the two-pass kernel (ablation DBG_K3_TWO_PASS); static like the other stand-alone hooks' scratch
 		static char* s_k3 = nullptr; static size_t s_k3_bytes = 0;
@@ -1118,8 +1130,15 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 		}
 		if (k3_scratch_init((hipStream_t)stream, s_k3, n_rays)) return fail("k3 scratch init");
 		a.k3_scratch = s_k3;
+		REQUIRE(!((g_debug_flags & DBG_K3_TWO_PASS) && (a.error_map || a.cdf.x_cond_y || a.cdf.img)), "the two-pass K3 (ablation) has no error map");
 	}
 	launch_compute_loss((hipStream_t)stream, a, n_rays);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_construct_error_cdfs(void* stream, uint32_t n_images, uint32_t width, uint32_t height, const float* error_map, float* cdf_x_cond_y, float* cdf_y, float* cdf_img) {
+	REQUIRE(n_images >= 1 && width >= 1 && height >= 1 && error_map && cdf_x_cond_y && cdf_y && cdf_img, "ngp_k_construct_error_cdfs: bad argument");
+	launch_construct_error_cdfs((hipStream_t)stream, n_images, width, height, error_map, cdf_x_cond_y, cdf_y, cdf_img);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1195,6 +1214,10 @@ struct ngp_nerf {
 	uint32_t* sync2 = nullptr; // {measured_before, measured, loss sum in units of 2^-24} for the cross-rank all-reduce (4 words allocated)
 	// in-library data-parallel step over RCCL (ngp_comm_init): communicator, its stream, bucket-reduced events
 	void* comm = nullptr; hipStream_t comm_stream = nullptr; hipEvent_t ev_red_a = nullptr, ev_red_b = nullptr; bool grads_pending = false;
+	// error-proportional pixel sampling (testbed.h:745-756, 810-815; off unless one of the option switches is set)
+	float* error_map = nullptr; size_t error_map_cap = 0; int32_t error_map_res[2] = {0, 0};
+	float* cdf_x_cond_y = nullptr; float* cdf_y = nullptr; float* cdf_img = nullptr; size_t cdf_xy_cap = 0, cdf_y_cap = 0; int32_t cdf_res[2] = {0, 0}; bool cdf_valid = false;
+	uint32_t n_steps_between_error_map_updates = 128, n_steps_since_error_map_update = 0; bool error_cycle_open = false;
 	// host-side deterministic state (no device read-back needed)
 	Rng rng, density_grid_rng;
 	uint32_t training_step = 0, prep_skip_counter = 0, ema_step = 0;
@@ -1264,6 +1287,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img}) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
 }
@@ -1381,6 +1405,58 @@ static bool next_prep_updates_grid(const ngp_nerf* t) {
 __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t world_size);
 // phase bit 1: K1..K4 (forward, loss, compaction); bit 2: controller, T1 / W / scatter (backward).  `global_counters`: the caller has
 // all-reduced the published counters (multi-rank), so the controller may run before the backward pass.
+// ---- error map and its CDFs (testbed_nerf.cu:2753-2759, 2791-2855) ----
+static bool error_map_wanted(const ngp_nerf* t) { return t->opt.accumulate_error_map || t->opt.sample_focal_plane_proportional_to_error || t->opt.sample_image_proportional_to_error; }
+static ErrorCdf error_cdf_args(const ngp_nerf* t) {
+	ErrorCdf c;
+	if (!t->cdf_valid) return c;
+	if (t->opt.sample_focal_plane_proportional_to_error) { c.x_cond_y = t->cdf_x_cond_y; c.y = t->cdf_y; }
+	if (t->opt.sample_image_proportional_to_error) c.img = t->cdf_img;
+	c.res[0] = t->cdf_res[0]; c.res[1] = t->cdf_res[1];
+	return c;
+}
+template <typename T> static int dev_grow(T** p, size_t* cap, size_t n) {
+	if (n <= *cap) return 0;
+	if (*p) HIPCHK(hipFree(*p));
+	*p = nullptr; *cap = 0;
+	if (dev_alloc(p, n)) return 1;
+	*cap = n;
+	return 0;
+}
+// Start of an accumulation cycle (testbed_nerf.cu:2753-2759): the map's resolution follows the number of rays one image receives until the next CDF
+// update; the reference reads rays_per_batch from its host-side counters, here it lives on the device (one 4-byte read-back per cycle, >= 128 steps).
+static int error_map_begin_cycle(ngp_nerf* t, hipStream_t s, const ngp_image_meta& meta0) {
+	uint32_t rays_per_batch = 0;
+	HIPCHK(hipMemcpyAsync(&rays_per_batch, &t->counters->rays_per_batch, 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	const uint32_t n_samples_per_image = (t->n_steps_between_error_map_updates * rays_per_batch) / t->n_images; // uint32 arithmetic, as in the reference
+	const int r = (int)(std::sqrt(std::sqrt((float)n_samples_per_image)) * 3.5f);
+	t->error_map_res[0] = std::min(r, meta0.resolution[0]); t->error_map_res[1] = std::min(r, meta0.resolution[1]);
+	REQUIRE(t->error_map_res[0] >= 2 && t->error_map_res[1] >= 2, "error map: fewer than 2 x 2 cells (too few rays per image)");
+	const size_t n = (size_t)t->error_map_res[0] * t->error_map_res[1] * t->n_images;
+	if (dev_grow(&t->error_map, &t->error_map_cap, n)) return 1;
+	HIPCHK(hipMemsetAsync(t->error_map, 0, n * 4, s));
+	t->error_cycle_open = true;
+	return 0;
+}
+static int error_map_allreduce(ngp_nerf* t, hipStream_t s, size_t n); // data-parallel: every rank has splatted its own rays only
+// End of a cycle (testbed_nerf.cu:2795-2855): CDFs from the map, update interval x 1.5
+static int error_map_build_cdfs(ngp_nerf* t, hipStream_t s) {
+	if (t->k1_prelaunched && t->k1_stream) HIPCHK(hipStreamSynchronize(t->k1_stream)); // a pre-launched K1 may still be reading the old CDFs; it is discarded below
+	++t->state_version;
+	const int32_t w = t->error_map_res[0], h = t->error_map_res[1];
+	const size_t n = (size_t)w * h * t->n_images;
+	if ((t->opt.world_size > 1 || t->comm) && error_map_allreduce(t, s, n)) return 1; // (a one-rank communicator: the identity, exercised by tests/test_gpu_dist.py)
+	if (dev_grow(&t->cdf_x_cond_y, &t->cdf_xy_cap, n) || dev_grow(&t->cdf_y, &t->cdf_y_cap, (size_t)h * t->n_images)) return 1;
+	if (!t->cdf_img && dev_alloc(&t->cdf_img, t->n_images)) return 1;
+	t->cdf_res[0] = w; t->cdf_res[1] = h;
+	launch_construct_error_cdfs(s, t->n_images, (uint32_t)w, (uint32_t)h, t->error_map, t->cdf_x_cond_y, t->cdf_y, t->cdf_img);
+	t->n_steps_since_error_map_update = 0;
+	t->cdf_valid = true; t->error_cycle_open = false;
+	t->n_steps_between_error_map_updates = (uint32_t)(t->n_steps_between_error_map_updates * 1.5f);
+	return 0;
+}
+
 static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_counters) {
 	REQUIRE(t->n_images > 0, "train: no dataset");
 	hipStream_t s = (hipStream_t)stream;
@@ -1392,7 +1468,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
+		k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
@@ -1400,9 +1476,15 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
 		k1.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
 		k1.depth_lambda = o.depth_supervision_lambda;
+		k1.cdf = error_cdf_args(t);
 		return k1;
 	};
 	if (phase & 1) {
+	if (error_map_wanted(t) && !t->error_cycle_open) {
+		REQUIRE(t->n_steps_since_error_map_update == 0, "error map: cycle state");
+		ngp_image_meta meta0; HIPCHK(hipMemcpy(&meta0, t->meta_dev, sizeof(meta0), hipMemcpyDeviceToHost));
+		if (error_map_begin_cycle(t, s, meta0)) return 1;
+	}
 	bool have_k1 = false;
 	if (t->k1_prelaunched) { // launched by the previous step: valid if nothing it depends on was changed through the API since
 		HIPCHK(hipStreamWaitEvent(s, t->ev_k1, 0));
@@ -1437,6 +1519,9 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	k3.ray_targets = lattice ? t->ray_targets : nullptr; k3.train_mode = o.train_mode; k3.k3_scratch = t->k3_scratch;
 	k3.depth_lambda = o.depth_supervision_lambda; k3.depth_loss_type = o.depth_loss_type;
 	if (k3.depth_lambda > 0.f) k3.k3_scratch = nullptr; // the two-pass ablation kernel has no depth term: the one-pass kernel runs
+	k3.cdf = error_cdf_args(t);
+	if (t->error_cycle_open) { k3.error_map = t->error_map; k3.error_map_res[0] = t->error_map_res[0]; k3.error_map_res[1] = t->error_map_res[1]; }
+	if (k3.error_map || k3.cdf.x_cond_y || k3.cdf.img) k3.k3_scratch = nullptr; // (nor the error map)
 	{ ProfScope ps(P_K3, s); launch_compute_loss(s, k3, t->max_rays); }
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	// single rank, forward and backward in one call: the controller rides on K4's last workgroup (no launch of its own)
@@ -1500,6 +1585,9 @@ extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	}
 	t->ctl_done = false;
 	++t->training_step;
+	if (t->error_cycle_open) { // testbed_nerf.cu:2791-2855
+		if (++t->n_steps_since_error_map_update >= t->n_steps_between_error_map_updates && error_map_build_cdfs(t, s)) return 1;
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1586,6 +1674,47 @@ static int dp_reduce_gradients(ngp_nerf* t, hipStream_t s) {
 	return 0;
 }
 
+static int error_map_allreduce(ngp_nerf* t, hipStream_t s, size_t n) {
+	REQUIRE(t->comm, "error-proportional sampling under data parallelism needs the in-library communicator (ngp_comm_init): the ranks' error maps are summed before the CDFs are built");
+	constexpr int kNcclFloat32 = 7;
+	RCCLCHK(g_rccl.AllReduce(t->error_map, t->error_map, n, kNcclFloat32, kNcclSum, t->comm, s));
+	return 0;
+}
+extern "C" int ngp_nerf_error_map_ptrs(ngp_nerf* t, float** error_map, int32_t error_map_res[2], float** cdf_x_cond_y, float** cdf_y, float** cdf_img, int32_t cdf_res[2],
+		int* cdf_valid, uint32_t* n_steps_between_updates, uint32_t* n_steps_since_update) {
+	REQUIRE(t, "ngp_nerf_error_map_ptrs: null argument");
+	if (error_map) *error_map = t->error_map;
+	if (error_map_res) { error_map_res[0] = t->error_map_res[0]; error_map_res[1] = t->error_map_res[1]; }
+	if (cdf_x_cond_y) *cdf_x_cond_y = t->cdf_x_cond_y;
+	if (cdf_y) *cdf_y = t->cdf_y;
+	if (cdf_img) *cdf_img = t->cdf_img;
+	if (cdf_res) { cdf_res[0] = t->cdf_res[0]; cdf_res[1] = t->cdf_res[1]; }
+	if (cdf_valid) *cdf_valid = t->cdf_valid ? 1 : 0;
+	if (n_steps_between_updates) *n_steps_between_updates = t->n_steps_between_error_map_updates;
+	if (n_steps_since_update) *n_steps_since_update = t->n_steps_since_error_map_update;
+	return 0;
+}
+// Testbed::Nerf::Training::n_steps_between_error_map_updates (testbed.h:813; 128 after a reset, x 1.5 per cycle): applies from the next cycle on
+extern "C" int ngp_nerf_set_error_map_interval(ngp_nerf* t, uint32_t n_steps) {
+	REQUIRE(t && n_steps >= 1, "ngp_nerf_set_error_map_interval: bad argument");
+	REQUIRE(!t->error_cycle_open, "ngp_nerf_set_error_map_interval: an accumulation cycle is open (the map's resolution was derived from the old interval)");
+	t->n_steps_between_error_map_updates = n_steps;
+	return 0;
+}
+// test / tooling hook: install CDFs computed elsewhere (all three, cdf_res[0] x cdf_res[1] cells per image); the option switches decide which of them the step uses
+extern "C" int ngp_nerf_set_error_cdfs_host(ngp_nerf* t, const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t cdf_res[2]) {
+	REQUIRE(t && cdf_x_cond_y && cdf_y && cdf_img && cdf_res && cdf_res[0] >= 1 && cdf_res[1] >= 1 && t->n_images > 0, "ngp_nerf_set_error_cdfs_host: bad argument");
+	invalidate_k1(t);
+	HIPCHK(hipDeviceSynchronize());
+	const size_t n = (size_t)cdf_res[0] * cdf_res[1] * t->n_images;
+	if (dev_grow(&t->cdf_x_cond_y, &t->cdf_xy_cap, n) || dev_grow(&t->cdf_y, &t->cdf_y_cap, (size_t)cdf_res[1] * t->n_images)) return 1;
+	if (!t->cdf_img && dev_alloc(&t->cdf_img, t->n_images)) return 1;
+	HIPCHK(hipMemcpy(t->cdf_x_cond_y, cdf_x_cond_y, n * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->cdf_y, cdf_y, (size_t)cdf_res[1] * t->n_images * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->cdf_img, cdf_img, (size_t)t->n_images * 4, hipMemcpyHostToDevice));
+	t->cdf_res[0] = cdf_res[0]; t->cdf_res[1] = cdf_res[1]; t->cdf_valid = true;
+	return 0;
+}
 extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 	for (uint32_t i = 0; i < n_steps; ++i) {
 		if (ngp_nerf_train_prep(t, stream)) return 1;

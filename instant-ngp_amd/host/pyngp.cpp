@@ -95,6 +95,9 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers).def_readwrite("density_grid_decay", &NerfTraining::density_grid_decay)
 		.def_readwrite("depth_supervision_lambda", &NerfTraining::depth_supervision_lambda)
 		.def_property("depth_loss_type", [](const NerfTraining& t) { return (ELossType)t.depth_loss_type; }, [](NerfTraining& t, ELossType v) { t.depth_loss_type = (int)v; })
+		.def_readwrite("sample_focal_plane_proportional_to_error", &NerfTraining::sample_focal_plane_proportional_to_error) // python_api.cu:795
+		.def_readwrite("sample_image_proportional_to_error", &NerfTraining::sample_image_proportional_to_error)             // python_api.cu:796
+		.def_readwrite("accumulate_error_map", &NerfTraining::accumulate_error_map)
 		.def_readonly("dataset", &NerfTraining::dataset);
 	py::class_<Nerf>(testbed, "Nerf")
 		.def_readwrite("sharpen", &Nerf::sharpen).def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)

@@ -235,6 +235,8 @@ ngp_nerf_options Testbed::current_options() const {
 	// Rfl / RflRelax: the reference needs its JIT-fused kernel for these (testbed_nerf.cu:3091-3094); here K3 evaluates their gradients
 	o.train_mode = nerf.training.train_mode == ETrainMode::Rfl ? 1 : nerf.training.train_mode == ETrainMode::RflRelax ? 2 : 0;
 	o.depth_supervision_lambda = nerf.training.depth_supervision_lambda; o.depth_loss_type = nerf.training.depth_loss_type;
+	o.sample_focal_plane_proportional_to_error = nerf.training.sample_focal_plane_proportional_to_error; o.sample_image_proportional_to_error = nerf.training.sample_image_proportional_to_error;
+	o.accumulate_error_map = nerf.training.accumulate_error_map;
 	return o;
 }
 

@@ -56,6 +56,9 @@ struct NerfTraining {
 	float density_grid_decay = 0.95f;                // testbed.h:818
 	float depth_supervision_lambda = 0.f;            // testbed.h:824
 	int depth_loss_type = NGP_LOSS_L1;               // testbed.h:796 (ELossType)
+	bool sample_focal_plane_proportional_to_error = false; // testbed.h:810
+	bool sample_image_proportional_to_error = false;       // testbed.h:811
+	bool accumulate_error_map = false;                     // (the reference always accumulates, testbed_nerf.cu:2793; here: while one of the two switches is on, or when this is set)
 	NerfDataset dataset;
 };
 

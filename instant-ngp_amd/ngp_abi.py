@@ -107,7 +107,8 @@ class NerfOptions(C.Structure):
                 ("background_color", f32 * 3), ("near_distance", f32), ("density_grid_decay", f32),
                 ("cone_angle_constant", f32), ("max_cascade", u32), ("target_batch_size", u32), ("loss_scale", f32),
                 ("seed", u64), ("rank", u32), ("world_size", u32), ("train_mode", i32),
-                ("depth_supervision_lambda", f32), ("depth_loss_type", i32)]
+                ("depth_supervision_lambda", f32), ("depth_loss_type", i32),
+                ("sample_focal_plane_proportional_to_error", i32), ("sample_image_proportional_to_error", i32), ("accumulate_error_map", i32)]
 
 
 class NerfStats(C.Structure):

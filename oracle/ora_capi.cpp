@@ -94,11 +94,18 @@ API void ora_model_eval_debug(void* mm, const float* coord, int use_inf, uint16_
 }
 
 // ---- stand-alone kernels (same argument meaning as ngp_k_* in include/ngp_hip.h) ----------------
+static ErrorCdf g_hook_cdf; static float* g_hook_error_map = nullptr; static int32_t g_hook_error_map_res[2] = {0, 0}; // error-proportional sampling of the stand-alone K1 / K3
+API void ora_set_error_sampling(const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t* cdf_res, float* error_map, const int32_t* error_map_res) {
+	g_hook_cdf = ErrorCdf(); g_hook_cdf.x_cond_y = cdf_x_cond_y; g_hook_cdf.y = cdf_y; g_hook_cdf.img = cdf_img;
+	if (cdf_res) { g_hook_cdf.res[0] = cdf_res[0]; g_hook_cdf.res[1] = cdf_res[1]; }
+	g_hook_error_map = error_map;
+	if (error_map_res) { g_hook_error_map_res[0] = error_map_res[0]; g_hook_error_map_res[1] = error_map_res[1]; }
+}
 API void ora_k_generate_training_samples(uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, ngp_aabb aabb, uint32_t max_samples, ngp_pcg32 rng,
 		uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out,
 		uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip, int snap, float cone_angle_constant) {
 	K1Out k = generate_training_samples(n_rays, ray_begin, ray_end, Aabb(aabb), max_samples, Pcg32(rng), ray_indices_out, rays_out, numsteps_out, coords_out,
-		n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant);
+		n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant, &g_hook_cdf);
 	*ray_counter = k.ray_counter; *numsteps_counter = k.numsteps_counter;
 }
 // CPU model of the production (sample-parallel) marcher, see ora_nerf.hpp lattice_march_counts; mode 0 = independent test, 1 = exact-skip walk
@@ -123,7 +130,7 @@ API void ora_k_compute_loss(uint32_t n_rays, uint32_t rays_counter, ngp_aabb aab
 	o.linear_colors = linear_colors; o.snap = snap; o.loss_type = loss_type; o.rgb_act = rgb_act; o.density_act = density_act; o.near_distance = near_distance;
 	o.train_mode = g_k3_train_mode; o.depth_lambda = g_k3_depth_lambda; o.depth_loss_type = g_k3_depth_loss_type;
 	*numsteps_counter_compacted = compute_loss(n_rays, rays_counter, Aabb(aabb), Pcg32(rng), max_samples_compacted, o, n_images, meta, network_output, out_stride,
-		ray_indices_in, rays_in, numsteps_inout, coords_in, coords_out, dloss, dl_stride, loss_output, mean_density);
+		ray_indices_in, rays_in, numsteps_inout, coords_in, coords_out, dloss, dl_stride, loss_output, mean_density, &g_hook_cdf, g_hook_error_map, g_hook_error_map_res);
 }
 API void ora_k_fill_rollover(uint32_t n_elements, uint32_t n_input, float* coords, uint32_t coord_stride, uint16_t* dloss, uint32_t dl_stride) {
 	fill_rollover_and_rescale_h(n_elements, dl_stride, n_input, dloss);
@@ -163,6 +170,36 @@ API float* ora_nerf_density_grid(void* t) { return ((NerfTrainer*)t)->density_gr
 API uint8_t* ora_nerf_bitfield(void* t) { return ((NerfTrainer*)t)->bitfield.data(); }
 API float ora_nerf_mean_density(void* t) { return ((NerfTrainer*)t)->mean_density; }
 API void ora_nerf_set_mean_density(void* t, float m) { ((NerfTrainer*)t)->mean_density = m; }
+// error map / CDFs of the trainer (pointers into its vectors; resolutions {x, y})
+API void ora_nerf_error_map(void* tt, float** error_map, int32_t* error_map_res, float** cdf_x_cond_y, float** cdf_y, float** cdf_img, int32_t* cdf_res, int* valid, uint32_t* n_between, uint32_t* n_since) {
+	NerfTrainer* t = (NerfTrainer*)tt;
+	if (error_map) *error_map = t->error_map.data();
+	if (error_map_res) { error_map_res[0] = t->error_map_res[0]; error_map_res[1] = t->error_map_res[1]; }
+	if (cdf_x_cond_y) *cdf_x_cond_y = t->cdf_x_cond_y.data();
+	if (cdf_y) *cdf_y = t->cdf_y.data();
+	if (cdf_img) *cdf_img = t->cdf_img.data();
+	if (cdf_res) { cdf_res[0] = t->cdf_res[0]; cdf_res[1] = t->cdf_res[1]; }
+	if (valid) *valid = t->is_cdf_valid;
+	if (n_between) *n_between = t->n_steps_between_error_map_updates;
+	if (n_since) *n_since = t->n_steps_since_error_map_update;
+}
+API void ora_nerf_set_error_cdfs(void* tt, const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t* cdf_res) {
+	NerfTrainer* t = (NerfTrainer*)tt;
+	const size_t n_img = t->meta.size();
+	t->cdf_x_cond_y.assign(cdf_x_cond_y, cdf_x_cond_y + (size_t)cdf_res[0] * cdf_res[1] * n_img);
+	t->cdf_y.assign(cdf_y, cdf_y + (size_t)cdf_res[1] * n_img);
+	t->cdf_img.assign(cdf_img, cdf_img + n_img);
+	t->cdf_res[0] = cdf_res[0]; t->cdf_res[1] = cdf_res[1]; t->is_cdf_valid = true;
+}
+API void ora_nerf_set_error_map_interval(void* tt, uint32_t n) { ((NerfTrainer*)tt)->n_steps_between_error_map_updates = n; }
+API void ora_nerf_set_options(void* tt, const ngp_nerf_options* o) { ((NerfTrainer*)tt)->opt = *o; }
+API void ora_construct_error_cdfs(uint32_t n_images, uint32_t width, uint32_t height, const float* data, float* cdf_x_cond_y, float* cdf_y, float* cdf_img) {
+	construct_error_cdfs(n_images, width, height, data, cdf_x_cond_y, cdf_y, cdf_img);
+}
+API void ora_sample_cdf_2d(const float* sample, uint32_t img, const int32_t* res, const float* cdf_x_cond_y, const float* cdf_y, float* uv_out, float* pdf_inout) {
+	vec2 r = sample_cdf_2d({sample[0], sample[1]}, img, res, cdf_x_cond_y, cdf_y, pdf_inout); uv_out[0] = r.x; uv_out[1] = r.y;
+}
+API uint32_t ora_image_idx_cdf(uint32_t base_idx, uint32_t n_images, const float* cdf, float* pdf) { return image_idx_cdf(base_idx, n_images, cdf, pdf); }
 API void ora_nerf_set_rays_per_batch(void* t, uint32_t r) { ((NerfTrainer*)t)->rays_per_batch = r; }
 API void ora_nerf_get_rng(void* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = ((NerfTrainer*)t)->rng.pod(); *grid_rng = ((NerfTrainer*)t)->density_grid_rng.pod(); }
 API int ora_nerf_render(void* t, const ngp_render_params* rp, float* frame, float* depth) { TRY(((NerfTrainer*)t)->render(*rp, frame, depth)) }

@@ -177,6 +177,82 @@ inline vec2 random_image_pos_training(Pcg32& rng, const int32_t res[2], bool sna
 	return uv;
 }
 
+// ---- training pixels drawn in proportion to the accumulated error ----
+struct ErrorCdf { const float* x_cond_y = nullptr; const float* y = nullptr; const float* img = nullptr; int32_t res[2] = {0, 0}; };
+// binary_search, common.h:207-230
+inline uint32_t binary_search(float val, const float* data, uint32_t length) {
+	if (length == 0) return 0;
+	uint32_t it, count = length, step, first = 0;
+	while (count > 0) {
+		it = first; step = count / 2; it += step;
+		if (data[it] < val) { first = ++it; count -= step + 1; } else count = step;
+	}
+	return std::min(first, length - 1);
+}
+// sample_cdf_2d, nerf_device.cuh:499-528 (UNIFORM_SAMPLING_FRACTION = 0.5: *pdf stays untouched on the uniform branch)
+inline vec2 sample_cdf_2d(vec2 sample, uint32_t img, const int32_t res[2], const float* cdf_x_cond_y, const float* cdf_y, float* pdf) {
+	const float UNIFORM_SAMPLING_FRACTION = 0.5f;
+	if (sample.x < UNIFORM_SAMPLING_FRACTION) { sample.x /= UNIFORM_SAMPLING_FRACTION; return sample; }
+	sample.x = (sample.x - UNIFORM_SAMPLING_FRACTION) / (1.0f - UNIFORM_SAMPLING_FRACTION);
+	cdf_y += (size_t)img * res[1];
+	uint32_t y = binary_search(sample.y, cdf_y, (uint32_t)res[1]);
+	float prev = y > 0 ? cdf_y[y - 1] : 0.0f;
+	float pmf_y = cdf_y[y] - prev;
+	sample.y = (sample.y - prev) / pmf_y;
+	cdf_x_cond_y += (size_t)img * res[1] * res[0] + (size_t)y * res[0];
+	uint32_t x = binary_search(sample.x, cdf_x_cond_y, (uint32_t)res[0]);
+	prev = x > 0 ? cdf_x_cond_y[x - 1] : 0.0f;
+	float pmf_x = cdf_x_cond_y[x] - prev;
+	sample.x = (sample.x - prev) / pmf_x;
+	if (pdf) *pdf = pmf_x * pmf_y * (float)(res[0] * res[1]);
+	return {((float)x + sample.x) / (float)res[0], ((float)y + sample.y) / (float)res[1]};
+}
+// image_idx with a CDF over the images, nerf_device.cuh:578-591
+inline uint32_t image_idx_cdf(uint32_t base_idx, uint32_t n_training_images, const float* cdf, float* pdf) {
+	float sample = ld_random_val(base_idx, 0xdeadbeef);
+	uint32_t img = binary_search(sample, cdf, n_training_images);
+	if (pdf) { float prev = img > 0 ? cdf[img - 1] : 0.0f; *pdf = (cdf[img] - prev) * n_training_images; }
+	return img;
+}
+// the pixel of global ray i as K1 (testbed_nerf.cu:726-730) and K3 (:955-961) derive it; rng is left behind the two uv draws
+inline vec2 training_pixel(const ErrorCdf* cdf, Pcg32& rng, uint32_t i, uint32_t n_rays, uint32_t n_images, const ngp_image_meta* meta, bool snap, uint32_t& img, float& img_pdf, float& uv_pdf) {
+	img_pdf = 1.0f; uv_pdf = 1.0f;
+	img = (cdf && cdf->img) ? image_idx_cdf(i, n_images, cdf->img, &img_pdf) : image_idx(i, n_rays, n_images);
+	const int32_t* res = meta[img].resolution;
+	vec2 uv; uv.x = rng.next_float(); uv.y = rng.next_float();
+	if (cdf && cdf->x_cond_y) uv = sample_cdf_2d(uv, img, cdf->res, cdf->x_cond_y, cdf->y, &uv_pdf);
+	if (snap) {
+		uv.x = ((float)clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1) + 0.5f) / (float)res[0];
+		uv.y = ((float)clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1) + 0.5f) / (float)res[1];
+	}
+	return uv;
+}
+// construct_cdf_2d / construct_cdf_1d / the host loop over the images, testbed_nerf.cu:1530-1580, 2832-2847
+inline void construct_error_cdfs(uint32_t n_images, uint32_t width, uint32_t height, const float* data, float* cdf_x_cond_y, float* cdf_y, float* cdf_img) {
+	const float MIN_PDF = 0.01f;
+	for (uint32_t img = 0; img < n_images; ++img) for (uint32_t y = 0; y < height; ++y) {
+		const size_t off = ((size_t)img * height + y) * width;
+		float cum = 0;
+		for (uint32_t x = 0; x < width; ++x) { cum += data[off + x] + 1e-10f; cdf_x_cond_y[off + x] = cum; }
+		cdf_y[img * height + y] = cum;
+		float norm = 1.0f / cum; // __frcp_rn
+		for (uint32_t x = 0; x < width; ++x) cdf_x_cond_y[off + x] = (1.0f - MIN_PDF) * cdf_x_cond_y[off + x] * norm + MIN_PDF * (float)(x + 1) / (float)width;
+	}
+	for (uint32_t img = 0; img < n_images; ++img) {
+		float* cy = cdf_y + (size_t)img * height;
+		float cum = 0;
+		for (uint32_t y = 0; y < height; ++y) { cum += cy[y]; cy[y] = cum; }
+		cdf_img[img] = cum;
+		float norm = 1.0f / cum;
+		for (uint32_t y = 0; y < height; ++y) cy[y] = (1.0f - MIN_PDF) * cy[y] * norm + MIN_PDF * (float)(y + 1) / (float)height;
+	}
+	float cum = 0;
+	for (uint32_t i = 0; i < n_images; ++i) { cum += cdf_img[i]; cdf_img[i] = cum; }
+	float norm = 1.0f / cum;
+	const float MIN_PMF = 0.1f;
+	for (uint32_t i = 0; i < n_images; ++i) cdf_img[i] = (1.0f - MIN_PMF) * cdf_img[i] * norm + MIN_PMF * (float)(i + 1) / (float)n_images;
+}
+
 // losses, nerf_device.cuh:75-143, 601-616
 struct LossAndGradient { vec3 loss, gradient; };
 inline LossAndGradient loss_and_gradient(vec3 target, vec3 pred, int type) {
@@ -216,14 +292,14 @@ struct K1Out {
 inline K1Out generate_training_samples(uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, const Aabb& aabb, uint32_t max_samples,
 		const Pcg32& rng_in, uint32_t* ray_indices_out, ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out /* 7 floats each */,
 		uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip,
-		bool snap_to_pixel_centers, float cone_angle_constant) {
+		bool snap_to_pixel_centers, float cone_angle_constant, const ErrorCdf* cdf = nullptr) {
 	K1Out k;
 	for (uint32_t i = ray_begin; i < ray_end && i < n_rays; ++i) {
-		uint32_t img = image_idx(i, n_rays, n_images);
-		const ngp_image_meta& m = meta[img];
 		Pcg32 rng = rng_in;
 		rng.advance((int64_t)(i * N_MAX_RANDOM_SAMPLES_PER_RAY));
-		vec2 uv = random_image_pos_training(rng, m.resolution, snap_to_pixel_centers);
+		uint32_t img; float img_pdf, uv_pdf;
+		vec2 uv = training_pixel(cdf, rng, i, n_rays, n_images, meta, snap_to_pixel_centers, img, img_pdf, uv_pdf);
+		const ngp_image_meta& m = meta[img];
 		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) continue; // masked away
 		/* max_level_rand_training = false: max_level = 1, no draw */
 		float motionblur_time = rng.next_float();
@@ -347,7 +423,8 @@ inline float read_depth(vec2 uv, const int32_t res[2], const float* depth) {
 inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb& aabb, const Pcg32& rng_in, uint32_t max_samples_compacted,
 		const K3Opts& o, uint32_t n_images, const ngp_image_meta* meta, const uint16_t* network_output, uint32_t out_stride,
 		const uint32_t* ray_indices_in, const ngp_ray* rays_in, uint32_t* numsteps_inout, const float* coords_in, float* coords_out,
-		uint16_t* dloss_doutput, uint32_t dl_stride, float* loss_output, float mean_density) {
+		uint16_t* dloss_doutput, uint32_t dl_stride, float* loss_output, float mean_density,
+		const ErrorCdf* cdf = nullptr, float* error_map = nullptr, const int32_t* error_map_res = nullptr) {
 	uint32_t counter = 0;
 	for (uint32_t i = 0; i < rays_counter; ++i) {
 		uint32_t numsteps = numsteps_inout[i * 2 + 0];
@@ -358,9 +435,9 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 		uint32_t ray_idx = ray_indices_in[i];
 		Pcg32 rng = rng_in;
 		rng.advance((int64_t)(ray_idx * N_MAX_RANDOM_SAMPLES_PER_RAY));
-		uint32_t img = image_idx(ray_idx, n_rays, n_images);
+		uint32_t img; float img_pdf, uv_pdf;
+		vec2 uv = training_pixel(cdf, rng, ray_idx, n_rays, n_images, meta, o.snap, img, img_pdf, uv_pdf);
 		const ngp_image_meta& m = meta[img];
-		vec2 uv = random_image_pos_training(rng, m.resolution, o.snap);
 		rng.advance(1); // motionblur_time
 		vec3 background_color = o.background_color;
 		if (o.random_bg) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
@@ -413,8 +490,21 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 		uint16_t* dl = dloss_doutput + (size_t)compacted_base * dl_stride;
 
 		LossAndGradient lg = loss_and_gradient(rgbtarget, rgb_ray, o.loss_type);
+		if (cdf && (cdf->x_cond_y || cdf->img)) lg.loss = lg.loss / (img_pdf * uv_pdf); // :1024; the gradient is deliberately not divided (:1031-1035)
 		float mean_loss = mean(lg.loss);
 		if (loss_output) loss_output[i] = mean_loss / (float)n_rays;
+		if (error_map) { // testbed_nerf.cu:1042-1071 (no sharpness data)
+			const float px = std::fmin(std::fmax(uv.x * (float)error_map_res[0] - 0.5f, 0.0f), (float)error_map_res[0] - (1.0f + 1e-4f));
+			const float py = std::fmin(std::fmax(uv.y * (float)error_map_res[1] - 0.5f, 0.0f), (float)error_map_res[1] - (1.0f + 1e-4f));
+			const int ix = (int)px, iy = (int)py;
+			const float wx = px - (float)ix, wy = py - (float)iy;
+			const int x = clampi(ix, 0, m.resolution[0] - 2), y = clampi(iy, 0, m.resolution[1] - 2);
+			float* e = error_map + (size_t)img * error_map_res[0] * error_map_res[1];
+			e[y * error_map_res[0] + x] += (1 - wx) * (1 - wy) * mean_loss;
+			e[y * error_map_res[0] + x + 1] += wx * (1 - wy) * mean_loss;
+			e[(y + 1) * error_map_res[0] + x] += (1 - wx) * wy * mean_loss;
+			e[(y + 1) * error_map_res[0] + x + 1] += wx * wy * mean_loss;
+		}
 		// testbed_nerf.cu:1027-1029: the depth image holds distances along the UNNORMALISED ray direction
 		const float target_depth = length(V3(rays_in[i].d)) * ((o.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
 		const LossAndGradient lg_depth = loss_and_gradient(V3(target_depth), V3(depth_ray), o.depth_loss_type);
@@ -634,6 +724,20 @@ struct NerfTrainer {
 	std::vector<float> coords, coords_compacted, loss;
 	std::vector<uint16_t> mlp_out, dloss;
 
+	// error map (testbed.h:745-756, 810-815): accumulated on every step like the reference (testbed_nerf.cu:2793)
+	std::vector<float> error_map, cdf_x_cond_y, cdf_y, cdf_img;
+	int32_t error_map_res[2] = {0, 0}, cdf_res[2] = {0, 0};
+	bool is_cdf_valid = false;
+	uint32_t n_steps_between_error_map_updates = 128, n_steps_since_error_map_update = 0;
+	ErrorCdf cdf_args() const {
+		ErrorCdf c;
+		if (!is_cdf_valid) return c;
+		if (opt.sample_focal_plane_proportional_to_error) { c.x_cond_y = cdf_x_cond_y.data(); c.y = cdf_y.data(); }
+		if (opt.sample_image_proportional_to_error) c.img = cdf_img.data();
+		c.res[0] = cdf_res[0]; c.res[1] = cdf_res[1];
+		return c;
+	}
+
 	NerfTrainer(Model* m, const ngp_nerf_options& o, const ngp_aabb& box) : model(m), opt(o), aabb(box) {
 		rng = Pcg32(o.seed);                         // testbed.cu:4163
 		density_grid_rng = Pcg32(rng.next_uint());   // testbed.cu:4178
@@ -685,6 +789,13 @@ struct NerfTrainer {
 		if (measured_batch_size_before_compaction == 0) { measured_batch_size_before_compaction = max_inference = max_samples; }
 		else max_inference = next_multiple(std::min(measured_batch_size_before_compaction, max_samples), 256u);
 		const uint32_t R = rays_per_batch;
+		if (n_steps_since_error_map_update == 0 && !meta.empty()) { // testbed_nerf.cu:2753-2759
+			uint32_t n_samples_per_image = (n_steps_between_error_map_updates * rays_per_batch) / (uint32_t)meta.size();
+			int r = (int)(std::sqrt(std::sqrt((float)n_samples_per_image)) * 3.5f);
+			error_map_res[0] = std::min(r, meta[0].resolution[0]); error_map_res[1] = std::min(r, meta[0].resolution[1]);
+			error_map.assign((size_t)error_map_res[0] * error_map_res[1] * meta.size(), 0.f);
+		}
+		const ErrorCdf cdf = cdf_args();
 		if (training_step == 0) n_rays_total = 0;
 		n_rays_total += R;
 		ray_indices.assign(R, 0); rays.assign(R, ngp_ray{}); numsteps.assign((size_t)R * 2, 0);
@@ -693,7 +804,7 @@ struct NerfTrainer {
 		uint32_t rb = (uint32_t)((uint64_t)R * opt.rank / std::max(1u, opt.world_size));
 		uint32_t re = (uint32_t)((uint64_t)R * (opt.rank + 1) / std::max(1u, opt.world_size));
 		K1Out k1 = generate_training_samples(R, rb, re, aabb, max_inference, rng, ray_indices.data(), rays.data(), numsteps.data(), coords.data(),
-			(uint32_t)meta.size(), meta.data(), xforms.data(), bitfield.data(), opt.max_cascade, opt.snap_to_pixel_centers, opt.cone_angle_constant);
+			(uint32_t)meta.size(), meta.data(), xforms.data(), bitfield.data(), opt.max_cascade, opt.snap_to_pixel_centers, opt.cone_angle_constant, &cdf);
 		uint32_t n_inf = std::min(k1.numsteps_counter, max_inference);
 		model->inference(coords.data(), 7, n_inf, mlp_out.data(), 4, false);
 		K3Opts ko;
@@ -702,7 +813,7 @@ struct NerfTrainer {
 		ko.loss_type = opt.loss_type; ko.rgb_act = opt.rgb_activation; ko.density_act = opt.density_activation; ko.near_distance = opt.near_distance;
 		ko.train_mode = opt.train_mode; ko.depth_lambda = opt.depth_supervision_lambda; ko.depth_loss_type = opt.depth_loss_type;
 		uint32_t compacted = compute_loss(R, k1.ray_counter, aabb, rng, B, ko, (uint32_t)meta.size(), meta.data(), mlp_out.data(), 4,
-			ray_indices.data(), rays.data(), numsteps.data(), coords.data(), coords_compacted.data(), dloss.data(), 4, loss.data(), mean_density);
+			ray_indices.data(), rays.data(), numsteps.data(), coords.data(), coords_compacted.data(), dloss.data(), 4, loss.data(), mean_density, &cdf, error_map.data(), error_map_res);
 		n_rays_last = k1.ray_counter;
 		counter_before = k1.numsteps_counter; counter_compacted = compacted;
 		uint32_t n_valid = std::min(compacted, B);
@@ -718,6 +829,7 @@ struct NerfTrainer {
 		model->optimizer_step(opt.loss_scale);
 		++training_step;
 		total_rays += rays_per_batch;
+		struct AtExit { NerfTrainer* t; ~AtExit() { t->update_error_cdfs(); } } at_exit{this}; // testbed_nerf.cu:2791-2855 follows the counter update
 		measured_batch_size = 0; measured_batch_size_before_compaction = 0;
 		if (counter_before == 0 || counter_compacted == 0) { loss_scalar = 0.f; return; }
 		measured_batch_size_before_compaction = counter_before;
@@ -727,6 +839,18 @@ struct NerfTrainer {
 		loss_scalar = (float)s * (float)measured_batch_size / (float)opt.target_batch_size;
 		rays_per_batch = (uint32_t)((float)rays_per_batch * (float)opt.target_batch_size / (float)measured_batch_size);
 		rays_per_batch = std::min(next_multiple(rays_per_batch, 256u), 1u << 18);
+	}
+
+	void update_error_cdfs() {
+		n_steps_since_error_map_update += 1;
+		if (n_steps_since_error_map_update < n_steps_between_error_map_updates) return;
+		cdf_res[0] = error_map_res[0]; cdf_res[1] = error_map_res[1];
+		const size_t n_img = meta.size();
+		cdf_x_cond_y.assign((size_t)cdf_res[0] * cdf_res[1] * n_img, 0.f); cdf_y.assign((size_t)cdf_res[1] * n_img, 0.f); cdf_img.assign(n_img, 0.f);
+		construct_error_cdfs((uint32_t)n_img, (uint32_t)cdf_res[0], (uint32_t)cdf_res[1], error_map.data(), cdf_x_cond_y.data(), cdf_y.data(), cdf_img.data());
+		n_steps_since_error_map_update = 0;
+		is_cdf_valid = true;
+		n_steps_between_error_map_updates = (uint32_t)(n_steps_between_error_map_updates * 1.5f);
 	}
 
 	// Testbed::train, testbed.cu:4561-4647 (one call = one optimizer step)

@@ -243,6 +243,17 @@ def test_rccl_in_library_world1(hip):
     print(f"rccl world-1 vs plain: loss {sb.loss:.6f} vs {sa.loss:.6f}")
     assert np.isfinite(sb.loss) and abs(sa.loss - sb.loss) <= 0.35 * sa.loss + 1e-5
     A.check(hip, hip.ngp_allreduce_gradients(t_b, None)); A.check(hip, hip.ngp_allreduce_counters(t_b, None))
+    # error-proportional pixel sampling under the communicator: the ranks' error maps are summed (fp32 all-reduce) before the CDFs are built
+    opts = A.default_nerf_options(1, target_batch_size=1 << 16, rank=0, world_size=1, sample_image_proportional_to_error=1, sample_focal_plane_proportional_to_error=1)
+    A.check(hip, hip.ngp_nerf_set_options(t_b, C.byref(opts)))
+    A.check(hip, hip.ngp_nerf_set_error_map_interval(t_b, 4))
+    A.check(hip, hip.ngp_nerf_train(t_b, None, 12))
+    torch.cuda.synchronize()
+    valid, nb = C.c_int(), C.c_uint32()
+    A.check(hip, hip.ngp_nerf_error_map_ptrs(t_b, None, None, None, None, None, None, C.byref(valid), C.byref(nb), None))
+    assert valid.value == 1 and nb.value == 9  # 4 -> 6 -> 9 after two updates
+    A.check(hip, hip.ngp_nerf_get_stats(t_b, None, C.byref(sb)))
+    assert np.isfinite(sb.loss) and sb.measured_batch_size > 0
     torch.cuda.synchronize()
     A.check(hip, hip.ngp_comm_destroy(t_b))
     hip.ngp_nerf_destroy(t_a); hip.ngp_nerf_destroy(t_b)

@@ -293,6 +293,78 @@ def _k3_body(ora, hip, scene, o, d, n_rays, max_samples, B):
     assert abs(float(loss.cpu()[0]) - float(o_loss.sum())) <= 5e-3 * abs(float(o_loss.sum())) + 1e-7
 
 
+def _error_cdfs(ora, n_img, h=20, w=28):
+    rs = np.random.default_rng(0)
+    err = rs.uniform(0.0, 1e-3, (n_img, h, w)).astype(np.float32)
+    err[1, 3:6, 10:14] += 0.05; err[3, 15:, :4] += 0.02; err[2] = 0.0
+    cxy = np.zeros_like(err); cy = np.zeros((n_img, h), np.float32); ci = np.zeros(n_img, np.float32)
+    f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ora.ora_construct_error_cdfs(n_img, w, h, f(err), f(cxy), f(cy), f(ci))
+    return err, cxy, cy, ci
+
+
+def test_construct_error_cdfs_bit_exact(ora, hip):
+    """construct_cdf_2d / construct_cdf_1d / the image CDF (testbed_nerf.cu:1530-1580, 2832-2847): sequential float sums in the same order, correctly rounded
+    reciprocals, no contraction -> the device kernels reproduce the oracle bit for bit (including an image that never received a ray)."""
+    import torch
+    n_img = 6
+    err, cxy, cy, ci = _error_cdfs(ora, n_img)
+    h, w = err.shape[1:]
+    e = torch.from_numpy(err).cuda(); a = torch.zeros_like(e); b = torch.zeros((n_img, h), device="cuda"); c = torch.zeros(n_img, device="cuda")
+    A.check(hip, hip.ngp_k_construct_error_cdfs(None, n_img, w, h, dptr(e), dptr(a), dptr(b), dptr(c)))
+    torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy(), cxy) and np.array_equal(b.cpu().numpy(), cy) and np.array_equal(c.cpu().numpy(), ci)
+
+
+@pytest.mark.parametrize("which", ["both", "pixels", "images"])
+@pytest.mark.parametrize("k1_flags,k3_flags", [(1, 0), (0, 0), (0, 134217728), (1, 32)])
+def test_error_proportional_sampling_k1_k3(ora, hip, scene, which, k1_flags, k3_flags):
+    """sample_focal_plane_proportional_to_error / sample_image_proportional_to_error (nerf_device.cuh:497-599): K1 draws image and pixel through the CDFs,
+    K3 re-derives the pixel, divides the loss by its density and splats the ray's mean loss into the error map (testbed_nerf.cu:1024, 1042-1071).
+    Rays (origin, direction: they encode image and pixel) bit-exact against the oracle for both K1 kernels; loss / gradients / compaction through the
+    usual K3 comparison; the error map within float-atomic reordering."""
+    import torch
+    n_img = len(scene["imgs"])
+    err, cxy, cy, ci = _error_cdfs(ora, n_img)
+    h, w = err.shape[1:]
+    f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    cres = (C.c_int32 * 2)(w, h); eres = (C.c_int32 * 2)(16, 16)
+    emap_o = np.zeros((n_img, 16, 16), np.float32); emap_d = torch.zeros((n_img, 16, 16), device="cuda")
+    dxy, dy, di = torch.from_numpy(cxy).cuda(), torch.from_numpy(cy).cuda(), torch.from_numpy(ci).cuda()
+    use_xy, use_img = which in ("both", "pixels"), which in ("both", "images")
+    ora.ora_set_error_sampling(f(cxy) if use_xy else None, f(cy) if use_xy else None, f(ci) if use_img else None, cres, f(emap_o), eres)
+    A.check(hip, hip.ngp_debug_set_error_sampling(dptr(dxy) if use_xy else None, dptr(dy) if use_xy else None, dptr(di) if use_img else None, cres, dptr(emap_d), eres))
+    n_rays, max_samples, B = 2048, 1 << 19, 1 << 19
+    try:
+        _dbg(hip, k1_flags)
+        o, d = _run_k1(ora, hip, scene, n_rays, max_samples)
+        n_o, n_d = o["ray_counter"].value, int(d["counters"].cpu()[0])
+        ri = d["ray_indices"].cpu().numpy().astype(np.uint32)[:n_d]; rays = d["rays"].cpu().numpy()[:n_d]
+        ref = {int(r): i for i, r in enumerate(o["ray_indices"][:n_o])}
+        both = [i for i in range(n_d) if int(ri[i]) in ref]
+        assert len(both) >= 0.995 * max(n_o, n_d) and n_o > 500
+        for i in both:
+            assert np.array_equal(rays[i].view(np.uint32), o["rays"][ref[int(ri[i])]].view(np.uint32)), "image / pixel choice differs"
+        # and the CDFs matter: the uniform stream picks other rays
+        ora.ora_set_error_sampling(None, None, None, None, None, None); hip.ngp_debug_set_error_sampling(None, None, None, None, None, None)
+        o_u, _ = _run_k1(ora, hip, scene, n_rays, max_samples)
+        assert not np.array_equal(o_u["rays"][:64], o["rays"][:64])
+        ora.ora_set_error_sampling(f(cxy) if use_xy else None, f(cy) if use_xy else None, f(ci) if use_img else None, cres, f(emap_o), eres)
+        A.check(hip, hip.ngp_debug_set_error_sampling(dptr(dxy) if use_xy else None, dptr(dy) if use_xy else None, dptr(di) if use_img else None, cres, dptr(emap_d), eres))
+        _dbg(hip, k3_flags)
+        _k3_body(ora, hip, scene, o, d, n_rays, max_samples, B)
+        torch.cuda.synchronize()
+        em = emap_d.cpu().numpy()
+        assert emap_o.sum() > 0 and em.min() >= 0
+        # rays whose march differs by a sample between the two K1 formulations (<= 0.5 %, lattice K1 only) see other network outputs: a percent of slack on the cells
+        assert abs(float(em.sum()) - float(emap_o.sum())) <= (1e-4 if k1_flags == 1 else 2e-2) * emap_o.sum()
+        if k1_flags == 1:
+            assert np.allclose(em, emap_o, rtol=2e-3, atol=1e-7 * emap_o.max() + 1e-9)
+    finally:
+        _dbg(hip, 0)
+        ora.ora_set_error_sampling(None, None, None, None, None, None); hip.ngp_debug_set_error_sampling(None, None, None, None, None, None)
+
+
 def test_k3_compaction_order_is_the_slot_order(ora, hip, scene):
     """The two-pass K3 (ablation flag 1048576) places the rays' compacted spans in ray-slot order (prefix sum, no span atomics): base[i + 1] = base[i] + count[i],
     and two runs on the same input give bit-identical outputs."""

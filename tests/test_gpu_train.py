@@ -307,3 +307,101 @@ def test_depth_supervision_end_to_end(hip, ora):
     print("mean rendered opacity / coverage / loss:", means)
     assert means["off"][1] > 0.1 and means["off"][0] > 0.1  # lambda = 0: the scene trains as if the depth images were not there
     assert means["on"][1] < 0.5 * means["off"][1], means      # the (wrong, far too small) depth targets are met by giving up solid surfaces: no pixel stays opaque
+
+
+def _error_state(hip, t):
+    em, cxy, cy, ci = (C.c_void_p() for _ in range(4))
+    er, cr = (C.c_int32 * 2)(), (C.c_int32 * 2)()
+    valid, nb, nsn = C.c_int(), C.c_uint32(), C.c_uint32()
+    A.check(hip, hip.ngp_nerf_error_map_ptrs(t, C.byref(em), er, C.byref(cxy), C.byref(cy), C.byref(ci), cr, C.byref(valid), C.byref(nb), C.byref(nsn)))
+    return dict(em=em, er=tuple(er), cxy=cxy, cy=cy, ci=ci, cr=tuple(cr), valid=valid.value, n_between=nb.value, n_since=nsn.value)
+
+
+def _dl(ptr_, n, dtype=np.float32):
+    rt = C.CDLL("libamdhip64.so")
+    a = np.empty(n, dtype)
+    assert rt.hipMemcpy(ptr(a), ptr_, C.c_size_t(a.nbytes), 2) == 0
+    return a
+
+
+def test_error_map_cycle_and_sampling(ora, hip):
+    """The trainer's error-map cycle (testbed_nerf.cu:2753-2759, 2791-2855) with both sampling switches on: map resolution from interval x rays / images,
+    CDFs valid after `interval` steps, interval x 1.5; the CDFs the library built are the oracle's construction of the library's own map (bit-exact); the
+    step after the update marches the rays the oracle's K1 derives from those CDFs (a pre-launched K1 of the old CDFs must have been discarded); training
+    keeps converging.  Without the switches nothing is allocated."""
+    import torch
+    B = 1 << 15
+    s = _make(ora, hip, B, n_images=8, res=64)
+    t, opts = s["t"], s["opts"]
+    n_img = 8
+    A.check(hip, hip.ngp_nerf_train(t, None, 3))
+    st = _error_state(hip, t)
+    assert not st["em"].value and not st["valid"] and st["n_since"] == 0, "default: no error map"
+    opts.sample_focal_plane_proportional_to_error = 1; opts.sample_image_proportional_to_error = 1
+    A.check(hip, hip.ngp_nerf_set_options(t, C.byref(opts)))
+    A.check(hip, hip.ngp_nerf_set_error_map_interval(t, 6))
+    rays0 = _stats(hip, t).rays_per_batch
+    A.check(hip, hip.ngp_nerf_train(t, None, 1))
+    st = _error_state(hip, t)
+    r = int(np.sqrt(np.sqrt(np.float32(6 * rays0 // n_img))) * np.float32(3.5))
+    assert st["er"] == (min(r, 64), min(r, 64)) and st["em"].value and not st["valid"] and st["n_since"] == 1, (st, r, rays0)
+    A.check(hip, hip.ngp_nerf_train(t, None, 4))
+    torch.cuda.synchronize()
+    st = _error_state(hip, t)
+    assert not st["valid"] and st["n_since"] == 5
+    em_before = _dl(st["em"], n_img * st["er"][0] * st["er"][1])
+    assert em_before.min() >= 0 and em_before.sum() > 0
+    with pytest.raises(RuntimeError):
+        A.check(hip, hip.ngp_nerf_set_error_map_interval(t, 9))  # only between cycles
+    A.check(hip, hip.ngp_nerf_train(t, None, 1))
+    torch.cuda.synchronize()
+    st = _error_state(hip, t)
+    assert st["valid"] and st["n_between"] == 9 and st["n_since"] == 0 and st["cr"] == st["er"]
+    w, h = st["cr"]
+    em = _dl(st["em"], n_img * w * h).reshape(n_img, h, w)
+    cxy, cy, ci = _dl(st["cxy"], n_img * w * h).reshape(n_img, h, w), _dl(st["cy"], n_img * h).reshape(n_img, h), _dl(st["ci"], n_img)
+    oxy = np.zeros_like(em); oy = np.zeros((n_img, h), np.float32); oi = np.zeros(n_img, np.float32)
+    f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ora.ora_construct_error_cdfs(n_img, w, h, f(em), f(oxy), f(oy), f(oi))
+    assert np.array_equal(cxy, oxy) and np.array_equal(cy, oy) and np.array_equal(ci, oi)
+    assert em.sum() >= em_before.sum()
+    # the next forward pass: its rays are the oracle K1's rays under these CDFs
+    rng, grng = A.Pcg32(), A.Pcg32(); hip.ngp_nerf_get_rng(t, C.byref(rng), C.byref(grng))
+    R = _stats(hip, t).rays_per_batch
+    A.check(hip, hip.ngp_nerf_train_prep(t, None))
+    hip.ngp_debug_set_flags(4096)  # DBG_NO_STREAM_OVERLAP: no K1 of the step after next over the buffers read below
+    try:
+        A.check(hip, hip.ngp_nerf_train_forward_backward(t, None))
+    finally:
+        hip.ngp_debug_set_flags(0)
+    torch.cuda.synchronize()
+    ri_p, rays_p, ns_p, co_p, mo_p, cc_p, dl_p, cn_p = (C.c_void_p() for _ in range(8))
+    A.check(hip, hip.ngp_nerf_scratch_ptrs(t, C.byref(ri_p), C.byref(rays_p), C.byref(ns_p), C.byref(co_p), C.byref(mo_p), C.byref(cc_p), C.byref(dl_p), C.byref(cn_p)))
+    n_act = _stats(hip, t).n_rays_last  # (the controller has run behind K4)
+    imgs, M, X, pix = s["keep"]
+    gp, bp = C.c_void_p(), C.c_void_p(); A.check(hip, hip.ngp_nerf_density_grid_ptrs(t, C.byref(gp), C.byref(bp), None))
+    bf = _dl(bp, 128 ** 3 // 8 * 8, np.uint8)
+    ora.ora_set_error_sampling(f(cxy), f(cy), f(ci), (C.c_int32 * 2)(w, h), None, None)
+    try:
+        rc, nc = C.c_uint32(), C.c_uint32()
+        o_ri = np.zeros(R, np.uint32); o_rays = np.zeros((R, 6), np.float32); o_ns = np.zeros((R, 2), np.uint32); o_co = np.zeros((B * 16, 7), np.float32)
+        ora.ora_k_generate_training_samples(R, 0, R, A.scene_aabb(1), B * 16, rng, C.byref(rc), C.byref(nc), ptr(o_ri), ptr(o_rays), ptr(o_ns), ptr(o_co),
+                                            n_img, M, X, ptr(bf), 0, 1, C.c_float(0.0))
+    finally:
+        ora.ora_set_error_sampling(None, None, None, None, None, None)
+    assert 0 < n_act <= R and abs(n_act - rc.value) <= 0.01 * rc.value + 2, (n_act, rc.value)
+    ri = _dl(ri_p, n_act, np.uint32); rays = _dl(rays_p, n_act * 6).reshape(-1, 6)
+    ref = {int(r): i for i, r in enumerate(o_ri[:rc.value])}
+    hit = [i for i in range(n_act) if int(ri[i]) in ref]
+    assert len(hit) >= 0.99 * n_act
+    for i in hit:
+        assert np.array_equal(rays[i].view(np.uint32), o_rays[ref[int(ri[i])]].view(np.uint32)), "K1 did not use the new CDFs"
+    A.check(hip, hip.ngp_nerf_train_finish(t, None))
+    # keeps training: loss after 150 more steps well below the loss now
+    l0 = _stats(hip, t).loss
+    A.check(hip, hip.ngp_nerf_train(t, None, 150))
+    s1 = _stats(hip, t)
+    assert np.isfinite(s1.loss) and s1.measured_batch_size > 0.5 * B and s1.loss < 0.7 * l0, (l0, s1.loss)
+    st = _error_state(hip, t)
+    assert st["valid"] and st["n_between"] > 9
+    hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
