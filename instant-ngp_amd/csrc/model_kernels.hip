@@ -1009,6 +1009,8 @@ DEV LevelConst level_const_uniform(const GridMeta* __restrict__ gm, uint32_t lev
 }
 
 // record value of one corner: the F halfs of the entry's gradient contribution (F = 4: 8 bytes, F = 2: 4 bytes)
+// workgroup barrier that orders LDS traffic only: outstanding global loads / atomics stay in flight (the caller must not rely on them)
+#define NGP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int F> struct BinVal;
 template <> struct BinVal<4> { typedef uint2 type; };
 template <> struct BinVal<2> { typedef uint32_t type; };
@@ -1016,12 +1018,14 @@ template <int F> DEV typename BinVal<F>::type pack_halfs(const float* v);
 template <> __device__ __forceinline__ uint2 pack_halfs<4>(const float* v) { const h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; return __builtin_bit_cast(uint2, hv); }
 template <> __device__ __forceinline__ uint32_t pack_halfs<2>(const float* v) { const h2 hv = {(_Float16)v[0], (_Float16)v[1]}; return __builtin_bit_cast(uint32_t, hv); }
 
-template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */, int F = 4>
-__global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
+// THREADS: 256 (two samples per thread at 512 samples per block) or 512 (one): the block's LDS image is the same, so 512 threads double the wavefronts per CU
+// (3 blocks of 50 KiB: 12 -> 24) -- the kernel is latency bound (position / gradient loads, the cursor atomics, four barriers), not LDS or issue bound.
+template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */, int F = 4, uint32_t THREADS = 256>
+__global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 	typedef typename BinVal<F>::type val_t;
 	constexpr uint32_t NCH = (1u << GRAD_BIN_MAX_TABLE_LOG2) >> CL2; // most chunks a level can have (128 / 256)
 	__shared__ uint32_t s_cnt[NCH], s_start[NCH], s_gbase[NCH];
-	__shared__ uint32_t s_wsum[4];
+	__shared__ uint32_t s_wsum[THREADS / 64];
 	__shared__ val_t s_val[GRAD_BIN_SAMPLES * 8];
 	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * 8];
 	const uint32_t tid = threadIdx.x, ly = blockIdx.y, level = a.levels[ly];
@@ -1034,16 +1038,17 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	auto chunk_of = [&](uint32_t idx) { return dense ? idx & (NCH - 1u) : idx >> CL2; };
 	auto local_of = [&](uint32_t idx) { return dense ? idx >> NCH_LOG2 : idx & ((1u << CL2) - 1u); };
 	const uint32_t n_chunks = dense ? NCH : lc.hs >> CL2;
-	for (uint32_t c = tid; c < NCH; c += 256) s_cnt[c] = 0;
+	for (uint32_t c = tid; c < NCH; c += THREADS) s_cnt[c] = 0;
 	__syncthreads();
-	constexpr int SPT = GRAD_BIN_SAMPLES / 256; // samples per thread
+	constexpr int SPT = GRAD_BIN_SAMPLES / THREADS; // samples per thread
+	static_assert(GRAD_BIN_SAMPLES % THREADS == 0 && NCH <= THREADS, "k_grad_bin: block shape");
 	uint32_t idx[SPT][8], rank[SPT][8];
 	val_t val[SPT][8];
 	bool valid[SPT];
 	const uint32_t lane = tid & 63u;
 #pragma unroll
 	for (int u = 0; u < SPT; ++u) {
-		const uint32_t s = blockIdx.x * GRAD_BIN_SAMPLES + u * 256 + tid;
+		const uint32_t s = blockIdx.x * GRAD_BIN_SAMPLES + u * THREADS + tid;
 		valid[u] = s < a.n;
 		float g[F];
 #pragma unroll
@@ -1111,21 +1116,23 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 	}
 	__syncthreads();
 	// exclusive prefix of the chunk counts (<= 256 chunks: one per thread) + slot reservation in the global lists
+	uint32_t gbase_reg = 0u;
 	{
 		const uint32_t cnt = tid < n_chunks ? s_cnt[tid < NCH ? tid : 0u] : 0u;
+		// The reservation only needs the count: the returning atomic is issued here and its result is first used behind the LDS scatter below, so its
+		// round trip to the memory side overlaps the prefix sum and the scatter.  The two barriers in between wait for LDS only (s_waitcnt lgkmcnt(0)):
+		// __syncthreads() would wait for the atomic as well.
+		if (tid < NCH && cnt) gbase_reg = atomicAdd(&a.cursors[ly * a.max_chunks + tid], cnt);
 		uint32_t x = cnt;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if ((tid & 63u) >= (uint32_t)d) x += y; }
 		if ((tid & 63u) == 63u) s_wsum[tid >> 6] = x;
-		__syncthreads();
+		NGP_LDS_BARRIER();
 		uint32_t woff = 0;
 		for (uint32_t w = 0; w < (tid >> 6); ++w) woff += s_wsum[w];
-		if (tid < NCH) {
-			s_start[tid] = woff + x - cnt;
-			s_gbase[tid] = cnt ? atomicAdd(&a.cursors[ly * a.max_chunks + tid], cnt) : 0u;
-		}
+		if (tid < NCH) s_start[tid] = woff + x - cnt;
 	}
-	__syncthreads();
+	NGP_LDS_BARRIER();
 #pragma unroll
 	for (int u = 0; u < SPT; ++u) {
 		if (!valid[u]) continue;
@@ -1137,9 +1144,12 @@ __global__ void __launch_bounds__(256) k_grad_bin(GradBinArgs a) {
 			s_key[pos] = (c << 16) | local_of(idx[u][k]);
 		}
 	}
+	if (tid < NCH) s_gbase[tid] = gbase_reg;
 	__syncthreads();
-	const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-	for (uint32_t i = tid; i < total; i += 256) {
+	uint32_t total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < THREADS / 64; ++w) total += s_wsum[w];
+	for (uint32_t i = tid; i < total; i += THREADS) {
 		const uint32_t key = s_key[i], c = key >> 16, local = key & 0xffffu;
 		const uint32_t d = s_gbase[c] + (i - s_start[c]);
 		const val_t v = s_val[i];
@@ -2103,7 +2113,10 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	if (max_rays == 0) return;
 	K2LazyArgs la = la_in;
 	const uint32_t tpw = 32u / la.tile_w;
-	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
+	// Resident blocks: 3 per CU.  A grid of exactly that size strides statically over the tiles, and a wavefront whose rays stay transparent for many tiles
+	// holds up its later tiles; NGP_K2_GRID_MULT > 1 launches that many times more blocks so that the dispatcher hands tiles out as blocks retire.
+	static const uint32_t grid_mult = [] { const char* e = getenv("NGP_K2_GRID_MULT"); const int v = e ? atoi(e) : 1; return (uint32_t)std::min(std::max(v, 1), 64); }();
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3 * grid_mult);
 	const uint32_t nr = mp.n_rgb_hidden;
 #define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
 #define NGP_LAUNCH_TILES_W(FF, NRR) do { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, FF, NRR); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, FF, NRR); else NGP_LAUNCH_TILES(32, FF, NRR); } while (0)
@@ -2171,7 +2184,9 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
 	} else {
+		static const uint32_t bin_threads = getenv("NGP_BIN_THREADS") ? (uint32_t)atoi(getenv("NGP_BIN_THREADS")) : 512u; // 256: the round-2 shape (ablation)
 		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<12, 256>), gb, dim3(256), 0, s, a);
+		else if (bin_threads == 512) hipLaunchKernelGGL((k_grad_bin<12, 512, 4, 512>), gb, dim3(512), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_bin<12, 512>), gb, dim3(256), 0, s, a);
 		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_accumulate<12, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
