@@ -245,10 +245,27 @@ DEV h8 sh4_frag(float dx, float dy, float dz, int hi) {
 }
 
 // copy the fragment-ordered weights into LDS (all threads of the block)
+// (loads are issued in batches of 8 / 4 before their LDS stores: one load per loop trip made every block start with 5 - 10 dependent round trips to L2)
 DEV void load_frags_to_lds(h8* dst, const ngp_half* __restrict__ src, int n_frags) {
 	const uint4* s = (const uint4*)src;
 	uint4* d = (uint4*)dst;
-	for (int i = threadIdx.x; i < n_frags * 64; i += blockDim.x) d[i] = s[i];
+	const int n = n_frags * 64, step = (int)blockDim.x;
+	int i = (int)threadIdx.x;
+	for (; i + 7 * step < n; i += 8 * step) {
+		uint4 r[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) r[k] = s[i + k * step];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) d[i + k * step] = r[k];
+	}
+	for (; i + 3 * step < n; i += 4 * step) {
+		uint4 r[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) r[k] = s[i + k * step];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) d[i + k * step] = r[k];
+	}
+	for (; i < n; i += step) d[i] = s[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2113,11 +2130,11 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	if (max_rays == 0) return;
 	K2LazyArgs la = la_in;
 	const uint32_t tpw = 32u / la.tile_w;
-	// Resident blocks: 3 per CU.  A grid of exactly that size strides statically over the tiles, and a wavefront whose rays stay transparent for many tiles
-	// holds up its later tiles; NGP_K2_GRID_MULT > 1 launches that many times more blocks so that the dispatcher hands tiles out as blocks retire.
-	static const uint32_t grid_mult = [] { const char* e = getenv("NGP_K2_GRID_MULT"); const int v = e ? atoi(e) : 1; return (uint32_t)std::min(std::max(v, 1), 64); }();
-	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3 * grid_mult);
-	const uint32_t nr = mp.n_rgb_hidden;
+	// Resident blocks only (3 per CU, 137 registers).  Measured and rejected in round 3 (profiles/r03_microbench_bin_threads_k2_grid.log): 2 - 16 x more blocks than
+	// resident slots (dispatcher hands tiles out as blocks retire) 0.13 -> 0.16 - 0.21 ms; 4 blocks per CU at 128 registers (28 B of scratch) 0.130 -> 0.134 ms; 8-wide
+	// tiles 0.131 -> 0.142 ms.  The kernel moves 400 MB of 128-byte lines for 8-byte table entries (profiles/r03_pmc_summary.txt): it runs at the memory side's
+	// random-line rate (3.3 TB/s), not at a latency or occupancy limit.
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
 #define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
 #define NGP_LAUNCH_TILES_W(FF, NRR) do { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, FF, NRR); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, FF, NRR); else NGP_LAUNCH_TILES(32, FF, NRR); } while (0)
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
