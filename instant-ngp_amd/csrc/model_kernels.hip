@@ -2135,6 +2135,7 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	// tiles 0.131 -> 0.142 ms.  The kernel moves 400 MB of 128-byte lines for 8-byte table entries (profiles/r03_pmc_summary.txt): it runs at the memory side's
 	// random-line rate (3.3 TB/s), not at a latency or occupancy limit.
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
+	const uint32_t nr = mp.n_rgb_hidden;
 #define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
 #define NGP_LAUNCH_TILES_W(FF, NRR) do { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, FF, NRR); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, FF, NRR); else NGP_LAUNCH_TILES(32, FF, NRR); } while (0)
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
