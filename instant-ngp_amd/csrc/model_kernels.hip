@@ -513,6 +513,10 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		FwdState<1> st;
 		const float* p = in + (size_t)sample * in_stride;
 		encode_sample<F, false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
+		if (la.enc_out && valid) { // for T1 (EncStashIn): this lane's half of the sample's encoding, 32 contiguous bytes
+			uint4* e = la.enc_out + (size_t)sample * 4 + (uint32_t)hi * 2;
+			e[0] = __builtin_bit_cast(uint4, st.enc[0][0]); e[1] = __builtin_bit_cast(uint4, st.enc[0][1]);
+		}
 		st.rin[0][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
 		fwd_density_l1<1>(fw, lane, st);
 		fwd_density_l2<1>(fw, lane, st);
@@ -718,10 +722,11 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 
 // SCATTER = false: every level's dL/d(enc) goes to denc_lv and the kernel issues no atomics (production: all levels through the bin lists);
 // compiled separately so that the scatter code's registers do not limit the occupancy of the gather-latency-bound forward / dgrad part.
-template <int CT, int MINW, bool SCATTER, int F = 4, int NR = 2>
+// STASH: the encodings come from the lazy K2's per-sample records (EncStashIn) instead of the hash tables.
+template <int CT, int MINW, bool SCATTER, int F = 4, int NR = 2, bool STASH = false>
 __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
 		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags,
-		uint2* __restrict__ denc_lv, uint32_t denc_cap) {
+		uint2* __restrict__ denc_lv, uint32_t denc_cap, EncStashIn stash_in = EncStashIn()) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
 	h8* bw = fw + n_fw(NR) * 64;
@@ -732,6 +737,9 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
 	const __half* table = (const __half*)mp.grid;
 	constexpr uint32_t TS = 32 * CT;
+	uint32_t n_valid_rows = 0;
+	if constexpr (STASH) n_valid_rows = min(*stash_in.n_valid_ptr, n);
+#pragma unroll 1
 	for (uint32_t tile = wave; (uint64_t)tile * TS < n; tile += n_waves) {
 		FwdState<CT> st;
 		uint32_t sidx[CT];
@@ -742,6 +750,14 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 			sidx[c] = s_raw;
 			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
 			px[c] = p[0]; py[c] = p[1]; pz[c] = p[2];
+			if constexpr (STASH) {
+				uint32_t row = min(s_raw, n - 1);
+				if (row >= n_valid_rows) row = n_valid_rows ? row % n_valid_rows : 0u; // K4's wrap-around padding: row e is a copy of row e % n_valid
+				const uint32_t src = n_valid_rows ? stash_in.src_index[row] : 0u;
+				const uint4* e = stash_in.enc + (size_t)src * 4 + (uint32_t)hi * 2;
+				st.enc[c][0] = __builtin_bit_cast(h8, e[0]); st.enc[c][1] = __builtin_bit_cast(h8, e[1]);
+				__builtin_amdgcn_sched_barrier(0); // without it the scheduler hoists the layers' LDS fragment loads above these two loads: 168 registers + 328 B of scratch instead of 130 + 0
+			} else
 			encode_sample<F>(gm, table, px[c], py[c], pz[c], hi, st.enc[c]);
 			st.rin[c][1] = sh4_frag(p[4], p[5], p[6], hi);
 			// stash for kernel W: [32-sample tile][s][lane] 16-byte chunks (lane-linear, coalesced)
@@ -2211,7 +2227,7 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	}
 }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t F) {
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t F, const EncStashIn* stash_in) {
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
@@ -2229,7 +2245,11 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 	}
 	// 3 wavefronts per SIMD without spills (164 registers) beat 4 with 36 spilled registers: T1 + bin + accumulate 0.219 vs 0.244 ms (profiles/r02_t1_occupancy.txt)
 	static const int t1_occ = getenv("NGP_T1_OCC") ? atoi(getenv("NGP_T1_OCC")) : 3;
-	if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3)
+	// (4 blocks per CU -- the stash variant compiles to 91 registers when asked -- measured no better: unit 0.189 vs 0.180 ms, profiles/r03_microbench_t1_stash.log)
+	if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3 && stash_in && stash_in->enc && !(flags & DBG_T1_NO_K2_STASH))
+		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false, 4, 2, true>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
+			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap, *stash_in);
+	else if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3)
 		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,
 			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap);
 	else if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2)) // no atomics in T1: every level's dL/d(enc) goes to denc_lv

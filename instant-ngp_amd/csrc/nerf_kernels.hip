@@ -679,6 +679,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			float* cj = cout + (size_t)j * 7;
 			const float c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3];
 			cj[0] = c0; cj[1] = c1; cj[2] = c2; cj[3] = c3; cj[4] = ci[4]; cj[5] = ci[5]; cj[6] = ci[6];
+			if (a.src_index_out) a.src_index_out[compacted_base + j] = base + j;
 			const f3 pos = unwarp_position(mk3(c0, c1, c2), aabb);
 			const float depth = dist3(pos, ray_o);
 			const float dt = unwarp_dt(c3);
@@ -983,6 +984,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				float* cj = cout + (size_t)s * 7;
 #pragma unroll
 				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
+				if (a.src_index_out) a.src_index_out[compacted_base + s] = base + s; // which K2 sample this batch row is (EncStashIn)
 				const f3 suffix = rgb_ray - ray2;
 				f3 dloss_by_drgb = weight * lgrad;
 				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + depth_loss_gradient * (T_after * depth - (depth_ray - depth2)); // depth supervision, testbed_nerf.cu:1126-1129
@@ -1298,6 +1300,7 @@ __global__ void __launch_bounds__(256) k_fill_rollover(uint32_t n_elements, cons
 	if (publish_dst2 && blockIdx.x == 0 && threadIdx.x == 0) {
 		publish_dst2[0] = publish_src2[0]; publish_dst2[1] = publish_src2[1];
 		if (publish_loss) { const float l = *publish_loss; publish_dst2[2] = l > 0.f ? (uint32_t)(fminf(l, 16.f) * 16777216.f) : 0u; } // NaN -> 0
+		publish_dst2[3] = min(*n_input_ptr, n_elements); // THIS rank's valid batch rows (not all-reduced; T1 reads it, EncStashIn::n_valid_ptr -- the controller resets K3's counter)
 	}
 	const uint32_t n_in = min(*n_input_ptr, n_elements); // K3's counter may overshoot the batch (its spans are clamped)
 	if (n_in != 0 && n_in < n_elements) {

@@ -410,7 +410,11 @@ extern "C" int ngp_model_encode(ngp_model* m, void* stream, const float* pos, ui
 	return 0;
 }
 
+static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in);
 extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride) {
+	return model_training_step_impl(m, stream, in, in_stride, n, dL_dy, dy_stride, nullptr);
+}
+static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in) {
 	REQUIRE(in_stride >= 7 && dy_stride >= 4 && dy_stride % 4 == 0, "training_step: in_stride >= 7, dy_stride a multiple of 4 halfs");
 	hipStream_t s = (hipStream_t)stream;
 	const size_t need = (size_t)((n + 31) / 32) * 2 * 64 * 8; // halfs
@@ -479,7 +483,7 @@ extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* 
 	if (ba.n_hashed && m->gm.F == 4 && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !m->bin_dense && !(g_debug_flags & DBG_T1_NO_SCATTER))
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
 	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
-		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n, m->gm.F); }
+		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n, m->gm.F, stash_in); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
 	hipStream_t sw = s;
@@ -1205,6 +1209,7 @@ struct ngp_nerf {
 	uint32_t k2_rounds = 1, k2_tile_w = 16; // rounds 1 = one launch, every wavefront follows its rays front to back (default); 2..8 = list-driven rounds (round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest).  Tile width 16: two rays per wavefront, 383k instead of 556k evaluations per step.  Measured per step (profiles/r02_microbench_k2.log, r02_microbench_final.log): 3 rounds x 32 = 0.171 ms, 1 x 32 = 0.131 ms, 1 x 16 = 0.112 ms.  NGP_K2_ROUNDS / NGP_K2_TILE override.
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
+	uint4* k2_enc = nullptr; uint32_t* src_index = nullptr; bool k2_enc_valid = false; // K2's per-sample encodings and K3's row -> sample map for T1 (EncStashIn); valid: written by this step's K2 / K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; uint32_t* r_n_inf = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
 	char* k1_scratch = nullptr; // RaySetup / occupancy masks / prefix sums of the sample-parallel K1
@@ -1243,7 +1248,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_positions_sorted, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices_sorted, n_cells) || dev_alloc(&t->grid_sort_temp, t->grid_sort_temp_bytes = grid_sample_sort_temp_bytes(n_cells)) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
-		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_enc, (size_t)max_samples * 4) || dev_alloc(&t->src_index, B) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
 		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * (o->max_cascade + 1) * 2) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays)) || dev_alloc(&t->k3_scratch, k3_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || k3_scratch_init(nullptr, t->k3_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
@@ -1287,7 +1292,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index}) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
 }
@@ -1505,9 +1510,14 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		la.n_rays_ptr = &c->ray_counter; la.tiles[0] = t->k2_tiles; la.tiles[1] = t->k2_tiles + t->k2_tile_cap; la.tile_cap = t->k2_tile_cap;
 		la.n_tiles_ptr = c->k2_tiles; la.T_run = t->k2_T; la.round = 0; la.n_rounds = t->k2_rounds; la.tile_w = t->k2_tile_w; la.n_eval_ptr = &c->k2_samples; la.density_activation = o.density_activation;
 		{ const float max_stepsize = MIN_CONE_STEP * (float)(1 << (N_CASCADES - 1)); la.dt_unwarp_scale = max_stepsize - MIN_CONE_STEP; la.dt_unwarp_offset = MIN_CONE_STEP; } // unwarp_dt
+		// T1 re-uses the encodings of the samples it differentiates (base.json's shape, production K3 kernels): 64 coalesced bytes per sample instead of 64 table gathers
+		const bool two_pass_k3 = (g_debug_flags & DBG_K3_TWO_PASS) && !(o.depth_supervision_lambda > 0.f) && !error_map_wanted(t) && !t->error_cycle_open;
+		t->k2_enc_valid = t->model->gm.F == 4 && t->model->cfg.n_hidden_layers_rgb == 2 && !(g_debug_flags & DBG_T1_NO_K2_STASH) && !two_pass_k3;
+		la.enc_out = t->k2_enc_valid ? t->k2_enc : nullptr;
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la, t->model->gm.F);
-	  } else
-	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4, t->model->gm.F); }
+	  } else {
+	  t->k2_enc_valid = false; // eager K2 (ablation): T1 gathers
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4, t->model->gm.F); } }
 	K3Args k3;
 	k3.n_rays = 0; k3.n_rays_ptr = &c->rays_per_batch; k3.aabb = t->aabb; k3.rng = pod(t->rng); k3.max_samples_compacted = B; k3.rays_counter = &c->ray_counter;
 	k3.loss_scale = o.loss_scale; for (int k = 0; k < 3; ++k) k3.background_color[k] = o.background_color[k];
@@ -1519,6 +1529,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	k3.ray_targets = lattice ? t->ray_targets : nullptr; k3.train_mode = o.train_mode; k3.k3_scratch = t->k3_scratch;
 	k3.depth_lambda = o.depth_supervision_lambda; k3.depth_loss_type = o.depth_loss_type;
 	if (k3.depth_lambda > 0.f) k3.k3_scratch = nullptr; // the two-pass ablation kernel has no depth term: the one-pass kernel runs
+	k3.src_index_out = t->k2_enc_valid ? t->src_index : nullptr;
 	k3.cdf = error_cdf_args(t);
 	if (t->error_cycle_open) { k3.error_map = t->error_map; k3.error_map_res[0] = t->error_map_res[0]; k3.error_map_res[1] = t->error_map_res[1]; }
 	if (k3.error_map || k3.cdf.x_cond_y || k3.cdf.img) k3.k3_scratch = nullptr; // (nor the error map)
@@ -1544,7 +1555,9 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		if (!t->ev_ctl) { HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
 		HIPCHK(hipEventRecord(t->ev_ctl, s));
 	}
-	if (ngp_model_training_step(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4)) return 1;
+	EncStashIn stash_in;
+	if (t->k2_enc_valid) { stash_in.enc = t->k2_enc; stash_in.src_index = t->src_index; stash_in.n_valid_ptr = t->sync2 + 3; }
+	if (model_training_step_impl(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4, t->k2_enc_valid ? &stash_in : nullptr)) return 1;
 	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
 	if (prelaunch) { // K1 of the NEXT step (its rng position), concurrent with this step's backward pass and optimizer
 		HIPCHK(hipStreamWaitEvent(t->k1_stream, t->ev_ctl, 0));

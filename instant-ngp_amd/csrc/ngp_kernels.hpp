@@ -19,6 +19,7 @@ enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
 	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
+	DBG_T1_NO_K2_STASH = 536870912 /* T1 gathers its encodings from the hash tables again (rounds 1-3a) instead of reading the ones K2 left behind for the same samples */,
 	DBG_K1_NO_FIRST_POINT_SKIP = 268435456 /* k1_count without the one-test-per-chunk rejection of the chunks behind the ray's exit */,
 	DBG_K3_ONE_RAY_PER_WAVE = 134217728 /* K3 with one wavefront per ray (rounds 1-2) instead of two rays per wavefront */,
 	DBG_K4_ZERO_PADDING = 67108864 /* test hook: the rows K4 pads the compacted batch with carry a zero loss gradient instead of the rescaled copy (the padding is the only part of a step that is not linear in the set of rays: tests/test_gpu_dist.py compares the 2-rank sum with the 1-rank gradient without it) */,
@@ -93,6 +94,7 @@ struct K3Args {
 	float depth_lambda = 0.f; int depth_loss_type = NGP_LOSS_L1; // depth supervision (testbed_nerf.cu:1027-1029, 1126-1129); ray_targets slot 6 = target depth (<= 0: none)
 	ErrorCdf cdf;             // must equal K1's: the ray's pixel is re-derived from its index (testbed_nerf.cu:955-961); the loss is divided by the pixel's density (:1024)
 	float* error_map = nullptr; int32_t error_map_res[2] = {0, 0}; // testbed_nerf.cu:1042-1071: every ray's mean loss, splatted bilinearly into its image's error map (float atomics)
+	uint32_t* src_index_out = nullptr; // optional: src_index_out[compacted row] = index of the row's sample in coords_in / network_output (for T1, see EncStashIn)
 	void* k3_scratch = nullptr; // k3_scratch_bytes(max_rays), initialised by k3_scratch_init: needed by the two-pass kernel (DBG_K3_TWO_PASS)
 };
 size_t k3_scratch_bytes(uint32_t max_rays);
@@ -163,6 +165,7 @@ struct K2LazyArgs {
 	int density_activation; float dt_unwarp_scale, dt_unwarp_offset; // dt = warped * scale + offset (unwarp_dt)
 	uint32_t round, n_rounds;
 	uint32_t tile_w;                // samples per tile: 16 (two rays' tiles per wavefront) or 32
+	uint4* enc_out = nullptr;       // optional: the encoding of every evaluated sample, 4 x 16 bytes per sample at [sample][hi][k-step] (the B-operand registers of its two lanes), for T1
 };
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
 	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la, uint32_t n_features = 4);
@@ -208,8 +211,13 @@ struct GradDenseArgs { // k_grad_dense: the dense levels' scatter from T1's leve
 };
 void launch_grad_dense(hipStream_t s, const GradDenseArgs& a);
 constexpr uint32_t T1_DENSE_EXTERNAL = 1u << 31; // launch_train_fwd_bwd flag (not a debug flag): dense levels' dL/d(enc) goes to denc_lv too, no scatter in T1
+// Encodings left behind by the lazy K2 (K2LazyArgs::enc_out) for the samples T1 is about to differentiate: src_index[j] = K2's sample of batch row j (written by
+// K3 next to the row), n_valid_ptr = rows K3 produced (rows behind it are K4's wrap-around copies of row j % n_valid).  T1 then reads 64 contiguous bytes per sample
+// instead of gathering 64 table entries through 128-byte lines (306 MB of line traffic per step, profiles/r03_pmc_summary.txt).
+struct EncStashIn { const uint4* enc = nullptr; const uint32_t* src_index = nullptr; const uint32_t* n_valid_ptr = nullptr; };
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t n_features = 4);
+	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t n_features = 4,
+	const EncStashIn* stash_in = nullptr);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden = 2);

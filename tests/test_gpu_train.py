@@ -405,3 +405,40 @@ def test_error_map_cycle_and_sampling(ora, hip):
     st = _error_state(hip, t)
     assert st["valid"] and st["n_between"] > 9
     hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
+
+
+def test_t1_reuses_k2_encodings_bit_exact(hip, ora):
+    """Production T1 reads the encodings the lazy K2 left behind for the same samples (64 contiguous bytes per sample through K3's row -> sample map) instead of
+    gathering them from the hash tables again.  Same batch, both ways (flag 536870912 = DBG_T1_NO_K2_STASH): every level's gradient goes through the exact
+    fixed-point lists and the weight gradients are summed in batch order, so the two gradient vectors must be IDENTICAL -- also when K4 has padded the batch
+    with wrap-around copies (early steps: few compacted samples)."""
+    import torch
+    B = 1 << 15
+    s = _make(ora, hip, B, n_images=8, res=64)
+    t, hm = s["t"], s["hm"]
+    n, n_mlp = C.c_uint64(), C.c_uint64()
+    hip.ngp_model_n_params(hm.h, C.byref(n), C.byref(n_mlp))
+    g = C.c_void_p(); hip.ngp_model_param_ptrs(hm.h, None, None, None, C.byref(g))
+    for steps_before in (2, 60):  # step 3: the batch is mostly padding; step ~63: full batches
+        A.check(hip, hip.ngp_nerf_train(t, None, steps_before))
+        A.check(hip, hip.ngp_nerf_train_prep(t, None))
+        try:
+            hip.ngp_debug_set_flags(4096)  # DBG_NO_STREAM_OVERLAP: no K1 of the next step in flight while the step is replayed
+            A.check(hip, hip.ngp_nerf_train_forward(t, None))
+            A.check(hip, hip.ngp_nerf_train_backward(t, None))
+            torch.cuda.synchronize()
+            g1 = _dl(g, n.value, np.uint16)
+            hip.ngp_debug_set_flags(4096 | 536870912)
+            A.check(hip, hip.ngp_nerf_train_backward(t, None))
+            torch.cuda.synchronize()
+            g2 = _dl(g, n.value, np.uint16)
+        finally:
+            hip.ngp_debug_set_flags(0)
+        st = _stats(hip, t)
+        assert np.count_nonzero(g1) > 1000
+        bad = np.flatnonzero(g1 != g2)
+        assert bad.size == 0, (steps_before, st.measured_batch_size, bad.size, bad[:8].tolist(), g1[bad[:4]].tolist(), g2[bad[:4]].tolist())
+        A.check(hip, hip.ngp_nerf_train_finish(t, None))
+    s1 = _stats(hip, t)
+    assert np.isfinite(s1.loss) and s1.measured_batch_size > 0
+    hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
