@@ -776,8 +776,11 @@ static __device__ __forceinline__ float half_incl_scan(float x) {
 // a trained scene keeps ~10 samples per ray, so a 64-lane wavefront per ray wastes 5/6 of every instruction (the kernel is VALU-issue bound);
 // the per-ray values move from scalar to per-lane registers, the scans become segmented, and both halves iterate until the longer ray is done.
 // ERR: error-proportional pixel sampling / error-map accumulation compiled in (off in the production instance: the extra live values cost it 16 bytes of scratch).
-template <int RPW, bool ERR>
+// PLAIN: train_mode Nerf and no depth supervision, as compile-time facts (the production instance): the Rfl / depth accumulators and their scans disappear.
+template <int RPW, bool ERR, bool PLAIN>
 __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
+	const int train_mode = PLAIN ? 0 : a.train_mode;
+	const float depth_lambda = PLAIN ? 0.f : a.depth_lambda;
 	constexpr uint32_t LPR = 64u / RPW, RPB = K3_RAYS_PER_BLOCK * RPW; // lanes per ray, rays per workgroup (16 wavefronts)
 	__shared__ uint32_t s_cnt[RPB];
 	__shared__ float s_loss[RPB];
@@ -804,7 +807,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	const __half* no = nullptr;
 	f3 rgb_ray = mk3(0.f), ray_o = mk3(0.f), rgbtarget = mk3(0.f), background_color = ld3(a.background_color), loss_bg = mk3(0.f);
 	float T_final = 1.f;
-	float depth_ray = 0.f, target_depth = -1.f; // depth supervision (a.depth_lambda > 0, wave-uniform)
+	float depth_ray = 0.f, target_depth = -1.f; // depth supervision (depth_lambda > 0, wave-uniform)
 	// the first LPR samples of the ray stay in registers for the adjoint pass (most rays keep fewer)
 	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f, k_cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	const bool vec_out = a.output_stride == 4, vec_dl = a.dloss_stride == 4;
@@ -823,7 +826,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		f4 tex = {0.f, 0.f, 0.f, 0.f};
 		if (a.ray_targets) { // computed once per ray by k1_setup
 			const float4 t0 = ((const float4*)(a.ray_targets + (size_t)i * 8))[0], t1 = ((const float4*)(a.ray_targets + (size_t)i * 8))[1];
-			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y); target_depth = t1.z;
+			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y); target_depth = PLAIN ? -1.f : t1.z;
 		} else {
 			const uint32_t ray_idx = uni(a.ray_indices_in[i]);
 			// The target-pixel chain (ray index -> image metadata -> texel) is issued BEFORE the sample pass so that its three
@@ -836,7 +839,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			rng.advance(1); // motionblur_time
 			if (a.random_bg_color) { background_color.x = rng.next_float(); background_color.y = rng.next_float(); background_color.z = rng.next_float(); }
 			tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
-			target_depth = len3(ld3(a.rays_in[i].d)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
+			target_depth = len3(ld3(a.rays_in[i].d)) * ((depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
 			// target colour and background: identical to the sequential kernel; needed BEFORE the sample pass by the Rfl mode
 			background_color = srgb_to_linear3(background_color);
 			const f3 trgb = mk3(tex.x, tex.y, tex.z);
@@ -874,7 +877,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
 				const float dt = unwarp_dt(dtw);
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
-				if (a.depth_lambda > 0.0f) { const float* ci = cin + (size_t)s * 7; sdepth = dist3(unwarp_position(mk3(ci[0], ci[1], ci[2]), aabb), ray_o); }
+				if (depth_lambda > 0.0f) { const float* ci = cin + (size_t)s * 7; sdepth = dist3(unwarp_position(mk3(ci[0], ci[1], ci[2]), aabb), ray_o); }
 			}
 			const float incl = seg_prod(1.f - alpha);
 			float excl = __shfl_up(incl, 1, 64);
@@ -886,8 +889,8 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const float w = proc ? alpha * T_k : 0.f;
 			// lanes behind the cut may hold unevaluated network outputs (lazy K2): select, never multiply
 			rgb_ray = rgb_ray + mk3(seg_total(proc ? w * rgb.x : 0.f), seg_total(proc ? w * rgb.y : 0.f), seg_total(proc ? w * rgb.z : 0.f));
-			if (a.depth_lambda > 0.0f) depth_ray += seg_total(proc ? w * sdepth : 0.f);
-			if (a.train_mode == 1) { // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
+			if (depth_lambda > 0.0f) depth_ray += seg_total(proc ? w * sdepth : 0.f);
+			if (train_mode == 1) { // Rfl: sum of weight * per-sample loss (train_nerf.cuh:219)
 				f3 ll, lgl; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lgl);
 				loss_bg = loss_bg + mk3(seg_total(proc ? w * ll.x : 0.f), seg_total(proc ? w * ll.y : 0.f), seg_total(proc ? w * ll.z : 0.f));
 			}
@@ -901,7 +904,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		T_final = T_run;
 		if (active && compacted == numsteps) {
 			rgb_ray = rgb_ray + T_final * background_color;
-			if (a.train_mode == 1) { f3 ll, lgl; loss_and_gradient(rgbtarget, background_color, a.loss_type, ll, lgl); loss_bg = loss_bg + T_final * ll; }
+			if (train_mode == 1) { f3 ll, lgl; loss_and_gradient(rgbtarget, background_color, a.loss_type, ll, lgl); loss_bg = loss_bg + T_final * ll; }
 		}
 	}
 	// one global atomic per workgroup reserves the spans of its rays
@@ -939,11 +942,11 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		if (compacted > 0) my_loss = ((lloss.x + lloss.y + lloss.z) / 3.0f) / (float)n_rays;
 		const float loss_scale = a.loss_scale / n_rays;
 		const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
-		const float output_l1_reg_density = (a.train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = (train_mode == 0 && *a.mean_density_ptr < MIN_OPTICAL_THICKNESS) ? 1e-4f : 0.0f;
 		float T_run = 1.f;
 		f3 ray2_run = mk3(0.f), lb2_run = mk3(0.f);
 		float depth_loss_gradient = 0.f, depth2_run = 0.f;
-		if (target_depth > 0.0f) { f3 dl_, dg_; loss_and_gradient(mk3(target_depth), mk3(depth_ray), a.depth_loss_type, dl_, dg_); depth_loss_gradient = a.depth_lambda * dg_.x; } // testbed_nerf.cu:1028-1029
+		if (target_depth > 0.0f) { f3 dl_, dg_; loss_and_gradient(mk3(target_depth), mk3(depth_ray), a.depth_loss_type, dl_, dg_); depth_loss_gradient = depth_lambda * dg_.x; } // testbed_nerf.cu:1028-1029
 		for (uint32_t c0 = 0; ; c0 += LPR) {
 			if (__ballot(c0 < compacted) == 0ull) break;
 			const uint32_t s = c0 + sl;
@@ -974,9 +977,9 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const float weight = alpha * T_k;
 			const f3 ray2 = ray2_run + mk3(seg_sum(weight * rgb.x), seg_sum(weight * rgb.y), seg_sum(weight * rgb.z));
 			float depth2 = depth2_run;
-			if (a.depth_lambda > 0.0f) depth2 = depth2_run + seg_sum(weight * depth);
+			if (depth_lambda > 0.0f) depth2 = depth2_run + seg_sum(weight * depth);
 			f3 lloc = mk3(0.f), gloc = mk3(0.f), lb2 = lb2_run;
-			if (a.train_mode == 1) { // Rfl: per-sample loss against the target and its running (inclusive) weighted sum
+			if (train_mode == 1) { // Rfl: per-sample loss against the target and its running (inclusive) weighted sum
 				loss_and_gradient(rgbtarget, rgb, a.loss_type, lloc, gloc);
 				lb2 = lb2_run + mk3(seg_sum(weight * lloc.x), seg_sum(weight * lloc.y), seg_sum(weight * lloc.z));
 			}
@@ -988,11 +991,11 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				const f3 suffix = rgb_ray - ray2;
 				f3 dloss_by_drgb = weight * lgrad;
 				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + depth_loss_gradient * (T_after * depth - (depth_ray - depth2)); // depth supervision, testbed_nerf.cu:1126-1129
-				if (a.train_mode == 1) { // fused_kernels/train_nerf.cuh:391-396
+				if (train_mode == 1) { // fused_kernels/train_nerf.cuh:391-396
 					dloss_by_drgb = weight * gloc;
 					const f3 v = T_after * lloc - (loss_bg - lb2);
 					dmlp_inner = v.x + v.y + v.z;
-				} else if (a.train_mode == 2) { // train_nerf.cuh:397-405
+				} else if (train_mode == 2) { // train_nerf.cuh:397-405
 					const f3 rgb_bg = suffix / fmaxf(1e-6f, T_after);
 					const f3 rgb_lerp = (1 - alpha) * rgb_bg + alpha * rgb;
 					f3 ll, lgl; loss_and_gradient(rgbtarget, rgb_lerp, a.loss_type, ll, lgl);
@@ -1013,8 +1016,8 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 			const int last = (int)(seg0 + LPR - 1u);
 			T_run = T_run * __shfl(incl, last, 64);
 			ray2_run = mk3(__shfl(ray2.x, last, 64), __shfl(ray2.y, last, 64), __shfl(ray2.z, last, 64));
-			if (a.depth_lambda > 0.0f) depth2_run = __shfl(depth2, last, 64);
-			if (a.train_mode == 1) lb2_run = mk3(__shfl(lb2.x, last, 64), __shfl(lb2.y, last, 64), __shfl(lb2.z, last, 64));
+			if (depth_lambda > 0.0f) depth2_run = __shfl(depth2, last, 64);
+			if (train_mode == 1) lb2_run = mk3(__shfl(lb2.x, last, 64), __shfl(lb2.y, last, 64), __shfl(lb2.z, last, 64));
 		}
 	}
 	if (sl == 0) s_loss[wid * RPW + sub] = my_loss;
@@ -1550,9 +1553,11 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	else if (!a.k3_scratch || !(g_debug_flags & DBG_K3_TWO_PASS)) {
 		const bool err = a.error_map || a.cdf.x_cond_y || a.cdf.img;
 		const dim3 g1(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), g2(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK * 2), 256u * 2u));
-		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) { if (err) hipLaunchKernelGGL((k_compute_loss_v2<1, true>), g1, dim3(1024), 0, s, a); else hipLaunchKernelGGL((k_compute_loss_v2<1, false>), g1, dim3(1024), 0, s, a); }
-		else if (err) hipLaunchKernelGGL((k_compute_loss_v2<2, true>), g2, dim3(1024), 0, s, a);
-		else hipLaunchKernelGGL((k_compute_loss_v2<2, false>), g2, dim3(1024), 0, s, a);
+		const bool plain = a.train_mode == 0 && !(a.depth_lambda > 0.f) && !(g_debug_flags & DBG_K3_GENERIC);
+		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) { if (err) hipLaunchKernelGGL((k_compute_loss_v2<1, true, false>), g1, dim3(1024), 0, s, a); else hipLaunchKernelGGL((k_compute_loss_v2<1, false, false>), g1, dim3(1024), 0, s, a); }
+		else if (err) hipLaunchKernelGGL((k_compute_loss_v2<2, true, false>), g2, dim3(1024), 0, s, a);
+		else if (plain) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true>), g2, dim3(1024), 0, s, a);
+		else hipLaunchKernelGGL((k_compute_loss_v2<2, false, false>), g2, dim3(1024), 0, s, a);
 	}
 	else {
 		const uint32_t grid = k1_grid(max_rays);

@@ -19,6 +19,7 @@ enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march
 	DBG_SEPARATE_CONTROLLER = 524288 /* batch-size controller as its own launch behind K4 (round-1 behaviour) */,
 	DBG_T1_DENSE_EXTERNAL = 262144 /* dense levels' atomics issued by k_grad_dense on its own stream instead of by T1: T1 189 -> 90 us, k_grad_dense 117 us; same wall time (profiles/r02_microbench_final.log) */,
 	DBG_W_SINGLE_ROLE = 32768 /* round-1 weight-gradient kernel: one wave per SIMD holds all 12 dW tiles */,
+	DBG_K3_GENERIC = 1073741824 /* K3 without the instance specialised for train_mode Nerf + no depth supervision (rounds 1-3a: one kernel for all modes) */,
 	DBG_T1_NO_K2_STASH = 536870912 /* T1 gathers its encodings from the hash tables again (rounds 1-3a) instead of reading the ones K2 left behind for the same samples */,
 	DBG_K1_NO_FIRST_POINT_SKIP = 268435456 /* k1_count without the one-test-per-chunk rejection of the chunks behind the ray's exit */,
 	DBG_K3_ONE_RAY_PER_WAVE = 134217728 /* K3 with one wavefront per ray (rounds 1-2) instead of two rays per wavefront */,

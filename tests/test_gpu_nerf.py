@@ -188,10 +188,11 @@ def test_k1_sample_cap(ora, hip, scene):
     assert not kept[np.argmin(kept):].any()
 
 
-@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (1, 0), (2, 0), (0, 134217728), (1, 134217728), (2, 134217728), (1, 32), (2, 32), (0, 1048576), (1, 1048576), (2, 1048576)])
+@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (0, 1073741824), (1, 0), (2, 0), (0, 134217728), (1, 134217728), (2, 134217728), (1, 32), (2, 32), (0, 1048576), (1, 1048576), (2, 1048576)])
 def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
     """K3 vs the oracle per ray, for the three train modes (0 Nerf, 1 Rfl, 2 RflRelax: fused_kernels/train_nerf.cuh:391-410) and for the three device
-    kernels (one pass, two rays per wavefront, span atomic per 32 rays = production; flag 134217728 = the same kernel with one ray per wavefront; flag
+    kernels (one pass, two rays per wavefront, span atomic per 32 rays = production, train mode 0 runs its instance specialised for Nerf mode without depth
+    supervision and flag 1073741824 the generic one; flag 134217728 = the same kernel with one ray per wavefront; flag
     1048576 = two passes with a prefix sum, deterministic order; flag 32 = the reference's sequential per-ray loops)."""
     import torch
     ora.ora_set_train_mode(train_mode); hip.ngp_debug_set_train_mode(train_mode); hip.ngp_debug_set_flags(k3_flags)
