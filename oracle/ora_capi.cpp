@@ -113,6 +113,12 @@ API void ora_k1_lattice_counts(int mode, uint32_t n_rays, uint32_t ray_begin, ui
 		const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip, int snap, float cone_angle_constant, uint32_t* out_counts, uint32_t max_lattice_points) {
 	lattice_march_counts(mode, n_rays, ray_begin, ray_end, Aabb(aabb), Pcg32(rng), n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant, out_counts, max_lattice_points);
 }
+// per ray {cause, count_ref, count_lattice, t_ulps, face_distance_cells} (5 x 4 bytes), see ora_nerf.hpp lattice_vs_reference_divergence
+API void ora_k1_lattice_divergence(uint32_t n_rays, ngp_aabb aabb, ngp_pcg32 rng, uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xforms, const uint8_t* bitfield,
+		uint32_t max_mip, int snap, float cone_angle_constant, void* out, uint32_t max_lattice_points) {
+	static_assert(sizeof(K1Divergence) == 20, "K1Divergence layout");
+	lattice_vs_reference_divergence(n_rays, Aabb(aabb), Pcg32(rng), n_images, meta, xforms, bitfield, max_mip, snap != 0, cone_angle_constant, (K1Divergence*)out, max_lattice_points);
+}
 API void ora_xform_given_rolling_shutter(const ngp_xform* X, const float* rs, const float* uv, float motionblur_time, float* out12) {
 	const mat4x3 m = get_xform_given_rolling_shutter(*X, rs, vec2{uv[0], uv[1]}, motionblur_time);
 	for (int c = 0; c < 4; ++c) { out12[c * 3 + 0] = m.c[c].x; out12[c * 3 + 1] = m.c[c].y; out12[c * 3 + 2] = m.c[c].z; }

@@ -402,6 +402,108 @@ inline void lattice_march_counts(int mode, uint32_t n_rays, uint32_t ray_begin, 
 	}
 }
 
+// WHERE does the lattice walk (mode 1 above, the production marcher's algorithm) leave the reference's loop (testbed_nerf.cu:798-807)?  Both marches of one ray
+// are run in lockstep over their visited points: the reference's t (accumulated: t += dt, t = advance_to_next_voxel(...)) against the closed-form lattice
+// t_j.  While all decisions agree the two visit "the same" points up to rounding of t; the first disagreement is classified:
+//   1 BOX_FACE    one position is inside the box and the other is not
+//   2 MIP         the two positions / step sizes select different cascades (cone_angle > 0 only)
+//   3 VOXEL_FACE  same cascade, different occupancy: the two positions must lie in DIFFERENT cells (else the test is the same bit)
+//   4 SKIP        same empty cell, but the skip lands on different lattice points (t_target sits on a lattice point up to rounding)
+//   5 OTHER       anything else (must not happen: same cell, same bit, same skip)
+// out per ray: cause (0 = the marches agree to the end), sample counts of both, |t_ref - t_lattice| in ulps of t at the divergence (max over the walk if none),
+// and for 3 the distance (in cells of that cascade) of the reference's position to the nearest cell face, for 4 the distance (in lattice steps) of the skip length to
+// the nearest integer (its ceil() picks the landing point).
+struct K1Divergence { uint32_t cause, count_ref, count_lattice; float t_ulps, face_distance_cells; };
+inline void lattice_vs_reference_divergence(uint32_t n_rays, const Aabb& aabb, const Pcg32& rng_in, uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xforms,
+		const uint8_t* bitfield, uint32_t max_mip, bool snap_to_pixel_centers, float cone_angle, K1Divergence* out, uint32_t max_lattice_points) {
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t ii = 0; ii < (int64_t)n_rays; ++ii) {
+		const uint32_t i = (uint32_t)ii;
+		K1Divergence r = {0u, 0u, 0u, 0.f, 0.f};
+		out[i] = r;
+		uint32_t img = image_idx(i, n_rays, n_images);
+		const ngp_image_meta& m = meta[img];
+		Pcg32 rng = rng_in;
+		rng.advance((int64_t)(i * N_MAX_RANDOM_SAMPLES_PER_RAY));
+		vec2 uv = random_image_pos_training(rng, m.resolution, snap_to_pixel_centers);
+		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) continue;
+		const float motionblur_time = rng.next_float();
+		const mat4x3 xform = get_xform_given_rolling_shutter(xforms[img], m.rolling_shutter, uv, motionblur_time);
+		vec3 ro, rd;
+		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform[3]; rd = xform[2]; }
+		const vec3 rdn = normalize(rd);
+		vec2 tminmax = aabb.ray_intersect(ro, rdn);
+		tminmax.x = std::fmax(tminmax.x, 0.0f);
+		const float startt = advance_n_steps(tminmax.x, cone_angle, rng.next_float());
+		const float nprime = to_stepping_space(startt, cone_angle);
+		const vec3 idir = V3(1.0f) / rdn;
+		auto ulps = [](float a, float b) { int e; std::frexp(std::fmax(std::fabs(a), std::fabs(b)), &e); return std::fabs(a - b) / std::scalbn(1.0f, e - 24); };
+		auto cell = [&](vec3 pos, uint32_t mip, int c[3]) { const float sc = std::scalbn(1.0f, -(int)mip); vec3 q = (pos - V3(0.5f)) * sc + V3(0.5f); c[0] = (int)(q.x * (float)NERF_GRIDSIZE); c[1] = (int)(q.y * (float)NERF_GRIDSIZE); c[2] = (int)(q.z * (float)NERF_GRIDSIZE); };
+		float t_ref = startt; uint32_t j = 0; bool diverged = false;
+		while (j < max_lattice_points && r.count_ref < NERF_STEPS && r.count_lattice < NERF_STEPS) {
+			const float t_lat = j == 0 ? startt : from_stepping_space(nprime + (float)j, cone_angle);
+			const vec3 p_ref = ro + t_ref * rdn, p_lat = ro + t_lat * rdn;
+			const float u = ulps(t_ref, t_lat);
+			r.t_ulps = std::fmax(r.t_ulps, u);
+			const bool in_ref = aabb.contains(p_ref), in_lat = aabb.contains(p_lat);
+			if (in_ref != in_lat) { r.cause = 1; r.t_ulps = u; diverged = true; break; }
+			if (!in_ref) break;
+			const float dt_ref = calc_dt(t_ref, cone_angle), dt_lat = calc_dt(t_lat, cone_angle);
+			const uint32_t mip_ref = mip_from_dt(dt_ref, p_ref, max_mip), mip_lat = mip_from_dt(dt_lat, p_lat, max_mip);
+			if (mip_ref != mip_lat) { r.cause = 2; r.t_ulps = u; diverged = true; break; }
+			const bool occ_ref = density_grid_occupied_at(p_ref, bitfield, mip_ref), occ_lat = density_grid_occupied_at(p_lat, bitfield, mip_lat);
+			int c_ref[3], c_lat[3]; cell(p_ref, mip_ref, c_ref); cell(p_lat, mip_lat, c_lat);
+			const bool same_cell = c_ref[0] == c_lat[0] && c_ref[1] == c_lat[1] && c_ref[2] == c_lat[2];
+			if (occ_ref != occ_lat) {
+				r.cause = same_cell ? 5 : 3; r.t_ulps = u; diverged = true;
+				const float sc = std::scalbn(1.0f, -(int)mip_ref); const vec3 q = ((p_ref - V3(0.5f)) * sc + V3(0.5f)) * (float)NERF_GRIDSIZE;
+				auto fd = [](float x) { return std::fabs(x - std::nearbyint(x)); };
+				r.face_distance_cells = std::fmin(fd(q.x), std::fmin(fd(q.y), fd(q.z)));
+				break;
+			}
+			if (occ_ref) { ++r.count_ref; ++r.count_lattice; t_ref += dt_ref; ++j; continue; }
+			const float t_next = advance_to_next_voxel(t_ref, cone_angle, p_ref, rdn, idir, mip_ref);
+			const float res = scalbnf((float)NERF_GRIDSIZE, -(int)mip_lat);
+			const float t_target = t_lat + distance_to_next_voxel(p_lat, rdn, idir, res);
+			const uint32_t k = (uint32_t)ceilf(std::fmax(to_stepping_space(t_target, cone_angle) - to_stepping_space(t_lat, cone_angle), 0.5f));
+			const float t_lat_next = from_stepping_space(nprime + (float)(j + k), cone_angle);
+			// the same landing point?  compare in stepping space: a different lattice point is >= 1 apart there
+			if (std::fabs(to_stepping_space(t_next, cone_angle) - to_stepping_space(t_lat_next, cone_angle)) > 0.5f) { r.cause = same_cell ? 4 : 3; r.t_ulps = u; diverged = true;
+				if (same_cell) { // how close was the skip length (in lattice steps) to an integer on either side?  (ceil() of it decides the landing point)
+					const float res_r = scalbnf((float)NERF_GRIDSIZE, -(int)mip_ref);
+					const float x_ref = to_stepping_space(t_ref + distance_to_next_voxel(p_ref, rdn, idir, res_r), cone_angle) - to_stepping_space(t_ref, cone_angle);
+					const float x_lat = to_stepping_space(t_target, cone_angle) - to_stepping_space(t_lat, cone_angle);
+					auto fi = [](float x) { return std::fabs(x - std::nearbyint(x)); };
+					r.face_distance_cells = std::fmin(fi(x_ref), fi(x_lat));
+				}
+				if (!same_cell) { const float sc = std::scalbn(1.0f, -(int)mip_ref); const vec3 q = ((p_ref - V3(0.5f)) * sc + V3(0.5f)) * (float)NERF_GRIDSIZE; auto fd = [](float x) { return std::fabs(x - std::nearbyint(x)); }; r.face_distance_cells = std::fmin(fd(q.x), std::fmin(fd(q.y), fd(q.z))); }
+				break; }
+			t_ref = t_next; j += k;
+		}
+		if (diverged) { // the counts of the two complete marches, for the statistics
+			uint32_t jj = 0, cnt = 0;
+			while (jj < max_lattice_points && cnt < NERF_STEPS) {
+				const float t = jj == 0 ? startt : from_stepping_space(nprime + (float)jj, cone_angle);
+				const vec3 pos = ro + t * rdn;
+				if (!aabb.contains(pos)) break;
+				const uint32_t mip = mip_from_dt(calc_dt(t, cone_angle), pos, max_mip);
+				if (density_grid_occupied_at(pos, bitfield, mip)) { ++cnt; ++jj; continue; }
+				const float res = scalbnf((float)NERF_GRIDSIZE, -(int)mip);
+				jj += (uint32_t)ceilf(std::fmax(to_stepping_space(t + distance_to_next_voxel(pos, rdn, idir, res), cone_angle) - to_stepping_space(t, cone_angle), 0.5f));
+			}
+			r.count_lattice = cnt;
+			float t = startt; vec3 pos; cnt = 0;
+			while (aabb.contains(pos = ro + t * rdn) && cnt < NERF_STEPS) {
+				const float dt = calc_dt(t, cone_angle);
+				const uint32_t mip = mip_from_dt(dt, pos, max_mip);
+				if (density_grid_occupied_at(pos, bitfield, mip)) { ++cnt; t += dt; } else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
+			}
+			r.count_ref = cnt;
+		}
+		out[i] = r;
+	}
+}
+
 // -------------------------------------------------------------------------------------------------
 // K3: compute_loss_kernel_train_nerf, testbed_nerf.cu:852-1180 (no envmap / error-map / exposure: off by default; depth supervision
 // :1027-1029, :1126-1129 behind depth_lambda > 0).  __expf is restated as expf.

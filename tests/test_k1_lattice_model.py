@@ -86,3 +86,71 @@ def test_lattice_model_vs_reference_loop_fox(ora, frac, blk):
     assert res[1][0] >= 0.995 and res[1][1] <= 6
     assert abs(res[1][2] - int(seq.sum())) <= 2e-4 * seq.sum()
     assert res[0][0] < res[1][0]  # what the exact skip rule buys
+
+
+DIV = np.dtype([("cause", np.uint32), ("count_ref", np.uint32), ("count_lattice", np.uint32), ("t_ulps", np.float32), ("face", np.float32)])
+CAUSES = {0: "none", 1: "box face", 2: "cascade boundary", 3: "voxel face", 4: "skip lands on a lattice point", 5: "other"}
+
+
+def _divergence(ora, n_rays, aabb, n_img, M, X, bf, max_mip, cone):
+    out = np.zeros(n_rays, DIV)
+    ora.ora_k1_lattice_divergence(n_rays, aabb, _rng(ora), n_img, M, X, ptr(bf), max_mip, 1, C.c_float(cone), out.ctypes.data_as(C.c_void_p), 2048)
+    return out
+
+
+def _check_divergences(d, label, min_same_sequence, min_same_count, max_ulps, max_face, max_skip):
+    act = (d["count_ref"] > 0) | (d["count_lattice"] > 0)
+    div = d[act & (d["cause"] != 0)]
+    same_seq = 1.0 - div.size / max(act.sum(), 1)
+    same_cnt = float((d["count_ref"][act] == d["count_lattice"][act]).mean())
+    hist = {CAUSES[c]: int((div["cause"] == c).sum()) for c in sorted(set(div["cause"].tolist()))}
+    vox, skp = div[div["cause"] == 3], div[div["cause"] == 4]
+    print(f"{label}: {act.sum()} active rays; {same_seq * 100:.2f} % visit exactly the reference's points, {same_cnt * 100:.3f} % end with the reference's sample count "
+          f"(largest difference {np.abs(d['count_ref'].astype(int) - d['count_lattice'].astype(int)).max()}); first divergences by cause {hist}; "
+          f"|t_ref - t_lattice| <= {d['t_ulps'][act].max():.1f} ulp over all visited points; voxel-face cases within {vox['face'].max() if vox.size else 0:.2e} cells of a face; "
+          f"skip lengths within {skp['face'].max() if skp.size else 0:.2e} steps of an integer")
+    # WHAT differs: every ray that leaves the reference's sequence of visited points does so where the two (rounding-different) positions straddle a box face, a
+    # cascade boundary or a voxel face, or where a skip length is an integer number of steps up to rounding (its ceil() picks the landing point) -- never inside a cell
+    assert np.all(div["cause"] != 5), "a divergence inside one cell: the two marches are different algorithms"
+    assert d["t_ulps"][act].max() <= max_ulps  # the closed-form lattice and the accumulated t stay within a few ulp of each other
+    if vox.size:
+        assert vox["face"].max() <= max_face
+    if skp.size:
+        assert skp["face"].max() <= max_skip
+    assert same_seq >= min_same_sequence and same_cnt >= min_same_count
+    return same_seq, same_cnt
+
+
+def test_divergence_from_the_reference_loop_is_a_boundary_effect_lego_format(ora):
+    """not "the device equals its own model" but WHAT separates the production marcher's algorithm from testbed_nerf.cu:798-807."""
+    imgs, xforms, meta = make_small_dataset(6, 48)
+    M, X = host_meta(imgs, xforms, meta)
+    grid = np.zeros(N_CELLS, np.float32)
+    ora.ora_k_mark_untrained_density_grid(N_CELLS, ptr(grid), len(imgs), M, X, 1)
+    mask = (np.random.default_rng(3).uniform(size=N_CELLS // 512) < 0.35).repeat(512)
+    grid = np.where((grid >= 0) & mask, 0.05, grid).astype(np.float32)
+    bf = np.zeros(N_CELLS, np.uint8)
+    ora.ora_k_grid_to_bitfield(ptr(grid), 0, ptr(bf), C.c_float(ora.ora_k_density_grid_mean(ptr(grid))))
+    n_rays = 16384
+    d = _divergence(ora, n_rays, A.scene_aabb(1), len(imgs), M, X, bf, 0, 0.0)
+    _check_divergences(d, "lego-format", 0.95, 0.995, 64.0, 1e-3, 3e-3)  # measured: 96.2 %, 99.645 %, 21 ulp, 2.0e-4 cells, 6.1e-4 steps
+    # consistent with the count-level comparison above
+    m1 = _model_counts(ora, 1, n_rays, A.scene_aabb(1), _rng(ora), len(imgs), M, X, bf, 0, 0.0)
+    seq = _seq_counts(ora, n_rays, A.scene_aabb(1), _rng(ora), len(imgs), M, X, bf, 0, 0.0)
+    assert np.array_equal(d["count_lattice"], m1) and np.array_equal(d["count_ref"], seq)
+
+
+@pytest.mark.parametrize("frac,blk", [(0.3, 512), (0.05, 64)])
+def test_divergence_from_the_reference_loop_is_a_boundary_effect_fox(ora, frac, blk):
+    """The same on the full-resolution fox capture (cone_angle 1/256, three cascades, OpenCV lens)."""
+    import test_gpu_fox as F
+    t, imgs, M, X = F._load_fox()
+    n_img, aabb, n_el = len(imgs), A.scene_aabb(4), N_CELLS * 3
+    grid = np.zeros(n_el, np.float32)
+    ora.ora_k_mark_untrained_density_grid(n_el, ptr(grid), n_img, M, X, 1)
+    mask = (np.random.default_rng(1).uniform(size=n_el // blk) < frac).repeat(blk)
+    grid = np.where((grid >= 0) & mask, 0.05, grid).astype(np.float32)
+    bf = np.zeros(N_CELLS, np.uint8)
+    ora.ora_k_grid_to_bitfield(ptr(grid), 2, ptr(bf), C.c_float(0.01))
+    d = _divergence(ora, 8192, aabb, n_img, M, X, bf, 2, 1 / 256.0)
+    _check_divergences(d, f"fox frac {frac} blk {blk}", 0.97, 0.998, 256.0, 5e-4, 1e-3)  # measured: 98.3-98.7 %, 99.92-99.96 %, 128 ulp, 6.5e-5 cells, 1.4e-4 steps
