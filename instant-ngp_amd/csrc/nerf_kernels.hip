@@ -1467,7 +1467,13 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 	hipLaunchKernelGGL(k_generate_training_samples, dim3(blocks(max_rays_this_rank, 128)), dim3(128), 0, s, a);
 }
 // persistent grid: up to 8 workgroups of 4 wavefronts per CU; every workgroup owns at most K1_MAX_RANGE consecutive slots
-static uint32_t k1_grid(uint32_t max_local_rays) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * 8u), blocks(max_local_rays, K1_MAX_RANGE)); }
+// The marcher's grid must equal the number of RESIDENT workgroups: every workgroup owns a contiguous slot range, so workgroups that start only when others retire
+// are a second round at partial occupancy.  k1_count<8, true> (one cascade) holds 77 registers = 6 workgroups of 4 wavefronts per CU -- the grid of 8 per CU used up
+// to round 3a ran 1.33 rounds: K1 0.181 -> 0.171 ms, step 0.600 -> 0.587 ms with 6 (profiles/r03_microbench_k1_grid.log).  k1_count<8, false> (98 registers, 4 per CU)
+// keeps 8 = two full rounds.  Scratch is sized for the largest grid.
+constexpr uint32_t K1_MAX_BLOCKS_PER_CU = 16;
+static uint32_t k1_blocks_per_cu(bool single_cascade) { static const int env = [] { const char* e = getenv("NGP_K1_BLOCKS_PER_CU"); return e ? std::min(std::max(atoi(e), 1), (int)K1_MAX_BLOCKS_PER_CU) : 0; }(); return env ? (uint32_t)env : single_cascade ? 6u : 8u; }
+static uint32_t k1_grid(uint32_t max_local_rays, uint32_t blocks_per_cu = K1_MAX_BLOCKS_PER_CU) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * blocks_per_cu), blocks(max_local_rays, K1_MAX_RANGE)); }
 // byte offset of the workgroup totals behind the RaySetup and mask arrays (64-bit atomics: naturally aligned)
 static size_t k1_partial_offset(uint32_t max_local_rays) { return ((size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + 15) / 16 * 16; }
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
@@ -1489,7 +1495,7 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	char* p = (char*)scratch;
 	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
 	uint64_t* masks = (uint64_t*)p;
-	const uint32_t ray_grid = k1_grid(max_local_rays);
+	const uint32_t ray_grid = k1_grid(max_local_rays, k1_blocks_per_cu(a.max_mip == 0));
 	p = (char*)scratch + k1_partial_offset(max_local_rays);
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
@@ -1560,7 +1566,7 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 		else hipLaunchKernelGGL((k_compute_loss_v2<2, false, false>), g2, dim3(1024), 0, s, a);
 	}
 	else {
-		const uint32_t grid = k1_grid(max_rays);
+		const uint32_t grid = k1_grid(max_rays, 8);
 		float* rec = (float*)a.k3_scratch; uint64_t* partial = (uint64_t*)(rec + (size_t)max_rays * K3_REC); uint32_t* done = (uint32_t*)(partial + grid);
 		hipLaunchKernelGGL((k_compute_loss_v3<0>), dim3(grid), dim3(256), 0, s, a, rec, partial, done);
 		hipLaunchKernelGGL((k_compute_loss_v3<1>), dim3(grid), dim3(256), 0, s, a, rec, partial, done);
