@@ -202,7 +202,7 @@ def run_ab_psnr(lib, scene, args, steps, seeds=(1337,)):
     return out
 
 
-def calibrate():
+def calibrate(lib=None):
     """Two seconds of box calibration, printed in `config.calibration`: boxes of this pool differ by 15-35 % on the same binary, so a line carries the
     means to tell a slow box from a regression -- device-to-device copy rate of a 1 GiB buffer (read + write bytes) and the rate of a fixed fp16 GEMM
     (8192^3 through the library GEMM: MFMA clocks)."""
@@ -224,7 +224,14 @@ def calibrate():
     gemm_tflops = 4 * 2 * 8192 ** 3 / (1e9 * e0.elapsed_time(e1))
     del x, y
     torch.cuda.empty_cache()
-    return {"d2d_copy_GBps": round(copy_gbs, 1), "fp16_gemm_8192_TFLOPs": round(gemm_tflops, 1),
+    extra = {}
+    if lib is not None:  # shader clock seen by a light kernel: the pool's boxes come in two classes that copy / GEMM rates do not separate (W: 47 vs 70 us)
+        ns = C.c_float()
+        if lib.ngp_debug_clock_probe(C.byref(ns)) == 0:
+            extra["valu_dependent_fma_ns"] = round(ns.value, 4)
+    pr = torch.cuda.get_device_properties(0)
+    extra["device"] = {"name": pr.name, "compute_units": pr.multi_processor_count, "clock_rate_khz": getattr(pr, "clock_rate", None)}
+    return {"d2d_copy_GBps": round(copy_gbs, 1), "fp16_gemm_8192_TFLOPs": round(gemm_tflops, 1), **extra,
             "reference_fast_box": {"d2d_copy_GBps": 5800.0, "note": "profiles/r03_dp_diag2_comm_after_training.txt: 5.77-5.80 TB/s read+write on the box that ran 0.65 ms per step"}}
 
 
@@ -301,7 +308,7 @@ def main():
         lib.ngp_debug_set_flags(int(os.environ["NGP_DEBUG_FLAGS"], 0))
     assert lib.ngp_device_available() == 1
 
-    calibration = None if args.no_calibration else calibrate()
+    calibration = None if args.no_calibration else calibrate(lib)
     scene = load_scene(args)
     if args.scaling == "strong":  # total work fixed: every rank trains B / N samples per step (the library needs a multiple of 256)
         args.batch = max(256, args.batch // world // 256 * 256)

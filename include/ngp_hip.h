@@ -150,6 +150,8 @@ int ngp_device_available(void);
  * communication (RCCL / torch.distributed "nccl") BEFORE its first model calls this first: on ROCm 7.0 streams that come into existence after an RCCL
  * communicator run their kernels 1.3 - 2x slower (profiles/r03_dp_overhead.txt).  New; no counterpart in the reference. */
 int ngp_init(void);
+/* Box calibration: nanoseconds per dependent fp32 FMA of a single wavefront (= the shader clock a light kernel gets; bench.py config.calibration). Blocks. */
+int ngp_debug_clock_probe(float* ns_per_dependent_fma_host);
 
 /* ------------------------------------------------------------------ model ---------------- */
 

@@ -62,6 +62,32 @@ static void prof_collect() {
 	}
 	g_prof.clear();
 }
+// Box calibration (bench.py config.calibration): shader-clock probe.  One wavefront per SIMD runs a chain of DEPENDENT fp32 FMAs -- nothing but the VALU issue rate of
+// a single wavefront, i.e. the shader clock the box grants a light kernel (the pool's boxes come in two classes that a GEMM or a copy does not tell apart, because those
+// run power- or memory-bound: the compute- and latency-bound kernels of this library run 1.1 - 1.5 x slower on one class).  Returns nanoseconds per dependent FMA.
+__global__ void __launch_bounds__(64) k_clock_probe(uint32_t iters, float* __restrict__ out) {
+	float x = (float)threadIdx.x * 1e-3f, a = 1.0000001f, b = 1e-7f;
+	for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+		for (int k = 0; k < 16; ++k) x = __builtin_fmaf(x, a, b);
+	}
+	if (x == 123.456f) out[0] = x; // never true: keeps the chain alive
+}
+extern "C" int ngp_debug_clock_probe(float* ns_per_dependent_fma_host) {
+	REQUIRE(ns_per_dependent_fma_host, "ngp_debug_clock_probe: null argument");
+	float* d = nullptr; HIPCHK(hipMalloc((void**)&d, 4));
+	hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+	const uint32_t iters = 1u << 16; // x 16 FMAs = 1.05 M dependent operations per wavefront
+	hipLaunchKernelGGL(k_clock_probe, dim3(1024), dim3(64), 0, nullptr, 1024u, d); // warm up (clock ramp)
+	HIPCHK(hipEventRecord(e0, nullptr));
+	hipLaunchKernelGGL(k_clock_probe, dim3(1024), dim3(64), 0, nullptr, iters, d);
+	HIPCHK(hipEventRecord(e1, nullptr));
+	HIPCHK(hipEventSynchronize(e1));
+	float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	*ns_per_dependent_fma_host = ms * 1e6f / ((float)iters * 16.f);
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+	return 0;
+}
 extern "C" int ngp_profile_enable(int on) {
 	prof_collect();
 	g_prof_on = on != 0;
