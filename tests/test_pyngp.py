@@ -51,6 +51,13 @@ def test_pyngp_loads_scene_like_the_reference(scene_dir):
     lin = np.where(a[..., :3] <= 0.04045, a[..., :3] / 12.92, ((a[..., :3] + 0.055) / 1.055) ** 2.4) * a[..., 3:4]
     assert ref.shape == (64, 64, 4) and np.abs(ref[..., :3] - lin).max() < 1e-5 and np.all(ref[..., 3] == 1.0)
     assert abs(t.fov - math.degrees(synth_scene.CAMERA_ANGLE_X)) < 1e-3
+    # Training members of python_api.cu:781-853 added in round 3: depth supervision, error-proportional sampling (defaults of testbed.h:796, 810-811, 824)
+    tr = t.nerf.training
+    assert tr.depth_supervision_lambda == 0.0 and tr.depth_loss_type == ngp.LossType.L1
+    assert tr.sample_focal_plane_proportional_to_error is False and tr.sample_image_proportional_to_error is False and tr.accumulate_error_map is False
+    tr.sample_image_proportional_to_error = True; tr.sample_focal_plane_proportional_to_error = True
+    assert tr.sample_image_proportional_to_error and tr.sample_focal_plane_proportional_to_error
+    tr.sample_image_proportional_to_error = False; tr.sample_focal_plane_proportional_to_error = False
     with pytest.raises(RuntimeError):
         t.load_training_data("/nonexistent/path")
     with pytest.raises(RuntimeError):
