@@ -1,6 +1,7 @@
 // mesh_lite.hpp -- minimal Wavefront OBJ and binary STL readers for the SDF primitive's data path (reference: load_obj via tinyobjloader,
 // src/tinyobj_loader_wrapper.cpp; dependencies/tinyobjloader is not used).  Output: 3 vertices per triangle, faces with more than three
-// corners fan-triangulated like tinyobjloader's `triangulate` default; texture / normal indices, groups and materials are ignored.
+// corners triangulated like tinyobjloader's `triangulate` default for quads (shorter diagonal) and as a fan for five and more corners (tinyobjloader clips ears there:
+// same surface for planar convex faces, other triangles); texture / normal indices, groups and materials are ignored.
 // load_stl: testbed_sdf.cu:1328-1361 (binary only: 80-byte header, uint32 face count, 50-byte faces = normal, 3 vertices, attribute word).
 #pragma once
 #include <cstdlib>
@@ -11,6 +12,18 @@
 #include <vector>
 
 namespace mesh_lite {
+
+// tinyobjloader's rule for quads (tiny_obj_loader.h, `triangulate`): [0, 1, 2] + [0, 2, 3] iff |v2 - v0|^2 < |v3 - v1|^2 in fp32, else [0, 1, 3] + [1, 2, 3].
+// Evaluated without FMA contraction, like the reference's host build (pinned against the library itself: tests/test_ref_loaders.py).
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("fp-contract=off")))
+#endif
+inline bool quad_splits_along_02(const float* v0, const float* v1, const float* v2, const float* v3) {
+	const float ax = v2[0] - v0[0], ay = v2[1] - v0[1], az = v2[2] - v0[2], bx = v3[0] - v1[0], by = v3[1] - v1[1], bz = v3[2] - v1[2];
+	volatile float a0 = ax * ax, a1 = ay * ay, a2 = az * az, b0 = bx * bx, b1 = by * by, b2 = bz * bz; // volatile: every product is rounded to fp32 before the sums
+	const float sqr02 = a0 + a1 + a2, sqr13 = b0 + b1 + b2;
+	return sqr02 < sqr13;
+}
 
 inline std::vector<float> load_obj(const std::string& path) {
 	std::ifstream f{path};
@@ -40,8 +53,11 @@ inline std::vector<float> load_obj(const std::string& path) {
 				if (i < 0 || i >= nv) throw std::runtime_error{"obj: face index out of range in '" + path + "'"};
 				idx.push_back(i);
 			}
-			for (size_t k = 2; k < idx.size(); ++k)
-				for (long q : {idx[0], idx[k - 1], idx[k]}) for (int c = 0; c < 3; ++c) out.push_back(v[(size_t)q * 3 + c]);
+			auto emit = [&](long q0, long q1, long q2) { for (long q : {q0, q1, q2}) for (int c = 0; c < 3; ++c) out.push_back(v[(size_t)q * 3 + c]); };
+			if (idx.size() == 4 && !quad_splits_along_02(&v[(size_t)idx[0] * 3], &v[(size_t)idx[1] * 3], &v[(size_t)idx[2] * 3], &v[(size_t)idx[3] * 3])) {
+				emit(idx[0], idx[1], idx[3]); emit(idx[1], idx[2], idx[3]); // tinyobjloader: a quad is split along its SHORTER diagonal (1-3 here, and on a tie)
+			} else
+			for (size_t k = 2; k < idx.size(); ++k) emit(idx[0], idx[k - 1], idx[k]);
 		}
 	}
 	if (out.empty()) throw std::runtime_error{"obj: no faces in '" + path + "'"};

@@ -45,6 +45,7 @@ PYBIND11_MODULE(pyngp, m) {
 		std::memcpy(out.mutable_data(), v.data(), v.size() * sizeof(float));
 		return out;
 	});
+	m.def("_natural_less", [](const std::string& a, const std::string& b) { return Testbed::natural_path_less(a, b); }); // not part of the reference API: the loader's frame order, for tests
 	m.def("read_stl", [](const std::string& path) { // binary STL (testbed_sdf.cu:1328-1361), float32 [n_triangles][3][3]
 		const std::vector<float> v = mesh_lite::load_stl(path);
 		py::array_t<float> out({(py::ssize_t)(v.size() / 9), (py::ssize_t)3, (py::ssize_t)3});

@@ -131,27 +131,59 @@ static bool decode_builtin(const std::string& path, int& w, int& h, std::vector<
 bool Testbed::read_image_builtin(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) { return decode_builtin(path, w, h, rgba); }
 bool Testbed::read_depth_png16(const std::string& path, int& w, int& h, std::vector<uint16_t>& gray) { return decode_png_gray16(path, w, h, gray); }
 
-// natural (numeric-aware) ordering of frame paths, nerf_loader.cu:347-349
+// Natural ordering of frame paths, nerf_loader.cu:347-349: `SI::natural::compare<std::string>` of the NaturalSort library the reference vendors, restated from its
+// behaviour and pinned against the library itself (tests/test_ref_loaders.py, oracle/_ref): characters compare case-INSENSITIVELY; runs of digits compare as numbers
+// (leading zeros ignored, then length, then digits), except that a run directly behind a '.' is a fractional part (digit by digit, trailing zeros ignored; against a
+// non-fractional run it is "greater" on the left and a tie on the right -- the library's `return true / false` from an int function); a run of blanks behind a blank is
+// skipped; when one string ends first it is the smaller one.  Equivalent names ("r_01" / "r_1") keep their file order here (stable sort; the reference's std::sort leaves
+// their order unspecified).
 static bool natural_less(const std::string& a, const std::string& b) {
+	auto at = [](const std::string& s, size_t i) -> unsigned char { return i < s.size() ? (unsigned char)s[i] : 0; };
+	auto lower_less = [](unsigned char x, unsigned char y) { return tolower(x) < tolower(y); };
+	auto digits_end = [](const std::string& s, size_t i) { while (i < s.size() && isdigit((unsigned char)s[i])) ++i; return i; };
 	size_t i = 0, j = 0;
+	bool blank1 = false, blank2 = false;
 	while (i < a.size() && j < b.size()) {
-		if (isdigit((unsigned char)a[i]) && isdigit((unsigned char)b[j])) {
-			size_t ie = i, je = j;
-			while (ie < a.size() && isdigit((unsigned char)a[ie])) ++ie;
-			while (je < b.size() && isdigit((unsigned char)b[je])) ++je;
-			const std::string na = a.substr(i, ie - i), nb = b.substr(j, je - j);
-			const size_t za = na.find_first_not_of('0'), zb = nb.find_first_not_of('0');
-			const std::string ta = za == std::string::npos ? "0" : na.substr(za), tb = zb == std::string::npos ? "0" : nb.substr(zb);
-			if (ta.size() != tb.size()) return ta.size() < tb.size();
-			if (ta != tb) return ta < tb;
-			i = ie; j = je;
-		} else {
-			if (a[i] != b[j]) return a[i] < b[j];
+		while (blank1 && i < a.size() && a[i] == ' ') ++i;
+		blank1 = at(a, i) == ' ';
+		while (blank2 && j < b.size() && b[j] == ' ') ++j;
+		blank2 = at(b, j) == ' ';
+		const unsigned char ca = at(a, i), cb = at(b, j);
+		if (!isdigit(ca) || !isdigit(cb)) {
+			if (lower_less(ca, cb)) return true;
+			if (lower_less(cb, ca)) return false;
+			if (i >= a.size() || j >= b.size()) break; // (both ran out behind trailing blanks: equivalent)
 			++i; ++j;
+			continue;
 		}
+		const size_t ie = digits_end(a, i), je = digits_end(b, j);
+		const bool frac1 = i > 0 && a[i - 1] == '.', frac2 = j > 0 && b[j - 1] == '.';
+		int r = 0;
+		if (frac1 && !frac2) r = 1;
+		else if (!frac1 && frac2) r = 0;
+		else if (frac1) {
+			size_t p = i, q = j;
+			while (p < ie && q < je && r == 0) { r = a[p] < b[q] ? -1 : a[p] > b[q] ? 1 : 0; if (r == 0) { ++p; ++q; } }
+			if (r == 0) {
+				while (p < ie && a[p] == '0') ++p;
+				while (q < je && b[q] == '0') ++q;
+				r = (p == ie && q != je) ? -1 : (p != ie && q == je) ? 1 : 0;
+			}
+		} else {
+			size_t p = i, q = j;
+			while (p < ie && a[p] == '0') ++p;
+			while (q < je && b[q] == '0') ++q;
+			if (ie - p != je - q) r = ie - p < je - q ? -1 : 1;
+			else for (; p < ie && r == 0; ++p, ++q) r = a[p] < b[q] ? -1 : a[p] > b[q] ? 1 : 0;
+		}
+		if (r < 0) return true;
+		if (r > 0) return false;
+		i = ie; j = je;
 	}
-	return a.size() - i < b.size() - j;
+	if (i >= a.size() && j >= b.size()) return false;
+	return i >= a.size();
 }
+bool Testbed::natural_path_less(const std::string& a, const std::string& b) { return natural_less(a, b); }
 
 // ------------------------------------------------------------------------------------------------
 Testbed::Testbed() {

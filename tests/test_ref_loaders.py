@@ -1,0 +1,145 @@
+"""CPU: the host's data-format readers against the reference's OWN dependencies, compiled from /root/reference where they lie into oracle/_ref/libloaders_ref.so
+(oracle/ref_loaders_wrapper.cpp; test infrastructure, git-ignored, built by oracle/Makefile when the reference tree is present):
+  host/exr_lite.hpp   vs tinyexr's LoadEXR (what src/tinyexr_wrapper.cu calls)                    -- every pixel, bit for bit
+  the frame order     vs NaturalSort's SI::natural::compare (nerf_loader.cu:347-349)              -- the same strict weak order on awkward names
+  host/mesh_lite.hpp  vs tinyobjloader's LoadObj as src/tinyobj_loader_wrapper.cu drives it       -- every triangle, bit for bit
+Skipped when oracle/_ref is not built (a checkout without the reference tree)."""
+import ctypes as C
+import itertools
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+SO = os.path.join(ROOT, "oracle", "_ref", "libloaders_ref.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(SO):
+        pytest.skip("oracle/_ref/libloaders_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    lib = C.CDLL(SO)
+    lib.ref_obj_load_triangles.restype = C.c_longlong
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ngp():
+    import pyngp
+    return pyngp
+
+
+def _ref_exr(ref, path):
+    w, h = C.c_int(), C.c_int()
+    assert ref.ref_exr_load_rgba(path.encode(), C.byref(w), C.byref(h), None) == 1, path
+    out = np.zeros((h.value, w.value, 4), np.float32)
+    assert ref.ref_exr_load_rgba(path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_float))) == 1
+    return out
+
+
+def test_exr_reader_equals_tinyexr_on_albert(ref, ngp):
+    src = os.path.join(ROOT, "_ref_data", "data", "image", "albert.exr")
+    if not os.path.exists(src):
+        pytest.skip("_ref_data/ not staged")
+    a, b = ngp.read_exr(src), _ref_exr(ref, src)
+    assert a.shape == b.shape == (1024, 1024, 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("compression", [0, 2, 3])  # NO, ZIPS (one scan line per block), ZIP (16 lines per block)
+@pytest.mark.parametrize("pixel_type", ["float", "half"])
+def test_exr_reader_equals_tinyexr_on_written_files(ref, ngp, tmp_path, compression, pixel_type):
+    """scan-line files written here by the published layout (RGBA, channels in file order A B G R, odd sizes, values incl. negatives / huge / denormals):
+    both readers must return the same floats"""
+    import struct
+    import zlib
+    w, h = 37, 21
+    rs = np.random.default_rng(7)
+    px = rs.normal(0, 3, (h, w, 4)).astype(np.float32)
+    px[0, 0] = [0.0, -0.0, 65504.0, 1e-7]; px[1, 1] = [1e4, -1e4, 6e-8, 1.0]
+    if pixel_type == "half":
+        px = px.astype(np.float16).astype(np.float32)
+    tcode, dt = (2, np.float32) if pixel_type == "float" else (1, np.float16)
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", tcode, 0, 1, 1) for n in ("A", "B", "G", "R")) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    head = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression])) + \
+        attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+        attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines_per_block = 16 if compression == 3 else 1
+
+    def zip_block(raw):  # OpenEXR ZIP: de-interleave even / odd bytes, delta-predict, deflate; stored raw when that is not smaller
+        t = bytes(raw[0::2]) + bytes(raw[1::2])
+        d = bytearray(len(t)); d[0] = t[0]
+        for i in range(1, len(t)):
+            d[i] = (t[i] - t[i - 1] + 128) & 255
+        z = zlib.compress(bytes(d))
+        return z if len(z) < len(raw) else raw
+    blocks = []
+    for y0 in range(0, h, lines_per_block):
+        raw = b"".join(px[y, :, k].astype(dt).tobytes() for y in range(y0, min(y0 + lines_per_block, h)) for k in (3, 2, 1, 0))
+        data = raw if compression == 0 else zip_block(raw)
+        blocks.append(struct.pack("<ii", y0, len(data)) + data)
+    offs, pos = [], len(head) + 8 * len(blocks)
+    for b in blocks:
+        offs.append(pos); pos += len(b)
+    f = tmp_path / f"t_{compression}_{pixel_type}.exr"
+    f.write_bytes(head + struct.pack(f"<{len(blocks)}Q", *offs) + b"".join(blocks))
+    a, b = ngp.read_exr(str(f)), _ref_exr(ref, str(f))
+    assert a.shape == b.shape == (h, w, 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
+    assert np.array_equal(a.view(np.uint32), px.view(np.uint32))  # and both return what was written
+
+
+def test_frame_order_equals_naturalsort(ref, ngp):
+    names = ["r_0.png", "r_1.png", "r_2.png", "r_10.png", "r_010.png", "r_9.png", "r_09.png", "r_100.png", "r_1a.png", "r_1b2.png", "r_1b10.png", "images/0001.jpg",
+             "images/0002.jpg", "images/0010.jpg", "images/2.jpg", "images/10", "images/10.png", "a", "a0", "a00", "a1", "b", "", "0", "00", "1", "01", "10", "2", "A1", "a_1", "a-1",
+             "frame_1_2", "frame_1_10", "frame_01_3", "x9y8", "x9y10", "x10y1", "./train/r_7", "./train/r_70", "./train/r_8"]
+    for a, b in itertools.product(names, repeat=2):
+        assert bool(ref.ref_natural_less(a.encode(), b.encode())) == ngp._natural_less(a, b), (a, b)
+    # the dataset's own frames: sorted the same way
+    import json
+    tf = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
+    if os.path.exists(tf):
+        paths = [f["file_path"] for f in json.load(open(tf))["frames"]]
+        import functools
+        cmp_ref = functools.cmp_to_key(lambda a, b: -1 if ref.ref_natural_less(a.encode(), b.encode()) else (1 if ref.ref_natural_less(b.encode(), a.encode()) else 0))
+        cmp_own = functools.cmp_to_key(lambda a, b: -1 if ngp._natural_less(a, b) else (1 if ngp._natural_less(b, a) else 0))
+        assert sorted(paths, key=cmp_ref) == sorted(paths, key=cmp_own)
+
+
+def _ref_obj(ref, path):
+    n = ref.ref_obj_load_triangles(path.encode(), None, C.c_longlong(0))
+    assert n > 0 and n % 9 == 0, n
+    out = np.zeros(n, np.float32)
+    assert ref.ref_obj_load_triangles(path.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_longlong(n)) == n
+    return out.reshape(-1, 3, 3)
+
+
+def test_obj_reader_equals_tinyobjloader_on_armadillo(ref, ngp):
+    src = os.path.join(ROOT, "_ref_data", "data", "sdf", "armadillo.obj")
+    if not os.path.exists(src):
+        pytest.skip("_ref_data/ not staged")
+    a, b = ngp.read_obj(src), _ref_obj(ref, src)
+    assert a.shape == b.shape and a.shape[0] == 99976
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_obj_reader_equals_tinyobjloader_on_awkward_file(ref, ngp, tmp_path):
+    """comments, texture / normal indices, negative (relative) indices, quads (tinyobjloader splits them along the shorter diagonal: both cases and the tie), exponents,
+    CRLF line ends, several groups / objects.  (Faces with five and more corners are ear-clipped by tinyobjloader and fanned here: same surface for planar convex faces,
+    other triangles -- not compared.)"""
+    txt = "\r\n".join([
+        "# a comment", "o first", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0.5 0.5 1e0", "v -2.5e-1 3.25 +4", "vt 0 0", "vt 1 1", "vn 0 0 1",
+        "g tri", "f 1 2 3", "f 1/1 3/2 4/1", "f 1//1 2//1 5//1", "f 2/1/1 3/2/1 5/1/1",
+        "g quad", "f 1 2 3 4", "f -6 -5 -4 -3", "f 1 2 6 4", "f 2 6 4 1", "f 5 6 1 2", "o second", "f 6 5 4", ""])
+    f = tmp_path / "awkward.obj"; f.write_text(txt)
+    a, b = ngp.read_obj(str(f)), _ref_obj(ref, str(f))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
