@@ -231,6 +231,15 @@ def calibrate(lib=None):
             extra["valu_dependent_fma_ns"] = round(ns.value, 4)
     pr = torch.cuda.get_device_properties(0)
     extra["device"] = {"name": pr.name, "compute_units": pr.multi_processor_count, "clock_rate_khz": getattr(pr, "clock_rate", None)}
+    try:  # the box's management view (power cap, clock range, performance level, partition modes): one of these may be what separates the two box classes
+        import subprocess
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showmaxpower", "--showpower", "--showsclkrange", "--showperflevel", "--showcomputepartition", "--showmemorypartition", "--showclocks", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout) if r.returncode == 0 and r.stdout.strip().startswith("{") else {}
+        card = next(iter(j.values()), {}) if isinstance(j, dict) else {}
+        extra["rocm_smi"] = {k: v for k, v in card.items() if isinstance(v, (str, int, float))} or {"raw": (r.stdout or r.stderr)[:400]}
+    except Exception as e:  # (no rocm-smi, no permission, timeout: the line does not depend on it)
+        extra["rocm_smi"] = {"unavailable": str(e)[:200]}
     return {"d2d_copy_GBps": round(copy_gbs, 1), "fp16_gemm_8192_TFLOPs": round(gemm_tflops, 1), **extra,
             "reference_fast_box": {"d2d_copy_GBps": 5800.0, "note": "profiles/r03_dp_diag2_comm_after_training.txt: 5.77-5.80 TB/s read+write on the box that ran 0.65 ms per step"}}
 
