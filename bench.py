@@ -318,6 +318,9 @@ def main():
     assert lib.ngp_device_available() == 1
 
     calibration = None if args.no_calibration else calibrate(lib)
+    # what is NOT the production path must be visible in the line: ablation bits in effect (ngp_debug_set_flags / NGP_DEBUG_FLAGS_OR) and every NGP_* environment knob
+    lib.ngp_debug_get_flags.restype = C.c_uint32
+    ablation = {"debug_flags": int(lib.ngp_debug_get_flags()), "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("NGP_")}}
     scene = load_scene(args)
     if args.scaling == "strong":  # total work fixed: every rank trains B / N samples per step (the library needs a multiple of 256)
         args.batch = max(256, args.batch // world // 256 * 256)
@@ -496,6 +499,7 @@ def main():
                        "test_psnr_db": psnr, "test_psnr_at_step": (psnr_step if psnr is not None else None),
                        "test_psnr_views": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "test_psnr_eval_seconds": round(t_eval, 3),
                        **({"calibration": calibration} if calibration else {}),
+                       "production_path": ablation["debug_flags"] == 0 and not ablation["env_knobs"], **({"ablation": ablation} if (ablation["debug_flags"] or ablation["env_knobs"]) else {}),
                        **({"dp_host_enqueue_ms_per_step": host_ms} if host_ms else {}),
                        **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {}),
                        **({"ab_psnr": ab} if ab else {})},

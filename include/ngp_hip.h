@@ -476,6 +476,8 @@ int ngp_host_pos_to_uv(const ngp_image_meta* meta, const float xform12[12], cons
 int ngp_host_xform_given_rolling_shutter(const ngp_xform* xform, const float rolling_shutter[4], const float uv[2], float motionblur_time, float xform12_out[12]);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);
+/* The switches in effect (NGP_DEBUG_FLAGS_OR from the environment included); 0 = the production path. */
+uint32_t ngp_debug_get_flags(void);
 /* train mode of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options) */
 int ngp_debug_set_train_mode(int mode);
 /* depth supervision of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options; testbed_nerf.cu:1027-1029, 1126-1129) */

@@ -117,6 +117,7 @@ extern "C" int ngp_host_pos_to_uv(const ngp_image_meta* m, const float xform12[1
 static uint32_t env_debug_or() { static const uint32_t v = getenv("NGP_DEBUG_FLAGS_OR") ? (uint32_t)strtoul(getenv("NGP_DEBUG_FLAGS_OR"), nullptr, 0) : 0u; return v; }
 static const bool g_debug_env_applied = [] { g_debug_flags |= env_debug_or(); return true; }();
 extern "C" int ngp_debug_set_flags(uint32_t flags) { g_debug_flags = flags | env_debug_or(); return 0; }
+extern "C" uint32_t ngp_debug_get_flags(void) { return g_debug_flags; } // what is in effect, NGP_DEBUG_FLAGS_OR included (bench.py records it: 0 = the production path)
 // layout of the hashed levels' binned scatter (tuning / test hook): table entries per chunk (2^11 or 2^12), one block per chunk
 // (split = 0) or per (chunk, feature pair) (split = 1), and a list-capacity override (0 = twice the mean; small values force the
 // overflow path of k_grad_bin).  NGP_BIN_CHUNK_LOG2 / NGP_BIN_SPLIT / NGP_BIN_CAP in the environment set the defaults.
