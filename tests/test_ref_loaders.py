@@ -143,3 +143,60 @@ def test_obj_reader_equals_tinyobjloader_on_awkward_file(ref, ngp, tmp_path):
     a, b = ngp.read_obj(str(f)), _ref_obj(ref, str(f))
     assert a.shape == b.shape, (a.shape, b.shape)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _write_with_reference(w, h, compression, half, path, seed=0):
+    """The reference's own tinyexr ENCODER writes the file (in a child process: its PIZ encoder corrupts the heap on very small images)."""
+    import subprocess
+    code = (f"import ctypes as C, numpy as np\n"
+            f"ref = C.CDLL({SO!r})\n"
+            f"px = np.random.default_rng({seed}).normal(0, 3, ({h}, {w}, 4)).astype(np.float32); px[..., 3] = 1.0; px[0, 0, :3] = [65504.0, -0.0, 1e-7]\n"
+            f"np.save({path + '.npy'!r}, px)\n"
+            f"assert ref.ref_exr_save_rgba({path!r}.encode(), {w}, {h}, px.ctypes.data_as(C.POINTER(C.c_float)), {compression}, {int(half)}) == 1\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    return r.returncode == 0 and os.path.exists(path)
+
+
+@pytest.mark.parametrize("compression", [1, 4])  # RLE, PIZ
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("size", [(37, 45), (64, 32), (600, 70), (33, 33), (129, 97)])
+def test_exr_rle_and_piz_written_by_tinyexr(ref, ngp, tmp_path, compression, half, size):
+    """RLE and PIZ (wavelet + Huffman; 32 scan lines per block; the 600-wide float case has > 2^14 distinct words per block = the 16-bit wavelet, the small ones the
+    14-bit one) files written by the reference's encoder: the host reader, tinyexr's reader and the written data agree bit for bit"""
+    w, h = size
+    f = str(tmp_path / f"t_{w}x{h}_{compression}_{int(half)}.exr")
+    if not _write_with_reference(w, h, compression, half, f):
+        pytest.skip("the reference's tinyexr encoder failed on this shape")
+    px = np.load(f + ".npy")
+    exp = px.astype(np.float16).astype(np.float32) if half else px
+    a, b = ngp.read_exr(f), _ref_exr(ref, f)
+    assert a.shape == b.shape == (h, w, 4)
+    if not half:  # (the encoder's float -> half conversion is its own business: it rounds a few subnormals differently from numpy)
+        assert np.array_equal(b.view(np.uint32), exp.view(np.uint32))
+    else:
+        assert np.allclose(b, exp, rtol=2e-3, atol=1e-7)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (np.abs(a - b).max(), int((a != b).sum()))
+
+
+def test_exr_piz_reader_survives_corruption(ref, tmp_path):
+    """every size, code length and offset in a PIZ block comes from the file: 400 random corruptions of block bytes must end in RuntimeError or a decoded image,
+    never in a crash (run in a child process so that a crash is a failure of this test, not of the session)"""
+    import subprocess
+    f = str(tmp_path / "p.exr")
+    if not _write_with_reference(96, 40, 4, True, f):
+        pytest.skip("the reference's tinyexr encoder failed")
+    code = (f"import sys, numpy as np\nsys.path.insert(0, {os.path.join(ROOT, 'instant-ngp_amd')!r})\nimport pyngp as ngp\n"
+            f"data = bytearray(open({f!r}, 'rb').read()); rs = np.random.default_rng(3); n_ok = n_err = 0\n"
+            f"start = len(data) // 6\n"
+            f"for t in range(400):\n"
+            f"    d = bytearray(data)\n"
+            f"    for _ in range(int(rs.integers(1, 6))):\n"
+            f"        d[int(rs.integers(start, len(d)))] = int(rs.integers(0, 256))\n"
+            f"    if t % 7 == 0: d = d[: int(rs.integers(start, len(d)))]\n"
+            f"    open({f + '.bad'!r}, 'wb').write(d)\n"
+            f"    try:\n        ngp.read_exr({f + '.bad'!r}); n_ok += 1\n    except RuntimeError: n_err += 1\n"
+            f"print(n_ok, n_err)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+    n_ok, n_err = map(int, r.stdout.split())
+    assert n_ok + n_err == 400 and n_err > 50
