@@ -1,9 +1,10 @@
 // mesh_lite.hpp -- minimal Wavefront OBJ and binary STL readers for the SDF primitive's data path (reference: load_obj via tinyobjloader,
 // src/tinyobj_loader_wrapper.cpp; dependencies/tinyobjloader is not used).  Output: 3 vertices per triangle, faces with more than three
-// corners triangulated like tinyobjloader's `triangulate` default for quads (shorter diagonal) and as a fan for five and more corners (tinyobjloader clips ears there:
-// same surface for planar convex faces, other triangles); texture / normal indices, groups and materials are ignored.
+// corners triangulated like tinyobjloader's `triangulate` default: quads along the shorter diagonal, five and more corners by its ear clipping; texture / normal indices,
+// groups and materials are ignored.
 // load_stl: testbed_sdf.cu:1328-1361 (binary only: 80-byte header, uint32 face count, 50-byte faces = normal, 3 vertices, attribute word).
 #pragma once
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -25,12 +26,62 @@ inline bool quad_splits_along_02(const float* v0, const float* v1, const float* 
 	return sqr02 < sqr13;
 }
 
+// tinyobjloader's triangulation of faces with five and more corners (its built-in ear clipping), restated from the library's behaviour and pinned against the library
+// itself (tests/test_ref_loaders.py): the face is projected onto two coordinate axes chosen from its first non-degenerate corner, then corners are clipped in a fixed
+// walk -- a candidate (v0, v1, v2) starting at `guess` is an ear unless cross * "area" < 0 (the library's own sign test) or another remaining corner lies inside it
+// (crossing-number test); an ear removes v1; a rejected candidate advances `guess`; the walk gives up when no corner could be removed for a full round.  fp32, no
+// FMA contraction (see quad_splits_along_02).  Appends vertex indices (three per triangle) to `tri`.
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("fp-contract=off")))
+#endif
+inline void ear_clip_like_tinyobj(const std::vector<float>& v, const std::vector<long>& face, std::vector<long>& tri) {
+	auto vol = [](float x) { volatile float y = x; return y; }; // every product / sum rounded to fp32 on its own
+	size_t axes[2] = {1, 2};
+	const size_t n0 = face.size();
+	for (size_t k = 0; k < n0; ++k) {
+		const float* a = &v[(size_t)face[k % n0] * 3]; const float* b = &v[(size_t)face[(k + 1) % n0] * 3]; const float* c = &v[(size_t)face[(k + 2) % n0] * 3];
+		const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2], e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+		const float cx = std::fabs(vol(vol(e0y * e1z) - vol(e0z * e1y))), cy = std::fabs(vol(vol(e0z * e1x) - vol(e0x * e1z))), cz = std::fabs(vol(vol(e0x * e1y) - vol(e0y * e1x)));
+		const float eps = 1.1920928955078125e-07f; // std::numeric_limits<float>::epsilon()
+		if (cx > eps || cy > eps || cz > eps) {
+			if (!(cx > cy && cx > cz)) { axes[0] = 0; if (cz > cx && cz > cy) axes[1] = 1; }
+			break;
+		}
+	}
+	std::vector<long> rem = face;
+	size_t guess = 0, remaining_iterations = rem.size(), previous = rem.size();
+	while (rem.size() > 3 && remaining_iterations > 0) {
+		const size_t np = rem.size();
+		if (guess >= np) guess -= np;
+		if (previous != np) { previous = np; remaining_iterations = np; } else --remaining_iterations;
+		long ind[3]; float vx[3], vy[3];
+		for (size_t k = 0; k < 3; ++k) { ind[k] = rem[(guess + k) % np]; vx[k] = v[(size_t)ind[k] * 3 + axes[0]]; vy[k] = v[(size_t)ind[k] * 3 + axes[1]]; }
+		const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+		const float cross = vol(vol(e0x * e1y) - vol(e0y * e1x));
+		const float area = vol(vol(vol(vx[0] * vy[1]) - vol(vy[0] * vx[1])) * 0.5f);
+		if (vol(cross * area) < 0.0f) { guess += 1; continue; }
+		bool overlap = false;
+		for (size_t other = 3; other < np && !overlap; ++other) {
+			const size_t idx = (guess + other) % np;
+			const float tx = v[(size_t)rem[idx] * 3 + axes[0]], ty = v[(size_t)rem[idx] * 3 + axes[1]];
+			int c = 0; // crossing number of (tx, ty) against the candidate triangle
+			for (int i = 0, j = 2; i < 3; j = i++)
+				if (((vy[i] > ty) != (vy[j] > ty)) && (tx < vol(vol(vol(vol(vx[j] - vx[i]) * vol(ty - vy[i])) / vol(vy[j] - vy[i])) + vx[i]))) c = !c;
+			overlap = c != 0;
+		}
+		if (overlap) { guess += 1; continue; }
+		tri.push_back(ind[0]); tri.push_back(ind[1]); tri.push_back(ind[2]);
+		rem.erase(rem.begin() + (ptrdiff_t)((guess + 1) % np));
+	}
+	if (rem.size() == 3) { tri.push_back(rem[0]); tri.push_back(rem[1]); tri.push_back(rem[2]); }
+}
+
 inline std::vector<float> load_obj(const std::string& path) {
 	std::ifstream f{path};
 	if (!f) throw std::runtime_error{"obj: could not open '" + path + "'"};
 	std::vector<float> v, out;
 	std::string line;
-	std::vector<long> idx;
+	std::vector<long> idx, tri;
 	while (std::getline(f, line)) {
 		const char* p = line.c_str();
 		while (*p == ' ' || *p == '\t') ++p;
@@ -56,8 +107,12 @@ inline std::vector<float> load_obj(const std::string& path) {
 			auto emit = [&](long q0, long q1, long q2) { for (long q : {q0, q1, q2}) for (int c = 0; c < 3; ++c) out.push_back(v[(size_t)q * 3 + c]); };
 			if (idx.size() == 4 && !quad_splits_along_02(&v[(size_t)idx[0] * 3], &v[(size_t)idx[1] * 3], &v[(size_t)idx[2] * 3], &v[(size_t)idx[3] * 3])) {
 				emit(idx[0], idx[1], idx[3]); emit(idx[1], idx[2], idx[3]); // tinyobjloader: a quad is split along its SHORTER diagonal (1-3 here, and on a tie)
-			} else
-			for (size_t k = 2; k < idx.size(); ++k) emit(idx[0], idx[k - 1], idx[k]);
+			} else if (idx.size() <= 4) {
+				for (size_t k = 2; k < idx.size(); ++k) emit(idx[0], idx[k - 1], idx[k]);
+			} else {
+				tri.clear(); ear_clip_like_tinyobj(v, idx, tri);
+				for (size_t k = 0; k + 2 < tri.size(); k += 3) emit(tri[k], tri[k + 1], tri[k + 2]);
+			}
 		}
 	}
 	if (out.empty()) throw std::runtime_error{"obj: no faces in '" + path + "'"};

@@ -133,8 +133,7 @@ def test_obj_reader_equals_tinyobjloader_on_armadillo(ref, ngp):
 
 def test_obj_reader_equals_tinyobjloader_on_awkward_file(ref, ngp, tmp_path):
     """comments, texture / normal indices, negative (relative) indices, quads (tinyobjloader splits them along the shorter diagonal: both cases and the tie), exponents,
-    CRLF line ends, several groups / objects.  (Faces with five and more corners are ear-clipped by tinyobjloader and fanned here: same surface for planar convex faces,
-    other triangles -- not compared.)"""
+    CRLF line ends, several groups / objects.  (Faces with five and more corners: test_obj_polygons_are_ear_clipped_like_tinyobjloader.)"""
     txt = "\r\n".join([
         "# a comment", "o first", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0.5 0.5 1e0", "v -2.5e-1 3.25 +4", "vt 0 0", "vt 1 1", "vn 0 0 1",
         "g tri", "f 1 2 3", "f 1/1 3/2 4/1", "f 1//1 2//1 5//1", "f 2/1/1 3/2/1 5/1/1",
@@ -200,3 +199,32 @@ def test_exr_piz_reader_survives_corruption(ref, tmp_path):
     assert r.returncode == 0, (r.returncode, r.stderr[-400:])
     n_ok, n_err = map(int, r.stdout.split())
     assert n_ok + n_err == 400 and n_err > 50
+
+
+def test_obj_polygons_are_ear_clipped_like_tinyobjloader(ref, ngp, tmp_path):
+    """faces with 5 .. 12 corners: planar convex, planar concave (star-shaped), non-planar, in every axis orientation, with collinear corners -- the triangle lists
+    must equal tinyobjloader's (its built-in ear clipping, restated in host/mesh_lite.hpp) bit for bit"""
+    rs = np.random.default_rng(11)
+    lines, n_v = [], 0
+    for case in range(300):
+        n = int(rs.integers(5, 13))
+        ang = np.sort(rs.uniform(0, 2 * np.pi, n))
+        rad = np.ones(n) if case % 3 == 0 else rs.uniform(0.3, 1.0, n)  # convex / star-shaped
+        poly = np.stack([rad * np.cos(ang), rad * np.sin(ang), np.zeros(n)], 1)
+        if case % 5 == 0:
+            poly[:, 2] += rs.normal(0, 0.2, n)  # non-planar
+        if case % 7 == 0 and n > 5:
+            poly[2] = 0.5 * (poly[1] + poly[3])  # a collinear corner
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        rot = q if case % 2 else np.eye(3)[:, rs.permutation(3)]  # arbitrary orientation / axis-aligned planes
+        poly = (poly @ rot.T + rs.normal(0, 2, 3)).astype(np.float32)
+        if case % 11 == 0:
+            poly = poly[::-1]  # clockwise
+        lines += [f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}" for p in poly]
+        lines.append("f " + " ".join(str(n_v + 1 + k) for k in range(n)))
+        n_v += n
+    f = tmp_path / "polys.obj"; f.write_text("\n".join(lines) + "\n")
+    a, b = ngp.read_obj(str(f)), _ref_obj(ref, str(f))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    bad = np.flatnonzero((a.view(np.uint32) != b.view(np.uint32)).reshape(len(a), -1).any(1))
+    assert bad.size == 0, (bad.size, bad[:5].tolist())
