@@ -34,9 +34,12 @@ static std::string read_text(const fs::path& p) {
 }
 static std::string lower(std::string s) { for (auto& c : s) c = (char)tolower(c); return s; }
 
-// ---- minimal PNG reader (8- or 16-bit gray / gray+alpha / RGB / RGBA, non-interlaced) on top of zlib ----
+// ---- PNG reader on top of zlib: every colour type (gray, RGB, palette, gray + alpha, RGBA), bit depths 1 / 2 / 4 / 8 / 16, Adam7 interlacing, tRNS transparency -- the
+// files stb_image reads (nerf_loader.cu:570-603), with its conventions for the 8-bit interface (pinned bit for bit against stb_image itself, tests/test_jpeg.py) ----
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-// un-filtered scan lines: `ch` channels of `depth` bits (big-endian samples for 16 bits), row-major
+// un-filtered, expanded image: `ch` channels of `depth` (8 or 16; big-endian samples for 16) bits, row-major.  Low bit depths are widened to 8 bits (gray: v * 255 / (2^d - 1),
+// the way stb_image scales them), palette indices are replaced by their colours (RGB, or RGBA when the file has a tRNS chunk), a tRNS colour key adds an alpha channel
+// (0 where the pixel equals the key, else opaque).
 static bool decode_png_raw(const std::string& path, int& w, int& h, int& ch, int& depth, std::vector<uint8_t>& img) {
 	std::ifstream f{path, std::ios::binary};
 	if (!f) return false;
@@ -44,44 +47,107 @@ static bool decode_png_raw(const std::string& path, int& w, int& h, int& ch, int
 	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
 	if (buf.size() < 33 || memcmp(buf.data(), sig, 8) != 0) return false;
 	size_t pos = 8;
-	int ctype = 0, interlace = 0;
-	depth = 0;
-	std::vector<uint8_t> idat;
+	int ctype = -1, interlace = 0, bits = 0;
+	std::vector<uint8_t> idat, plte, trns;
 	while (pos + 12 <= buf.size()) {
 		const uint32_t len = be32(&buf[pos]);
 		const std::string type((const char*)&buf[pos + 4], 4);
 		const uint8_t* data = &buf[pos + 8];
-		if (pos + 12 + len > buf.size()) return false;
-		if (type == "IHDR") { w = (int)be32(data); h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+		if (len > buf.size() || pos + 12 + len > buf.size()) return false;
+		if (type == "IHDR") { if (len < 13) return false; w = (int)be32(data); h = (int)be32(data + 4); bits = data[8]; ctype = data[9]; interlace = data[12]; }
+		else if (type == "PLTE") plte.assign(data, data + len);
+		else if (type == "tRNS") trns.assign(data, data + len);
 		else if (type == "IDAT") idat.insert(idat.end(), data, data + len);
 		else if (type == "IEND") break;
 		pos += 12 + len;
 	}
-	if ((depth != 8 && depth != 16) || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 4 || ctype == 6) || w <= 0 || h <= 0 || (uint64_t)w * h > (1ull << 28)) return false;
-	ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : 4;
-	const int bpp = ch * depth / 8; // bytes per pixel: the filters' "previous pixel" distance
-	const size_t stride = (size_t)w * bpp;
-	std::vector<uint8_t> raw((stride + 1) * h);
+	if (w <= 0 || h <= 0 || (uint64_t)w * h > (1ull << 28) || interlace > 1) return false;
+	const int file_ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+	const bool depth_ok = ctype == 0 ? (bits == 1 || bits == 2 || bits == 4 || bits == 8 || bits == 16) : ctype == 3 ? (bits == 1 || bits == 2 || bits == 4 || bits == 8) : (bits == 8 || bits == 16);
+	if (!file_ch || !depth_ok) return false;
+	if (ctype == 3 && (plte.empty() || plte.size() % 3 || plte.size() > 768)) return false;
+	const int px_bits = file_ch * bits;                        // bits per pixel in the file
+	const int fbpp = std::max(1, px_bits / 8);                  // the filters' "previous pixel" distance in bytes
+	auto row_bytes = [&](int n) { return ((size_t)n * px_bits + 7) / 8; };
+	// the inflated stream: one image (or seven Adam7 passes), every row = filter byte + packed samples
+	static const int xo[7] = {0, 4, 0, 2, 0, 1, 0}, yo[7] = {0, 0, 4, 0, 2, 0, 1}, xs[7] = {8, 8, 4, 4, 2, 2, 1}, ys[7] = {8, 8, 8, 4, 4, 2, 2};
+	const int n_pass = interlace ? 7 : 1;
+	size_t total = 0;
+	for (int p = 0; p < n_pass; ++p) {
+		const int pw = interlace ? (w - xo[p] + xs[p] - 1) / xs[p] : w, ph = interlace ? (h - yo[p] + ys[p] - 1) / ys[p] : h;
+		if (pw > 0 && ph > 0) total += (row_bytes(pw) + 1) * (size_t)ph;
+	}
+	std::vector<uint8_t> raw(total);
 	uLongf out_len = (uLongf)raw.size();
-	if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return false;
-	img.assign(stride * h, 0);
-	for (int y = 0; y < h; ++y) {
-		const uint8_t ft = raw[(stride + 1) * y];
-		const uint8_t* src = &raw[(stride + 1) * y + 1];
-		uint8_t* dst = &img[stride * y];
-		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-		for (size_t x = 0; x < stride; ++x) {
-			const int a = x >= (size_t)bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
-			int v = src[x];
-			switch (ft) {
-				case 1: v += a; break;
-				case 2: v += b; break;
-				case 3: v += (a + b) >> 1; break;
-				case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-				default: break;
+	if (idat.empty() || uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return false;
+	// samples of the file, one per byte (8-bit and lower depths) or two (16 bits), in image order
+	const int sbytes = bits == 16 ? 2 : 1;
+	std::vector<uint8_t> smp((size_t)w * h * file_ch * sbytes);
+	size_t off = 0;
+	std::vector<uint8_t> prev, cur;
+	for (int p = 0; p < n_pass; ++p) {
+		const int pw = interlace ? (w - xo[p] + xs[p] - 1) / xs[p] : w, ph = interlace ? (h - yo[p] + ys[p] - 1) / ys[p] : h;
+		if (pw <= 0 || ph <= 0) continue;
+		const size_t rb = row_bytes(pw);
+		prev.assign(rb, 0); cur.assign(rb, 0);
+		for (int y = 0; y < ph; ++y) {
+			const uint8_t ft = raw[off]; const uint8_t* src = &raw[off + 1]; off += rb + 1;
+			if (ft > 4) return false;
+			for (size_t x = 0; x < rb; ++x) {
+				const int a = x >= (size_t)fbpp ? cur[x - fbpp] : 0, b = y ? prev[x] : 0, c = (y && x >= (size_t)fbpp) ? prev[x - fbpp] : 0;
+				int v = src[x];
+				switch (ft) {
+					case 1: v += a; break;
+					case 2: v += b; break;
+					case 3: v += (a + b) >> 1; break;
+					case 4: { const int q = a + b - c, pa = abs(q - a), pb = abs(q - b), pc = abs(q - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+					default: break;
+				}
+				cur[x] = (uint8_t)v;
 			}
-			dst[x] = (uint8_t)v;
+			const int oy = interlace ? yo[p] + y * ys[p] : y;
+			for (int x = 0; x < pw; ++x) {
+				const int ox = interlace ? xo[p] + x * xs[p] : x;
+				uint8_t* d = &smp[((size_t)oy * w + ox) * file_ch * sbytes];
+				if (bits >= 8) memcpy(d, &cur[(size_t)x * file_ch * sbytes], (size_t)file_ch * sbytes);
+				else { const size_t bit = (size_t)x * bits; d[0] = (uint8_t)((cur[bit >> 3] >> (8 - bits - (bit & 7))) & ((1 << bits) - 1)); } // one channel (gray / palette), MSB first
+			}
+			prev.swap(cur);
 		}
+	}
+	depth = bits == 16 ? 16 : 8;
+	const size_t n_px = (size_t)w * h;
+	if (ctype == 3) { // palette -> RGB(A)
+		const bool has_a = !trns.empty();
+		ch = has_a ? 4 : 3;
+		const size_t n_pal = plte.size() / 3;
+		img.assign(n_px * ch, 0);
+		for (size_t i = 0; i < n_px; ++i) {
+			const size_t k = smp[i];
+			if (k >= n_pal) return false; // (stb_image reads an uninitialised palette entry here: nothing to match)
+			img[i * ch + 0] = plte[k * 3]; img[i * ch + 1] = plte[k * 3 + 1]; img[i * ch + 2] = plte[k * 3 + 2];
+			if (has_a) img[i * ch + 3] = k < trns.size() ? trns[k] : 255;
+		}
+		return true;
+	}
+	if (bits < 8) { const int scale = bits == 1 ? 255 : bits == 2 ? 85 : 17; for (uint8_t& v : smp) v = (uint8_t)(v * scale); }
+	const bool key = !trns.empty() && (ctype == 0 || ctype == 2);
+	if (!key) { ch = file_ch; img.swap(smp); return true; }
+	if (trns.size() < (size_t)file_ch * 2) return false;
+	ch = file_ch + 1;
+	img.assign(n_px * ch * sbytes, 0);
+	uint8_t kb[6]; // the key in the layout of the samples
+	for (int c = 0; c < file_ch; ++c) {
+		if (bits == 16) { kb[c * 2] = trns[c * 2]; kb[c * 2 + 1] = trns[c * 2 + 1]; }
+		else kb[c] = (uint8_t)(trns[c * 2 + 1] * (bits == 1 ? 255 : bits == 2 ? 85 : bits == 4 ? 17 : 1)); // low byte of the 16-bit key, scaled like the samples
+	}
+	for (size_t i = 0; i < n_px; ++i) {
+		const uint8_t* sp = &smp[i * file_ch * sbytes];
+		uint8_t* d = &img[i * ch * sbytes];
+		memcpy(d, sp, (size_t)file_ch * sbytes);
+		const bool transparent = memcmp(sp, kb, (size_t)file_ch * sbytes) == 0;
+		d[file_ch * sbytes] = transparent ? 0 : 255;
+		if (sbytes == 2) d[file_ch * sbytes + 1] = transparent ? 0 : 255;
 	}
 	return true;
 }

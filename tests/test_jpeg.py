@@ -86,3 +86,114 @@ def test_fox_loads_without_the_python_decoder():
         assert t.nerf.training.dataset.n_images == 50 and t.nerf.training.dataset.metadata[0].resolution == [1080, 1920]
     finally:
         ngp._set_image_decoder(ngp._pil_decoder)
+
+
+def _write_png(path, samples, ctype, bits, interlace, rs, plte=None, trns=None):
+    """a PNG written by hand from the published format: samples [h][w][channels] (ints), any colour type / bit depth, random filter type per row, optional Adam7"""
+    import struct
+    import zlib
+    h, w, ch = samples.shape
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    def pack(row):  # [w][ch] -> bytes
+        flat = row.reshape(-1)
+        if bits == 16:
+            return b"".join(struct.pack(">H", int(v)) for v in flat)
+        if bits == 8:
+            return bytes(int(v) for v in flat)
+        out = bytearray((len(flat) * bits + 7) // 8)
+        for i, v in enumerate(flat):
+            bit = i * bits
+            out[bit >> 3] |= int(v) << (8 - bits - (bit & 7))
+        return bytes(out)
+
+    def rows(sub):
+        hh, ww, _ = sub.shape
+        bpp = max(1, ch * bits // 8)
+        out, prev = b"", None
+        for y in range(hh):
+            raw = pack(sub[y])
+            ft = int(rs.integers(0, 5))
+            f = bytearray(len(raw))
+            for x in range(len(raw)):
+                a = raw[x - bpp] if x >= bpp else 0
+                b = prev[x] if prev is not None else 0
+                c = prev[x - bpp] if (prev is not None and x >= bpp) else 0
+                if ft == 0: p = 0
+                elif ft == 1: p = a
+                elif ft == 2: p = b
+                elif ft == 3: p = (a + b) >> 1
+                else:
+                    q = a + b - c; pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                f[x] = (raw[x] - p) & 255
+            out += bytes([ft]) + bytes(f); prev = raw
+        return out
+    if interlace:
+        data = b""
+        for xo, yo, xs, ys in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[yo::ys, xo::xs]
+            if sub.shape[0] and sub.shape[1]:
+                data += rows(sub)
+    else:
+        data = rows(samples)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bits, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        png += chunk(b"PLTE", bytes(plte))
+    if trns is not None:
+        png += chunk(b"tRNS", bytes(trns))
+    z = zlib.compress(data)
+    for k in range(0, len(z), 4093):  # several IDAT chunks
+        png += chunk(b"IDAT", z[k:k + 4093])
+    open(path, "wb").write(png + chunk(b"IEND", b""))
+
+
+def test_png_variants_against_the_reference_decoder(tmp_path):
+    """every colour type x bit depth x interlacing x tRNS combination of the PNG format, random filters: the host's reader returns stb_image's RGBA8 (and its 16-bit
+    single-channel result, the depth-image path) bit for bit"""
+    import ctypes as C
+    import struct
+    so = os.path.join(ROOT, "oracle", "_ref", "libstb_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd"))
+    import pyngp as ngp
+    ref = C.CDLL(so)
+    rs = np.random.default_rng(5)
+    n = 0
+    for ctype, depths in ((0, (1, 2, 4, 8, 16)), (2, (8, 16)), (3, (1, 2, 4, 8)), (4, (8, 16)), (6, (8, 16))):
+        chn = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+        for bits in depths:
+            for interlace in (0, 1):
+                for with_trns in ((False, True) if ctype in (0, 2, 3) else (False,)):
+                    for (w, h) in ((1, 1), (7, 5), (33, 17)):
+                        plte = trns = None
+                        if ctype == 3:
+                            n_pal = min(1 << bits, int(rs.integers(2, 200)))
+                            plte = rs.integers(0, 256, n_pal * 3).astype(np.uint8)
+                            smp = rs.integers(0, n_pal, (h, w, 1))
+                            if with_trns:
+                                trns = rs.integers(0, 256, int(rs.integers(1, n_pal + 1))).astype(np.uint8)
+                        else:
+                            smp = rs.integers(0, 1 << bits, (h, w, chn))
+                            if bits == 16:
+                                smp[rs.uniform(size=smp.shape) < 0.3] &= 0xff00  # so that a 16-bit colour key can match more than one pixel
+                            if with_trns:
+                                key = smp[int(rs.integers(0, h)), int(rs.integers(0, w))]
+                                smp[rs.uniform(size=(h, w)) < 0.3] = key
+                                trns = b"".join(struct.pack(">H", int(v)) for v in key)
+                        f = str(tmp_path / f"v_{ctype}_{bits}_{interlace}_{int(with_trns)}_{w}x{h}.png")
+                        _write_png(f, smp, ctype, bits, interlace, rs, plte, trns)
+                        ww, hh = C.c_int(), C.c_int()
+                        exp = np.zeros((h, w, 4), np.uint8)
+                        assert ref.ref_stbi_load_rgba(f.encode(), C.byref(ww), C.byref(hh), exp.ctypes.data_as(C.POINTER(C.c_ubyte))) == 1, f
+                        got = ngp.read_image(f)
+                        assert got.shape == (h, w, 4) and np.array_equal(got, exp), (f, got.reshape(-1, 4)[:4].tolist(), exp.reshape(-1, 4)[:4].tolist())
+                        e16 = np.zeros((h, w), np.uint16)
+                        assert ref.ref_stbi_load_gray16(f.encode(), C.byref(ww), C.byref(hh), e16.ctypes.data_as(C.POINTER(C.c_ushort))) == 1
+                        g16 = ngp.read_depth_png(f)
+                        assert np.array_equal(np.asarray(g16).reshape(h, w), e16), f
+                        n += 1
+    assert n == 156
