@@ -1,7 +1,7 @@
-// jpeg_lite.hpp -- baseline JPEG decoder for the NeRF loader's data path (reference: load_stbi -> stbi_load, nerf_loader.cu:570-603; the reference vendors
+// jpeg_lite.hpp -- baseline and progressive JPEG decoder for the NeRF loader's data path (reference: load_stbi -> stbi_load, nerf_loader.cu:570-603; the reference vendors
 // stb_image).  Scope: what cameras and colmap pipelines write -- 8-bit baseline sequential DCT (SOF0 / SOF1 Huffman), 1 or 3 components, any sampling
-// factors, restart intervals, interleaved and per-component scans; progressive / arithmetic / CMYK files return false (the caller's fallback decoder gets
-// them).  The three places where JPEG decoders legitimately differ by a level -- the integer inverse DCT (12-bit constants, rounding in both passes), the
+// factors, restart intervals, interleaved and per-component scans -- and progressive DCT (SOF2: spectral selection + successive approximation, round 3); arithmetic /
+// lossless / CMYK files return false (the caller's fallback decoder gets them).  The three places where JPEG decoders legitimately differ by a level -- the integer inverse DCT (12-bit constants, rounding in both passes), the
 // chroma up-sampling (3:1 tent filter in each direction) and the fixed-point YCbCr -> RGB matrix -- follow stb_image's arithmetic, so that the training
 // pixels are the ones the reference trains on (checked bit for bit against stb_image compiled from the reference's tree: oracle/_ref, tests/test_jpeg.py).
 #pragma once
@@ -46,6 +46,7 @@ struct Component {
 	int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dc_pred = 0;
 	int x = 0, y = 0, w2 = 0, h2 = 0; // size in samples, padded plane size
 	std::vector<uint8_t> plane;
+	std::vector<int16_t> coeff; // progressive files: 64 coefficients per block of the padded plane, block row-major
 };
 
 class Decoder {
@@ -60,14 +61,15 @@ public:
 			if (m < 0) return false;
 			if (m == 0xD9) break; // EOI
 			if (m == 0xDA) { // SOS
-				if (!have_frame || !read_sos() || !decode_scan()) return false;
+				if (!have_frame || !read_sos() || !(progressive ? decode_scan_progressive() : decode_scan())) return false;
 				continue;
 			}
-			if (m == 0xC0 || m == 0xC1) { if (!read_sof()) return false; have_frame = true; continue; }
-			if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) return false; // progressive / lossless / arithmetic
+			if (m == 0xC0 || m == 0xC1 || m == 0xC2) { if (have_frame) return false; progressive = m == 0xC2; if (!read_sof()) return false; have_frame = true; continue; }
+			if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return false; // lossless / arithmetic / hierarchical
 			if (!read_segment(m)) return false;
 		}
 		if (!have_frame || !scanned) return false;
+		if (progressive) finish_progressive();
 		return output(w, h, rgba);
 	}
 
@@ -79,6 +81,8 @@ private:
 	int n_comp = 0, img_w = 0, img_h = 0, h_max = 1, v_max = 1, mcu_w = 0, mcu_h = 0, mcu_x = 0, mcu_y = 0;
 	int restart_interval = 0, todo = 0, scan_n = 0, order[3] = {0, 0, 0};
 	bool jfif = false, scanned = false; int adobe_transform = -1;
+	// progressive (SOF2): coefficients of every block are kept over the scans (spectral selection ss..se, successive approximation ah / al), the inverse DCT runs at the end
+	bool progressive = false; int ss = 0, se = 63, ah = 0, al = 0, eob_run = 0;
 	// entropy-coded segment reader
 	uint32_t code_buffer = 0; int code_bits = 0; bool nomore = false; int marker = -1;
 
@@ -153,6 +157,7 @@ private:
 			c.x = (img_w * c.h + h_max - 1) / h_max; c.y = (img_h * c.v + v_max - 1) / v_max;
 			c.w2 = mcu_x * c.h * 8; c.h2 = mcu_y * c.v * 8;
 			c.plane.assign((size_t)c.w2 * c.h2, 0);
+			if (progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);
 		}
 		return true;
 	}
@@ -169,12 +174,13 @@ private:
 			if (comp[which].hd > 3 || comp[which].ha > 3) return false;
 			order[i] = which;
 		}
-		if (get8() != 0) return false; // spectral selection start (baseline: 0 .. 63, no successive approximation)
-		get8(); if (get8() != 0) return false;
+		ss = get8(); se = get8(); const int a = get8(); ah = a >> 4; al = a & 15;
+		if (progressive) { if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return false; }
+		else if (ss != 0 || ah != 0 || al != 0) return false; // baseline: the whole spectrum, no successive approximation
 		return true;
 	}
 	void reset_entropy() {
-		code_bits = 0; code_buffer = 0; nomore = false; marker = -1;
+		code_bits = 0; code_buffer = 0; nomore = false; marker = -1; eob_run = 0;
 		for (int i = 0; i < n_comp; ++i) comp[i].dc_pred = 0;
 		todo = restart_interval ? restart_interval : 0x7fffffff;
 	}
@@ -219,6 +225,122 @@ private:
 		code_bits -= n;
 		const int v = (int)(k & mask);
 		return sgn ? v : v - (int)mask;
+	}
+	int get_bits(int n) { // n raw bits
+		if (code_bits < n) grow();
+		const uint32_t k = (code_buffer << n) | (code_buffer >> (32 - n)), mask = (1u << n) - 1u;
+		code_buffer = k & ~mask;
+		code_bits -= n;
+		return (int)(k & mask);
+	}
+	bool get_bit() {
+		if (code_bits < 1) grow();
+		const uint32_t k = code_buffer;
+		code_buffer <<= 1; --code_bits;
+		return (k & 0x80000000u) != 0;
+	}
+	// progressive DC scan of one block: first pass = the difference-coded DC shifted by al (and the block is cleared), refinement = one more bit
+	bool decode_block_prog_dc(int16_t* data, Component& c) {
+		if (se != 0) return false; // a scan carries DC or AC coefficients, not both
+		if (code_bits < 16) grow();
+		if (ah == 0) {
+			std::memset(data, 0, 64 * sizeof(int16_t));
+			const int t = huff_decode(hdc[c.hd]);
+			if (t < 0 || t > 15) return false;
+			const int diff = t ? extend_receive(t) : 0;
+			const int dc = c.dc_pred + diff;
+			c.dc_pred = dc;
+			data[0] = (int16_t)(dc * (1 << al));
+		} else if (get_bit()) data[0] = (int16_t)(data[0] + (int16_t)(1 << al));
+		return true;
+	}
+	// progressive AC scan of one block (ITU T.81 G.1.2.2 / G.1.2.3): first pass = run / size pairs with end-of-band runs over several blocks, refinement = one correction
+	// bit for every coefficient that is already non-zero and +-(1 << al) for the newly non-zero ones
+	bool decode_block_prog_ac(int16_t* data, Component& c) {
+		if (ss == 0) return false;
+		const Huffman& h = hac[c.ha];
+		if (ah == 0) {
+			if (eob_run) { --eob_run; return true; }
+			int k = ss;
+			do {
+				if (code_bits < 16) grow();
+				const int rs = huff_decode(h);
+				if (rs < 0) return false;
+				const int s = rs & 15, r = rs >> 4;
+				if (s == 0) {
+					if (r < 15) { eob_run = 1 << r; if (r) eob_run += get_bits(r); --eob_run; break; }
+					k += 16;
+				} else {
+					k += r;
+					const int zig = dezigzag(k++);
+					data[zig] = (int16_t)(extend_receive(s) * (1 << al));
+				}
+			} while (k <= se);
+			return true;
+		}
+		const int16_t bit = (int16_t)(1 << al);
+		auto refine = [&](int16_t* p) { if (get_bit() && (*p & bit) == 0) *p = (int16_t)(*p > 0 ? *p + bit : *p - bit); };
+		if (eob_run) {
+			--eob_run;
+			for (int k = ss; k <= se; ++k) { int16_t* p = &data[dezigzag(k)]; if (*p != 0) refine(p); }
+			return true;
+		}
+		int k = ss;
+		do {
+			const int rs = huff_decode(h);
+			if (rs < 0) return false;
+			int s = rs & 15, r = rs >> 4;
+			if (s == 0) {
+				if (r < 15) { eob_run = (1 << r) - 1; if (r) eob_run += get_bits(r); r = 64; } // the rest of the band: only refinements
+			} else {
+				if (s != 1) return false;
+				s = get_bit() ? bit : -bit;
+			}
+			while (k <= se) { // skip r zero-history coefficients, refining the non-zero ones on the way; then place the new coefficient
+				int16_t* p = &data[dezigzag(k++)];
+				if (*p != 0) refine(p);
+				else { if (r == 0) { *p = (int16_t)s; break; } --r; }
+			}
+		} while (k <= se);
+		return true;
+	}
+	bool decode_scan_progressive() {
+		reset_entropy();
+		if (scan_n == 1) {
+			Component& c = comp[order[0]];
+			const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3, cw = c.w2 >> 3;
+			for (int j = 0; j < bh; ++j) for (int i = 0; i < bw; ++i) {
+				int16_t* data = &c.coeff[64 * ((size_t)i + (size_t)j * cw)];
+				if (!(ss == 0 ? decode_block_prog_dc(data, c) : decode_block_prog_ac(data, c))) return false;
+				if (!restart_or_end()) { j = bh; break; }
+			}
+		} else {
+			for (int j = 0; j < mcu_y; ++j) for (int i = 0; i < mcu_x; ++i) {
+				for (int k = 0; k < scan_n; ++k) {
+					Component& c = comp[order[k]];
+					const int cw = c.w2 >> 3;
+					for (int y = 0; y < c.v; ++y) for (int x = 0; x < c.h; ++x)
+						if (!decode_block_prog_dc(&c.coeff[64 * ((size_t)(i * c.h + x) + (size_t)(j * c.v + y) * cw)], c)) return false;
+				}
+				if (!restart_or_end()) { j = mcu_y; break; }
+			}
+		}
+		scanned = true;
+		if (marker < 0 && !nomore) {
+			while (pos < end) { if (*pos == 0xFF && pos + 1 < end && pos[1] != 0 && !(pos[1] >= 0xD0 && pos[1] <= 0xD7)) break; ++pos; }
+		}
+		return true;
+	}
+	void finish_progressive() { // dequantise with the tables in force at the end of the file, inverse DCT
+		for (int n = 0; n < n_comp; ++n) {
+			Component& c = comp[n];
+			const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3, cw = c.w2 >> 3;
+			for (int j = 0; j < bh; ++j) for (int i = 0; i < bw; ++i) {
+				int16_t* data = &c.coeff[64 * ((size_t)i + (size_t)j * cw)];
+				for (int k = 0; k < 64; ++k) data[k] = (int16_t)(data[k] * dequant[c.tq][k]);
+				idct_block(&c.plane[(size_t)c.w2 * j * 8 + (size_t)i * 8], c.w2, data);
+			}
+		}
 	}
 	bool decode_block(int16_t data[64], Component& c) {
 		if (code_bits < 16) grow();

@@ -157,11 +157,11 @@ PYBIND11_MODULE(pyngp, m) {
 
 	m.def("read_image", [](const std::string& path) {
 		int w = 0, h = 0; std::vector<uint8_t> px;
-		if (!Testbed::read_image_builtin(path, w, h, px)) throw std::runtime_error{"read_image: '" + path + "' is not a PNG / baseline JPEG the built-in readers decode"};
+		if (!Testbed::read_image_builtin(path, w, h, px)) throw std::runtime_error{"read_image: '" + path + "' is not a PNG / JPEG the built-in readers decode"};
 		py::array_t<uint8_t> out({h, w, 4});
 		std::memcpy(out.mutable_data(), px.data(), px.size());
 		return out;
-	}, "RGBA8 [h, w, 4] by the loader's built-in PNG / baseline-JPEG readers (no Pillow)");
+	}, "RGBA8 [h, w, 4] by the loader's built-in PNG / JPEG readers (no Pillow)");
 	m.def("read_depth_png", [](const std::string& path) {
 		int w = 0, h = 0; std::vector<uint16_t> px;
 		if (!Testbed::read_depth_png16(path, w, h, px)) throw std::runtime_error{"read_depth_png: could not decode '" + path + "'"};

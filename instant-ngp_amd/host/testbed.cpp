@@ -186,8 +186,8 @@ static bool decode_png_gray16(const std::string& path, int& w, int& h, std::vect
 	return true;
 }
 
-// load_stbi (nerf_loader.cu:570-603) with the built-in readers: PNG and baseline JPEG decode natively in C++ (host/jpeg_lite.hpp); anything else
-// (progressive JPEG, ...) is left to the decoder hook a Python host may register
+// load_stbi (nerf_loader.cu:570-603) with the built-in readers: PNG and JPEG (baseline + progressive) decode natively in C++ (host/jpeg_lite.hpp); anything else
+// (arithmetic-coded or CMYK JPEG, BMP, TGA, ...) is left to the decoder hook a Python host may register
 static bool decode_builtin(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
 	const std::string ext = lower(fs::path(path).extension().string());
 	if (ext == ".png") return decode_png(path, w, h, rgba);

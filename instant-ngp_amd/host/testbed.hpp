@@ -121,7 +121,7 @@ public:
 	void set_fov(float degrees);
 
 	static ImageDecoder s_fallback_decoder;
-	// the loader's built-in readers (load_stbi, nerf_loader.cu:570-603, 633): PNG + baseline JPEG -> RGBA8, 16-bit PNG -> one channel; test hooks for pyngp
+	// the loader's built-in readers (load_stbi, nerf_loader.cu:570-603, 633): PNG + JPEG (baseline, progressive) -> RGBA8, 16-bit PNG -> one channel; test hooks for pyngp
 	static bool read_image_builtin(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba);
 	static bool read_depth_png16(const std::string& path, int& w, int& h, std::vector<uint16_t>& gray);
 	static bool natural_path_less(const std::string& a, const std::string& b); // the loader's frame order (nerf_loader.cu:347-349: SI::natural::compare)
