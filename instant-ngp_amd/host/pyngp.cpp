@@ -116,6 +116,11 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>())
 		.def("want_repl", &Testbed::want_repl)
 		.def("compute_image_mse", &Testbed::compute_image_mse, py::arg("quantize") = false)
+		.def("_image_pixels", [](const Testbed& t) { // not part of the reference API: the image primitive's pixels as load_image left them (linear RGBA float32 [h, w, 4])
+			py::array_t<float> out({(py::ssize_t)t.image_height(), (py::ssize_t)t.image_width(), (py::ssize_t)4});
+			std::memcpy(out.mutable_data(), t.image_pixels().data(), t.image_pixels().size() * sizeof(float));
+			return out;
+		})
 		.def("calculate_iou", &Testbed::calculate_iou, py::arg("n_samples") = 128u * 128u * 128u * 4u, py::arg("scale_existing_results_factor") = 0.0f, py::arg("blocking") = true, py::arg("force_use_octree") = false)
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view)
 		.def("set_nerf_camera_matrix", [](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
@@ -169,7 +174,7 @@ PYBIND11_MODULE(pyngp, m) {
 		std::memcpy(out.mutable_data(), px.data(), px.size() * 2);
 		return out;
 	}, "one 16-bit channel [h, w] of a PNG, as the loader reads depth images");
-	// decoder hook for images the built-in readers do not decode (progressive JPEG, ...): Pillow, if importable
+	// decoder hook for images the built-in readers do not decode (BMP, TGA, arithmetic-coded JPEG, ...): Pillow, if importable
 	m.def("_set_image_decoder", [](py::function fn) {
 		Testbed::s_fallback_decoder = [fn](const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba) {
 			py::gil_scoped_acquire gil;

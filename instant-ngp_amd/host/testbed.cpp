@@ -440,11 +440,22 @@ void Testbed::load_training_data(const std::string& path_in) {
 			m_mesh = ext == ".stl" ? mesh_lite::load_stl(path.string()) : mesh_lite::load_obj(path.string());
 			NGP_CHECK(ngp_sdf_normalize_mesh_host(m_mesh.data(), m_mesh.size() / 3, &m_mesh_aabb, nullptr));
 			mode = ETestbedMode::Sdf;
-		} else { // load_image, testbed_image.cu: EXR natively, 8-bit formats through the decoder hook (sRGB -> linear)
+		} else { // load_image, testbed_image.cu:393-458: EXR and the .bin format natively (linear), PNG / JPEG natively and other 8-bit formats through the decoder hook (sRGB -> linear)
 			if (ext == ".exr") exr_lite::read_rgba(path.string(), m_image_w, m_image_h, m_image_pixels);
-			else {
+			else if (ext == ".bin") { // load_binary_image, testbed_image.cu:439-458: int32 height, int32 width, then height x width RGBA halfs
+				std::ifstream f{path, std::ios::binary};
+				int32_t hw[2] = {0, 0};
+				f.read((char*)hw, 8);
+				if (!f || hw[0] <= 0 || hw[1] <= 0 || (uint64_t)hw[0] * (uint64_t)hw[1] > (1ull << 28)) throw std::runtime_error{"Could not load binary image '" + path.string() + "'"};
+				m_image_h = hw[0]; m_image_w = hw[1];
+				std::vector<uint16_t> halfs((size_t)m_image_w * m_image_h * 4);
+				f.read((char*)halfs.data(), (std::streamsize)(halfs.size() * 2));
+				if (f.gcount() != (std::streamsize)(halfs.size() * 2)) throw std::runtime_error{"Binary image '" + path.string() + "' is truncated"};
+				m_image_pixels.resize(halfs.size());
+				for (size_t i = 0; i < halfs.size(); ++i) m_image_pixels[i] = exr_lite::half_to_float(halfs[i]);
+			} else {
 				std::vector<uint8_t> rgba;
-				bool ok = ext == ".png" && decode_png(path.string(), m_image_w, m_image_h, rgba);
+				bool ok = decode_builtin(path.string(), m_image_w, m_image_h, rgba);
 				if (!ok && s_fallback_decoder) ok = s_fallback_decoder(path.string(), m_image_w, m_image_h, rgba);
 				if (!ok) throw std::runtime_error{"Could not load image '" + path.string() + "'"};
 				m_image_pixels.resize(rgba.size());

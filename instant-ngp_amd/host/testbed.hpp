@@ -141,6 +141,9 @@ private:
 	// image / SDF modes: the NetworkWithInputEncoding model + its trainer state
 	ngp_encmlp* m_encmlp = nullptr; ngp_image* m_image = nullptr; ngp_sdf* m_sdf = nullptr;
 	std::vector<float> m_image_pixels; int m_image_w = 0, m_image_h = 0; // RGBA float32, linear
+public:
+	const std::vector<float>& image_pixels() const { return m_image_pixels; } int image_width() const { return m_image_w; } int image_height() const { return m_image_h; } // image mode: what load_image read (tests)
+private:
 	std::vector<float> m_mesh; ngp_aabb m_mesh_aabb{};                   // 9 floats per triangle, normalised into the unit cube (load_mesh)
 	void ensure_encmlp_trainer();
 	bool m_dataset_dirty = true;

@@ -469,3 +469,34 @@ def test_loader_rolling_shutter_and_motion(tmp_path):
     assert np.array_equal(np.array(d.xforms[0], np.float32), to_ngp(m0)) and np.array_equal(np.array(d.xforms_end[0], np.float32), to_ngp(m0))
     assert np.array_equal(np.array(d.xforms[1], np.float32), to_ngp(m0)) and np.array_equal(np.array(d.xforms_end[1], np.float32), to_ngp(m1))
     assert np.array_equal(np.array(d.xforms[2], np.float32), to_ngp(m1)) and np.array_equal(np.array(d.xforms_end[2], np.float32), to_ngp(m0))
+
+
+def test_image_mode_loads_bin_jpeg_png_natively(tmp_path):
+    """load_image (testbed_image.cu:393-458): `.bin` = int32 height, int32 width, RGBA halfs (linear); JPEG / PNG through the built-in readers (sRGB -> linear), no decoder hook"""
+    import struct
+    from PIL import Image
+    import pyngp as ngp
+    rs = np.random.default_rng(2)
+    h, w = 9, 14
+    px = rs.uniform(0, 4, (h, w, 4)).astype(np.float16)
+    f = tmp_path / "img.bin"; f.write_bytes(struct.pack("<ii", h, w) + px.tobytes())
+    t = ngp.Testbed()
+    t.load_training_data(str(f))
+    assert t.mode == ngp.TestbedMode.Image
+    got = t._image_pixels()
+    assert got.shape == (h, w, 4) and np.array_equal(got, px.astype(np.float32))
+    (tmp_path / "short.bin").write_bytes(struct.pack("<ii", h, w) + px.tobytes()[:-10])
+    with pytest.raises(RuntimeError):
+        t.load_training_data(str(tmp_path / "short.bin"))
+    img = rs.integers(0, 255, (20, 31, 3), dtype=np.uint8)
+    ngp._set_image_decoder(lambda p: None)  # no Pillow fallback: the built-in readers must do it
+    try:
+        for name, kw in (("a.jpg", dict(quality=90)), ("b.jpg", dict(quality=90, progressive=True)), ("c.png", {})):
+            p = str(tmp_path / name); Image.fromarray(img, "RGB").save(p, **kw)
+            t.load_training_data(p)
+            got = t._image_pixels()
+            ref = ngp.read_image(p).astype(np.float32) / 255.0
+            lin = np.where(ref <= 0.04045, ref / 12.92, ((ref + 0.055) / 1.055) ** 2.4); lin[..., 3] = ref[..., 3]
+            assert got.shape == (20, 31, 4) and np.abs(got - lin).max() < 1e-6, name
+    finally:
+        ngp._set_image_decoder(ngp._pil_decoder)
