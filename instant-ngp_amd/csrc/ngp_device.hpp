@@ -450,10 +450,12 @@ NGP_HD f2 dir_to_latlong(f3 dir) { return {atan2f(dir.x, dir.z) / (NGP_PI * 2.0f
 NGP_HD f2 dir_to_equirectangular(f3 dir) { return {atan2f(dir.x, dir.z) / (NGP_PI * 2.0f) + 0.5f, dir.y / 2.0f + 0.5f}; }
 NGP_HD bool lens_is_360(int lens_mode) { return lens_mode == NGP_LENS_LATLONG || lens_mode == NGP_LENS_EQUIRECTANGULAR; }
 
-// uv_to_ray, common_device.cuh:413-490 without foveation / hidden-area mask / distortion map / aperture, parallax_shift = 0.
+// uv_to_ray, common_device.cuh:413-490 with the default foveation (a clamp of uv to the unit square), without hidden-area mask / distortion map / aperture, parallax_shift = 0.
 // Returns false where the lens has no ray for this uv (f-theta outside its field of view): the caller drops the ray / pixel.
 NGP_HD bool uv_to_ray(f2 uv, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode,
 		const float* lens_params, float near_distance, f3& o, f3& d) {
+	// foveation.warp(uv) (:429) with the default Foveation: clamp(x, 0, 1) * 1 + 0 per axis (common_device.cuh:215-224); the identity for every uv the samplers produce
+	uv = {uv.x < 0.0f ? 0.0f : (uv.x > 1.0f ? 1.0f : uv.x), uv.y < 0.0f ? 0.0f : (uv.y > 1.0f ? 1.0f : uv.y)};
 	f3 dir, head = mk3(0.f);
 	if (lens_mode == NGP_LENS_PERSPECTIVE || lens_mode == NGP_LENS_OPENCV) { // the lenses of the BASELINE datasets: arithmetic unchanged since round 1
 		dir = mk3((uv.x - center[0]) * (float)res[0] / focal[0], (uv.y - center[1]) * (float)res[1] / focal[1], 1.0f);
@@ -484,8 +486,9 @@ NGP_HD bool uv_to_ray(f2 uv, const int32_t res[2], const float focal[2], const M
 	o = origin; d = dir;
 	return true;
 }
-// pos_to_uv, common_device.cuh:527-577 (f-theta has no forward mapping: treated like Perspective, as the reference's release build does)
-NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode, const float* lens_params) {
+// pos_to_uv, common_device.cuh:527-577 (f-theta has no forward mapping: treated like Perspective, as the reference's release build does).  The reference
+// ends in foveation.unwarp(uv) (:576), and with the default Foveation of this path (testbed_nerf.cu:147) that clamps each axis to [0, 1] (common_device.cuh:226-235).
+NGP_HD f2 pos_to_uv_before_foveation(f3 pos, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode, const float* lens_params) {
 	f3 dir = pos - cam.c[3];
 	const f3 a = cam.c[0], b = cam.c[1], c = cam.c[2];
 	float det = a.x * (b.y * c.z - c.y * b.z) - b.x * (a.y * c.z - c.y * a.z) + c.x * (a.y * b.z - b.y * a.z);
@@ -505,6 +508,10 @@ NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M4
 	else if (lens_mode == NGP_LENS_OPENCV_FISHEYE) opencv_fisheye_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
 	dir.x += du; dir.y += dv;
 	return {dir.x * focal[0] / (float)res[0] + center[0], dir.y * focal[1] / (float)res[1] + center[1]};
+}
+NGP_HD f2 pos_to_uv(f3 pos, const int32_t res[2], const float focal[2], const M43& cam, const float center[2], int lens_mode, const float* lens_params) {
+	const f2 uv = pos_to_uv_before_foveation(pos, res, focal, cam, center, lens_mode, lens_params);
+	return {uv.x < 0.0f ? 0.0f : (uv.x > 1.0f ? 1.0f : uv.x), uv.y < 0.0f ? 0.0f : (uv.y > 1.0f ? 1.0f : uv.y)};
 }
 
 // tonemap(vec3, ETonemapCurve), render_buffer.cu:264-321: Identity 0, ACES 1 (Narkowicz fit incl. the 0.6 pre-exposure), Hable 2 (Uncharted-2

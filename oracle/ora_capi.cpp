@@ -57,6 +57,24 @@ API void ora_pos_to_uv(const float* pos3, const ngp_image_meta* m, const float* 
 	uv2[0] = uv.x; uv2[1] = uv.y;
 }
 
+// twins of the exports of oracle/_ref/libngpdev_ref.so (the reference's own device headers compiled for the CPU): tests/test_ref_device.py compares them bit for bit
+API float ora_distance_to_next_voxel(const float* pos, const float* dir, float res) { const vec3 d = V3(dir); return distance_to_next_voxel(V3(pos), d, V3(1.0f) / d, res); }
+API int ora_density_grid_occupied_at(const float* pos, const uint8_t* bitfield, uint32_t mip) { return density_grid_occupied_at(V3(pos), bitfield, mip) ? 1 : 0; }
+API float ora_if_unoccupied_advance_to_next_occupied_voxel(float t, float cone, const float* o, const float* d, const uint8_t* bitfield, uint32_t min_mip, uint32_t max_mip, const ngp_aabb* box) {
+	const vec3 dir = V3(d); return if_unoccupied_advance_to_next_occupied_voxel(t, cone, V3(o), dir, V3(1.0f) / dir, bitfield, min_mip, max_mip, Aabb(*box));
+}
+API void ora_warp_position(const float* pos, const ngp_aabb* box, float* out) { const vec3 r = warp_position(V3(pos), Aabb(*box)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+API void ora_unwarp_position(const float* pos, const ngp_aabb* box, float* out) { const vec3 r = unwarp_position(V3(pos), Aabb(*box)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+API void ora_warp_direction(const float* dir, float* out) { const vec3 r = warp_direction(V3(dir)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+API float ora_network_to_rgb(float v, int act) { return network_to_rgb(v, act); }
+API float ora_network_to_rgb_derivative(float v, int act) { return network_to_rgb_derivative(v, act); }
+API float ora_network_to_density(float v, int act) { return network_to_density(v, act); }
+API float ora_network_to_density_derivative(float v, int act) { return network_to_density_derivative(v, act); }
+API void ora_ld_random_pixel_offset(uint32_t spp, float* out2) { const vec2 r = ld_random_pixel_offset(spp); out2[0] = r.x; out2[1] = r.y; }
+API int ora_aabb_contains(const ngp_aabb* a, const float* p) { return Aabb(*a).contains(V3(p)) ? 1 : 0; }
+API void ora_read_rgba_byte(const float* uv, const int32_t* res, const void* pixels, float* out4) { const vec4 r = read_rgba({uv[0], uv[1]}, res, pixels, NGP_IMAGE_BYTE); out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w; }
+API float ora_read_depth(const float* uv, const int32_t* res, const float* depth) { return read_depth({uv[0], uv[1]}, res, depth); }
+
 // ---- model -----------------------------------------------------------------------------------
 API int ora_model_create(const ngp_model_config* cfg, uint64_t seed, void** out) { TRY(*out = new Model(*cfg, seed)) }
 API void ora_model_destroy(void* m) { delete (Model*)m; }

@@ -134,10 +134,12 @@ inline vec3 equirectangular_to_dir(vec2 uv) {
 inline vec2 dir_to_latlong(vec3 dir) { return {std::atan2(dir.x, dir.z) / (ORA_PI * 2.0f) + 0.5f, std::asin(dir.y) / ORA_PI + 0.5f}; }
 inline vec2 dir_to_equirectangular(vec3 dir) { return {std::atan2(dir.x, dir.z) / (ORA_PI * 2.0f) + 0.5f, dir.y / 2.0f + 0.5f}; }
 
-// uv_to_ray, common_device.cuh:413-490: all seven lens modes; no foveation / hidden-area mask / distortion map / aperture;
+// uv_to_ray, common_device.cuh:413-490: all seven lens modes; default foveation (a clamp of uv to the unit square); no hidden-area mask / distortion map / aperture;
 // parallax_shift = 0.  Returns false for Ray::invalid() (f-theta outside its field of view).
 inline bool uv_to_ray(vec2 uv, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
 		int lens_mode, const float* lens_params, float near_distance, vec3& o, vec3& d) {
+	// warped_uv = foveation.warp(uv) (:429): with the default Foveation every caller of this path passes, clamp(x, 0, 1) * 1 + 0 per axis (common_device.cuh:215-224)
+	uv = {uv.x < 0.0f ? 0.0f : (uv.x > 1.0f ? 1.0f : uv.x), uv.y < 0.0f ? 0.0f : (uv.y > 1.0f ? 1.0f : uv.y)};
 	vec3 head_pos = {0.f, 0.f, 0.f};
 	vec3 dir;
 	if (lens_mode == NGP_LENS_FTHETA) {
@@ -668,8 +670,9 @@ inline uint32_t compute_loss(uint32_t n_rays, uint32_t rays_counter, const Aabb&
 // occupancy grid, testbed_nerf.cu:87-396, 2476-2633
 // -------------------------------------------------------------------------------------------------
 // pos_to_uv, common_device.cuh:527-577 (f-theta has no forward mapping: the reference asserts in debug builds and falls through to the
-// undistorted perspective mapping otherwise)
-inline vec2 pos_to_uv(vec3 pos, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
+// undistorted perspective mapping otherwise).  The reference returns foveation.unwarp(uv) (:576); with the default Foveation this path uses ({} at testbed_nerf.cu:147)
+// that is (clamp(y, 0, 1) - 0) / 1 per axis (common_device.cuh:226-235): the result is CLAMPED to the unit square.
+inline vec2 pos_to_uv_before_foveation(vec3 pos, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2],
 		int lens_mode, const float* lens_params) {
 	vec3 dir = pos - cam[3];
 	// inverse(mat3(cam)) * dir via cofactors
@@ -691,6 +694,12 @@ inline vec2 pos_to_uv(vec3 pos, const int32_t res[2], const float focal[2], cons
 	else if (lens_mode == NGP_LENS_OPENCV_FISHEYE) opencv_fisheye_lens_distortion_delta(lens_params, dir.x, dir.y, &du, &dv);
 	dir.x += du; dir.y += dv;
 	return {dir.x * focal[0] / (float)res[0] + screen_center[0], dir.y * focal[1] / (float)res[1] + screen_center[1]};
+}
+
+inline float default_foveation_unwarp(float y) { y = y < 0.0f ? 0.0f : (y > 1.0f ? 1.0f : y); return (y - 0.0f) / 1.0f; }
+inline vec2 pos_to_uv(vec3 pos, const int32_t res[2], const float focal[2], const mat4x3& cam, const float screen_center[2], int lens_mode, const float* lens_params) {
+	const vec2 uv = pos_to_uv_before_foveation(pos, res, focal, cam, screen_center, lens_mode, lens_params);
+	return {default_foveation_unwarp(uv.x), default_foveation_unwarp(uv.y)};
 }
 
 // mark_untrained_density_grid, testbed_nerf.cu:87-162
