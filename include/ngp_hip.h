@@ -474,6 +474,11 @@ int ngp_host_pos_to_uv(const ngp_image_meta* meta, const float xform12[12], cons
 /* get_xform_given_rolling_shutter (common_device.cuh:670-674) of csrc/ngp_device.hpp evaluated on the host (test hook): the training camera of a pixel
  * (uv) of a frame with rolling shutter {a, b, c, d} -> t = a + b u + c v + d motionblur_time, interpolated between xform.start and xform.end */
 int ngp_host_xform_given_rolling_shutter(const ngp_xform* xform, const float rolling_shutter[4], const float uv[2], float motionblur_time, float xform12_out[12]);
+/* Test hook, no GPU: ngp_sdf_create's mesh setup (TriangleBvh::build-style median splits that reorder the triangles, triangle_bvh.cu:757-840; DiscreteDistribution over the
+ * surface areas, discrete_distribution.h:21-38) and the Raystab signed distance of csrc/sdf_kernels.hip (triangle_bvh.cu:631-650, 893-909) evaluated on the host from the same
+ * source.  distances_inout: upper bounds in (when use_upper_bounds), signed distances out.  triangles_ordered_out (9 floats each) / cdf_out: optional. */
+int ngp_host_sdf_signed_distance(const float* triangles_host, uint32_t n_triangles, const float* positions_host, uint32_t n, float* distances_inout, int use_upper_bounds,
+                                 float* triangles_ordered_out, float* cdf_out);
 /* ablation switches of csrc/ngp_kernels.hpp (0 = production path); process-wide */
 int ngp_debug_set_flags(uint32_t flags);
 /* The switches in effect (NGP_DEBUG_FLAGS_OR from the environment included); 0 = the production path. */

@@ -887,6 +887,39 @@ static uint32_t sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvh
 	}
 	return max_depth;
 }
+// DiscreteDistribution::build over the surface areas (discrete_distribution.h:21-38) -- of the REORDERED triangles, like the reference
+static void sdf_surface_cdf(const std::vector<SdfTriangle>& tris, std::vector<float>& cdf) {
+	const uint32_t n_triangles = (uint32_t)tris.size();
+	cdf.resize(n_triangles);
+	std::vector<float> w(n_triangles);
+	float total = 0;
+	for (uint32_t i = 0; i < n_triangles; ++i) {
+		const SdfTriangle& q = tris[i];
+		const float e1[3] = {q.b[0] - q.a[0], q.b[1] - q.a[1], q.b[2] - q.a[2]}, e2[3] = {q.c[0] - q.a[0], q.c[1] - q.a[1], q.c[2] - q.a[2]};
+		const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+		w[i] = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
+		total += w[i];
+	}
+	const float inv = 1 / total;
+	float acc = 0;
+	for (uint32_t i = 0; i < n_triangles; ++i) { acc += w[i] * inv; cdf[i] = acc; }
+	cdf.back() = 1.0f;
+}
+// Test hook, no GPU: the mesh setup of ngp_sdf_create (BVH build with its triangle reordering, surface CDF) and the ground-truth signed distance of
+// csrc/sdf_kernels.hip evaluated ON THE HOST from the same source.  distances_inout holds upper bounds when use_upper_bounds != 0.
+extern "C" int ngp_host_sdf_signed_distance(const float* triangles_host, uint32_t n_triangles, const float* positions_host, uint32_t n, float* distances_inout, int use_upper_bounds,
+		float* triangles_ordered_out, float* cdf_out) {
+	REQUIRE(triangles_host && n_triangles > 0 && (n == 0 || (positions_host && distances_inout)), "ngp_host_sdf_signed_distance: null / empty argument");
+	std::vector<SdfTriangle> tris(n_triangles);
+	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
+	std::vector<SdfBvhNode> nodes;
+	const uint32_t depth = sdf_build_bvh(tris, nodes, 8);
+	REQUIRE(depth + 2 <= 64, "ngp_host_sdf_signed_distance: BVH deeper than the traversal stack");
+	if (triangles_ordered_out) memcpy(triangles_ordered_out, tris.data(), (size_t)n_triangles * sizeof(SdfTriangle));
+	if (cdf_out) { std::vector<float> cdf; sdf_surface_cdf(tris, cdf); memcpy(cdf_out, cdf.data(), cdf.size() * 4); }
+	host_sdf_signed_distance(n, positions_host, distances_inout, nodes.data(), tris.data(), use_upper_bounds);
+	return 0;
+}
 extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, uint32_t n_triangles, ngp_aabb aabb, const ngp_sdf_options* o, ngp_sdf** out) {
 	REQUIRE(model && triangles_host && o && out && n_triangles > 0, "ngp_sdf_create: null / empty argument");
 	REQUIRE(model->cfg.n_pos_dims == 3 && model->cfg.n_output_dims == 1, "ngp_sdf_create: the model must map 3-D positions to 1 output (network_dims_sdf)");
@@ -899,23 +932,8 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	std::vector<SdfBvhNode> nodes;
 	const uint32_t bvh_depth = sdf_build_bvh(tris, nodes, 8); // m_sdf.triangle_bvh->build(triangles_cpu, 8); reorders the triangles
 	if (bvh_depth + 2 > 64) { delete t; return fail("ngp_sdf_create: BVH deeper than the device traversal stack (64 entries)"); } // median split: depth = ceil(log2(n / 8)) <= 29
-	// DiscreteDistribution::build over the surface areas (discrete_distribution.h:21-38) -- of the REORDERED triangles, like the reference
-	std::vector<float> cdf(n_triangles);
-	{
-		std::vector<float> w(n_triangles);
-		float total = 0;
-		for (uint32_t i = 0; i < n_triangles; ++i) {
-			const SdfTriangle& q = tris[i];
-			const float e1[3] = {q.b[0] - q.a[0], q.b[1] - q.a[1], q.b[2] - q.a[2]}, e2[3] = {q.c[0] - q.a[0], q.c[1] - q.a[1], q.c[2] - q.a[2]};
-			const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
-			w[i] = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
-			total += w[i];
-		}
-		const float inv = 1 / total;
-		float acc = 0;
-		for (uint32_t i = 0; i < n_triangles; ++i) { acc += w[i] * inv; cdf[i] = acc; }
-		cdf.back() = 1.0f;
-	}
+	std::vector<float> cdf;
+	sdf_surface_cdf(tris, cdf);
 	t->cap = std::max<uint32_t>(o->batch_size, 1u << 21); // calculate_iou works in batches of 128^3 = 2^21
 	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
 		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8)) { delete t; return 1; }

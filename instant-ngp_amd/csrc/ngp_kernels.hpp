@@ -258,6 +258,7 @@ struct SdfSampleArgs {
 };
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a);
 void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds);
+void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters);
 
 // ---- renderer (render_kernels.hip) ------------------------------------------------------------

@@ -16,13 +16,13 @@ namespace ngp {
 
 constexpr float SDF_MAX_DIST = 10.0f; // triangle_bvh.cu:42
 
-static __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-static __device__ __forceinline__ float len2(f3 a) { return dot3(a, a); }
-static __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); } // tcnn sign()
-static __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+static __host__ __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static __host__ __device__ __forceinline__ float len2(f3 a) { return dot3(a, a); }
+static __host__ __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); } // tcnn sign()
+static __host__ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
 // Triangle::distance_sq, triangle.cuh:108-129 (iq's triangle distance)
-static __device__ __forceinline__ float tri_distance_sq(const SdfTriangle& t, f3 pos) {
+static __host__ __device__ __forceinline__ float tri_distance_sq(const SdfTriangle& t, f3 pos) {
 	const f3 a = ld3(t.a), b = ld3(t.b), c = ld3(t.c);
 	const f3 v21 = b - a, p1 = pos - a, v32 = c - b, p2 = pos - b, v13 = a - c, p3 = pos - c;
 	const f3 nor = cross3(v21, v13);
@@ -35,7 +35,7 @@ static __device__ __forceinline__ float tri_distance_sq(const SdfTriangle& t, f3
 	return dot3(nor, p1) * dot3(nor, p1) / len2(nor);
 }
 // Triangle::ray_intersect, triangle.cuh:87-101
-static __device__ __forceinline__ float tri_ray_intersect(const SdfTriangle& tr, f3 ro, f3 rd) {
+static __host__ __device__ __forceinline__ float tri_ray_intersect(const SdfTriangle& tr, f3 ro, f3 rd) {
 	const f3 a = ld3(tr.a), v1v0 = ld3(tr.b) - a, v2v0 = ld3(tr.c) - a, rov0 = ro - a;
 	const f3 n = cross3(v1v0, v2v0), q = cross3(rov0, rd);
 	const float d = 1.0f / dot3(rd, n);
@@ -45,12 +45,12 @@ static __device__ __forceinline__ float tri_ray_intersect(const SdfTriangle& tr,
 	return t;
 }
 // BoundingBox::distance_sq, bounding_box.cuh:228-230
-static __device__ __forceinline__ float bb_distance_sq(const SdfBvhNode& n, f3 p) {
+static __host__ __device__ __forceinline__ float bb_distance_sq(const SdfBvhNode& n, f3 p) {
 	const float dx = fmaxf(fmaxf(n.bmin[0] - p.x, p.x - n.bmax[0]), 0.f), dy = fmaxf(fmaxf(n.bmin[1] - p.y, p.y - n.bmax[1]), 0.f), dz = fmaxf(fmaxf(n.bmin[2] - p.z, p.z - n.bmax[2]), 0.f);
 	return dx * dx + dy * dy + dz * dz;
 }
 // BoundingBox::ray_intersect(...).x, bounding_box.cuh:163-210: entry parameter of the slab test (FLT_MAX on a miss; may be negative inside the box)
-static __device__ __forceinline__ float bb_ray_entry(const SdfBvhNode& n, f3 o, f3 d) {
+static __host__ __device__ __forceinline__ float bb_ray_entry(const SdfBvhNode& n, f3 o, f3 d) {
 	float tmin = (n.bmin[0] - o.x) / d.x, tmax = (n.bmax[0] - o.x) / d.x;
 	if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
 	float tymin = (n.bmin[1] - o.y) / d.y, tymax = (n.bmax[1] - o.y) / d.y;
@@ -66,7 +66,7 @@ static __device__ __forceinline__ float bb_ray_entry(const SdfBvhNode& n, f3 o, 
 }
 
 // closest_triangle(...).second: distance to the nearest triangle, bounded above by sqrt(max_distance_sq)
-static __device__ float bvh_unsigned_distance(f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance_sq) {
+static __host__ __device__ float bvh_unsigned_distance(f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance_sq) {
 	// stack depth: ngp_sdf_create checks the tree's depth against the 64 entries.  An entry carries its box distance, so a node that became
 	// farther than the best hit while it waited on the stack is dropped when it is popped.
 	int stack[64]; float sdist[64]; int sp = 0;
@@ -88,7 +88,7 @@ static __device__ float bvh_unsigned_distance(f3 p, const SdfBvhNode* __restrict
 	return found ? sqrtf(best) : 0.0f; // "No closest triangle found": the reference returns 0 as well (triangle_bvh.cu:562-566)
 }
 // ray_intersect(...).first >= 0: is any triangle hit within SDF_MAX_DIST?
-static __device__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris) {
+static __host__ __device__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris) {
 	int stack[64]; int sp = 0;
 	stack[sp++] = 0;
 	while (sp > 0) {
@@ -103,7 +103,7 @@ static __device__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode* __res
 	return false;
 }
 // cylindrical_to_dir / fibonacci_dir<32>, random_val.cuh:45-101
-static __device__ __forceinline__ f3 fibonacci_dir32(uint32_t i, float ox, float oy) {
+static __host__ __device__ __forceinline__ f3 fibonacci_dir32(uint32_t i, float ox, float oy) {
 	const float epsilon = 1.33f; // N_DIRS = 32 >= 24
 	const float GOLDEN_RATIO = 1.6180339887498948482045868343656f;
 	float px = (i + epsilon) / (32 - 1 + 2 * epsilon) + ox; px = px - floorf(px);
@@ -114,7 +114,7 @@ static __device__ __forceinline__ f3 fibonacci_dir32(uint32_t i, float ox, float
 	return mk3(sin_theta * cp, sin_theta * sp, cos_theta);
 }
 // signed_distance_raystab, triangle_bvh.cu:631-650 with the per-element rng of signed_distance_raystab_kernel (:893-909)
-static __device__ float bvh_signed_distance_raystab(uint32_t i, f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance) {
+static __host__ __device__ float bvh_signed_distance_raystab(uint32_t i, f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance) {
 	const float distance = bvh_unsigned_distance(p, nodes, tris, max_distance * max_distance);
 	ngp_pcg32 dflt; dflt.state = 0x853c49e6748fea9bULL; dflt.inc = 0xda3e39cb94b95bdbULL; // default-constructed pcg32
 	Rng rng(dflt);
@@ -177,6 +177,13 @@ __global__ void __launch_bounds__(256) k_sdf_signed_distance(uint32_t n, const f
 	if (i >= n) return;
 	const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
 	distances[i] = bvh_signed_distance_raystab(i, p, nodes, tris, use_upper_bounds ? distances[i] : SDF_MAX_DIST);
+}
+// the same function on the host (test hook; the product never calls it)
+void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds) {
+	for (uint32_t i = 0; i < n; ++i) {
+		const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
+		distances[i] = bvh_signed_distance_raystab(i, p, nodes, tris, use_upper_bounds ? distances[i] : SDF_MAX_DIST);
+	}
 }
 // compare_signs_kernel (no octree): counters[0..5] = ref inside / outside, model inside / outside, intersection, union
 __global__ void __launch_bounds__(256) k_sdf_compare_signs(uint32_t n, const float* __restrict__ ref, const __half* __restrict__ model, uint32_t model_stride, uint32_t* __restrict__ counters) {

@@ -213,7 +213,8 @@ struct __half {
 		float f; std::memcpy(&f, &x, 4); return f; }
 };
 struct ngp_shim_dim3 { uint32_t x = 0, y = 0, z = 0; };
-static const ngp_shim_dim3 threadIdx, blockIdx, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+static const ngp_shim_dim3 threadIdx, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+static thread_local ngp_shim_dim3 blockIdx; // written by the CPU stand-in for linear_kernel (gpu_memory.h here)
 inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 // CUDA builtins the host-compilable inline functions mention
