@@ -12,6 +12,9 @@
 // and brute-force definitions of Morton / occupancy indices.  Two results the reference itself logged (notebooks/instant_ngp.ipynb: the hash
 // grid's parameter count for a 16 x 2 configuration, the fox cameras' bounding box after loading) are pinned in tests/test_oracle_pins.py and
 // tests/test_host_logic.py; nothing else is.
+// Round 3: the reference's own code, compiled for the CPU from where it lies against a stand-in for tcnn's vector types (oracle/ref_shim, oracle/Makefile `ref`), now
+// pins what is IN the reference's repository bit for bit: the device headers (tests/test_ref_device.py), the kernels of testbed_nerf.cu -- K1, K3, occupancy grid, error-map
+// CDFs (tests/test_ref_kernels.py) -- and the triangle BVH (tests/test_ref_sdf.py).  Still unpinned: everything marked [tcnn] (hash grid, MLPs, optimizer, pcg32, slerp).
 //
 // ora_math.hpp: half, pcg32, vec3, Morton codes, colour transfer, AABB, ray stepping and
 // occupancy-grid index math.

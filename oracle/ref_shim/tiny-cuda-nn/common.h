@@ -102,11 +102,20 @@ template <typename T, uint32_t N> T max(const tvec<T, N>& a) { T r = a[0]; for (
 template <typename T, uint32_t N> tvec<T, N> pow(const tvec<T, N>& a, T b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::pow(a[i], b); return r; }
 template <typename T, uint32_t N> tvec<T, N> pow(const tvec<T, N>& a, const tvec<T, N>& b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::pow(a[i], b[i]); return r; }
 template <typename T, uint32_t N> tvec<T, N> copysign(const tvec<T, N>& a, const tvec<T, N>& b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::copysign(a[i], b[i]); return r; }
-template <typename T> T clamp(T v, T lo, T hi) { return std::max(lo, std::min(v, hi)); }
-template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, const tvec<T, N>& lo, const tvec<T, N>& hi) { return max(lo, min(v, hi)); }
-template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, T lo, T hi) { return max(tvec<T, N>(lo), min(v, tvec<T, N>(hi))); }
-template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, T lo, const tvec<T, N>& hi) { return max(tvec<T, N>(lo), min(v, hi)); }
-template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, const tvec<T, N>& lo, T hi) { return max(lo, min(v, tvec<T, N>(hi))); }
+// Scalar clamp.  GLSL defines clamp(x, lo, hi) = min(max(x, lo), hi); that is the default here.  It only matters where the bounds cross, and the reference has one such
+// call on the hot path: mip_from_dt ends in clamp((int)mip, exponent, (int)max_cascade) (nerf_device.cuh:459) with exponent > max_cascade for long steps.  min(max()) yields
+// max_cascade -- what the pre-tcnn-vector code base wrote out as min(max_cascade, max(exponent, mip)), and what the oracle and the HIP kernels do.  A lower-bound-first
+// conditional (v < lo ? lo : (hi < v ? hi : v)), which tcnn's scalar clamp may well be, yields `exponent`: -DNGP_SHIM_CLAMP_LOWER_FIRST builds that variant
+// (oracle/_ref/libngpkern_ref_clamp_lower_first.so) so that tests/test_ref_kernels.py can state what would change.
+#ifdef NGP_SHIM_CLAMP_LOWER_FIRST
+template <typename T> T clamp(T v, T lo, T hi) { return v < lo ? lo : (hi < v ? hi : v); }
+#else
+template <typename T> T clamp(T v, T lo, T hi) { return std::min(std::max(v, lo), hi); }
+#endif
+template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, const tvec<T, N>& lo, const tvec<T, N>& hi) { return min(max(v, lo), hi); }
+template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, T lo, T hi) { return min(max(v, tvec<T, N>(lo)), tvec<T, N>(hi)); }
+template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, T lo, const tvec<T, N>& hi) { return min(max(v, tvec<T, N>(lo)), hi); }
+template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, const tvec<T, N>& lo, T hi) { return min(max(v, lo), tvec<T, N>(hi)); }
 template <typename T> T mix(T a, T b, T t) { return a * (T(1) - t) + b * t; }
 template <typename T, uint32_t N> tvec<T, N> mix(const tvec<T, N>& a, const tvec<T, N>& b, T t) { return a * (T(1) - t) + b * t; }
 template <typename T, uint32_t N> tvec<T, N> mix(const tvec<T, N>& a, const tvec<T, N>& b, const tvec<T, N>& t) { return a * (tvec<T, N>(T(1)) - t) + b * t; }
@@ -179,7 +188,9 @@ inline tmat<float, 4, 4> mat_log(const tmat<float, 4, 4>&) { ngp_shim_unpinned("
 inline tmat<float, 4, 4> mat_exp(const tmat<float, 4, 4>&) { ngp_shim_unpinned("mat_exp"); }
 inline mat3 mat_log(const mat3&) { ngp_shim_unpinned("mat_log"); }
 inline mat3 mat_exp(const mat3&) { ngp_shim_unpinned("mat_exp"); }
-inline mat3 slerp(const mat3&, const mat3&, float) { ngp_shim_unpinned("slerp"); }
+// camera_slerp of a camera WITHOUT motion (start == end, every shipped dataset): the matrix itself -- the assumption the oracle and the HIP path make as well (tcnn routes
+// through quaternions; whether that round trip returns the input bits cannot be known from the mount).  Cameras with motion: not pinned here.
+inline mat3 slerp(const mat3& a, const mat3& b, float) { if (a == b) return a; ngp_shim_unpinned("slerp of two different rotations"); }
 template <uint32_t N> tvec<float, N> tan(const tvec<float, N>& a) { tvec<float, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::tan(a[i]); return r; }
 template <uint32_t N> tvec<float, N> atan(const tvec<float, N>& a) { tvec<float, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::atan(a[i]); return r; }
 // a ray as the reference's headers use it (origin, direction, point at t, validity = non-zero direction)
@@ -212,6 +223,26 @@ struct __half {
 		else if (e == 31) x = sign | 0x7f800000u | (m << 13); else x = sign | ((e - 15 + 127) << 23) | (m << 13);
 		float f; std::memcpy(&f, &x, 4); return f; }
 };
+// "atomics" of a one-thread-at-a-time CPU run of the reference's kernels (ref_nerf_kernels_wrapper): plain read-modify-write, returning the old value like CUDA's
+template <typename T, typename U> inline T atomicAdd(T* p, U v) { const T old = *p; *p = (T)(old + (T)v); return old; }
+template <typename T, typename U> inline T atomicMax(T* p, U v) { const T old = *p; if ((T)v > old) *p = (T)v; return old; }
+template <typename T, typename U> inline T atomicMin(T* p, U v) { const T old = *p; if ((T)v < old) *p = (T)v; return old; }
+inline __half operator*(__half a, __half b) { return __half((float)a * (float)b); }
+inline __half operator+(__half a, __half b) { return __half((float)a + (float)b); }
+namespace tcnn {
+using network_precision_t = __half; // TCNN_HALF_PRECISION builds (every GPU the reference's README lists as supported at full speed)
+// tcnn's pitched pointer (common.h): rows of `stride_in_bytes` bytes; operator()(row) addresses a row, += / -= move by rows
+template <typename T> struct PitchedPtr {
+	PitchedPtr() : ptr{nullptr}, stride_in_bytes{sizeof(T)} {}
+	PitchedPtr(T* ptr, size_t stride_in_elements, size_t offset = 0, size_t extra_stride_bytes = 0) : ptr{ptr + offset}, stride_in_bytes{stride_in_elements * sizeof(T) + extra_stride_bytes} {}
+	template <typename U> explicit PitchedPtr(PitchedPtr<U> other) : ptr{(T*)other.ptr}, stride_in_bytes{other.stride_in_bytes} {}
+	T* operator()(uint32_t y) const { return (T*)((const char*)ptr + y * stride_in_bytes); }
+	void operator+=(uint32_t y) { ptr = (T*)((const char*)ptr + y * stride_in_bytes); }
+	void operator-=(uint32_t y) { ptr = (T*)((const char*)ptr - y * stride_in_bytes); }
+	explicit operator bool() const { return ptr; }
+	T* ptr; size_t stride_in_bytes;
+};
+} // namespace tcnn
 struct ngp_shim_dim3 { uint32_t x = 0, y = 0, z = 0; };
 static const ngp_shim_dim3 threadIdx, blockDim{1, 1, 1}, gridDim{1, 1, 1};
 static thread_local ngp_shim_dim3 blockIdx; // written by the CPU stand-in for linear_kernel (gpu_memory.h here)

@@ -1,0 +1,269 @@
+"""CPU: the oracle's kernels against THE REFERENCE'S OWN KERNELS.
+
+oracle/_ref/libngpkern_ref.so is the kernel section of /root/reference/src/testbed_nerf.cu -- generate_training_samples_nerf, compute_loss_kernel_train_nerf, the
+occupancy-grid kernels, the error-map CDF kernels: the reference's text, read where it lies -- compiled for the CPU against oracle/ref_shim (oracle/Makefile,
+oracle/ref_nerf_kernels_pre.hpp / _post.hpp) and run one "thread" at a time in element order, which is the order the sequential oracle works in.  Each ref_k_* export has
+the signature of the oracle's ora_k_* twin; same inputs in, every output compared BIT FOR BIT: ray order, sample counts and slots, rays, warped sample coordinates, the
+compacted batch, dL/doutput in fp16, the per-ray losses, the error map, occupancy values, bitfields, CDFs.  The oracle is what every HIP kernel is compared with on the
+GPU (tests/test_gpu_nerf.py), so this closes the chain reference kernel -> oracle -> HIP kernel for the in-repository part of the hot path.  Not covered, as stated in
+DESIGN.md section 5: tcnn's own code (hash grid, MLPs, optimizer), cameras with motion (tcnn's slerp), and what the shim assumes about tcnn's vector arithmetic.
+Skipped when oracle/_ref is not built."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ngp_abi as A
+from common import host_meta, make_small_dataset, ptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_ref", "libngpkern_ref.so")
+N_CELLS = 128 ** 3
+F = C.c_float
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(SO):
+        pytest.skip("oracle/_ref/libngpkern_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    return C.CDLL(SO)
+
+
+def _rng(ora, seed=1337):
+    s = A.Pcg32()
+    ora.ora_pcg32_seed(C.byref(s), C.c_uint64(seed), C.c_uint64(1))
+    return s
+
+
+def _occupancy(lib, prefix, M, X, n_img, n_cascades=1):
+    """cells seen by a camera, thinned in blobs so that rays cross empty space; returns grid, bitfield, mean -- computed by `lib` (oracle or reference)"""
+    n = N_CELLS * n_cascades
+    grid = np.zeros(n, np.float32)
+    getattr(lib, prefix + "k_mark_untrained_density_grid")(n, ptr(grid), n_img, M, X, 1)
+    mask = (np.random.default_rng(3).uniform(size=n // 512) < 0.35).repeat(512)
+    grid = np.where((grid >= 0) & mask, 0.05, grid).astype(np.float32)
+    mean = float(np.maximum(grid[:N_CELLS], 0).astype(np.float64).sum() / N_CELLS)
+    bf = np.zeros(N_CELLS, np.uint8)  # 8 levels of N_CELLS / 8 bytes: both sides always write (and pool through) all NERF_CASCADES levels
+    getattr(lib, prefix + "k_grid_to_bitfield")(ptr(grid), n_cascades - 1, ptr(bf), F(mean))
+    return grid, bf, mean
+
+
+@pytest.fixture(scope="module")
+def scene(ora):
+    imgs, xforms, meta = make_small_dataset(6, 48)
+    M, X = host_meta(imgs, xforms, meta)
+    grid, bf, mean = _occupancy(ora, "ora_", M, X, len(imgs))
+    return dict(imgs=imgs, M=M, X=X, grid=grid, bf=bf, mean=mean, n_img=len(imgs))
+
+
+def _k1(lib, prefix, ora, scene, n_rays, max_samples, rb, re, snap, cone, aabb_scale=1, bf=None, max_mip=0):
+    o = dict(ray_counter=C.c_uint32(), numsteps_counter=C.c_uint32(), ray_indices=np.zeros(n_rays, np.uint32), rays=np.zeros((n_rays, 6), np.float32),
+             numsteps=np.zeros((n_rays, 2), np.uint32), coords=np.zeros((max_samples, 7), np.float32))
+    getattr(lib, prefix + "k_generate_training_samples")(n_rays, rb, re, A.scene_aabb(aabb_scale), max_samples, _rng(ora), C.byref(o["ray_counter"]), C.byref(o["numsteps_counter"]),
+        ptr(o["ray_indices"]), ptr(o["rays"]), ptr(o["numsteps"]), ptr(o["coords"]), scene["n_img"], scene["M"], scene["X"], ptr(scene["bf"] if bf is None else bf), max_mip, snap, F(cone))
+    return o
+
+
+def _same_k1(a, b):
+    assert a["ray_counter"].value == b["ray_counter"].value and a["numsteps_counter"].value == b["numsteps_counter"].value
+    n, t = a["ray_counter"].value, min(a["numsteps_counter"].value, len(a["coords"]))
+    assert n > 0 and t > 0
+    assert np.array_equal(a["ray_indices"][:n], b["ray_indices"][:n]) and np.array_equal(a["numsteps"][:n], b["numsteps"][:n])
+    assert np.array_equal(a["rays"][:n].view(np.uint32), b["rays"][:n].view(np.uint32))
+    used = int((a["numsteps"][:n, 0] + a["numsteps"][:n, 1]).max())
+    assert np.array_equal(a["coords"][:used].view(np.uint32), b["coords"][:used].view(np.uint32))
+    return n, used
+
+
+def test_occupancy_grid_kernels(ref, ora, scene):
+    """mark_untrained_density_grid, grid_to_bitfield + bitfield_max_pool (two cascades), generate_grid_samples_nerf_nonuniform, splat_grid_samples_nerf_max_nearest_neighbor,
+    ema_grid_samples_nerf (testbed_nerf.cu:87-429)"""
+    M, X, n_img = scene["M"], scene["X"], scene["n_img"]
+    g_o, bf_o, _ = _occupancy(ora, "ora_", M, X, n_img, 2)
+    g_r, bf_r, _ = _occupancy(ref, "ref_", M, X, n_img, 2)
+    assert np.array_equal(g_o.view(np.uint32), g_r.view(np.uint32)) and np.array_equal(bf_o, bf_r) and 0.02 < np.unpackbits(bf_o).mean() < 0.9
+    rs = np.random.default_rng(0)
+    grid = np.where(g_o >= 0, rs.uniform(0, 0.05, g_o.size), -1).astype(np.float32)
+    for step, thresh, n in ((0, -0.01, 5000), (7, 0.01, 5000)):
+        outs = []
+        for lib, p in ((ora, "ora_"), (ref, "ref_")):
+            pos = np.zeros((n, 3), np.float32); idx = np.zeros(n, np.uint32)
+            getattr(lib, p + "k_generate_grid_samples")(n, _rng(ora, 7), step, A.scene_aabb(2), ptr(grid), ptr(pos), ptr(idx), 2, F(thresh))
+            outs.append((pos, idx))
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    idx = outs[0][1]
+    dens = rs.normal(-1, 2, n).astype(np.float16).view(np.uint16)
+    tmp = []
+    for lib, p in ((ora, "ora_"), (ref, "ref_")):
+        t = np.zeros_like(grid)
+        getattr(lib, p + "k_splat_grid_samples")(n, ptr(idx), ptr(dens), 1, ptr(t), A.ACT_EXPONENTIAL)
+        g = grid.copy()
+        getattr(lib, p + "k_ema_grid_samples")(grid.size, F(0.95), ptr(g), ptr(t))
+        tmp.append((t, g))
+    assert np.array_equal(tmp[0][0].view(np.uint32), tmp[1][0].view(np.uint32)) and np.array_equal(tmp[0][1].view(np.uint32), tmp[1][1].view(np.uint32))
+    assert (tmp[0][0] > 0).sum() > 1000
+
+
+@pytest.mark.parametrize("snap,cone,shard", [(1, 0.0, (0, 1)), (0, 0.0, (0, 1)), (1, 1.0 / 256.0, (0, 1)), (0, 1.0 / 256.0, (1, 3))])
+def test_k1_generate_training_samples(ref, ora, scene, snap, cone, shard):
+    """generate_training_samples_nerf (testbed_nerf.cu:691-850): image and pixel choice, ray set-up, the march through the occupancy grid with its voxel skipping, slot
+    allocation, warped coordinates -- constant and growing step size, snapped and jittered pixels, a data-parallel shard of the ray range, and the sample cap"""
+    n_rays = 3000
+    rb, re = n_rays * shard[0] // shard[1], n_rays * (shard[0] + 1) // shard[1]
+    a = _k1(ora, "ora_", ora, scene, n_rays, 1 << 19, rb, re, snap, cone); b = _k1(ref, "ref_", ora, scene, n_rays, 1 << 19, rb, re, snap, cone)
+    n, used = _same_k1(a, b)
+    assert n > 0.3 * (re - rb) and used > 20 * n
+    # the cap: rays whose span would end beyond max_samples are dropped, later shorter ones may still fit (sequential slot order)
+    a = _k1(ora, "ora_", ora, scene, n_rays, used // 3, rb, re, snap, cone); b = _k1(ref, "ref_", ora, scene, n_rays, used // 3, rb, re, snap, cone)
+    n2, _ = _same_k1(a, b)
+    assert n2 < n
+
+
+def test_k1_cascades(ref, ora, scene):
+    """aabb_scale 4 (three cascades): mip_from_dt / mip_from_pos, coarser cells away from the centre, max_mip = 2"""
+    M, X, n_img = scene["M"], scene["X"], scene["n_img"]
+    g, bf, _ = _occupancy(ora, "ora_", M, X, n_img, 3)
+    a = _k1(ora, "ora_", ora, scene, 2000, 1 << 19, 0, 2000, 1, 1.0 / 256.0, 4, bf, 2); b = _k1(ref, "ref_", ora, scene, 2000, 1 << 19, 0, 2000, 1, 1.0 / 256.0, 4, bf, 2)
+    _same_k1(a, b)
+
+
+def test_k1_scalar_clamp_with_crossed_bounds(ref, ora, scene):
+    """The one place where the answer depends on tcnn source that is absent: mip_from_dt's clamp((int)mip, exponent, (int)max_cascade) (nerf_device.cuh:459) when a long step
+    asks for a cascade above max_cascade.  GLSL's min(max()) (the shim's default, the oracle, the HIP kernels, and the pre-tcnn code's min(max_cascade, max(exponent, mip)))
+    stays at max_cascade; a lower-bound-first conditional marches such points through the next coarser POOLED level.  oracle/_ref/libngpkern_ref_clamp_lower_first.so is the
+    reference's K1 compiled with that variant: identical with a constant step (cone angle 0: every aabb_scale = 1 scene, the headline configuration), and with the growing
+    step of larger scenes a conservative coarser test for the far part of a ray -- a few per cent of the rays gain a sample or two."""
+    alt_so = SO.replace(".so", "_clamp_lower_first.so")
+    if not os.path.exists(alt_so):
+        pytest.skip("variant library not built")
+    alt = C.CDLL(alt_so)
+    M, X, n_img = scene["M"], scene["X"], scene["n_img"]
+    n = N_CELLS * 2
+    grid = np.zeros(n, np.float32); ora.ora_k_mark_untrained_density_grid(n, ptr(grid), n_img, M, X, 1)
+    grid = np.where((grid >= 0) & (np.random.default_rng(3).uniform(size=n // 8) < 0.15).repeat(8), 0.05, grid).astype(np.float32)  # fine-grained: a pooled cell differs from its children
+    bf = np.zeros(N_CELLS, np.uint8); ora.ora_k_grid_to_bitfield(ptr(grid), 1, ptr(bf), F(0.01))
+    for cone, may_differ in ((0.0, False), (1.0 / 256.0, True)):
+        a = _k1(ref, "ref_", ora, scene, 3000, 1 << 21, 0, 3000, 1, cone, 2, bf, 1); b = _k1(alt, "ref_", ora, scene, 3000, 1 << 21, 0, 3000, 1, cone, 2, bf, 1)
+        o = _k1(ora, "ora_", ora, scene, 3000, 1 << 21, 0, 3000, 1, cone, 2, bf, 1)
+        _same_k1(o, a)
+        na = a["ray_counter"].value
+        assert na == b["ray_counter"].value and np.array_equal(a["ray_indices"][:na], b["ray_indices"][:na])
+        differ = int((a["numsteps"][:na, 0] != b["numsteps"][:na, 0]).sum()); sa, sb = a["numsteps_counter"].value, b["numsteps_counter"].value
+        if not may_differ:
+            assert differ == 0 and sa == sb
+        else:
+            assert 0 < differ <= 0.05 * na and sa <= sb <= 1.005 * sa, (differ, sa, sb)
+
+
+def _k3(lib, prefix, ora, scene, k1, n_rays, B, net_u, loss_type, color_srgb, random_bg, linear_colors, rgb_act, density_act, snap, near):
+    n_act = k1["ray_counter"].value
+    ns = k1["numsteps"].copy(); cc = np.zeros((B, 7), np.float32); dl = np.zeros((B, 4), np.uint16); loss = np.zeros(n_rays, np.float32); cnt = C.c_uint32()
+    getattr(lib, prefix + "k_compute_loss")(n_rays, n_act, A.scene_aabb(1), _rng(ora), B, F(128.0), (F * 3)(0.2, 0.5, 0.7), color_srgb, random_bg, linear_colors, scene["n_img"], scene["M"],
+        ptr(net_u), 4, C.byref(cnt), ptr(k1["ray_indices"]), ptr(k1["rays"]), ptr(ns), ptr(k1["coords"]), ptr(cc), ptr(dl), 4, loss_type, ptr(loss), rgb_act, density_act, snap,
+        F(scene["mean"]), F(near))
+    return dict(ns=ns, cc=cc, dl=dl, loss=loss, cnt=cnt.value)
+
+
+def _same_k3(a, b, n_act):
+    assert a["cnt"] == b["cnt"] and a["cnt"] > 0
+    assert np.array_equal(a["ns"][:n_act], b["ns"][:n_act])
+    c = min(a["cnt"], len(a["cc"]))
+    assert np.array_equal(a["cc"][:c].view(np.uint32), b["cc"][:c].view(np.uint32))
+    assert np.array_equal(a["dl"][:c], b["dl"][:c]), int((a["dl"][:c] != b["dl"][:c]).sum())
+    assert np.array_equal(a["loss"].view(np.uint32), b["loss"].view(np.uint32))
+    assert np.abs(a["dl"][:c].view(np.float16).astype(np.float32)).sum() > 0 and a["loss"].sum() > 0
+
+
+K3_CASES = [(A.LOSS_HUBER, 0, 1, 0, A.ACT_LOGISTIC, A.ACT_EXPONENTIAL), (A.LOSS_L2, 1, 0, 0, A.ACT_LOGISTIC, A.ACT_EXPONENTIAL), (A.LOSS_L1, 0, 0, 1, A.ACT_EXPONENTIAL, A.ACT_RELU),
+            (A.LOSS_MAPE, 1, 1, 1, A.ACT_RELU, A.ACT_LOGISTIC), (A.LOSS_SMAPE, 0, 1, 0, A.ACT_NONE, A.ACT_EXPONENTIAL), (A.LOSS_LOGL1, 1, 1, 0, A.ACT_LOGISTIC, A.ACT_EXPONENTIAL),
+            (A.LOSS_RELATIVE_L2, 0, 0, 0, A.ACT_LOGISTIC, A.ACT_NONE)]
+
+
+@pytest.mark.parametrize("loss_type,color_srgb,random_bg,linear_colors,rgb_act,density_act", K3_CASES)
+def test_k3_compute_loss(ref, ora, scene, loss_type, color_srgb, random_bg, linear_colors, rgb_act, density_act):
+    """compute_loss_kernel_train_nerf (testbed_nerf.cu:852-1181): front-to-back compositing with early termination, the seven losses, background handling (fixed / random,
+    sRGB / linear), the adjoint loop, density regularisation near the camera, compaction into the padded batch -- and the batch clamp when the compacted samples do not fit"""
+    n_rays = 2048
+    k1 = _k1(ora, "ora_", ora, scene, n_rays, 1 << 19, 0, n_rays, 1, 0.0)
+    total = k1["numsteps_counter"].value
+    rs = np.random.default_rng(1)
+    net = np.zeros((1 << 19, 4), np.float16)
+    net[:total, :3] = rs.normal(0, 1.5, (total, 3)); net[:total, 3] = rs.normal(-1.0, 2.5, total)
+    net_u = net.view(np.uint16)
+    for B in (1 << 19, 4096):
+        a = _k3(ora, "ora_", ora, scene, k1, n_rays, B, net_u, loss_type, color_srgb, random_bg, linear_colors, rgb_act, density_act, 1, 0.1)
+        b = _k3(ref, "ref_", ora, scene, k1, n_rays, B, net_u, loss_type, color_srgb, random_bg, linear_colors, rgb_act, density_act, 1, 0.1)
+        _same_k3(a, b, k1["ray_counter"].value)
+
+
+@pytest.mark.parametrize("depth_loss", [A.LOSS_L1, A.LOSS_L2, A.LOSS_HUBER])
+def test_k3_depth_supervision(ref, ora, scene, depth_loss):
+    """depth supervision (testbed_nerf.cu:1027-1029, 1126-1129): a depth image per view with holes (0 = no measurement)"""
+    n_rays = 1500
+    w, h = scene["M"][0].resolution[0], scene["M"][0].resolution[1]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    keep = []
+    for i in range(scene["n_img"]):
+        dep = (0.9 + 0.4 * np.sin(0.13 * xx + i) * np.cos(0.09 * yy)).astype(np.float32)
+        dep[(xx.astype(int) + yy.astype(int) + i) % 7 == 0] = 0.0
+        dep = np.ascontiguousarray(dep.reshape(-1)); keep.append(dep); scene["M"][i].depth = dep.ctypes.data
+    ora.ora_set_depth_supervision(F(0.7), depth_loss); ref.ref_set_depth_supervision(F(0.7), depth_loss)
+    try:
+        k1 = _k1(ora, "ora_", ora, scene, n_rays, 1 << 18, 0, n_rays, 0, 1.0 / 256.0)
+        total = k1["numsteps_counter"].value
+        rs = np.random.default_rng(2)
+        net = np.zeros((1 << 18, 4), np.float16); net[:total, :3] = rs.normal(0, 1.5, (total, 3)); net[:total, 3] = rs.normal(-1.0, 2.5, total)
+        a = _k3(ora, "ora_", ora, scene, k1, n_rays, 1 << 18, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 0, 0.1)
+        b = _k3(ref, "ref_", ora, scene, k1, n_rays, 1 << 18, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 0, 0.1)
+        _same_k3(a, b, k1["ray_counter"].value)
+    finally:
+        ora.ora_set_depth_supervision(F(0.0), A.LOSS_L1); ref.ref_set_depth_supervision(F(0.0), A.LOSS_L1)
+        for i in range(scene["n_img"]):
+            scene["M"][i].depth = None
+
+
+def test_error_map_sampling_and_deposit(ref, ora, scene):
+    """construct_cdf_2d / construct_cdf_1d (testbed_nerf.cu:1530-1580), K1 drawing images and pixels from the CDFs (nerf_device.cuh:497-599) and K3 depositing the per-ray
+    error into the map with the pdf correction (testbed_nerf.cu:1042-1071)"""
+    n_img, hh, ww = scene["n_img"], 20, 28
+    rs = np.random.default_rng(0)
+    err = rs.uniform(0.0, 1e-3, (n_img, hh, ww)).astype(np.float32)
+    err[1, 3:6, 10:14] += 0.05; err[3, 15:, :4] += 0.02; err[2] = 0.0
+    cdfs = []
+    for lib, p in ((ora, "ora_"), (ref, "ref_k_")):
+        cxy = np.zeros_like(err); cy = np.zeros((n_img, hh), np.float32); ci = np.zeros(n_img, np.float32)
+        getattr(lib, p + "construct_error_cdfs")(n_img, ww, hh, _fp(err), _fp(cxy), _fp(cy), _fp(ci))
+        cdfs.append((cxy, cy, ci))
+    for x, y in zip(cdfs[0][:2], cdfs[1][:2]):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    # the kernels leave the per-image sums in cdf_img; the image CDF is computed from them on the host (testbed_nerf.cu:2831-2846), restated here in float32
+    raw = cdfs[1][2]; cum = np.float32(0); acc = np.zeros(n_img, np.float32)
+    for i in range(n_img):
+        cum = np.float32(cum + raw[i]); acc[i] = cum
+    norm = np.float32(1.0) / cum
+    host = np.array([np.float32(np.float32(np.float32(np.float32(1.0) - np.float32(0.1)) * acc[i]) * norm) + np.float32(np.float32(np.float32(0.1) * np.float32(i + 1)) / np.float32(n_img)) for i in range(n_img)], np.float32)
+    assert np.array_equal(cdfs[0][2].view(np.uint32), host.view(np.uint32))
+    cxy, cy, ci = cdfs[0]
+    res = (C.c_int32 * 2)(ww, hh)
+    n_rays = 2000
+    out = []
+    for lib, p, setter in ((ora, "ora_", ora.ora_set_error_sampling), (ref, "ref_", ref.ref_set_error_sampling)):
+        emap = np.zeros((n_img, hh, ww), np.float32)
+        setter(_fp(cxy), _fp(cy), _fp(ci), res, _fp(emap), res)
+        try:
+            k1 = _k1(lib, p, ora, scene, n_rays, 1 << 19, 0, n_rays, 0, 0.0)
+            total = k1["numsteps_counter"].value
+            net = np.zeros((1 << 19, 4), np.float16); r2 = np.random.default_rng(4)
+            net[:total, :3] = r2.normal(0, 1.5, (total, 3)); net[:total, 3] = r2.normal(-1.0, 2.5, total)
+            k3 = _k3(lib, p, ora, scene, k1, n_rays, 1 << 19, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 0, 0.1)
+        finally:
+            setter(None, None, None, None, None, None)
+        out.append((k1, k3, emap))
+    _same_k1(out[0][0], out[1][0])
+    _same_k3(out[0][1], out[1][1], out[0][0]["ray_counter"].value)
+    assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32)) and (out[0][2] > 0).sum() > 200
