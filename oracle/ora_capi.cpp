@@ -278,6 +278,7 @@ API void ora_sdf_signed_distance(const float* tris9, uint32_t n_tris, const floa
 API float ora_tri_distance_sq(const float* t9, const float* p) { return tri_distance_sq(*(const Tri*)t9, V3(p)); }
 API float ora_tri_ray_intersect(const float* t9, const float* ro, const float* rd) { return tri_ray_intersect(*(const Tri*)t9, V3(ro), V3(rd)); }
 API void ora_fibonacci_dir32(uint32_t i, const float* offset2, float* out) { const vec3 r = fibonacci_dir32(i, offset2[0], offset2[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+API float ora_logistic_from_uniform(float x, float stddev) { return logistic_from_uniform(x, stddev); }
 API uint32_t ora_cdf_search(float val, const float* cdf, uint32_t n) { return cdf_search(val, cdf, n); }
 API void ora_sdf_generate_positions(const float* tris9, uint32_t n_tris, const float* cdf, uint32_t n, uint32_t n_exact, uint32_t n_surface, ngp_pcg32 rng, float stddev,
 		ngp_aabb box, float* positions, float* distances) {

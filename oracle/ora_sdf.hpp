@@ -1,5 +1,6 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ora_math.hpp header).  PARITY PINNED for the ground-truth signed distance against the reference's triangle BVH compiled for
-// the CPU (oracle/_ref/libngpbvh_ref.so, tests/test_ref_sdf.py: |distance| bit for bit); UNPINNED for the sample generator (testbed_sdf.cu is not compilable here).
+// the CPU (oracle/_ref/libngpbvh_ref.so, tests/test_ref_sdf.py: |distance| bit for bit); PINNED for the sample generator from the random numbers on against the reference's kernels of
+// testbed_sdf.cu (oracle/_ref/libngpimgsdf_ref.so); tcnn's random-number generators themselves are [tcnn].
 // ora_sdf.hpp: the SDF primitive's data path restated on the CPU WITHOUT an acceleration structure: ground-truth signed distances by
 // brute force over all triangles (Triangle::distance_sq / ray_intersect, triangle.cuh:87-129; signed_distance_raystab with 32 Fibonacci stab
 // rays, triangle_bvh.cu:631-650, per-element rng :893-909; fibonacci_dir random_val.cuh:45-101) and generate_training_samples_sdf's

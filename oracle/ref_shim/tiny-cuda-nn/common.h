@@ -52,6 +52,8 @@ template <typename T> struct tvec<T, 3> {
 	const T& operator[](uint32_t i) const { return i == 0 ? x : i == 1 ? y : z; }
 	tvec<T, 2>& xy() { return *reinterpret_cast<tvec<T, 2>*>(this); } // (x, y are the first two members: swizzles that can be assigned to)
 	const tvec<T, 2>& xy() const { return *reinterpret_cast<const tvec<T, 2>*>(this); }
+	tvec<T, 2>& yz() { return *reinterpret_cast<tvec<T, 2>*>(&y); }
+	const tvec<T, 2>& yz() const { return *reinterpret_cast<const tvec<T, 2>*>(&y); }
 	tvec<T, 3>& rgb() { return *this; }
 	const tvec<T, 3>& rgb() const { return *this; }
 	static constexpr uint32_t size() { return 3; }
@@ -136,6 +138,7 @@ inline float fract(float x) { return x - std::floor(x); }
 using vec2 = tvec<float, 2>; using vec3 = tvec<float, 3>; using vec4 = tvec<float, 4>;
 using ivec2 = tvec<int, 2>; using ivec3 = tvec<int, 3>; using ivec4 = tvec<int, 4>;
 using uvec2 = tvec<uint32_t, 2>; using uvec3 = tvec<uint32_t, 3>; using uvec4 = tvec<uint32_t, 4>;
+using u16vec3 = tvec<uint16_t, 3>;
 using bvec3 = tvec<bool, 3>;
 using u16vec2 = tvec<uint16_t, 2>;
 

@@ -4,7 +4,8 @@ oracle/_ref/libngpbvh_ref.so is src/triangle_bvh.cu (with triangle.cuh, bounding
 (oracle/Makefile, oracle/ref_bvh_wrapper.cpp) against oracle/ref_shim; its "kernels" run as loops.  The oracle (oracle/ora_sdf.hpp) restates the same ground truth WITHOUT an
 acceleration structure, and the HIP path's own BVH is checked against that oracle on the GPU (tests/test_sdf.py).  Here: the reference's BVH, built and traversed by the
 reference's code, must give the oracle's numbers -- unsigned distances bit for bit (a traversal only prunes), signs of the 32-ray stab test on every query point that is not
-within rounding of a silhouette.  Skipped when oracle/_ref is not built."""
+within rounding of a silhouette.  Second part (below): the batch generators of the image and SDF primitives against the reference's own kernels of testbed_image.cu /
+testbed_sdf.cu (oracle/_ref/libngpimgsdf_ref.so).  Skipped when oracle/_ref is not built."""
 import ctypes as C
 import os
 
@@ -229,3 +230,100 @@ def test_product_bvh_on_the_host_equals_the_reference_bvh(ref, o, hip_lib, mesh)
     area = np.array([ref.ref_tri_surface_area(_fp(t)) for t in ordered], np.float32)
     cdf_ref = np.zeros(n_tris, np.float32); ref.ref_discrete_distribution_build(_fp(area), n_tris, _fp(cdf_ref))
     assert np.array_equal(_bits(cdf), _bits(cdf_ref))
+
+
+# ---- the sample generators of the image and SDF primitives against the reference's own kernels (oracle/_ref/libngpimgsdf_ref.so) --------------------------------------
+IMGSDF_SO = os.path.join(ROOT, "oracle", "_ref", "libngpimgsdf_ref.so")
+
+
+@pytest.fixture(scope="module")
+def refk():
+    if not os.path.exists(IMGSDF_SO):
+        pytest.skip("oracle/_ref/libngpimgsdf_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    return C.CDLL(IMGSDF_SO)
+
+
+def _seeded(ora, seed=1337, advance=0):
+    import ngp_abi as A
+    s = A.Pcg32(); ora.ora_pcg32_seed(C.byref(s), C.c_uint64(seed), C.c_uint64(1))
+    if advance:
+        ora.ora_pcg32_advance(C.byref(s), C.c_int64(advance))
+    return s
+
+
+@pytest.mark.parametrize("n,stratified,snap,linear", [(4096, 1, 0, 0), (4096, 0, 1, 1), (3000, 1, 1, 0), (1024, 0, 0, 1)])
+def test_image_batch_against_the_reference_kernels(refk, o, n, stratified, snap, linear):
+    """train_image's batch (testbed_image.cu:66-82 stratify2_kernel, :176-229 eval_image_kernel_and_snap<float, 3>) from the same uniform numbers: positions (stratified, snapped
+    to pixel centres) and targets (nearest texel when snapping, bilinear otherwise, sRGB or linear), bit for bit against the oracle's image_generate_batch, which is what the
+    HIP trainer's batches are compared with on the GPU.  tcnn's generate_random_uniform is not part of this: both sides start from the oracle's uniform numbers."""
+    rs = np.random.default_rng(0); w, h = 37, 23
+    img = np.ascontiguousarray(rs.uniform(0, 1.2, (h, w, 4)).astype(np.float32))
+    raw = np.zeros((n, 2), np.float32); t0 = np.zeros((n, 3), np.float32)
+    o.ora_image_generate_batch(_fp(img), w, h, n, _seeded(o), 0, 0, 1, _fp(raw), _fp(t0))  # no stratification, no snapping: the positions are the uniform numbers
+    assert 0.0 <= raw.min() and raw.max() < 1.0
+    pos_o = np.zeros((n, 2), np.float32); tgt_o = np.zeros((n, 3), np.float32)
+    o.ora_image_generate_batch(_fp(img), w, h, n, _seeded(o), stratified, snap, linear, _fp(pos_o), _fp(tgt_o))
+    pos_r = raw.copy(); tgt_r = np.zeros((n, 3), np.float32)
+    refk.ref_image_generate_batch_from_uniforms(_fp(img), w, h, n, stratified, snap, linear, _fp(pos_r), _fp(tgt_r))
+    assert np.array_equal(_bits(pos_o), _bits(pos_r)) and np.array_equal(_bits(tgt_o), _bits(tgt_r))
+    assert stratified == 0 or n != 4096 or not np.array_equal(pos_o, raw)
+
+
+def test_image_mse_kernels(refk):
+    """compute_image_mse's kernels (testbed_image.cu:459-488) against the formula csrc/image_kernels.hip k_image_mse and its GPU test use: per-pixel dot(diff, diff) / 3, with
+    the prediction optionally rounded to bytes by (int)(p * 255 + 0.5) clamped to [0, 255]"""
+    rs = np.random.default_rng(1); n, w, h = 5000, 61, 40
+    pos = np.zeros((w * h, 2), np.float32); refk.ref_image_coords_from_idx(w * h, 0, w, h, _fp(pos))
+    xs, ys = np.meshgrid(np.arange(w), np.arange(h))
+    mine = np.stack([(xs.reshape(-1).astype(np.float32) + np.float32(0.5)) / np.float32(w), (ys.reshape(-1).astype(np.float32) + np.float32(0.5)) / np.float32(h)], 1).astype(np.float32)
+    assert np.array_equal(_bits(pos), _bits(mine))
+    tgt = rs.uniform(0, 1, (n, 3)).astype(np.float32); pred = rs.uniform(-0.1, 1.1, (n, 3)).astype(np.float32)
+    for q in (0, 1):
+        out = np.zeros(n, np.float32); refk.ref_image_mse(n, _fp(tgt), _fp(pred), _fp(out), q)
+        p = pred if not q else (np.clip((pred * np.float32(255.0) + np.float32(0.5)).astype(np.int32), 0, 255).astype(np.float32) / np.float32(255.0))
+        d = tgt - p
+        want = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]) / np.float32(3.0)
+        assert np.array_equal(_bits(out), _bits(want.astype(np.float32)))
+
+
+def test_sdf_training_positions_against_the_reference_kernels(refk, o):
+    """generate_training_samples_sdf (testbed_sdf.cu:1449-1544) from the random numbers on: sample_uniform_on_triangle_kernel (surface CDF -> triangle -> uniform point),
+    scale_to_aabb_kernel + assign_float for the uniform eighth, perturb_sdf_samples for the offset points -- positions and distance upper bounds bit for bit against the
+    oracle's sdf_generate_positions.  The random numbers themselves (tcnn's generate_random_uniform / _logistic) are the oracle's on both sides; the signed distances that
+    follow are pinned by the BVH tests above."""
+    import ngp_abi as A
+    rs = np.random.default_rng(2)
+    tris = _torus_mesh(32, 16); n_tris = len(tris)
+    area = np.array([0.5 * np.linalg.norm(np.cross(t[3:6] - t[0:3], t[6:9] - t[0:3])) for t in tris.astype(np.float64)], np.float32)
+    cdf = (np.cumsum(area.astype(np.float64)) / area.astype(np.float64).sum()).astype(np.float32); cdf[-1] = 1.0
+    n = 4096; n_exact, n_surface = n // 8 * 4, n // 8 * 7
+    stddev = float(np.float32(np.sqrt(0.75)) / np.float32(1024.0))
+    box = A.Aabb(); unit = A.Aabb()
+    for k in range(3):
+        box.min[k] = [0.05, 0.1, 0.2][k]; box.max[k] = [0.95, 0.9, 0.8][k]; unit.min[k] = 0.0; unit.max[k] = 1.0
+    # the uniform numbers: with no surface samples and the unit box, positions = 0 + u * 1 = u
+    u = np.zeros((n, 3), np.float32); dummy = np.zeros(n, np.float32)
+    o.ora_sdf_generate_positions(_fp(tris), n_tris, _fp(cdf), n, 0, 0, _seeded(o), F(stddev), unit, _fp(u), _fp(dummy))
+    # the perturbation stream continues 3 n draws further on (the oracle's layout of generate_random_logistic after generate_random_uniform)
+    n_off = n_surface - n_exact
+    u2 = np.zeros((n_off, 3), np.float32); d2 = np.zeros(n_off, np.float32)
+    o.ora_sdf_generate_positions(_fp(tris), n_tris, _fp(cdf), n_off, 0, 0, _seeded(o, advance=3 * n), F(stddev), unit, _fp(u2), _fp(d2))
+    o.ora_logistic_from_uniform.restype = F
+    pert = np.array([[o.ora_logistic_from_uniform(F(float(x)), F(stddev)) for x in row] for row in u2], np.float32)
+    pos_o = np.zeros((n, 3), np.float32); dist_o = np.zeros(n, np.float32)
+    o.ora_sdf_generate_positions(_fp(tris), n_tris, _fp(cdf), n, n_exact, n_surface, _seeded(o), F(stddev), box, _fp(pos_o), _fp(dist_o))
+    pos_r = u.copy(); dist_r = np.full(n, -1.0, np.float32)
+    refk.ref_sdf_generate_positions_from_randoms(_fp(tris), n_tris, _fp(cdf), n, n_exact, n_surface, _fp(pert), box, _fp(pos_r), _fp(dist_r))
+    assert np.array_equal(_bits(pos_o), _bits(pos_r)) and np.array_equal(_bits(dist_o), _bits(dist_r))
+    assert (dist_o[:n_exact] == 0).all() and (dist_o[n_exact:n_surface] > 0).all() and len(set(dist_o[n_surface:].tolist())) == 1
+
+
+def test_sdf_iou_counters(refk):
+    """compare_signs_kernel without an octree (testbed_sdf.cu:540-569): the eight counters calculate_iou reads, against the definition csrc/sdf_kernels.hip k_sdf_compare_signs
+    implements (inside = distance <= 0; counters = ref inside / outside, model inside / outside, intersection, union, outside-octree = 0, inside-octree = n)"""
+    rs = np.random.default_rng(3); n = 20000
+    pos = rs.uniform(0, 1, (n, 3)).astype(np.float32)
+    dr = rs.normal(0, 1, n).astype(np.float32); dm = (dr + rs.normal(0, 0.5, n)).astype(np.float32); dr[::97] = 0.0; dm[::89] = -0.0
+    c = np.zeros(8, np.uint32); refk.ref_sdf_compare_signs(n, _fp(pos), _fp(dr), _fp(dm), c.ctypes.data_as(C.c_void_p))
+    i1, i2 = dr <= 0, dm <= 0
+    assert c.tolist() == [int(i1.sum()), int((~i1).sum()), int(i2.sum()), int((~i2).sum()), int((i1 & i2).sum()), int((i1 | i2).sum()), 0, n]
