@@ -1,6 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ora_math.hpp header).  PARITY PINNED for K1, K3, the occupancy-grid kernels and the error-map CDF kernels against the
-// reference's own kernels compiled for the CPU (oracle/_ref/libngpkern_ref.so, tests/test_ref_kernels.py: bit for bit), UNPINNED for the renderer and the trainer's
-// host logic.
+// reference's own kernels compiled for the CPU (oracle/_ref/libngpkern_ref.so, tests/test_ref_kernels.py: bit for bit), for render() against the reference's fused
+// renderer (libngprender_ref.so: bit for bit) and for the Rfl / RflRelax train modes against its fused training kernel (libngptrain_ref.so: 2 fp16 ulp); UNPINNED for the
+// trainer's host logic (Testbed members).
 //
 // ora_nerf.hpp: CPU restatement of the ngp-side NeRF kernels: camera model, K1
 // generate_training_samples_nerf, K3 compute_loss_kernel_train_nerf, the occupancy-grid update chain,

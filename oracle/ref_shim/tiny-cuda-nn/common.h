@@ -28,7 +28,15 @@ namespace tcnn {
 using std::min; using std::max; using std::abs; using std::sqrt; using std::pow; using std::exp; using std::log; using std::floor; using std::ceil; using std::copysign;
 using std::isfinite; using std::isnan; using std::sin; using std::cos; using std::tan; using std::atan; using std::atan2; using std::asin; using std::acos; using std::fmod;
 
-template <typename T, uint32_t N> struct tvec;
+// vectors of other lengths (the fused kernels' network input, vec<7>): plain arrays
+template <typename T, uint32_t N> struct tvec {
+	T data[N];
+	tvec() : data{} {}
+	tvec(T s) { for (uint32_t i = 0; i < N; ++i) data[i] = s; }
+	T& operator[](uint32_t i) { return data[i]; }
+	const T& operator[](uint32_t i) const { return data[i]; }
+	static constexpr uint32_t size() { return N; }
+};
 template <typename T> struct tvec<T, 2> {
 	union { T x, r; }; union { T y, g; };
 	tvec() : x{}, y{} {}
@@ -139,6 +147,7 @@ using vec2 = tvec<float, 2>; using vec3 = tvec<float, 3>; using vec4 = tvec<floa
 using ivec2 = tvec<int, 2>; using ivec3 = tvec<int, 3>; using ivec4 = tvec<int, 4>;
 using uvec2 = tvec<uint32_t, 2>; using uvec3 = tvec<uint32_t, 3>; using uvec4 = tvec<uint32_t, 4>;
 using u16vec3 = tvec<uint16_t, 3>;
+template <uint32_t N> using vec = tvec<float, N>;
 using bvec3 = tvec<bool, 3>;
 using u16vec2 = tvec<uint16_t, 2>;
 

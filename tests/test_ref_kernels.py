@@ -267,3 +267,110 @@ def test_error_map_sampling_and_deposit(ref, ora, scene):
     _same_k1(out[0][0], out[1][0])
     _same_k3(out[0][1], out[1][1], out[0][0]["ray_counter"].value)
     assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32)) and (out[0][2] > 0).sum() > 200
+
+
+RENDER_SO = os.path.join(ROOT, "oracle", "_ref", "libngprender_ref.so")
+
+
+@pytest.mark.parametrize("aabb_scale,spp,snap,min_transmittance", [(1, 0, 1, 1e-4), (1, 3, 0, 0.8), (4, 1, 0, 1e-4)])
+def test_fused_renderer(ora, scene, aabb_scale, spp, snap, min_transmittance):
+    """fused_kernels/render_nerf.cuh -- the reference's per-pixel renderer, compiled for the CPU with the oracle's network plugged in as its eval_nerf -- against the oracle's
+    render(): pixel jitter, camera ray, entry into the render box, the jittered first step, skipping through the (pooled) occupancy levels, compositing with early
+    termination and re-normalisation, the depth of the heaviest sample, sRGB -> linear.  Frame (premultiplied linear RGBA) and depth, bit for bit."""
+    if not os.path.exists(RENDER_SO):
+        pytest.skip("oracle/_ref/libngprender_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    from common import OraModel
+    refr = C.CDLL(RENDER_SO)
+    cfg = A.base_model_config(aabb_scale)
+    om = OraModel(ora, cfg)
+    rs = np.random.default_rng(5)
+    p = om.params_fp
+    p[om.n_mlp:] = rs.uniform(-1, 1, om.n - om.n_mlp).astype(np.float32)  # trained-like table values: densities and colours vary over space
+    ora.ora_model_sync_half(om.h)
+    opts = A.default_nerf_options(aabb_scale, target_batch_size=1 << 14)
+    aabb = A.scene_aabb(aabb_scale)
+    ot = C.c_void_p()
+    assert ora.ora_nerf_create(om.h, C.byref(opts), aabb, C.byref(ot)) == 0
+    try:
+        ora.ora_nerf_set_dataset(ot, scene["n_img"], scene["M"], scene["X"])
+        n_casc = opts.max_cascade + 1
+        ora.ora_nerf_density_grid.restype = C.POINTER(C.c_float); ora.ora_nerf_bitfield.restype = C.POINTER(C.c_uint8)
+        grid = np.ctypeslib.as_array(ora.ora_nerf_density_grid(ot), shape=(N_CELLS * n_casc,))
+        grid[:] = np.where(rs.uniform(size=N_CELLS * n_casc // 64).repeat(64) < 0.3, 0.5, 0.0)
+        ora.ora_nerf_update_mean_and_bitfield(ot)
+        bf = np.ctypeslib.as_array(ora.ora_nerf_bitfield(ot), shape=(N_CELLS,))
+        res = 28
+        rp = A.RenderParams()
+        rp.resolution[0], rp.resolution[1] = res, res - 6
+        M, X = scene["M"], scene["X"]
+        rp.focal_length[0] = rp.focal_length[1] = M[0].focal_length[0] * res / M[0].resolution[0]
+        rp.screen_center[0], rp.screen_center[1] = 0.5, 0.47
+        for k in range(12):
+            rp.camera[k] = X[2].start[k]
+        rp.lens_mode = 0; rp.spp_index = spp; rp.snap_to_pixel_centers = snap; rp.min_transmittance = min_transmittance; rp.near_distance = 0.05; rp.use_inference_params = 0
+        rp.render_aabb = aabb
+        n_px = rp.resolution[0] * rp.resolution[1]
+        f_o = np.zeros((n_px, 4), np.float32); d_o = np.zeros(n_px, np.float32)
+        assert ora.ora_nerf_render(ot, C.byref(rp), ptr(f_o), ptr(d_o)) == 0
+        f_r = np.zeros((n_px, 4), np.float32); d_r = np.zeros(n_px, np.float32)
+        infer = C.cast(ora.ora_model_inference, C.c_void_p)
+        refr.ref_render_nerf(C.byref(rp), aabb, bf.ctypes.data_as(C.c_void_p), opts.max_cascade, F(opts.cone_angle_constant), opts.rgb_activation, opts.density_activation,
+                             opts.linear_colors, infer, om.h, ptr(f_r), ptr(d_r))
+        assert np.array_equal(f_o.view(np.uint32), f_r.view(np.uint32)) and np.array_equal(d_o.view(np.uint32), d_r.view(np.uint32))
+        # (a random network is translucent: accumulated alpha 0.1 .. 0.4; min_transmittance = 0.8 makes the early-termination branch and its re-normalisation run)
+        assert (f_o[:, 3] > 0.05).mean() > 0.5 and len(np.unique(d_o)) > 20 and (min_transmittance < 0.5 or (f_o[:, 3] == 1.0).mean() > 0.2)
+    finally:
+        ora.ora_nerf_destroy(ot)
+
+
+TRAIN_SO = os.path.join(ROOT, "oracle", "_ref", "libngptrain_ref.so")
+
+
+@pytest.mark.parametrize("train_mode,loss_type", [(0, A.LOSS_HUBER), (1, A.LOSS_HUBER), (2, A.LOSS_HUBER), (1, A.LOSS_L2), (2, A.LOSS_L2)])
+def test_train_modes_against_the_fused_training_kernel(ora, scene, train_mode, loss_type):
+    """fused_kernels/train_nerf.cuh -- the reference's one-kernel training step and the only place where ETrainMode::Rfl / RflRelax are written down (:391-410) -- compiled for
+    the CPU with the oracle's network as its eval_nerf.  The samples it chose (its own marcher) and the network's outputs at them go through the oracle's K3 in the same
+    train mode; per ray the loss and per sample dL/doutput must agree.  Not to the bit: the fused kernel carries the accumulated alpha (T = 1 - color.a) where the unfused
+    K3 -- pinned to the bit above -- multiplies transmittances (so losses with a discontinuous gradient, L1, are left out: a last-bit difference flips a sign); bar: 2 fp16 ulp relative + 2e-7 absolute on the gradient (loss scale 128), 1e-5 relative on the loss."""
+    if not os.path.exists(TRAIN_SO):
+        pytest.skip("oracle/_ref/libngptrain_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    from common import OraModel
+    reft = C.CDLL(TRAIN_SO)
+    om = OraModel(ora, A.base_model_config(1))
+    rs = np.random.default_rng(6)
+    p = om.params_fp; p[om.n_mlp:] = rs.uniform(-1, 1, om.n - om.n_mlp).astype(np.float32); ora.ora_model_sync_half(om.h)
+    n_rays, cap = 300, 1 << 17
+    bg = (F * 3)(0.2, 0.5, 0.7)
+    rc, nc = C.c_uint32(), C.c_uint32()
+    ri = np.zeros(n_rays, np.uint32); ns = np.zeros((n_rays, 2), np.uint32); cc = np.zeros((cap, 7), np.float32); dl = np.zeros((cap, 4), np.uint16); loss = np.zeros(n_rays, np.float32)
+    reft.ref_fused_train_nerf(n_rays, A.scene_aabb(1), cap, _rng(ora), scene["n_img"], scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, F(0.0), F(128.0), bg, 0, 0, 0, loss_type,
+                              A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, F(scene["mean"]), F(0.1), train_mode, C.cast(ora.ora_model_inference, C.c_void_p), om.h,
+                              C.byref(rc), C.byref(nc), ptr(ri), ptr(ns), ptr(cc), ptr(dl), ptr(loss))
+    n_act, total = rc.value, nc.value
+    assert n_act > 0.5 * n_rays and total > 10 * n_act and total <= cap
+    # the rays themselves: the unfused K1 sets them up from the same random numbers (pinned above); rays it drops (no sample on its march) are left out
+    k1 = _k1(ora, "ora_", ora, scene, n_rays, 1 << 19, 0, n_rays, 1, 0.0)
+    ray_of = {int(r): k1["rays"][j] for j, r in enumerate(k1["ray_indices"][: k1["ray_counter"].value])}
+    keep = [j for j in range(n_act) if int(ri[j]) in ray_of]
+    assert len(keep) > 0.9 * n_act
+    ri_k = np.ascontiguousarray(ri[keep]); ns_k = np.ascontiguousarray(ns[keep]); rays_k = np.ascontiguousarray(np.stack([ray_of[int(r)] for r in ri_k]).astype(np.float32))
+    net = np.zeros((cap, 4), np.uint16)
+    ora.ora_model_inference(om.h, ptr(cc), 7, total, ptr(net), 4, 0)
+    o_cc = np.zeros((cap, 7), np.float32); o_dl = np.zeros((cap, 4), np.uint16); o_loss = np.zeros(n_rays, np.float32); o_cnt = C.c_uint32(); o_ns = ns_k.copy()
+    ora.ora_set_train_mode(train_mode)
+    try:
+        ora.ora_k_compute_loss(n_rays, len(keep), A.scene_aabb(1), _rng(ora), cap, F(128.0), bg, 0, 0, 0, scene["n_img"], scene["M"], ptr(net), 4, C.byref(o_cnt), ptr(ri_k), ptr(rays_k),
+                               ptr(o_ns), ptr(cc), ptr(o_cc), ptr(o_dl), 4, loss_type, ptr(o_loss), A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, F(scene["mean"]), F(0.1))
+    finally:
+        ora.ora_set_train_mode(0)
+    assert np.array_equal(o_ns[:, 0], ns_k[:, 0])  # both stop compositing at the same sample
+    n_cmp = 0; worst = 0.0
+    for j in range(len(keep)):
+        k, bf_, bo = int(ns_k[j, 0]), int(ns_k[j, 1]), int(o_ns[j, 1])
+        a = dl[bf_:bf_ + k].view(np.float16).astype(np.float32); b = o_dl[bo:bo + k].view(np.float16).astype(np.float32)
+        err = np.abs(a - b) - (2e-7 + 2.0 ** -9 * np.abs(b))
+        worst = max(worst, float(err.max()))
+        n_cmp += k
+        assert abs(loss[keep[j]] - o_loss[j]) <= 1e-5 * abs(o_loss[j]) + 1e-12, (j, loss[keep[j]], o_loss[j])
+    assert worst <= 0.0 and n_cmp > 2500, worst
+    assert np.abs(dl[:total].view(np.float16).astype(np.float32)).max() > 1e-4
