@@ -374,3 +374,41 @@ def test_train_modes_against_the_fused_training_kernel(ora, scene, train_mode, l
         assert abs(loss[keep[j]] - o_loss[j]) <= 1e-5 * abs(o_loss[j]) + 1e-12, (j, loss[keep[j]], o_loss[j])
     assert worst <= 0.0 and n_cmp > 2500, worst
     assert np.abs(dl[:total].view(np.float16).astype(np.float32)).max() > 1e-4
+
+
+def test_tonemap_and_accumulate_against_render_buffer_cu():
+    """tonemap_kernel with tonemap() (render_buffer.cu:264-342, 511-543) and accumulate_kernel (:228-262) compiled for the CPU, against the PRODUCT's per-pixel tonemapping
+    evaluated on the host from the device source (ngp_host_tonemap_pixel = csrc/ngp_device.hpp tonemap_pixel): background behind the premultiplied colour, exposure, the four
+    curves (Identity, ACES, Hable, Reinhard), linear -> sRGB.  Backgrounds whose sRGB -> linear conversion is exact (the kernel takes an sRGB background, the product a linear
+    one).  Bar: 4 ulp (the product folds each curve's constants into one rational expression; the reference evaluates the textbook form), bit-exact for the Identity curve
+    with a power-of-two exposure.  accumulate_kernel's running mean (old * n + new) / (n + 1): restated bit for bit; the product's k_render_accumulate uses the
+    incremental form old + (new - old) * (1 / (n + 1)), which must agree to rounding (3e-7)."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libngprb_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libngprb_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    rb = C.CDLL(so); lib = A.load_hip()
+    rs = np.random.default_rng(0); n = 400
+    a = rs.uniform(0, 1, n).astype(np.float32); a[::7] = 1.0; a[::11] = 0.0
+    acc = np.ascontiguousarray(np.concatenate([rs.uniform(0, 3, (n, 3)).astype(np.float32) * a[:, None], a[:, None]], 1))
+    out = (F * 4)()
+    for bg in ((0, 0, 0, 1), (1, 1, 1, 1), (0, 0, 0, 0), (1, 1, 1, 0.5)):
+        for curve in range(4):
+            for to_srgb in (0, 1):
+                for exposure in (0.0, 1.0, -2.0, 0.37):
+                    ref_out = np.zeros((n, 4), np.float32)
+                    rb.ref_tonemap(n, F(exposure), (F * 4)(*bg), _fp(acc.copy()), to_srgb, curve, 0, 0, _fp(ref_out))
+                    mine = np.zeros((n, 4), np.float32)
+                    for i in range(n):
+                        assert lib.ngp_host_tonemap_pixel((F * 4)(*acc[i]), F(exposure), (F * 4)(*bg), to_srgb, curve, out) == 0
+                        mine[i] = out[:]
+                    if curve == 0 and exposure != 0.37:
+                        assert np.array_equal(mine.view(np.uint32), ref_out.view(np.uint32)), (bg, curve, to_srgb, exposure)
+                    else:
+                        assert np.allclose(mine, ref_out, rtol=4 * 2.0 ** -23, atol=1e-7), (bg, curve, to_srgb, exposure, np.abs(mine - ref_out).max())
+    frame = rs.uniform(0, 1, (n, 4)).astype(np.float32); mean = rs.uniform(0, 1, (n, 4)).astype(np.float32)
+    for count in (0.0, 1.0, 7.0):
+        m = mean.copy(); rb.ref_accumulate(n, _fp(frame.copy()), _fp(m), F(count), 0)
+        want = (mean * np.float32(count) + frame) / np.float32(count + 1)
+        assert np.array_equal(m.view(np.uint32), want.astype(np.float32).view(np.uint32))
+        incremental = mean + (frame - mean) * (np.float32(1.0) / np.float32(count + 1))
+        assert np.allclose(incremental, m, rtol=3e-7, atol=1e-7)
