@@ -281,7 +281,7 @@ NGP_HD uint32_t mip_from_dt(float dt, f3 pos, uint32_t max_cascade = N_CASCADES 
 	frexpf(dt, &exponent);
 	return (uint32_t)clampi((int)mip, exponent, (int)max_cascade);
 }
-NGP_D float skip_to_next_occupied(float t, float cone_angle, f3 o, f3 d, f3 idir, const uint8_t* __restrict__ grid,
+NGP_HD float skip_to_next_occupied(float t, float cone_angle, f3 o, f3 d, f3 idir, const uint8_t* __restrict__ grid,
 		uint32_t min_mip, uint32_t max_mip, const Box& aabb) {
 	while (true) {
 		f3 pos = o + d * t;
@@ -548,11 +548,11 @@ NGP_HD f4 tonemap_pixel(f4 c, float exposure_scale, float bg0, float bg1, float 
 }
 
 // read_depth, common_device.cuh:874-878
-NGP_D float read_depth(f2 uv, const int32_t res[2], const float* __restrict__ depth) {
+NGP_HD float read_depth(f2 uv, const int32_t res[2], const float* __restrict__ depth) {
 	const int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1), py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);
 	return depth[(size_t)px + (size_t)py * res[0]];
 }
-NGP_D f4 read_rgba(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type) {
+NGP_HD f4 read_rgba(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type) {
 	int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1);
 	int py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);
 	size_t idx = (size_t)px + (size_t)py * res[0];

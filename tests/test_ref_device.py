@@ -41,14 +41,40 @@ def ref():
     return lib
 
 
-@pytest.fixture(scope="module")
-def o(ora):
-    for n in ("calc_dt", "advance_n_steps", "to_stepping_space", "from_stepping_space", "advance_to_next_voxel", "distance_to_next_voxel", "warp_dt", "unwarp_dt", "network_to_rgb",
-              "network_to_rgb_derivative", "network_to_density", "network_to_density_derivative", "ld_random_val", "srgb_to_linear", "linear_to_srgb", "read_depth",
-              "if_unoccupied_advance_to_next_occupied_voxel"):
-        getattr(ora, "ora_" + n).restype = F
-    ora.ora_sobol.restype = C.c_uint32
-    return ora
+FLOAT_FNS = ("calc_dt", "advance_n_steps", "to_stepping_space", "from_stepping_space", "advance_to_next_voxel", "distance_to_next_voxel", "warp_dt", "unwarp_dt", "network_to_rgb",
+             "network_to_rgb_derivative", "network_to_density", "network_to_density_derivative", "ld_random_val", "srgb_to_linear", "linear_to_srgb", "read_depth",
+             "if_unoccupied_advance_to_next_occupied_voxel")
+
+
+class _ProductOnTheHost:
+    """`ora_<name>` -> `ngp_host_<name>` of libngp_hip.so (include/ngp_hip_host_hooks.h): the product's device source evaluated on the host, in the oracle's place"""
+
+    def __init__(self, lib, ora):
+        self._lib, self._ora = lib, ora
+        for n in FLOAT_FNS:
+            getattr(lib, "ngp_host_" + n).restype = F
+        lib.ngp_host_sobol.restype = C.c_uint32; lib.ngp_host_image_idx_cdf.restype = C.c_uint32
+
+    def __getattr__(self, name):
+        lib = self._lib
+        if name == "ora_uv_to_ray":  # (the camera hooks predate this file and take the metadata first)
+            return lambda uv, m, x, o3, d3: lib.ngp_host_uv_to_ray(m, x, uv, o3, d3)
+        if name == "ora_pos_to_uv":
+            return lambda p, m, x, uv2: lib.ngp_host_pos_to_uv(m, x, p, uv2)
+        if name == "ora_construct_error_cdfs":  # test set-up only (a kernel, compared on the GPU and in tests/test_ref_kernels.py)
+            return self._ora.ora_construct_error_cdfs
+        return getattr(lib, "ngp_host_" + name[4:])
+
+
+@pytest.fixture(scope="module", params=["oracle", "product_device_source_on_the_host"])
+def o(request, ora):
+    """the side that is held against the reference: the oracle's restatement, or the product's own device functions compiled for the host"""
+    if request.param == "oracle":
+        for n in FLOAT_FNS:
+            getattr(ora, "ora_" + n).restype = F
+        ora.ora_sobol.restype = C.c_uint32; ora.ora_image_idx_cdf.restype = C.c_uint32
+        return ora
+    return _ProductOnTheHost(A.load_hip(), ora)
 
 
 CONES = (0.0, 1.0 / 256.0, 1.0 / 128.0, 0.01)
@@ -236,7 +262,7 @@ def test_sampling_sequences_colour_and_texels(ref, o):
     cxy = np.zeros_like(err); cy = np.zeros((n_img, ch), np.float32); ci = np.zeros(n_img, np.float32)
     o.ora_construct_error_cdfs(n_img, cw, ch, _fp(err), _fp(cxy), _fp(cy), _fp(ci))
     pa, pb = C.c_float(), C.c_float()
-    o.ora_image_idx_cdf.restype = C.c_uint32; ref.ref_image_idx.restype = C.c_uint32
+    ref.ref_image_idx.restype = C.c_uint32
     for i in rs.integers(0, 2 ** 20, 600).tolist():
         assert o.ora_image_idx_cdf(int(i), n_img, _fp(ci), C.byref(pa)) == ref.ref_image_idx(int(i), 4096, 0, n_img, _fp(ci), C.byref(pb)) and _bits(pa.value) == _bits(pb.value)
     cres = (C.c_int32 * 2)(cw, ch)
