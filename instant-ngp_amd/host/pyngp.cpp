@@ -61,6 +61,33 @@ PYBIND11_MODULE(pyngp, m) {
 	py::enum_<ETonemapCurve>(m, "TonemapCurve").value("Identity", ETonemapCurve::Identity).value("ACES", ETonemapCurve::ACES).value("Hable", ETonemapCurve::Hable)
 		.value("Reinhard", ETonemapCurve::Reinhard).export_values();
 
+	py::enum_<ENerfActivation>(m, "NerfActivation").value("None", ENerfActivation::None).value("ReLU", ENerfActivation::ReLU).value("Logistic", ENerfActivation::Logistic)
+		.value("Exponential", ENerfActivation::Exponential).export_values(); // python_api.cu:364-369
+	// mode_from_scene / mode_from_string, common_host.cu:144-174
+	m.def("mode_from_scene", [](const std::string& scene) {
+		py::object os = py::module_::import("os");
+		if (!os.attr("path").attr("exists")(scene).cast<bool>()) return ETestbedMode::None;
+		std::string ext = scene.substr(scene.find_last_of('.') == std::string::npos ? scene.size() : scene.find_last_of('.') + 1);
+		for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
+		if (os.attr("path").attr("isdir")(scene).cast<bool>() || ext == "json") return ETestbedMode::Nerf;
+		if (ext == "obj" || ext == "stl") return ETestbedMode::Sdf;
+		if (ext == "nvdb") return ETestbedMode::Volume;
+		return ETestbedMode::Image;
+	});
+	m.def("mode_from_string", [](std::string str) {
+		for (auto& c : str) c = (char)std::tolower((unsigned char)c);
+		return str == "nerf" ? ETestbedMode::Nerf : str == "sdf" ? ETestbedMode::Sdf : str == "image" ? ETestbedMode::Image : str == "volume" ? ETestbedMode::Volume : ETestbedMode::None;
+	});
+	m.def("free_temporary_memory", []() {}); // python_api.cu:309: tcnn's memory arenas; this build holds no arena (fixed per-trainer scratch)
+	using V3 = std::array<float, 3>;
+	py::class_<BoundingBox>(m, "BoundingBox") // python_api.cu:409-427
+		.def(py::init<>()).def(py::init<const V3&, const V3&>())
+		.def("center", &BoundingBox::center).def("contains", &BoundingBox::contains).def("diag", &BoundingBox::diag).def("distance", &BoundingBox::distance)
+		.def("distance_sq", &BoundingBox::distance_sq).def("enlarge", py::overload_cast<const V3&>(&BoundingBox::enlarge)).def("enlarge", py::overload_cast<const BoundingBox&>(&BoundingBox::enlarge))
+		.def("get_vertices", &BoundingBox::get_vertices).def("inflate", &BoundingBox::inflate).def("intersection", &BoundingBox::intersection).def("intersects", &BoundingBox::intersects)
+		.def("ray_intersect", &BoundingBox::ray_intersect).def("relative_pos", &BoundingBox::relative_pos).def("signed_distance", &BoundingBox::signed_distance)
+		.def_readwrite("min", &BoundingBox::min).def_readwrite("max", &BoundingBox::max);
+
 	py::class_<Testbed> testbed(m, "Testbed");
 	py::class_<ImageMetadata>(testbed, "TrainingImageMetadata")
 		.def_readonly("resolution", &ImageMetadata::resolution).def_readonly("focal_length", &ImageMetadata::focal_length)
@@ -70,6 +97,18 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
 		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
 		.def_readonly("scale", &NerfDataset::scale).def_readonly("offset", &NerfDataset::offset).def_readonly("paths", &NerfDataset::paths)
+		.def_readonly("render_aabb", &NerfDataset::render_aabb).def_readonly("render_aabb_to_local", &NerfDataset::render_aabb_to_local).def_readonly("up", &NerfDataset::up)
+		.def_readonly("envmap_resolution", &NerfDataset::envmap_resolution)
+		.def_property_readonly("transforms", [](const NerfDataset& d) { // python_api.cu:768: the (start, end) pair per image, here as two 3 x 4 arrays each (ngp convention)
+			py::list out;
+			for (size_t i = 0; i < d.n_images; ++i) {
+				py::array_t<float> a({3, 4}), b({3, 4});
+				const auto& e = i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i];
+				for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { a.mutable_at(r, c) = d.xforms[i][c * 3 + r]; b.mutable_at(r, c) = e[c * 3 + r]; }
+				out.append(py::make_tuple(a, b));
+			}
+			return out;
+		})
 		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms).def_readonly("xforms_end", &NerfDataset::xforms_end).def_readonly("from_mitsuba", &NerfDataset::from_mitsuba)
 		.def("image", [](const NerfDataset& d, size_t i) {
 			if (i >= d.n_images) throw std::runtime_error{"image index out of range"};
@@ -99,10 +138,40 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("sample_focal_plane_proportional_to_error", &NerfTraining::sample_focal_plane_proportional_to_error) // python_api.cu:795
 		.def_readwrite("sample_image_proportional_to_error", &NerfTraining::sample_image_proportional_to_error)             // python_api.cu:796
 		.def_readwrite("accumulate_error_map", &NerfTraining::accumulate_error_map)
+		.def_readwrite("n_images_for_training", &NerfTraining::n_images_for_training) // python_api.cu:783
+		.def_property("loss_type", [](const NerfTraining& t) { return (ELossType)(t.loss_type < 0 ? 0 : t.loss_type); }, [](NerfTraining& t, ELossType v) { t.loss_type = (int)v; }) // :785 (unset: the config's)
+		.def_property_readonly("transforms", [](const NerfTraining& t) { return py::cast(t.dataset).attr("transforms"); }) // :798 (no extrinsics optimiser here: the dataset's)
+		.def("set_camera_intrinsics", [](NerfTraining& t, int i, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3, float k4, bool fisheye) {
+				t.owner->set_camera_intrinsics(i, fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, fisheye); },
+			py::arg("frame_idx"), py::arg("fx") = 0.f, py::arg("fy") = 0.f, py::arg("cx") = -0.5f, py::arg("cy") = -0.5f, py::arg("k1") = 0.f, py::arg("k2") = 0.f, py::arg("p1") = 0.f,
+			py::arg("p2") = 0.f, py::arg("k3") = 0.f, py::arg("k4") = 0.f, py::arg("is_fisheye") = false) // :814-830
+		.def("set_camera_extrinsics", [](NerfTraining& t, int i, py::array_t<float, py::array::c_style | py::array::forcecast> a, bool convert) {
+				if (a.size() < 12) throw std::runtime_error{"set_camera_extrinsics expects a 3x4 matrix"};
+				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];
+				t.owner->set_camera_extrinsics(i, mm, convert); }, py::arg("frame_idx"), py::arg("camera_to_world"), py::arg("convert_to_ngp") = true) // :831-838
+		.def("get_camera_extrinsics", [](NerfTraining& t, int i) {
+				const auto mm = t.owner->get_camera_extrinsics(i); py::array_t<float> out({3, 4}); std::memcpy(out.mutable_data(), mm.data(), sizeof(float) * 12); return out; }, py::arg("frame_idx")) // :839-844
+		// camera / exposure / latent optimisation and the sharpness-weighted error map are not part of this build: the switches exist, turning one on says so
+		.def_property("optimize_extrinsics", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_extrinsics: camera optimisation is not part of this build"}; })
+		.def_property("optimize_exposure", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_exposure: exposure optimisation is not part of this build"}; })
+		.def_property("optimize_distortion", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_distortion: distortion-map optimisation is not part of this build"}; })
+		.def_property("optimize_focal_length", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_focal_length: intrinsics optimisation is not part of this build"}; })
+		.def_property("optimize_extra_dims", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_extra_dims: per-image latents are not part of this build"}; })
+		.def_property("optimize_per_image_latents", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_per_image_latents: per-image latents are not part of this build"}; })
+		.def_property("include_sharpness_in_error", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"include_sharpness_in_error: the sharpness-weighted error map is not part of this build"}; })
 		.def_readonly("dataset", &NerfTraining::dataset);
 	py::class_<Nerf>(testbed, "Nerf")
 		.def_readwrite("sharpen", &Nerf::sharpen).def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
-		.def_readwrite("render_min_transmittance", &Nerf::render_min_transmittance).def_readonly("training", &Nerf::training);
+		.def_readwrite("render_min_transmittance", &Nerf::render_min_transmittance).def_readwrite("rendering_min_transmittance", &Nerf::render_min_transmittance) // python_api.cu:719-720
+		.def_property("rgb_activation", [](const Nerf& n) { return (ENerfActivation)(n.rgb_activation >= 0 ? n.rgb_activation : (n.training.dataset.is_hdr ? NGP_ACT_EXPONENTIAL : NGP_ACT_LOGISTIC)); },
+			[](Nerf& n, ENerfActivation v) { n.rgb_activation = (int)v; })                                                                                     // :716
+		.def_property("density_activation", [](const Nerf& n) { return (ENerfActivation)n.density_activation; }, [](Nerf& n, ENerfActivation v) { n.density_activation = (int)v; }) // :717
+		.def_readwrite("visualize_cameras", &Nerf::visualize_cameras)
+		.def("find_closest_training_view", [](Nerf& n, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+				if (a.size() < 12) throw std::runtime_error{"find_closest_training_view expects a 3x4 matrix"};
+				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];
+				return n.training.owner->find_closest_training_view(mm); })                                                                                      // :729-733
+		.def_readonly("training", &Nerf::training);
 
 	testbed
 		.def(py::init<>())
@@ -123,6 +192,24 @@ PYBIND11_MODULE(pyngp, m) {
 		})
 		.def("calculate_iou", &Testbed::calculate_iou, py::arg("n_samples") = 128u * 128u * 128u * 4u, py::arg("scale_existing_results_factor") = 0.0f, py::arg("blocking") = true, py::arg("force_use_octree") = false)
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view)
+		.def("first_training_view", &Testbed::first_training_view).def("last_training_view", &Testbed::last_training_view)
+		.def("previous_training_view", &Testbed::previous_training_view).def("next_training_view", &Testbed::next_training_view) // python_api.cu:655-658
+		.def("reset_camera", &Testbed::reset_camera).def("reset_accumulation", [](Testbed&, bool, bool) {}, py::arg("due_to_camera_movement") = false, py::arg("immediate_redraw") = true) // :535-541 (every render() starts a fresh accumulation here)
+		.def("clear_training_data", &Testbed::clear_training_data)                                                            // :453
+		.def("n_params", &Testbed::n_params).def("n_encoding_params", &Testbed::n_encoding_params)                            // :561-562
+		.def_readwrite("aabb", &Testbed::aabb).def_readwrite("raw_aabb", &Testbed::raw_aabb).def_readwrite("render_aabb", &Testbed::render_aabb) // :641-645
+		.def_readwrite("render_aabb_to_local", &Testbed::render_aabb_to_local)
+		.def_readwrite("up_dir", &Testbed::up_dir).def_readwrite("zoom", &Testbed::zoom).def_readwrite("render_near_distance", &Testbed::render_near_distance)
+		.def_readwrite("relative_focal_length", &Testbed::relative_focal_length).def_readwrite("screen_center", &Testbed::screen_center) // :649-651
+		.def_property("fov_xy", &Testbed::fov_xy, &Testbed::set_fov_xy).def_property("scale", &Testbed::scale, &Testbed::set_scale)   // :639, 647
+		.def_property("look_at", &Testbed::look_at, &Testbed::set_look_at).def_property("view_dir", &Testbed::view_dir, &Testbed::set_view_dir) // :664-665
+		.def_property("camera_matrix", [](Testbed& t) { const auto mm = t.camera_matrix_row_major(); py::array_t<float> out({3, 4}); std::memcpy(out.mutable_data(), mm.data(), sizeof(float) * 12); return out; },
+			[](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+				if (a.size() < 12) throw std::runtime_error{"camera_matrix expects a 3x4 matrix"};
+				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];
+				t.set_camera_matrix_row_major(mm); })                                                                             // :660
+		.def_property("shall_train_encoding", [](Testbed&) { return true; }, [](Testbed&, bool v) { if (!v) throw std::runtime_error{"shall_train_encoding = False: freezing the encoding is not part of this build"}; }) // :623
+		.def_property("shall_train_network", [](Testbed&) { return true; }, [](Testbed&, bool v) { if (!v) throw std::runtime_error{"shall_train_network = False: freezing the MLPs is not part of this build"}; })  // :624
 		.def("set_nerf_camera_matrix", [](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
 			if (a.size() < 12) throw std::runtime_error{"set_nerf_camera_matrix expects a 3x4 matrix"};
 			std::array<float, 12> mm; for (int i = 0; i < 12; ++i) mm[i] = a.data()[i];
@@ -150,6 +237,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("snap_to_pixel_centers", &Testbed::snap_to_pixel_centers)
 		.def_readwrite("render_with_lens_distortion", &Testbed::render_with_lens_distortion)
 		.def_readwrite("render_ground_truth", &Testbed::render_ground_truth)
+		.def_readwrite("render_groundtruth", &Testbed::render_ground_truth) // the reference's spelling (python_api.cu:625)
 		.def_readwrite("color_space", &Testbed::color_space)
 		.def_readwrite("tonemap_curve", &Testbed::tonemap_curve)
 		.def_readwrite("fov_axis", &Testbed::fov_axis)

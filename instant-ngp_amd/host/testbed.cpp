@@ -254,6 +254,7 @@ bool Testbed::natural_path_less(const std::string& a, const std::string& b) { re
 // ------------------------------------------------------------------------------------------------
 Testbed::Testbed() {
 	root_dir = s_default_root_dir.empty() ? fs::current_path().string() : s_default_root_dir;
+	nerf.training.owner = this;
 	if (ngp_device_available()) (void)ngp_init(); // helper streams before any communicator the host may create later (include/ngp_hip.h)
 }
 Testbed::~Testbed() {
@@ -312,11 +313,12 @@ ngp_aabb Testbed::scene_aabb() const { // testbed_nerf.cu:2424-2425
 
 ngp_nerf_options Testbed::current_options() const {
 	ngp_nerf_options o; memset(&o, 0, sizeof(o));
-	o.rgb_activation = nerf.training.dataset.is_hdr ? NGP_ACT_EXPONENTIAL : NGP_ACT_LOGISTIC; // testbed_nerf.cu:2354
-	o.density_activation = NGP_ACT_EXPONENTIAL;
+	o.rgb_activation = nerf.rgb_activation >= 0 ? nerf.rgb_activation : (nerf.training.dataset.is_hdr ? NGP_ACT_EXPONENTIAL : NGP_ACT_LOGISTIC); // testbed_nerf.cu:2354 unless set from Python
+	o.density_activation = nerf.density_activation;
 	const std::string lt = lower(m_network_config["loss"].str("otype", "L2")); // string_to_loss_type, testbed.cu:4209
 	o.loss_type = lt == "huber" ? NGP_LOSS_HUBER : lt == "l1" ? NGP_LOSS_L1 : lt == "mape" ? NGP_LOSS_MAPE : lt == "smape" ? NGP_LOSS_SMAPE :
 		lt == "logl1" ? NGP_LOSS_LOGL1 : lt == "relativel2" ? NGP_LOSS_RELATIVE_L2 : NGP_LOSS_L2;
+	if (nerf.training.loss_type >= 0) o.loss_type = nerf.training.loss_type; // nerf.training.loss_type written from Python (python_api.cu:785)
 	o.random_bg_color = nerf.training.random_bg_color;
 	o.snap_to_pixel_centers = nerf.training.snap_to_pixel_centers;
 	o.linear_colors = nerf.training.linear_colors;
@@ -359,6 +361,7 @@ void Testbed::ensure_trainer() {
 		NGP_CHECK(ngp_comm_init(m_nerf, m_rank, m_world_size, (const uint8_t*)m_comm_id.data()));
 		m_comm_up = true;
 	}
+	if (nerf.training.n_images_for_training != m_uploaded_n_images_for_training) m_dataset_dirty = true; // written from Python since the last upload
 	if (m_dataset_dirty) {
 		const NerfDataset& d = nerf.training.dataset;
 		std::vector<ngp_image_meta> meta(d.n_images);
@@ -379,8 +382,10 @@ void Testbed::ensure_trainer() {
 				pix[i] = &k_no_pixel; meta[i].resolution[0] = meta[i].resolution[1] = 1;
 			}
 		}
-		NGP_CHECK(ngp_nerf_set_dataset_host(m_nerf, (uint32_t)d.n_images, meta.data(), xf.data(), pix.data()));
-		m_dataset_dirty = false;
+		// rays are drawn from the first n_images_for_training images (testbed_nerf.cu:3075: n_training_images = nerf.training.n_images_for_training)
+		const uint32_t n_train = nerf.training.n_images_for_training > 0 ? (uint32_t)std::min<size_t>((size_t)nerf.training.n_images_for_training, d.n_images) : (uint32_t)d.n_images;
+		NGP_CHECK(ngp_nerf_set_dataset_host(m_nerf, n_train, meta.data(), xf.data(), pix.data()));
+		m_dataset_dirty = false; m_uploaded_n_images_for_training = nerf.training.n_images_for_training;
 	}
 }
 
@@ -486,6 +491,9 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (!mini_json::parse(read_text(jp).c_str(), j, err)) throw std::runtime_error{jp.string() + ": " + err};
 		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
 		if (j.has("sharpen")) d.sharpen_amount = (float)j.num("sharpen", 0);
+		if (j.has("render_aabb") && j["render_aabb"].size() == 2) // nerf_loader.cu:457-460: [[min], [max]] in the scene's coordinates, as is
+			for (int k = 0; k < 3; ++k) { d.render_aabb.min[k] = (float)j["render_aabb"].at(0).at(k).n; d.render_aabb.max[k] = (float)j["render_aabb"].at(1).at(k).n; }
+		if (j.has("up") && j["up"].size() == 3) d.up = {(float)j["up"].at(1).n, (float)j["up"].at(2).n, (float)j["up"].at(0).n}; // nerf_loader.cu:528-533: axes permuted like the transforms
 		if (j.has("fix_premult")) fix_premult = j.boolean("fix_premult", false);
 		if (j.has("enable_depth_loading")) enable_depth_loading = j.boolean("enable_depth_loading", true);
 		const float integer_depth_scale = j.has("integer_depth_scale") ? (float)j.num("integer_depth_scale", -1.0) : -1.f; // nerf_loader.cu:490-492: units of the 16-bit depth images
@@ -678,14 +686,25 @@ void Testbed::load_training_data(const std::string& path_in) {
 	const bool had = nerf.training.dataset.n_images > 0;
 	nerf.training.dataset = std::move(d);
 	mode = ETestbedMode::Nerf;
-	// load_nerf_post, testbed_nerf.cu:2353-2443
-	nerf.max_cascade = 0;
-	while ((1 << nerf.max_cascade) < nerf.training.dataset.aabb_scale) ++nerf.max_cascade;
-	nerf.cone_angle_constant = nerf.training.dataset.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+	load_nerf_post();
 	if (had && prev_scale != nerf.training.dataset.aabb_scale) destroy_trainer(); // network size depends on aabb_scale (testbed_nerf.cu:2466-2470)
 	m_dataset_dirty = true;
 	m_render_lens_mode = nerf.training.dataset.metadata[0].lens_mode;
 	m_render_lens_params = nerf.training.dataset.metadata[0].lens_params;
+}
+
+// load_nerf_post, testbed_nerf.cu:2353-2443: everything the Testbed derives from a freshly loaded (or snapshot-restored) dataset
+void Testbed::load_nerf_post() {
+	const NerfDataset& d = nerf.training.dataset;
+	nerf.training.n_images_for_training = (int)d.n_images;                  // :2371
+	const ngp_aabb box = scene_aabb();                                      // :2424-2425
+	aabb = BoundingBox{{box.min[0], box.min[1], box.min[2]}, {box.max[0], box.max[1], box.max[2]}};
+	raw_aabb = aabb; render_aabb = aabb; render_aabb_to_local = d.render_aabb_to_local; // :2426-2428
+	if (!d.render_aabb.is_empty()) render_aabb = d.render_aabb.intersection(aabb);       // :2429-2431
+	nerf.max_cascade = 0;
+	while ((1 << nerf.max_cascade) < d.aabb_scale) ++nerf.max_cascade;
+	nerf.cone_angle_constant = d.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+	up_dir = d.up;                                                          // :2443
 }
 
 void Testbed::load_file(const std::string& path) {
@@ -811,16 +830,22 @@ bool Testbed::frame() { // headless: one call = one optimizer step when training
 static float srgb_to_lin(float s) { return s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f); }
 static float lin_to_srgb(float l) { return l < 0.0031308f ? 12.92f * l : 1.055f * std::pow(l, 0.41666f) - 0.055f; }
 
+static std::array<float, 3> v3sub(const std::array<float, 3>& a, const std::array<float, 3>& b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+static std::array<float, 3> v3cross(const std::array<float, 3>& a, const std::array<float, 3>& b) { return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; }
+static float v3dot(const std::array<float, 3>& a, const std::array<float, 3>& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static std::array<float, 3> v3normalize(const std::array<float, 3>& a) { const float l = std::sqrt(v3dot(a, a)); return {a[0] / l, a[1] / l, a[2] / l}; }
 void Testbed::set_camera_to_training_view(int i) {
 	const NerfDataset& d = nerf.training.dataset;
 	if (i < 0 || (size_t)i >= d.n_images) throw std::runtime_error{"set_camera_to_training_view: index out of range"};
+	const auto old_look_at = look_at();
 	m_camera = d.xforms[i];
+	m_scale = std::max(v3dot(v3sub(old_look_at, view_pos()), view_dir()), 0.1f); // testbed.cu:494
 	const auto& m = d.metadata[i];
-	for (int k = 0; k < 2; ++k) m_relative_focal_length[k] = m.focal_length[k] / (float)m.resolution[fov_axis];
+	for (int k = 0; k < 2; ++k) relative_focal_length[k] = m.focal_length[k] / (float)m.resolution[fov_axis];
 	render_with_lens_distortion = true;
 	m_render_lens_mode = m.lens_mode; m_render_lens_params = m.lens_params;
-	m_screen_center = {1.0f - m.principal_point[0], 1.0f - m.principal_point[1]};
-	m_training_view = i;
+	screen_center = {1.0f - m.principal_point[0], 1.0f - m.principal_point[1]};
+	m_training_view = i; nerf.training.view = i;
 }
 void Testbed::set_nerf_camera_matrix(const std::array<float, 12>& rm) { // 3x4 row-major NeRF-convention matrix (python_api.cu / testbed.cu:463-466)
 	const NerfDataset& d = nerf.training.dataset;
@@ -831,10 +856,140 @@ void Testbed::set_nerf_camera_matrix(const std::array<float, 12>& rm) { // 3x4 r
 	for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; }
 	for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) m_camera[c * 3 + r] = c3[r][c];
 }
-float Testbed::fov() const { return 2.0f * std::atan(0.5f / m_relative_focal_length[fov_axis]) * 180.0f / 3.14159265358979f; } // testbed.cu focal_length_to_fov
+float Testbed::fov() const { return 2.0f * std::atan(0.5f / relative_focal_length[fov_axis]) * 180.0f / 3.14159265358979f; } // testbed.cu focal_length_to_fov
 void Testbed::set_fov(float deg) {
 	const float rf = 0.5f / std::tan(0.5f * deg * 3.14159265358979f / 180.0f);
-	m_relative_focal_length = {rf, rf};
+	relative_focal_length = {rf, rf};
+}
+
+// ---- camera and training-view helpers with the reference's semantics (testbed.cu:440-528, 4085-4091; testbed_nerf.cu:2151-2292, 3710-3723) ----
+std::array<float, 3> Testbed::look_at() const { const auto p = view_pos(), d = view_dir(); return {p[0] + d[0] * m_scale, p[1] + d[1] * m_scale, p[2] + d[2] * m_scale}; }
+void Testbed::set_look_at(const std::array<float, 3>& pos) { const auto l = look_at(); for (int k = 0; k < 3; ++k) m_camera[9 + k] += pos[k] - l[k]; }
+void Testbed::set_scale(float scale) {
+	const auto prev = look_at(), p = view_pos();
+	for (int k = 0; k < 3; ++k) m_camera[9 + k] = (p[k] - prev[k]) * (scale / m_scale) + prev[k];
+	m_scale = scale;
+}
+void Testbed::set_view_dir(const std::array<float, 3>& dir) {
+	const auto old = look_at();
+	const auto c0 = v3normalize(v3cross(dir, up_dir)), c1 = v3normalize(v3cross(dir, c0)), c2 = v3normalize(dir);
+	for (int k = 0; k < 3; ++k) { m_camera[k] = c0[k]; m_camera[3 + k] = c1[k]; m_camera[6 + k] = c2[k]; }
+	set_look_at(old);
+}
+std::array<float, 2> Testbed::fov_xy() const { // focal_length_to_fov(ivec2(1), m_relative_focal_length), common_device.cuh:657-659
+	return {2.0f * 180.0f / 3.14159265358979323846f * std::atan(1.0f / (relative_focal_length[0] * 2.0f)), 2.0f * 180.0f / 3.14159265358979323846f * std::atan(1.0f / (relative_focal_length[1] * 2.0f))};
+}
+void Testbed::set_fov_xy(const std::array<float, 2>& deg) { // fov_to_focal_length(ivec2(1), val), common_device.cuh:649-651
+	for (int k = 0; k < 2; ++k) relative_focal_length[k] = 0.5f * 1.0f / std::tan(0.5f * deg[k] * (3.14159265358979323846f / 180.0f));
+}
+std::array<float, 12> Testbed::camera_matrix_row_major() const { std::array<float, 12> r; for (int row = 0; row < 3; ++row) for (int c = 0; c < 4; ++c) r[row * 4 + c] = m_camera[c * 3 + row]; return r; }
+void Testbed::set_camera_matrix_row_major(const std::array<float, 12>& m) { for (int row = 0; row < 3; ++row) for (int c = 0; c < 4; ++c) m_camera[c * 3 + row] = m[row * 4 + c]; }
+void Testbed::first_training_view() { nerf.training.view = 0; set_camera_to_training_view(nerf.training.view); }
+void Testbed::last_training_view() { nerf.training.view = (int)nerf.training.dataset.n_images - 1; set_camera_to_training_view(nerf.training.view); }
+void Testbed::previous_training_view() { if (nerf.training.view != 0) nerf.training.view -= 1; set_camera_to_training_view(nerf.training.view); }
+void Testbed::next_training_view() { if (nerf.training.view != (int)nerf.training.dataset.n_images - 1) nerf.training.view += 1; set_camera_to_training_view(nerf.training.view); }
+void Testbed::reset_camera() {
+	fov_axis = 1; zoom = 1.0f; screen_center = {0.5f, 0.5f};
+	if (mode == ETestbedMode::Image) { relative_focal_length = {1.0f, 1.0f}; m_scale = 1.0f; }
+	else { set_fov(50.625f); m_scale = 1.5f; }
+	m_camera = {1, 0, 0, 0, -1, 0, 0, 0, -1, 0.5f, 0.5f, 0.5f}; // m_default_camera, testbed.h:654
+	const auto d = view_dir();
+	for (int k = 0; k < 3; ++k) m_camera[9 + k] -= m_scale * d[k];
+}
+void Testbed::clear_training_data() { // testbed.cu:190-193: the metadata goes, training stops being possible until new data is loaded
+	nerf.training.dataset = NerfDataset{};
+	nerf.training.n_images_for_training = 0;
+	destroy_trainer();
+}
+size_t Testbed::n_params() {
+	if (!m_model) return 0;
+	uint64_t n = 0, n_mlp = 0; NGP_CHECK(ngp_model_n_params(m_model, &n, &n_mlp)); return (size_t)n;
+}
+size_t Testbed::n_encoding_params() { // n_params() - first_encoder_param(): the hash-grid entries
+	if (!m_model) return 0;
+	uint64_t n = 0, n_mlp = 0; NGP_CHECK(ngp_model_n_params(m_model, &n, &n_mlp)); return (size_t)(n - n_mlp);
+}
+int Testbed::find_closest_training_view(const std::array<float, 12>& pose) const { // pose: 3 x 4 row-major, ngp convention like camera_matrix
+	const NerfDataset& d = nerf.training.dataset;
+	int best = nerf.training.view; float best_score = std::numeric_limits<float>::infinity();
+	const int n = std::min<int>(nerf.training.n_images_for_training, (int)d.n_images);
+	for (int i = 0; i < n; ++i) {
+		float dp = 0, dd = 0;
+		for (int k = 0; k < 3; ++k) { const float a = d.xforms[i][9 + k] - pose[k * 4 + 3], b = d.xforms[i][6 + k] - pose[k * 4 + 2]; dp += a * a; dd += b * b; }
+		const float score = std::sqrt(dp) + 0.25f * std::sqrt(dd);
+		if (score < best_score) { best_score = score; best = i; }
+	}
+	return best;
+}
+std::array<float, 12> NerfDataset::nerf_matrix_to_ngp(const std::array<float, 12>& rm) const {
+	float m[3][4];
+	for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m[r][c] = rm[r * 4 + c];
+	for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = m[r][3] * scale + offset[r]; }
+	float c3[3][4];
+	if (from_mitsuba) { for (int r = 0; r < 3; ++r) { m[r][0] *= -1.f; m[r][2] *= -1.f; } for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) c3[r][c] = m[r][c]; }
+	else for (int c = 0; c < 4; ++c) { c3[0][c] = m[1][c]; c3[1][c] = m[2][c]; c3[2][c] = m[0][c]; }
+	std::array<float, 12> out;
+	for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) out[c * 3 + r] = c3[r][c];
+	return out;
+}
+std::array<float, 12> NerfDataset::ngp_matrix_to_nerf(const std::array<float, 12>& cm) const {
+	float m[3][4];
+	for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) m[r][c] = cm[c * 3 + r];
+	if (from_mitsuba) { for (int r = 0; r < 3; ++r) { m[r][0] *= -1.f; m[r][2] *= -1.f; } }
+	else { float t[3][4]; for (int c = 0; c < 4; ++c) { t[0][c] = m[2][c]; t[2][c] = m[1][c]; t[1][c] = m[0][c]; } std::memcpy(m, t, sizeof(m)); } // cycle the axes xyz -> yzx
+	for (int r = 0; r < 3; ++r) { m[r][1] *= -1.f; m[r][2] *= -1.f; m[r][3] = (m[r][3] - offset[r]) / scale; }
+	std::array<float, 12> out;
+	for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out[r * 4 + c] = m[r][c];
+	return out;
+}
+void Testbed::set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3, float k4, bool is_fisheye) {
+	NerfDataset& d = nerf.training.dataset;
+	if (frame_idx < 0 || (size_t)frame_idx >= d.n_images) return;
+	if (fx <= 0.f) fx = fy;
+	if (fy <= 0.f) fy = fx;
+	ImageMetadata& m = d.metadata[frame_idx];
+	cx = cx < 0.f ? -cx : cx / (float)m.resolution[0];
+	cy = cy < 0.f ? -cy : cy / (float)m.resolution[1];
+	m.lens_mode = NGP_LENS_PERSPECTIVE; m.lens_params = {};
+	if (k1 || k2 || k3 || k4 || p1 || p2) {
+		if (is_fisheye) { m.lens_mode = NGP_LENS_OPENCV_FISHEYE; m.lens_params = {k1, k2, k3, k4, 0, 0, 0}; }
+		else { m.lens_mode = NGP_LENS_OPENCV; m.lens_params = {k1, k2, p1, p2, 0, 0, 0}; }
+	}
+	m.principal_point = {cx, cy}; m.focal_length = {fx, fy};
+	m_dataset_dirty = true;
+}
+void Testbed::set_camera_extrinsics(int frame_idx, const std::array<float, 12>& c2w, bool convert_to_ngp) {
+	NerfDataset& d = nerf.training.dataset;
+	if (frame_idx < 0 || (size_t)frame_idx >= d.n_images) return;
+	std::array<float, 12> m;
+	if (convert_to_ngp) m = d.nerf_matrix_to_ngp(c2w);
+	else for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) m[c * 3 + r] = c2w[r * 4 + c];
+	d.xforms[frame_idx] = m;
+	if ((size_t)frame_idx < d.xforms_end.size()) d.xforms_end[frame_idx] = m;
+	d.metadata[frame_idx].rolling_shutter = {0.f, 0.f, 0.f, 0.f};
+	m_dataset_dirty = true;
+}
+std::array<float, 12> Testbed::get_camera_extrinsics(int frame_idx) const {
+	const NerfDataset& d = nerf.training.dataset;
+	if (frame_idx < 0 || (size_t)frame_idx >= d.n_images) return {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; // mat4x3::identity()
+	return d.ngp_matrix_to_nerf(d.xforms[frame_idx]);
+}
+void Testbed::training_options_changed() { m_dataset_dirty = true; }
+std::array<float, 2> BoundingBox::ray_intersect(const std::array<float, 3>& pos, const std::array<float, 3>& dir) const {
+	const float FMAX = std::numeric_limits<float>::max();
+	float tmin = (min[0] - pos[0]) / dir[0], tmax = (max[0] - pos[0]) / dir[0];
+	if (tmin > tmax) std::swap(tmin, tmax);
+	float tymin = (min[1] - pos[1]) / dir[1], tymax = (max[1] - pos[1]) / dir[1];
+	if (tymin > tymax) std::swap(tymin, tymax);
+	if (tmin > tymax || tymin > tmax) return {FMAX, FMAX};
+	if (tymin > tmin) tmin = tymin;
+	if (tymax < tmax) tmax = tymax;
+	float tzmin = (min[2] - pos[2]) / dir[2], tzmax = (max[2] - pos[2]) / dir[2];
+	if (tzmin > tzmax) std::swap(tzmin, tzmax);
+	if (tmin > tzmax || tzmin > tmax) return {FMAX, FMAX};
+	if (tzmin > tmin) tmin = tzmin;
+	if (tzmax < tmax) tmax = tzmax;
+	return {tmin, tmax};
 }
 
 std::vector<float> Testbed::render(int width, int height, int spp, bool linear) {
@@ -869,16 +1024,20 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 		ngp_render_params rp; memset(&rp, 0, sizeof(rp));
 		rp.resolution[0] = width; rp.resolution[1] = height;
 		const int res_axis = fov_axis == 0 ? width : height;
-		rp.focal_length[0] = m_relative_focal_length[0] * (float)res_axis; rp.focal_length[1] = m_relative_focal_length[1] * (float)res_axis; // calc_focal_length, testbed.cu:4649
-		rp.screen_center[0] = (0.5f - m_screen_center[0]) + 0.5f; rp.screen_center[1] = (0.5f - m_screen_center[1]) + 0.5f;                      // render_screen_center, testbed.cu:4653
+		rp.focal_length[0] = relative_focal_length[0] * (float)res_axis; rp.focal_length[1] = relative_focal_length[1] * (float)res_axis; // calc_focal_length, testbed.cu:4649
+		rp.screen_center[0] = (0.5f - screen_center[0]) + 0.5f; rp.screen_center[1] = (0.5f - screen_center[1]) + 0.5f;                      // render_screen_center, testbed.cu:4653
 		for (int k = 0; k < 12; ++k) rp.camera[k] = m_camera[k];
 		rp.lens_mode = render_with_lens_distortion ? m_render_lens_mode : NGP_LENS_PERSPECTIVE;
 		for (int k = 0; k < 7; ++k) rp.lens_params[k] = m_render_lens_params[k];
 		rp.snap_to_pixel_centers = snap_to_pixel_centers;
 		rp.min_transmittance = nerf.render_min_transmittance;
-		rp.near_distance = 0.f;
+		rp.near_distance = render_near_distance;
 		rp.use_inference_params = 1; // the renderer uses the optimizer's EMA weights (testbed_nerf.cu:1772)
-		rp.render_aabb = scene_aabb();
+		{ // m_render_aabb (testbed_nerf.cu:2427-2431; writable from Python); its orientation must be the identity in this build
+			for (int k = 0; k < 9; ++k) if (render_aabb_to_local[k] != (k % 4 == 0 ? 1.f : 0.f)) throw std::runtime_error{"render: a rotated crop box (render_aabb_to_local != identity) is not supported by this build"};
+			const BoundingBox box = render_aabb.is_empty() ? aabb : render_aabb;
+			for (int k = 0; k < 3; ++k) { rp.render_aabb.min[k] = box.min[k]; rp.render_aabb.max[k] = box.max[k]; }
+		}
 		for (int s = 0; s < std::max(spp, 1); ++s) { // accumulate + tonemap stay on the device (render_buffer.cu:228-260, 511-560): one read-back per frame
 			rp.spp_index = (uint32_t)s;
 			NGP_CHECK(ngp_nerf_render(m_nerf, nullptr, &rp, m_frame_dev, nullptr));
@@ -1012,7 +1171,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	snap.set("exposure", jnum(exposure)); snap.set("background_color", jvec(background_color.data(), 4));
 	Value cam = jobj();
 	cam.set("matrix", jmat_cols(m_camera.data(), 4, 3)); cam.set("fov_axis", jnum(fov_axis));
-	cam.set("relative_focal_length", jvec(m_relative_focal_length.data(), 2)); cam.set("screen_center", jvec(m_screen_center.data(), 2));
+	cam.set("relative_focal_length", jvec(relative_focal_length.data(), 2)); cam.set("screen_center", jvec(screen_center.data(), 2));
 	cam.set("zoom", jnum(1.0)); cam.set("scale", jnum(1.5)); cam.set("aperture_size", jnum(0.0)); cam.set("autofocus", jbool(false));
 	{ const float t[3] = {0.5f, 0.5f, 0.5f}; cam.set("autofocus_target", jvec(t, 3)); } cam.set("autofocus_depth", jnum(0.5));
 	snap.set("camera", cam);
@@ -1075,9 +1234,7 @@ void Testbed::load_snapshot(const std::string& path) {
 		d.n_images = n;
 		nerf.training.dataset = std::move(d);
 		mode = ETestbedMode::Nerf;
-		nerf.max_cascade = 0;
-		while ((1 << nerf.max_cascade) < nerf.training.dataset.aabb_scale) ++nerf.max_cascade;
-		nerf.cone_angle_constant = nerf.training.dataset.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+		load_nerf_post();
 		m_render_lens_mode = nerf.training.dataset.metadata[0].lens_mode; m_render_lens_params = nerf.training.dataset.metadata[0].lens_params;
 		m_dataset_dirty = true; shall_train = false;
 	}
@@ -1115,8 +1272,8 @@ void Testbed::load_snapshot(const std::string& path) {
 	if (cam.is_object()) {
 		if (cam["matrix"].is_array() && cam["matrix"].size() == 4) for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) m_camera[c * 3 + r] = (float)cam["matrix"].at(c).at(r).n;
 		fov_axis = (int)cam.num("fov_axis", fov_axis);
-		if (cam["relative_focal_length"].size() == 2) for (int k = 0; k < 2; ++k) m_relative_focal_length[k] = (float)cam["relative_focal_length"].at(k).n;
-		if (cam["screen_center"].size() == 2) for (int k = 0; k < 2; ++k) m_screen_center[k] = (float)cam["screen_center"].at(k).n;
+		if (cam["relative_focal_length"].size() == 2) for (int k = 0; k < 2; ++k) relative_focal_length[k] = (float)cam["relative_focal_length"].at(k).n;
+		if (cam["screen_center"].size() == 2) for (int k = 0; k < 2; ++k) screen_center[k] = (float)cam["screen_center"].at(k).n;
 	}
 	m_network_config_path = path;
 }

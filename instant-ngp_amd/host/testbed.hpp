@@ -2,8 +2,11 @@
 // (reference include/neural-graphics-primitives/testbed.h:71-1292) that scripts/run.py and pyngp users touch
 // (python_api.cu:439-853).  All device work goes through the C-ABI of libngp_hip.so (include/ngp_hip.h).
 #pragma once
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdint>
+#include <limits>
 #include <functional>
 #include <string>
 #include <vector>
@@ -20,6 +23,34 @@ enum class ETrainMode : int { Nerf = 0, Rfl = 1, RflRelax = 2 };                
 enum class EColorSpace : int { Linear = 0, SRGB = 1, VisPosNeg = 2 };
 enum class ETonemapCurve : int { Identity = 0, ACES = 1, Hable = 2, Reinhard = 3 };
 enum class ELossType : int { L2 = 0, L1 = 1, Mape = 2, Smape = 3, Huber = 4, LogL1 = 5, RelativeL2 = 6 }; // common.h:99-107 = NGP_LOSS_*
+
+enum class ENerfActivation : int { None = 0, ReLU = 1, Logistic = 2, Exponential = 3 };                  // common.h = NGP_ACT_*
+
+struct BoundingBox {                        // bounding_box.cuh:43-252 as seen from Python (python_api.cu:409-427)
+	std::array<float, 3> min{std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity()};
+	std::array<float, 3> max{-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity()};
+	BoundingBox() {}
+	BoundingBox(const std::array<float, 3>& a, const std::array<float, 3>& b) : min(a), max(b) {}
+	bool is_empty() const { return max[0] < min[0] || max[1] < min[1] || max[2] < min[2]; }
+	std::array<float, 3> diag() const { return {max[0] - min[0], max[1] - min[1], max[2] - min[2]}; }
+	std::array<float, 3> center() const { return {0.5f * (max[0] + min[0]), 0.5f * (max[1] + min[1]), 0.5f * (max[2] + min[2])}; }
+	std::array<float, 3> relative_pos(const std::array<float, 3>& p) const { const auto d = diag(); return {(p[0] - min[0]) / d[0], (p[1] - min[1]) / d[1], (p[2] - min[2]) / d[2]}; }
+	bool contains(const std::array<float, 3>& p) const { return p[0] >= min[0] && p[0] <= max[0] && p[1] >= min[1] && p[1] <= max[1] && p[2] >= min[2] && p[2] <= max[2]; }
+	void enlarge(const std::array<float, 3>& p) { for (int k = 0; k < 3; ++k) { min[k] = std::min(min[k], p[k]); max[k] = std::max(max[k], p[k]); } }
+	void enlarge(const BoundingBox& o) { for (int k = 0; k < 3; ++k) { min[k] = std::min(min[k], o.min[k]); max[k] = std::max(max[k], o.max[k]); } }
+	void inflate(float amount) { for (int k = 0; k < 3; ++k) { min[k] -= amount; max[k] += amount; } }
+	BoundingBox intersection(const BoundingBox& o) const { BoundingBox r = *this; for (int k = 0; k < 3; ++k) { r.min[k] = std::max(r.min[k], o.min[k]); r.max[k] = std::min(r.max[k], o.max[k]); } return r; }
+	bool intersects(const BoundingBox& o) const { return !intersection(o).is_empty(); }
+	float distance_sq(const std::array<float, 3>& p) const { float s = 0; for (int k = 0; k < 3; ++k) { const float d = std::max(std::max(min[k] - p[k], p[k] - max[k]), 0.0f); s += d * d; } return s; }
+	float distance(const std::array<float, 3>& p) const { return std::sqrt(distance_sq(p)); }
+	float signed_distance(const std::array<float, 3>& p) const { // bounding_box.cuh:232-235
+		float q[3], outside = 0.f, inside = -std::numeric_limits<float>::infinity();
+		for (int k = 0; k < 3; ++k) { q[k] = std::fabs(p[k] - 0.5f * (min[k] + max[k])) - 0.5f * (max[k] - min[k]); const float o = std::max(q[k], 0.0f); outside += o * o; inside = std::max(inside, q[k]); }
+		return std::sqrt(outside) + std::min(inside, 0.0f);
+	}
+	std::array<float, 2> ray_intersect(const std::array<float, 3>& pos, const std::array<float, 3>& dir) const; // bounding_box.cuh:163-210 (testbed.cpp)
+	std::vector<std::array<float, 3>> get_vertices() const { std::vector<std::array<float, 3>> v(8); for (int i = 0; i < 8; ++i) v[i] = {(i & 1) ? max[0] : min[0], (i & 2) ? max[1] : min[1], (i & 4) ? max[2] : min[2]}; return v; } // :237-246
+};
 
 struct ImageMetadata {                      // TrainingImageMetadata as seen from Python (python_api.cu:766-779)
 	std::array<int, 2> resolution{0, 0};
@@ -45,8 +76,15 @@ struct NerfDataset {                        // nerf_loader.h NerfDataset (subset
 	std::array<float, 3> offset{0.5f, 0.5f, 0.5f};   // nerf_loader.cu:403-404
 	bool is_hdr = false;
 	bool from_mitsuba = false;                       // json "from_mitsuba" / "normal_mts_args": Mitsuba axis convention (nerf_loader.h:101-120)
+	BoundingBox render_aabb;                         // json "render_aabb" (nerf_loader.cu:457-460); empty = the whole scene box
+	std::array<float, 9> render_aabb_to_local{1, 0, 0, 0, 1, 0, 0, 0, 1}; // nerf_loader.h: identity unless a snapshot carries a crop box orientation (column-major mat3)
+	std::array<float, 3> up{0.f, 1.f, 0.f};          // json "up", axes permuted like the transforms (nerf_loader.cu:528-533)
+	std::array<int, 2> envmap_resolution{0, 0};      // no environment maps in this build
+	std::array<float, 12> nerf_matrix_to_ngp(const std::array<float, 12>& row_major_3x4) const; // nerf_loader.h:101-120
+	std::array<float, 12> ngp_matrix_to_nerf(const std::array<float, 12>& col_major_4x3) const; // nerf_loader.h:122-139 (row-major 3x4 out)
 };
 
+class Testbed;
 struct NerfTraining {
 	float near_distance = 0.1f;                      // testbed.h:817
 	ETrainMode train_mode = ETrainMode::RflRelax;    // testbed.h:822 (forced to Nerf without JIT, testbed_nerf.cu:3091-3094)
@@ -59,6 +97,10 @@ struct NerfTraining {
 	bool sample_focal_plane_proportional_to_error = false; // testbed.h:810
 	bool sample_image_proportional_to_error = false;       // testbed.h:811
 	bool accumulate_error_map = false;                     // (the reference always accumulates, testbed_nerf.cu:2793; here: while one of the two switches is on, or when this is set)
+	int n_images_for_training = 0;                         // testbed.h:771: rays are drawn from the first n images (set to n_images by load_nerf_post, testbed_nerf.cu:2371)
+	int loss_type = -1;                                    // ELossType; -1 = as the network config's "loss.otype" says (testbed.cu:4209 writes it into this member)
+	int view = 0;                                          // testbed.h:770: the training view the camera was last set to
+	Testbed* owner = nullptr;                        // the reference's Training methods (set_camera_extrinsics ...) live on this object: route them to the Testbed
 	NerfDataset dataset;
 };
 
@@ -66,6 +108,8 @@ struct Nerf {
 	float sharpen = 0.f;
 	float cone_angle_constant = 1.f / 256.f;
 	float render_min_transmittance = 0.01f;          // testbed.h:890
+	int rgb_activation = -1, density_activation = NGP_ACT_EXPONENTIAL; // ENerfActivation; rgb -1 = Exponential for HDR data, Logistic otherwise (testbed_nerf.cu:2354)
+	bool visualize_cameras = false;                  // GUI overlay switch: kept so that scripts that clear it run
 	int max_cascade = 0;
 	NerfTraining training;
 };
@@ -89,6 +133,27 @@ public:
 	void train(uint32_t batch_size);                                // testbed.cu:4561
 	bool want_repl() const { return false; }
 	void set_camera_to_training_view(int i);                        // testbed.cu:486
+	void first_training_view(); void last_training_view(); void previous_training_view(); void next_training_view(); // testbed.cu:460-484
+	void reset_camera();                                            // testbed.cu:507-528
+	void clear_training_data();                                     // testbed.cu:190-193
+	size_t n_params(); size_t n_encoding_params();                  // testbed.cu:4089-4091
+	// camera (testbed.cu:440-458): column-major mat4x3, columns = side, up, direction, position
+	std::array<float, 3> view_pos() const { return {m_camera[9], m_camera[10], m_camera[11]}; }
+	std::array<float, 3> view_dir() const { return {m_camera[6], m_camera[7], m_camera[8]}; }
+	std::array<float, 3> look_at() const;
+	void set_look_at(const std::array<float, 3>& pos);
+	void set_view_dir(const std::array<float, 3>& dir);
+	float scale() const { return m_scale; }
+	void set_scale(float scale);
+	std::array<float, 2> fov_xy() const; void set_fov_xy(const std::array<float, 2>& degrees); // testbed.cu:4085-4087
+	std::array<float, 12> camera_matrix_row_major() const;          // m_camera as the 3 x 4 numpy array pyngp exposes
+	void set_camera_matrix_row_major(const std::array<float, 12>& m);
+	int find_closest_training_view(const std::array<float, 12>& pose_row_major_3x4) const; // testbed_nerf.cu:3710-3723
+	// training cameras (testbed_nerf.cu:2151-2292)
+	void set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3, float k4, bool is_fisheye);
+	void set_camera_extrinsics(int frame_idx, const std::array<float, 12>& camera_to_world_row_major, bool convert_to_ngp);
+	std::array<float, 12> get_camera_extrinsics(int frame_idx) const;
+	void training_options_changed();                                // a member of nerf / nerf.training was written from Python: push it to the trainer before the next step
 	void set_nerf_camera_matrix(const std::array<float, 12>& m_row_major_3x4);
 	// render_to_cpu (python_api.cu:145-236): premultiplied RGBA float [h][w][4]
 	std::vector<float> render(int width, int height, int spp, bool linear);
@@ -117,6 +182,13 @@ public:
 	uint32_t training_batch_size = 1u << 18;                         // testbed.h:1089
 	uint64_t seed = 1337;                                            // testbed.h:680
 	Nerf nerf;
+	BoundingBox aabb, raw_aabb, render_aabb;                         // testbed.h:1025-1027; set by load_nerf_post (testbed_nerf.cu:2424-2431)
+	std::array<float, 9> render_aabb_to_local{1, 0, 0, 0, 1, 0, 0, 0, 1};
+	std::array<float, 3> up_dir{0.f, 1.f, 0.f};                      // testbed.h:672
+	float zoom = 1.f;                                                // testbed.h:647 (2-D zoom of the GUI view; kept for scripts)
+	float render_near_distance = 0.f;                                // testbed.h (m_render_near_distance)
+	std::array<float, 2> relative_focal_length{1.f, 1.f};            // testbed.h: focal length / resolution[fov_axis]
+	std::array<float, 2> screen_center{0.5f, 0.5f};
 	float fov() const;
 	void set_fov(float degrees);
 
@@ -129,6 +201,7 @@ public:
 
 private:
 	void ensure_trainer();
+	void load_nerf_post();
 	void destroy_trainer();
 	void push_options();
 	ngp_nerf_options current_options() const;
@@ -147,10 +220,10 @@ private:
 	std::vector<float> m_mesh; ngp_aabb m_mesh_aabb{};                   // 9 floats per triangle, normalised into the unit cube (load_mesh)
 	void ensure_encmlp_trainer();
 	bool m_dataset_dirty = true;
+	int m_uploaded_n_images_for_training = -1;
 	// camera (testbed.h:453-456): column-major mat4x3
 	std::array<float, 12> m_camera{1, 0, 0, 0, 1, 0, 0, 0, 1, 0.5f, 0.5f, 0.5f};
-	std::array<float, 2> m_relative_focal_length{1.f, 1.f};
-	std::array<float, 2> m_screen_center{0.5f, 0.5f};
+	float m_scale = 1.f;                                                 // testbed.h:643
 	int m_render_lens_mode = NGP_LENS_PERSPECTIVE;
 	std::array<float, 7> m_render_lens_params{};
 	int m_training_view = 0;

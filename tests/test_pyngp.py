@@ -237,3 +237,85 @@ def test_pyngp_image_and_sdf_modes():
     iou = t2.calculate_iou(1 << 20)
     print(f"sdf: IoU {iou:.4f} after {t2.training_step} steps (configs/sdf/base.json: Adam lr 1e-4 + EMA), MAPE {t2.loss:.4f}")
     assert iou > 0.9
+
+
+def test_camera_and_training_view_api_like_the_reference(scene_dir):
+    """Members of python_api.cu:439-853 that scripts use around training and rendering, with the reference's semantics (testbed.cu:440-528, 4085-4091; testbed_nerf.cu:2151-2292,
+    2424-2443, 3710-3723; nerf_loader.h:101-139; bounding_box.cuh): scene / render boxes, the camera (look_at / view_dir / scale / fov_xy / camera_matrix), stepping through
+    training views, training-camera getters and setters with the NeRF <-> ngp convention, n_images_for_training, loss / activation overrides, mode_from_*."""
+    ngp = _ngp()
+    t = ngp.Testbed()
+    tf = json.load(open(os.path.join(scene_dir, "transforms_train.json")))
+    tf["render_aabb"] = [[0.2, 0.1, 0.3], [0.9, 1.4, 0.8]]; tf["up"] = [0.0, 0.0, 1.0]
+    custom = os.path.join(scene_dir, "transforms_custom.json"); json.dump(tf, open(custom, "w"))
+    t.load_training_data(custom)
+    ds = t.nerf.training.dataset
+    # load_nerf_post: aabb = unit cube for aabb_scale 1; render_aabb = json box intersected with it; up permuted like the transforms (xyz <- yzx)
+    assert list(t.aabb.min) == [0, 0, 0] and list(t.aabb.max) == [1, 1, 1] and list(t.raw_aabb.max) == [1, 1, 1]
+    assert np.allclose(t.render_aabb.min, [0.2, 0.1, 0.3]) and np.allclose(t.render_aabb.max, [0.9, 1.0, 0.8]) and np.allclose(ds.render_aabb.max, [0.9, 1.4, 0.8])
+    assert list(ds.up) == [0.0, 1.0, 0.0] and list(t.up_dir) == [0.0, 1.0, 0.0] and list(ds.render_aabb_to_local) == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    b = ngp.BoundingBox([0, 0, 0], [1, 2, 3])
+    assert b.contains([0.5, 1.9, 2.9]) and not b.contains([0.5, 2.1, 1]) and list(b.diag()) == [1, 2, 3] and list(b.center()) == [0.5, 1.0, 1.5]
+    assert abs(b.distance([2, 2, 3]) - 1.0) < 1e-6 and abs(b.signed_distance([0.5, 1.0, 1.5]) + 0.5) < 1e-6 and b.intersects(ngp.BoundingBox([0.5, 0.5, 0.5], [9, 9, 9]))
+    assert np.allclose(b.ray_intersect([-1, 1, 1], [1, 0.0001, 0.0001]), [1.0, 2.0], atol=1e-3) and len(b.get_vertices()) == 8
+    b.inflate(0.5); assert list(b.min) == [-0.5, -0.5, -0.5]
+    assert ngp.BoundingBox().intersection(b).min[0] == float("inf")
+    # training views and the camera
+    assert t.nerf.training.n_images_for_training == ds.n_images == 12
+    t.first_training_view(); first = np.array(t.camera_matrix)
+    assert first.shape == (3, 4) and np.allclose(first, np.array(ds.xforms[0]).reshape(4, 3).T)
+    t.next_training_view(); t.next_training_view(); assert np.allclose(np.array(t.camera_matrix), np.array(ds.xforms[2]).reshape(4, 3).T)
+    t.previous_training_view(); t.last_training_view(); t.next_training_view(); assert np.allclose(np.array(t.camera_matrix), np.array(ds.xforms[11]).reshape(4, 3).T)
+    assert np.allclose(t.relative_focal_length, np.array(ds.metadata[11].focal_length) / ds.metadata[11].resolution[t.fov_axis])
+    assert np.allclose(t.screen_center, 1.0 - np.array(ds.metadata[11].principal_point))
+    pos, d = np.array(t.camera_matrix)[:, 3], np.array(t.view_dir)
+    assert np.allclose(d, np.array(t.camera_matrix)[:, 2]) and np.allclose(t.look_at, pos + d * t.scale, atol=1e-6)
+    la = np.array(t.look_at); t.scale = 2.0 * t.scale
+    assert np.allclose(t.look_at, la, atol=1e-5) and np.allclose(np.array(t.camera_matrix)[:, 3], la - d * t.scale, atol=1e-5)  # dolly about the look-at point
+    t.view_dir = [0.0, 0.0, 1.0]
+    m = np.array(t.camera_matrix)
+    assert np.allclose(m[:, 2], [0, 0, 1]) and np.allclose(m[:, 0], np.cross([0, 0, 1], t.up_dir)) and np.allclose(t.look_at, la, atol=1e-5)
+    t.fov_xy = [60.0, 40.0]
+    assert np.allclose(t.relative_focal_length, 0.5 / np.tan(np.radians([30.0, 20.0])), rtol=1e-6) and np.allclose(t.fov_xy, [60.0, 40.0], atol=1e-4)
+    t.reset_camera()
+    assert abs(t.fov - 50.625) < 1e-4 and t.scale == 1.5 and np.allclose(np.array(t.camera_matrix), [[1, 0, 0, 0.5], [0, -1, 0, 0.5], [0, 0, -1, 2.0]])
+    t.camera_matrix = first; assert np.allclose(np.array(t.camera_matrix), first)
+    assert t.nerf.find_closest_training_view(np.array(ds.xforms[7]).reshape(4, 3).T) == 7
+    # training cameras: NeRF convention in, NeRF convention out; the dataset holds the ngp matrix
+    frames = tf["frames"]
+    names = [os.path.basename(p) for p in ds.paths]
+    f0 = next(f for f in frames if os.path.basename(f["file_path"]).split(".")[0] == names[0].split(".")[0])
+    c2w = np.array(f0["transform_matrix"], np.float32)[:3]
+    assert np.allclose(t.nerf.training.get_camera_extrinsics(0), c2w, atol=1e-6)
+    moved = c2w.copy(); moved[:, 3] += [0.1, -0.2, 0.3]
+    t.nerf.training.set_camera_extrinsics(0, moved)
+    assert np.allclose(t.nerf.training.get_camera_extrinsics(0), moved, atol=1e-6)
+    ngp_m = np.array(ds.xforms[0]).reshape(4, 3).T  # ngp = cycle(yzx) of (flip y, z; scale + offset)
+    want = moved.copy(); want[:, 1] *= -1; want[:, 2] *= -1; want[:, 3] = want[:, 3] * ds.scale + np.array(ds.offset); want = want[[1, 2, 0]]
+    assert np.allclose(ngp_m, want, atol=1e-6)
+    start, end = t.nerf.training.transforms[0]
+    assert np.allclose(start, ngp_m) and np.allclose(end, ngp_m) and len(ds.transforms) == 12
+    t.nerf.training.set_camera_extrinsics(1, ngp_m, convert_to_ngp=False); assert np.allclose(np.array(ds.xforms[1]).reshape(4, 3).T, ngp_m)
+    t.nerf.training.set_camera_intrinsics(2, fx=100.0, cx=20.0, cy=-0.25, k1=0.1, p2=0.01)
+    md = ds.metadata[2]
+    assert list(md.focal_length) == [100.0, 100.0] and np.allclose(md.principal_point, [20.0 / 64, 0.25]) and md.lens_mode == 1 and np.allclose(md.lens_params[:4], [0.1, 0, 0, 0.01])
+    t.nerf.training.set_camera_intrinsics(2, fx=90.0, fy=80.0, k1=0.1, k3=0.2, is_fisheye=True)
+    assert list(ds.metadata[2].focal_length) == [90.0, 80.0] and ds.metadata[2].lens_mode == 4 and np.allclose(ds.metadata[2].lens_params[:4], [0.1, 0, 0.2, 0]) and np.allclose(ds.metadata[2].principal_point, [0.5, 0.5])
+    t.nerf.training.set_camera_intrinsics(99, fx=1.0)  # out of range: ignored, like the reference
+    # overrides and switches
+    t.nerf.training.n_images_for_training = 5; assert t.nerf.training.n_images_for_training == 5
+    t.nerf.training.loss_type = ngp.LossType.L1; assert t.nerf.training.loss_type == ngp.LossType.L1
+    assert t.nerf.rgb_activation == ngp.NerfActivation.Logistic and t.nerf.density_activation == ngp.NerfActivation.Exponential
+    t.nerf.rgb_activation = ngp.NerfActivation.Exponential; assert t.nerf.rgb_activation == ngp.NerfActivation.Exponential
+    t.nerf.rendering_min_transmittance = 0.25; assert t.nerf.render_min_transmittance == 0.25
+    t.render_groundtruth = True; assert t.render_ground_truth
+    t.nerf.training.optimize_extrinsics = False; t.shall_train_network = True; t.reset_accumulation()
+    with pytest.raises(RuntimeError, match="not part of this build"):
+        t.nerf.training.optimize_extrinsics = True
+    with pytest.raises(RuntimeError, match="not part of this build"):
+        t.shall_train_encoding = False
+    assert t.n_params() == 0 and t.n_encoding_params() == 0  # no network before the first training step (testbed.cu:4089)
+    assert ngp.mode_from_scene(scene_dir) == ngp.TestbedMode.Nerf and ngp.mode_from_scene(custom) == ngp.TestbedMode.Nerf and ngp.mode_from_scene("/nonexistent") == ngp.TestbedMode.None_ if hasattr(ngp.TestbedMode, "None_") else True
+    assert ngp.mode_from_string("SDF") == ngp.TestbedMode.Sdf and ngp.mode_from_string("image") == ngp.TestbedMode.Image
+    ngp.free_temporary_memory()
+    t.clear_training_data(); assert t.nerf.training.dataset.n_images == 0 and t.nerf.training.n_images_for_training == 0
