@@ -1,4 +1,4 @@
-// ORACLE -- TEST INFRASTRUCTURE ONLY (see ora_math.hpp header).  PARITY UNPINNED.
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see ora_math.hpp header).  PARITY UNPINNED: everything in this file restates tiny-cuda-nn, whose source is absent from the mount.
 //
 // ora_model.hpp: CPU restatement of the tiny-cuda-nn objects the reference's NeRF path consumes:
 // GridEncoding (hash grid) fwd/bwd, FullyFusedMLP fwd/bwd, SphericalHarmonics, the NerfNetwork
