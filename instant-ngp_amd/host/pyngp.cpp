@@ -45,6 +45,12 @@ PYBIND11_MODULE(pyngp, m) {
 		std::memcpy(out.mutable_data(), v.data(), v.size() * sizeof(float));
 		return out;
 	});
+	m.def("_sharpen_rgba8", [](py::array_t<uint8_t, py::array::c_style | py::array::forcecast> img, float amount, bool has_mask) { // not part of the reference API: the loader's sharpening, for tests
+		if (img.ndim() != 3 || img.shape(2) != 4) throw std::runtime_error{"_sharpen_rgba8 expects [h, w, 4] uint8"};
+		const int h = (int)img.shape(0), w = (int)img.shape(1);
+		const auto r = Testbed::sharpen_rgba8_for_tests(std::vector<uint8_t>(img.data(), img.data() + (size_t)w * h * 4), w, h, amount, has_mask);
+		py::array_t<uint16_t> out({h, w, 4}); std::memcpy(out.mutable_data(), r.data(), r.size() * 2); return out;
+	}, py::arg("rgba8"), py::arg("amount"), py::arg("has_mask") = false);
 	m.def("_natural_less", [](const std::string& a, const std::string& b) { return Testbed::natural_path_less(a, b); }); // not part of the reference API: the loader's frame order, for tests
 	m.def("read_stl", [](const std::string& path) { // binary STL (testbed_sdf.cu:1328-1361), float32 [n_triangles][3][3]
 		const std::vector<float> v = mesh_lite::load_stl(path);

@@ -420,7 +420,8 @@ std::vector<uint16_t> sharpen_half(const std::vector<uint16_t>& src, int w, int 
 	}
 	return dst;
 }
-std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int h, float amount) {
+// has_mask: the image came with a dynamic mask; its hot-pink pixels (mask_color 0x00FF00FF) become -1 before the filter, as from_rgba32 makes them (common_device.cuh:729-731)
+std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int h, float amount, bool has_mask) {
 	const int64_t n = (int64_t)w * h;
 	std::vector<uint16_t> src((size_t)n * 4);
 	auto s2l = [](float s) { return s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f); };
@@ -428,9 +429,11 @@ std::vector<uint16_t> sharpen_rgba8(const std::vector<uint8_t>& rgba, int w, int
 		const float alpha = rgba[i * 4 + 3] * (1.0f / 255.0f);
 		for (int c = 0; c < 3; ++c) src[i * 4 + c] = f32_to_f16(s2l(rgba[i * 4 + c] * (1.0f / 255.0f)) * alpha);
 		src[i * 4 + 3] = f32_to_f16(alpha);
+		if (has_mask && rgba[i * 4] == 0xFF && rgba[i * 4 + 1] == 0x00 && rgba[i * 4 + 2] == 0xFF && rgba[i * 4 + 3] == 0x00) for (int c = 0; c < 4; ++c) src[i * 4 + c] = f32_to_f16(-1.0f);
 	}
 	return sharpen_half(src, w, h, amount);
 }
+std::vector<uint16_t> Testbed::sharpen_rgba8_for_tests(const std::vector<uint8_t>& rgba, int w, int h, float amount, bool has_mask) { return sharpen_rgba8(rgba, w, h, amount, has_mask); }
 
 void Testbed::load_training_data(const std::string& path_in) {
 	fs::path path = path_in;
@@ -601,7 +604,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 	}
 	std::sort(frames.begin(), frames.end(), [](const Frame& a, const Frame& b) { return natural_less(a.image_path, b.image_path); });
 	for (Frame& F : frames) {
-		int w = 0, h = 0; std::vector<uint8_t> rgba;
+		int w = 0, h = 0; std::vector<uint8_t> rgba; bool has_mask = false;
 		std::vector<uint16_t> hdr_half; // EXR frames: linear RGBA halfs (EImageDataType::Half), nerf_loader.cu:569-573 + tinyexr_wrapper.cu:39-53
 		const std::string ext_l = lower(fs::path(F.image_path).extension().string());
 		bool ok = false;
@@ -640,7 +643,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 				for (size_t i = 0; i < (size_t)w * h; ++i) { const float s = a[i * 4] * (1.f / 255.f); rgba[i * 4 + 3] = (uint8_t)(255.0f * (s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f))); }
 			}
 			const fs::path mask_path = ip.parent_path() / ("dynamic_mask_" + ip.stem().string() + ".png");
-			if (fs::exists(mask_path)) { // masked pixels become "hot pink" 0x00FF00FF, which read_rgba reports as "no pixel": such rays are not trained
+			has_mask = fs::exists(mask_path);
+			if (has_mask) { // masked pixels become "hot pink" 0x00FF00FF, which read_rgba reports as "no pixel": such rays are not trained
 				int wa = 0, ha = 0; std::vector<uint8_t> mk;
 				if (!decode_any(mask_path, wa, ha, mk)) throw std::runtime_error{"Dynamic mask " + mask_path.string() + " could not be loaded."};
 				if (wa != w || ha != h) throw std::runtime_error{"Dynamic mask " + mask_path.string() + " has wrong resolution."};
@@ -665,7 +669,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 		else F.meta.principal_point = {0.5f, 0.5f};
 		d.pixels_half.emplace_back();
 		if (!hdr_half.empty()) d.pixels_half.back() = d.sharpen_amount > 0.f ? sharpen_half(hdr_half, w, h, d.sharpen_amount) : std::move(hdr_half);
-		else if (d.sharpen_amount > 0.f) d.pixels_half.back() = sharpen_rgba8(rgba, w, h, d.sharpen_amount);
+		else if (d.sharpen_amount > 0.f) d.pixels_half.back() = sharpen_rgba8(rgba, w, h, d.sharpen_amount, has_mask);
 		d.depth.emplace_back();
 		if (!F.depth_path.empty() && fs::exists(F.depth_path)) { // copy_depth, nerf_loader.cu:73-82: float depth = integer depth * (integer_depth_scale * dataset scale); 0 = no measurement
 			int wa = 0, ha = 0; std::vector<uint16_t> dp;

@@ -196,6 +196,7 @@ public:
 	// the loader's built-in readers (load_stbi, nerf_loader.cu:570-603, 633): PNG + JPEG (baseline, progressive) -> RGBA8, 16-bit PNG -> one channel; test hooks for pyngp
 	static bool read_image_builtin(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba);
 	static bool read_depth_png16(const std::string& path, int& w, int& h, std::vector<uint16_t>& gray);
+	static std::vector<uint16_t> sharpen_rgba8_for_tests(const std::vector<uint8_t>& rgba, int w, int h, float amount, bool has_mask); // the loader's sharpening (nerf_loader.cu:805-827), for tests
 	static bool natural_path_less(const std::string& a, const std::string& b); // the loader's frame order (nerf_loader.cu:347-349: SI::natural::compare)
 	static std::string s_default_root_dir;                           // directory that holds configs/ (set by the binding layer)                          // non-PNG images (jpg/exr): provided by the binding layer
 

@@ -39,3 +39,21 @@ REF void ref_sdf_compare_signs(uint32_t n, const float* positions, const float* 
 	FOR_EACH_THREAD(n) compare_signs_kernel(n, (const vec3*)positions, distances_ref, distances_model, counters8, nullptr, 0);
 	blockIdx.x = 0;
 }
+// NerfDataset::set_training_image's image conversions (nerf_loader.cu:41-105, 778-827): convert_rgba32 for byte images; from_rgba32<__half> + sharpen<__half> when a sharpening
+// amount is set; copy_depth<uint16_t> for integer depth images
+REF void ref_convert_rgba32(uint64_t n, const uint8_t* pixels, uint8_t* out, int white_2_transparent, int black_2_transparent, uint32_t mask_color) {
+	FOR_EACH_THREAD((uint32_t)n) convert_rgba32(n, pixels, out, white_2_transparent != 0, black_2_transparent != 0, mask_color);
+	blockIdx.x = 0;
+}
+REF void ref_sharpen_rgba8(const uint8_t* pixels, uint32_t w, uint32_t h, float sharpen_amount, int white_2_transparent, int black_2_transparent, uint32_t mask_color, uint16_t* out_half) {
+	const uint64_t n = (uint64_t)w * h;
+	std::vector<__half> lin(n * 4);
+	FOR_EACH_THREAD((uint32_t)n) from_rgba32<__half>(n, pixels, lin.data(), white_2_transparent != 0, black_2_transparent != 0, mask_color);
+	const float center_w = 4.f + 1.f / sharpen_amount;
+	FOR_EACH_THREAD((uint32_t)n) sharpen<__half>(n, w, lin.data(), (__half*)out_half, center_w, 1.f / (center_w - 4.f));
+	blockIdx.x = 0;
+}
+REF void ref_copy_depth_u16(uint64_t n, float* dst, const uint16_t* src, float depth_scale) {
+	FOR_EACH_THREAD((uint32_t)n) copy_depth<uint16_t>(n, dst, src, depth_scale);
+	blockIdx.x = 0;
+}
