@@ -129,6 +129,12 @@ PYBIND11_MODULE(pyngp, m) {
 			std::memcpy(out.mutable_data(), d.pixels_half[i].data(), d.pixels_half[i].size() * 2);
 			return out;
 		}, "sharpened training image i as IEEE binary16 bit patterns [h, w, 4] (view as float16): linear premultiplied RGBA, what the trainer samples when nerf.sharpen > 0")
+		.def("image_float", [](const NerfDataset& d, size_t i) {
+			if (i >= d.n_images || i >= d.pixels_float.size() || d.pixels_float[i].empty()) throw std::runtime_error{"image_float: image was not set through training.set_image"};
+			py::array_t<float> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});
+			std::memcpy(out.mutable_data(), d.pixels_float[i].data(), d.pixels_float[i].size() * 4);
+			return out;
+		}, "training image i as handed to training.set_image: linear premultiplied RGBA float32 [h, w, 4]")
 		.def("depth", [](const NerfDataset& d, size_t i) {
 			if (i >= d.n_images || i >= d.depth.size() || d.depth[i].empty()) throw std::runtime_error{"depth: image has no depth (json depth_path + integer_depth_scale)"};
 			py::array_t<float> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0]});
@@ -155,6 +161,11 @@ PYBIND11_MODULE(pyngp, m) {
 				if (a.size() < 12) throw std::runtime_error{"set_camera_extrinsics expects a 3x4 matrix"};
 				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];
 				t.owner->set_camera_extrinsics(i, mm, convert); }, py::arg("frame_idx"), py::arg("camera_to_world"), py::arg("convert_to_ngp") = true) // :831-838
+		.def("set_image", [](NerfTraining& t, int i, py::array_t<float, py::array::c_style | py::array::forcecast> img, py::array_t<float, py::array::c_style | py::array::forcecast> depth, float depth_scale) {
+				if (img.ndim() != 3 || img.shape(2) != 4) throw std::runtime_error{"image should be (H,W,C) where C=4"};
+				const bool has_depth = depth.size() == img.shape(0) * img.shape(1);
+				t.owner->set_training_image(i, (int)img.shape(1), (int)img.shape(0), img.data(), has_depth ? depth.data() : nullptr, depth_scale); },
+			py::arg("frame_idx"), py::arg("img"), py::arg("depth_img"), py::arg("depth_scale") = 1.0f) // python_api.cu:45-72, 845-852
 		.def("get_camera_extrinsics", [](NerfTraining& t, int i) {
 				const auto mm = t.owner->get_camera_extrinsics(i); py::array_t<float> out({3, 4}); std::memcpy(out.mutable_data(), mm.data(), sizeof(float) * 12); return out; }, py::arg("frame_idx")) // :839-844
 		// camera / exposure / latent optimisation and the sharpness-weighted error map are not part of this build: the switches exist, turning one on says so
@@ -201,6 +212,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("first_training_view", &Testbed::first_training_view).def("last_training_view", &Testbed::last_training_view)
 		.def("previous_training_view", &Testbed::previous_training_view).def("next_training_view", &Testbed::next_training_view) // python_api.cu:655-658
 		.def("reset_camera", &Testbed::reset_camera).def("reset_accumulation", [](Testbed&, bool, bool) {}, py::arg("due_to_camera_movement") = false, py::arg("immediate_redraw") = true) // :535-541 (every render() starts a fresh accumulation here)
+		.def("create_empty_nerf_dataset", &Testbed::create_empty_nerf_dataset, py::arg("n_images"), py::arg("aabb_scale") = 1, py::arg("is_hdr") = false) // python_api.cu:444-451
 		.def("clear_training_data", &Testbed::clear_training_data)                                                            // :453
 		.def("n_params", &Testbed::n_params).def("n_encoding_params", &Testbed::n_encoding_params)                            // :561-562
 		.def_readwrite("aabb", &Testbed::aabb).def_readwrite("raw_aabb", &Testbed::raw_aabb).def_readwrite("render_aabb", &Testbed::render_aabb) // :641-645

@@ -377,7 +377,9 @@ void Testbed::ensure_trainer() {
 			pix[i] = d.pixels[i].data();
 			if (i < d.depth.size() && !d.depth[i].empty()) meta[i].depth = d.depth[i].data(); // host pointer: ngp_nerf_set_dataset_host uploads it
 			if (i < d.pixels_half.size() && !d.pixels_half[i].empty()) { meta[i].image_data_type = NGP_IMAGE_HALF; pix[i] = d.pixels_half[i].data(); } // sharpened at load time
-			if (d.pixels[i].empty()) { // metadata restored from a snapshot: a 1x1 transparent stand-in keeps the device arrays well formed (render-only)
+			if (i < d.pixels_float.size() && !d.pixels_float[i].empty()) { meta[i].image_data_type = NGP_IMAGE_FLOAT; pix[i] = d.pixels_float[i].data(); } // set_image
+			const bool no_pixels = d.pixels[i].empty() && !(i < d.pixels_float.size() && !d.pixels_float[i].empty()) && !(i < d.pixels_half.size() && !d.pixels_half[i].empty());
+			if (no_pixels) { // metadata restored from a snapshot, or a slot of create_empty_nerf_dataset that set_image has not filled yet: a 1x1 transparent stand-in keeps the device arrays well formed (render-only)
 				static const uint32_t k_no_pixel = 0u;
 				pix[i] = &k_no_pixel; meta[i].resolution[0] = meta[i].resolution[1] = 1;
 			}
@@ -793,8 +795,13 @@ void Testbed::train(uint32_t batch_size) {
 		if (training_step % 16 == 0 || training_step == 1) { if (m_image) NGP_CHECK(ngp_image_loss(m_image, nullptr, &loss)); else NGP_CHECK(ngp_sdf_loss(m_sdf, nullptr, &loss)); }
 		return;
 	}
-	if (nerf.training.dataset.n_images > 0 && nerf.training.dataset.pixels[0].empty())
-		throw std::runtime_error{"Cannot train: the dataset was restored from a snapshot's metadata only. Load the training data first."};
+	{
+		const NerfDataset& d = nerf.training.dataset;
+		auto has_pixels = [&](size_t i) { return !d.pixels[i].empty() || (i < d.pixels_float.size() && !d.pixels_float[i].empty()) || (i < d.pixels_half.size() && !d.pixels_half[i].empty()); };
+		if (d.n_images > 0 && !has_pixels(0))
+			throw std::runtime_error{"Cannot train: the first training image holds no pixels (a dataset restored from a snapshot's metadata only, or created empty and not yet filled by training.set_image)."};
+		if (nerf.training.n_images_for_training <= 0) throw std::runtime_error{"Cannot train: nerf.training.n_images_for_training is 0."};
+	}
 	if (batch_size != training_batch_size && !m_nerf) training_batch_size = batch_size;
 	ensure_trainer();
 	push_options();
@@ -900,6 +907,36 @@ void Testbed::reset_camera() {
 	const auto d = view_dir();
 	for (int k = 0; k < 3; ++k) m_camera[9 + k] -= m_scale * d[k];
 }
+void Testbed::create_empty_nerf_dataset(size_t n_images, int aabb_scale, bool is_hdr) {
+	NerfDataset d;
+	d.n_images = n_images; d.aabb_scale = aabb_scale; d.is_hdr = is_hdr;
+	d.metadata.assign(n_images, ImageMetadata{});
+	d.xforms.assign(n_images, std::array<float, 12>{1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}); d.xforms_end = d.xforms; // mat4x3::identity()
+	d.pixels.assign(n_images, {}); d.pixels_half.assign(n_images, {}); d.pixels_float.assign(n_images, {}); d.depth.assign(n_images, {});
+	d.paths.assign(n_images, std::string());
+	if ((aabb_scale & (aabb_scale - 1)) != 0 || aabb_scale < 1 || aabb_scale > 128) throw std::runtime_error{"create_empty_nerf_dataset: aabb_scale must be a power of two <= 128"};
+	const int prev_scale = nerf.training.dataset.aabb_scale; const bool had = nerf.training.dataset.n_images > 0;
+	nerf.training.dataset = std::move(d);
+	mode = ETestbedMode::Nerf;
+	load_nerf_post();
+	nerf.training.n_images_for_training = 0; // testbed_nerf.cu:2349: the caller raises it as images arrive
+	if (had && prev_scale != aabb_scale) destroy_trainer();
+	m_dataset_dirty = true;
+}
+void Testbed::set_training_image(int frame_idx, int w, int h, const float* rgba, const float* depth, float depth_scale) {
+	NerfDataset& d = nerf.training.dataset;
+	if (frame_idx < 0 || (size_t)frame_idx >= d.n_images) throw std::runtime_error{"Invalid frame index"};
+	if (w < 1 || h < 1) throw std::runtime_error{"image should be (H,W,C) where C=4"};
+	if (d.pixels_float.size() < d.n_images) d.pixels_float.resize(d.n_images);
+	if (d.depth.size() < d.n_images) d.depth.resize(d.n_images);
+	d.pixels_float[frame_idx].assign(rgba, rgba + (size_t)w * h * 4);
+	d.pixels[frame_idx].clear(); if ((size_t)frame_idx < d.pixels_half.size()) d.pixels_half[frame_idx].clear();
+	d.metadata[frame_idx].resolution = {w, h};
+	// copy_depth<float> (nerf_loader.cu:73-82): no depth data, or a scale <= 0, means "no measurement anywhere"
+	d.depth[frame_idx].clear();
+	if (depth && depth_scale > 0.f) { d.depth[frame_idx].resize((size_t)w * h); for (size_t i = 0; i < (size_t)w * h; ++i) d.depth[frame_idx][i] = depth[i] * depth_scale; }
+	m_dataset_dirty = true;
+}
 void Testbed::clear_training_data() { // testbed.cu:190-193: the metadata goes, training stops being possible until new data is loaded
 	nerf.training.dataset = NerfDataset{};
 	nerf.training.n_images_for_training = 0;
@@ -1003,6 +1040,7 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 		// overlay_image_kernel (render_buffer.cu:344-412): point-sample the training image at pixel centres
 		const NerfDataset& d = nerf.training.dataset;
 		const auto& m = d.metadata[m_training_view];
+		if (d.pixels[m_training_view].empty()) throw std::runtime_error{"render_ground_truth: this training image has no 8-bit pixels on the host (set through training.set_image, or restored from a snapshot)"};
 		const uint8_t* px = d.pixels[m_training_view].data();
 		for (int y = 0; y < height; ++y) for (int x = 0; x < width; ++x) {
 			const float u = ((float)x + 0.5f) / (float)width, v = ((float)y + 0.5f) / (float)height;

@@ -68,6 +68,7 @@ struct NerfDataset {                        // nerf_loader.h NerfDataset (subset
 	std::vector<std::array<float, 12>> xforms_end;  // TrainingXForm::end: json "transform_matrix_end" (== start without motion data)
 	std::vector<std::vector<uint8_t>> pixels;        // RGBA8 per image (host copy; also feeds render_ground_truth)
 	std::vector<std::vector<float>> depth;            // per image: empty, or one float per pixel in scene units (json "depth_path" + "integer_depth_scale", nerf_loader.cu:629-641, 73-82)
+	std::vector<std::vector<float>> pixels_float;     // images handed over by Training.set_image (python_api.cu:45-72): linear premultiplied RGBA float32, sampled as EImageDataType::Float
 	std::vector<std::vector<uint16_t>> pixels_half;  // sharpened images (nerf.sharpen > 0): linear premultiplied RGBA halfs, what the trainer then samples
 	float sharpen_amount = 0.f;                      // what the images were loaded with (json "sharpen" overrides nerf.sharpen, nerf_loader.cu:462)
 	std::vector<std::string> paths;
@@ -136,6 +137,8 @@ public:
 	void first_training_view(); void last_training_view(); void previous_training_view(); void next_training_view(); // testbed.cu:460-484
 	void reset_camera();                                            // testbed.cu:507-528
 	void clear_training_data();                                     // testbed.cu:190-193
+	void create_empty_nerf_dataset(size_t n_images, int aabb_scale = 1, bool is_hdr = false); // testbed_nerf.cu:2344-2351, nerf_loader.cu:148-172
+	void set_training_image(int frame_idx, int w, int h, const float* rgba, const float* depth_or_null, float depth_scale); // NerfDataset::set_training_image for float data (nerf_loader.cu:749-850)
 	size_t n_params(); size_t n_encoding_params();                  // testbed.cu:4089-4091
 	// camera (testbed.cu:440-458): column-major mat4x3, columns = side, up, direction, position
 	std::array<float, 3> view_pos() const { return {m_camera[9], m_camera[10], m_camera[11]}; }

