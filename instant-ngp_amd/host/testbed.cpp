@@ -1196,9 +1196,13 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 			Value x = jobj(); x.set("start", jmat_cols(d.xforms[i].data(), 4, 3)); x.set("end", jmat_cols((i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i]).data(), 4, 3)); xfs.arr.push_back(x);
 		}
 		jd.set("metadata", metas); jd.set("xforms", xfs);
-		const ngp_aabb box = scene_aabb(); jd.set("render_aabb", jbox(box));
-		const float eye3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; jd.set("render_aabb_to_local", jmat_cols(eye3, 3, 3));
-		const float up[3] = {0.f, 1.f, 0.f}; jd.set("up", jvec(up, 3)); jd.set("offset", jvec(d.offset.data(), 3));
+		{ // to_json(NerfDataset), json_binding.h: the dataset's own crop box (empty = none: the scene box is written, as before), its orientation and up vector
+			ngp_aabb box = scene_aabb();
+			if (!d.render_aabb.is_empty()) for (int k = 0; k < 3; ++k) { box.min[k] = d.render_aabb.min[k]; box.max[k] = d.render_aabb.max[k]; }
+			jd.set("render_aabb", jbox(box));
+		}
+		jd.set("render_aabb_to_local", jmat_cols(d.render_aabb_to_local.data(), 3, 3));
+		jd.set("up", jvec(d.up.data(), 3)); jd.set("offset", jvec(d.offset.data(), 3));
 		const int env[2] = {0, 0}; jd.set("envmap_resolution", jvec(env, 2)); jd.set("scale", jnum(d.scale)); jd.set("aabb_scale", jnum(d.aabb_scale));
 		jd.set("from_mitsuba", jbool(d.from_mitsuba)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(0));
 		jn.set("dataset", jd);
@@ -1207,14 +1211,18 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	snap.set("training_step", jnum(training_step)); snap.set("loss", jnum(loss));
 	const ngp_aabb box = scene_aabb();
 	snap.set("aabb", jbox(box)); snap.set("bounding_radius", jnum(1.0));
-	{ const float eye3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; snap.set("render_aabb_to_local", jmat_cols(eye3, 3, 3)); }
-	snap.set("render_aabb", jbox(box));
-	{ const float up[3] = {0.f, 1.f, 0.f}, sun[3] = {0.577f, 0.577f, 0.577f}; snap.set("up_dir", jvec(up, 3)); snap.set("sun_dir", jvec(sun, 3)); }
+	snap.set("render_aabb_to_local", jmat_cols(render_aabb_to_local.data(), 3, 3));
+	{ // m_render_aabb / m_up_dir, testbed.cu:5319-5320
+		ngp_aabb rb = box;
+		if (!render_aabb.is_empty()) for (int k = 0; k < 3; ++k) { rb.min[k] = render_aabb.min[k]; rb.max[k] = render_aabb.max[k]; }
+		snap.set("render_aabb", jbox(rb));
+	}
+	{ const float sun[3] = {0.577f, 0.577f, 0.577f}; snap.set("up_dir", jvec(up_dir.data(), 3)); snap.set("sun_dir", jvec(sun, 3)); }
 	snap.set("exposure", jnum(exposure)); snap.set("background_color", jvec(background_color.data(), 4));
 	Value cam = jobj();
 	cam.set("matrix", jmat_cols(m_camera.data(), 4, 3)); cam.set("fov_axis", jnum(fov_axis));
 	cam.set("relative_focal_length", jvec(relative_focal_length.data(), 2)); cam.set("screen_center", jvec(screen_center.data(), 2));
-	cam.set("zoom", jnum(1.0)); cam.set("scale", jnum(1.5)); cam.set("aperture_size", jnum(0.0)); cam.set("autofocus", jbool(false));
+	cam.set("zoom", jnum(zoom)); cam.set("scale", jnum(m_scale)); cam.set("aperture_size", jnum(0.0)); cam.set("autofocus", jbool(false));
 	{ const float t[3] = {0.5f, 0.5f, 0.5f}; cam.set("autofocus_target", jvec(t, 3)); } cam.set("autofocus_depth", jnum(0.5));
 	snap.set("camera", cam);
 	root.set("snapshot", snap);
@@ -1250,6 +1258,9 @@ void Testbed::load_snapshot(const std::string& path) {
 		NerfDataset d;
 		d.aabb_scale = (int)jd.num("aabb_scale", aabb_scale); d.scale = (float)jd.num("scale", 0.33); d.is_hdr = jd["is_hdr"].type == Value::Bool && jd["is_hdr"].b; d.from_mitsuba = jd.boolean("from_mitsuba", false);
 		if (jd["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)jd["offset"].at(k).n;
+		if (jd["up"].size() == 3) for (int k = 0; k < 3; ++k) d.up[k] = (float)jd["up"].at(k).n;
+		if (jd["render_aabb"].is_object() && jd["render_aabb"]["min"].size() == 3 && jd["render_aabb"]["max"].size() == 3)
+			for (int k = 0; k < 3; ++k) { d.render_aabb.min[k] = (float)jd["render_aabb"]["min"].at(k).n; d.render_aabb.max[k] = (float)jd["render_aabb"]["max"].at(k).n; }
 		const size_t n = jd["metadata"].size();
 		for (size_t i = 0; i < n; ++i) {
 			const Value& jm = jd["metadata"].at(i);
@@ -1316,6 +1327,14 @@ void Testbed::load_snapshot(const std::string& path) {
 		fov_axis = (int)cam.num("fov_axis", fov_axis);
 		if (cam["relative_focal_length"].size() == 2) for (int k = 0; k < 2; ++k) relative_focal_length[k] = (float)cam["relative_focal_length"].at(k).n;
 		if (cam["screen_center"].size() == 2) for (int k = 0; k < 2; ++k) screen_center[k] = (float)cam["screen_center"].at(k).n;
+		zoom = (float)cam.num("zoom", zoom); m_scale = (float)cam.num("scale", m_scale);
+	}
+	{ // m_render_aabb, m_up_dir (testbed.cu:5456-5459); the crop box orientation travels with them
+		const Value& rb = snap["render_aabb"];
+		if (rb.is_object() && rb["min"].size() == 3 && rb["max"].size() == 3) for (int k = 0; k < 3; ++k) { render_aabb.min[k] = (float)rb["min"].at(k).n; render_aabb.max[k] = (float)rb["max"].at(k).n; }
+		if (snap["up_dir"].size() == 3) for (int k = 0; k < 3; ++k) up_dir[k] = (float)snap["up_dir"].at(k).n;
+		const Value& rl = snap["render_aabb_to_local"];
+		if (rl.is_array() && rl.size() == 3) for (int c = 0; c < 3; ++c) if (rl.at(c).size() == 3) for (int r = 0; r < 3; ++r) render_aabb_to_local[c * 3 + r] = (float)rl.at(c).at(r).n;
 	}
 	m_network_config_path = path;
 }
