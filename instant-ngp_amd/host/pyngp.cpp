@@ -190,6 +190,15 @@ PYBIND11_MODULE(pyngp, m) {
 				return n.training.owner->find_closest_training_view(mm); })                                                                                      // :729-733
 		.def_readonly("training", &Nerf::training);
 
+	py::enum_<ERandomMode>(m, "RandomMode").value("Random", ERandomMode::Random).value("Halton", ERandomMode::Halton).value("Sobol", ERandomMode::Sobol)
+		.value("Stratified", ERandomMode::Stratified).export_values();                                           // python_api.cu:344-349
+	py::enum_<EMeshSdfMode>(m, "MeshSdfMode").value("Watertight", EMeshSdfMode::Watertight).value("Raystab", EMeshSdfMode::Raystab).value("PathEscape", EMeshSdfMode::PathEscape).export_values(); // :376-380
+	py::class_<ImageTraining>(testbed, "ImageTraining").def_readwrite("snap_to_pixel_centers", &ImageTraining::snap_to_pixel_centers).def_readwrite("linear_colors", &ImageTraining::linear_colors); // :877-879
+	py::class_<ImagePrimitive>(testbed, "Image").def_readonly("training", &ImagePrimitive::training).def_readwrite("random_mode", &ImagePrimitive::random_mode);                                   // :874-875
+	py::class_<SdfTraining>(testbed, "SdfTraining").def_readwrite("generate_sdf_data_online", &SdfTraining::generate_sdf_data_online).def_readwrite("surface_offset_scale", &SdfTraining::surface_offset_scale); // :870-872
+	py::class_<SdfPrimitive>(testbed, "Sdf").def_readonly("training", &SdfPrimitive::training).def_readwrite("mesh_sdf_mode", &SdfPrimitive::mesh_sdf_mode).def_readwrite("mesh_scale", &SdfPrimitive::mesh_scale)
+		.def_readwrite("zero_offset", &SdfPrimitive::zero_offset).def_readwrite("use_triangle_octree", &SdfPrimitive::use_triangle_octree).def_readwrite("calculate_iou_online", &SdfPrimitive::calculate_iou_online); // :855-868 (the members the trainer and the ground truth use; the shading ones belong to SDF rendering)
+
 	testbed
 		.def(py::init<>())
 		.def(py::init([](ETestbedMode) { return std::make_unique<Testbed>(); }))
@@ -263,6 +272,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("training_batch_size", &Testbed::training_batch_size)
 		.def_readwrite("seed", &Testbed::seed)
 		.def_property_readonly("nerf", [](Testbed& t) -> Nerf& { return t.nerf; }, py::return_value_policy::reference_internal)
+		.def_property_readonly("image", [](Testbed& t) -> ImagePrimitive& { return t.image; }, py::return_value_policy::reference_internal)
+		.def_property_readonly("sdf", [](Testbed& t) -> SdfPrimitive& { return t.sdf; }, py::return_value_policy::reference_internal)
 		.def_property_readonly("rays_per_batch", [](Testbed& t) { return t.stats().rays_per_batch; })
 		.def_property_readonly("measured_batch_size", [](Testbed& t) { return t.stats().measured_batch_size; });
 

@@ -448,7 +448,8 @@ void Testbed::load_training_data(const std::string& path_in) {
 		m_network_config = mini_json::Value{};
 		if (ext == ".obj" || ext == ".stl") { // load_mesh, testbed_sdf.cu:1363-1447
 			m_mesh = ext == ".stl" ? mesh_lite::load_stl(path.string()) : mesh_lite::load_obj(path.string());
-			NGP_CHECK(ngp_sdf_normalize_mesh_host(m_mesh.data(), m_mesh.size() / 3, &m_mesh_aabb, nullptr));
+			NGP_CHECK(ngp_sdf_normalize_mesh_host(m_mesh.data(), m_mesh.size() / 3, &m_mesh_aabb, &sdf.mesh_scale)); // m_sdf.mesh_scale, testbed_sdf.cu:1404
+			aabb = raw_aabb = render_aabb = BoundingBox{{m_mesh_aabb.min[0], m_mesh_aabb.min[1], m_mesh_aabb.min[2]}, {m_mesh_aabb.max[0], m_mesh_aabb.max[1], m_mesh_aabb.max[2]}}; // :1408-1410
 			mode = ETestbedMode::Sdf;
 		} else { // load_image, testbed_image.cu:393-458: EXR and the .bin format natively (linear), PNG / JPEG natively and other 8-bit formats through the decoder hook (sRGB -> linear)
 			if (ext == ".exr") exr_lite::read_rgba(path.string(), m_image_w, m_image_h, m_image_pixels);
@@ -765,11 +766,15 @@ void Testbed::ensure_encmlp_trainer() {
 	const int loss_type = lt == "mape" ? NGP_LOSS_MAPE : lt == "l1" ? NGP_LOSS_L1 : lt == "relativel2" ? NGP_LOSS_RELATIVE_L2 : NGP_LOSS_L2;
 	if (image) {
 		ngp_image_options io; memset(&io, 0, sizeof(io));
-		io.snap_to_pixel_centers = 1; io.linear_colors = 0; io.stratified = 1; io.loss_type = loss_type; io.loss_scale = 128.f; io.batch_size = training_batch_size; io.seed = seed;
+		if (this->image.random_mode != ERandomMode::Random && this->image.random_mode != ERandomMode::Stratified) throw std::runtime_error{"image.random_mode: Halton / Sobol sampling of the image trainer is not part of this build (Random, Stratified)"};
+		io.snap_to_pixel_centers = this->image.training.snap_to_pixel_centers; io.linear_colors = this->image.training.linear_colors; io.stratified = this->image.random_mode == ERandomMode::Stratified; io.loss_type = loss_type; io.loss_scale = 128.f; io.batch_size = training_batch_size; io.seed = seed;
 		NGP_CHECK(ngp_image_create(m_encmlp, m_image_pixels.data(), NGP_IMAGE_FLOAT, m_image_w, m_image_h, &io, &m_image));
 	} else {
 		ngp_sdf_options so; memset(&so, 0, sizeof(so));
-		so.loss_type = loss_type; so.loss_scale = 128.f; so.batch_size = training_batch_size; so.seed = seed; so.surface_offset_scale = 1.f; so.zero_offset = 0.f;
+		so.loss_type = loss_type; so.loss_scale = 128.f; so.batch_size = training_batch_size; so.seed = seed; so.surface_offset_scale = sdf.training.surface_offset_scale; so.zero_offset = sdf.zero_offset;
+		if (sdf.mesh_sdf_mode != EMeshSdfMode::Raystab) throw std::runtime_error{"sdf.mesh_sdf_mode: only Raystab ground truth is part of this build (Watertight needs the averaged-normal query, PathEscape OptiX)"};
+		if (sdf.use_triangle_octree) throw std::runtime_error{"sdf.use_triangle_octree: the octree sampler is not part of this build"};
+		if (!sdf.training.generate_sdf_data_online) throw std::runtime_error{"sdf.training.generate_sdf_data_online = False: overriding the training data is not part of this build"};
 		NGP_CHECK(ngp_sdf_create(m_encmlp, m_mesh.data(), (uint32_t)(m_mesh.size() / 9), m_mesh_aabb, &so, &m_sdf));
 	}
 }

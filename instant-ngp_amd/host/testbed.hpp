@@ -115,6 +115,20 @@ struct Nerf {
 	NerfTraining training;
 };
 
+enum class ERandomMode : int { Random = 0, Halton = 1, Sobol = 2, Stratified = 3 };   // common.h
+enum class EMeshSdfMode : int { Watertight = 0, Raystab = 1, PathEscape = 2 };         // common.h:118-122
+struct ImageTraining { bool snap_to_pixel_centers = true; bool linear_colors = false; };  // testbed.h:966-967
+struct ImagePrimitive { ImageTraining training; ERandomMode random_mode = ERandomMode::Stratified; }; // testbed.h:970
+struct SdfTraining { bool generate_sdf_data_online = true; float surface_offset_scale = 1.0f; };       // testbed.h:937-938
+struct SdfPrimitive {                                                                    // testbed.h:905-950 (what the trainer and the ground truth use)
+	SdfTraining training;
+	EMeshSdfMode mesh_sdf_mode = EMeshSdfMode::Raystab;
+	float mesh_scale = 1.f;          // set by load_mesh (testbed_sdf.cu:1404)
+	float zero_offset = 0.f;
+	bool use_triangle_octree = false;
+	bool calculate_iou_online = false;
+};
+
 using ImageDecoder = std::function<bool(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba)>;
 
 class Testbed {
@@ -185,6 +199,8 @@ public:
 	uint32_t training_batch_size = 1u << 18;                         // testbed.h:1089
 	uint64_t seed = 1337;                                            // testbed.h:680
 	Nerf nerf;
+	ImagePrimitive image;                                            // python_api.cu:673, 874-879: settings read when the image trainer is created
+	SdfPrimitive sdf;                                                // python_api.cu:672, 855-872
 	BoundingBox aabb, raw_aabb, render_aabb;                         // testbed.h:1025-1027; set by load_nerf_post (testbed_nerf.cu:2424-2431)
 	std::array<float, 9> render_aabb_to_local{1, 0, 0, 0, 1, 0, 0, 0, 1};
 	std::array<float, 3> up_dir{0.f, 1.f, 0.f};                      // testbed.h:672

@@ -384,3 +384,21 @@ def test_training_from_a_dataset_handed_over_in_memory(scene_dir):
     assert np.allclose(np.array(mem.nerf.training.dataset.xforms), np.array(ds.xforms), atol=1e-6)
     l_disk, l_mem = run(disk), run(mem)
     assert 0 < l_disk < 0.01 and 0 < l_mem < 0.01 and abs(l_mem - l_disk) < 0.5 * max(l_disk, l_mem) + 1e-3, (l_disk, l_mem)
+
+
+def test_image_and_sdf_settings_objects():
+    """Testbed.image / Testbed.sdf (python_api.cu:672-673, 855-879): the settings the image and SDF trainers are created with, and load_mesh's scale / box (testbed_sdf.cu:1380-1410)"""
+    ngp = _ngp()
+    t = ngp.Testbed()
+    assert t.image.random_mode == ngp.RandomMode.Stratified and t.image.training.snap_to_pixel_centers and not t.image.training.linear_colors      # testbed.h:966-970
+    assert t.sdf.mesh_sdf_mode == ngp.MeshSdfMode.Raystab and t.sdf.training.surface_offset_scale == 1.0 and t.sdf.training.generate_sdf_data_online and t.sdf.zero_offset == 0.0
+    t.image.training.linear_colors = True; t.image.random_mode = ngp.RandomMode.Random; t.sdf.training.surface_offset_scale = 2.0
+    assert t.image.training.linear_colors and t.image.random_mode == ngp.RandomMode.Random and t.sdf.training.surface_offset_scale == 2.0
+    mesh = os.path.join(ROOT, "_ref_data", "data", "sdf", "armadillo.obj")
+    if os.path.exists(mesh):
+        t.load_training_data(mesh)
+        v = np.array([[float(x) for x in l.split()[1:4]] for l in open(mesh) if l.startswith("v ")], np.float32)
+        lo, hi = v.min(0), v.max(0); d = hi - lo
+        amt = np.float32(np.sqrt((d * d).sum())) * np.float32(0.005)  # raw box inflated by 0.5 % of its diagonal; the scale is its largest extent
+        assert t.mode == ngp.TestbedMode.Sdf and abs(t.sdf.mesh_scale - float((d + 2 * amt).max())) < 1e-4 * t.sdf.mesh_scale
+        assert (np.array(t.aabb.min) >= 0).all() and (np.array(t.aabb.max) <= 1).all() and max(np.array(t.aabb.max) - np.array(t.aabb.min)) > 0.99
