@@ -226,6 +226,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("n_params", &Testbed::n_params).def("n_encoding_params", &Testbed::n_encoding_params)                            // :561-562
 		.def_readwrite("aabb", &Testbed::aabb).def_readwrite("raw_aabb", &Testbed::raw_aabb).def_readwrite("render_aabb", &Testbed::render_aabb) // :641-645
 		.def_readwrite("render_aabb_to_local", &Testbed::render_aabb_to_local)
+		.def_readwrite("visualize_unit_cube", &Testbed::visualize_unit_cube)
 		.def_readwrite("up_dir", &Testbed::up_dir).def_readwrite("zoom", &Testbed::zoom).def_readwrite("render_near_distance", &Testbed::render_near_distance)
 		.def_readwrite("relative_focal_length", &Testbed::relative_focal_length).def_readwrite("screen_center", &Testbed::screen_center) // :649-651
 		.def_property("fov_xy", &Testbed::fov_xy, &Testbed::set_fov_xy).def_property("scale", &Testbed::scale, &Testbed::set_scale)   // :639, 647

@@ -803,9 +803,9 @@ void Testbed::train(uint32_t batch_size) {
 	{
 		const NerfDataset& d = nerf.training.dataset;
 		auto has_pixels = [&](size_t i) { return !d.pixels[i].empty() || (i < d.pixels_float.size() && !d.pixels_float[i].empty()) || (i < d.pixels_half.size() && !d.pixels_half[i].empty()); };
-		if (d.n_images > 0 && !has_pixels(0))
+		if (d.n_images > 0 && nerf.training.n_images_for_training > 0 && !has_pixels(0))
 			throw std::runtime_error{"Cannot train: the first training image holds no pixels (a dataset restored from a snapshot's metadata only, or created empty and not yet filled by training.set_image)."};
-		if (nerf.training.n_images_for_training <= 0) throw std::runtime_error{"Cannot train: nerf.training.n_images_for_training is 0."};
+		if (nerf.training.n_images_for_training <= 0) return; // train_nerf returns at once (testbed_nerf.cu:2705-2707): a streaming client has not delivered an image yet
 	}
 	if (batch_size != training_batch_size && !m_nerf) training_batch_size = batch_size;
 	ensure_trainer();

@@ -204,6 +204,7 @@ public:
 	BoundingBox aabb, raw_aabb, render_aabb;                         // testbed.h:1025-1027; set by load_nerf_post (testbed_nerf.cu:2424-2431)
 	std::array<float, 9> render_aabb_to_local{1, 0, 0, 0, 1, 0, 0, 0, 1};
 	std::array<float, 3> up_dir{0.f, 1.f, 0.f};                      // testbed.h:672
+	bool visualize_unit_cube = false;                                // GUI overlay switch: kept so that scripts that set it run
 	float zoom = 1.f;                                                // testbed.h:647 (2-D zoom of the GUI view; kept for scripts)
 	float render_near_distance = 0.f;                                // testbed.h (m_render_near_distance)
 	std::array<float, 2> relative_focal_length{1.f, 1.f};            // testbed.h: focal length / resolution[fov_axis]
