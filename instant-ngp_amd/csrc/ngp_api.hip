@@ -1239,7 +1239,7 @@ struct ngp_nerf {
 	ngp_model* model;
 	ngp_nerf_options opt;
 	ngp_aabb aabb;
-	uint32_t n_images = 0;
+	uint32_t n_images = 0, n_images_marked = 0; // n_images_marked: Nerf::Training::n_images_for_training_prev (testbed.h)
 	ngp_image_meta* meta_dev = nullptr; ngp_xform* xforms_dev = nullptr;
 	std::vector<void*> owned_pixels;
 	float* density_grid = nullptr; float* density_grid_tmp = nullptr; uint8_t* bitfield = nullptr; float* mean = nullptr; float* mean_partial = nullptr;
@@ -1395,9 +1395,10 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	const uint32_t n_elements = GRID_N_CELLS * (t->opt.max_cascade + 1);
 	const uint32_t n_samples = n_uniform + n_nonuniform;
 	REQUIRE(n_samples <= t->grid_sample_cap, "update_density_grid: too many samples");
-	if (t->training_step == 0) {
-		t->ema_step = 0;
-		launch_mark_untrained(s, n_elements, t->density_grid, t->n_images, t->meta_dev, t->xforms_dev, 1);
+	if (t->training_step == 0 || t->n_images != t->n_images_marked) { // testbed_nerf.cu:2500-2517: at the first step, and again whenever the number of training images changed
+		t->n_images_marked = t->n_images;                             // (a streaming client raising n_images_for_training): cells only the new cameras see become trainable
+		if (t->training_step == 0) t->ema_step = 0;
+		launch_mark_untrained(s, n_elements, t->density_grid, t->n_images, t->meta_dev, t->xforms_dev, t->training_step == 0 ? 1 : 0);
 	}
 	{ ProfScope ps(P_GRID_MISC, s);
 	HIPCHK(hipMemsetAsync(t->density_grid_tmp, 0, (size_t)n_elements * 4, s));

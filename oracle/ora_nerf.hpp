@@ -827,7 +827,7 @@ struct NerfTrainer {
 	uint32_t ema_step = 0;
 	Pcg32 rng, density_grid_rng;
 	uint32_t training_step = 0;
-	uint32_t rays_per_batch = 1u << 12, n_rays_total = 0;
+	uint32_t rays_per_batch = 1u << 12, n_rays_total = 0, n_images_marked = 0;
 	uint32_t measured_batch_size = 0, measured_batch_size_before_compaction = 0;
 	uint32_t n_rays_last = 0;
 	float loss_scalar = 0.f;
@@ -869,9 +869,10 @@ struct NerfTrainer {
 	void update_density_grid(float decay, uint32_t n_uniform, uint32_t n_nonuniform) {
 		const uint32_t n_elements = NERF_GRID_N_CELLS * (opt.max_cascade + 1);
 		const uint32_t n_samples = n_uniform + n_nonuniform;
-		if (training_step == 0) {
-			ema_step = 0;
-			mark_untrained_density_grid(n_elements, density_grid.data(), (uint32_t)meta.size(), meta.data(), xforms.data(), true);
+		if (training_step == 0 || (uint32_t)meta.size() != n_images_marked) { // testbed_nerf.cu:2500-2517: again whenever the number of training images changed
+			n_images_marked = (uint32_t)meta.size();
+			if (training_step == 0) ema_step = 0;
+			mark_untrained_density_grid(n_elements, density_grid.data(), (uint32_t)meta.size(), meta.data(), xforms.data(), training_step == 0);
 		}
 		std::vector<float> positions((size_t)n_samples * 3), tmp(n_elements, 0.f);
 		std::vector<uint32_t> indices(n_samples);
