@@ -205,6 +205,13 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("load_file", &Testbed::load_file, py::call_guard<py::gil_scoped_release>())
 		.def("load_training_data", &Testbed::load_training_data, "Load training data from a given path.")
 		.def("reload_network_from_file", &Testbed::reload_network_from_file, py::arg("path") = "")
+		.def("reload_network_from_json", [](Testbed& t, py::object json, const std::string& base) { // python_api.cu:544-550: a dict (or a JSON string)
+				const std::string text = py::isinstance<py::str>(json) ? json.cast<std::string>() : py::module_::import("json").attr("dumps")(json).cast<std::string>();
+				t.reload_network_from_json_text(text, base); }, py::arg("json"), py::arg("config_base_path") = "")
+		.def("_network_config_json", [](const Testbed& t) { return mini_json::dump(t.network_config()); }) // not part of the reference API: the merged config, for tests
+		.def_property_readonly("bounding_radius", [](const Testbed&) { return 0.8660254037844386f; }) // testbed.h m_bounding_radius = length(vec3(0.5))
+		.def_property("jit_fusion", [](Testbed&) { return true; }, [](Testbed&, bool) {}) // python_api.cu: the reference's JIT-fused kernels on / off; the kernels here are fused at build time either way
+		.def_property("max_level_rand_training", [](Testbed&) { return false; }, [](Testbed&, bool v) { if (v) throw std::runtime_error{"max_level_rand_training: random level cut-off is not part of this build"}; })
 		.def("reset", &Testbed::reset_network).def("reset_network", &Testbed::reset_network)
 		.def("load_snapshot", &Testbed::load_snapshot).def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())

@@ -300,6 +300,19 @@ void Testbed::reload_network_from_file(const std::string& path_in) {
 	reset_network();
 }
 
+// reload_network_from_json, testbed.cu:346-351: the config as a JSON document; a "parent" entry resolves against config_base_path (a file name, or a directory with a trailing slash)
+void Testbed::reload_network_from_json_text(const std::string& json_text, const std::string& config_base_path) {
+	mini_json::Value v; std::string err;
+	if (!mini_json::parse(json_text.c_str(), v, err)) throw std::runtime_error{"reload_network_from_json: " + err};
+	if (v.has("parent")) {
+		mini_json::Value parent = load_config_recursive(fs::path(config_base_path).parent_path() / v.str("parent", ""), 1);
+		mini_json::merge_patch(parent, v);
+		v = parent;
+	}
+	m_network_config = v;
+	reset_network();
+}
+
 void Testbed::reset_network() {
 	destroy_trainer(); // rebuilt lazily with the current dataset / options
 	training_step = 0;

@@ -141,6 +141,8 @@ public:
 	void load_file(const std::string& path);                        // testbed.cu:183-252
 	void load_training_data(const std::string& path);               // testbed.cu:156
 	void reload_network_from_file(const std::string& path = "");    // testbed.cu:311
+	void reload_network_from_json_text(const std::string& json_text, const std::string& config_base_path = ""); // testbed.cu:346-351
+	const mini_json::Value& network_config() const { return m_network_config; }
 	void reset_network();                                           // testbed.cu:4160
 	void load_snapshot(const std::string& path);                    // testbed.cu:5357
 	void save_snapshot(const std::string& path, bool include_optimizer_state = false); // testbed.cu:5288

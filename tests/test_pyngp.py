@@ -402,3 +402,21 @@ def test_image_and_sdf_settings_objects():
         amt = np.float32(np.sqrt((d * d).sum())) * np.float32(0.005)  # raw box inflated by 0.5 % of its diagonal; the scale is its largest extent
         assert t.mode == ngp.TestbedMode.Sdf and abs(t.sdf.mesh_scale - float((d + 2 * amt).max())) < 1e-4 * t.sdf.mesh_scale
         assert (np.array(t.aabb.min) >= 0).all() and (np.array(t.aabb.max) <= 1).all() and max(np.array(t.aabb.max) - np.array(t.aabb.min)) > 0.99
+
+
+def test_reload_network_from_json():
+    """reload_network_from_json (python_api.cu:544-550, testbed.cu:346-351): a config handed over as a dict, its "parent" resolved against config_base_path and merge-patched"""
+    ngp = _ngp()
+    t = ngp.Testbed(); t.mode = ngp.TestbedMode.Nerf
+    base = os.path.join(t.root_dir, "configs", "nerf", "")
+    t.reload_network_from_json({"parent": "base.json", "encoding": {"n_levels": 16, "n_features_per_level": 2}, "loss": {"otype": "L1"}}, base)
+    c = json.loads(t._network_config_json())
+    ref = json.load(open(os.path.join(base, "base.json")))
+    assert c["encoding"]["n_levels"] == 16 and c["encoding"]["n_features_per_level"] == 2 and c["encoding"]["otype"] == ref["encoding"]["otype"]
+    assert c["loss"]["otype"] == "L1" and c["network"] == ref["network"] and c["optimizer"] == ref["optimizer"]
+    t.reload_network_from_json(json.dumps({"loss": {"otype": "Huber"}}))
+    assert json.loads(t._network_config_json()) == {"loss": {"otype": "Huber"}} and t.training_step == 0
+    with pytest.raises(RuntimeError):
+        t.reload_network_from_json("{not json")
+    assert abs(t.bounding_radius - math.sqrt(0.75)) < 1e-6 and t.jit_fusion
+    t.jit_fusion = False; t.max_level_rand_training = False
