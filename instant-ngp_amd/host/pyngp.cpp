@@ -13,6 +13,17 @@
 namespace py = pybind11;
 using namespace ngp_host;
 
+static py::list dataset_transforms(const NerfDataset& d) {
+	py::list out;
+	for (size_t i = 0; i < d.n_images; ++i) {
+		py::array_t<float> a({3, 4}), b({3, 4});
+		const auto& e = i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i];
+		for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { a.mutable_at(r, c) = d.xforms[i][c * 3 + r]; b.mutable_at(r, c) = e[c * 3 + r]; }
+		out.append(py::make_tuple(a, b));
+	}
+	return out;
+}
+
 static py::array_t<float> render_to_numpy(Testbed& t, int w, int h, int spp, bool linear) {
 	std::vector<float> px;
 	{
@@ -105,16 +116,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readonly("scale", &NerfDataset::scale).def_readonly("offset", &NerfDataset::offset).def_readonly("paths", &NerfDataset::paths)
 		.def_readonly("render_aabb", &NerfDataset::render_aabb).def_readonly("render_aabb_to_local", &NerfDataset::render_aabb_to_local).def_readonly("up", &NerfDataset::up)
 		.def_readonly("envmap_resolution", &NerfDataset::envmap_resolution)
-		.def_property_readonly("transforms", [](const NerfDataset& d) { // python_api.cu:768: the (start, end) pair per image, here as two 3 x 4 arrays each (ngp convention)
-			py::list out;
-			for (size_t i = 0; i < d.n_images; ++i) {
-				py::array_t<float> a({3, 4}), b({3, 4});
-				const auto& e = i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i];
-				for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { a.mutable_at(r, c) = d.xforms[i][c * 3 + r]; b.mutable_at(r, c) = e[c * 3 + r]; }
-				out.append(py::make_tuple(a, b));
-			}
-			return out;
-		})
+		.def_property_readonly("transforms", [](const NerfDataset& d) { return dataset_transforms(d); }) // python_api.cu:768: the (start, end) pair per image, here as two 3 x 4 arrays each (ngp convention)
 		.def_readonly("is_hdr", &NerfDataset::is_hdr).def_readonly("xforms", &NerfDataset::xforms).def_readonly("xforms_end", &NerfDataset::xforms_end).def_readonly("from_mitsuba", &NerfDataset::from_mitsuba)
 		.def("image", [](const NerfDataset& d, size_t i) {
 			if (i >= d.n_images) throw std::runtime_error{"image index out of range"};
@@ -152,7 +154,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("accumulate_error_map", &NerfTraining::accumulate_error_map)
 		.def_readwrite("n_images_for_training", &NerfTraining::n_images_for_training) // python_api.cu:783
 		.def_property("loss_type", [](const NerfTraining& t) { return (ELossType)(t.loss_type < 0 ? 0 : t.loss_type); }, [](NerfTraining& t, ELossType v) { t.loss_type = (int)v; }) // :785 (unset: the config's)
-		.def_property_readonly("transforms", [](const NerfTraining& t) { return py::cast(t.dataset).attr("transforms"); }) // :798 (no extrinsics optimiser here: the dataset's)
+		.def_property_readonly("transforms", [](const NerfTraining& t) { return dataset_transforms(t.dataset); }) // :798 (no extrinsics optimiser here: the dataset's)
 		.def("set_camera_intrinsics", [](NerfTraining& t, int i, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3, float k4, bool fisheye) {
 				t.owner->set_camera_intrinsics(i, fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, fisheye); },
 			py::arg("frame_idx"), py::arg("fx") = 0.f, py::arg("fy") = 0.f, py::arg("cx") = -0.5f, py::arg("cy") = -0.5f, py::arg("k1") = 0.f, py::arg("k2") = 0.f, py::arg("p1") = 0.f,
