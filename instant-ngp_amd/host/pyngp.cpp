@@ -255,6 +255,15 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("render", [](Testbed& t, int w, int h, int spp, bool linear, float, float, float, float) { return render_to_numpy(t, w, h, spp, linear); },
 			py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
 			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
+		.def("render_with_depth", [](Testbed& t, int w, int h, int spp, bool linear, float, float, float, float) { // python_api.cu:520-532: (rgba [h, w, 4], depth [h, w])
+				std::vector<float> px, depth;
+				{ py::gil_scoped_release release; px = t.render(w, h, spp, linear, &depth); }
+				py::array_t<float> a({h, w, 4}), d({h, w});
+				std::memcpy(a.mutable_data(), px.data(), px.size() * sizeof(float));
+				if (depth.size() == (size_t)w * h) std::memcpy(d.mutable_data(), depth.data(), depth.size() * sizeof(float)); else std::fill(d.mutable_data(), d.mutable_data() + (size_t)w * h, 0.f);
+				return py::make_tuple(a, d); },
+			py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
+			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
 		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error{"init_window: GUI is out of scope of this build (headless MI355X path)"}; },
 			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
 		.def("init_vr", [](Testbed&) { throw std::runtime_error{"init_vr: VR is out of scope of this build"}; })

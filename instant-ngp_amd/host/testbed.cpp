@@ -1051,7 +1051,7 @@ std::array<float, 2> BoundingBox::ray_intersect(const std::array<float, 3>& pos,
 	return {tmin, tmax};
 }
 
-std::vector<float> Testbed::render(int width, int height, int spp, bool linear) {
+std::vector<float> Testbed::render(int width, int height, int spp, bool linear, std::vector<float>* depth_out) {
 	std::vector<float> out((size_t)width * height * 4, 0.f);
 	const float bg[4] = {srgb_to_lin(background_color[0]), srgb_to_lin(background_color[1]), srgb_to_lin(background_color[2]), background_color[3]};
 	if (render_ground_truth) {
@@ -1074,12 +1074,13 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 		ensure_trainer();
 		push_options();
 		const size_t n = (size_t)width * height * 4;
-		if (2 * n > m_frame_dev_floats) { // [frame of one spp | accumulated frame]
+		if (2 * n + n / 4 > m_frame_dev_floats) { // [frame of one spp | accumulated frame | depth of the last spp]
 			if (m_frame_dev) HIP_CHECK(hipFree(m_frame_dev));
-			HIP_CHECK(hipMalloc((void**)&m_frame_dev, 2 * n * sizeof(float)));
-			m_frame_dev_floats = 2 * n;
+			HIP_CHECK(hipMalloc((void**)&m_frame_dev, (2 * n + n / 4) * sizeof(float)));
+			m_frame_dev_floats = 2 * n + n / 4;
 		}
 		float* accum = m_frame_dev + n;
+		float* depth_dev = depth_out ? m_frame_dev + 2 * n : nullptr;
 		HIP_CHECK(hipMemsetAsync(accum, 0, n * sizeof(float), nullptr));
 		ngp_render_params rp; memset(&rp, 0, sizeof(rp));
 		rp.resolution[0] = width; rp.resolution[1] = height;
@@ -1100,11 +1101,12 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear) 
 		}
 		for (int s = 0; s < std::max(spp, 1); ++s) { // accumulate + tonemap stay on the device (render_buffer.cu:228-260, 511-560): one read-back per frame
 			rp.spp_index = (uint32_t)s;
-			NGP_CHECK(ngp_nerf_render(m_nerf, nullptr, &rp, m_frame_dev, nullptr));
+			NGP_CHECK(ngp_nerf_render(m_nerf, nullptr, &rp, m_frame_dev, depth_dev));
 			NGP_CHECK(ngp_render_accumulate(nullptr, m_frame_dev, accum, n, (uint32_t)s));
 		}
 		NGP_CHECK(ngp_render_tonemap_curve(nullptr, accum, (uint64_t)width * height, exposure, bg, 0, (int)tonemap_curve));
 		HIP_CHECK(hipMemcpy(out.data(), accum, n * sizeof(float), hipMemcpyDeviceToHost));
+		if (depth_out) { depth_out->resize(n / 4); HIP_CHECK(hipMemcpy(depth_out->data(), depth_dev, (n / 4) * sizeof(float), hipMemcpyDeviceToHost)); } // render_to_cpu's second array (python_api.cu:231-236): the depth buffer as the last sample left it
 	}
 	if (!linear) for (size_t i = 0; i < (size_t)width * height; ++i) for (int k = 0; k < 3; ++k) out[i * 4 + k] = lin_to_srgb(out[i * 4 + k]);
 	return out;

@@ -175,7 +175,7 @@ public:
 	void training_options_changed();                                // a member of nerf / nerf.training was written from Python: push it to the trainer before the next step
 	void set_nerf_camera_matrix(const std::array<float, 12>& m_row_major_3x4);
 	// render_to_cpu (python_api.cu:145-236): premultiplied RGBA float [h][w][4]
-	std::vector<float> render(int width, int height, int spp, bool linear);
+	std::vector<float> render(int width, int height, int spp, bool linear, std::vector<float>* depth_out = nullptr); // depth_out: render_with_depth (python_api.cu:520-532)
 	ngp_nerf_stats stats();
 	// image / SDF primitives (testbed_image.cu, testbed_sdf.cu): same entry points (load_training_data, train / frame, loss), plus
 	float compute_image_mse(bool quantize_to_byte = false);                    // testbed_image.cu:490
