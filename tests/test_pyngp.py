@@ -209,14 +209,14 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     assert t3.training_step == 400 and np.abs(a - c).max() < 2e-3
     # render_with_depth (python_api.cu:520-532): the same frame plus the depth buffer; and a crop box written from Python empties what lies outside
     rgba, depth = t.render_with_depth(64, 64, 1, True)
-    assert rgba.shape == (64, 64, 4) and depth.shape == (64, 64) and np.abs(rgba - a).max() < 1e-6
+    assert rgba.shape == (64, 64, 4) and depth.shape == (64, 64) and np.abs(rgba - a).max() < 1e-4
     hit = rgba[..., 3] > 0.5
     assert hit.mean() > 0.02 and np.isfinite(depth[hit]).all() and (depth[hit] > 0.05).all() and (depth[hit] < 4.0).all()
     full = t.render_aabb
     t.render_aabb = ngp.BoundingBox([0.0, 0.0, 0.0], [1e-3, 1e-3, 1e-3])
     assert t.render(64, 64, 1, True)[..., 3].max() < 1e-3
     t.render_aabb = full
-    assert np.abs(t.render(64, 64, 1, True) - a).max() < 1e-6
+    assert np.abs(t.render(64, 64, 1, True) - a).max() < 1e-4
 
 
 @pytest.mark.gpu
