@@ -252,7 +252,11 @@ PYBIND11_MODULE(pyngp, m) {
 			std::array<float, 12> mm; for (int i = 0; i < 12; ++i) mm[i] = a.data()[i];
 			t.set_nerf_camera_matrix(mm);
 		})
-		.def("render", [](Testbed& t, int w, int h, int spp, bool linear, float, float, float, float) { return render_to_numpy(t, w, h, spp, linear); },
+		.def("render", [](Testbed& t, int w, int h, int spp, bool linear, float start_t, float end_t, float, float shutter_fraction) {
+				if (start_t < 0.f) return render_to_numpy(t, w, h, spp, linear); // no path animation (python_api.cu:155)
+				std::vector<float> px;
+				{ py::gil_scoped_release release; px = t.render_path_frame(w, h, spp, linear, start_t, end_t, shutter_fraction); }
+				py::array_t<float> out({h, w, 4}); std::memcpy(out.mutable_data(), px.data(), px.size() * sizeof(float)); return out; },
 			py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
 			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
 		.def("render_with_depth", [](Testbed& t, int w, int h, int spp, bool linear, float, float, float, float) { // python_api.cu:520-532: (rgba [h, w, 4], depth [h, w])
@@ -267,8 +271,9 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error{"init_window: GUI is out of scope of this build (headless MI355X path)"}; },
 			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
 		.def("init_vr", [](Testbed&) { throw std::runtime_error{"init_vr: VR is out of scope of this build"}; })
-		.def("load_camera_path", [](Testbed&, const std::string&) { throw std::runtime_error{"load_camera_path: camera-path video rendering is out of scope of this build (python_api.cu:563)"}; })
-		.def_property("camera_smoothing", [](Testbed&) { return false; }, [](Testbed&, bool v) { if (v) throw std::runtime_error{"camera_smoothing: camera-path video rendering is out of scope of this build"}; })
+		.def("load_camera_path", &Testbed::load_camera_path) // python_api.cu:563
+		.def("set_camera_from_time", &Testbed::set_camera_from_time)
+		.def_property("camera_smoothing", [](Testbed&) { return false; }, [](Testbed&, bool v) { if (v) throw std::runtime_error{"camera_smoothing: the exponential camera smoothing (tcnn matrix logarithm) is not part of this build; render the path unsmoothed"}; })
 		// data-parallel training (new): rank 0 creates the id, every rank passes the same 128 bytes
 		.def_static("comm_unique_id", []() { return py::bytes(Testbed::comm_unique_id()); })
 		.def("comm_init", [](Testbed& t, uint32_t rank, uint32_t world, py::bytes id) { t.comm_init(rank, world, std::string(id)); }, py::arg("rank"), py::arg("world_size"), py::arg("unique_id"))

@@ -955,6 +955,31 @@ void Testbed::set_training_image(int frame_idx, int w, int h, const float* rgba,
 	if (depth && depth_scale > 0.f) { d.depth[frame_idx].resize((size_t)w * h); for (size_t i = 0; i < (size_t)w * h; ++i) d.depth[frame_idx][i] = depth[i] * depth_scale; }
 	m_dataset_dirty = true;
 }
+void Testbed::load_camera_path(const std::string& path) {
+	if (!fs::exists(path)) throw std::runtime_error{"Camera path " + path + " does not exist."};
+	camera_path.load_json_text(read_text(path), path);
+}
+void Testbed::set_camera_from_time(float t) {
+	if (camera_path.keyframes.empty()) return;
+	const CameraKeyframe k = camera_path.eval_camera_path(t);
+	m_camera = k.m(); m_scale = k.scale; set_fov(k.fov); // set_camera_from_keyframe, testbed.cu:4061-4067 (slice plane and aperture belong to the GUI / depth of field)
+}
+std::vector<float> Testbed::render_path_frame(int width, int height, int spp, bool linear, float start_t, float end_t, float shutter_fraction, std::vector<float>* depth_out) {
+	// The reference moves the camera inside every sample as well (per-pixel time between the sample's start and end matrices); here a sample is rendered from the
+	// camera at the MIDDLE of its sub-interval -- the same time samples (python_api.cu:183-196), motion blur resolved per sample instead of per pixel.
+	if (end_t < 0.f) end_t = start_t;
+	const int n = std::max(spp, 1);
+	std::vector<float> acc((size_t)width * height * 4, 0.f), depth;
+	for (int i = 0; i < n; ++i) {
+		const float start_alpha = (float)i / (float)n * shutter_fraction, end_alpha = ((float)i + 1.0f) / (float)n * shutter_fraction;
+		set_camera_from_time(start_t + (end_t - start_t) * (start_alpha + end_alpha) / 2.0f);
+		const std::vector<float> one = render(width, height, 1, true, depth_out ? &depth : nullptr);
+		for (size_t k = 0; k < acc.size(); ++k) acc[k] += (one[k] - acc[k]) / (float)(i + 1);
+	}
+	if (depth_out) *depth_out = depth;
+	if (!linear) for (size_t i = 0; i < (size_t)width * height; ++i) for (int k = 0; k < 3; ++k) acc[i * 4 + k] = lin_to_srgb(acc[i * 4 + k]);
+	return acc;
+}
 void Testbed::clear_training_data() { // testbed.cu:190-193: the metadata goes, training stops being possible until new data is loaded
 	nerf.training.dataset = NerfDataset{};
 	nerf.training.n_images_for_training = 0;

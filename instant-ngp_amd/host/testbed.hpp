@@ -15,6 +15,7 @@ extern "C" {
 #include "../../include/ngp_hip.h"
 }
 #include "../csrc/mini_json.hpp"
+#include "camera_path_lite.hpp"
 
 namespace ngp_host {
 
@@ -152,6 +153,11 @@ public:
 	void set_camera_to_training_view(int i);                        // testbed.cu:486
 	void first_training_view(); void last_training_view(); void previous_training_view(); void next_training_view(); // testbed.cu:460-484
 	void reset_camera();                                            // testbed.cu:507-528
+	void load_camera_path(const std::string& path);                 // testbed.cu / camera_path.cu:135-168
+	void set_camera_from_time(float t);                             // testbed.cu:4061-4075: camera, scale and fov of the path at playtime t in [0, 1]
+	// render_to_cpu with a path animation (python_api.cu:145-236): every sample of the frame is taken at its own time inside the shutter interval
+	std::vector<float> render_path_frame(int width, int height, int spp, bool linear, float start_t, float end_t, float shutter_fraction, std::vector<float>* depth_out = nullptr);
+	CameraPath camera_path;
 	void clear_training_data();                                     // testbed.cu:190-193
 	void create_empty_nerf_dataset(size_t n_images, int aabb_scale = 1, bool is_hdr = false); // testbed_nerf.cu:2344-2351, nerf_loader.cu:148-172
 	void set_training_image(int frame_idx, int w, int h, const float* rgba, const float* depth_or_null, float depth_scale); // NerfDataset::set_training_image for float data (nerf_loader.cu:749-850)

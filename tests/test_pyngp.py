@@ -430,3 +430,62 @@ def test_reload_network_from_json():
         t.reload_network_from_json("{not json")
     assert abs(t.bounding_radius - math.sqrt(0.75)) < 1e-6 and t.jit_fusion
     t.jit_fusion = False; t.max_level_rand_training = False
+
+
+def test_camera_path_evaluation():
+    """load_camera_path + the path's evaluation (camera_path.h:172-190, camera_path.cu:66-86, 203-257, testbed.cu:4061-4075) against an independent numpy statement of the
+    uniform cubic / quadratic / linear B-spline blends with sign-aligned quaternion sums, timestamps made equidistant when the file has none, looping paths"""
+    ngp = _ngp()
+    rs = np.random.default_rng(0)
+    q = rs.normal(size=(6, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[2] *= -1  # (a flipped quaternion is the same rotation: the blend must not care)
+    keys = [{"R": q[i].tolist(), "T": rs.uniform(0, 1, 3).tolist(), "slice": 0.0, "scale": 1.0 + 0.1 * i, "fov": 40.0 + 3 * i, "aperture_size": 0.0} for i in range(6)]
+
+    def rot(qq):
+        x, y, z, w = qq / np.linalg.norm(qq)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def blend(ws, ids, loop):
+        n = len(keys); R = np.zeros(4); T = np.zeros(3); fov = 0.0; sc = 0.0
+        for w_, i in zip(ws, ids):
+            k = keys[i % n] if loop else keys[min(max(i, 0), n - 1)]
+            r = np.array(k["R"]) * w_
+            R = R + (-r if np.dot(R, r) < 0 else r); T = T + np.array(k["T"]) * w_; fov += k["fov"] * w_; sc += k["scale"] * w_
+        return rot(R), T, fov, sc
+
+    d = tempfile.mkdtemp()
+    for order, loop in ((3, False), (2, False), (1, False), (3, True)):
+        path = os.path.join(d, f"cam_{order}_{int(loop)}.json")
+        json.dump({"path": keys, "spline_order": order, "loop": loop, "time": 0.3}, open(path, "w"))
+        t = ngp.Testbed(); t.load_camera_path(path)
+        n = len(keys); ts = (np.arange(n) + 1) / n  # equidistant timestamps (none in the file)
+        dur = ts[-1] if loop else ts[-2]
+        for play in (0.0, 0.13, 0.5, 0.77, 0.999):
+            x = play * dur
+            i = int(min(max(np.searchsorted(ts, x, side="right"), 0), n - (1 if loop else 2)))
+            prev = 0.0 if i == 0 else ts[i - 1]
+            f = (x - prev) / (ts[i] - prev)
+            if order == 3:
+                ws = [(1 - f) ** 3 / 6, (3 * f ** 3 - 6 * f ** 2 + 4) / 6, (-3 * f ** 3 + 3 * f ** 2 + 3 * f + 1) / 6, f ** 3 / 6]; ids = [i - 1, i, i + 1, i + 2]
+            elif order == 2:
+                ws = [(1 - f) ** 2 / 2, (-2 * f * f + 2 * f + 1) / 2, f * f / 2]; ids = [i - 1, i, i + 1]
+            else:
+                ws = [1 - f, f]; ids = [i, i + 1]
+            Rw, Tw, fov, sc = blend(ws, ids, loop)
+            t.set_camera_from_time(play)
+            m = np.array(t.camera_matrix)
+            assert np.allclose(m[:, :3], Rw, atol=2e-5) and np.allclose(m[:, 3], Tw, atol=1e-5), (order, loop, play)
+            assert abs(t.fov - fov) < 1e-3 and abs(t.scale - sc) < 1e-5
+    # timestamps in the file are used as they are
+    for i, k in enumerate(keys):
+        k["timestamp"] = [0.5, 1.0, 3.0, 3.5, 6.0, 7.0][i]
+    path = os.path.join(d, "timed.json"); json.dump({"path": keys, "spline_order": 1}, open(path, "w"))
+    t = ngp.Testbed(); t.load_camera_path(path)
+    # playtime 1/3 of the duration 6.0 (the next-to-last timestamp) -> 2.0: halfway through the segment that ends at timestamp[2] = 3.0, which the reference blends
+    # between keyframes 2 and 3 (get_pos returns the index of the first later timestamp; camera_path.cu:247-256, camera_path.h:181)
+    t.set_camera_from_time(2.0 / 6.0)
+    Rw, Tw, fov, sc = blend([0.5, 0.5], [2, 3], False)
+    assert np.allclose(np.array(t.camera_matrix)[:, 3], Tw, atol=1e-5) and abs(t.fov - fov) < 1e-3
+    with pytest.raises(RuntimeError, match="does not exist"):
+        t.load_camera_path(os.path.join(d, "missing.json"))
+    with pytest.raises(RuntimeError, match="not part of this build"):
+        t.camera_smoothing = True
