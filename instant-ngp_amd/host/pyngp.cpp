@@ -105,11 +105,19 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("ray_intersect", &BoundingBox::ray_intersect).def("relative_pos", &BoundingBox::relative_pos).def("signed_distance", &BoundingBox::signed_distance)
 		.def_readwrite("min", &BoundingBox::min).def_readwrite("max", &BoundingBox::max);
 
+	py::enum_<ELensMode>(m, "LensMode").value("Perspective", ELensMode::Perspective).value("OpenCV", ELensMode::OpenCV).value("FTheta", ELensMode::FTheta).value("LatLong", ELensMode::LatLong)
+		.value("OpenCVFisheye", ELensMode::OpenCVFisheye).value("Equirectangular", ELensMode::Equirectangular).value("Orthographic", ELensMode::Orthographic).export_values(); // python_api.cu:391-399
+	py::class_<Lens>(m, "Lens").def(py::init<>()) // python_api.cu:429-433; a VALUE here: assign the whole object back (md.lens = l) to change a lens
+		.def_property("mode", [](const Lens& l) { return (ELensMode)l.mode; }, [](Lens& l, ELensMode v) { l.mode = (int)v; })
+		.def_readwrite("params", &Lens::params);
 	py::class_<Testbed> testbed(m, "Testbed");
 	py::class_<ImageMetadata>(testbed, "TrainingImageMetadata")
 		.def_readonly("resolution", &ImageMetadata::resolution).def_readonly("focal_length", &ImageMetadata::focal_length)
 		.def_readonly("principal_point", &ImageMetadata::principal_point).def_readonly("lens_mode", &ImageMetadata::lens_mode)
-		.def_readonly("lens_params", &ImageMetadata::lens_params).def_readonly("rolling_shutter", &ImageMetadata::rolling_shutter);
+		.def_readonly("lens_params", &ImageMetadata::lens_params).def_readonly("rolling_shutter", &ImageMetadata::rolling_shutter)
+		.def_property_readonly("lens", [](const ImageMetadata& m) { Lens l; l.mode = m.lens_mode; l.params = m.lens_params; return l; })               // python_api.cu:759 (write through training.set_camera_intrinsics)
+		.def_property_readonly("camera_distortion", [](const ImageMetadata& m) { Lens l; l.mode = m.lens_mode; l.params = m.lens_params; return l; }) // :758 legacy name
+		.def_property_readonly("light_dir", [](const ImageMetadata&) { return std::array<float, 3>{0.f, 0.f, 0.f}; });                                    // :764 (unused by the NeRF path)
 	py::class_<NerfDataset>(testbed, "NerfDataset")
 		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
 		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
@@ -235,6 +243,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("n_params", &Testbed::n_params).def("n_encoding_params", &Testbed::n_encoding_params)                            // :561-562
 		.def_readwrite("aabb", &Testbed::aabb).def_readwrite("raw_aabb", &Testbed::raw_aabb).def_readwrite("render_aabb", &Testbed::render_aabb) // :641-645
 		.def_readwrite("render_aabb_to_local", &Testbed::render_aabb_to_local)
+		.def_property("render_lens", &Testbed::render_lens, &Testbed::set_render_lens) // python_api.cu: m_render_lens
 		.def_readwrite("visualize_unit_cube", &Testbed::visualize_unit_cube)
 		.def_readwrite("up_dir", &Testbed::up_dir).def_readwrite("zoom", &Testbed::zoom).def_readwrite("render_near_distance", &Testbed::render_near_distance)
 		.def_readwrite("relative_focal_length", &Testbed::relative_focal_length).def_readwrite("screen_center", &Testbed::screen_center) // :649-651

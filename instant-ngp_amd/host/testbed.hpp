@@ -53,6 +53,9 @@ struct BoundingBox {                        // bounding_box.cuh:43-252 as seen f
 	std::vector<std::array<float, 3>> get_vertices() const { std::vector<std::array<float, 3>> v(8); for (int i = 0; i < 8; ++i) v[i] = {(i & 1) ? max[0] : min[0], (i & 2) ? max[1] : min[1], (i & 4) ? max[2] : min[2]}; return v; } // :237-246
 };
 
+struct Lens { int mode = NGP_LENS_PERSPECTIVE; std::array<float, 7> params{}; };   // common.h Lens {ELensMode mode; float params[7]} as seen from Python (python_api.cu:429-433)
+enum class ELensMode : int { Perspective = 0, OpenCV = 1, FTheta = 2, LatLong = 3, OpenCVFisheye = 4, Equirectangular = 5, Orthographic = 6 }; // = NGP_LENS_*
+
 struct ImageMetadata {                      // TrainingImageMetadata as seen from Python (python_api.cu:766-779)
 	std::array<int, 2> resolution{0, 0};
 	std::array<float, 2> focal_length{1000.f, 1000.f};
@@ -214,6 +217,8 @@ public:
 	std::array<float, 3> up_dir{0.f, 1.f, 0.f};                      // testbed.h:672
 	bool visualize_unit_cube = false;                                // GUI overlay switch: kept so that scripts that set it run
 	float zoom = 1.f;                                                // testbed.h:647 (2-D zoom of the GUI view; kept for scripts)
+	Lens render_lens() const { Lens l; l.mode = m_render_lens_mode; l.params = m_render_lens_params; return l; }              // testbed.h m_render_lens
+	void set_render_lens(const Lens& l) { m_render_lens_mode = l.mode; m_render_lens_params = l.params; }
 	float render_near_distance = 0.f;                                // testbed.h (m_render_near_distance)
 	std::array<float, 2> relative_focal_length{1.f, 1.f};            // testbed.h: focal length / resolution[fov_axis]
 	std::array<float, 2> screen_center{0.5f, 0.5f};

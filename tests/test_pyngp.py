@@ -312,6 +312,9 @@ def test_camera_and_training_view_api_like_the_reference(scene_dir):
     t.nerf.training.set_camera_intrinsics(2, fx=90.0, fy=80.0, k1=0.1, k3=0.2, is_fisheye=True)
     assert list(ds.metadata[2].focal_length) == [90.0, 80.0] and ds.metadata[2].lens_mode == 4 and np.allclose(ds.metadata[2].lens_params[:4], [0.1, 0, 0.2, 0]) and np.allclose(ds.metadata[2].principal_point, [0.5, 0.5])
     t.nerf.training.set_camera_intrinsics(99, fx=1.0)  # out of range: ignored, like the reference
+    assert ds.metadata[2].lens.mode == ngp.LensMode.OpenCVFisheye and np.allclose(list(ds.metadata[2].lens.params)[:4], [0.1, 0, 0.2, 0]) and ds.metadata[2].camera_distortion.mode == ngp.LensMode.OpenCVFisheye
+    t.set_camera_to_training_view(2); assert t.render_lens.mode == ngp.LensMode.OpenCVFisheye and t.render_with_lens_distortion
+    l = ngp.Lens(); l.mode = ngp.LensMode.Perspective; t.render_lens = l; assert t.render_lens.mode == ngp.LensMode.Perspective and list(ds.metadata[0].light_dir) == [0, 0, 0]
     # overrides and switches
     t.nerf.training.n_images_for_training = 5; assert t.nerf.training.n_images_for_training == 5
     t.nerf.training.loss_type = ngp.LossType.L1; assert t.nerf.training.loss_type == ngp.LossType.L1
