@@ -412,3 +412,33 @@ def test_tonemap_and_accumulate_against_render_buffer_cu():
         assert np.array_equal(m.view(np.uint32), want.astype(np.float32).view(np.uint32))
         incremental = mean + (frame - mean) * (np.float32(1.0) / np.float32(count + 1))
         assert np.allclose(incremental, m, rtol=3e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("image_type", [A.IMAGE_HALF, A.IMAGE_FLOAT])
+def test_k1_k3_with_half_and_float_images(ref, ora, image_type):
+    """the same kernels reading training images of EImageDataType::Half (what the loader produces for HDR and sharpened data) and ::Float (training.set_image): linear
+    premultiplied RGBA, negative red = masked pixel that K1 must skip (read_rgba, common_device.cuh:846-872)"""
+    imgs, xforms, meta = make_small_dataset(4, 40)
+    rs = np.random.default_rng(8)
+    conv = []
+    for im in imgs:
+        px = im.astype(np.float32) / 255.0
+        a = px[..., 3:4]
+        lin = np.where(px[..., :3] <= 0.04045, px[..., :3] / 12.92, ((px[..., :3] + 0.055) / 1.055) ** 2.4) * a
+        f = np.concatenate([lin, a], 2).astype(np.float32)
+        f[5:9, 7:15] = -1.0  # a masked block
+        conv.append(np.ascontiguousarray(f.astype(np.float16) if image_type == A.IMAGE_HALF else f))
+    M, X = host_meta(imgs, xforms, meta)
+    for i, c in enumerate(conv):
+        M[i].pixels = c.ctypes.data; M[i].image_data_type = image_type
+    grid, bf, mean = _occupancy(ora, "ora_", M, X, len(imgs))
+    sc = dict(imgs=conv, M=M, X=X, grid=grid, bf=bf, mean=mean, n_img=len(imgs))
+    n_rays = 1500
+    a = _k1(ora, "ora_", ora, sc, n_rays, 1 << 19, 0, n_rays, 0, 0.0); b = _k1(ref, "ref_", ora, sc, n_rays, 1 << 19, 0, n_rays, 0, 0.0)
+    n, used = _same_k1(a, b)
+    assert n < n_rays - 5  # rays that drew a masked pixel are gone
+    net = np.zeros((1 << 19, 4), np.float16); total = a["numsteps_counter"].value
+    net[:total, :3] = rs.normal(0, 1.5, (total, 3)); net[:total, 3] = rs.normal(-1.0, 2.5, total)
+    ka = _k3(ora, "ora_", ora, sc, a, n_rays, 1 << 19, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_EXPONENTIAL, A.ACT_EXPONENTIAL, 0, 0.1)
+    kb = _k3(ref, "ref_", ora, sc, a, n_rays, 1 << 19, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_EXPONENTIAL, A.ACT_EXPONENTIAL, 0, 0.1)
+    _same_k3(ka, kb, n)
