@@ -18,7 +18,7 @@ constexpr float SDF_MAX_DIST = 10.0f; // triangle_bvh.cu:42
 
 static __host__ __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 static __host__ __device__ __forceinline__ float len2(f3 a) { return dot3(a, a); }
-static __host__ __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); } // tcnn sign()
+static __host__ __device__ __forceinline__ float sgnf(float x) { return copysignf(1.0f, x); } // tcnn's sign(): copysign(1, x), never 0
 static __host__ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
 // Triangle::distance_sq, triangle.cuh:108-129 (iq's triangle distance)

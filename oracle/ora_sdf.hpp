@@ -14,7 +14,7 @@ namespace ora {
 struct Tri { float a[3], b[3], c[3]; };
 inline vec3 cross3(vec3 a, vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float len2(vec3 a) { return dot(a, a); }
-inline float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+inline float sgnf(float x) { return std::copysign(1.0f, x); } // tcnn's sign(): copysign(1, x), never 0 [vec.h, from memory]
 inline float clamp01(float x) { return std::fmin(std::fmax(x, 0.0f), 1.0f); }
 
 inline float tri_distance_sq(const Tri& t, vec3 pos) {

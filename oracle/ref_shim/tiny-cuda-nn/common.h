@@ -101,7 +101,7 @@ template <uint32_t N> tvec<uint32_t, N> operator>>(const tvec<uint32_t, N>& a, u
 
 #define NGP_SHIM_MAP1(name, expr) template <typename T, uint32_t N> tvec<T, N> name(const tvec<T, N>& a) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) { const T v = a[i]; r[i] = (T)(expr); } return r; }
 NGP_SHIM_MAP1(abs, std::abs(v)) NGP_SHIM_MAP1(floor, std::floor(v)) NGP_SHIM_MAP1(ceil, std::ceil(v)) NGP_SHIM_MAP1(sqrt, std::sqrt(v)) NGP_SHIM_MAP1(exp, std::exp(v)) NGP_SHIM_MAP1(log, std::log(v))
-NGP_SHIM_MAP1(sin, std::sin(v)) NGP_SHIM_MAP1(cos, std::cos(v)) NGP_SHIM_MAP1(sign, (v > T(0)) - (v < T(0))) NGP_SHIM_MAP1(isfinite, std::isfinite(v))
+NGP_SHIM_MAP1(sin, std::sin(v)) NGP_SHIM_MAP1(cos, std::cos(v)) NGP_SHIM_MAP1(sign, std::copysign(T(1), v)) NGP_SHIM_MAP1(isfinite, std::isfinite(v))
 #undef NGP_SHIM_MAP1
 template <typename T, uint32_t N> tvec<T, N> min(const tvec<T, N>& a, const tvec<T, N>& b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::min(a[i], b[i]); return r; }
 template <typename T, uint32_t N> tvec<T, N> max(const tvec<T, N>& a, const tvec<T, N>& b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::max(a[i], b[i]); return r; }
@@ -138,7 +138,9 @@ template <typename T> tvec<T, 3> cross(const tvec<T, 3>& a, const tvec<T, 3>& b)
 template <typename T, uint32_t N> T mean(const tvec<T, N>& a) { T r = a[0]; for (uint32_t i = 1; i < N; ++i) r += a[i]; return r / (T)N; }
 template <typename T, uint32_t N> T sum(const tvec<T, N>& a) { T r = a[0]; for (uint32_t i = 1; i < N; ++i) r += a[i]; return r; }
 template <typename T, uint32_t N> T product(const tvec<T, N>& a) { T r = a[0]; for (uint32_t i = 1; i < N; ++i) r *= a[i]; return r; }
-inline float sign(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+// sign: tcnn's is copysign(1, x) [vec.h, from memory] -- never 0, unlike GLSL's; it matters for direction components that are exactly 0 (axis-parallel rays in
+// distance_to_next_voxel: with a three-valued sign the step to the next voxel collapses to 0 for half of them).  The oracle and the HIP code use the same form.
+inline float sign(float v) { return std::copysign(1.0f, v); }
 inline float logistic(float x) { return 1.0f / (1.0f + std::exp(-x)); }
 inline float logit(float x) { return -std::log(1.0f / (std::fmin(std::fmax(x, 1e-9f), 1.0f - 1e-9f)) - 1.0f); }
 inline float fract(float x) { return x - std::floor(x); }

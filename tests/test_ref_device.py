@@ -132,6 +132,12 @@ def test_occupancy_indexing_and_skipping(ref, o):
         assert _bits(o.ora_distance_to_next_voxel(_fp(p), _fp(d), F(res))) == _bits(ref.ref_distance_to_next_voxel(_fp(p), _fp(d), F(res)))
         t, c = float(rs.uniform(0, 3)), CONES[i % 4]
         assert _bits(o.ora_advance_to_next_voxel(F(t), F(c), _fp(p), _fp(d), mip)) == _bits(ref.ref_advance_to_next_voxel(F(t), F(c), _fp(p), _fp(d), mip)), (i, t, c)
+    # axis-parallel rays: a direction component that is exactly 0 goes through sign(0), which is +1 in tcnn (copysign) -- the voxel step stays finite and positive
+    for i in range(8, 608):  # (the first eight positions sit on voxel faces, where a zero distance is the right answer)
+        p = pos[i]; d = rs.normal(size=3).astype(np.float32); d[i % 3] = 0.0 if i % 2 else -0.0; d /= np.linalg.norm(d)
+        a, b = o.ora_distance_to_next_voxel(_fp(p), _fp(d), F(128.0)), ref.ref_distance_to_next_voxel(_fp(p), _fp(d), F(128.0))
+        assert _bits(a) == _bits(b) and a > 0 and np.isfinite(a), (i, a, b)
+        assert _bits(o.ora_advance_to_next_voxel(F(0.7), F(CONES[i % 4]), _fp(p), _fp(d), 0)) == _bits(ref.ref_advance_to_next_voxel(F(0.7), F(CONES[i % 4]), _fp(p), _fp(d), 0))
     for scale, max_mip in ((1, 0), (4, 2), (16, 4)):
         box = A.scene_aabb(scale)
         for i in range(400):
