@@ -4,3 +4,7 @@
 #include <neural-graphics-primitives/common.h>
 #include <tiny-cuda-nn/gpu_memory.h>
 #include <tinylogger/tinylogger.h>
+#include <filesystem/path.h>
+#include <string>
+namespace fmt { template <typename... A> inline std::string format(const char* f, const A&...) { return f; } } // status / error strings only
+namespace ngp { namespace fs = filesystem; }

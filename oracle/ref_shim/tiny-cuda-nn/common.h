@@ -174,7 +174,40 @@ template <typename T, uint32_t C, uint32_t R> bool operator!=(const tmat<T, C, R
 using mat2x3 = tmat<float, 2, 3>; using mat2 = tmat<float, 2, 2>; using mat3 = tmat<float, 3, 3>; using mat4 = tmat<float, 4, 4>; using mat4x3 = tmat<float, 4, 3>; using mat3x4 = tmat<float, 3, 4>;
 template <typename T> tvec<T, 3> row(const tmat<T, 3, 3>& a, uint32_t r) { return {a.m[0][r], a.m[1][r], a.m[2][r]}; }
 
-struct quat { float x = 0, y = 0, z = 0, w = 1; };
+// quaternion {x, y, z, w} with the handful of operations camera_path.h / .cu use (GLM-style: to_mat3 = mat3_cast, quat(mat3) = quat_cast by the largest diagonal term)
+struct quat {
+	float x = 0, y = 0, z = 0, w = 1;
+	quat() {}
+	quat(float x_, float y_, float z_, float w_) : x{x_}, y{y_}, z{z_}, w{w_} {}
+	explicit quat(const tmat<float, 3, 3>& m) {
+		const float fx = m[0][0] - m[1][1] - m[2][2], fy = m[1][1] - m[0][0] - m[2][2], fz = m[2][2] - m[0][0] - m[1][1], fw = m[0][0] + m[1][1] + m[2][2];
+		int big = 0; float fb = fw;
+		if (fx > fb) { fb = fx; big = 1; }
+		if (fy > fb) { fb = fy; big = 2; }
+		if (fz > fb) { fb = fz; big = 3; }
+		const float bv = std::sqrt(fb + 1.0f) * 0.5f, mult = 0.25f / bv;
+		switch (big) {
+			case 0: w = bv; x = (m[1][2] - m[2][1]) * mult; y = (m[2][0] - m[0][2]) * mult; z = (m[0][1] - m[1][0]) * mult; break;
+			case 1: w = (m[1][2] - m[2][1]) * mult; x = bv; y = (m[0][1] + m[1][0]) * mult; z = (m[2][0] + m[0][2]) * mult; break;
+			case 2: w = (m[2][0] - m[0][2]) * mult; x = (m[0][1] + m[1][0]) * mult; y = bv; z = (m[1][2] + m[2][1]) * mult; break;
+			default: w = (m[0][1] - m[1][0]) * mult; x = (m[2][0] + m[0][2]) * mult; y = (m[1][2] + m[2][1]) * mult; z = bv; break;
+		}
+	}
+};
+inline quat operator*(const quat& q, float f) { return {q.x * f, q.y * f, q.z * f, q.w * f}; }
+inline quat operator+(const quat& a, const quat& b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline quat operator-(const quat& q) { return {-q.x, -q.y, -q.z, -q.w}; }
+inline float dot(const quat& a, const quat& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+inline quat normalize(const quat& q) { const float l = std::sqrt(dot(q, q)); return {q.x / l, q.y / l, q.z / l, q.w / l}; }
+inline tmat<float, 3, 3> to_mat3(const quat& q) {
+	const float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z, qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+	tmat<float, 3, 3> r;
+	r[0] = tvec<float, 3>(1.0f - 2.0f * (qyy + qzz), 2.0f * (qxy + qwz), 2.0f * (qxz - qwy));
+	r[1] = tvec<float, 3>(2.0f * (qxy - qwz), 1.0f - 2.0f * (qxx + qzz), 2.0f * (qyz + qwx));
+	r[2] = tvec<float, 3>(2.0f * (qxz + qwy), 2.0f * (qyz - qwx), 1.0f - 2.0f * (qxx + qyy));
+	return r;
+}
+inline quat slerp(const quat&, const quat&, float) { std::fprintf(stderr, "oracle/ref_shim: slerp(quat) is tcnn code that is absent from the mount\n"); std::abort(); }
 // 3 x 3 inverse (pos_to_uv's camera-space transform): reciprocal of the determinant times the cofactors, in the glm formulation tcnn's types follow.  tcnn itself is
 // absent from the mount, so the rounding of this function is an ASSUMPTION the oracle shares, not something this shim can pin.
 inline mat3 inverse(const mat3& m) {

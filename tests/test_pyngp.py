@@ -492,3 +492,29 @@ def test_camera_path_evaluation():
         t.load_camera_path(os.path.join(d, "missing.json"))
     with pytest.raises(RuntimeError, match="not part of this build"):
         t.camera_smoothing = True
+
+
+def test_camera_path_against_the_reference_code():
+    """host/camera_path_lite.hpp against camera_path.h / camera_path.cu compiled for the CPU (oracle/_ref/libngpcampath_ref.so): spline orders 0..3, looping paths, timestamps
+    from the file or made equidistant; camera matrix, fov and scale along the path.  (Quaternion arithmetic of the reference side is the shim's: tcnn is absent.)"""
+    import ctypes as C
+    so = os.path.join(ROOT, "oracle", "_ref", "libngpcampath_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libngpcampath_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    ref = C.CDLL(so); ngp = _ngp()
+    rs = np.random.default_rng(3); d = tempfile.mkdtemp()
+    for case in range(24):
+        n = int(rs.integers(1, 9)); order = case % 4; loop = bool((case // 4) % 2) and n > 1; timed = case >= 16
+        q = rs.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        ts = np.cumsum(rs.uniform(0.2, 2.0, n)) if timed else np.zeros(n)
+        keys = [{"R": q[i].tolist(), "T": rs.uniform(-1, 2, 3).tolist(), "slice": 0.0, "scale": float(rs.uniform(0.5, 2)), "fov": float(rs.uniform(20, 90)), "aperture_size": 0.0,
+                 "timestamp": float(ts[i])} for i in range(n)]
+        path = os.path.join(d, f"p{case}.json"); json.dump({"path": keys, "spline_order": order, "loop": loop}, open(path, "w"))
+        t = ngp.Testbed(); t.load_camera_path(path)
+        flat = np.array([k["R"] + k["T"] + [k["slice"], k["scale"], k["fov"], k["aperture_size"], k["timestamp"]] for k in keys], np.float32)
+        for play in (0.0, 0.21, 0.5, 0.83, 1.0):
+            out = np.zeros(14, np.float32)
+            ref.ref_eval_camera_path(flat.ctypes.data_as(C.c_void_p), n, order, int(loop), 1, C.c_float(play), out.ctypes.data_as(C.c_void_p))
+            t.set_camera_from_time(play)
+            assert np.allclose(np.array(t.camera_matrix).reshape(-1), out[:12], atol=2e-6), (case, n, order, loop, timed, play)
+            assert abs(t.fov - out[12]) < 2e-4 and abs(t.scale - out[13]) < 1e-6
