@@ -361,3 +361,19 @@ def test_loader_image_conversions_against_nerf_loader_cu(refk):
     d16 = rs.integers(0, 65536, 500).astype(np.uint16); dst = np.zeros(500, np.float32)
     refk.ref_copy_depth_u16(C.c_uint64(500), _fp(dst), d16.ctypes.data_as(C.c_void_p), F(0.33 * 0.001))
     assert np.array_equal(_bits(dst), _bits(d16.astype(np.float32) * np.float32(0.33 * 0.001)))
+
+
+def test_product_bvh_on_the_host_equals_the_oracle(o, hip_lib):
+    """the same comparison without the reference tree: the product's BVH build + traversal evaluated on the host against the oracle's brute force over the product's triangle
+    order (runs wherever the repository builds)"""
+    rs = np.random.default_rng(21)
+    tris = _torus_mesh(40, 20); n_tris = len(tris); n = 3000
+    pick = tris[rs.integers(0, n_tris, n)]
+    cent = ((pick[:, 0:3] + pick[:, 3:6] + pick[:, 6:9]) / 3).astype(np.float32)
+    pos = np.ascontiguousarray(np.where((np.arange(n) % 2 == 0)[:, None], rs.uniform(0, 1, (n, 3)), cent + rs.logistic(0, 0.02, (n, 3))).astype(np.float32))
+    mine = np.zeros(n, np.float32); ordered = np.zeros_like(tris)
+    assert hip_lib.ngp_host_sdf_signed_distance(_fp(tris), n_tris, _fp(pos), n, _fp(mine), 0, _fp(ordered), None) == 0
+    want = np.zeros(n, np.float32); o.ora_sdf_signed_distance(_fp(ordered), n_tris, _fp(pos), n, None, _fp(want))
+    assert np.array_equal(_bits(np.abs(mine)), _bits(np.abs(want)))
+    off = np.abs(want) > 1e-6
+    assert (np.signbit(mine[off]) != np.signbit(want[off])).mean() <= 0.002 and 0.05 < (want < 0).mean() < 0.7
