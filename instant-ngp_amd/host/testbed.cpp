@@ -734,9 +734,11 @@ void Testbed::load_file(const std::string& path) {
 	if (ext == ".json") {
 		mini_json::Value j; std::string err;
 		if (!mini_json::parse(read_text(path).c_str(), j, err)) throw std::runtime_error{path + ": " + err};
-		if (j.has("frames")) load_training_data(path);         // a NeRF scene (mode_from_scene, common_host.cu:144-160)
-		else if (j.has("encoding") || j.has("parent") || j.has("network") || j.has("optimizer")) reload_network_from_file(path);
-		else throw std::runtime_error{"File '" + path + "' is not a recognised scene / config json."};
+		// testbed.cu:371-395 in the reference's order: network config, camera path, otherwise training data
+		if (j.has("parent") || j.has("network") || j.has("encoding") || j.has("loss") || j.has("optimizer")) reload_network_from_file(path);
+		else if (j.has("path")) load_camera_path(path);
+		else if (j.has("frames")) load_training_data(path);   // a NeRF scene (mode_from_scene, common_host.cu:144-160)
+		else throw std::runtime_error{"File '" + path + "' is not a recognised scene / config / camera-path json."};
 		return;
 	}
 	if (fs::exists(path)) { load_training_data(path); return; } // a mesh (SDF) or an image: mode_from_scene, common_host.cu:144-160

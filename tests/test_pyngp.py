@@ -490,6 +490,8 @@ def test_camera_path_evaluation():
     assert np.allclose(np.array(t.camera_matrix)[:, 3], Tw, atol=1e-5) and abs(t.fov - fov) < 1e-3
     with pytest.raises(RuntimeError, match="does not exist"):
         t.load_camera_path(os.path.join(d, "missing.json"))
+    t2 = ngp.Testbed(); t2.load_file(path); t2.set_camera_from_time(2.0 / 6.0)  # load_file recognises a camera path by its "path" key (testbed.cu:390-394)
+    assert np.allclose(np.array(t2.camera_matrix), np.array(t.camera_matrix))
     with pytest.raises(RuntimeError, match="not part of this build"):
         t.camera_smoothing = True
 
