@@ -328,7 +328,7 @@ def test_camera_and_training_view_api_like_the_reference(scene_dir):
     with pytest.raises(RuntimeError, match="not part of this build"):
         t.shall_train_encoding = False
     assert t.n_params() == 0 and t.n_encoding_params() == 0  # no network before the first training step (testbed.cu:4089)
-    assert ngp.mode_from_scene(scene_dir) == ngp.TestbedMode.Nerf and ngp.mode_from_scene(custom) == ngp.TestbedMode.Nerf and ngp.mode_from_scene("/nonexistent") == ngp.TestbedMode.None_ if hasattr(ngp.TestbedMode, "None_") else True
+    assert ngp.mode_from_scene(scene_dir) == ngp.TestbedMode.Nerf and ngp.mode_from_scene(custom) == ngp.TestbedMode.Nerf and ngp.mode_from_scene("/nonexistent") == ngp.TestbedMode.__members__["None"]
     assert ngp.mode_from_string("SDF") == ngp.TestbedMode.Sdf and ngp.mode_from_string("image") == ngp.TestbedMode.Image
     ngp.free_temporary_memory()
     t.clear_training_data(); assert t.nerf.training.dataset.n_images == 0 and t.nerf.training.n_images_for_training == 0
