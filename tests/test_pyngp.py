@@ -139,8 +139,11 @@ def test_load_snapshot_validates_before_touching_the_gpu():
         t.load_snapshot(write("f.ingp", {"snapshot": good}))  # .ingp must be zlib framed
 
 
-@pytest.mark.gpu
-def test_run_py_flow_train_eval_snapshot(scene_dir):
+@pytest.fixture(scope="module")
+def trained(scene_dir):
+    """run.py's training phase, once per module: 400 steps on the synthetic scene, then both snapshot kinds written.  The tests below
+    each look at ONE thing (loss, wire format, test-view PSNR, snapshot round trip, depth, crop box) so that one failing line cannot
+    hide the others."""
     ngp = _ngp()
     t = ngp.Testbed()
     t.load_training_data(os.path.join(scene_dir, "transforms_train.json"))
@@ -151,8 +154,8 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     while t.frame():
         if t.training_step >= 400:
             break
-    assert t.training_step == 400 and 0 < t.loss < 0.01
-    # run.py:257-317 evaluation on held-out views
+    step, loss = t.training_step, t.loss
+    # run.py:257-317 evaluation settings
     t.background_color = [0.0, 0.0, 0.0, 1.0]
     t.snap_to_pixel_centers = True
     t.nerf.render_min_transmittance = 1e-4
@@ -161,11 +164,29 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     t.save_snapshot(snap, True)  # with optimizer state: the EMA (inference) weights used by the renderer are restored too
     snap_plain = os.path.join(os.path.dirname(snap), "weights_only.msgpack")
     t.save_snapshot(snap_plain, False)
-    # the files are the reference's wire format: zlib(msgpack(config + "snapshot")) (testbed.cu:5288-5352) -- read them with an
-    # independent msgpack implementation
+    t.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
+    t.render_with_lens_distortion = True
+    return {"t": t, "step": step, "loss": loss, "snap": snap, "snap_plain": snap_plain}
+
+
+def _view(t, i=1):
+    t.render_ground_truth = False
+    t.set_camera_to_training_view(i)
+    return t.render(64, 64, 1, True)
+
+
+@pytest.mark.gpu
+def test_flow_training_converges(trained):
+    assert trained["step"] == 400 and 0 < trained["loss"] < 0.01
+
+
+@pytest.mark.gpu
+def test_flow_snapshot_wire_format(trained):
+    """The files are the reference's wire format: zlib(msgpack(config + "snapshot")) (testbed.cu:5288-5352) -- read with an
+    independent msgpack implementation."""
     import zlib
     import msgpack
-    doc = msgpack.unpackb(zlib.decompress(open(snap, "rb").read()), raw=False)
+    doc = msgpack.unpackb(zlib.decompress(open(trained["snap"], "rb").read()), raw=False)
     sn = doc["snapshot"]
     assert "encoding" in doc and "network" in doc and sn["version"] == 1 and sn["mode"] == "nerf" and sn["training_step"] == 400
     assert sn["params_type"] == "__half" and len(sn["params_binary"]) == 2 * sn["n_params"] and sn["n_params"] == 10240 + 2920448 * 4
@@ -173,10 +194,14 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
     assert sn["nerf"]["aabb_scale"] == 1 and sn["nerf"]["rgb"]["rays_per_batch"] % 256 == 0 and sn["nerf"]["dataset"]["n_images"] == len(sn["nerf"]["dataset"]["xforms"])
     assert len(sn["camera"]["matrix"]) == 4 and len(sn["camera"]["matrix"][0]) == 3 and sn["aabb"]["min"] == [0.0, 0.0, 0.0]
     assert sn["ngp_hip_optimizer"]["otype"] == "ngp_hip" and "optimizer" not in sn  # private key: a real instant-ngp build ignores it
-    doc2 = msgpack.unpackb(open(snap_plain, "rb").read(), raw=False)
+    doc2 = msgpack.unpackb(open(trained["snap_plain"], "rb").read(), raw=False)
     assert "ngp_hip_optimizer" not in doc2["snapshot"] and doc2["snapshot"]["params_binary"] == sn["params_binary"]
-    t.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
-    t.render_with_lens_distortion = True
+
+
+@pytest.mark.gpu
+def test_flow_test_view_psnr(trained):
+    """run.py:257-317: held-out views, ground truth vs 4 spp render, PSNR in sRGB."""
+    t = trained["t"]
     psnrs = []
     for i in range(t.nerf.training.dataset.n_images):
         res = t.nerf.training.dataset.metadata[i].resolution
@@ -190,31 +215,56 @@ def test_run_py_flow_train_eval_snapshot(scene_dir):
         psnrs.append(-10 * math.log10(mse))
     print("test-view PSNR", psnrs)
     assert min(psnrs) > 22.0
-    # snapshot round trip: a fresh Testbed renders the same image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["snap", "snap_plain"])
+def test_flow_snapshot_round_trip(trained, scene_dir, kind):
+    """A fresh Testbed renders the same image from the full snapshot, and from the parameters-only one (what Trainer::deserialize
+    restores without optimizer state: same inference weights -> same image)."""
+    ngp = _ngp()
+    a = _view(trained["t"])
     t2 = ngp.Testbed()
     t2.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
-    t2.load_snapshot(snap)
+    t2.load_snapshot(trained[kind])
     assert t2.training_step == 400
     t2.background_color = [0.0, 0.0, 0.0, 1.0]; t2.snap_to_pixel_centers = True; t2.nerf.render_min_transmittance = 1e-4
-    t2.set_camera_to_training_view(1); t.set_camera_to_training_view(1)
-    a, b = t.render(64, 64, 1, True), t2.render(64, 64, 1, True)
+    b = _view(t2)
     assert np.abs(a - b).max() < 2e-3
-    # parameters-only snapshot (what Trainer::deserialize restores without optimizer state): same inference weights -> same image
-    t3 = ngp.Testbed()
-    t3.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
-    t3.load_snapshot(snap_plain)
-    t3.background_color = [0.0, 0.0, 0.0, 1.0]; t3.snap_to_pixel_centers = True; t3.nerf.render_min_transmittance = 1e-4
-    t3.set_camera_to_training_view(1)
-    c = t3.render(64, 64, 1, True)
-    assert t3.training_step == 400 and np.abs(a - c).max() < 2e-3
-    # render_with_depth (python_api.cu:520-532): the same frame plus the depth buffer; and a crop box written from Python empties what lies outside
+
+
+@pytest.mark.gpu
+def test_flow_render_with_depth(trained):
+    """render_with_depth (python_api.cu:520-532): the same frame plus the depth buffer.  Rays that end in the background keep MAX_DEPTH
+    (testbed_nerf.cu:1333-1378), so "hit" is depth < MAX_DEPTH -- NOT alpha, which an opaque background sets to 1 everywhere."""
+    t = trained["t"]
+    a = _view(t)
+    t.set_camera_to_training_view(1)
     rgba, depth = t.render_with_depth(64, 64, 1, True)
     assert rgba.shape == (64, 64, 4) and depth.shape == (64, 64) and np.abs(rgba - a).max() < 1e-4
-    hit = rgba[..., 3] > 0.5
-    assert hit.mean() > 0.02 and np.isfinite(depth[hit]).all() and (depth[hit] > 0.05).all() and (depth[hit] < 4.0).all()
+    MAX_DEPTH = 16384.0
+    hit = depth < MAX_DEPTH
+    assert 0.02 < hit.mean() < 0.98 and np.isfinite(depth).all() and (depth[hit] > 0.05).all() and (depth[hit] < 4.0).all()
+    # with a transparent background the composited alpha marks the same pixels as the depth buffer
+    bg = t.background_color
+    t.background_color = [0.0, 0.0, 0.0, 0.0]
+    rgba0, depth0 = t.render_with_depth(64, 64, 1, True)
+    t.background_color = bg
+    assert np.array_equal(depth0, depth)
+    assert (rgba0[..., 3][hit] > 0.19).all() and (rgba0[..., 3][~hit] < 0.21).all()  # render_kernels.hip: depth is written where alpha > 0.2
+
+
+@pytest.mark.gpu
+def test_flow_crop_box(trained):
+    """A crop box written from Python empties what lies outside; restoring it restores the image."""
+    ngp = _ngp()
+    t = trained["t"]
+    a = _view(t)
     full = t.render_aabb
     t.render_aabb = ngp.BoundingBox([0.0, 0.0, 0.0], [1e-3, 1e-3, 1e-3])
+    t.background_color = [0.0, 0.0, 0.0, 0.0]
     assert t.render(64, 64, 1, True)[..., 3].max() < 1e-3
+    t.background_color = [0.0, 0.0, 0.0, 1.0]
     t.render_aabb = full
     assert np.abs(t.render(64, 64, 1, True) - a).max() < 1e-4
 
