@@ -32,13 +32,16 @@ import ngp_abi as A
 
 # algorithmic work per unit, SURVEY.md 8(d) / DESIGN.md "roofline accounting"
 BYTES_PER_SAMPLE_FWD = 28 + 512 + 8          # coords + 8 levels x 8 corners x 8 B gather + rgbsigma half4
-BYTES_PER_SAMPLE_T1 = 28 + 512 + 8 + 1024    # forward gather + dL/dy + scatter as read-modify-write
+BYTES_PER_SAMPLE_T1_GATHER = 28 + 512 + 8 + 1024  # T1 that gathers its own encodings (every configuration but base.json's shape): forward gather + dL/dy + scatter as read-modify-write
+BYTES_PER_SAMPLE_T1 = 28 + 64 + 8 + 1024     # production T1 (base.json): reads the 64-byte encoding K2 left behind instead of gathering 512 B (those gathers are K2's and charged there)
+BYTES_PER_SAMPLE_K3 = 38                     # per NETWORK EVALUATION: rgbsigma half4 in + (compacted) coords 28 + dL/dy 8 out, amortised; K3 + K4 are VALU bound, listed for the whole-step sum
 BYTES_PER_PARAM_OPT = 38
 FLOP_PER_SAMPLE_FWD = 2 * (3072 + 7168)      # both MLPs, one sample, forward
 FLOP_PER_SAMPLE_TRAIN = 3 * FLOP_PER_SAMPLE_FWD  # forward + dgrad + wgrad
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 MFMA_PEAK_TFLOPS = 2500.0                    # dense fp16 MFMA peak (no sparsity)
 REFERENCE_ORDER_FLAGS = 1 | 32 | 2048 | 8192  # sequential K1, sequential K3, half atomics for every level, eager K2
+CLAMP_MIN_MAX_FLAG = 2147483648  # DBG_K1_MIP_CLAMP_MIN_MAX (csrc/ngp_kernels.hpp)
 
 
 class CudaView:
@@ -167,13 +170,19 @@ def run_ab_psnr(lib, scene, args, steps, seeds=(1337,)):
     """north_star parity proxy (the CUDA reference cannot run here): train the same scene / seed / ray stream with the production
     path and with the reference-order path, evaluate PSNR at equal step counts with the run.py procedure.  Several seeds (parameter
     initialisation AND ray stream): per path mean and standard deviation, and the PAIRED difference production - reference_order with its
-    standard error -- single pairs vary by +-0.15 dB per path, so only the mean over seeds can resolve the north-star tolerance of 0.1 dB."""
-    out = {"eval": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "steps": steps, "seeds": list(seeds), "production": {}, "reference_order": {},
-           "reference_order_flags": REFERENCE_ORDER_FLAGS}
-    per = {"production": {str(k): [] for k in steps}, "reference_order": {str(k): [] for k in steps}}
-    wall = {"production": 0.0, "reference_order": 0.0}
+    standard error -- single pairs vary by +-0.15 dB per path, so only the mean over seeds can resolve the north-star tolerance of 0.1 dB.
+    --ab-clamp-variants adds both paths with mip_from_dt's crossed-bounds clamp as min(max()) (DBG_K1_MIP_CLAMP_MIN_MAX): the round-4 decision
+    (tcnn's lower-bound-first form, the default) against its alternative; only multi-cascade scenes (fox) can differ."""
+    paths = [("production", 0), ("reference_order", REFERENCE_ORDER_FLAGS)]
+    if args.ab_clamp_variants:
+        paths += [("production_clamp_min_max", CLAMP_MIN_MAX_FLAG), ("reference_order_clamp_min_max", REFERENCE_ORDER_FLAGS | CLAMP_MIN_MAX_FLAG)]
+    out = {"eval": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "steps": steps, "seeds": list(seeds), "scene": scene["name"],
+           "reference_order_flags": REFERENCE_ORDER_FLAGS, "paths": {n: f for n, f in paths}}
+    per = {n: {str(k): [] for k in steps} for n, _ in paths}
+    wall = {n: 0.0 for n, _ in paths}
+    spr = {n: [] for n, _ in paths}
     for seed in seeds:
-        for name, flags in (("production", 0), ("reference_order", REFERENCE_ORDER_FLAGS)):
+        for name, flags in paths:
             lib.ngp_debug_set_flags(flags)
             try:
                 _, _, model, nerf = make_trainer(lib, scene, args.batch, seed=seed)
@@ -183,22 +192,32 @@ def run_ab_psnr(lib, scene, args, steps, seeds=(1337,)):
                     A.check(lib, lib.ngp_nerf_train(nerf, None, target - done)); done = target
                     per[name][str(target)].append(round(eval_psnr(lib, nerf, scene, args.eval_spp), 4))
                 wall[name] += time.perf_counter() - t0
+                st = get_stats(lib, nerf)
+                spr[name].append(round(st.measured_batch_size_before_compaction / max(st.n_rays_last, 1), 3))  # marched samples per ray at the end
                 lib.ngp_nerf_destroy(nerf); lib.ngp_model_destroy(model)
             finally:
                 lib.ngp_debug_set_flags(0)
     n = len(seeds)
-    for name in ("production", "reference_order"):
+    for name, _ in paths:
         out[name] = {k: round(float(np.mean(v)), 4) for k, v in per[name].items()}
         out[name + "_per_seed"] = per[name]
         out[name + "_std_db"] = {k: round(float(np.std(v, ddof=1)), 4) if n > 1 else None for k, v in per[name].items()}
         out[name + "_wall_s"] = round(wall[name], 2)
-    d = {k: np.array(per["production"][k]) - np.array(per["reference_order"][k]) for k in per["production"]}
-    out["delta_db"] = {k: round(float(v.mean()), 4) for k, v in d.items()}                       # mean paired difference
-    out["delta_db_per_seed"] = {k: [round(float(x), 4) for x in v] for k, v in d.items()}
-    out["delta_db_stderr"] = {k: round(float(v.std(ddof=1) / math.sqrt(n)), 4) if n > 1 else None for k, v in d.items()}
+        out[name + "_marched_samples_per_ray_end"] = spr[name]
+
+    def paired(x, y):
+        d = {k: np.array(per[x][k]) - np.array(per[y][k]) for k in per[x]}
+        r = {"delta_db": {k: round(float(v.mean()), 4) for k, v in d.items()},
+             "delta_db_per_seed": {k: [round(float(e), 4) for e in v] for k, v in d.items()},
+             "delta_db_stderr": {k: round(float(v.std(ddof=1) / math.sqrt(n)), 4) if n > 1 else None for k, v in d.items()}}
+        r["within_0p1_db"] = {k: (abs(r["delta_db"][k]) + 2 * r["delta_db_stderr"][k] <= 0.1) if n > 1 else None for k in r["delta_db"]}
+        return r
+    pr = paired("production", "reference_order")
+    out.update(pr)                                                                   # (keys of rounds 2-3: delta_db, delta_db_per_seed, delta_db_stderr, within_0p1_db)
     out["max_abs_delta_db"] = max(abs(v) for v in out["delta_db"].values())
-    # done-criterion of the round-2 review: |mean delta| <= 0.1 dB with the +-2 standard-error interval inside +-0.1
-    out["within_0p1_db"] = {k: (abs(out["delta_db"][k]) + 2 * out["delta_db_stderr"][k] <= 0.1) if n > 1 else None for k in out["delta_db"]}
+    if args.ab_clamp_variants:
+        out["clamp_lower_first_minus_min_max"] = {"production": paired("production", "production_clamp_min_max"), "reference_order": paired("reference_order", "reference_order_clamp_min_max")}
+        out["production_minus_reference_order_with_min_max"] = paired("production_clamp_min_max", "reference_order_clamp_min_max")
     return out
 
 
@@ -290,6 +309,7 @@ def main():
     ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
     ap.add_argument("--ab-seeds", type=int, default=1, help="--ab-psnr: number of seeds (1337, 1338, ...) per path; mean, standard deviation and the paired difference with its standard error are reported")
     ap.add_argument("--ab-seed0", type=int, default=1337, help="--ab-psnr: first seed")
+    ap.add_argument("--ab-clamp-variants", action="store_true", help="--ab-psnr: also train both paths with mip_from_dt's crossed-bounds clamp as min(max()) (ablation of the round-4 decision)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = --batch samples per GPU per step (default, the driver's mode); strong = --batch samples per step in total (B / N per GPU)")
     ap.add_argument("--dp-backend", choices=["auto", "rccl", "torch"], default="auto", help="N > 1: gradient / counter all-reduce inside libngp_hip (RCCL, ngp_comm_*) or through torch.distributed")
     args = ap.parse_args()
@@ -417,26 +437,55 @@ def main():
     lib.ngp_profile_name.restype = C.c_char_p
     kern = {lib.ngp_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(npf) if cnt[i]}
     n_inf_avg = s3.network_evaluations  # network evaluations of the last step's K2 (lazy K2: fewer than the marched samples)
-    per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd": BYTES_PER_SAMPLE_T1 * args.batch,
+    stash = bool(lib.ngp_nerf_uses_k2_stash(nerf)) if hasattr(lib, "ngp_nerf_uses_k2_stash") else True
+    t1_bytes = BYTES_PER_SAMPLE_T1 if stash else BYTES_PER_SAMPLE_T1_GATHER
+    # algorithmic bytes per launch of the kernels that have a byte model.  Each byte is charged ONCE: the 512-byte gather belongs to K2,
+    # the scatter unit (T1 + k_grad_bin + k_grad_accumulate) is charged what it moves itself.
+    per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd+k_grad_bin+k_grad_accumulate": t1_bytes * args.batch,
                         "k_optimizer": BYTES_PER_PARAM_OPT * n_params.value}
     if "k_grad_bin+accumulate" in kern and "k_train_fwd_bwd" in kern:
-        # the hashed levels' scatter runs in two follow-up kernels: one unit of algorithmic work (T1 sample = 1,572 B), one roofline entry
+        # the scatter runs in two follow-up kernels of T1: one unit of algorithmic work, one entry of the per-step table
         t1 = kern.pop("k_train_fwd_bwd"); gb = kern.pop("k_grad_bin+accumulate")
         kern["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = (t1[0] + gb[0], t1[1])
-        per_launch_bytes["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = per_launch_bytes["k_train_fwd_bwd"]
+    elif "k_train_fwd_bwd" in kern:
+        kern["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = kern.pop("k_train_fwd_bwd")
     kern_ms = {k: v[0] / args.profile_steps for k, v in kern.items()}
-    dominant = max((k for k in kern if k in per_launch_bytes), key=lambda k: kern[k][0])
+    # the dominant SINGLE kernel with a byte model: K2 (k_inference_tiles) or the optimizer sweep -- the scatter unit is three kernels and is reported beside it
+    single = [k for k in ("k_inference", "k_optimizer") if k in kern]
+    dominant = max(single, key=lambda k: kern[k][0] / kern[k][1])
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
-    traffic = traffic_src = None
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+    pmc = None
+    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", fn)))[dominant]["bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             traffic_src = f"profiles/{fn} (separate rocprofv3 --pmc passes of this command; see the file for the correction applied)"
             break
         except Exception:
             pass
+
+    def pmc_bytes(k):
+        try:
+            return pmc[k]["bytes_per_launch"]
+        except Exception:
+            return None
+    traffic = pmc_bytes(dominant)
+    if traffic is None:
+        traffic_src = None
     ms_step = 1e3 * elapsed / args.steps
+    su = "k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"
+    units = {}
+    for k in (dominant, su, "k_optimizer", "k_inference"):
+        if k in kern and k not in units:
+            t_ms = kern[k][0] / kern[k][1]
+            units[k] = {"algorithmic_bytes_per_launch": int(per_launch_bytes[k]), "avg_launch_ms": round(t_ms, 4), "achieved_GBps": round(per_launch_bytes[k] / (t_ms * 1e-3) / 1e9, 1),
+                        "frac": round(per_launch_bytes[k] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_bytes(k),
+                        "traffic_over_algorithmic": (round(pmc_bytes(k) / per_launch_bytes[k], 3) if pmc_bytes(k) else None)}
+    # whole step: every algorithmic byte of the step (each charged once) over the measured step time of the timed region
+    step_bytes = BYTES_PER_SAMPLE_FWD * n_inf_avg + t1_bytes * args.batch + BYTES_PER_PARAM_OPT * n_params.value + BYTES_PER_SAMPLE_K3 * n_inf_avg
+    whole = {"algorithmic_bytes_per_step": int(step_bytes), "ms_per_step": round(ms_step, 4), "achieved_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+             "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "note": "K2 548 B x evaluations + scatter unit (28 + 64 + 8 + 1024) B x batch + optimizer 38 B x parameters + K3/K4 38 B x evaluations; K1 (VALU bound lattice march), the occupancy-grid update and W (MFMA) move no modelled bytes"}
     flop_step = FLOP_PER_SAMPLE_FWD * n_inf_avg + FLOP_PER_SAMPLE_TRAIN * args.batch
     wg = kern.get("k_wgrad")
     mfma = {"flop_per_step": int(flop_step), "achieved_tflops": round(flop_step / (ms_step * 1e-3) / 1e12, 2), "peak_tflops": MFMA_PEAK_TFLOPS,
@@ -448,6 +497,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(per_launch_bytes[dominant]),
+                "units": units, "whole_step": whole,
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}, "mfma": mfma}
 
     t_eval = time.perf_counter()

@@ -455,6 +455,9 @@ int ngp_profile_enable(int on);
 int ngp_profile_count(void);
 const char* ngp_profile_name(int i);
 int ngp_profile_read(double* ms_sum_host, uint64_t* launches_host);
+/* 1 if the last training step's backward pass read its encodings from the forward pass's stash (base.json's shape, production kernels) instead of gathering them again:
+ * decides which byte model bench.py charges the scatter unit (no reference counterpart: tcnn always re-gathers). */
+int ngp_nerf_uses_k2_stash(ngp_nerf*);
 
 /* ------------------------------------------------------------------ test hooks ----------- */
 /* Not part of the reference's API surface: expose intermediate state to the parity tests. */

@@ -15,6 +15,10 @@
 #include "ngp_kernels.hpp"
 
 namespace ngp {
+// mip of a marched point (nerf_device.cuh:450-460).  Default: the reference's arithmetic with tcnn's lower-bound-first clamp (a pooled level above max_mip for long steps);
+// ablation DBG_K1_MIP_CLAMP_MIN_MAX: min(max()) = never above max_mip.
+static __device__ __forceinline__ uint32_t k1_mip(const K1Args& a, float dt, f3 pos) { const uint32_t m = mip_from_dt(dt, pos, a.max_mip); return a.clamp_min_max ? min(m, a.max_mip) : m; }
+
 
 uint32_t g_debug_flags = 0;
 
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 			f3 pos;
 			while (aabb.contains(pos = ro + t * rdn) && j < N_STEPS) {
 				float dt = calc_dt(t, cone_angle);
-				uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
+				uint32_t mip = k1_mip(a, dt, pos);
 				if (occupied_at(pos, a.bitfield, mip)) { ++j; t += dt; }
 				else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
 			}
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 	f3 pos;
 	while (aabb.contains(pos = ro + t * rdn) && j < numsteps) {
 		float dt = calc_dt(t, cone_angle);
-		uint32_t mip = mip_from_dt(dt, pos, a.max_mip);
+		uint32_t mip = k1_mip(a, dt, pos);
 		if (occupied_at(pos, a.bitfield, mip)) {
 			f3 wp = warp_position(pos, aabb);
 			float* c = co + (size_t)j * 7;
@@ -266,8 +270,8 @@ static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], u
 // scrambled rays, so the ranges are statistically equal), publishes the packed {samples, rays} total of its range, and the last workgroup to
 // finish (ticket counter) turns the G totals into exclusive offsets + the two global counters.  k1_write, launched with the same G, re-scans
 // the <= 128 counts of its own range in LDS.  Same slot-ordered spans as a global scan: deterministic, no atomics on the sample buffer.
-// K1_GROUP = lattice chunks tested (= occupancy loads in flight) per iteration.  SINGLE_CASCADE (aabb_scale 1: max_mip == 0): every point's mip
-// is 0 (mip_from_dt clamps to max_cascade), so dt, both frexp chains and the mip scaling drop out -- the kernel is VALU bound (~110
+// K1_GROUP = lattice chunks tested (= occupancy loads in flight) per iteration.  SINGLE_CASCADE (aabb_scale 1: max_mip == 0, AND a constant step: cone_angle == 0,
+// i.e. dt * 256 < 1): every point's mip is 0 (mip_from_dt returns mip_from_pos), so dt, both frexp chains and the mip scaling drop out -- the kernel is VALU bound (~110
 // instructions per lattice point, 4 cycles each per wavefront), this removes a third of them.
 template <uint32_t K1_GROUP, bool SINGLE_CASCADE>
 __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__ rs, uint64_t* __restrict__ masks, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
@@ -291,9 +295,10 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	// of their midpoint against the DILATED coarse grid (second half of the LDS copy), whole chunks without a hit are not evaluated at all
 	const bool group_skip = SINGLE_CASCADE && prefilter && a.segment_skip && a.cone_angle_constant <= 1e-5f;
 	if (prefilter && li_begin < li_end) {
-		const uint32_t n_words = (a.max_mip + 1) * COARSE_WORDS;
+		// every level the march can ask for: mip_from_dt returns max(mip_from_pos, exponent of the step), which exceeds max_mip for long steps (pooled levels)
+		const uint32_t n_words = (SINGLE_CASCADE ? 1u : a.n_mips) * COARSE_WORDS;
 		for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) s_coarse[w] = a.bitfield_coarse[w];
-		if (group_skip) for (uint32_t w = threadIdx.x; w < COARSE_WORDS; w += blockDim.x) s_coarse[COARSE_WORDS + w] = a.bitfield_coarse[n_words + w];
+		if (group_skip) for (uint32_t w = threadIdx.x; w < COARSE_WORDS; w += blockDim.x) s_coarse[COARSE_WORDS + w] = a.bitfield_coarse[a.n_mips * COARSE_WORDS + w];
 	}
 	__syncthreads();
 	uint64_t wave_total = 0ull; // packed {samples (low 32), rays with samples (high 32)} of this wavefront's rays
@@ -317,7 +322,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 			if (inside) {
 				if (!SINGLE_CASCADE) {
 					const float dt = calc_dt(t, a.cone_angle_constant);
-					mip = mip_from_dt(dt, pos, a.max_mip);
+					mip = k1_mip(a, dt, pos);
 				}
 				occ = prefilter ? occupied_at_linear_prefiltered(pos, a.bitfield_linear, s_coarse, mip)
 					: a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
@@ -1495,14 +1500,16 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	char* p = (char*)scratch;
 	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
 	uint64_t* masks = (uint64_t*)p;
-	const uint32_t ray_grid = k1_grid(max_local_rays, k1_blocks_per_cu(a.max_mip == 0));
+	// single-cascade instance: max_mip == 0 and a constant step below one cell (dt * 2 * GRIDSIZE < 1: mip_from_dt never looks at the step)
+	const bool single = a.max_mip == 0 && a.cone_angle_constant <= 1e-5f;
+	const uint32_t ray_grid = k1_grid(max_local_rays, k1_blocks_per_cu(single));
 	p = (char*)scratch + k1_partial_offset(max_local_rays);
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
-	if (a.max_mip == 0) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? 2 * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
-	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? (a.max_mip + 1) * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? 2 * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? a.n_mips * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {

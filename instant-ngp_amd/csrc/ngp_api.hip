@@ -1117,15 +1117,15 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.max_samples_ptr = max_samples_ptr; a.rng = rng; a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out;
 	a.rays_out = rays_out; a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
-	a.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
+	a.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE); a.clamp_min_max = (g_debug_flags & DBG_K1_MIP_CLAMP_MIN_MAX) ? 1u : 0u;
 	a.cdf = g_hook_cdf;
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
 	static uint32_t* s_coarse = nullptr;
 	if (!s_coarse && dev_alloc(&s_coarse, (size_t)COARSE_WORDS * N_CASCADES * 2)) return 1;
-	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, std::min<uint32_t>(max_mip + 1, N_CASCADES), s_coarse);
-	a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse; a.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; a.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0;
+	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, N_CASCADES, s_coarse);
+	a.n_mips = N_CASCADES; a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse; a.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; a.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0;
 	const uint32_t max_local = n_rays / world_size + 1;
 	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
 		launch_generate_training_samples((hipStream_t)stream, a, max_local);
@@ -1266,7 +1266,7 @@ struct ngp_nerf {
 	void* comm = nullptr; hipStream_t comm_stream = nullptr; hipEvent_t ev_red_a = nullptr, ev_red_b = nullptr; bool grads_pending = false;
 	// error-proportional pixel sampling (testbed.h:745-756, 810-815; off unless one of the option switches is set)
 	float* error_map = nullptr; size_t error_map_cap = 0; int32_t error_map_res[2] = {0, 0};
-	float* cdf_x_cond_y = nullptr; float* cdf_y = nullptr; float* cdf_img = nullptr; size_t cdf_xy_cap = 0, cdf_y_cap = 0; int32_t cdf_res[2] = {0, 0}; bool cdf_valid = false;
+	float* cdf_x_cond_y = nullptr; float* cdf_y = nullptr; float* cdf_img = nullptr; size_t cdf_xy_cap = 0, cdf_y_cap = 0, cdf_img_cap = 0; int32_t cdf_res[2] = {0, 0}; bool cdf_valid = false;
 	uint32_t n_steps_between_error_map_updates = 128, n_steps_since_error_map_update = 0; bool error_cycle_open = false;
 	// host-side deterministic state (no device read-back needed)
 	Rng rng, density_grid_rng;
@@ -1294,14 +1294,14 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->grid_positions_sorted, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices_sorted, n_cells) || dev_alloc(&t->grid_sort_temp, t->grid_sort_temp_bytes = grid_sample_sort_temp_bytes(n_cells)) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_enc, (size_t)max_samples * 4) || dev_alloc(&t->src_index, B) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * (o->max_cascade + 1) * 2) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * N_CASCADES * 2) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays)) || dev_alloc(&t->k3_scratch, k3_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || k3_scratch_init(nullptr, t->k3_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
-	HIPCHK(hipMemset(t->bitfield_linear, 0, (size_t)GRID_N_CELLS / 8 * (o->max_cascade + 1)));
-	HIPCHK(hipMemset(t->bitfield_coarse, 0, (size_t)COARSE_WORDS * 4 * (o->max_cascade + 1) * 2));
+	HIPCHK(hipMemset(t->bitfield_linear, 0, (size_t)GRID_N_CELLS / 8 * N_CASCADES));
+	HIPCHK(hipMemset(t->bitfield_coarse, 0, (size_t)COARSE_WORDS * 4 * N_CASCADES * 2));
 	TrainCounters c; memset(&c, 0, sizeof(c));
 	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
 	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
@@ -1350,6 +1350,9 @@ static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_ima
 	if (dev_alloc(&t->meta_dev, n) || dev_alloc(&t->xforms_dev, n)) return 1;
 	HIPCHK(hipMemcpy(t->meta_dev, meta.data(), n * sizeof(ngp_image_meta), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->xforms_dev, xforms, n * sizeof(ngp_xform), hipMemcpyHostToDevice));
+	if (n != t->n_images) { // the error map and the three CDFs are laid out per image: an open accumulation cycle and installed CDFs end with the old image count
+		t->cdf_valid = false; t->error_cycle_open = false; t->n_steps_since_error_map_update = 0; // (the next step opens a cycle sized for n; dev_grow regrows the buffers)
+	}
 	t->n_images = n;
 	return 0;
 }
@@ -1428,7 +1431,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	++t->ema_step;
 	launch_grid_mean(s, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
-	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1, t->bitfield_coarse);
+	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, N_CASCADES, t->bitfield_coarse); // all pooled levels: the march may ask for one above max_cascade (mip_from_dt)
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1499,7 +1502,7 @@ static int error_map_build_cdfs(ngp_nerf* t, hipStream_t s) {
 	const size_t n = (size_t)w * h * t->n_images;
 	if ((t->opt.world_size > 1 || t->comm) && error_map_allreduce(t, s, n)) return 1; // (a one-rank communicator: the identity, exercised by tests/test_gpu_dist.py)
 	if (dev_grow(&t->cdf_x_cond_y, &t->cdf_xy_cap, n) || dev_grow(&t->cdf_y, &t->cdf_y_cap, (size_t)h * t->n_images)) return 1;
-	if (!t->cdf_img && dev_alloc(&t->cdf_img, t->n_images)) return 1;
+	if (dev_grow(&t->cdf_img, &t->cdf_img_cap, (size_t)t->n_images)) return 1;
 	t->cdf_res[0] = w; t->cdf_res[1] = h;
 	launch_construct_error_cdfs(s, t->n_images, (uint32_t)w, (uint32_t)h, t->error_map, t->cdf_x_cond_y, t->cdf_y, t->cdf_img);
 	t->n_steps_since_error_map_update = 0;
@@ -1519,13 +1522,13 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
+		k1.n_mips = N_CASCADES; k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;
 		k1.numsteps_out = t->numsteps; k1.coords_out = t->coords; k1.n_images = t->n_images; k1.metadata = t->meta_dev; k1.xforms = t->xforms_dev;
 		k1.bitfield = t->bitfield; k1.max_mip = o.max_cascade; k1.snap_to_pixel_centers = o.snap_to_pixel_centers; k1.cone_angle_constant = o.cone_angle_constant;
-		k1.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE);
+		k1.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE); k1.clamp_min_max = (g_debug_flags & DBG_K1_MIP_CLAMP_MIN_MAX) ? 1u : 0u;
 		k1.depth_lambda = o.depth_supervision_lambda;
 		k1.cdf = error_cdf_args(t);
 		return k1;
@@ -1767,7 +1770,7 @@ extern "C" int ngp_nerf_set_error_cdfs_host(ngp_nerf* t, const float* cdf_x_cond
 	HIPCHK(hipDeviceSynchronize());
 	const size_t n = (size_t)cdf_res[0] * cdf_res[1] * t->n_images;
 	if (dev_grow(&t->cdf_x_cond_y, &t->cdf_xy_cap, n) || dev_grow(&t->cdf_y, &t->cdf_y_cap, (size_t)cdf_res[1] * t->n_images)) return 1;
-	if (!t->cdf_img && dev_alloc(&t->cdf_img, t->n_images)) return 1;
+	if (dev_grow(&t->cdf_img, &t->cdf_img_cap, (size_t)t->n_images)) return 1;
 	HIPCHK(hipMemcpy(t->cdf_x_cond_y, cdf_x_cond_y, n * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->cdf_y, cdf_y, (size_t)cdf_res[1] * t->n_images * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->cdf_img, cdf_img, (size_t)t->n_images * 4, hipMemcpyHostToDevice));
@@ -1795,6 +1798,7 @@ extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 	return 0;
 }
 extern "C" int ngp_nerf_counter_ptrs(ngp_nerf* t, uint32_t** counters2) { *counters2 = t->sync2; return 0; }
+extern "C" int ngp_nerf_uses_k2_stash(ngp_nerf* t) { return t && t->k2_enc_valid ? 1 : 0; }
 extern "C" int ngp_nerf_get_stats(ngp_nerf* t, void* stream, ngp_nerf_stats* out) {
 	TrainCounters c;
 	HIPCHK(hipMemcpyAsync(&c, t->counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1814,7 +1818,7 @@ extern "C" int ngp_nerf_set_density_grid_host(ngp_nerf* t, void* stream, const f
 	HIPCHK(hipMemcpy(t->density_grid, grid_host, n * 4, hipMemcpyHostToDevice));
 	launch_grid_mean((hipStream_t)stream, t->density_grid, t->mean_partial, t->mean);
 	launch_grid_to_bitfield((hipStream_t)stream, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
-	launch_build_linear_bitfield((hipStream_t)stream, t->bitfield, t->bitfield_linear, t->opt.max_cascade + 1, t->bitfield_coarse);
+	launch_build_linear_bitfield((hipStream_t)stream, t->bitfield, t->bitfield_linear, N_CASCADES, t->bitfield_coarse);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -41,6 +41,9 @@ NGP_HD float dist3(f3 a, f3 b) { return len3(a - b); }
 NGP_HD float sgn(float x) { return copysignf(1.0f, x); }
 NGP_HD float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 NGP_HD int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// tcnn's scalar clamp (vec.h: `a < b ? b : (c < a ? c : a)`): LOWER BOUND FIRST.  Same as clampi unless the bounds cross (lo > hi), where it returns lo.  The hot path has one
+// call with crossed bounds: mip_from_dt (nerf_device.cuh:459).  Decision of round 4, DESIGN.md section 5 (vii).
+NGP_HD int clampi_lower_first(int v, int lo, int hi) { return v < lo ? lo : (hi < v ? hi : v); }
 NGP_HD float logisticf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 struct M43 { f3 c[4]; };
@@ -279,7 +282,11 @@ NGP_HD uint32_t mip_from_dt(float dt, f3 pos, uint32_t max_cascade = N_CASCADES 
 	if (dt < 1.0f) return mip;
 	int exponent;
 	frexpf(dt, &exponent);
-	return (uint32_t)clampi((int)mip, exponent, (int)max_cascade);
+	// clamp(mip, exponent, max_cascade) with exponent > max_cascade for long steps (far samples of multi-cascade scenes): tcnn's clamp tests the lower bound first and
+	// returns `exponent`, i.e. the march goes through the POOLED bitfield levels above max_cascade (update_density_grid_mean_and_bitfield pools all NERF_CASCADES levels) --
+	// the behaviour of the pre-tcnn code as well (min(NERF_CASCADES() - 1, max(exponent, mip)): capped by the number of levels, not by the scene's max_cascade).
+	// exponent <= 6 (calc_dt caps dt at MIN_CONE_STEP * 128), so the result is always a valid bitfield level.
+	return (uint32_t)clampi_lower_first((int)mip, exponent, (int)max_cascade);
 }
 NGP_HD float skip_to_next_occupied(float t, float cone_angle, f3 o, f3 d, f3 idir, const uint8_t* __restrict__ grid,
 		uint32_t min_mip, uint32_t max_mip, const Box& aabb) {

@@ -24,6 +24,7 @@ enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march
 	DBG_K1_NO_FIRST_POINT_SKIP = 268435456 /* k1_count without the one-test-per-chunk rejection of the chunks behind the ray's exit */,
 	DBG_K3_ONE_RAY_PER_WAVE = 134217728 /* K3 with one wavefront per ray (rounds 1-2) instead of two rays per wavefront */,
 	DBG_K4_ZERO_PADDING = 67108864 /* test hook: the rows K4 pads the compacted batch with carry a zero loss gradient instead of the rescaled copy (the padding is the only part of a step that is not linear in the set of rays: tests/test_gpu_dist.py compares the 2-rank sum with the 1-rank gradient without it) */,
+	DBG_K1_MIP_CLAMP_MIN_MAX = 2147483648u /* ablation of the round-4 decision on mip_from_dt's crossed-bounds clamp (nerf_device.cuh:459): GLSL's min(max()) -- the march never leaves max_cascade -- instead of tcnn's lower-bound-first conditional; only differs with cone_angle > 0 (profiles/r04_ab_psnr_fox_clamp.json) */,
 	DBG_K1_INDEPENDENT_LATTICE = 16384 /* lattice K1 without the exact skip rule: every lattice point tested on its own (round-1 behaviour; exact only for cone_angle == 0) */ };
 
 // Device-resident NerfCounters (testbed.h / testbed_nerf.cu:2669-2702) + per-step scratch counters.
@@ -62,6 +63,8 @@ struct K1Args {
 	uint32_t n_images; const ngp_image_meta* metadata; const ngp_xform* xforms;
 	const uint8_t* bitfield; uint32_t max_mip;
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
+	uint32_t clamp_min_max = 0;                // ablation DBG_K1_MIP_CLAMP_MIN_MAX
+	uint32_t n_mips = 1; // bitfield levels present in bitfield_linear / bitfield_coarse (N_CASCADES: mip_from_dt may ask for a pooled level above max_mip, nerf_device.cuh:459)
 	const uint32_t* bitfield_coarse = nullptr; // optional: one bit per 4x4x4 cells of the x-major copy, followed by its one-cell dilation (same launcher): k1_count's LDS prefilters
 	uint32_t no_first_point_skip = 0;          // ablation DBG_K1_NO_FIRST_POINT_SKIP: k1_count evaluates every chunk of a group, also those behind the ray's exit from the box (rounds 1-2)
 	uint32_t segment_skip = 0;                 // ablation DBG_K1_SEGMENT_SKIP: k1_count rejects 8-point lattice segments by their midpoint (single cascade, cone_angle 0)

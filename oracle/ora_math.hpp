@@ -466,7 +466,11 @@ inline uint32_t mip_from_dt(float dt, vec3 pos, uint32_t max_cascade = NERF_CASC
 	if (dt < 1.0f) return mip;
 	int exponent;
 	std::frexp(dt, &exponent);
-	return (uint32_t)clampi((int)mip, exponent, (int)max_cascade);
+	// tcnn's scalar clamp tests the lower bound first (vec.h: a < b ? b : (c < a ? c : a)): with exponent > max_cascade (long steps) the result is `exponent`, a pooled
+	// level above max_cascade -- also what the pre-tcnn code did (min(NERF_CASCADES() - 1, max(exponent, mip))).  Pinned against the reference compiled with that clamp
+	// (oracle/_ref/libngpkern_ref.so, tests/test_ref_kernels.py); the min(max()) variant is kept as libngpkern_ref_clamp_min_max.so to state the difference.
+	const int m = (int)mip, hi = (int)max_cascade;
+	return (uint32_t)(m < exponent ? exponent : (hi < m ? hi : m));
 }
 // nerf_device.cuh:462-495 (MIP_FROM_DT = false instantiation; aabb_to_local = identity)
 inline float if_unoccupied_advance_to_next_occupied_voxel(float t, float cone_angle, vec3 o, vec3 d, vec3 idir,

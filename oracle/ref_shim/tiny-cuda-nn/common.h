@@ -112,15 +112,16 @@ template <typename T, uint32_t N> T max(const tvec<T, N>& a) { T r = a[0]; for (
 template <typename T, uint32_t N> tvec<T, N> pow(const tvec<T, N>& a, T b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::pow(a[i], b); return r; }
 template <typename T, uint32_t N> tvec<T, N> pow(const tvec<T, N>& a, const tvec<T, N>& b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::pow(a[i], b[i]); return r; }
 template <typename T, uint32_t N> tvec<T, N> copysign(const tvec<T, N>& a, const tvec<T, N>& b) { tvec<T, N> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::copysign(a[i], b[i]); return r; }
-// Scalar clamp.  GLSL defines clamp(x, lo, hi) = min(max(x, lo), hi); that is the default here.  It only matters where the bounds cross, and the reference has one such
-// call on the hot path: mip_from_dt ends in clamp((int)mip, exponent, (int)max_cascade) (nerf_device.cuh:459) with exponent > max_cascade for long steps.  min(max()) yields
-// max_cascade -- what the pre-tcnn-vector code base wrote out as min(max_cascade, max(exponent, mip)), and what the oracle and the HIP kernels do.  A lower-bound-first
-// conditional (v < lo ? lo : (hi < v ? hi : v)), which tcnn's scalar clamp may well be, yields `exponent`: -DNGP_SHIM_CLAMP_LOWER_FIRST builds that variant
-// (oracle/_ref/libngpkern_ref_clamp_lower_first.so) so that tests/test_ref_kernels.py can state what would change.
-#ifdef NGP_SHIM_CLAMP_LOWER_FIRST
-template <typename T> T clamp(T v, T lo, T hi) { return v < lo ? lo : (hi < v ? hi : v); }
-#else
+// Scalar clamp.  tcnn's vec.h defines clamp(a, b, c) = a < b ? b : (c < a ? c : a): the LOWER bound is tested first.  It only matters where the bounds cross, and the reference
+// has one such call on the hot path: mip_from_dt ends in clamp((int)mip, exponent, (int)max_cascade) (nerf_device.cuh:459) with exponent > max_cascade for long steps; the
+// lower-bound-first form yields `exponent` (a pooled bitfield level above max_cascade), which is also what the pre-tcnn-vector code base computed
+// (min(NERF_CASCADES() - 1, max(exponent, mip)): capped by the number of levels, not by max_cascade).  The oracle and the HIP kernels follow it since round 4.
+// GLSL's min(max(x, lo), hi) would stay at max_cascade: -DNGP_SHIM_CLAMP_MIN_MAX builds that variant (oracle/_ref/libngpkern_ref_clamp_min_max.so) so that
+// tests/test_ref_kernels.py can state what the choice changes.
+#ifdef NGP_SHIM_CLAMP_MIN_MAX
 template <typename T> T clamp(T v, T lo, T hi) { return std::min(std::max(v, lo), hi); }
+#else
+template <typename T> T clamp(T v, T lo, T hi) { return v < lo ? lo : (hi < v ? hi : v); }
 #endif
 template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, const tvec<T, N>& lo, const tvec<T, N>& hi) { return min(max(v, lo), hi); }
 template <typename T, uint32_t N> tvec<T, N> clamp(const tvec<T, N>& v, T lo, T hi) { return min(max(v, tvec<T, N>(lo)), tvec<T, N>(hi)); }

@@ -217,20 +217,34 @@ def test_flow_test_view_psnr(trained):
     assert min(psnrs) > 22.0
 
 
+def _restore(ngp, scene_dir, path):
+    t2 = ngp.Testbed()
+    t2.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
+    t2.load_snapshot(path)
+    assert t2.training_step == 400
+    t2.background_color = [0.0, 0.0, 0.0, 1.0]; t2.snap_to_pixel_centers = True; t2.nerf.render_min_transmittance = 1e-4
+    return t2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["snap", "snap_plain"])
 def test_flow_snapshot_round_trip(trained, scene_dir, kind):
     """A fresh Testbed renders the same image from the full snapshot, and from the parameters-only one (what Trainer::deserialize
-    restores without optimizer state: same inference weights -> same image)."""
+    restores without optimizer state: same inference weights -> same image).  The wire format keeps the density grid as __half
+    (testbed.cu:5297-5300), so the FIRST generation may flip cells that sit at the occupancy threshold (a handful of pixels move by
+    < 1e-2); a snapshot of the restored state is a fixed point of that rounding: the SECOND generation must be bit-identical."""
     ngp = _ngp()
     a = _view(trained["t"])
-    t2 = ngp.Testbed()
-    t2.load_training_data(os.path.join(scene_dir, "transforms_test.json"))
-    t2.load_snapshot(trained[kind])
-    assert t2.training_step == 400
-    t2.background_color = [0.0, 0.0, 0.0, 1.0]; t2.snap_to_pixel_centers = True; t2.nerf.render_min_transmittance = 1e-4
+    t2 = _restore(ngp, scene_dir, trained[kind])
     b = _view(t2)
-    assert np.abs(a - b).max() < 2e-3
+    d = np.abs(a - b)
+    print(f"{kind}: first generation max {d.max():.2e} mean {d.mean():.2e} pixels > 2e-3: {(d.max(axis=-1) > 2e-3).sum()}")
+    assert d.max() < 1e-2 and d.mean() < 5e-5 and (d.max(axis=-1) > 2e-3).mean() < 0.005
+    snap2 = os.path.join(tempfile.mkdtemp(), "again.ingp" if kind == "snap" else "again.msgpack")
+    t2.save_snapshot(snap2, kind == "snap")
+    t3 = _restore(ngp, scene_dir, snap2)
+    c = _view(t3)
+    assert np.array_equal(b, c), f"second generation differs: {np.abs(b - c).max()}"
 
 
 @pytest.mark.gpu
@@ -260,7 +274,7 @@ def test_flow_crop_box(trained):
     ngp = _ngp()
     t = trained["t"]
     a = _view(t)
-    full = t.render_aabb
+    full = ngp.BoundingBox(list(t.render_aabb.min), list(t.render_aabb.max))  # a COPY: the property returns a reference into the Testbed, as pybind's def_readwrite does in the reference (python_api.cu:641-645)
     t.render_aabb = ngp.BoundingBox([0.0, 0.0, 0.0], [1e-3, 1e-3, 1e-3])
     t.background_color = [0.0, 0.0, 0.0, 0.0]
     assert t.render(64, 64, 1, True)[..., 3].max() < 1e-3

@@ -133,12 +133,12 @@ def test_k1_cascades(ref, ora, scene):
 
 
 def test_k1_scalar_clamp_with_crossed_bounds(ref, ora, scene):
-    """The one place where the answer depends on tcnn source that is absent: mip_from_dt's clamp((int)mip, exponent, (int)max_cascade) (nerf_device.cuh:459) when a long step
-    asks for a cascade above max_cascade.  GLSL's min(max()) (the shim's default, the oracle, the HIP kernels, and the pre-tcnn code's min(max_cascade, max(exponent, mip)))
-    stays at max_cascade; a lower-bound-first conditional marches such points through the next coarser POOLED level.  oracle/_ref/libngpkern_ref_clamp_lower_first.so is the
-    reference's K1 compiled with that variant: identical with a constant step (cone angle 0: every aabb_scale = 1 scene, the headline configuration), and with the growing
-    step of larger scenes a conservative coarser test for the far part of a ray -- a few per cent of the rays gain a sample or two."""
-    alt_so = SO.replace(".so", "_clamp_lower_first.so")
+    """mip_from_dt's clamp((int)mip, exponent, (int)max_cascade) (nerf_device.cuh:459) when a long step asks for a cascade above max_cascade.  tcnn's scalar clamp tests the
+    lower bound first -> `exponent`: such points are marched through the next coarser POOLED bitfield level.  That is the shim's default (= the reference's K1 as compiled here),
+    the oracle and the HIP kernels (round 4).  oracle/_ref/libngpkern_ref_clamp_min_max.so is the same K1 with GLSL's min(max()), which stays at
+    max_cascade: identical with a constant step (cone angle 0: every aabb_scale = 1 scene, the headline configuration); with the growing step of larger scenes the
+    lower-bound-first form is a conservative coarser test for the far part of a ray -- a few per cent of the rays carry a sample or two more."""
+    alt_so = SO.replace(".so", "_clamp_min_max.so")
     if not os.path.exists(alt_so):
         pytest.skip("variant library not built")
     alt = C.CDLL(alt_so)
@@ -147,17 +147,19 @@ def test_k1_scalar_clamp_with_crossed_bounds(ref, ora, scene):
     grid = np.zeros(n, np.float32); ora.ora_k_mark_untrained_density_grid(n, ptr(grid), n_img, M, X, 1)
     grid = np.where((grid >= 0) & (np.random.default_rng(3).uniform(size=n // 8) < 0.15).repeat(8), 0.05, grid).astype(np.float32)  # fine-grained: a pooled cell differs from its children
     bf = np.zeros(N_CELLS, np.uint8); ora.ora_k_grid_to_bitfield(ptr(grid), 1, ptr(bf), F(0.01))
+    # (k_grid_to_bitfield pools through all NERF_CASCADES levels, like update_density_grid_mean_and_bitfield: the levels above max_cascade exist)
     for cone, may_differ in ((0.0, False), (1.0 / 256.0, True)):
         a = _k1(ref, "ref_", ora, scene, 3000, 1 << 21, 0, 3000, 1, cone, 2, bf, 1); b = _k1(alt, "ref_", ora, scene, 3000, 1 << 21, 0, 3000, 1, cone, 2, bf, 1)
         o = _k1(ora, "ora_", ora, scene, 3000, 1 << 21, 0, 3000, 1, cone, 2, bf, 1)
-        _same_k1(o, a)
+        _same_k1(o, a)                                                    # the oracle is the reference's K1 (lower bound first)
         na = a["ray_counter"].value
         assert na == b["ray_counter"].value and np.array_equal(a["ray_indices"][:na], b["ray_indices"][:na])
         differ = int((a["numsteps"][:na, 0] != b["numsteps"][:na, 0]).sum()); sa, sb = a["numsteps_counter"].value, b["numsteps_counter"].value
+        print(f"cone {cone}: rays {na}, rays whose sample count depends on the clamp {differ}, samples lower-first {sa} vs min-max {sb}")
         if not may_differ:
             assert differ == 0 and sa == sb
         else:
-            assert 0 < differ <= 0.05 * na and sa <= sb <= 1.005 * sa, (differ, sa, sb)
+            assert 0 < differ <= 0.05 * na and sb <= sa <= 1.005 * sb, (differ, sa, sb)
 
 
 def _k3(lib, prefix, ora, scene, k1, n_rays, B, net_u, loss_type, color_srgb, random_bg, linear_colors, rgb_act, density_act, snap, near):
