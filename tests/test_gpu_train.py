@@ -233,7 +233,7 @@ def test_render_matches_oracle(ora, hip, scene):
       rgba  (premultiplied linear): half network outputs, otherwise the same arithmetic -> bounds = 2 x the measured values below;
       depth (camera-space depth of the max-weight sample where alpha > 0.2, MAX_DEPTH elsewhere): an argmax over samples, so half-ulp noise may
              pick the neighbouring sample (one step) on a few pixels, and alpha within 1e-3 of 0.2 may classify differently.
-    Measured (round 4, MI355X): see the printed lines in profiles/r04_pytest_gpu.log."""
+    Measured (round 4, MI355X): the comment at RENDER_TOL below; printed lines in profiles/r04_pytest_gpu.log."""
     import torch
     from common import dptr
     B = 1 << 16
@@ -297,18 +297,23 @@ def test_render_matches_oracle(ora, hip, scene):
         print(f"render {scene} view {view}: coverage {cover:.3f} rgba max err {err.max():.2e} 99th pct {np.quantile(err, 0.99):.2e} | depth: hit pixels {int(both.sum())} "
               f"classification mismatches {int((hit_o != hit_d).sum())} max err {derr.max():.2e} 99th pct {np.quantile(derr, 0.99):.2e} exact-ish (<1e-4) {float((derr < 1e-4).mean()):.4f}")
         assert cover > 0.05 and both.mean() > 0.05  # something is visible
-        assert np.quantile(err, 0.99) <= RENDER_TOL[scene]["rgba_q99"] and err.max() <= RENDER_TOL[scene]["rgba_max"]
-        assert (hit_o != hit_d).mean() <= 0.002                      # alpha next to 0.2
+        tol = RENDER_TOL[scene]
+        assert np.quantile(err, 0.99) <= tol["rgba_q99"] and (err.max(axis=1) > 2e-3).mean() <= tol["rgba_outliers"] and err.max() <= tol["rgba_max"]
+        assert (hit_o != hit_d).mean() <= 0.001                      # alpha next to 0.2 (measured: 0 pixels)
         assert np.isfinite(d).all() and (d[~hit_d] == MAX_DEPTH).all()
-        assert (derr < 1e-4).mean() >= RENDER_TOL[scene]["depth_same_sample"]      # the same max-weight sample
-        assert np.quantile(derr, 0.99) <= RENDER_TOL[scene]["depth_q99"]
+        assert (derr < 1e-4).mean() >= tol["depth_same_sample"]      # the same max-weight sample
+        assert np.quantile(derr, 0.99) <= tol["depth_q99"]
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
 
 
-# bounds = ~2 x what round 4 measured on MI355X (profiles/r04_pytest_gpu.log)
+# Bounds = 2-3 x what round 4 measured on MI355X (profiles/r04_pytest_gpu.log), six frames of 40,000 pixels:
+#   rgba  99th percentile 2.6e-5 .. 5.2e-5; a FEW pixels per frame (< 0.05 %) move by up to 2.6e-2: the device marches the lattice in closed form, the oracle accumulates
+#         t += dt, so a point that sits on a voxel face can test the neighbouring cell (tests/test_k1_lattice_model.py classifies these) and one sample appears / disappears;
+#   depth the same max-weight sample (|delta| < 1e-4) on 99.90 - 99.92 % of the hit pixels, 99th percentile 8e-7 .. 2e-6; the rest picked another sample of nearly equal
+#         weight (any distance along the ray); alpha-0.2 classification: 0 mismatches.
 RENDER_TOL = {
-    "synthetic_aabb1": dict(rgba_q99=4e-3, rgba_max=2e-2, depth_same_sample=0.95, depth_q99=0.05),
-    "fox_small_aabb4": dict(rgba_q99=4e-3, rgba_max=2e-2, depth_same_sample=0.95, depth_q99=0.2),
+    "synthetic_aabb1": dict(rgba_q99=1e-4, rgba_outliers=1e-3, rgba_max=2e-2, depth_same_sample=0.997, depth_q99=1e-4),
+    "fox_small_aabb4": dict(rgba_q99=1.5e-4, rgba_outliers=1e-3, rgba_max=8e-2, depth_same_sample=0.997, depth_q99=1e-4),
 }
 
 
