@@ -1198,6 +1198,23 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 	}
 }
 
+// [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters, 4 parameters
+// (= one F=4 hash-table entry) per thread: 8-byte gradient / half-parameter accesses, 16-byte fp32 state accesses; the
+// Adam state of an entry is only touched when one of its gradients is non-zero (sparse update of the reference).
+DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint16_t& step) {
+	if (matrix) gradient += a.l2_reg * weight_fp;
+	const float gradient_sq = gradient * gradient;
+	const float first = m = a.beta1 * m + (1 - a.beta1) * gradient;
+	const float second = v = a.beta2 * v + (1 - a.beta2) * gradient_sq;
+	// per-parameter step counter, 16 bits SATURATING: it only feeds the two debias factors, and 1 - beta^t is exactly 1.0f in fp32 long before
+	// t = 65,535 (beta2 = 0.99: t > 1,700; beta2 = 0.999: t > 17,000) -- the result is the one of a 32-bit counter, at half the bytes per updated entry
+	const uint32_t current_step = step == 0xFFFFu ? 0xFFFFu : (uint32_t)(++step);
+	float lr = a.lr;
+	// beta^t as exp(t ln beta): the per-parameter step counters make powf the dominant cost of the sweep otherwise
+	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
+	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
+	return weight_fp - effective_lr * first;
+}
 // half -> integer multiple of 2^-24 (every finite half is one: subnormal step 2^-24, largest 65504 = 2047 << 29 units)
 DEV long long half_bits_to_fixed(uint32_t hbits) {
 	const uint32_t e = (hbits >> 10) & 31u, m = hbits & 1023u;
@@ -1212,9 +1229,10 @@ DEV long long half_bits_to_fixed(uint32_t hbits) {
 //                  every record byte is fetched once;
 //   SPLIT = true:  one block = one chunk x one feature pair (round-1 layout: half the LDS, but both blocks fetch every record).
 // The block also empties its list for the next step (no separate reset launch).
-template <uint32_t CL2, bool SPLIT, int F = 4>
+template <uint32_t CL2, bool SPLIT, int F = 4, bool ADAM = false>
 __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	static_assert(F == 4 || !SPLIT, "the split layout exists for F = 4 only");
+	static_assert(!ADAM || (F == 4 && !SPLIT), "the fused optimizer epilogue exists for the production layout (F = 4, one block per chunk)");
 	constexpr uint32_t E = 1u << CL2, NF = SPLIT ? 2u : (uint32_t)F;
 	__shared__ unsigned long long acc[E * NF];
 	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = SPLIT ? blockIdx.z : 0u, level = a.levels[ly];
@@ -1224,7 +1242,8 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	const bool dense = res * res * res <= (uint64_t)hs; // interleaved chunks: entry = local * NCH + chunk (see k_grad_bin)
 	if (c >= (dense ? (1u << NCH_LOG2) : (hs >> CL2))) return;
 	uint32_t* cursor = a.cursors + ly * a.max_chunks + c;
-	const uint32_t n = min(*cursor, a.cap);
+	const uint32_t n_raw = *cursor;
+	const uint32_t n = min(n_raw, a.cap);
 	for (uint32_t i = tid; i < E * NF; i += 1024) acc[i] = 0ull;
 	__syncthreads(); // every thread has read the cursor
 	if (tid == 0) { // the list is empty again for the next step; SPLIT: the second of the two blocks that share it does that
@@ -1290,6 +1309,57 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 		typedef typename BinVal<F>::type val_t;
 		val_t* gt = (val_t*)((__half*)a.grid_grad_ + ((size_t)offset + (dense ? (size_t)c : ((size_t)c << CL2))) * F);
 		const uint32_t n_local = dense ? (hs > c ? (hs - c + (1u << NCH_LOG2) - 1u) >> NCH_LOG2 : 0u) : E; // dense: entries c, c + NCH, c + 2 NCH, ... < hs
+		if constexpr (ADAM) if (!dense) {
+			// Fused optimizer step for this chunk (k_optimizer's arithmetic, entry by entry): the gradient the sweep would read is the half-rounded sum -- formed here the
+			// same way and used from registers.  Only a list that overflowed has gradient mass in the table (k_grad_bin's fallback atomics): read and cleared then.
+			const AdamArgs& o = a.adam;
+			const bool overflow = n_raw > a.cap;
+			const uint64_t i4_0 = o.n_mlp / 4 + (uint64_t)offset + ((uint64_t)c << CL2); // index in 4-parameter units (= table entries behind the MLP block)
+			for (uint32_t e = tid; e < E; e += 1024) {
+				const uint64_t i4 = i4_0 + e;
+				float r[4];
+#pragma unroll
+				for (int f = 0; f < 4; ++f) r[f] = (float)(long long)acc[f * E + e] * 0x1p-24f;
+				if (overflow) {
+					const uint2 oldv = gt[e];
+					const _Float16* old = (const _Float16*)&oldv;
+#pragma unroll
+					for (int f = 0; f < 4; ++f) r[f] += (float)old[f];
+					if (oldv.x | oldv.y) gt[e] = make_uint2(0u, 0u);
+				}
+				const h4 g4 = __builtin_bit_cast(h4, pack_halfs<4>(r));
+				h4 w4 = __builtin_bit_cast(h4, ((const uint2*)o.params)[i4]);
+				float g[4]; bool upd[4]; bool any = false;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) { g[k] = (float)g4[k] / o.loss_scale; upd[k] = o.optimize_non_matrix != 0 && g[k] != 0.f; any |= upd[k]; }
+				if (any) {
+					float4 mw = ((const float4*)o.master)[i4], m4 = ((const float4*)o.m)[i4], v4 = ((const float4*)o.v)[i4];
+					uint2 st = ((const uint2*)o.steps)[i4];
+					float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						if (!upd[k]) continue;
+						const float nw = adam_update(o, false, g[k], mwp[k], mp[k], vp[k], sp[k]);
+						mwp[k] = nw;
+						w4[k] = (_Float16)nw;
+					}
+					((float4*)o.master)[i4] = mw; ((float4*)o.m)[i4] = m4; ((float4*)o.v)[i4] = v4; ((uint2*)o.steps)[i4] = st;
+					((uint2*)o.params)[i4] = __builtin_bit_cast(uint2, w4);
+				}
+				float4 e4 = ((const float4*)o.ema)[i4];
+				float* ep = (float*)&e4;
+				h4 inf4;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const float filtered = (ep[k] * o.ema_decay * o.ema_debias_old + (float)w4[k] * (1 - o.ema_decay)) * o.ema_debias_new;
+					ep[k] = filtered;
+					inf4[k] = (_Float16)filtered;
+				}
+				((float4*)o.ema)[i4] = e4;
+				((uint2*)o.params_inf)[i4] = __builtin_bit_cast(uint2, inf4);
+			}
+			return;
+		}
 		for (uint32_t e = tid; e < n_local; e += 1024) {
 			const size_t o = dense ? ((size_t)e << NCH_LOG2) : (size_t)e;
 			const val_t oldv = gt[o]; // zero unless a list overflowed
@@ -2040,23 +2110,6 @@ __global__ void k_build_frags(const __half* __restrict__ mlp_params, uint32_t n_
 	if (bw) bw[bw_perm[p]] = v;
 }
 
-// [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters, 4 parameters
-// (= one F=4 hash-table entry) per thread: 8-byte gradient / half-parameter accesses, 16-byte fp32 state accesses; the
-// Adam state of an entry is only touched when one of its gradients is non-zero (sparse update of the reference).
-DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint16_t& step) {
-	if (matrix) gradient += a.l2_reg * weight_fp;
-	const float gradient_sq = gradient * gradient;
-	const float first = m = a.beta1 * m + (1 - a.beta1) * gradient;
-	const float second = v = a.beta2 * v + (1 - a.beta2) * gradient_sq;
-	// per-parameter step counter, 16 bits SATURATING: it only feeds the two debias factors, and 1 - beta^t is exactly 1.0f in fp32 long before
-	// t = 65,535 (beta2 = 0.99: t > 1,700; beta2 = 0.999: t > 17,000) -- the result is the one of a 32-bit counter, at half the bytes per updated entry
-	const uint32_t current_step = step == 0xFFFFu ? 0xFFFFu : (uint32_t)(++step);
-	float lr = a.lr;
-	// beta^t as exp(t ln beta): the per-parameter step counters make powf the dominant cost of the sweep otherwise
-	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
-	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
-	return weight_fp - effective_lr * first;
-}
 __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 	const uint64_t i4 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t i = i4 * 4;
@@ -2215,7 +2268,8 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	if (a.chunk_log2 == 11) {
 		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<11, 256>), gb, dim3(256), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
-		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
+		if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<11, false, 4, true>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		else if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
 	} else {
 		static const uint32_t bin_threads = getenv("NGP_BIN_THREADS") ? (uint32_t)atoi(getenv("NGP_BIN_THREADS")) : 512u; // 256: the round-2 shape (ablation)
@@ -2223,7 +2277,8 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 		// (1024 samples / threads per block -- twice the run length, half the cursor atomics, but one 100 KiB block per CU: unit 0.150 -> 0.164 ms, rejected)
 		else if (bin_threads == 512) hipLaunchKernelGGL((k_grad_bin<12, 512, 4, 512>), gb, dim3(512), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_bin<12, 512>), gb, dim3(256), 0, s, a);
-		if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
+		if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<12, false, 4, true>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		else if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_grad_accumulate<12, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
 	}
 }

@@ -242,6 +242,7 @@ struct ngp_model {
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
+	bool adam_fused_pending = false; uint64_t adam_sweep_end = 0; // this step's k_grad_accumulate has already applied the optimizer to the hashed levels: the sweep covers [0, adam_sweep_end) only
 	bool grads_clean = true; // the hash-grid part of `grads` is all zero (after creation / after an optimizer sweep that zeroed it)
 };
 
@@ -437,11 +438,14 @@ extern "C" int ngp_model_encode(ngp_model* m, void* stream, const float* pos, ui
 	return 0;
 }
 
-static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in);
+static AdamArgs make_adam_args(const ngp_model* m, float loss_scale, uint32_t step);
+static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in, float fuse_optimizer_loss_scale = 0.f);
 extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride) {
 	return model_training_step_impl(m, stream, in, in_stride, n, dL_dy, dy_stride, nullptr);
 }
-static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in) {
+// fuse_optimizer_loss_scale > 0: the caller runs ngp_model_optimizer_step(m, stream, that loss scale) next, with nothing in between that looks at the hash-grid gradients
+// (ngp_nerf_train on one GPU): k_grad_accumulate then applies the optimizer to the hashed levels itself (GradBinArgs::fuse_adam).
+static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in, float fuse_optimizer_loss_scale) {
 	REQUIRE(in_stride >= 7 && dy_stride >= 4 && dy_stride % 4 == 0, "training_step: in_stride >= 7, dy_stride a multiple of 4 halfs");
 	hipStream_t s = (hipStream_t)stream;
 	const size_t need = (size_t)((n + 31) / 32) * 2 * 64 * 8; // halfs
@@ -537,6 +541,20 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 		ProfScope ps(P_GRAD_BIN, s);
 		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap; ba.n_features = m->gm.F;
 		ba.vals = m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
+		ba.fuse_adam = 0;
+		static const bool no_fuse = getenv("NGP_NO_FUSED_ADAM") && atoi(getenv("NGP_NO_FUSED_ADAM")) != 0; // ablation: separate sweep over all parameters (rounds 1-3)
+		if (fuse_optimizer_loss_scale > 0.f && !no_fuse && m->gm.F == 4 && !ba.split && m->bin_dense) {
+			// parameter order = MLP, then the levels coarse -> fine: the dense levels (and the MLP) stay with the sweep, everything from the first hashed level on is done here
+			uint64_t first_hashed = m->n_params; bool ordered = true;
+			for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
+				const uint64_t res = m->gm.resolution[l], begin = m->n_mlp + (uint64_t)m->gm.offset[l] * m->gm.F;
+				if (res * res * res > m->gm.hashmap_size[l]) first_hashed = std::min(first_hashed, begin); else if (begin >= first_hashed) ordered = false;
+			}
+			if (ordered && first_hashed < m->n_params && first_hashed % 4 == 0) {
+				ba.fuse_adam = 1; ba.adam = make_adam_args(m, fuse_optimizer_loss_scale, m->step + 1);
+				m->adam_fused_pending = true; m->adam_sweep_end = first_hashed;
+			}
+		}
 		launch_grad_bin(s, ba);
 		if (da.n_levels && !overlap) launch_grad_dense(s, da); // profiling / single-stream mode: part of the same scope (one unit of algorithmic work)
 	}
@@ -1003,22 +1021,28 @@ extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* po
 	return 0;
 }
 
-extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
-	++m->step; // Adam::step: ++m_current_step
+// arguments of optimizer step number `step` (Adam::step has already counted it)
+static AdamArgs make_adam_args(const ngp_model* m, float loss_scale, uint32_t step) {
 	AdamArgs a;
 	a.n_params = m->n_params; a.n_mlp = m->n_mlp; a.loss_scale = loss_scale; a.lr = m->lr;
 	a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.epsilon; a.l2_reg = m->cfg.l2_reg;
 	a.log_beta1 = std::log(m->cfg.beta1); a.log_beta2 = std::log(m->cfg.beta2);
-	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
 	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding;
 	a.zero_grid_grads = !(g_debug_flags & DBG_NO_GRAD_ZERO_IN_OPTIMIZER);
 	const float d = m->cfg.ema_decay;
 	a.ema_decay = d;
-	a.ema_debias_old = 1 - std::pow(d, (float)(m->step - 1));
-	a.ema_debias_new = 1 / (1 - std::pow(d, (float)m->step));
+	a.ema_debias_old = 1 - std::pow(d, (float)(step - 1));
+	a.ema_debias_new = 1 / (1 - std::pow(d, (float)step));
 	a.master = m->master; a.params = m->params; a.params_inf = m->params_inf; a.grads = m->grads;
 	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema;
 	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
+	return a;
+}
+extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
+	++m->step; // Adam::step: ++m_current_step
+	AdamArgs a = make_adam_args(m, loss_scale, m->step);
+	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
+	if (m->adam_fused_pending) { a.n_params = m->adam_sweep_end; m->adam_fused_pending = false; } // the hashed levels were updated by this step's k_grad_accumulate (same arguments)
 	{ ProfScope ps(P_OPTIMIZER, (hipStream_t)stream); launch_optimizer_step((hipStream_t)stream, a); }
 	m->grads_clean = a.zero_grid_grads != 0;
 	HIPCHK(hipGetLastError());
@@ -1511,7 +1535,7 @@ static int error_map_build_cdfs(ngp_nerf* t, hipStream_t s) {
 	return 0;
 }
 
-static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_counters) {
+static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_counters, bool optimizer_follows = false) {
 	REQUIRE(t->n_images > 0, "train: no dataset");
 	hipStream_t s = (hipStream_t)stream;
 	const ngp_nerf_options& o = t->opt;
@@ -1606,7 +1630,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	}
 	EncStashIn stash_in;
 	if (t->k2_enc_valid) { stash_in.enc = t->k2_enc; stash_in.src_index = t->src_index; stash_in.n_valid_ptr = t->sync2 + 3; }
-	if (model_training_step_impl(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4, t->k2_enc_valid ? &stash_in : nullptr)) return 1;
+	if (model_training_step_impl(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4, t->k2_enc_valid ? &stash_in : nullptr, optimizer_follows && o.world_size == 1 && !t->comm ? o.loss_scale : 0.f)) return 1;
 	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
 	if (prelaunch) { // K1 of the NEXT step (its rng position), concurrent with this step's backward pass and optimizer
 		HIPCHK(hipStreamWaitEvent(t->k1_stream, t->ev_ctl, 0));
@@ -1792,7 +1816,7 @@ extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 			if (ngp_allreduce_counters(t, stream)) return 1;
 			if (ngp_nerf_train_backward(t, stream)) return 1;
 			if (dp_reduce_gradients(t, (hipStream_t)stream)) return 1;
-		} else if (ngp_nerf_train_forward_backward(t, stream)) return 1;
+		} else if (nerf_step_impl(t, stream, 3, false, true)) return 1; // (= ngp_nerf_train_forward_backward, and the optimizer step follows at once: its hashed-level part is fused into the scatter)
 		if (ngp_nerf_train_finish(t, stream)) return 1;
 	}
 	return 0;

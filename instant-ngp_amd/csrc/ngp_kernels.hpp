@@ -198,6 +198,17 @@ uint32_t wgrad_n_partials();
 constexpr uint32_t GRAD_BIN_MAX_TABLE_LOG2 = 19; // hashmap sizes up to 2^19 (2^12 .. 2^19)
 // chunk_log2: table entries per chunk (2^12: 128 KiB of 64-bit accumulators for the four features of an entry, one block per CU;
 // 2^11: 64 KiB, two blocks per CU).  split: round-1 layout, one block per (chunk, feature pair) -- both blocks fetch every record.
+struct AdamArgs {
+	uint64_t n_params, n_mlp;
+	float loss_scale, lr, beta1, beta2, eps, l2_reg, log_beta1, log_beta2;
+	int optimize_matrix, optimize_non_matrix;
+	int zero_grid_grads; // leave the hash-grid gradients zeroed for the next step's scatter (GradientMode::Overwrite without a memset launch)
+	float ema_decay, ema_debias_old, ema_debias_new;
+	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
+	float* m; float* v; uint16_t* steps /* per-parameter Adam step counters, saturating */; float* ema;
+	const uint32_t* fw_perm; const uint32_t* bw_perm; // n_mlp-entry scatter tables into the fragment buffers (0xFFFFFFFF = none)
+	ngp_half* fw_frags; ngp_half* bw_frags; ngp_half* fw_frags_inf; 
+};
 struct GradBinArgs {
 	const GridMeta* gm; const float* in; uint32_t in_stride, n;
 	const void* denc_lv; uint32_t denc_cap; // level-major dL/d(enc): F halfs per (level, sample)
@@ -205,6 +216,11 @@ struct GradBinArgs {
 	uint32_t chunk_log2, split, merge_runs, no_dense_merge;
 	uint32_t n_features; // F: 4 (8-byte record values) or 2 (4-byte)
 	void* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
+	// Single-GPU steps: k_grad_accumulate applies the optimizer to the HASHED levels in its epilogue -- the chunk's gradient sums are in LDS, so the 23 MB gradient write,
+	// its re-read by the sweep and the sweep's pass over those levels disappear (same arithmetic: the sums are rounded to half exactly as the stored gradient would be).
+	// The sweep (k_optimizer) then covers parameters [0, adam.n_params) = MLP + dense levels only.  Off (0): gradients are written for a separate optimizer step
+	// (C-ABI callers that look at gradients, the data-parallel all-reduce).
+	uint32_t fuse_adam = 0; AdamArgs adam{};
 };
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
 struct GradDenseArgs { // k_grad_dense: the dense levels' scatter from T1's level-major dL/d(enc)
@@ -226,17 +242,6 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden = 2);
 
-struct AdamArgs {
-	uint64_t n_params, n_mlp;
-	float loss_scale, lr, beta1, beta2, eps, l2_reg, log_beta1, log_beta2;
-	int optimize_matrix, optimize_non_matrix;
-	int zero_grid_grads; // leave the hash-grid gradients zeroed for the next step's scatter (GradientMode::Overwrite without a memset launch)
-	float ema_decay, ema_debias_old, ema_debias_new;
-	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
-	float* m; float* v; uint16_t* steps /* per-parameter Adam step counters, saturating */; float* ema;
-	const uint32_t* fw_perm; const uint32_t* bw_perm; // n_mlp-entry scatter tables into the fragment buffers (0xFFFFFFFF = none)
-	ngp_half* fw_frags; ngp_half* bw_frags; ngp_half* fw_frags_inf; 
-};
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
 
 // ---- image primitive (image_kernels.hip) ------------------------------------------------------

@@ -552,3 +552,50 @@ def test_error_map_survives_a_growing_dataset(ora, hip):
     A.check(hip, hip.ngp_nerf_train(t, None, 20))
     assert np.isfinite(_stats(hip, t).loss)
     hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
+
+
+def test_fused_optimizer_epilogue_is_the_separate_sweep(ora, hip):
+    """ngp_nerf_train on one GPU applies the optimizer to the hashed levels inside k_grad_accumulate (the gradient sums are in LDS: no gradient write, no second pass
+    over those parameters) and sweeps only the MLP + dense levels; the split calls (forward_backward, then finish) write gradients and sweep everything.  Same arithmetic
+    (the sums are rounded to half as the stored gradient would be), so from the same seed both trainers must hold IDENTICAL master parameters, Adam moments, per-parameter
+    step counters and EMA weights after 40 steps -- with the deterministic (slot-ordered) K3 compaction, because the production K3 orders the batch rows by atomic arrival
+    and the weight gradients are summed in row order.  40 steps cover occupancy-grid updates and the batch-size controller's ramp."""
+    B = 1 << 16
+    flags = 1048576  # DBG_K3_TWO_PASS
+    blobs, losses = [], []
+    for fused in (True, False):
+        hip.ngp_debug_set_flags(flags)
+        try:
+            s = _make(ora, hip, B, n_images=8, res=64)
+            t = s["t"]
+            if fused:
+                A.check(hip, hip.ngp_nerf_train(t, None, 40))
+            else:
+                for _ in range(40):
+                    A.check(hip, hip.ngp_nerf_train_prep(t, None))
+                    A.check(hip, hip.ngp_nerf_train_forward_backward(t, None))
+                    A.check(hip, hip.ngp_nerf_train_finish(t, None))
+            st = _stats(hip, t)
+            size = hip.ngp_model_serialized_size; size.restype = C.c_uint64
+            nbytes = size(s["hm"].h, 1)
+            buf = np.zeros(nbytes, np.uint8)
+            A.check(hip, hip.ngp_model_serialize_host(s["hm"].h, ptr(buf), C.c_uint64(nbytes), 1))
+            inf = np.zeros(s["om"].n, np.uint16)
+            pi = C.c_void_p(); hip.ngp_model_param_ptrs(s["hm"].h, None, None, C.byref(pi), None)
+            import torch
+            torch.cuda.synchronize()
+            assert C.CDLL("libamdhip64.so").hipMemcpy(ptr(inf), pi, C.c_size_t(inf.nbytes), 2) == 0
+            blobs.append((buf, inf)); losses.append((st.training_step, st.loss, st.rays_per_batch, st.measured_batch_size))
+            hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
+        finally:
+            hip.ngp_debug_set_flags(0)
+    print("fused vs split:", losses)
+    assert losses[0] == losses[1] and losses[0][0] == 40
+    n = (blobs[0][0].size - 32) // 4 // 5
+    hdr = 32
+    for k, name in enumerate(("master", "adam_m", "adam_v", "adam_steps", "ema")):
+        a = blobs[0][0][hdr + k * n * 4: hdr + (k + 1) * n * 4].view(np.uint32); b = blobs[1][0][hdr + k * n * 4: hdr + (k + 1) * n * 4].view(np.uint32)
+        bad = np.flatnonzero(a != b)
+        assert bad.size == 0, (name, bad.size, bad[:8].tolist())
+    assert np.array_equal(blobs[0][1], blobs[1][1]), "inference (EMA) half parameters differ"
+    assert np.array_equal(blobs[0][0][:hdr], blobs[1][0][:hdr])
