@@ -1201,7 +1201,10 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 // [tcnn optimizers/adam.h adam_step + ema.h ema_step_half_precision], one sweep over all parameters, 4 parameters
 // (= one F=4 hash-table entry) per thread: 8-byte gradient / half-parameter accesses, 16-byte fp32 state accesses; the
 // Adam state of an entry is only touched when one of its gradients is non-zero (sparse update of the reference).
+// (no fp contraction in the two update rules: they are instantiated in k_optimizer AND in k_grad_accumulate's fused epilogue, and both must round identically --
+// tests/test_gpu_train.py::test_fused_optimizer_epilogue_is_the_separate_sweep; it is also the arithmetic of the un-contracted oracle)
 DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint16_t& step) {
+#pragma clang fp contract(off)
 	if (matrix) gradient += a.l2_reg * weight_fp;
 	const float gradient_sq = gradient * gradient;
 	const float first = m = a.beta1 * m + (1 - a.beta1) * gradient;
@@ -1214,6 +1217,11 @@ DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weig
 	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
 	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
 	return weight_fp - effective_lr * first;
+}
+// ema_step_half_precision [tcnn optimizers/ema.h]: debiased exponential moving average of the half weights
+DEV float ema_update(const AdamArgs& a, float ema_old, float w) {
+#pragma clang fp contract(off)
+	return (ema_old * a.ema_decay * a.ema_debias_old + w * (1 - a.ema_decay)) * a.ema_debias_new;
 }
 // half -> integer multiple of 2^-24 (every finite half is one: subnormal step 2^-24, largest 65504 = 2047 << 29 units)
 DEV long long half_bits_to_fixed(uint32_t hbits) {
@@ -1351,7 +1359,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 				h4 inf4;
 #pragma unroll
 				for (int k = 0; k < 4; ++k) {
-					const float filtered = (ep[k] * o.ema_decay * o.ema_debias_old + (float)w4[k] * (1 - o.ema_decay)) * o.ema_debias_new;
+					const float filtered = ema_update(o, ep[k], (float)w4[k]);
 					ep[k] = filtered;
 					inf4[k] = (_Float16)filtered;
 				}
@@ -2148,7 +2156,7 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 	h4 inf4;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
-		const float filtered = (ep[k] * a.ema_decay * a.ema_debias_old + (float)w4[k] * (1 - a.ema_decay)) * a.ema_debias_new;
+		const float filtered = ema_update(a, ep[k], (float)w4[k]);
 		ep[k] = filtered;
 		inf4[k] = (_Float16)filtered;
 		if (matrix) ((_Float16*)a.fw_frags_inf)[a.fw_perm[i + k]] = inf4[k];
@@ -2203,7 +2211,8 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	// resident slots (dispatcher hands tiles out as blocks retire) 0.13 -> 0.16 - 0.21 ms; 4 blocks per CU at 128 registers (28 B of scratch) 0.130 -> 0.134 ms; 8-wide
 	// tiles 0.131 -> 0.142 ms.  The kernel moves 400 MB of 128-byte lines for 8-byte table entries (profiles/r03_pmc_summary.txt): it runs at the memory side's
 	// random-line rate (3.3 TB/s), not at a latency or occupancy limit.
-	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * 3);
+	static const uint32_t k2_bpc = getenv("NGP_K2_BLOCKS_PER_CU") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_K2_BLOCKS_PER_CU")), 1), 3) : 3u; // experiment: leave wave slots to a concurrent VALU-bound kernel
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * k2_bpc);
 	const uint32_t nr = mp.n_rgb_hidden;
 #define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
 #define NGP_LAUNCH_TILES_W(FF, NRR) do { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, FF, NRR); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, FF, NRR); else NGP_LAUNCH_TILES(32, FF, NRR); } while (0)

@@ -1495,7 +1495,7 @@ int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays) {
 	return hipMemsetAsync((char*)scratch + (size_t)max_rays * K3_REC * 4, 0, (size_t)k1_grid(max_rays) * 8 + 256, s) == hipSuccess ? 0 : 1;
 }
 // K1 as three launches: setup (thread per ray), count (wave per ray + the prefix sum over workgroup totals), write (wave per ray)
-void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch) {
+void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch, bool count_only) {
 	if (max_local_rays == 0) return;
 	char* p = (char*)scratch;
 	RaySetup* rs = (RaySetup*)p; p += (size_t)max_local_rays * sizeof(RaySetup);
@@ -1510,7 +1510,7 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
 	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? 2 * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? a.n_mips * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
-	hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
+	if (!count_only) hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {
 	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;

@@ -110,7 +110,7 @@ struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t c
 constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multiplicative-hash constant), larger than every ray count => coprime to it, and well mixed modulo powers of two; see k1_setup
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays); // once per allocation (and whenever max_local_rays changes)
-void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch);
+void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, uint32_t max_local_rays, void* scratch, bool count_only = false /* experiment: setup + count without the write pass */);
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse = nullptr);
 void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays);
 // testbed_nerf.cu:2795-2847: error map (n_images x height x width) -> cdf_x_cond_y (same shape), cdf_y (n_images x height), cdf_img (n_images)

@@ -285,7 +285,10 @@ struct Model {
 	// dL_dy: [0..2] -> rgb net output gradient (extract_rgb :206), [3] added to density-net output 0
 	// (add_density_gradient :235).  Grid gradient: [tcnn kernel_grid_backward] half atomicAdd of
 	// (half)(dL_dy_f * weight) -- accumulated here in sample order.
-	void training_step(const float* coords, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
+	// exact_grid_sums (test aid, NOT the reference's arithmetic): the SAME half contributions (half)(dL/d(enc) * weight) are summed per table entry in double and rounded
+	// to half once -- the order-independent sum that the reference's chain of half atomicAdds approximates with one rounding per contribution.  The HIP path sums exactly
+	// (64-bit fixed point): tests use this variant to show that its distance from the reference-order result is the reference's own accumulation noise.
+	void training_step(const float* coords, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, bool exact_grid_sums = false) {
 		std::vector<float> dW(n_mlp, 0.f);
 		std::vector<uint16_t> dL_denc((size_t)n * n_enc);
 		#pragma omp parallel
@@ -315,6 +318,8 @@ struct Model {
 		#pragma omp parallel for schedule(dynamic, 1)
 		for (int64_t l = 0; l < (int64_t)grid.n_levels; ++l) {
 			uint16_t* lvl = gg + (size_t)grid.offsets[l] * grid.F;
+			std::vector<double> acc;
+			if (exact_grid_sums) acc.assign((size_t)(grid.offsets[l + 1] - grid.offsets[l]) * grid.F, 0.0);
 			for (uint32_t i = 0; i < n; ++i) {
 				uint32_t idx[8]; float w[8];
 				grid_level_lookup(grid, (uint32_t)l, coords + (size_t)i * stride, idx, w);
@@ -322,11 +327,13 @@ struct Model {
 					float g = h2f(dL_denc[(size_t)i * n_enc + l * grid.F + f]);
 					for (uint32_t c = 0; c < 8; ++c) {
 						uint16_t v = f2h(g * w[c]);
+						if (exact_grid_sums) { acc[(size_t)idx[c] * grid.F + f] += (double)h2f(v); continue; }
 						uint16_t& dst = lvl[(size_t)idx[c] * grid.F + f];
 						dst = f2h(h2f(dst) + h2f(v));
 					}
 				}
 			}
+			if (exact_grid_sums) for (size_t k = 0; k < acc.size(); ++k) lvl[k] = f2h((float)acc[k]);
 		}
 	}
 

@@ -40,10 +40,11 @@ def load():
         L.ora_nerf_update_density_grid.argtypes = [vp, f32, u32, u32]
         L.ora_sobol.restype = u32; L.ora_morton3D.restype = u32; L.ora_morton3D_invert.restype = u32; L.ora_pcg32_next_uint.restype = u32
         L.ora_hfma.restype = u16; L.ora_hfma.argtypes = [u16, u16, u16]
+        L.ora_model_set_step.argtypes = [vp, u32, f32]
         for name in ("ora_model_n_params", "ora_model_n_mlp_params"):
             getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]
         for name in ("ora_model_params_fp", "ora_model_params", "ora_model_params_inference", "ora_model_gradients", "ora_model_adam_m",
-                     "ora_model_adam_v", "ora_nerf_density_grid", "ora_nerf_bitfield"):
+                     "ora_model_adam_v", "ora_model_adam_steps", "ora_model_ema", "ora_nerf_density_grid", "ora_nerf_bitfield"):
             getattr(L, name).restype = vp; getattr(L, name).argtypes = [vp]
         for name in ("ora_encmlp_n_params", "ora_encmlp_n_mlp"):
             getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]

@@ -107,6 +107,21 @@ class OraModel:
     def grads(self):
         return self.arr("ora_model_gradients", np.uint16)
 
+    def load_serialized(self, blob):
+        """the device model's state (ngp_model_serialize_host with optimizer state: header, master, Adam m / v / steps, EMA) into the oracle's trainer"""
+        hdr = np.frombuffer(blob[:32].tobytes(), np.uint32)
+        step = int(hdr[4]); lr = float(np.frombuffer(blob[24:28].tobytes(), np.float32)[0])
+        n = self.n
+        body = blob[32:].view(np.uint32).reshape(5, n)
+        self.params_fp[:] = body[0].view(np.float32)
+        self.arr("ora_model_adam_m", np.float32)[:] = body[1].view(np.float32)
+        self.arr("ora_model_adam_v", np.float32)[:] = body[2].view(np.float32)
+        self.arr("ora_model_adam_steps", np.uint32)[:] = body[3]
+        self.L.ora_model_sync_half(self.h)                       # params = params_inference = half(master) ...
+        self.arr("ora_model_ema", np.float32)[:] = body[4].view(np.float32)
+        self.params_inf[:] = body[4].view(np.float32).astype(np.float16).view(np.uint16)   # ... then the inference weights = half(EMA)
+        self.L.ora_model_set_step(self.h, step, lr)
+
     def inference(self, coords, use_inf=False):
         n = coords.shape[0]
         out = np.zeros((n, 4), dtype=np.uint16)
@@ -125,8 +140,9 @@ class OraModel:
         self.L.ora_model_encode(self.h, ptr(pos), pos.shape[1], n, ptr(out))
         return out
 
-    def training_step(self, coords, dl):
-        self.L.ora_model_training_step(self.h, ptr(coords), 7, coords.shape[0], ptr(dl), dl.shape[1])
+    def training_step(self, coords, dl, exact_grid_sums=False):
+        """exact_grid_sums: the same half contributions summed per table entry in double, one rounding (test aid; the reference adds them one by one in half)"""
+        (self.L.ora_model_training_step_exact_sums if exact_grid_sums else self.L.ora_model_training_step)(self.h, ptr(coords), 7, coords.shape[0], ptr(dl), dl.shape[1])
 
     def __del__(self):
         try:

@@ -135,7 +135,7 @@ def _worker(rank, world, port, q):
                 a, b = g_sum.numpy().astype(np.float64), g_one.numpy().astype(np.float64)
                 rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
                 print(f"step 0: {len(one)} rays, summed-gradient rel-L2 vs single rank {rel:.3e}")
-                assert rel < 0.25, rel
+                assert rel < 0.2, rel   # measured 0.073 / 0.105 (255 rays at B = 2^17: nearly every row of a rank's half batch is padding, wrapped per rank)
     # (iv) replicated optimizer on identical reduced gradients: both ranks hold bit-identical parameters after N steps
     p = np.empty(hm.n, np.float32)
     A.check(lib, lib.ngp_model_get_params_host(hm.h, p.ctypes.data_as(C.c_void_p), C.c_uint64(p.size)))
@@ -196,10 +196,10 @@ def _worker(rank, world, port, q):
             print(f"steady state, padding {'zeroed' if zero_pad else 'as in production'}: loss 2 ranks {l2:.6f} vs 1 rank {l1:.6f}; compacted per rank {m2} vs {m1} of {B_GLOBAL}; "
                   f"summed-gradient rel-L2 {rel:.3e}")
             assert m1 > 0.8 * B_GLOBAL and m1 < B_GLOBAL and m2 < B_GLOBAL // world, f"the check must run below the batch clamp ({m1}, {m2} of {B_GLOBAL})"
-            assert abs(l2 - l1) <= 0.02 * l1, (l2, l1)   # the loss of the union batch (Testbed.loss) on every rank
+            assert abs(l2 - l1) <= 1e-3 * l1, (l2, l1)   # the loss of the union batch (Testbed.loss) on every rank: equal to six digits in every run so far
             # without the padding rows the step is linear in the set of rays: 2-rank sum == 1-rank gradient up to half rounding of the partial sums;
             # with them the difference is the wrap of each rank's first rows (a few per cent of the batch at n_in ~ 0.97 B)
-            assert rel < (0.02 if zero_pad else 0.20), rel  # with padding: each rank wraps its first rows to B / G (~10 % of the batch here)
+            assert rel < (1e-3 if zero_pad else 0.10), rel  # measured 2.6e-4 / 0.038 - 0.049; with padding: each rank wraps its first rows to B / G (~10 % of the batch here)
         q.put("ok")
     dist.barrier()
     lib.ngp_nerf_destroy(t)
@@ -257,3 +257,78 @@ def test_rccl_in_library_world1(hip):
     torch.cuda.synchronize()
     A.check(hip, hip.ngp_comm_destroy(t_b))
     hip.ngp_nerf_destroy(t_a); hip.ngp_nerf_destroy(t_b)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# one process per GPU over RCCL inside the library -- the configuration the driver's scaling run uses (bench.py --gpus N)
+# ------------------------------------------------------------------------------------------------------------------------
+def _rccl_worker(rank, world, port, q):
+    """ngp_nerf_train with an in-library communicator of `world` ranks, rank r on device r: every rank must derive the same ray counts, hold bit-identical parameters
+    after the replicated optimizer steps (the all-reduced gradient is the same vector on every rank), and train (loss falls, stays finite)."""
+    sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "instant-ngp_amd")]
+    import hashlib
+    import ngp_abi as A
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)                       # before the library creates its helper streams (they belong to the current device)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = A.load_hip()
+    A.check(lib, lib.ngp_init())
+    hm, t, keep = _setup(A, lib, rank, world, (1 << 16) // world)
+    uid = [None]
+    if rank == 0:
+        buf = (C.c_uint8 * 128)(); A.check(lib, lib.ngp_comm_unique_id(buf)); uid[0] = bytes(buf)
+    dist.broadcast_object_list(uid, 0)
+    A.check(lib, lib.ngp_comm_init(t, rank, world, (C.c_uint8 * 128)(*uid[0])))
+    losses = []
+    for _ in range(4):
+        A.check(lib, lib.ngp_nerf_train(t, None, 10))
+        torch.cuda.synchronize()
+        st = A.NerfStats(); A.check(lib, lib.ngp_nerf_get_stats(t, None, C.byref(st)))
+        losses.append(float(st.loss))
+        rpb = [None] * world; dist.all_gather_object(rpb, (int(st.rays_per_batch), int(st.training_step), float(st.loss)))
+        assert len(set(rpb)) == 1, rpb               # same controller decision, same step, same (union-batch) loss on every rank
+    p = np.empty(hm.n, np.float32)
+    A.check(lib, lib.ngp_model_get_params_host(hm.h, p.ctypes.data_as(C.c_void_p), C.c_uint64(p.size)))
+    digests = [None] * world; dist.all_gather_object(digests, hashlib.sha1(p.tobytes()).hexdigest())
+    assert len(set(digests)) == 1, "ranks diverged"
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], losses   # (losses[0] is already ten steps in)
+    dist.barrier()
+    torch.cuda.synchronize()
+    A.check(lib, lib.ngp_comm_destroy(t))
+    lib.ngp_nerf_destroy(t)
+    dist.destroy_process_group()
+    if rank == 0:
+        q.put(("ok", losses))
+
+
+def _run_rccl(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    tag, losses = q.get(timeout=5)
+    print(f"in-library RCCL step, {world} rank(s) on {world} device(s): loss per 10 steps {losses}")
+    assert tag == "ok"
+
+
+@pytest.mark.timeout(700)
+def test_rccl_step_one_process_per_device_world1():
+    """the worker of the multi-device test below with a single rank (any box): same code path, communicator of one"""
+    _run_rccl(1)
+
+
+@pytest.mark.timeout(700)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's 8-GPU box): RCCL across real devices")
+def test_rccl_step_one_process_per_device_world2():
+    _run_rccl(2)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 8, reason="needs the 8-GPU node")
+def test_rccl_step_one_process_per_device_world8():
+    _run_rccl(8)

@@ -39,13 +39,17 @@ def _stats(hip, t):
 
 
 def test_training_loop_tracks_oracle(ora, hip):
-    """Four optimizer steps from the same initial state, device vs oracle: step counters, marched / compacted samples PER RAY, the batch-size
-    controller's decisions and the loss.  At initialisation every occupancy cell sits AT the threshold (density = exp(~0) * min step everywhere,
-    threshold = mean), so half-ulp differences of the density MLP flip occupancy bits, and the controller rounds its ray count up to a multiple
-    of 256 -- a discrete decision next to a rounding boundary at these tiny ray counts: the two runs track each other only statistically (over 20
-    device runs step 4 marched 2.0e5 .. 2.7e5 samples against the oracle's 2.27e5, profiles/r02_tracking_test_spread.txt).  Per-ray
-    quantities are compared so that a different controller decision in one step does not fail the next; the per-kernel tests hold the tight
-    tolerances."""
+    """Device trainer vs the oracle's trainer, step by step, in two regimes.
+    (a) From initialisation, four optimizer steps: step counters, marched / compacted samples PER RAY, the batch-size controller's decisions and the loss.  At initialisation
+        every occupancy cell sits AT the threshold (density = exp(~0) * min step everywhere, threshold = mean), so half-ulp differences of the density MLP flip occupancy
+        bits, and the controller rounds its ray count up to a multiple of 256 -- a discrete decision next to a rounding boundary at these tiny ray counts: the two runs track
+        each other only statistically (over 20 device runs step 4 marched 2.0e5 .. 2.7e5 samples against the oracle's 2.27e5, profiles/r02_tracking_test_spread.txt), hence
+        the wide bounds of this part.
+    (b) From a TRAINED state (64 device steps; parameters, Adam moments, step counters, EMA, occupancy grid, rng and ray count copied into the oracle): three more steps without
+        an occupancy-grid update in between.  Nothing sits at a threshold any more, so the two trainers must agree per step to a few per cent: rays that hit (K1's lattice vs the
+        reference recurrence: 0.3 % of rays), marched and compacted samples per ray, the controller's next ray count (one 256-step) and the loss.  Bounds = 2 x measured
+        (profiles/r04_pytest_gpu.log)."""
+    import torch
     B = 1 << 17
     s = _make(ora, hip, B, rays0=256)
     rays_h = rays_o = 256
@@ -66,7 +70,43 @@ def test_training_loop_tracks_oracle(ora, hip):
         # (which rays the sample cap drops differs: the device fills its ray slots in a scrambled order, the oracle in index order)
         assert abs(hs.loss - os_.loss) <= 0.3 * abs(os_.loss) + 1e-5, (step, hs.loss, os_.loss)
         rays_h, rays_o = hs.rays_per_batch, os_.rays_per_batch
+    # ---- (b) from a trained state ----
+    t, hm, om, ot = s["t"], s["hm"], s["om"], s["ot"]
+    A.check(hip, hip.ngp_nerf_train(t, None, 60))           # step 64: the next three steps have no grid update pending between them (prep is skipped below on both sides)
+    size = hip.ngp_model_serialized_size; size.restype = C.c_uint64
+    nbytes = size(hm.h, 1)
+    blob = np.zeros(nbytes, np.uint8)
+    A.check(hip, hip.ngp_model_serialize_host(hm.h, ptr(blob), C.c_uint64(nbytes), 1))
+    om.load_serialized(blob)
+    gp = C.c_void_p(); hip.ngp_nerf_density_grid_ptrs(t, C.byref(gp), None, None)
+    grid = np.empty(128 ** 3, np.float32); rt = C.CDLL("libamdhip64.so"); torch.cuda.synchronize()
+    assert rt.hipMemcpy(ptr(grid), gp, C.c_size_t(grid.nbytes), 2) == 0
+    C.memmove(ora.ora_nerf_density_grid(ot), grid.ctypes.data, grid.nbytes)
+    ora.ora_nerf_update_mean_and_bitfield(ot)
+    rng, grng = A.Pcg32(), A.Pcg32(); hip.ngp_nerf_get_rng(t, C.byref(rng), C.byref(grng))
+    ora.ora_nerf_set_rng(ot, C.byref(rng))
+    hs = _stats(hip, t)
+    ora.ora_nerf_set_rays_per_batch(ot, hs.rays_per_batch); ora.ora_nerf_set_training_step(ot, hs.training_step)
+    rays = hs.rays_per_batch
+    for step in range(3):
+        A.check(hip, hip.ngp_nerf_train_forward_backward(t, None)); A.check(hip, hip.ngp_nerf_train_finish(t, None))
+        assert ora.ora_nerf_train_forward_backward(ot) == 0 and ora.ora_nerf_train_finish(ot) == 0, ora.ora_last_error()
+        hs = _stats(hip, t); os_ = A.NerfStats(); ora.ora_nerf_get_stats(ot, C.byref(os_))
+        d = dict(hit=(hs.n_rays_last, os_.n_rays_last), marched=(hs.measured_batch_size_before_compaction, os_.measured_batch_size_before_compaction),
+                 compacted=(hs.measured_batch_size, os_.measured_batch_size), next_rays=(hs.rays_per_batch, os_.rays_per_batch), loss=(hs.loss, os_.loss))
+        print("trained state, step", step, "rays", rays, {k: (v, round(abs(v[0] - v[1]) / max(abs(v[1]), 1e-12), 5)) for k, v in d.items()})
+        assert hs.training_step == os_.training_step
+        tol = TRACK_TOL if step == 0 else {k: 2 * v for k, v in TRACK_TOL.items()}   # later steps inherit the (tiny) parameter differences of the earlier ones
+        for k in ("hit", "marched", "compacted", "loss"):
+            assert abs(d[k][0] - d[k][1]) <= tol[k] * abs(d[k][1]), (step, k, d[k])
+        assert abs(int(hs.rays_per_batch) - int(os_.rays_per_batch)) <= 256
+        # the next step starts from the same ray count on both sides, so that one controller rounding cannot fail it
+        A.check(hip, hip.ngp_nerf_set_rays_per_batch(t, os_.rays_per_batch)); rays = os_.rays_per_batch
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
+
+
+# relative bounds of part (b), first step; = 2 x measured in round 4 (see the docstring)
+TRACK_TOL = dict(hit=0.01, marched=0.02, compacted=0.02, loss=0.05)
 
 
 def test_training_converges(hip, ora):
@@ -590,7 +630,8 @@ def test_fused_optimizer_epilogue_is_the_separate_sweep(ora, hip):
         finally:
             hip.ngp_debug_set_flags(0)
     print("fused vs split:", losses)
-    assert losses[0] == losses[1] and losses[0][0] == 40
+    # (the loss scalar is a float atomic sum over rays: equal up to its order)
+    assert losses[0][0] == losses[1][0] == 40 and losses[0][2:] == losses[1][2:] and abs(losses[0][1] - losses[1][1]) <= 1e-5 * losses[1][1]
     n = (blobs[0][0].size - 32) // 4 // 5
     hdr = 32
     for k, name in enumerate(("master", "adam_m", "adam_v", "adam_steps", "ema")):
