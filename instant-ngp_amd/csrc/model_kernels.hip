@@ -1216,12 +1216,16 @@ DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weig
 	// beta^t as exp(t ln beta): the per-parameter step counters make powf the dominant cost of the sweep otherwise
 	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
 	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
-	return weight_fp - effective_lr * first;
+	float nw = weight_fp - effective_lr * first;
+	asm volatile("" : "+v"(nw)); // the fp32 value exists before the caller rounds it to half (no v_fma_mixlo_f16 from the unrounded expression: the master weight and its half copy must agree)
+	return nw;
 }
 // ema_step_half_precision [tcnn optimizers/ema.h]: debiased exponential moving average of the half weights
 DEV float ema_update(const AdamArgs& a, float ema_old, float w) {
 #pragma clang fp contract(off)
-	return (ema_old * a.ema_decay * a.ema_debias_old + w * (1 - a.ema_decay)) * a.ema_debias_new;
+	float r = (ema_old * a.ema_decay * a.ema_debias_old + w * (1 - a.ema_decay)) * a.ema_debias_new;
+	asm volatile("" : "+v"(r)); // as in adam_update: the inference half weight is the rounding of THIS fp32 value in every instantiation
+	return r;
 }
 // half -> integer multiple of 2^-24 (every finite half is one: subnormal step 2^-24, largest 65504 = 2047 << 29 units)
 DEV long long half_bits_to_fixed(uint32_t hbits) {

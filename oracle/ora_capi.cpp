@@ -104,8 +104,8 @@ API void ora_model_inference(void* m, const float* in, uint32_t in_stride, uint3
 API void ora_model_density(void* m, const float* pos, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride, int use_inf) {
 	((Model*)m)->density(pos, stride, n, out, out_stride, use_inf != 0);
 }
-API void ora_model_training_step_exact_sums(void* m, const float* in, uint32_t in_stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
-	((Model*)m)->training_step(in, in_stride, n, dL_dy, dy_stride, true);
+API void ora_model_training_step_exact_sums(void* m, const float* in, uint32_t in_stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, int mode) {
+	((Model*)m)->training_step(in, in_stride, n, dL_dy, dy_stride, mode);
 }
 API void ora_model_training_step(void* m, const float* in, uint32_t in_stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
 	((Model*)m)->training_step(in, in_stride, n, dL_dy, dy_stride);
@@ -231,6 +231,7 @@ API void ora_sample_cdf_2d(const float* sample, uint32_t img, const int32_t* res
 }
 API uint32_t ora_image_idx_cdf(uint32_t base_idx, uint32_t n_images, const float* cdf, float* pdf) { return image_idx_cdf(base_idx, n_images, cdf, pdf); }
 API void ora_nerf_set_rays_per_batch(void* t, uint32_t r) { ((NerfTrainer*)t)->rays_per_batch = r; }
+API void ora_nerf_set_measured(void* t, uint32_t before_compaction, uint32_t compacted) { ((NerfTrainer*)t)->measured_batch_size_before_compaction = before_compaction; ((NerfTrainer*)t)->measured_batch_size = compacted; }
 API void ora_nerf_set_rng(void* t, const ngp_pcg32* rng) { ((NerfTrainer*)t)->rng = Pcg32(*rng); }
 API void ora_nerf_set_training_step(void* t, uint32_t step) { ((NerfTrainer*)t)->training_step = step; }
 API void ora_nerf_get_rng(void* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = ((NerfTrainer*)t)->rng.pod(); *grid_rng = ((NerfTrainer*)t)->density_grid_rng.pod(); }

@@ -288,7 +288,11 @@ struct Model {
 	// exact_grid_sums (test aid, NOT the reference's arithmetic): the SAME half contributions (half)(dL/d(enc) * weight) are summed per table entry in double and rounded
 	// to half once -- the order-independent sum that the reference's chain of half atomicAdds approximates with one rounding per contribution.  The HIP path sums exactly
 	// (64-bit fixed point): tests use this variant to show that its distance from the reference-order result is the reference's own accumulation noise.
-	void training_step(const float* coords, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, bool exact_grid_sums = false) {
+	// grid_sum_mode (test aids, NOT the reference's arithmetic): 0 = the reference (chain of half adds); 1 = exact_grid_sums as described above; 2 = the UNROUNDED products
+	// dL/d(enc) * weight summed in double and rounded to half once -- the gradient the half dL/d(enc) implies, with no per-contribution rounding at all (the device merges runs of
+	// samples in one cell in fp32 before it rounds, DESIGN 3.1, so on the coarse levels it is closer to this than to mode 1).
+	void training_step(const float* coords, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, int grid_sum_mode = 0) {
+		const bool exact_grid_sums = grid_sum_mode != 0;
 		std::vector<float> dW(n_mlp, 0.f);
 		std::vector<uint16_t> dL_denc((size_t)n * n_enc);
 		#pragma omp parallel
@@ -327,7 +331,7 @@ struct Model {
 					float g = h2f(dL_denc[(size_t)i * n_enc + l * grid.F + f]);
 					for (uint32_t c = 0; c < 8; ++c) {
 						uint16_t v = f2h(g * w[c]);
-						if (exact_grid_sums) { acc[(size_t)idx[c] * grid.F + f] += (double)h2f(v); continue; }
+						if (exact_grid_sums) { acc[(size_t)idx[c] * grid.F + f] += grid_sum_mode == 2 ? (double)g * (double)w[c] : (double)h2f(v); continue; }
 						uint16_t& dst = lvl[(size_t)idx[c] * grid.F + f];
 						dst = f2h(h2f(dst) + h2f(v));
 					}

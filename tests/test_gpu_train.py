@@ -86,8 +86,12 @@ def test_training_loop_tracks_oracle(ora, hip):
     rng, grng = A.Pcg32(), A.Pcg32(); hip.ngp_nerf_get_rng(t, C.byref(rng), C.byref(grng))
     ora.ora_nerf_set_rng(ot, C.byref(rng))
     hs = _stats(hip, t)
-    ora.ora_nerf_set_rays_per_batch(ot, hs.rays_per_batch); ora.ora_nerf_set_training_step(ot, hs.training_step)
-    rays = hs.rays_per_batch
+    # 10 % fewer rays than the controller asks for, on both sides: neither K1's sample cap (the previous step's marched count) nor K3's batch clamp binds -- both drop
+    # rays in an order that differs by design (scrambled slots vs index order)
+    rays = int(hs.rays_per_batch * 0.9) // 256 * 256
+    A.check(hip, hip.ngp_nerf_set_rays_per_batch(t, rays))
+    ora.ora_nerf_set_rays_per_batch(ot, rays); ora.ora_nerf_set_training_step(ot, hs.training_step)
+    ora.ora_nerf_set_measured(ot, hs.measured_batch_size_before_compaction, hs.measured_batch_size)
     for step in range(3):
         A.check(hip, hip.ngp_nerf_train_forward_backward(t, None)); A.check(hip, hip.ngp_nerf_train_finish(t, None))
         assert ora.ora_nerf_train_forward_backward(ot) == 0 and ora.ora_nerf_train_finish(ot) == 0, ora.ora_last_error()
@@ -100,13 +104,15 @@ def test_training_loop_tracks_oracle(ora, hip):
         for k in ("hit", "marched", "compacted", "loss"):
             assert abs(d[k][0] - d[k][1]) <= tol[k] * abs(d[k][1]), (step, k, d[k])
         assert abs(int(hs.rays_per_batch) - int(os_.rays_per_batch)) <= 256
-        # the next step starts from the same ray count on both sides, so that one controller rounding cannot fail it
-        A.check(hip, hip.ngp_nerf_set_rays_per_batch(t, os_.rays_per_batch)); rays = os_.rays_per_batch
+        # the next step starts from the same ray count on both sides, 5 % fewer than this one: K1's sample cap is the PREVIOUS step's marched count (testbed_nerf.cu:3055-3060),
+        # so a step that marches more than its predecessor drops rays -- in slot order on the device, in index order in the oracle (measured: 2622 vs 2508 rays kept)
+        rays = int(rays * 0.95) // 256 * 256
+        A.check(hip, hip.ngp_nerf_set_rays_per_batch(t, rays)); ora.ora_nerf_set_rays_per_batch(ot, rays)
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
 
 
 # relative bounds of part (b), first step; = 2 x measured in round 4 (see the docstring)
-TRACK_TOL = dict(hit=0.01, marched=0.02, compacted=0.02, loss=0.05)
+TRACK_TOL = dict(hit=0.005, marched=0.005, compacted=0.01, loss=0.02)   # measured at the first step: 0, 0, 0, 3e-5; at the second: marched 2e-5, compacted 4e-3, loss 1.2e-2
 
 
 def test_training_converges(hip, ora):
@@ -620,12 +626,12 @@ def test_fused_optimizer_epilogue_is_the_separate_sweep(ora, hip):
             nbytes = size(s["hm"].h, 1)
             buf = np.zeros(nbytes, np.uint8)
             A.check(hip, hip.ngp_model_serialize_host(s["hm"].h, ptr(buf), C.c_uint64(nbytes), 1))
-            inf = np.zeros(s["om"].n, np.uint16)
-            pi = C.c_void_p(); hip.ngp_model_param_ptrs(s["hm"].h, None, None, C.byref(pi), None)
+            inf = np.zeros(s["om"].n, np.uint16); par = np.zeros(s["om"].n, np.uint16)
+            pi, pp = C.c_void_p(), C.c_void_p(); hip.ngp_model_param_ptrs(s["hm"].h, None, C.byref(pp), C.byref(pi), None)
             import torch
             torch.cuda.synchronize()
-            assert C.CDLL("libamdhip64.so").hipMemcpy(ptr(inf), pi, C.c_size_t(inf.nbytes), 2) == 0
-            blobs.append((buf, inf)); losses.append((st.training_step, st.loss, st.rays_per_batch, st.measured_batch_size))
+            assert C.CDLL("libamdhip64.so").hipMemcpy(ptr(inf), pi, C.c_size_t(inf.nbytes), 2) == 0 and C.CDLL("libamdhip64.so").hipMemcpy(ptr(par), pp, C.c_size_t(par.nbytes), 2) == 0
+            blobs.append((buf, inf, par)); losses.append((st.training_step, st.loss, st.rays_per_batch, st.measured_batch_size))
             hip.ngp_nerf_destroy(t); ora.ora_nerf_destroy(s["ot"])
         finally:
             hip.ngp_debug_set_flags(0)
@@ -638,5 +644,7 @@ def test_fused_optimizer_epilogue_is_the_separate_sweep(ora, hip):
         a = blobs[0][0][hdr + k * n * 4: hdr + (k + 1) * n * 4].view(np.uint32); b = blobs[1][0][hdr + k * n * 4: hdr + (k + 1) * n * 4].view(np.uint32)
         bad = np.flatnonzero(a != b)
         assert bad.size == 0, (name, bad.size, bad[:8].tolist())
-    assert np.array_equal(blobs[0][1], blobs[1][1]), "inference (EMA) half parameters differ"
+    for k, name in ((1, "inference (EMA) half parameters"), (2, "half parameters")):
+        bad = np.flatnonzero(blobs[0][k] != blobs[1][k])
+        assert bad.size == 0, (name, bad.size, bad[:8].tolist(), blobs[0][k][bad[:8]].tolist(), blobs[1][k][bad[:8]].tolist())
     assert np.array_equal(blobs[0][0][:hdr], blobs[1][0][:hdr])
