@@ -780,6 +780,9 @@ static __device__ __forceinline__ float half_incl_scan(float x) {
 // RPW = rays per wavefront.  1: one wavefront per ray (64 samples per pass iteration).  2 (production): the two 32-lane halves of a wavefront work on two rays --
 // a trained scene keeps ~10 samples per ray, so a 64-lane wavefront per ray wastes 5/6 of every instruction (the kernel is VALU-issue bound);
 // the per-ray values move from scalar to per-lane registers, the scans become segmented, and both halves iterate until the longer ray is done.
+// (Four rays per wavefront -- 16-lane DPP rows -- were measured in round 4: 0.0632 / 0.0646 / 0.0651 ms against 0.0615 / 0.0631 / 0.0629 ms for two, interleaved on one box,
+// profiles/r04_microbench_k3_four_rays_per_wave_no_gain.log: below 32 lanes per ray the kernel is bound by its per-ray dependent loads and the workgroup's span atomic, not
+// by instruction issue.  Not kept.)
 // ERR: error-proportional pixel sampling / error-map accumulation compiled in (off in the production instance: the extra live values cost it 16 bytes of scratch).
 // PLAIN: train_mode Nerf and no depth supervision, as compile-time facts (the production instance): the Rfl / depth accumulators and their scans disappear.
 template <int RPW, bool ERR, bool PLAIN>
@@ -795,10 +798,12 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
 	const uint32_t sub = lane / LPR, sl = lane % LPR, seg0 = sub * LPR; // which ray of the wavefront, lane inside the ray's segment, the segment's first lane
 	auto uni = [&](uint32_t v) { return RPW == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; }; // per-ray values: scalar when the wavefront has one ray
+	static_assert(RPW == 1 || RPW == 2, "rays per wavefront");
 	auto seg_prod = [&](float x) { return RPW == 1 ? wave_incl_scan<true>(x) : half_incl_scan<true>(x); };
 	auto seg_sum = [&](float x) { return RPW == 1 ? wave_incl_scan<false>(x) : half_incl_scan<false>(x); };
 	auto seg_total = [&](float x) { return __shfl(seg_sum(x), (int)(seg0 + LPR - 1u), 64); };       // sum over the ray's segment, in every lane of it
-	auto seg_mask = [&](bool pred) { const uint64_t m = __ballot(pred); return RPW == 1 ? m : (m >> seg0) & 0xffffffffull; }; // ballot restricted to the segment
+	constexpr uint64_t SEG_BITS = LPR >= 64u ? ~0ull : ((1ull << (LPR & 63u)) - 1ull);
+	auto seg_mask = [&](bool pred) { const uint64_t m = __ballot(pred); return RPW == 1 ? m : (m >> seg0) & SEG_BITS; }; // ballot restricted to the segment
 	const Box aabb(a.aabb);
 	const float EPSILON = 1e-4f;
 	float block_loss = 0.f; // thread 0 only
@@ -915,14 +920,13 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	// one global atomic per workgroup reserves the spans of its rays
 	if (sl == 0) s_cnt[wid * RPW + sub] = active ? compacted : 0u;
 	__syncthreads();
-	if (threadIdx.x == 0) {
+	if (threadIdx.x == 0) { // exclusive prefix of the workgroup's counts (left in s_cnt) + its total
 		uint32_t tot = 0;
-		for (uint32_t w = 0; w < RPB; ++w) tot += s_cnt[w];
+		for (uint32_t w = 0; w < RPB; ++w) { const uint32_t cw = s_cnt[w]; s_cnt[w] = tot; tot += cw; }
 		s_base = tot ? atomicAdd(a.numsteps_counter_compacted, tot) : 0u;
 	}
 	__syncthreads();
-	uint32_t compacted_base = s_base;
-	for (uint32_t w = 0; w < wid * RPW + sub; ++w) compacted_base += s_cnt[w];
+	const uint32_t compacted_base = s_base + s_cnt[wid * RPW + sub];
 	float my_loss = 0.f;
 	if (active) {
 		compacted = min(a.max_samples_compacted - min(a.max_samples_compacted, compacted_base), compacted);
