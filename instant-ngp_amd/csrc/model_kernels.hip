@@ -148,6 +148,8 @@ DEV h4 level_features4(const __half* __restrict__ table, const LevelConst& lc, f
 		}
 	} else {
 #pragma unroll
+		// (round 4: the same gathers with the nt policy -- global_load ... nt, L1 bypassed -- make K2 0.133 -> 0.21 ms: the x-adjacent corner pairs and the coarse
+		// levels live on L1 hits; profiles/r04_microbench_k2_nt_gathers_slower.log)
 		for (int c = 0; c < 8; ++c) v[c] = t[cr.idx[c]];  // 8 independent 8-byte gathers in flight
 	}
 	h2 r0 = {(_Float16)0.f, (_Float16)0.f}, r1 = r0;
