@@ -38,7 +38,7 @@ static std::vector<ProfEntry> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 static double g_prof_ms[P_COUNT]; static uint64_t g_prof_n[P_COUNT];
 static const char* kProfNames[P_COUNT] = {"k_generate_training_samples", "k_inference", "k_compute_loss", "k_fill_rollover", "k_train_fwd_bwd", "k_wgrad",
-	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters", "k_grad_bin+accumulate"};
+	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters", "k_grad_bin+accumulate", "k_encode_tiles_xcd"};
 static hipEvent_t prof_event() {
 	if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
 	hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -1278,6 +1278,7 @@ struct ngp_nerf {
 	uint32_t k2_rounds = 1, k2_tile_w = 16; // rounds 1 = one launch, every wavefront follows its rays front to back (default); 2..8 = list-driven rounds (round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest).  Tile width 16: two rays per wavefront, 383k instead of 556k evaluations per step.  Measured per step (profiles/r02_microbench_k2.log, r02_microbench_final.log): 3 rounds x 32 = 0.171 ms, 1 x 32 = 0.131 ms, 1 x 16 = 0.112 ms.  NGP_K2_ROUNDS / NGP_K2_TILE override.
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
+	bool k2_xcd_encode = false; uint32_t* xcd_work = nullptr; uint2* k2_enc_lv = nullptr; // k_encode_tiles_xcd: work counters (zero between launches), level-major encodings of the round-0 tiles
 	uint4* k2_enc = nullptr; uint32_t* src_index = nullptr; bool k2_enc_valid = false; // K2's per-sample encodings and K3's row -> sample map for T1 (EncStashIn); valid: written by this step's K2 / K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; uint32_t* r_n_inf = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
@@ -1309,6 +1310,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	t->density_grid_rng = make_rng(t->rng.next_uint()); // testbed.cu:4178
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
+	if (const char* e = getenv("NGP_K2_XCD_ENCODE")) t->k2_xcd_encode = atoi(e) != 0;
 	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 1), K2_ROUNDS);
 	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : atoi(e) == 8 ? 8u : 16u;
 	if (t->k2_tile_w == 8) t->k2_rounds = 1;
@@ -1361,7 +1363,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->xcd_work, (void*)t->k2_enc_lv}) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
 }
@@ -1587,6 +1589,16 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		const bool two_pass_k3 = (g_debug_flags & DBG_K3_TWO_PASS) && !(o.depth_supervision_lambda > 0.f) && !error_map_wanted(t) && !t->error_cycle_open;
 		t->k2_enc_valid = t->model->gm.F == 4 && t->model->cfg.n_hidden_layers_rgb == 2 && !(g_debug_flags & DBG_T1_NO_K2_STASH) && !two_pass_k3;
 		la.enc_out = t->k2_enc_valid ? t->k2_enc : nullptr;
+		// ABLATION (off by default; NGP_K2_XCD_ENCODE=1 when the trainer is created): level-per-XCD encoding of the first tile of every ray (nearly all evaluated samples),
+		// then K2 loads instead of gathering them.  Built and measured in round 4 (VERDICT r3 item 4 i): the encoding stage alone takes 0.105 ms against 0.120 ms for the
+		// whole fused K2 -- a 4 MB level does not stay resident in a 4 MiB L2 next to the streamed coordinates (TCC hit rate 66 %, still 1 M fabric lines per launch),
+		// profiles/r04_microbench_k2_xcd_encode.log.  Same encodings bit for bit (tests/test_gpu_train.py::test_xcd_encode_ablation_is_bit_identical).
+		if (t->k2_xcd_encode && t->model->gm.F == 4 && t->k2_rounds == 1 && (t->k2_tile_w == 16 || t->k2_tile_w == 32) && t->model->gm.n_levels <= 16) {
+			if (!t->xcd_work) { if (dev_alloc(&t->xcd_work, 32) || dev_alloc(&t->k2_enc_lv, (size_t)t->model->gm.n_levels * max_samples)) return 1; HIPCHK(hipMemsetAsync(t->xcd_work, 0, 32 * 4, s)); }
+			ProfScope ps2(P_K2_ENCODE_XCD, s);
+			launch_encode_tiles_xcd(s, t->model->gm_dev, model_ptrs(t->model, false).grid, t->coords, 7, t->k2_tiles, &c->ray_counter, t->k2_tile_cap, t->k2_tile_w, t->k2_enc_lv, max_samples, t->xcd_work, t->model->gm.n_levels);
+			la.enc_pre = 1; la.enc_lv = t->k2_enc_lv; la.enc_lv_stride = max_samples;
+		}
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la, t->model->gm.F);
 	  } else {
 	  t->k2_enc_valid = false; // eager K2 (ablation): T1 gathers
