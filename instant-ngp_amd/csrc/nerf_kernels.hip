@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 // bit-identical, the rest carry <= 2-ulp offsets in t (tests/test_gpu_nerf.py quantifies both).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
+constexpr uint32_t LAT_MAX_POINTS = LAT_MAX_CHUNKS * 64;
 constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
 constexpr uint32_t K1_TICKET_CLASSES = 32; // sub-counters of k1_count's workgroup ticket
 constexpr uint32_t K1_MAX_RANGE = 256;    // most slots a k1_count / k1_write workgroup owns (grid >= ceil(max rays / 256))
@@ -197,33 +198,33 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	uint32_t img; float pix_pdf;
 	f2 uv = training_pixel(a.cdf, rng, i, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
 	const ngp_image_meta& m = a.metadata[img];
-	const f4 tex = read_rgba(uv, m.resolution, m.pixels, m.image_data_type);
-	const bool masked = tex.x < 0.0f; // masked-away pixel: the ray is not marched
 	RaySetup& out = rs[li];
 	if (role != 0) {
 		// K3's target colour (testbed_nerf.cu:930-960): same rng stream position, same arithmetic -- channel c of every 3-vector
 		const uint32_t c = role - 1;
+		float tex_w; const float tc = read_rgba_channel(uv, m.resolution, m.pixels, m.image_data_type, c, tex_w);
+		const bool masked = m.image_data_type == NGP_IMAGE_BYTE ? tc < 0.0f : read_rgba_masked(uv, m.resolution, m.pixels, m.image_data_type); // masked-away pixel (red < 0): the ray is not marched
 		float tgt = 0.f, bg = 0.f;
 		if (!masked) {
 			(void)rng.next_float(); // motionblur_time
 			bg = a.background_color[c];
 			if (a.random_bg_color) { for (uint32_t k = 0; k <= c; ++k) bg = rng.next_float(); }
 			bg = srgb_to_linear(bg);
-			const float tc = c == 0 ? tex.x : c == 1 ? tex.y : tex.z;
 			if (a.linear_colors || !a.color_space_srgb) {
-				tgt = tc + (1.0f - tex.w) * bg;
+				tgt = tc + (1.0f - tex_w) * bg;
 				if (!a.linear_colors) { tgt = linear_to_srgb(tgt); bg = linear_to_srgb(bg); }
 			} else {
 				bg = linear_to_srgb(bg);
-				if (tex.w > 0) tgt = linear_to_srgb(tc / tex.w) * tex.w + (1.0f - tex.w) * bg;
+				if (tex_w > 0) tgt = linear_to_srgb(tc / tex_w) * tex_w + (1.0f - tex_w) * bg;
 				else tgt = bg;
 			}
 		}
 		out.tgt[c] = tgt; out.tgt[3 + c] = bg;
 		return;
 	}
+	const bool masked = read_rgba_masked(uv, m.resolution, m.pixels, m.image_data_type);
 	const Box aabb(a.aabb);
-	float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f}, startt = 0.f, nprime = 0.f; uint32_t flags = 0;
+	float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f}, dn[3] = {0.f, 0.f, 1.f}, startt = 0.f, nprime = 0.f; uint32_t n_in = 0;
 	if (!masked) {
 		const float motionblur_time = rng.next_float();
 		const M43 xform = xform_given_rolling_shutter(a.xforms[img], m.rolling_shutter, uv, motionblur_time); // common_device.cuh:670-674
@@ -233,14 +234,23 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 		f2 tminmax = aabb.ray_intersect(ro, rdn);
 		tminmax.x = fmaxf(tminmax.x, 0.0f);
 		startt = advance_n_steps(tminmax.x, a.cone_angle_constant, rng.next_float());
-		o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; d[0] = rd.x; d[1] = rd.y; d[2] = rd.z;
+		o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; d[0] = rd.x; d[1] = rd.y; d[2] = rd.z; dn[0] = rdn.x; dn[1] = rdn.y; dn[2] = rdn.z;
 		nprime = to_stepping_space(startt, a.cone_angle_constant);
-		flags = aabb.contains(ro + startt * rdn) ? 1u : 0u;
+		// The lattice points inside the box are a PREFIX of the lattice (every coordinate of ro + t_j * rdn is monotonic in j, in fp32 as well): their number by bisection
+		// with the marchers' own arithmetic.  0 = the march starts outside the box (no samples).
+		if (aabb.contains(ro + startt * rdn)) {
+			uint32_t lo = 0u, hi = LAT_MAX_POINTS; // invariant: point lo is inside, point hi is outside (or past the lattice)
+			while (hi - lo > 1u) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (aabb.contains(ro + from_stepping_space(nprime + (float)mid, a.cone_angle_constant) * rdn)) lo = mid; else hi = mid;
+			}
+			n_in = hi;
+		}
 		// K3's target depth (testbed_nerf.cu:1027): distance along the unnormalised direction; <= 0 = not supervised
 		out.tgt[6] = sqrtf(dot3(rd, rd)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
 	} else out.tgt[6] = -1.0f;
-	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2];
-	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = flags; out.ray_index = i;
+	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2]; out.rdn[0] = dn[0]; out.rdn[1] = dn[1]; out.rdn[2] = dn[2];
+	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = n_in; out.ray_index = i;
 	if (!a.ray_targets_out) for (int k = 0; k < 6; ++k) out.tgt[k] = 0.f;
 }
 
@@ -266,6 +276,44 @@ static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], u
 	block_total = sm[0] + sm[1] + sm[2] + sm[3];
 	return woff + x - tsum;
 }
+// Tail of both counting kernels: publish the workgroup's packed {samples, rays} total; the last workgroup to arrive turns the totals into exclusive offsets + the two global counters.
+static __device__ __forceinline__ void k1_publish_and_scan(const K1Args& a, uint64_t wave_total, uint64_t* __restrict__ partial, uint32_t* __restrict__ done, uint64_t* s_tot /* 4 */, uint64_t* s_scan /* 4 */, uint32_t& s_ticket) {
+	const uint32_t lane = threadIdx.x & 63u;
+	if (lane == 0) s_tot[threadIdx.x >> 6] = wave_total;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		// The total is published with a RETURNING device-scope atomic (performed at the coherence point; its return value is awaited before the
+		// ticket is drawn) instead of store + __threadfence(): an agent-scope release fence writes back the XCD's whole L2 on this multi-XCD
+		// part, and 2048 of them made this kernel 47 us slower (profiles/r02_k1_experiments.txt).
+		const uint64_t prev = atomicExch((unsigned long long*)(partial + blockIdx.x), (unsigned long long)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3])));
+		// two-level ticket: one counter word retires only ~90 returning atomics per microsecond, so workgroup b draws from sub-counter
+		// b % 32 and only the last of each residue class draws from the top counter
+		const uint32_t cls = blockIdx.x % K1_TICKET_CLASSES, n_cls = (gridDim.x - cls + K1_TICKET_CLASSES - 1) / K1_TICKET_CLASSES;
+		uint32_t last = 0u;
+		if (atomicAdd(done + 1 + cls, (uint32_t)(prev >> 63) + 1u) == n_cls - 1) { // (prev >> 63 == 0: the data dependence orders the ticket behind the exchange)
+			atomicExch(done + 1 + cls, 0u);
+			last = atomicAdd(done, 1u) == min(gridDim.x, K1_TICKET_CLASSES) - 1 ? 1u : 0u;
+		}
+		s_ticket = last;
+	}
+	__syncthreads();
+	if (!s_ticket) return;
+	// last workgroup: every total has been exchanged in; read them at the coherence point as well (atomic RMW with 0)
+	uint64_t run = 0ull;
+	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
+		uint64_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? (uint64_t)atomicAdd((unsigned long long*)(partial + e), 0ull) : 0ull; }
+		uint64_t tot;
+		uint64_t pre = run + block_excl_scan_1024(v, s_scan, tot);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; if (e < gridDim.x) partial[e] = pre; pre += v[k]; }
+		run += tot;
+		__syncthreads(); // s_scan is reused by the next round
+	}
+	if (threadIdx.x == 0) { *a.numsteps_counter = (uint32_t)run; *a.ray_counter = (uint32_t)(run >> 32); atomicExch(done, 0u); }
+}
+
 // Prefix sum over the per-ray counts without scan launches: workgroup b owns the CONTIGUOUS slot range [b n / G, (b + 1) n / G) (slots are
 // scrambled rays, so the ranges are statistically equal), publishes the packed {samples, rays} total of its range, and the last workgroup to
 // finish (ticket counter) turns the G totals into exclusive offsets + the two global counters.  k1_write, launched with the same G, re-scans
@@ -291,14 +339,10 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	// access, and a chunk without any coarse hit costs no memory latency at all
 	extern __shared__ uint32_t s_coarse[];
 	const bool prefilter = a.bitfield_coarse != nullptr && a.bitfield_linear != nullptr;
-	// single cascade + constant step (cone_angle 0): 8-point lattice segments (7 steps = 0.012 < one coarse cell = 0.031) are rejected by ONE test
-	// of their midpoint against the DILATED coarse grid (second half of the LDS copy), whole chunks without a hit are not evaluated at all
-	const bool group_skip = SINGLE_CASCADE && prefilter && a.segment_skip && a.cone_angle_constant <= 1e-5f;
 	if (prefilter && li_begin < li_end) {
 		// every level the march can ask for: mip_from_dt returns max(mip_from_pos, exponent of the step), which exceeds max_mip for long steps (pooled levels)
 		const uint32_t n_words = (SINGLE_CASCADE ? 1u : a.n_mips) * COARSE_WORDS;
 		for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) s_coarse[w] = a.bitfield_coarse[w];
-		if (group_skip) for (uint32_t w = threadIdx.x; w < COARSE_WORDS; w += blockDim.x) s_coarse[COARSE_WORDS + w] = a.bitfield_coarse[a.n_mips * COARSE_WORDS + w];
 	}
 	__syncthreads();
 	uint64_t wave_total = 0ull; // packed {samples (low 32), rays with samples (high 32)} of this wavefront's rays
@@ -347,19 +391,6 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
 			uint64_t m[K1_GROUP], in[K1_GROUP];
 			uint32_t mip0[K1_GROUP]; bool uni[K1_GROUP]; // exact skip: the chunk's mip (of its first point) / is it the same for all points inside the box?
-			uint64_t seg_hit = ~0ull, seg_in = ~0ull; // lane l <-> the 8 lattice points ch0 * 64 + 8 l .. + 7 (chunk u = lanes 8 u .. 8 u + 7)
-			if (group_skip) {
-				const uint32_t j0 = ch0 * 64 + 8 * lane;
-				const float tm = (r.nprime + ((float)j0 + 3.5f)) * MIN_CONE_STEP; // from_stepping_space at cone_angle 0
-				const f3 pm = ro + tm * rdn;
-				const uint32_t cx = (uint32_t)clampi((int)floorf(pm.x * (float)COARSE_SIZE), 0, (int)COARSE_SIZE - 1), cy = (uint32_t)clampi((int)floorf(pm.y * (float)COARSE_SIZE), 0, (int)COARSE_SIZE - 1),
-					cz = (uint32_t)clampi((int)floorf(pm.z * (float)COARSE_SIZE), 0, (int)COARSE_SIZE - 1);
-				const uint32_t cidx = cx + COARSE_SIZE * (cy + COARSE_SIZE * cz);
-				seg_hit = __ballot(((s_coarse[COARSE_WORDS + (cidx >> 5)] >> (cidx & 31u)) & 1u) != 0u);
-				// the march is inside the box from its first point up to its exit: a chunk lies wholly outside iff its FIRST point does (exact test)
-				const float t0 = lattice_t(r, j0, a.cone_angle_constant);
-				seg_in = __ballot(aabb.contains(ro + t0 * rdn));
-			}
 			// The in-box lattice points of a ray are a contiguous range (every coordinate of ro + t * rdn is monotonic in t, in fp32 as well, and so is t in
 			// j), so a chunk whose FIRST point is outside the box lies wholly outside: one test per chunk (lane u = chunk u of the group) instead of 64 point
 			// evaluations.  A ray crosses ~9 chunks, the groups are 8 wide: this skips the ~6 chunks behind the exit that the last group used to evaluate
@@ -368,10 +399,6 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				if (!((first_in >> u) & 1u) && !a.no_first_point_skip) { m[u] = 0ull; in[u] = 0ull; mip0[u] = 0u; uni[u] = true; continue; }
-				if (group_skip && !((seg_hit >> (8 * u)) & 0xffull)) { // no occupied cell anywhere near the chunk's 64 points
-					m[u] = 0ull; in[u] = ((seg_in >> (8 * u)) & 1ull) ? ~0ull : 0ull; mip0[u] = 0u; uni[u] = true;
-					continue;
-				}
 				bool inside, occ; uint32_t mip, skip;
 				eval_point((ch0 + u) * 64 + lane, false, inside, occ, mip, skip);
 				m[u] = __ballot(occ);
@@ -425,39 +452,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	}
 	wave_total += (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
 	}
-	if (lane == 0) s_tot[threadIdx.x >> 6] = wave_total;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		// The total is published with a RETURNING device-scope atomic (performed at the coherence point; its return value is awaited before the
-		// ticket is drawn) instead of store + __threadfence(): an agent-scope release fence writes back the XCD's whole L2 on this multi-XCD
-		// part, and 2048 of them made this kernel 47 us slower (profiles/r02_k1_experiments.txt).
-		const uint64_t prev = atomicExch((unsigned long long*)(partial + blockIdx.x), (unsigned long long)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3])));
-		// two-level ticket: one counter word retires only ~90 returning atomics per microsecond, so workgroup b draws from sub-counter
-		// b % 32 and only the last of each residue class draws from the top counter
-		const uint32_t cls = blockIdx.x % K1_TICKET_CLASSES, n_cls = (gridDim.x - cls + K1_TICKET_CLASSES - 1) / K1_TICKET_CLASSES;
-		uint32_t last = 0u;
-		if (atomicAdd(done + 1 + cls, (uint32_t)(prev >> 63) + 1u) == n_cls - 1) { // (prev >> 63 == 0: the data dependence orders the ticket behind the exchange)
-			atomicExch(done + 1 + cls, 0u);
-			last = atomicAdd(done, 1u) == min(gridDim.x, K1_TICKET_CLASSES) - 1 ? 1u : 0u;
-		}
-		s_ticket = last;
-	}
-	__syncthreads();
-	if (!s_ticket) return;
-	// last workgroup: every total has been exchanged in; read them at the coherence point as well (atomic RMW with 0)
-	uint64_t run = 0ull;
-	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
-		uint64_t v[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? (uint64_t)atomicAdd((unsigned long long*)(partial + e), 0ull) : 0ull; }
-		uint64_t tot;
-		uint64_t pre = run + block_excl_scan_1024(v, s_scan, tot);
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; if (e < gridDim.x) partial[e] = pre; pre += v[k]; }
-		run += tot;
-		__syncthreads(); // s_scan is reused by the next round
-	}
-	if (threadIdx.x == 0) { *a.numsteps_counter = (uint32_t)run; *a.ray_counter = (uint32_t)(run >> 32); atomicExch(done, 0u); }
+	k1_publish_and_scan(a, wave_total, partial, done, s_tot, s_scan, s_ticket);
 }
 
 __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __restrict__ rs, const uint64_t* __restrict__ masks, const uint64_t* __restrict__ partial) {
@@ -526,6 +521,176 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 	}
 }
 
+// ---- K1 for one cascade and a constant step (aabb_scale 1, cone_angle 0: the headline configuration), round 4 ------------------------------------------------------------
+// k1_count evaluates every lattice point up to the ray's exit -- 3.8 10^7 points per step for the 1.7 10^6 that become samples -- at ~70 VALU instructions per point: the
+// kernel is bound by instruction issue, not by memory.  Here the lattice is cut into SEGMENTS of 8 points.  k1_setup (thread per ray) has counted the points inside the box
+// (a prefix of the lattice, by bisection); one prepass lane per segment tests (conservatively) whether anything is occupied near the segment: its midpoint against the
+// dilated mid grid in LDS (k_build_mid_dilated_bitfield).  The segments that pass are compacted into a list (prefix popcount -> LDS), and only their points are evaluated,
+// sixteen segments (two independent occupancy loads per lane) per iteration, with exactly the arithmetic of k1_count's eval_point.  Candidates are visited in lattice
+// order, so the ballot of the occupied ones IS the ray's sample list in output order: the kernel stores each sample's lattice index j (16 bits, N_STEPS entries per slot)
+// and k1_write_list reads it back -- one lane per SAMPLE, where k1_write spends a 64-lane iteration per chunk on ~3 samples.  Same samples bit for bit
+// (tests/test_gpu_nerf.py::test_k1_ablation_variants_are_the_same_marcher runs the chunk kernels as the ablation).
+constexpr uint32_t K1_SEG = 8;                                   // lattice points per segment
+constexpr uint32_t K1_MAX_SEGS = LAT_MAX_POINTS / K1_SEG;         // 256 per ray
+// this workgroup's contiguous slot range (32-bit arithmetic when it cannot overflow: the 64-bit division is ~110 scalar instructions)
+static __device__ __forceinline__ void k1_slot_range(uint32_t n_local, uint32_t b, uint32_t g, uint32_t& li_begin, uint32_t& li_end) {
+	if (n_local <= (1u << 19) && g <= (1u << 12)) { li_begin = n_local * b / g; li_end = n_local * (b + 1u) / g; }
+	else { li_begin = (uint32_t)(((uint64_t)n_local * b) / g); li_end = (uint32_t)(((uint64_t)n_local * (b + 1u)) / g); }
+}
+__global__ void __launch_bounds__(256) k1_count_segments(K1Args a, RaySetup* __restrict__ rs, uint16_t* __restrict__ jlist, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
+	__shared__ uint64_t s_tot[4];
+	__shared__ uint64_t s_scan[4];
+	__shared__ uint32_t s_ticket;
+	__shared__ uint8_t s_seg[4][K1_MAX_SEGS]; // per wavefront: the segments of its ray that passed the prepass, in lattice order
+	extern __shared__ uint32_t s_pre[];       // [COARSE_WORDS coarse of cascade 0][MID_WORDS dilated mid grid]
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
+	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	uint32_t li_begin, li_end; k1_slot_range(ray_end - ray_begin, blockIdx.x, gridDim.x, li_begin, li_end);
+	if (li_begin < li_end) { // 36 KiB per workgroup: all nine 16-byte loads of a thread in flight before the first LDS store
+		static_assert(COARSE_WORDS == 4 * 256 && MID_WORDS == 8 * 4 * 256, "one + eight uint4 per thread of a 256-thread workgroup");
+		const uint4* src_c = (const uint4*)a.bitfield_coarse; const uint4* src_m = (const uint4*)(a.bitfield_coarse + (size_t)a.n_mips * COARSE_WORDS);
+		uint4 v[9];
+		v[0] = src_c[threadIdx.x];
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) v[1 + k] = src_m[threadIdx.x + 256u * k];
+		uint4* dst = (uint4*)s_pre;
+		dst[threadIdx.x] = v[0];
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) dst[256u + threadIdx.x + 256u * k] = v[1 + k];
+	}
+	__syncthreads();
+	const uint32_t* s_mid = s_pre + COARSE_WORDS;
+	uint64_t wave_total = 0ull;
+	for (uint32_t li = li_begin + wid; li < li_end; li += 4) {
+		const RaySetup& r = rs[li];
+		const uint32_t n_in = r.flags; // lattice points inside the box: [0, n_in)
+		uint32_t cnt = 0;
+		if (n_in) {
+			const f3 ro = ld3(r.o), rdn = ld3(r.rdn);
+			const float startt = r.startt, nprime = r.nprime;
+			const uint32_t n_segs = (n_in + K1_SEG - 1u) / K1_SEG;
+			// prepass: one lane per segment
+			uint32_t n_hit = 0;
+			for (uint32_t s0 = 0; s0 < n_segs; s0 += 64u) {
+				const uint32_t sg = s0 + lane;
+				const f3 pm = ro + ((nprime + ((float)(sg * K1_SEG) + 0.5f * (float)(K1_SEG - 1))) * MIN_CONE_STEP) * rdn;
+				const uint32_t mx = (uint32_t)clampi((int)(pm.x * (float)MID_SIZE), 0, (int)MID_SIZE - 1), my = (uint32_t)clampi((int)(pm.y * (float)MID_SIZE), 0, (int)MID_SIZE - 1),
+					mz = (uint32_t)clampi((int)(pm.z * (float)MID_SIZE), 0, (int)MID_SIZE - 1);
+				const uint32_t midx = mx + MID_SIZE * (my + MID_SIZE * mz);
+				const bool hit = sg < n_segs && ((s_mid[midx >> 5] >> (midx & 31u)) & 1u) != 0u;
+				const uint64_t hm = __ballot(hit);
+				if (hit) s_seg[wid][n_hit + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint8_t)sg;
+				n_hit += (uint32_t)__popcll(hm);
+			}
+			__builtin_amdgcn_wave_barrier(); // the list is read by other lanes of the same wavefront (LDS operations of a wavefront complete in order)
+			uint16_t* jl = jlist + (size_t)li * N_STEPS;
+			for (uint32_t h0 = 0; h0 < n_hit && cnt < N_STEPS; h0 += 16u) {
+				bool occ[2]; uint32_t jj[2];
+#pragma unroll
+				for (uint32_t u = 0; u < 2; ++u) {
+					const uint32_t h = min(h0 + 8u * u + (lane >> 3), n_hit - 1u);
+					const uint32_t j = (uint32_t)s_seg[wid][h] * K1_SEG + (lane & 7u);
+					jj[u] = j;
+					const f3 pos = ro + (j == 0u ? startt : (nprime + (float)j) * MIN_CONE_STEP) * rdn; // lattice_t at cone_angle 0
+					occ[u] = h0 + 8u * u + (lane >> 3) < n_hit && j < n_in && occupied_at_linear_prefiltered(pos, a.bitfield_linear, s_pre, 0u);
+				}
+#pragma unroll
+				for (uint32_t u = 0; u < 2; ++u) {
+					const uint64_t m = __ballot(occ[u]);
+					const uint32_t k = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+					if (occ[u] && k < N_STEPS) jl[k] = (uint16_t)jj[u];
+					cnt += (uint32_t)__popcll(m);
+				}
+			}
+			cnt = min(cnt, N_STEPS);
+			__builtin_amdgcn_wave_barrier(); // s_seg is rewritten for the next ray
+		}
+		if (lane == 0) rs[li].count = cnt;
+		wave_total += (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
+	}
+	k1_publish_and_scan(a, wave_total, partial, done, s_tot, s_scan, s_ticket);
+}
+
+// One lane per SAMPLE of the workgroup's slot range (a contiguous span of the sample buffer): the sample's ray by bisection over the range's span offsets in LDS, its lattice
+// index from the list k1_count_segments left, the position with k1_write's arithmetic; the 7-float records of 64 samples are transposed through LDS so that the wavefront
+// stores 7 x 256 contiguous bytes instead of 7 x 64 dwords at a 28-byte stride.  K1_WRITE_SPLIT workgroups share one slot range (its 64-sample batches interleaved), so
+// that the grid has twice the wavefronts of the counting kernel's (whose LDS image limits it to four workgroups per CU).
+constexpr uint32_t K1_WRITE_SPLIT = 2;
+__global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* __restrict__ rs, const uint16_t* __restrict__ jlist, const uint64_t* __restrict__ partial) {
+	__shared__ uint64_t s_scan[4];
+	__shared__ uint32_t s_base[K1_MAX_RANGE + 1]; // exclusive prefix of the range's sample counts (relative to the range's first sample)
+	__shared__ uint32_t s_cut;                    // first sample (relative) of the first ray that does not fit under the sample cap
+	__shared__ float s_stage[4][64 * 7];
+	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
+	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
+	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
+	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	const Box aabb(a.aabb);
+	const uint32_t range = blockIdx.x / K1_WRITE_SPLIT, part = blockIdx.x % K1_WRITE_SPLIT;
+	uint32_t li_begin, li_end; k1_slot_range(ray_end - ray_begin, range, gridDim.x / K1_WRITE_SPLIT, li_begin, li_end);
+	const uint32_t n_slots = li_end - li_begin; // <= K1_MAX_RANGE
+	if (threadIdx.x == 0) s_cut = 0xffffffffu;
+	const uint64_t range_off = partial[range]; // {first sample, first ray slot} of the range
+	uint32_t my_count = 0;
+	{
+		uint64_t v[4] = {0ull, 0ull, 0ull, 0ull};
+		if (threadIdx.x < n_slots) { my_count = rs[li_begin + threadIdx.x].count; v[0] = (uint64_t)my_count | ((uint64_t)(my_count > 0 ? 1u : 0u) << 32); }
+		uint64_t tot;
+		const uint64_t pre = block_excl_scan_1024(v, s_scan, tot); // (contains a barrier: s_cut is initialised behind it)
+		if (threadIdx.x < n_slots) s_base[threadIdx.x] = (uint32_t)pre;
+		if (threadIdx.x == 0) s_base[n_slots] = (uint32_t)tot;
+		// the ray records: one thread per ray of the range (shared between the range's workgroups)
+		if (my_count > 0) {
+			const uint32_t base = (uint32_t)range_off + (uint32_t)pre, slot = (uint32_t)(range_off >> 32) + (uint32_t)(pre >> 32);
+			const bool fits = base + my_count <= max_samples; // testbed_nerf.cu:813-815: rays past the cap are dropped
+			if (!fits) atomicMin(&s_cut, (uint32_t)pre);
+			if (threadIdx.x % K1_WRITE_SPLIT == part) {
+				const RaySetup& r = rs[li_begin + threadIdx.x];
+				a.ray_indices_out[slot] = r.ray_index;
+				ngp_ray rr; rr.o[0] = r.o[0]; rr.o[1] = r.o[1]; rr.o[2] = r.o[2]; rr.d[0] = r.d[0]; rr.d[1] = r.d[1]; rr.d[2] = r.d[2];
+				a.rays_out[slot] = rr;
+				a.numsteps_out[slot * 2 + 0] = fits ? my_count : 0u;
+				a.numsteps_out[slot * 2 + 1] = base;
+				if (a.k2_tiles0_out) { // lazy K2, round 0: the first tile of this ray (dropped rays: an empty tile)
+					const uint32_t c0 = fits ? my_count : 0u;
+					a.k2_tiles0_out[slot] = make_uint4(base, min(c0, a.k2_tile_w), slot, c0 - min(c0, a.k2_tile_w));
+				}
+				if (a.ray_targets_out) {
+					float4* tg = (float4*)(a.ray_targets_out + (size_t)slot * 8);
+					tg[0] = make_float4(r.tgt[0], r.tgt[1], r.tgt[2], r.tgt[3]); tg[1] = make_float4(r.tgt[4], r.tgt[5], r.tgt[6], 0.f);
+				}
+			}
+		}
+		__syncthreads();
+	}
+	// samples past the cap's cut are not written (dropped rays form a suffix of the slot order: the span base is monotone)
+	const uint32_t n_total = min(s_base[n_slots], s_cut);
+	float* st = s_stage[wid];
+	for (uint32_t e0 = (part * 4u + wid) * 64u; e0 < n_total; e0 += K1_WRITE_SPLIT * 4u * 64u) {
+		const uint32_t e = min(e0 + lane, n_total - 1u), n = min(n_total - e0, 64u);
+		// the sample's slot: the last one whose span starts at or before e (empty slots share their successor's offset and lose against it)
+		uint32_t lo = 0u, hi = n_slots;
+		while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_base[mid] <= e) lo = mid; else hi = mid; }
+		const RaySetup& r = rs[li_begin + lo];
+		const uint32_t j = (uint32_t)jlist[(size_t)(li_begin + lo) * N_STEPS + (e - s_base[lo])];
+		const f3 ro = ld3(r.o), rdn = ld3(r.rdn);
+		const float t = j == 0u ? r.startt : from_stepping_space(r.nprime + (float)j, a.cone_angle_constant); // lattice_t
+		const f3 pos = ro + t * rdn;
+		const float dt = calc_dt(t, a.cone_angle_constant);
+		const f3 wp = warp_position(pos, aabb), wd = warp_direction(rdn);
+		float* c = st + lane * 7u;
+		c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+		__builtin_amdgcn_wave_barrier();
+		float* co = a.coords_out + ((size_t)(uint32_t)range_off + e0) * 7;
+#pragma unroll
+		for (uint32_t q = 0; q < 7; ++q) { const uint32_t x = q * 64u + lane; if (x < n * 7u) co[x] = st[x]; }
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
 // x-major copy of the Morton-ordered bitfield (all cascades): one thread per output byte = 8 x-consecutive cells
 __global__ void k_build_linear_bitfield(const uint8_t* __restrict__ bitfield, uint8_t* __restrict__ linear, uint32_t n_bytes) {
 	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -560,28 +725,23 @@ __global__ void __launch_bounds__(256) k_build_coarse_bitfield(const uint8_t* __
 	const uint64_t m = __ballot(any);
 	if (casc < n_cascades && (threadIdx.x & 31u) == 0) coarse[t >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
 }
-// dilation of the coarse grid by one coarse cell in every direction (OR over the 3x3x3 neighbourhood), stored behind it: a clear bit proves
-// that every cell within one coarse-cell edge (4 fine cells) of ANY position inside that coarse cell is empty -- k1_count skips whole
-// 8-point lattice segments with one test of their midpoint
-__global__ void __launch_bounds__(256) k_dilate_coarse_bitfield(const uint32_t* __restrict__ coarse, uint32_t* __restrict__ dilated, uint32_t n_cascades) {
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t per = COARSE_SIZE * COARSE_SIZE * COARSE_SIZE;
-	const uint32_t casc = t / per, c = t % per;
+// "Mid" grid of cascade 0: one bit per 2x2x2 cells, DILATED by one mid cell in every direction (OR over the 6x6x6 fine cells around the mid cell).  A clear bit proves that
+// every fine cell within one mid-cell edge (2 fine cells = 1/64) of ANY position inside that mid cell is empty -- k1_count_segments rejects whole 8-point lattice segments
+// (7 steps = 0.012 long, i.e. every point within 0.006 of the midpoint in every coordinate) by one test of their midpoint.  One thread per mid cell.
+__global__ void __launch_bounds__(256) k_build_mid_dilated_bitfield(const uint8_t* __restrict__ linear, uint32_t* __restrict__ mid) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // grid = MID_SIZE^3 exactly
+	const int cx = (int)(t % MID_SIZE), cy = (int)((t / MID_SIZE) % MID_SIZE), cz = (int)(t / (MID_SIZE * MID_SIZE));
+	const int x0 = max(2 * cx - 2, 0), x1 = min(2 * cx + 3, (int)GRIDSIZE - 1); // inclusive range of fine x: at most 6 bits inside one 16-bit window
 	bool any = false;
-	if (casc < n_cascades) {
-		const int cx = (int)(c % COARSE_SIZE), cy = (int)((c / COARSE_SIZE) % COARSE_SIZE), cz = (int)(c / (COARSE_SIZE * COARSE_SIZE));
-		const uint32_t* src = coarse + (size_t)casc * COARSE_WORDS;
-		for (int dz = -1; dz <= 1; ++dz)
-			for (int dy = -1; dy <= 1; ++dy)
-				for (int dx = -1; dx <= 1; ++dx) {
-					const int x = cx + dx, y = cy + dy, z = cz + dz;
-					if (x < 0 || y < 0 || z < 0 || x >= (int)COARSE_SIZE || y >= (int)COARSE_SIZE || z >= (int)COARSE_SIZE) continue;
-					const uint32_t n = (uint32_t)x + COARSE_SIZE * ((uint32_t)y + COARSE_SIZE * (uint32_t)z);
-					any |= ((src[n >> 5] >> (n & 31u)) & 1u) != 0u;
-				}
-	}
+	for (int z = max(2 * cz - 2, 0); z <= min(2 * cz + 3, (int)GRIDSIZE - 1); ++z)
+		for (int y = max(2 * cy - 2, 0); y <= min(2 * cy + 3, (int)GRIDSIZE - 1); ++y) {
+			const uint32_t row = GRIDSIZE * ((uint32_t)y + GRIDSIZE * (uint32_t)z); // multiple of 8: the row's bits start at a byte
+			const uint32_t b0 = (row + (uint32_t)x0) >> 3, b1 = (row + (uint32_t)x1) >> 3;
+			const uint32_t w = (uint32_t)linear[b0] | ((uint32_t)linear[b1] << (8u * (b1 - b0)));
+			any |= ((w >> ((uint32_t)x0 & 7u)) & ((1u << (uint32_t)(x1 - x0 + 1)) - 1u)) != 0u;
+		}
 	const uint64_t m = __ballot(any);
-	if (casc < n_cascades && (threadIdx.x & 31u) == 0) dilated[t >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
+	if ((threadIdx.x & 31u) == 0) mid[t >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1482,11 +1642,15 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 // keeps 8 = two full rounds.  Scratch is sized for the largest grid.
 constexpr uint32_t K1_MAX_BLOCKS_PER_CU = 16;
 static uint32_t k1_blocks_per_cu(bool single_cascade) { static const int env = [] { const char* e = getenv("NGP_K1_BLOCKS_PER_CU"); return e ? std::min(std::max(atoi(e), 1), (int)K1_MAX_BLOCKS_PER_CU) : 0; }(); return env ? (uint32_t)env : single_cascade ? 6u : 8u; }
+static uint32_t k1_blocks_per_cu_segments() { static const int env = [] { const char* e = getenv("NGP_K1_SEG_BLOCKS_PER_CU"); return e ? std::min(std::max(atoi(e), 1), (int)K1_MAX_BLOCKS_PER_CU) : 0; }(); return env ? (uint32_t)env : 4u; }
 static uint32_t k1_grid(uint32_t max_local_rays, uint32_t blocks_per_cu = K1_MAX_BLOCKS_PER_CU) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * blocks_per_cu), blocks(max_local_rays, K1_MAX_RANGE)); }
 // byte offset of the workgroup totals behind the RaySetup and mask arrays (64-bit atomics: naturally aligned)
 static size_t k1_partial_offset(uint32_t max_local_rays) { return ((size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + 15) / 16 * 16; }
+// ... and, behind the ticket counters, the per-slot sample lists of k1_count_segments (N_STEPS 16-bit lattice indices per slot: 512 MiB for 2^18 slots, of which a step touches
+// the first ~64 bytes of ~5 10^4)
+static size_t k1_jlist_offset(uint32_t max_local_rays) { return k1_partial_offset(max_local_rays) + ((size_t)k1_grid(max_local_rays) * 8 + 256 + 15) / 16 * 16; }
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays) {
-	return k1_partial_offset(max_local_rays) + (size_t)k1_grid(max_local_rays) * 8 + 256;
+	return k1_jlist_offset(max_local_rays) + (size_t)max_local_rays * N_STEPS * 2;
 }
 // the ticket counter behind the workgroup totals must start at zero (k1_count's last workgroup leaves it at zero again)
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays) {
@@ -1511,17 +1675,25 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
 	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
+	if (single && a.bitfield_coarse && a.bitfield_linear && !a.chunk_march && !a.no_first_point_skip) {
+		// one cascade, constant step: segment prepass + sample lists.  36 KiB of LDS per workgroup: 4 resident per CU = the persistent grid
+		uint16_t* jlist = (uint16_t*)((char*)scratch + k1_jlist_offset(max_local_rays));
+		const uint32_t seg_grid = k1_grid(max_local_rays, k1_blocks_per_cu_segments());
+		hipLaunchKernelGGL(k1_count_segments, dim3(seg_grid), dim3(256), (COARSE_WORDS + MID_WORDS) * 4, s, a, rs, jlist, partial, done);
+		if (!count_only) hipLaunchKernelGGL(k1_write_list, dim3(seg_grid * K1_WRITE_SPLIT), dim3(256), 0, s, a, rs, jlist, partial);
+		return;
+	}
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
-	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? 2 * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? a.n_mips * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
 	if (!count_only) hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {
 	const uint32_t n_bytes = GRID_N_CELLS / 8 * n_cascades;
 	hipLaunchKernelGGL(k_build_linear_bitfield, dim3(blocks(n_bytes, 256)), dim3(256), 0, s, bitfield, linear, n_bytes);
-	if (coarse) { // [n_cascades x COARSE_WORDS coarse][n_cascades x COARSE_WORDS dilated]
+	if (coarse) { // k1_prefilter_words(n_cascades): [n_cascades x COARSE_WORDS coarse][MID_WORDS dilated mid grid of cascade 0]
 		hipLaunchKernelGGL(k_build_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, linear, coarse, n_cascades);
-		hipLaunchKernelGGL(k_dilate_coarse_bitfield, dim3(blocks(COARSE_WORDS * 32 * n_cascades, 256)), dim3(256), 0, s, coarse, coarse + (size_t)COARSE_WORDS * n_cascades, n_cascades);
+		hipLaunchKernelGGL(k_build_mid_dilated_bitfield, dim3(MID_WORDS * 32 / 256), dim3(256), 0, s, linear, coarse + (size_t)COARSE_WORDS * n_cascades);
 	}
 }
 // ---- CDFs of the accumulated error (testbed_nerf.cu:1530-1580, 2795-2847) ----

@@ -1147,9 +1147,9 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
 	static uint32_t* s_coarse = nullptr;
-	if (!s_coarse && dev_alloc(&s_coarse, (size_t)COARSE_WORDS * N_CASCADES * 2)) return 1;
+	if (!s_coarse && dev_alloc(&s_coarse, (size_t)k1_prefilter_words(N_CASCADES))) return 1;
 	launch_build_linear_bitfield((hipStream_t)stream, bitfield, s_linear, N_CASCADES, s_coarse);
-	a.n_mips = N_CASCADES; a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse; a.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; a.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0;
+	a.n_mips = N_CASCADES; a.bitfield_linear = s_linear; a.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : s_coarse; a.chunk_march = (g_debug_flags & DBG_K1_CHUNK_MARCH) != 0; a.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0;
 	const uint32_t max_local = n_rays / world_size + 1;
 	if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) {
 		launch_generate_training_samples((hipStream_t)stream, a, max_local);
@@ -1320,14 +1320,14 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->grid_positions_sorted, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices_sorted, n_cells) || dev_alloc(&t->grid_sort_temp, t->grid_sort_temp_bytes = grid_sample_sort_temp_bytes(n_cells)) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
 		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_enc, (size_t)max_samples * 4) || dev_alloc(&t->src_index, B) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES) || dev_alloc(&t->bitfield_coarse, (size_t)COARSE_WORDS * N_CASCADES * 2) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES) || dev_alloc(&t->bitfield_coarse, (size_t)k1_prefilter_words(N_CASCADES)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays)) || dev_alloc(&t->k3_scratch, k3_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || k3_scratch_init(nullptr, t->k3_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
 	HIPCHK(hipMemset(t->bitfield, 0, GRID_N_CELLS / 8 * N_CASCADES));
 	HIPCHK(hipMemset(t->mean, 0, 4));
 	HIPCHK(hipMemset(t->bitfield_linear, 0, (size_t)GRID_N_CELLS / 8 * N_CASCADES));
-	HIPCHK(hipMemset(t->bitfield_coarse, 0, (size_t)COARSE_WORDS * 4 * N_CASCADES * 2));
+	HIPCHK(hipMemset(t->bitfield_coarse, 0, (size_t)k1_prefilter_words(N_CASCADES) * 4));
 	TrainCounters c; memset(&c, 0, sizeof(c));
 	c.rays_per_batch = 1u << 12;   // reset_network, testbed.cu:4171
 	c.max_inference = max_samples; // first step: measured_batch_size_before_compaction == 0 (testbed_nerf.cu:3056-3057)
@@ -1548,7 +1548,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		K1Args k1;
 		k1.n_rays = 0; k1.n_rays_ptr = &c->rays_per_batch; k1.rank = o.rank; k1.world_size = o.world_size; k1.aabb = t->aabb;
 		k1.max_samples = max_samples; k1.max_samples_ptr = &c->max_inference; k1.rng = pod(t->rng);
-		k1.n_mips = N_CASCADES; k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.segment_skip = (g_debug_flags & DBG_K1_SEGMENT_SKIP) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
+		k1.n_mips = N_CASCADES; k1.bitfield_linear = t->bitfield_linear; k1.bitfield_coarse = (g_debug_flags & DBG_K1_NO_PREFILTER) ? nullptr : t->bitfield_coarse; k1.chunk_march = (g_debug_flags & DBG_K1_CHUNK_MARCH) != 0; k1.no_first_point_skip = (g_debug_flags & DBG_K1_NO_FIRST_POINT_SKIP) != 0; k1.k2_tiles0_out = lattice ? t->k2_tiles : nullptr; k1.k2_tile_w = t->k2_tile_w;
 		k1.ray_targets_out = lattice ? t->ray_targets : nullptr; for (int k = 0; k < 3; ++k) k1.background_color[k] = o.background_color[k];
 		k1.color_space_srgb = o.color_space_srgb; k1.random_bg_color = o.random_bg_color; k1.linear_colors = o.linear_colors;
 		k1.ray_counter = &c->ray_counter; k1.numsteps_counter = &c->numsteps_counter; k1.ray_indices_out = t->ray_indices; k1.rays_out = t->rays;

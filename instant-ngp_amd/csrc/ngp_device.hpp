@@ -215,6 +215,8 @@ NGP_HD bool occupied_at_linear(f3 pos, const uint8_t* __restrict__ bitfield_line
 // 1024 words per cascade, built by k_build_coarse_bitfield from the linear copy), so a clear coarse bit proves the cell empty without a
 // memory access.  Identical result to occupied_at_linear by construction.
 constexpr uint32_t COARSE_SIZE = GRIDSIZE / 4, COARSE_WORDS = COARSE_SIZE * COARSE_SIZE * COARSE_SIZE / 32;
+constexpr uint32_t MID_SIZE = GRIDSIZE / 2, MID_WORDS = MID_SIZE * MID_SIZE * MID_SIZE / 32; // one bit per 2x2x2 cells (k_build_mid_dilated_bitfield)
+constexpr uint32_t k1_prefilter_words(uint32_t n_cascades) { return COARSE_WORDS * n_cascades + MID_WORDS; } // launch_build_linear_bitfield's `coarse` output
 NGP_D bool occupied_at_linear_prefiltered(f3 pos, const uint8_t* __restrict__ bitfield_linear, const uint32_t* coarse, uint32_t mip) {
 	float mip_scale = scalbnf(1.0f, -(int)mip);
 	pos = pos - mk3(0.5f);
@@ -578,6 +580,36 @@ NGP_HD f4 read_rgba(f2 uv, const int32_t res[2], const void* __restrict__ pixels
 		return {p[0], p[1], p[2], p[3]};
 	}
 	return {5.0f, 0.0f, 0.0f, 1.0f};
+}
+
+// One component of read_rgba (c = 0..2 premultiplied colour, same arithmetic) + alpha, and the masked-pixel test alone: k1_setup's threads need one channel or only
+// the mask, and the byte path costs one powf per channel.
+NGP_HD bool read_rgba_masked(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type) {
+	int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1);
+	int py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);
+	size_t idx = (size_t)px + (size_t)py * res[0];
+	if (type == NGP_IMAGE_BYTE) return ((const uint32_t*)pixels)[idx] == 0x00FF00FFu;
+	if (type == NGP_IMAGE_HALF) return __half2float(((const __half*)pixels)[idx * 4]) < 0.0f;
+	if (type == NGP_IMAGE_FLOAT) return ((const float*)pixels)[idx * 4] < 0.0f;
+	return false;
+}
+NGP_HD float read_rgba_channel(f2 uv, const int32_t res[2], const void* __restrict__ pixels, int type, uint32_t c, float& alpha) {
+	int px = clampi((int)(uv.x * (float)res[0]), 0, res[0] - 1);
+	int py = clampi((int)(uv.y * (float)res[1]), 0, res[1] - 1);
+	size_t idx = (size_t)px + (size_t)py * res[0];
+	if (type == NGP_IMAGE_BYTE) {
+		uint32_t val = ((const uint32_t*)pixels)[idx];
+		if (val == 0x00FF00FFu) { alpha = -1.f; return -1.f; }
+		alpha = ((val & 0xFF000000u) >> 24) * (1.0f / 255.0f);
+		return srgb_to_linear(((val >> (8u * c)) & 0xFFu) * (1.0f / 255.0f)) * alpha;
+	} else if (type == NGP_IMAGE_HALF) {
+		const __half* p = (const __half*)pixels + idx * 4;
+		alpha = __half2float(p[3]); return __half2float(p[c]);
+	} else if (type == NGP_IMAGE_FLOAT) {
+		const float* p = (const float*)pixels + idx * 4;
+		alpha = p[3]; return p[c];
+	}
+	alpha = 1.0f; return c == 0 ? 5.0f : 0.0f;
 }
 
 NGP_HD uint32_t image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_images) { return ((base_idx * n_images) / n_rays) % n_images; }

@@ -10,7 +10,7 @@ namespace ngp {
 extern uint32_t g_debug_flags;
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_NO_HASHED_MERGE = 65536 /* k_grad_bin sums same-cell runs before the sort on the dense levels only (hashed levels: one record per sample and corner): bin + accumulate 150 -> 161 us (profiles/r02_microbench_bin_merge.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
-	DBG_K1_SEGMENT_SKIP = 33554432 /* k1_count rejects 8-point lattice segments by one midpoint test against the dilated coarse grid and skips chunks without a hit: exact, but slower (80 -> 95 us: most chunks of a trained scene have a hit within one coarse cell, and the conditional evaluation breaks the batching of the eight occupancy loads; profiles/r02_k1_segment_skip.txt) */,
+	DBG_K1_CHUNK_MARCH = 33554432 /* single cascade + constant step: the chunk kernels k1_count<8, true> / k1_write (production up to round 4a: every lattice point up to the ray's exit is evaluated, 64 per iteration) instead of k1_count_segments / k1_write_list */,
 	DBG_BIN_NO_DENSE_MERGE = 16777216 /* no run merging on the dense levels either: their lists overflow into the atomics fallback (0.16 -> 0.81 ms) */,
 	DBG_T1_DENSE_ATOMICS = 8388608 /* dense levels' gradients as merged half atomics issued by T1 (rounds 1-2a) instead of through k_grad_bin / k_grad_accumulate: T1 183 -> 89 us, bin + accumulate 123 -> 173 us (profiles/r02_microbench_dense_bins.log) */,
 	DBG_GRID_NO_SORT = 4194304 /* occupancy-grid update evaluates its samples in generation order (round-1 behaviour) */,
@@ -65,9 +65,9 @@ struct K1Args {
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
 	uint32_t clamp_min_max = 0;                // ablation DBG_K1_MIP_CLAMP_MIN_MAX
 	uint32_t n_mips = 1; // bitfield levels present in bitfield_linear / bitfield_coarse (N_CASCADES: mip_from_dt may ask for a pooled level above max_mip, nerf_device.cuh:459)
-	const uint32_t* bitfield_coarse = nullptr; // optional: one bit per 4x4x4 cells of the x-major copy, followed by its one-cell dilation (same launcher): k1_count's LDS prefilters
+	const uint32_t* bitfield_coarse = nullptr; // optional: k1_prefilter_words(n_mips) words from launch_build_linear_bitfield: one bit per 4x4x4 cells of every level of the x-major copy, then the dilated mid grid of level 0 (2x2x2 cells per bit): the marchers' LDS prefilters
 	uint32_t no_first_point_skip = 0;          // ablation DBG_K1_NO_FIRST_POINT_SKIP: k1_count evaluates every chunk of a group, also those behind the ray's exit from the box (rounds 1-2)
-	uint32_t segment_skip = 0;                 // ablation DBG_K1_SEGMENT_SKIP: k1_count rejects 8-point lattice segments by their midpoint (single cascade, cone_angle 0)
+	uint32_t chunk_march = 0;                  // ablation DBG_K1_CHUNK_MARCH: the chunk kernels also for one cascade + constant step
 	uint4* k2_tiles0_out; uint32_t k2_tile_w; // optional: round-0 tile list of the lazy K2 (one descriptor per active ray: its first k2_tile_w samples)
 	int snap_to_pixel_centers; float cone_angle_constant;
 	int exact_skip; // lattice K1: follow the reference's skip rule (advance_to_next_voxel) over the lattice instead of testing every point on its own
@@ -106,7 +106,7 @@ int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays);
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
 // per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
-struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[7]; uint32_t ray_index; }; // tgt = {rgb target, background, target depth}
+struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[7]; uint32_t ray_index; float rdn[3]; }; // flags: from k1_setup = number of lattice points inside the box (a prefix of the lattice; 0 = the ray is not marched); tgt = {rgb target, background, target depth}; rdn = normalize(d)
 constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multiplicative-hash constant), larger than every ray count => coprime to it, and well mixed modulo powers of two; see k1_setup
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays); // once per allocation (and whenever max_local_rays changes)

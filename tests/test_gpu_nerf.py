@@ -159,9 +159,12 @@ def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
 
 @pytest.mark.parametrize("flags", [2097152, 33554432, 268435456])
 def test_k1_ablation_variants_are_the_same_marcher(ora, hip, scene, flags):
-    """k1_count without the coarse-occupancy prefilter (flag 2097152) and with the midpoint test of 8-point segments against the dilated coarse
-    grid (flag 33554432): both are exact accelerations, so the per-ray sample counts equal the CPU lattice model's exactly."""
+    """The marcher's accelerations are exact: k1_count without the coarse-occupancy prefilter (flag 2097152), without the one-test-per-chunk rejection behind
+    the ray's exit (268435456), and the chunk kernels k1_count / k1_write (33554432: every lattice point up to the exit evaluated, production up to round 4a)
+    in place of the segment prepass + sample lists of k1_count_segments / k1_write_list: per-ray sample counts equal the CPU lattice model's exactly, and
+    every output buffer equals the production path's bit for bit."""
     n_rays = 4096
+    _, p = _run_k1(ora, hip, scene, n_rays, 1 << 20)
     hip.ngp_debug_set_flags(flags)
     try:
         o, d = _run_k1(ora, hip, scene, n_rays, 1 << 20)
@@ -174,6 +177,9 @@ def test_k1_ablation_variants_are_the_same_marcher(ora, hip, scene, flags):
     ora.ora_k1_lattice_counts(0, n_rays, 0, n_rays, A.scene_aabb(1), _rng(ora), len(scene["imgs"]), scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, C.c_float(0.0), ptr(model), 2048)
     dev = np.zeros(n_rays, np.uint32); dev[ri] = ns[:, 0]
     assert n_d > 100 and np.array_equal(dev, model), f"{(dev != model).sum()} rays differ"
+    n_s = int(d["counters"].cpu().numpy().astype(np.uint32)[1])
+    for key, n in (("counters", 2), ("ray_indices", n_d), ("numsteps", n_d), ("rays", n_d), ("coords", n_s)):
+        assert np.array_equal(p[key].cpu().numpy()[:n].view(np.uint32), d[key].cpu().numpy()[:n].view(np.uint32)), f"{key} differs from the production path"
 
 
 def test_k1_sample_cap(ora, hip, scene):

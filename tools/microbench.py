@@ -18,7 +18,7 @@ VARIANTS = [
     ("bin_no_dense_merge", 16777216, (12, 0, 0), (1, 16)),   # dense levels in the bin lists without run merging
     ("t1_dense_atomics", 8388608, (12, 0, 0), (1, 16)),   # dense levels as half atomics from T1 instead of through the bin lists
     ("grid_no_sort", 4194304, (12, 0, 0), (1, 16)),   # occupancy-grid update in generation order
-    ("k1_segment_skip", 33554432, (12, 0, 0), (1, 16)),   # k1_count skips chunks whose 8-point segments all miss the dilated coarse grid
+    ("k1_chunk_march", 33554432, (12, 0, 0), (1, 16)),     # chunk kernels k1_count / k1_write instead of the segment prepass + sample lists
     ("k1_no_prefilter", 2097152, (12, 0, 0), (1, 16)),   # k1_count without the coarse-occupancy prefilter in LDS
     ("k2_tile8", 0, (12, 0, 0), (1, 8)),
     ("k2_tile32", 0, (12, 0, 0), (1, 32)),
