@@ -84,7 +84,7 @@ typedef struct ngp_model_config {
 	uint32_t n_hidden_layers;       /* density net: 1 */
 	uint32_t n_hidden_layers_rgb;   /* rgb net: 2 */
 	uint32_t sh_degree;             /* "dir_encoding": SphericalHarmonics degree 4 */
-	uint32_t n_extra_dims;          /* 0 for lego / fox */
+	uint32_t n_extra_dims;          /* NerfDataset::n_extra_dims() (nerf_loader.h:85-87): 0 for lego / fox; 3 = light directions; <= 16 */
 	/* "optimizer": Ema( ExponentialDecay( Adam ) ) */
 	float learning_rate, beta1, beta2, epsilon, l2_reg;
 	float ema_decay;
@@ -195,6 +195,12 @@ int ngp_model_density(ngp_model*, void* stream, const float* pos, uint32_t pos_s
  * gradient; parameter gradients are overwritten. dL_dy: `dy_stride` halfs per element, [0..3] used. */
 int ngp_model_training_step(ngp_model*, void* stream, const float* in, uint32_t in_stride, uint32_t n,
                             const ngp_half* dL_dy, uint32_t dy_stride);
+/* The same with dL_dinput requested for the extra dims (Trainer::training_step(..., dL_dinput, ...) with prepare_input_gradients,
+ * testbed_nerf.cu:3309-3323; nerf_network.h:238-252: the dir encoding's backward): dL_dextra (device, n x n_extra_dims floats, may be
+ * NULL) receives the extra-dims columns of dL/d(input) -- what compute_extra_dims_gradient_train_nerf (testbed_nerf.cu:1293-1330) reads
+ * through coords_gradient(j)->get_extra_dims(). Models created with n_extra_dims > 0 only. */
+int ngp_model_training_step_extra(ngp_model*, void* stream, const float* in, uint32_t in_stride, uint32_t n,
+                                  const ngp_half* dL_dy, uint32_t dy_stride, float* dL_dextra);
 
 /* Trainer::optimizer_step(stream, loss_scale) (testbed_nerf.cu:2770): Adam -> ExponentialDecay -> EMA. */
 int ngp_model_optimizer_step(ngp_model*, void* stream, float loss_scale);
@@ -437,6 +443,24 @@ typedef struct ngp_render_params {
 } ngp_render_params;
 int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_host,
                     float* frame_buffer, float* depth_buffer);
+
+/* Extra (latent / light-direction) dims of a model created with n_extra_dims > 0: one vector per training image, copied behind every
+ * NerfCoordinate of the image's rays (testbed_nerf.cu:718-744, 833) and, when optimize_extra_dims is on, trained by one
+ * VarAdamOptimizer per image (adam_optimizer.h:27-47; testbed_nerf.cu:2743-2750, 2860-2878, 3325-3340).
+ * set: Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683) -- the host computes the initial values (warped light directions
+ *      or uniform random latents), this installs them and resets the optimizers; n_images must equal the dataset's.
+ * get: Training::get_extra_dims_cpu (testbed_nerf.cu:1862-1877) for the first n_images images.
+ * rendering: set_rendering_extra_dims_from_training_view / set_rendering_extra_dims (testbed_nerf.cu:3685-3735): view >= 0 = that
+ *      training view's dims; view < 0 = `values` (n_extra_dims floats; NULL = image 0's, the state after reset_extra_dims). */
+int ngp_nerf_set_extra_dims(ngp_nerf*, const float* values_host, uint32_t n_images);
+/* stand-alone launches of compute_extra_dims_gradient_train_nerf and of the VarAdamOptimizer step over device buffers (test hooks) */
+int ngp_k_extra_dims_gradient(void* stream, uint32_t n_rays_total, uint32_t rays_counter, float* grad_out, uint32_t n_extra, uint32_t n_images,
+                              const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows);
+int ngp_k_extra_dims_adam(void* stream, uint32_t n, float* variable, const float* gradient_scaled, float* m, float* v, uint32_t iter, float lr, float loss_scale);
+int ngp_nerf_get_extra_dims(ngp_nerf*, float* values_host, uint32_t n_images);
+int ngp_nerf_get_extra_dims_gradient(ngp_nerf*, float* values_host, uint32_t n_images); /* test hook: extra_dims_gradient_gpu of the last step (loss-scaled) */
+int ngp_nerf_set_optimize_extra_dims(ngp_nerf*, int on);                                 /* m_nerf.training.optimize_extra_dims (testbed.h) */
+int ngp_nerf_set_rendering_extra_dims(ngp_nerf*, int training_view, const float* values_host);
 
 /* CudaRenderBuffer::accumulate (running mean over spp, render_buffer.cu:228-260) and tonemap (Identity curve: 2^exposure, background behind
  * the premultiplied colour, optional linear -> sRGB; :511-560) on device buffers of RGBA float32 */

@@ -252,6 +252,21 @@ DEV h8 sh4_frag(float dx, float dy, float dz, int hi) {
 	return r;
 }
 
+// Extra (latent / light-direction) dims of the dir encoding (nerf_network.h:84, Composite: Identity over the dims behind the direction): third k-step of the colour
+// network's first layer.  xp = the sample's n_extra floats behind its NerfCoordinate (in + 7); the lane keeps k-slots 8*(j>>2)+4*hi+(j&3); [tcnn] padding columns = 1.
+DEV h8 extra_frag(const float* __restrict__ xp, uint32_t n_extra, int hi) {
+	h8 r;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t k = 8u * (j >> 2) + 4u * hi + (j & 3);
+		r[j] = k < n_extra ? (_Float16)xp[k] : (_Float16)1.f;
+	}
+	return r;
+}
+// fragment indices of a model with extra dims: behind the regular ones, so that every other index is the same in both kinds of model
+// fw: n_fw(NR) + mt (k-step 2 of R1, mt = 0, 1);  bw: n_bw(NR) + s (dgrad rows 32..63 of R1^T -- 32..47 are the extra dims --, k-steps s = 0..3)
+constexpr int N_FW_EXTRA = 2, N_BW_EXTRA = 4;
+
 // copy the fragment-ordered weights into LDS (all threads of the block)
 // (loads are issued in batches of 8 / 4 before their LDS stores: one load per loop trip made every block start with 5 - 10 dependent round trips to L2)
 DEV void load_frags_to_lds(h8* dst, const ngp_half* __restrict__ src, int n_frags) {
@@ -282,7 +297,7 @@ DEV void load_frags_to_lds(h8* dst, const ngp_half* __restrict__ src, int n_frag
 template <int CT>
 struct FwdState {
 	h8 enc[CT][2];      // encoding fragments (k-steps 0,1)
-	h8 rin[CT][2];      // rgb-net input: [0] = density-net output (16), [1] = SH (16)
+	h8 rin[CT][3];      // rgb-net input: [0] = density-net output (16), [1] = SH (16), [2] (models with extra dims only) = the extra dims + padding ones (16)
 	h8 hb[CT][4];       // current 64-wide hidden activation fragments
 	uint32_t m1d[CT], m1r[CT], m2r[2][CT]; // ReLU bit masks: bit (16*mt + r); m2r[k] = the k-th 64 x 64 colour layer
 	float sigma[CT];    // density logit (valid on hi == 0 lanes)
@@ -333,21 +348,27 @@ DEV void fwd_density_l2(const h8* fw, int lane, FwdState<CT>& st) {
 		st.sigma[c] = (float)st.rin[c][0][0]; // neuron 0 lives in reg 0 of the hi == 0 lanes (half-rounded)
 	}
 }
-template <int CT>
-DEV void fwd_rgb_l1(const h8* fw, int lane, FwdState<CT>& st) {
+template <int CT, int EX = 0>
+DEV void fwd_rgb_l1(const h8* fw, int lane, FwdState<CT>& st, const int xfrag = 0 /* EX: index of the first extra fragment */) {
 	f16v acc[2][CT];
 #pragma unroll
 	for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
 		for (int c = 0; c < CT; ++c) acc[mt][c] = zero16();
 #pragma unroll
-	for (int mt = 0; mt < 2; ++mt)
+	for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 			h8 a = lds_frag(fw, FW_R1 + mt * 2 + s, lane);
 #pragma unroll
 			for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, st.rin[c][s], acc[mt][c]);
 		}
+		if constexpr (EX != 0) {
+			h8 a = lds_frag(fw, xfrag + mt, lane);
+#pragma unroll
+			for (int c = 0; c < CT; ++c) acc[mt][c] = mfma(a, st.rin[c][2], acc[mt][c]);
+		}
+	}
 #pragma unroll
 	for (int c = 0; c < CT; ++c) {
 		st.m1r[c] = 0;
@@ -401,9 +422,9 @@ DEV void fwd_rgb_l3(const h8* fw, int lane, const FwdState<CT>& st, f16v out[CT]
 }
 
 // the colour network with NR hidden layers (configs/nerf/base_1layer / base(_2layer) / base_3layer.json): hidden activations only
-template <int CT, int NR>
+template <int CT, int NR, int EX = 0>
 DEV void fwd_rgb_hidden(const h8* fw, int lane, FwdState<CT>& st) {
-	fwd_rgb_l1<CT>(fw, lane, st);
+	fwd_rgb_l1<CT, EX>(fw, lane, st, n_fw(NR));
 #pragma unroll
 	for (int k = 0; k < NR - 1; ++k) fwd_rgb_l2<CT>(fw, lane, st, k);
 }
@@ -411,12 +432,12 @@ DEV void fwd_rgb_hidden(const h8* fw, int lane, FwdState<CT>& st) {
 // ---------------------------------------------------------------------------------------------
 // inference kernel (K2, density-grid queries, renderer): persistent waves, 64 samples per iteration
 // ---------------------------------------------------------------------------------------------
-template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW, int F = 4, int NR = 2>
+template <bool DENSITY_ONLY, int CT, bool PAIR, int MINW, int F = 4, int NR = 2, int EX = 0>
 __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n_max,
 		const uint32_t* __restrict__ n_ptr, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
-	load_frags_to_lds(fw, mp.fw_frags, DENSITY_ONLY ? 8 : n_fw(NR));
+	load_frags_to_lds(fw, mp.fw_frags, DENSITY_ONLY ? 8 : n_fw(NR) + (EX ? N_FW_EXTRA : 0));
 	__syncthreads();
 	const uint32_t n = n_ptr ? min(*n_ptr, n_max) : n_max;
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
@@ -433,6 +454,7 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
 			encode_sample<F, PAIR>(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
 			if (!DENSITY_ONLY) st.rin[c][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
+			if constexpr (!DENSITY_ONLY && EX != 0) st.rin[c][2] = extra_frag(p + dir_offset + 3, mp.n_extra, hi);
 		}
 		fwd_density_l1<CT>(fw, lane, st);
 		fwd_density_l2<CT>(fw, lane, st);
@@ -442,7 +464,7 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 				if (hi == 0 && sidx[c] < n) out[(size_t)sidx[c] * out_stride] = __float2half(st.sigma[c]);
 			continue;
 		}
-		fwd_rgb_hidden<CT, NR>(fw, lane, st);
+		fwd_rgb_hidden<CT, NR, EX>(fw, lane, st);
 		f16v o[CT];
 		fwd_rgb_l3<CT>(fw, lane, st, o, fw_r3(NR));
 #pragma unroll
@@ -799,15 +821,15 @@ DEV void atomic_add_h2(__half* addr, h2 v) {
 // SCATTER = false: every level's dL/d(enc) goes to denc_lv and the kernel issues no atomics (production: all levels through the bin lists);
 // compiled separately so that the scatter code's registers do not limit the occupancy of the gather-latency-bound forward / dgrad part.
 // STASH: the encodings come from the lazy K2's per-sample records (EncStashIn) instead of the hash tables.
-template <int CT, int MINW, bool SCATTER, int F = 4, int NR = 2, bool STASH = false>
+template <int CT, int MINW, bool SCATTER, int F = 4, int NR = 2, bool STASH = false, int EX = 0>
 __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n,
 		const __half* __restrict__ dL_dy, uint32_t dy_stride, __half* __restrict__ grid_grad, uint4* __restrict__ enc_stash, uint32_t flags,
-		uint2* __restrict__ denc_lv, uint32_t denc_cap, EncStashIn stash_in = EncStashIn()) {
+		uint2* __restrict__ denc_lv, uint32_t denc_cap, EncStashIn stash_in = EncStashIn(), float* __restrict__ dextra_out = nullptr /* EX: optional dL/d(extra dims), n x n_extra floats */) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
-	h8* bw = fw + n_fw(NR) * 64;
-	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
-	load_frags_to_lds(bw, mp.bw_frags, n_bw(NR));
+	h8* bw = fw + (n_fw(NR) + (EX ? N_FW_EXTRA : 0)) * 64;
+	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR) + (EX ? N_FW_EXTRA : 0));
+	load_frags_to_lds(bw, mp.bw_frags, n_bw(NR) + (EX ? N_BW_EXTRA : 0));
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
@@ -836,13 +858,14 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 			} else
 			encode_sample<F>(gm, table, px[c], py[c], pz[c], hi, st.enc[c]);
 			st.rin[c][1] = sh4_frag(p[4], p[5], p[6], hi);
+			if constexpr (EX != 0) st.rin[c][2] = extra_frag(p + 7, mp.n_extra, hi);
 			// stash for kernel W: [32-sample tile][s][lane] 16-byte chunks (lane-linear, coalesced)
 			enc_stash[(((size_t)tile * CT + c) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, st.enc[c][0]);
 			enc_stash[(((size_t)tile * CT + c) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, st.enc[c][1]);
 		}
 		fwd_density_l1<CT>(fw, lane, st);
 		fwd_density_l2<CT>(fw, lane, st);
-		fwd_rgb_hidden<CT, NR>(fw, lane, st);
+		fwd_rgb_hidden<CT, NR, EX>(fw, lane, st);
 
 		// ---- backward (dgrad chain) ----
 		h8 dy0[CT];          // dL/d(rgb output) fragment, k-step 0
@@ -896,6 +919,28 @@ __global__ void __launch_bounds__(256, MINW) k_train_fwd_bwd(const GridMeta* __r
 				}
 		}
 		// rgb L1^T : d_rin = W1^T * d_h1 ; only rows 0..15 (density-net output) are consumed
+		if constexpr (EX != 0) if (dextra_out) {
+			// ... and rows 32..47 = dL/d(extra dims): the colour network's input gradient is a half matrix in the reference, the Identity encoding's backward hands it on
+			// as float (nerf_network.h:238-252 -> coords_gradient, testbed_nerf.cu:1326)
+			f16v acc[CT];
+#pragma unroll
+			for (int c = 0; c < CT; ++c) acc[c] = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				h8 a = lds_frag(bw, n_bw(NR) + s, lane);
+#pragma unroll
+				for (int c = 0; c < CT; ++c) acc[c] = mfma(a, dh[c][s], acc[c]);
+			}
+#pragma unroll
+			for (int c = 0; c < CT; ++c) {
+				if (sidx[c] >= n) continue;
+#pragma unroll
+				for (int r = 0; r < 8; ++r) { // tile rows (r & 3) + 8 (r >> 2) + 4 hi < 16
+					const uint32_t k = (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * hi);
+					if (k < mp.n_extra) dextra_out[(size_t)sidx[c] * mp.n_extra + k] = (float)(_Float16)acc[c][r];
+				}
+			}
+		}
 		h8 ddens[CT];
 		{
 			f16v acc[CT];
@@ -1554,22 +1599,22 @@ constexpr int n_dw_tiles(int nr) { return 8 + 4 * (nr - 1); } // d1:(0,1) d2:(2,
 // NR = 2 is the round-1 kernel (ablation DBG_W_SINGLE_ROLE; production runs the two-role k_wgrad2 below); NR = 1 and 3 (configs/nerf/base_1layer.json,
 // base_3layer.json) run this one.  Per 32-sample tile: forward chain with the SWAPPED activations (lane = neuron, registers = samples) of every hidden
 // colour layer kept for the weight-gradient products, then the dgrad chain in both layouts, layer by layer from the output.
-template <int NR>
+template <int NR, int EX = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n, const __half* __restrict__ dL_dy, uint32_t dy_stride,
 		const uint4* __restrict__ enc_stash, float* __restrict__ partials) {
-	constexpr int NT = n_dw_tiles(NR);
+	constexpr int NT = n_dw_tiles(NR); // EX: + 2 tiles (columns 32..63 of the first colour layer's 64 x 48 matrix, 32..47 real) behind them
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
-	h8* bw = fw + n_fw(NR) * 64;
-	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
+	h8* bw = fw + (n_fw(NR) + (EX ? N_FW_EXTRA : 0)) * 64;
+	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR) + (EX ? N_FW_EXTRA : 0));
 	load_frags_to_lds(bw, mp.bw_frags, n_bw(NR));
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6;
 	const uint32_t wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
-	f16v dW[NT];
+	f16v dW[NT + (EX ? 2 : 0)];
 #pragma unroll
-	for (int t = 0; t < NT; ++t) dW[t] = zero16();
+	for (int t = 0; t < NT + (EX ? 2 : 0); ++t) dW[t] = zero16();
 	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
 
 	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) { // ct = 32-sample column tile
@@ -1581,6 +1626,7 @@ k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint3
 		st.enc[0][0] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 0) * 64 + lane]);
 		st.enc[0][1] = __builtin_bit_cast(h8, enc_stash[((size_t)ct * 2 + 1) * 64 + lane]);
 		st.rin[0][1] = sh4_frag(p[4], p[5], p[6], hi);
+		if constexpr (EX != 0) st.rin[0][2] = extra_frag(p + 7, mp.n_extra, hi);
 		h8 dy0 = zero8(); _Float16 dsig = (_Float16)0.f;
 		if (hi == 0 && valid) { // out-of-range columns contribute nothing: their output gradient is zero
 			const h4 g = __builtin_bit_cast(h4, *(const uint2*)(dL_dy + (size_t)s_raw * dy_stride));
@@ -1595,9 +1641,10 @@ k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint3
 			f16v t = zero16();
 #pragma unroll
 			for (int s = 0; s < 2; ++s) t = mfma(st.rin[0][s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
+			if constexpr (EX != 0) t = mfma(st.rin[0][2], lds_frag(fw, n_fw(NR) + kt, lane), t);
 			sw_to_frags(t, true, H_sw[0][kt]);
 		}
-		fwd_rgb_l1<1>(fw, lane, st);
+		fwd_rgb_l1<1, EX>(fw, lane, st, n_fw(NR));
 #pragma unroll
 		for (int k = 0; k < NR - 1; ++k) {
 #pragma unroll
@@ -1668,6 +1715,14 @@ k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint3
 			for (int it = 0; it < 2; ++it)
 #pragma unroll
 				for (int q = 0; q < 2; ++q) dW[4 + it] = mfma(d_sw[it][q], rin_sw[q], dW[4 + it]);
+			if constexpr (EX != 0) { // columns 32..47: the extra dims and the padding ones (lanes 16..31 of the swapped tile stay zero)
+				h8 x_sw[2];
+				f16v tx = mfma(st.rin[0][2], I0, zero16()); sw_to_frags(tx, false, x_sw);
+#pragma unroll
+				for (int it = 0; it < 2; ++it)
+#pragma unroll
+					for (int q = 0; q < 2; ++q) dW[NT + it] = mfma(d_sw[it][q], x_sw[q], dW[NT + it]);
+			}
 		}
 		// d_rin -> d_densout (+ dsigma on neuron 0)
 		h8 ddens;
@@ -1709,9 +1764,10 @@ k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint3
 
 	// ---- reduce the 4 waves of the block through LDS (re-using the fragment region), 4 tiles at a time: 16 KiB <= the 28 KiB of fragments at NR = 1 ----
 	float* red = (float*)smem;
-	float* dstp = partials + (size_t)blockIdx.x * (NT * 16 * 64);
+	float* dstp = partials + (size_t)blockIdx.x * ((NT + (EX ? 2 : 0)) * 16 * 64);
 #pragma unroll
-	for (int part = 0; part < NT / 4; ++part) {
+	for (int part = 0; part < NT / 4 + (EX ? 1 : 0); ++part) {
+		const int nt = part < NT / 4 ? 4 : 2; // the two extra tiles are a last, half-sized part
 		__syncthreads();
 		for (int w = 0; w < 4; ++w) {
 			if (wid == w) {
@@ -1719,13 +1775,14 @@ k_wgrad_nr(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint3
 				for (int t = 0; t < 4; ++t)
 #pragma unroll
 					for (int r = 0; r < 16; ++r) {
+						if (t >= nt) continue;
 						float* dst = red + ((size_t)t * 16 + r) * 64 + lane;
-						*dst = (w == 0 ? 0.f : *dst) + dW[part * 4 + t][r];
+						*dst = (w == 0 ? 0.f : *dst) + dW[part * 4 + t < NT + (EX ? 2 : 0) ? part * 4 + t : 0][r];
 					}
 			}
 			__syncthreads();
 		}
-		for (int i = threadIdx.x; i < 4 * 16 * 64; i += blockDim.x) dstp[part * 4 * 16 * 64 + i] = red[i];
+		for (int i = threadIdx.x; i < nt * 16 * 64; i += blockDim.x) dstp[part * 4 * 16 * 64 + i] = red[i];
 	}
 }
 
@@ -1904,13 +1961,13 @@ k_wgrad2(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_
 // coalesced 256-byte reads, then combine through LDS in a fixed order (deterministic).
 // 16 wavefronts per 64 elements (each sums every 16th partial, 4 independent loads in flight), then a fixed-order tree over the 16 sums:
 // the 12.6 MB of partials stream at memory speed instead of as 64 dependent loads per wavefront (17.7 -> see DESIGN 8).
-__global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad, uint32_t nr /* hidden colour layers */) {
+__global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad, uint32_t nr /* hidden colour layers */, uint32_t ex /* 1: model with extra dims (first colour layer 64 x 48, two more tiles behind the regular ones) */) {
 	__shared__ float sm[16][64];
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	const uint32_t e = blockIdx.x * 64 + lane; // element of [tile][r][lane]
 	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 	const uint32_t n_tiles = 8 + 4 * (nr - 1);
-	const size_t PS = (size_t)n_tiles * 16 * 64;
+	const size_t PS = (size_t)(n_tiles + 2 * ex) * 16 * 64;
 	uint32_t g = wid;
 	for (; g + 48 < n_partials; g += 64) {
 		s0 += partials[(size_t)g * PS + e]; s1 += partials[(size_t)(g + 16) * PS + e];
@@ -1933,11 +1990,13 @@ __global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__
 	}
 	const int t = e / (16 * 64), r = (e / 64) % 16;
 	int layer_off, R, C, it, kt;
+	const int c1 = 32 + 16 * (int)ex, xo = 64 * 16 * (int)ex; // width of the first colour layer; what it adds to the offsets of the layers behind it
 	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
 	else if (t < 4) { layer_off = 2048; R = 16; C = 64; it = 0; kt = t - 2; }
-	else if (t < 6) { layer_off = 3072; R = 64; C = 32; it = t - 4; kt = 0; }
-	else if (t < (int)n_tiles - 2) { const int k = (t - 6) >> 2, u = (t - 6) & 3; layer_off = 5120 + 4096 * k; R = 64; C = 64; it = u >> 1; kt = u & 1; }
-	else { layer_off = 5120 + 4096 * ((int)nr - 1); R = 16; C = 64; it = 0; kt = t - ((int)n_tiles - 2); }
+	else if (t < 6) { layer_off = 3072; R = 64; C = c1; it = t - 4; kt = 0; }
+	else if (t < (int)n_tiles - 2) { const int k = (t - 6) >> 2, u = (t - 6) & 3; layer_off = 5120 + xo + 4096 * k; R = 64; C = 64; it = u >> 1; kt = u & 1; }
+	else if (t < (int)n_tiles) { layer_off = 5120 + xo + 4096 * ((int)nr - 1); R = 16; C = 64; it = 0; kt = t - ((int)n_tiles - 2); }
+	else { layer_off = 3072; R = 64; C = c1; it = t - (int)n_tiles; kt = 1; }
 	const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((int)lane >> 5);
 	const int k = kt * 32 + ((int)lane & 31);
 	if (i < R && k < C) mlp_grad[layer_off + i * C + k] = __float2half(s);
@@ -2267,6 +2326,8 @@ void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, co
 		if (F == 2) NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 2, 2);
 		else if (pair) { if (occ4) NGP_LAUNCH_INF(true, true, 4, 8 * 1024, 4, 2); else NGP_LAUNCH_INF(true, true, 3, 8 * 1024, 4, 2); }
 		else { if (occ4) NGP_LAUNCH_INF(true, false, 4, 8 * 1024, 4, 2); else NGP_LAUNCH_INF(true, false, 3, 8 * 1024, 4, 2); }
+	} else if (mp.n_extra) { // extra dims: L = 8, F = 4, two hidden colour layers (ngp_model_create)
+		hipLaunchKernelGGL((k_inference<false, 1, false, 3, 4, 2, 1>), dim3(grid), dim3(256), (n_fw(2) + N_FW_EXTRA) * 1024, s, gm, mp, in, in_stride, n_max, n_ptr, (__half*)out, out_stride, dir_offset);
 	} else if (F == 2 || nr != 2) { // L = 16, F = 2 and / or 1 or 3 hidden colour layers (no ablation variants)
 		if (F == 2) { if (nr == 1) NGP_LAUNCH_INF(false, false, 3, n_fw(1) * 1024, 2, 1); else if (nr == 3) NGP_LAUNCH_INF(false, false, 3, n_fw(3) * 1024, 2, 3); else NGP_LAUNCH_INF(false, false, 3, n_fw(2) * 1024, 2, 2); }
 		else { if (nr == 1) NGP_LAUNCH_INF(false, false, 3, n_fw(1) * 1024, 4, 1); else NGP_LAUNCH_INF(false, false, 3, n_fw(3) * 1024, 4, 3); }
@@ -2374,11 +2435,19 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	}
 }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
-		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t F, const EncStashIn* stash_in) {
+		const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t F, const EncStashIn* stash_in, float* dextra_out) {
 	if (n == 0) return;
 	const uint32_t tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, (uint64_t)num_cus() * 3);
 	const uint32_t nr = mp.n_rgb_hidden;
+	if (mp.n_extra) { // extra dims: L = 8, F = 4, two hidden colour layers; every level's dL/d(enc) through the lists (the caller provides them) or, without lists, atomics
+		const uint32_t lds = (uint32_t)(n_fw(2) + N_FW_EXTRA + n_bw(2) + N_BW_EXTRA) * 1024;
+		if ((flags & T1_DENSE_EXTERNAL) && denc_lv) hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false, 4, 2, false, 1>), dim3(grid), dim3(256), lds, s, gm, mp, in, in_stride, n,
+			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap, EncStashIn(), dextra_out);
+		else hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, true, 4, 2, false, 1>), dim3(grid), dim3(256), lds, s, gm, mp, in, in_stride, n,
+			(const __half*)dL_dy, dy_stride, (__half*)grid_grad, (uint4*)enc_stash, flags, (uint2*)denc_lv, denc_cap, EncStashIn(), dextra_out);
+		return;
+	}
 	if (F == 2 || nr != 2) { // L = 16, F = 2 and / or 1 or 3 hidden colour layers: every level through the lists (no atomics in T1) or, without lists, atomics
 		const bool no_scatter = (flags & T1_DENSE_EXTERNAL) && denc_lv;
 #define NGP_LAUNCH_T1(SC, FF, NRR) hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, SC, FF, NRR>), dim3(grid), dim3(256), (n_fw(NRR) + n_bw(NRR)) * 1024, s, gm, mp, in, in_stride, n, \
@@ -2418,14 +2487,16 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 	if (n == 0) return;
 	const uint32_t nr = mp.n_rgb_hidden, lds = (uint32_t)(n_fw((int)nr) + n_bw((int)nr)) * 1024;
 #define NGP_LAUNCH_W(NRR) hipLaunchKernelGGL(k_wgrad_nr<NRR>, dim3(n_partials), dim3(256), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials)
-	if (nr == 1) NGP_LAUNCH_W(1);
+	if (mp.n_extra) hipLaunchKernelGGL((k_wgrad_nr<2, 1>), dim3(n_partials), dim3(256), lds + N_FW_EXTRA * 1024, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
+	else if (nr == 1) NGP_LAUNCH_W(1);
 	else if (nr == 3) NGP_LAUNCH_W(3);
 	else if (g_debug_flags & DBG_W_SINGLE_ROLE) NGP_LAUNCH_W(2);
 	else hipLaunchKernelGGL(k_wgrad2, dim3(n_partials), dim3(512), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
 #undef NGP_LAUNCH_W
 }
-void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden) {
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_dw_tiles((int)n_rgb_hidden) * 16), dim3(1024), 0, s, partials, n_partials, (__half*)mlp_grad, n_rgb_hidden);
+void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden, uint32_t n_extra) {
+	const uint32_t ex = n_extra ? 1u : 0u;
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_dw_tiles((int)n_rgb_hidden) + 2 * ex) * 16), dim3(1024), 0, s, partials, n_partials, (__half*)mlp_grad, n_rgb_hidden, ex);
 }
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a) {
 	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params / 4 + 255) / 256)), dim3(256), 0, s, a);

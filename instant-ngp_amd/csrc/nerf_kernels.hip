@@ -75,6 +75,8 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 	const uint32_t i = ray_begin + threadIdx.x + blockIdx.x * blockDim.x;
 	if (blockIdx.x * blockDim.x >= ray_end - ray_begin) return; // whole block out of range (uniform)
 	const Box aabb(a.aabb);
+	const uint32_t cs = 7u + a.n_extra; // floats per NerfCoordinate (PitchedPtr stride, testbed_nerf.cu:3010-3011)
+	const float* extra = nullptr;          // the ray's extra dims = its image's (testbed_nerf.cu:744)
 
 	bool valid = i < ray_end;
 	uint32_t numsteps = 0;
@@ -86,6 +88,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 		uint32_t img; float pix_pdf;
 		f2 uv = training_pixel(a.cdf, rng, i, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
 		const ngp_image_meta& m = a.metadata[img];
+		if (a.n_extra) extra = a.extra_dims + (size_t)img * a.n_extra;
 		if (read_rgba(uv, m.resolution, m.pixels, m.image_data_type).x < 0.0f) valid = false;
 		if (valid) {
 			const float motionblur_time = rng.next_float();
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 	a.numsteps_out[ray_idx * 2 + 0] = numsteps;
 	a.numsteps_out[ray_idx * 2 + 1] = base;
 
-	float* co = a.coords_out + (size_t)base * 7;
+	float* co = a.coords_out + (size_t)base * cs;
 	const f3 wd = warp_direction(rdn);
 	float t = startt;
 	uint32_t j = 0;
@@ -141,8 +144,9 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 		uint32_t mip = k1_mip(a, dt, pos);
 		if (occupied_at(pos, a.bitfield, mip)) {
 			f3 wp = warp_position(pos, aabb);
-			float* c = co + (size_t)j * 7;
+			float* c = co + (size_t)j * cs;
 			c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+			for (uint32_t k = 7; k < cs; ++k) c[k] = extra[k - 7]; // set_with_optional_extra_dims, testbed_nerf.cu:833
 			++j; t += dt;
 		} else t = advance_to_next_voxel(t, cone_angle, pos, rdn, idir, mip);
 	}
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 		out.tgt[6] = sqrtf(dot3(rd, rd)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
 	} else out.tgt[6] = -1.0f;
 	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2]; out.rdn[0] = dn[0]; out.rdn[1] = dn[1]; out.rdn[2] = dn[2];
-	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = n_in; out.ray_index = i;
+	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = n_in; out.ray_index = i; out.img = img;
 	if (!a.ray_targets_out) for (int k = 0; k < 6; ++k) out.tgt[k] = 0.f;
 }
 
@@ -464,6 +468,7 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t lane = threadIdx.x & 63u;
 	const Box aabb(a.aabb);
+	const uint32_t cs = 7u + a.n_extra;
 	// this workgroup's slot range (the same split as k1_count's) and the spans of its rays: offset of the range + exclusive scan inside it
 	const uint32_t n_local = ray_end - ray_begin;
 	const uint32_t li_begin = (uint32_t)(((uint64_t)n_local * blockIdx.x) / gridDim.x), li_end = (uint32_t)(((uint64_t)n_local * (blockIdx.x + 1)) / gridDim.x);
@@ -500,7 +505,7 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 	if (!fits) continue;
 	const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
 	const f3 wd = warp_direction(rdn);
-	float* co = a.coords_out + (size_t)base * 7;
+	float* co = a.coords_out + (size_t)base * cs;
 	uint32_t written = 0;
 	const uint32_t n_chunks = r.flags;
 	// all chunk masks of the ray with ONE load (lane = chunk), then broadcast from registers: the loop has no memory latency in it
@@ -513,8 +518,9 @@ __global__ void __launch_bounds__(256) k1_write(K1Args a, const RaySetup* __rest
 			const f3 pos = ro + t * rdn;
 			const float dt = calc_dt(t, a.cone_angle_constant);
 			const f3 wp = warp_position(pos, aabb);
-			float* c = co + (size_t)k * 7;
+			float* c = co + (size_t)k * cs;
 			c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+			for (uint32_t x = 7; x < cs; ++x) c[x] = a.extra_dims[(size_t)r.img * a.n_extra + (x - 7)];
 		}
 		written += (uint32_t)__popcll(m);
 	}
@@ -681,6 +687,15 @@ __global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* _
 		const f3 pos = ro + t * rdn;
 		const float dt = calc_dt(t, a.cone_angle_constant);
 		const f3 wp = warp_position(pos, aabb), wd = warp_direction(rdn);
+		if (a.n_extra) { // records of 7 + n_extra floats (the ray's image's extra dims behind the NerfCoordinate): stored by their own lanes
+			if (lane < n) {
+				const uint32_t cs = 7u + a.n_extra;
+				float* c = a.coords_out + ((size_t)(uint32_t)range_off + e0 + lane) * cs;
+				c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+				for (uint32_t x = 7; x < cs; ++x) c[x] = a.extra_dims[(size_t)r.img * a.n_extra + (x - 7)];
+			}
+			continue;
+		}
 		float* c = st + lane * 7u;
 		c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
 		__builtin_amdgcn_wave_barrier();
@@ -748,6 +763,7 @@ __global__ void __launch_bounds__(256) k_build_mid_dilated_bitfield(const uint8_
 // K3
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
+	const uint32_t cs = a.cstride;
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t n_active = *a.rays_counter;
 	if (blockIdx.x * blockDim.x >= n_active) return;
@@ -766,7 +782,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 	if (active) {
 		numsteps = a.numsteps_inout[i * 2 + 0];
 		base = a.numsteps_inout[i * 2 + 1];
-		cin = a.coords_in + (size_t)base * 7;
+		cin = a.coords_in + (size_t)base * cs;
 		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
 		ray_o = ld3(a.rays_in[i].o);
 		const uint32_t ray_idx = a.ray_indices_in[i];
@@ -795,12 +811,12 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 			if (T < EPSILON) break;
 			const __half* lo = no + (size_t)compacted_numsteps * a.output_stride;
 			const f3 rgb = mk3(act_rgb(__half2float(lo[0]), a.rgb_activation), act_rgb(__half2float(lo[1]), a.rgb_activation), act_rgb(__half2float(lo[2]), a.rgb_activation));
-			const float dt = unwarp_dt(cin[(size_t)compacted_numsteps * 7 + 3]);
+			const float dt = unwarp_dt(cin[(size_t)compacted_numsteps * cs + 3]);
 			const float density = act_density(__half2float(lo[3]), a.density_activation);
 			const float alpha = 1.f - __expf(-density * dt);
 			const float weight = alpha * T;
 			rgb_ray = rgb_ray + weight * rgb;
-			if (a.depth_lambda > 0.0f) { const float* ck = cin + (size_t)compacted_numsteps * 7; depth_ray += weight * dist3(unwarp_position(mk3(ck[0], ck[1], ck[2]), aabb), ray_o); }
+			if (a.depth_lambda > 0.0f) { const float* ck = cin + (size_t)compacted_numsteps * cs; depth_ray += weight * dist3(unwarp_position(mk3(ck[0], ck[1], ck[2]), aabb), ray_o); }
 			if (a.train_mode == 1) { f3 ll, lg2; loss_and_gradient(rgbtarget, rgb, a.loss_type, ll, lg2); loss_bg = loss_bg + weight * ll; }
 			T *= (1.f - alpha);
 		}
@@ -824,7 +840,7 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		a.numsteps_inout[i * 2 + 1] = compacted_base;
 	}
 	if (active && compacted_numsteps > 0) {
-		float* cout = a.coords_out + (size_t)compacted_base * 7;
+		float* cout = a.coords_out + (size_t)compacted_base * cs;
 		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
 		f3 lloss, lgrad;
 		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
@@ -840,10 +856,11 @@ __global__ void __launch_bounds__(128) k_compute_loss(K3Args a) {
 		f3 rgb_ray2 = mk3(0.f), loss_bg2 = mk3(0.f);
 		T = 1.f;
 		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
-			const float* ci = cin + (size_t)j * 7;
-			float* cj = cout + (size_t)j * 7;
+			const float* ci = cin + (size_t)j * cs;
+			float* cj = cout + (size_t)j * cs;
 			const float c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3];
 			cj[0] = c0; cj[1] = c1; cj[2] = c2; cj[3] = c3; cj[4] = ci[4]; cj[5] = ci[5]; cj[6] = ci[6];
+			for (uint32_t k = 7; k < cs; ++k) cj[k] = ci[k];
 			if (a.src_index_out) a.src_index_out[compacted_base + j] = base + j;
 			const f3 pos = unwarp_position(mk3(c0, c1, c2), aabb);
 			const float depth = dist3(pos, ray_o);
@@ -947,6 +964,7 @@ static __device__ __forceinline__ float half_incl_scan(float x) {
 // PLAIN: train_mode Nerf and no depth supervision, as compile-time facts (the production instance): the Rfl / depth accumulators and their scans disappear.
 template <int RPW, bool ERR, bool PLAIN>
 __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
+	const uint32_t cs = PLAIN ? 7u : a.cstride; // (the production instance keeps the NerfCoordinate's 7 floats as a compile-time stride: models with extra dims run the generic one)
 	const int train_mode = PLAIN ? 0 : a.train_mode;
 	const float depth_lambda = PLAIN ? 0.f : a.depth_lambda;
 	constexpr uint32_t LPR = 64u / RPW, RPB = K3_RAYS_PER_BLOCK * RPW; // lanes per ray, rays per workgroup (16 wavefronts)
@@ -1022,7 +1040,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				else rgbtarget = background_color;
 			}
 		}
-		cin = a.coords_in + (size_t)base * 7;
+		cin = a.coords_in + (size_t)base * cs;
 		no = (const __half*)a.network_output + (size_t)base * a.output_stride;
 	}
 	{ // ---- pass 1: composite front to back until the transmittance cut; every lane of the wavefront takes part in the scans ----
@@ -1038,16 +1056,16 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				float l0, l1, l2, l3, dtw;
 				load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
 				if (c0 == 0) {
-					const float* ci = cin + (size_t)s * 7;
+					const float* ci = cin + (size_t)s * cs;
 #pragma unroll
 					for (int k = 0; k < 7; ++k) k_cc[k] = ci[k];
 					k_l0 = l0; k_l1 = l1; k_l2 = l2; k_l3 = l3;
 					dtw = k_cc[3];
-				} else dtw = cin[(size_t)s * 7 + 3];
+				} else dtw = cin[(size_t)s * cs + 3];
 				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
 				const float dt = unwarp_dt(dtw);
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
-				if (depth_lambda > 0.0f) { const float* ci = cin + (size_t)s * 7; sdepth = dist3(unwarp_position(mk3(ci[0], ci[1], ci[2]), aabb), ray_o); }
+				if (depth_lambda > 0.0f) { const float* ci = cin + (size_t)s * cs; sdepth = dist3(unwarp_position(mk3(ci[0], ci[1], ci[2]), aabb), ray_o); }
 			}
 			const float incl = seg_prod(1.f - alpha);
 			float excl = __shfl_up(incl, 1, 64);
@@ -1093,7 +1111,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		if (sl == 0) { a.numsteps_inout[i * 2 + 0] = compacted; a.numsteps_inout[i * 2 + 1] = compacted_base; }
 	} else compacted = 0;
 	{ // ---- pass 2: adjoint + compaction ----
-		float* cout = a.coords_out + (size_t)compacted_base * 7;
+		float* cout = a.coords_out + (size_t)compacted_base * cs;
 		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
 		f3 lloss = mk3(0.f), lgrad = mk3(0.f);
 		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
@@ -1129,7 +1147,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 					for (int k = 0; k < 7; ++k) cc[k] = k_cc[k];
 					l0 = k_l0; l1 = k_l1; l2 = k_l2; l3 = k_l3;
 				} else {
-					const float* ci = cin + (size_t)s * 7;
+					const float* ci = cin + (size_t)s * cs;
 #pragma unroll
 					for (int k = 0; k < 7; ++k) cc[k] = ci[k];
 					load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
@@ -1153,9 +1171,10 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 				lb2 = lb2_run + mk3(seg_sum(weight * lloc.x), seg_sum(weight * lloc.y), seg_sum(weight * lloc.z));
 			}
 			if (valid) {
-				float* cj = cout + (size_t)s * 7;
+				float* cj = cout + (size_t)s * cs;
 #pragma unroll
 				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
+				for (uint32_t k = 7; k < cs; ++k) cj[k] = cin[(size_t)s * cs + k];
 				if (a.src_index_out) a.src_index_out[compacted_base + s] = base + s; // which K2 sample this batch row is (EncStashIn)
 				const f3 suffix = rgb_ray - ray2;
 				f3 dloss_by_drgb = weight * lgrad;
@@ -1207,6 +1226,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 constexpr uint32_t K3_REC = 16; // floats per ray record
 template <int PASS>
 __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __restrict__ rec, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
+	const uint32_t cs = a.cstride;
 	__shared__ uint64_t s_tot[4];
 	__shared__ uint64_t s_scan[4];
 	__shared__ uint32_t s_ticket;
@@ -1256,7 +1276,7 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 					else rgbtarget = background_color;
 				}
 			}
-			const float* cin = a.coords_in + (size_t)base * 7;
+			const float* cin = a.coords_in + (size_t)base * cs;
 			const __half* no = (const __half*)a.network_output + (size_t)base * a.output_stride;
 			float T_run = 1.f;
 			uint32_t compacted = 0;
@@ -1267,7 +1287,7 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 				if (valid) {
 					float l0, l1, l2, l3;
 					load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
-					const float dtw = cin[(size_t)s * 7 + 3];
+					const float dtw = cin[(size_t)s * cs + 3];
 					rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
 					const float dt = unwarp_dt(dtw);
 					alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
@@ -1353,9 +1373,9 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 		compacted = min(a.max_samples_compacted - min(a.max_samples_compacted, compacted_base), compacted);
 		if (lane == 0) { a.numsteps_inout[i * 2 + 0] = compacted; a.numsteps_inout[i * 2 + 1] = compacted_base; }
 		if (compacted == 0) continue;
-		const float* cin = a.coords_in + (size_t)base * 7;
+		const float* cin = a.coords_in + (size_t)base * cs;
 		const __half* no = (const __half*)a.network_output + (size_t)base * a.output_stride;
-		float* cout = a.coords_out + (size_t)compacted_base * 7;
+		float* cout = a.coords_out + (size_t)compacted_base * cs;
 		__half* dl = (__half*)a.dloss_doutput + (size_t)compacted_base * a.dloss_stride;
 		f3 lloss, lgrad;
 		loss_and_gradient(rgbtarget, rgb_ray, a.loss_type, lloss, lgrad);
@@ -1372,7 +1392,7 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 			f3 rgb = mk3(0.f);
 			float cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 			if (valid) {
-				const float* ci = cin + (size_t)s * 7;
+				const float* ci = cin + (size_t)s * cs;
 #pragma unroll
 				for (int k = 0; k < 7; ++k) cc[k] = ci[k];
 				load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
@@ -1393,9 +1413,10 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 				lb2 = lb2_run + mk3(wave_incl_sum(weight * lloc.x, lane), wave_incl_sum(weight * lloc.y, lane), wave_incl_sum(weight * lloc.z, lane));
 			}
 			if (valid) {
-				float* cj = cout + (size_t)s * 7;
+				float* cj = cout + (size_t)s * cs;
 #pragma unroll
 				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
+				for (uint32_t k = 7; k < cs; ++k) cj[k] = cin[(size_t)s * cs + k];
 				const f3 suffix = rgb_ray - ray2;
 				f3 dloss_by_drgb = weight * lgrad;
 				float dmlp_inner = dot3(lgrad, T_after * rgb - suffix) + 0.0f;
@@ -1435,7 +1456,7 @@ __global__ void __launch_bounds__(256) k_compute_loss_v3(K3Args a, float* __rest
 // NerfCounters::update_after_training (testbed_nerf.cu:2669-2702) on the device-resident counters: one thread
 static __device__ __forceinline__ void update_counters_body(TrainCounters* c, uint32_t target_batch_size, uint32_t world_size) {
 	const uint32_t before = c->numsteps_counter, compacted = c->numsteps_counter_compacted;
-	c->n_rays_last = c->ray_counter;
+	c->n_rays_last = c->ray_counter; c->rays_per_batch_last = c->rays_per_batch;
 	c->total_rays += c->rays_per_batch;
 	c->training_step += 1;
 	if (before == 0 || compacted == 0) {
@@ -1626,10 +1647,50 @@ __global__ void k_clamp_compacted(TrainCounters* c, uint32_t target_batch_size) 
 	c->n_inference = min(c->numsteps_counter, c->max_inference);
 }
 
+// compute_extra_dims_gradient_train_nerf (testbed_nerf.cu:1293-1330): one thread per compacted ray sums its samples' dL/d(extra dims) (the network's input gradient, left
+// per batch row by T1) into its image's gradient with float atomics.  numsteps = {compacted count, compacted base} as K3 left them; rays whose span was cut by the batch
+// size carry count 0.
+__global__ void __launch_bounds__(128) k_extra_dims_gradient(const uint32_t* __restrict__ n_rays_total_ptr, const uint32_t* __restrict__ rays_counter, float* __restrict__ extra_grad,
+		uint32_t n_extra, uint32_t n_images, const uint32_t* __restrict__ ray_indices, const uint32_t* __restrict__ numsteps, const float* __restrict__ dextra, uint32_t max_rows,
+		const float* __restrict__ cdf_img) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= *rays_counter) return;
+	const uint32_t count = numsteps[i * 2 + 0], base = numsteps[i * 2 + 1];
+	if (count == 0 || base + count > max_rows) return;
+	const uint32_t ray_idx = ray_indices[i];
+	const uint32_t img = cdf_img ? image_idx_cdf(ray_idx, n_images, cdf_img, nullptr) : image_idx(ray_idx, *n_rays_total_ptr, n_images);
+	float* g = extra_grad + (size_t)img * n_extra;
+	for (uint32_t k = 0; k < n_extra; ++k) {
+		float sum = 0.f; // (the reference issues one atomic per sample and dim; the ray's samples are summed here first -- same set of fp32 additions up to their order)
+		for (uint32_t j = 0; j < count; ++j) sum += dextra[(size_t)(base + j) * n_extra + k];
+		atomicAdd(g + k, sum);
+	}
+}
+// VarAdamOptimizer::step (adam_optimizer.h:37-47) for every image's variable at once: one thread per (image, dim); gradient / LOSS_SCALE as in testbed_nerf.cu:2868
+__global__ void __launch_bounds__(128) k_extra_dims_adam(uint32_t n, float* __restrict__ variable, const float* __restrict__ gradient, float* __restrict__ m, float* __restrict__ v,
+		uint32_t iter, float lr, float loss_scale) {
+#pragma clang fp contract(off)
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const float beta1 = 0.9f, beta2 = 0.99f, epsilon = 1e-8f; // VarAdamOptimizer(n_extra_dims, 1e-4f): the defaults of adam_optimizer.h:29
+	const float actual_learning_rate = lr * sqrtf(1.0f - powf(beta2, (float)iter)) / (1.0f - powf(beta1, (float)iter));
+	const float g = gradient[i] / loss_scale;
+	const float fm = m[i] = beta1 * m[i] + (1.0f - beta1) * g;
+	const float sm = v[i] = beta2 * v[i] + (1.0f - beta2) * g * g;
+	variable[i] -= actual_learning_rate * fm / (sqrtf(sm) + epsilon);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t blocks(uint32_t n, uint32_t t) { return (n + t - 1) / t; }
+void launch_extra_dims_gradient(hipStream_t s, uint32_t max_rays, const uint32_t* n_rays_total_ptr, const uint32_t* rays_counter, float* extra_grad, uint32_t n_extra, uint32_t n_images,
+		const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows, const float* cdf_img) {
+	hipLaunchKernelGGL(k_extra_dims_gradient, dim3(blocks(max_rays, 128)), dim3(128), 0, s, n_rays_total_ptr, rays_counter, extra_grad, n_extra, n_images, ray_indices, numsteps, dextra, max_rows, cdf_img);
+}
+void launch_extra_dims_adam(hipStream_t s, uint32_t n, float* variable, const float* gradient, float* m, float* v, uint32_t iter, float lr, float loss_scale) {
+	if (n) hipLaunchKernelGGL(k_extra_dims_adam, dim3(blocks(n, 128)), dim3(128), 0, s, n, variable, gradient, m, v, iter, lr, loss_scale);
+}
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank) {
 	if (max_rays_this_rank == 0) return;
@@ -1742,7 +1803,7 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 	else if (!a.k3_scratch || !(g_debug_flags & DBG_K3_TWO_PASS)) {
 		const bool err = a.error_map || a.cdf.x_cond_y || a.cdf.img;
 		const dim3 g1(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK), 256u * 2u)), g2(std::min<uint32_t>(blocks(max_rays, K3_RAYS_PER_BLOCK * 2), 256u * 2u));
-		const bool plain = a.train_mode == 0 && !(a.depth_lambda > 0.f) && !(g_debug_flags & DBG_K3_GENERIC);
+		const bool plain = a.train_mode == 0 && !(a.depth_lambda > 0.f) && !(g_debug_flags & DBG_K3_GENERIC) && a.cstride == 7;
 		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) { if (err) hipLaunchKernelGGL((k_compute_loss_v2<1, true, false>), g1, dim3(1024), 0, s, a); else hipLaunchKernelGGL((k_compute_loss_v2<1, false, false>), g1, dim3(1024), 0, s, a); }
 		else if (err) hipLaunchKernelGGL((k_compute_loss_v2<2, true, false>), g2, dim3(1024), 0, s, a);
 		else if (plain) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true>), g2, dim3(1024), 0, s, a);

@@ -243,6 +243,7 @@ struct ngp_model {
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
 	bool adam_fused_pending = false; uint64_t adam_sweep_end = 0; // this step's k_grad_accumulate has already applied the optimizer to the hashed levels: the sweep covers [0, adam_sweep_end) only
+	float* dextra_out = nullptr; // this training step also leaves dL/d(extra dims) per sample here (n x n_extra_dims floats; set by the callers that want it)
 	bool grads_clean = true; // the hash-grid part of `grads` is all zero (after creation / after an optimizer sweep that zeroed it)
 };
 
@@ -273,11 +274,14 @@ static void build_grid_meta(const ngp_model_config& c, GridMeta& g) {
 
 // MLP layers in parameter order (nerf_network.h:357-372): density L1, L2, then the colour network's L1, its NR - 1 layers of 64 x 64, and its output
 // layer; row-major [out][in].  Fragment bases as in model_kernels.hip (FW_* / BW_*, fw_r3 / bw_r3).
-struct LayerDesc { uint32_t R, C, off, fw_base, bw_base; };
-static std::vector<LayerDesc> nerf_layers(uint32_t n_rgb_hidden) {
-	std::vector<LayerDesc> L = {{64, 32, 0, 0, 0}, {16, 64, 2048, 4, 4}, {64, 32, 3072, 8, 6}};
-	for (uint32_t k = 0; k + 1 < n_rgb_hidden; ++k) L.push_back({64, 64, 5120 + 4096 * k, 12 + 8 * k, 10 + 8 * k});
-	L.push_back({16, 64, 5120 + 4096 * (n_rgb_hidden - 1), 12 + 8 * (n_rgb_hidden - 1), 10 + 8 * (n_rgb_hidden - 1)});
+// Extra dims (n_extra_dims > 0): the colour network's first layer is 64 x 48 (nerf_network.h:84-95: dir encoding = 16 SH + the extra dims, padded to 32 columns); its
+// columns 32..47 live in fragments BEHIND the regular ones (xfw / xbw = their first index, 0 = none), so every other fragment index is the same in both kinds of model.
+struct LayerDesc { uint32_t R, C, off, fw_base, bw_base, xfw = 0, xbw = 0; };
+static std::vector<LayerDesc> nerf_layers(uint32_t n_rgb_hidden, bool extra = false) {
+	const uint32_t xo = extra ? 64u * 16u : 0u;
+	std::vector<LayerDesc> L = {{64, 32, 0, 0, 0}, {16, 64, 2048, 4, 4}, {64, extra ? 48u : 32u, 3072, 8, 6, extra ? n_fw_frags(n_rgb_hidden) : 0u, extra ? n_bw_frags(n_rgb_hidden) : 0u}};
+	for (uint32_t k = 0; k + 1 < n_rgb_hidden; ++k) L.push_back({64, 64, 5120 + xo + 4096 * k, 12 + 8 * k, 10 + 8 * k});
+	L.push_back({16, 64, 5120 + xo + 4096 * (n_rgb_hidden - 1), 12 + 8 * (n_rgb_hidden - 1), 10 + 8 * (n_rgb_hidden - 1)});
 	return L;
 }
 
@@ -291,13 +295,13 @@ static void build_perms(const std::vector<LayerDesc>& layers, uint32_t n_mlp, st
 			{ // forward: A[row = i][k]; fragment index = base + (i/32) * (C/16) + s
 				const uint32_t mt = i / 32, s = k / 16, kk = k % 16;
 				const uint32_t j = (kk / 8) * 4 + (kk % 4), hi = (kk % 8) / 4;
-				const uint32_t frag = L.fw_base + mt * (L.C / 16) + s, lane = hi * 32 + (i % 32);
+				const uint32_t frag = s >= 2 && L.xfw ? L.xfw + mt : L.fw_base + mt * ((L.xfw ? 32u : L.C) / 16) + s, lane = hi * 32 + (i % 32);
 				fw[p] = (frag * 64 + lane) * 8 + j;
 			}
 			{ // dgrad: A[row = k][i]; fragment index = base + (k/32) * ceil(R/16) + s
 				const uint32_t mt = k / 32, s = i / 16, ii = i % 16;
 				const uint32_t j = (ii / 8) * 4 + (ii % 4), hi = (ii % 8) / 4;
-				const uint32_t frag = L.bw_base + mt * ((L.R + 15) / 16) + s, lane = hi * 32 + (k % 32);
+				const uint32_t frag = mt >= 1 && L.xbw ? L.xbw + s : L.bw_base + mt * ((L.R + 15) / 16) + s, lane = hi * 32 + (k % 32);
 				bw[p] = (frag * 64 + lane) * 8 + j;
 			}
 		}
@@ -314,14 +318,17 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 	// base.json, notebooks/instant_ngp.ipynb:5838); any log2_hashmap_size (base_14, small, big: table sizes the record lists do not cover fall back to half atomics)
 	REQUIRE((cfg->n_features_per_level == 4 && cfg->n_levels == 8) || (cfg->n_features_per_level == 2 && cfg->n_levels == 16), "the fused kernels take the hash grid as L = 8, F = 4 or L = 16, F = 2");
 	REQUIRE(cfg->log2_hashmap_size >= 12 && cfg->log2_hashmap_size <= 24 && cfg->base_resolution >= 2 && cfg->per_level_scale >= 1.0f, "hash grid: log2_hashmap_size in [12, 24], base_resolution >= 2, per_level_scale >= 1");
-	REQUIRE(cfg->sh_degree == 4 && cfg->n_extra_dims == 0, "only SphericalHarmonics degree 4 without extra dims is implemented");
+	REQUIRE(cfg->sh_degree == 4, "only SphericalHarmonics degree 4 is implemented");
+	REQUIRE(cfg->n_extra_dims <= 16, "at most 16 extra dims (the dir encoding's Identity part fills one 16-wide k-step of the colour network's input)");
+	REQUIRE(cfg->n_extra_dims == 0 || (cfg->n_features_per_level == 4 && cfg->n_hidden_layers_rgb == 2), "extra dims are implemented for configs/nerf/base.json's shape: L = 8, F = 4, two hidden colour layers");
 	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
 	ngp_model* m = new ngp_model();
 	m->cfg = *cfg;
 	build_grid_meta(*cfg, m->gm);
-	const uint32_t nr = cfg->n_hidden_layers_rgb, n_fw_halfs = n_fw_frags(nr) * FRAG_HALFS, n_bw_halfs = n_bw_frags(nr) * FRAG_HALFS;
-	const std::vector<LayerDesc> layers = nerf_layers(nr);
-	m->n_mlp = n_mlp_params(nr);
+	const bool extra = cfg->n_extra_dims > 0;
+	const uint32_t nr = cfg->n_hidden_layers_rgb, n_fw_halfs = (n_fw_frags(nr) + (extra ? 2u : 0u)) * FRAG_HALFS, n_bw_halfs = (n_bw_frags(nr) + (extra ? 4u : 0u)) * FRAG_HALFS;
+	const std::vector<LayerDesc> layers = nerf_layers(nr, extra);
+	m->n_mlp = n_mlp_params(nr) + (extra ? 64u * 16u : 0u);
 	m->n_params = m->n_mlp + (uint64_t)m->gm.offset[cfg->n_levels] * cfg->n_features_per_level;
 	m->lr = cfg->learning_rate;
 	const uint64_t P = m->n_params;
@@ -339,7 +346,7 @@ extern "C" int ngp_model_create(const ngp_model_config* cfg, uint64_t seed, ngp_
 	HIPCHK(hipMemcpy(m->fw_perm, fwp.data(), fwp.size() * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(m->bw_perm, bwp.data(), bwp.size() * 4, hipMemcpyHostToDevice));
 	m->n_partials = wgrad_n_partials();
-	if (dev_alloc(&m->wgrad_partials, (size_t)m->n_partials * (8 + 4 * (nr - 1)) * 16 * 64)) { delete m; return 1; }
+	if (dev_alloc(&m->wgrad_partials, (size_t)m->n_partials * (8 + 4 * (nr - 1) + (extra ? 2 : 0)) * 16 * 64)) { delete m; return 1; }
 	// Trainer::initialize_params: pcg32{seed}; Xavier-uniform matrices, U(-1e-4, 1e-4) grid (element j <- draw j)
 	std::vector<float> init(P);
 	Rng rnd = make_rng(seed);
@@ -413,6 +420,7 @@ static ModelPtrs model_ptrs(const ngp_model* m, bool inference) {
 	mp.fw_frags = inference ? m->fw_frags_inf : m->fw_frags;
 	mp.bw_frags = m->bw_frags;
 	mp.n_rgb_hidden = m->cfg.n_hidden_layers_rgb;
+	mp.n_extra = m->cfg.n_extra_dims;
 	return mp;
 }
 
@@ -441,12 +449,21 @@ extern "C" int ngp_model_encode(ngp_model* m, void* stream, const float* pos, ui
 static AdamArgs make_adam_args(const ngp_model* m, float loss_scale, uint32_t step);
 static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in, float fuse_optimizer_loss_scale = 0.f);
 extern "C" int ngp_model_training_step(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride) {
+	m->dextra_out = nullptr;
 	return model_training_step_impl(m, stream, in, in_stride, n, dL_dy, dy_stride, nullptr);
+}
+extern "C" int ngp_model_training_step_extra(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, float* dL_dextra) {
+	REQUIRE(m->cfg.n_extra_dims > 0 || !dL_dextra, "training_step_extra: the model has no extra dims");
+	m->dextra_out = dL_dextra;
+	const int r = model_training_step_impl(m, stream, in, in_stride, n, dL_dy, dy_stride, nullptr);
+	m->dextra_out = nullptr;
+	return r;
 }
 // fuse_optimizer_loss_scale > 0: the caller runs ngp_model_optimizer_step(m, stream, that loss scale) next, with nothing in between that looks at the hash-grid gradients
 // (ngp_nerf_train on one GPU): k_grad_accumulate then applies the optimizer to the hashed levels itself (GradBinArgs::fuse_adam).
 static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in, float fuse_optimizer_loss_scale) {
-	REQUIRE(in_stride >= 7 && dy_stride >= 4 && dy_stride % 4 == 0, "training_step: in_stride >= 7, dy_stride a multiple of 4 halfs");
+	REQUIRE(in_stride >= 7 + m->cfg.n_extra_dims && dy_stride >= 4 && dy_stride % 4 == 0, "training_step: in_stride >= 7 + n_extra_dims, dy_stride a multiple of 4 halfs");
+	if (m->cfg.n_extra_dims) stash_in = nullptr; // (the lazy K2 that leaves the encodings behind has no extra-dims instance)
 	hipStream_t s = (hipStream_t)stream;
 	const size_t need = (size_t)((n + 31) / 32) * 2 * 64 * 8; // halfs
 	if (need > m->stash_halfs) {
@@ -514,7 +531,7 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 	if (ba.n_hashed && m->gm.F == 4 && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !m->bin_dense && !(g_debug_flags & DBG_T1_NO_SCATTER))
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
 	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
-		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n, m->gm.F, stash_in); }
+		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n, m->gm.F, stash_in, m->dextra_out); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
 	hipStream_t sw = s;
@@ -536,7 +553,7 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 		}
 	}
 	{ ProfScope ps(P_W_WGRAD, sw); launch_wgrad(sw, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
-	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads, m->cfg.n_hidden_layers_rgb); }
+	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads, m->cfg.n_hidden_layers_rgb, m->cfg.n_extra_dims); }
 	if (ba.n_hashed) {
 		ProfScope ps(P_GRAD_BIN, s);
 		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap; ba.n_features = m->gm.F;
@@ -1297,6 +1314,11 @@ struct ngp_nerf {
 	Rng rng, density_grid_rng;
 	uint32_t training_step = 0, prep_skip_counter = 0, ema_step = 0;
 	uint32_t max_rays = 1u << 18;
+	// extra (latent / light-direction) dims, testbed.h Nerf::Training::extra_dims_gpu / extra_dims_opt / rendering_extra_dims: n_extra floats per image (+ one slot behind them
+	// for the dims a rendering uses), their gradient, the per-image VarAdamOptimizer state (adam_optimizer.h:27-47; one iteration count: every image steps every time)
+	uint32_t n_extra = 0, extra_cap = 0 /* images the buffers hold */, extra_iter = 0; bool optimize_extra_dims = false;
+	float* extra_dims = nullptr; float* extra_grad = nullptr; float* extra_m = nullptr; float* extra_v = nullptr; float* dextra = nullptr /* dL/d(extra dims) per batch row */;
+	int rendering_extra_view = -1; std::vector<float> rendering_extra; // testbed_nerf.cu:3685-3707: the dims a rendering uses = those of a training view, or explicit values
 };
 
 
@@ -1305,7 +1327,7 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	REQUIRE(o->world_size >= 1 && o->rank < o->world_size, "ngp_nerf_create: bad rank/world_size");
 	REQUIRE(o->max_cascade < N_CASCADES, "ngp_nerf_create: max_cascade must be < 8 (NERF_CASCADES)");
 	ngp_nerf* t = new ngp_nerf();
-	t->model = model; t->opt = *o; t->aabb = aabb;
+	t->model = model; t->opt = *o; t->aabb = aabb; t->n_extra = model->cfg.n_extra_dims;
 	t->rng = make_rng(o->seed);                         // testbed.cu:4163
 	t->density_grid_rng = make_rng(t->rng.next_uint()); // testbed.cu:4178
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
@@ -1319,8 +1341,8 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 		dev_alloc(&t->mean, 1) || dev_alloc(&t->mean_partial, 256) || dev_alloc(&t->grid_positions, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices, n_cells) ||
 		dev_alloc(&t->grid_positions_sorted, (size_t)n_cells * 3) || dev_alloc(&t->grid_indices_sorted, n_cells) || dev_alloc(&t->grid_sort_temp, t->grid_sort_temp_bytes = grid_sample_sort_temp_bytes(n_cells)) ||
 		dev_alloc(&t->grid_mlp_out, n_cells) || dev_alloc(&t->counters, 1) || dev_alloc(&t->ray_indices, t->max_rays) || dev_alloc(&t->rays, t->max_rays) ||
-		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_enc, (size_t)max_samples * 4) || dev_alloc(&t->src_index, B) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * 7) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
-		dev_alloc(&t->coords_compacted, (size_t)B * 7) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES) || dev_alloc(&t->bitfield_coarse, (size_t)k1_prefilter_words(N_CASCADES)) ||
+		dev_alloc(&t->numsteps, (size_t)t->max_rays * 2) || dev_alloc(&t->ray_targets, (size_t)t->max_rays * 8) || dev_alloc(&t->k2_enc, (size_t)max_samples * 4) || dev_alloc(&t->src_index, B) || dev_alloc(&t->k2_T, t->max_rays) || dev_alloc(&t->k2_tiles, (size_t)2 * (t->k2_tile_cap = max_samples / 16 + t->max_rays)) || dev_alloc(&t->coords, (size_t)max_samples * (7 + model->cfg.n_extra_dims)) || dev_alloc(&t->mlp_out, (size_t)max_samples * 4) ||
+		dev_alloc(&t->coords_compacted, (size_t)B * (7 + model->cfg.n_extra_dims)) || dev_alloc(&t->dloss, (size_t)B * 4) || dev_alloc(&t->sync2, 4) || dev_alloc(&t->bitfield_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES) || dev_alloc(&t->bitfield_coarse, (size_t)k1_prefilter_words(N_CASCADES)) ||
 		dev_alloc(&t->k1_scratch, k1_lattice_scratch_bytes(t->max_rays)) || dev_alloc(&t->k3_scratch, k3_scratch_bytes(t->max_rays))) { delete t; return 1; }
 	if (k1_lattice_scratch_init(nullptr, t->k1_scratch, t->max_rays) || k3_scratch_init(nullptr, t->k3_scratch, t->max_rays) || hipDeviceSynchronize() != hipSuccess) { delete t; return fail("k1 scratch init"); }
 	HIPCHK(hipMemset(t->density_grid, 0, (size_t)n_cells * 4));
@@ -1363,7 +1385,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->xcd_work, (void*)t->k2_enc_lv}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->xcd_work, (void*)t->k2_enc_lv, (void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v, (void*)t->dextra}) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
 }
@@ -1380,6 +1402,18 @@ static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_ima
 		t->cdf_valid = false; t->error_cycle_open = false; t->n_steps_since_error_map_update = 0; // (the next step opens a cycle sized for n; dev_grow regrows the buffers)
 	}
 	t->n_images = n;
+	if (t->n_extra && n > t->extra_cap) { // the extra dims follow the image count: existing values are kept, new images start at zero (ngp_nerf_set_extra_dims installs the reference's initial values)
+		float* nd = nullptr; float* ng = nullptr; float* nm = nullptr; float* nv = nullptr;
+		const size_t cnt = (size_t)(n + 1) * t->n_extra;
+		if (dev_alloc(&nd, cnt) || dev_alloc(&ng, cnt) || dev_alloc(&nm, cnt) || dev_alloc(&nv, cnt)) return 1;
+		HIPCHK(hipMemset(nd, 0, cnt * 4)); HIPCHK(hipMemset(ng, 0, cnt * 4)); HIPCHK(hipMemset(nm, 0, cnt * 4)); HIPCHK(hipMemset(nv, 0, cnt * 4));
+		if (t->extra_dims) {
+			const size_t old = (size_t)t->extra_cap * t->n_extra * 4;
+			HIPCHK(hipMemcpy(nd, t->extra_dims, old, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nm, t->extra_m, old, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nv, t->extra_v, old, hipMemcpyDeviceToDevice));
+			for (void* q : {(void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v}) (void)hipFree(q);
+		}
+		t->extra_dims = nd; t->extra_grad = ng; t->extra_m = nm; t->extra_v = nv; t->extra_cap = n;
+	}
 	return 0;
 }
 extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_image_meta* meta, const ngp_xform* xforms, const void* const* pixels_host) {
@@ -1557,6 +1591,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		k1.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE); k1.clamp_min_max = (g_debug_flags & DBG_K1_MIP_CLAMP_MIN_MAX) ? 1u : 0u;
 		k1.depth_lambda = o.depth_supervision_lambda;
 		k1.cdf = error_cdf_args(t);
+		k1.extra_dims = t->extra_dims; k1.n_extra = t->n_extra;
 		return k1;
 	};
 	if (phase & 1) {
@@ -1577,7 +1612,8 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		if (g_debug_flags & DBG_K1_REFERENCE_LAYOUT) launch_generate_training_samples(s, k1, t->max_rays);
 		else launch_generate_training_samples_lattice(s, k1, t->max_rays, t->k1_scratch);
 	}
-	const bool lazy_k2 = lattice && !(g_debug_flags & DBG_K2_EAGER); // the round-0 tile list comes from the lattice K1
+	const uint32_t cs = 7 + t->n_extra; // floats per NerfCoordinate
+	const bool lazy_k2 = lattice && !(g_debug_flags & DBG_K2_EAGER) && !t->n_extra; // the round-0 tile list comes from the lattice K1 (models with extra dims: every sample, like the reference)
 	if (!lazy_k2) { ProfScope ps(P_COUNTERS, s); launch_clamp_compacted(s, c, B); } // n_inference for the eager K2
 	{ ProfScope ps(P_K2_INFERENCE, s);
 	  if (lazy_k2) {
@@ -1602,7 +1638,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la, t->model->gm.F);
 	  } else {
 	  t->k2_enc_valid = false; // eager K2 (ablation): T1 gathers
-	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, max_samples, &c->n_inference, t->mlp_out, 4, false, 4, t->model->gm.F); } }
+	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, cs, max_samples, &c->n_inference, t->mlp_out, 4, false, 4, t->model->gm.F); } }
 	K3Args k3;
 	k3.n_rays = 0; k3.n_rays_ptr = &c->rays_per_batch; k3.aabb = t->aabb; k3.rng = pod(t->rng); k3.max_samples_compacted = B; k3.rays_counter = &c->ray_counter;
 	k3.loss_scale = o.loss_scale; for (int k = 0; k < 3; ++k) k3.background_color[k] = o.background_color[k];
@@ -1615,6 +1651,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	k3.depth_lambda = o.depth_supervision_lambda; k3.depth_loss_type = o.depth_loss_type;
 	if (k3.depth_lambda > 0.f) k3.k3_scratch = nullptr; // the two-pass ablation kernel has no depth term: the one-pass kernel runs
 	k3.src_index_out = t->k2_enc_valid ? t->src_index : nullptr;
+	k3.cstride = cs;
 	k3.cdf = error_cdf_args(t);
 	if (t->error_cycle_open) { k3.error_map = t->error_map; k3.error_map_res[0] = t->error_map_res[0]; k3.error_map_res[1] = t->error_map_res[1]; }
 	if (k3.error_map || k3.cdf.x_cond_y || k3.cdf.img) k3.k3_scratch = nullptr; // (nor the error map)
@@ -1622,7 +1659,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	// K4 clamps K3's counter itself and publishes {marched, compacted} for the cross-rank all-reduce (8e)
 	// single rank, forward and backward in one call: the controller rides on K4's last workgroup (no launch of its own)
 	const bool fuse_ctl = (phase & 2) && o.world_size == 1 && !(g_debug_flags & DBG_SEPARATE_CONTROLLER);
-	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, 7, t->dloss, 4, &c->numsteps_counter, t->sync2, fuse_ctl ? c : nullptr, o.world_size, &c->loss_sum); }
+	{ ProfScope ps(P_K4, s); launch_fill_rollover(s, B, &c->numsteps_counter_compacted, t->coords_compacted, cs, t->dloss, 4, &c->numsteps_counter, t->sync2, fuse_ctl ? c : nullptr, o.world_size, &c->loss_sum); }
 	if (fuse_ctl) t->ctl_done = true;
 	}
 	if (phase & 2) {
@@ -1634,7 +1671,8 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, B, o.world_size);
 		t->ctl_done = true;
 	}
-	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t);
+	const bool train_extra = t->n_extra && t->optimize_extra_dims; // (testbed_nerf.cu:2743)
+	const bool prelaunch = early_ctl && lattice && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP) && !next_prep_updates_grid(t) && !train_extra; // (the next K1 copies the extra dims this step's optimizer is about to change)
 	if (prelaunch) {
 		if (!t->k1_stream) { if (create_helper_stream(&g_k1_stream, true)) return 1; t->k1_stream = g_k1_stream; } // highest priority: K1's small latency-bound kernels slip in between the backward pass's workgroups
 		if (!t->ev_ctl) { HIPCHK(hipEventCreateWithFlags(&t->ev_ctl, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_k1, hipEventDisableTiming)); }
@@ -1642,7 +1680,19 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 	}
 	EncStashIn stash_in;
 	if (t->k2_enc_valid) { stash_in.enc = t->k2_enc; stash_in.src_index = t->src_index; stash_in.n_valid_ptr = t->sync2 + 3; }
-	if (model_training_step_impl(t->model, stream, t->coords_compacted, 7, B, t->dloss, 4, t->k2_enc_valid ? &stash_in : nullptr, optimizer_follows && o.world_size == 1 && !t->comm ? o.loss_scale : 0.f)) return 1;
+	if (train_extra) {
+		REQUIRE(o.world_size == 1, "optimize_extra_dims: single rank only (the per-image gradients are not all-reduced)");
+		if (!t->dextra && dev_alloc(&t->dextra, (size_t)B * t->n_extra)) return 1;
+		t->model->dextra_out = t->dextra;
+	}
+	const int tr = model_training_step_impl(t->model, stream, t->coords_compacted, 7 + t->n_extra, B, t->dloss, 4, t->k2_enc_valid ? &stash_in : nullptr, optimizer_follows && o.world_size == 1 && !t->comm ? o.loss_scale : 0.f);
+	t->model->dextra_out = nullptr;
+	if (tr) return 1;
+	if (train_extra) { // testbed_nerf.cu:2745-2750 (clear) + :3325-3340 (compute_extra_dims_gradient_train_nerf over the compacted rays)
+		HIPCHK(hipMemsetAsync(t->extra_grad, 0, (size_t)t->n_images * t->n_extra * 4, s));
+		// (the controller has closed the step by now -- single rank: it rides on K4 or runs right behind it -- and keeps the step's ray counts in *_last)
+		launch_extra_dims_gradient(s, t->max_rays, &c->rays_per_batch_last, &c->n_rays_last, t->extra_grad, t->n_extra, t->n_images, t->ray_indices, t->numsteps, t->dextra, B, error_cdf_args(t).img);
+	}
 	t->rng.advance(1ull << 32); // m_rng.advance(), testbed_nerf.cu:3377
 	if (prelaunch) { // K1 of the NEXT step (its rng position), concurrent with this step's backward pass and optimizer
 		HIPCHK(hipStreamWaitEvent(t->k1_stream, t->ev_ctl, 0));
@@ -1677,6 +1727,8 @@ extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	if (t->grads_pending) { HIPCHK(hipStreamWaitEvent(s, t->ev_red_a, 0)); HIPCHK(hipStreamWaitEvent(s, t->ev_red_b, 0)); t->grads_pending = false; }
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
+	if (t->n_extra && t->optimize_extra_dims) // testbed_nerf.cu:2860-2878: one VarAdamOptimizer step per image at the network optimizer's current learning rate
+		launch_extra_dims_adam(s, t->n_images * t->n_extra, t->extra_dims, t->extra_grad, t->extra_m, t->extra_v, ++t->extra_iter, t->model->lr, t->opt.loss_scale);
 	if (!t->ctl_done) { // the controller has not run behind K3 (multi-rank caller using ngp_nerf_train_forward_backward)
 		if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
 		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size, t->opt.world_size);
@@ -1887,6 +1939,57 @@ extern "C" int ngp_nerf_set_k2_params(ngp_nerf* t, uint32_t rounds, uint32_t til
 extern "C" int ngp_nerf_set_rng(ngp_nerf* t, const ngp_pcg32* rng) { invalidate_k1(t); t->rng.state = rng->state; t->rng.inc = rng->inc; return 0; }
 extern "C" int ngp_nerf_get_rng(ngp_nerf* t, ngp_pcg32* rng, ngp_pcg32* grid_rng) { *rng = pod(t->rng); *grid_rng = pod(t->density_grid_rng); return 0; }
 
+// stand-alone launches of the two extra-dims kernels (test hooks like ngp_k_generate_training_samples): device pointers
+extern "C" int ngp_k_extra_dims_gradient(void* stream, uint32_t n_rays_total, uint32_t rays_counter, float* grad_out, uint32_t n_extra, uint32_t n_images, const uint32_t* ray_indices,
+		const uint32_t* numsteps, const float* dextra, uint32_t max_rows) {
+	static uint32_t* s_cnt = nullptr;
+	if (!s_cnt && dev_alloc(&s_cnt, 2)) return 1;
+	const uint32_t h[2] = {n_rays_total, rays_counter};
+	HIPCHK(hipMemcpyAsync(s_cnt, h, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+	launch_extra_dims_gradient((hipStream_t)stream, rays_counter, s_cnt, s_cnt + 1, grad_out, n_extra, n_images, ray_indices, numsteps, dextra, max_rows, nullptr);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+extern "C" int ngp_k_extra_dims_adam(void* stream, uint32_t n, float* variable, const float* gradient_scaled, float* m, float* v, uint32_t iter, float lr, float loss_scale) {
+	launch_extra_dims_adam((hipStream_t)stream, n, variable, gradient_scaled, m, v, iter, lr, loss_scale);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+// ---- extra dims (testbed.h Nerf::Training::extra_dims_gpu, optimize_extra_dims; python_api.cu set_rendering_extra_dims*) ----
+// values: n_images x n_extra_dims floats on the host (reset_extra_dims computes them: warped light directions / uniform random latents, testbed_nerf.cu:3656-3683);
+// installs them and resets the per-image optimizers (reset_state)
+extern "C" int ngp_nerf_set_extra_dims(ngp_nerf* t, const float* values, uint32_t n_images) {
+	REQUIRE(t && values && t->n_extra > 0, "set_extra_dims: the model has no extra dims");
+	REQUIRE(n_images == t->n_images && t->extra_dims, "set_extra_dims: one vector per image of the dataset (set the dataset first)");
+	invalidate_k1(t);
+	const size_t cnt = (size_t)n_images * t->n_extra;
+	HIPCHK(hipMemcpy(t->extra_dims, values, cnt * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(t->extra_m, 0, cnt * 4)); HIPCHK(hipMemset(t->extra_v, 0, cnt * 4));
+	t->extra_iter = 0;
+	return 0;
+}
+extern "C" int ngp_nerf_get_extra_dims(ngp_nerf* t, float* values, uint32_t n_images) {
+	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->n_images && t->extra_dims, "get_extra_dims: no extra dims / too many images");
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(values, t->extra_dims, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+extern "C" int ngp_nerf_get_extra_dims_gradient(ngp_nerf* t, float* values, uint32_t n_images) { // the last step's (loss-scaled) per-image gradient: test hook
+	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->n_images && t->extra_grad, "get_extra_dims_gradient: no extra dims / too many images");
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(values, t->extra_grad, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+extern "C" int ngp_nerf_set_optimize_extra_dims(ngp_nerf* t, int on) { REQUIRE(t, "null trainer"); invalidate_k1(t); t->optimize_extra_dims = on != 0; return 0; }
+// view >= 0: render with that training view's dims; view < 0: with `values` (n_extra_dims floats; null = image 0's, the state after reset_extra_dims)
+extern "C" int ngp_nerf_set_rendering_extra_dims(ngp_nerf* t, int view, const float* values) {
+	REQUIRE(t && t->n_extra > 0, "set_rendering_extra_dims: the model has no extra dims");
+	t->rendering_extra_view = view;
+	t->rendering_extra.clear();
+	if (view < 0 && values) t->rendering_extra.assign(values, values + t->n_extra);
+	return 0;
+}
+
 // Testbed::render_nerf (testbed_nerf.cu:1894-2149): one spp of a frame into premultiplied linear RGBA + depth
 extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_params* rp, float* frame, float* depth) {
 	REQUIRE(t && rp && frame, "render: null argument");
@@ -1895,13 +1998,22 @@ extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_param
 	constexpr uint32_t TILE = 1u << 18;
 	if (!t->r_rays) {
 		if (dev_alloc(&t->r_rays, TILE) || dev_alloc(&t->r_masks, (size_t)TILE * RENDER_MAX_CHUNKS) || dev_alloc(&t->r_alive, TILE) || dev_alloc(&t->r_n_alive, 2) ||
-			dev_alloc(&t->r_coords, (size_t)TILE * RENDER_STEPS * 7) || dev_alloc(&t->r_out, (size_t)TILE * RENDER_STEPS * 4)) return 1;
+			dev_alloc(&t->r_coords, (size_t)TILE * RENDER_STEPS * (7 + t->n_extra)) || dev_alloc(&t->r_out, (size_t)TILE * RENDER_STEPS * 4)) return 1;
 	}
 	t->r_n_inf = t->r_n_alive + 1; // live rays x RENDER_STEPS: the inference kernel's device-side element count
 	RenderArgs a;
 	a.p = *rp; a.train_aabb = t->aabb; a.bitfield = t->bitfield; a.max_mip = t->opt.max_cascade; a.cone_angle = t->opt.cone_angle_constant;
 	a.rgb_activation = t->opt.rgb_activation; a.density_activation = t->opt.density_activation; a.linear_colors = t->opt.linear_colors;
 	a.rays = t->r_rays; a.masks = t->r_masks;
+	if (t->n_extra) { // Testbed::Nerf::get_rendering_extra_dims (testbed_nerf.cu:3685-3707): a training view's dims, or the explicit values, through the slot behind the images'
+		REQUIRE(t->extra_dims, "render: a model with extra dims needs a dataset (the extra dims are per image)");
+		REQUIRE(t->rendering_extra_view < (int)t->n_images, "render: rendering_extra_dims_from_training_view out of range");
+		float* slot = t->extra_dims + (size_t)t->extra_cap * t->n_extra;
+		if (t->rendering_extra_view >= 0) HIPCHK(hipMemcpyAsync(slot, t->extra_dims + (size_t)t->rendering_extra_view * t->n_extra, t->n_extra * 4, hipMemcpyDeviceToDevice, s));
+		else if (t->rendering_extra.size() == t->n_extra) HIPCHK(hipMemcpyAsync(slot, t->rendering_extra.data(), t->n_extra * 4, hipMemcpyHostToDevice, s));
+		else HIPCHK(hipMemcpyAsync(slot, t->extra_dims, t->n_extra * 4, hipMemcpyDeviceToDevice, s)); // reset_extra_dims: rendering_extra_dims = those of image 0 (testbed_nerf.cu:3679-3682)
+		a.extra_dims = slot; a.n_extra = t->n_extra;
+	}
 	const uint64_t n_pix = (uint64_t)rp->resolution[0] * rp->resolution[1];
 	for (uint64_t begin = 0; begin < n_pix; begin += TILE) {
 		const uint32_t n = (uint32_t)std::min<uint64_t>(TILE, n_pix - begin);
@@ -1917,7 +2029,7 @@ extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_param
 		for (uint32_t round = 0, group = 2; n_alive > 0 && round < max_rounds; group = std::min(group * 2, 16u)) {
 			for (uint32_t g = 0; g < group && round < max_rounds; ++g, ++round) {
 				launch_render_emit(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords);
-				launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7, n_alive * RENDER_STEPS, t->r_n_inf, t->r_out, 4, false, 4, t->model->gm.F);
+				launch_inference(s, t->model->gm_dev, model_ptrs(t->model, rp->use_inference_params != 0), t->r_coords, 7 + t->n_extra, n_alive * RENDER_STEPS, t->r_n_inf, t->r_out, 4, false, 4, t->model->gm.F);
 				launch_render_composite(s, a, n_alive, t->r_alive, t->r_n_alive, t->r_coords, t->r_out);
 				launch_render_compact(s, a, n, t->r_alive, t->r_n_alive);
 			}

@@ -48,6 +48,7 @@ struct TrainCounters {
 	uint32_t k2_tiles[8];                           // lazy K2: number of tiles of rounds 1..7 ([0] unused: round 0 = one tile per active ray)
 	uint32_t k2_samples, k2_samples_last;           // network evaluations performed by K2 in this / the previous step (statistics)
 	uint32_t k4_ticket;                             // K4's workgroup ticket (the last one runs the controller); zero between launches
+	uint32_t rays_per_batch_last;                   // R of the step the controller last closed (n_rays_last's companion: the extra-dims gradient maps that step's rays to images)
 };
 
 // error-proportional sampling of the training pixels (testbed.h:756 error_map; nerf_device.cuh:497-599): all null = the uniform stream
@@ -76,6 +77,7 @@ struct K1Args {
 	float* ray_targets_out; float background_color[3]; int color_space_srgb, random_bg_color, linear_colors;
 	float depth_lambda = 0.f; // > 0: the ray's target depth (testbed_nerf.cu:1027) goes into slot 6 of its target record
 	ErrorCdf cdf;             // testbed_nerf.cu:3152-3155: x_cond_y / y set = sample_focal_plane_proportional_to_error, img set = sample_image_proportional_to_error
+	const float* extra_dims = nullptr; uint32_t n_extra = 0; // testbed_nerf.cu:718-719, 744: n_extra floats per image, copied behind every NerfCoordinate of the image's rays (coords_out stride = 7 + n_extra)
 };
 
 struct K3Args {
@@ -99,14 +101,19 @@ struct K3Args {
 	ErrorCdf cdf;             // must equal K1's: the ray's pixel is re-derived from its index (testbed_nerf.cu:955-961); the loss is divided by the pixel's density (:1024)
 	float* error_map = nullptr; int32_t error_map_res[2] = {0, 0}; // testbed_nerf.cu:1042-1071: every ray's mean loss, splatted bilinearly into its image's error map (float atomics)
 	uint32_t* src_index_out = nullptr; // optional: src_index_out[compacted row] = index of the row's sample in coords_in / network_output (for T1, see EncStashIn)
+	uint32_t cstride = 7;       // floats per NerfCoordinate in coords_in / coords_out (7 + n_extra_dims: the extra dims travel with the compacted samples)
 	void* k3_scratch = nullptr; // k3_scratch_bytes(max_rays), initialised by k3_scratch_init: needed by the two-pass kernel (DBG_K3_TWO_PASS)
 };
+// compute_extra_dims_gradient_train_nerf (testbed_nerf.cu:1293-1330) and the per-image VarAdamOptimizer::step (adam_optimizer.h:37-47, testbed_nerf.cu:2860-2878)
+void launch_extra_dims_gradient(hipStream_t s, uint32_t max_rays, const uint32_t* n_rays_total_ptr, const uint32_t* rays_counter, float* extra_grad, uint32_t n_extra, uint32_t n_images,
+	const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows, const float* cdf_img);
+void launch_extra_dims_adam(hipStream_t s, uint32_t n, float* variable, const float* gradient, float* m, float* v, uint32_t iter, float lr, float loss_scale);
 size_t k3_scratch_bytes(uint32_t max_rays);
 int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays);
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank);
 // per-ray state of the sample-parallel K1 (k1_setup -> k1_count -> scan -> k1_write)
-struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[7]; uint32_t ray_index; float rdn[3]; }; // flags: from k1_setup = number of lattice points inside the box (a prefix of the lattice; 0 = the ray is not marched); tgt = {rgb target, background, target depth}; rdn = normalize(d)
+struct RaySetup { float o[3]; float d[3]; float startt; float nprime; uint32_t count; uint32_t flags; float tgt[7]; uint32_t ray_index; float rdn[3]; uint32_t img; }; // flags: from k1_setup = number of lattice points inside the box (a prefix of the lattice; 0 = the ray is not marched); tgt = {rgb target, background, target depth}; rdn = normalize(d)
 constexpr uint64_t K1_SCRAMBLE_PRIME = 2654435761ull; // prime (Knuth's multiplicative-hash constant), larger than every ray count => coprime to it, and well mixed modulo powers of two; see k1_setup
 size_t k1_lattice_scratch_bytes(uint32_t max_local_rays);
 int k1_lattice_scratch_init(hipStream_t s, void* scratch, uint32_t max_local_rays); // once per allocation (and whenever max_local_rays changes)
@@ -154,6 +161,7 @@ struct ModelPtrs {
 	const ngp_half* fw_frags;   // n_fw_frags(n_rgb_hidden) * 512 halfs
 	const ngp_half* bw_frags;   // n_bw_frags(n_rgb_hidden) * 512 halfs
 	uint32_t n_rgb_hidden = 2;  // hidden layers of the colour network: 1, 2 (base.json) or 3
+	uint32_t n_extra = 0;       // extra dims behind every NerfCoordinate (nerf_network.h:84); > 0: two more forward / four more dgrad fragments behind the regular ones
 };
 
 // lazy (front-to-back) K2 in rounds of 32-sample tiles (one tile = 32 consecutive samples of ONE ray): round r evaluates samples
@@ -242,10 +250,10 @@ constexpr uint32_t T1_DENSE_EXTERNAL = 1u << 31; // launch_train_fwd_bwd flag (n
 struct EncStashIn { const uint4* enc = nullptr; const uint32_t* src_index = nullptr; const uint32_t* n_valid_ptr = nullptr; };
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
 	const ngp_half* dL_dy, uint32_t dy_stride, ngp_half* grid_grad, ngp_half* enc_stash, uint32_t flags, void* denc_lv, uint32_t denc_cap, uint32_t n_features = 4,
-	const EncStashIn* stash_in = nullptr);
+	const EncStashIn* stash_in = nullptr, float* dextra_out = nullptr /* models with extra dims: optional dL/d(extra dims), n x n_extra floats */);
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
-void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden = 2);
+void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden = 2, uint32_t n_extra = 0);
 
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
 
@@ -293,6 +301,7 @@ struct RenderArgs {
 	int rgb_activation, density_activation, linear_colors;
 	RenderRay* rays;
 	uint64_t* masks;
+	const float* extra_dims = nullptr; uint32_t n_extra = 0; // the rendering's extra dims, written behind every NerfCoordinate (testbed_nerf.cu:211-213, 463-465)
 };
 void launch_render_setup(hipStream_t s, const RenderArgs& a, uint32_t pixel_begin, uint32_t n);
 void launch_render_compact(hipStream_t s, const RenderArgs& a, uint32_t n, uint32_t* alive_list, uint32_t* n_alive);

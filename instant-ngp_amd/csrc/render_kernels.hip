@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(128) k_render_emit(RenderArgs a, const uint32_
 	const f3 wd = warp_direction(rd);
 	uint32_t cursor = r.cursor, emitted = 0;
 	const uint32_t end = r.n_chunks * 64;
-	float* c = coords + (size_t)s * RENDER_STEPS * 7;
+	const uint32_t cs = 7u + a.n_extra;
+	float* c = coords + (size_t)s * RENDER_STEPS * cs;
 	while (emitted < RENDER_STEPS && cursor < end) {
 		const uint64_t m = a.masks[(size_t)li * RENDER_MAX_CHUNKS + (cursor >> 6)] >> (cursor & 63u);
 		if (!m) { cursor = (cursor | 63u) + 1; continue; }
@@ -104,13 +105,15 @@ __global__ void __launch_bounds__(128) k_render_emit(RenderArgs a, const uint32_
 		const float t = rlattice_t(r, cursor, a.cone_angle);
 		const float dt = calc_dt(t, a.cone_angle);
 		const f3 wp = warp_position(ro + rd * t, train_box);
-		float* cc = c + (size_t)emitted * 7;
+		float* cc = c + (size_t)emitted * cs;
 		cc[0] = wp.x; cc[1] = wp.y; cc[2] = wp.z; cc[3] = warp_dt(dt); cc[4] = wd.x; cc[5] = wd.y; cc[6] = wd.z;
+		for (uint32_t x = 7; x < cs; ++x) cc[x] = a.extra_dims[x - 7];
 		++emitted; ++cursor;
 	}
 	for (uint32_t k = emitted; k < RENDER_STEPS; ++k) { // unused slots: a harmless, in-range query
-		float* cc = c + (size_t)k * 7;
+		float* cc = c + (size_t)k * cs;
 		cc[0] = cc[1] = cc[2] = 0.5f; cc[3] = 0.f; cc[4] = cc[5] = cc[6] = 0.5f;
+		for (uint32_t x = 7; x < cs; ++x) cc[x] = a.extra_dims[x - 7];
 	}
 	a.rays[li].cursor = cursor;
 	a.rays[li].n_emitted = emitted;
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(128) k_render_composite(RenderArgs a, const ui
 	const f3 cam_fwd = cam.c[2], cam_pos = cam.c[3];
 	bool alive = true;
 	for (uint32_t k = 0; k < r.n_emitted; ++k) {
-		const float* cc = coords + ((size_t)s * RENDER_STEPS + k) * 7;
+		const float* cc = coords + ((size_t)s * RENDER_STEPS + k) * (7u + a.n_extra);
 		const __half* o = net_out + ((size_t)s * RENDER_STEPS + k) * 4;
 		const float dt = unwarp_dt(cc[3]);
 		const f3 pos = unwarp_position(mk3(cc[0], cc[1], cc[2]), train_box);

@@ -178,13 +178,13 @@ PYBIND11_MODULE(pyngp, m) {
 			py::arg("frame_idx"), py::arg("img"), py::arg("depth_img"), py::arg("depth_scale") = 1.0f) // python_api.cu:45-72, 845-852
 		.def("get_camera_extrinsics", [](NerfTraining& t, int i) {
 				const auto mm = t.owner->get_camera_extrinsics(i); py::array_t<float> out({3, 4}); std::memcpy(out.mutable_data(), mm.data(), sizeof(float) * 12); return out; }, py::arg("frame_idx")) // :839-844
-		// camera / exposure / latent optimisation and the sharpness-weighted error map are not part of this build: the switches exist, turning one on says so
+		// camera / exposure optimisation and the sharpness-weighted error map are not part of this build: the switches exist, turning one on says so
 		.def_property("optimize_extrinsics", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_extrinsics: camera optimisation is not part of this build"}; })
 		.def_property("optimize_exposure", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_exposure: exposure optimisation is not part of this build"}; })
 		.def_property("optimize_distortion", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_distortion: distortion-map optimisation is not part of this build"}; })
 		.def_property("optimize_focal_length", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_focal_length: intrinsics optimisation is not part of this build"}; })
-		.def_property("optimize_extra_dims", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_extra_dims: per-image latents are not part of this build"}; })
-		.def_property("optimize_per_image_latents", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"optimize_per_image_latents: per-image latents are not part of this build"}; })
+		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims).def_readwrite("optimize_per_image_latents", &NerfTraining::optimize_extra_dims) // python_api.cu:789-790
+		.def("get_extra_dims", [](NerfTraining& t, int i) { return t.owner->get_extra_dims(i); }, py::arg("frame_idx"))                                        // :810-813
 		.def_property("include_sharpness_in_error", [](const NerfTraining&) { return false; }, [](NerfTraining&, bool v) { if (v) throw std::runtime_error{"include_sharpness_in_error: the sharpness-weighted error map is not part of this build"}; })
 		.def_readonly("dataset", &NerfTraining::dataset);
 	py::class_<Nerf>(testbed, "Nerf")
@@ -194,6 +194,13 @@ PYBIND11_MODULE(pyngp, m) {
 			[](Nerf& n, ENerfActivation v) { n.rgb_activation = (int)v; })                                                                                     // :716
 		.def_property("density_activation", [](const Nerf& n) { return (ENerfActivation)n.density_activation; }, [](Nerf& n, ENerfActivation v) { n.density_activation = (int)v; }) // :717
 		.def_readwrite("visualize_cameras", &Nerf::visualize_cameras)
+		.def_readwrite("rendering_extra_dims_from_training_view", &Nerf::rendering_extra_dims_from_training_view)                                          // python_api.cu:725-727
+		.def("set_rendering_extra_dims_from_training_view", [](Nerf& n, int v) { n.rendering_extra_dims_from_training_view = v; })                           // :735-737
+		.def("set_rendering_extra_dims", [](Nerf& n, const std::vector<float>& v) { n.rendering_extra_dims = v; n.rendering_extra_dims_from_training_view = -1; }) // :739
+		.def("get_rendering_extra_dims", [](Nerf& n) {                                                                                                     // :741
+				if (n.rendering_extra_dims_from_training_view >= 0) return n.training.owner->get_extra_dims(n.rendering_extra_dims_from_training_view);
+				if (!n.rendering_extra_dims.empty()) return n.rendering_extra_dims;
+				return n.training.dataset.n_extra_dims() ? n.training.owner->get_extra_dims(0) : std::vector<float>{}; })
 		.def("find_closest_training_view", [](Nerf& n, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
 				if (a.size() < 12) throw std::runtime_error{"find_closest_training_view expects a 3x4 matrix"};
 				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];

@@ -358,7 +358,7 @@ void Testbed::ensure_trainer() {
 	if (m_network_config.type != mini_json::Value::Object) reload_network_from_file("");
 	if (!m_model) {
 		ngp_model_config cfg;
-		NGP_CHECK(ngp_model_config_from_json(mini_json::dump(m_network_config).c_str(), (uint32_t)nerf.training.dataset.aabb_scale, 0, &cfg));
+		NGP_CHECK(ngp_model_config_from_json(mini_json::dump(m_network_config).c_str(), (uint32_t)nerf.training.dataset.aabb_scale, nerf.training.dataset.n_extra_dims(), &cfg)); // testbed.cu:4281-4294: NerfNetwork(..., n_extra_dims, ...)
 		NGP_CHECK(ngp_model_create(&cfg, seed, &m_model));
 	}
 	if (!m_nerf) {
@@ -401,12 +401,55 @@ void Testbed::ensure_trainer() {
 		const uint32_t n_train = nerf.training.n_images_for_training > 0 ? (uint32_t)std::min<size_t>((size_t)nerf.training.n_images_for_training, d.n_images) : (uint32_t)d.n_images;
 		NGP_CHECK(ngp_nerf_set_dataset_host(m_nerf, n_train, meta.data(), xf.data(), pix.data()));
 		m_dataset_dirty = false; m_uploaded_n_images_for_training = nerf.training.n_images_for_training;
+		if (d.n_extra_dims() > 0 && m_extra_dims_for != m_nerf) { // Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683), once per trainer
+			const std::vector<float> e = initial_extra_dims();
+			std::vector<float> first(e.begin(), e.begin() + (size_t)n_train * d.n_extra_dims());
+			NGP_CHECK(ngp_nerf_set_extra_dims(m_nerf, first.data(), n_train));
+			m_extra_dims_for = m_nerf;
+		}
 	}
 }
 
 void Testbed::push_options() {
 	ngp_nerf_options o = current_options();
 	NGP_CHECK(ngp_nerf_set_options(m_nerf, &o));
+	if (nerf.training.dataset.n_extra_dims() > 0) {
+		// testbed_nerf.cu:2743: the latents train when the dataset has learnable dims and the switch is on (light directions alone are fixed inputs)
+		NGP_CHECK(ngp_nerf_set_optimize_extra_dims(m_nerf, nerf.training.dataset.n_extra_learnable_dims > 0 && nerf.training.optimize_extra_dims ? 1 : 0));
+		const bool explicit_vals = nerf.rendering_extra_dims_from_training_view < 0 && nerf.rendering_extra_dims.size() == nerf.training.dataset.n_extra_dims();
+		NGP_CHECK(ngp_nerf_set_rendering_extra_dims(m_nerf, nerf.rendering_extra_dims_from_training_view, explicit_vals ? nerf.rendering_extra_dims.data() : nullptr));
+	}
+}
+
+// Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683): per image the warped (normalised) light direction in the first three dims when the dataset has light
+// directions, uniform random values in [-1, 1) otherwise, drawn image by image from the testbed's rng -- pcg32{seed} at load time (load_nerf_post, :2378, runs before
+// reset_network re-seeds m_rng) [tcnn pcg32.h]
+std::vector<float> Testbed::initial_extra_dims() const {
+	const NerfDataset& d = nerf.training.dataset;
+	const uint32_t n = d.n_extra_dims();
+	std::vector<float> out((size_t)d.n_images * n);
+	uint64_t state = 0, inc = 3; // pcg32(initstate = seed, initseq = 1)
+	auto next_uint = [&]() { const uint64_t old = state; state = old * 0x5851f42d4c957f2dULL + inc; const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u); return (xs >> rot) | (xs << ((~rot + 1u) & 31)); };
+	next_uint(); state += seed; next_uint();
+	auto next_float = [&]() { union { uint32_t u; float f; } x; x.u = (next_uint() >> 9) | 0x3f800000u; return x.f - 1.0f; };
+	for (size_t i = 0; i < d.n_images; ++i) {
+		const auto& l = d.metadata[i].light_dir;
+		const float len = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+		for (uint32_t j = 0; j < n; ++j) {
+			if (d.has_light_dirs && j < 3) out[i * n + j] = (l[j] / len + 1.0f) * 0.5f; // warp_direction(normalize(light_dir))
+			else out[i * n + j] = next_float() * 2.0f - 1.0f;
+		}
+	}
+	return out;
+}
+std::vector<float> Testbed::get_extra_dims(int trainview) { // Training::get_extra_dims_cpu, testbed_nerf.cu:1862-1877
+	const uint32_t n = nerf.training.dataset.n_extra_dims();
+	if (n == 0) return {};
+	if (trainview < 0 || (size_t)trainview >= nerf.training.dataset.n_images) throw std::runtime_error{"Invalid training view."};
+	ensure_trainer();
+	std::vector<float> all((size_t)(trainview + 1) * n);
+	NGP_CHECK(ngp_nerf_get_extra_dims(m_nerf, all.data(), (uint32_t)trainview + 1));
+	return std::vector<float>(all.end() - n, all.end());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,6 +553,7 @@ void Testbed::load_training_data(const std::string& path_in) {
 		if (!mini_json::parse(read_text(jp).c_str(), j, err)) throw std::runtime_error{jp.string() + ": " + err};
 		if (j.has("aabb_scale")) d.aabb_scale = (int)j.num("aabb_scale", 1);
 		if (j.has("sharpen")) d.sharpen_amount = (float)j.num("sharpen", 0);
+		if (j.has("n_extra_learnable_dims")) d.n_extra_learnable_dims = (uint32_t)j.num("n_extra_learnable_dims", 0); // nerf_loader.cu:482-483
 		if (j.has("render_aabb") && j["render_aabb"].size() == 2) // nerf_loader.cu:457-460: [[min], [max]] in the scene's coordinates, as is
 			for (int k = 0; k < 3; ++k) { d.render_aabb.min[k] = (float)j["render_aabb"].at(0).at(k).n; d.render_aabb.max[k] = (float)j["render_aabb"].at(1).at(k).n; }
 		if (j.has("up") && j["up"].size() == 3) d.up = {(float)j["up"].at(1).n, (float)j["up"].at(2).n, (float)j["up"].at(0).n}; // nerf_loader.cu:528-533: axes permuted like the transforms
@@ -594,6 +638,16 @@ void Testbed::load_training_data(const std::string& path_in) {
 				for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) out[c * 3 + r] = c3[r][c];
 			};
 			to_ngp(tm_start, F.xform); to_ngp(tm_end, F.xform_end);
+			if (f.has("driver_parameters")) { // nerf_loader.cu:671-680: a light direction per frame replaces learnable dims
+				const auto& dp = f["driver_parameters"];
+				float l[3] = {(float)dp.num("LightX", 0), (float)dp.num("LightY", 0), (float)dp.num("LightZ", 0)};
+				const float len = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+				for (float& v : l) v /= len;
+				// nerf_direction_to_ngp (nerf_loader.h:141-152): y and z flipped, then -- unless from_mitsuba -- the axes cycled xyz <- yzx
+				l[1] *= -1.f; l[2] *= -1.f;
+				if (d.from_mitsuba) { l[0] *= -1.f; l[2] *= -1.f; F.meta.light_dir = {l[0], l[1], l[2]}; } else F.meta.light_dir = {l[1], l[2], l[0]};
+				d.has_light_dirs = true; d.n_extra_learnable_dims = 0;
+			}
 			{ // "rolling_shutter": [a, b, c, d?] (nerf_loader.cu:204-215), global with per-frame override (read_lens :699)
 				const mini_json::Value* rs = f.has("rolling_shutter") ? &f["rolling_shutter"] : (j.has("rolling_shutter") ? &j["rolling_shutter"] : nullptr);
 				if (rs && rs->size() >= 3) F.meta.rolling_shutter = {(float)rs->at(0).n, (float)rs->at(1).n, (float)rs->at(2).n, rs->size() >= 4 ? (float)rs->at(3).n : 0.f};
@@ -702,12 +756,12 @@ void Testbed::load_training_data(const std::string& path_in) {
 	if ((d.aabb_scale & (d.aabb_scale - 1)) != 0) throw std::runtime_error{"NeRF dataset's `aabb_scale` must be a power of two."};
 	if (d.aabb_scale > 128) throw std::runtime_error{"NeRF dataset must have `aabb_scale <= 128`."};
 
-	const int prev_scale = nerf.training.dataset.aabb_scale;
+	const int prev_scale = nerf.training.dataset.aabb_scale; const uint32_t prev_extra = nerf.training.dataset.n_extra_dims();
 	const bool had = nerf.training.dataset.n_images > 0;
 	nerf.training.dataset = std::move(d);
 	mode = ETestbedMode::Nerf;
 	load_nerf_post();
-	if (had && prev_scale != nerf.training.dataset.aabb_scale) destroy_trainer(); // network size depends on aabb_scale (testbed_nerf.cu:2466-2470)
+	if (had && (prev_scale != nerf.training.dataset.aabb_scale || prev_extra != nerf.training.dataset.n_extra_dims())) destroy_trainer(); // network size depends on aabb_scale (testbed_nerf.cu:2466-2470) and on the extra dims (testbed.cu:4281-4294)
 	m_dataset_dirty = true;
 	m_render_lens_mode = nerf.training.dataset.metadata[0].lens_mode;
 	m_render_lens_params = nerf.training.dataset.metadata[0].lens_params;
@@ -724,6 +778,7 @@ void Testbed::load_nerf_post() {
 	nerf.max_cascade = 0;
 	while ((1 << nerf.max_cascade) < d.aabb_scale) ++nerf.max_cascade;
 	nerf.cone_angle_constant = d.aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+	nerf.training.optimize_extra_dims = d.n_extra_learnable_dims > 0;       // :2379
 	up_dir = d.up;                                                          // :2443
 }
 
@@ -1251,7 +1306,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 		jd.set("render_aabb_to_local", jmat_cols(d.render_aabb_to_local.data(), 3, 3));
 		jd.set("up", jvec(d.up.data(), 3)); jd.set("offset", jvec(d.offset.data(), 3));
 		const int env[2] = {0, 0}; jd.set("envmap_resolution", jvec(env, 2)); jd.set("scale", jnum(d.scale)); jd.set("aabb_scale", jnum(d.aabb_scale));
-		jd.set("from_mitsuba", jbool(d.from_mitsuba)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(0));
+		jd.set("from_mitsuba", jbool(d.from_mitsuba)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(d.n_extra_learnable_dims));
 		jn.set("dataset", jd);
 	}
 	snap.set("nerf", jn);

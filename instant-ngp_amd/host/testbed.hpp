@@ -63,6 +63,7 @@ struct ImageMetadata {                      // TrainingImageMetadata as seen fro
 	int lens_mode = NGP_LENS_PERSPECTIVE;
 	std::array<float, 7> lens_params{};
 	std::array<float, 4> rolling_shutter{};          // {a, b, c, d}: pixel time t = a + b u + c v + d motionblur_time (nerf_loader.cu:204-215)
+	std::array<float, 3> light_dir{0.f, 0.f, 0.f};    // json "driver_parameters" LightX / LightY / LightZ, normalised, in ngp's axes (nerf_loader.cu:671-680)
 };
 
 struct NerfDataset {                        // nerf_loader.h NerfDataset (subset)
@@ -85,6 +86,9 @@ struct NerfDataset {                        // nerf_loader.h NerfDataset (subset
 	std::array<float, 9> render_aabb_to_local{1, 0, 0, 0, 1, 0, 0, 0, 1}; // nerf_loader.h: identity unless a snapshot carries a crop box orientation (column-major mat3)
 	std::array<float, 3> up{0.f, 1.f, 0.f};          // json "up", axes permuted like the transforms (nerf_loader.cu:528-533)
 	std::array<int, 2> envmap_resolution{0, 0};      // no environment maps in this build
+	uint32_t n_extra_learnable_dims = 0;             // json "n_extra_learnable_dims" (nerf_loader.cu:482-483): per-image latent codes
+	bool has_light_dirs = false;                     // a frame carried "driver_parameters" (nerf_loader.cu:671-680): three fixed extra dims = the warped light direction
+	uint32_t n_extra_dims() const { return (has_light_dirs ? 3u : 0u) + n_extra_learnable_dims; } // nerf_loader.h:85-87
 	std::array<float, 12> nerf_matrix_to_ngp(const std::array<float, 12>& row_major_3x4) const; // nerf_loader.h:101-120
 	std::array<float, 12> ngp_matrix_to_nerf(const std::array<float, 12>& col_major_4x3) const; // nerf_loader.h:122-139 (row-major 3x4 out)
 };
@@ -105,6 +109,7 @@ struct NerfTraining {
 	int n_images_for_training = 0;                         // testbed.h:771: rays are drawn from the first n images (set to n_images by load_nerf_post, testbed_nerf.cu:2371)
 	int loss_type = -1;                                    // ELossType; -1 = as the network config's "loss.otype" says (testbed.cu:4209 writes it into this member)
 	int view = 0;                                          // testbed.h:770: the training view the camera was last set to
+	bool optimize_extra_dims = false;                      // testbed.h: set when the dataset has learnable dims (testbed_nerf.cu:2379); python_api.cu:789-790
 	Testbed* owner = nullptr;                        // the reference's Training methods (set_camera_extrinsics ...) live on this object: route them to the Testbed
 	NerfDataset dataset;
 };
@@ -116,6 +121,8 @@ struct Nerf {
 	int rgb_activation = -1, density_activation = NGP_ACT_EXPONENTIAL; // ENerfActivation; rgb -1 = Exponential for HDR data, Logistic otherwise (testbed_nerf.cu:2354)
 	bool visualize_cameras = false;                  // GUI overlay switch: kept so that scripts that clear it run
 	int max_cascade = 0;
+	int rendering_extra_dims_from_training_view = -1;   // testbed.h; python_api.cu:725-727
+	std::vector<float> rendering_extra_dims;         // set_rendering_extra_dims (python_api.cu:739); empty = image 0's, the state after reset_extra_dims
 	NerfTraining training;
 };
 
@@ -177,6 +184,7 @@ public:
 	std::array<float, 12> camera_matrix_row_major() const;          // m_camera as the 3 x 4 numpy array pyngp exposes
 	void set_camera_matrix_row_major(const std::array<float, 12>& m);
 	int find_closest_training_view(const std::array<float, 12>& pose_row_major_3x4) const; // testbed_nerf.cu:3710-3723
+	std::vector<float> get_extra_dims(int trainview); // Training::get_extra_dims_cpu, testbed_nerf.cu:1862-1877
 	// training cameras (testbed_nerf.cu:2151-2292)
 	void set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2, float k3, float k4, bool is_fisheye);
 	void set_camera_extrinsics(int frame_idx, const std::array<float, 12>& camera_to_world_row_major, bool convert_to_ngp);
@@ -238,6 +246,8 @@ private:
 	void load_nerf_post();
 	void destroy_trainer();
 	void push_options();
+	std::vector<float> initial_extra_dims() const;   // reset_extra_dims' values for every image of the dataset (testbed_nerf.cu:3656-3683)
+	const void* m_extra_dims_for = nullptr;         // the trainer the initial extra dims were installed in
 	ngp_nerf_options current_options() const;
 	ngp_aabb scene_aabb() const;
 

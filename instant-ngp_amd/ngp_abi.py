@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libngp_hip.so")
+LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(HERE, "libngp_hip.so")  # NGP_HIP_LIB: another build of the same library (A / B measurements of two builds on one box)
 
 u32, i32, f32, u64, u8, u16 = C.c_uint32, C.c_int32, C.c_float, C.c_uint64, C.c_uint8, C.c_uint16
 vp = C.c_void_p

@@ -107,6 +107,9 @@ API void ora_model_density(void* m, const float* pos, uint32_t stride, uint32_t 
 API void ora_model_training_step_exact_sums(void* m, const float* in, uint32_t in_stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, int mode) {
 	((Model*)m)->training_step(in, in_stride, n, dL_dy, dy_stride, mode);
 }
+API void ora_model_training_step_extra(void* m, const float* in, uint32_t in_stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, float* dL_dextra) {
+	((Model*)m)->training_step(in, in_stride, n, dL_dy, dy_stride, 0, dL_dextra);
+}
 API void ora_model_training_step(void* m, const float* in, uint32_t in_stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride) {
 	((Model*)m)->training_step(in, in_stride, n, dL_dy, dy_stride);
 }
@@ -162,6 +165,10 @@ API void ora_k_compute_loss(uint32_t n_rays, uint32_t rays_counter, ngp_aabb aab
 	*numsteps_counter_compacted = compute_loss(n_rays, rays_counter, Aabb(aabb), Pcg32(rng), max_samples_compacted, o, n_images, meta, network_output, out_stride,
 		ray_indices_in, rays_in, numsteps_inout, coords_in, coords_out, dloss, dl_stride, loss_output, mean_density, &g_hook_cdf, g_hook_error_map, g_hook_error_map_res);
 }
+API void ora_extra_dims_gradient(uint32_t n_rays_total, uint32_t rays_counter, float* grad_out, uint32_t n_extra, uint32_t n_images, const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra) {
+	extra_dims_gradient(n_rays_total, n_rays_total, rays_counter, grad_out, n_extra, n_images, ray_indices, numsteps, dextra);
+}
+API void ora_var_adam_step(uint32_t n, float* variable, const float* gradient_scaled, float* m, float* v, uint32_t iter, float lr, float loss_scale) { var_adam_step(n, variable, gradient_scaled, m, v, iter, lr, loss_scale); }
 API void ora_k_fill_rollover(uint32_t n_elements, uint32_t n_input, float* coords, uint32_t coord_stride, uint16_t* dloss, uint32_t dl_stride) {
 	fill_rollover_and_rescale_h(n_elements, dl_stride, n_input, dloss);
 	fill_rollover_f(n_elements, coord_stride, n_input, coords);

@@ -186,6 +186,7 @@ struct Model {
 	GridLayout grid;
 	MlpShape density_net, rgb_net;
 	uint32_t n_enc = 32;       // L*F
+	uint32_t n_extra = 0, rgb_in = 32; // extra (latent / light-direction) dims of the dir encoding; width of the colour network's input
 	size_t n_mlp = 0, n_params = 0, off_density = 0, off_rgb = 0, off_grid = 0;
 
 	std::vector<float> params_fp;             // Trainer::params_full_precision
@@ -202,7 +203,13 @@ struct Model {
 		n_enc = c.n_levels * c.n_features_per_level;
 		if (n_enc % 16) throw std::runtime_error("oracle: L*F must be a multiple of 16");
 		density_net = {n_enc, c.n_neurons, c.n_hidden_layers, 16};
-		rgb_net = {16 + 16, c.n_neurons, c.n_hidden_layers_rgb, 16};
+		// nerf_network.h:81-95: the dir encoding (Composite: SphericalHarmonics over 3 dims, Identity over the n_extra_dims others) is padded to the colour network's
+		// alignment (16): 16 + n_extra -> 32 columns when n_extra > 0; the colour network's input = density output (16) + that.
+		// [tcnn, restated: encodings fill their padding columns with ONES (encodings/identity.h, composite.h), so the padded columns act as a learned bias]
+		n_extra = c.n_extra_dims;
+		if (n_extra > 16) throw std::runtime_error("oracle: at most 16 extra dims");
+		rgb_in = 16 + 16 + (n_extra ? 16u : 0u);
+		rgb_net = {rgb_in, c.n_neurons, c.n_hidden_layers_rgb, 16};
 		off_density = 0; off_rgb = density_net.n_params();
 		n_mlp = off_rgb + rgb_net.n_params();
 		off_grid = n_mlp;
@@ -238,11 +245,12 @@ struct Model {
 	void eval(const float* coord, bool inference, uint16_t out4[4], uint16_t* enc_out = nullptr, uint16_t* dact = nullptr,
 			uint16_t* rgb_in_out = nullptr, uint16_t* ract = nullptr, uint16_t* rgb_out16 = nullptr) const {
 		const uint16_t* p = P(inference);
-		std::vector<uint16_t> enc(n_enc), da(density_net.n_hidden * density_net.width), rin(32), ra(rgb_net.n_hidden * rgb_net.width);
+		std::vector<uint16_t> enc(n_enc), da(density_net.n_hidden * density_net.width), rin(rgb_in), ra(rgb_net.n_hidden * rgb_net.width);
 		uint16_t ro[16];
 		grid_encode(grid, p + off_grid, coord, enc.data());
 		mlp_forward(density_net, p + off_density, enc.data(), da.data(), rin.data()); // density out -> rows 0..15 of rgb input
 		sh4(coord + 4, rin.data() + 16);                                             // dir enc -> rows 16..31 (nerf_network.h:122)
+		for (uint32_t k = 0; k + 32 < rgb_in; ++k) rin[32 + k] = f2h(k < n_extra ? coord[7 + k] : 1.0f); // Identity over the extra dims (scale 1, offset 0), padding = 1
 		mlp_forward(rgb_net, p + off_rgb, rin.data(), ra.data(), ro);
 		out4[0] = ro[0]; out4[1] = ro[1]; out4[2] = ro[2]; out4[3] = rin[0];
 		if (enc_out) std::copy(enc.begin(), enc.end(), enc_out);
@@ -291,14 +299,16 @@ struct Model {
 	// grid_sum_mode (test aids, NOT the reference's arithmetic): 0 = the reference (chain of half adds); 1 = exact_grid_sums as described above; 2 = the UNROUNDED products
 	// dL/d(enc) * weight summed in double and rounded to half once -- the gradient the half dL/d(enc) implies, with no per-contribution rounding at all (the device merges runs of
 	// samples in one cell in fp32 before it rounds, DESIGN 3.1, so on the coarse levels it is closer to this than to mode 1).
-	void training_step(const float* coords, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, int grid_sum_mode = 0) {
+	// dL_dextra (optional, n x n_extra floats): dL/d(input) of the extra dims = the Identity encoding's backward of the colour network's (half) input gradient
+	// (nerf_network.h:238-252 with dL_dinput; consumed by compute_extra_dims_gradient_train_nerf, testbed_nerf.cu:1293-1330)
+	void training_step(const float* coords, uint32_t stride, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, int grid_sum_mode = 0, float* dL_dextra = nullptr) {
 		const bool exact_grid_sums = grid_sum_mode != 0;
 		std::vector<float> dW(n_mlp, 0.f);
 		std::vector<uint16_t> dL_denc((size_t)n * n_enc);
 		#pragma omp parallel
 		{
 			std::vector<float> dWt(n_mlp, 0.f);
-			std::vector<uint16_t> enc(n_enc), da(density_net.n_hidden * density_net.width), rin(32), ra(rgb_net.n_hidden * rgb_net.width);
+			std::vector<uint16_t> enc(n_enc), da(density_net.n_hidden * density_net.width), rin(rgb_in), ra(rgb_net.n_hidden * rgb_net.width);
 			#pragma omp for schedule(static)
 			for (int64_t i = 0; i < (int64_t)n; ++i) {
 				uint16_t o4[4];
@@ -306,8 +316,9 @@ struct Model {
 				eval(c, false, o4, enc.data(), da.data(), rin.data(), ra.data());
 				uint16_t drgb[16] = {0};
 				for (int k = 0; k < 3; ++k) drgb[k] = dL_dy[(size_t)i * dy_stride + k];
-				uint16_t drin[32];
+				uint16_t drin[48];
 				mlp_backward(rgb_net, params.data() + off_rgb, rin.data(), ra.data(), drgb, dWt.data() + off_rgb, drin);
+				if (dL_dextra) for (uint32_t k = 0; k < n_extra; ++k) dL_dextra[(size_t)i * n_extra + k] = h2f(drin[32 + k]);
 				// add_density_gradient: half add
 				drin[0] = f2h(h2f(drin[0]) + h2f(dL_dy[(size_t)i * dy_stride + 3]));
 				mlp_backward(density_net, params.data() + off_density, enc.data(), da.data(), drin, dWt.data() + off_density,

@@ -212,6 +212,34 @@ inline vec2 sample_cdf_2d(vec2 sample, uint32_t img, const int32_t res[2], const
 	if (pdf) *pdf = pmf_x * pmf_y * (float)(res[0] * res[1]);
 	return {((float)x + sample.x) / (float)res[0], ((float)y + sample.y) / (float)res[1]};
 }
+// compute_extra_dims_gradient_train_nerf (testbed_nerf.cu:1293-1330): every compacted ray adds its samples' dL/d(extra dims) -- the extra-dims columns of the network's
+// input gradient, coords_gradient(j)->get_extra_dims() -- to its image's gradient, in ray and sample order (the reference: float atomicAdd per sample and dim).
+inline void extra_dims_gradient(uint32_t n_rays, uint32_t n_rays_total, uint32_t rays_counter, float* extra_dims_gradient_out, uint32_t n_extra_dims, uint32_t n_training_images,
+		const uint32_t* ray_indices_in, const uint32_t* numsteps_in, const float* coords_gradient_extra /* row-major [row][n_extra_dims] */) {
+	(void)n_rays;
+	for (uint32_t i = 0; i < rays_counter; ++i) {
+		const uint32_t numsteps = numsteps_in[i * 2 + 0];
+		if (numsteps == 0) continue;
+		const uint32_t base = numsteps_in[i * 2 + 1];
+		const uint32_t img = image_idx(ray_indices_in[i], n_rays_total, n_training_images);
+		float* g = extra_dims_gradient_out + (size_t)n_extra_dims * img;
+		for (uint32_t j = 0; j < numsteps; ++j)
+			for (uint32_t k = 0; k < n_extra_dims; ++k) g[k] += coords_gradient_extra[(size_t)(base + j) * n_extra_dims + k];
+	}
+}
+// VarAdamOptimizer::step (adam_optimizer.h:37-47) as driven by testbed_nerf.cu:2860-2878: gradient / LOSS_SCALE, the network optimizer's learning rate, hyperparameters of
+// VarAdamOptimizer(n_extra_dims, 1e-4f) (epsilon 1e-8, beta1 0.9, beta2 0.99); iter = the optimizer's iteration count AFTER this step (>= 1)
+inline void var_adam_step(uint32_t n, float* variable, const float* gradient_scaled, float* first_moment, float* second_moment, uint32_t iter, float learning_rate, float loss_scale) {
+	const float epsilon = 1e-8f, beta1 = 0.9f, beta2 = 0.99f;
+	const float actual_learning_rate = learning_rate * std::sqrt(1.0f - std::pow(beta2, (float)iter)) / (1.0f - std::pow(beta1, (float)iter));
+	for (uint32_t i = 0; i < n; ++i) {
+		const float g = gradient_scaled[i] / loss_scale;
+		first_moment[i] = beta1 * first_moment[i] + (1.0f - beta1) * g;
+		second_moment[i] = beta2 * second_moment[i] + (1.0f - beta2) * g * g;
+		variable[i] -= actual_learning_rate * first_moment[i] / (std::sqrt(second_moment[i]) + epsilon);
+	}
+}
+
 // image_idx with a CDF over the images, nerf_device.cuh:578-591
 inline uint32_t image_idx_cdf(uint32_t base_idx, uint32_t n_training_images, const float* cdf, float* pdf) {
 	float sample = ld_random_val(base_idx, 0xdeadbeef);
