@@ -868,9 +868,10 @@ struct ngp_sdf {
 	ngp_sdf_options opt{};
 	ngp_aabb aabb{};
 	uint32_t n_triangles = 0;
-	SdfTriangle* tris = nullptr; SdfBvhNode* nodes = nullptr; float* cdf = nullptr;
+	SdfTriangle* tris = nullptr; SdfBvhNode2* nodes = nullptr; int root = 0; float* cdf = nullptr;
 	float* positions = nullptr; float* distances = nullptr; ngp_half* pred = nullptr; uint32_t cap = 0;
 	float* loss_sum = nullptr; uint32_t* iou_counters = nullptr;
+	uint32_t* stab_list = nullptr; uint32_t* stab_count = nullptr; // survivors of the first stab rays (sdf_kernels.hip): cap list entries + cap "escaped" marks
 	Rng rng; uint32_t training_step = 0;
 };
 // load_mesh's normalisation (testbed_sdf.cu:1380-1410): raw box inflated by 0.5 % of its diagonal, scaled by its largest extent and centred in the unit cube
@@ -891,7 +892,7 @@ extern "C" int ngp_sdf_normalize_mesh_host(float* v, uint64_t n_vertices, ngp_aa
 	if (mesh_scale_out) *mesh_scale_out = scale;
 	return 0;
 }
-// returns the depth of the tree (root = 0): the device traversals keep at most depth + 1 nodes on their 64-entry stacks
+// returns the depth of the tree (root = 0): the device traversals keep at most depth + 1 nodes on their 30-entry stacks (child references are pushed, the root first)
 static uint32_t sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode>& nodes, uint32_t leaf_size) {
 	struct Job { int node; size_t begin, end; uint32_t depth; };
 	uint32_t max_depth = 0;
@@ -922,6 +923,21 @@ static uint32_t sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvh
 	}
 	return max_depth;
 }
+// Device form of the tree (sdf_kernels.hip): every inner node carries the boxes of both children; a child reference is the child's index (inner node) or
+// ~((first triangle << 3) | count) (leaf).  Indexed like `nodes` (the leaves' slots stay unused).  Returns the root's reference.
+static int sdf_flatten_bvh(const std::vector<SdfBvhNode>& nodes, std::vector<SdfBvhNode2>& out) {
+	auto ref_of = [&](int i) { const SdfBvhNode& n = nodes[i]; return n.left < 0 ? ~(int)((((uint32_t)(-n.left - 1)) << 3) | (uint32_t)((-n.right - 1) - (-n.left - 1))) : i; };
+	out.assign(nodes.size(), SdfBvhNode2{});
+	for (size_t i = 0; i < nodes.size(); ++i) {
+		const SdfBvhNode& n = nodes[i];
+		if (n.left < 0) continue;
+		SdfBvhNode2& o = out[i];
+		for (int k = 0; k < 3; ++k) { o.lmin[k] = nodes[n.left].bmin[k]; o.lmax[k] = nodes[n.left].bmax[k]; o.rmin[k] = nodes[n.right].bmin[k]; o.rmax[k] = nodes[n.right].bmax[k]; }
+		o.left = ref_of(n.left); o.right = ref_of(n.right);
+	}
+	return ref_of(0);
+}
+constexpr uint32_t SDF_LEAF_SIZE = 4, SDF_MAX_DEPTH = 29; // (sdf_kernels.hip: leaves of <= 4 triangles are fetched in one batch; 30 stack entries)
 // DiscreteDistribution::build over the surface areas (discrete_distribution.h:21-38) -- of the REORDERED triangles, like the reference
 static void sdf_surface_cdf(const std::vector<SdfTriangle>& tris, std::vector<float>& cdf) {
 	const uint32_t n_triangles = (uint32_t)tris.size();
@@ -948,11 +964,13 @@ extern "C" int ngp_host_sdf_signed_distance(const float* triangles_host, uint32_
 	std::vector<SdfTriangle> tris(n_triangles);
 	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
 	std::vector<SdfBvhNode> nodes;
-	const uint32_t depth = sdf_build_bvh(tris, nodes, 8);
-	REQUIRE(depth + 2 <= 64, "ngp_host_sdf_signed_distance: BVH deeper than the traversal stack");
+	const uint32_t depth = sdf_build_bvh(tris, nodes, SDF_LEAF_SIZE);
+	REQUIRE(depth <= SDF_MAX_DEPTH && n_triangles < (1u << 28), "ngp_host_sdf_signed_distance: BVH deeper than the traversal stack");
+	std::vector<SdfBvhNode2> nodes2;
+	const int root = sdf_flatten_bvh(nodes, nodes2);
 	if (triangles_ordered_out) memcpy(triangles_ordered_out, tris.data(), (size_t)n_triangles * sizeof(SdfTriangle));
 	if (cdf_out) { std::vector<float> cdf; sdf_surface_cdf(tris, cdf); memcpy(cdf_out, cdf.data(), cdf.size() * 4); }
-	host_sdf_signed_distance(n, positions_host, distances_inout, nodes.data(), tris.data(), use_upper_bounds);
+	host_sdf_signed_distance(n, positions_host, distances_inout, nodes2.data(), root, tris.data(), use_upper_bounds);
 	return 0;
 }
 extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, uint32_t n_triangles, ngp_aabb aabb, const ngp_sdf_options* o, ngp_sdf** out) {
@@ -965,24 +983,29 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	std::vector<SdfTriangle> tris(n_triangles);
 	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
 	std::vector<SdfBvhNode> nodes;
-	const uint32_t bvh_depth = sdf_build_bvh(tris, nodes, 8); // m_sdf.triangle_bvh->build(triangles_cpu, 8); reorders the triangles
-	if (bvh_depth + 2 > 64) { delete t; return fail("ngp_sdf_create: BVH deeper than the device traversal stack (64 entries)"); } // median split: depth = ceil(log2(n / 8)) <= 29
+	// m_sdf.triangle_bvh->build(triangles_cpu, 8) reorders the triangles; so does this tree (a binary median split down to 4 triangles: the ground truth does not depend on the
+	// tree, the surface samples' triangle order follows it like the reference's follows its own)
+	const uint32_t bvh_depth = sdf_build_bvh(tris, nodes, SDF_LEAF_SIZE);
+	if (bvh_depth > SDF_MAX_DEPTH || n_triangles >= (1u << 28)) { delete t; return fail("ngp_sdf_create: BVH deeper than the device traversal stack (30 entries)"); } // median split: depth = ceil(log2(n / 4))
+	std::vector<SdfBvhNode2> nodes2;
+	t->root = sdf_flatten_bvh(nodes, nodes2);
 	std::vector<float> cdf;
 	sdf_surface_cdf(tris, cdf);
 	t->cap = std::max<uint32_t>(o->batch_size, 1u << 21); // calculate_iou works in batches of 128^3 = 2^21
-	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
-		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8)) { delete t; return 1; }
+	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes2.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
+		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8) || dev_alloc(&t->stab_list, (size_t)t->cap * 2) || dev_alloc(&t->stab_count, 1)) { delete t; return 1; }
 	HIPCHK(hipMemcpy(t->tris, tris.data(), tris.size() * sizeof(SdfTriangle), hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(t->nodes, nodes.data(), nodes.size() * sizeof(SdfBvhNode), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->nodes, nodes2.data(), nodes2.size() * sizeof(SdfBvhNode2), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(t->loss_sum, 0, 4));
+	HIPCHK(hipMemset(t->stab_list + t->cap, 0, (size_t)t->cap * 4)); // the first stab rays' "escaped" marks
 	*out = t;
 	return 0;
 }
 extern "C" void ngp_sdf_destroy(ngp_sdf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
-	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count}) if (p) (void)hipFree(p);
 	delete t;
 }
 // generate_training_samples_sdf: fills positions / distances for `n` samples and advances m_rng like the reference
@@ -997,7 +1020,7 @@ static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only
 	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = t->positions; a.distances = t->distances;
 	launch_sdf_generate_positions(s, a);
 	t->rng.advance((uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull); // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
-	launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->tris, 1);
+	launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->root, t->tris, 1, t->stab_list, t->stab_list + t->cap, t->stab_count);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1033,7 +1056,9 @@ extern "C" int ngp_sdf_iou(ngp_sdf* t, uint32_t n_samples, double* iou_host) {
 }
 extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distances) { if (positions) *positions = t->positions; if (distances) *distances = t->distances; return 0; }
 extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* positions, uint32_t n, float* out) {
-	launch_sdf_signed_distance((hipStream_t)stream, n, positions, out, t->nodes, t->tris, 0);
+	REQUIRE(t && (n == 0 || (positions && out)), "ngp_sdf_signed_distance: null argument");
+	for (uint32_t done = 0; done < n; done += t->cap) // the survivor list of the stab rays holds t->cap points
+		launch_sdf_signed_distance((hipStream_t)stream, std::min(n - done, t->cap), positions + (size_t)done * 3, out + done, t->nodes, t->root, t->tris, 0, t->stab_list, t->stab_list + t->cap, t->stab_count);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

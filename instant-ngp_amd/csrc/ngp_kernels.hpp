@@ -278,8 +278,11 @@ struct SdfSampleArgs {
 	float* positions; float* distances;
 };
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a);
-void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds);
-void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
+// device form of the tree: a node carries both children's boxes; a child reference is an inner node's index (>= 0) or a leaf ~((first triangle << 3) | count), count <= 4
+struct SdfBvhNode2 { float lmin[3], lmax[3], rmin[3], rmax[3]; int left, right; int pad[2]; }; // 64 bytes
+void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds,
+		uint32_t* survivors /* n entries */, uint32_t* escaped /* n entries, zero on entry and on exit */, uint32_t* n_survivors /* one word */);
+void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters);
 
 // ---- renderer (render_kernels.hip) ------------------------------------------------------------

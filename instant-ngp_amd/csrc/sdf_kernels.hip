@@ -45,62 +45,110 @@ static __host__ __device__ __forceinline__ float tri_ray_intersect(const SdfTria
 	return t;
 }
 // BoundingBox::distance_sq, bounding_box.cuh:228-230
-static __host__ __device__ __forceinline__ float bb_distance_sq(const SdfBvhNode& n, f3 p) {
-	const float dx = fmaxf(fmaxf(n.bmin[0] - p.x, p.x - n.bmax[0]), 0.f), dy = fmaxf(fmaxf(n.bmin[1] - p.y, p.y - n.bmax[1]), 0.f), dz = fmaxf(fmaxf(n.bmin[2] - p.z, p.z - n.bmax[2]), 0.f);
+static __host__ __device__ __forceinline__ float bb_distance_sq(const float* __restrict__ bmin, const float* __restrict__ bmax, f3 p) {
+	const float dx = fmaxf(fmaxf(bmin[0] - p.x, p.x - bmax[0]), 0.f), dy = fmaxf(fmaxf(bmin[1] - p.y, p.y - bmax[1]), 0.f), dz = fmaxf(fmaxf(bmin[2] - p.z, p.z - bmax[2]), 0.f);
 	return dx * dx + dy * dy + dz * dz;
 }
-// BoundingBox::ray_intersect(...).x, bounding_box.cuh:163-210: entry parameter of the slab test (FLT_MAX on a miss; may be negative inside the box)
-static __host__ __device__ __forceinline__ float bb_ray_entry(const SdfBvhNode& n, f3 o, f3 d) {
-	float tmin = (n.bmin[0] - o.x) / d.x, tmax = (n.bmax[0] - o.x) / d.x;
-	if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
-	float tymin = (n.bmin[1] - o.y) / d.y, tymax = (n.bmax[1] - o.y) / d.y;
-	if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
-	if (tmin > tymax || tymin > tmax) return 3.402823466e+38f;
-	if (tymin > tmin) tmin = tymin;
-	if (tymax < tmax) tmax = tymax;
-	float tzmin = (n.bmin[2] - o.z) / d.z, tzmax = (n.bmax[2] - o.z) / d.z;
-	if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
-	if (tmin > tzmax || tzmin > tmax) return 3.402823466e+38f;
-	if (tzmin > tmin) tmin = tzmin;
-	return tmin;
-}
+// ---- traversal (round 4) ----------------------------------------------------------------------------------------------------
+// Both walks are chains of dependent memory round trips (the query points are i.i.d., so a wavefront's lanes diverge from the root on), and the chip has fewer points in
+// flight than lanes: what counts is round trips per step.  Hence
+//   * a node carries the boxes of BOTH children (SdfBvhNode2, 64 bytes, four 16-byte loads issued together): one round trip per inner step instead of two (node, then
+//     its children);
+//   * a child reference is either an inner node's index (>= 0) or a leaf ~((first triangle << 3) | count) with count <= SDF_LEAF_TRIS = 4: the leaf's triangles are
+//     loaded in one batch (clamped indices, surplus results ignored) -- one round trip per leaf instead of one per triangle behind an early-out branch;
+//   * the node stack -- <= SDF_STACK references (median split: depth = ceil(log2(n / 4)), a depth-first walk of a binary tree keeps at most depth + 1 references) --
+//     lives in LDS on the device, one column per thread (entry i of thread t at [i * 256 + t]: conflict-free), instead of 512 bytes of scratch per thread; on the host
+//     (test hook) it is a local array.
+constexpr int SDF_STACK = 30;
+constexpr int SDF_LEAF_TRIS = 4;
+struct SdfLocalStack { int v[SDF_STACK]; __host__ __device__ __forceinline__ int get(int i) const { return v[i]; } __host__ __device__ __forceinline__ void set(int i, int x) { v[i] = x; } };
+struct SdfLdsStack { int* col; __device__ __forceinline__ int get(int i) const { return col[i * 256]; } __device__ __forceinline__ void set(int i, int x) { col[i * 256] = x; } };
 
-// closest_triangle(...).second: distance to the nearest triangle, bounded above by sqrt(max_distance_sq)
-static __host__ __device__ float bvh_unsigned_distance(f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance_sq) {
-	// stack depth: ngp_sdf_create checks the tree's depth against the 64 entries.  An entry carries its box distance, so a node that became
-	// farther than the best hit while it waited on the stack is dropped when it is popped.
-	int stack[64]; float sdist[64]; int sp = 0;
-	stack[sp] = 0; sdist[sp++] = 0.f;
+// the whole node in four 16-byte loads issued back to back (the child references arrive with the boxes, not in a second round trip when they are pushed)
+static __host__ __device__ __forceinline__ SdfBvhNode2 load_node(const SdfBvhNode2* __restrict__ nodes, int ref) {
+	struct alignas(16) Q { uint32_t w[4]; };
+	const Q* q = (const Q*)(nodes + ref);
+	Q v[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) v[k] = q[k];
+	SdfBvhNode2 n;
+	__builtin_memcpy(&n, v, sizeof(n));
+	return n;
+}
+// closest_triangle(...).second: distance to the nearest triangle, bounded above by sqrt(max_distance_sq).  Near child first; the result is the minimum of
+// tri_distance_sq over every triangle whose boxes are not farther than the running minimum, i.e. independent of the visiting order and of the tree's shape.
+template <class Stack>
+static __host__ __device__ __forceinline__ float bvh_unsigned_distance(f3 p, const SdfBvhNode2* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, float max_distance_sq, Stack& st) {
+	constexpr int DONE = 0x7fffffff;
+	int sp = 0, ref = root;
 	float best = max_distance_sq; bool found = false;
-	while (sp > 0) {
-		--sp;
-		if (sdist[sp] > best) continue;
-		const SdfBvhNode& n = nodes[stack[sp]];
-		if (n.left < 0) {
-			for (int i = -n.left - 1; i < -n.right - 1; ++i) { const float d = tri_distance_sq(tris[i], p); if (d <= best) { best = d; found = true; } }
-		} else {
-			const float dl = bb_distance_sq(nodes[n.left], p), dr = bb_distance_sq(nodes[n.right], p);
-			// far child first onto the stack, so the near one is popped next
-			if (dl <= dr) { if (dr <= best) { stack[sp] = n.right; sdist[sp++] = dr; } if (dl <= best) { stack[sp] = n.left; sdist[sp++] = dl; } }
-			else { if (dl <= best) { stack[sp] = n.left; sdist[sp++] = dl; } if (dr <= best) { stack[sp] = n.right; sdist[sp++] = dr; } }
+	// "while-while": every lane first descends through inner nodes to its next leaf, then the wavefront's leaves are evaluated together -- the long leaf code runs once per
+	// round instead of in every step in which some lane happens to be at a leaf
+	for (;;) {
+		while (ref >= 0 && ref != DONE) {
+			const SdfBvhNode2 n = load_node(nodes, ref);
+			const float dl = bb_distance_sq(n.lmin, n.lmax, p), dr = bb_distance_sq(n.rmin, n.rmax, p);
+			const bool tl = dl <= best, tr = dr <= best;
+			if (tl & tr) { const bool left_first = dl <= dr; st.set(sp++, left_first ? n.right : n.left); ref = left_first ? n.left : n.right; } // near child next, far child waits
+			else if (tl | tr) ref = tl ? n.left : n.right;
+			else ref = sp > 0 ? st.get(--sp) : DONE; // (a reference that became farther than the best hit while it waited costs one wasted step: its children fail the test)
 		}
+		if (ref == DONE) break;
+		{
+			const int first = (~ref) >> 3, cnt = (~ref) & 7;
+			SdfTriangle T[SDF_LEAF_TRIS]; // all loads first: one round trip
+#pragma unroll
+			for (int k = 0; k < SDF_LEAF_TRIS; ++k) T[k] = tris[first + (k < cnt ? k : cnt - 1)];
+#pragma unroll
+			for (int k = 0; k < SDF_LEAF_TRIS; ++k) { const float d = tri_distance_sq(T[k], p); const bool better = (k < cnt) & (d <= best); best = better ? d : best; found = found | better; }
+		}
+		if (sp == 0) break;
+		ref = st.get(--sp);
 	}
 	return found ? sqrtf(best) : 0.0f; // "No closest triangle found": the reference returns 0 as well (triangle_bvh.cu:562-566)
 }
-// ray_intersect(...).first >= 0: is any triangle hit within SDF_MAX_DIST?
-static __host__ __device__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris) {
-	int stack[64]; int sp = 0;
-	stack[sp++] = 0;
-	while (sp > 0) {
-		const SdfBvhNode& n = nodes[stack[--sp]];
-		if (n.left < 0) {
-			for (int i = -n.left - 1; i < -n.right - 1; ++i) if (tri_ray_intersect(tris[i], o, d) < SDF_MAX_DIST) return true;
-		} else {
-			if (bb_ray_entry(nodes[n.right], o, d) < SDF_MAX_DIST) stack[sp++] = n.right; // depth checked at creation (ngp_sdf_create)
-			if (bb_ray_entry(nodes[n.left], o, d) < SDF_MAX_DIST) stack[sp++] = n.left;
+// Slab test of a stab ray with the reciprocal direction (six multiplications instead of the six IEEE divisions of BoundingBox::ray_intersect).  Only a conservative
+// filter in front of the exact triangle tests: a box is accepted when [t_enter, t_exit] is non-empty after t_exit has been widened by 4 ulp (covers the rounding of
+// both bounds), t_exit >= 0 (the triangle test rejects t < 0) and t_enter < SDF_MAX_DIST.  fminf / fmaxf drop the NaN of 0 * inf (origin on a face, axis-parallel ray).
+static __host__ __device__ __forceinline__ float bb_ray_entry_inv(const float* __restrict__ bmin, const float* __restrict__ bmax, f3 o, f3 inv) {
+	const float x1 = (bmin[0] - o.x) * inv.x, x2 = (bmax[0] - o.x) * inv.x;
+	const float y1 = (bmin[1] - o.y) * inv.y, y2 = (bmax[1] - o.y) * inv.y;
+	const float z1 = (bmin[2] - o.z) * inv.z, z2 = (bmax[2] - o.z) * inv.z;
+	const float t_enter = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+	const float t_exit = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+	return (t_exit >= 0.0f && t_enter <= t_exit * 1.0000005f) ? t_enter : 3.402823466e+38f;
+}
+// ray_intersect(...).first >= 0: is any triangle hit within SDF_MAX_DIST?  Any-hit, so the order is free: the child the ray enters first is walked first (a hit
+// ends the walk).  `stop` (device: an LDS flag shared by the 32 rays of one point, nullptr elsewhere) ends it from outside; the return value is then meaningless.
+template <class Stack>
+static __host__ __device__ __forceinline__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode2* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, Stack& st, const volatile int* stop) {
+	constexpr int DONE = 0x7fffffff;
+	const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	int sp = 0, ref = root;
+	for (;;) {
+		if (stop && *stop) return true;
+		while (ref >= 0 && ref != DONE) { // inner nodes, down to this lane's next leaf
+			const SdfBvhNode2 n = load_node(nodes, ref);
+			const float tl = bb_ray_entry_inv(n.lmin, n.lmax, o, inv), tr = bb_ray_entry_inv(n.rmin, n.rmax, o, inv);
+			const bool hl = tl < SDF_MAX_DIST, hr = tr < SDF_MAX_DIST;
+			if (hl & hr) { const bool left_first = tl <= tr; st.set(sp++, left_first ? n.right : n.left); ref = left_first ? n.left : n.right; }
+			else if (hl | hr) ref = hl ? n.left : n.right;
+			else ref = sp > 0 ? st.get(--sp) : DONE;
 		}
+		if (ref == DONE) return false;
+		{
+			const int first = (~ref) >> 3, cnt = (~ref) & 7;
+			SdfTriangle T[SDF_LEAF_TRIS]; // all loads first: one round trip
+#pragma unroll
+			for (int k = 0; k < SDF_LEAF_TRIS; ++k) T[k] = tris[first + (k < cnt ? k : cnt - 1)];
+			bool hit = false;
+#pragma unroll
+			for (int k = 0; k < SDF_LEAF_TRIS; ++k) hit = hit | ((k < cnt) & (tri_ray_intersect(T[k], o, d) < SDF_MAX_DIST));
+			if (hit) return true;
+		}
+		if (sp == 0) return false;
+		ref = st.get(--sp);
 	}
-	return false;
 }
 // cylindrical_to_dir / fibonacci_dir<32>, random_val.cuh:45-101
 static __host__ __device__ __forceinline__ f3 fibonacci_dir32(uint32_t i, float ox, float oy) {
@@ -113,15 +161,20 @@ static __host__ __device__ __forceinline__ f3 fibonacci_dir32(uint32_t i, float 
 	float sp, cp; sincosf(phi, &sp, &cp);
 	return mk3(sin_theta * cp, sin_theta * sp, cos_theta);
 }
-// signed_distance_raystab, triangle_bvh.cu:631-650 with the per-element rng of signed_distance_raystab_kernel (:893-909)
-static __host__ __device__ float bvh_signed_distance_raystab(uint32_t i, f3 p, const SdfBvhNode* __restrict__ nodes, const SdfTriangle* __restrict__ tris, float max_distance) {
-	const float distance = bvh_unsigned_distance(p, nodes, tris, max_distance * max_distance);
-	ngp_pcg32 dflt; dflt.state = 0x853c49e6748fea9bULL; dflt.inc = 0xda3e39cb94b95bdbULL; // default-constructed pcg32
+// the stab rays' random lattice offset: per-element rng of signed_distance_raystab_kernel (triangle_bvh.cu:893-909), default-constructed pcg32 advanced by 2 i
+static __host__ __device__ __forceinline__ void stab_offset(uint32_t i, float& ox, float& oy) {
+	ngp_pcg32 dflt; dflt.state = 0x853c49e6748fea9bULL; dflt.inc = 0xda3e39cb94b95bdbULL;
 	Rng rng(dflt);
 	rng.advance((uint64_t)(i * 2u));
-	const float ox = rng.next_float(), oy = rng.next_float();
+	ox = rng.next_float(); oy = rng.next_float();
+}
+// signed_distance_raystab, triangle_bvh.cu:631-650, one point after the other (the host's test hook; the device splits the same functions over two kernels, below)
+static float bvh_signed_distance_raystab_serial(uint32_t i, f3 p, const SdfBvhNode2* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, float max_distance) {
+	SdfLocalStack st;
+	const float distance = bvh_unsigned_distance(p, nodes, root, tris, max_distance * max_distance, st);
+	float ox, oy; stab_offset(i, ox, oy);
 	for (uint32_t k = 0; k < 32; ++k)
-		if (!bvh_ray_hits_anything(p, fibonacci_dir32(k, ox, oy), nodes, tris)) return distance; // a stab ray escapes: outside
+		if (!bvh_ray_hits_anything(p, fibonacci_dir32(k, ox, oy), nodes, root, tris, st, nullptr)) return distance; // a stab ray escapes: outside
 	return -distance;
 }
 
@@ -170,19 +223,79 @@ __global__ void __launch_bounds__(256) k_sdf_generate_positions(SdfSampleArgs a)
 	a.positions[(size_t)i * 3 + 0] = s.x; a.positions[(size_t)i * 3 + 1] = s.y; a.positions[(size_t)i * 3 + 2] = s.z;
 	a.distances[i] = dist;
 }
-// signed_distance_gpu(n, Raystab, positions + n_exact, distances + n_exact, ..., use_existing_distances_as_upper_bounds)
-__global__ void __launch_bounds__(256) k_sdf_signed_distance(uint32_t n, const float* __restrict__ positions, float* __restrict__ distances, const SdfBvhNode* __restrict__ nodes,
-		const SdfTriangle* __restrict__ tris, int use_upper_bounds) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// signed_distance_gpu(n, Raystab, positions + n_exact, distances + n_exact, ..., use_existing_distances_as_upper_bounds) in three launches:
+//   k_sdf_distance_first_rays  one lane per (point, role), the role by blockIdx.y: 0 = unsigned distance, 1 .. first_rays = stab ray role - 1 of the Fibonacci lattice.  The
+//                              walks are chains of dependent loads and a batch has fewer points than the chip has lanes, so the independent walks of a point run side by
+//                              side instead of one after the other.  A ray that escapes marks its point: outside, settled (for an outside point a ray towards the open
+//                              side usually does).  Measured (profiles/r04_f4_sdf_ground_truth.txt): the launch lasts as long as its slowest distance walk -- a uniform
+//                              point's walk is ~125 inner steps + ~40 leaves (max 360 + 165) at ~2 us per dependent step.
+//   k_sdf_compact_survivors    points none of whose first rays escaped -> survivor list, -distance provisionally
+//   k_sdf_stab_rays            32 lanes per survivor, lane k = stab ray k (the first ones are known hits and idle).  Inside points -- every ray hits -- cost the longest
+//                              of the remaining short any-hit walks instead of their sum; the first ray that finishes without a hit raises the point's LDS flag, which
+//                              stops the others and flips the sign.
+// The answer is "does ANY of the 32 rays escape", whatever the order, so the split returns what the serial loop of the reference returns.
+__global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, const float* __restrict__ positions, float* __restrict__ distances, const SdfBvhNode2* __restrict__ nodes, int root,
+		const SdfTriangle* __restrict__ tris, int use_upper_bounds, uint32_t* __restrict__ escaped) {
+	__shared__ int s_stack[SDF_STACK * 256];
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
 	if (i >= n) return;
+	SdfLdsStack st; st.col = s_stack + threadIdx.x;
 	const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
-	distances[i] = bvh_signed_distance_raystab(i, p, nodes, tris, use_upper_bounds ? distances[i] : SDF_MAX_DIST);
+	if (role == 0) {
+		const float max_distance = use_upper_bounds ? distances[i] : SDF_MAX_DIST;
+		distances[i] = bvh_unsigned_distance(p, nodes, root, tris, max_distance * max_distance, st);
+	} else {
+		float ox, oy; stab_offset(i, ox, oy);
+		if (!bvh_ray_hits_anything(p, fibonacci_dir32(role - 1u, ox, oy), nodes, root, tris, st, nullptr)) escaped[i] = 1u;
+	}
 }
-// the same function on the host (test hook; the product never calls it)
-void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds) {
+__global__ void __launch_bounds__(256) k_sdf_compact_survivors(uint32_t n, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ survivors, uint32_t* __restrict__ n_survivors) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool survivor = false;
+	if (i < n) {
+		survivor = escaped[i] == 0u;
+		escaped[i] = 0u; // clean for the next call
+		if (survivor) distances[i] = -distances[i];
+	}
+	// wave-aggregated append
+	const uint64_t m = __ballot(survivor);
+	if (m) {
+		const uint32_t lane = threadIdx.x & 63u;
+		uint32_t base = 0;
+		if (lane == (uint32_t)__ffsll((unsigned long long)m) - 1u) base = atomicAdd(n_survivors, (uint32_t)__popcll(m));
+		base = __shfl(base, __ffsll((unsigned long long)m) - 1);
+		if (survivor) survivors[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+	}
+}
+__global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restrict__ positions, float* __restrict__ distances, const SdfBvhNode2* __restrict__ nodes, int root,
+		const SdfTriangle* __restrict__ tris, const uint32_t* __restrict__ survivors, const uint32_t* __restrict__ n_survivors, uint32_t first_rays) {
+	__shared__ int s_stack[SDF_STACK * 256];
+	__shared__ int s_escaped[8];
+	const uint32_t n = *n_survivors;
+	const uint32_t grp = threadIdx.x >> 5, k = threadIdx.x & 31u;
+	if (k == 0) s_escaped[grp] = 0;
+	__syncthreads();
+	// grid-stride over the survivors, eight per workgroup and round; a group's 32 lanes are half a wavefront, so its flag is written and read by one wavefront only
+	for (uint32_t g = blockIdx.x * 8u + grp; g < n; g += gridDim.x * 8u) {
+		const uint32_t i = survivors[g];
+		const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
+		float ox, oy; stab_offset(i, ox, oy);
+		SdfLdsStack st; st.col = s_stack + threadIdx.x;
+		volatile int* flag = &s_escaped[grp];
+		if (k >= first_rays && !bvh_ray_hits_anything(p, fibonacci_dir32(k, ox, oy), nodes, root, tris, st, flag)) {
+			*flag = 1;
+			distances[i] = fabsf(distances[i]); // every escaping lane writes the same value
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (k == 0) *flag = 0; // (wavefront-private flag: program order is enough)
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+// the same functions on the host (test hook; the product never calls it)
+void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds) {
 	for (uint32_t i = 0; i < n; ++i) {
 		const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
-		distances[i] = bvh_signed_distance_raystab(i, p, nodes, tris, use_upper_bounds ? distances[i] : SDF_MAX_DIST);
+		distances[i] = bvh_signed_distance_raystab_serial(i, p, nodes, root, tris, use_upper_bounds ? distances[i] : SDF_MAX_DIST);
 	}
 }
 // compare_signs_kernel (no octree): counters[0..5] = ref inside / outside, model inside / outside, intersection, union
@@ -199,8 +312,15 @@ __global__ void __launch_bounds__(256) k_sdf_compare_signs(uint32_t n, const flo
 }
 
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a) { if (a.n) hipLaunchKernelGGL(k_sdf_generate_positions, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
-void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode* nodes, const SdfTriangle* tris, int use_upper_bounds) {
-	if (n) hipLaunchKernelGGL(k_sdf_signed_distance, dim3((n + 255) / 256), dim3(256), 0, s, n, positions, distances, nodes, tris, use_upper_bounds);
+void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds,
+		uint32_t* survivors, uint32_t* escaped, uint32_t* n_survivors) {
+	if (!n) return;
+	static const uint32_t first_rays = getenv("NGP_SDF_FIRST_RAYS") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_FIRST_RAYS")), 0), 32) : 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel (ablation knob)
+	(void)hipMemsetAsync(n_survivors, 0, 4, s); // (`escaped` is zero: ngp_sdf_create clears it, k_sdf_compact_survivors leaves it clean)
+	hipLaunchKernelGGL(k_sdf_distance_first_rays, dim3((n + 255) / 256, 1 + first_rays), dim3(256), 0, s, n, positions, distances, nodes, root, tris, use_upper_bounds, escaped);
+	hipLaunchKernelGGL(k_sdf_compact_survivors, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, escaped, survivors, n_survivors);
+	// five 30 KiB workgroups fit a CU's LDS: a grid of resident workgroups walks the list (its length is only known on the device)
+	hipLaunchKernelGGL(k_sdf_stab_rays, dim3(std::min<uint32_t>((n + 7) / 8, 256u * 5u)), dim3(256), 0, s, positions, distances, nodes, root, tris, survivors, n_survivors, first_rays);
 }
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters) {
 	if (n) hipLaunchKernelGGL(k_sdf_compare_signs, dim3((n + 255) / 256), dim3(256), 0, s, n, ref, (const __half*)model, model_stride, counters);

@@ -212,9 +212,13 @@ def test_gradient_reduction_and_var_adam_kernels(ora, hip):
         assert np.allclose(vd.cpu().numpy(), var, rtol=0, atol=2e-6), np.abs(vd.cpu().numpy() - var).max()
 
 
-def _tinted_dataset(n_img, res):
-    """the small synthetic scene with a per-image colour cast that only a per-image input can explain"""
-    imgs, xforms, meta = make_small_dataset(n_img, res)
+def _tinted_dataset(n_img, res, n_poses=None):
+    """the small synthetic scene with a per-image colour cast that only a per-image input can explain.  n_poses < n_img: image i is taken from pose i % n_poses, so
+    several images share one camera and differ by their cast alone (a view-dependent colour cannot tell them apart, an appearance vector can)"""
+    n_poses = n_poses or n_img
+    imgs0, xforms0, meta = make_small_dataset(n_poses, res)
+    imgs = [imgs0[i % n_poses] for i in range(n_img)]
+    xforms = [xforms0[i % n_poses] for i in range(n_img)]
     rng = np.random.default_rng(11)
     tints = rng.uniform(0.55, 1.0, (n_img, 3)).astype(np.float32)
     out = []
@@ -280,9 +284,10 @@ def test_trainer_with_extra_dims(hip):
 @pytest.mark.gpu
 def test_latents_explain_a_per_image_colour_cast(hip):
     """What the extra dims are for (appearance embeddings): on images with a per-image colour cast a model with 4 learnable dims per image reaches a clearly lower training
-    loss than base.json's plain model after the same number of steps."""
+    loss than base.json's plain model after the same number of steps.  Pairs of images share one camera pose: the plain model's best answer for such a pair is the mean of
+    the two casts (a loss floor of about (c dt / 2)^2), the latents are the only input that separates them."""
     n_img = 12
-    imgs, xforms, meta, tints = _tinted_dataset(n_img, 96)
+    imgs, xforms, meta, tints = _tinted_dataset(n_img, 96, n_poses=6)
     losses = {}
     for name, n_extra in (("plain", 0), ("latents", 4)):
         cfg = A.base_model_config(1, n_extra_dims=n_extra)
@@ -298,7 +303,7 @@ def test_latents_explain_a_per_image_colour_cast(hip):
         losses[name] = float(np.mean(ls))
         hip.ngp_nerf_destroy(t)
     print(losses)
-    assert losses["latents"] < 0.7 * losses["plain"], losses
+    assert losses["latents"] < 0.5 * losses["plain"], losses
 
 
 @pytest.mark.gpu
