@@ -1168,16 +1168,20 @@ template <> __device__ __forceinline__ uint32_t pack_halfs<2>(const float* v) { 
 
 // THREADS: 256 (two samples per thread at 512 samples per block) or 512 (one): the block's LDS image is the same, so 512 threads double the wavefronts per CU
 // (3 blocks of 50 KiB: 12 -> 24) -- the kernel is latency bound (position / gradient loads, the cursor atomics, four barriers), not LDS or issue bound.
-template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */, int F = 4, uint32_t THREADS = 256>
+// D = 2: the image primitive's 2-D grid (4 corners per sample; its samples are i.i.d. pixels, so runs are not merged)
+template <uint32_t CL2, uint32_t GRAD_BIN_SAMPLES /* samples of one level per block: 256 | 512 */, int F = 4, uint32_t THREADS = 256, int D = 3>
 __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 	typedef typename BinVal<F>::type val_t;
+	static_assert(D == 3 || (D == 2 && F == 2), "k_grad_bin: 3-D grids, or the 2-D F = 2 grid of the image primitive");
+	constexpr int NC = 1 << D; // corners per sample
 	constexpr uint32_t NCH = (1u << GRAD_BIN_MAX_TABLE_LOG2) >> CL2; // most chunks a level can have (128 / 256)
 	__shared__ uint32_t s_cnt[NCH], s_start[NCH], s_gbase[NCH];
 	__shared__ uint32_t s_wsum[THREADS / 64];
-	__shared__ val_t s_val[GRAD_BIN_SAMPLES * 8];
-	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * 8];
+	__shared__ val_t s_val[GRAD_BIN_SAMPLES * NC];
+	__shared__ uint32_t s_key[GRAD_BIN_SAMPLES * NC];
 	const uint32_t tid = threadIdx.x, ly = blockIdx.y, level = a.levels[ly];
-	const LevelConst lc = level_const_uniform(a.gm, level);
+	LevelConst lc = level_const_uniform(a.gm, level);
+	if (D == 2) lc.hashed = (uint64_t)lc.res * lc.res > (uint64_t)lc.hs;
 	// Chunk of a table entry.  Hashed level: 2^CL2 consecutive entries (the hash spreads every sample's corners over all chunks).  Dense level
 	// (a.dense_too): entries are INTERLEAVED over all NCH chunks (chunk = index mod NCH, local = index / NCH), so that the spatially clustered
 	// samples of a scene still fill the lists evenly; a dense level has at most 2^19 entries, i.e. local < 2^CL2.
@@ -1190,8 +1194,8 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 	__syncthreads();
 	constexpr int SPT = GRAD_BIN_SAMPLES / THREADS; // samples per thread
 	static_assert(GRAD_BIN_SAMPLES % THREADS == 0 && NCH <= THREADS, "k_grad_bin: block shape");
-	uint32_t idx[SPT][8], rank[SPT][8];
-	val_t val[SPT][8];
+	uint32_t idx[SPT][NC], rank[SPT][NC];
+	val_t val[SPT][NC];
 	bool valid[SPT];
 	const uint32_t lane = tid & 63u;
 #pragma unroll
@@ -1201,11 +1205,24 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 		float g[F];
 #pragma unroll
 		for (int f = 0; f < F; ++f) g[f] = 0.f;
-		Corners cr;
+		struct { uint32_t idx[NC]; float w[NC]; uint32_t cell_xy, cell_z; } cr;
 		{
 			const uint32_t sc = valid[u] ? s : a.n - 1; // every lane takes part in the shuffles below
 			const float* p = a.in + (size_t)sc * a.in_stride;
-			level_corners(lc, p[0], p[1], p[2], cr);
+			if constexpr (D == 3) {
+				Corners c3;
+				level_corners(lc, p[0], p[1], p[2], c3);
+#pragma unroll
+				for (int k = 0; k < NC; ++k) { cr.idx[k] = c3.idx[k]; cr.w[k] = c3.w[k]; }
+				cr.cell_xy = c3.cell_xy; cr.cell_z = c3.cell_z;
+			} else {
+				CornersND<D> c2;
+				const float x2[2] = {p[0], p[1]};
+				level_corners_nd<D>(a.gm, level, x2, c2);
+#pragma unroll
+				for (int k = 0; k < NC; ++k) { cr.idx[k] = c2.idx[k]; cr.w[k] = c2.w[k]; }
+				cr.cell_xy = s; cr.cell_z = 0u; // (never merged)
+			}
 			if (valid[u]) {
 				const val_t raw = ((const val_t*)a.denc_lv)[(size_t)level * a.denc_cap + sc];
 				const _Float16* gh = (const _Float16*)&raw;
@@ -1222,14 +1239,14 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;
 		const bool head = lane == 0 || key_xy != pxy || key_z != pz || !valid[u] || !pvalid;
 		const uint64_t hm = __ballot(head);
-		const bool merge = (a.merge_runs || (dense && !a.no_dense_merge)) && __popcll(hm) <= 48; // dense (coarse) levels: most lanes are followers
+		const bool merge = D == 3 && (a.merge_runs || (dense && !a.no_dense_merge)) && __popcll(hm) <= 48; // dense (coarse) levels: most lanes are followers
 		bool emit = valid[u];
 		if (merge) {
 			const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
 			const uint32_t run_right = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : (63u - lane); // followers to my right that belong to my run
-			float v[8][F];
+			float v[NC][F];
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { const float w = cr.w[k];
+			for (int k = 0; k < NC; ++k) { const float w = cr.w[k];
 #pragma unroll
 				for (int f = 0; f < F; ++f) v[k][f] = g[f] * w; }
 #pragma unroll
@@ -1237,16 +1254,16 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 				const bool take = run_right >= (uint32_t)d;
 				if (__ballot(take) == 0ull) break; // no run reaches this far (wave-uniform): runs are a ray's samples in one cell, rarely longer than 8 - 16
 #pragma unroll
-				for (int k = 0; k < 8; ++k)
+				for (int k = 0; k < NC; ++k)
 #pragma unroll
 					for (int f = 0; f < F; ++f) { const float t = __shfl_down(v[k][f], d, 64); if (take) v[k][f] += t; }
 			}
 			emit = valid[u] && head;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) val[u][k] = pack_halfs<F>(v[k]);
+			for (int k = 0; k < NC; ++k) val[u][k] = pack_halfs<F>(v[k]);
 		} else {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
+			for (int k = 0; k < NC; ++k) {
 				const float w = cr.w[k];
 				float v[F];
 #pragma unroll
@@ -1257,7 +1274,7 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 		valid[u] = emit;
 		if (!emit) continue;
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = 0; k < NC; ++k) {
 			idx[u][k] = cr.idx[k];
 			rank[u][k] = atomicAdd(&s_cnt[chunk_of(cr.idx[k])], 1u);
 		}
@@ -1285,7 +1302,7 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 	for (int u = 0; u < SPT; ++u) {
 		if (!valid[u]) continue;
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = 0; k < NC; ++k) {
 			const uint32_t c = chunk_of(idx[u][k]);
 			const uint32_t pos = s_start[c] + rank[u][k];
 			s_val[pos] = val[u][k];
@@ -1366,7 +1383,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	const uint32_t hs = a.gm->hashmap_size[level], offset = a.gm->offset[level];
 	constexpr uint32_t NCH_LOG2 = GRAD_BIN_MAX_TABLE_LOG2 - CL2;
 	const uint64_t res = a.gm->resolution[level];
-	const bool dense = res * res * res <= (uint64_t)hs; // interleaved chunks: entry = local * NCH + chunk (see k_grad_bin)
+	const bool dense = (a.n_pos_dims == 2 ? res * res : res * res * res) <= (uint64_t)hs; // interleaved chunks: entry = local * NCH + chunk (see k_grad_bin)
 	if (c >= (dense ? (1u << NCH_LOG2) : (hs >> CL2))) return;
 	uint32_t* cursor = a.cursors + ly * a.max_chunks + c;
 	const uint32_t n_raw = *cursor;
@@ -2090,7 +2107,15 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_train_fwd_bwd(EncTrainArgs a)
 #pragma unroll
 		for (int s = 0; s < 4; ++s) denc = mfma(lds_frag(bw, BW_R1 + s, lane), dh1[s], denc);
 		// ---- GridEncoding backward: register pair (2m, 2m+1) = features 0,1 of level (m & 1) + 4 (m >> 1) + 2 hi ----
-		if (a.grid_grad && sv) {
+		if (a.denc_lv && sv) {
+			// the scatter runs through the record lists (k_grad_bin / k_grad_accumulate behind this kernel): dL/d(enc) leaves level-major, one half2 per (level, sample)
+#pragma unroll
+			for (int m = 0; m < 8; ++m) {
+				const uint32_t level = (uint32_t)((m & 1) + 4 * (m >> 1) + 2 * hi);
+				const h2 g = {(_Float16)denc[2 * m], (_Float16)denc[2 * m + 1]};
+				a.denc_lv[(size_t)level * a.denc_cap + s_raw] = __builtin_bit_cast(uint32_t, g);
+			}
+		} else if (a.grid_grad && sv) {
 #pragma unroll
 			for (int m = 0; m < 8; ++m) {
 				const uint32_t level = (uint32_t)((m & 1) + 4 * (m >> 1) + 2 * hi);
@@ -2403,10 +2428,17 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 	hipLaunchKernelGGL(k_build_frags, dim3((n_mlp + 255) / 256), dim3(256), 0, s, (const __half*)mlp_params, n_mlp, fw_perm, bw_perm, (__half*)fw, (__half*)bw);
 }
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
+#define REQUIRE_VOID(c) do { if (!(c)) { fprintf(stderr, "launch_grad_bin: unsupported layout (%s)\n", #c); abort(); } } while (0)
 void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
 	if (a.n == 0 || a.n_hashed == 0) return;
 	static const uint32_t ns = getenv("NGP_BIN_SAMPLES") ? (uint32_t)atoi(getenv("NGP_BIN_SAMPLES")) : 512u;
 	const dim3 gb((a.n + ns - 1) / ns, a.n_hashed);
+	if (a.n_features == 2 && a.n_pos_dims == 2) { // the image primitive's grid (encmlp trainer): 4 corners per sample
+		REQUIRE_VOID(a.chunk_log2 == 12);
+		hipLaunchKernelGGL((k_grad_bin<12, 512, 2, 256, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		return;
+	}
 	if (a.n_features == 2) { // L = 16, F = 2: one block per chunk, both features (4-byte record values)
 		if (a.chunk_log2 == 11) {
 			hipLaunchKernelGGL((k_grad_bin<11, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);

@@ -602,6 +602,8 @@ struct ngp_encmlp {
 	float* wgrad_partials = nullptr; uint32_t n_partials = 0;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
+	// scatter through the record lists (k_grad_bin / k_grad_accumulate, as in ngp_model): level-major dL/d(enc) + one list per (level, 4096-entry chunk)
+	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0, bin_lists = 0;
 };
 static void build_grid_meta_nd(const ngp_encmlp_config& c, GridMeta& g) {
 	memset(&g, 0, sizeof(g));
@@ -689,7 +691,7 @@ extern "C" int ngp_encmlp_create(const ngp_encmlp_config* cfg, uint64_t seed, ng
 extern "C" void ngp_encmlp_destroy(ngp_encmlp* m) {
 	if (!m) return;
 	void* ptrs[] = {m->gm_dev, m->master, m->params, m->params_inf, m->grads, m->adam_m, m->adam_v, m->ema, m->adam_steps, m->fw_perm, m->bw_perm, m->fw_frags, m->bw_frags,
-		m->fw_frags_inf, m->enc_stash, m->dy_stash, m->wgrad_partials};
+		m->fw_frags_inf, m->enc_stash, m->dy_stash, m->wgrad_partials, m->denc_lv, m->bin_vals, m->bin_idxs, m->bin_cursors};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	delete m;
 }
@@ -736,13 +738,54 @@ static int encmlp_training_step(ngp_encmlp* m, hipStream_t s, const float* in, u
 	}
 	HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); // GradientMode::Overwrite
 	if (loss_sum_dev) HIPCHK(hipMemsetAsync(loss_sum_dev, 0, 4, s));
+	// The encoding's backward pass through the record lists (round 4; rounds 2-3: atomicAdd(__half2) from the fused kernel, 2.2 ms per 2^18 SDF samples -- the memory side
+	// retires ~15 G atomic operations per second): every level -- hashed ones by 4096-entry chunk, dense ones interleaved over the 128 chunks -- is counting-sorted by
+	// k_grad_bin and summed exactly in LDS by k_grad_accumulate.  Needs base.json's table size (T = 2^19: all lists share one capacity); other sizes keep the atomics.
+	GradBinArgs ba;
+	ba.n_hashed = 0; ba.max_chunks = (1u << GRAD_BIN_MAX_TABLE_LOG2) >> 12; ba.chunk_log2 = 12; ba.split = 0; ba.merge_runs = 0; ba.no_dense_merge = 0;
+	ba.n_features = 2; ba.n_pos_dims = m->cfg.n_pos_dims;
+	if (m->train_encoding && !(g_debug_flags & DBG_T1_NO_BINNING) && m->gm.n_levels <= MAX_LEVELS) {
+		bool ok = true;
+		for (uint32_t l = 0; l < m->gm.n_levels; ++l) {
+			const uint64_t res = m->gm.resolution[l], hs = m->gm.hashmap_size[l];
+			const bool dense = (m->cfg.n_pos_dims == 2 ? res * res : res * res * res) <= hs;
+			if (dense ? hs > (1ull << GRAD_BIN_MAX_TABLE_LOG2) : hs != (1ull << GRAD_BIN_MAX_TABLE_LOG2)) { ok = false; break; }
+			ba.levels[ba.n_hashed++] = l;
+		}
+		if (!ok) ba.n_hashed = 0;
+	}
+	if (ba.n_hashed) {
+		const uint32_t corners = 1u << m->cfg.n_pos_dims;
+		const uint32_t cap_want = std::max<uint32_t>(2048u, (uint32_t)((((uint64_t)n * corners * 2) / ba.max_chunks + 1023) / 1024 * 1024)); // twice the mean number of records per list
+		const uint32_t n_lists = ba.n_hashed * ba.max_chunks;
+		if (n > m->bin_n || cap_want > m->bin_cap || n_lists != m->bin_lists) {
+			HIPCHK(hipStreamSynchronize(s));
+			for (void* p : {m->denc_lv, m->bin_vals, m->bin_idxs, (void*)m->bin_cursors}) if (p) HIPCHK(hipFree(p));
+			m->denc_lv = m->bin_vals = m->bin_idxs = nullptr; m->bin_cursors = nullptr;
+			const uint32_t n_alloc = std::max(n, m->bin_n), cap_alloc = std::max(cap_want, m->bin_cap);
+			m->bin_n = m->bin_cap = m->bin_lists = 0;
+			HIPCHK(hipMalloc(&m->denc_lv, (size_t)m->gm.n_levels * n_alloc * 4));
+			HIPCHK(hipMalloc(&m->bin_vals, (size_t)n_lists * cap_alloc * 4));
+			HIPCHK(hipMalloc(&m->bin_idxs, (size_t)n_lists * cap_alloc * 2));
+			HIPCHK(hipMalloc((void**)&m->bin_cursors, (size_t)n_lists * 2 * 4));
+			HIPCHK(hipMemsetAsync(m->bin_cursors, 0, (size_t)n_lists * 2 * 4, s));
+			m->bin_n = n_alloc; m->bin_cap = cap_alloc; m->bin_lists = n_lists;
+		}
+	}
 	EncTrainArgs a;
 	a.gm = m->gm_dev; a.table = (const __half*)(m->params + m->n_mlp); a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags;
 	a.in = in; a.in_stride = in_stride; a.n = n; a.target = target; a.target_stride = target_stride; a.n_out = m->cfg.n_output_dims;
 	a.loss_type = loss_type; a.loss_scale = loss_scale; a.dy_in = dy; a.dy_stride = dy_stride;
 	a.grid_grad = m->train_encoding ? (__half*)(m->grads + m->n_mlp) : nullptr;
 	a.enc_stash = (uint4*)m->enc_stash; a.dy_stash = (uint2*)m->dy_stash; a.loss_sum = loss_sum_dev; a.pred_out = pred_out; a.pred_stride = pred_stride;
+	if (ba.n_hashed) { a.denc_lv = (uint32_t*)m->denc_lv; a.denc_cap = m->bin_n; }
 	launch_encmlp_train(s, a, m->cfg.n_pos_dims, dy != nullptr, m->wgrad_partials, m->n_partials, m->grads);
+	if (ba.n_hashed) {
+		ba.gm = m->gm_dev; ba.in = in; ba.in_stride = in_stride; ba.n = n; ba.denc_lv = m->denc_lv; ba.denc_cap = m->bin_n; ba.cap = m->bin_cap;
+		ba.vals = m->bin_vals; ba.idxs = (uint16_t*)m->bin_idxs; ba.cursors = m->bin_cursors; ba.cursor_done = m->bin_cursors + m->bin_lists; ba.grid_grad_ = m->grads + m->n_mlp;
+		ba.fuse_adam = 0;
+		launch_grad_bin(s, ba);
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }

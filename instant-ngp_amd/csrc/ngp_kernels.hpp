@@ -201,6 +201,7 @@ struct EncTrainArgs {
 	__half* grid_grad;                                      // encoding gradient table (nullptr: the encoding is not trained)
 	uint4* enc_stash; uint2* dy_stash;                      // for the weight-gradient kernel
 	float* loss_sum; ngp_half* pred_out; uint32_t pred_stride; // optional: sum of the per-element loss values, network outputs
+	uint32_t* denc_lv = nullptr; uint32_t denc_cap = 0;     // non-null: dL/d(enc) is left level-major (one half2 per (level, sample)) for the record lists instead of being scattered with atomics
 };
 void launch_encmlp_train(hipStream_t s, const EncTrainArgs& a, uint32_t n_pos_dims, bool external_dy, float* wgrad_partials, uint32_t n_partials, ngp_half* mlp_grad);
 void launch_encode_only(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out, uint32_t n_features = 4);
@@ -228,6 +229,7 @@ struct GradBinArgs {
 	uint32_t levels[MAX_LEVELS]; uint32_t n_hashed, max_chunks, cap;
 	uint32_t chunk_log2, split, merge_runs, no_dense_merge;
 	uint32_t n_features; // F: 4 (8-byte record values) or 2 (4-byte)
+	uint32_t n_pos_dims = 3; // 3, or 2 for the image primitive's grid (F = 2 only)
 	void* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
 	// Single-GPU steps: k_grad_accumulate applies the optimizer to the HASHED levels in its epilogue -- the chunk's gradient sums are in LDS, so the 23 MB gradient write,
 	// its re-read by the sweep and the sweep's pass over those levels disappear (same arithmetic: the sums are rounded to half exactly as the stored gradient would be).
