@@ -117,7 +117,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readonly("lens_params", &ImageMetadata::lens_params).def_readonly("rolling_shutter", &ImageMetadata::rolling_shutter)
 		.def_property_readonly("lens", [](const ImageMetadata& m) { Lens l; l.mode = m.lens_mode; l.params = m.lens_params; return l; })               // python_api.cu:759 (write through training.set_camera_intrinsics)
 		.def_property_readonly("camera_distortion", [](const ImageMetadata& m) { Lens l; l.mode = m.lens_mode; l.params = m.lens_params; return l; }) // :758 legacy name
-		.def_property_readonly("light_dir", [](const ImageMetadata&) { return std::array<float, 3>{0.f, 0.f, 0.f}; });                                    // :764 (unused by the NeRF path)
+		.def_readonly("light_dir", &ImageMetadata::light_dir);                                                                                            // :764 (nerf_loader.cu:671-680)
 	py::class_<NerfDataset>(testbed, "NerfDataset")
 		.def_property_readonly("n_images", [](const NerfDataset& d) { return d.n_images; })
 		.def_readonly("metadata", &NerfDataset::metadata).def_readonly("aabb_scale", &NerfDataset::aabb_scale)
@@ -133,6 +133,8 @@ PYBIND11_MODULE(pyngp, m) {
 			return out;
 		}, "RGBA8 pixels of training image i (host copy)")
 		.def_readonly("sharpen_amount", &NerfDataset::sharpen_amount)
+		.def_readonly("n_extra_learnable_dims", &NerfDataset::n_extra_learnable_dims).def_readonly("has_light_dirs", &NerfDataset::has_light_dirs) // (read-only views of nerf_loader.h:84-87; the reference binds none of them)
+		.def_property_readonly("n_extra_dims", [](const NerfDataset& d) { return d.n_extra_dims(); })
 		.def("image_half", [](const NerfDataset& d, size_t i) {
 			if (i >= d.n_images || i >= d.pixels_half.size() || d.pixels_half[i].empty()) throw std::runtime_error{"image_half: no sharpened image (nerf.sharpen == 0?)"};
 			py::array_t<uint16_t> out({d.metadata[i].resolution[1], d.metadata[i].resolution[0], 4});

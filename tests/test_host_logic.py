@@ -293,6 +293,43 @@ def test_loader_conventions_aabb_mitsuba_masks(tmp_path):
     assert not d.from_mitsuba and np.allclose(np.array(d.xforms[0]).reshape(4, 3), ngp_matrix(0.33, [0.5] * 3, False), atol=1e-6)
 
 
+def test_loader_extra_dims_and_light_directions(tmp_path):
+    """nerf_loader.cu:482-483 (`n_extra_learnable_dims`) and :671-680 (`driver_parameters` LightX/Y/Z -> three fixed extra dims that replace learnable ones), nerf_loader.h:85-87
+    (n_extra_dims), nerf_loader.h:141-152 (nerf_direction_to_ngp); Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683): warped light direction, else U[-1, 1)."""
+    import json
+    import pyngp as ngp
+    rng = np.random.default_rng(2)
+    img = rng.integers(1, 255, (6, 8, 4), dtype=np.uint8); img[..., 3] = 255
+    M = np.array([[0.9, 0.1, -0.2, 1.5], [-0.1, 0.95, 0.3, -0.5], [0.25, -0.28, 0.92, 2.0], [0, 0, 0, 1]], dtype=np.float32)
+    for i in range(3):
+        _write_png(tmp_path / f"f{i}.png", img)
+    frames = [{"file_path": f"f{i}.png", "transform_matrix": M.tolist()} for i in range(3)]
+
+    def load(doc):
+        (tmp_path / "transforms.json").write_text(json.dumps(doc))
+        t = ngp.Testbed()
+        t.load_training_data(str(tmp_path / "transforms.json"))
+        return t
+
+    t = load({"camera_angle_x": 0.8, "n_extra_learnable_dims": 16, "frames": frames})
+    d = t.nerf.training.dataset
+    assert d.n_extra_learnable_dims == 16 and not d.has_light_dirs and d.n_extra_dims == 16
+    assert t.nerf.training.optimize_extra_dims is True  # load_nerf_post, testbed_nerf.cu:2379
+    lights = [(1.0, 2.0, 2.0), (0.0, -3.0, 4.0), (-1.0, 0.0, 0.0)]
+    lit = [dict(f, driver_parameters={"LightX": l[0], "LightY": l[1], "LightZ": l[2]}) for f, l in zip(frames, lights)]
+    t = load({"camera_angle_x": 0.8, "n_extra_learnable_dims": 16, "frames": lit})
+    d = t.nerf.training.dataset
+    assert d.has_light_dirs and d.n_extra_learnable_dims == 0 and d.n_extra_dims == 3 and t.nerf.training.optimize_extra_dims is False
+    for m, l in zip(d.metadata, lights):
+        n = np.array(l, np.float32) / np.float32(np.linalg.norm(l))
+        want = np.array([-n[1], -n[2], n[0]])  # y, z flipped, then xyz <- yzx
+        assert np.allclose(m.light_dir, want, atol=1e-6)
+    t = load({"camera_angle_x": 0.8, "from_mitsuba": True, "frames": lit})
+    for m, l in zip(t.nerf.training.dataset.metadata, lights):
+        n = np.array(l, np.float32) / np.float32(np.linalg.norm(l))
+        assert np.allclose(m.light_dir, [-n[0], -n[1], n[2]], atol=1e-6)  # y, z flipped, then x and z negated
+
+
 def test_tonemap_pixel_matches_the_reference_formulas():
     """CudaRenderBuffer::tonemap per pixel (render_buffer.cu:264-341, 511-548) as the device evaluates it -- csrc/ngp_device.hpp tonemap_pixel
     compiled for the host -- against the formulas in float64: background behind the premultiplied colour with weight (1 - a) * bg.a,

@@ -463,6 +463,54 @@ def test_training_from_a_dataset_handed_over_in_memory(scene_dir):
     assert 0 < l_disk < 0.01 and 0 < l_mem < 0.01 and abs(l_mem - l_disk) < 0.5 * max(l_disk, l_mem) + 1e-3, (l_disk, l_mem)
 
 
+@pytest.mark.gpu
+def test_training_with_per_image_latents(scene_dir):
+    """A transforms.json with `n_extra_learnable_dims` (nerf_loader.cu:482-483): the network's direction encoding takes 3 + n dims (nerf_network.h:84), every image owns a
+    vector that trains with the network (testbed_nerf.cu:2743-2750, 2860-2878, 3325-3340), a frame is rendered with one vector (get_rendering_extra_dims, :3685-3707)."""
+    ngp = _ngp()
+    import shutil
+    d = tempfile.mkdtemp(prefix="ngp_scene_latents_")
+    for f in os.listdir(scene_dir):
+        src = os.path.join(scene_dir, f)
+        (shutil.copytree if os.path.isdir(src) else shutil.copy)(src, os.path.join(d, f))
+    doc = json.load(open(os.path.join(d, "transforms_train.json")))
+    doc["n_extra_learnable_dims"] = 4
+    json.dump(doc, open(os.path.join(d, "transforms_train.json"), "w"))
+    t = ngp.Testbed()
+    t.load_training_data(os.path.join(d, "transforms_train.json"))
+    t.reload_network_from_file("")
+    ds = t.nerf.training.dataset
+    assert ds.n_extra_learnable_dims == 4 and ds.n_extra_dims == 4 and t.nerf.training.optimize_extra_dims
+    t.shall_train = True
+    t.training_batch_size = 1 << 16
+    e0 = [np.array(t.nerf.training.get_extra_dims(i)) for i in range(ds.n_images)]
+    assert all(e.shape == (4,) and np.all(np.abs(e) <= 1) for e in e0) and not np.allclose(e0[0], e0[1])  # reset_extra_dims: U[-1, 1) per image
+    while t.frame():
+        if t.training_step >= 200:
+            break
+    e1 = [np.array(t.nerf.training.get_extra_dims(i)) for i in range(ds.n_images)]
+    assert all(np.isfinite(e).all() for e in e1) and all(np.abs(a - b).max() > 1e-4 for a, b in zip(e0, e1)), "every image's vector has moved"
+    assert np.isfinite(t.loss) and 0 < t.loss < 0.05
+    # the switch: latents frozen, network keeps training
+    t.nerf.training.optimize_extra_dims = False
+    for _ in range(5):
+        t.frame()
+    e2 = [np.array(t.nerf.training.get_extra_dims(i)) for i in range(ds.n_images)]
+    assert all(np.array_equal(a, b) for a, b in zip(e1, e2))
+    # rendering: one vector per frame -- a training view's, or explicit values
+    t.shall_train = False
+    t.background_color = [0.0, 0.0, 0.0, 1.0]
+    t.set_camera_to_training_view(2)
+    t.nerf.set_rendering_extra_dims_from_training_view(2)
+    assert np.allclose(t.nerf.get_rendering_extra_dims(), e2[2])
+    a = t.render(48, 48, 1, True)
+    t.nerf.set_rendering_extra_dims(list(map(float, e2[2])))
+    b = t.render(48, 48, 1, True)
+    t.nerf.set_rendering_extra_dims([float(x) for x in -e2[2]])
+    c = t.render(48, 48, 1, True)
+    assert np.isfinite(a).all() and np.array_equal(a, b) and np.abs(a - c).max() > 1e-4
+
+
 def test_image_and_sdf_settings_objects():
     """Testbed.image / Testbed.sdf (python_api.cu:672-673, 855-879): the settings the image and SDF trainers are created with, and load_mesh's scale / box (testbed_sdf.cu:1380-1410)"""
     ngp = _ngp()
