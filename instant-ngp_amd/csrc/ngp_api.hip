@@ -1546,7 +1546,8 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 		ProfScope ps(P_GRID_MISC, s);
 		uint32_t key_bits = 21; for (uint32_t c = t->opt.max_cascade; c; c >>= 1) ++key_bits; // 3 x 7 Morton bits + the cascade
 		// the low 6 Morton bits (the cell inside its 4x4x4 block) stay unsorted: one radix pass less, the same coherence for the hash-grid levels
-		if (grid_sample_sort(s, t->grid_sort_temp, t->grid_sort_temp_bytes, t->grid_indices, t->grid_indices_sorted, t->grid_positions, t->grid_positions_sorted, n_samples, 6, key_bits))
+		static const uint32_t begin_bit = getenv("NGP_GRID_SORT_BEGIN_BIT") ? (uint32_t)atoi(getenv("NGP_GRID_SORT_BEGIN_BIT")) : 6u; // (ablation knob: coarser blocks = fewer radix passes, less coherence)
+		if (grid_sample_sort(s, t->grid_sort_temp, t->grid_sort_temp_bytes, t->grid_indices, t->grid_indices_sorted, t->grid_positions, t->grid_positions_sorted, n_samples, std::min(begin_bit, key_bits - 1u), key_bits))
 			return fail("update_density_grid: sort failed");
 		eval_pos = t->grid_positions_sorted; eval_idx = t->grid_indices_sorted;
 	}
