@@ -911,7 +911,7 @@ struct ngp_sdf {
 	ngp_sdf_options opt{};
 	ngp_aabb aabb{};
 	uint32_t n_triangles = 0;
-	SdfTriangle* tris = nullptr; SdfBvhNode2* nodes = nullptr; int root = 0; float* cdf = nullptr;
+	SdfTriangle* tris = nullptr; SdfBvhNode4* nodes = nullptr; int root = 0; uint32_t stack_entries = 4; float* cdf = nullptr;
 	float* positions = nullptr; float* distances = nullptr; ngp_half* pred = nullptr; uint32_t cap = 0;
 	float* loss_sum = nullptr; uint32_t* iou_counters = nullptr;
 	uint32_t* stab_list = nullptr; uint32_t* stab_count = nullptr; // survivors of the first stab rays (sdf_kernels.hip): cap list entries + cap "escaped" marks
@@ -935,7 +935,7 @@ extern "C" int ngp_sdf_normalize_mesh_host(float* v, uint64_t n_vertices, ngp_aa
 	if (mesh_scale_out) *mesh_scale_out = scale;
 	return 0;
 }
-// returns the depth of the tree (root = 0): the device traversals keep at most depth + 1 nodes on their 30-entry stacks (child references are pushed, the root first)
+// returns the depth of the tree (root = 0): the binary tree the 4-wide device tree is folded from (sdf_flatten_bvh)
 static uint32_t sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvhNode>& nodes, uint32_t leaf_size) {
 	struct Job { int node; size_t begin, end; uint32_t depth; };
 	uint32_t max_depth = 0;
@@ -966,21 +966,41 @@ static uint32_t sdf_build_bvh(std::vector<SdfTriangle>& tris, std::vector<SdfBvh
 	}
 	return max_depth;
 }
-// Device form of the tree (sdf_kernels.hip): every inner node carries the boxes of both children; a child reference is the child's index (inner node) or
-// ~((first triangle << 3) | count) (leaf).  Indexed like `nodes` (the leaves' slots stay unused).  Returns the root's reference.
-static int sdf_flatten_bvh(const std::vector<SdfBvhNode>& nodes, std::vector<SdfBvhNode2>& out) {
-	auto ref_of = [&](int i) { const SdfBvhNode& n = nodes[i]; return n.left < 0 ? ~(int)((((uint32_t)(-n.left - 1)) << 3) | (uint32_t)((-n.right - 1) - (-n.left - 1))) : i; };
-	out.assign(nodes.size(), SdfBvhNode2{});
-	for (size_t i = 0; i < nodes.size(); ++i) {
-		const SdfBvhNode& n = nodes[i];
-		if (n.left < 0) continue;
-		SdfBvhNode2& o = out[i];
-		for (int k = 0; k < 3; ++k) { o.lmin[k] = nodes[n.left].bmin[k]; o.lmax[k] = nodes[n.left].bmax[k]; o.rmin[k] = nodes[n.right].bmin[k]; o.rmax[k] = nodes[n.right].bmax[k]; }
-		o.left = ref_of(n.left); o.right = ref_of(n.right);
+// Device form of the tree (sdf_kernels.hip): 4-wide nodes -- every second level of the binary tree folded away: a node's children are its binary grandchildren (a binary
+// child that is a leaf stays one child).  A child reference is the child's index in `out` (inner node) or ~((first triangle << 3) | count) (leaf); empty slots carry
+// 0x7fffffff and an empty box.  Returns the root's reference; *depth4 = depth of the 4-wide tree.
+static int sdf_flatten_bvh(const std::vector<SdfBvhNode>& nodes, std::vector<SdfBvhNode4>& out, uint32_t* depth4) {
+	auto is_leaf = [&](int i) { return nodes[i].left < 0; };
+	auto leaf_ref = [&](int i) { const SdfBvhNode& n = nodes[i]; return ~(int)((((uint32_t)(-n.left - 1)) << 3) | (uint32_t)((-n.right - 1) - (-n.left - 1))); };
+	out.clear();
+	*depth4 = 0;
+	if (is_leaf(0)) return leaf_ref(0);
+	struct Job { int bin; int slot; uint32_t depth; };
+	out.emplace_back();
+	std::vector<Job> stack{{0, 0, 0u}};
+	while (!stack.empty()) {
+		const Job j = stack.back(); stack.pop_back();
+		*depth4 = std::max(*depth4, j.depth + 1); // (its children -- leaves at least -- sit one level below)
+		int kids[4]; int nk = 0;
+		for (int c : {nodes[j.bin].left, nodes[j.bin].right}) {
+			if (is_leaf(c)) kids[nk++] = c; else { kids[nk++] = nodes[c].left; kids[nk++] = nodes[c].right; }
+		}
+		SdfBvhNode4 o;
+		for (int k = 0; k < 4; ++k) {
+			for (int a = 0; a < 3; ++a) { o.lo[a][k] = INFINITY; o.hi[a][k] = -INFINITY; }
+			o.ref[k] = 0x7fffffff; o.pad[k] = 0;
+		}
+		for (int k = 0; k < nk; ++k) {
+			const SdfBvhNode& c = nodes[kids[k]];
+			for (int a = 0; a < 3; ++a) { o.lo[a][k] = c.bmin[a]; o.hi[a][k] = c.bmax[a]; }
+			if (is_leaf(kids[k])) o.ref[k] = leaf_ref(kids[k]);
+			else { o.ref[k] = (int)out.size(); out.emplace_back(); stack.push_back({kids[k], o.ref[k], j.depth + 1}); }
+		}
+		out[j.slot] = o;
 	}
-	return ref_of(0);
+	return 0;
 }
-constexpr uint32_t SDF_LEAF_SIZE = 4, SDF_MAX_DEPTH = 29; // (sdf_kernels.hip: leaves of <= 4 triangles are fetched in one batch; 30 stack entries)
+constexpr uint32_t SDF_LEAF_SIZE = 4, SDF_MAX_DEPTH4 = 15; // (sdf_kernels.hip: leaves of <= 4 triangles are fetched in one batch; 3 * 15 + 1 = 46 <= 48 stack entries)
 // DiscreteDistribution::build over the surface areas (discrete_distribution.h:21-38) -- of the REORDERED triangles, like the reference
 static void sdf_surface_cdf(const std::vector<SdfTriangle>& tris, std::vector<float>& cdf) {
 	const uint32_t n_triangles = (uint32_t)tris.size();
@@ -1008,9 +1028,10 @@ extern "C" int ngp_host_sdf_signed_distance(const float* triangles_host, uint32_
 	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
 	std::vector<SdfBvhNode> nodes;
 	const uint32_t depth = sdf_build_bvh(tris, nodes, SDF_LEAF_SIZE);
-	REQUIRE(depth <= SDF_MAX_DEPTH && n_triangles < (1u << 28), "ngp_host_sdf_signed_distance: BVH deeper than the traversal stack");
-	std::vector<SdfBvhNode2> nodes2;
-	const int root = sdf_flatten_bvh(nodes, nodes2);
+	(void)depth;
+	std::vector<SdfBvhNode4> nodes2; uint32_t depth4 = 0;
+	const int root = sdf_flatten_bvh(nodes, nodes2, &depth4);
+	REQUIRE(depth4 <= SDF_MAX_DEPTH4 && n_triangles < (1u << 28), "ngp_host_sdf_signed_distance: BVH deeper than the traversal stack");
 	if (triangles_ordered_out) memcpy(triangles_ordered_out, tris.data(), (size_t)n_triangles * sizeof(SdfTriangle));
 	if (cdf_out) { std::vector<float> cdf; sdf_surface_cdf(tris, cdf); memcpy(cdf_out, cdf.data(), cdf.size() * 4); }
 	host_sdf_signed_distance(n, positions_host, distances_inout, nodes2.data(), root, tris.data(), use_upper_bounds);
@@ -1029,16 +1050,19 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	// m_sdf.triangle_bvh->build(triangles_cpu, 8) reorders the triangles; so does this tree (a binary median split down to 4 triangles: the ground truth does not depend on the
 	// tree, the surface samples' triangle order follows it like the reference's follows its own)
 	const uint32_t bvh_depth = sdf_build_bvh(tris, nodes, SDF_LEAF_SIZE);
-	if (bvh_depth > SDF_MAX_DEPTH || n_triangles >= (1u << 28)) { delete t; return fail("ngp_sdf_create: BVH deeper than the device traversal stack (30 entries)"); } // median split: depth = ceil(log2(n / 4))
-	std::vector<SdfBvhNode2> nodes2;
-	t->root = sdf_flatten_bvh(nodes, nodes2);
+	(void)bvh_depth;
+	std::vector<SdfBvhNode4> nodes2; uint32_t depth4 = 0;
+	t->root = sdf_flatten_bvh(nodes, nodes2, &depth4);
+	if (depth4 > SDF_MAX_DEPTH4 || n_triangles >= (1u << 28)) { delete t; return fail("ngp_sdf_create: BVH deeper than the device traversal stack"); } // median split: binary depth = ceil(log2(n / 4)) <= 26, 4-wide depth = ceil of half of it
+	t->stack_entries = 3 * depth4 + 1;
+	if (nodes2.empty()) nodes2.emplace_back(); // (a mesh of <= 4 triangles: the root is a leaf reference, the node array is never read)
 	std::vector<float> cdf;
 	sdf_surface_cdf(tris, cdf);
 	t->cap = std::max<uint32_t>(o->batch_size, 1u << 21); // calculate_iou works in batches of 128^3 = 2^21
 	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes2.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
 		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8) || dev_alloc(&t->stab_list, (size_t)t->cap * 2) || dev_alloc(&t->stab_count, 1)) { delete t; return 1; }
 	HIPCHK(hipMemcpy(t->tris, tris.data(), tris.size() * sizeof(SdfTriangle), hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(t->nodes, nodes2.data(), nodes2.size() * sizeof(SdfBvhNode2), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->nodes, nodes2.data(), nodes2.size() * sizeof(SdfBvhNode4), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(t->loss_sum, 0, 4));
 	HIPCHK(hipMemset(t->stab_list + t->cap, 0, (size_t)t->cap * 4)); // the first stab rays' "escaped" marks
@@ -1063,7 +1087,7 @@ static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only
 	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = t->positions; a.distances = t->distances;
 	launch_sdf_generate_positions(s, a);
 	t->rng.advance((uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull); // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
-	launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->root, t->tris, 1, t->stab_list, t->stab_list + t->cap, t->stab_count);
+	launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->stab_list, t->stab_list + t->cap, t->stab_count);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1101,7 +1125,7 @@ extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distanc
 extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* positions, uint32_t n, float* out) {
 	REQUIRE(t && (n == 0 || (positions && out)), "ngp_sdf_signed_distance: null argument");
 	for (uint32_t done = 0; done < n; done += t->cap) // the survivor list of the stab rays holds t->cap points
-		launch_sdf_signed_distance((hipStream_t)stream, std::min(n - done, t->cap), positions + (size_t)done * 3, out + done, t->nodes, t->root, t->tris, 0, t->stab_list, t->stab_list + t->cap, t->stab_count);
+		launch_sdf_signed_distance((hipStream_t)stream, std::min(n - done, t->cap), positions + (size_t)done * 3, out + done, t->nodes, t->root, t->stack_entries, t->tris, 0, t->stab_list, t->stab_list + t->cap, t->stab_count);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

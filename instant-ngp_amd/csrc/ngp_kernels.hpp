@@ -280,11 +280,13 @@ struct SdfSampleArgs {
 	float* positions; float* distances;
 };
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a);
-// device form of the tree: a node carries both children's boxes; a child reference is an inner node's index (>= 0) or a leaf ~((first triangle << 3) | count), count <= 4
-struct SdfBvhNode2 { float lmin[3], lmax[3], rmin[3], rmax[3]; int left, right; int pad[2]; }; // 64 bytes
-void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds,
-		uint32_t* survivors /* n entries */, uint32_t* escaped /* n entries, zero on entry and on exit */, uint32_t* n_survivors /* one word */);
-void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
+// device form of the tree: 4-wide nodes of one 128-byte line -- the boxes of up to four children (component-major: lo[axis][child]) and their references: an inner node's
+// index (>= 0), a leaf ~((first triangle << 3) | count) with count <= 4, or 0x7fffffff for an empty slot (box [+inf, -inf])
+struct SdfBvhNode4 { float lo[3][4], hi[3][4]; int ref[4]; int pad[4]; };
+static_assert(sizeof(SdfBvhNode4) == 128, "SdfBvhNode4 is one cache line");
+void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries /* 3 * depth + 1 */,
+		const SdfTriangle* tris, int use_upper_bounds, uint32_t* survivors /* n entries */, uint32_t* escaped /* n entries, zero on entry and on exit */, uint32_t* n_survivors /* one word */);
+void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters);
 
 // ---- renderer (render_kernels.hip) ------------------------------------------------------------

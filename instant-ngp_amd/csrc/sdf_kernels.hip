@@ -44,98 +44,113 @@ static __host__ __device__ __forceinline__ float tri_ray_intersect(const SdfTria
 	if (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f || t < 0.0f) t = 3.402823466e+38f;
 	return t;
 }
-// BoundingBox::distance_sq, bounding_box.cuh:228-230
-static __host__ __device__ __forceinline__ float bb_distance_sq(const float* __restrict__ bmin, const float* __restrict__ bmax, f3 p) {
-	const float dx = fmaxf(fmaxf(bmin[0] - p.x, p.x - bmax[0]), 0.f), dy = fmaxf(fmaxf(bmin[1] - p.y, p.y - bmax[1]), 0.f), dz = fmaxf(fmaxf(bmin[2] - p.z, p.z - bmax[2]), 0.f);
-	return dx * dx + dy * dy + dz * dz;
-}
 // ---- traversal (round 4) ----------------------------------------------------------------------------------------------------
-// Both walks are chains of dependent memory round trips (the query points are i.i.d., so a wavefront's lanes diverge from the root on), and the chip has fewer points in
-// flight than lanes: what counts is round trips per step.  Hence
-//   * a node carries the boxes of BOTH children (SdfBvhNode2, 64 bytes, four 16-byte loads issued together): one round trip per inner step instead of two (node, then
-//     its children);
+// Both walks are chains of dependent memory round trips (the query points are i.i.d., so a wavefront's lanes diverge from the root on), and a batch has fewer points
+// than the chip has lanes: what counts is the number of round trips in the slowest lane.  Hence
+//   * 4-wide nodes: a node carries the boxes of its (up to) four children -- the binary median-split tree with every second level folded away -- in exactly one 128-byte
+//     line (SdfBvhNode4, eight 16-byte loads issued together): half the depth of the binary tree, one round trip per inner step (rounds 2-3: node, then its two
+//     children, then the next node);
 //   * a child reference is either an inner node's index (>= 0) or a leaf ~((first triangle << 3) | count) with count <= SDF_LEAF_TRIS = 4: the leaf's triangles are
 //     loaded in one batch (clamped indices, surplus results ignored) -- one round trip per leaf instead of one per triangle behind an early-out branch;
-//   * the node stack -- <= SDF_STACK references (median split: depth = ceil(log2(n / 4)), a depth-first walk of a binary tree keeps at most depth + 1 references) --
-//     lives in LDS on the device, one column per thread (entry i of thread t at [i * 256 + t]: conflict-free), instead of 512 bytes of scratch per thread; on the host
-//     (test hook) it is a local array.
-constexpr int SDF_STACK = 30;
+//   * "while-while": every lane first descends through inner nodes to its next leaf, then the wavefront's leaves are evaluated together -- the long leaf code runs once
+//     per round instead of in every step in which some lane happens to be at a leaf;
+//   * the reference stack (a depth-first walk keeps at most 3 * depth + 1 references of a 4-wide tree) lives in LDS on the device, one column per thread (entry i of
+//     thread t at [i * 256 + t]: conflict-free, sized by the tree's depth at launch), instead of 512 bytes of scratch per thread; on the host (test hook) a local array.
+constexpr int SDF_STACK_MAX = 48; // 3 * 15 + 1: 4-wide depth <= 15 (binary depth <= 29, ngp_sdf_create checks)
 constexpr int SDF_LEAF_TRIS = 4;
-struct SdfLocalStack { int v[SDF_STACK]; __host__ __device__ __forceinline__ int get(int i) const { return v[i]; } __host__ __device__ __forceinline__ void set(int i, int x) { v[i] = x; } };
+constexpr int SDF_DONE = 0x7fffffff;
+struct SdfLocalStack { int v[SDF_STACK_MAX]; __host__ __device__ __forceinline__ int get(int i) const { return v[i]; } __host__ __device__ __forceinline__ void set(int i, int x) { v[i] = x; } };
 struct SdfLdsStack { int* col; __device__ __forceinline__ int get(int i) const { return col[i * 256]; } __device__ __forceinline__ void set(int i, int x) { col[i * 256] = x; } };
 
-// the whole node in four 16-byte loads issued back to back (the child references arrive with the boxes, not in a second round trip when they are pushed)
-static __host__ __device__ __forceinline__ SdfBvhNode2 load_node(const SdfBvhNode2* __restrict__ nodes, int ref) {
+// the whole node (one 128-byte line) in eight 16-byte loads issued back to back
+static __host__ __device__ __forceinline__ SdfBvhNode4 load_node(const SdfBvhNode4* __restrict__ nodes, int ref) {
 	struct alignas(16) Q { uint32_t w[4]; };
 	const Q* q = (const Q*)(nodes + ref);
-	Q v[4];
+	Q v[8];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) v[k] = q[k];
-	SdfBvhNode2 n;
+	for (int k = 0; k < 8; ++k) v[k] = q[k];
+	SdfBvhNode4 n;
 	__builtin_memcpy(&n, v, sizeof(n));
 	return n;
 }
-// closest_triangle(...).second: distance to the nearest triangle, bounded above by sqrt(max_distance_sq).  Near child first; the result is the minimum of
+// ascending sort of four (key, reference) pairs, branch-free (5 compare-exchanges)
+static __host__ __device__ __forceinline__ void sort4(float (&k)[4], int (&r)[4]) {
+#define SDF_CX(i, j) { const bool sw = k[j] < k[i]; const float ka = sw ? k[j] : k[i], kb = sw ? k[i] : k[j]; const int ra = sw ? r[j] : r[i], rb = sw ? r[i] : r[j]; k[i] = ka; k[j] = kb; r[i] = ra; r[j] = rb; }
+	SDF_CX(0, 1) SDF_CX(2, 3) SDF_CX(0, 2) SDF_CX(1, 3) SDF_CX(1, 2)
+#undef SDF_CX
+}
+// BoundingBox::distance_sq of child c
+static __host__ __device__ __forceinline__ float child_distance_sq(const SdfBvhNode4& n, int c, f3 p) {
+	const float dx = fmaxf(fmaxf(n.lo[0][c] - p.x, p.x - n.hi[0][c]), 0.f), dy = fmaxf(fmaxf(n.lo[1][c] - p.y, p.y - n.hi[1][c]), 0.f), dz = fmaxf(fmaxf(n.lo[2][c] - p.z, p.z - n.hi[2][c]), 0.f);
+	return dx * dx + dy * dy + dz * dz; // (an empty slot's box is [+inf, -inf]: +inf)
+}
+// closest_triangle(...).second: distance to the nearest triangle, bounded above by sqrt(max_distance_sq).  Nearest child first; the result is the minimum of
 // tri_distance_sq over every triangle whose boxes are not farther than the running minimum, i.e. independent of the visiting order and of the tree's shape.
 template <class Stack>
-static __host__ __device__ __forceinline__ float bvh_unsigned_distance(f3 p, const SdfBvhNode2* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, float max_distance_sq, Stack& st) {
-	constexpr int DONE = 0x7fffffff;
+static __host__ __device__ __forceinline__ float bvh_unsigned_distance(f3 p, const SdfBvhNode4* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, float max_distance_sq, Stack& st) {
 	int sp = 0, ref = root;
 	float best = max_distance_sq; bool found = false;
-	// "while-while": every lane first descends through inner nodes to its next leaf, then the wavefront's leaves are evaluated together -- the long leaf code runs once per
-	// round instead of in every step in which some lane happens to be at a leaf
 	for (;;) {
-		while (ref >= 0 && ref != DONE) {
-			const SdfBvhNode2 n = load_node(nodes, ref);
-			const float dl = bb_distance_sq(n.lmin, n.lmax, p), dr = bb_distance_sq(n.rmin, n.rmax, p);
-			const bool tl = dl <= best, tr = dr <= best;
-			if (tl & tr) { const bool left_first = dl <= dr; st.set(sp++, left_first ? n.right : n.left); ref = left_first ? n.left : n.right; } // near child next, far child waits
-			else if (tl | tr) ref = tl ? n.left : n.right;
-			else ref = sp > 0 ? st.get(--sp) : DONE; // (a reference that became farther than the best hit while it waited costs one wasted step: its children fail the test)
+		while (ref >= 0 && ref != SDF_DONE) {
+			const SdfBvhNode4 n = load_node(nodes, ref);
+			float d[4]; int r[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) { d[c] = child_distance_sq(n, c, p); r[c] = n.ref[c]; }
+			sort4(d, r);
+			// farther children onto the stack, farthest first, so that the nearer ones are popped first (a reference that became farther than the best hit while it waited
+			// costs one wasted step: its children are inside its box and fail the test)
+			if (d[3] <= best) st.set(sp++, r[3]);
+			if (d[2] <= best) st.set(sp++, r[2]);
+			if (d[1] <= best) st.set(sp++, r[1]);
+			ref = d[0] <= best ? r[0] : (sp > 0 ? st.get(--sp) : SDF_DONE);
 		}
-		if (ref == DONE) break;
+		if (ref == SDF_DONE) break;
 		{
 			const int first = (~ref) >> 3, cnt = (~ref) & 7;
 			SdfTriangle T[SDF_LEAF_TRIS]; // all loads first: one round trip
 #pragma unroll
 			for (int k = 0; k < SDF_LEAF_TRIS; ++k) T[k] = tris[first + (k < cnt ? k : cnt - 1)];
 #pragma unroll
-			for (int k = 0; k < SDF_LEAF_TRIS; ++k) { const float d = tri_distance_sq(T[k], p); const bool better = (k < cnt) & (d <= best); best = better ? d : best; found = found | better; }
+			for (int k = 0; k < SDF_LEAF_TRIS; ++k) { const float dd = tri_distance_sq(T[k], p); const bool better = (k < cnt) & (dd <= best); best = better ? dd : best; found = found | better; }
 		}
 		if (sp == 0) break;
 		ref = st.get(--sp);
 	}
 	return found ? sqrtf(best) : 0.0f; // "No closest triangle found": the reference returns 0 as well (triangle_bvh.cu:562-566)
 }
-// Slab test of a stab ray with the reciprocal direction (six multiplications instead of the six IEEE divisions of BoundingBox::ray_intersect).  Only a conservative
-// filter in front of the exact triangle tests: a box is accepted when [t_enter, t_exit] is non-empty after t_exit has been widened by 4 ulp (covers the rounding of
-// both bounds), t_exit >= 0 (the triangle test rejects t < 0) and t_enter < SDF_MAX_DIST.  fminf / fmaxf drop the NaN of 0 * inf (origin on a face, axis-parallel ray).
-static __host__ __device__ __forceinline__ float bb_ray_entry_inv(const float* __restrict__ bmin, const float* __restrict__ bmax, f3 o, f3 inv) {
-	const float x1 = (bmin[0] - o.x) * inv.x, x2 = (bmax[0] - o.x) * inv.x;
-	const float y1 = (bmin[1] - o.y) * inv.y, y2 = (bmax[1] - o.y) * inv.y;
-	const float z1 = (bmin[2] - o.z) * inv.z, z2 = (bmax[2] - o.z) * inv.z;
+// Slab test of a stab ray against child c with the reciprocal direction (six multiplications instead of the six IEEE divisions of BoundingBox::ray_intersect).  Only a
+// conservative filter in front of the exact triangle tests: a box is accepted when [t_enter, t_exit] is non-empty after t_exit has been widened by 4 ulp (covers the
+// rounding of both bounds), t_exit >= 0 (the triangle test rejects t < 0) and t_enter < SDF_MAX_DIST.  fminf / fmaxf drop the NaN of 0 * inf (origin on a face,
+// axis-parallel ray); an empty slot ([+inf, -inf]) has t_exit < t_enter or NaNs only and is rejected.
+static __host__ __device__ __forceinline__ float child_ray_entry(const SdfBvhNode4& n, int c, f3 o, f3 inv) {
+	const float x1 = (n.lo[0][c] - o.x) * inv.x, x2 = (n.hi[0][c] - o.x) * inv.x;
+	const float y1 = (n.lo[1][c] - o.y) * inv.y, y2 = (n.hi[1][c] - o.y) * inv.y;
+	const float z1 = (n.lo[2][c] - o.z) * inv.z, z2 = (n.hi[2][c] - o.z) * inv.z;
 	const float t_enter = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
 	const float t_exit = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-	return (t_exit >= 0.0f && t_enter <= t_exit * 1.0000005f) ? t_enter : 3.402823466e+38f;
+	return (n.ref[c] != SDF_DONE && t_exit >= 0.0f && t_enter <= t_exit * 1.0000005f) ? t_enter : 3.402823466e+38f;
 }
 // ray_intersect(...).first >= 0: is any triangle hit within SDF_MAX_DIST?  Any-hit, so the order is free: the child the ray enters first is walked first (a hit
 // ends the walk).  `stop` (device: an LDS flag shared by the 32 rays of one point, nullptr elsewhere) ends it from outside; the return value is then meaningless.
 template <class Stack>
-static __host__ __device__ __forceinline__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode2* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, Stack& st, const volatile int* stop) {
-	constexpr int DONE = 0x7fffffff;
+static __host__ __device__ __forceinline__ bool bvh_ray_hits_anything(f3 o, f3 d, const SdfBvhNode4* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, Stack& st, const volatile int* stop) {
 	const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 	int sp = 0, ref = root;
 	for (;;) {
 		if (stop && *stop) return true;
-		while (ref >= 0 && ref != DONE) { // inner nodes, down to this lane's next leaf
-			const SdfBvhNode2 n = load_node(nodes, ref);
-			const float tl = bb_ray_entry_inv(n.lmin, n.lmax, o, inv), tr = bb_ray_entry_inv(n.rmin, n.rmax, o, inv);
-			const bool hl = tl < SDF_MAX_DIST, hr = tr < SDF_MAX_DIST;
-			if (hl & hr) { const bool left_first = tl <= tr; st.set(sp++, left_first ? n.right : n.left); ref = left_first ? n.left : n.right; }
-			else if (hl | hr) ref = hl ? n.left : n.right;
-			else ref = sp > 0 ? st.get(--sp) : DONE;
+		for (uint32_t it = 1; ref >= 0 && ref != SDF_DONE; ++it) { // inner nodes, down to this lane's next leaf
+			if (stop && (it & 7u) == 0u && *stop) return true; // (a long descent of a grazing ray: look at the flag every eighth step)
+			const SdfBvhNode4 n = load_node(nodes, ref);
+			float t[4]; int r[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) { t[c] = child_ray_entry(n, c, o, inv); r[c] = n.ref[c]; }
+			sort4(t, r);
+			if (t[3] < SDF_MAX_DIST) st.set(sp++, r[3]);
+			if (t[2] < SDF_MAX_DIST) st.set(sp++, r[2]);
+			if (t[1] < SDF_MAX_DIST) st.set(sp++, r[1]);
+			ref = t[0] < SDF_MAX_DIST ? r[0] : (sp > 0 ? st.get(--sp) : SDF_DONE);
 		}
-		if (ref == DONE) return false;
+		if (ref == SDF_DONE) return false;
 		{
 			const int first = (~ref) >> 3, cnt = (~ref) & 7;
 			SdfTriangle T[SDF_LEAF_TRIS]; // all loads first: one round trip
@@ -169,7 +184,7 @@ static __host__ __device__ __forceinline__ void stab_offset(uint32_t i, float& o
 	ox = rng.next_float(); oy = rng.next_float();
 }
 // signed_distance_raystab, triangle_bvh.cu:631-650, one point after the other (the host's test hook; the device splits the same functions over two kernels, below)
-static float bvh_signed_distance_raystab_serial(uint32_t i, f3 p, const SdfBvhNode2* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, float max_distance) {
+static float bvh_signed_distance_raystab_serial(uint32_t i, f3 p, const SdfBvhNode4* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, float max_distance) {
 	SdfLocalStack st;
 	const float distance = bvh_unsigned_distance(p, nodes, root, tris, max_distance * max_distance, st);
 	float ox, oy; stab_offset(i, ox, oy);
@@ -234,9 +249,9 @@ __global__ void __launch_bounds__(256) k_sdf_generate_positions(SdfSampleArgs a)
 //                              of the remaining short any-hit walks instead of their sum; the first ray that finishes without a hit raises the point's LDS flag, which
 //                              stops the others and flips the sign.
 // The answer is "does ANY of the 32 rays escape", whatever the order, so the split returns what the serial loop of the reference returns.
-__global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, const float* __restrict__ positions, float* __restrict__ distances, const SdfBvhNode2* __restrict__ nodes, int root,
-		const SdfTriangle* __restrict__ tris, int use_upper_bounds, uint32_t* __restrict__ escaped) {
-	__shared__ int s_stack[SDF_STACK * 256];
+__global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, const float* __restrict__ positions, float* __restrict__ distances,
+		const SdfBvhNode4* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, int use_upper_bounds, uint32_t* __restrict__ escaped) {
+	extern __shared__ int s_stack[]; // stack entries x 256 (launch_sdf_signed_distance)
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
 	if (i >= n) return;
 	SdfLdsStack st; st.col = s_stack + threadIdx.x;
@@ -246,7 +261,9 @@ __global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, con
 		distances[i] = bvh_unsigned_distance(p, nodes, root, tris, max_distance * max_distance, st);
 	} else {
 		float ox, oy; stab_offset(i, ox, oy);
-		if (!bvh_ray_hits_anything(p, fibonacci_dir32(role - 1u, ox, oy), nodes, root, tris, st, nullptr)) escaped[i] = 1u;
+		// The point's mark doubles as the stop flag of its other first rays: an escaping ray that grazes the mesh walks hundreds of nodes (up to ~1200 on armadillo) --
+		// once one ray of the point has escaped, the others' answers are not needed any more.
+		if (!bvh_ray_hits_anything(p, fibonacci_dir32(role - 1u, ox, oy), nodes, root, tris, st, (const volatile int*)(escaped + i))) escaped[i] = 1u;
 	}
 }
 __global__ void __launch_bounds__(256) k_sdf_compact_survivors(uint32_t n, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ survivors, uint32_t* __restrict__ n_survivors) {
@@ -267,9 +284,9 @@ __global__ void __launch_bounds__(256) k_sdf_compact_survivors(uint32_t n, float
 		if (survivor) survivors[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
 	}
 }
-__global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restrict__ positions, float* __restrict__ distances, const SdfBvhNode2* __restrict__ nodes, int root,
+__global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restrict__ positions, float* __restrict__ distances, const SdfBvhNode4* __restrict__ nodes, int root,
 		const SdfTriangle* __restrict__ tris, const uint32_t* __restrict__ survivors, const uint32_t* __restrict__ n_survivors, uint32_t first_rays) {
-	__shared__ int s_stack[SDF_STACK * 256];
+	extern __shared__ int s_stack[]; // stack entries x 256 (launch_sdf_signed_distance)
 	__shared__ int s_escaped[8];
 	const uint32_t n = *n_survivors;
 	const uint32_t grp = threadIdx.x >> 5, k = threadIdx.x & 31u;
@@ -292,7 +309,7 @@ __global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restric
 	}
 }
 // the same functions on the host (test hook; the product never calls it)
-void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds) {
+void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, const SdfTriangle* tris, int use_upper_bounds) {
 	for (uint32_t i = 0; i < n; ++i) {
 		const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
 		distances[i] = bvh_signed_distance_raystab_serial(i, p, nodes, root, tris, use_upper_bounds ? distances[i] : SDF_MAX_DIST);
@@ -312,15 +329,19 @@ __global__ void __launch_bounds__(256) k_sdf_compare_signs(uint32_t n, const flo
 }
 
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a) { if (a.n) hipLaunchKernelGGL(k_sdf_generate_positions, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
-void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode2* nodes, int root, const SdfTriangle* tris, int use_upper_bounds,
-		uint32_t* survivors, uint32_t* escaped, uint32_t* n_survivors) {
+void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries, const SdfTriangle* tris,
+		int use_upper_bounds, uint32_t* survivors, uint32_t* escaped, uint32_t* n_survivors) {
 	if (!n) return;
 	static const uint32_t first_rays = getenv("NGP_SDF_FIRST_RAYS") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_FIRST_RAYS")), 0), 32) : 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel (ablation knob)
+	const uint32_t entries = std::min<uint32_t>(std::max<uint32_t>(stack_entries, 4u), (uint32_t)SDF_STACK_MAX), lds = entries * 256u * 4u; // (<= 48 KiB)
 	(void)hipMemsetAsync(n_survivors, 0, 4, s); // (`escaped` is zero: ngp_sdf_create clears it, k_sdf_compact_survivors leaves it clean)
-	hipLaunchKernelGGL(k_sdf_distance_first_rays, dim3((n + 255) / 256, 1 + first_rays), dim3(256), 0, s, n, positions, distances, nodes, root, tris, use_upper_bounds, escaped);
+	// (Ordering the points along a Morton curve first -- neighbouring lanes then walk nearly the same nodes -- was measured and is SLOWER: 2.7 vs 1.9 ms for the first launch,
+	// profiles/r04_f4_sdf_ground_truth.txt.)
+	hipLaunchKernelGGL(k_sdf_distance_first_rays, dim3((n + 255) / 256, 1 + first_rays), dim3(256), lds, s, n, positions, distances, nodes, root, tris, use_upper_bounds, escaped);
 	hipLaunchKernelGGL(k_sdf_compact_survivors, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, escaped, survivors, n_survivors);
-	// five 30 KiB workgroups fit a CU's LDS: a grid of resident workgroups walks the list (its length is only known on the device)
-	hipLaunchKernelGGL(k_sdf_stab_rays, dim3(std::min<uint32_t>((n + 7) / 8, 256u * 5u)), dim3(256), 0, s, positions, distances, nodes, root, tris, survivors, n_survivors, first_rays);
+	// a grid of resident workgroups walks the survivor list (its length is only known on the device): as many as the stacks let a CU hold
+	const uint32_t per_cu = std::max(1u, std::min(5u, (160u * 1024u) / (lds + 64u)));
+	hipLaunchKernelGGL(k_sdf_stab_rays, dim3(std::min<uint32_t>((n + 7) / 8, 256u * per_cu)), dim3(256), lds, s, positions, distances, nodes, root, tris, survivors, n_survivors, first_rays);
 }
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters) {
 	if (n) hipLaunchKernelGGL(k_sdf_compare_signs, dim3((n + 255) / 256), dim3(256), 0, s, n, ref, (const __half*)model, model_stride, counters);
