@@ -441,8 +441,13 @@ def main():
     t1_bytes = BYTES_PER_SAMPLE_T1 if stash else BYTES_PER_SAMPLE_T1_GATHER
     # algorithmic bytes per launch of the kernels that have a byte model.  Each byte is charged ONCE: the 512-byte gather belongs to K2,
     # the scatter unit (T1 + k_grad_bin + k_grad_accumulate) is charged what it moves itself.
-    per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd+k_grad_bin+k_grad_accumulate": t1_bytes * args.batch,
-                        "k_optimizer": BYTES_PER_PARAM_OPT * n_params.value}
+    # Single-GPU production step: k_grad_accumulate applies the optimizer to the hashed levels in its epilogue, k_optimizer sweeps the MLP + dense levels only -- each kernel is
+    # charged the parameters it updates (38 B each), the step's sum is unchanged.
+    lib.ngp_model_last_sweep_params.restype = C.c_uint64
+    n_sweep = int(lib.ngp_model_last_sweep_params(model)) or n_params.value
+    n_fused = n_params.value - n_sweep
+    per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd+k_grad_bin+k_grad_accumulate": t1_bytes * args.batch + BYTES_PER_PARAM_OPT * n_fused,
+                        "k_optimizer": BYTES_PER_PARAM_OPT * n_sweep}
     if "k_grad_bin+accumulate" in kern and "k_train_fwd_bwd" in kern:
         # the scatter runs in two follow-up kernels of T1: one unit of algorithmic work, one entry of the per-step table
         t1 = kern.pop("k_train_fwd_bwd"); gb = kern.pop("k_grad_bin+accumulate")
@@ -485,7 +490,7 @@ def main():
     step_bytes = BYTES_PER_SAMPLE_FWD * n_inf_avg + t1_bytes * args.batch + BYTES_PER_PARAM_OPT * n_params.value + BYTES_PER_SAMPLE_K3 * n_inf_avg
     whole = {"algorithmic_bytes_per_step": int(step_bytes), "ms_per_step": round(ms_step, 4), "achieved_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
              "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-             "note": "K2 548 B x evaluations + scatter unit (28 + 64 + 8 + 1024) B x batch + optimizer 38 B x parameters + K3/K4 38 B x evaluations; K1 (VALU bound lattice march), the occupancy-grid update and W (MFMA) move no modelled bytes"}
+             "note": "K2 548 B x evaluations + scatter unit (28 + 64 + 8 + 1024) B x batch + optimizer 38 B x parameters (hashed levels: inside k_grad_accumulate's epilogue on one GPU, charged to the scatter unit; MLP + dense levels: k_optimizer) + K3/K4 38 B x evaluations; K1 (VALU bound lattice march), the occupancy-grid update and W (MFMA) move no modelled bytes"}
     flop_step = FLOP_PER_SAMPLE_FWD * n_inf_avg + FLOP_PER_SAMPLE_TRAIN * args.batch
     wg = kern.get("k_wgrad")
     mfma = {"flop_per_step": int(flop_step), "achieved_tflops": round(flop_step / (ms_step * 1e-3) / 1e12, 2), "peak_tflops": MFMA_PEAK_TFLOPS,

@@ -482,6 +482,9 @@ int ngp_profile_read(double* ms_sum_host, uint64_t* launches_host);
 /* 1 if the last training step's backward pass read its encodings from the forward pass's stash (base.json's shape, production kernels) instead of gathering them again:
  * decides which byte model bench.py charges the scatter unit (no reference counterpart: tcnn always re-gathers). */
 int ngp_nerf_uses_k2_stash(ngp_nerf*);
+/* Number of parameters the last ngp_model_optimizer_step swept in k_optimizer itself: all of them, or -- when the step's k_grad_accumulate applied the optimizer to the hashed
+ * levels in its epilogue (single-GPU ngp_nerf_train) -- the MLP and the dense levels only.  For bench.py's byte model of the two kernels (no reference counterpart). */
+uint64_t ngp_model_last_sweep_params(const ngp_model*);
 
 /* ------------------------------------------------------------------ test hooks ----------- */
 /* Not part of the reference's API surface: expose intermediate state to the parity tests. */

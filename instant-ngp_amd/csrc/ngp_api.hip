@@ -242,7 +242,7 @@ struct ngp_model {
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
-	bool adam_fused_pending = false; uint64_t adam_sweep_end = 0; // this step's k_grad_accumulate has already applied the optimizer to the hashed levels: the sweep covers [0, adam_sweep_end) only
+	bool adam_fused_pending = false; uint64_t adam_sweep_end = 0, last_sweep_params = 0; // this step's k_grad_accumulate has already applied the optimizer to the hashed levels: the sweep covers [0, adam_sweep_end) only
 	float* dextra_out = nullptr; // this training step also leaves dL/d(extra dims) per sample here (n x n_extra_dims floats; set by the callers that want it)
 	bool grads_clean = true; // the hash-grid part of `grads` is all zero (after creation / after an optimizer sweep that zeroed it)
 };
@@ -1151,7 +1151,8 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	++m->step; // Adam::step: ++m_current_step
 	AdamArgs a = make_adam_args(m, loss_scale, m->step);
 	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
-	if (m->adam_fused_pending) { a.n_params = m->adam_sweep_end; m->adam_fused_pending = false; } // the hashed levels were updated by this step's k_grad_accumulate (same arguments)
+	if (m->adam_fused_pending) { a.n_params = m->adam_sweep_end; m->adam_fused_pending = false; }
+	m->last_sweep_params = a.n_params; // the hashed levels were updated by this step's k_grad_accumulate (same arguments)
 	{ ProfScope ps(P_OPTIMIZER, (hipStream_t)stream); launch_optimizer_step((hipStream_t)stream, a); }
 	m->grads_clean = a.zero_grid_grads != 0;
 	HIPCHK(hipGetLastError());
@@ -1980,6 +1981,7 @@ extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 }
 extern "C" int ngp_nerf_counter_ptrs(ngp_nerf* t, uint32_t** counters2) { *counters2 = t->sync2; return 0; }
 extern "C" int ngp_nerf_uses_k2_stash(ngp_nerf* t) { return t && t->k2_enc_valid ? 1 : 0; }
+extern "C" uint64_t ngp_model_last_sweep_params(const ngp_model* m) { return m ? m->last_sweep_params : 0; }
 extern "C" int ngp_nerf_get_stats(ngp_nerf* t, void* stream, ngp_nerf_stats* out) {
 	TrainCounters c;
 	HIPCHK(hipMemcpyAsync(&c, t->counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
