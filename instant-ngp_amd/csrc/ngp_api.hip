@@ -141,7 +141,12 @@ extern "C" int ngp_profile_read(double* ms_sum, uint64_t* launches) {
 // step ran 1.3 - 2x longer (+20 us even for one-wavefront kernels): 1.12 ms per step against 0.66 ms with the communicator created after the first steps
 // (profiles/r03_dp_overhead.txt).  NGP_LAZY_STREAMS=1 restores the old order (diagnostic).
 static bool lazy_streams() { static const bool v = getenv("NGP_LAZY_STREAMS") && atoi(getenv("NGP_LAZY_STREAMS")) != 0; return v; }
+static int g_helper_stream_device = -1; // the device the process-wide helper streams belong to (one process per GPU: SURVEY 8e)
 static int create_helper_stream(hipStream_t* st, bool high_priority) {
+	int dev = 0; HIPCHK(hipGetDevice(&dev));
+	if (g_helper_stream_device < 0) g_helper_stream_device = dev;
+	// one process drives one GPU: a model / trainer created with another device current would launch its backward pass on the first device's streams
+	REQUIRE(dev == g_helper_stream_device, "libngp_hip's helper streams belong to the device that was current at ngp_init() / the first model; select the device (hipSetDevice / torch.cuda.set_device) before that and use one process per GPU");
 	if (*st) return 0;
 	if (high_priority) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi)); }
 	else HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));

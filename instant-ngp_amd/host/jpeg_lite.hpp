@@ -19,6 +19,7 @@ struct Huffman {
 	uint8_t values[256], size[257];
 	uint32_t maxcode[18];
 	int delta[17];
+	bool defined = false; // a DHT segment has filled this table (a scan that names an undefined table is rejected: read_sos)
 	bool build(const uint8_t counts[16], const uint8_t* vals, int n_vals) {
 		int k = 0;
 		for (int i = 0; i < 16; ++i) for (int j = 0; j < counts[i]; ++j) { if (k >= 256) return false; size[k++] = (uint8_t)(i + 1); }
@@ -38,6 +39,7 @@ struct Huffman {
 			const int s = size[i];
 			if (s <= 9) { const int c0 = code[i] << (9 - s), m = 1 << (9 - s); for (int j = 0; j < m; ++j) fast[c0 + j] = (uint8_t)i; }
 		}
+		defined = true;
 		return true;
 	}
 };
@@ -75,8 +77,8 @@ public:
 
 private:
 	const uint8_t *buf = nullptr, *end = nullptr, *pos = nullptr;
-	Huffman hdc[4], hac[4];
-	uint16_t dequant[4][64];
+	Huffman hdc[4] = {}, hac[4] = {};
+	uint16_t dequant[4][64] = {};
 	Component comp[3];
 	int n_comp = 0, img_w = 0, img_h = 0, h_max = 1, v_max = 1, mcu_w = 0, mcu_h = 0, mcu_x = 0, mcu_y = 0;
 	int restart_interval = 0, todo = 0, scan_n = 0, order[3] = {0, 0, 0};
@@ -175,6 +177,11 @@ private:
 			order[i] = which;
 		}
 		ss = get8(); se = get8(); const int a = get8(); ah = a >> 4; al = a & 15;
+		for (int i = 0; i < scan_n; ++i) { // every table the scan will decode with must have been defined (corrupt files: clean failure instead of garbage tables)
+			const Component& c = comp[order[i]];
+			const bool needs_dc = !progressive || ss == 0, needs_ac = !progressive || se > 0;
+			if ((needs_dc && ah == 0 && !hdc[c.hd].defined) || (needs_ac && !hac[c.ha].defined)) return false;
+		}
 		if (progressive) { if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return false; }
 		else if (ss != 0 || ah != 0 || al != 0) return false; // baseline: the whole spectrum, no successive approximation
 		return true;
@@ -207,7 +214,7 @@ private:
 		}
 		const uint32_t temp = code_buffer >> 16;
 		int len = 10;
-		for (;; ++len) if (temp < h.maxcode[len]) break;
+		for (; len < 17; ++len) if (temp < h.maxcode[len]) break;
 		if (len == 17) { code_bits -= 16; return -1; }
 		if (len > code_bits) return -1;
 		const int idx = (int)((code_buffer >> (32 - len)) & ((1u << len) - 1u)) + h.delta[len];
@@ -228,6 +235,7 @@ private:
 	}
 	int get_bits(int n) { // n raw bits
 		if (code_bits < n) grow();
+		if (code_bits < n) return 0; // truncated stream (a marker stopped grow())
 		const uint32_t k = (code_buffer << n) | (code_buffer >> (32 - n)), mask = (1u << n) - 1u;
 		code_buffer = k & ~mask;
 		code_bits -= n;
@@ -235,6 +243,7 @@ private:
 	}
 	bool get_bit() {
 		if (code_bits < 1) grow();
+		if (code_bits < 1) return false; // truncated stream
 		const uint32_t k = code_buffer;
 		code_buffer <<= 1; --code_bits;
 		return (k & 0x80000000u) != 0;

@@ -225,3 +225,30 @@ def test_jpeg_reader_survives_corruption(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stderr[-400:])
     n_ok, n_err = map(int, r.stdout.split())
     assert n_ok + n_err == 900
+
+
+def test_jpeg_scan_that_names_an_undefined_huffman_table_is_refused(tmp_path):
+    """a file whose DHT segments are missing (or whose SOS names a table id no DHT defined): the tables are value-initialised and read_sos() refuses the scan -- a clean
+    RuntimeError from read_image instead of decoding through uninitialised tables"""
+    import pyngp as ngp
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    p = str(tmp_path / "ok.jpg")
+    Image.fromarray(rng.integers(0, 255, (40, 56, 3), dtype=np.uint8), "RGB").save(p, quality=80, subsampling=2)
+    data = open(p, "rb").read()
+    assert ngp.read_image(p).shape[:2] == (40, 56)
+    # walk the marker segments up to SOS and drop every DHT (0xFFC4)
+    out, i = bytearray(data[:2]), 2
+    while data[i + 1] != 0xDA:
+        L = (data[i + 2] << 8) | data[i + 3]
+        if data[i + 1] != 0xC4:
+            out += data[i:i + 2 + L]
+        i += 2 + L
+    out += data[i:]
+    bad = str(tmp_path / "no_dht.jpg"); open(bad, "wb").write(out)
+    ngp._set_image_decoder(lambda path: None)  # no fallback decoder: the refusal must surface
+    try:
+        with pytest.raises(RuntimeError):
+            ngp.read_image(bad)
+    finally:
+        ngp._set_image_decoder(ngp._pil_decoder)
