@@ -377,3 +377,25 @@ def test_product_bvh_on_the_host_equals_the_oracle(o, hip_lib):
     assert np.array_equal(_bits(np.abs(mine)), _bits(np.abs(want)))
     off = np.abs(want) > 1e-6
     assert (np.signbit(mine[off]) != np.signbit(want[off])).mean() <= 0.002 and 0.05 < (want < 0).mean() < 0.7
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 4, 5, 9, 17, 33])
+def test_product_bvh_on_tiny_meshes(o, hip_lib, n_tris):
+    """the 4-wide device tree at its corners: a mesh of <= 4 triangles is a single leaf reference (no node is ever read), 5 .. 16 triangles give a root with leaf children and
+    empty slots, 17+ the first inner grandchildren -- the host evaluation of csrc/sdf_kernels.hip against the oracle's brute force"""
+    rs = np.random.default_rng(100 + n_tris)
+    c = rs.uniform(0.3, 0.7, (n_tris, 1, 3))
+    tris = np.ascontiguousarray((c + rs.normal(0, 0.08, (n_tris, 3, 3))).reshape(n_tris, 9).astype(np.float32))
+    n = 600
+    pos = np.ascontiguousarray(rs.uniform(0.05, 0.95, (n, 3)).astype(np.float32))
+    mine = np.zeros(n, np.float32); ordered = np.zeros_like(tris)
+    assert hip_lib.ngp_host_sdf_signed_distance(_fp(tris), n_tris, _fp(pos), n, _fp(mine), 0, _fp(ordered), None) == 0
+    assert sorted(map(bytes, ordered)) == sorted(map(bytes, tris))
+    want = np.zeros(n, np.float32); o.ora_sdf_signed_distance(_fp(ordered), n_tris, _fp(pos), n, None, _fp(want))
+    assert np.array_equal(_bits(np.abs(mine)), _bits(np.abs(want)))
+    assert (np.signbit(mine) != np.signbit(want)).mean() <= 0.005  # (open triangle soup: most rays escape; a grazing ray may differ by a rounding)
+    # upper bounds: a bound below the true distance finds nothing (0), a bound above it changes nothing
+    bound = (np.abs(want) * rs.choice([0.5, 1.001, 3.0], n)).astype(np.float32)
+    mine_b = bound.copy(); assert hip_lib.ngp_host_sdf_signed_distance(_fp(tris), n_tris, _fp(pos), n, _fp(mine_b), 1, None, None) == 0
+    tight = bound < np.abs(want)
+    assert np.all(np.abs(mine_b[tight]) == 0) and np.array_equal(_bits(np.abs(mine_b[~tight])), _bits(np.abs(want[~tight])))
