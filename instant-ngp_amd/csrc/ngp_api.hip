@@ -919,7 +919,9 @@ struct ngp_sdf {
 	SdfTriangle* tris = nullptr; SdfBvhNode4* nodes = nullptr; int root = 0; uint32_t stack_entries = 4; float* cdf = nullptr;
 	float* positions = nullptr; float* distances = nullptr; ngp_half* pred = nullptr; uint32_t cap = 0;
 	float* loss_sum = nullptr; uint32_t* iou_counters = nullptr;
-	uint32_t* stab_list = nullptr; uint32_t* stab_count = nullptr; // survivors of the first stab rays (sdf_kernels.hip): cap list entries + cap "escaped" marks
+	uint32_t* stab_list = nullptr; uint32_t* stab_count = nullptr; // scratch of the ground-truth launches (sdf_kernels.hip, SdfQueryScratch): 6 x cap words
+	void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
+	SdfQueryScratch query() const { return {stab_list, stab_list + cap, stab_count, stab_list + 2 * (size_t)cap, stab_list + 3 * (size_t)cap, stab_list + 4 * (size_t)cap, stab_list + 5 * (size_t)cap, sort_temp, sort_temp_bytes}; }
 	Rng rng; uint32_t training_step = 0;
 };
 // load_mesh's normalisation (testbed_sdf.cu:1380-1410): raw box inflated by 0.5 % of its diagonal, scaled by its largest extent and centred in the unit cube
@@ -1065,7 +1067,7 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	sdf_surface_cdf(tris, cdf);
 	t->cap = std::max<uint32_t>(o->batch_size, 1u << 21); // calculate_iou works in batches of 128^3 = 2^21
 	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes2.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
-		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8) || dev_alloc(&t->stab_list, (size_t)t->cap * 2) || dev_alloc(&t->stab_count, 1)) { delete t; return 1; }
+		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8) || dev_alloc(&t->stab_list, (size_t)t->cap * 6) || dev_alloc((char**)&t->sort_temp, t->sort_temp_bytes = sdf_point_sort_temp_bytes(t->cap)) || dev_alloc(&t->stab_count, 1)) { delete t; return 1; }
 	HIPCHK(hipMemcpy(t->tris, tris.data(), tris.size() * sizeof(SdfTriangle), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->nodes, nodes2.data(), nodes2.size() * sizeof(SdfBvhNode4), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice));
@@ -1077,7 +1079,7 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 extern "C" void ngp_sdf_destroy(ngp_sdf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
-	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, t->sort_temp}) if (p) (void)hipFree(p);
 	delete t;
 }
 // generate_training_samples_sdf: fills positions / distances for `n` samples and advances m_rng like the reference
@@ -1092,7 +1094,7 @@ static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only
 	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = t->positions; a.distances = t->distances;
 	launch_sdf_generate_positions(s, a);
 	t->rng.advance((uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull); // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
-	launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->stab_list, t->stab_list + t->cap, t->stab_count);
+	if (launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->query())) return fail("sdf ground truth: point sort failed");
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -1130,7 +1132,7 @@ extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distanc
 extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* positions, uint32_t n, float* out) {
 	REQUIRE(t && (n == 0 || (positions && out)), "ngp_sdf_signed_distance: null argument");
 	for (uint32_t done = 0; done < n; done += t->cap) // the survivor list of the stab rays holds t->cap points
-		launch_sdf_signed_distance((hipStream_t)stream, std::min(n - done, t->cap), positions + (size_t)done * 3, out + done, t->nodes, t->root, t->stack_entries, t->tris, 0, t->stab_list, t->stab_list + t->cap, t->stab_count);
+		if (launch_sdf_signed_distance((hipStream_t)stream, std::min(n - done, t->cap), positions + (size_t)done * 3, out + done, t->nodes, t->root, t->stack_entries, t->tris, 0, t->query())) return fail("sdf ground truth: point sort failed");
 	HIPCHK(hipGetLastError());
 	return 0;
 }

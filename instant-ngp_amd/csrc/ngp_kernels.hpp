@@ -284,8 +284,18 @@ void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a);
 // index (>= 0), a leaf ~((first triangle << 3) | count) with count <= 4, or 0x7fffffff for an empty slot (box [+inf, -inf])
 struct SdfBvhNode4 { float lo[3][4], hi[3][4]; int ref[4]; int pad[4]; };
 static_assert(sizeof(SdfBvhNode4) == 128, "SdfBvhNode4 is one cache line");
-void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries /* 3 * depth + 1 */,
-		const SdfTriangle* tris, int use_upper_bounds, uint32_t* survivors /* n entries */, uint32_t* escaped /* n entries, zero on entry and on exit */, uint32_t* n_survivors /* one word */);
+// scratch of one ground-truth call over <= cap points (allocated by ngp_sdf_create)
+struct SdfQueryScratch {
+	uint32_t* survivors;   // cap: points none of whose first stab rays escaped
+	uint32_t* escaped;     // cap: per-point mark of the first stab rays, zero on entry and on exit
+	uint32_t* n_survivors; // one word
+	uint32_t* keys; uint32_t* keys_sorted; uint32_t* idx; uint32_t* order; // cap each: (cost class, Morton) keys of the points, identity, and the sorted order
+	void* sort_temp; size_t sort_temp_bytes;
+};
+size_t sdf_point_sort_temp_bytes(uint32_t n);
+int sdf_point_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n);
+int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries /* 3 * depth + 1 */,
+		const SdfTriangle* tris, int use_upper_bounds, const SdfQueryScratch& q);
 void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters);
 

@@ -249,11 +249,26 @@ __global__ void __launch_bounds__(256) k_sdf_generate_positions(SdfSampleArgs a)
 //                              of the remaining short any-hit walks instead of their sum; the first ray that finishes without a hit raises the point's LDS flag, which
 //                              stops the others and flips the sign.
 // The answer is "does ANY of the 32 rays escape", whatever the order, so the split returns what the serial loop of the reference returns.
-__global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, const float* __restrict__ positions, float* __restrict__ distances,
+// (Ablation only, NGP_SDF_POINT_ORDER: the production order is the batch's.)  Sort key of a query point: bit 30 = cost class (a point whose upper bound is large -- the batch's uniform points, bound = the box diagonal -- walks ~5 x more nodes than a
+// near-surface point whose bound is its offset: the classes must not share wavefronts, a wavefront lasts as long as its slowest lane), bits 0..29 = Morton code of the position
+// (10 bits per axis over the unit cube): neighbours along the curve walk nearly the same nodes, so a wavefront's lanes agree on most branches.
+static __device__ __forceinline__ uint32_t spread10(uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v; }
+__global__ void __launch_bounds__(256) k_sdf_point_keys(uint32_t n, const float* __restrict__ positions, const float* __restrict__ upper_bounds /* nullptr: one class */, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t q[3];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) { const float x = positions[(size_t)i * 3 + a]; q[a] = (uint32_t)fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f); } // (NaN -> 0)
+	const uint32_t cls = upper_bounds && upper_bounds[i] > 0.0625f ? 1u : 0u;
+	keys[i] = (cls << 30) | spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+	idx[i] = i;
+}
+__global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, const uint32_t* __restrict__ order, const float* __restrict__ positions, float* __restrict__ distances,
 		const SdfBvhNode4* __restrict__ nodes, int root, const SdfTriangle* __restrict__ tris, int use_upper_bounds, uint32_t* __restrict__ escaped) {
 	extern __shared__ int s_stack[]; // stack entries x 256 (launch_sdf_signed_distance)
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
-	if (i >= n) return;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
+	if (t >= n) return;
+	const uint32_t i = order[t];
 	SdfLdsStack st; st.col = s_stack + threadIdx.x;
 	const f3 p = mk3(positions[(size_t)i * 3], positions[(size_t)i * 3 + 1], positions[(size_t)i * 3 + 2]);
 	if (role == 0) {
@@ -266,15 +281,17 @@ __global__ void __launch_bounds__(256) k_sdf_distance_first_rays(uint32_t n, con
 		if (!bvh_ray_hits_anything(p, fibonacci_dir32(role - 1u, ox, oy), nodes, root, tris, st, (const volatile int*)(escaped + i))) escaped[i] = 1u;
 	}
 }
-__global__ void __launch_bounds__(256) k_sdf_compact_survivors(uint32_t n, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ survivors, uint32_t* __restrict__ n_survivors) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_sdf_compact_survivors(uint32_t n, const uint32_t* __restrict__ order, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ survivors, uint32_t* __restrict__ n_survivors) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	bool survivor = false;
-	if (i < n) {
+	uint32_t i = 0;
+	if (t < n) {
+		i = order[t];
 		survivor = escaped[i] == 0u;
 		escaped[i] = 0u; // clean for the next call
 		if (survivor) distances[i] = -distances[i];
 	}
-	// wave-aggregated append
+	// wave-aggregated append (a wavefront's share of the list keeps the sorted order)
 	const uint64_t m = __ballot(survivor);
 	if (m) {
 		const uint32_t lane = threadIdx.x & 63u;
@@ -329,19 +346,23 @@ __global__ void __launch_bounds__(256) k_sdf_compare_signs(uint32_t n, const flo
 }
 
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a) { if (a.n) hipLaunchKernelGGL(k_sdf_generate_positions, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
-void launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries, const SdfTriangle* tris,
-		int use_upper_bounds, uint32_t* survivors, uint32_t* escaped, uint32_t* n_survivors) {
-	if (!n) return;
+int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries, const SdfTriangle* tris,
+		int use_upper_bounds, const SdfQueryScratch& q) {
+	if (!n) return 0;
 	static const uint32_t first_rays = getenv("NGP_SDF_FIRST_RAYS") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_FIRST_RAYS")), 0), 32) : 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel (ablation knob)
+	// 0: batch order (production); 1: (cost class, Morton) order; 2: Morton order, one class.  Ablation knob: coherent wavefronts measured SLOWER (batch 3.5 -> 4.3 ms, 2^18 uniform points
+	// 3.2 -> 5.6 / 6.2 ms, profiles/r04_f4_sdf_ground_truth.txt v7) -- sorted points make concurrently running wavefronts hammer the same lines.
+	static const int point_order = getenv("NGP_SDF_POINT_ORDER") ? atoi(getenv("NGP_SDF_POINT_ORDER")) : 0;
 	const uint32_t entries = std::min<uint32_t>(std::max<uint32_t>(stack_entries, 4u), (uint32_t)SDF_STACK_MAX), lds = entries * 256u * 4u; // (<= 48 KiB)
-	(void)hipMemsetAsync(n_survivors, 0, 4, s); // (`escaped` is zero: ngp_sdf_create clears it, k_sdf_compact_survivors leaves it clean)
-	// (Ordering the points along a Morton curve first -- neighbouring lanes then walk nearly the same nodes -- was measured and is SLOWER: 2.7 vs 1.9 ms for the first launch,
-	// profiles/r04_f4_sdf_ground_truth.txt.)
-	hipLaunchKernelGGL(k_sdf_distance_first_rays, dim3((n + 255) / 256, 1 + first_rays), dim3(256), lds, s, n, positions, distances, nodes, root, tris, use_upper_bounds, escaped);
-	hipLaunchKernelGGL(k_sdf_compact_survivors, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, escaped, survivors, n_survivors);
+	(void)hipMemsetAsync(q.n_survivors, 0, 4, s); // (`escaped` is zero: ngp_sdf_create clears it, k_sdf_compact_survivors leaves it clean)
+	hipLaunchKernelGGL(k_sdf_point_keys, dim3((n + 255) / 256), dim3(256), 0, s, n, positions, (use_upper_bounds && point_order == 1) ? distances : nullptr, q.keys, point_order ? q.idx : q.order);
+	if (point_order && sdf_point_sort(s, q.sort_temp, q.sort_temp_bytes, q.keys, q.keys_sorted, q.idx, q.order, n)) return 1;
+	hipLaunchKernelGGL(k_sdf_distance_first_rays, dim3((n + 255) / 256, 1 + first_rays), dim3(256), lds, s, n, q.order, positions, distances, nodes, root, tris, use_upper_bounds, q.escaped);
+	hipLaunchKernelGGL(k_sdf_compact_survivors, dim3((n + 255) / 256), dim3(256), 0, s, n, q.order, distances, q.escaped, q.survivors, q.n_survivors);
 	// a grid of resident workgroups walks the survivor list (its length is only known on the device): as many as the stacks let a CU hold
 	const uint32_t per_cu = std::max(1u, std::min(5u, (160u * 1024u) / (lds + 64u)));
-	hipLaunchKernelGGL(k_sdf_stab_rays, dim3(std::min<uint32_t>((n + 7) / 8, 256u * per_cu)), dim3(256), lds, s, positions, distances, nodes, root, tris, survivors, n_survivors, first_rays);
+	hipLaunchKernelGGL(k_sdf_stab_rays, dim3(std::min<uint32_t>((n + 7) / 8, 256u * per_cu)), dim3(256), lds, s, positions, distances, nodes, root, tris, q.survivors, q.n_survivors, first_rays);
+	return 0;
 }
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters) {
 	if (n) hipLaunchKernelGGL(k_sdf_compare_signs, dim3((n + 255) / 256), dim3(256), 0, s, n, ref, (const __half*)model, model_stride, counters);

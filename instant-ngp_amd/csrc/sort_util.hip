@@ -26,4 +26,15 @@ int grid_sample_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_
 	return rocprim::radix_sort_pairs<GridSortConfig>(temp, temp_bytes, idx_in, idx_out, (const GridSamplePos*)pos_in, (GridSamplePos*)pos_out, (size_t)n, begin_bit, end_bit, s) == hipSuccess ? 0 : 1;
 }
 
+// SDF ground truth: the query points of a batch ordered by (cost class, Morton curve) (csrc/sdf_kernels.hip) -- (31-bit key, point index) pairs
+size_t sdf_point_sort_temp_bytes(uint32_t n) {
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs<GridSortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 31u, (hipStream_t)nullptr);
+	return bytes;
+}
+int sdf_point_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n) {
+	if (n == 0) return 0;
+	return rocprim::radix_sort_pairs<GridSortConfig>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u, 31u, s) == hipSuccess ? 0 : 1;
+}
+
 } // namespace ngp
