@@ -47,6 +47,28 @@ REF void ref_k_generate_training_samples(uint32_t n_rays, uint32_t ray_begin, ui
 	}
 	blockIdx.x = 0;
 }
+// the same launch with extra dims (:3089-3096: extra_dims_gpu.data(), n_extra_dims; coords pitched by (7 + n_extra_dims) floats, :3044-3046)
+REF void ref_k_generate_training_samples_extra(uint32_t n_rays, uint32_t ray_begin, uint32_t ray_end, ngp_aabb aabb, uint32_t max_samples, ngp_pcg32 rng,
+		uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out /* (7 + n_extra) floats per sample */,
+		uint32_t n_images, const ngp_image_meta* meta, const ngp_xform* xforms, const uint8_t* bitfield, uint32_t max_mip, int snap, float cone_angle_constant,
+		const float* extra_dims, uint32_t n_extra) {
+	const auto m = META(n_images, meta); const auto x = XFORMS(n_images, xforms);
+	*ray_counter = 0; *numsteps_counter = 0;
+	for (uint32_t i = ray_begin; i < ray_end; ++i) {
+		blockIdx.x = i;
+		generate_training_samples_nerf(n_rays, BB(aabb), max_samples, 0u, RNG(rng), ray_counter, numsteps_counter, ray_indices_out, (Ray*)rays_out, numsteps_out,
+			PitchedPtr<NerfCoordinate>((NerfCoordinate*)coords_out, 1, 0, n_extra * sizeof(float)), n_images, m.data(), x.data(), bitfield, max_mip, false, nullptr, snap != 0, false, cone_angle_constant,
+			Buffer2DView<const vec2>{}, g_cdf_x_cond_y, g_cdf_y, g_cdf_img, g_cdf_res, extra_dims, n_extra);
+	}
+	blockIdx.x = 0;
+}
+// compute_extra_dims_gradient_train_nerf (:1293-1330) as train_nerf_step launches it (:3325-3340): coords_gradient = the network's input gradient, pitched like the coordinates
+REF void ref_k_extra_dims_gradient(uint32_t n_rays, uint32_t n_rays_total, uint32_t rays_counter, float* extra_dims_gradient, uint32_t n_extra, uint32_t n_images,
+		const uint32_t* ray_indices_in, uint32_t* numsteps_in, float* coords_gradient /* (7 + n_extra) floats per row */) {
+	FOR_EACH_THREAD(rays_counter) compute_extra_dims_gradient_train_nerf(n_rays, n_rays_total, &rays_counter, extra_dims_gradient, n_extra, n_images, ray_indices_in, numsteps_in,
+		PitchedPtr<NerfCoordinate>((NerfCoordinate*)coords_gradient, 1, 0, n_extra * sizeof(float)), g_cdf_img);
+	blockIdx.x = 0;
+}
 // compute_loss_kernel_train_nerf (:852-1181) as train_nerf_step launches it (:3171-3228): no envmap, no sharpness, no exposure training, padded_output_width = out_stride
 static float g_depth_lambda = 0.f; static int g_depth_loss_type = NGP_LOSS_L1;
 REF void ref_set_depth_supervision(float lambda, int loss_type) { g_depth_lambda = lambda; g_depth_loss_type = loss_type; }

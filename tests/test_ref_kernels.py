@@ -444,3 +444,70 @@ def test_k1_k3_with_half_and_float_images(ref, ora, image_type):
     ka = _k3(ora, "ora_", ora, sc, a, n_rays, 1 << 19, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_EXPONENTIAL, A.ACT_EXPONENTIAL, 0, 0.1)
     kb = _k3(ref, "ref_", ora, sc, a, n_rays, 1 << 19, net.view(np.uint16), A.LOSS_HUBER, 0, 1, 0, A.ACT_EXPONENTIAL, A.ACT_EXPONENTIAL, 0, 0.1)
     _same_k3(ka, kb, n)
+
+
+# ---- extra (latent / light-direction) dims: the reference's own code for every piece of them that is in its repository --------------------------------------------
+@pytest.mark.parametrize("n_extra", [3, 16])
+def test_k1_with_extra_dims(ref, ora, scene, n_extra):
+    """generate_training_samples_nerf with extra_dims_gpu (testbed_nerf.cu:744, 833, NerfCoordinate::set_with_optional_extra_dims): every sample row = the 7 floats of the
+    plain launch + its ray's image's vector (extra_dims_gpu + img * n), rows pitched by (7 + n) floats -- what the HIP K1 and the oracle-based GPU tests assume"""
+    n_rays, max_samples = 2000, 1 << 18
+    plain = _k1(ora, "ora_", ora, scene, n_rays, max_samples, 0, n_rays, 1, 0.0)
+    extra = np.random.default_rng(5).uniform(-1, 1, (scene["n_img"], n_extra)).astype(np.float32)
+    o = dict(ray_counter=C.c_uint32(), numsteps_counter=C.c_uint32(), ray_indices=np.zeros(n_rays, np.uint32), rays=np.zeros((n_rays, 6), np.float32),
+             numsteps=np.zeros((n_rays, 2), np.uint32), coords=np.full((max_samples, 7 + n_extra), np.nan, np.float32))
+    ref.ref_k_generate_training_samples_extra(n_rays, 0, n_rays, A.scene_aabb(1), max_samples, _rng(ora), C.byref(o["ray_counter"]), C.byref(o["numsteps_counter"]),
+        ptr(o["ray_indices"]), ptr(o["rays"]), ptr(o["numsteps"]), ptr(o["coords"]), scene["n_img"], scene["M"], scene["X"], ptr(scene["bf"]), 0, 1, F(0.0), _fp(extra), n_extra)
+    n = plain["ray_counter"].value
+    assert n > 500 and o["ray_counter"].value == n and o["numsteps_counter"].value == plain["numsteps_counter"].value
+    assert np.array_equal(o["ray_indices"][:n], plain["ray_indices"][:n]) and np.array_equal(o["numsteps"][:n], plain["numsteps"][:n])
+    used = int((plain["numsteps"][:n, 0] + plain["numsteps"][:n, 1]).max())
+    assert np.array_equal(o["coords"][:used, :7].view(np.uint32), plain["coords"][:used].view(np.uint32))
+    # image of a ray: image_idx(i, n_rays, n_rays_total, n_images) = i * n_images / n_rays (nerf_device.cuh:593-599, no cdf)
+    for r in range(0, n, 37):
+        img = int(plain["ray_indices"][r]) * scene["n_img"] // n_rays
+        cnt, base = plain["numsteps"][r]
+        assert np.array_equal(o["coords"][base:base + cnt, 7:], np.broadcast_to(extra[img], (cnt, n_extra)))
+
+
+def test_extra_dims_gradient_kernel(ref, ora):
+    """compute_extra_dims_gradient_train_nerf (testbed_nerf.cu:1293-1330) against the oracle's restatement (oracle/ora_nerf.hpp extra_dims_gradient), bit for bit: float sums in ray
+    and sample order (the CPU stand-in runs one thread after the other, like the oracle)"""
+    rs = np.random.default_rng(11)
+    n_rays, n_img, n_extra = 700, 9, 5
+    counts = rs.integers(0, 12, n_rays).astype(np.uint32)
+    counts[rs.integers(0, n_rays, 40)] = 0  # rays whose samples were all cut: skipped
+    numsteps = np.zeros((n_rays, 2), np.uint32); numsteps[:, 0] = counts; numsteps[:, 1] = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    rows = int(counts.sum())
+    ray_indices = rs.permutation(4 * n_rays)[:n_rays].astype(np.uint32)  # global ray numbers of a batch of 4 n_rays rays
+    grad_rows = np.zeros((rows, 7 + n_extra), np.float32)
+    grad_rows[:, 7:] = rs.normal(0, 1, (rows, n_extra)).astype(np.float32)
+    grad_rows[:, :7] = rs.normal(0, 1, (rows, 7)).astype(np.float32)  # (the position / direction gradients: ignored)
+    want = np.zeros((n_img, n_extra), np.float32)
+    ref.ref_k_extra_dims_gradient(4 * n_rays, 4 * n_rays, n_rays, _fp(want), n_extra, n_img, ptr(ray_indices), ptr(numsteps), _fp(grad_rows))
+    mine = np.zeros((n_img, n_extra), np.float32)
+    dextra = np.ascontiguousarray(grad_rows[:, 7:])
+    ora.ora_extra_dims_gradient(4 * n_rays, n_rays, _fp(mine), n_extra, n_img, ptr(ray_indices), ptr(numsteps), _fp(dextra))
+    assert np.abs(want).min() > 0 and np.array_equal(mine.view(np.uint32), want.view(np.uint32))
+
+
+def test_var_adam_optimizer(ora):
+    """VarAdamOptimizer (include/neural-graphics-primitives/adam_optimizer.h:25-47, the reference's class compiled here) driven as train_nerf drives the per-image latent
+    optimizers (testbed_nerf.cu:2860-2878) against the oracle's var_adam_step, bit for bit over 50 steps with a changing learning rate"""
+    so = os.path.join(ROOT, "oracle", "_ref", "libngpadam_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libngpadam_ref.so not built (needs /root/reference; `make -C oracle ref`)")
+    lib = C.CDLL(so)
+    rs = np.random.default_rng(4)
+    n, steps, loss_scale = 16, 50, 128.0
+    init = rs.uniform(-1, 1, n).astype(np.float32)
+    grads = (rs.normal(0, 1, (steps, n)) * rs.choice([1e-3, 1.0, 50.0], (steps, 1)) * loss_scale).astype(np.float32)
+    grads[7] = 0  # a step without gradient still moves the variables (momentum)
+    lrs = (1e-2 * 0.33 ** (np.arange(steps) // 20)).astype(np.float32)
+    want = np.zeros((steps, n), np.float32)
+    lib.ref_var_adam_steps(n, _fp(init), _fp(grads), _fp(lrs), steps, F(loss_scale), _fp(want))
+    v, m1, m2 = init.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for s_ in range(steps):
+        ora.ora_var_adam_step(n, _fp(v), _fp(np.ascontiguousarray(grads[s_])), _fp(m1), _fp(m2), s_ + 1, F(float(lrs[s_])), F(loss_scale))
+        assert np.array_equal(v.view(np.uint32), want[s_].view(np.uint32)), s_
+    assert np.abs(want[-1] - init).max() > 1e-3
