@@ -453,6 +453,10 @@ int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_hos
  * rendering: set_rendering_extra_dims_from_training_view / set_rendering_extra_dims (testbed_nerf.cu:3685-3735): view >= 0 = that
  *      training view's dims; view < 0 = `values` (n_extra_dims floats; NULL = image 0's, the state after reset_extra_dims). */
 int ngp_nerf_set_extra_dims(ngp_nerf*, const float* values_host, uint32_t n_images);
+/* Training::extra_dims_opt as snapshots carry it (testbed.cu:5311, 5482-5486; adam_optimizer.h to_json / from_json): the per-image VarAdamOptimizers' moments (n_images x
+ * n_extra_dims floats each) and iteration count (one: they step together).  set installs variables, moments and count without resetting anything. */
+int ngp_nerf_get_extra_dims_optimizer(ngp_nerf*, float* first_moment_host, float* second_moment_host, uint32_t* iter, uint32_t n_images);
+int ngp_nerf_set_extra_dims_optimizer(ngp_nerf*, const float* variable_host, const float* first_moment_host, const float* second_moment_host, uint32_t iter, uint32_t n_images);
 /* stand-alone launches of compute_extra_dims_gradient_train_nerf and of the VarAdamOptimizer step over device buffers (test hooks) */
 int ngp_k_extra_dims_gradient(void* stream, uint32_t n_rays_total, uint32_t rays_counter, float* grad_out, uint32_t n_extra, uint32_t n_images,
                               const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows);

@@ -2076,6 +2076,28 @@ extern "C" int ngp_nerf_get_extra_dims(ngp_nerf* t, float* values, uint32_t n_im
 	HIPCHK(hipMemcpy(values, t->extra_dims, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
 	return 0;
 }
+// The per-image optimizers' state (Training::extra_dims_opt, a std::vector<VarAdamOptimizer>: snapshots carry it, testbed.cu:5311 / 5482-5486): first / second moments
+// (n_images x n_extra_dims each) and the iteration count -- one count here, the reference's optimizers all step together.  set: variables, moments and count as they are
+// (no reset), for the first n_images images.
+extern "C" int ngp_nerf_get_extra_dims_optimizer(ngp_nerf* t, float* first_moment, float* second_moment, uint32_t* iter, uint32_t n_images) {
+	REQUIRE(t && first_moment && second_moment && iter && t->n_extra > 0 && n_images <= t->n_images && t->extra_dims, "get_extra_dims_optimizer: no extra dims / too many images");
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(first_moment, t->extra_m, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(second_moment, t->extra_v, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
+	*iter = t->extra_iter;
+	return 0;
+}
+extern "C" int ngp_nerf_set_extra_dims_optimizer(ngp_nerf* t, const float* variable, const float* first_moment, const float* second_moment, uint32_t iter, uint32_t n_images) {
+	REQUIRE(t && variable && first_moment && second_moment && t->n_extra > 0 && n_images <= t->n_images && t->extra_dims, "set_extra_dims_optimizer: no extra dims / too many images");
+	invalidate_k1(t);
+	HIPCHK(hipDeviceSynchronize());
+	const size_t bytes = (size_t)n_images * t->n_extra * 4;
+	HIPCHK(hipMemcpy(t->extra_dims, variable, bytes, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->extra_m, first_moment, bytes, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(t->extra_v, second_moment, bytes, hipMemcpyHostToDevice));
+	t->extra_iter = iter;
+	return 0;
+}
 extern "C" int ngp_nerf_get_extra_dims_gradient(ngp_nerf* t, float* values, uint32_t n_images) { // the last step's (loss-scaled) per-image gradient: test hook
 	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->n_images && t->extra_grad, "get_extra_dims_gradient: no extra dims / too many images");
 	HIPCHK(hipDeviceSynchronize());

@@ -1272,7 +1272,26 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	const ngp_nerf_stats st = stats();
 	Value jn = jobj();
 	jn.set("aabb_scale", jnum(nerf.training.dataset.aabb_scale));
-	{ Value e; e.type = Value::Array; jn.set("cam_pos_offset", e); jn.set("cam_rot_offset", e); jn.set("extra_dims_opt", e); } // camera / extra-dims optimisation is not part of this build
+	{ Value e; e.type = Value::Array; jn.set("cam_pos_offset", e); jn.set("cam_rot_offset", e); } // camera optimisation is not part of this build
+	{ // snapshot["nerf"]["extra_dims_opt"] = m_nerf.training.extra_dims_opt (testbed.cu:5311): one VarAdamOptimizer per image (adam_optimizer.h:72-81)
+		Value arr; arr.type = Value::Array;
+		const uint32_t ne = nerf.training.dataset.n_extra_dims();
+		const uint32_t n_img = ne ? (uint32_t)std::min<size_t>(nerf.training.dataset.n_images, nerf.training.n_images_for_training > 0 ? (size_t)nerf.training.n_images_for_training : nerf.training.dataset.n_images) : 0u;
+		if (ne && n_img) {
+			std::vector<float> var((size_t)n_img * ne), m1(var.size()), m2(var.size()); uint32_t iter = 0;
+			NGP_CHECK(ngp_nerf_get_extra_dims(m_nerf, var.data(), n_img));
+			NGP_CHECK(ngp_nerf_get_extra_dims_optimizer(m_nerf, m1.data(), m2.data(), &iter, n_img));
+			const float lr = ngp_model_learning_rate(m_model); // set_learning_rate(m_optimizer->learning_rate()) before every step (testbed_nerf.cu:2874)
+			for (uint32_t i = 0; i < n_img; ++i) {
+				Value o = jobj();
+				o.set("iter", jnum(iter)); o.set("first_moment", jvec(m1.data() + (size_t)i * ne, ne)); o.set("second_moment", jvec(m2.data() + (size_t)i * ne, ne));
+				o.set("variable", jvec(var.data() + (size_t)i * ne, ne));
+				o.set("learning_rate", jnum(iter ? lr : 1e-4f)); o.set("epsilon", jnum(1e-8f)); o.set("beta1", jnum(0.9f)); o.set("beta2", jnum(0.99f));
+				arr.arr.push_back(o);
+			}
+		}
+		jn.set("extra_dims_opt", arr);
+	}
 	Value rgb = jobj(); rgb.set("rays_per_batch", jnum(st.rays_per_batch)); rgb.set("measured_batch_size", jnum(st.measured_batch_size));
 	rgb.set("measured_batch_size_before_compaction", jnum(st.measured_batch_size_before_compaction));
 	jn.set("rgb", rgb);
@@ -1387,6 +1406,7 @@ void Testbed::load_snapshot(const std::string& path) {
 			d.paths.push_back(jd["paths"].is_array() && i < jd["paths"].size() ? jd["paths"].at(i).s : std::string());
 		}
 		d.n_images = n;
+		d.n_extra_learnable_dims = (uint32_t)jd.num("n_extra_learnable_dims", 0); // from_json(NerfDataset), json_binding.h:190
 		nerf.training.dataset = std::move(d);
 		mode = ETestbedMode::Nerf;
 		load_nerf_post();
@@ -1417,6 +1437,21 @@ void Testbed::load_snapshot(const std::string& path) {
 		for (uint64_t i = 0; i < gf; ++i) { uint16_t h; memcpy(&h, &gb.bin[i * 2], 2); grid[i] = f16_to_f32(h); }
 		NGP_CHECK(ngp_nerf_set_density_grid_host(m_nerf, nullptr, grid.data(), grid.size()));
 	} else if (gb.type == Value::Binary && !gb.bin.empty()) throw std::runtime_error{"Incompatible number of grid cascades."};
+	{ // m_nerf.training.extra_dims_opt = snapshot["nerf"]["extra_dims_opt"]; update_extra_dims() (testbed.cu:5482-5486)
+		const Value& eo = jn["extra_dims_opt"];
+		const uint32_t ne = nerf.training.dataset.n_extra_dims();
+		if (ne && eo.is_array() && eo.size() > 0) {
+			const uint32_t n_up = (uint32_t)std::min<size_t>(nerf.training.dataset.n_images, nerf.training.n_images_for_training > 0 ? (size_t)nerf.training.n_images_for_training : nerf.training.dataset.n_images);
+			const uint32_t n_img = (uint32_t)std::min<size_t>(eo.size(), n_up);
+			std::vector<float> var((size_t)n_img * ne), m1(var.size()), m2(var.size());
+			for (uint32_t i = 0; i < n_img; ++i) {
+				const Value& o = eo.at(i);
+				if (o["variable"].size() != ne || o["first_moment"].size() != ne || o["second_moment"].size() != ne) throw std::runtime_error{"Snapshot extra_dims_opt does not match the dataset's extra dims."};
+				for (uint32_t k = 0; k < ne; ++k) { var[(size_t)i * ne + k] = (float)o["variable"].at(k).n; m1[(size_t)i * ne + k] = (float)o["first_moment"].at(k).n; m2[(size_t)i * ne + k] = (float)o["second_moment"].at(k).n; }
+			}
+			NGP_CHECK(ngp_nerf_set_extra_dims_optimizer(m_nerf, var.data(), m1.data(), m2.data(), (uint32_t)eo.at(0).num("iter", 0), n_img));
+		}
+	}
 	training_step = (uint32_t)snap.num("training_step", 0);
 	loss = (float)snap.num("loss", 0.0);
 	NGP_CHECK(ngp_nerf_set_training_step(m_nerf, training_step));

@@ -463,19 +463,73 @@ def test_training_from_a_dataset_handed_over_in_memory(scene_dir):
     assert 0 < l_disk < 0.01 and 0 < l_mem < 0.01 and abs(l_mem - l_disk) < 0.5 * max(l_disk, l_mem) + 1e-3, (l_disk, l_mem)
 
 
-@pytest.mark.gpu
-def test_training_with_per_image_latents(scene_dir):
-    """A transforms.json with `n_extra_learnable_dims` (nerf_loader.cu:482-483): the network's direction encoding takes 3 + n dims (nerf_network.h:84), every image owns a
-    vector that trains with the network (testbed_nerf.cu:2743-2750, 2860-2878, 3325-3340), a frame is rendered with one vector (get_rendering_extra_dims, :3685-3707)."""
-    ngp = _ngp()
+def _latent_scene(scene_dir, n_extra=4):
+    """a copy of the synthetic scene whose transforms_train.json asks for learnable per-image dims"""
     import shutil
     d = tempfile.mkdtemp(prefix="ngp_scene_latents_")
     for f in os.listdir(scene_dir):
         src = os.path.join(scene_dir, f)
         (shutil.copytree if os.path.isdir(src) else shutil.copy)(src, os.path.join(d, f))
     doc = json.load(open(os.path.join(d, "transforms_train.json")))
-    doc["n_extra_learnable_dims"] = 4
+    doc["n_extra_learnable_dims"] = n_extra
     json.dump(doc, open(os.path.join(d, "transforms_train.json"), "w"))
+    return d
+
+
+@pytest.mark.gpu
+def test_snapshot_carries_the_latent_optimizers(scene_dir):
+    """snapshot["nerf"]["extra_dims_opt"] (testbed.cu:5311, 5482-5486): one VarAdamOptimizer per image -- iter, both moments, the variable, the hyperparameters
+    (adam_optimizer.h:72-95) -- written as nlohmann would write them, read back into a fresh Testbed, and the optimizers carry on where they stopped"""
+    import zlib
+    import msgpack
+    ngp = _ngp()
+    d = _latent_scene(scene_dir)
+    t = ngp.Testbed()
+    t.load_training_data(os.path.join(d, "transforms_train.json"))
+    t.reload_network_from_file("")
+    t.shall_train = True
+    t.training_batch_size = 1 << 16
+    while t.frame():
+        if t.training_step >= 30:
+            break
+    n = t.nerf.training.dataset.n_images
+    e = [np.array(t.nerf.training.get_extra_dims(i), np.float32) for i in range(n)]
+    snap = os.path.join(tempfile.mkdtemp(), "latents.ingp")
+    t.save_snapshot(snap, True)
+    doc = msgpack.unpackb(zlib.decompress(open(snap, "rb").read()), raw=False)
+    eo = doc["snapshot"]["nerf"]["extra_dims_opt"]
+    assert len(eo) == n and doc["snapshot"]["nerf"]["dataset"]["n_extra_learnable_dims"] == 4
+    for i, o in enumerate(eo):
+        assert o["iter"] == 30 and abs(o["epsilon"] - 1e-8) < 1e-12 and abs(o["beta1"] - 0.9) < 1e-6 and abs(o["beta2"] - 0.99) < 1e-6 and o["learning_rate"] > 0
+        assert np.array_equal(np.array(o["variable"], np.float32), e[i]) and len(o["first_moment"]) == 4 and len(o["second_moment"]) == 4
+        assert np.abs(o["first_moment"]).max() > 0 and np.min(o["second_moment"]) >= 0 and np.max(o["second_moment"]) > 0
+    t2 = ngp.Testbed()
+    t2.load_training_data(os.path.join(d, "transforms_train.json"))
+    t2.training_batch_size = 1 << 16  # (before the trainer exists: the batch size is fixed at its creation)
+    t2.load_snapshot(snap)
+    assert t2.training_step == 30
+    e2 = [np.array(t2.nerf.training.get_extra_dims(i), np.float32) for i in range(n)]
+    assert all(np.array_equal(a, b) for a, b in zip(e, e2))
+    t2.shall_train = True
+    t2.frame()
+    assert t2.training_step == 31
+    snap2 = os.path.join(os.path.dirname(snap), "latents_31.ingp")
+    t2.save_snapshot(snap2, True)
+    eo2 = msgpack.unpackb(zlib.decompress(open(snap2, "rb").read()), raw=False)["snapshot"]["nerf"]["extra_dims_opt"]
+    assert all(o["iter"] == 31 for o in eo2), "the optimizers continue from the restored iteration count (debiasing factors)"
+    e3 = [np.array(o["variable"], np.float32) for o in eo2]
+    assert all(np.abs(a - b).max() > 0 for a, b in zip(e2, e3))
+    # the step from restored moments is NOT the step from zero moments: |delta| of a first step would be ~ lr (debiasing factor 1), a 31st step with warm moments is smaller on average
+    step = np.mean([np.abs(a - b).mean() for a, b in zip(e2, e3)])
+    assert step < 0.9 * eo2[0]["learning_rate"], (step, eo2[0]["learning_rate"])
+
+
+@pytest.mark.gpu
+def test_training_with_per_image_latents(scene_dir):
+    """A transforms.json with `n_extra_learnable_dims` (nerf_loader.cu:482-483): the network's direction encoding takes 3 + n dims (nerf_network.h:84), every image owns a
+    vector that trains with the network (testbed_nerf.cu:2743-2750, 2860-2878, 3325-3340), a frame is rendered with one vector (get_rendering_extra_dims, :3685-3707)."""
+    ngp = _ngp()
+    d = _latent_scene(scene_dir)
     t = ngp.Testbed()
     t.load_training_data(os.path.join(d, "transforms_train.json"))
     t.reload_network_from_file("")
