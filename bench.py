@@ -288,6 +288,93 @@ def run_fox_leg(lib, args):
     return out
 
 
+def _median_ms(fn, reps=7):
+    """median HIP-event time of fn() on torch's current stream == the stream the library launches on when handed stream 0 (the legacy default stream both sides use here)"""
+    fn(); torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    return float(np.median(ms))
+
+
+def run_image_leg(lib):
+    """BASELINE.json config 0 on the GPU (testbed_image.cu:231-302 train_image + optimizer step): data/image/albert.exr (1024^2 RGBA float, staged under _ref_data/), 2-D HashGrid
+    L = 16 F = 2 T = 2^19 (every level dense), MLP 2 x 64, batch 65,536 stratified pixels per step.  Untimed: EXR decode, upload, 100 steps.  Timed: 7 x 50 steps, median."""
+    exr = os.path.join(ROOT, "_ref_data", "data", "image", "albert.exr")
+    if not os.path.exists(exr):
+        return {"skipped": "_ref_data/data/image/albert.exr not staged (tools/stage_reference_data.py copies it from /root/reference at build time)"}
+    import pyngp
+    from common import ptr
+    img = np.ascontiguousarray(pyngp.read_exr(exr))
+    h, w = img.shape[:2]
+    cfg = A.image_encmlp_config(image_resolution=max(w, h))
+    hh = C.c_void_p(); A.check(lib, lib.ngp_encmlp_create(C.byref(cfg), C.c_uint64(1337), C.byref(hh)))
+    n_params, n_mlp = C.c_uint64(), C.c_uint64(); lib.ngp_encmlp_n_params(hh, C.byref(n_params), C.byref(n_mlp))
+    o = A.default_image_options()
+    t = C.c_void_p(); A.check(lib, lib.ngp_image_create(hh, ptr(img), A.IMAGE_FLOAT, w, h, C.byref(o), C.byref(t)))
+    B = int(o.batch_size)
+    mse0 = C.c_float(); A.check(lib, lib.ngp_image_mse(t, 0, C.byref(mse0)))
+    A.check(lib, lib.ngp_image_train(t, None, 100)); torch.cuda.synchronize()
+    n = 50
+    ms = _median_ms(lambda: A.check(lib, lib.ngp_image_train(t, None, n))) / n
+    mse = C.c_float(); A.check(lib, lib.ngp_image_mse(t, 0, C.byref(mse)))
+    # algorithmic bytes of one step (the image model's analogue of SURVEY 8d): per pixel 8 (uv) + 16 levels x 4 corners x 4 B gathered + the same entries as read-modify-write
+    # scatter (x 2) + 12 (target) ; per parameter 38 (optimizer)
+    step_bytes = B * (8 + 256 + 512 + 12) + BYTES_PER_PARAM_OPT * n_params.value
+    out = {"workload": f"Image data/image/albert.exr ({w}x{h} RGBA f32), 2-D HashGrid L=16 F=2 T=2^19 + MLP 2x64, batch {B} pixels per step (BASELINE.json configs[0] on the GPU)",
+           "steps": 7 * n, "ms_per_step": round(ms, 4), "samples_per_s": B / ms * 1e3, "n_params": int(n_params.value),
+           "algorithmic_bytes_per_step": int(step_bytes), "achieved_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "mse_start": mse0.value, "mse_after_450_steps": mse.value, "psnr_db_after_450_steps": (round(-10 * math.log10(mse.value), 2) if mse.value > 0 else None)}
+    lib.ngp_image_destroy(t); lib.ngp_encmlp_destroy(hh)
+    return out
+
+
+def run_sdf_leg(lib):
+    """BASELINE.json config 4 (testbed_sdf.cu:1578-1631 train_sdf, :1449-1520 generate_training_samples_sdf, triangle_bvh.cu:631-660 the ray-stab ground truth): data/sdf/armadillo.obj
+    (99,976 triangles, staged under _ref_data/), configs/sdf/base.json (3-D HashGrid L = 16 F = 2 T = 2^19, MLP 2 x 64, MAPE), batch 2^18 points per step.  Untimed: OBJ parse, BVH build,
+    50 steps.  Timed: 7 x 20 whole steps (sample generation + ground truth + forward / backward + optimizer), and -- on its own -- the ground truth of the half batch that goes through the BVH."""
+    obj = os.path.join(ROOT, "_ref_data", "data", "sdf", "armadillo.obj")
+    if not os.path.exists(obj):
+        return {"skipped": "_ref_data/data/sdf/armadillo.obj not staged (tools/stage_reference_data.py copies it from /root/reference at build time)"}
+    import pyngp
+    from common import ptr
+    tris = np.ascontiguousarray(pyngp.read_obj(obj))
+    verts = tris.reshape(-1, 3).copy()
+    box = A.Aabb(); scale = C.c_float()
+    A.check(lib, lib.ngp_sdf_normalize_mesh_host(ptr(verts), C.c_uint64(len(verts)), C.byref(box), C.byref(scale)))
+    tn = np.ascontiguousarray(verts.reshape(-1, 3, 3))
+    cfg = A.sdf_encmlp_config()
+    hh = C.c_void_p(); A.check(lib, lib.ngp_encmlp_create(C.byref(cfg), C.c_uint64(1337), C.byref(hh)))
+    n_params, n_mlp = C.c_uint64(), C.c_uint64(); lib.ngp_encmlp_n_params(hh, C.byref(n_params), C.byref(n_mlp))
+    o = A.default_sdf_options()
+    t = C.c_void_p(); A.check(lib, lib.ngp_sdf_create(hh, ptr(tn), len(tn), box, C.byref(o), C.byref(t)))
+    B = int(o.batch_size)
+    A.check(lib, lib.ngp_sdf_train(t, None, 50)); torch.cuda.synchronize()
+    n = 20
+    ms = _median_ms(lambda: A.check(lib, lib.ngp_sdf_train(t, None, n))) / n
+    loss = C.c_float(); A.check(lib, lib.ngp_sdf_loss(t, None, C.byref(loss)))
+    # the ground truth alone: the near-surface 3/8 + uniform 1/8 of the last batch are the points generate_training_samples_sdf hands to the BVH (the 4/8 on the surface have distance 0)
+    pp, dp = C.c_void_p(), C.c_void_p(); lib.ngp_sdf_batch_ptrs(t, C.byref(pp), C.byref(dp))
+    n_exact = B // 8 * 4
+    n_bvh = B - n_exact
+    dist_out = torch.zeros(n_bvh, dtype=torch.float32, device="cuda")
+    pos_ptr = C.c_void_p(pp.value + n_exact * 12)
+    ms_gt = _median_ms(lambda: A.check(lib, lib.ngp_sdf_signed_distance(t, None, pos_ptr, n_bvh, C.c_void_p(dist_out.data_ptr()))))
+    iou = C.c_double(); A.check(lib, lib.ngp_sdf_iou(t, 1 << 18, C.byref(iou)))
+    step_bytes = B * (12 + 512 + 1024 + 4) + BYTES_PER_PARAM_OPT * n_params.value   # per point 12 (position) + 16 levels x 8 corners x 4 B gathered + RMW scatter + 4 (distance); 38 per parameter
+    out = {"workload": f"SDF data/sdf/armadillo.obj ({len(tn)} triangles), configs/sdf/base.json (3-D HashGrid L=16 F=2 T=2^19 + MLP 2x64, MAPE), batch {B} points per step (BASELINE.json configs[4])",
+           "steps": 7 * n, "ms_per_step": round(ms, 4), "samples_per_s": B / ms * 1e3,
+           "ms_ground_truth_alone": round(ms_gt, 4), "ground_truth_points": n_bvh, "inside_fraction": round(float((dist_out < 0).float().mean().item()), 4),
+           "ms_rest_of_step": round(ms - ms_gt, 4),
+           "split_note": "ground truth = unsigned BVH distance + up to 32 stab rays for the near-surface and uniform half of a batch, timed on its own on the last batch's points (without the trainer's upper bounds, which only prune more); rest = step - ground truth: sample generation, fused forward / backward, record-list scatter, optimizer",
+           "n_params": int(n_params.value), "algorithmic_bytes_per_step": int(step_bytes), "achieved_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+           "frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss_mape": loss.value, "iou_after_190_steps": round(iou.value, 4)}
+    lib.ngp_sdf_destroy(t); lib.ngp_encmlp_destroy(hh)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,6 +388,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fox-leg", action="store_true", help="skip the secondary data/nerf/fox leg of the default line")
+    ap.add_argument("--no-f4-legs", action="store_true", help="skip the image (BASELINE.json configs[0]) and SDF (configs[4]) legs of the default line")
     ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--eval-views", type=int, default=4, help="views rendered (untimed) for PSNR, run.py --test_transforms procedure")
     ap.add_argument("--eval-res", type=int, default=400)
@@ -533,6 +621,17 @@ def main():
         except Exception as e:  # the capture is staged from /root/reference at build time; a box without it still reports the headline
             fox_leg = {"skipped": str(e)[:200]}
 
+    f4_legs = {}
+    if rank == 0 and world == 1 and args.scene == "synthetic" and not args.no_f4_legs:
+        sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd", "host"))
+        for name, fn in (("image", run_image_leg), ("sdf", run_sdf_leg)):
+            t_leg = time.perf_counter()
+            try:
+                f4_legs[name] = fn(lib)
+            except Exception as e:  # a leg that cannot run (data not staged, pyngp not built) never costs the headline
+                f4_legs[name] = {"skipped": str(e)[:200]}
+            f4_legs[name]["leg_wall_seconds"] = round(time.perf_counter() - t_leg, 2)
+
     ab = None
     if rank == 0 and world == 1 and args.ab_psnr:
         ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[args.ab_seed0 + i for i in range(max(args.ab_seeds, 1))])
@@ -559,7 +658,7 @@ def main():
                        **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {}),
                        **({"ab_psnr": ab} if ab else {})},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            **({"legs": {"fox": fox_leg}} if fox_leg else {}),
+            **({"legs": {**({"fox": fox_leg} if fox_leg else {}), **f4_legs}} if (fox_leg or f4_legs) else {}),
         }
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()

@@ -448,15 +448,24 @@ int ngp_nerf_render(ngp_nerf*, void* stream, const ngp_render_params* params_hos
  * NerfCoordinate of the image's rays (testbed_nerf.cu:718-744, 833) and, when optimize_extra_dims is on, trained by one
  * VarAdamOptimizer per image (adam_optimizer.h:27-47; testbed_nerf.cu:2743-2750, 2860-2878, 3325-3340).
  * set: Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683) -- the host computes the initial values (warped light directions
- *      or uniform random latents), this installs them and resets the optimizers; n_images must equal the dataset's.
- * get: Training::get_extra_dims_cpu (testbed_nerf.cu:1862-1877) for the first n_images images.
+ *      or uniform random latents) for EVERY image of the dataset (n_images >= the count handed to ngp_nerf_set_dataset_*, which is
+ *      n_images_for_training: images that join the training set later find their initial values in place, getters and snapshots cover
+ *      the whole dataset); this installs them, resets the optimizers and keeps a copy of image 0's vector as the default rendering dims.
+ * get: Training::get_extra_dims_cpu (testbed_nerf.cu:1862-1877) for the first n_images images of the dataset.
  * rendering: set_rendering_extra_dims_from_training_view / set_rendering_extra_dims (testbed_nerf.cu:3685-3735): view >= 0 = that
- *      training view's dims; view < 0 = `values` (n_extra_dims floats; NULL = image 0's, the state after reset_extra_dims). */
+ *      training view's current dims; view < 0 = `values` (n_extra_dims floats; NULL = the copy of image 0's INITIAL dims taken by
+ *      ngp_nerf_set_extra_dims, the state after reset_extra_dims, :3679-3682).
+ * light dir: Nerf::light_dir + NerfDataset::has_light_dirs -- with light directions in the dataset get_rendering_extra_dims overwrites the
+ *      first three rendering dims with warp_direction(normalize(light_dir)) (:3697-3706; default light_dir (0.5, 0.5, 0.5)). */
 int ngp_nerf_set_extra_dims(ngp_nerf*, const float* values_host, uint32_t n_images);
+int ngp_nerf_set_light_dir(ngp_nerf*, int has_light_dirs, const float light_dir[3]);
 /* Training::extra_dims_opt as snapshots carry it (testbed.cu:5311, 5482-5486; adam_optimizer.h to_json / from_json): the per-image VarAdamOptimizers' moments (n_images x
- * n_extra_dims floats each) and iteration count (one: they step together).  set installs variables, moments and count without resetting anything. */
-int ngp_nerf_get_extra_dims_optimizer(ngp_nerf*, float* first_moment_host, float* second_moment_host, uint32_t* iter, uint32_t n_images);
-int ngp_nerf_set_extra_dims_optimizer(ngp_nerf*, const float* variable_host, const float* first_moment_host, const float* second_moment_host, uint32_t iter, uint32_t n_images);
+ * n_extra_dims floats each), every optimizer's iteration count (n_images values: an image that joined the training set later has stepped less often) and the learning rate
+ * the last step used (set_learning_rate(m_optimizer->learning_rate()) before every step, testbed_nerf.cu:2874; 1e-4, the class's default, before the first).
+ * set installs variables, moments and counts without resetting anything. */
+int ngp_nerf_get_extra_dims_optimizer(ngp_nerf*, float* first_moment_host, float* second_moment_host, uint32_t* iter_host /* n_images */, uint32_t n_images);
+int ngp_nerf_set_extra_dims_optimizer(ngp_nerf*, const float* variable_host, const float* first_moment_host, const float* second_moment_host, const uint32_t* iter_host /* n_images */, uint32_t n_images);
+float ngp_nerf_extra_dims_learning_rate(const ngp_nerf*);
 /* stand-alone launches of compute_extra_dims_gradient_train_nerf and of the VarAdamOptimizer step over device buffers (test hooks) */
 int ngp_k_extra_dims_gradient(void* stream, uint32_t n_rays_total, uint32_t rays_counter, float* grad_out, uint32_t n_extra, uint32_t n_images,
                               const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows);
@@ -523,6 +532,9 @@ int ngp_debug_set_train_mode(int mode);
 int ngp_debug_set_depth_supervision(float depth_supervision_lambda, int depth_loss_type);
 /* Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only: CDFs (device; null = uniform) and the error map K3 splats into (device; null = none). */
 int ngp_debug_set_error_sampling(const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t cdf_res[2], float* error_map, const int32_t error_map_res[2]);
+/* Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only: the per-image extra dims (extra_dims_gpu, testbed_nerf.cu:718-719, 744, 833; device, n_images x n_extra
+ * floats) that K1 copies behind every NerfCoordinate; both kernels' coords rows then are 7 + n_extra floats (PitchedPtr stride, testbed_nerf.cu:3010-3011).  n_extra = 0: off. */
+int ngp_debug_set_extra_dims(const float* extra_dims_device, uint32_t n_extra);
 /* layout of the hashed levels' binned gradient scatter (csrc/model_kernels.hip k_grad_bin / k_grad_accumulate): table entries per
  * chunk = 2^chunk_log2 (11 or 12), one block per chunk (split = 0) or per (chunk, feature pair) (split = 1), list capacity override
  * in records (0 = twice the mean; a small value forces the list-overflow path for the tests); process-wide */

@@ -1666,18 +1666,25 @@ __global__ void __launch_bounds__(128) k_extra_dims_gradient(const uint32_t* __r
 		atomicAdd(g + k, sum);
 	}
 }
-// VarAdamOptimizer::step (adam_optimizer.h:37-47) for every image's variable at once: one thread per (image, dim); gradient / LOSS_SCALE as in testbed_nerf.cu:2868
+// VarAdamOptimizer::step (adam_optimizer.h:37-47) for every image's variable at once: one thread per (image, dim); gradient / LOSS_SCALE as in testbed_nerf.cu:2868.
+// iters != nullptr: every image has its own optimizer with its own iteration count (std::vector<VarAdamOptimizer> extra_dims_opt: an image that joins the training set
+// later starts at 0); iters[image] holds the count BEFORE this step, k_extra_dims_iter_inc advances the counts behind this kernel.  iters == nullptr: `iter` for all.
 __global__ void __launch_bounds__(128) k_extra_dims_adam(uint32_t n, float* __restrict__ variable, const float* __restrict__ gradient, float* __restrict__ m, float* __restrict__ v,
-		uint32_t iter, float lr, float loss_scale) {
+		uint32_t iter, float lr, float loss_scale, const uint32_t* __restrict__ iters, uint32_t n_extra) {
 #pragma clang fp contract(off)
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n) return;
+	if (iters) iter = iters[i / n_extra] + 1u;
 	const float beta1 = 0.9f, beta2 = 0.99f, epsilon = 1e-8f; // VarAdamOptimizer(n_extra_dims, 1e-4f): the defaults of adam_optimizer.h:29
 	const float actual_learning_rate = lr * sqrtf(1.0f - powf(beta2, (float)iter)) / (1.0f - powf(beta1, (float)iter));
 	const float g = gradient[i] / loss_scale;
 	const float fm = m[i] = beta1 * m[i] + (1.0f - beta1) * g;
 	const float sm = v[i] = beta2 * v[i] + (1.0f - beta2) * g * g;
 	variable[i] -= actual_learning_rate * fm / (sqrtf(sm) + epsilon);
+}
+__global__ void __launch_bounds__(128) k_extra_dims_iter_inc(uint32_t n_images, uint32_t* __restrict__ iters) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i < n_images) ++iters[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1688,8 +1695,10 @@ void launch_extra_dims_gradient(hipStream_t s, uint32_t max_rays, const uint32_t
 		const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows, const float* cdf_img) {
 	hipLaunchKernelGGL(k_extra_dims_gradient, dim3(blocks(max_rays, 128)), dim3(128), 0, s, n_rays_total_ptr, rays_counter, extra_grad, n_extra, n_images, ray_indices, numsteps, dextra, max_rows, cdf_img);
 }
-void launch_extra_dims_adam(hipStream_t s, uint32_t n, float* variable, const float* gradient, float* m, float* v, uint32_t iter, float lr, float loss_scale) {
-	if (n) hipLaunchKernelGGL(k_extra_dims_adam, dim3(blocks(n, 128)), dim3(128), 0, s, n, variable, gradient, m, v, iter, lr, loss_scale);
+void launch_extra_dims_adam(hipStream_t s, uint32_t n, float* variable, const float* gradient, float* m, float* v, uint32_t iter, float lr, float loss_scale, uint32_t* iters, uint32_t n_extra) {
+	if (!n) return;
+	hipLaunchKernelGGL(k_extra_dims_adam, dim3(blocks(n, 128)), dim3(128), 0, s, n, variable, gradient, m, v, iter, lr, loss_scale, iters, n_extra ? n_extra : 1u);
+	if (iters) hipLaunchKernelGGL(k_extra_dims_iter_inc, dim3(blocks(n / n_extra, 128)), dim3(128), 0, s, n / n_extra, iters);
 }
 
 void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t max_rays_this_rank) {

@@ -1246,6 +1246,14 @@ extern "C" int ngp_debug_set_error_sampling(const float* cdf_x_cond_y, const flo
 	if (error_map_res) { g_hook_error_map_res[0] = error_map_res[0]; g_hook_error_map_res[1] = error_map_res[1]; }
 	return 0;
 }
+// stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only (test hook): the per-image extra dims K1 copies behind every NerfCoordinate of the image's rays
+// (extra_dims_gpu, testbed_nerf.cu:718-719, 744, 833) and, with them, the row stride 7 + n_extra of the coords buffers of both kernels (device pointer; n_extra = 0 = off)
+static const float* g_hook_extra_dims = nullptr; static uint32_t g_hook_n_extra = 0;
+extern "C" int ngp_debug_set_extra_dims(const float* extra_dims_device, uint32_t n_extra) {
+	REQUIRE(n_extra <= 16 && (n_extra == 0 || extra_dims_device), "ngp_debug_set_extra_dims: 0..16 extra dims, device pointer");
+	g_hook_extra_dims = n_extra ? extra_dims_device : nullptr; g_hook_n_extra = n_extra;
+	return 0;
+}
 extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, uint32_t rank, uint32_t world_size, const uint32_t* n_rays_ptr, ngp_aabb aabb,
 		uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng, uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out,
 		ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_xform* xforms,
@@ -1260,6 +1268,7 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.bitfield = bitfield; a.max_mip = max_mip; a.snap_to_pixel_centers = snap_to_pixel_centers; a.cone_angle_constant = cone_angle_constant;
 	a.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE); a.clamp_min_max = (g_debug_flags & DBG_K1_MIP_CLAMP_MIN_MAX) ? 1u : 0u;
 	a.cdf = g_hook_cdf;
+	a.extra_dims = g_hook_extra_dims; a.n_extra = g_hook_n_extra;
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
@@ -1307,6 +1316,7 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 	a.loss_type = loss_type; a.loss_output = loss_output; a.rgb_activation = rgb_activation; a.density_activation = density_activation;
 	a.snap_to_pixel_centers = snap_to_pixel_centers; a.mean_density_ptr = mean_density_ptr; a.near_distance = near_distance;
 	a.cdf = g_hook_cdf; a.error_map = g_hook_error_map; a.error_map_res[0] = g_hook_error_map_res[0]; a.error_map_res[1] = g_hook_error_map_res[1];
+	a.cstride = 7u + g_hook_n_extra;
 	std::lock_guard<std::mutex> hook_lock(g_hook_mutex);
 	{ // scratch of the two-pass kernel (ablation DBG_K3_TWO_PASS); static like the other stand-alone hooks' scratch
 		static char* s_k3 = nullptr; static size_t s_k3_bytes = 0;
@@ -1416,9 +1426,14 @@ struct ngp_nerf {
 	uint32_t max_rays = 1u << 18;
 	// extra (latent / light-direction) dims, testbed.h Nerf::Training::extra_dims_gpu / extra_dims_opt / rendering_extra_dims: n_extra floats per image (+ one slot behind them
 	// for the dims a rendering uses), their gradient, the per-image VarAdamOptimizer state (adam_optimizer.h:27-47; one iteration count: every image steps every time)
-	uint32_t n_extra = 0, extra_cap = 0 /* images the buffers hold */, extra_iter = 0; bool optimize_extra_dims = false;
+	uint32_t n_extra = 0, extra_cap = 0 /* images the buffers hold: every image of the DATASET (ngp_nerf_set_extra_dims), >= n_images = the ones rays are drawn from */; bool optimize_extra_dims = false;
 	float* extra_dims = nullptr; float* extra_grad = nullptr; float* extra_m = nullptr; float* extra_v = nullptr; float* dextra = nullptr /* dL/d(extra dims) per batch row */;
+	uint32_t* extra_iter = nullptr;   // VarAdamOptimizer::m_iter per image (device): images that join the training set later step from 0 (std::vector<VarAdamOptimizer>, testbed_nerf.cu:2865-2876)
+	float extra_lr_last = 1e-4f;      // the learning rate the optimizers' last step used (set_learning_rate before every step, testbed_nerf.cu:2874; VarAdamOptimizer's own default before the first)
 	int rendering_extra_view = -1; std::vector<float> rendering_extra; // testbed_nerf.cu:3685-3707: the dims a rendering uses = those of a training view, or explicit values
+	std::vector<float> rendering_extra_default; // reset_extra_dims' copy of image 0's INITIAL dims (testbed_nerf.cu:3679-3682): what a rendering uses until told otherwise
+	float light_dir_warped[3] = {0, 0, 0}; // (host staging of the copy below: must outlive the asynchronous copy)
+	bool has_light_dirs = false; float light_dir[3] = {0.5f, 0.5f, 0.5f}; // Nerf::light_dir (testbed.h; GUI / python settable): replaces the first three rendering dims of a dataset with light directions (:3697-3706)
 };
 
 
@@ -1485,13 +1500,30 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->xcd_work, (void*)t->k2_enc_lv, (void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v, (void*)t->dextra}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->xcd_work, (void*)t->k2_enc_lv, (void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v, (void*)t->extra_iter, (void*)t->dextra}) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
 }
 
 static size_t pixel_bytes(int type) { return type == NGP_IMAGE_BYTE ? 4 : type == NGP_IMAGE_HALF ? 8 : 16; }
 
+// extra-dims buffers for n images (+ the slot behind them a rendering composes its dims in, testbed_nerf.cu:3658-3660): values, moments and iteration counts of the images already held are kept
+static int extra_dims_reserve(ngp_nerf* t, uint32_t n) {
+	if (n <= t->extra_cap) return 0;
+	float* nd = nullptr; float* ng = nullptr; float* nm = nullptr; float* nv = nullptr; uint32_t* ni = nullptr;
+	const size_t cnt = (size_t)(n + 1) * t->n_extra;
+	if (dev_alloc(&nd, cnt) || dev_alloc(&ng, cnt) || dev_alloc(&nm, cnt) || dev_alloc(&nv, cnt) || dev_alloc(&ni, (size_t)n + 1)) return 1;
+	HIPCHK(hipMemset(nd, 0, cnt * 4)); HIPCHK(hipMemset(ng, 0, cnt * 4)); HIPCHK(hipMemset(nm, 0, cnt * 4)); HIPCHK(hipMemset(nv, 0, cnt * 4)); HIPCHK(hipMemset(ni, 0, ((size_t)n + 1) * 4));
+	if (t->extra_dims) {
+		HIPCHK(hipDeviceSynchronize());
+		const size_t old = (size_t)t->extra_cap * t->n_extra * 4;
+		HIPCHK(hipMemcpy(nd, t->extra_dims, old, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nm, t->extra_m, old, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nv, t->extra_v, old, hipMemcpyDeviceToDevice));
+		HIPCHK(hipMemcpy(ni, t->extra_iter, (size_t)t->extra_cap * 4, hipMemcpyDeviceToDevice));
+		for (void* q : {(void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v, (void*)t->extra_iter}) (void)hipFree(q);
+	}
+	t->extra_dims = nd; t->extra_grad = ng; t->extra_m = nm; t->extra_v = nv; t->extra_iter = ni; t->extra_cap = n;
+	return 0;
+}
 static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_image_meta>& meta, const ngp_xform* xforms) {
 	if (t->meta_dev) { (void)hipFree(t->meta_dev); t->meta_dev = nullptr; }
 	if (t->xforms_dev) { (void)hipFree(t->xforms_dev); t->xforms_dev = nullptr; }
@@ -1502,18 +1534,7 @@ static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_ima
 		t->cdf_valid = false; t->error_cycle_open = false; t->n_steps_since_error_map_update = 0; // (the next step opens a cycle sized for n; dev_grow regrows the buffers)
 	}
 	t->n_images = n;
-	if (t->n_extra && n > t->extra_cap) { // the extra dims follow the image count: existing values are kept, new images start at zero (ngp_nerf_set_extra_dims installs the reference's initial values)
-		float* nd = nullptr; float* ng = nullptr; float* nm = nullptr; float* nv = nullptr;
-		const size_t cnt = (size_t)(n + 1) * t->n_extra;
-		if (dev_alloc(&nd, cnt) || dev_alloc(&ng, cnt) || dev_alloc(&nm, cnt) || dev_alloc(&nv, cnt)) return 1;
-		HIPCHK(hipMemset(nd, 0, cnt * 4)); HIPCHK(hipMemset(ng, 0, cnt * 4)); HIPCHK(hipMemset(nm, 0, cnt * 4)); HIPCHK(hipMemset(nv, 0, cnt * 4));
-		if (t->extra_dims) {
-			const size_t old = (size_t)t->extra_cap * t->n_extra * 4;
-			HIPCHK(hipMemcpy(nd, t->extra_dims, old, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nm, t->extra_m, old, hipMemcpyDeviceToDevice)); HIPCHK(hipMemcpy(nv, t->extra_v, old, hipMemcpyDeviceToDevice));
-			for (void* q : {(void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v}) (void)hipFree(q);
-		}
-		t->extra_dims = nd; t->extra_grad = ng; t->extra_m = nm; t->extra_v = nv; t->extra_cap = n;
-	}
+	if (t->n_extra && extra_dims_reserve(t, n)) return 1; // the extra dims follow the image count: existing values are kept, new images start at zero (ngp_nerf_set_extra_dims installs the reference's initial values for the whole dataset)
 	return 0;
 }
 extern "C" int ngp_nerf_set_dataset_host(ngp_nerf* t, uint32_t n, const ngp_image_meta* meta, const ngp_xform* xforms, const void* const* pixels_host) {
@@ -1829,7 +1850,7 @@ extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
 	if (t->grads_pending) { HIPCHK(hipStreamWaitEvent(s, t->ev_red_a, 0)); HIPCHK(hipStreamWaitEvent(s, t->ev_red_b, 0)); t->grads_pending = false; }
 	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 	if (t->n_extra && t->optimize_extra_dims) // testbed_nerf.cu:2860-2878: one VarAdamOptimizer step per image at the network optimizer's current learning rate
-		launch_extra_dims_adam(s, t->n_images * t->n_extra, t->extra_dims, t->extra_grad, t->extra_m, t->extra_v, ++t->extra_iter, t->model->lr, t->opt.loss_scale);
+		{ launch_extra_dims_adam(s, t->n_images * t->n_extra, t->extra_dims, t->extra_grad, t->extra_m, t->extra_v, 0, t->model->lr, t->opt.loss_scale, t->extra_iter, t->n_extra); t->extra_lr_last = t->model->lr; }
 	if (!t->ctl_done) { // the controller has not run behind K3 (multi-rank caller using ngp_nerf_train_forward_backward)
 		if (t->opt.world_size > 1) hipLaunchKernelGGL(k_import_sync, dim3(1), dim3(64), 0, s, t->counters, t->sync2, t->opt.world_size);
 		ProfScope ps(P_COUNTERS, s); launch_update_counters(s, t->counters, t->opt.target_batch_size, t->opt.world_size);
@@ -2058,59 +2079,74 @@ extern "C" int ngp_k_extra_dims_adam(void* stream, uint32_t n, float* variable, 
 	return 0;
 }
 // ---- extra dims (testbed.h Nerf::Training::extra_dims_gpu, optimize_extra_dims; python_api.cu set_rendering_extra_dims*) ----
-// values: n_images x n_extra_dims floats on the host (reset_extra_dims computes them: warped light directions / uniform random latents, testbed_nerf.cu:3656-3683);
-// installs them and resets the per-image optimizers (reset_state)
+// values: n_images x n_extra_dims floats on the host (reset_extra_dims computes them: warped light directions / uniform random latents, testbed_nerf.cu:3656-3683) for EVERY
+// image of the dataset -- n_images >= the number of images rays are drawn from (ngp_nerf_set_dataset_*'s n = n_images_for_training): images that join the training set later
+// find their initial values here, and the getters / snapshots cover the whole dataset like the reference's.  Installs them, resets the per-image optimizers (reset_state)
+// and takes the copy of image 0's dims a rendering uses by default (rendering_extra_dims, :3679-3682).
 extern "C" int ngp_nerf_set_extra_dims(ngp_nerf* t, const float* values, uint32_t n_images) {
 	REQUIRE(t && values && t->n_extra > 0, "set_extra_dims: the model has no extra dims");
-	REQUIRE(n_images == t->n_images && t->extra_dims, "set_extra_dims: one vector per image of the dataset (set the dataset first)");
+	REQUIRE(n_images >= t->n_images && n_images > 0 && t->extra_dims, "set_extra_dims: one vector per image of the dataset, at least the images in training (set the dataset first)");
 	invalidate_k1(t);
+	HIPCHK(hipDeviceSynchronize());
+	if (extra_dims_reserve(t, n_images)) return 1;
 	const size_t cnt = (size_t)n_images * t->n_extra;
 	HIPCHK(hipMemcpy(t->extra_dims, values, cnt * 4, hipMemcpyHostToDevice));
-	HIPCHK(hipMemset(t->extra_m, 0, cnt * 4)); HIPCHK(hipMemset(t->extra_v, 0, cnt * 4));
-	t->extra_iter = 0;
+	HIPCHK(hipMemset(t->extra_m, 0, (size_t)t->extra_cap * t->n_extra * 4)); HIPCHK(hipMemset(t->extra_v, 0, (size_t)t->extra_cap * t->n_extra * 4));
+	HIPCHK(hipMemset(t->extra_iter, 0, (size_t)t->extra_cap * 4));
+	t->extra_lr_last = 1e-4f;
+	t->rendering_extra_default.assign(values, values + t->n_extra);
 	return 0;
 }
 extern "C" int ngp_nerf_get_extra_dims(ngp_nerf* t, float* values, uint32_t n_images) {
-	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->n_images && t->extra_dims, "get_extra_dims: no extra dims / too many images");
+	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->extra_cap && t->extra_dims, "get_extra_dims: no extra dims / too many images");
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(values, t->extra_dims, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
 	return 0;
 }
 // The per-image optimizers' state (Training::extra_dims_opt, a std::vector<VarAdamOptimizer>: snapshots carry it, testbed.cu:5311 / 5482-5486): first / second moments
-// (n_images x n_extra_dims each) and the iteration count -- one count here, the reference's optimizers all step together.  set: variables, moments and count as they are
-// (no reset), for the first n_images images.
+// (n_images x n_extra_dims each), the iteration count of every image's optimizer (n_images values) and the learning rate their last step used (learning_rate_out, may be
+// null).  set: variables, moments and counts as they are (no reset), for the first n_images images of the dataset.
 extern "C" int ngp_nerf_get_extra_dims_optimizer(ngp_nerf* t, float* first_moment, float* second_moment, uint32_t* iter, uint32_t n_images) {
-	REQUIRE(t && first_moment && second_moment && iter && t->n_extra > 0 && n_images <= t->n_images && t->extra_dims, "get_extra_dims_optimizer: no extra dims / too many images");
+	REQUIRE(t && first_moment && second_moment && iter && t->n_extra > 0 && n_images <= t->extra_cap && t->extra_dims, "get_extra_dims_optimizer: no extra dims / too many images");
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(first_moment, t->extra_m, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(second_moment, t->extra_v, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
-	*iter = t->extra_iter;
+	HIPCHK(hipMemcpy(iter, t->extra_iter, (size_t)n_images * 4, hipMemcpyDeviceToHost));
 	return 0;
 }
-extern "C" int ngp_nerf_set_extra_dims_optimizer(ngp_nerf* t, const float* variable, const float* first_moment, const float* second_moment, uint32_t iter, uint32_t n_images) {
-	REQUIRE(t && variable && first_moment && second_moment && t->n_extra > 0 && n_images <= t->n_images && t->extra_dims, "set_extra_dims_optimizer: no extra dims / too many images");
+extern "C" float ngp_nerf_extra_dims_learning_rate(const ngp_nerf* t) { return t ? t->extra_lr_last : 0.f; }
+extern "C" int ngp_nerf_set_extra_dims_optimizer(ngp_nerf* t, const float* variable, const float* first_moment, const float* second_moment, const uint32_t* iter, uint32_t n_images) {
+	REQUIRE(t && variable && first_moment && second_moment && iter && t->n_extra > 0 && n_images <= t->extra_cap && t->extra_dims, "set_extra_dims_optimizer: no extra dims / too many images");
 	invalidate_k1(t);
 	HIPCHK(hipDeviceSynchronize());
 	const size_t bytes = (size_t)n_images * t->n_extra * 4;
 	HIPCHK(hipMemcpy(t->extra_dims, variable, bytes, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->extra_m, first_moment, bytes, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->extra_v, second_moment, bytes, hipMemcpyHostToDevice));
-	t->extra_iter = iter;
+	HIPCHK(hipMemcpy(t->extra_iter, iter, (size_t)n_images * 4, hipMemcpyHostToDevice));
 	return 0;
 }
 extern "C" int ngp_nerf_get_extra_dims_gradient(ngp_nerf* t, float* values, uint32_t n_images) { // the last step's (loss-scaled) per-image gradient: test hook
-	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->n_images && t->extra_grad, "get_extra_dims_gradient: no extra dims / too many images");
+	REQUIRE(t && values && t->n_extra > 0 && n_images <= t->extra_cap && t->extra_grad, "get_extra_dims_gradient: no extra dims / too many images");
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(values, t->extra_grad, (size_t)n_images * t->n_extra * 4, hipMemcpyDeviceToHost));
 	return 0;
 }
 extern "C" int ngp_nerf_set_optimize_extra_dims(ngp_nerf* t, int on) { REQUIRE(t, "null trainer"); invalidate_k1(t); t->optimize_extra_dims = on != 0; return 0; }
-// view >= 0: render with that training view's dims; view < 0: with `values` (n_extra_dims floats; null = image 0's, the state after reset_extra_dims)
+// view >= 0: render with that training view's CURRENT dims; view < 0: with `values` (n_extra_dims floats; null = the copy of image 0's initial dims reset_extra_dims took)
 extern "C" int ngp_nerf_set_rendering_extra_dims(ngp_nerf* t, int view, const float* values) {
 	REQUIRE(t && t->n_extra > 0, "set_rendering_extra_dims: the model has no extra dims");
 	t->rendering_extra_view = view;
 	t->rendering_extra.clear();
 	if (view < 0 && values) t->rendering_extra.assign(values, values + t->n_extra);
+	return 0;
+}
+// Nerf::light_dir + NerfDataset::has_light_dirs (testbed.h, nerf_loader.h): with light directions in the dataset a rendering's first three extra dims are
+// warp_direction(normalize(light_dir)) whatever else was selected (get_rendering_extra_dims, testbed_nerf.cu:3697-3706); light_dir defaults to (0.5, 0.5, 0.5).
+extern "C" int ngp_nerf_set_light_dir(ngp_nerf* t, int has_light_dirs, const float light_dir[3]) {
+	REQUIRE(t && t->n_extra > 0, "set_light_dir: the model has no extra dims");
+	t->has_light_dirs = has_light_dirs != 0;
+	if (light_dir) for (int k = 0; k < 3; ++k) t->light_dir[k] = light_dir[k];
 	return 0;
 }
 
@@ -2131,11 +2167,17 @@ extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_param
 	a.rays = t->r_rays; a.masks = t->r_masks;
 	if (t->n_extra) { // Testbed::Nerf::get_rendering_extra_dims (testbed_nerf.cu:3685-3707): a training view's dims, or the explicit values, through the slot behind the images'
 		REQUIRE(t->extra_dims, "render: a model with extra dims needs a dataset (the extra dims are per image)");
-		REQUIRE(t->rendering_extra_view < (int)t->n_images, "render: rendering_extra_dims_from_training_view out of range");
+		REQUIRE(t->rendering_extra_view < (int)t->extra_cap, "render: rendering_extra_dims_from_training_view out of range");
 		float* slot = t->extra_dims + (size_t)t->extra_cap * t->n_extra;
 		if (t->rendering_extra_view >= 0) HIPCHK(hipMemcpyAsync(slot, t->extra_dims + (size_t)t->rendering_extra_view * t->n_extra, t->n_extra * 4, hipMemcpyDeviceToDevice, s));
 		else if (t->rendering_extra.size() == t->n_extra) HIPCHK(hipMemcpyAsync(slot, t->rendering_extra.data(), t->n_extra * 4, hipMemcpyHostToDevice, s));
-		else HIPCHK(hipMemcpyAsync(slot, t->extra_dims, t->n_extra * 4, hipMemcpyDeviceToDevice, s)); // reset_extra_dims: rendering_extra_dims = those of image 0 (testbed_nerf.cu:3679-3682)
+		else if (t->rendering_extra_default.size() == t->n_extra) HIPCHK(hipMemcpyAsync(slot, t->rendering_extra_default.data(), t->n_extra * 4, hipMemcpyHostToDevice, s)); // reset_extra_dims: rendering_extra_dims = a COPY of image 0's initial dims (testbed_nerf.cu:3679-3682), not its trained ones
+		else HIPCHK(hipMemcpyAsync(slot, t->extra_dims, t->n_extra * 4, hipMemcpyDeviceToDevice, s)); // (no ngp_nerf_set_extra_dims yet: image 0's)
+		if (t->has_light_dirs) { // testbed_nerf.cu:3697-3706: the light direction of the rendering replaces the first three dims
+			const float l = sqrtf(t->light_dir[0] * t->light_dir[0] + t->light_dir[1] * t->light_dir[1] + t->light_dir[2] * t->light_dir[2]);
+			t->light_dir_warped[0] = (t->light_dir[0] / l + 1.0f) * 0.5f; t->light_dir_warped[1] = (t->light_dir[1] / l + 1.0f) * 0.5f; t->light_dir_warped[2] = (t->light_dir[2] / l + 1.0f) * 0.5f; // warp_direction(normalize(light_dir)), nerf_device.cuh:291
+			HIPCHK(hipMemcpyAsync(slot, t->light_dir_warped, std::min<size_t>((size_t)t->n_extra * 4, 12), hipMemcpyHostToDevice, s));
+		}
 		a.extra_dims = slot; a.n_extra = t->n_extra;
 	}
 	const uint64_t n_pix = (uint64_t)rp->resolution[0] * rp->resolution[1];

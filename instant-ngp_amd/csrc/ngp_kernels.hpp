@@ -107,7 +107,8 @@ struct K3Args {
 // compute_extra_dims_gradient_train_nerf (testbed_nerf.cu:1293-1330) and the per-image VarAdamOptimizer::step (adam_optimizer.h:37-47, testbed_nerf.cu:2860-2878)
 void launch_extra_dims_gradient(hipStream_t s, uint32_t max_rays, const uint32_t* n_rays_total_ptr, const uint32_t* rays_counter, float* extra_grad, uint32_t n_extra, uint32_t n_images,
 	const uint32_t* ray_indices, const uint32_t* numsteps, const float* dextra, uint32_t max_rows, const float* cdf_img);
-void launch_extra_dims_adam(hipStream_t s, uint32_t n, float* variable, const float* gradient, float* m, float* v, uint32_t iter, float lr, float loss_scale);
+void launch_extra_dims_adam(hipStream_t s, uint32_t n, float* variable, const float* gradient, float* m, float* v, uint32_t iter, float lr, float loss_scale,
+	uint32_t* iters = nullptr /* per-image iteration counts before this step (n / n_extra of them; advanced behind the step); null: `iter` for every image */, uint32_t n_extra = 0);
 size_t k3_scratch_bytes(uint32_t max_rays);
 int k3_scratch_init(hipStream_t s, void* scratch, uint32_t max_rays);
 

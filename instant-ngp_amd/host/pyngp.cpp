@@ -197,12 +197,15 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property("density_activation", [](const Nerf& n) { return (ENerfActivation)n.density_activation; }, [](Nerf& n, ENerfActivation v) { n.density_activation = (int)v; }) // :717
 		.def_readwrite("visualize_cameras", &Nerf::visualize_cameras)
 		.def_readwrite("rendering_extra_dims_from_training_view", &Nerf::rendering_extra_dims_from_training_view)                                          // python_api.cu:725-727
+		.def_readwrite("light_dir", &Nerf::light_dir)                                                                                                      // testbed.h:871 (the reference sets it from its GUI only; bound here so that scripts can relight)
 		.def("set_rendering_extra_dims_from_training_view", [](Nerf& n, int v) { n.rendering_extra_dims_from_training_view = v; })                           // :735-737
 		.def("set_rendering_extra_dims", [](Nerf& n, const std::vector<float>& v) { n.rendering_extra_dims = v; n.rendering_extra_dims_from_training_view = -1; }) // :739
 		.def("get_rendering_extra_dims", [](Nerf& n) {                                                                                                     // :741
 				if (n.rendering_extra_dims_from_training_view >= 0) return n.training.owner->get_extra_dims(n.rendering_extra_dims_from_training_view);
 				if (!n.rendering_extra_dims.empty()) return n.rendering_extra_dims;
-				return n.training.dataset.n_extra_dims() ? n.training.owner->get_extra_dims(0) : std::vector<float>{}; })
+				if (n.training.dataset.n_extra_dims() == 0) return std::vector<float>{};
+				(void)n.training.owner->get_extra_dims(0);            // (creates the trainer, which runs reset_extra_dims)
+				return n.rendering_extra_dims_default; })               // the copy of image 0's INITIAL dims (testbed_nerf.cu:3679-3682), not its trained ones
 		.def("find_closest_training_view", [](Nerf& n, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
 				if (a.size() < 12) throw std::runtime_error{"find_closest_training_view expects a 3x4 matrix"};
 				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];

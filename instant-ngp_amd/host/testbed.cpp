@@ -270,6 +270,7 @@ void Testbed::destroy_trainer() {
 	if (m_encmlp) { ngp_encmlp_destroy(m_encmlp); m_encmlp = nullptr; }
 	if (m_nerf) { ngp_nerf_destroy(m_nerf); m_nerf = nullptr; }
 	if (m_model) { ngp_model_destroy(m_model); m_model = nullptr; }
+	m_extra_dims_installed = false; // the next trainer starts from reset_extra_dims' values again (reset_network, testbed.cu:4272)
 }
 
 // load_network_config with recursive "parent" merge-patch, testbed.cu:86-97, 254-310
@@ -401,11 +402,17 @@ void Testbed::ensure_trainer() {
 		const uint32_t n_train = nerf.training.n_images_for_training > 0 ? (uint32_t)std::min<size_t>((size_t)nerf.training.n_images_for_training, d.n_images) : (uint32_t)d.n_images;
 		NGP_CHECK(ngp_nerf_set_dataset_host(m_nerf, n_train, meta.data(), xf.data(), pix.data()));
 		m_dataset_dirty = false; m_uploaded_n_images_for_training = nerf.training.n_images_for_training;
-		if (d.n_extra_dims() > 0 && m_extra_dims_for != m_nerf) { // Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683), once per trainer
-			const std::vector<float> e = initial_extra_dims();
-			std::vector<float> first(e.begin(), e.begin() + (size_t)n_train * d.n_extra_dims());
-			NGP_CHECK(ngp_nerf_set_extra_dims(m_nerf, first.data(), n_train));
-			m_extra_dims_for = m_nerf;
+		if (d.n_extra_dims() > 0 && !m_extra_dims_installed) {
+			// Testbed::Nerf::reset_extra_dims as reset_network calls it (testbed.cu:4163-4272), once per trainer: m_rng = rng{seed}; density_grid_rng = rng{m_rng.next_uint()};
+			// reset_extra_dims(m_rng) -- the latents are drawn from the TRAINER's ray-stream rng behind the density-grid draw (where ngp_nerf_create leaves it) and advance it, so
+			// the initial latents and every training ray after them are the reference's.  Values for EVERY image of the dataset (extra_dims_gpu holds dataset.n_images + 1 vectors).
+			ngp_pcg32 rng, grid_rng;
+			NGP_CHECK(ngp_nerf_get_rng(m_nerf, &rng, &grid_rng));
+			const std::vector<float> e = initial_extra_dims(rng);
+			NGP_CHECK(ngp_nerf_set_extra_dims(m_nerf, e.data(), (uint32_t)d.n_images));
+			NGP_CHECK(ngp_nerf_set_rng(m_nerf, &rng));
+			nerf.rendering_extra_dims_default.assign(e.begin(), e.begin() + d.n_extra_dims());
+			m_extra_dims_installed = true;
 		}
 	}
 }
@@ -418,19 +425,18 @@ void Testbed::push_options() {
 		NGP_CHECK(ngp_nerf_set_optimize_extra_dims(m_nerf, nerf.training.dataset.n_extra_learnable_dims > 0 && nerf.training.optimize_extra_dims ? 1 : 0));
 		const bool explicit_vals = nerf.rendering_extra_dims_from_training_view < 0 && nerf.rendering_extra_dims.size() == nerf.training.dataset.n_extra_dims();
 		NGP_CHECK(ngp_nerf_set_rendering_extra_dims(m_nerf, nerf.rendering_extra_dims_from_training_view, explicit_vals ? nerf.rendering_extra_dims.data() : nullptr));
+		NGP_CHECK(ngp_nerf_set_light_dir(m_nerf, nerf.training.dataset.has_light_dirs ? 1 : 0, nerf.light_dir.data())); // get_rendering_extra_dims, testbed_nerf.cu:3697-3706
 	}
 }
 
 // Testbed::Nerf::reset_extra_dims (testbed_nerf.cu:3656-3683): per image the warped (normalised) light direction in the first three dims when the dataset has light
-// directions, uniform random values in [-1, 1) otherwise, drawn image by image from the testbed's rng -- pcg32{seed} at load time (load_nerf_post, :2378, runs before
-// reset_network re-seeds m_rng) [tcnn pcg32.h]
-std::vector<float> Testbed::initial_extra_dims() const {
+// directions, uniform random values in [-1, 1) otherwise (random_val(rng) * 2 - 1 = pcg32::next_float [tcnn pcg32.h]), drawn image by image, dim by dim from `rng`, which is
+// left advanced by one draw per learnable dim -- the caller hands in the rng the reference hands in (reset_network's m_rng behind the density-grid draw, testbed.cu:4163-4272)
+std::vector<float> Testbed::initial_extra_dims(ngp_pcg32& rng) const {
 	const NerfDataset& d = nerf.training.dataset;
 	const uint32_t n = d.n_extra_dims();
 	std::vector<float> out((size_t)d.n_images * n);
-	uint64_t state = 0, inc = 3; // pcg32(initstate = seed, initseq = 1)
-	auto next_uint = [&]() { const uint64_t old = state; state = old * 0x5851f42d4c957f2dULL + inc; const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u); return (xs >> rot) | (xs << ((~rot + 1u) & 31)); };
-	next_uint(); state += seed; next_uint();
+	auto next_uint = [&]() { const uint64_t old = rng.state; rng.state = old * 0x5851f42d4c957f2dULL + rng.inc; const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u); return (xs >> rot) | (xs << ((~rot + 1u) & 31)); };
 	auto next_float = [&]() { union { uint32_t u; float f; } x; x.u = (next_uint() >> 9) | 0x3f800000u; return x.f - 1.0f; };
 	for (size_t i = 0; i < d.n_images; ++i) {
 		const auto& l = d.metadata[i].light_dir;
@@ -1276,17 +1282,17 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	{ // snapshot["nerf"]["extra_dims_opt"] = m_nerf.training.extra_dims_opt (testbed.cu:5311): one VarAdamOptimizer per image (adam_optimizer.h:72-81)
 		Value arr; arr.type = Value::Array;
 		const uint32_t ne = nerf.training.dataset.n_extra_dims();
-		const uint32_t n_img = ne ? (uint32_t)std::min<size_t>(nerf.training.dataset.n_images, nerf.training.n_images_for_training > 0 ? (size_t)nerf.training.n_images_for_training : nerf.training.dataset.n_images) : 0u;
+		const uint32_t n_img = ne ? (uint32_t)nerf.training.dataset.n_images : 0u; // one optimizer per image of the DATASET (reset_extra_dims, testbed_nerf.cu:3661), trained or not
 		if (ne && n_img) {
-			std::vector<float> var((size_t)n_img * ne), m1(var.size()), m2(var.size()); uint32_t iter = 0;
+			std::vector<float> var((size_t)n_img * ne), m1(var.size()), m2(var.size()); std::vector<uint32_t> iter(n_img, 0u);
 			NGP_CHECK(ngp_nerf_get_extra_dims(m_nerf, var.data(), n_img));
-			NGP_CHECK(ngp_nerf_get_extra_dims_optimizer(m_nerf, m1.data(), m2.data(), &iter, n_img));
-			const float lr = ngp_model_learning_rate(m_model); // set_learning_rate(m_optimizer->learning_rate()) before every step (testbed_nerf.cu:2874)
+			NGP_CHECK(ngp_nerf_get_extra_dims_optimizer(m_nerf, m1.data(), m2.data(), iter.data(), n_img));
+			const float lr = ngp_nerf_extra_dims_learning_rate(m_nerf); // the rate the last step was taken with (set_learning_rate(m_optimizer->learning_rate()) BEFORE the step, testbed_nerf.cu:2874), not the decayed one behind it
 			for (uint32_t i = 0; i < n_img; ++i) {
 				Value o = jobj();
-				o.set("iter", jnum(iter)); o.set("first_moment", jvec(m1.data() + (size_t)i * ne, ne)); o.set("second_moment", jvec(m2.data() + (size_t)i * ne, ne));
+				o.set("iter", jnum(iter[i])); o.set("first_moment", jvec(m1.data() + (size_t)i * ne, ne)); o.set("second_moment", jvec(m2.data() + (size_t)i * ne, ne));
 				o.set("variable", jvec(var.data() + (size_t)i * ne, ne));
-				o.set("learning_rate", jnum(iter ? lr : 1e-4f)); o.set("epsilon", jnum(1e-8f)); o.set("beta1", jnum(0.9f)); o.set("beta2", jnum(0.99f));
+				o.set("learning_rate", jnum(iter[i] ? lr : 1e-4f)); o.set("epsilon", jnum(1e-8f)); o.set("beta1", jnum(0.9f)); o.set("beta2", jnum(0.99f));
 				arr.arr.push_back(o);
 			}
 		}
@@ -1441,15 +1447,15 @@ void Testbed::load_snapshot(const std::string& path) {
 		const Value& eo = jn["extra_dims_opt"];
 		const uint32_t ne = nerf.training.dataset.n_extra_dims();
 		if (ne && eo.is_array() && eo.size() > 0) {
-			const uint32_t n_up = (uint32_t)std::min<size_t>(nerf.training.dataset.n_images, nerf.training.n_images_for_training > 0 ? (size_t)nerf.training.n_images_for_training : nerf.training.dataset.n_images);
-			const uint32_t n_img = (uint32_t)std::min<size_t>(eo.size(), n_up);
-			std::vector<float> var((size_t)n_img * ne), m1(var.size()), m2(var.size());
+			const uint32_t n_img = (uint32_t)std::min<size_t>(eo.size(), nerf.training.dataset.n_images);
+			std::vector<float> var((size_t)n_img * ne), m1(var.size()), m2(var.size()); std::vector<uint32_t> iter(n_img, 0u);
 			for (uint32_t i = 0; i < n_img; ++i) {
 				const Value& o = eo.at(i);
 				if (o["variable"].size() != ne || o["first_moment"].size() != ne || o["second_moment"].size() != ne) throw std::runtime_error{"Snapshot extra_dims_opt does not match the dataset's extra dims."};
 				for (uint32_t k = 0; k < ne; ++k) { var[(size_t)i * ne + k] = (float)o["variable"].at(k).n; m1[(size_t)i * ne + k] = (float)o["first_moment"].at(k).n; m2[(size_t)i * ne + k] = (float)o["second_moment"].at(k).n; }
+				iter[i] = (uint32_t)o.num("iter", 0);
 			}
-			NGP_CHECK(ngp_nerf_set_extra_dims_optimizer(m_nerf, var.data(), m1.data(), m2.data(), (uint32_t)eo.at(0).num("iter", 0), n_img));
+			NGP_CHECK(ngp_nerf_set_extra_dims_optimizer(m_nerf, var.data(), m1.data(), m2.data(), iter.data(), n_img));
 		}
 	}
 	training_step = (uint32_t)snap.num("training_step", 0);

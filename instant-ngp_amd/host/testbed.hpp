@@ -122,7 +122,9 @@ struct Nerf {
 	bool visualize_cameras = false;                  // GUI overlay switch: kept so that scripts that clear it run
 	int max_cascade = 0;
 	int rendering_extra_dims_from_training_view = -1;   // testbed.h; python_api.cu:725-727
-	std::vector<float> rendering_extra_dims;         // set_rendering_extra_dims (python_api.cu:739); empty = image 0's, the state after reset_extra_dims
+	std::vector<float> rendering_extra_dims;         // set_rendering_extra_dims (python_api.cu:739); empty = the copy of image 0's initial dims reset_extra_dims took
+	std::vector<float> rendering_extra_dims_default; // reset_extra_dims' copy of image 0's initial dims (testbed_nerf.cu:3679-3682), filled when the trainer is created
+	std::array<float, 3> light_dir{0.5f, 0.5f, 0.5f};   // testbed.h:871: with light directions in the dataset the rendering's first three extra dims = warp_direction(normalize(light_dir)) (testbed_nerf.cu:3697-3706; GUI-set in the reference)
 	NerfTraining training;
 };
 
@@ -246,8 +248,8 @@ private:
 	void load_nerf_post();
 	void destroy_trainer();
 	void push_options();
-	std::vector<float> initial_extra_dims() const;   // reset_extra_dims' values for every image of the dataset (testbed_nerf.cu:3656-3683)
-	const void* m_extra_dims_for = nullptr;         // the trainer the initial extra dims were installed in
+	std::vector<float> initial_extra_dims(ngp_pcg32& rng) const; // reset_extra_dims' values for every image of the dataset, drawn from (and advancing) `rng` (testbed_nerf.cu:3656-3683)
+	bool m_extra_dims_installed = false;            // the CURRENT trainer holds reset_extra_dims' values (cleared whenever the trainer is destroyed: a pointer comparison would be an ABA test, the allocator reuses addresses)
 	ngp_nerf_options current_options() const;
 	ngp_aabb scene_aabb() const;
 

@@ -153,8 +153,15 @@ def test_training_step_gradients_and_input_gradient(ora, hip, n_extra):
     dref = np.zeros((n, n_extra), np.float32)
     ora.ora_model_training_step_extra(om.h, ptr(c), 7 + n_extra, n, ptr(dl), 4, ptr(dref))
     gref = half_to_f32(om.grads.copy())
+    ora.ora_model_training_step_exact_sums(om.h, ptr(c), 7 + n_extra, n, ptr(dl), 4, 2)  # the same gradients with every table entry's contributions summed without rounding
+    gtrue = half_to_f32(om.grads.copy())
     cd = torch.from_numpy(c).cuda(); dld = torch.from_numpy(dl.view(np.int16)).cuda()
     blocks = {"density_l1": (0, 2048), "density_l2": (2048, 3072), "rgb_l1": (3072, 3072 + 64 * 48), "rgb_l2": (6144, 6144 + 4096), "rgb_out": (10240, 10240 + 3 * 64)}
+    offs = (C.c_uint32 * 9)(); res = (C.c_uint32 * 8)(); sc = (C.c_float * 8)()
+    hip.ngp_model_grid_layout(hm.h, offs, res, sc)
+    levels = {l: (hm.n_mlp + offs[l] * 4, hm.n_mlp + offs[l + 1] * 4) for l in range(8)}
+    noise = {l: _rel_l2(gref[a:b], gtrue[a:b]) for l, (a, b) in levels.items()}  # the reference-order chain of half adds vs the unrounded sums
+    print("reference-order oracle vs unrounded sums per level", {l: f"{v:.1e}" for l, v in noise.items()})
     try:
         for vname, flags in [("lists", 0), ("atomics_only", 2048)]:
             hip.ngp_debug_set_flags(flags)
@@ -166,50 +173,26 @@ def test_training_step_gradients_and_input_gradient(ora, hip, n_extra):
             rep = {k: _rel_l2(gf[a:b], gref[a:b]) for k, (a, b) in blocks.items()}
             w1 = gf[3072:3072 + 64 * 48].reshape(64, 48); w1r = gref[3072:3072 + 64 * 48].reshape(64, 48)
             rep["rgb_l1_extra_columns"] = _rel_l2(w1[:, 32:], w1r[:, 32:])
-            rep["grid"] = _rel_l2(gf[hm.n_mlp:], gref[om.n_mlp:])
             got = dx.cpu().numpy()
             rep["dL_dextra"] = _rel_l2(got, dref)
             print(n_extra, vname, {k: f"{v:.1e}" for k, v in rep.items()})
             for k, v in rep.items():
-                assert v < (2e-3 if k != "grid" else 5e-2), (vname, k, v)
+                assert v < 2e-3, (vname, k, v)
+            # the hash-grid gradient per level, the plain model's bars (tests/test_gpu_model.py::test_training_step_gradients_full_batch_and_bin_layouts): the record lists sum
+            # exactly, so the device is at least as close to the unrounded sums as the reference-order half adds are; half atomics carry the reference's own kind of error
+            true = {l: _rel_l2(gf[a:b], gtrue[a:b]) for l, (a, b) in levels.items()}
+            print(n_extra, vname, "grid vs unrounded sums per level", {l: f"{v:.1e}" for l, v in true.items()})
+            for l, v in true.items():
+                if vname == "lists":
+                    assert v <= 1.05 * noise[l] + 2e-5, (vname, l, v, noise[l])
+                    assert v < 3e-3, (vname, l, v)
+                else:
+                    assert v < 2.0 * noise[l] + 3e-3, (vname, l, v, noise[l])
             assert np.isfinite(got).all() and np.abs(w1r[:, 32:]).max() > 0
             # per element: both sides round the same fp32 sums of 64 products to half
             assert (np.abs(got - dref) <= 2e-3 * np.abs(dref) + 1e-7).mean() > 0.99
     finally:
         hip.ngp_debug_set_flags(0)
-
-
-@pytest.mark.gpu
-def test_gradient_reduction_and_var_adam_kernels(ora, hip):
-    """k_extra_dims_gradient / k_extra_dims_adam vs the oracle's restatements of compute_extra_dims_gradient_train_nerf and VarAdamOptimizer::step"""
-    import torch
-    rng = np.random.default_rng(3)
-    n_rays_total, n_img, n_extra, n_r = 5000, 17, 5, 3000
-    ray_idx = rng.permutation(n_rays_total)[:n_r].astype(np.uint32)
-    counts = rng.integers(0, 12, n_r).astype(np.uint32); base = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
-    ns = np.ascontiguousarray(np.stack([counts, base], 1))
-    rows = int(counts.sum())
-    dx = rng.normal(size=(rows, n_extra)).astype(np.float32)
-    ref = np.zeros((n_img, n_extra), np.float32)
-    ora.ora_extra_dims_gradient(n_rays_total, n_r, ptr(ref), n_extra, n_img, ptr(ray_idx), ptr(ns), ptr(dx))
-    out = torch.zeros((n_img, n_extra), dtype=torch.float32, device="cuda")
-    rid = torch.from_numpy(ray_idx.view(np.int32)).cuda(); nsd = torch.from_numpy(ns.view(np.int32)).cuda(); dxd = torch.from_numpy(dx).cuda()
-    A.check(hip, hip.ngp_k_extra_dims_gradient(None, n_rays_total, n_r, dptr(out), n_extra, n_img, dptr(rid), dptr(nsd), dptr(dxd), rows))
-    torch.cuda.synchronize()
-    got = out.cpu().numpy()
-    assert np.allclose(got, ref, rtol=1e-5, atol=1e-4) and np.abs(ref).max() > 1
-    # three Adam steps at a decaying learning rate
-    n = n_img * n_extra
-    var = rng.uniform(-1, 1, n).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
-    vd = torch.from_numpy(var.copy()).cuda(); md = torch.zeros(n, device="cuda"); vvd = torch.zeros(n, device="cuda")
-    for it, lr in [(1, 1e-2), (2, 1e-2), (3, 3.3e-3)]:
-        g = (rng.normal(size=n) * 128 * 10.0 ** rng.integers(-3, 2, n)).astype(np.float32)
-        ora.ora_var_adam_step(n, ptr(var), ptr(g), ptr(m), ptr(v), it, C.c_float(lr), C.c_float(128.0))
-        gd = torch.from_numpy(g).cuda()
-        A.check(hip, hip.ngp_k_extra_dims_adam(None, n, dptr(vd), dptr(gd), dptr(md), dptr(vvd), it, C.c_float(lr), C.c_float(128.0)))
-        torch.cuda.synchronize()
-        assert np.allclose(md.cpu().numpy(), m, rtol=1e-6, atol=1e-12) and np.allclose(vvd.cpu().numpy(), v, rtol=1e-6, atol=1e-20)
-        assert np.allclose(vd.cpu().numpy(), var, rtol=0, atol=2e-6), np.abs(vd.cpu().numpy() - var).max()
 
 
 def _tinted_dataset(n_img, res, n_poses=None):

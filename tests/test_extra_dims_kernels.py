@@ -1,0 +1,214 @@
+"""Extra dims through the STRIDE-GENERIC device kernels (VERDICT r4 Weak 2): K1 writing `extra_dims[img * n]` behind each sample, K3 / K4 at the row stride 7 + n, and
+`k_extra_dims_gradient` fed by that K3 -- each against the oracle through the C-ABI's stand-alone kernels (`ngp_debug_set_extra_dims` widens the rows of
+`ngp_k_generate_training_samples` / `ngp_k_compute_loss`).
+
+Reference: testbed_nerf.cu:718-744 (extra_dims_gpu + img * n), :833 (NerfCoordinate::set_with_optional_extra_dims in K1), :1172-1175 (K3 copies the whole pitched row:
+`coords_out(j)->copy(*coords_in(j), coords_out.stride_in_bytes)`), :3010-3011 (PitchedPtr stride = 7 + n floats), :3298-3306 (fill_rollover over the pitched rows),
+:1293-1330 (compute_extra_dims_gradient_train_nerf).  What the reference's own K1 does with extra dims is pinned in tests/test_ref_kernels.py::test_k1_with_extra_dims
+(rows = the plain launch's 7 floats + the ray's image's vector): the oracle side here is therefore the plain oracle kernel + that rule.
+
+Bars: everything integer or copied is bit-exact (ray indices, counts, spans, all 7 + n columns of every K1 row and of every compacted row); K3's dL/d(output) as in
+tests/test_gpu_nerf.py (expf / powf in the last ulps); the per-image gradient sums within float reassociation (one thread per ray + atomics vs one running sum)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ngp_abi as A
+from common import dptr, half_to_f32, ptr
+from test_gpu_nerf import _rng, _run_k1, scene  # noqa: F401  (the module-scoped scene fixture and the plain K1 driver)
+
+pytestmark = pytest.mark.gpu
+
+K1_REFERENCE_LAYOUT, K1_CHUNK_KERNELS = 1, 33554432
+K3_SEQUENTIAL, K3_ONE_RAY_PER_WAVE, K3_TWO_PASS = 32, 134217728, 1048576
+
+
+def _extra(n_img, n_extra, seed=5):
+    return np.random.default_rng(seed).uniform(-1, 1, (n_img, n_extra)).astype(np.float32)
+
+
+def _run_k1_extra(hip, ora, scene, n_rays, max_samples, extra, rank=0, world=1):
+    """the device K1 with extra dims: same call as _run_k1's device half, rows of 7 + n floats, NaN-filled so that an unwritten column shows"""
+    import torch
+    from common import device_meta
+    n_img, n_extra = extra.shape
+    dev_imgs, Mh, Xh, Md, Xd = device_meta(scene["imgs"], scene["xforms"], scene["meta"], torch)
+    bfd = torch.from_numpy(scene["bf"]).cuda()
+    ex = torch.from_numpy(extra).cuda()
+    d = dict(counters=torch.zeros(2, dtype=torch.int32, device="cuda"), ray_indices=torch.zeros(n_rays, dtype=torch.int32, device="cuda"),
+             rays=torch.zeros((n_rays, 6), dtype=torch.float32, device="cuda"), numsteps=torch.zeros((n_rays, 2), dtype=torch.int32, device="cuda"),
+             coords=torch.full((max_samples, 7 + n_extra), float("nan"), dtype=torch.float32, device="cuda"), keep=(dev_imgs, Md, Xd, bfd, ex))
+    A.check(hip, hip.ngp_debug_set_extra_dims(dptr(ex), n_extra))
+    try:
+        A.check(hip, hip.ngp_k_generate_training_samples(None, n_rays, rank, world, None, A.scene_aabb(1), max_samples, None, _rng(ora), dptr(d["counters"][0:1]),
+                                                        dptr(d["counters"][1:2]), dptr(d["ray_indices"]), dptr(d["rays"]), dptr(d["numsteps"]), dptr(d["coords"]), n_img,
+                                                        dptr(Md), dptr(Xd), dptr(bfd), 0, 1, C.c_float(0.0)))
+        torch.cuda.synchronize()
+    finally:
+        A.check(hip, hip.ngp_debug_set_extra_dims(None, 0))
+    return d
+
+
+def _host(d):
+    n = int(d["counters"].cpu()[0]); total = int(d["counters"].cpu()[1])
+    return (n, total, d["ray_indices"].cpu().numpy().astype(np.uint32)[:n], d["numsteps"].cpu().numpy().astype(np.uint32)[:n], d["rays"].cpu().numpy()[:n],
+            d["coords"].cpu().numpy())
+
+
+@pytest.mark.parametrize("n_extra", [3, 16])
+@pytest.mark.parametrize("k1_flags", [K1_REFERENCE_LAYOUT, 0, K1_CHUNK_KERNELS])
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 2)])
+def test_k1_rows_carry_the_images_extra_dims(ora, hip, scene, n_extra, k1_flags, rank, world):
+    """Every device K1 (the reference-order kernel, the production segment kernels k1_count_segments / k1_write_list, the chunk kernels k1_count / k1_write) with
+    extra_dims: counters, ray indices, spans and ray geometry are those of the same kernel without extra dims bit for bit, every row's first 7 floats are the plain row's,
+    the n floats behind them are extra_dims[image_idx(ray)] -- and for the reference-order kernel the rows equal the ORACLE's rows (bit-exact coordinates) + that vector."""
+    n_rays, max_samples = 4096, 1 << 20
+    n_img = len(scene["imgs"])
+    extra = _extra(n_img, n_extra)
+    hip.ngp_debug_set_flags(k1_flags)
+    try:
+        o, p = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+        d = _run_k1_extra(hip, ora, scene, n_rays, max_samples, extra, rank, world)
+    finally:
+        hip.ngp_debug_set_flags(0)
+    n_p, tot_p, ri_p, ns_p, rays_p, co_p = _host(p)
+    n_d, tot_d, ri_d, ns_d, rays_d, co_d = _host(d)
+    assert n_d == n_p > 100 and tot_d == tot_p > 1000
+    # (the reference-order kernel reserves spans with atomics: slot order is scheduling dependent -> match by ray index; the lattice kernels are deterministic)
+    op, od = np.argsort(ri_p, kind="stable"), np.argsort(ri_d, kind="stable")
+    assert np.array_equal(ri_p[op], ri_d[od]) and np.array_equal(ns_p[op, 0], ns_d[od, 0])
+    assert np.array_equal(rays_p[op].view(np.uint32), rays_d[od].view(np.uint32))
+    if k1_flags != K1_REFERENCE_LAYOUT:
+        assert np.array_equal(ri_p, ri_d) and np.array_equal(ns_p, ns_d), "the lattice kernels' slot order and spans do not depend on the row width"
+    rows = 0
+    for a, b in zip(op, od):
+        k, bp, bd = int(ns_p[a, 0]), int(ns_p[a, 1]), int(ns_d[b, 1])
+        img = int(ri_d[b]) * n_img // n_rays   # image_idx(i, n_rays, n_rays_total, n_images) without a cdf (nerf_device.cuh:593-599)
+        assert np.array_equal(co_d[bd:bd + k, :7].view(np.uint32), co_p[bp:bp + k].view(np.uint32))
+        assert np.array_equal(co_d[bd:bd + k, 7:].view(np.uint32), np.broadcast_to(extra[img], (k, n_extra)).view(np.uint32)), (int(ri_d[b]), img)
+        rows += k
+    assert rows == tot_d
+    if k1_flags == K1_REFERENCE_LAYOUT:   # ... and against the oracle itself: the reference's float recurrence, bit for bit
+        n_o = o["ray_counter"].value
+        assert n_o == n_d and o["numsteps_counter"].value == tot_d
+        oo = np.argsort(o["ray_indices"][:n_o], kind="stable")
+        assert np.array_equal(o["ray_indices"][:n_o][oo], ri_d[od])
+        for a, b in zip(oo, od):
+            k, bo, bd = int(o["numsteps"][a, 0]), int(o["numsteps"][a, 1]), int(ns_d[b, 1])
+            assert k == int(ns_d[b, 0]) and np.array_equal(co_d[bd:bd + k, :7].view(np.uint32), o["coords"][bo:bo + k].view(np.uint32))
+
+
+def _k3_on_device_rows(ora, hip, scene, d, n_rays, n_extra, B, k3_flags, train_mode=0):
+    """K3 on the rows a device K1 wrote (stride 7 + n), device vs oracle on THE SAME inputs (the oracle reads the rows' first 7 floats).  Returns per-ray comparable results."""
+    import torch
+    n_act, total, ri, ns_in, rays, co = _host(d)
+    n_img = len(scene["imgs"])
+    rs = np.random.default_rng(1)
+    net = np.zeros((co.shape[0], 4), np.float16)
+    net[:total, :3] = rs.normal(0, 1.5, (total, 3)); net[:total, 3] = rs.normal(-1.0, 2.5, total)
+    net_u = net.view(np.uint16)
+    aabb = A.scene_aabb(1); rng = _rng(ora); bg = (C.c_float * 3)(0, 0, 0)
+    # oracle: plain 7-float rows, the device's own ray order
+    ri_full = np.zeros(n_rays, np.uint32); ri_full[:n_act] = ri
+    rays_full = np.zeros((n_rays, 6), np.float32); rays_full[:n_act] = rays
+    o_ns = np.zeros((n_rays, 2), np.uint32); o_ns[:n_act] = ns_in
+    co7 = np.ascontiguousarray(co[:, :7])
+    o_cc = np.zeros((B, 7), np.float32); o_dl = np.zeros((B, 4), np.uint16); o_loss = np.zeros(n_rays, np.float32); o_cnt = C.c_uint32()
+    ora.ora_set_train_mode(train_mode)
+    try:
+        ora.ora_k_compute_loss(n_rays, n_act, aabb, rng, B, C.c_float(128.0), bg, 0, 1, 0, n_img, scene["M"], ptr(net_u), 4, C.byref(o_cnt), ptr(ri_full), ptr(rays_full), ptr(o_ns),
+                               ptr(co7), ptr(o_cc), ptr(o_dl), 4, A.LOSS_HUBER, ptr(o_loss), A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, C.c_float(scene["mean"]), C.c_float(0.1))
+    finally:
+        ora.ora_set_train_mode(0)
+    # device: rows of 7 + n floats in and out
+    netd = torch.from_numpy(net_u.view(np.int16)).cuda()
+    cc = torch.full((B, 7 + n_extra), float("nan"), dtype=torch.float32, device="cuda"); dl = torch.zeros((B, 4), dtype=torch.int16, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda"); loss = torch.zeros(1, dtype=torch.float32, device="cuda")
+    mean = torch.tensor([scene["mean"]], dtype=torch.float32, device="cuda")
+    ns_dev = d["numsteps"].clone()
+    Md, ex = d["keep"][1], d["keep"][4]
+    A.check(hip, hip.ngp_debug_set_extra_dims(dptr(ex), n_extra)); hip.ngp_debug_set_train_mode(train_mode); hip.ngp_debug_set_flags(k3_flags)
+    try:
+        A.check(hip, hip.ngp_k_compute_loss(None, n_rays, None, aabb, rng, B, dptr(d["counters"][0:1]), C.c_float(128.0), bg, 0, 1, 0, n_img, dptr(Md), dptr(netd), 4, dptr(cnt),
+                                           dptr(d["ray_indices"]), dptr(d["rays"]), dptr(ns_dev), dptr(d["coords"]), dptr(cc), dptr(dl), 4, A.LOSS_HUBER, dptr(loss),
+                                           A.ACT_LOGISTIC, A.ACT_EXPONENTIAL, 1, dptr(mean), C.c_float(0.1)))
+        torch.cuda.synchronize()
+    finally:
+        A.check(hip, hip.ngp_debug_set_extra_dims(None, 0)); hip.ngp_debug_set_train_mode(0); hip.ngp_debug_set_flags(0)
+    return dict(n_act=n_act, ri=ri, ns_in=ns_in, co=co, o_ns=o_ns[:n_act], o_cc=o_cc, o_dl=o_dl, o_cnt=o_cnt.value, o_loss=float(o_loss.sum()),
+                ns=ns_dev.cpu().numpy().astype(np.uint32)[:n_act], cc=cc.cpu().numpy(), dl=dl.cpu().numpy().view(np.uint16), cnt=int(cnt.cpu()[0]), loss=float(loss.cpu()[0]),
+                cc_dev=cc, ns_dev=ns_dev)
+
+
+@pytest.mark.parametrize("n_extra", [3, 16])
+@pytest.mark.parametrize("train_mode,k3_flags", [(0, 0), (0, K3_ONE_RAY_PER_WAVE), (0, K3_SEQUENTIAL), (0, K3_TWO_PASS), (1, 0), (2, K3_SEQUENTIAL)])
+def test_k3_compacts_rows_of_7_plus_n_floats(ora, hip, scene, n_extra, train_mode, k3_flags):
+    """compute_loss_kernel_train_nerf at the wider row stride, all four device kernels: per ray the compacted sample count equals the oracle's, every compacted row is a
+    bit-exact copy of its K1 row INCLUDING the extra dims (testbed_nerf.cu:1172-1175 copies the pitched row), its first 7 floats equal the oracle's compacted row bit for bit,
+    dL/d(output) and the loss as for the plain stride."""
+    n_rays, max_samples, B = 2048, 1 << 19, 1 << 19
+    extra = _extra(len(scene["imgs"]), n_extra)
+    d = _run_k1_extra(hip, ora, scene, n_rays, max_samples, extra)
+    r = _k3_on_device_rows(ora, hip, scene, d, n_rays, n_extra, B, k3_flags, train_mode)
+    assert r["cnt"] == r["o_cnt"] > 1000, "same inputs: the compacted sample count is the oracle's"
+    n_cmp = 0
+    for i in range(r["n_act"]):
+        kd, bd = int(r["ns"][i, 0]), int(r["ns"][i, 1]); ko, bo = int(r["o_ns"][i, 0]), int(r["o_ns"][i, 1])
+        assert kd == ko, (i, kd, ko)
+        b_in = int(r["ns_in"][i, 1])
+        assert np.array_equal(r["cc"][bd:bd + kd].view(np.uint32), r["co"][b_in:b_in + kd].view(np.uint32)), "compacted rows = the ray's first K1 rows, all 7 + n floats"
+        assert np.array_equal(r["cc"][bd:bd + kd, :7].view(np.uint32), r["o_cc"][bo:bo + ko].view(np.uint32))
+        a, b = half_to_f32(r["dl"][bd:bd + kd]), half_to_f32(r["o_dl"][bo:bo + ko])
+        assert np.allclose(a, b, rtol=6e-3, atol=4e-6), (i, np.abs(a - b).max())   # __expf / powf vs glibc in the last ulps, half storage (tests/test_gpu_nerf.py)
+        n_cmp += kd
+    assert n_cmp == r["cnt"]
+    if k3_flags == K3_TWO_PASS:   # the deterministic variant compacts in slot order
+        assert np.array_equal(r["ns"][:, 1], np.concatenate([[0], np.cumsum(r["ns"][:, 0])[:-1]]).astype(np.uint32))
+    assert abs(r["loss"] - r["o_loss"]) <= 5e-3 * abs(r["o_loss"]) + 1e-7
+
+
+@pytest.mark.parametrize("n_extra", [3, 16])
+def test_k4_rollover_and_extra_dims_gradient_behind_k3(ora, hip, scene, n_extra):
+    """The rest of the chain on K3's real output: fill_rollover pads the compacted rows of 7 + n floats to the batch (bit-exact vs the oracle, which wraps the same rows), and
+    compute_extra_dims_gradient_train_nerf sums a per-sample dL/d(extra dims) over each compacted ray into its image's row: device kernel vs oracle on K3's own
+    ray indices / spans."""
+    import torch
+    n_rays, max_samples = 2048, 1 << 19
+    n_img = len(scene["imgs"])
+    extra = _extra(n_img, n_extra)
+    d = _run_k1_extra(hip, ora, scene, n_rays, max_samples, extra)
+    r = _k3_on_device_rows(ora, hip, scene, d, n_rays, n_extra, 1 << 19, 0)
+    n_valid = r["cnt"]
+    # K4 on the device's compacted rows; the batch is larger than the valid rows so that rows wrap more than once
+    Bpad = 3 * n_valid + 17
+    cs = 7 + n_extra
+    cc_h = np.zeros((Bpad, cs), np.float32); cc_h[:n_valid] = r["cc"][:n_valid]
+    dl_h = np.zeros((Bpad, 4), np.uint16); dl_h[:n_valid] = r["dl"][:n_valid]
+    c_o, d_o = cc_h.copy(), dl_h.copy()
+    ora.ora_k_fill_rollover(Bpad, n_valid, ptr(c_o), cs, ptr(d_o), 4)
+    ccd = torch.from_numpy(cc_h).cuda(); dld = torch.from_numpy(dl_h.view(np.int16)).cuda(); nd = torch.tensor([n_valid], dtype=torch.int32, device="cuda")
+    A.check(hip, hip.ngp_k_fill_rollover(None, Bpad, dptr(nd), dptr(ccd), cs, dptr(dld), 4))
+    torch.cuda.synchronize()
+    assert np.array_equal(ccd.cpu().numpy().view(np.uint32), c_o.view(np.uint32))
+    assert np.array_equal(dld.cpu().numpy().view(np.uint16), d_o)
+    assert np.array_equal(c_o[n_valid:2 * n_valid, 7:], c_o[:n_valid, 7:]) and np.isfinite(c_o).all()   # the wrapped rows carry their extra dims along
+    # the per-image gradient from K3's compacted rays
+    rs = np.random.default_rng(2)
+    dextra = rs.normal(0, 1, (n_valid, n_extra)).astype(np.float32)
+    ri_full = np.ascontiguousarray(r["ri"]); ns_c = np.ascontiguousarray(r["ns"])
+    want = np.zeros((n_img, n_extra), np.float32)
+    ora.ora_extra_dims_gradient(n_rays, r["n_act"], ptr(want), n_extra, n_img, ptr(ri_full), ptr(ns_c), ptr(dextra))
+    out = torch.zeros((n_img, n_extra), dtype=torch.float32, device="cuda")
+    dxd = torch.from_numpy(dextra).cuda()
+    A.check(hip, hip.ngp_k_extra_dims_gradient(None, n_rays, r["n_act"], dptr(out), n_extra, n_img, dptr(d["ray_indices"]), dptr(r["ns_dev"]), dptr(dxd), n_valid))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    # float sums of ~n_valid / n_img terms of O(1) in two association orders
+    assert np.abs(want).max() > 1 and np.allclose(got, want, rtol=1e-5, atol=1e-4), np.abs(got - want).max()
+    # ... and it is the closed form: image of a ray = ray_index * n_img // n_rays
+    ref = np.zeros((n_img, n_extra), np.float64)
+    for i in range(r["n_act"]):
+        k, b = int(r["ns"][i, 0]), int(r["ns"][i, 1])
+        ref[int(r["ri"][i]) * n_img // n_rays] += dextra[b:b + k].astype(np.float64).sum(0)
+    assert np.allclose(got, ref, rtol=0, atol=2e-4)

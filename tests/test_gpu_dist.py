@@ -228,27 +228,40 @@ def test_multi_rank_step_world2_shared_gpu():
 
 
 def test_rccl_in_library_world1(hip):
-    """ngp_comm_unique_id / ngp_comm_init / the bucketed all-reduce inside ngp_nerf_train with a communicator of ONE rank: the collectives
-    are identities, so training must equal the plain single-rank run bit for bit (same kernels, same order of the optimizer input)."""
+    """ngp_comm_unique_id / ngp_comm_init / the all-reduces inside ngp_nerf_train with a communicator of ONE rank: the collectives are identities, so training IS the plain
+    single-rank run -- asserted as what an identity is: the same ray / sample counters on every step checked and BIT-IDENTICAL parameters after 30 steps.  (The data-parallel
+    step takes the separate optimizer sweep where the plain step updates the hashed levels in k_grad_accumulate's epilogue: the two are bit-identical,
+    tests/test_gpu_train.py::test_fused_optimizer_epilogue_is_the_separate_sweep.)  The one order-dependent piece of a training step, K3's span reservation by atomics (which
+    rays the batch clamp drops, and the row order W sums over), is replaced by its deterministic two-pass variant for BOTH runs (ablation DBG_K3_TWO_PASS, slot-ordered
+    compaction): every other kernel of the step is deterministic -- K1's prefix-sum spans, the lazy K2 per ray, exact fixed-point sums in the record lists of every level, W's
+    fixed-order reduction tree, max-splat of the occupancy grid."""
     import ngp_abi as A
-    hm_a, t_a, keep_a = _setup(A, hip, 0, 1, 1 << 16)
-    hm_b, t_b, keep_b = _setup(A, hip, 0, 1, 1 << 16)
-    uid = (C.c_uint8 * 128)()
-    A.check(hip, hip.ngp_comm_unique_id(uid))
-    A.check(hip, hip.ngp_comm_init(t_b, 0, 1, uid))
-    for _ in range(3):
-        A.check(hip, hip.ngp_nerf_train(t_a, None, 10))
-        A.check(hip, hip.ngp_nerf_train(t_b, None, 10))
-        torch.cuda.synchronize()
-    sa, sb = A.NerfStats(), A.NerfStats()
-    A.check(hip, hip.ngp_nerf_get_stats(t_a, None, C.byref(sa))); A.check(hip, hip.ngp_nerf_get_stats(t_b, None, C.byref(sb)))
-    # two trainings differ by the arrival order of the dense levels' half atomics: counters agree statistically, not bit for bit
-    # (at ~1800 rays per batch one 256-ray granule of the controller is 14 % of the batch, and the compacted sample count follows the ray count)
-    assert sa.training_step == sb.training_step == 30 and abs(int(sa.rays_per_batch) - int(sb.rays_per_batch)) <= 512 + 0.1 * sa.rays_per_batch and abs(int(sa.measured_batch_size) - int(sb.measured_batch_size)) <= 0.3 * sa.measured_batch_size
-    # Adam turns every non-zero gradient into a step of ~lr, so the arrival order of the dense levels' half atomics decorrelates individual
-    # table entries between ANY two runs within tens of steps: compare the training signal, not the parameter vectors
-    print(f"rccl world-1 vs plain: loss {sb.loss:.6f} vs {sa.loss:.6f}")
-    assert np.isfinite(sb.loss) and abs(sa.loss - sb.loss) <= 0.35 * sa.loss + 1e-5
+    K3_TWO_PASS = 1048576
+    hip.ngp_debug_set_flags(K3_TWO_PASS)
+    try:
+        hm_a, t_a, keep_a = _setup(A, hip, 0, 1, 1 << 16)
+        hm_b, t_b, keep_b = _setup(A, hip, 0, 1, 1 << 16)
+        uid = (C.c_uint8 * 128)()
+        A.check(hip, hip.ngp_comm_unique_id(uid))
+        A.check(hip, hip.ngp_comm_init(t_b, 0, 1, uid))
+        sa, sb = A.NerfStats(), A.NerfStats()
+        for _ in range(3):
+            A.check(hip, hip.ngp_nerf_train(t_a, None, 10))
+            A.check(hip, hip.ngp_nerf_train(t_b, None, 10))
+            torch.cuda.synchronize()
+            A.check(hip, hip.ngp_nerf_get_stats(t_a, None, C.byref(sa))); A.check(hip, hip.ngp_nerf_get_stats(t_b, None, C.byref(sb)))
+            assert (sa.training_step, sa.rays_per_batch, sa.n_rays_last, sa.measured_batch_size) == (sb.training_step, sb.rays_per_batch, sb.n_rays_last, sb.measured_batch_size), \
+                [(s_.training_step, s_.rays_per_batch, s_.n_rays_last, s_.measured_batch_size) for s_ in (sa, sb)]
+        assert sa.training_step == 30 and sa.measured_batch_size > 0
+        pa, pb = hm_a.read("master", torch), hm_b.read("master", torch)
+        n_diff = int((pa.view(np.uint32) != pb.view(np.uint32)).sum())
+        print(f"rccl world-1 vs plain: loss {sb.loss:.8f} vs {sa.loss:.8f}; rays per batch {sb.rays_per_batch}; parameters that differ {n_diff} of {pa.size}")
+        assert n_diff == 0, f"{n_diff} of {pa.size} master parameters differ between the one-rank communicator and the plain run (max |delta| {np.abs(pa - pb).max():.3e})"
+        assert np.array_equal(hm_a.read("inference", torch), hm_b.read("inference", torch))   # EMA parameters
+        # the loss: a float sum by atomics in the plain step, an integer sum in units of 2^-24 per ray under the communicator -> equal to rounding, not bit for bit
+        assert np.isfinite(sb.loss) and abs(sa.loss - sb.loss) <= 1e-4 * sa.loss + 1e-7, (sa.loss, sb.loss)
+    finally:
+        hip.ngp_debug_set_flags(0)
     A.check(hip, hip.ngp_allreduce_gradients(t_b, None)); A.check(hip, hip.ngp_allreduce_counters(t_b, None))
     # error-proportional pixel sampling under the communicator: the ranks' error maps are summed (fp32 all-reduce) before the CDFs are built
     opts = A.default_nerf_options(1, target_batch_size=1 << 16, rank=0, world_size=1, sample_image_proportional_to_error=1, sample_focal_plane_proportional_to_error=1)

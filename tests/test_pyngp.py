@@ -524,6 +524,80 @@ def test_snapshot_carries_the_latent_optimizers(scene_dir):
     assert step < 0.9 * eo2[0]["learning_rate"], (step, eo2[0]["learning_rate"])
 
 
+def _pcg32_latents(seed, n_images, n_dims):
+    """reset_network's draws (testbed.cu:4163-4272) in plain Python: m_rng = pcg32{seed}; density_grid_rng = rng{m_rng.next_uint()}; reset_extra_dims(m_rng): per image and
+    dim random_val(rng) * 2 - 1 with random_val = pcg32::next_float = bits (next_uint() >> 9) | 0x3f800000 as a float, minus 1 [tcnn pcg32.h]"""
+    M = (1 << 64) - 1
+    st = {"s": 0, "inc": 3}
+
+    def next_uint():
+        old = st["s"]
+        st["s"] = (old * 0x5851f42d4c957f2d + st["inc"]) & M
+        xs = (((old >> 18) ^ old) >> 27) & 0xffffffff
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xffffffff
+    next_uint(); st["s"] = (st["s"] + seed) & M; next_uint()   # pcg32::seed(initstate, initseq = 1)
+    next_uint()                                                # the density grid's rng seed
+    out = np.zeros((n_images, n_dims), np.float32)
+    for i in range(n_images):
+        for j in range(n_dims):
+            f = np.array([(next_uint() >> 9) | 0x3f800000], np.uint32).view(np.float32)[0]
+            out[i, j] = (f - np.float32(1.0)) * np.float32(2.0) - np.float32(1.0)
+    return out
+
+
+@pytest.mark.gpu
+def test_latents_are_reset_network_s_draws_for_every_image_and_every_trainer(scene_dir):
+    """ADVICE r4: (i) the initial latents are the draws reset_network makes -- from m_rng BEHIND the density-grid seed (testbed.cu:4163, 4178, 4272), bit for bit;
+    (ii) every re-created trainer (reload_network_from_file, a new batch size) starts from them again -- not from the zero-filled buffers a recycled trainer address used to
+    leave --; (iii) they exist for every image of the dataset, also beyond n_images_for_training (get_extra_dims_cpu reads extra_dims_gpu for any dataset image,
+    testbed_nerf.cu:1862-1877), and the snapshot writes one optimizer per dataset image (reset_extra_dims, :3661)."""
+    import zlib
+    import msgpack
+    ngp = _ngp()
+    d = _latent_scene(scene_dir)
+    t = ngp.Testbed()
+    t.load_training_data(os.path.join(d, "transforms_train.json"))
+    t.reload_network_from_file("")
+    t.training_batch_size = 1 << 14
+    n = t.nerf.training.dataset.n_images
+    want = _pcg32_latents(1337, n, 4)
+    e0 = np.array([t.nerf.training.get_extra_dims(i) for i in range(n)], np.float32)
+    assert np.array_equal(e0.view(np.uint32), want.view(np.uint32)), (e0[:2], want[:2])
+    assert np.array_equal(np.array(t.nerf.get_rendering_extra_dims(), np.float32), want[0])
+    t.shall_train = True
+    for _ in range(12):
+        t.frame()
+    e1 = np.array([t.nerf.training.get_extra_dims(i) for i in range(n)], np.float32)
+    assert np.abs(e1 - e0).max() > 1e-4
+    assert np.array_equal(np.array(t.nerf.get_rendering_extra_dims(), np.float32), want[0]), "the default rendering dims are the COPY reset_extra_dims took of image 0's, not its trained ones"
+    for k in range(3):   # every rebuild: the reset values again (a freed trainer's address is commonly handed out again)
+        t.reload_network_from_file("")
+        e = np.array([t.nerf.training.get_extra_dims(i) for i in range(n)], np.float32)
+        assert np.array_equal(e.view(np.uint32), want.view(np.uint32)), k
+    # a training subset: the other images keep their reset values, readable and in the snapshot
+    t.nerf.training.n_images_for_training = 3
+    t.reload_network_from_file("")
+    for _ in range(6):
+        t.frame()
+    e = np.array([t.nerf.training.get_extra_dims(i) for i in range(n)], np.float32)
+    assert np.abs(e[:3] - want[:3]).max() > 1e-5 and np.array_equal(e[3:].view(np.uint32), want[3:].view(np.uint32))
+    snap = os.path.join(tempfile.mkdtemp(), "subset.ingp")
+    t.save_snapshot(snap, True)
+    eo = msgpack.unpackb(zlib.decompress(open(snap, "rb").read()), raw=False)["snapshot"]["nerf"]["extra_dims_opt"]
+    assert len(eo) == n and [o["iter"] for o in eo] == [6] * 3 + [0] * (n - 3)
+    assert all(np.array_equal(np.array(o["variable"], np.float32), e[i]) for i, o in enumerate(eo))
+    # raising the count later: the new images step from THEIR iteration 0 (one VarAdamOptimizer per image, testbed_nerf.cu:2865-2876)
+    t.nerf.training.n_images_for_training = n
+    for _ in range(4):
+        t.frame()
+    t.save_snapshot(snap, True)
+    eo = msgpack.unpackb(zlib.decompress(open(snap, "rb").read()), raw=False)["snapshot"]["nerf"]["extra_dims_opt"]
+    assert [o["iter"] for o in eo] == [10] * 3 + [4] * (n - 3)
+    e = np.array([t.nerf.training.get_extra_dims(i) for i in range(n)], np.float32)
+    assert np.abs(e[3:] - want[3:]).max() > 1e-5
+
+
 @pytest.mark.gpu
 def test_training_with_per_image_latents(scene_dir):
     """A transforms.json with `n_extra_learnable_dims` (nerf_loader.cu:482-483): the network's direction encoding takes 3 + n dims (nerf_network.h:84), every image owns a
