@@ -177,17 +177,18 @@ def test_training_step_gradients_and_input_gradient(ora, hip, n_extra):
             rep["dL_dextra"] = _rel_l2(got, dref)
             print(n_extra, vname, {k: f"{v:.1e}" for k, v in rep.items()})
             for k, v in rep.items():
-                assert v < 2e-3, (vname, k, v)
-            # the hash-grid gradient per level, the plain model's bars (tests/test_gpu_model.py::test_training_step_gradients_full_batch_and_bin_layouts): the record lists sum
-            # exactly, so the device is at least as close to the unrounded sums as the reference-order half adds are; half atomics carry the reference's own kind of error
+                assert v < 1.5e-3, (vname, k, v)   # measured <= 6.7e-4 (GPUTEST r05 batch a)
+            # the hash-grid gradient per level against the UNROUNDED sums, the plain model's bar (tests/test_gpu_model.py GRID_TRUE_TOL): the record lists sum exactly, what is
+            # left is the MLP backward's half rounding of dL/d(enc) -- measured 2.8e-4 .. 1.2e-3 per level (n_extra 3 and 16; GPUTEST r05 batch a), bound 2 x that.  (At 2^15
+            # samples few entries collide, so the reference-order chain of half adds is nearly exact as well -- `noise` 2.4e-4 .. 2.5e-3 -- and the plain test's "at least as
+            # close as the reference order" statement, made at 2^18 samples, has nothing to separate here.)  Half atomics carry the reference's own kind of error on top.
             true = {l: _rel_l2(gf[a:b], gtrue[a:b]) for l, (a, b) in levels.items()}
             print(n_extra, vname, "grid vs unrounded sums per level", {l: f"{v:.1e}" for l, v in true.items()})
             for l, v in true.items():
                 if vname == "lists":
-                    assert v <= 1.05 * noise[l] + 2e-5, (vname, l, v, noise[l])
-                    assert v < 3e-3, (vname, l, v)
+                    assert v < 2.5e-3, (vname, l, v)
                 else:
-                    assert v < 2.0 * noise[l] + 3e-3, (vname, l, v, noise[l])
+                    assert v < 2.0 * noise[l] + 2.5e-3, (vname, l, v, noise[l])
             assert np.isfinite(got).all() and np.abs(w1r[:, 32:]).max() > 0
             # per element: both sides round the same fp32 sums of 64 products to half
             assert (np.abs(got - dref) <= 2e-3 * np.abs(dref) + 1e-7).mean() > 0.99

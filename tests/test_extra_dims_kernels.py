@@ -205,10 +205,11 @@ def test_k4_rollover_and_extra_dims_gradient_behind_k3(ora, hip, scene, n_extra)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     # float sums of ~n_valid / n_img terms of O(1) in two association orders
-    assert np.abs(want).max() > 1 and np.allclose(got, want, rtol=1e-5, atol=1e-4), np.abs(got - want).max()
+    # (~n_valid / n_img terms of O(1) per element: the rounding error scales with the sum of the terms' magnitudes, not with the result -- measured 3.3e-6 of the largest sum)
+    assert np.abs(want).max() > 1 and np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
     # ... and it is the closed form: image of a ray = ray_index * n_img // n_rays
     ref = np.zeros((n_img, n_extra), np.float64)
     for i in range(r["n_act"]):
         k, b = int(r["ns"][i, 0]), int(r["ns"][i, 1])
         ref[int(r["ri"][i]) * n_img // n_rays] += dextra[b:b + k].astype(np.float64).sum(0)
-    assert np.allclose(got, ref, rtol=0, atol=2e-4)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
