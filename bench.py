@@ -536,6 +536,11 @@ def main():
     n_fused = n_params.value - n_sweep
     per_launch_bytes = {"k_inference": BYTES_PER_SAMPLE_FWD * n_inf_avg, "k_train_fwd_bwd+k_grad_bin+k_grad_accumulate": t1_bytes * args.batch + BYTES_PER_PARAM_OPT * n_fused,
                         "k_optimizer": BYTES_PER_PARAM_OPT * n_sweep}
+    fused_ms = None
+    if "k_train_fused" in kern:
+        # round 5: T1 and W are one kernel (k_train_fused); it is the front of the scatter unit (it emits dL/d(enc)) AND the weight-gradient kernel
+        fused_ms = kern["k_train_fused"][0] / kern["k_train_fused"][1]
+        kern["k_train_fwd_bwd"] = kern.pop("k_train_fused")
     if "k_grad_bin+accumulate" in kern and "k_train_fwd_bwd" in kern:
         # the scatter runs in two follow-up kernels of T1: one unit of algorithmic work, one entry of the per-step table
         t1 = kern.pop("k_train_fwd_bwd"); gb = kern.pop("k_grad_bin+accumulate")
@@ -549,7 +554,7 @@ def main():
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
     pmc = None
-    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             traffic_src = f"profiles/{fn} (separate rocprofv3 --pmc passes of this command; see the file for the correction applied)"
@@ -581,11 +586,15 @@ def main():
              "note": "K2 548 B x evaluations + scatter unit (28 + 64 + 8 + 1024) B x batch + optimizer 38 B x parameters (hashed levels: inside k_grad_accumulate's epilogue on one GPU, charged to the scatter unit; MLP + dense levels: k_optimizer) + K3/K4 38 B x evaluations; K1 (VALU bound lattice march), the occupancy-grid update and W (MFMA) move no modelled bytes"}
     flop_step = FLOP_PER_SAMPLE_FWD * n_inf_avg + FLOP_PER_SAMPLE_TRAIN * args.batch
     wg = kern.get("k_wgrad")
+    fused_mfma = ({"kernel": "k_train_fused (T1 + W: forward, dgrad, weight gradients of one batch)", "algorithmic_flop": int(FLOP_PER_SAMPLE_TRAIN * args.batch), "avg_launch_ms": round(fused_ms, 4),
+                   "achieved_tflops": round(FLOP_PER_SAMPLE_TRAIN * args.batch / (fused_ms * 1e-3) / 1e12, 2),
+                   "frac_of_2.5PF": round(FLOP_PER_SAMPLE_TRAIN * args.batch / (fused_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)} if fused_ms else None)
     mfma = {"flop_per_step": int(flop_step), "achieved_tflops": round(flop_step / (ms_step * 1e-3) / 1e12, 2), "peak_tflops": MFMA_PEAK_TFLOPS,
             "frac_of_2.5PF": round(flop_step / (ms_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "k_wgrad": ({"algorithmic_flop": int(FLOP_PER_SAMPLE_FWD * args.batch), "avg_launch_ms": round(wg[0] / wg[1], 4),
                          "achieved_tflops": round(FLOP_PER_SAMPLE_FWD * args.batch / (wg[0] / wg[1] * 1e-3) / 1e12, 2),
                          "frac_of_2.5PF": round(FLOP_PER_SAMPLE_FWD * args.batch / (wg[0] / wg[1] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)} if wg else None),
+            **({"k_train_fused": fused_mfma} if fused_mfma else {}),
             "note": "the path is gather / scatter bound: MFMA is a minor term (SURVEY 8d); counter-based MFMA busy fractions: profiles/r02_pmc_mfma*.txt"}
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -526,6 +526,9 @@ int ngp_host_sdf_signed_distance(const float* triangles_host, uint32_t n_triangl
 int ngp_debug_set_flags(uint32_t flags);
 /* The switches in effect (NGP_DEBUG_FLAGS_OR from the environment included); 0 = the production path. */
 uint32_t ngp_debug_get_flags(void);
+/* second word of ablation switches (DBG2_* of csrc/ngp_kernels.hpp; NGP_DEBUG_FLAGS2_OR): 1 = the backward pass as T1 + W, two kernels (round 4), instead of k_train_fused */
+int ngp_debug_set_flags2(uint32_t flags);
+uint32_t ngp_debug_get_flags2(void);
 /* train mode of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options) */
 int ngp_debug_set_train_mode(int mode);
 /* depth supervision of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options; testbed_nerf.cu:1027-1029, 1126-1129) */

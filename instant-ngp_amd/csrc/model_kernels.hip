@@ -62,8 +62,11 @@ DEV h8 to_frag(const f16v& d, int q, uint32_t& mask_bits) {
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
 		float v = d[8 * q + j];
-		if (RELU) { bool p = v > 0.f; mask_bits |= (p ? 1u : 0u) << (8 * q + j); v = p ? v : 0.f; }
+		if (RELU) v = v > 0.f ? v : 0.f;
 		r[j] = (_Float16)v;
+		// the ReLU state is that of the STORED (half) activation, as in tcnn's backward and the oracle (oracle/ora_model.hpp: `!(h2f(in[k]) > 0.f)`): a pre-activation in
+		// (0, 2^-25) rounds to a zero activation and passes no gradient (rounds 1-4 tested the fp32 value; k_train_fused's packed conversions test the half as well)
+		if (RELU) mask_bits |= ((float)r[j] > 0.f ? 1u : 0u) << (8 * q + j);
 	}
 	return r;
 }
@@ -1973,6 +1976,297 @@ k_wgrad2(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// T1 + W in ONE kernel (round 5; base.json's shape with the lazy K2's encoding stash): the two roles of k_wgrad2, role A also emitting what T1 emits.
+// k_wgrad2's role A already evaluates T1's whole chain (forward, dgrad down to d(density-net hidden layer)) to get its operands, so T1 was a second, separate
+// evaluation of the same chain (25 us) whose only product of its own is dL/d(enc) = W1d^T * d_h1d: here role A computes it from the d_h1d it holds (2 + 4 more
+// MFMAs per 32 samples) and stores it level-major for k_grad_bin.  The encodings come straight from K2's per-sample records (EncStashIn), no lane-linear copy
+// in between.
+// Fragment conversions (the VALU between two MFMAs was the bound of both kernels: 2,420 VALU instructions for 108 MFMAs per tile pair in k_wgrad2, i.e. 9,700 issue
+// cycles against 3,500): fp32 -> half as v_cvt_pk_f16_f32 (two elements per instruction, RNE like the scalar conversion), ReLU as v_pk_max_i16 on the half bit
+// patterns (exact: negative halfs and -0 are negative int16), the per-lane ReLU bit masks of the chain layout accumulated with v_dot2_u32_u16 over the 0/1 flags of a
+// packed pair (v_pk_min_u16(a, 1)), and gradients masked with the half-domain test `activation != 0` -- the stored forward activation, as tcnn's backward and the
+// oracle do (the scalar helpers above test the fp32 pre-activation: the two differ only for 0 < x < 2^-25, which rounds to a zero activation).
+// ---------------------------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+DEV uint32_t cvt_pk(float a, float b) { const f2v v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2)); }
+DEV uint32_t relu_pk(uint32_t h) { uint32_t r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(h)); return r; }
+DEV uint32_t flags_pk(uint32_t a) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(0x00010001u)); return r; }   // 1 per non-zero half (a >= +0 as a half: after relu_pk)
+DEV uint32_t dot2_acc(uint32_t flags, uint32_t k, uint32_t acc) { uint32_t r; asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(flags), "s"(k), "v"(acc)); return r; }
+DEV uint32_t nz_mask_pk(uint32_t a) { uint32_t r; asm("v_pk_sub_u16 %0, 0, %1" : "=v"(r) : "v"(flags_pk(a))); return r; } // 0xffff per non-zero half
+// D tile (fp32, regs 8Q .. 8Q+7) -> half fragment
+template <int Q> DEV h8 frag_plain(const f16v& d) {
+	u4v r;
+#pragma unroll
+	for (int p = 0; p < 4; ++p) r[p] = cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]);
+	return __builtin_bit_cast(h8, r);
+}
+// ... with ReLU; bits (8Q + j) of `bits` (a 16-bit field per D tile) record which elements are non-zero
+template <int Q> DEV h8 frag_relu_bits(const f16v& d, uint32_t& bits) {
+	u4v r;
+#pragma unroll
+	for (int p = 0; p < 4; ++p) {
+		r[p] = relu_pk(cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]));
+		bits = dot2_acc(flags_pk(r[p]), (1u << (8 * Q + 2 * p)) | (1u << (16 + 8 * Q + 2 * p + 1)), bits);
+	}
+	return __builtin_bit_cast(h8, r);
+}
+// ... the ReLU bits alone (the activation itself is not needed)
+template <int Q> DEV void relu_bits_only(const f16v& d, uint32_t& bits) {
+#pragma unroll
+	for (int p = 0; p < 4; ++p) bits = dot2_acc(flags_pk(relu_pk(cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]))), (1u << (8 * Q + 2 * p)) | (1u << (16 + 8 * Q + 2 * p + 1)), bits);
+}
+// ... masked by 16 ReLU bits (bit 8Q + j)
+template <int Q> DEV h8 frag_masked_bits(const f16v& d, uint32_t bits16) {
+	u4v r;
+#pragma unroll
+	for (int p = 0; p < 4; ++p) {
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe(bits16, 8 * Q + 2 * p, 1), hi = (uint32_t)__builtin_amdgcn_sbfe(bits16, 8 * Q + 2 * p + 1, 1);
+		r[p] = cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]) & __builtin_amdgcn_perm(hi, lo, 0x07060100u); // {hi.b3, hi.b2, lo.b1, lo.b0}
+	}
+	return __builtin_bit_cast(h8, r);
+}
+// swapped-layout tile (lane = neuron, regs = samples) -> two operand fragments: plain, with ReLU, or masked by the (post-ReLU) forward activation
+DEV void swf_plain(const f16v& d, h8 out[2]) { out[0] = frag_plain<0>(d); out[1] = frag_plain<1>(d); }
+DEV void swf_relu(const f16v& d, h8 out[2]) {
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		u4v r;
+#pragma unroll
+		for (int p = 0; p < 4; ++p) r[p] = relu_pk(cvt_pk(d[8 * q + 2 * p], d[8 * q + 2 * p + 1]));
+		out[q] = __builtin_bit_cast(h8, r);
+	}
+}
+DEV void swf_masked(const f16v& d, const h8 act[2], h8 out[2]) {
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		u4v r; const u4v a = __builtin_bit_cast(u4v, act[q]);
+#pragma unroll
+		for (int p = 0; p < 4; ++p) r[p] = cvt_pk(d[8 * q + 2 * p], d[8 * q + 2 * p + 1]) & nz_mask_pk(a[p]);
+		out[q] = __builtin_bit_cast(h8, r);
+	}
+}
+// the density network + the colour network's first layer in chain layout (what both roles need): hb = the colour net's first hidden activation, rin[0] = the
+// density net's output, bits of the two 64-wide ReLU layers (bit 16 mt + r of the tile register r of row tile mt)
+struct FusedFwd { h8 enc[2]; h8 rin[2]; h8 hb[4]; uint32_t m1d, m1r; };
+template <bool NEED_M1D>
+DEV void fused_fwd_to_h1r(const h8* fw, int lane, FusedFwd& st) {
+	h8 h1d[4];
+	st.m1d = 0;
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt) {
+		f16v acc = zero16();
+#pragma unroll
+		for (int s = 0; s < 2; ++s) acc = mfma(lds_frag(fw, FW_D1 + mt * 2 + s, lane), st.enc[s], acc);
+		uint32_t mb = 0;
+		if (NEED_M1D) { h1d[2 * mt] = frag_relu_bits<0>(acc, mb); h1d[2 * mt + 1] = frag_relu_bits<1>(acc, mb); st.m1d |= mb << (16 * mt); }
+		else { h8 t[2]; swf_relu(acc, t); h1d[2 * mt] = t[0]; h1d[2 * mt + 1] = t[1]; }
+	}
+	{
+		f16v acc = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) acc = mfma(lds_frag(fw, FW_D2 + s, lane), h1d[s], acc);
+		st.rin[0] = frag_plain<0>(acc);
+	}
+	st.m1r = 0;
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt) {
+		f16v acc = zero16();
+#pragma unroll
+		for (int s = 0; s < 2; ++s) acc = mfma(lds_frag(fw, FW_R1 + mt * 2 + s, lane), st.rin[s], acc);
+		uint32_t mb = 0;
+		st.hb[2 * mt] = frag_relu_bits<0>(acc, mb); st.hb[2 * mt + 1] = frag_relu_bits<1>(acc, mb);
+		st.m1r |= mb << (16 * mt);
+	}
+}
+template <int ROLE>
+DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, const float* __restrict__ p, const uint4* __restrict__ e,
+		const __half* __restrict__ dL_dy, uint32_t dy_stride, uint32_t s_raw, const h8& I0, const h8& I1, f16v dW[6], uint2* __restrict__ denc_lv, uint32_t denc_cap) {
+	FusedFwd st;
+	st.enc[0] = __builtin_bit_cast(h8, e[0]); st.enc[1] = __builtin_bit_cast(h8, e[1]);
+	__builtin_amdgcn_sched_barrier(0); // (as in T1: keeps the layers' LDS fragment loads behind the two global loads)
+	st.rin[1] = sh4_frag(p[4], p[5], p[6], hi);
+	h8 dy0 = zero8(); _Float16 dsig = (_Float16)0.f;
+	if (hi == 0 && valid) {
+		const h4 g = __builtin_bit_cast(h4, *(const uint2*)(dL_dy + (size_t)s_raw * dy_stride));
+		dy0[0] = g[0]; dy0[1] = g[1]; dy0[2] = g[2]; dsig = g[3];
+	}
+	fused_fwd_to_h1r<ROLE == 0>(fw, lane, st);
+	// swapped activations of the colour net's first hidden layer: both roles mask gradients with them
+	h8 h1r_sw[2][2];
+#pragma unroll
+	for (int kt = 0; kt < 2; ++kt) {
+		f16v t = zero16();
+#pragma unroll
+		for (int s = 0; s < 2; ++s) t = mfma(st.rin[s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
+		swf_relu(t, h1r_sw[kt]);
+	}
+	if (ROLE == 1) {
+		// ---- role B: r3 = d_out x h2r^T, r2 = d_h2 x h1r^T ----
+		h8 h2r_sw[2][2];
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) t = mfma(st.hb[s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
+			swf_relu(t, h2r_sw[kt]);
+		}
+		h8 g_sw[2];
+		{ f16v t = mfma(dy0, I0, zero16()); swf_plain(t, g_sw); }
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[4 + kt] = mfma(g_sw[q], h2r_sw[kt][q], dW[4 + kt]);
+#pragma unroll
+		for (int it = 0; it < 2; ++it) {
+			f16v dsw = mfma(dy0, lds_frag(bw, BW_R3 + it, lane), zero16());
+			h8 d2_sw[2];
+			swf_masked(dsw, h2r_sw[it], d2_sw);
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+				for (int q = 0; q < 2; ++q) dW[it * 2 + kt] = mfma(d2_sw[q], h1r_sw[kt][q], dW[it * 2 + kt]);
+		}
+		return;
+	}
+	// ---- role A: r1 = d_h1r x rin^T, d2 = d_densout x h1d^T, d1 = d_h1d x enc^T, and T1's dL/d(enc) ----
+	uint32_t m2r = 0; // ReLU state of the colour net's second hidden layer (chain layout): only the bits are needed
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt) {
+		f16v acc = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) acc = mfma(lds_frag(fw, FW_R2 + mt * 4 + s, lane), st.hb[s], acc);
+		uint32_t mb = 0;
+		relu_bits_only<0>(acc, mb); relu_bits_only<1>(acc, mb);
+		m2r |= mb << (16 * mt);
+	}
+	h8 dh[4];
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt) {
+		f16v d = mfma(lds_frag(bw, BW_R3 + mt, lane), dy0, zero16());
+		dh[2 * mt + 0] = frag_masked_bits<0>(d, m2r >> (16 * mt));
+		dh[2 * mt + 1] = frag_masked_bits<1>(d, m2r >> (16 * mt));
+	}
+	h8 dh1[4];
+	{
+		h8 rin_sw[2];
+		{ f16v t = mfma(st.rin[0], I0, zero16()); t = mfma(st.rin[1], I1, t); swf_plain(t, rin_sw); }
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			f16v d = zero16(), dsw = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				const h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
+				d = mfma(a, dh[s], d);
+				dsw = mfma(dh[s], a, dsw);
+			}
+			dh1[2 * mt + 0] = frag_masked_bits<0>(d, st.m1r >> (16 * mt));
+			dh1[2 * mt + 1] = frag_masked_bits<1>(d, st.m1r >> (16 * mt));
+			h8 d1_sw[2];
+			swf_masked(dsw, h1r_sw[mt], d1_sw);
+#pragma unroll
+			for (int q = 0; q < 2; ++q) dW[4 + mt] = mfma(d1_sw[q], rin_sw[q], dW[4 + mt]);
+		}
+	}
+	h8 ddens;
+	{
+		f16v d = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) d = mfma(lds_frag(bw, BW_R1 + s, lane), dh1[s], d);
+		ddens = frag_plain<0>(d);
+		if (hi == 0) ddens[0] = (_Float16)((float)ddens[0] + (float)dsig); // add_density_gradient (nerf_network.h:235): half add into density-net output 0
+	}
+	h8 g_sw[2];
+	{ f16v t = mfma(ddens, I0, zero16()); swf_plain(t, g_sw); }
+	h8 h1d_sw[2][2];
+#pragma unroll
+	for (int kt = 0; kt < 2; ++kt) {
+		f16v t = zero16();
+#pragma unroll
+		for (int s = 0; s < 2; ++s) t = mfma(st.enc[s], lds_frag(fw, FW_D1 + kt * 2 + s, lane), t);
+		swf_relu(t, h1d_sw[kt]);
+	}
+#pragma unroll
+	for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+		for (int q = 0; q < 2; ++q) dW[2 + kt] = mfma(g_sw[q], h1d_sw[kt][q], dW[2 + kt]);
+	h8 enc_sw[2];
+	{ f16v t = mfma(st.enc[0], I0, zero16()); t = mfma(st.enc[1], I1, t); swf_plain(t, enc_sw); }
+	h8 dh1d[4]; // chain layout: the operand of T1's last product
+#pragma unroll
+	for (int it = 0; it < 2; ++it) {
+		const h8 a = lds_frag(bw, BW_D2 + it, lane);
+		f16v dsw = mfma(ddens, a, zero16());
+		h8 dd_sw[2];
+		swf_masked(dsw, h1d_sw[it], dd_sw);
+#pragma unroll
+		for (int q = 0; q < 2; ++q) dW[0 + it] = mfma(dd_sw[q], enc_sw[q], dW[0 + it]);
+		f16v d = mfma(a, ddens, zero16());
+		dh1d[2 * it + 0] = frag_masked_bits<0>(d, st.m1d >> (16 * it));
+		dh1d[2 * it + 1] = frag_masked_bits<1>(d, st.m1d >> (16 * it));
+	}
+	// density L1^T : dL/d(enc) = W1d^T * d_h1d  (32 features = one row tile), stored level-major as T1 stores it: lane (sample, hi) owns levels 2 rr + hi
+	f16v denc = zero16();
+#pragma unroll
+	for (int s = 0; s < 4; ++s) denc = mfma(lds_frag(bw, BW_D1 + s, lane), dh1d[s], denc);
+	if (valid) {
+#pragma unroll
+		for (int rr = 0; rr < 4; ++rr) {
+			const uint2 g = {cvt_pk(denc[4 * rr + 0], denc[4 * rr + 1]), cvt_pk(denc[4 * rr + 2], denc[4 * rr + 3])};
+			denc_lv[(size_t)(2 * rr + hi) * denc_cap + s_raw] = g;
+		}
+	}
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_train_fused(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_t n, const __half* __restrict__ dL_dy, uint32_t dy_stride,
+		EncStashIn stash_in, uint2* __restrict__ denc_lv, uint32_t denc_cap, float* __restrict__ partials) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	h8* fw = (h8*)smem;
+	h8* bw = fw + N_FW_FRAGS * 64;
+	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
+	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6, role = wid >> 2, w4 = wid & 3;
+	const uint32_t wave = blockIdx.x * 4 + w4, n_waves = gridDim.x * 4; // the two roles walk the same tiles
+	f16v dW[6]; // role A: d1 (0,1), d2 (2,3), r1 (4,5) = tiles 0..5; role B: r2 (0..3), r3 (4,5) = tiles 6..11
+#pragma unroll
+	for (int t = 0; t < 6; ++t) dW[t] = zero16();
+	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
+	const uint32_t n_valid_rows = min(*stash_in.n_valid_ptr, n);
+	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) {
+		const uint32_t s_raw = ct * 32 + col;
+		const bool valid = s_raw < n;
+		uint32_t row = min(s_raw, n - 1);
+		const float* p = in + (size_t)row * in_stride;
+		if (row >= n_valid_rows) row = n_valid_rows ? row % n_valid_rows : 0u; // K4's wrap-around padding: row e is a copy of row e % n_valid
+		const uint32_t src = n_valid_rows ? stash_in.src_index[row] : 0u;
+		const uint4* e = stash_in.enc + (size_t)src * 4 + (uint32_t)hi * 2;
+		if (role == 0) fused_tile<0>(fw, bw, lane, hi, valid, p, e, dL_dy, dy_stride, s_raw, I0, I1, dW, denc_lv, denc_cap);
+		else fused_tile<1>(fw, bw, lane, hi, valid, p, e, dL_dy, dy_stride, s_raw, I0, I1, dW, denc_lv, denc_cap);
+	}
+	// reduce the 4 waves of each role through LDS (re-using the fragment region: 6 tiles * 16 regs * 64 lanes * 4 B = 24 KiB), one role at a time
+	float* red = (float*)smem;
+	float* dstp = partials + (size_t)blockIdx.x * (N_DW_TILES * 16 * 64);
+	for (int r = 0; r < 2; ++r) {
+		__syncthreads();
+		for (int w = 0; w < 4; ++w) {
+			if (role == r && w4 == w) {
+#pragma unroll
+				for (int t = 0; t < 6; ++t)
+#pragma unroll
+					for (int q = 0; q < 16; ++q) {
+						float* dst = red + ((size_t)t * 16 + q) * 64 + lane;
+						*dst = (w == 0 ? 0.f : *dst) + dW[t][q];
+					}
+			}
+			__syncthreads();
+		}
+		for (int i = threadIdx.x; i < 6 * 16 * 64; i += blockDim.x) dstp[r * 6 * 16 * 64 + i] = red[i];
+	}
+}
+
 // sum the per-block partials, un-permute the D tiles into row-major [out][in] and round to half.
 // One block per 64 consecutive elements (= one register row of a tile): 4 waves each sum a quarter of the partials with
 // coalesced 256-byte reads, then combine through LDS in a fixed order (deterministic).
@@ -2525,6 +2819,13 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 	else if (g_debug_flags & DBG_W_SINGLE_ROLE) NGP_LAUNCH_W(2);
 	else hipLaunchKernelGGL(k_wgrad2, dim3(n_partials), dim3(512), lds, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, (const uint4*)enc_stash, wgrad_partials);
 #undef NGP_LAUNCH_W
+}
+// T1 + W fused (base.json's shape, encodings from the lazy K2's stash): dL/d(enc) of every level -> denc_lv (level-major), weight-gradient partials -> wgrad_partials
+void launch_train_fused(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
+		const EncStashIn& stash_in, void* denc_lv, uint32_t denc_cap, float* wgrad_partials, uint32_t n_partials) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_train_fused, dim3(n_partials), dim3(512), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, stash_in,
+		(uint2*)denc_lv, denc_cap, wgrad_partials);
 }
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden, uint32_t n_extra) {
 	const uint32_t ex = n_extra ? 1u : 0u;

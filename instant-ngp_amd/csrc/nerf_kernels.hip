@@ -21,6 +21,7 @@ static __device__ __forceinline__ uint32_t k1_mip(const K1Args& a, float dt, f3 
 
 
 uint32_t g_debug_flags = 0;
+uint32_t g_debug_flags2 = 0;
 
 static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total) {
 	const uint32_t lane = threadIdx.x & 63u;

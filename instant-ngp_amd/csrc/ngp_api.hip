@@ -38,7 +38,7 @@ static std::vector<ProfEntry> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 static double g_prof_ms[P_COUNT]; static uint64_t g_prof_n[P_COUNT];
 static const char* kProfNames[P_COUNT] = {"k_generate_training_samples", "k_inference", "k_compute_loss", "k_fill_rollover", "k_train_fwd_bwd", "k_wgrad",
-	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters", "k_grad_bin+accumulate", "k_encode_tiles_xcd"};
+	"k_wgrad_reduce", "k_optimizer", "k_inference<density_only>", "occupancy_grid_misc", "grad_memset", "counters", "k_grad_bin+accumulate", "k_encode_tiles_xcd", "k_train_fused"};
 static hipEvent_t prof_event() {
 	if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
 	hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -118,6 +118,10 @@ static uint32_t env_debug_or() { static const uint32_t v = getenv("NGP_DEBUG_FLA
 static const bool g_debug_env_applied = [] { g_debug_flags |= env_debug_or(); return true; }();
 extern "C" int ngp_debug_set_flags(uint32_t flags) { g_debug_flags = flags | env_debug_or(); return 0; }
 extern "C" uint32_t ngp_debug_get_flags(void) { return g_debug_flags; } // what is in effect, NGP_DEBUG_FLAGS_OR included (bench.py records it: 0 = the production path)
+static uint32_t env_debug2_or() { static const uint32_t v = getenv("NGP_DEBUG_FLAGS2_OR") ? (uint32_t)strtoul(getenv("NGP_DEBUG_FLAGS2_OR"), nullptr, 0) : 0u; return v; }
+static const bool g_debug2_env_applied = [] { g_debug_flags2 |= env_debug2_or(); return true; }();
+extern "C" int ngp_debug_set_flags2(uint32_t flags) { g_debug_flags2 = flags | env_debug2_or(); return 0; }
+extern "C" uint32_t ngp_debug_get_flags2(void) { return g_debug_flags2; }
 // layout of the hashed levels' binned scatter (tuning / test hook): table entries per chunk (2^11 or 2^12), one block per chunk
 // (split = 0) or per (chunk, feature pair) (split = 1), and a list-capacity override (0 = twice the mean; small values force the
 // overflow path of k_grad_bin).  NGP_BIN_CHUNK_LOG2 / NGP_BIN_SPLIT / NGP_BIN_CAP in the environment set the defaults.
@@ -535,7 +539,12 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 	da.n_levels = 0;
 	if (ba.n_hashed && m->gm.F == 4 && (g_debug_flags & DBG_T1_DENSE_EXTERNAL) && !m->bin_dense && !(g_debug_flags & DBG_T1_NO_SCATTER))
 		for (uint32_t l = 0; l < m->gm.n_levels; ++l) { const uint64_t res = m->gm.resolution[l]; if (res * res * res <= m->gm.hashmap_size[l]) da.levels[da.n_levels++] = l; }
-	{ ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
+	// T1 + W in one kernel (round 5): base.json's shape with K2's encoding stash and every level's dL/d(enc) going through the lists -- the configuration whose T1 is the
+	// STASH instance of k_train_fwd_bwd and whose W is k_wgrad2.  Everything else (and the ablation DBG2_NO_FUSED_T1W) runs the two kernels.
+	const bool fused_t1w = stash_in && stash_in->enc && m->gm.F == 4 && m->cfg.n_hidden_layers_rgb == 2 && !m->cfg.n_extra_dims && ba.n_hashed && (da.n_levels || m->bin_dense) && !m->dextra_out
+		&& !(g_debug_flags & (DBG_T1_NO_K2_STASH | DBG_T1_OCC2 | DBG_T1_NO_SCATTER | DBG_W_SINGLE_ROLE)) && !(g_debug_flags2 & DBG2_NO_FUSED_T1W);
+	if (fused_t1w) { ProfScope ps(P_TRAIN_FUSED, s); launch_train_fused(s, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, *stash_in, m->denc_lv, m->bin_n, m->wgrad_partials, m->n_partials); }
+	else { ProfScope ps(P_T1_FWD_BWD_SCATTER, s); launch_train_fwd_bwd(s, m->gm_dev, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->grads + m->n_mlp, m->enc_stash,
 		g_debug_flags | ((da.n_levels || m->bin_dense) ? T1_DENSE_EXTERNAL : 0u), ba.n_hashed ? m->denc_lv : nullptr, m->bin_n, m->gm.F, stash_in, m->dextra_out); }
 	// fork: per-kernel profiling keeps everything on one stream so that the HIP-event times are those of isolated kernels
 	const bool overlap = ba.n_hashed && !g_prof_on && !(g_debug_flags & DBG_NO_STREAM_OVERLAP);
@@ -557,7 +566,7 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 			HIPCHK(hipEventRecord(m->ev_join2, m->side2));
 		}
 	}
-	{ ProfScope ps(P_W_WGRAD, sw); launch_wgrad(sw, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
+	if (!fused_t1w) { ProfScope ps(P_W_WGRAD, sw); launch_wgrad(sw, model_ptrs(m, false), in, in_stride, n, dL_dy, dy_stride, m->enc_stash, m->wgrad_partials, m->n_partials); }
 	{ ProfScope ps(P_WGRAD_REDUCE, sw); launch_wgrad_reduce(sw, m->wgrad_partials, m->n_partials, m->grads, m->cfg.n_hidden_layers_rgb, m->cfg.n_extra_dims); }
 	if (ba.n_hashed) {
 		ProfScope ps(P_GRAD_BIN, s);

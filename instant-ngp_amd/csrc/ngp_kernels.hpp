@@ -8,6 +8,8 @@ namespace ngp {
 
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
+extern uint32_t g_debug_flags2; // second word of ablation switches (ngp_debug_set_flags2; the 32 bits of the first are taken)
+enum : uint32_t { DBG2_NO_FUSED_T1W = 1 /* round-4 backward pass: T1 (k_train_fwd_bwd) and W (k_wgrad2) as two kernels instead of k_train_fused */ };
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_NO_HASHED_MERGE = 65536 /* k_grad_bin sums same-cell runs before the sort on the dense levels only (hashed levels: one record per sample and corner): bin + accumulate 150 -> 161 us (profiles/r02_microbench_bin_merge.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
 	DBG_K1_CHUNK_MARCH = 33554432 /* single cascade + constant step: the chunk kernels k1_count<8, true> / k1_write (production up to round 4a: every lattice point up to the ray's exit is evaluated, 64 per iteration) instead of k1_count_segments / k1_write_list */,
@@ -257,6 +259,8 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs
 void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 	const ngp_half* enc_stash, float* wgrad_partials, uint32_t n_partials);
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden = 2, uint32_t n_extra = 0);
+void launch_train_fused(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
+	const EncStashIn& stash_in, void* denc_lv, uint32_t denc_cap, float* wgrad_partials, uint32_t n_partials);
 
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a);
 
@@ -330,6 +334,6 @@ void launch_render_accumulate(hipStream_t s, uint32_t n_floats, const float* fra
 void launch_render_tonemap(hipStream_t s, uint32_t n_pixels, float* rgba, float exposure_scale, const float bg[4], int to_srgb, int curve);
 
 // ---- optional per-kernel HIP-event timing (bench.py roofline leg) -----------------------------
-enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_GRAD_BIN, P_K2_ENCODE_XCD, P_COUNT };
+enum ProfId { P_K1 = 0, P_K2_INFERENCE, P_K3, P_K4, P_T1_FWD_BWD_SCATTER, P_W_WGRAD, P_WGRAD_REDUCE, P_OPTIMIZER, P_GRID_DENSITY, P_GRID_MISC, P_GRAD_MEMSET, P_COUNTERS, P_GRAD_BIN, P_K2_ENCODE_XCD, P_TRAIN_FUSED, P_COUNT };
 
 } // namespace ngp

@@ -550,12 +550,20 @@ def test_t1_reuses_k2_encodings_bit_exact(hip, ora):
             A.check(hip, hip.ngp_nerf_train_backward(t, None))
             torch.cuda.synchronize()
             g2 = _dl(g, n.value, np.uint16)
+            # round 5: the production backward pass is ONE kernel (k_train_fused = T1 + W: role A of the weight-gradient kernel also emits dL/d(enc)); flags2 = 1
+            # (DBG2_NO_FUSED_T1W) replays the same batch through the round-4 pair k_train_fwd_bwd<STASH> + k_wgrad2: same operands, same order of every sum
+            hip.ngp_debug_set_flags(4096); hip.ngp_debug_set_flags2(1)
+            A.check(hip, hip.ngp_nerf_train_backward(t, None))
+            torch.cuda.synchronize()
+            g3 = _dl(g, n.value, np.uint16)
         finally:
-            hip.ngp_debug_set_flags(0)
+            hip.ngp_debug_set_flags(0); hip.ngp_debug_set_flags2(0)
         st = _stats(hip, t)
         assert np.count_nonzero(g1) > 1000
         bad = np.flatnonzero(g1 != g2)
         assert bad.size == 0, (steps_before, st.measured_batch_size, bad.size, bad[:8].tolist(), g1[bad[:4]].tolist(), g2[bad[:4]].tolist())
+        bad = np.flatnonzero(g1 != g3)
+        assert bad.size == 0, ("fused T1 + W vs the two kernels", steps_before, bad.size, bad[:8].tolist(), g1[bad[:4]].tolist(), g3[bad[:4]].tolist())
         A.check(hip, hip.ngp_nerf_train_finish(t, None))
     s1 = _stats(hip, t)
     assert np.isfinite(s1.loss) and s1.measured_batch_size > 0

@@ -8,7 +8,7 @@ OUT=${1:-$R/gpurun_out/pmc}
 cd /tmp; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  timeout 400 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "k_train_fwd_bwd|k_grad_bin|k_grad_accumulate|k_inference|k_optimizer|k_wgrad|k_compute_loss_v2|k1_count|k1_write" -d /tmp/pmc_$C -o p -- python $R/tools/microbench.py 1000 8 default > ${OUT}_$C.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "k_train_fused|k_train_fwd_bwd|k_grad_bin|k_grad_accumulate|k_inference|k_optimizer|k_wgrad|k_compute_loss_v2|k1_count|k1_write" -d /tmp/pmc_$C -o p -- python $R/tools/microbench.py 1000 8 default > ${OUT}_$C.log 2>&1
   python $R/tools/rocpd_pmc.py /tmp/pmc_$C/p_results.db > ${OUT}_$C.txt 2>&1
   rm -rf /tmp/pmc_$C
 done
