@@ -1989,12 +1989,13 @@ k_wgrad2(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, uint32_
 // oracle do (the scalar helpers above test the fp32 pre-activation: the two differ only for 0 < x < 2^-25, which rounds to a zero activation).
 // ---------------------------------------------------------------------------------------------
 typedef float f2v __attribute__((ext_vector_type(2)));
+typedef short s2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 DEV uint32_t cvt_pk(float a, float b) { const f2v v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2)); }
-DEV uint32_t relu_pk(uint32_t h) { uint32_t r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(h)); return r; }
-DEV uint32_t flags_pk(uint32_t a) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(0x00010001u)); return r; }   // 1 per non-zero half (a >= +0 as a half: after relu_pk)
-DEV uint32_t dot2_acc(uint32_t flags, uint32_t k, uint32_t acc) { uint32_t r; asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(flags), "s"(k), "v"(acc)); return r; }
-DEV uint32_t nz_mask_pk(uint32_t a) { uint32_t r; asm("v_pk_sub_u16 %0, 0, %1" : "=v"(r) : "v"(flags_pk(a))); return r; } // 0xffff per non-zero half
+DEV uint32_t relu_pk(uint32_t h) { const s2v z = {0, 0}; return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2v, h), z)); } // v_pk_max_i16
+// 1 per non-zero half (a >= +0 as a half: after relu_pk).  (inline asm: LLVM canonicalises umin(x, 1) to a compare + select per half, four instructions for this one)
+DEV uint32_t flags_pk(uint32_t a) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(0x00010001u)); return r; }
+DEV uint32_t nz_mask_pk(uint32_t a) { return __umul24(flags_pk(a), 0xffffu); } // 0xffff per non-zero half
 // D tile (fp32, regs 8Q .. 8Q+7) -> half fragment
 template <int Q> DEV h8 frag_plain(const f16v& d) {
 	u4v r;
@@ -2002,29 +2003,27 @@ template <int Q> DEV h8 frag_plain(const f16v& d) {
 	for (int p = 0; p < 4; ++p) r[p] = cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]);
 	return __builtin_bit_cast(h8, r);
 }
-// ... with ReLU; bits (8Q + j) of `bits` (a 16-bit field per D tile) record which elements are non-zero
+// ... with ReLU.  `bits` records which elements are non-zero, one 16-bit pattern per D tile spread over both halves of the word so that a packed pair's two flags
+// (bits 0 and 16 of flags_pk) go in with one shift-or: element 2p + h of registers 8Q .. 8Q+7 <-> bit 16 h + 4 Q + p (a second D tile of the layer sits 8 bits higher)
 template <int Q> DEV h8 frag_relu_bits(const f16v& d, uint32_t& bits) {
 	u4v r;
 #pragma unroll
 	for (int p = 0; p < 4; ++p) {
 		r[p] = relu_pk(cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]));
-		bits = dot2_acc(flags_pk(r[p]), (1u << (8 * Q + 2 * p)) | (1u << (16 + 8 * Q + 2 * p + 1)), bits);
+		bits |= flags_pk(r[p]) << (4 * Q + p);
 	}
 	return __builtin_bit_cast(h8, r);
 }
 // ... the ReLU bits alone (the activation itself is not needed)
 template <int Q> DEV void relu_bits_only(const f16v& d, uint32_t& bits) {
 #pragma unroll
-	for (int p = 0; p < 4; ++p) bits = dot2_acc(flags_pk(relu_pk(cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]))), (1u << (8 * Q + 2 * p)) | (1u << (16 + 8 * Q + 2 * p + 1)), bits);
+	for (int p = 0; p < 4; ++p) bits |= flags_pk(relu_pk(cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]))) << (4 * Q + p);
 }
-// ... masked by 16 ReLU bits (bit 8Q + j)
-template <int Q> DEV h8 frag_masked_bits(const f16v& d, uint32_t bits16) {
+// ... masked by the ReLU bits of its D tile (layout above)
+template <int Q> DEV h8 frag_masked_bits(const f16v& d, uint32_t bits) {
 	u4v r;
 #pragma unroll
-	for (int p = 0; p < 4; ++p) {
-		const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe(bits16, 8 * Q + 2 * p, 1), hi = (uint32_t)__builtin_amdgcn_sbfe(bits16, 8 * Q + 2 * p + 1, 1);
-		r[p] = cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]) & __builtin_amdgcn_perm(hi, lo, 0x07060100u); // {hi.b3, hi.b2, lo.b1, lo.b0}
-	}
+	for (int p = 0; p < 4; ++p) r[p] = cvt_pk(d[8 * Q + 2 * p], d[8 * Q + 2 * p + 1]) & __umul24((bits >> (4 * Q + p)) & 0x00010001u, 0xffffu);
 	return __builtin_bit_cast(h8, r);
 }
 // swapped-layout tile (lane = neuron, regs = samples) -> two operand fragments: plain, with ReLU, or masked by the (post-ReLU) forward activation
@@ -2048,7 +2047,7 @@ DEV void swf_masked(const f16v& d, const h8 act[2], h8 out[2]) {
 	}
 }
 // the density network + the colour network's first layer in chain layout (what both roles need): hb = the colour net's first hidden activation, rin[0] = the
-// density net's output, bits of the two 64-wide ReLU layers (bit 16 mt + r of the tile register r of row tile mt)
+// density net's output, ReLU bits of the two 64-wide layers (frag_relu_bits' layout, row tile mt shifted by 8 mt)
 struct FusedFwd { h8 enc[2]; h8 rin[2]; h8 hb[4]; uint32_t m1d, m1r; };
 template <bool NEED_M1D>
 DEV void fused_fwd_to_h1r(const h8* fw, int lane, FusedFwd& st) {
@@ -2060,7 +2059,7 @@ DEV void fused_fwd_to_h1r(const h8* fw, int lane, FusedFwd& st) {
 #pragma unroll
 		for (int s = 0; s < 2; ++s) acc = mfma(lds_frag(fw, FW_D1 + mt * 2 + s, lane), st.enc[s], acc);
 		uint32_t mb = 0;
-		if (NEED_M1D) { h1d[2 * mt] = frag_relu_bits<0>(acc, mb); h1d[2 * mt + 1] = frag_relu_bits<1>(acc, mb); st.m1d |= mb << (16 * mt); }
+		if (NEED_M1D) { h1d[2 * mt] = frag_relu_bits<0>(acc, mb); h1d[2 * mt + 1] = frag_relu_bits<1>(acc, mb); st.m1d |= mb << (8 * mt); }
 		else { h8 t[2]; swf_relu(acc, t); h1d[2 * mt] = t[0]; h1d[2 * mt + 1] = t[1]; }
 	}
 	{
@@ -2077,12 +2076,16 @@ DEV void fused_fwd_to_h1r(const h8* fw, int lane, FusedFwd& st) {
 		for (int s = 0; s < 2; ++s) acc = mfma(lds_frag(fw, FW_R1 + mt * 2 + s, lane), st.rin[s], acc);
 		uint32_t mb = 0;
 		st.hb[2 * mt] = frag_relu_bits<0>(acc, mb); st.hb[2 * mt + 1] = frag_relu_bits<1>(acc, mb);
-		st.m1r |= mb << (16 * mt);
+		st.m1r |= mb << (8 * mt);
 	}
 }
+// Roles (two wavefronts per SIMD work on the SAME 32-sample tile): role A = the density network's weight gradients (d1, d2: 4 tiles) + dL/d(enc) -- it needs the whole
+// chain, forward and backward --, role B = the colour network's (r1, r2, r3: 8 tiles), which needs the forward chain and the colour network's backward products only.
+// (k_wgrad2 gave r1 to role A: 75 MFMAs + 720 VALU instructions per tile against 39 + 250 in role B, and role A is the pole; this split is 63 / 61 MFMAs.)
+constexpr int FUSED_NT_A = 4, FUSED_NT_B = 8;
 template <int ROLE>
-DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, const float* __restrict__ p, const uint4* __restrict__ e,
-		const __half* __restrict__ dL_dy, uint32_t dy_stride, uint32_t s_raw, const h8& I0, const h8& I1, f16v dW[6], uint2* __restrict__ denc_lv, uint32_t denc_cap) {
+DEV void fused_tile(const h8* fw, const h8* bw, const h8* idf, int lane, int hi, bool valid, const float* __restrict__ p, const uint4* __restrict__ e,
+		const __half* __restrict__ dL_dy, uint32_t dy_stride, uint32_t s_raw, f16v dW[FUSED_NT_B], uint2* __restrict__ denc_lv, uint32_t denc_cap) {
 	FusedFwd st;
 	st.enc[0] = __builtin_bit_cast(h8, e[0]); st.enc[1] = __builtin_bit_cast(h8, e[1]);
 	__builtin_amdgcn_sched_barrier(0); // (as in T1: keeps the layers' LDS fragment loads behind the two global loads)
@@ -2093,45 +2096,8 @@ DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, co
 		dy0[0] = g[0]; dy0[1] = g[1]; dy0[2] = g[2]; dsig = g[3];
 	}
 	fused_fwd_to_h1r<ROLE == 0>(fw, lane, st);
-	// swapped activations of the colour net's first hidden layer: both roles mask gradients with them
-	h8 h1r_sw[2][2];
-#pragma unroll
-	for (int kt = 0; kt < 2; ++kt) {
-		f16v t = zero16();
-#pragma unroll
-		for (int s = 0; s < 2; ++s) t = mfma(st.rin[s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
-		swf_relu(t, h1r_sw[kt]);
-	}
-	if (ROLE == 1) {
-		// ---- role B: r3 = d_out x h2r^T, r2 = d_h2 x h1r^T ----
-		h8 h2r_sw[2][2];
-#pragma unroll
-		for (int kt = 0; kt < 2; ++kt) {
-			f16v t = zero16();
-#pragma unroll
-			for (int s = 0; s < 4; ++s) t = mfma(st.hb[s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
-			swf_relu(t, h2r_sw[kt]);
-		}
-		h8 g_sw[2];
-		{ f16v t = mfma(dy0, I0, zero16()); swf_plain(t, g_sw); }
-#pragma unroll
-		for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-			for (int q = 0; q < 2; ++q) dW[4 + kt] = mfma(g_sw[q], h2r_sw[kt][q], dW[4 + kt]);
-#pragma unroll
-		for (int it = 0; it < 2; ++it) {
-			f16v dsw = mfma(dy0, lds_frag(bw, BW_R3 + it, lane), zero16());
-			h8 d2_sw[2];
-			swf_masked(dsw, h2r_sw[it], d2_sw);
-#pragma unroll
-			for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-				for (int q = 0; q < 2; ++q) dW[it * 2 + kt] = mfma(d2_sw[q], h1r_sw[kt][q], dW[it * 2 + kt]);
-		}
-		return;
-	}
-	// ---- role A: r1 = d_h1r x rin^T, d2 = d_densout x h1d^T, d1 = d_h1d x enc^T, and T1's dL/d(enc) ----
-	uint32_t m2r = 0; // ReLU state of the colour net's second hidden layer (chain layout): only the bits are needed
+	// ReLU state of the colour net's second hidden layer in chain layout: only the bits are needed (both roles mask R3^T * d_out with them)
+	uint32_t m2r = 0;
 #pragma unroll
 	for (int mt = 0; mt < 2; ++mt) {
 		f16v acc = zero16();
@@ -2139,35 +2105,80 @@ DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, co
 		for (int s = 0; s < 4; ++s) acc = mfma(lds_frag(fw, FW_R2 + mt * 4 + s, lane), st.hb[s], acc);
 		uint32_t mb = 0;
 		relu_bits_only<0>(acc, mb); relu_bits_only<1>(acc, mb);
-		m2r |= mb << (16 * mt);
+		m2r |= mb << (8 * mt);
 	}
-	h8 dh[4];
-#pragma unroll
-	for (int mt = 0; mt < 2; ++mt) {
-		f16v d = mfma(lds_frag(bw, BW_R3 + mt, lane), dy0, zero16());
-		dh[2 * mt + 0] = frag_masked_bits<0>(d, m2r >> (16 * mt));
-		dh[2 * mt + 1] = frag_masked_bits<1>(d, m2r >> (16 * mt));
-	}
-	h8 dh1[4];
-	{
-		h8 rin_sw[2];
-		{ f16v t = mfma(st.rin[0], I0, zero16()); t = mfma(st.rin[1], I1, t); swf_plain(t, rin_sw); }
+	auto colour_dh = [&](h8 dh[4]) { // d(second hidden colour layer) in chain layout = ReLU-masked R3^T * d_out
 #pragma unroll
 		for (int mt = 0; mt < 2; ++mt) {
-			f16v d = zero16(), dsw = zero16();
+			f16v d = mfma(lds_frag(bw, BW_R3 + mt, lane), dy0, zero16());
+			dh[2 * mt + 0] = frag_masked_bits<0>(d, m2r >> (8 * mt));
+			dh[2 * mt + 1] = frag_masked_bits<1>(d, m2r >> (8 * mt));
+		}
+	};
+	if (ROLE == 1) {
+		// ---- role B: r3 = d_out x h2r^T, r2 = d_h2 x h1r^T, r1 = d_h1r x rin^T  (dW[0..3] = r2, dW[4..5] = r3, dW[6..7] = r1) ----
+		h8 h1r_sw[2][2]; // swapped activations of the colour net's first hidden layer
 #pragma unroll
-			for (int s = 0; s < 4; ++s) {
-				const h8 a = lds_frag(bw, BW_R2 + mt * 4 + s, lane);
-				d = mfma(a, dh[s], d);
-				dsw = mfma(dh[s], a, dsw);
+		for (int kt = 0; kt < 2; ++kt) {
+			f16v t = zero16();
+#pragma unroll
+			for (int s = 0; s < 2; ++s) t = mfma(st.rin[s], lds_frag(fw, FW_R1 + kt * 2 + s, lane), t);
+			swf_relu(t, h1r_sw[kt]);
+		}
+		{
+			h8 h2r_sw[2][2];
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt) {
+				f16v t = zero16();
+#pragma unroll
+				for (int s = 0; s < 4; ++s) t = mfma(st.hb[s], lds_frag(fw, FW_R2 + kt * 4 + s, lane), t);
+				swf_relu(t, h2r_sw[kt]);
 			}
-			dh1[2 * mt + 0] = frag_masked_bits<0>(d, st.m1r >> (16 * mt));
-			dh1[2 * mt + 1] = frag_masked_bits<1>(d, st.m1r >> (16 * mt));
+			h8 g_sw[2];
+			{ f16v t = mfma(dy0, lds_frag(idf, 0, lane), zero16()); swf_plain(t, g_sw); }
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+				for (int q = 0; q < 2; ++q) dW[4 + kt] = mfma(g_sw[q], h2r_sw[kt][q], dW[4 + kt]);
+#pragma unroll
+			for (int it = 0; it < 2; ++it) {
+				f16v dsw = mfma(dy0, lds_frag(bw, BW_R3 + it, lane), zero16());
+				h8 d2_sw[2];
+				swf_masked(dsw, h2r_sw[it], d2_sw);
+#pragma unroll
+				for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+					for (int q = 0; q < 2; ++q) dW[it * 2 + kt] = mfma(d2_sw[q], h1r_sw[kt][q], dW[it * 2 + kt]);
+			}
+		}
+		h8 rin_sw[2];
+		{ f16v t = mfma(st.rin[0], lds_frag(idf, 0, lane), zero16()); t = mfma(st.rin[1], lds_frag(idf, 1, lane), t); swf_plain(t, rin_sw); }
+		__builtin_amdgcn_sched_barrier(0); // (r1 behind r2 / r3: h2r_sw is dead before dh comes alive, 128 accumulator registers leave no room for both)
+		h8 dh[4];
+		colour_dh(dh);
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			f16v dsw = zero16();
+#pragma unroll
+			for (int s = 0; s < 4; ++s) dsw = mfma(dh[s], lds_frag(bw, BW_R2 + mt * 4 + s, lane), dsw);
 			h8 d1_sw[2];
 			swf_masked(dsw, h1r_sw[mt], d1_sw);
 #pragma unroll
-			for (int q = 0; q < 2; ++q) dW[4 + mt] = mfma(d1_sw[q], rin_sw[q], dW[4 + mt]);
+			for (int q = 0; q < 2; ++q) dW[6 + mt] = mfma(d1_sw[q], rin_sw[q], dW[6 + mt]);
 		}
+		return;
+	}
+	// ---- role A: d2 = d_densout x h1d^T, d1 = d_h1d x enc^T, and T1's dL/d(enc)  (dW[0..1] = d1, dW[2..3] = d2) ----
+	h8 dh[4];
+	colour_dh(dh);
+	h8 dh1[4];
+#pragma unroll
+	for (int mt = 0; mt < 2; ++mt) {
+		f16v d = zero16();
+#pragma unroll
+		for (int s = 0; s < 4; ++s) d = mfma(lds_frag(bw, BW_R2 + mt * 4 + s, lane), dh[s], d);
+		dh1[2 * mt + 0] = frag_masked_bits<0>(d, st.m1r >> (8 * mt));
+		dh1[2 * mt + 1] = frag_masked_bits<1>(d, st.m1r >> (8 * mt));
 	}
 	h8 ddens;
 	{
@@ -2178,7 +2189,7 @@ DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, co
 		if (hi == 0) ddens[0] = (_Float16)((float)ddens[0] + (float)dsig); // add_density_gradient (nerf_network.h:235): half add into density-net output 0
 	}
 	h8 g_sw[2];
-	{ f16v t = mfma(ddens, I0, zero16()); swf_plain(t, g_sw); }
+	{ f16v t = mfma(ddens, lds_frag(idf, 0, lane), zero16()); swf_plain(t, g_sw); }
 	h8 h1d_sw[2][2];
 #pragma unroll
 	for (int kt = 0; kt < 2; ++kt) {
@@ -2192,7 +2203,7 @@ DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, co
 #pragma unroll
 		for (int q = 0; q < 2; ++q) dW[2 + kt] = mfma(g_sw[q], h1d_sw[kt][q], dW[2 + kt]);
 	h8 enc_sw[2];
-	{ f16v t = mfma(st.enc[0], I0, zero16()); t = mfma(st.enc[1], I1, t); swf_plain(t, enc_sw); }
+	{ f16v t = mfma(st.enc[0], lds_frag(idf, 0, lane), zero16()); t = mfma(st.enc[1], lds_frag(idf, 1, lane), t); swf_plain(t, enc_sw); }
 	h8 dh1d[4]; // chain layout: the operand of T1's last product
 #pragma unroll
 	for (int it = 0; it < 2; ++it) {
@@ -2203,8 +2214,8 @@ DEV void fused_tile(const h8* fw, const h8* bw, int lane, int hi, bool valid, co
 #pragma unroll
 		for (int q = 0; q < 2; ++q) dW[0 + it] = mfma(dd_sw[q], enc_sw[q], dW[0 + it]);
 		f16v d = mfma(a, ddens, zero16());
-		dh1d[2 * it + 0] = frag_masked_bits<0>(d, st.m1d >> (16 * it));
-		dh1d[2 * it + 1] = frag_masked_bits<1>(d, st.m1d >> (16 * it));
+		dh1d[2 * it + 0] = frag_masked_bits<0>(d, st.m1d >> (8 * it));
+		dh1d[2 * it + 1] = frag_masked_bits<1>(d, st.m1d >> (8 * it));
 	}
 	// density L1^T : dL/d(enc) = W1d^T * d_h1d  (32 features = one row tile), stored level-major as T1 stores it: lane (sample, hi) owns levels 2 rr + hi
 	f16v denc = zero16();
@@ -2227,13 +2238,14 @@ k_train_fused(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, ui
 	h8* bw = fw + N_FW_FRAGS * 64;
 	load_frags_to_lds(fw, mp.fw_frags, N_FW_FRAGS);
 	load_frags_to_lds(bw, mp.bw_frags, N_BW_FRAGS);
-	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5, wid = threadIdx.x >> 6, role = wid >> 2, w4 = wid & 3;
+	h8* idf = bw + N_BW_FRAGS * 64; // the two identity fragments (transposes through the MFMA) live in LDS like the weights: 8 registers less per lane
+	if (wid < 2) idf[wid * 64 + lane] = ident_frag(wid, lane);
+	__syncthreads();
 	const uint32_t wave = blockIdx.x * 4 + w4, n_waves = gridDim.x * 4; // the two roles walk the same tiles
-	f16v dW[6]; // role A: d1 (0,1), d2 (2,3), r1 (4,5) = tiles 0..5; role B: r2 (0..3), r3 (4,5) = tiles 6..11
+	f16v dW[FUSED_NT_B]; // role A: d1 (0,1), d2 (2,3) = tiles 0..3 of the partials; role B: r2 (0..3), r3 (4,5), r1 (6,7) = tiles 6..9, 10..11, 4..5
 #pragma unroll
-	for (int t = 0; t < 6; ++t) dW[t] = zero16();
-	const h8 I0 = ident_frag(0, lane), I1 = ident_frag(1, lane);
+	for (int t = 0; t < FUSED_NT_B; ++t) dW[t] = zero16();
 	const uint32_t n_valid_rows = min(*stash_in.n_valid_ptr, n);
 	for (uint32_t ct = wave; (uint64_t)ct * 32 < n; ct += n_waves) {
 		const uint32_t s_raw = ct * 32 + col;
@@ -2243,27 +2255,34 @@ k_train_fused(ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride, ui
 		if (row >= n_valid_rows) row = n_valid_rows ? row % n_valid_rows : 0u; // K4's wrap-around padding: row e is a copy of row e % n_valid
 		const uint32_t src = n_valid_rows ? stash_in.src_index[row] : 0u;
 		const uint4* e = stash_in.enc + (size_t)src * 4 + (uint32_t)hi * 2;
-		if (role == 0) fused_tile<0>(fw, bw, lane, hi, valid, p, e, dL_dy, dy_stride, s_raw, I0, I1, dW, denc_lv, denc_cap);
-		else fused_tile<1>(fw, bw, lane, hi, valid, p, e, dL_dy, dy_stride, s_raw, I0, I1, dW, denc_lv, denc_cap);
+		if (role == 0) fused_tile<0>(fw, bw, idf, lane, hi, valid, p, e, dL_dy, dy_stride, s_raw, dW, denc_lv, denc_cap);
+		else fused_tile<1>(fw, bw, idf, lane, hi, valid, p, e, dL_dy, dy_stride, s_raw, dW, denc_lv, denc_cap);
 	}
-	// reduce the 4 waves of each role through LDS (re-using the fragment region: 6 tiles * 16 regs * 64 lanes * 4 B = 24 KiB), one role at a time
+	// reduce the 4 waves of each role through LDS (re-using the fragment region: <= 8 tiles * 16 regs * 64 lanes * 4 B = 32 KiB), one role at a time, in a fixed order
 	float* red = (float*)smem;
 	float* dstp = partials + (size_t)blockIdx.x * (N_DW_TILES * 16 * 64);
 	for (int r = 0; r < 2; ++r) {
+		const int nt = r == 0 ? FUSED_NT_A : FUSED_NT_B;
 		__syncthreads();
 		for (int w = 0; w < 4; ++w) {
 			if (role == r && w4 == w) {
 #pragma unroll
-				for (int t = 0; t < 6; ++t)
+				for (int t = 0; t < FUSED_NT_B; ++t) {
+					if (t >= nt) break;
 #pragma unroll
 					for (int q = 0; q < 16; ++q) {
 						float* dst = red + ((size_t)t * 16 + q) * 64 + lane;
 						*dst = (w == 0 ? 0.f : *dst) + dW[t][q];
 					}
+				}
 			}
 			__syncthreads();
 		}
-		for (int i = threadIdx.x; i < 6 * 16 * 64; i += blockDim.x) dstp[r * 6 * 16 * 64 + i] = red[i];
+		// partial tile order (k_wgrad_reduce): d1 (0,1), d2 (2,3), r1 (4,5), r2 (6..9), r3 (10,11)
+		for (int i = threadIdx.x; i < nt * 16 * 64; i += blockDim.x) {
+			const int t = i / (16 * 64), dst_t = r == 0 ? t : (t < 6 ? 6 + t : t - 2);
+			dstp[dst_t * 16 * 64 + (i % (16 * 64))] = red[i];
+		}
 	}
 }
 
@@ -2824,7 +2843,7 @@ void launch_wgrad(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t 
 void launch_train_fused(hipStream_t s, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride,
 		const EncStashIn& stash_in, void* denc_lv, uint32_t denc_cap, float* wgrad_partials, uint32_t n_partials) {
 	if (n == 0) return;
-	hipLaunchKernelGGL(k_train_fused, dim3(n_partials), dim3(512), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, stash_in,
+	hipLaunchKernelGGL(k_train_fused, dim3(n_partials), dim3(512), (N_FW_FRAGS + N_BW_FRAGS + 2) * 1024, s, mp, in, in_stride, n, (const __half*)dL_dy, dy_stride, stash_in,
 		(uint2*)denc_lv, denc_cap, wgrad_partials);
 }
 void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partials, ngp_half* mlp_grad, uint32_t n_rgb_hidden, uint32_t n_extra) {
