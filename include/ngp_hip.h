@@ -404,6 +404,21 @@ int ngp_comm_init(ngp_nerf*, uint32_t rank, uint32_t world_size, const uint8_t i
 int ngp_comm_destroy(ngp_nerf*);
 int ngp_allreduce_gradients(ngp_nerf*, void* stream);
 int ngp_allreduce_counters(ngp_nerf*, void* stream);
+/* Sharded data-parallel step (round 5): from two ranks on, ngp_nerf_train under an ngp_comm_init communicator runs reduce-scatter(fp16 gradients, two
+ * buckets of whole levels: the first one beside the second one's accumulation) -> Adam on THIS rank's 1 / world_size piece of each bucket (+ the replicated MLP, whose
+ * 20 KB of gradients are all-reduced) -> all-gather of the new half parameters -> EMA / inference copy of the foreign pieces from the gathered parameters.
+ * NGP_DP_ALLREDUCE=1 keeps the all-reduce + replicated-sweep step of rounds 2-4.  There is no counterpart in the reference (it has no multi-GPU training).
+ *   ngp_nerf_dp_set_sharded / ngp_nerf_dp_layout / ngp_nerf_train_finish_sharded: for callers that run the collectives themselves (as with ngp_nerf_train_forward /
+ *     _backward / ngp_nerf_counter_ptrs): set_sharded computes the layout (fails if a bucket does not divide into world_size pieces of whole entries); layout returns the
+ *     two buckets' parameter ranges [begin, end) -- rank r owns [begin + r * (end - begin) / world, ... + (end - begin) / world) of each; after the backward pass the caller
+ *     sums the MLP gradients [0, n_mlp) over all ranks and each rank's pieces over all ranks (reduce-scatter), calls finish_sharded(phase 0) = the local Adam step,
+ *     all-gathers the half parameters of the pieces, and calls finish_sharded(phase 1) = foreign EMA + the rest of ngp_nerf_train_finish.
+ *   ngp_nerf_dp_gather_state: COLLECTIVE -- the fp32 master parameters, Adam moments and step counters of every rank's own pieces to all ranks (only the half parameters
+ *     and the inference copy are kept current everywhere); call on every rank before reading parameters / serialising a sharded run. */
+int ngp_nerf_dp_set_sharded(ngp_nerf*, int on);
+int ngp_nerf_dp_layout(ngp_nerf*, uint64_t begin[2], uint64_t end[2]);
+int ngp_nerf_train_finish_sharded(ngp_nerf*, void* stream, int phase);
+int ngp_nerf_dp_gather_state(ngp_nerf*, void* stream);
 /* Three uint32 {measured_before_compaction, measured, this rank's loss sum in units of 2^-24} to all-reduce(sum) across ranks (8e):
  * every rank then derives the same next rays_per_batch and reports the loss of the union batch. */
 int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters3);

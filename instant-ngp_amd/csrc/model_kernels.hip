@@ -1382,7 +1382,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	static_assert(!ADAM || (F == 4 && !SPLIT), "the fused optimizer epilogue exists for the production layout (F = 4, one block per chunk)");
 	constexpr uint32_t E = 1u << CL2, NF = SPLIT ? 2u : (uint32_t)F;
 	__shared__ unsigned long long acc[E * NF];
-	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y, fp = SPLIT ? blockIdx.z : 0u, level = a.levels[ly];
+	const uint32_t tid = threadIdx.x, c = blockIdx.x, ly = blockIdx.y + a.acc_ly_begin, fp = SPLIT ? blockIdx.z : 0u, level = a.levels[ly];
 	const uint32_t hs = a.gm->hashmap_size[level], offset = a.gm->offset[level];
 	constexpr uint32_t NCH_LOG2 = GRAD_BIN_MAX_TABLE_LOG2 - CL2;
 	const uint64_t res = a.gm->resolution[level];
@@ -2589,8 +2589,11 @@ __global__ void k_build_frags(const __half* __restrict__ mlp_params, uint32_t n_
 	if (bw) bw[bw_perm[p]] = v;
 }
 
+// Sweeps parameters [a.range_begin, a.n_params) (both multiples of 4).  a.ema_only: the Adam step of this range ran elsewhere and the new half parameters are in place
+// (sharded data-parallel step: another rank owns the range and its parameters arrived by all-gather) -- only the EMA / inference copy is advanced and the consumed
+// gradients are cleared.
 __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
-	const uint64_t i4 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t i4 = a.range_begin / 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t i = i4 * 4;
 	if (i >= a.n_params) return;
 	const bool matrix = i < a.n_mlp; // n_mlp is a multiple of 4
@@ -2604,6 +2607,7 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 		upd[k] = matrix ? (a.optimize_matrix != 0) : (a.optimize_non_matrix != 0 && g[k] != 0.f);
 		any |= upd[k];
 	}
+	if (a.ema_only) any = false;
 	if (any) {
 		float4 mw = ((const float4*)a.master)[i4], m4 = ((const float4*)a.m)[i4], v4 = ((const float4*)a.v)[i4];
 		uint2 st = ((const uint2*)a.steps)[i4];
@@ -2742,41 +2746,55 @@ void launch_build_frags(hipStream_t s, const ngp_half* mlp_params, uint32_t n_ml
 }
 uint32_t wgrad_n_partials() { return (uint32_t)num_cus(); }
 #define REQUIRE_VOID(c) do { if (!(c)) { fprintf(stderr, "launch_grad_bin: unsupported layout (%s)\n", #c); abort(); } } while (0)
-void launch_grad_bin(hipStream_t s, const GradBinArgs& a) {
-	if (a.n == 0 || a.n_hashed == 0) return;
+// what: bit 0 = k_grad_bin (every listed level), bit 1 = k_grad_accumulate over the listed levels [a.acc_ly_begin, a.acc_ly_begin + a.acc_ly_count) (count 0 = all of them).
+// The sharded data-parallel step accumulates in two launches so that the first bucket's reduce-scatter runs beside the second launch.
+void launch_grad_bin(hipStream_t s, const GradBinArgs& a_in, uint32_t what) {
+	if (a_in.n == 0 || a_in.n_hashed == 0) return;
+	GradBinArgs a = a_in;
+	if (a.acc_ly_count == 0) { a.acc_ly_begin = 0; a.acc_ly_count = a.n_hashed; }
+	const bool do_bin = (what & 1u) != 0, do_acc = (what & 2u) != 0;
+	const uint32_t ny = a.acc_ly_count;
 	static const uint32_t ns = getenv("NGP_BIN_SAMPLES") ? (uint32_t)atoi(getenv("NGP_BIN_SAMPLES")) : 512u;
 	const dim3 gb((a.n + ns - 1) / ns, a.n_hashed);
 	if (a.n_features == 2 && a.n_pos_dims == 2) { // the image primitive's grid (encmlp trainer): 4 corners per sample
 		REQUIRE_VOID(a.chunk_log2 == 12);
-		hipLaunchKernelGGL((k_grad_bin<12, 512, 2, 256, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
-		hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		if (do_bin) hipLaunchKernelGGL((k_grad_bin<12, 512, 2, 256, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
+		if (do_acc) hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
 		return;
 	}
 	if (a.n_features == 2) { // L = 16, F = 2: one block per chunk, both features (4-byte record values)
 		if (a.chunk_log2 == 11) {
-			hipLaunchKernelGGL((k_grad_bin<11, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
-			hipLaunchKernelGGL((k_grad_accumulate<11, false, 2>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+			if (do_bin) hipLaunchKernelGGL((k_grad_bin<11, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
+			if (do_acc) hipLaunchKernelGGL((k_grad_accumulate<11, false, 2>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
 		} else {
-			hipLaunchKernelGGL((k_grad_bin<12, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
-			hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+			if (do_bin) hipLaunchKernelGGL((k_grad_bin<12, 512, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
+			if (do_acc) hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
 		}
 		return;
 	}
 	if (a.chunk_log2 == 11) {
-		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<11, 256>), gb, dim3(256), 0, s, a);
-		else hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
-		if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<11, false, 4, true>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
-		else if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
-		else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		if (do_bin) {
+			if (ns == 256) hipLaunchKernelGGL((k_grad_bin<11, 256>), gb, dim3(256), 0, s, a);
+			else hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
+		}
+		if (do_acc) {
+			if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<11, false, 4, true>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
+			else if (a.split) hipLaunchKernelGGL((k_grad_accumulate<11, true>), dim3(a.max_chunks, ny, 2), dim3(1024), 0, s, a);
+			else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
+		}
 	} else {
 		static const uint32_t bin_threads = getenv("NGP_BIN_THREADS") ? (uint32_t)atoi(getenv("NGP_BIN_THREADS")) : 512u; // 256: the round-2 shape (ablation)
-		if (ns == 256) hipLaunchKernelGGL((k_grad_bin<12, 256>), gb, dim3(256), 0, s, a);
-		// (1024 samples / threads per block -- twice the run length, half the cursor atomics, but one 100 KiB block per CU: unit 0.150 -> 0.164 ms, rejected)
-		else if (bin_threads == 512) hipLaunchKernelGGL((k_grad_bin<12, 512, 4, 512>), gb, dim3(512), 0, s, a);
-		else hipLaunchKernelGGL((k_grad_bin<12, 512>), gb, dim3(256), 0, s, a);
-		if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<12, false, 4, true>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
-		else if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, a.n_hashed, 2), dim3(1024), 0, s, a);
-		else hipLaunchKernelGGL((k_grad_accumulate<12, false>), dim3(a.max_chunks, a.n_hashed, 1), dim3(1024), 0, s, a);
+		if (do_bin) {
+			if (ns == 256) hipLaunchKernelGGL((k_grad_bin<12, 256>), gb, dim3(256), 0, s, a);
+			// (1024 samples / threads per block -- twice the run length, half the cursor atomics, but one 100 KiB block per CU: unit 0.150 -> 0.164 ms, rejected)
+			else if (bin_threads == 512) hipLaunchKernelGGL((k_grad_bin<12, 512, 4, 512>), gb, dim3(512), 0, s, a);
+			else hipLaunchKernelGGL((k_grad_bin<12, 512>), gb, dim3(256), 0, s, a);
+		}
+		if (do_acc) {
+			if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<12, false, 4, true>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
+			else if (a.split) hipLaunchKernelGGL((k_grad_accumulate<12, true>), dim3(a.max_chunks, ny, 2), dim3(1024), 0, s, a);
+			else hipLaunchKernelGGL((k_grad_accumulate<12, false>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
+		}
 	}
 }
 void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n,
@@ -2851,7 +2869,8 @@ void launch_wgrad_reduce(hipStream_t s, const float* partials, uint32_t n_partia
 	hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_dw_tiles((int)n_rgb_hidden) + 2 * ex) * 16), dim3(1024), 0, s, partials, n_partials, (__half*)mlp_grad, n_rgb_hidden, ex);
 }
 void launch_optimizer_step(hipStream_t s, const AdamArgs& a) {
-	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)((a.n_params / 4 + 255) / 256)), dim3(256), 0, s, a);
+	if (a.n_params <= a.range_begin) return;
+	hipLaunchKernelGGL(k_optimizer, dim3((uint32_t)(((a.n_params - a.range_begin) / 4 + 255) / 256)), dim3(256), 0, s, a);
 }
 
 } // namespace ngp

@@ -165,8 +165,8 @@ static int create_helper_stream(hipStream_t* st, bool high_priority) {
 // neither adds hardware queues -- two trainers with their own streams ran the second one at 1.17 instead of 0.78 ms per step,
 // profiles/r03_bench_n1_slow_box.json -- nor creates streams behind a communicator that exists by then.  ngp_init() creates them explicitly for hosts
 // that set up communication before their first model.
-static hipStream_t g_side_stream = nullptr, g_side2_stream = nullptr, g_k1_stream = nullptr;
-static int ensure_helper_streams() { return create_helper_stream(&g_side_stream, false) || create_helper_stream(&g_k1_stream, true); }
+static hipStream_t g_side_stream = nullptr, g_side2_stream = nullptr, g_k1_stream = nullptr, g_comm_stream = nullptr;
+static int ensure_helper_streams() { return create_helper_stream(&g_side_stream, false) || create_helper_stream(&g_k1_stream, true) || create_helper_stream(&g_comm_stream, true); }
 extern "C" int ngp_init(void) {
 	REQUIRE(ngp_device_available(), "no HIP device visible: libngp_hip has no CPU fallback");
 	return ensure_helper_streams();
@@ -249,6 +249,9 @@ struct ngp_model {
 	hipStream_t side = nullptr, side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
 	// data-parallel step: events that mark the two gradient buckets final (recorded when record_bucket_events is set, see ngp_comm_*)
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
+	// sharded data-parallel step (round 5): k_grad_accumulate runs in two launches -- the first dp_split_ly listed levels (bucket A), then the rest (bucket B) -- and
+	// ev_bucket_a marks bucket A's gradients final on the caller's stream, so that its reduce-scatter runs beside bucket B's accumulation (0 = one launch, no event)
+	uint32_t dp_split_level = 0; hipEvent_t ev_bucket_a = nullptr; bool dp_split_done = false /* the last training step accumulated in two launches and recorded ev_bucket_a */;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
 	bool adam_fused_pending = false; uint64_t adam_sweep_end = 0, last_sweep_params = 0; // this step's k_grad_accumulate has already applied the optimizer to the hashed levels: the sweep covers [0, adam_sweep_end) only
@@ -382,6 +385,7 @@ extern "C" void ngp_model_destroy(ngp_model* m) {
 	if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
 	if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
 	if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+	if (m->ev_bucket_a) (void)hipEventDestroy(m->ev_bucket_a);
 	if (m->ev_hashed_ready) (void)hipEventDestroy(m->ev_hashed_ready);
 	if (m->ev_mlp_ready) (void)hipEventDestroy(m->ev_mlp_ready);
 	delete m;
@@ -586,7 +590,18 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 				m->adam_fused_pending = true; m->adam_sweep_end = first_hashed;
 			}
 		}
-		launch_grad_bin(s, ba);
+		uint32_t split_ly = 0; // listed levels below the bucket boundary
+		if (m->dp_split_level) for (uint32_t k = 0; k < ba.n_hashed; ++k) if (ba.levels[k] < m->dp_split_level) ++split_ly;
+		m->dp_split_done = false;
+		if (split_ly > 0 && split_ly < ba.n_hashed && !ba.fuse_adam && !g_prof_on) {
+			if (!m->ev_bucket_a) HIPCHK(hipEventCreateWithFlags(&m->ev_bucket_a, hipEventDisableTiming));
+			launch_grad_bin(s, ba, 1u);
+			ba.acc_ly_begin = 0; ba.acc_ly_count = split_ly; launch_grad_bin(s, ba, 2u);
+			HIPCHK(hipEventRecord(m->ev_bucket_a, s));
+			ba.acc_ly_begin = split_ly; ba.acc_ly_count = ba.n_hashed - split_ly; launch_grad_bin(s, ba, 2u);
+			ba.acc_ly_begin = ba.acc_ly_count = 0;
+			m->dp_split_done = true;
+		} else launch_grad_bin(s, ba);
 		if (da.n_levels && !overlap) launch_grad_dense(s, da); // profiling / single-stream mode: part of the same scope (one unit of algorithmic work)
 	}
 	if (da.n_levels && overlap) HIPCHK(hipStreamWaitEvent(sw, m->ev_join2, 0)); // bucket A (MLP + dense levels) is final behind W's stream from here on
@@ -1425,6 +1440,10 @@ struct ngp_nerf {
 	uint32_t* sync2 = nullptr; // {measured_before, measured, loss sum in units of 2^-24} for the cross-rank all-reduce (4 words allocated)
 	// in-library data-parallel step over RCCL (ngp_comm_init): communicator, its stream, bucket-reduced events
 	void* comm = nullptr; hipStream_t comm_stream = nullptr; hipEvent_t ev_red_a = nullptr, ev_red_b = nullptr; bool grads_pending = false;
+	// Sharded data-parallel step (round 5): the hash table's parameters [dp_begin[b], dp_end[b]) of bucket b = 0, 1 (level groups) are cut into world_size equal
+	// pieces; rank r owns piece r of both buckets: it receives their summed gradients (reduce-scatter), runs Adam on them and hands the new half parameters to everybody
+	// (all-gather).  The MLP (10,240 parameters) stays replicated (its gradients are all-reduced).  dp_sharded = the layout exists and the mode is on.
+	bool dp_sharded = false; uint64_t dp_begin[2] = {0, 0}, dp_end[2] = {0, 0}; hipEvent_t ev_rs_a = nullptr; AdamArgs dp_adam; /* this step's optimizer arguments (local part -> tail) */
 	// error-proportional pixel sampling (testbed.h:745-756, 810-815; off unless one of the option switches is set)
 	float* error_map = nullptr; size_t error_map_cap = 0; int32_t error_map_res[2] = {0, 0};
 	float* cdf_x_cond_y = nullptr; float* cdf_y = nullptr; float* cdf_img = nullptr; size_t cdf_xy_cap = 0, cdf_y_cap = 0, cdf_img_cap = 0; int32_t cdf_res[2] = {0, 0}; bool cdf_valid = false;
@@ -1854,10 +1873,12 @@ __global__ void k_import_sync(TrainCounters* c, const uint32_t* sync2, uint32_t 
 }
 
 // optimizer_step + NerfCounters::update_after_training, testbed_nerf.cu:2770-2778
-extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) {
+static int nerf_finish_impl(ngp_nerf* t, void* stream, bool run_optimizer);
+extern "C" int ngp_nerf_train_finish(ngp_nerf* t, void* stream) { return nerf_finish_impl(t, stream, true); }
+static int nerf_finish_impl(ngp_nerf* t, void* stream, bool run_optimizer) {
 	hipStream_t s = (hipStream_t)stream;
 	if (t->grads_pending) { HIPCHK(hipStreamWaitEvent(s, t->ev_red_a, 0)); HIPCHK(hipStreamWaitEvent(s, t->ev_red_b, 0)); t->grads_pending = false; }
-	if (ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
+	if (run_optimizer && ngp_model_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 	if (t->n_extra && t->optimize_extra_dims) // testbed_nerf.cu:2860-2878: one VarAdamOptimizer step per image at the network optimizer's current learning rate
 		{ launch_extra_dims_adam(s, t->n_images * t->n_extra, t->extra_dims, t->extra_grad, t->extra_m, t->extra_v, 0, t->model->lr, t->opt.loss_scale, t->extra_iter, t->n_extra); t->extra_lr_last = t->model->lr; }
 	if (!t->ctl_done) { // the controller has not run behind K3 (multi-rank caller using ngp_nerf_train_forward_backward)
@@ -1884,6 +1905,9 @@ struct RcclApi {
 	int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
 	int (*CommDestroy)(void*) = nullptr;
 	int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+	int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr; // (sendbuff, recvbuff, recvcount, datatype, op, comm, stream)
+	int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;           // (sendbuff, recvbuff, sendcount, datatype, comm, stream)
+	int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -1897,6 +1921,9 @@ static int rccl_load() {
 	g_rccl.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(h, "ncclCommInitRank");
 	g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
 	g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+	g_rccl.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclReduceScatter");
+	g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+	g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart"); g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
 	g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
 	if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) return fail("librccl: missing symbols");
 	g_rccl.lib = h;
@@ -1905,6 +1932,85 @@ static int rccl_load() {
 #define RCCLCHK(x) do { int r_ = (x); if (r_ != 0) return fail(std::string(#x) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); } while (0)
 constexpr int kNcclUint32 = 3, kNcclHalf = 6, kNcclSum = 0; // ncclDataType_t / ncclRedOp_t values of rccl.h
 
+// ---- sharded data-parallel step (round 5) ------------------------------------------------------------------------------------------------------------------
+// Rounds 2-4: all-reduce(fp16 gradients) -> the full optimizer sweep replicated on every rank (38 B x P of memory traffic per rank and step, 63 us, and one 23.4 MB ring
+// that starts behind the last kernel of the backward pass).  Now: the table is cut into two buckets of whole levels (A = the coarse half of the entries, B = the rest);
+// bucket A's reduce-scatter starts when ITS levels are accumulated and runs beside bucket B's accumulation; every rank runs Adam on its 1/G piece of both buckets
+// only (+ the replicated 10,240-parameter MLP, whose gradients are all-reduced: 20 KB) and all-gathers the new half parameters, which the next step's K1 (it needs no
+// parameters) overlaps; the EMA / inference copy of the foreign pieces is advanced locally from the gathered parameters (12 B x P instead of 38 B x P).
+// Same bytes on the wire as the all-reduce (a ring all-reduce IS reduce-scatter + all-gather), less of them exposed, 1/G of the Adam state touched per rank.
+// Per-rank optimizer state (fp32 master, Adam moments, step counters) of the FOREIGN pieces goes stale: ngp_nerf_dp_gather_state (collective) refreshes it before a
+// snapshot / parameter read-back.
+static int dp_setup_sharded(ngp_nerf* t, bool on) {
+	ngp_model* m = t->model;
+	t->dp_sharded = false; m->dp_split_level = 0;
+	if (!on) return 0;
+	const uint32_t W = t->opt.world_size, L = m->gm.n_levels, F = m->gm.F;
+	REQUIRE(L >= 2, "sharded data-parallel step: the table has one level");
+	const uint64_t total = m->gm.offset[L]; // entries
+	// Bucket boundary = half of the LEVELS: k_grad_accumulate runs one block per (chunk, level) with the same number of chunks on every level and one 128 KiB block per CU,
+	// so two launches of L / 2 levels each keep whole rounds of blocks (base.json: 2 x 512 blocks on 256 CUs), where a split by bytes (5 + 3 levels: 2.5 + 1.5 rounds)
+	// cost 25 us of tails (profiles/r05_dp_sharded_world1.json).  Bucket A is then the smaller one (28 % of the entries): its exchange fits beside bucket B's accumulation.
+	const uint32_t ka = L / 2;
+	const uint64_t b0 = m->n_mlp, b1 = m->n_mlp + (uint64_t)m->gm.offset[ka] * F, b2 = m->n_mlp + total * F;
+	REQUIRE(b2 == m->n_params, "sharded data-parallel step: parameter layout");
+	REQUIRE((b1 - b0) % (4ull * W) == 0 && (b2 - b1) % (4ull * W) == 0, "sharded data-parallel step: a bucket does not divide into world_size pieces of whole entries (falls back to the all-reduce step)");
+	t->dp_begin[0] = b0; t->dp_end[0] = b1; t->dp_begin[1] = b1; t->dp_end[1] = b2;
+	m->dp_split_level = (getenv("NGP_DP_NO_SPLIT") && atoi(getenv("NGP_DP_NO_SPLIT")) != 0) ? 0u : ka; // (ablation: one accumulate launch, both buckets' exchange on the caller's stream)
+	if (!t->ev_rs_a) HIPCHK(hipEventCreateWithFlags(&t->ev_rs_a, hipEventDisableTiming));
+	t->dp_sharded = true;
+	return 0;
+}
+extern "C" int ngp_nerf_dp_set_sharded(ngp_nerf* t, int on) { REQUIRE(t, "null trainer"); return dp_setup_sharded(t, on != 0); }
+extern "C" int ngp_nerf_dp_layout(ngp_nerf* t, uint64_t begin[2], uint64_t end[2]) {
+	REQUIRE(t && begin && end, "ngp_nerf_dp_layout: null argument");
+	for (int b = 0; b < 2; ++b) { begin[b] = t->dp_sharded ? t->dp_begin[b] : 0; end[b] = t->dp_sharded ? t->dp_end[b] : 0; }
+	return 0;
+}
+// this step's Adam on the replicated MLP and on this rank's pieces (their summed gradients are in place)
+static int dp_optimizer_local(ngp_nerf* t, hipStream_t s) {
+	ngp_model* m = t->model;
+	++m->step;
+	AdamArgs a = make_adam_args(m, t->opt.loss_scale, m->step);
+	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
+	t->dp_adam = a;
+	ProfScope ps(P_OPTIMIZER, s);
+	a.range_begin = 0; a.n_params = m->n_mlp; launch_optimizer_step(s, a);
+	for (int b = 0; b < 2; ++b) {
+		const uint64_t piece = (t->dp_end[b] - t->dp_begin[b]) / t->opt.world_size;
+		a.range_begin = t->dp_begin[b] + piece * t->opt.rank; a.n_params = a.range_begin + piece; launch_optimizer_step(s, a);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+// ... and, once every rank's new half parameters have arrived, the EMA / inference copy of the foreign pieces (and their consumed gradients cleared)
+static int dp_optimizer_tail(ngp_nerf* t, hipStream_t s) {
+	ngp_model* m = t->model;
+	AdamArgs a = t->dp_adam;
+	a.ema_only = 1;
+	{
+		ProfScope ps(P_OPTIMIZER, s);
+		for (int b = 0; b < 2; ++b) {
+			const uint64_t piece = (t->dp_end[b] - t->dp_begin[b]) / t->opt.world_size, own = t->dp_begin[b] + piece * t->opt.rank;
+			a.range_begin = t->dp_begin[b]; a.n_params = own; launch_optimizer_step(s, a);
+			a.range_begin = own + piece; a.n_params = t->dp_end[b]; launch_optimizer_step(s, a);
+		}
+	}
+	m->last_sweep_params = m->n_params;
+	m->grads_clean = a.zero_grid_grads != 0;
+	HIPCHK(hipGetLastError());
+	if (m->cfg.decay_interval > 0 && m->step >= m->cfg.decay_start && m->step % m->cfg.decay_interval == 0) m->lr *= m->cfg.decay_base; // ExponentialDecay::step [tcnn]
+	return 0;
+}
+static int nerf_finish_impl(ngp_nerf* t, void* stream, bool run_optimizer);
+// For callers that run the collectives themselves (tests/test_gpu_dist.py: gloo through host memory):  phase 0 = Adam on the MLP + this rank's pieces (after the
+// reduce-scatter / all-reduce put the summed gradients in place), phase 1 = the foreign pieces' EMA + the rest of ngp_nerf_train_finish (after the all-gather of the parameters).
+extern "C" int ngp_nerf_train_finish_sharded(ngp_nerf* t, void* stream, int phase) {
+	REQUIRE(t && t->dp_sharded, "ngp_nerf_train_finish_sharded: the sharded step is not set up (ngp_nerf_dp_set_sharded / ngp_comm_init)");
+	if (phase == 0) return dp_optimizer_local(t, (hipStream_t)stream);
+	if (dp_optimizer_tail(t, (hipStream_t)stream)) return 1;
+	return nerf_finish_impl(t, stream, false);
+}
 extern "C" int ngp_comm_unique_id(uint8_t id_out_host[128]) {
 	REQUIRE(id_out_host, "ngp_comm_unique_id: null argument");
 	if (rccl_load()) return 1;
@@ -1920,6 +2026,12 @@ extern "C" int ngp_comm_init(ngp_nerf* t, uint32_t rank, uint32_t world_size, co
 	NcclId id; memcpy(id.internal, id_host, 128);
 	RCCLCHK(g_rccl.CommInitRank(&t->comm, (int)world_size, id, (int)rank));
 	t->model->record_bucket_events = false; // the all-reduce runs on the caller's stream behind the backward pass: no communication stream, no bucket events
+	// the sharded step (reduce-scatter -> Adam on this rank's pieces -> all-gather) is the default from two ranks on; NGP_DP_ALLREDUCE=1 keeps the round-2..4 step
+	// (all-reduce -> replicated sweep), NGP_DP_SHARDED=1 runs the sharded structure with a communicator of one rank as well (diagnostic / test)
+	const bool force_allreduce = getenv("NGP_DP_ALLREDUCE") && atoi(getenv("NGP_DP_ALLREDUCE")) != 0; // (read per communicator: a test sets them between two trainers)
+	const bool force_sharded = getenv("NGP_DP_SHARDED") && atoi(getenv("NGP_DP_SHARDED")) != 0;
+	const bool want = !force_allreduce && (world_size > 1 || force_sharded) && g_rccl.ReduceScatter && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd;
+	if (want) (void)dp_setup_sharded(t, true); // (a layout that does not divide by the world size keeps the all-reduce step)
 	return 0;
 }
 extern "C" int ngp_comm_destroy(ngp_nerf* t) {
@@ -1927,6 +2039,7 @@ extern "C" int ngp_comm_destroy(ngp_nerf* t) {
 	(void)hipDeviceSynchronize();
 	RCCLCHK(g_rccl.CommDestroy(t->comm));
 	t->comm = nullptr; t->model->record_bucket_events = false;
+	(void)dp_setup_sharded(t, false);
 	if (t->comm_stream) { (void)hipStreamDestroy(t->comm_stream); t->comm_stream = nullptr; }
 	if (t->ev_red_a) { (void)hipEventDestroy(t->ev_red_a); (void)hipEventDestroy(t->ev_red_b); t->ev_red_a = t->ev_red_b = nullptr; }
 	return 0;
@@ -1952,6 +2065,55 @@ static int dp_reduce_gradients(ngp_nerf* t, hipStream_t s) {
 	ngp_model* m = t->model;
 	if (!dp_skip_allreduce()) RCCLCHK(g_rccl.AllReduce(m->grads, m->grads, m->n_params, kNcclHalf, kNcclSum, t->comm, s));
 	t->grads_pending = false;
+	return 0;
+}
+
+// reduce-scatter (bucket A beside bucket B's accumulation, on the communication stream) -> local Adam -> all-gather -> foreign EMA, all behind ngp_nerf_train_backward
+static int dp_sharded_exchange_and_step(ngp_nerf* t, hipStream_t s) {
+	ngp_model* m = t->model;
+	const uint32_t W = t->opt.world_size, r = t->opt.rank;
+	const bool skip = dp_skip_allreduce();
+	ngp_half* g = m->grads; ngp_half* p = m->params;
+	const uint64_t pieceA = (t->dp_end[0] - t->dp_begin[0]) / W, pieceB = (t->dp_end[1] - t->dp_begin[1]) / W;
+	const bool split = m->dp_split_done && g_comm_stream != nullptr;
+	if (split) { // bucket A's gradients are final behind ev_bucket_a: its exchange runs on the communication stream while the caller's stream accumulates bucket B
+		HIPCHK(hipStreamWaitEvent(g_comm_stream, m->ev_bucket_a, 0));
+		if (!skip) RCCLCHK(g_rccl.ReduceScatter(g + t->dp_begin[0], g + t->dp_begin[0] + pieceA * r, pieceA, kNcclHalf, kNcclSum, t->comm, g_comm_stream));
+		HIPCHK(hipEventRecord(t->ev_rs_a, g_comm_stream));
+	}
+	if (!skip) {
+		RCCLCHK(g_rccl.AllReduce(g, g, m->n_mlp, kNcclHalf, kNcclSum, t->comm, s)); // the replicated MLP (20 KB)
+		if (!split) RCCLCHK(g_rccl.ReduceScatter(g + t->dp_begin[0], g + t->dp_begin[0] + pieceA * r, pieceA, kNcclHalf, kNcclSum, t->comm, s));
+		RCCLCHK(g_rccl.ReduceScatter(g + t->dp_begin[1], g + t->dp_begin[1] + pieceB * r, pieceB, kNcclHalf, kNcclSum, t->comm, s));
+	}
+	if (split) HIPCHK(hipStreamWaitEvent(s, t->ev_rs_a, 0));
+	t->grads_pending = false;
+	if (dp_optimizer_local(t, s)) return 1;
+	if (!skip) { // the new half parameters of every rank's pieces (the next step's K1 runs on its own stream beside this)
+		RCCLCHK(g_rccl.GroupStart());
+		RCCLCHK(g_rccl.AllGather(p + t->dp_begin[0] + pieceA * r, p + t->dp_begin[0], pieceA, kNcclHalf, t->comm, s));
+		RCCLCHK(g_rccl.AllGather(p + t->dp_begin[1] + pieceB * r, p + t->dp_begin[1], pieceB, kNcclHalf, t->comm, s));
+		RCCLCHK(g_rccl.GroupEnd());
+	}
+	return dp_optimizer_tail(t, s);
+}
+// Collective: every rank's fp32 master parameters, Adam moments, per-parameter step counters and EMA state of its OWN pieces -> all ranks (the sharded step keeps only
+// the half parameters and the inference copy current everywhere).  Call on every rank before ngp_model_get_params_host / ngp_model_serialize_host of a sharded run.
+extern "C" int ngp_nerf_dp_gather_state(ngp_nerf* t, void* stream) {
+	REQUIRE(t, "null trainer");
+	if (!t->dp_sharded || !t->comm || t->opt.world_size < 2) return 0;
+	ngp_model* m = t->model; hipStream_t s = (hipStream_t)stream;
+	constexpr int kNcclFloat32 = 7, kNcclUint16AsHalf = kNcclHalf; // (16-bit payloads travel as halfs: all-gather does not interpret them)
+	RCCLCHK(g_rccl.GroupStart());
+	for (int b = 0; b < 2; ++b) {
+		const uint64_t piece = (t->dp_end[b] - t->dp_begin[b]) / t->opt.world_size, lo = t->dp_begin[b], own = lo + piece * t->opt.rank;
+		RCCLCHK(g_rccl.AllGather(m->master + own, m->master + lo, piece, kNcclFloat32, t->comm, s));
+		RCCLCHK(g_rccl.AllGather(m->adam_m + own, m->adam_m + lo, piece, kNcclFloat32, t->comm, s));
+		RCCLCHK(g_rccl.AllGather(m->adam_v + own, m->adam_v + lo, piece, kNcclFloat32, t->comm, s));
+		RCCLCHK(g_rccl.AllGather(m->adam_steps + own, m->adam_steps + lo, piece, kNcclUint16AsHalf, t->comm, s));
+	}
+	RCCLCHK(g_rccl.GroupEnd());
+	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }
 
@@ -2010,6 +2172,11 @@ extern "C" int ngp_nerf_train(ngp_nerf* t, void* stream, uint32_t n_steps) {
 			if (ngp_nerf_train_forward(t, stream)) return 1;
 			if (ngp_allreduce_counters(t, stream)) return 1;
 			if (ngp_nerf_train_backward(t, stream)) return 1;
+			if (t->dp_sharded) { // reduce-scatter -> Adam on this rank's pieces -> all-gather -> the rest of the step
+				if (dp_sharded_exchange_and_step(t, (hipStream_t)stream)) return 1;
+				if (nerf_finish_impl(t, stream, false)) return 1;
+				continue;
+			}
 			if (dp_reduce_gradients(t, (hipStream_t)stream)) return 1;
 		} else if (nerf_step_impl(t, stream, 3, false, true)) return 1; // (= ngp_nerf_train_forward_backward, and the optimizer step follows at once: its hashed-level part is fused into the scatter)
 		if (ngp_nerf_train_finish(t, stream)) return 1;

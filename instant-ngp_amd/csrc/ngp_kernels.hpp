@@ -216,7 +216,8 @@ constexpr uint32_t GRAD_BIN_MAX_TABLE_LOG2 = 19; // hashmap sizes up to 2^19 (2^
 // chunk_log2: table entries per chunk (2^12: 128 KiB of 64-bit accumulators for the four features of an entry, one block per CU;
 // 2^11: 64 KiB, two blocks per CU).  split: round-1 layout, one block per (chunk, feature pair) -- both blocks fetch every record.
 struct AdamArgs {
-	uint64_t n_params, n_mlp;
+	uint64_t n_params, n_mlp; // the sweep covers [range_begin, n_params)
+	uint64_t range_begin = 0; int ema_only = 0; // sharded data-parallel step: a sub-range of the parameters; ema_only = EMA / inference copy + gradient clearing only (the range's Adam step ran on its owner rank)
 	float loss_scale, lr, beta1, beta2, eps, l2_reg, log_beta1, log_beta2;
 	int optimize_matrix, optimize_non_matrix;
 	int zero_grid_grads; // leave the hash-grid gradients zeroed for the next step's scatter (GradientMode::Overwrite without a memset launch)
@@ -234,13 +235,14 @@ struct GradBinArgs {
 	uint32_t n_features; // F: 4 (8-byte record values) or 2 (4-byte)
 	uint32_t n_pos_dims = 3; // 3, or 2 for the image primitive's grid (F = 2 only)
 	void* vals; uint16_t* idxs; uint32_t* cursors; uint32_t* cursor_done; ngp_half* grid_grad_;
+	uint32_t acc_ly_begin = 0, acc_ly_count = 0; // k_grad_accumulate: the listed levels it covers (count 0 = all); the sharded data-parallel step accumulates bucket by bucket
 	// Single-GPU steps: k_grad_accumulate applies the optimizer to the HASHED levels in its epilogue -- the chunk's gradient sums are in LDS, so the 23 MB gradient write,
 	// its re-read by the sweep and the sweep's pass over those levels disappear (same arithmetic: the sums are rounded to half exactly as the stored gradient would be).
 	// The sweep (k_optimizer) then covers parameters [0, adam.n_params) = MLP + dense levels only.  Off (0): gradients are written for a separate optimizer step
 	// (C-ABI callers that look at gradients, the data-parallel all-reduce).
 	uint32_t fuse_adam = 0; AdamArgs adam{};
 };
-void launch_grad_bin(hipStream_t s, const GradBinArgs& a);
+void launch_grad_bin(hipStream_t s, const GradBinArgs& a, uint32_t what = 3u /* bit 0: k_grad_bin, bit 1: k_grad_accumulate */);
 struct GradDenseArgs { // k_grad_dense: the dense levels' scatter from T1's level-major dL/d(enc)
 	const GridMeta* gm; const float* in; uint32_t in_stride, n;
 	const uint2* denc_lv; uint32_t denc_cap;

@@ -1246,6 +1246,9 @@ bool ends_with_ci(const std::string& s, const char* ext) { const size_t n = strl
 
 void Testbed::save_snapshot(const std::string& path, bool include_optimizer_state) {
 	ensure_trainer();
+	// data parallel (sharded step): the fp32 master parameters / Adam state of the other ranks' pieces are gathered first -- a COLLECTIVE: with an optimizer state every rank
+	// calls save_snapshot (each may write its own file); the half / inference parameters (all a snapshot without optimizer state holds) are current on every rank anyway
+	if (m_world_size > 1 && m_comm_up && include_optimizer_state) NGP_CHECK(ngp_nerf_dp_gather_state(m_nerf, nullptr));
 	Value root = m_network_config.type == Value::Object ? m_network_config : jobj();
 	Value snap = jobj();
 	// ---- tcnn Trainer::serialize ----

@@ -227,6 +227,102 @@ def test_multi_rank_step_world2_shared_gpu():
     assert q.get(timeout=5) == "ok"
 
 
+def _sharded_worker(rank, world, port, q):
+    """Two trainers per process on the same ray stream: one steps with the all-reduce + replicated-sweep step (rounds 2-4), one with the sharded step (reduce-scatter ->
+    Adam on this rank's pieces -> all-gather -> foreign EMA).  The collectives run over gloo through host memory (one GPU is shared); everything else is the library."""
+    sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "instant-ngp_amd")]
+    import ngp_abi as A
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    lib = A.load_hip()
+    lib.ngp_debug_set_flags(1048576)  # DBG_K3_TWO_PASS: deterministic compaction, so that the two trainers of a process see the same batch rows in the same order
+    tr = {}
+    for mode in ("allreduce", "sharded"):
+        hm, t, keep = _setup(A, lib, rank, world, B_GLOBAL // world)
+        g = C.c_void_p(); pp = C.c_void_p(); lib.ngp_model_param_ptrs(hm.h, None, C.byref(pp), None, C.byref(g))
+        cp = C.c_void_p(); lib.ngp_nerf_counter_ptrs(t, C.byref(cp))
+        tr[mode] = dict(hm=hm, t=t, keep=keep, grads=torch.as_tensor(_View(g.value, hm.n, "<f2"), device="cuda"), params=torch.as_tensor(_View(pp.value, hm.n, "<f2"), device="cuda"),
+                        cnt=torch.as_tensor(_View(cp.value, 3, "<i4"), device="cuda"))
+    sh = tr["sharded"]
+    A.check(lib, lib.ngp_nerf_dp_set_sharded(sh["t"], 1))
+    b = (C.c_uint64 * 2)(); e = (C.c_uint64 * 2)(); A.check(lib, lib.ngp_nerf_dp_layout(sh["t"], b, e))
+    n_mlp = sh["hm"].n_mlp
+    assert b[0] == n_mlp and e[0] == b[1] and e[1] == sh["hm"].n and all((e[k] - b[k]) % (4 * world) == 0 for k in range(2)), (list(b), list(e))
+    pieces = [(int(b[k]) + (int(e[k]) - int(b[k])) // world * rank, (int(e[k]) - int(b[k])) // world) for k in range(2)]
+    n_steps = 24
+    for step in range(n_steps):
+        for mode in ("allreduce", "sharded"):
+            d = tr[mode]; t = d["t"]
+            A.check(lib, lib.ngp_nerf_train_prep(t, None))
+            A.check(lib, lib.ngp_nerf_train_forward(t, None))
+            torch.cuda.synchronize()
+            c_host = d["cnt"].cpu().to(torch.int64); dist.all_reduce(c_host); d["cnt"].copy_(c_host.to(torch.int32).cuda())
+            A.check(lib, lib.ngp_nerf_train_backward(t, None))
+            torch.cuda.synchronize()
+            g_sum = d["grads"].float().cpu(); dist.all_reduce(g_sum); g_sum = g_sum.half()
+            if mode == "allreduce":
+                d["grads"].copy_(g_sum.cuda())
+                A.check(lib, lib.ngp_nerf_train_finish(t, None))
+            else:
+                # reduce-scatter: only the MLP block and this rank's pieces receive the sums; the foreign pieces keep this rank's local (partial) gradients
+                d["grads"][:n_mlp].copy_(g_sum[:n_mlp].cuda())
+                for (o, n) in pieces:
+                    d["grads"][o:o + n].copy_(g_sum[o:o + n].cuda())
+                A.check(lib, lib.ngp_nerf_train_finish_sharded(t, None, 0))
+                torch.cuda.synchronize()
+                # all-gather of the pieces' new half parameters
+                for k in range(2):
+                    o, n = pieces[k]
+                    mine = d["params"][o:o + n].cpu().view(torch.int32)   # (pieces are whole 4-half entries; gloo has no 16-bit integer type)
+                    got = [torch.empty_like(mine) for _ in range(world)]
+                    dist.all_gather(got, mine)
+                    for r_ in range(world):
+                        if r_ != rank:
+                            o_r = int(b[k]) + n * r_
+                            d["params"][o_r:o_r + n].copy_(got[r_].view(torch.float16).cuda())
+                A.check(lib, lib.ngp_nerf_train_finish_sharded(t, None, 1))
+            torch.cuda.synchronize()
+        sa, ss = A.NerfStats(), A.NerfStats()
+        A.check(lib, lib.ngp_nerf_get_stats(tr["allreduce"]["t"], None, C.byref(sa))); A.check(lib, lib.ngp_nerf_get_stats(sh["t"], None, C.byref(ss)))
+        assert (sa.training_step, sa.rays_per_batch, sa.n_rays_last, sa.measured_batch_size) == (ss.training_step, ss.rays_per_batch, ss.n_rays_last, ss.measured_batch_size), (step, "counters")
+    pa, ps = tr["allreduce"]["hm"], sh["hm"]
+    for which in ("params", "inference"):
+        x, y = pa.read(which, torch), ps.read(which, torch)
+        n_diff = int((x != y).sum())
+        assert n_diff == 0, f"rank {rank}: {n_diff} of {x.size} {which} halfs differ between the sharded and the all-reduce step after {n_steps} steps"
+    ma, ms = pa.read("master", torch), ps.read("master", torch)
+    own = np.zeros(ma.size, bool); own[:n_mlp] = True
+    for (o, n) in pieces:
+        own[o:o + n] = True
+    assert np.array_equal(ma[own].view(np.uint32), ms[own].view(np.uint32)), "fp32 master parameters of the MLP / this rank's pieces"
+    assert (ma[~own] != ms[~own]).any(), "the foreign pieces' fp32 state is NOT maintained by the sharded step (that is the saving)"
+    g = sh["grads"].cpu().numpy().view(np.uint16)
+    assert not g[n_mlp:].any(), "every grid gradient is cleared for the next step's scatter, foreign pieces included"
+    print(f"rank {rank}: sharded == all-reduce step, {n_steps} steps, loss {ss.loss:.6f}; pieces {pieces}")
+    q.put("ok")
+    dist.barrier()
+    lib.ngp_nerf_destroy(tr["allreduce"]["t"]); lib.ngp_nerf_destroy(sh["t"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sharded_step_equals_allreduce_step_world2_shared_gpu():
+    """Round 5's data-parallel step -- reduce-scatter of the fp16 gradients, Adam on each rank's 1 / G piece of the table (+ the replicated MLP), all-gather of the new
+    half parameters, EMA of the foreign pieces from the gathered parameters -- leaves BIT-IDENTICAL half parameters and inference (EMA) parameters to the all-reduce +
+    replicated-sweep step, on both ranks, after 24 steps; the fp32 state of the foreign pieces is not maintained (checked: it differs) and all gradients are cleared."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(800)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok" and q.get(timeout=5) == "ok"
+
+
 def test_rccl_in_library_world1(hip):
     """ngp_comm_unique_id / ngp_comm_init / the all-reduces inside ngp_nerf_train with a communicator of ONE rank: the collectives are identities, so training IS the plain
     single-rank run -- asserted as what an identity is: the same ray / sample counters on every step checked and BIT-IDENTICAL parameters after 30 steps.  (The data-parallel
@@ -262,6 +358,29 @@ def test_rccl_in_library_world1(hip):
         assert np.isfinite(sb.loss) and abs(sa.loss - sb.loss) <= 1e-4 * sa.loss + 1e-7, (sa.loss, sb.loss)
     finally:
         hip.ngp_debug_set_flags(0)
+    # the sharded step's structure with the same one-rank communicator kind (NGP_DP_SHARDED=1: reduce-scatter / all-gather of one rank are in-place identities; bucket A's
+    # exchange runs on the communication stream behind its event, Adam runs piece by piece, the "foreign" EMA pass is empty): again bit-identical to the plain run
+    hip.ngp_debug_set_flags(K3_TWO_PASS)
+    os.environ["NGP_DP_SHARDED"] = "1"
+    try:
+        hm_c, t_c, keep_c = _setup(A, hip, 0, 1, 1 << 16)
+        uid2 = (C.c_uint8 * 128)()
+        A.check(hip, hip.ngp_comm_unique_id(uid2))
+        A.check(hip, hip.ngp_comm_init(t_c, 0, 1, uid2))
+        b2 = (C.c_uint64 * 2)(); e2 = (C.c_uint64 * 2)(); A.check(hip, hip.ngp_nerf_dp_layout(t_c, b2, e2))
+        assert e2[1] == hm_c.n and b2[0] == hm_c.n_mlp and b2[1] == e2[0] and e2[0] > b2[0], "the sharded layout must be active"
+        A.check(hip, hip.ngp_nerf_train(t_c, None, 30))
+        torch.cuda.synchronize()
+        sc_ = A.NerfStats(); A.check(hip, hip.ngp_nerf_get_stats(t_c, None, C.byref(sc_)))
+        assert (sc_.training_step, sc_.rays_per_batch, sc_.measured_batch_size) == (sa.training_step, sa.rays_per_batch, sa.measured_batch_size)
+        pc = hm_c.read("master", torch)
+        n_diff = int((pa.view(np.uint32) != pc.view(np.uint32)).sum())
+        print(f"rccl world-1 SHARDED step vs plain: loss {sc_.loss:.8f} vs {sa.loss:.8f}; parameters that differ {n_diff} of {pa.size}")
+        assert n_diff == 0 and np.array_equal(hm_a.read("inference", torch), hm_c.read("inference", torch))
+        A.check(hip, hip.ngp_nerf_dp_gather_state(t_c, None))   # (one rank: nothing to gather)
+        A.check(hip, hip.ngp_comm_destroy(t_c)); hip.ngp_nerf_destroy(t_c)
+    finally:
+        os.environ.pop("NGP_DP_SHARDED", None); hip.ngp_debug_set_flags(0)
     A.check(hip, hip.ngp_allreduce_gradients(t_b, None)); A.check(hip, hip.ngp_allreduce_counters(t_b, None))
     # error-proportional pixel sampling under the communicator: the ranks' error maps are summed (fp32 all-reduce) before the CDFs are built
     opts = A.default_nerf_options(1, target_batch_size=1 << 16, rank=0, world_size=1, sample_image_proportional_to_error=1, sample_focal_plane_proportional_to_error=1)
@@ -307,10 +426,16 @@ def _rccl_worker(rank, world, port, q):
         losses.append(float(st.loss))
         rpb = [None] * world; dist.all_gather_object(rpb, (int(st.rays_per_batch), int(st.training_step), float(st.loss)))
         assert len(set(rpb)) == 1, rpb               # same controller decision, same step, same (union-batch) loss on every rank
+    # the half parameters every rank trains and renders with are kept identical by the step itself (sharded step: all-gather; all-reduce step: replicated sweep) ...
+    ph = hm.read("params", torch); pi = hm.read("inference", torch)
+    digests = [None] * world; dist.all_gather_object(digests, hashlib.sha1(ph.tobytes() + pi.tobytes()).hexdigest())
+    assert len(set(digests)) == 1, "ranks diverged (half / inference parameters)"
+    # ... the fp32 optimizer state of the foreign pieces only after the collective gather (sharded step, world > 1; a no-op otherwise)
+    A.check(lib, lib.ngp_nerf_dp_gather_state(t, None))
     p = np.empty(hm.n, np.float32)
     A.check(lib, lib.ngp_model_get_params_host(hm.h, p.ctypes.data_as(C.c_void_p), C.c_uint64(p.size)))
     digests = [None] * world; dist.all_gather_object(digests, hashlib.sha1(p.tobytes()).hexdigest())
-    assert len(set(digests)) == 1, "ranks diverged"
+    assert len(set(digests)) == 1, "ranks diverged (fp32 master parameters after ngp_nerf_dp_gather_state)"
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], losses   # (losses[0] is already ten steps in)
     dist.barrier()
     torch.cuda.synchronize()
