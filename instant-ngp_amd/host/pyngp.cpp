@@ -235,7 +235,9 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property("jit_fusion", [](Testbed&) { return true; }, [](Testbed&, bool) {}) // python_api.cu: the reference's JIT-fused kernels on / off; the kernels here are fused at build time either way
 		.def_property("max_level_rand_training", [](Testbed&) { return false; }, [](Testbed&, bool v) { if (v) throw std::runtime_error{"max_level_rand_training: random level cut-off is not part of this build"}; })
 		.def("reset", &Testbed::reset_network).def("reset_network", &Testbed::reset_network)
-		.def("load_snapshot", &Testbed::load_snapshot).def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
+		.def("load_snapshot", &Testbed::load_snapshot).def("_nerf_dataset_to_json", &Testbed::nerf_dataset_to_json_text)       // test hooks: snapshot["nerf"]["dataset"] as JSON text (json_binding.h to_json / from_json), host only
+		.def("_nerf_dataset_from_json", &Testbed::nerf_dataset_from_json_text)
+		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())
 		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>())
 		.def("want_repl", &Testbed::want_repl)

@@ -1205,8 +1205,9 @@ std::vector<float> Testbed::render(int width, int height, int spp, bool linear, 
 // "snapshot" object, `.ingp` = the same bytes through zlib (zstr).  ngp-side fields and the vector / bounding-box / dataset
 // encodings follow testbed.cu:5288-5343 and json_binding.h; the tcnn-side fields (Trainer::serialize: "n_params", "params_type",
 // "params_binary" = inference parameters in half, optional "optimizer") are restated from memory of the public tiny-cuda-nn
-// [tcnn, unverifiable here: the submodule is absent and the mount holds no snapshot file].  The optimizer state is stored under
-// "optimizer" in THIS library's own binary form ("otype": "ngp_hip"), which a real instant-ngp build would not accept.
+// [tcnn, unverifiable here: the submodule is absent and the mount holds no snapshot file].  The optimizer state is written under
+// "optimizer" in tcnn's nesting and key names as far as they can be restated here (round 5; rounds 1-4 wrote one private blob,
+// which load_snapshot still reads), the fp32 master parameters under the private key "ngp_hip_master_binary".
 // ------------------------------------------------------------------------------------------------
 namespace {
 using mini_json::Value;
@@ -1244,6 +1245,105 @@ float f16_to_f32(uint16_t h) {
 bool ends_with_ci(const std::string& s, const char* ext) { const size_t n = strlen(ext); if (s.size() < n) return false; for (size_t i = 0; i < n; ++i) if (tolower((unsigned char)s[s.size() - n + i]) != ext[i]) return false; return true; }
 } // namespace
 
+// from_json(NerfDataset) / from_json(Lens) / from_json(TrainingXForm) / from_json(BoundingBox), json_binding.h:30-34, 67-105, 141-190: the dataset METADATA a snapshot
+// embeds (no pixels), with the reference reader's dataset-wide defaults and legacy keys ("lens" / "camera_distortion", "principal_point", "rolling_shutter", "focal_length",
+// "image_resolution" at the top level; "focal_lengths"; a per-image "metadata" entry overrides them) so that documents of older instant-ngp versions read the same way.
+static void lens_from_json(const mini_json::Value& lens, ImageMetadata& m) { // from_json(Lens), json_binding.h:67-100 (anything unrecognised = Perspective)
+	m.lens_mode = NGP_LENS_PERSPECTIVE;
+	if (!lens.is_object()) return;
+	if (lens.has("k1")) {
+		if (lens.boolean("is_fisheye", false)) { m.lens_mode = NGP_LENS_OPENCV_FISHEYE; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("k3", 0); m.lens_params[3] = (float)lens.num("k4", 0); }
+		else { m.lens_mode = NGP_LENS_OPENCV; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("p1", 0); m.lens_params[3] = (float)lens.num("p2", 0); }
+	} else if (lens.has("ftheta_p0")) { m.lens_mode = NGP_LENS_FTHETA; for (int k = 0; k < 5; ++k) m.lens_params[k] = (float)lens.num(std::string("ftheta_p") + char('0' + k), 0); m.lens_params[5] = (float)lens.num("w", 0); m.lens_params[6] = (float)lens.num("h", 0); }
+	else if (lens.has("latlong")) m.lens_mode = NGP_LENS_LATLONG;
+	else if (lens.has("equirectangular")) m.lens_mode = NGP_LENS_EQUIRECTANGULAR;
+	else if (lens.has("orthographic")) m.lens_mode = NGP_LENS_ORTHOGRAPHIC;
+}
+NerfDataset Testbed::dataset_from_json(const mini_json::Value& jd, int default_aabb_scale) {
+	if (!jd.is_object() || !jd["xforms"].is_array()) throw std::runtime_error{"Snapshot holds no dataset metadata and no training data is loaded."};
+	NerfDataset d;
+	const size_t n = jd.has("n_images") ? (size_t)jd.num("n_images", 0) : jd["xforms"].size();
+	if (jd["xforms"].size() < n) throw std::runtime_error{"Snapshot dataset: fewer xforms than images."};
+	d.aabb_scale = (int)jd.num("aabb_scale", default_aabb_scale); d.scale = (float)jd.num("scale", 0.33); d.is_hdr = jd["is_hdr"].type == Value::Bool && jd["is_hdr"].b; d.from_mitsuba = jd.boolean("from_mitsuba", false);
+	if (jd["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)jd["offset"].at(k).n;
+	if (jd["up"].size() == 3) for (int k = 0; k < 3; ++k) d.up[k] = (float)jd["up"].at(k).n;
+	if (jd["render_aabb"].is_object() && jd["render_aabb"]["min"].size() == 3 && jd["render_aabb"]["max"].size() == 3)
+		for (int k = 0; k < 3; ++k) { d.render_aabb.min[k] = (float)jd["render_aabb"]["min"].at(k).n; d.render_aabb.max[k] = (float)jd["render_aabb"]["max"].at(k).n; }
+	if (jd["render_aabb_to_local"].size() == 3) for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) d.render_aabb_to_local[c * 3 + r] = (float)jd["render_aabb_to_local"].at(c).at(r).n;
+	auto vec_into = [](const Value& v, auto& dst, size_t cnt) { if (v.is_array() && v.size() == cnt) for (size_t k = 0; k < cnt; ++k) dst[k] = (typename std::remove_reference<decltype(dst[0])>::type)v.at(k).n; };
+	for (size_t i = 0; i < n; ++i) {
+		ImageMetadata m;
+		// dataset-wide defaults first, legacy names included (json_binding.h:149-156)
+		if (jd.has("lens")) lens_from_json(jd["lens"], m);
+		if (jd.has("camera_distortion")) lens_from_json(jd["camera_distortion"], m);
+		vec_into(jd["principal_point"], m.principal_point, 2); vec_into(jd["rolling_shutter"], m.rolling_shutter, 4); vec_into(jd["focal_length"], m.focal_length, 2); vec_into(jd["image_resolution"], m.resolution, 2);
+		if (jd["focal_lengths"].is_array() && i < jd["focal_lengths"].size()) vec_into(jd["focal_lengths"].at(i), m.focal_length, 2);
+		if (jd["metadata"].is_array() && i < jd["metadata"].size()) {
+			const Value& jm = jd["metadata"].at(i);
+			vec_into(jm["resolution"], m.resolution, 2); vec_into(jm["focal_length"], m.focal_length, 2); vec_into(jm["principal_point"], m.principal_point, 2);
+			if (jm.has("lens")) lens_from_json(jm["lens"], m);
+			if (jm.has("camera_distortion")) lens_from_json(jm["camera_distortion"], m);
+			vec_into(jm["rolling_shutter"], m.rolling_shutter, 4); // (written per image by to_json; the reference's reader takes the dataset-wide value only)
+		}
+		std::array<float, 12> x{}, xe{};
+		const Value& xs = jd["xforms"].at(i)["start"];
+		const Value& xend = jd["xforms"].at(i).has("end") ? jd["xforms"].at(i)["end"] : xs;
+		for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) { x[c * 3 + r] = (float)xs.at(c).at(r).n; xe[c * 3 + r] = (float)xend.at(c).at(r).n; }
+		d.metadata.push_back(m); d.xforms.push_back(x); d.xforms_end.push_back(xe); d.pixels.emplace_back(); d.pixels_half.emplace_back(); // no pixels
+		d.paths.push_back(jd["paths"].is_array() && i < jd["paths"].size() ? jd["paths"].at(i).s : std::string());
+	}
+	d.n_images = n;
+	d.n_extra_learnable_dims = (uint32_t)jd.num("n_extra_learnable_dims", 0); // from_json(NerfDataset), json_binding.h:190
+	return d;
+}
+// test hooks (pyngp: Testbed._nerf_dataset_to_json / _nerf_dataset_from_json): the two functions above through JSON text, no device needed
+std::string Testbed::nerf_dataset_to_json_text() const { return mini_json::dump(dataset_to_json()); }
+void Testbed::nerf_dataset_from_json_text(const std::string& text) {
+	mini_json::Value v; std::string err;
+	if (!mini_json::parse(text.c_str(), v, err)) throw std::runtime_error{"nerf_dataset_from_json: " + err};
+	destroy_trainer();
+	nerf.training.dataset = dataset_from_json(v, nerf.training.dataset.aabb_scale);
+	mode = ETestbedMode::Nerf;
+	load_nerf_post();
+	m_dataset_dirty = true; shall_train = false;
+}
+
+// to_json(NerfDataset) / to_json(Lens) / to_json(TrainingXForm) / to_json(BoundingBox), json_binding.h:24-139 (vectors as arrays, matrices as arrays of columns: [tcnn vec_json.h]).
+// Pinned against the reference's own functions compiled from where they lie: tests/test_ref_snapshot.py (oracle/ref_json_wrapper.cpp).
+mini_json::Value Testbed::dataset_to_json() const {
+	const NerfDataset& d = nerf.training.dataset;
+	Value jd = jobj(); jd.set("n_images", jnum((double)d.n_images));
+	Value paths; paths.type = Value::Array; for (const auto& p : d.paths) paths.arr.push_back(jstr(p)); jd.set("paths", paths);
+	Value metas; metas.type = Value::Array; Value xfs; xfs.type = Value::Array;
+	for (size_t i = 0; i < d.n_images; ++i) {
+		const ImageMetadata& m = d.metadata[i];
+		Value jm = jobj(); jm.set("focal_length", jvec(m.focal_length.data(), 2));
+		Value lens; // to_json(Lens), json_binding.h:37-65: a Perspective lens sets no key, so nlohmann leaves the value null (NOT an empty object); every other model creates the object
+		if (m.lens_mode != NGP_LENS_PERSPECTIVE) lens = jobj();
+		if (m.lens_mode == NGP_LENS_OPENCV) { lens.set("is_fisheye", jbool(false)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("p1", jnum(m.lens_params[2])); lens.set("p2", jnum(m.lens_params[3])); }
+		else if (m.lens_mode == NGP_LENS_OPENCV_FISHEYE) { lens.set("is_fisheye", jbool(true)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("k3", jnum(m.lens_params[2])); lens.set("k4", jnum(m.lens_params[3])); }
+		else if (m.lens_mode == NGP_LENS_FTHETA) { for (int k = 0; k < 5; ++k) lens.set(std::string("ftheta_p") + char('0' + k), jnum(m.lens_params[k])); lens.set("w", jnum(m.lens_params[5])); lens.set("h", jnum(m.lens_params[6])); }
+		else if (m.lens_mode == NGP_LENS_LATLONG) lens.set("latlong", jbool(true));
+		else if (m.lens_mode == NGP_LENS_EQUIRECTANGULAR) lens.set("equirectangular", jbool(true));
+		else if (m.lens_mode == NGP_LENS_ORTHOGRAPHIC) lens.set("orthographic", jbool(true));
+		jm.set("lens", lens); jm.set("principal_point", jvec(m.principal_point.data(), 2));
+		jm.set("rolling_shutter", jvec(m.rolling_shutter.data(), 4)); jm.set("resolution", jvec(m.resolution.data(), 2));
+		metas.arr.push_back(jm);
+		Value x = jobj(); x.set("start", jmat_cols(d.xforms[i].data(), 4, 3)); x.set("end", jmat_cols((i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i]).data(), 4, 3)); xfs.arr.push_back(x);
+	}
+	jd.set("metadata", metas); jd.set("xforms", xfs);
+	{ // to_json(NerfDataset), json_binding.h: the dataset's own crop box (empty = none: the scene box is written, as before), its orientation and up vector
+		ngp_aabb box = scene_aabb();
+		if (!d.render_aabb.is_empty()) for (int k = 0; k < 3; ++k) { box.min[k] = d.render_aabb.min[k]; box.max[k] = d.render_aabb.max[k]; }
+		jd.set("render_aabb", jbox(box));
+	}
+	jd.set("render_aabb_to_local", jmat_cols(d.render_aabb_to_local.data(), 3, 3));
+	jd.set("up", jvec(d.up.data(), 3)); jd.set("offset", jvec(d.offset.data(), 3));
+	const int env[2] = {0, 0}; jd.set("envmap_resolution", jvec(env, 2)); jd.set("scale", jnum(d.scale)); jd.set("aabb_scale", jnum(d.aabb_scale));
+	jd.set("from_mitsuba", jbool(d.from_mitsuba)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(d.n_extra_learnable_dims));
+	return jd;
+}
+
 void Testbed::save_snapshot(const std::string& path, bool include_optimizer_state) {
 	ensure_trainer();
 	// data parallel (sharded step): the fp32 master parameters / Adam state of the other ranks' pieces are gathered first -- a COLLECTIVE: with an optimizer state every rank
@@ -1261,11 +1361,25 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	HIP_CHECK(hipMemcpy(pb.bin.data(), inference, n_params * 2, hipMemcpyDeviceToHost));
 	snap.set("n_params", jnum((double)n_params)); snap.set("params_type", jstr("__half")); snap.set("params_binary", pb);
 	if (include_optimizer_state) {
-		Value opt = jobj(); opt.set("otype", jstr("ngp_hip"));
-		Value blob; blob.type = Value::Binary; blob.bin.resize(ngp_model_serialized_size(m_model, 1));
-		NGP_CHECK(ngp_model_serialize_host(m_model, blob.bin.data(), blob.bin.size(), 1));
-		opt.set("state_binary", blob);
-		snap.set("ngp_hip_optimizer", opt); // NOT under "optimizer": a real instant-ngp build would try to deserialise that key with tcnn's Adam / EMA layout
+		// snapshot["optimizer"] = m_optimizer->serialize() [tcnn, from memory -- trainer.h Trainer::serialize; optimizers/ema.h, exponential_decay.h, adam.h]: the optimizers nest as
+		// the config nests them (configs/nerf/base.json: Ema { ExponentialDecay { Adam } }), each level {"nested": <inner>, own fields}; Adam writes "current_step",
+		// "base_learning_rate", "first_moments_binary", "second_moments_binary" (GPUMemory<float> as msgpack bin) and "param_steps_binary" (GPUMemory<uint32_t>); Ema writes
+		// its step count and "weights_ema_binary".  Unverifiable in this mount (tcnn's sources are absent): the key names are the best restatement available, and a reader
+		// that knows more keys ignores none of these.  The fp32 master parameters -- which tcnn does NOT serialise (its deserialize casts "params_binary" up) -- travel
+		// under a private key so that a snapshot of this library resumes bit for bit.
+		std::vector<uint8_t> blob(ngp_model_serialized_size(m_model, 1));
+		NGP_CHECK(ngp_model_serialize_host(m_model, blob.data(), blob.size(), 1));
+		struct Hdr { uint32_t magic, version; uint64_t n_params; uint32_t step, with_optimizer; float lr; uint32_t pad; } h; // SerHeader of csrc/ngp_api.hip
+		memcpy(&h, blob.data(), sizeof(h));
+		const size_t nb = (size_t)n_params * 4; const uint8_t* pbase = blob.data() + sizeof(h);
+		auto bin = [&](int k) { Value v; v.type = Value::Binary; v.bin.assign(pbase + (size_t)k * nb, pbase + (size_t)(k + 1) * nb); return v; }; // 0 master, 1 m, 2 v, 3 steps (u32), 4 ema
+		Value adam = jobj();
+		adam.set("current_step", jnum(h.step)); adam.set("base_learning_rate", jnum(h.lr)); // (the rate Adam steps with now: ExponentialDecay has already applied its factors)
+		adam.set("first_moments_binary", bin(1)); adam.set("second_moments_binary", bin(2)); adam.set("param_steps_binary", bin(3));
+		Value decay = jobj(); decay.set("nested", adam); decay.set("base_learning_rate", jnum(m_network_config["optimizer"]["nested"]["nested"].num("learning_rate", m_network_config["optimizer"].num("learning_rate", 1e-2))));
+		Value ema = jobj(); ema.set("nested", decay); ema.set("ema_step", jnum(h.step)); ema.set("full_precision", jbool(true)); ema.set("weights_ema_binary", bin(4));
+		snap.set("optimizer", ema);
+		snap.set("ngp_hip_master_binary", bin(0));
 	}
 	// ---- Testbed::save_snapshot, testbed.cu:5291-5343 ----
 	snap.set("version", jnum(1)); snap.set("mode", jstr("nerf"));
@@ -1304,39 +1418,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	Value rgb = jobj(); rgb.set("rays_per_batch", jnum(st.rays_per_batch)); rgb.set("measured_batch_size", jnum(st.measured_batch_size));
 	rgb.set("measured_batch_size_before_compaction", jnum(st.measured_batch_size_before_compaction));
 	jn.set("rgb", rgb);
-	{ // to_json(NerfDataset), json_binding.h:114-139
-		const NerfDataset& d = nerf.training.dataset;
-		Value jd = jobj(); jd.set("n_images", jnum((double)d.n_images));
-		Value paths; paths.type = Value::Array; for (const auto& p : d.paths) paths.arr.push_back(jstr(p)); jd.set("paths", paths);
-		Value metas; metas.type = Value::Array; Value xfs; xfs.type = Value::Array;
-		for (size_t i = 0; i < d.n_images; ++i) {
-			const ImageMetadata& m = d.metadata[i];
-			Value jm = jobj(); jm.set("focal_length", jvec(m.focal_length.data(), 2));
-			Value lens = jobj();
-			// to_json(Lens), json_binding.h:37-65
-			if (m.lens_mode == NGP_LENS_OPENCV) { lens.set("is_fisheye", jbool(false)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("p1", jnum(m.lens_params[2])); lens.set("p2", jnum(m.lens_params[3])); }
-			else if (m.lens_mode == NGP_LENS_OPENCV_FISHEYE) { lens.set("is_fisheye", jbool(true)); lens.set("k1", jnum(m.lens_params[0])); lens.set("k2", jnum(m.lens_params[1])); lens.set("k3", jnum(m.lens_params[2])); lens.set("k4", jnum(m.lens_params[3])); }
-			else if (m.lens_mode == NGP_LENS_FTHETA) { for (int k = 0; k < 5; ++k) lens.set(std::string("ftheta_p") + char('0' + k), jnum(m.lens_params[k])); lens.set("w", jnum(m.lens_params[5])); lens.set("h", jnum(m.lens_params[6])); }
-			else if (m.lens_mode == NGP_LENS_LATLONG) lens.set("latlong", jbool(true));
-			else if (m.lens_mode == NGP_LENS_EQUIRECTANGULAR) lens.set("equirectangular", jbool(true));
-			else if (m.lens_mode == NGP_LENS_ORTHOGRAPHIC) lens.set("orthographic", jbool(true));
-			jm.set("lens", lens); jm.set("principal_point", jvec(m.principal_point.data(), 2));
-			jm.set("rolling_shutter", jvec(m.rolling_shutter.data(), 4)); jm.set("resolution", jvec(m.resolution.data(), 2));
-			metas.arr.push_back(jm);
-			Value x = jobj(); x.set("start", jmat_cols(d.xforms[i].data(), 4, 3)); x.set("end", jmat_cols((i < d.xforms_end.size() ? d.xforms_end[i] : d.xforms[i]).data(), 4, 3)); xfs.arr.push_back(x);
-		}
-		jd.set("metadata", metas); jd.set("xforms", xfs);
-		{ // to_json(NerfDataset), json_binding.h: the dataset's own crop box (empty = none: the scene box is written, as before), its orientation and up vector
-			ngp_aabb box = scene_aabb();
-			if (!d.render_aabb.is_empty()) for (int k = 0; k < 3; ++k) { box.min[k] = d.render_aabb.min[k]; box.max[k] = d.render_aabb.max[k]; }
-			jd.set("render_aabb", jbox(box));
-		}
-		jd.set("render_aabb_to_local", jmat_cols(d.render_aabb_to_local.data(), 3, 3));
-		jd.set("up", jvec(d.up.data(), 3)); jd.set("offset", jvec(d.offset.data(), 3));
-		const int env[2] = {0, 0}; jd.set("envmap_resolution", jvec(env, 2)); jd.set("scale", jnum(d.scale)); jd.set("aabb_scale", jnum(d.aabb_scale));
-		jd.set("from_mitsuba", jbool(d.from_mitsuba)); jd.set("is_hdr", jbool(d.is_hdr)); jd.set("wants_importance_sampling", jbool(true)); jd.set("n_extra_learnable_dims", jnum(d.n_extra_learnable_dims));
-		jn.set("dataset", jd);
-	}
+	jn.set("dataset", dataset_to_json()); // to_json(NerfDataset), json_binding.h:114-139
 	snap.set("nerf", jn);
 	snap.set("training_step", jnum(training_step)); snap.set("loss", jnum(loss));
 	const ngp_aabb box = scene_aabb();
@@ -1383,40 +1465,7 @@ void Testbed::load_snapshot(const std::string& path) {
 		// No training data loaded: restore the dataset METADATA embedded in the snapshot (from_json(NerfDataset), json_binding.h:141-190;
 		// testbed.cu:5386-5400), enough to render / evaluate (`run.py --load_snapshot x.ingp` without --scene).  There are no pixels:
 		// training stays off until load_training_data is called.
-		const Value& jd = jn["dataset"];
-		if (!jd.is_object() || !jd["metadata"].is_array()) throw std::runtime_error{"Snapshot holds no dataset metadata and no training data is loaded."};
-		NerfDataset d;
-		d.aabb_scale = (int)jd.num("aabb_scale", aabb_scale); d.scale = (float)jd.num("scale", 0.33); d.is_hdr = jd["is_hdr"].type == Value::Bool && jd["is_hdr"].b; d.from_mitsuba = jd.boolean("from_mitsuba", false);
-		if (jd["offset"].size() == 3) for (int k = 0; k < 3; ++k) d.offset[k] = (float)jd["offset"].at(k).n;
-		if (jd["up"].size() == 3) for (int k = 0; k < 3; ++k) d.up[k] = (float)jd["up"].at(k).n;
-		if (jd["render_aabb"].is_object() && jd["render_aabb"]["min"].size() == 3 && jd["render_aabb"]["max"].size() == 3)
-			for (int k = 0; k < 3; ++k) { d.render_aabb.min[k] = (float)jd["render_aabb"]["min"].at(k).n; d.render_aabb.max[k] = (float)jd["render_aabb"]["max"].at(k).n; }
-		const size_t n = jd["metadata"].size();
-		for (size_t i = 0; i < n; ++i) {
-			const Value& jm = jd["metadata"].at(i);
-			ImageMetadata m;
-			for (int k = 0; k < 2; ++k) { m.resolution[k] = (int)jm["resolution"].at(k).n; m.focal_length[k] = (float)jm["focal_length"].at(k).n; m.principal_point[k] = (float)jm["principal_point"].at(k).n; }
-			const Value& lens = jm["lens"];
-			if (lens.is_object()) { // from_json(Lens), json_binding.h:67-100
-				if (lens.has("k1")) {
-					if (lens.boolean("is_fisheye", false)) { m.lens_mode = NGP_LENS_OPENCV_FISHEYE; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("k3", 0); m.lens_params[3] = (float)lens.num("k4", 0); }
-					else { m.lens_mode = NGP_LENS_OPENCV; m.lens_params[0] = (float)lens.num("k1", 0); m.lens_params[1] = (float)lens.num("k2", 0); m.lens_params[2] = (float)lens.num("p1", 0); m.lens_params[3] = (float)lens.num("p2", 0); }
-				} else if (lens.has("ftheta_p0")) { m.lens_mode = NGP_LENS_FTHETA; for (int k = 0; k < 5; ++k) m.lens_params[k] = (float)lens.num(std::string("ftheta_p") + char('0' + k), 0); m.lens_params[5] = (float)lens.num("w", 0); m.lens_params[6] = (float)lens.num("h", 0); }
-				else if (lens.has("latlong")) m.lens_mode = NGP_LENS_LATLONG;
-				else if (lens.has("equirectangular")) m.lens_mode = NGP_LENS_EQUIRECTANGULAR;
-				else if (lens.has("orthographic")) m.lens_mode = NGP_LENS_ORTHOGRAPHIC;
-			}
-			if (jm["rolling_shutter"].size() == 4) for (int k = 0; k < 4; ++k) m.rolling_shutter[k] = (float)jm["rolling_shutter"].at(k).n;
-			std::array<float, 12> x{}, xe{};
-			const Value& xs = jd["xforms"].at(i)["start"];
-			const Value& xend = jd["xforms"].at(i).has("end") ? jd["xforms"].at(i)["end"] : xs;
-			for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) { x[c * 3 + r] = (float)xs.at(c).at(r).n; xe[c * 3 + r] = (float)xend.at(c).at(r).n; }
-			d.metadata.push_back(m); d.xforms.push_back(x); d.xforms_end.push_back(xe); d.pixels.emplace_back(); d.pixels_half.emplace_back(); // no pixels
-			d.paths.push_back(jd["paths"].is_array() && i < jd["paths"].size() ? jd["paths"].at(i).s : std::string());
-		}
-		d.n_images = n;
-		d.n_extra_learnable_dims = (uint32_t)jd.num("n_extra_learnable_dims", 0); // from_json(NerfDataset), json_binding.h:190
-		nerf.training.dataset = std::move(d);
+		nerf.training.dataset = dataset_from_json(jn["dataset"], aabb_scale);
 		mode = ETestbedMode::Nerf;
 		load_nerf_post();
 		m_render_lens_mode = nerf.training.dataset.metadata[0].lens_mode; m_render_lens_params = nerf.training.dataset.metadata[0].lens_params;
@@ -1428,9 +1477,39 @@ void Testbed::load_snapshot(const std::string& path) {
 	ensure_trainer();
 	uint64_t n_params = 0, n_mlp = 0;
 	NGP_CHECK(ngp_model_n_params(m_model, &n_params, &n_mlp));
-	const Value& opt = snap.has("ngp_hip_optimizer") ? snap["ngp_hip_optimizer"] : snap["optimizer"]; // ("optimizer": files written by round 1 of this library)
+	const Value& opt = snap.has("ngp_hip_optimizer") ? snap["ngp_hip_optimizer"] : snap["optimizer"]; // ("ngp_hip_optimizer" / "otype": "ngp_hip": files written by rounds 1-4 of this library)
+	// tcnn's shape (see save_snapshot): the Adam level is the innermost "nested" that carries the moments
+	const Value* adam = nullptr; const Value* ema = nullptr;
+	for (const Value* lv = &snap["optimizer"]; lv && lv->is_object(); lv = lv->has("nested") ? &(*lv)["nested"] : nullptr) {
+		if (lv->has("weights_ema_binary")) ema = lv;
+		if (lv->has("first_moments_binary") && lv->has("second_moments_binary")) { adam = lv; break; }
+	}
 	if (opt.is_object() && opt.str("otype", "") == "ngp_hip" && opt["state_binary"].type == Value::Binary) {
 		NGP_CHECK(ngp_model_deserialize_host(m_model, opt["state_binary"].bin.data(), opt["state_binary"].bin.size()));
+	} else if (adam) { // Trainer::deserialize with optimizer state [tcnn, from memory]
+		const Value& pb = snap["params_binary"];
+		if ((uint64_t)snap.num("n_params", 0) != n_params || pb.type != Value::Binary) throw std::runtime_error{"Snapshot parameters do not match the network config."};
+		const size_t nb = (size_t)n_params * 4;
+		struct Hdr { uint32_t magic, version; uint64_t n_params; uint32_t step, with_optimizer; float lr; uint32_t pad; } h = {0x4E475031u, 1, n_params, (uint32_t)adam->num("current_step", 0), 1u, (float)adam->num("base_learning_rate", 1e-2), 0};
+		std::vector<uint8_t> blob(sizeof(h) + nb * 5);
+		memcpy(blob.data(), &h, sizeof(h));
+		uint8_t* pbase = blob.data() + sizeof(h);
+		auto as_f32 = [&](const Value& v, int k, const char* what, bool allow_half) {
+			if (v.type == Value::Binary && v.bin.size() == nb) { memcpy(pbase + (size_t)k * nb, v.bin.data(), nb); return; }
+			if (allow_half && v.type == Value::Binary && v.bin.size() == nb / 2) { float* d = (float*)(pbase + (size_t)k * nb); for (uint64_t i = 0; i < n_params; ++i) { uint16_t hh; memcpy(&hh, &v.bin[i * 2], 2); d[i] = f16_to_f32(hh); } return; }
+			throw std::runtime_error{std::string("Snapshot optimizer state: '") + what + "' has the wrong size."};
+		};
+		// master parameters: this library's private fp32 copy when present, else "params_binary" cast up (what tcnn's deserialize does)
+		if (snap["ngp_hip_master_binary"].type == Value::Binary) as_f32(snap["ngp_hip_master_binary"], 0, "ngp_hip_master_binary", false);
+		else if (snap.str("params_type", "__half") == "float") as_f32(pb, 0, "params_binary", false);
+		else as_f32(pb, 0, "params_binary", true);
+		as_f32((*adam)["first_moments_binary"], 1, "first_moments_binary", false);
+		as_f32((*adam)["second_moments_binary"], 2, "second_moments_binary", false);
+		if (adam->has("param_steps_binary")) as_f32((*adam)["param_steps_binary"], 3, "param_steps_binary", false); // (uint32 counters: same width)
+		else { uint32_t* d = (uint32_t*)(pbase + 3 * nb); for (uint64_t i = 0; i < n_params; ++i) d[i] = h.step; } // [tcnn: older files have no per-parameter counters]
+		if (ema) as_f32((*ema)["weights_ema_binary"], 4, "weights_ema_binary", true);
+		else memcpy(pbase + 4 * nb, pbase, nb); // no EMA level: the inference parameters are the parameters
+		NGP_CHECK(ngp_model_deserialize_host(m_model, blob.data(), blob.size()));
 	} else { // Trainer::deserialize without optimizer state: parameters only, in the precision named by "params_type"
 		const Value& pb = snap["params_binary"];
 		if (pb.type != Value::Binary || (uint64_t)snap.num("n_params", 0) != n_params) throw std::runtime_error{"Snapshot parameters do not match the network config."};

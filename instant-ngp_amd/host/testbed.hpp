@@ -243,7 +243,13 @@ public:
 	static bool natural_path_less(const std::string& a, const std::string& b); // the loader's frame order (nerf_loader.cu:347-349: SI::natural::compare)
 	static std::string s_default_root_dir;                           // directory that holds configs/ (set by the binding layer)                          // non-PNG images (jpg/exr): provided by the binding layer
 
+	// snapshot["nerf"]["dataset"] (json_binding.h to_json / from_json of NerfDataset) as JSON text: test hooks, host only
+	std::string nerf_dataset_to_json_text() const;
+	void nerf_dataset_from_json_text(const std::string& text);
+
 private:
+	mini_json::Value dataset_to_json() const;
+	static NerfDataset dataset_from_json(const mini_json::Value& jd, int default_aabb_scale);
 	void ensure_trainer();
 	void load_nerf_post();
 	void destroy_trainer();

@@ -20,6 +20,7 @@
 #define __global__
 #define __forceinline__ inline
 #define __restrict__
+#include <type_traits>
 #define TCNN_HOST_DEVICE
 #define TCNN_DEVICE
 #define TCNN_HOST
@@ -174,6 +175,9 @@ template <typename T, uint32_t C, uint32_t R> bool operator==(const tmat<T, C, R
 template <typename T, uint32_t C, uint32_t R> bool operator!=(const tmat<T, C, R>& a, const tmat<T, C, R>& b) { return !(a == b); }
 using mat2x3 = tmat<float, 2, 3>; using mat2 = tmat<float, 2, 2>; using mat3 = tmat<float, 3, 3>; using mat4 = tmat<float, 4, 4>; using mat4x3 = tmat<float, 4, 3>; using mat3x4 = tmat<float, 3, 4>;
 template <typename T> tvec<T, 3> row(const tmat<T, 3, 3>& a, uint32_t r) { return {a.m[0][r], a.m[1][r], a.m[2][r]}; }
+// [tcnn vec.h, from memory] row r of any matrix, and a copy of the matrix with row r replaced (nerf_loader.h:113-116 cycles the axes of a mat4x3 with them)
+template <typename T, uint32_t C, uint32_t R, typename = typename std::enable_if<!(C == 3 && R == 3)>::type> tvec<T, C> row(const tmat<T, C, R>& a, uint32_t r) { tvec<T, C> v; for (uint32_t c = 0; c < C; ++c) v[c] = a.m[c][r]; return v; }
+template <typename T, uint32_t C, uint32_t R> tmat<T, C, R> row(const tmat<T, C, R>& a, uint32_t r, const tvec<T, C>& v) { tmat<T, C, R> o = a; for (uint32_t c = 0; c < C; ++c) o.m[c][r] = v[c]; return o; }
 
 // quaternion {x, y, z, w} with the handful of operations camera_path.h / .cu use (GLM-style: to_mat3 = mat3_cast, quat(mat3) = quat_cast by the largest diagonal term)
 struct quat {
