@@ -544,6 +544,11 @@ uint32_t ngp_debug_get_flags(void);
 /* second word of ablation switches (DBG2_* of csrc/ngp_kernels.hpp; NGP_DEBUG_FLAGS2_OR): 1 = the backward pass as T1 + W, two kernels (round 4), instead of k_train_fused */
 int ngp_debug_set_flags2(uint32_t flags);
 uint32_t ngp_debug_get_flags2(void);
+/* The same switches PER HANDLE: a handle with an override (on != 0) runs its calls (training step, inference, rendering, grid update, optimizer) under `flags` / `flags2`
+ * whatever the process-wide words say; on = 0 removes it.  ngp_nerf_set_debug_flags covers the trainer and its model.  Thread-compatible like every call on a handle:
+ * calls on handles with different overrides must not overlap in time on different threads. */
+int ngp_model_set_debug_flags(ngp_model*, int on, uint32_t flags, uint32_t flags2);
+int ngp_nerf_set_debug_flags(ngp_nerf*, int on, uint32_t flags, uint32_t flags2);
 /* train mode of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options) */
 int ngp_debug_set_train_mode(int mode);
 /* depth supervision of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options; testbed_nerf.cu:1027-1029, 1126-1129) */

@@ -20,12 +20,15 @@
 //    reference's `fma((T)weight, grid_val, result)`.
 //  * Swapping the MFMA operands yields the transposed product (lane = neuron, registers = samples),
 //    which is exactly the operand layout of the weight-gradient GEMM dW = dY * X^T (contraction over
-//    samples).  The backward therefore needs no LDS transposes either: kernel T1 (forward + dgrad +
-//    hash-grid scatter, latency-bound, low VGPR) and kernel W (recompute + wgrad, MFMA-bound, 1
-//    wave/SIMD with 192 accumulator registers) are separate launches.
+//    samples).  The backward therefore needs no LDS transposes either.  Production (base.json's shape, round 5): ONE kernel,
+//    k_train_fused -- two roles per SIMD, each recomputing the part of the chain it needs: role A the density network's
+//    weight gradients + dL/d(enc), role B the colour network's; every other shape: kernel T1 (k_train_fwd_bwd: forward + dgrad,
+//    low VGPR) and kernel W (k_wgrad2 / k_wgrad_nr: recompute + wgrad) as separate launches.
 //  * ReLU state is kept as 1 bit per neuron (one VGPR per layer per tile) instead of saved activations.
-//  * Hash-table gradients use packed-half atomics (global_atomic_pk_add_f16) like the reference's
-//    atomicAdd(__half2).
+//  * Hash-table gradients: EVERY level goes through record lists (k_grad_bin: counting sort by table chunk in LDS; k_grad_accumulate:
+//    exact 64-bit fixed-point sums in LDS, each gradient written once, the optimizer applied in the epilogue on one GPU) -- no global
+//    atomics on the production path.  Packed-half atomics (global_atomic_pk_add_f16, the reference's atomicAdd(__half2)) remain as the
+//    fallback for table sizes the lists do not cover, for overflowing lists, and as the ablation DBG_T1_NO_BINNING.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "ngp_kernels.hpp"

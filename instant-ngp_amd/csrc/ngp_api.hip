@@ -122,6 +122,16 @@ static uint32_t env_debug2_or() { static const uint32_t v = getenv("NGP_DEBUG_FL
 static const bool g_debug2_env_applied = [] { g_debug_flags2 |= env_debug2_or(); return true; }();
 extern "C" int ngp_debug_set_flags2(uint32_t flags) { g_debug_flags2 = flags | env_debug2_or(); return 0; }
 extern "C" uint32_t ngp_debug_get_flags2(void) { return g_debug_flags2; }
+// Per-handle ablation switches (ngp_model_set_debug_flags / ngp_nerf_set_debug_flags): a handle that carries an override runs ITS calls under those switches whatever the
+// process-wide ones say -- two trainers of one process can then differ (an A / B of two kernel variants side by side, a caller pinning the production path for its handle
+// while a test harness toggles the global bits).  Applied for the duration of a call on the handle (training step, inference, rendering, grid update) and restored behind
+// it; like every call on a handle it is thread-compatible, not thread-safe: calls on handles with DIFFERENT overrides must not overlap in time on different threads.
+struct DebugOverride { bool on = false; uint32_t flags = 0, flags2 = 0; };
+struct FlagScope {
+	uint32_t saved = 0, saved2 = 0; bool active = false;
+	explicit FlagScope(const DebugOverride& o) { if (o.on) { active = true; saved = g_debug_flags; saved2 = g_debug_flags2; g_debug_flags = o.flags | env_debug_or(); g_debug_flags2 = o.flags2 | env_debug2_or(); } }
+	~FlagScope() { if (active) { g_debug_flags = saved; g_debug_flags2 = saved2; } }
+};
 // layout of the hashed levels' binned scatter (tuning / test hook): table entries per chunk (2^11 or 2^12), one block per chunk
 // (split = 0) or per (chunk, feature pair) (split = 1), and a list-capacity override (0 = twice the mean; small values force the
 // overflow path of k_grad_bin).  NGP_BIN_CHUNK_LOG2 / NGP_BIN_SPLIT / NGP_BIN_CAP in the environment set the defaults.
@@ -251,6 +261,7 @@ struct ngp_model {
 	bool record_bucket_events = false; hipEvent_t ev_hashed_ready = nullptr, ev_mlp_ready = nullptr;
 	// sharded data-parallel step (round 5): k_grad_accumulate runs in two launches -- the first dp_split_ly listed levels (bucket A), then the rest (bucket B) -- and
 	// ev_bucket_a marks bucket A's gradients final on the caller's stream, so that its reduce-scatter runs beside bucket B's accumulation (0 = one launch, no event)
+	DebugOverride dbg; // per-handle ablation switches (ngp_model_set_debug_flags)
 	uint32_t dp_split_level = 0; hipEvent_t ev_bucket_a = nullptr; bool dp_split_done = false /* the last training step accumulated in two launches and recorded ev_bucket_a */;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
@@ -439,6 +450,7 @@ static ModelPtrs model_ptrs(const ngp_model* m, bool inference) {
 
 extern "C" int ngp_model_inference(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,
 		ngp_half* out, uint32_t out_stride, int use_inference_params) {
+	FlagScope flag_scope_(m->dbg);
 	REQUIRE(in_stride >= 7 && out_stride >= 4 && out_stride % 4 == 0, "inference: in_stride >= 7, out_stride a multiple of 4 halfs");
 	{ ProfScope ps(P_K2_INFERENCE, (hipStream_t)stream);
 	  launch_inference((hipStream_t)stream, m->gm_dev, model_ptrs(m, use_inference_params != 0), in, in_stride, n_max, n_ptr, out, out_stride, false, 4, m->gm.F); }
@@ -475,6 +487,7 @@ extern "C" int ngp_model_training_step_extra(ngp_model* m, void* stream, const f
 // fuse_optimizer_loss_scale > 0: the caller runs ngp_model_optimizer_step(m, stream, that loss scale) next, with nothing in between that looks at the hash-grid gradients
 // (ngp_nerf_train on one GPU): k_grad_accumulate then applies the optimizer to the hashed levels itself (GradBinArgs::fuse_adam).
 static int model_training_step_impl(ngp_model* m, void* stream, const float* in, uint32_t in_stride, uint32_t n, const ngp_half* dL_dy, uint32_t dy_stride, const EncStashIn* stash_in, float fuse_optimizer_loss_scale) {
+	FlagScope flag_scope_(m->dbg);
 	REQUIRE(in_stride >= 7 + m->cfg.n_extra_dims && dy_stride >= 4 && dy_stride % 4 == 0, "training_step: in_stride >= 7 + n_extra_dims, dy_stride a multiple of 4 halfs");
 	if (m->cfg.n_extra_dims) stash_in = nullptr; // (the lazy K2 that leaves the encodings behind has no extra-dims instance)
 	hipStream_t s = (hipStream_t)stream;
@@ -1179,6 +1192,7 @@ static AdamArgs make_adam_args(const ngp_model* m, float loss_scale, uint32_t st
 	return a;
 }
 extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_scale) {
+	FlagScope flag_scope_(m->dbg);
 	++m->step; // Adam::step: ++m_current_step
 	AdamArgs a = make_adam_args(m, loss_scale, m->step);
 	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
@@ -1443,6 +1457,7 @@ struct ngp_nerf {
 	// Sharded data-parallel step (round 5): the hash table's parameters [dp_begin[b], dp_end[b]) of bucket b = 0, 1 (level groups) are cut into world_size equal
 	// pieces; rank r owns piece r of both buckets: it receives their summed gradients (reduce-scatter), runs Adam on them and hands the new half parameters to everybody
 	// (all-gather).  The MLP (10,240 parameters) stays replicated (its gradients are all-reduced).  dp_sharded = the layout exists and the mode is on.
+	DebugOverride dbg; // per-handle ablation switches (ngp_nerf_set_debug_flags; the trainer's model runs under them as well)
 	bool dp_sharded = false; uint64_t dp_begin[2] = {0, 0}, dp_end[2] = {0, 0}; hipEvent_t ev_rs_a = nullptr; AdamArgs dp_adam; /* this step's optimizer arguments (local part -> tail) */
 	// error-proportional pixel sampling (testbed.h:745-756, 810-815; off unless one of the option switches is set)
 	float* error_map = nullptr; size_t error_map_cap = 0; int32_t error_map_res[2] = {0, 0};
@@ -1601,6 +1616,7 @@ extern "C" int ngp_nerf_set_dataset_device(ngp_nerf* t, uint32_t n, const ngp_im
 
 // update_density_grid_nerf, testbed_nerf.cu:2476-2592
 extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float decay, uint32_t n_uniform, uint32_t n_nonuniform) {
+	FlagScope flag_scope_(t->dbg);
 	invalidate_k1(t);
 	REQUIRE(t->n_images > 0, "update_density_grid: no dataset");
 	hipStream_t s = (hipStream_t)stream;
@@ -1722,6 +1738,7 @@ static int error_map_build_cdfs(ngp_nerf* t, hipStream_t s) {
 }
 
 static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_counters, bool optimizer_follows = false) {
+	FlagScope flag_scope_(t->dbg);
 	REQUIRE(t->n_images > 0, "train: no dataset");
 	hipStream_t s = (hipStream_t)stream;
 	const ngp_nerf_options& o = t->opt;
@@ -2328,6 +2345,7 @@ extern "C" int ngp_nerf_set_light_dir(ngp_nerf* t, int has_light_dirs, const flo
 
 // Testbed::render_nerf (testbed_nerf.cu:1894-2149): one spp of a frame into premultiplied linear RGBA + depth
 extern "C" int ngp_nerf_render(ngp_nerf* t, void* stream, const ngp_render_params* rp, float* frame, float* depth) {
+	FlagScope flag_scope_(t->dbg);
 	REQUIRE(t && rp && frame, "render: null argument");
 	REQUIRE(rp->lens_mode >= NGP_LENS_PERSPECTIVE && rp->lens_mode <= NGP_LENS_ORTHOGRAPHIC, "render: unknown lens mode");
 	hipStream_t s = (hipStream_t)stream;
@@ -2406,5 +2424,15 @@ extern "C" int ngp_render_tonemap(void* stream, float* rgba, uint64_t n_pixels, 
 extern "C" int ngp_host_tonemap_pixel(const float rgba[4], float exposure, const float background_linear[4], int to_srgb, int curve, float out[4]) {
 	const f4 r = tonemap_pixel({rgba[0], rgba[1], rgba[2], rgba[3]}, std::pow(2.0f, exposure), background_linear[0], background_linear[1], background_linear[2], background_linear[3], to_srgb, curve);
 	out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+	return 0;
+}
+
+// per-handle ablation switches (see FlagScope): on = 0 removes the override (the handle follows the process-wide switches again)
+extern "C" int ngp_model_set_debug_flags(ngp_model* m, int on, uint32_t flags, uint32_t flags2) { REQUIRE(m, "null model"); m->dbg.on = on != 0; m->dbg.flags = flags; m->dbg.flags2 = flags2; return 0; }
+extern "C" int ngp_nerf_set_debug_flags(ngp_nerf* t, int on, uint32_t flags, uint32_t flags2) {
+	REQUIRE(t, "null trainer");
+	invalidate_k1(t);
+	t->dbg.on = on != 0; t->dbg.flags = flags; t->dbg.flags2 = flags2;
+	t->model->dbg = t->dbg;
 	return 0;
 }

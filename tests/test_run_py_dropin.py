@@ -45,9 +45,16 @@ def test_run_py_trains_saves_and_reports_psnr():
     assert os.path.getsize(snap) > 1 << 20
     for f in ("ref.png", "out.png", "diff.png"):  # run.py writes the first test view next to the working directory
         assert os.path.exists(os.path.join(d, f))
-    # the snapshot run.py wrote loads back through run.py (--load_snapshot without --scene is not supported here: the dataset comes from --scene)
+    # the snapshot run.py wrote loads back through run.py, next to the dataset ...
     cmd2 = [sys.executable, RUN_PY, "--scene", os.path.join(d, "transforms_train.json"), "--load_snapshot", snap, "--test_transforms", os.path.join(d, "transforms_test.json")]
     r2 = subprocess.run(cmd2, env=ENV, cwd=d, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     m2 = re.search(r"PSNR=([0-9.]+)", r2.stdout)
     assert m2 and abs(float(m2.group(1)) - psnr) < 0.05, (r2.stdout[-500:], psnr)
+    # ... and WITHOUT --scene: the dataset metadata comes from the snapshot itself (from_json(NerfDataset), testbed.cu:5386-5400; host/testbed.cpp dataset_from_json),
+    # enough to evaluate on the test transforms -- same PSNR again
+    cmd3 = [sys.executable, RUN_PY, "--load_snapshot", snap, "--test_transforms", os.path.join(d, "transforms_test.json")]
+    r3 = subprocess.run(cmd3, env=ENV, cwd=d, capture_output=True, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    m3 = re.search(r"PSNR=([0-9.]+)", r3.stdout)
+    assert m3 and abs(float(m3.group(1)) - psnr) < 0.05, (r3.stdout[-500:], psnr)
