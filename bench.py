@@ -173,11 +173,12 @@ def run_ab_psnr(lib, scene, args, steps, seeds=(1337,)):
     standard error -- single pairs vary by +-0.15 dB per path, so only the mean over seeds can resolve the north-star tolerance of 0.1 dB.
     --ab-clamp-variants adds both paths with mip_from_dt's crossed-bounds clamp as min(max()) (DBG_K1_MIP_CLAMP_MIN_MAX): the round-4 decision
     (tcnn's lower-bound-first form, the default) against its alternative; only multi-cascade scenes (fox) can differ."""
-    paths = [("production", 0), ("reference_order", REFERENCE_ORDER_FLAGS)]
+    ref_flags = REFERENCE_ORDER_FLAGS & ~8192 if getattr(args, "ab_lazy_k2", False) else REFERENCE_ORDER_FLAGS
+    paths = [("production", 0), ("reference_order", ref_flags)]
     if args.ab_clamp_variants:
-        paths += [("production_clamp_min_max", CLAMP_MIN_MAX_FLAG), ("reference_order_clamp_min_max", REFERENCE_ORDER_FLAGS | CLAMP_MIN_MAX_FLAG)]
+        paths += [("production_clamp_min_max", CLAMP_MIN_MAX_FLAG), ("reference_order_clamp_min_max", ref_flags | CLAMP_MIN_MAX_FLAG)]
     out = {"eval": f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}", "steps": steps, "seeds": list(seeds), "scene": scene["name"],
-           "reference_order_flags": REFERENCE_ORDER_FLAGS, "paths": {n: f for n, f in paths}}
+           "reference_order_flags": ref_flags, "paths": {n: f for n, f in paths}}
     per = {n: {str(k): [] for k in steps} for n, _ in paths}
     wall = {n: 0.0 for n, _ in paths}
     spr = {n: [] for n, _ in paths}
@@ -397,6 +398,8 @@ def main():
     ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
     ap.add_argument("--ab-seeds", type=int, default=1, help="--ab-psnr: number of seeds (1337, 1338, ...) per path; mean, standard deviation and the paired difference with its standard error are reported")
     ap.add_argument("--ab-seed0", type=int, default=1337, help="--ab-psnr: first seed")
+    ap.add_argument("--ab-only", action="store_true", help="run only the --ab-psnr experiment (no timed region) and print its JSON: tools/ab_psnr_parallel.py runs several of these side by side, one seed range each")
+    ap.add_argument("--ab-lazy-k2", action="store_true", help="--ab-psnr: the reference-order path keeps the lazy K2 (it produces the same compacted batch as the eager order: tests/test_gpu_train.py::test_lazy_k2_matches_eager) -- the path then differs from production in sample positions (sequential K1), compositing order (sequential K3) and gradient sums (half atomics) only, at 2/3 of the time")
     ap.add_argument("--ab-clamp-variants", action="store_true", help="--ab-psnr: also train both paths with mip_from_dt's crossed-bounds clamp as min(max()) (ablation of the round-4 decision)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak = --batch samples per GPU per step (default, the driver's mode); strong = --batch samples per step in total (B / N per GPU)")
     ap.add_argument("--dp-backend", choices=["auto", "rccl", "torch"], default="auto", help="N > 1: gradient / counter all-reduce inside libngp_hip (RCCL, ngp_comm_*) or through torch.distributed")
@@ -430,6 +433,10 @@ def main():
     lib.ngp_debug_get_flags.restype = C.c_uint32
     ablation = {"debug_flags": int(lib.ngp_debug_get_flags()), "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("NGP_")}}
     scene = load_scene(args)
+    if args.ab_only:
+        ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[args.ab_seed0 + i for i in range(max(args.ab_seeds, 1))])
+        result_out.write(json.dumps(ab) + "\n"); result_out.flush()
+        return
     if args.scaling == "strong":  # total work fixed: every rank trains B / N samples per step (the library needs a multiple of 256)
         args.batch = max(256, args.batch // world // 256 * 256)
     cfg, opts, model, nerf = make_trainer(lib, scene, args.batch, rank, world)
