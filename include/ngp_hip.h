@@ -168,7 +168,10 @@ void ngp_model_destroy(ngp_model*);
 
 /* n_params (nerf_network.h:388-390); *n_mlp_params = "matrix" params (first in the layout). */
 int ngp_model_n_params(const ngp_model*, uint64_t* n_params, uint64_t* n_mlp_params);
-/* Trainer::params / params_inference / gradients device pointers (for snapshots / all-reduce). */
+/* Trainer::params / params_inference / gradients device pointers (for snapshots / all-reduce).
+ * On one GPU ngp_nerf_train applies the optimizer to the hashed levels inside the scatter kernel's epilogue: after such a step
+ * `gradients` holds the MLP and dense-level gradients only, the hashed levels' slots are NOT written (they stay zero).  A caller
+ * that reads gradients back uses ngp_nerf_train_forward_backward / ngp_model_backward (never fused), or NGP_NO_FUSED_ADAM=1. */
 int ngp_model_param_ptrs(ngp_model*, float** master, ngp_half** params, ngp_half** inference_params,
                          ngp_half** gradients);
 /* Per-level offsets (in entries) and hashmap sizes; MultiLevelEncoding::level_params_offset

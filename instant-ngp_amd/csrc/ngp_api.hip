@@ -598,7 +598,9 @@ static int model_training_step_impl(ngp_model* m, void* stream, const float* in,
 				const uint64_t res = m->gm.resolution[l], begin = m->n_mlp + (uint64_t)m->gm.offset[l] * m->gm.F;
 				if (res * res * res > m->gm.hashmap_size[l]) first_hashed = std::min(first_hashed, begin); else if (begin >= first_hashed) ordered = false;
 			}
-			if (ordered && first_hashed < m->n_params && first_hashed % 4 == 0) {
+			// the sweep's own precondition, checked BEFORE the epilogue may touch a parameter (a refused optimizer step must not leave the hashed levels updated)
+			const bool betas_ok = 65535.0f * std::log(m->cfg.beta1) < -18.f && 65535.0f * std::log(m->cfg.beta2) < -18.f;
+			if (ordered && betas_ok && first_hashed < m->n_params && first_hashed % 4 == 0) {
 				ba.fuse_adam = 1; ba.adam = make_adam_args(m, fuse_optimizer_loss_scale, m->step + 1);
 				m->adam_fused_pending = true; m->adam_sweep_end = first_hashed;
 			}
@@ -1195,7 +1197,10 @@ extern "C" int ngp_model_optimizer_step(ngp_model* m, void* stream, float loss_s
 	FlagScope flag_scope_(m->dbg);
 	++m->step; // Adam::step: ++m_current_step
 	AdamArgs a = make_adam_args(m, loss_scale, m->step);
-	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
+	if (!(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f)) {
+		--m->step; m->adam_fused_pending = false; // nothing was applied (the fused epilogue checks the same condition before it is armed)
+		REQUIRE(false, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
+	}
 	if (m->adam_fused_pending) { a.n_params = m->adam_sweep_end; m->adam_fused_pending = false; }
 	m->last_sweep_params = a.n_params; // the hashed levels were updated by this step's k_grad_accumulate (same arguments)
 	{ ProfScope ps(P_OPTIMIZER, (hipStream_t)stream); launch_optimizer_step((hipStream_t)stream, a); }
