@@ -707,20 +707,19 @@ __global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* _
 	}
 }
 
-// x-major copy of the Morton-ordered bitfield (all cascades): one thread per output byte = 8 x-consecutive cells
+// x-major copy of the Morton-ordered bitfield (all cascades): one thread per output byte = 8 x-consecutive cells (x0 a multiple of 8).  Their Morton indices are
+// m0 + {0, 1, 8, 9, 64, 65, 72, 73} with m0 = morton(x0, y, z) (x's bits land on Morton bits 0, 3, 6; m0's own bits 0, 3, 6 are clear): two bit pairs in the 16-bit
+// word at byte m0 / 8 (even: Morton bit 3 is clear) and two in the word eight bytes further -- two loads and four shifts instead of eight Morton codes and eight byte
+// loads (round 5: 29 -> see profiles/r05_*grid*).
 __global__ void k_build_linear_bitfield(const uint8_t* __restrict__ bitfield, uint8_t* __restrict__ linear, uint32_t n_bytes) {
 	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_bytes) return;
 	const uint32_t casc = b / (GRID_N_CELLS / 8), lb = b % (GRID_N_CELLS / 8);
 	const uint32_t cell0 = lb * 8, x0 = cell0 % GRIDSIZE, y = (cell0 / GRIDSIZE) % GRIDSIZE, z = cell0 / (GRIDSIZE * GRIDSIZE);
 	const uint8_t* src = bitfield + grid_mip_offset(casc) / 8;
-	uint32_t out = 0;
-#pragma unroll
-	for (uint32_t k = 0; k < 8; ++k) {
-		const uint32_t m = morton3D(x0 + k, y, z);
-		out |= ((src[m >> 3] >> (m & 7u)) & 1u) << k;
-	}
-	linear[b] = (uint8_t)out;
+	const uint32_t m0 = morton3D(x0, y, z), sh = m0 & 7u; // sh in {0, 2, 4, 6}
+	const uint32_t w0 = *(const uint16_t*)(src + (m0 >> 3)), w1 = *(const uint16_t*)(src + (m0 >> 3) + 8);
+	linear[b] = (uint8_t)(((w0 >> sh) & 3u) | (((w0 >> (sh + 8u)) & 3u) << 2) | (((w1 >> sh) & 3u) << 4) | (((w1 >> (sh + 8u)) & 3u) << 6));
 }
 
 // one bit per 4x4x4 block of cells of the x-major copy: one thread per coarse cell, 32 coarse cells (one word) per 32 threads
@@ -1558,11 +1557,17 @@ __global__ void k_generate_grid_samples(uint32_t n_elements, ngp_pcg32 rng_in, c
 	Rng rng(rng_in);
 	rng.advance((uint64_t)(i * 4u));
 	const uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
-	uint32_t idx = 0;
-	for (uint32_t j = 0; j < 10; ++j) {
-		idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % GRID_N_CELLS;
-		idx += level * GRID_N_CELLS;
-		if (grid_in[idx] > thresh) break;
+	// up to ten candidate cells, the first one above the threshold (the last one if none is): the first candidate alone (the uniform samples nearly always keep it), then the
+	// other nine with their loads in flight together instead of one dependent round trip per rejected candidate (the non-uniform samples reject most)
+	const uint32_t h0 = (i + step * n_elements) * 56924617u + 96925573u;
+	uint32_t idx = h0 % GRID_N_CELLS + level * GRID_N_CELLS;
+	if (!(grid_in[idx] > thresh)) {
+		uint32_t cand[9]; float val[9];
+#pragma unroll
+		for (uint32_t j = 1; j < 10; ++j) { cand[j - 1] = (h0 + j * 19349663u) % GRID_N_CELLS + level * GRID_N_CELLS; val[j - 1] = grid_in[cand[j - 1]]; }
+		idx = cand[8];
+#pragma unroll
+		for (int j = 7; j >= 0; --j) idx = val[j] > thresh ? cand[j] : idx;
 	}
 	const uint32_t pos_idx = idx % GRID_N_CELLS;
 	const uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);

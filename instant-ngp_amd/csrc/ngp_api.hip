@@ -958,9 +958,9 @@ struct ngp_sdf {
 	SdfTriangle* tris = nullptr; SdfBvhNode4* nodes = nullptr; int root = 0; uint32_t stack_entries = 4; float* cdf = nullptr;
 	float* positions = nullptr; float* distances = nullptr; ngp_half* pred = nullptr; uint32_t cap = 0;
 	float* loss_sum = nullptr; uint32_t* iou_counters = nullptr;
-	uint32_t* stab_list = nullptr; uint32_t* stab_count = nullptr; // scratch of the ground-truth launches (sdf_kernels.hip, SdfQueryScratch): 6 x cap words
+	uint32_t* stab_list = nullptr; uint32_t* stab_count = nullptr; float* stab_offsets = nullptr; // scratch of the ground-truth launches (sdf_kernels.hip, SdfQueryScratch): 6 x cap words, 4 counter words, cap x 2 lattice offsets
 	void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
-	SdfQueryScratch query() const { return {stab_list, stab_list + cap, stab_count, stab_list + 2 * (size_t)cap, stab_list + 3 * (size_t)cap, stab_list + 4 * (size_t)cap, stab_list + 5 * (size_t)cap, sort_temp, sort_temp_bytes}; }
+	SdfQueryScratch query() const { return {stab_list, stab_list + cap, stab_count, stab_list + 2 * (size_t)cap, stab_list + 3 * (size_t)cap, stab_list + 4 * (size_t)cap, stab_list + 5 * (size_t)cap, sort_temp, sort_temp_bytes, stab_offsets, stab_count + 1}; }
 	Rng rng; uint32_t training_step = 0;
 };
 // load_mesh's normalisation (testbed_sdf.cu:1380-1410): raw box inflated by 0.5 % of its diagonal, scaled by its largest extent and centred in the unit cube
@@ -1106,19 +1106,22 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	sdf_surface_cdf(tris, cdf);
 	t->cap = std::max<uint32_t>(o->batch_size, 1u << 21); // calculate_iou works in batches of 128^3 = 2^21
 	if (dev_alloc(&t->tris, n_triangles) || dev_alloc(&t->nodes, nodes2.size()) || dev_alloc(&t->cdf, n_triangles) || dev_alloc(&t->positions, (size_t)t->cap * 3) ||
-		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8) || dev_alloc(&t->stab_list, (size_t)t->cap * 6) || dev_alloc((char**)&t->sort_temp, t->sort_temp_bytes = sdf_point_sort_temp_bytes(t->cap)) || dev_alloc(&t->stab_count, 1)) { delete t; return 1; }
+		dev_alloc(&t->distances, t->cap) || dev_alloc(&t->pred, t->cap) || dev_alloc(&t->loss_sum, 1) || dev_alloc(&t->iou_counters, 8) || dev_alloc(&t->stab_list, (size_t)t->cap * 6) || dev_alloc((char**)&t->sort_temp, t->sort_temp_bytes = sdf_point_sort_temp_bytes(t->cap)) || dev_alloc(&t->stab_count, 4) || dev_alloc(&t->stab_offsets, (size_t)t->cap * 2)) { delete t; return 1; }
 	HIPCHK(hipMemcpy(t->tris, tris.data(), tris.size() * sizeof(SdfTriangle), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->nodes, nodes2.data(), nodes2.size() * sizeof(SdfBvhNode4), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemset(t->loss_sum, 0, 4));
 	HIPCHK(hipMemset(t->stab_list + t->cap, 0, (size_t)t->cap * 4)); // the first stab rays' "escaped" marks
+	HIPCHK(hipMemset(t->stab_count, 0, 16));
+	launch_sdf_stab_offsets(nullptr, t->cap, t->stab_offsets);
+	HIPCHK(hipDeviceSynchronize());
 	*out = t;
 	return 0;
 }
 extern "C" void ngp_sdf_destroy(ngp_sdf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
-	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, t->sort_temp}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, (void*)t->stab_offsets, t->sort_temp}) if (p) (void)hipFree(p);
 	delete t;
 }
 // generate_training_samples_sdf: fills positions / distances for `n` samples and advances m_rng like the reference

@@ -298,8 +298,11 @@ struct SdfQueryScratch {
 	uint32_t* n_survivors; // one word
 	uint32_t* keys; uint32_t* keys_sorted; uint32_t* idx; uint32_t* order; // cap each: (cost class, Morton) keys of the points, identity, and the sorted order
 	void* sort_temp; size_t sort_temp_bytes;
+	float* stab_offsets;   // cap x 2: the stab rays' lattice offsets of point i (a function of i alone)
+	uint32_t* work_ctr;    // 2 words: items reserved from the persistent kernel's two lists, zero between calls
 };
 size_t sdf_point_sort_temp_bytes(uint32_t n);
+void launch_sdf_stab_offsets(hipStream_t s, uint32_t n, float* offsets);
 int sdf_point_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n);
 int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries /* 3 * depth + 1 */,
 		const SdfTriangle* tris, int use_upper_bounds, const SdfQueryScratch& q);

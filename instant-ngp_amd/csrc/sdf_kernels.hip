@@ -325,6 +325,143 @@ __global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restric
 		__builtin_amdgcn_wave_barrier();
 	}
 }
+// ---- round 5: ONE persistent launch, lanes refilled from work lists -----------------------------------------------------------------------------------------------
+// What the three launches above leave on the table: a wavefront lasts as long as its slowest lane, and the walk lengths have heavy tails (a near-surface point's distance walk
+// 39 steps on average, a uniform point's 163 with a maximum of ~530; an escaping first ray: median 6 steps, but up to ~1200 when it grazes the mesh; an inside point's 32 rays
+// ~35 each) -- most lanes of most wavefront-steps are idle, and a wavefront-step costs its ~250 VALU instructions whatever the number of live lanes.  Here the walks are ITEMS
+// of two lists -- distance item t = point t; ray item r * n_pad + t = stab ray r of point t, ray-major, so that by the time ray r of a point comes up its earlier rays have
+// usually decided it (an escaped point's remaining rays are dropped at the fetch: one coalesced load of 64 marks) -- and a lane whose walk has ended takes the next live item
+// of its wavefront's reservation (SDF_FETCH_CHUNK items per returning atomic; candidates -> lanes by ballot ranks through 64 words of LDS).  Inner steps come in rounds of at
+// most SDF_INNER_STEPS, then the wavefront's leaves are evaluated together (while-while with a bound: a grazing ray's long chain of inner nodes does not hold the others'
+// leaves back).  A wavefront works on one list at a time (the two walks are different code) and moves to the other list when its own is drained.  k_sdf_finalize applies the
+// sign once every walk has ended: negative iff none of the point's rays escaped -- what the reference's serial loop returns, whatever the order.
+constexpr uint32_t SDF_FETCH_CHUNK = 256; // items per reservation (n_pad is a multiple of it: a reservation holds one ray index)
+constexpr uint32_t SDF_REFILL_MIN = 16;   // idle lanes that make a wavefront look for work before its next round
+constexpr uint32_t SDF_INNER_STEPS = 8;   // inner-node steps per round
+struct SdfWalkArgs {
+	uint32_t n, n_pad, stack_entries; int root, use_upper_bounds;
+	const float* positions; float* distances; const SdfBvhNode4* nodes; const SdfTriangle* tris;
+	uint32_t* escaped; const float* stab_offsets; uint32_t* ctr; // ctr[0]: distance items reserved, ctr[1]: ray items reserved (zero on entry; k_sdf_finalize clears them)
+};
+__global__ void __launch_bounds__(256) k_sdf_stab_offsets(uint32_t n, float* __restrict__ offsets) { // stab_offset(i) depends on i alone: computed once per trainer
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { float ox, oy; stab_offset(i, ox, oy); offsets[2 * i] = ox; offsets[2 * i + 1] = oy; }
+}
+// the marks cross XCDs while the kernel runs: device-scope (write-through / L1-bypassing) accesses; a stale read only costs a walk whose answer is not needed
+static __device__ __forceinline__ uint32_t sdf_mark_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void sdf_mark_set(uint32_t* p) { __hip_atomic_store(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// One wavefront's reservation of a list and the hand-out of its live items to idle lanes.
+struct SdfFetch {
+	uint32_t lo = 0, hi = 0; bool exhausted = false; // wavefront-uniform
+	// idle lanes receive the next live items (`item`, return value true).  Afterwards every idle lane has one, or the list is exhausted.
+	template <bool RAYS>
+	__device__ __forceinline__ bool fill(const SdfWalkArgs& a, bool idle, uint32_t* s_pick /* 64 words of this wavefront */, uint32_t& item) {
+		const uint32_t lane = threadIdx.x & 63u; const uint64_t lt = (1ull << lane) - 1ull;
+		const uint32_t total = RAYS ? 32u * a.n_pad : a.n;
+		bool got = false;
+		for (;;) {
+			const uint64_t im = __ballot(idle && !got);
+			if (!im) break;
+			if (lo >= hi) {
+				if (exhausted) break;
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(a.ctr + (RAYS ? 1 : 0), SDF_FETCH_CHUNK);
+				base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+				if (base >= total) { exhausted = true; break; }
+				lo = base; hi = min(base + SDF_FETCH_CHUNK, total);
+			}
+			const uint32_t cand = lo + lane;
+			bool live = cand < hi;
+			if (RAYS) { const uint32_t t = cand - (lo / a.n_pad) * a.n_pad; live = live && t < a.n; if (live) live = sdf_mark_load(a.escaped + t) == 0u; }
+			const uint64_t lm = __ballot(live);
+			const uint32_t n_live = (uint32_t)__popcll(lm), n_idle = (uint32_t)__popcll(im);
+			if (live) s_pick[__popcll(lm & lt)] = cand;
+			__builtin_amdgcn_wave_barrier();
+			const uint32_t rank = (uint32_t)__popcll(im & lt);
+			if (idle && !got && rank < n_live) { item = s_pick[rank]; got = true; }
+			// live candidates nobody took stay in the reservation
+			lo = n_live <= n_idle ? min(lo + 64u, hi) : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pick[n_idle - 1u]) + 1u;
+			__builtin_amdgcn_wave_barrier();
+		}
+		return got;
+	}
+};
+template <bool RAYS>
+static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLdsStack& st, uint32_t* s_pick) {
+	SdfFetch f;
+	bool busy = false, found = false;
+	uint32_t i = 0, round = 0;
+	int ref = SDF_DONE, sp = 0;
+	f3 p = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f), inv = mk3(0.f, 0.f, 0.f);
+	float best = 0.f;
+	for (;;) {
+		// 1. work for the idle lanes
+		if (!f.exhausted && (uint32_t)__popcll(__ballot(!busy)) >= SDF_REFILL_MIN) {
+			uint32_t item = 0;
+			if (f.template fill<RAYS>(a, !busy, s_pick, item)) {
+				busy = true; sp = 0; ref = a.root; round = 0;
+				const uint32_t r = RAYS ? item / a.n_pad : 0u;
+				i = RAYS ? item - r * a.n_pad : item;
+				p = mk3(a.positions[(size_t)i * 3], a.positions[(size_t)i * 3 + 1], a.positions[(size_t)i * 3 + 2]);
+				if (RAYS) { d = fibonacci_dir32(r, a.stab_offsets[2 * i], a.stab_offsets[2 * i + 1]); inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+				else { const float md = a.use_upper_bounds ? a.distances[i] : SDF_MAX_DIST; best = md * md; found = false; }
+			}
+		}
+		if (!__ballot(busy)) break; // (the hand-out gives every idle lane an item unless the list is exhausted)
+		// 2. another ray of the point has escaped meanwhile: this one's answer is not needed
+		if (RAYS && busy && (round & 1u) && sdf_mark_load(a.escaped + i) != 0u) { busy = false; ref = SDF_DONE; }
+		++round;
+		// 3. inner nodes, towards each lane's next leaf
+		for (uint32_t it = 0; it < SDF_INNER_STEPS && ref >= 0 && ref != SDF_DONE; ++it) {
+			const SdfBvhNode4 n = load_node(a.nodes, ref);
+			float t[4]; int r[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) { t[c] = RAYS ? child_ray_entry(n, c, p, inv) : child_distance_sq(n, c, p); r[c] = n.ref[c]; }
+			sort4(t, r);
+			const float lim = RAYS ? SDF_MAX_DIST : best; // rays: entered before the far end; distance: not farther than the running minimum
+			const bool k3 = RAYS ? t[3] < lim : t[3] <= lim, k2 = RAYS ? t[2] < lim : t[2] <= lim, k1 = RAYS ? t[1] < lim : t[1] <= lim, k0 = RAYS ? t[0] < lim : t[0] <= lim;
+			if (k3) st.set(sp++, r[3]);
+			if (k2) st.set(sp++, r[2]);
+			if (k1) st.set(sp++, r[1]);
+			ref = k0 ? r[0] : (sp > 0 ? st.get(--sp) : SDF_DONE);
+		}
+		// 4. the wavefront's leaves together; walks that have run out of nodes end
+		if (busy && ref < 0) {
+			const int first = (~ref) >> 3, cnt = (~ref) & 7;
+			SdfTriangle T[SDF_LEAF_TRIS]; // all loads first: one round trip
+#pragma unroll
+			for (int k = 0; k < SDF_LEAF_TRIS; ++k) T[k] = a.tris[first + (k < cnt ? k : cnt - 1)];
+			bool hit = false;
+			if (RAYS) {
+#pragma unroll
+				for (int k = 0; k < SDF_LEAF_TRIS; ++k) hit = hit | ((k < cnt) & (tri_ray_intersect(T[k], p, d) < SDF_MAX_DIST));
+			} else {
+#pragma unroll
+				for (int k = 0; k < SDF_LEAF_TRIS; ++k) { const float dd = tri_distance_sq(T[k], p); const bool better = (k < cnt) & (dd <= best); best = better ? dd : best; found = found | better; }
+			}
+			if (hit) { busy = false; ref = SDF_DONE; }        // any hit settles a stab ray
+			else ref = sp > 0 ? st.get(--sp) : SDF_DONE;
+		}
+		if (busy && ref == SDF_DONE) {                         // nothing left to visit
+			if (RAYS) sdf_mark_set(a.escaped + i);             // the ray escaped: the point is outside
+			else a.distances[i] = found ? sqrtf(best) : 0.0f;  // "No closest triangle found": 0, as the reference (triangle_bvh.cu:562-566)
+			busy = false;
+		}
+	}
+}
+__global__ void __launch_bounds__(256, 4) k_sdf_walks(SdfWalkArgs a) {
+	extern __shared__ int s_stack[]; // [stack_entries][256] reference stacks | [4][64] hand-out words
+	SdfLdsStack st; st.col = s_stack + threadIdx.x;
+	uint32_t* s_pick = (uint32_t*)(s_stack + (size_t)a.stack_entries * 256u) + (threadIdx.x >> 6) * 64u;
+	// the distance walks are ~1/8 of the steps: every eighth workgroup starts on them, everybody helps with the other list when its own is drained
+	if ((blockIdx.x & 7u) == 0u) { sdf_walk_list<false>(a, st, s_pick); sdf_walk_list<true>(a, st, s_pick); }
+	else { sdf_walk_list<true>(a, st, s_pick); sdf_walk_list<false>(a, st, s_pick); }
+}
+__global__ void __launch_bounds__(256) k_sdf_finalize(uint32_t n, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ ctr) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { if (escaped[i] == 0u) distances[i] = -distances[i]; escaped[i] = 0u; } // clean for the next call
+	if (i == 0) { ctr[0] = 0u; ctr[1] = 0u; }
+}
 // the same functions on the host (test hook; the product never calls it)
 void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, const SdfTriangle* tris, int use_upper_bounds) {
 	for (uint32_t i = 0; i < n; ++i) {
@@ -345,10 +482,24 @@ __global__ void __launch_bounds__(256) k_sdf_compare_signs(uint32_t n, const flo
 	}
 }
 
+void launch_sdf_stab_offsets(hipStream_t s, uint32_t n, float* offsets) { if (n) hipLaunchKernelGGL(k_sdf_stab_offsets, dim3((n + 255) / 256), dim3(256), 0, s, n, offsets); }
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a) { if (a.n) hipLaunchKernelGGL(k_sdf_generate_positions, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries, const SdfTriangle* tris,
 		int use_upper_bounds, const SdfQueryScratch& q) {
 	if (!n) return 0;
+	static const bool persistent = !(getenv("NGP_SDF_PERSISTENT") && atoi(getenv("NGP_SDF_PERSISTENT")) == 0); // 0: the round-4 three-launch path (ablation)
+	if (persistent) {
+		SdfWalkArgs a;
+		a.n = n; a.n_pad = (n + SDF_FETCH_CHUNK - 1u) / SDF_FETCH_CHUNK * SDF_FETCH_CHUNK; a.stack_entries = std::min<uint32_t>(std::max<uint32_t>(stack_entries, 4u), (uint32_t)SDF_STACK_MAX);
+		a.root = root; a.use_upper_bounds = use_upper_bounds; a.positions = positions; a.distances = distances; a.nodes = nodes; a.tris = tris;
+		a.escaped = q.escaped; a.stab_offsets = q.stab_offsets; a.ctr = q.work_ctr;
+		const uint32_t lds = a.stack_entries * 256u * 4u + 4u * 64u * 4u, per_cu = std::max(1u, std::min(4u, (160u * 1024u) / (lds + 64u)));
+		// a grid of resident workgroups (no more than there are reservations to make)
+		const uint32_t grid = std::min<uint32_t>(256u * per_cu, (uint32_t)(((uint64_t)33u * a.n_pad / SDF_FETCH_CHUNK + 3u) / 4u) + 8u);
+		hipLaunchKernelGGL(k_sdf_walks, dim3(grid), dim3(256), lds, s, a);
+		hipLaunchKernelGGL(k_sdf_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, q.escaped, q.work_ctr);
+		return 0;
+	}
 	static const uint32_t first_rays = getenv("NGP_SDF_FIRST_RAYS") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_FIRST_RAYS")), 0), 32) : 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel (ablation knob)
 	// 0: batch order (production); 1: (cost class, Morton) order; 2: Morton order, one class.  Ablation knob: coherent wavefronts measured SLOWER (batch 3.5 -> 4.3 ms, 2^18 uniform points
 	// 3.2 -> 5.6 / 6.2 ms, profiles/r04_f4_sdf_ground_truth.txt v7) -- sorted points make concurrently running wavefronts hammer the same lines.
