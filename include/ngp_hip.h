@@ -556,6 +556,11 @@ int ngp_nerf_set_debug_flags(ngp_nerf*, int on, uint32_t flags, uint32_t flags2)
 int ngp_debug_set_train_mode(int mode);
 /* depth supervision of the STAND-ALONE ngp_k_compute_loss (the trainer takes it from ngp_nerf_options; testbed_nerf.cu:1027-1029, 1126-1129) */
 int ngp_debug_set_depth_supervision(float depth_supervision_lambda, int depth_loss_type);
+/* Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only: the per-ray target records the trainer's ray set-up kernel computes for K3 (what
+ * compute_loss_kernel_train_nerf derives per ray at testbed_nerf.cu:930-1027: target colour, background, target depth).  K1 writes them to `buf` (device, 8 floats per
+ * ray slot) with the given colour options, K3 reads them instead of deriving them.  plain_dataset != 0: the caller vouches for 8-bit images, Perspective / OpenCV lenses
+ * and still cameras (the ray set-up kernel's small instance).  buf = null: off. */
+int ngp_debug_set_ray_targets(float* buf, int plain_dataset, const float* background_color3, int color_space_srgb, int random_bg_color, int linear_colors);
 /* Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only: CDFs (device; null = uniform) and the error map K3 splats into (device; null = none). */
 int ngp_debug_set_error_sampling(const float* cdf_x_cond_y, const float* cdf_y, const float* cdf_img, const int32_t cdf_res[2], float* error_map, const int32_t error_map_res[2]);
 /* Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only: the per-image extra dims (extra_dims_gpu, testbed_nerf.cu:718-719, 744, 833; device, n_images x n_extra

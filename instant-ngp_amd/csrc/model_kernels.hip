@@ -1341,19 +1341,7 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 // Adam state of an entry is only touched when one of its gradients is non-zero (sparse update of the reference).
 // (no fp contraction in the two update rules: they are instantiated in k_optimizer AND in k_grad_accumulate's fused epilogue, and both must round identically --
 // tests/test_gpu_train.py::test_fused_optimizer_epilogue_is_the_separate_sweep; it is also the arithmetic of the un-contracted oracle)
-// The debiased learning rate of optimizer step t of a parameter: lr * sqrt(1 - beta2^t) / (1 - beta1^t), beta^t as exp(t ln beta) (the per-parameter step counters make
-// powf the dominant cost of the sweep otherwise).  It depends on t alone, and the four parameters of a table entry nearly always share t (they are touched together): the
-// callers keep the last (t, value) pair of their entry (AdamDebiasCache) and evaluate the expression again only for a different t -- the same expression, the same bits.
-// Once t ln beta < -18 for both betas, exp() < 2^-25 and both 1 - exp() round to exactly 1.0f: lr * sqrt(1) / 1 IS lr (round 5: half of k_grad_accumulate's issue slots
-// were VALU, a third of them these two exp, the sqrt and the division per parameter).
-struct AdamDebiasCache { uint32_t step = 0u; float lr = 0.f; };
-DEV float adam_debiased_lr(const AdamArgs& a, uint32_t current_step) {
-#pragma clang fp contract(off)
-	const float x2 = (float)current_step * a.log_beta2, x1 = (float)current_step * a.log_beta1;
-	if (x2 < -18.0f && x1 < -18.0f) return a.lr;
-	return a.lr * (sqrtf(1 - __expf(x2)) / (1 - __expf(x1)));
-}
-DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint16_t& step, AdamDebiasCache& dc) {
+DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weight_fp, float& m, float& v, uint16_t& step) {
 #pragma clang fp contract(off)
 	if (matrix) gradient += a.l2_reg * weight_fp;
 	const float gradient_sq = gradient * gradient;
@@ -1362,8 +1350,11 @@ DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weig
 	// per-parameter step counter, 16 bits SATURATING: it only feeds the two debias factors, and 1 - beta^t is exactly 1.0f in fp32 long before
 	// t = 65,535 (beta2 = 0.99: t > 1,700; beta2 = 0.999: t > 17,000) -- the result is the one of a 32-bit counter, at half the bytes per updated entry
 	const uint32_t current_step = step == 0xFFFFu ? 0xFFFFu : (uint32_t)(++step);
-	if (current_step != dc.step) { dc.step = current_step; dc.lr = adam_debiased_lr(a, current_step); } // (current_step >= 1: a fresh cache never matches)
-	const float lr = dc.lr;
+	float lr = a.lr;
+	// beta^t as exp(t ln beta): the per-parameter step counters make powf the dominant cost of the sweep otherwise.  (Round 5: evaluating this factor once per distinct
+	// step count of an entry's four parameters -- they nearly always share it -- removes 15 % of k_grad_accumulate's VALU instructions and not a microsecond of its time:
+	// the kernel waits for its LDS atomics and its records, profiles/r05_ab_rng_tables_adam_cache.txt.)
+	lr *= sqrtf(1 - __expf((float)current_step * a.log_beta2)) / (1 - __expf((float)current_step * a.log_beta1));
 	const float effective_lr = fminf(fmaxf(lr / (sqrtf(second) + a.eps), 0.0f), 3.402823466e+38f);
 	float nw = weight_fp - effective_lr * first;
 	asm volatile("" : "+v"(nw)); // the fp32 value exists before the caller rounds it to half (no v_fma_mixlo_f16 from the unrounded expression: the master weight and its half copy must agree)
@@ -1497,11 +1488,10 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 					float4 mw = ((const float4*)o.master)[i4], m4 = ((const float4*)o.m)[i4], v4 = ((const float4*)o.v)[i4];
 					uint2 st = ((const uint2*)o.steps)[i4];
 					float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
-					AdamDebiasCache dc;
 #pragma unroll
 					for (int k = 0; k < 4; ++k) {
 						if (!upd[k]) continue;
-						const float nw = adam_update(o, false, g[k], mwp[k], mp[k], vp[k], sp[k], dc);
+						const float nw = adam_update(o, false, g[k], mwp[k], mp[k], vp[k], sp[k]);
 						mwp[k] = nw;
 						w4[k] = (_Float16)nw;
 					}
@@ -2627,11 +2617,10 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 		float4 mw = ((const float4*)a.master)[i4], m4 = ((const float4*)a.m)[i4], v4 = ((const float4*)a.v)[i4];
 		uint2 st = ((const uint2*)a.steps)[i4];
 		float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
-		AdamDebiasCache dc;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			if (!upd[k]) continue;
-			const float nw = adam_update(a, matrix, g[k], mwp[k], mp[k], vp[k], sp[k], dc);
+			const float nw = adam_update(a, matrix, g[k], mwp[k], mp[k], vp[k], sp[k]);
 			mwp[k] = nw;
 			w4[k] = (_Float16)nw;
 			if (matrix) {

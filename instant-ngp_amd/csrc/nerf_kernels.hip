@@ -185,6 +185,11 @@ static __device__ __forceinline__ uint32_t k1_slot_to_ray(uint32_t li, uint32_t 
 // target colour, normalisation, box intersection, stepping-space conversion) on fewer threads than the chip has lanes, so it is split
 // into four independent roles on separate wavefronts (blockIdx.y): role 0 = ray geometry, roles 1..3 = one colour channel of the
 // target / background each (the conversions are component-wise: same arithmetic, same results).  Measured: 48 -> see DESIGN 8.
+// PLAIN (round 5): the instance for the datasets of BASELINE.json -- every image 8-bit, Perspective or OpenCV lens, still camera, uniform pixel sampling, no depth
+// supervision (checked on the host: K1Args::plain_dataset and the launch).  The general instance carries seven lens models, the rolling-shutter slerp, three pixel
+// formats and the CDF samplers: 37 KiB of instructions that these short-lived threads mostly fetch and skip (the slow class of boxes charges ~12 of the kernel's ~30 us
+// for it, docs/ROUND_NOTES.md round 3).  Same functions with constant arguments, so the same arithmetic on the paths that remain.
+template <bool PLAIN>
 __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__ rs) {
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
@@ -201,14 +206,15 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	Rng rng(a.rng);
 	rng.advance((uint64_t)(i * N_RANDOM_PER_RAY));
 	uint32_t img; float pix_pdf;
-	f2 uv = training_pixel(a.cdf, rng, i, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
+	f2 uv = training_pixel(PLAIN ? ErrorCdf{} : a.cdf, rng, i, n_rays, a.n_images, a.metadata, a.snap_to_pixel_centers, img, pix_pdf);
 	const ngp_image_meta& m = a.metadata[img];
+	const int pixel_type = PLAIN ? (int)NGP_IMAGE_BYTE : m.image_data_type;
 	RaySetup& out = rs[li];
 	if (role != 0) {
 		// K3's target colour (testbed_nerf.cu:930-960): same rng stream position, same arithmetic -- channel c of every 3-vector
 		const uint32_t c = role - 1;
-		float tex_w; const float tc = read_rgba_channel(uv, m.resolution, m.pixels, m.image_data_type, c, tex_w);
-		const bool masked = m.image_data_type == NGP_IMAGE_BYTE ? tc < 0.0f : read_rgba_masked(uv, m.resolution, m.pixels, m.image_data_type); // masked-away pixel (red < 0): the ray is not marched
+		float tex_w; const float tc = read_rgba_channel(uv, m.resolution, m.pixels, pixel_type, c, tex_w);
+		const bool masked = pixel_type == NGP_IMAGE_BYTE ? tc < 0.0f : read_rgba_masked(uv, m.resolution, m.pixels, pixel_type); // masked-away pixel (red < 0): the ray is not marched
 		float tgt = 0.f, bg = 0.f;
 		if (!masked) {
 			(void)rng.next_float(); // motionblur_time
@@ -227,14 +233,15 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 		out.tgt[c] = tgt; out.tgt[3 + c] = bg;
 		return;
 	}
-	const bool masked = read_rgba_masked(uv, m.resolution, m.pixels, m.image_data_type);
+	const bool masked = read_rgba_masked(uv, m.resolution, m.pixels, pixel_type);
 	const Box aabb(a.aabb);
 	float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f}, dn[3] = {0.f, 0.f, 1.f}, startt = 0.f, nprime = 0.f; uint32_t n_in = 0;
 	if (!masked) {
 		const float motionblur_time = rng.next_float();
-		const M43 xform = xform_given_rolling_shutter(a.xforms[img], m.rolling_shutter, uv, motionblur_time); // common_device.cuh:670-674
+		const M43 xform = PLAIN ? ldm43(a.xforms[img].start) : xform_given_rolling_shutter(a.xforms[img], m.rolling_shutter, uv, motionblur_time); // common_device.cuh:670-674 (a still camera's matrix is returned untouched)
+		const int lens_mode = PLAIN ? (m.lens_mode == NGP_LENS_OPENCV ? (int)NGP_LENS_OPENCV : (int)NGP_LENS_PERSPECTIVE) : m.lens_mode;
 		f3 ro, rd;
-		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, m.lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform.c[3]; rd = xform.c[2]; } // testbed_nerf.cu:776-778
+		if (!uv_to_ray(uv, m.resolution, m.focal_length, xform, m.principal_point, lens_mode, m.lens_params, 0.0f, ro, rd)) { ro = xform.c[3]; rd = xform.c[2]; } // testbed_nerf.cu:776-778
 		const f3 rdn = normalize3(rd);
 		f2 tminmax = aabb.ray_intersect(ro, rdn);
 		tminmax.x = fmaxf(tminmax.x, 0.0f);
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 			n_in = hi;
 		}
 		// K3's target depth (testbed_nerf.cu:1027): distance along the unnormalised direction; <= 0 = not supervised
-		out.tgt[6] = sqrtf(dot3(rd, rd)) * ((a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
+		out.tgt[6] = sqrtf(dot3(rd, rd)) * ((!PLAIN && a.depth_lambda > 0.0f && m.depth) ? read_depth(uv, m.resolution, m.depth) : -1.0f);
 	} else out.tgt[6] = -1.0f;
 	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2]; out.rdn[0] = dn[0]; out.rdn[1] = dn[1]; out.rdn[2] = dn[2];
 	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = n_in; out.ray_index = i; out.img = img;
@@ -962,7 +969,9 @@ static __device__ __forceinline__ float half_incl_scan(float x) {
 // by instruction issue.  Not kept.)
 // ERR: error-proportional pixel sampling / error-map accumulation compiled in (off in the production instance: the extra live values cost it 16 bytes of scratch).
 // PLAIN: train_mode Nerf and no depth supervision, as compile-time facts (the production instance): the Rfl / depth accumulators and their scans disappear.
-template <int RPW, bool ERR, bool PLAIN>
+// TGT (round 5): the rays' targets come from k1_setup (K3Args::ray_targets; the trainer's lattice path) -- the instance does not carry the target-pixel chain at all
+// (pixel sampler, three pixel formats, six sRGB conversions: a fifth of the PLAIN instance's code).
+template <int RPW, bool ERR, bool PLAIN, bool TGT = false>
 __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 	const uint32_t cs = PLAIN ? 7u : a.cstride; // (the production instance keeps the NerfCoordinate's 7 floats as a compile-time stride: models with extra dims run the generic one)
 	const int train_mode = PLAIN ? 0 : a.train_mode;
@@ -1012,7 +1021,7 @@ __global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
 		base = uni(a.numsteps_inout[i * 2 + 1]);
 		ray_o = ld3(a.rays_in[i].o);
 		f4 tex = {0.f, 0.f, 0.f, 0.f};
-		if (a.ray_targets) { // computed once per ray by k1_setup
+		if (TGT || a.ray_targets) { // computed once per ray by k1_setup
 			const float4 t0 = ((const float4*)(a.ray_targets + (size_t)i * 8))[0], t1 = ((const float4*)(a.ray_targets + (size_t)i * 8))[1];
 			rgbtarget = mk3(t0.x, t0.y, t0.z); background_color = mk3(t0.w, t1.x, t1.y); target_depth = PLAIN ? -1.f : t1.z;
 		} else {
@@ -1750,7 +1759,9 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	p = (char*)scratch + k1_partial_offset(max_local_rays);
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
-	hipLaunchKernelGGL(k1_setup, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
+	const bool plain = a.plain_dataset && !(g_debug_flags2 & DBG2_K1_SETUP_GENERAL) && !a.cdf.img && !a.cdf.x_cond_y && !(a.depth_lambda > 0.0f);
+	if (plain) hipLaunchKernelGGL(k1_setup<true>, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
+	else hipLaunchKernelGGL(k1_setup<false>, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
 	if (single && a.bitfield_coarse && a.bitfield_linear && !a.chunk_march && !a.no_first_point_skip) {
 		// one cascade, constant step: segment prepass + sample lists.  36 KiB of LDS per workgroup: 4 resident per CU = the persistent grid
 		uint16_t* jlist = (uint16_t*)((char*)scratch + k1_jlist_offset(max_local_rays));
@@ -1821,6 +1832,7 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 		const bool plain = a.train_mode == 0 && !(a.depth_lambda > 0.f) && !(g_debug_flags & DBG_K3_GENERIC) && a.cstride == 7;
 		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) { if (err) hipLaunchKernelGGL((k_compute_loss_v2<1, true, false>), g1, dim3(1024), 0, s, a); else hipLaunchKernelGGL((k_compute_loss_v2<1, false, false>), g1, dim3(1024), 0, s, a); }
 		else if (err) hipLaunchKernelGGL((k_compute_loss_v2<2, true, false>), g2, dim3(1024), 0, s, a);
+		else if (plain && a.ray_targets) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true>), g2, dim3(1024), 0, s, a);
 		else if (plain) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true>), g2, dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_compute_loss_v2<2, false, false>), g2, dim3(1024), 0, s, a);
 	}

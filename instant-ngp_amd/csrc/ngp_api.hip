@@ -1300,6 +1300,17 @@ extern "C" int ngp_debug_set_extra_dims(const float* extra_dims_device, uint32_t
 	g_hook_extra_dims = n_extra ? extra_dims_device : nullptr; g_hook_n_extra = n_extra;
 	return 0;
 }
+// Stand-alone ngp_k_generate_training_samples / ngp_k_compute_loss only (test hook): the per-ray target records {rgbtarget[3], background[3], depth, 0} that the trainer's
+// k1_setup computes for K3 (K1Args::ray_targets_out / K3Args::ray_targets) -- K1 writes them into `buf` (device, 8 floats per ray slot) with these colour options, K3 reads
+// them instead of walking the target-pixel chain itself (its TGT instance when the mode is plain).  plain_dataset: the caller vouches for 8-bit images, Perspective /
+// OpenCV lenses and still cameras (k1_setup<PLAIN>).  buf = null: off.
+static float* g_hook_ray_targets = nullptr; static int g_hook_plain_dataset = 0; static float g_hook_bg[3] = {0.f, 0.f, 0.f}; static int g_hook_srgb = 0, g_hook_random_bg = 0, g_hook_linear = 0;
+extern "C" int ngp_debug_set_ray_targets(float* buf, int plain_dataset, const float* background_color, int color_space_srgb, int random_bg_color, int linear_colors) {
+	g_hook_ray_targets = buf; g_hook_plain_dataset = plain_dataset;
+	for (int k = 0; k < 3; ++k) g_hook_bg[k] = background_color ? background_color[k] : 0.f;
+	g_hook_srgb = color_space_srgb; g_hook_random_bg = random_bg_color; g_hook_linear = linear_colors;
+	return 0;
+}
 extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, uint32_t rank, uint32_t world_size, const uint32_t* n_rays_ptr, ngp_aabb aabb,
 		uint32_t max_samples, const uint32_t* max_samples_ptr, ngp_pcg32 rng, uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out,
 		ngp_ray* rays_out, uint32_t* numsteps_out, float* coords_out, uint32_t n_training_images, const ngp_image_meta* metadata, const ngp_xform* xforms,
@@ -1315,6 +1326,8 @@ extern "C" int ngp_k_generate_training_samples(void* stream, uint32_t n_rays, ui
 	a.exact_skip = !(g_debug_flags & DBG_K1_INDEPENDENT_LATTICE); a.clamp_min_max = (g_debug_flags & DBG_K1_MIP_CLAMP_MIN_MAX) ? 1u : 0u;
 	a.cdf = g_hook_cdf;
 	a.extra_dims = g_hook_extra_dims; a.n_extra = g_hook_n_extra;
+	a.plain_dataset = g_hook_plain_dataset;
+	if (g_hook_ray_targets) { a.ray_targets_out = g_hook_ray_targets; for (int k = 0; k < 3; ++k) a.background_color[k] = g_hook_bg[k]; a.color_space_srgb = g_hook_srgb; a.random_bg_color = g_hook_random_bg; a.linear_colors = g_hook_linear; }
 	static char* s_scratch = nullptr; static size_t s_scratch_bytes = 0;
 	static uint8_t* s_linear = nullptr;
 	if (!s_linear && dev_alloc(&s_linear, (size_t)GRID_N_CELLS / 8 * N_CASCADES)) return 1;
@@ -1353,7 +1366,7 @@ extern "C" int ngp_k_compute_loss(void* stream, uint32_t n_rays, const uint32_t*
 		uint32_t dloss_stride, int loss_type, float* loss_output, int rgb_activation, int density_activation, int snap_to_pixel_centers,
 		const float* mean_density_ptr, float near_distance) {
 	K3Args a;
-	a.ray_targets = nullptr; a.train_mode = g_k3_train_mode; a.depth_lambda = g_k3_depth_lambda; a.depth_loss_type = g_k3_depth_loss_type;
+	a.ray_targets = g_hook_ray_targets; a.train_mode = g_k3_train_mode; a.depth_lambda = g_k3_depth_lambda; a.depth_loss_type = g_k3_depth_loss_type;
 	a.n_rays = n_rays; a.n_rays_ptr = n_rays_ptr; a.aabb = aabb; a.rng = rng; a.max_samples_compacted = max_samples_compacted; a.rays_counter = rays_counter;
 	a.loss_scale = loss_scale; for (int k = 0; k < 3; ++k) a.background_color[k] = background_color[k];
 	a.color_space_srgb = color_space_srgb; a.random_bg_color = random_bg_color; a.linear_colors = linear_colors; a.n_images = n_training_images; a.metadata = metadata;
@@ -1437,7 +1450,7 @@ struct ngp_nerf {
 	ngp_nerf_options opt;
 	ngp_aabb aabb;
 	uint32_t n_images = 0, n_images_marked = 0; // n_images_marked: Nerf::Training::n_images_for_training_prev (testbed.h)
-	ngp_image_meta* meta_dev = nullptr; ngp_xform* xforms_dev = nullptr;
+	ngp_image_meta* meta_dev = nullptr; ngp_xform* xforms_dev = nullptr; bool plain_dataset = false; // (set_dataset_common)
 	std::vector<void*> owned_pixels;
 	float* density_grid = nullptr; float* density_grid_tmp = nullptr; uint8_t* bitfield = nullptr; float* mean = nullptr; float* mean_partial = nullptr;
 	float* grid_positions = nullptr; uint32_t* grid_indices = nullptr; ngp_half* grid_mlp_out = nullptr; uint32_t grid_sample_cap = 0;
@@ -1581,6 +1594,15 @@ static int set_dataset_common(ngp_nerf* t, uint32_t n, const std::vector<ngp_ima
 	if (dev_alloc(&t->meta_dev, n) || dev_alloc(&t->xforms_dev, n)) return 1;
 	HIPCHK(hipMemcpy(t->meta_dev, meta.data(), n * sizeof(ngp_image_meta), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(t->xforms_dev, xforms, n * sizeof(ngp_xform), hipMemcpyHostToDevice));
+	// k1_setup's small instance serves datasets like BASELINE.json's: 8-bit pixels, Perspective / OpenCV lenses, still cameras (the general one every other dataset)
+	t->plain_dataset = true;
+	for (uint32_t i = 0; i < n && t->plain_dataset; ++i) {
+		const ngp_image_meta& mi = meta[i];
+		bool plain = mi.image_data_type == NGP_IMAGE_BYTE && (mi.lens_mode == NGP_LENS_PERSPECTIVE || mi.lens_mode == NGP_LENS_OPENCV);
+		for (int k = 0; k < 4; ++k) plain = plain && mi.rolling_shutter[k] == 0.f;
+		for (int k = 0; k < 12; ++k) plain = plain && xforms[i].start[k] == xforms[i].end[k];
+		t->plain_dataset = plain;
+	}
 	if (n != t->n_images) { // the error map and the three CDFs are laid out per image: an open accumulation cycle and installed CDFs end with the old image count
 		t->cdf_valid = false; t->error_cycle_open = false; t->n_steps_since_error_map_update = 0; // (the next step opens a cycle sized for n; dev_grow regrows the buffers)
 	}
@@ -1767,6 +1789,7 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		k1.depth_lambda = o.depth_supervision_lambda;
 		k1.cdf = error_cdf_args(t);
 		k1.extra_dims = t->extra_dims; k1.n_extra = t->n_extra;
+		k1.plain_dataset = t->plain_dataset ? 1 : 0;
 		return k1;
 	};
 	if (phase & 1) {

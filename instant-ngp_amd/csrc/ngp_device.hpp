@@ -67,25 +67,16 @@ struct Rng {
 		x.u = (next_uint() >> 9) | 0x3f800000u;
 		return x.f - 1.0f;
 	}
-	// pcg32::advance (the LCG's skip-ahead in log time).  The reference's loop squares the multiplier and updates the increment for EVERY bit of delta (four 64-bit
-	// multiplications per bit, quarter-rate integer multiplies on the vector ALU) -- but bit b's multiplier M^(2^b) is a constant and its increment is
-	// (1 + M + ... + M^(2^b - 1)) * inc, a constant times the stream's (wavefront-uniform) increment: with both as compile-time tables only the SET bits of delta cost
-	// anything (two multiplications each).  Arithmetic mod 2^64 is exact, so the state is the reference's bit for bit (tests/test_ref_device.py, test_rng.py).
-	// Round 5: every thread of K1's set-up, K3 and the occupancy-grid sampler starts with one of these.
-	struct SkipTables { uint64_t mult[64], geo[64]; };
-	static constexpr SkipTables skip_tables() {
-		SkipTables t{};
-		uint64_t m = 0x5851f42d4c957f2dULL, g = 1u;
-		for (int b = 0; b < 64; ++b) { t.mult[b] = m; t.geo[b] = g; g *= m + 1u; m *= m; }
-		return t;
-	}
+	// pcg32::advance, the reference's loop.  (Round 5 tried compile-time tables of M^(2^b) and (1 + M + ... + M^(2^b - 1)) so that only the set bits of delta cost
+	// multiplications -- exact, but the unrolled form is ~1 KiB of code per call site and K1's set-up / K3 got 5 - 7 us SLOWER on a slow-class box: these kernels pay for
+	// code size, profiles/r05_ab_rng_tables_adam_cache.txt.)
 	NGP_HD void advance(uint64_t delta) {
-		constexpr SkipTables T = skip_tables();
-		uint64_t acc_mult = 1u, acc_plus = 0u;
-#pragma unroll
-		for (int b = 0; b < 64; ++b) {
-			if (b >= 24 && (delta >> b) == 0u) break; // (the common deltas are below 2^24: no test per bit there)
-			if ((delta >> b) & 1u) { acc_mult *= T.mult[b]; acc_plus = acc_plus * T.mult[b] + T.geo[b] * inc; }
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+		while (delta > 0) {
+			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+			cur_plus = (cur_mult + 1) * cur_plus;
+			cur_mult *= cur_mult;
+			delta >>= 1;
 		}
 		state = acc_mult * state + acc_plus;
 	}

@@ -9,7 +9,10 @@ namespace ngp {
 // debug / ablation switches (ngp_debug_set_flags); 0 in production
 extern uint32_t g_debug_flags;
 extern uint32_t g_debug_flags2; // second word of ablation switches (ngp_debug_set_flags2; the 32 bits of the first are taken)
-enum : uint32_t { DBG2_NO_FUSED_T1W = 1 /* round-4 backward pass: T1 (k_train_fwd_bwd) and W (k_wgrad2) as two kernels instead of k_train_fused */ };
+enum : uint32_t {
+	DBG2_NO_FUSED_T1W = 1,      // round-4 backward pass: T1 (k_train_fwd_bwd) and W (k_wgrad2) as two kernels instead of k_train_fused
+	DBG2_K1_SETUP_GENERAL = 2,  // k1_setup's general instance (seven lens models, rolling shutter, three pixel formats, CDF samplers) also for plain datasets
+};
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_NO_HASHED_MERGE = 65536 /* k_grad_bin sums same-cell runs before the sort on the dense levels only (hashed levels: one record per sample and corner): bin + accumulate 150 -> 161 us (profiles/r02_microbench_bin_merge.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,
 	DBG_K1_CHUNK_MARCH = 33554432 /* single cascade + constant step: the chunk kernels k1_count<8, true> / k1_write (production up to round 4a: every lattice point up to the ray's exit is evaluated, 64 per iteration) instead of k1_count_segments / k1_write_list */,
@@ -79,6 +82,7 @@ struct K1Args {
 	float* ray_targets_out; float background_color[3]; int color_space_srgb, random_bg_color, linear_colors;
 	float depth_lambda = 0.f; // > 0: the ray's target depth (testbed_nerf.cu:1027) goes into slot 6 of its target record
 	ErrorCdf cdf;             // testbed_nerf.cu:3152-3155: x_cond_y / y set = sample_focal_plane_proportional_to_error, img set = sample_image_proportional_to_error
+	int plain_dataset = 0;    // host-checked: every image has 8-bit pixels, a Perspective / OpenCV lens and a still camera (start == end, no rolling shutter): k1_setup's small instance
 	const float* extra_dims = nullptr; uint32_t n_extra = 0; // testbed_nerf.cu:718-719, 744: n_extra floats per image, copied behind every NerfCoordinate of the image's rays (coords_out stride = 7 + n_extra)
 };
 

@@ -101,14 +101,34 @@ def test_k1_sequential_kernel_bit_exact(ora, hip, scene, n_rays, rank, world):
         assert np.array_equal(coords[bd:bd + k].view(np.uint32), o["coords"][bo:bo + k].view(np.uint32))
 
 
+class _ray_targets:
+    """The trainer's arrangement for the stand-alone kernels: k1_setup also computes the rays' target records (its four roles), K3 reads them instead of walking the
+    target-pixel chain itself.  plain = 1: k1_setup<PLAIN> (the instance for 8-bit images, Perspective / OpenCV lenses, still cameras -- this scene)."""
+    def __init__(self, hip, n_rays, plain):
+        import torch
+        self.hip, self.buf = hip, torch.zeros(n_rays * 8, dtype=torch.float32, device="cuda")
+        self.plain = plain
+    def __enter__(self):
+        A.check(self.hip, self.hip.ngp_debug_set_ray_targets(dptr(self.buf), self.plain, (C.c_float * 3)(0, 0, 0), 0, 1, 0))  # the colour options _k3_body hands to K3
+        return self
+    def __exit__(self, *exc):
+        self.hip.ngp_debug_set_ray_targets(None, 0, None, 0, 0, 0)
+
+
+@pytest.mark.parametrize("plain", [None, 0, 1])
 @pytest.mark.parametrize("n_rays,rank,world", [(4096, 0, 1), (1000, 0, 1), (4096, 1, 2)])
-def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world):
+def test_k1_sample_parallel_kernel(ora, hip, scene, n_rays, rank, world, plain):
     """Production K1 (one wavefront per ray over the closed-form lattice t_j = from_stepping_space(n' + j)).
     Deterministic output (ray-index order, prefix-sum spans). Versus the sequential recurrence: rays and ray geometry
     bit-exact; >= 99.5 % of rays with identical sample counts, >= 90 % bit-identical, every matching-count ray within
-    2e-6 absolute of the reference positions (<= 2 ulp of t in [0, 2.5]), total sample count within 0.1 %."""
+    2e-6 absolute of the reference positions (<= 2 ulp of t in [0, 2.5]), total sample count within 0.1 %.
+    plain = 0 / 1 (round 5): with the set-up kernel's colour roles switched on as in the trainer, general instance / k1_setup<PLAIN>: same bars."""
     max_samples = 1 << 20
-    o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+    if plain is None:
+        o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
+    else:
+        with _ray_targets(hip, n_rays, plain):
+            o, d = _run_k1(ora, hip, scene, n_rays, max_samples, rank, world)
     n_o = o["ray_counter"].value
     cnt = d["counters"].cpu().numpy().astype(np.uint32)
     n_d = int(cnt[0])
@@ -206,6 +226,20 @@ def test_k3_loss_and_compaction(ora, hip, scene, train_mode, k3_flags):
         _k3_loss_and_compaction(ora, hip, scene)
     finally:
         ora.ora_set_train_mode(0); hip.ngp_debug_set_train_mode(0); hip.ngp_debug_set_flags(0)
+
+
+@pytest.mark.parametrize("plain,train_mode", [(0, 0), (1, 0), (1, 1), (1, 2)])
+def test_k3_targets_from_the_setup_kernel(ora, hip, scene, plain, train_mode):
+    """The trainer's division of labour, kernel by kernel against the oracle: k1_setup (general instance / <PLAIN>) computes every ray's target colour and background
+    in its colour roles, K3 reads the records -- in train mode 0 through k_compute_loss_v2<2, false, PLAIN, TGT>, the production instance, which carries no target-pixel
+    code at all (round 5: 32 -> 12 KiB of instructions) -- and loss, gradients and compacted rows per ray meet the same bars as the kernels that derive the targets
+    themselves (test_k3_loss_and_compaction)."""
+    ora.ora_set_train_mode(train_mode); hip.ngp_debug_set_train_mode(train_mode)
+    try:
+        with _ray_targets(hip, 2048, plain):
+            _k3_loss_and_compaction(ora, hip, scene)
+    finally:
+        ora.ora_set_train_mode(0); hip.ngp_debug_set_train_mode(0)
 
 
 @pytest.mark.parametrize("depth_loss,k3_flags", [(A.LOSS_L1, 0), (A.LOSS_L2, 0), (A.LOSS_L1, 134217728), (A.LOSS_L1, 32), (A.LOSS_HUBER, 32)])
