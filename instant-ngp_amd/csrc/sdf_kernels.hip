@@ -335,6 +335,9 @@ __global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restric
 // most SDF_INNER_STEPS, then the wavefront's leaves are evaluated together (while-while with a bound: a grazing ray's long chain of inner nodes does not hold the others'
 // leaves back).  A wavefront works on one list at a time (the two walks are different code) and moves to the other list when its own is drained.  k_sdf_finalize applies the
 // sign once every walk has ended: negative iff none of the point's rays escaped -- what the reference's serial loop returns, whatever the order.
+// Measured after it (profiles/r05_f4_sdf_half_nodes_ab.jsonl): the same walker on 64-byte nodes (half-precision boxes rounded outwards: boxes only prune, so the answers stay
+// bit-identical; half the lines and half the load instructions per step) is NOT faster (batch 3.08 - 3.15 vs 3.05 - 3.10 ms, uniform points slower) -- neither idle lanes nor
+// lines per step bound these walks; removed again.
 constexpr uint32_t SDF_FETCH_CHUNK = 256; // items per reservation (n_pad is a multiple of it: a reservation holds one ray index)
 constexpr uint32_t SDF_REFILL_MIN = 16;   // idle lanes that make a wavefront look for work before its next round
 constexpr uint32_t SDF_INNER_STEPS = 8;   // inner-node steps per round
