@@ -41,9 +41,10 @@ def main():
             e["write_requests"] = {"total": n, "64B": n64, "atomics": c.get("TCC_EA0_ATOMIC_sum", 0)}
             e["write_bytes"] = 64 * n64 + 32 * max(n - n64, 0)
             e["write_bytes_as_write_size"] = 64 * n
-    unit = ["k_train_fwd_bwd", "k_grad_bin", "k_grad_accumulate"]
+    unit = ["k_train_fused" if "k_train_fused" in out else "k_train_fwd_bwd", "k_grad_bin", "k_grad_accumulate"]  # round 5: k_train_fused (T1 + W in one kernel) is the unit's front
     if all(u in out and "read_bytes" in out[u] and "write_bytes" in out[u] for u in unit):
         out["k_train_fwd_bwd+k_grad_bin+k_grad_accumulate"] = {
+            "kernels": unit,
             "bytes_per_launch": int(sum(out[u]["read_bytes"] + out[u]["write_bytes"] for u in unit)),
             "bytes_per_launch_as_fetch_write_size": int(sum(out[u]["read_bytes_as_fetch_size"] + out[u]["write_bytes_as_write_size"] for u in unit)),
             "bytes_per_launch_fetch_x2": int(sum(2 * out[u]["read_bytes_as_fetch_size"] + out[u]["write_bytes_as_write_size"] for u in unit))}
