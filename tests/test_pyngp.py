@@ -238,19 +238,26 @@ def test_flow_snapshot_written_elsewhere_continues_training(trained, scene_dir):
     del sn["optimizer"]["nested"]["nested"]["param_steps_binary"]
     path = os.path.join(tempfile.mkdtemp(), "foreign.ingp")
     open(path, "wb").write(zlib.compress(msgpack.packb(doc, use_bin_type=True)))
-    t2 = ngp.Testbed()
-    t2.load_training_data(os.path.join(scene_dir, "transforms_train.json"))
-    t2.training_batch_size = 1 << 16
-    t2.load_snapshot(path)
-    assert t2.training_step == 400
-    t2.shall_train = True
-    losses = []
-    for _ in range(40):
-        t2.frame()
-        losses.append(t2.loss)
-    assert t2.training_step == 440 and np.isfinite(losses).all()
-    print(f"trained loss {trained['loss']:.5f}; continued from the re-encoded snapshot: first {losses[0]:.5f}, last {losses[-1]:.5f}")
-    assert max(losses) < 3.0 * trained["loss"] + 1e-4, "a cold optimizer (zero moments, step 1 debiasing) or mis-read state makes the first steps jump"
+    def continue_from(snapshot):
+        t = ngp.Testbed()
+        t.load_training_data(os.path.join(scene_dir, "transforms_train.json"))
+        t.training_batch_size = 1 << 16
+        t.load_snapshot(snapshot)
+        assert t.training_step == 400
+        t.shall_train = True
+        losses = []
+        for _ in range(40):
+            t.frame()
+            losses.append(t.loss)
+        assert t.training_step == 440 and np.isfinite(losses).all()
+        return t, losses
+    # The yardstick is the SAME continuation from this library's own snapshot (fp32 masters and per-parameter counters included): on this small scene the loss of a
+    # 2^16-sample batch scatters between 2e-5 and 4e-4 from step to step, so a bound against the one value the fixture happened to record at step 400 is a coin toss
+    # (it failed once in the round-5 final tier at 3.4e-4 against 1.7e-4).  A cold optimizer -- zero moments, step-1 debiasing -- takes lr-sized steps and lands at 1e-2.
+    _, native = continue_from(trained["snap"])
+    t2, losses = continue_from(path)
+    print(f"trained loss {trained['loss']:.5f}; continued 40 steps: own snapshot max {max(native):.5f}, re-encoded snapshot first {losses[0]:.5f}, last {losses[-1]:.5f}, max {max(losses):.5f}")
+    assert max(losses) < 2.0 * max(native) + 1e-4, "a cold optimizer (zero moments, step 1 debiasing) or mis-read state makes the first steps jump"
     snap2 = os.path.join(os.path.dirname(path), "again.ingp")
     t2.save_snapshot(snap2, True)
     a2 = msgpack.unpackb(zlib.decompress(open(snap2, "rb").read()), raw=False)["snapshot"]["optimizer"]["nested"]["nested"]
