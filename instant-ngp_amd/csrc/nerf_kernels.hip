@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* _
 // x-major copy of the Morton-ordered bitfield (all cascades): one thread per output byte = 8 x-consecutive cells (x0 a multiple of 8).  Their Morton indices are
 // m0 + {0, 1, 8, 9, 64, 65, 72, 73} with m0 = morton(x0, y, z) (x's bits land on Morton bits 0, 3, 6; m0's own bits 0, 3, 6 are clear): two bit pairs in the 16-bit
 // word at byte m0 / 8 (even: Morton bit 3 is clear) and two in the word eight bytes further -- two loads and four shifts instead of eight Morton codes and eight byte
-// loads (round 5: 29 -> see profiles/r05_*grid*).
+// loads (round 5: 29.3 -> 9.4 us per update, profiles/r04_final_kernel_trace_summary_nooverlap.txt vs r05_final_kernel_trace_summary_nooverlap.txt).
 __global__ void k_build_linear_bitfield(const uint8_t* __restrict__ bitfield, uint8_t* __restrict__ linear, uint32_t n_bytes) {
 	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_bytes) return;
