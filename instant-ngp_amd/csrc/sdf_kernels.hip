@@ -336,13 +336,14 @@ __global__ void __launch_bounds__(256, 5) k_sdf_stab_rays(const float* __restric
 // leaves back).  A wavefront works on one list at a time (the two walks are different code) and moves to the other list when its own is drained.  k_sdf_finalize applies the
 // sign once every walk has ended: negative iff none of the point's rays escaped -- what the reference's serial loop returns, whatever the order.
 // Measured after it (profiles/r05_f4_sdf_half_nodes_ab.jsonl): the same walker on 64-byte nodes (half-precision boxes rounded outwards: boxes only prune, so the answers stay
-// bit-identical; half the lines and half the load instructions per step) is NOT faster (batch 3.08 - 3.15 vs 3.05 - 3.10 ms, uniform points slower) -- neither idle lanes nor
-// lines per step bound these walks; removed again.
+// bit-identical; half the lines and half the load instructions per step) is NOT faster (batch 3.08 - 3.15 vs 3.05 - 3.10 ms, uniform points slower); neither are 2, 3 or 6
+// workgroups per CU instead of 4, nor polling the marks less often (profiles/r05_f4_sdf_walk_occupancy.txt): the launch is as long as its longest dependent chain (one lane's
+// ~500 - 1200 rounds), which is why the distance items are handed out long walks first.
 constexpr uint32_t SDF_FETCH_CHUNK = 256; // items per reservation (n_pad is a multiple of it: a reservation holds one ray index)
 constexpr uint32_t SDF_REFILL_MIN = 16;   // idle lanes that make a wavefront look for work before its next round
 constexpr uint32_t SDF_INNER_STEPS = 8;   // inner-node steps per round
 struct SdfWalkArgs {
-	uint32_t n, n_pad, stack_entries; int root, use_upper_bounds;
+	uint32_t n, n_pad, stack_entries, poll_mask, dist_reversed; int root, use_upper_bounds; // poll_mask: a walking ray looks at its point's mark in the rounds with (round & poll_mask) == poll_mask
 	const float* positions; float* distances; const SdfBvhNode4* nodes; const SdfTriangle* tris;
 	uint32_t* escaped; const float* stab_offsets; uint32_t* ctr; // ctr[0]: distance items reserved, ctr[1]: ray items reserved (zero on entry; k_sdf_finalize clears them)
 };
@@ -404,7 +405,9 @@ static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLd
 			if (f.template fill<RAYS>(a, !busy, s_pick, item)) {
 				busy = true; sp = 0; ref = a.root; round = 0;
 				const uint32_t r = RAYS ? item / a.n_pad : 0u;
-				i = RAYS ? item - r * a.n_pad : item;
+				// distance items from the END of the batch first: the launch is as long as its longest dependent chain, and the long distance walks (the uniform points, whose upper
+				// bound is the box diagonal: 163 rounds on average, up to ~530) sit behind the near-surface points in a training batch -- they must not start last
+				i = RAYS ? item - r * a.n_pad : (a.dist_reversed ? a.n - 1u - item : item);
 				p = mk3(a.positions[(size_t)i * 3], a.positions[(size_t)i * 3 + 1], a.positions[(size_t)i * 3 + 2]);
 				if (RAYS) { d = fibonacci_dir32(r, a.stab_offsets[2 * i], a.stab_offsets[2 * i + 1]); inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 				else { const float md = a.use_upper_bounds ? a.distances[i] : SDF_MAX_DIST; best = md * md; found = false; }
@@ -412,7 +415,7 @@ static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLd
 		}
 		if (!__ballot(busy)) break; // (the hand-out gives every idle lane an item unless the list is exhausted)
 		// 2. another ray of the point has escaped meanwhile: this one's answer is not needed
-		if (RAYS && busy && (round & 1u) && sdf_mark_load(a.escaped + i) != 0u) { busy = false; ref = SDF_DONE; }
+		if (RAYS && busy && (round & a.poll_mask) == a.poll_mask && sdf_mark_load(a.escaped + i) != 0u) { busy = false; ref = SDF_DONE; }
 		++round;
 		// 3. inner nodes, towards each lane's next leaf
 		for (uint32_t it = 0; it < SDF_INNER_STEPS && ref >= 0 && ref != SDF_DONE; ++it) {
@@ -452,7 +455,10 @@ static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLd
 		}
 	}
 }
-__global__ void __launch_bounds__(256, 4) k_sdf_walks(SdfWalkArgs a) {
+// OCC = workgroups per CU the instance is compiled for: 4 (98 registers, no scratch) or 6 (80 registers, 32 bytes of scratch; six 26.6 KiB stack images are what a CU's LDS
+// holds for armadillo's depth) -- the walks wait 75 % of their cycles (profiles/r05_pmc_sdf_walks.txt), so more of them in flight per SIMD is the lever that is left.
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) k_sdf_walks(SdfWalkArgs a) {
 	extern __shared__ int s_stack[]; // [stack_entries][256] reference stacks | [4][64] hand-out words
 	SdfLdsStack st; st.col = s_stack + threadIdx.x;
 	uint32_t* s_pick = (uint32_t*)(s_stack + (size_t)a.stack_entries * 256u) + (threadIdx.x >> 6) * 64u;
@@ -496,10 +502,17 @@ int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions
 		a.n = n; a.n_pad = (n + SDF_FETCH_CHUNK - 1u) / SDF_FETCH_CHUNK * SDF_FETCH_CHUNK; a.stack_entries = std::min<uint32_t>(std::max<uint32_t>(stack_entries, 4u), (uint32_t)SDF_STACK_MAX);
 		a.root = root; a.use_upper_bounds = use_upper_bounds; a.positions = positions; a.distances = distances; a.nodes = nodes; a.tris = tris;
 		a.escaped = q.escaped; a.stab_offsets = q.stab_offsets; a.ctr = q.work_ctr;
-		const uint32_t lds = a.stack_entries * 256u * 4u + 4u * 64u * 4u, per_cu = std::max(1u, std::min(4u, (160u * 1024u) / (lds + 64u)));
+		// how often a walking ray polls its point's mark (a device-scope load per lane: 64 uncoalesced memory-side requests per wavefront): every 2nd / 8th / ... round, or never
+		// (0xffffffff: the marks are then only read at the hand-out).  Ablation knob NGP_SDF_POLL_MASK; measured: profiles/r05_f4_sdf_walk_occupancy.txt
+		static const uint32_t poll_mask = getenv("NGP_SDF_POLL_MASK") ? (uint32_t)strtoul(getenv("NGP_SDF_POLL_MASK"), nullptr, 0) : 7u;
+		a.poll_mask = poll_mask;
+		static const bool dist_batch_order = getenv("NGP_SDF_DIST_ORDER") && atoi(getenv("NGP_SDF_DIST_ORDER")) == 0; // ablation: distance items in batch order (calls k .. u)
+		a.dist_reversed = dist_batch_order ? 0u : 1u;
+		static const uint32_t occ = getenv("NGP_SDF_WALK_OCC") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_WALK_OCC")), 1), 6) : 4u; // workgroups per CU (ablation knob; measured: profiles/r05_f4_sdf_walk_occupancy.txt)
+		const uint32_t lds = a.stack_entries * 256u * 4u + 4u * 64u * 4u, per_cu = std::max(1u, std::min(occ, (160u * 1024u) / (lds + 64u)));
 		// a grid of resident workgroups (no more than there are reservations to make)
 		const uint32_t grid = std::min<uint32_t>(256u * per_cu, (uint32_t)(((uint64_t)33u * a.n_pad / SDF_FETCH_CHUNK + 3u) / 4u) + 8u);
-		hipLaunchKernelGGL(k_sdf_walks, dim3(grid), dim3(256), lds, s, a);
+		if (per_cu > 4u) hipLaunchKernelGGL(k_sdf_walks<6>, dim3(grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(k_sdf_walks<4>, dim3(grid), dim3(256), lds, s, a);
 		hipLaunchKernelGGL(k_sdf_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, q.escaped, q.work_ctr);
 		return 0;
 	}
