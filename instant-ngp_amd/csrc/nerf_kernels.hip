@@ -271,7 +271,8 @@ static __device__ __forceinline__ float lattice_t(const RaySetup& r, uint32_t j,
 }
 
 // ---- exclusive prefix sum over packed {samples (low 32), rays (high 32)} ------------------------
-static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], uint64_t* sm /* 4 */, uint64_t& block_total) {
+template <uint32_t NW = 4 /* wavefronts per workgroup */>
+static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], uint64_t* sm /* NW */, uint64_t& block_total) {
 	// each thread owns 4 consecutive elements; returns the exclusive prefix of the thread's first element
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint64_t tsum = v[0] + v[1] + v[2] + v[3];
@@ -286,10 +287,12 @@ static __device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t v[4], u
 	uint64_t woff = 0;
 	for (uint32_t w = 0; w < wid; ++w) woff += sm[w];
 	block_total = sm[0] + sm[1] + sm[2] + sm[3];
+	if constexpr (NW == 8) block_total += (sm[4] + sm[5]) + (sm[6] + sm[7]);
 	return woff + x - tsum;
 }
 // Tail of both counting kernels: publish the workgroup's packed {samples, rays} total; the last workgroup to arrive turns the totals into exclusive offsets + the two global counters.
-static __device__ __forceinline__ void k1_publish_and_scan(const K1Args& a, uint64_t wave_total, uint64_t* __restrict__ partial, uint32_t* __restrict__ done, uint64_t* s_tot /* 4 */, uint64_t* s_scan /* 4 */, uint32_t& s_ticket) {
+template <uint32_t NW = 4 /* wavefronts per workgroup */>
+static __device__ __forceinline__ void k1_publish_and_scan(const K1Args& a, uint64_t wave_total, uint64_t* __restrict__ partial, uint32_t* __restrict__ done, uint64_t* s_tot /* NW */, uint64_t* s_scan /* NW */, uint32_t& s_ticket) {
 	const uint32_t lane = threadIdx.x & 63u;
 	if (lane == 0) s_tot[threadIdx.x >> 6] = wave_total;
 	__syncthreads();
@@ -297,7 +300,9 @@ static __device__ __forceinline__ void k1_publish_and_scan(const K1Args& a, uint
 		// The total is published with a RETURNING device-scope atomic (performed at the coherence point; its return value is awaited before the
 		// ticket is drawn) instead of store + __threadfence(): an agent-scope release fence writes back the XCD's whole L2 on this multi-XCD
 		// part, and 2048 of them made this kernel 47 us slower (profiles/r02_k1_experiments.txt).
-		const uint64_t prev = atomicExch((unsigned long long*)(partial + blockIdx.x), (unsigned long long)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3])));
+		uint64_t block_sum = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+		if constexpr (NW == 8) block_sum += (s_tot[4] + s_tot[5]) + (s_tot[6] + s_tot[7]);
+		const uint64_t prev = atomicExch((unsigned long long*)(partial + blockIdx.x), (unsigned long long)block_sum);
 		// two-level ticket: one counter word retires only ~90 returning atomics per microsecond, so workgroup b draws from sub-counter
 		// b % 32 and only the last of each residue class draws from the top counter
 		const uint32_t cls = blockIdx.x % K1_TICKET_CLASSES, n_cls = (gridDim.x - cls + K1_TICKET_CLASSES - 1) / K1_TICKET_CLASSES;
@@ -312,12 +317,12 @@ static __device__ __forceinline__ void k1_publish_and_scan(const K1Args& a, uint
 	if (!s_ticket) return;
 	// last workgroup: every total has been exchanged in; read them at the coherence point as well (atomic RMW with 0)
 	uint64_t run = 0ull;
-	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += SCAN_BLOCK) {
+	for (uint32_t b0 = 0; b0 < gridDim.x; b0 += NW * 256u) {
 		uint64_t v[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; v[k] = e < gridDim.x ? (uint64_t)atomicAdd((unsigned long long*)(partial + e), 0ull) : 0ull; }
 		uint64_t tot;
-		uint64_t pre = run + block_excl_scan_1024(v, s_scan, tot);
+		uint64_t pre = run + block_excl_scan_1024<NW>(v, s_scan, tot);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { const uint32_t e = b0 + threadIdx.x * 4 + k; if (e < gridDim.x) partial[e] = pre; pre += v[k]; }
 		run += tot;
@@ -551,33 +556,37 @@ static __device__ __forceinline__ void k1_slot_range(uint32_t n_local, uint32_t 
 	if (n_local <= (1u << 19) && g <= (1u << 12)) { li_begin = n_local * b / g; li_end = n_local * (b + 1u) / g; }
 	else { li_begin = (uint32_t)(((uint64_t)n_local * b) / g); li_end = (uint32_t)(((uint64_t)n_local * (b + 1u)) / g); }
 }
-__global__ void __launch_bounds__(256) k1_count_segments(K1Args a, RaySetup* __restrict__ rs, uint16_t* __restrict__ jlist, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
-	__shared__ uint64_t s_tot[4];
-	__shared__ uint64_t s_scan[4];
+// NW = wavefronts per workgroup (round 6): the 36 KiB LDS image allows four workgroups per CU whatever their size, the kernel holds < 64 registers and waits for its loads
+// (RaySetup -> segment list -> occupancy bytes, a dependent chain per ray) 62 % of its wave cycles: eight wavefronts per workgroup = 8 per SIMD instead of 4.
+template <uint32_t NW>
+__global__ void __launch_bounds__(64 * NW) k1_count_segments(K1Args a, RaySetup* __restrict__ rs, uint16_t* __restrict__ jlist, uint64_t* __restrict__ partial, uint32_t* __restrict__ done) {
+	__shared__ uint64_t s_tot[NW];
+	__shared__ uint64_t s_scan[NW];
 	__shared__ uint32_t s_ticket;
-	__shared__ uint8_t s_seg[4][K1_MAX_SEGS]; // per wavefront: the segments of its ray that passed the prepass, in lattice order
+	__shared__ uint8_t s_seg[NW][K1_MAX_SEGS]; // per wavefront: the segments of its ray that passed the prepass, in lattice order
 	extern __shared__ uint32_t s_pre[];       // [COARSE_WORDS coarse of cascade 0][MID_WORDS dilated mid grid]
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint32_t li_begin, li_end; k1_slot_range(ray_end - ray_begin, blockIdx.x, gridDim.x, li_begin, li_end);
-	if (li_begin < li_end) { // 36 KiB per workgroup: all nine 16-byte loads of a thread in flight before the first LDS store
+	if (li_begin < li_end) { // 36 KiB per workgroup: all 16-byte loads of a thread in flight before the first LDS store
 		static_assert(COARSE_WORDS == 4 * 256 && MID_WORDS == 8 * 4 * 256, "one + eight uint4 per thread of a 256-thread workgroup");
 		const uint4* src_c = (const uint4*)a.bitfield_coarse; const uint4* src_m = (const uint4*)(a.bitfield_coarse + (size_t)a.n_mips * COARSE_WORDS);
-		uint4 v[9];
-		v[0] = src_c[threadIdx.x];
+		constexpr uint32_t T = 64u * NW, MK = 8u * 256u / T; // mid-grid uint4 per thread
+		uint4 v[1 + MK];
+		if (threadIdx.x < 256u) v[0] = src_c[threadIdx.x];
 #pragma unroll
-		for (uint32_t k = 0; k < 8; ++k) v[1 + k] = src_m[threadIdx.x + 256u * k];
+		for (uint32_t k = 0; k < MK; ++k) v[1 + k] = src_m[threadIdx.x + T * k];
 		uint4* dst = (uint4*)s_pre;
-		dst[threadIdx.x] = v[0];
+		if (threadIdx.x < 256u) dst[threadIdx.x] = v[0];
 #pragma unroll
-		for (uint32_t k = 0; k < 8; ++k) dst[256u + threadIdx.x + 256u * k] = v[1 + k];
+		for (uint32_t k = 0; k < MK; ++k) dst[256u + threadIdx.x + T * k] = v[1 + k];
 	}
 	__syncthreads();
 	const uint32_t* s_mid = s_pre + COARSE_WORDS;
 	uint64_t wave_total = 0ull;
-	for (uint32_t li = li_begin + wid; li < li_end; li += 4) {
+	for (uint32_t li = li_begin + wid; li < li_end; li += NW) {
 		const RaySetup& r = rs[li];
 		const uint32_t n_in = r.flags; // lattice points inside the box: [0, n_in)
 		uint32_t cnt = 0;
@@ -624,7 +633,7 @@ __global__ void __launch_bounds__(256) k1_count_segments(K1Args a, RaySetup* __r
 		if (lane == 0) rs[li].count = cnt;
 		wave_total += (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
 	}
-	k1_publish_and_scan(a, wave_total, partial, done, s_tot, s_scan, s_ticket);
+	k1_publish_and_scan<NW>(a, wave_total, partial, done, s_tot, s_scan, s_ticket);
 }
 
 // One lane per SAMPLE of the workgroup's slot range (a contiguous span of the sample buffer): the sample's ray by bisection over the range's span offsets in LDS, its lattice
@@ -1766,7 +1775,9 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 		// one cascade, constant step: segment prepass + sample lists.  36 KiB of LDS per workgroup: 4 resident per CU = the persistent grid
 		uint16_t* jlist = (uint16_t*)((char*)scratch + k1_jlist_offset(max_local_rays));
 		const uint32_t seg_grid = k1_grid(max_local_rays, k1_blocks_per_cu_segments());
-		hipLaunchKernelGGL(k1_count_segments, dim3(seg_grid), dim3(256), (COARSE_WORDS + MID_WORDS) * 4, s, a, rs, jlist, partial, done);
+		static const uint32_t seg_waves = getenv("NGP_K1_SEG_WAVES") && atoi(getenv("NGP_K1_SEG_WAVES")) == 4 ? 4u : 8u; // 4: the round-4/5 shape (ablation)
+		if (seg_waves == 8) hipLaunchKernelGGL(k1_count_segments<8>, dim3(seg_grid), dim3(512), (COARSE_WORDS + MID_WORDS) * 4, s, a, rs, jlist, partial, done);
+		else hipLaunchKernelGGL(k1_count_segments<4>, dim3(seg_grid), dim3(256), (COARSE_WORDS + MID_WORDS) * 4, s, a, rs, jlist, partial, done);
 		if (!count_only) hipLaunchKernelGGL(k1_write_list, dim3(seg_grid * K1_WRITE_SPLIT), dim3(256), 0, s, a, rs, jlist, partial);
 		return;
 	}
