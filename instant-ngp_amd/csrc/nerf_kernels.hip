@@ -980,12 +980,14 @@ static __device__ __forceinline__ float half_incl_scan(float x) {
 // PLAIN: train_mode Nerf and no depth supervision, as compile-time facts (the production instance): the Rfl / depth accumulators and their scans disappear.
 // TGT (round 5): the rays' targets come from k1_setup (K3Args::ray_targets; the trainer's lattice path) -- the instance does not carry the target-pixel chain at all
 // (pixel sampler, three pixel formats, six sRGB conversions: a fifth of the PLAIN instance's code).
-template <int RPW, bool ERR, bool PLAIN, bool TGT = false>
-__global__ void __launch_bounds__(1024) k_compute_loss_v2(K3Args a) {
+// WPB = wavefronts per workgroup, MINW = wavefronts per SIMD the register allocation must allow (round 6): a workgroup's wavefronts all wait at the same two barriers and on
+// the same returning span atomic, so ONE 16-wavefront workgroup per CU (what 96 registers allow) leaves the CU idle during every such wait; smaller workgroups take turns.
+template <int RPW, bool ERR, bool PLAIN, bool TGT = false, int WPB = 16, int MINW = 4>
+__global__ void __launch_bounds__(64 * WPB, MINW) k_compute_loss_v2(K3Args a) {
 	const uint32_t cs = PLAIN ? 7u : a.cstride; // (the production instance keeps the NerfCoordinate's 7 floats as a compile-time stride: models with extra dims run the generic one)
 	const int train_mode = PLAIN ? 0 : a.train_mode;
 	const float depth_lambda = PLAIN ? 0.f : a.depth_lambda;
-	constexpr uint32_t LPR = 64u / RPW, RPB = K3_RAYS_PER_BLOCK * RPW; // lanes per ray, rays per workgroup (16 wavefronts)
+	constexpr uint32_t LPR = 64u / RPW, RPB = (uint32_t)WPB * RPW; // lanes per ray, rays per workgroup
 	__shared__ uint32_t s_cnt[RPB];
 	__shared__ float s_loss[RPB];
 	__shared__ uint32_t s_base;
@@ -1843,7 +1845,13 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 		const bool plain = a.train_mode == 0 && !(a.depth_lambda > 0.f) && !(g_debug_flags & DBG_K3_GENERIC) && a.cstride == 7;
 		if (g_debug_flags & DBG_K3_ONE_RAY_PER_WAVE) { if (err) hipLaunchKernelGGL((k_compute_loss_v2<1, true, false>), g1, dim3(1024), 0, s, a); else hipLaunchKernelGGL((k_compute_loss_v2<1, false, false>), g1, dim3(1024), 0, s, a); }
 		else if (err) hipLaunchKernelGGL((k_compute_loss_v2<2, true, false>), g2, dim3(1024), 0, s, a);
-		else if (plain && a.ray_targets) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true>), g2, dim3(1024), 0, s, a);
+		else if (plain && a.ray_targets) {
+			// production instance: 8 wavefronts (16 rays) per workgroup at 5 wavefronts per SIMD = two independent workgroups per CU (round 6, profiles/r06_ab_k3_workgroup_shape.txt;
+			// 4-wavefront workgroups double the span atomics once more and are 20 - 35 us SLOWER: one counter word retires ~100 returning atomics per microsecond)
+			static const bool wg16 = getenv("NGP_K3_WG16") && atoi(getenv("NGP_K3_WG16")) != 0; // the round-3..5 shape (ablation)
+			if (wg16) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true>), g2, dim3(1024), 0, s, a);
+			else hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true, 8, 5>), dim3(std::min<uint32_t>(blocks(max_rays, 16), 256u * 2u)), dim3(512), 0, s, a);
+		}
 		else if (plain) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true>), g2, dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_compute_loss_v2<2, false, false>), g2, dim3(1024), 0, s, a);
 	}
