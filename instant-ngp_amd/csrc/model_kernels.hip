@@ -200,6 +200,65 @@ DEV h2 level_features2_3d(const __half* __restrict__ table, const LevelConst& lc
 	return r;
 }
 
+// F = 4, two levels' gathers in flight (16 independent loads per lane between waits instead of 8): the per-tile chain of the lazy K2 is position load -> four dependent gather
+// rounds -> MFMA chain, and the kernel keeps only 3 wavefronts per SIMD busy; this halves the dependent rounds.  Same loads, same half fma chain per level (corner order 0..7).
+DEV void level_features4_x2(const __half* __restrict__ table, const LevelConst& la, const LevelConst& lb, float x, float y, float z, h4& ra, h4& rb) {
+	Corners ca, cb;
+	level_corners(la, x, y, z, ca);
+	level_corners(lb, x, y, z, cb);
+	const uint2* ta = (const uint2*)table + la.offset; const uint2* tb = (const uint2*)table + lb.offset;
+	uint2 va[8], vb[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) va[c] = ta[ca.idx[c]];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) vb[c] = tb[cb.idx[c]];
+	h2 a0 = {(_Float16)0.f, (_Float16)0.f}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		const _Float16 wh = (_Float16)ca.w[c]; const h2 w2 = {wh, wh};
+		a0 = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, va[c].x), a0);
+		a1 = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, va[c].y), a1);
+	}
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		const _Float16 wh = (_Float16)cb.w[c]; const h2 w2 = {wh, wh};
+		b0 = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, vb[c].x), b0);
+		b1 = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, vb[c].y), b1);
+	}
+	ra = h4{a0[0], a0[1], a1[0], a1[1]}; rb = h4{b0[0], b0[1], b1[0], b1[1]};
+	__builtin_amdgcn_sched_barrier(0);
+}
+// The level constants from a 16-byte-per-level LDS table {scale, resolution | hashed << 31, hashmap_size, offset} (fill_level_table) instead of from GridMeta in global memory:
+// level_const's `hi ? gm.x[l + 1] : gm.x[l]` compiles to four VECTOR global loads per level (the address depends on the lane), i.e. a second memory round trip in front
+// of every level's gathers -- the lazy K2 paid eight dependent round trips per tile where four are needed (round 6).
+DEV void fill_level_table(uint4* lct, const GridMeta* __restrict__ gm) {
+	const uint32_t l = threadIdx.x;
+	if (l < 16u) {
+		uint4 v = make_uint4(0u, 0u, 0u, 0u);
+		if (l < gm->n_levels) {
+			const uint32_t res = gm->resolution[l], hs = gm->hashmap_size[l];
+			v = make_uint4(__float_as_uint(gm->scale[l]), res | (((uint64_t)res * res * res > (uint64_t)hs) ? 0x80000000u : 0u), hs, gm->offset[l]);
+		}
+		lct[l] = v;
+	}
+}
+DEV LevelConst level_const_lds(const uint4* lct, int level) {
+	const uint4 v = lct[level];
+	LevelConst c; c.scale = __uint_as_float(v.x); c.res = v.y & 0x7fffffffu; c.hashed = (v.y >> 31) != 0u; c.hs = v.z; c.offset = v.w;
+	return c;
+}
+template <int DEPTH>
+DEV void encode_sample_lds(const uint4* lct, const __half* __restrict__ table, float x, float y, float z, int hi, h8 out[2]) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int s = 0; s < 2; ++s) {
+		h4 a, b;
+		if constexpr (DEPTH == 2) level_features4_x2(table, level_const_lds(lct, 4 * s + 0 + hi), level_const_lds(lct, 4 * s + 2 + hi), x, y, z, a, b);
+		else { a = level_features4<false>(table, level_const_lds(lct, 4 * s + 0 + hi), x, y, z, lane); b = level_features4<false>(table, level_const_lds(lct, 4 * s + 2 + hi), x, y, z, lane); }
+		out[s] = h8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+	}
+}
+
 // Encoding of one sample column into the lane's two B-operand fragments (k-steps 0,1).  Fragment element (s, hi, j) is input feature
 // k = 16 s + 8 (j >> 2) + 4 hi + (j & 3):  F = 4: feature j & 3 of level 4 s + 2 (j >> 2) + hi;  F = 2: feature j & 1 of level 8 s + 4 (j >> 2) + 2 hi + ((j & 3) >> 1).
 template <int F = 4, bool PAIR = false>
@@ -443,6 +502,9 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 		const uint32_t* __restrict__ n_ptr, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
+	__shared__ uint4 s_lct[16];
+	constexpr bool LCT = F == 4 && !PAIR; // level constants from an LDS table (round 6, see fill_level_table)
+	if constexpr (LCT) fill_level_table(s_lct, gm);
 	load_frags_to_lds(fw, mp.fw_frags, DENSITY_ONLY ? 8 : n_fw(NR) + (EX ? N_FW_EXTRA : 0));
 	__syncthreads();
 	const uint32_t n = n_ptr ? min(*n_ptr, n_max) : n_max;
@@ -458,7 +520,8 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 			const uint32_t s_raw = tile * TS + c * 32 + col;
 			sidx[c] = s_raw;
 			const float* p = in + (size_t)min(s_raw, n - 1) * in_stride;
-			encode_sample<F, PAIR>(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
+			if constexpr (LCT) encode_sample_lds<1>(s_lct, table, p[0], p[1], p[2], hi, st.enc[c]);
+			else encode_sample<F, PAIR>(gm, table, p[0], p[1], p[2], hi, st.enc[c]);
 			if (!DENSITY_ONLY) st.rin[c][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
 			if constexpr (!DENSITY_ONLY && EX != 0) st.rin[c][2] = extra_frag(p + dir_offset + 3, mp.n_extra, hi);
 		}
@@ -554,7 +617,7 @@ __global__ void __launch_bounds__(256) k_encode_tiles_xcd(const GridMeta* __rest
 // ---------------------------------------------------------------------------------------------
 // TW = tile width in samples: 32 (one tile per wavefront) or 16 (two tiles of two different rays share the wavefront's 32 MFMA
 // columns -- rays end after ~12 compacted samples, so 16-wide tiles evaluate fewer samples behind the cut and fill the columns).
-template <uint32_t TW, int F = 4, int NR = 2>
+template <uint32_t TW, int F = 4, int NR = 2, int DEPTH = 0 /* F = 4: 0 = level constants from GridMeta (rounds 1-5), 1 | 2 = from the LDS table, with one | two levels' gathers in flight */>
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,6 +626,8 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 	const uint32_t n_tiles = min(r == 0 ? *la.n_rays_ptr : la.n_tiles_ptr[r], la.tile_cap);
 	if (blockIdx.x * 4 * TPW >= n_tiles) return; // uniform: late rounds are small
 	h8* fw = (h8*)smem;
+	__shared__ uint4 s_lct[16];
+	if constexpr (DEPTH != 0) fill_level_table(s_lct, gm);
 	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
@@ -615,7 +680,8 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 			for (int u = 0; u < 4; ++u) q[u] = valid ? la.enc_lv[(size_t)(2 * u + hi) * la.enc_lv_stride + sample] : make_uint2(0u, 0u); // levels hi, 2 + hi (k-step 0), 4 + hi, 6 + hi (k-step 1)
 			st.enc[0][0] = __builtin_bit_cast(h8, make_uint4(q[0].x, q[0].y, q[1].x, q[1].y));
 			st.enc[0][1] = __builtin_bit_cast(h8, make_uint4(q[2].x, q[2].y, q[3].x, q[3].y));
-		} else encode_sample<F, false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
+		} else if constexpr (DEPTH != 0 && F == 4) encode_sample_lds<DEPTH>(s_lct, table, p[0], p[1], p[2], hi, st.enc[0]);
+		else encode_sample<F, false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
 		if (la.enc_out && valid) { // for T1 (EncStashIn): this lane's half of the sample's encoding, 32 contiguous bytes
 			uint4* e = la.enc_out + (size_t)sample * 4 + (uint32_t)hi * 2;
 			e[0] = __builtin_bit_cast(uint4, st.enc[0][0]); e[1] = __builtin_bit_cast(uint4, st.enc[0][1]);
@@ -2706,8 +2772,11 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	const uint32_t nr = mp.n_rgb_hidden;
 #define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
 #define NGP_LAUNCH_TILES_W(FF, NRR) do { if (la.tile_w == 8) NGP_LAUNCH_TILES(8, FF, NRR); else if (la.tile_w == 16) NGP_LAUNCH_TILES(16, FF, NRR); else NGP_LAUNCH_TILES(32, FF, NRR); } while (0)
+	static const int k2_depth = getenv("NGP_K2_DEPTH") ? atoi(getenv("NGP_K2_DEPTH")) : 2; // 0: level constants from GridMeta (rounds 1-5, ablation); 1 / 2: from the LDS table (profiles/r06_ab_k2_level_table.txt)
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
+		if (k2_depth == 2 && F == 4 && nr == 2 && la.tile_w == 16) { hipLaunchKernelGGL((k_inference_tiles<16, 4, 2, 2>), dim3(grid), dim3(256), n_fw(2) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset); continue; }
+		if (k2_depth == 1 && F == 4 && nr == 2 && la.tile_w == 16) { hipLaunchKernelGGL((k_inference_tiles<16, 4, 2, 1>), dim3(grid), dim3(256), n_fw(2) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset); continue; }
 		if (F == 2) { if (nr == 1) NGP_LAUNCH_TILES_W(2, 1); else if (nr == 3) NGP_LAUNCH_TILES_W(2, 3); else NGP_LAUNCH_TILES_W(2, 2); }
 		else { if (nr == 1) NGP_LAUNCH_TILES_W(4, 1); else if (nr == 3) NGP_LAUNCH_TILES_W(4, 3); else NGP_LAUNCH_TILES_W(4, 2); }
 	}
