@@ -90,6 +90,8 @@ typedef struct ngp_model_config {
 	float ema_decay;
 	uint32_t decay_start, decay_interval;
 	float decay_base;
+	uint32_t ema_full_precision;    /* [tcnn EmaOptimizer "full_precision", default false] 0: the EMA state is the network-precision inference buffer itself
+	                                   (ema_step_half_precision, fed with the half weights); 1: an fp32 state fed with the fp32 master weights (ema_step_full_precision) */
 } ngp_model_config;
 
 /* Run-time options of the NeRF trainer; defaults = the reference's member defaults. */
@@ -217,6 +219,15 @@ uint32_t ngp_model_step(const ngp_model*);
 uint64_t ngp_model_serialized_size(const ngp_model*, int with_optimizer);
 int ngp_model_serialize_host(ngp_model*, void* buffer_host, uint64_t size, int with_optimizer);
 int ngp_model_deserialize_host(ngp_model*, const void* buffer_host, uint64_t size);
+/* The payload's layout for callers that translate it into another container (Testbed::save_snapshot / load_snapshot write tcnn's per-optimizer keys, testbed.cu:5289, 5468):
+ * a header, then sections of n_params x 4 bytes each in the order below; `ngp_model_state_header` reads (buffer -> out arguments, write = 0) or writes (write = 1) the
+ * header fields so that no caller carries a copy of the header struct. */
+enum { NGP_STATE_MASTER = 0 /* f32 */, NGP_STATE_ADAM_M = 1 /* f32 */, NGP_STATE_ADAM_V = 2 /* f32 */, NGP_STATE_ADAM_STEPS = 3 /* u32 per parameter */,
+       NGP_STATE_EMA = 4 /* f32: the EMA state ("full_precision") or the half inference parameters widened */, NGP_STATE_N_SECTIONS = 5 };
+uint64_t ngp_model_state_offset(uint64_t n_params, int section);
+int ngp_model_state_header(void* buffer_host, uint64_t size, int write, uint64_t* n_params, uint32_t* step, float* learning_rate, uint32_t* with_optimizer);
+/* the configuration the model was created with (e.g. for the snapshot writer: ema_full_precision) */
+int ngp_model_get_config(const ngp_model*, ngp_model_config* out);
 
 /* ------------------------------------------------------------------ encoding + MLP ------ */
 /* The image and SDF primitives' model (configs/image/base.json, configs/sdf/base.json): a HashGrid encoding of a 2-D / 3-D

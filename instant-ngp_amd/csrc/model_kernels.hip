@@ -1426,7 +1426,11 @@ DEV float adam_update(const AdamArgs& a, bool matrix, float gradient, float weig
 	asm volatile("" : "+v"(nw)); // the fp32 value exists before the caller rounds it to half (no v_fma_mixlo_f16 from the unrounded expression: the master weight and its half copy must agree)
 	return nw;
 }
-// ema_step_half_precision [tcnn optimizers/ema.h]: debiased exponential moving average of the half weights
+// [tcnn optimizers/ema.h] debiased exponential moving average, the two kernels of EmaOptimizer::step:
+//   ema_step_half_precision (the default, "full_precision": false): the state IS the network-precision EMA buffer (= the inference parameters): ema_old = (float)weights_ema[i],
+//                            w = (float)weights[i] (the half copy), weights_ema[i] = (T)filtered;
+//   ema_step_full_precision ("full_precision": true): ema_old = tmp[i] (an fp32 buffer), w = weights_full_precision[i] (the fp32 master), tmp[i] = filtered, weights_ema[i] = (T)filtered.
+// Rounds 1-5 ran a hybrid (fp32 state, half weights) that is neither; AdamArgs::ema_full_precision selects between the two since round 6.
 DEV float ema_update(const AdamArgs& a, float ema_old, float w) {
 #pragma clang fp contract(off)
 	float r = (ema_old * a.ema_decay * a.ema_debias_old + w * (1 - a.ema_decay)) * a.ema_debias_new;
@@ -1546,14 +1550,19 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 					if (oldv.x | oldv.y) gt[e] = make_uint2(0u, 0u);
 				}
 				const h4 g4 = __builtin_bit_cast(h4, pack_halfs<4>(r));
-				h4 w4 = __builtin_bit_cast(h4, ((const uint2*)o.params)[i4]);
 				float g[4]; bool upd[4]; bool any = false;
 #pragma unroll
 				for (int k = 0; k < 4; ++k) { g[k] = (float)g4[k] / o.loss_scale; upd[k] = o.optimize_non_matrix != 0 && g[k] != 0.f; any |= upd[k]; }
+				// the half parameters are ALWAYS the rounding of the fp32 masters (adam below, model_refresh_half): an entry whose masters are read anyway does not read them
+				h4 w4; float4 mw = make_float4(0.f, 0.f, 0.f, 0.f);
+				float* mwp = (float*)&mw;
+				if (any || o.ema_full_precision) mw = ((const float4*)o.master)[i4];
 				if (any) {
-					float4 mw = ((const float4*)o.master)[i4], m4 = ((const float4*)o.m)[i4], v4 = ((const float4*)o.v)[i4];
+#pragma unroll
+					for (int k = 0; k < 4; ++k) w4[k] = (_Float16)mwp[k];
+					float4 m4 = ((const float4*)o.m)[i4], v4 = ((const float4*)o.v)[i4];
 					uint2 st = ((const uint2*)o.steps)[i4];
-					float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
+					float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
 #pragma unroll
 					for (int k = 0; k < 4; ++k) {
 						if (!upd[k]) continue;
@@ -1563,17 +1572,20 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 					}
 					((float4*)o.master)[i4] = mw; ((float4*)o.m)[i4] = m4; ((float4*)o.v)[i4] = v4; ((uint2*)o.steps)[i4] = st;
 					((uint2*)o.params)[i4] = __builtin_bit_cast(uint2, w4);
-				}
-				float4 e4 = ((const float4*)o.ema)[i4];
-				float* ep = (float*)&e4;
+				} else w4 = __builtin_bit_cast(h4, ((const uint2*)o.params)[i4]);
 				h4 inf4;
+				if (o.ema_decay == 0.f) inf4 = w4; // no Ema wrapper: the inference parameters are the parameters
+				else if (o.ema_full_precision) {
+					float4 e4 = ((const float4*)o.ema)[i4];
+					float* ep = (float*)&e4;
 #pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const float filtered = ema_update(o, ep[k], (float)w4[k]);
-					ep[k] = filtered;
-					inf4[k] = (_Float16)filtered;
+					for (int k = 0; k < 4; ++k) { const float filtered = ema_update(o, ep[k], mwp[k]); ep[k] = filtered; inf4[k] = (_Float16)filtered; }
+					((float4*)o.ema)[i4] = e4;
+				} else {
+					const h4 old4 = __builtin_bit_cast(h4, ((const uint2*)o.params_inf)[i4]);
+#pragma unroll
+					for (int k = 0; k < 4; ++k) inf4[k] = (_Float16)ema_update(o, (float)old4[k], (float)w4[k]);
 				}
-				((float4*)o.ema)[i4] = e4;
 				((uint2*)o.params_inf)[i4] = __builtin_bit_cast(uint2, inf4);
 			}
 			return;
@@ -2679,10 +2691,13 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 		any |= upd[k];
 	}
 	if (a.ema_only) any = false;
+	float4 mw = make_float4(0.f, 0.f, 0.f, 0.f);
+	float* mwp = (float*)&mw;
+	if (any || (a.ema_full_precision && a.ema_decay != 0.f)) mw = ((const float4*)a.master)[i4];
 	if (any) {
-		float4 mw = ((const float4*)a.master)[i4], m4 = ((const float4*)a.m)[i4], v4 = ((const float4*)a.v)[i4];
+		float4 m4 = ((const float4*)a.m)[i4], v4 = ((const float4*)a.v)[i4];
 		uint2 st = ((const uint2*)a.steps)[i4];
-		float* mwp = (float*)&mw; float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
+		float* mp = (float*)&m4; float* vp = (float*)&v4; uint16_t* sp = (uint16_t*)&st;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			if (!upd[k]) continue;
@@ -2697,17 +2712,23 @@ __global__ void __launch_bounds__(256) k_optimizer(AdamArgs a) {
 		((float4*)a.master)[i4] = mw; ((float4*)a.m)[i4] = m4; ((float4*)a.v)[i4] = v4; ((uint2*)a.steps)[i4] = st;
 		((uint2*)a.params)[i4] = __builtin_bit_cast(uint2, w4);
 	}
-	float4 e4 = ((const float4*)a.ema)[i4];
-	float* ep = (float*)&e4;
 	h4 inf4;
+	if (a.ema_decay == 0.f) inf4 = w4; // no Ema wrapper (image / SDF configs): the inference parameters are the parameters
+	else if (a.ema_full_precision) { // ema_step_full_precision: fp32 state, fp32 master weights (sharded data parallelism keeps the all-reduce step in this mode: foreign masters are stale)
+		float4 e4 = ((const float4*)a.ema)[i4];
+		float* ep = (float*)&e4;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const float filtered = ema_update(a, ep[k], (float)w4[k]);
-		ep[k] = filtered;
-		inf4[k] = (_Float16)filtered;
-		if (matrix) ((_Float16*)a.fw_frags_inf)[a.fw_perm[i + k]] = inf4[k];
+		for (int k = 0; k < 4; ++k) { const float filtered = ema_update(a, ep[k], mwp[k]); ep[k] = filtered; inf4[k] = (_Float16)filtered; }
+		((float4*)a.ema)[i4] = e4;
+	} else { // ema_step_half_precision: the state is the inference buffer itself
+		const h4 old4 = __builtin_bit_cast(h4, ((const uint2*)a.params_inf)[i4]);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) inf4[k] = (_Float16)ema_update(a, (float)old4[k], (float)w4[k]);
 	}
-	((float4*)a.ema)[i4] = e4;
+	if (matrix) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) ((_Float16*)a.fw_frags_inf)[a.fw_perm[i + k]] = inf4[k];
+	}
 	((uint2*)a.params_inf)[i4] = __builtin_bit_cast(uint2, inf4);
 }
 

@@ -218,12 +218,12 @@ extern "C" int ngp_model_config_from_json(const char* json_host, uint32_t aabb_s
 	c->n_extra_dims = n_extra_dims;
 	// optimizer: Ema( ExponentialDecay( Adam ) ), configs/nerf/base.json:5-22; walk the nesting
 	c->learning_rate = 1e-2f; c->beta1 = 0.9f; c->beta2 = 0.99f; c->epsilon = 1e-15f; c->l2_reg = 1e-6f;
-	c->ema_decay = 0.0f; c->decay_start = 0; c->decay_interval = 0; c->decay_base = 1.0f;
+	c->ema_decay = 0.0f; c->ema_full_precision = 0; c->decay_start = 0; c->decay_interval = 0; c->decay_base = 1.0f;
 	const mini_json::Value* o = &root["optimizer"];
 	for (int depth = 0; depth < 4 && o->is_object(); ++depth) {
 		std::string t = o->str("otype", "");
 		for (auto& ch : t) ch = (char)tolower(ch);
-		if (t == "ema") c->ema_decay = (float)o->num("decay", 0.99);
+		if (t == "ema") { c->ema_decay = (float)o->num("decay", 0.99); c->ema_full_precision = o->boolean("full_precision", false) ? 1u : 0u; } // [tcnn EmaOptimizer::update_hyperparams]
 		else if (t == "exponentialdecay") {
 			c->decay_start = (uint32_t)o->num("decay_start", 10000); c->decay_interval = (uint32_t)o->num("decay_interval", 10000);
 			c->decay_base = (float)o->num("decay_base", 0.33);
@@ -1192,7 +1192,7 @@ static AdamArgs make_adam_args(const ngp_model* m, float loss_scale, uint32_t st
 	a.ema_debias_old = 1 - std::pow(d, (float)(step - 1));
 	a.ema_debias_new = 1 / (1 - std::pow(d, (float)step));
 	a.master = m->master; a.params = m->params; a.params_inf = m->params_inf; a.grads = m->grads;
-	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema;
+	a.m = m->adam_m; a.v = m->adam_v; a.steps = m->adam_steps; a.ema = m->ema; a.ema_full_precision = m->cfg.ema_full_precision ? 1 : 0;
 	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
 	return a;
 }
@@ -1218,6 +1218,20 @@ extern "C" float ngp_model_learning_rate(const ngp_model* m) { return m->lr; }
 extern "C" uint32_t ngp_model_step(const ngp_model* m) { return m->step; }
 
 struct SerHeader { uint32_t magic, version; uint64_t n_params; uint32_t step, with_optimizer; float lr; uint32_t pad; };
+__global__ void k_inference_to_ema(const __half* __restrict__ inf, float* __restrict__ ema, uint64_t n) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) ema[i] = __half2float(inf[i]);
+}
+extern "C" uint64_t ngp_model_state_offset(uint64_t n_params, int section) { return sizeof(SerHeader) + (uint64_t)section * n_params * 4; }
+extern "C" int ngp_model_state_header(void* buf, uint64_t size, int write, uint64_t* n_params, uint32_t* step, float* lr, uint32_t* with_optimizer) {
+	REQUIRE(buf && size >= sizeof(SerHeader) && n_params && step && lr && with_optimizer, "ngp_model_state_header: null argument / truncated buffer");
+	if (write) { const SerHeader h = {0x4E475031u, 1, *n_params, *step, (uint32_t)(*with_optimizer != 0), *lr, 0}; memcpy(buf, &h, sizeof(h)); return 0; }
+	SerHeader h; memcpy(&h, buf, sizeof(h));
+	REQUIRE(h.magic == 0x4E475031u && h.version == 1, "ngp_model_state_header: bad magic/version");
+	*n_params = h.n_params; *step = h.step; *lr = h.lr; *with_optimizer = h.with_optimizer;
+	return 0;
+}
+extern "C" int ngp_model_get_config(const ngp_model* m, ngp_model_config* out) { REQUIRE(m && out, "ngp_model_get_config: null argument"); *out = m->cfg; return 0; }
 extern "C" uint64_t ngp_model_serialized_size(const ngp_model* m, int with_optimizer) {
 	return sizeof(SerHeader) + m->n_params * 4 * (with_optimizer ? 5 : 1);
 }
@@ -1238,6 +1252,8 @@ extern "C" int ngp_model_serialize_host(ngp_model* m, void* buf, uint64_t size, 
 			for (uint64_t i = 0; i < m->n_params; ++i) dst[i] = st16[i];
 			p += nb;
 		}
+		// EMA section (fp32 in this private blob): the fp32 state in "full_precision" mode, else the half inference parameters widened (exactly) -- they ARE the state
+		if (!m->cfg.ema_full_precision) hipLaunchKernelGGL(k_inference_to_ema, dim3((uint32_t)((m->n_params + 255) / 256)), dim3(256), 0, 0, (const __half*)m->params_inf, m->ema, m->n_params);
 		HIPCHK(hipMemcpy(p, m->ema, nb, hipMemcpyDeviceToHost)); p += nb;
 	}
 	return 0;
@@ -1995,6 +2011,7 @@ static int dp_setup_sharded(ngp_nerf* t, bool on) {
 	if (!on) return 0;
 	const uint32_t W = t->opt.world_size, L = m->gm.n_levels, F = m->gm.F;
 	REQUIRE(L >= 2, "sharded data-parallel step: the table has one level");
+	REQUIRE(!m->cfg.ema_full_precision, "sharded data-parallel step: a full-precision EMA needs every parameter's fp32 master on every rank (falls back to the all-reduce step)");
 	const uint64_t total = m->gm.offset[L]; // entries
 	// Bucket boundary = half of the LEVELS: k_grad_accumulate runs one block per (chunk, level) with the same number of chunks on every level and one 128 KiB block per CU,
 	// so two launches of L / 2 levels each keep whole rounds of blocks (base.json: 2 x 512 blocks on 256 CUs), where a split by bytes (5 + 3 levels: 2.5 + 1.5 rounds)

@@ -226,6 +226,7 @@ struct AdamArgs {
 	int optimize_matrix, optimize_non_matrix;
 	int zero_grid_grads; // leave the hash-grid gradients zeroed for the next step's scatter (GradientMode::Overwrite without a memset launch)
 	float ema_decay, ema_debias_old, ema_debias_new;
+	int ema_full_precision = 0; // [tcnn EmaOptimizer "full_precision"] 0 (default): the EMA state is the half inference buffer; 1: fp32 state `ema` fed with the fp32 masters
 	float* master; ngp_half* params; ngp_half* params_inf; ngp_half* grads;
 	float* m; float* v; uint16_t* steps /* per-parameter Adam step counters, saturating */; float* ema;
 	const uint32_t* fw_perm; const uint32_t* bw_perm; // n_mlp-entry scatter tables into the fragment buffers (0xFFFFFFFF = none)

@@ -1369,17 +1369,22 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 		// under a private key so that a snapshot of this library resumes bit for bit.
 		std::vector<uint8_t> blob(ngp_model_serialized_size(m_model, 1));
 		NGP_CHECK(ngp_model_serialize_host(m_model, blob.data(), blob.size(), 1));
-		struct Hdr { uint32_t magic, version; uint64_t n_params; uint32_t step, with_optimizer; float lr; uint32_t pad; } h; // SerHeader of csrc/ngp_api.hip
-		memcpy(&h, blob.data(), sizeof(h));
-		const size_t nb = (size_t)n_params * 4; const uint8_t* pbase = blob.data() + sizeof(h);
-		auto bin = [&](int k) { Value v; v.type = Value::Binary; v.bin.assign(pbase + (size_t)k * nb, pbase + (size_t)(k + 1) * nb); return v; }; // 0 master, 1 m, 2 v, 3 steps (u32), 4 ema
+		struct { uint64_t n_params; uint32_t step, with_optimizer; float lr; } h;
+		NGP_CHECK(ngp_model_state_header(blob.data(), blob.size(), 0, &h.n_params, &h.step, &h.lr, &h.with_optimizer));
+		const size_t nb = (size_t)n_params * 4;
+		auto bin = [&](int section) { Value v; v.type = Value::Binary; const uint8_t* b = blob.data() + ngp_model_state_offset(n_params, section); v.bin.assign(b, b + nb); return v; };
+		ngp_model_config mc; NGP_CHECK(ngp_model_get_config(m_model, &mc));
 		Value adam = jobj();
 		adam.set("current_step", jnum(h.step)); adam.set("base_learning_rate", jnum(h.lr)); // (the rate Adam steps with now: ExponentialDecay has already applied its factors)
-		adam.set("first_moments_binary", bin(1)); adam.set("second_moments_binary", bin(2)); adam.set("param_steps_binary", bin(3));
+		adam.set("first_moments_binary", bin(NGP_STATE_ADAM_M)); adam.set("second_moments_binary", bin(NGP_STATE_ADAM_V)); adam.set("param_steps_binary", bin(NGP_STATE_ADAM_STEPS));
 		Value decay = jobj(); decay.set("nested", adam); decay.set("base_learning_rate", jnum(m_network_config["optimizer"]["nested"]["nested"].num("learning_rate", m_network_config["optimizer"].num("learning_rate", 1e-2))));
-		Value ema = jobj(); ema.set("nested", decay); ema.set("ema_step", jnum(h.step)); ema.set("full_precision", jbool(true)); ema.set("weights_ema_binary", bin(4));
+		// EmaOptimizer::serialize [tcnn, from memory]: "weights_ema_binary" = m_weights_ema, a GPUMemory<T> -- the EMA weights in NETWORK precision ("params_type"), which is what
+		// the inference parameters are (`pb` above).  A "full_precision" EMA's fp32 state travels under a private key next to the master parameters (round-5 files carried an
+		// fp32 blob under the reference's key: a tcnn reader sizes its buffer from the byte count and would have read garbage).
+		Value ema = jobj(); ema.set("nested", decay); ema.set("ema_step", jnum(h.step)); ema.set("full_precision", jbool(mc.ema_full_precision != 0)); ema.set("weights_ema_binary", pb);
 		snap.set("optimizer", ema);
-		snap.set("ngp_hip_master_binary", bin(0));
+		snap.set("ngp_hip_master_binary", bin(NGP_STATE_MASTER));
+		if (mc.ema_full_precision) snap.set("ngp_hip_ema_binary", bin(NGP_STATE_EMA));
 	}
 	// ---- Testbed::save_snapshot, testbed.cu:5291-5343 ----
 	snap.set("version", jnum(1)); snap.set("mode", jstr("nerf"));
@@ -1490,10 +1495,10 @@ void Testbed::load_snapshot(const std::string& path) {
 		const Value& pb = snap["params_binary"];
 		if ((uint64_t)snap.num("n_params", 0) != n_params || pb.type != Value::Binary) throw std::runtime_error{"Snapshot parameters do not match the network config."};
 		const size_t nb = (size_t)n_params * 4;
-		struct Hdr { uint32_t magic, version; uint64_t n_params; uint32_t step, with_optimizer; float lr; uint32_t pad; } h = {0x4E475031u, 1, n_params, (uint32_t)adam->num("current_step", 0), 1u, (float)adam->num("base_learning_rate", 1e-2), 0};
-		std::vector<uint8_t> blob(sizeof(h) + nb * 5);
-		memcpy(blob.data(), &h, sizeof(h));
-		uint8_t* pbase = blob.data() + sizeof(h);
+		struct { uint64_t n_params; uint32_t step, with_optimizer; float lr; } h = {n_params, (uint32_t)adam->num("current_step", 0), 1u, (float)adam->num("base_learning_rate", 1e-2)};
+		std::vector<uint8_t> blob(ngp_model_state_offset(n_params, NGP_STATE_N_SECTIONS));
+		NGP_CHECK(ngp_model_state_header(blob.data(), blob.size(), 1, &h.n_params, &h.step, &h.lr, &h.with_optimizer));
+		uint8_t* pbase = blob.data() + ngp_model_state_offset(n_params, 0);
 		auto as_f32 = [&](const Value& v, int k, const char* what, bool allow_half) {
 			if (v.type == Value::Binary && v.bin.size() == nb) { memcpy(pbase + (size_t)k * nb, v.bin.data(), nb); return; }
 			if (allow_half && v.type == Value::Binary && v.bin.size() == nb / 2) { float* d = (float*)(pbase + (size_t)k * nb); for (uint64_t i = 0; i < n_params; ++i) { uint16_t hh; memcpy(&hh, &v.bin[i * 2], 2); d[i] = f16_to_f32(hh); } return; }
@@ -1507,7 +1512,8 @@ void Testbed::load_snapshot(const std::string& path) {
 		as_f32((*adam)["second_moments_binary"], 2, "second_moments_binary", false);
 		if (adam->has("param_steps_binary")) as_f32((*adam)["param_steps_binary"], 3, "param_steps_binary", false); // (uint32 counters: same width)
 		else { uint32_t* d = (uint32_t*)(pbase + 3 * nb); for (uint64_t i = 0; i < n_params; ++i) d[i] = h.step; } // [tcnn: older files have no per-parameter counters]
-		if (ema) as_f32((*ema)["weights_ema_binary"], 4, "weights_ema_binary", true);
+		if (snap["ngp_hip_ema_binary"].type == Value::Binary) as_f32(snap["ngp_hip_ema_binary"], 4, "ngp_hip_ema_binary", false); // this library's fp32 state of a "full_precision" EMA
+		else if (ema) as_f32((*ema)["weights_ema_binary"], 4, "weights_ema_binary", true);
 		else memcpy(pbase + 4 * nb, pbase, nb); // no EMA level: the inference parameters are the parameters
 		NGP_CHECK(ngp_model_deserialize_host(m_model, blob.data(), blob.size()));
 	} else { // Trainer::deserialize without optimizer state: parameters only, in the precision named by "params_type"

@@ -47,7 +47,7 @@ class ModelConfig(C.Structure):
                 ("per_level_scale", f32), ("n_neurons", u32), ("n_hidden_layers", u32), ("n_hidden_layers_rgb", u32),
                 ("sh_degree", u32), ("n_extra_dims", u32),
                 ("learning_rate", f32), ("beta1", f32), ("beta2", f32), ("epsilon", f32), ("l2_reg", f32),
-                ("ema_decay", f32), ("decay_start", u32), ("decay_interval", u32), ("decay_base", f32)]
+                ("ema_decay", f32), ("decay_start", u32), ("decay_interval", u32), ("decay_base", f32), ("ema_full_precision", u32)]
 
 
 class EncMlpConfig(C.Structure):
@@ -173,6 +173,9 @@ def load_hip():
         _lib.ngp_model_learning_rate.restype = f32
         _lib.ngp_model_step.restype = u32
         _lib.ngp_model_serialized_size.restype = u64
+        if hasattr(_lib, "ngp_model_state_offset"):  # (absent from older builds loaded through NGP_HIP_LIB)
+            _lib.ngp_model_state_offset.restype = u64
+            _lib.ngp_model_state_offset.argtypes = [u64, C.c_int]
         _lib.ngp_encmlp_learning_rate.restype = f32
         _lib.ngp_encmlp_step.restype = u32
     return _lib

@@ -378,15 +378,21 @@ struct Model {
 		}
 		// ExponentialDecay::step
 		if (cfg.decay_interval > 0 && step >= cfg.decay_start && step % cfg.decay_interval == 0) lr *= cfg.decay_base;
-		// Ema::step (ema_step_half_precision)
+		// EmaOptimizer::step [tcnn optimizers/ema.h, restated from memory: Appendix-A switch `ema_full_precision` = the optimizer's "full_precision" hyperparameter, default false]:
+		//   ema_step_half_precision: filtered = ((float)weights_ema[i] * decay * debias_old + (float)weights[i] * (1 - decay)) * debias_new;  weights_ema[i] = (T)filtered
+		//   ema_step_full_precision: filtered = (tmp[i] * decay * debias_old + weights_full_precision[i] * (1 - decay)) * debias_new;  tmp[i] = filtered;  weights_ema[i] = (T)filtered
+		// (rounds 1-5 restated a hybrid -- fp32 state, half weights -- which is neither kernel)
 		const float d = cfg.ema_decay;
 		const float debias_old = 1 - std::pow(d, (float)(step - 1));
 		const float debias_new = 1 / (1 - std::pow(d, (float)step));
+		const bool full = cfg.ema_full_precision != 0;
 		#pragma omp parallel for schedule(static)
 		for (int64_t i = 0; i < (int64_t)n_params; ++i) {
-			float filtered = (ema_tmp[i] * d * debias_old + h2f(params[i]) * (1 - d)) * debias_new;
-			ema_tmp[i] = filtered;
+			if (d == 0.f) { params_inf[i] = params[i]; ema_tmp[i] = h2f(params[i]); continue; } // no Ema wrapper
+			const float filtered = full ? (ema_tmp[i] * d * debias_old + params_fp[i] * (1 - d)) * debias_new
+			                            : (h2f(params_inf[i]) * d * debias_old + h2f(params[i]) * (1 - d)) * debias_new;
 			params_inf[i] = f2h(filtered);
+			ema_tmp[i] = full ? filtered : h2f(params_inf[i]); // half mode: the buffer mirrors the state (the tests move trainer states through it)
 		}
 	}
 };

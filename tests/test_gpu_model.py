@@ -17,8 +17,8 @@ from common import HipModel, OraModel, dptr, half_to_f32, ptr, random_coords
 pytestmark = pytest.mark.gpu
 
 
-def _models(ora, hip):
-    cfg = A.base_model_config(1)
+def _models(ora, hip, **cfg_kw):
+    cfg = A.base_model_config(1, **cfg_kw)
     om = OraModel(ora, cfg)
     hm = HipModel(hip, cfg)
     # make the two models bit-identical (initialisation itself is compared in test_init_parity)
@@ -190,9 +190,12 @@ def test_hashed_level_gradients_are_reproducible_and_exactly_summed(ora, hip):
         assert np.count_nonzero(a0[lo:hi_]) > 0
 
 
-def test_optimizer_step_parity(ora, hip):
+@pytest.mark.parametrize("ema_full_precision", [0, 1])
+def test_optimizer_step_parity(ora, hip, ema_full_precision):
+    """Adam + the two EMA kernels of tcnn's EmaOptimizer: the default half-precision state (the inference buffer itself, fed with the half weights) and
+    "full_precision" (fp32 state fed with the fp32 masters); the half mode must agree to the BIT with the oracle given equal weights (same fp32 expression, one rounding)."""
     import torch
-    cfg, om, hm = _models(ora, hip)
+    cfg, om, hm = _models(ora, hip, ema_full_precision=ema_full_precision)
     n = 4096
     c = random_coords(n, seed=33, ray_coherent=True)
     rng = np.random.default_rng(9)
@@ -216,6 +219,7 @@ def test_optimizer_step_parity(ora, hip):
         assert np.allclose(pm, ref, rtol=2e-5, atol=1e-8), np.abs(pm - ref).max()
         inf = half_to_f32(hm.read("inference", torch)); rinf = half_to_f32(om.params_inf)
         assert np.allclose(inf, rinf, rtol=2e-3, atol=1e-6)
+        if step == 0 and not ema_full_precision: assert np.array_equal(hm.read("inference", torch), hm.read("params", torch))  # debias_old = 0: the first EMA of half weights is the weights
         # keep both models identical for the next iteration
         hm.set_params(ref.copy()) if False else None
     assert hip.ngp_model_step(hm.h) == 3
