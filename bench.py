@@ -53,42 +53,23 @@ class CudaView:
 # ------------------------------------------------------------------------------------------------------------------------
 # scenes
 # ------------------------------------------------------------------------------------------------------------------------
-def load_scene(args):
-    """-> dict(images=[cuda uint8 HxWx4], M, X (ctypes arrays with device pixel pointers), n, aabb_scale, eval=[(gt cuda uint8, RenderParams)], eval_kind)"""
-    if args.scene == "synthetic":
-        import synth_scene
-        images, xforms, meta, _ = synth_scene.make_dataset(args.images, args.res, "cuda")
-        n = len(images)
-        M = (A.ImageMeta * n)(); X = (A.Xform * n)()
-        for i in range(n):
-            M[i].pixels = images[i].data_ptr(); M[i].image_data_type = A.IMAGE_BYTE; M[i].lens_mode = A.LENS_PERSPECTIVE
-            M[i].resolution[0], M[i].resolution[1] = meta["resolution"]
-            M[i].principal_point[0] = M[i].principal_point[1] = 0.5
-            M[i].focal_length[0], M[i].focal_length[1] = meta["focal_length"]
-            for k in range(12):
-                X[i].start[k] = X[i].end[k] = float(xforms[i][k])
-        ev = []
-        if args.eval_views > 0:
-            res = args.eval_res
-            gts, exf, emeta, _ = synth_scene.make_dataset(args.eval_views, res, "cuda", phase=1.234)
-            for gt, xf in zip(gts, exf):
-                rp = A.RenderParams()
-                rp.resolution[0] = rp.resolution[1] = res
-                rp.focal_length[0], rp.focal_length[1] = emeta["focal_length"]
-                rp.screen_center[0] = rp.screen_center[1] = 0.5
-                for k in range(12):
-                    rp.camera[k] = float(xf[k])
-                rp.lens_mode = 0
-                ev.append((gt, rp))
-        return dict(images=images, M=M, X=X, n=n, aabb_scale=1, eval=ev, eval_kind="held-out views (synthetic test cameras)",
-                    name=f"NeRF nerf_synthetic/lego-format synthetic scene ({n} views {args.res}x{args.res} RGBA8)")
-    # fox: the reference's real capture, through this repo's C++ loader (host/testbed.cpp load_training_data; JPEG decode by Pillow)
-    path = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
-    if not os.path.exists(path):
-        raise RuntimeError("--scene fox needs _ref_data/data/nerf/fox (tools/stage_reference_data.py copies it from /root/reference at build time)")
+LEGO_CANDIDATES = ("data/nerf/nerf_synthetic/lego", "_ref_data/data/nerf/nerf_synthetic/lego", "data/nerf_synthetic/lego", "_ref_data/data/nerf_synthetic/lego")
+
+
+def find_lego():
+    """scripts/scenes.py:25-32, 53: the reference keeps nerf_synthetic under data/nerf/nerf_synthetic/<scene>/transforms_train.json.  The set is not shipped with the reference and there
+    is no network, so this normally returns None and the stand-in is used; NGP_LEGO_DIR or a copy under data/ (or the staged _ref_data/) makes the headline run on the real set."""
+    cands = ([os.environ["NGP_LEGO_DIR"]] if os.environ.get("NGP_LEGO_DIR") else []) + [os.path.join(ROOT, c) for c in LEGO_CANDIDATES]
+    for d in cands:
+        f = os.path.join(d, "transforms_train.json")
+        if os.path.exists(f):
+            return f
+    return None
+
+
+def _scene_from_testbed_dataset(t, args, name, test_transforms=None):
+    """a dataset loaded by this repo's C++ loader (host/testbed.cpp load_training_data) -> the device-resident scene dict"""
     import pyngp as ngp
-    t = ngp.Testbed()
-    t.load_training_data(path)
     d = t.nerf.training.dataset
     n = d.n_images
     images = [torch.from_numpy(np.ascontiguousarray(d.image(i))).cuda() for i in range(n)]
@@ -103,21 +84,104 @@ def load_scene(args):
             M[i].lens_params[k] = m.lens_params[k]
         for k in range(12):
             X[i].start[k] = X[i].end[k] = d.xforms[i][k]
-    ev = []
-    for i in [int(round(k * (n - 1) / max(args.eval_views - 1, 1))) for k in range(args.eval_views)] if args.eval_views > 0 else []:
+
+    def view(img, Mi, Xi):
         # Testbed::set_camera_to_training_view (testbed.cu:486-505): camera = xform, screen_center = 1 - principal point, lens of the view
         rp = A.RenderParams()
-        rp.resolution[0], rp.resolution[1] = M[i].resolution[0], M[i].resolution[1]
-        rp.focal_length[0], rp.focal_length[1] = M[i].focal_length[0], M[i].focal_length[1]
-        rp.screen_center[0] = 1.0 - (1.0 - M[i].principal_point[0]); rp.screen_center[1] = 1.0 - (1.0 - M[i].principal_point[1])
+        rp.resolution[0], rp.resolution[1] = Mi.resolution[0], Mi.resolution[1]
+        rp.focal_length[0], rp.focal_length[1] = Mi.focal_length[0], Mi.focal_length[1]
+        rp.screen_center[0] = 1.0 - (1.0 - Mi.principal_point[0]); rp.screen_center[1] = 1.0 - (1.0 - Mi.principal_point[1])
         for k in range(12):
-            rp.camera[k] = X[i].start[k]
-        rp.lens_mode = M[i].lens_mode
+            rp.camera[k] = Xi.start[k]
+        rp.lens_mode = Mi.lens_mode
         for k in range(7):
-            rp.lens_params[k] = M[i].lens_params[k]
-        ev.append((images[i], rp))
-    return dict(images=images, M=M, X=X, n=n, aabb_scale=int(d.aabb_scale), eval=ev, eval_kind="TRAINING views (the capture has no test split)",
-                name=f"NeRF data/nerf/fox real capture ({n} JPEGs {M[0].resolution[0]}x{M[0].resolution[1]}, OpenCV lens, aabb_scale {int(d.aabb_scale)})", keep=t)
+            rp.lens_params[k] = Mi.lens_params[k]
+        return (img, rp)
+    ev, keep, kind = [], [t], "TRAINING views (the capture has no test split)"
+    nv = args.eval_views
+    if nv > 0 and test_transforms and os.path.exists(test_transforms):  # scripts/run.py:257-317: --test_transforms = the held-out split
+        t2 = ngp.Testbed(); t2.load_training_data(test_transforms)
+        d2 = t2.nerf.training.dataset
+        keep.append(t2)
+        for i in [int(round(k * (d2.n_images - 1) / max(nv - 1, 1))) for k in range(nv)]:
+            m = d2.metadata[i]
+            img = torch.from_numpy(np.ascontiguousarray(d2.image(i))).cuda()
+            Mi = A.ImageMeta(); Xi = A.Xform()
+            Mi.lens_mode = m.lens_mode; Mi.resolution[0], Mi.resolution[1] = m.resolution
+            Mi.principal_point[0], Mi.principal_point[1] = m.principal_point; Mi.focal_length[0], Mi.focal_length[1] = m.focal_length
+            for k in range(7):
+                Mi.lens_params[k] = m.lens_params[k]
+            for k in range(12):
+                Xi.start[k] = d2.xforms[i][k]
+            ev.append(view(img, Mi, Xi))
+        kind = "held-out views (transforms_test.json)"
+    elif nv > 0:
+        for i in [int(round(k * (n - 1) / max(nv - 1, 1))) for k in range(nv)]:
+            ev.append(view(images[i], M[i], X[i]))
+    return dict(images=images, M=M, X=X, n=n, aabb_scale=int(d.aabb_scale), eval=ev, eval_kind=kind, name=name, keep=keep)
+
+
+def load_scene(args, which=None):
+    """-> dict(images=[cuda uint8 HxWx4], M, X (ctypes arrays with device pixel pointers), n, aabb_scale, eval=[(gt cuda uint8, RenderParams)], eval_kind, name, data)
+    which: "synthetic" | "hard" (the two stand-ins, instant-ngp_amd/synth_scene.py) | "fox" | "lego" | a path to a transforms*.json; "auto" = lego when a copy exists, else "synthetic"."""
+    which = which or args.scene
+    if which == "auto":
+        which = "lego" if find_lego() else "synthetic"
+    if which in ("synthetic", "hard"):
+        import synth_scene
+        variant = "hard" if which == "hard" else "lego-format"
+        images, xforms, meta, _ = synth_scene.make_dataset(args.images, args.res, "cuda", variant=variant)
+        n = len(images)
+        M = (A.ImageMeta * n)(); X = (A.Xform * n)()
+        for i in range(n):
+            M[i].pixels = images[i].data_ptr(); M[i].image_data_type = A.IMAGE_BYTE; M[i].lens_mode = A.LENS_PERSPECTIVE
+            M[i].resolution[0], M[i].resolution[1] = meta["resolution"]
+            M[i].principal_point[0] = M[i].principal_point[1] = 0.5
+            M[i].focal_length[0], M[i].focal_length[1] = meta["focal_length"]
+            for k in range(12):
+                X[i].start[k] = X[i].end[k] = float(xforms[i][k])
+        ev = []
+        if args.eval_views > 0:
+            res = args.eval_res
+            gts, exf, emeta, _ = synth_scene.make_dataset(args.eval_views, res, "cuda", phase=1.234, variant=variant)
+            for gt, xf in zip(gts, exf):
+                rp = A.RenderParams()
+                rp.resolution[0] = rp.resolution[1] = res
+                rp.focal_length[0], rp.focal_length[1] = emeta["focal_length"]
+                rp.screen_center[0] = rp.screen_center[1] = 0.5
+                for k in range(12):
+                    rp.camera[k] = float(xf[k])
+                rp.lens_mode = 0
+                ev.append((gt, rp))
+        desc = ("hard synthetic scene (thin grille / poles / stud field / 24 small spheres, pixel-scale texture, view-dependent highlights)" if which == "hard"
+                else "synthetic scene (5 boxes + 3 spheres)")
+        return dict(images=images, M=M, X=X, n=n, aabb_scale=1, eval=ev, eval_kind="held-out views (synthetic test cameras)", which=which, data="synthetic",
+                    metric_scene="nerf_synthetic/lego-format " + ("hard " if which == "hard" else "") + "synthetic scene",
+                    name=f"NeRF nerf_synthetic/lego-format {desc} ({n} views {args.res}x{args.res} RGBA8)")
+    sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd", "host"))
+    import pyngp as ngp
+    if which == "fox":  # the reference's real capture, through this repo's C++ loader (native JPEG decode)
+        path = os.path.join(ROOT, "_ref_data", "data", "nerf", "fox", "transforms.json")
+        if not os.path.exists(path):
+            raise RuntimeError("--scene fox needs _ref_data/data/nerf/fox (tools/stage_reference_data.py copies it from /root/reference at build time)")
+        t = ngp.Testbed(); t.load_training_data(path)
+        sc = _scene_from_testbed_dataset(t, args, "")
+        sc.update(which="fox", data="reference-shipped capture (data/nerf/fox)", metric_scene="data/nerf/fox",
+                  name=f"NeRF data/nerf/fox real capture ({sc['n']} JPEGs {sc['M'][0].resolution[0]}x{sc['M'][0].resolution[1]}, OpenCV lens, aabb_scale {sc['aabb_scale']})")
+        return sc
+    path = find_lego() if which == "lego" else which
+    if not path or not os.path.exists(path):
+        raise RuntimeError(f"--scene {which}: no such transforms file" if which != "lego" else "--scene lego: nerf_synthetic/lego not found (NGP_LEGO_DIR, data/nerf/nerf_synthetic/lego, _ref_data/...)")
+    if os.path.isdir(path):
+        path = os.path.join(path, "transforms_train.json" if os.path.exists(os.path.join(path, "transforms_train.json")) else "transforms.json")
+    t = ngp.Testbed(); t.load_training_data(path)
+    test = os.path.join(os.path.dirname(path), "transforms_test.json") if os.path.basename(path) == "transforms_train.json" else None
+    sc = _scene_from_testbed_dataset(t, args, "", test)
+    is_lego = os.path.basename(os.path.dirname(os.path.abspath(path))) == "lego"
+    sc.update(which="lego" if is_lego else "path", data=("nerf_synthetic/lego" if is_lego else "dataset ") + f" loaded from {path}",
+              metric_scene="nerf_synthetic/lego" if is_lego else os.path.relpath(path, ROOT),
+              name=f"NeRF {'nerf_synthetic/lego' if is_lego else path} ({sc['n']} views {sc['M'][0].resolution[0]}x{sc['M'][0].resolution[1]}, aabb_scale {sc['aabb_scale']})")
+    return sc
 
 
 def make_trainer(lib, scene, batch, rank=0, world=1, seed=1337, model_kw=None):
@@ -264,27 +328,52 @@ def calibrate(lib=None):
             "reference_fast_box": {"d2d_copy_GBps": 5800.0, "note": "profiles/r03_dp_diag2_comm_after_training.txt: 5.77-5.80 TB/s read+write on the box that ran 0.65 ms per step"}}
 
 
-def run_fox_leg(lib, args):
-    """Secondary leg of the default line (BASELINE.json config 2: data/nerf/fox, same network config, 1 GPU): untimed load + pretrain, then the same
-    barrier-bracketed timing as the headline."""
+def psnr_curve_of(lib, nerf, scene, args, steps, train):
+    """BASELINE.json's second metric, the run.py procedure (scripts/run.py:229-317) at the given training steps: keep training (untimed), evaluate at each step"""
+    curve = {}
+    for target in steps:
+        cur = get_stats(lib, nerf).training_step
+        if target > cur:
+            train(target - cur)
+        curve[str(get_stats(lib, nerf).training_step)] = round(eval_psnr(lib, nerf, scene, args.eval_spp), 3)
+    return curve
+
+
+def run_scene_leg(lib, args, which, pretrain, n=200):
+    """Secondary leg of the default line: another scene with the same network config on 1 GPU -- `fox` (BASELINE.json configs[2], the reference's shipped real capture) or `hard` (the
+    lego-hard stand-in) -- untimed load + pretrain, the same synchronize-bracketed timing as the headline over n steps, then the PSNR@step curve."""
     import copy
-    a2 = copy.copy(args); a2.scene = "fox"; a2.eval_views = 0
+    a2 = copy.copy(args); a2.scene = which
     t0 = time.perf_counter()
-    scene = load_scene(a2)
+    scene = load_scene(a2, which)
     load_s = time.perf_counter() - t0
     _, _, model, nerf = make_trainer(lib, scene, args.batch)
-    A.check(lib, lib.ngp_nerf_train(nerf, None, 5000 + 20))  # (the occupancy grid of a real capture keeps pruning for a few thousand steps: samples marched per ray fall until then)
+    curve = {}
+    steps = sorted(int(x) for x in args.psnr_steps.split(",") if x) if args.psnr_steps and args.eval_views > 0 else []
+    early = [k for k in steps if k <= pretrain]
+    if early:  # curve points below the pretrain count are taken on the way
+        curve.update(psnr_curve_of(lib, nerf, scene, args, early, lambda k: A.check(lib, lib.ngp_nerf_train(nerf, None, k))))
+    cur = get_stats(lib, nerf).training_step
+    A.check(lib, lib.ngp_nerf_train(nerf, None, max(pretrain - cur, 0)))  # (the occupancy grid of a real capture keeps pruning for a few thousand steps: samples marched per ray fall until then)
     torch.cuda.synchronize()
     s0 = get_stats(lib, nerf)
-    n = 100
     t0 = time.perf_counter()
     A.check(lib, lib.ngp_nerf_train(nerf, None, n))
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     s1 = get_stats(lib, nerf)
-    out = {"workload": scene["name"] + ", configs/nerf/base.json, batch 2^18 samples per step", "pretrain_steps": 5020, "steps": n, "ms_per_step": round(1e3 * el / n, 4),
+    out = {"workload": scene["name"] + ", configs/nerf/base.json, batch 2^18 samples per step", "pretrain_steps": pretrain, "steps": n, "ms_per_step": round(1e3 * el / n, 4),
            "rays_per_s": (s1.total_rays - s0.total_rays) / el, "samples_per_s": (s1.total_samples - s0.total_samples) / el,
-           "rays_per_step": (s1.total_rays - s0.total_rays) / n, "loss": s1.loss, "load_seconds": round(load_s, 2)}
+           "rays_per_step": (s1.total_rays - s0.total_rays) / n, "samples_per_ray_compacted": (s1.total_samples - s0.total_samples) / max(s1.total_rays - s0.total_rays, 1),
+           "marched_samples_per_hit_ray": s1.measured_batch_size_before_compaction / max(s1.n_rays_last, 1), "loss": s1.loss, "load_seconds": round(load_s, 2)}
+    late = [k for k in steps if k > pretrain]
+    if late:
+        t0 = time.perf_counter()
+        curve.update(psnr_curve_of(lib, nerf, scene, args, late, lambda k: A.check(lib, lib.ngp_nerf_train(nerf, None, k))))
+        out["psnr_curve_seconds"] = round(time.perf_counter() - t0, 2)
+    if curve:
+        out["test_psnr_curve_db"] = curve
+        out["test_psnr_views"] = f"{len(scene['eval'])} {scene['eval_kind']}, spp {args.eval_spp}"
     lib.ngp_nerf_destroy(nerf); lib.ngp_model_destroy(model)
     return out
 
@@ -381,8 +470,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pretrain", type=int, default=1000, help="untimed training steps that bring the occupancy grid to steady state")
-    ap.add_argument("--scene", choices=["synthetic", "fox"], default="synthetic")
+    ap.add_argument("--pretrain", type=int, default=1010, help="untimed training steps that bring the occupancy grid to steady state (1010 + the driver's 5 warm-up steps: the 20 timed steps then hold ONE occupancy-grid update -- the reference updates every 16th step, i.e. 1.25 per 20 steps; the line says how many its window held and carries a 200-step figure beside it)")
+    ap.add_argument("--scene", default="auto", help="auto (nerf_synthetic/lego when a copy exists -- NGP_LEGO_DIR, data/nerf/nerf_synthetic/lego, _ref_data/... --, else the synthetic stand-in) | synthetic | hard | fox | lego | path to a transforms*.json (scripts/scenes.py:25-32)")
+    ap.add_argument("--steady-steps", type=int, default=200, help="a second, longer timed window behind the K timed steps (reported beside them; 0 = off)")
+    ap.add_argument("--no-hard-leg", action="store_true", help="skip the lego-hard stand-in leg of the default line")
     ap.add_argument("--images", type=int, default=100)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--batch", type=int, default=1 << 18)
@@ -394,7 +485,7 @@ def main():
     ap.add_argument("--eval-views", type=int, default=4, help="views rendered (untimed) for PSNR, run.py --test_transforms procedure")
     ap.add_argument("--eval-res", type=int, default=400)
     ap.add_argument("--eval-spp", type=int, default=1)
-    ap.add_argument("--psnr-steps", type=str, default="", help="comma separated training steps at which to also evaluate the PSNR after the timed region (untimed), e.g. 5000,10000,35000")
+    ap.add_argument("--psnr-steps", type=str, default="1000,5000,10000,35000", help="comma separated training steps at which the PSNR is evaluated after the timed region (untimed; BASELINE.json's PSNR@step, run.py's default n_steps = 35000); '' = off")
     ap.add_argument("--ab-psnr", type=str, default="", help="comma separated steps: equal-step PSNR of the production path vs the reference-order path (two fresh trainings, untimed)")
     ap.add_argument("--ab-seeds", type=int, default=1, help="--ab-psnr: number of seeds (1337, 1338, ...) per path; mean, standard deviation and the paired difference with its standard error are reported")
     ap.add_argument("--ab-seed0", type=int, default=1337, help="--ab-psnr: first seed")
@@ -519,6 +610,23 @@ def main():
     rays = s1.total_rays - s0.total_rays                # global rays launched over the K steps (all ranks)
     samples = (s1.total_samples - s0.total_samples) * world
     value = rays / elapsed
+    # occupancy-grid updates inside the K timed steps (training_prep_nerf at testbed.cu:4596's cadence: every 16th step beyond step 256): the step counter before / after says how many
+    def n_grid_updates(a, b):  # prep of step k updates when k % 16 == 0 (k >= 256)
+        return sum(1 for k in range(a, b) if k >= 256 and k % 16 == 0)
+    window = {"first_step": int(s0.training_step), "steps": args.steps, "grid_updates_in_window": n_grid_updates(int(s0.training_step), int(s1.training_step)),
+              "grid_updates_per_window_steady_state": round(args.steps / 16.0, 3)}
+    steady = None
+    if args.steady_steps > 0:  # a longer window behind the K steps: the steady-state average (same bracketing)
+        barrier()
+        t0 = time.perf_counter()
+        step(args.steady_steps)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        if dist is not None:
+            e2 = torch.tensor([el2], dtype=torch.float64, device="cuda"); dist.all_reduce(e2, op=dist.ReduceOp.MAX); el2 = float(e2.item()); dist.barrier()
+        s2 = get_stats(lib, nerf)
+        steady = {"steps": args.steady_steps, "ms_per_step": round(1e3 * el2 / args.steady_steps, 4), "rays_per_s": (s2.total_rays - s1.total_rays) / el2,
+                  "samples_per_s": (s2.total_samples - s1.total_samples) * world / el2, "grid_updates_in_window": n_grid_updates(int(s1.training_step), int(s2.training_step))}
 
     # ---- roofline leg: per-kernel HIP-event timing over further (untimed) steps --------------------------------
     lib.ngp_profile_enable(1)
@@ -561,7 +669,7 @@ def main():
     avg_ms = kern[dominant][0] / kern[dominant][1]
     achieved = per_launch_bytes[dominant] / (avg_ms * 1e-3) / 1e9
     pmc = None
-    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # PMC counters cannot be sampled from inside the process: committed rocprofv3 --pmc passes (tools/pmc_traffic.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
             traffic_src = f"profiles/{fn} (separate rocprofv3 --pmc passes of this command; see the file for the correction applied)"
@@ -616,29 +724,33 @@ def main():
 
     # optional PSNR@step curve (BASELINE.json's second metric): keep training, untimed, and evaluate at the requested steps
     psnr_curve = {}
-    if rank == 0 and world == 1 and args.psnr_steps:
+    t_curve = time.perf_counter()
+    if rank == 0 and world == 1 and args.psnr_steps and args.eval_views > 0:
         if psnr is not None:
             psnr_curve[str(psnr_step)] = round(psnr, 3)
-        for target in sorted(int(x) for x in args.psnr_steps.split(",") if x):
-            cur = get_stats(lib, nerf).training_step
-            if target > cur:
-                step(target - cur)
-            psnr_curve[str(get_stats(lib, nerf).training_step)] = round(eval_psnr(lib, nerf, scene, args.eval_spp), 3)
+        psnr_curve.update(psnr_curve_of(lib, nerf, scene, args, [k for k in sorted(int(x) for x in args.psnr_steps.split(",") if x) if k > psnr_step], step))
+    t_curve = time.perf_counter() - t_curve
 
     # ---- CPU baseline: the oracle (port) runs bounded steps from the same trained state --------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(lib, model, nerf, cfg, scene, s3, args)
 
-    fox_leg = None
-    if rank == 0 and world == 1 and args.scene == "synthetic" and not args.no_fox_leg:
+    fox_leg = hard_leg = None
+    main_default = scene.get("which") in ("synthetic", "lego")
+    if rank == 0 and world == 1 and main_default and not args.no_fox_leg:
         try:
-            fox_leg = run_fox_leg(lib, args)
+            fox_leg = run_scene_leg(lib, args, "fox", 5020)
         except Exception as e:  # the capture is staged from /root/reference at build time; a box without it still reports the headline
             fox_leg = {"skipped": str(e)[:200]}
+    if rank == 0 and world == 1 and main_default and not args.no_hard_leg:
+        try:
+            hard_leg = run_scene_leg(lib, args, "hard", 2020)
+        except Exception as e:
+            hard_leg = {"skipped": str(e)[:200]}
 
     f4_legs = {}
-    if rank == 0 and world == 1 and args.scene == "synthetic" and not args.no_f4_legs:
+    if rank == 0 and world == 1 and main_default and not args.no_f4_legs:
         sys.path.insert(0, os.path.join(ROOT, "instant-ngp_amd", "host"))
         for name, fn in (("image", run_image_leg), ("sdf", run_sdf_leg)):
             t_leg = time.perf_counter()
@@ -653,15 +765,16 @@ def main():
         ab = run_ab_psnr(lib, scene, args, sorted(int(x) for x in args.ab_psnr.split(",") if x), seeds=[args.ab_seed0 + i for i in range(max(args.ab_seeds, 1))])
 
     if rank == 0:
-        lego = args.scene == "synthetic"
         out = {
-            "metric": ("training rays/sec on nerf_synthetic/lego-format scene" if lego else "training rays/sec on data/nerf/fox") + ", configs/nerf/base.json, B=2^18 samples/step",
+            # rays/s = samples/s / (samples per ray), and the second factor is a property of the SCENE (4.5 on the easy stand-in, ~60 on fox): the portable figure is samples/s
+            "metric": f"training rays/sec on {scene['metric_scene']}, configs/nerf/base.json, B=2^18 samples/step ({samples / elapsed / 1e6:.0f} M samples/s at {samples / max(rays, 1):.2f} compacted samples per ray)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic" if lego else "reference-shipped capture (data/nerf/fox)",
+            "dtype": "f16", "data": scene["data"],
             "config": {"workload": scene["name"] + ", configs/nerf/base.json (hash L=8 F=4 T=2^19, MLP 64), batch " + (f"2^{int(math.log2(args.batch))}" if args.batch & (args.batch - 1) == 0 else str(args.batch)) + " samples per GPU per step, rays/step adaptive (cap 2^18)",
                        "parallelism": f"dp{world}", **({"dp_backend": dp_backend} if dp_backend else {}),
-                       "pretrain_steps": args.pretrain, "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
+                       "pretrain_steps": args.pretrain, "timed_window": window, **({"steady_window": steady} if steady else {}),
+                       "rays_per_step": rays / args.steps, "samples_per_s": samples / elapsed,
                        "samples_per_ray_compacted": samples / max(rays, 1),
                        "ray_hit_fraction": s1.n_rays_last / max(s1.rays_per_batch, 1), "rays_hit_last_step": s1.n_rays_last, "rays_per_batch_last_step": s1.rays_per_batch,
                        "marched_samples_last_step": s1.measured_batch_size_before_compaction, "network_evaluations_last_step": s1.network_evaluations,
@@ -671,10 +784,10 @@ def main():
                        **({"calibration": calibration} if calibration else {}),
                        "production_path": ablation["debug_flags"] == 0 and not ablation["env_knobs"], **({"ablation": ablation} if (ablation["debug_flags"] or ablation["env_knobs"]) else {}),
                        **({"dp_host_enqueue_ms_per_step": host_ms} if host_ms else {}),
-                       **({"test_psnr_curve_db": psnr_curve} if psnr_curve else {}),
+                       **({"test_psnr_curve_db": psnr_curve, "test_psnr_curve_seconds": round(t_curve, 2)} if psnr_curve else {}),
                        **({"ab_psnr": ab} if ab else {})},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            **({"legs": {**({"fox": fox_leg} if fox_leg else {}), **f4_legs}} if (fox_leg or f4_legs) else {}),
+            **({"legs": {**({"fox": fox_leg} if fox_leg else {}), **({"hard": hard_leg} if hard_leg else {}), **f4_legs}} if (fox_leg or hard_leg or f4_legs) else {}),
         }
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()

@@ -194,9 +194,10 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
-	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
-	if (li >= ray_end - ray_begin) return;
 	const uint32_t role = blockIdx.y;
+	// grid-stride over the slots (round 6): the launch used to be sized for the ray cap (2^18 slots -> 8192 workgroups of which a step's ~6 10^4 rays use a quarter; the rest cost
+	// dispatch time only); now a fixed grid covers 2^16 slots per pass
+	for (uint32_t li = threadIdx.x + blockIdx.x * blockDim.x; li < ray_end - ray_begin; li += gridDim.x * blockDim.x) {
 	// Slot li marches global ray ray_begin + pi(li), pi = a fixed bijection of [0, n_local) (multiplication by a prime > 2^18 x world):
 	// slots are filled in slot order, so the rays that K1's sample cap (testbed_nerf.cu:813-815) and K3's batch clamp drop -- the LAST
 	// slots -- are spread evenly over the ray range.  In plain index order they were always the rays of the last image(s)
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 			}
 		}
 		out.tgt[c] = tgt; out.tgt[3 + c] = bg;
-		return;
+		continue;
 	}
 	const bool masked = read_rgba_masked(uv, m.resolution, m.pixels, pixel_type);
 	const Box aabb(a.aabb);
@@ -264,6 +265,7 @@ __global__ void __launch_bounds__(128) k1_setup(K1Args a, RaySetup* __restrict__
 	out.o[0] = o[0]; out.o[1] = o[1]; out.o[2] = o[2]; out.d[0] = d[0]; out.d[1] = d[1]; out.d[2] = d[2]; out.rdn[0] = dn[0]; out.rdn[1] = dn[1]; out.rdn[2] = dn[2];
 	out.startt = startt; out.nprime = nprime; out.count = 0; out.flags = n_in; out.ray_index = i; out.img = img;
 	if (!a.ray_targets_out) for (int k = 0; k < 6; ++k) out.tgt[k] = 0.f;
+	}
 }
 
 static __device__ __forceinline__ float lattice_t(const RaySetup& r, uint32_t j, float cone_angle) {
@@ -1771,8 +1773,9 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	uint64_t* partial = (uint64_t*)p; p += (size_t)ray_grid * 8;
 	uint32_t* done = (uint32_t*)p;
 	const bool plain = a.plain_dataset && !(g_debug_flags2 & DBG2_K1_SETUP_GENERAL) && !a.cdf.img && !a.cdf.x_cond_y && !(a.depth_lambda > 0.0f);
-	if (plain) hipLaunchKernelGGL(k1_setup<true>, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
-	else hipLaunchKernelGGL(k1_setup<false>, dim3(blocks(max_local_rays, 128), a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
+	const uint32_t setup_grid = std::min<uint32_t>(blocks(max_local_rays, 128), 512u); // 2^16 slots per pass of the kernel's grid-stride loop
+	if (plain) hipLaunchKernelGGL(k1_setup<true>, dim3(setup_grid, a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
+	else hipLaunchKernelGGL(k1_setup<false>, dim3(setup_grid, a.ray_targets_out ? 4 : 1), dim3(128), 0, s, a, rs);
 	if (single && a.bitfield_coarse && a.bitfield_linear && !a.chunk_march && !a.no_first_point_skip) {
 		// one cascade, constant step: segment prepass + sample lists.  36 KiB of LDS per workgroup: 4 resident per CU = the persistent grid
 		uint16_t* jlist = (uint16_t*)((char*)scratch + k1_jlist_offset(max_local_rays));

@@ -32,6 +32,42 @@ _PRIMS = [
 ]
 
 
+def _hard_prims():
+    """The "hard" variant (round 6): what makes nerf_synthetic/lego slow to fit and the stand-in above easy is missing there -- thin structures (a grille of
+    2-3 cm bars, poles, a stud field), many small occluders, and texture at the scale of a pixel.  Deterministic (seeded), same cameras / format / aabb_scale."""
+    rng = np.random.default_rng(20240930)
+    prims = [("box", ((-0.95, -0.95, -0.38), (0.95, 0.95, -0.30)), (0.50, 0.50, 0.48))]   # base plate
+    # stud field on the plate: 9 x 9 short cylinders approximated by small spheres
+    for ix in range(9):
+        for iy in range(9):
+            if (ix + iy) % 2 == 0:
+                prims.append(("sphere", ((-0.8 + 0.2 * ix, -0.8 + 0.2 * iy, -0.29), 0.045), (0.75, 0.72, 0.20)))
+    # body: three stacked blocks
+    prims += [("box", ((-0.50, -0.30, -0.30), (0.30, 0.30, 0.00)), (0.85, 0.62, 0.08)),
+              ("box", ((-0.40, -0.22, 0.00), (0.20, 0.22, 0.22)), (0.80, 0.12, 0.10)),
+              ("box", ((0.30, -0.10, -0.30), (0.85, 0.10, -0.12)), (0.12, 0.32, 0.78))]
+    # grille: thin bars (2.5 cm) in two directions above the body
+    for k in range(9):
+        x = -0.45 + 0.1 * k
+        prims.append(("box", ((x, -0.34, 0.24), (x + 0.025, 0.34, 0.265)), (0.15, 0.15, 0.17)))
+    for k in range(7):
+        y = -0.30 + 0.1 * k
+        prims.append(("box", ((-0.47, y, 0.265), (0.42, y + 0.025, 0.29)), (0.70, 0.70, 0.74)))
+    # poles and a boom of thin boxes
+    for (x, y, h) in ((-0.85, -0.75, 0.55), (-0.85, 0.75, 0.35), (0.85, 0.75, 0.65), (0.85, -0.75, 0.25), (0.0, 0.85, 0.50), (0.0, -0.85, 0.45)):
+        prims.append(("box", ((x - 0.015, y - 0.015, -0.30), (x + 0.015, y + 0.015, h)), (0.18, 0.55, 0.25)))
+    prims.append(("box", ((-0.85, -0.76, 0.52), (0.85, -0.74, 0.54)), (0.85, 0.85, 0.30)))
+    prims.append(("box", ((-0.86, -0.75, 0.30), (-0.84, 0.75, 0.32)), (0.85, 0.40, 0.30)))
+    # scattered small spheres
+    for _ in range(24):
+        c = (float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.2, 0.6)))
+        prims.append(("sphere", (c, float(rng.uniform(0.03, 0.07))), tuple(float(v) for v in rng.uniform(0.15, 0.95, 3))))
+    return prims
+
+
+_PRIMS_HARD = _hard_prims()
+
+
 def camera_poses(n, seed_phase=0.0):
     """n camera-to-world matrices (NeRF / OpenGL convention: -Z forward, +Y up), Fibonacci hemisphere."""
     poses = []
@@ -61,8 +97,10 @@ def nerf_matrix_to_ngp(c2w):
     return m.T.reshape(-1).astype(np.float32)  # columns contiguous
 
 
-def _intersect(o, d):
-    """o, d: [N,3] torch (NeRF world). Returns rgb [N,3] in linear-ish display space and alpha [N]."""
+def _intersect(o, d, variant="lego-format"):
+    """o, d: [N,3] torch (NeRF world). Returns rgb [N,3] in linear-ish display space and alpha [N].
+    variant "hard": _PRIMS_HARD, texture at 3 x the spatial frequency, and a VIEW-DEPENDENT term (Blinn-Phong highlight) so that the colour network has something to fit."""
+    hard = variant == "hard"
     N = o.shape[0]
     dev, dt = o.device, o.dtype
     best_t = torch.full((N,), float("inf"), device=dev, dtype=dt)
@@ -71,7 +109,7 @@ def _intersect(o, d):
     light = torch.tensor([0.35, -0.45, 0.82], device=dev, dtype=dt)
     light = light / light.norm()
     inv = 1.0 / torch.where(d.abs() < 1e-9, torch.full_like(d, 1e-9), d)
-    for kind, prm, col in _PRIMS:
+    for kind, prm, col in (_PRIMS_HARD if hard else _PRIMS):
         colt = torch.tensor(col, device=dev, dtype=dt)
         if kind == "box":
             lo = torch.tensor(prm[0], device=dev, dtype=dt); hi = torch.tensor(prm[1], device=dev, dtype=dt)
@@ -92,16 +130,23 @@ def _intersect(o, d):
             n = (oc + d * t[:, None]) / r
         p = o + d * t[:, None]
         # procedural albedo variation (studs / stripes) so the views carry high-frequency detail
-        tex = 0.82 + 0.18 * torch.sign(torch.sin(p[:, 0] * 19.0) * torch.sin(p[:, 1] * 19.0) * torch.sin(p[:, 2] * 19.0 + 0.5))
-        shade = 0.35 + 0.65 * (n * light).sum(1).clamp_min(0)
-        c_out = colt[None, :] * (tex * shade)[:, None]
+        if hard:
+            tex = 0.70 + 0.30 * torch.sin(p[:, 0] * 61.0) * torch.sin(p[:, 1] * 57.0) * torch.sin(p[:, 2] * 53.0 + 0.5) + 0.12 * torch.sign(torch.sin(p[:, 0] * 140.0 + p[:, 1] * 90.0))
+            shade = 0.30 + 0.60 * (n * light).sum(1).clamp_min(0)
+            hvec = light[None, :] - d; hvec = hvec / hvec.norm(dim=1, keepdim=True)
+            spec = 0.45 * (n * hvec).sum(1).clamp_min(0) ** 24                      # view dependent
+            c_out = colt[None, :] * (tex * shade)[:, None] + spec[:, None]
+        else:
+            tex = 0.82 + 0.18 * torch.sign(torch.sin(p[:, 0] * 19.0) * torch.sin(p[:, 1] * 19.0) * torch.sin(p[:, 2] * 19.0 + 0.5))
+            shade = 0.35 + 0.65 * (n * light).sum(1).clamp_min(0)
+            c_out = colt[None, :] * (tex * shade)[:, None]
         best_t = torch.where(hit, t, best_t)
         rgb = torch.where(hit[:, None], c_out, rgb)
     alpha = torch.isfinite(best_t).to(dt)
     return rgb.clamp(0, 1), alpha
 
 
-def render_view(c2w, res, device="cpu"):
+def render_view(c2w, res, device="cpu", variant="lego-format"):
     """RGBA8 image [H, W, 4] uint8 (sRGB-encoded colour, straight alpha), like a nerf_synthetic PNG."""
     W = H = res
     focal = 0.5 * W / math.tan(0.5 * CAMERA_ANGLE_X)
@@ -111,18 +156,18 @@ def render_view(c2w, res, device="cpu"):
     d = dirs @ c2w_t[:3, :3].T
     d = d / d.norm(dim=1, keepdim=True)
     o = c2w_t[:3, 3][None, :].expand_as(d)
-    rgb, alpha = _intersect(o, d)
+    rgb, alpha = _intersect(o, d, variant)
     img = torch.cat([rgb * alpha[:, None], alpha[:, None]], dim=1)  # non-hit pixels are (0,0,0,0)
     return (img.reshape(H, W, 4) * 255.0 + 0.5).clamp(0, 255).to(torch.uint8)
 
 
-def make_dataset(n_images=100, res=800, device="cpu", phase=0.0):
+def make_dataset(n_images=100, res=800, device="cpu", phase=0.0, variant="lego-format"):
     """In-memory dataset: list of uint8 [H,W,4] tensors (on `device`), per-image metadata dicts."""
     poses = camera_poses(n_images, phase)
     focal = 0.5 * res / math.tan(0.5 * CAMERA_ANGLE_X)  # nerf_loader.cu:256-263 (camera_angle_x -> focal length)
     images, xforms = [], []
     for c2w in poses:
-        images.append(render_view(c2w, res, device))
+        images.append(render_view(c2w, res, device, variant))
         xforms.append(nerf_matrix_to_ngp(c2w))
     meta = dict(resolution=(res, res), focal_length=(focal, focal), principal_point=(0.5, 0.5), aabb_scale=1)
     return images, xforms, meta, poses
