@@ -962,6 +962,9 @@ struct ngp_sdf {
 	void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
 	SdfQueryScratch query() const { return {stab_list, stab_list + cap, stab_count, stab_list + 2 * (size_t)cap, stab_list + 3 * (size_t)cap, stab_list + 4 * (size_t)cap, stab_list + 5 * (size_t)cap, sort_temp, sort_temp_bytes, stab_offsets, stab_count + 1}; }
 	Rng rng; uint32_t training_step = 0;
+	// batch n + 1 is generated (positions + ground truth: it depends on no parameter) on a side stream while batch n trains: a second batch-sized buffer pair and two events (round 6)
+	float* positions2 = nullptr; float* distances2 = nullptr; hipEvent_t ev_free = nullptr, ev_batch = nullptr;
+	float* batch_positions = nullptr; float* batch_distances = nullptr; // where the last trained batch lies (null: positions / distances)
 };
 // load_mesh's normalisation (testbed_sdf.cu:1380-1410): raw box inflated by 0.5 % of its diagonal, scaled by its largest extent and centred in the unit cube
 extern "C" int ngp_sdf_normalize_mesh_host(float* v, uint64_t n_vertices, ngp_aabb* aabb_out, float* mesh_scale_out) {
@@ -1121,11 +1124,14 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 extern "C" void ngp_sdf_destroy(ngp_sdf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
-	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, (void*)t->stab_offsets, t->sort_temp}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, (void*)t->stab_offsets, t->sort_temp, (void*)t->positions2, (void*)t->distances2}) if (p) (void)hipFree(p);
+	if (t->ev_free) (void)hipEventDestroy(t->ev_free);
+	if (t->ev_batch) (void)hipEventDestroy(t->ev_batch);
 	delete t;
 }
 // generate_training_samples_sdf: fills positions / distances for `n` samples and advances m_rng like the reference
-static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only) {
+static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only, float* positions = nullptr, float* distances = nullptr) {
+	if (!positions) { positions = t->positions; distances = t->distances; }
 	const uint32_t base = n / 8;
 	SdfSampleArgs a;
 	a.n = n; a.n_exact = uniform_only ? 0 : base * 4; a.n_surface = uniform_only ? 0 : base * 7;
@@ -1133,21 +1139,44 @@ static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only
 	a.stddev = std::sqrt(0.75f) / 1024.0f * t->opt.surface_offset_scale; // m_bounding_radius = length(vec3(0.5)) (testbed_sdf.cu:1424)
 	a.aabb = t->aabb;
 	for (int k = 0; k < 3; ++k) { a.aabb.min[k] -= t->opt.zero_offset; a.aabb.max[k] += t->opt.zero_offset; } // sdf_aabb.inflate(zero_offset)
-	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = t->positions; a.distances = t->distances;
+	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = positions; a.distances = distances;
 	launch_sdf_generate_positions(s, a);
 	t->rng.advance((uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull); // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
-	if (launch_sdf_signed_distance(s, n - a.n_exact, t->positions + (size_t)a.n_exact * 3, t->distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->query())) return fail("sdf ground truth: point sort failed");
+	if (launch_sdf_signed_distance(s, n - a.n_exact, positions + (size_t)a.n_exact * 3, distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->query())) return fail("sdf ground truth: point sort failed");
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 extern "C" int ngp_sdf_train(ngp_sdf* t, void* stream, uint32_t n_steps) {
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n = t->opt.batch_size;
+	// The ground truth of a batch (BVH distance + stab rays: 2.6 ms, a launch as long as its longest walk with most lanes idle) depends on the rng stream and the mesh only, the
+	// training part (0.7 ms) on the batch: inside one call, batch i + 1 is generated on a side stream into the second buffer pair while batch i trains.  Same rng positions, same
+	// batches, same order of the training steps as the serial loop (NGP_SDF_NO_PREFETCH=1); nothing is pending when the call returns, so rng consumers between calls
+	// (calculate_iou) see the reference's order.
+	static const bool no_prefetch = getenv("NGP_SDF_NO_PREFETCH") && atoi(getenv("NGP_SDF_NO_PREFETCH")) != 0;
+	const bool prefetch = !no_prefetch && n_steps > 1 && !g_prof_on;
+	if (prefetch) {
+		if (!t->positions2 && (dev_alloc(&t->positions2, (size_t)n * 3) || dev_alloc(&t->distances2, n))) return 1;
+		if (create_helper_stream(&g_side_stream, false)) return 1;
+		if (!t->ev_free) { HIPCHK(hipEventCreateWithFlags(&t->ev_free, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_batch, hipEventDisableTiming)); }
+	}
+	float* pos[2] = {t->positions, t->positions2}; float* dst[2] = {t->distances, t->distances2};
+	uint32_t cur = 0;
+	bool have = false; // batch i is already in pos[cur] / dst[cur] (generated on the side stream during step i - 1)
 	for (uint32_t i = 0; i < n_steps; ++i) {
-		if (sdf_generate(t, s, n, false)) return 1; // training_prep_sdf with generate_sdf_data_online (the shuffle of train_sdf permutes a full batch: no effect on its sum)
-		if (encmlp_training_step(t->model, s, t->positions, 3, n, t->distances, 1, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
+		if (!have && sdf_generate(t, s, n, false, pos[cur], dst[cur])) return 1; // training_prep_sdf with generate_sdf_data_online (the shuffle of train_sdf permutes a full batch: no effect on its sum)
+		const bool next = prefetch && i + 1 < n_steps;
+		if (next) { // the other pair was last read by step i - 1, the ground-truth scratch by batch i: both are behind this point of the caller's stream
+			HIPCHK(hipEventRecord(t->ev_free, s)); HIPCHK(hipStreamWaitEvent(g_side_stream, t->ev_free, 0));
+			if (sdf_generate(t, g_side_stream, n, false, pos[cur ^ 1u], dst[cur ^ 1u])) return 1;
+			HIPCHK(hipEventRecord(t->ev_batch, g_side_stream));
+		}
+		if (encmlp_training_step(t->model, s, pos[cur], 3, n, dst[cur], 1, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
 		if (ngp_encmlp_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 		++t->training_step;
+		t->batch_positions = pos[cur]; t->batch_distances = dst[cur]; // ngp_sdf_batch_ptrs: the last trained batch
+		have = next;
+		if (next) { HIPCHK(hipStreamWaitEvent(s, t->ev_batch, 0)); cur ^= 1u; }
 	}
 	return 0;
 }
@@ -1170,7 +1199,11 @@ extern "C" int ngp_sdf_iou(ngp_sdf* t, uint32_t n_samples, double* iou_host) {
 	*iou_host = c[5] ? (double)c[4] / (double)c[5] : 0.0;
 	return 0;
 }
-extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distances) { if (positions) *positions = t->positions; if (distances) *distances = t->distances; return 0; }
+extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distances) {
+	if (positions) *positions = t->batch_positions ? t->batch_positions : t->positions;
+	if (distances) *distances = t->batch_distances ? t->batch_distances : t->distances;
+	return 0;
+}
 extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* positions, uint32_t n, float* out) {
 	REQUIRE(t && (n == 0 || (positions && out)), "ngp_sdf_signed_distance: null argument");
 	for (uint32_t done = 0; done < n; done += t->cap) // the survivor list of the stab rays holds t->cap points

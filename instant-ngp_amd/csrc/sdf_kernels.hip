@@ -508,7 +508,7 @@ int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions
 		a.poll_mask = poll_mask;
 		static const bool dist_batch_order = getenv("NGP_SDF_DIST_ORDER") && atoi(getenv("NGP_SDF_DIST_ORDER")) == 0; // ablation: distance items in batch order (calls k .. u)
 		a.dist_reversed = dist_batch_order ? 0u : 1u;
-		static const uint32_t occ = getenv("NGP_SDF_WALK_OCC") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_WALK_OCC")), 1), 6) : 4u; // workgroups per CU (ablation knob; measured: profiles/r05_f4_sdf_walk_occupancy.txt)
+		static const uint32_t occ = getenv("NGP_SDF_WALK_OCC") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_WALK_OCC")), 1), 6) : 2u; // workgroups per CU (ablation knob; round 5 measured 2 / 3 / 4 as equal, profiles/r05_f4_sdf_walk_occupancy.txt; round 6: 2 is 4 - 6 % faster alone and leaves the CUs room for the training step that now runs beside the walks, profiles/r06_ab_sdf_prefetch.txt)
 		const uint32_t lds = a.stack_entries * 256u * 4u + 4u * 64u * 4u, per_cu = std::max(1u, std::min(occ, (160u * 1024u) / (lds + 64u)));
 		// a grid of resident workgroups (no more than there are reservations to make)
 		const uint32_t grid = std::min<uint32_t>(256u * per_cu, (uint32_t)(((uint64_t)33u * a.n_pad / SDF_FETCH_CHUNK + 3u) / 4u) + 8u);
