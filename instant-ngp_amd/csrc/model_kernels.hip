@@ -765,17 +765,15 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 template <int D> struct CornersND { uint32_t idx[1 << D]; float w[1 << D]; };
 // [tcnn grid.h] grid_index + interpolation weights of one level for a D-dimensional position (F = 2 tables)
 template <int D>
-DEV void level_corners_nd(const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x, CornersND<D>& out) {
+DEV void level_corners_nd(const LevelConst& lc, const float* __restrict__ x, CornersND<D>& out) {
 #pragma clang fp contract(off)
-	const float scale = gm->scale[level];
-	const uint32_t res = gm->resolution[level], hs = gm->hashmap_size[level];
+	const float scale = lc.scale;
+	const uint32_t res = lc.res, hs = lc.hs;
 	uint32_t g[D]; float p[D];
-	uint64_t cells = 1; bool dense = true; // dense iff res^D <= hs
 #pragma unroll
 	for (int d = 0; d < D; ++d) {
 		const float q = fmaf(scale, x[d], 0.5f), f = floorf(q);
 		g[d] = (uint32_t)(int)f; p[d] = q - f;
-		cells *= res; if (cells > hs) dense = false;
 	}
 	constexpr int NC = 1 << D;
 #pragma unroll
@@ -786,36 +784,61 @@ DEV void level_corners_nd(const GridMeta* __restrict__ gm, uint32_t level, const
 		for (int d = 0; d < D; ++d) { if ((c & (1 << d)) == 0) { wc *= 1 - p[d]; a[d] = g[d]; } else { wc *= p[d]; a[d] = g[d] + 1; } }
 		asm volatile("" : "+v"(wc)); // keep the fp32 rounding of the weight before the half conversion (see level_corners)
 		uint32_t idx;
-		if (dense) {
+		if (!lc.hashed) {
 			uint32_t stride = 1; idx = 0;
 #pragma unroll
 			for (int d = 0; d < D; ++d) { idx += a[d] * stride; stride *= res; }
-			idx = idx % hs; // [tcnn] the dense index can exceed the (8-aligned) level size only by wrapping at the last cell row
+			// [tcnn] `% hashmap_size`: the dense index exceeds the (8-aligned) level size only at the last cell row (positions on the upper faces): one compare instead of a
+			// 32-bit division per corner (~30 instructions x 128 corners per 3-D sample; round 6)
+			if (idx >= hs) idx %= hs;
 		} else {
 			const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
 			idx = 0;
 #pragma unroll
 			for (int d = 0; d < D; ++d) idx ^= a[d] * primes[d];
-			idx = idx % hs;
+			idx = (hs & (hs - 1u)) == 0u ? idx & (hs - 1u) : idx % hs; // a hashed level has hs = 2^log2_hashmap_size
 		}
 		out.idx[c] = idx; out.w[c] = wc;
 	}
 }
 template <int D>
-DEV h2 level_features2(const __half* __restrict__ table, const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x) {
-	CornersND<D> cr;
-	level_corners_nd<D>(gm, level, x, cr);
-	const uint32_t* t = (const uint32_t*)table + gm->offset[level];
-	constexpr int NC = 1 << D;
-	uint32_t v[NC];
+DEV LevelConst level_const_nd(const GridMeta* __restrict__ gm, uint32_t level) {
+	LevelConst lc; lc.scale = gm->scale[level]; lc.res = gm->resolution[level]; lc.hs = gm->hashmap_size[level]; lc.offset = gm->offset[level];
+	uint64_t cells = 1; bool dense = true; // dense iff res^D <= hs
 #pragma unroll
-	for (int c = 0; c < NC; ++c) v[c] = t[cr.idx[c]];
+	for (int d = 0; d < D; ++d) { cells *= lc.res; if (cells > lc.hs) dense = false; }
+	lc.hashed = !dense;
+	return lc;
+}
+template <int D>
+DEV void level_corners_nd(const GridMeta* __restrict__ gm, uint32_t level, const float* __restrict__ x, CornersND<D>& out) { level_corners_nd<D>(level_const_nd<D>(gm, level), x, out); }
+// (level, hi)-dependent constants of the F = 2 kernels from an LDS table (see fill_level_table; D decides which levels are dense)
+template <int D>
+DEV void fill_level_table_nd(uint4* lct, const GridMeta* __restrict__ gm) {
+	const uint32_t l = threadIdx.x;
+	if (l < 16u) {
+		uint4 v = make_uint4(0u, 0u, 0u, 0u);
+		if (l < gm->n_levels) { const LevelConst lc = level_const_nd<D>(gm, l); v = make_uint4(__float_as_uint(lc.scale), lc.res | (lc.hashed ? 0x80000000u : 0u), lc.hs, lc.offset); }
+		lct[l] = v;
+	}
+}
+template <int D>
+DEV h2 level_features2_lds(const __half* __restrict__ table, const uint4* lct, uint32_t level, const float* __restrict__ x) {
+	const uint4 v = lct[level];
+	LevelConst lc; lc.scale = __uint_as_float(v.x); lc.res = v.y & 0x7fffffffu; lc.hashed = (v.y >> 31) != 0u; lc.hs = v.z; lc.offset = v.w;
+	CornersND<D> cr;
+	level_corners_nd<D>(lc, x, cr);
+	const uint32_t* t = (const uint32_t*)table + lc.offset;
+	constexpr int NC = 1 << D;
+	uint32_t vv[NC];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) vv[c] = t[cr.idx[c]];
 	h2 r = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
 		const _Float16 wh = (_Float16)cr.w[c];
 		const h2 w2 = {wh, wh};
-		r = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, v[c]), r);
+		r = __builtin_elementwise_fma(w2, __builtin_bit_cast(h2, vv[c]), r);
 	}
 	__builtin_amdgcn_sched_barrier(0);
 	return r;
@@ -826,6 +849,8 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_inference(const GridMeta* __r
 		const float* __restrict__ in, uint32_t in_stride, uint32_t n, __half* __restrict__ out, uint32_t out_stride, uint32_t n_out) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
+	__shared__ uint4 s_lct[16];
+	fill_level_table_nd<D>(s_lct, gm);
 	load_frags_to_lds(fw, frags, (int)N_FW_FRAGS);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
@@ -842,7 +867,7 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_inference(const GridMeta* __r
 			h8 e;
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
-				const h2 f = level_features2<D>(table, gm, (uint32_t)(8 * s + 4 * (q >> 1) + 2 * hi + (q & 1)), x);
+				const h2 f = level_features2_lds<D>(table, s_lct, (uint32_t)(8 * s + 4 * (q >> 1) + 2 * hi + (q & 1)), x);
 				e[2 * q] = f[0]; e[2 * q + 1] = f[1];
 			}
 			st.rin[0][s] = e;
@@ -1466,7 +1491,11 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	uint32_t* cursor = a.cursors + ly * a.max_chunks + c;
 	const uint32_t n_raw = *cursor;
 	const uint32_t n = min(n_raw, a.cap);
-	for (uint32_t i = tid; i < E * NF; i += 1024) acc[i] = 0ull;
+	// entries this chunk owns: a dense level's chunk holds entries c, c + NCH, c + 2 NCH, ... < hs -- a few hundred for the coarse levels (the image model's sixteen levels
+	// launch 2048 blocks for 7 10^5 entries), not 2^CL2
+	const uint32_t n_entries = dense ? (hs > c ? (hs - c + (1u << NCH_LOG2) - 1u) >> NCH_LOG2 : 0u) : E;
+	if (n_raw == 0u && !(ADAM && !dense)) return; // nothing listed: the gradients stay what they are (zero: cleared by the optimizer sweep / the step's memset); the cursor is zero already
+	for (uint32_t f = 0; f < NF; ++f) for (uint32_t i = tid; i < n_entries; i += 1024) acc[f * E + i] = 0ull;
 	__syncthreads(); // every thread has read the cursor
 	if (tid == 0) { // the list is empty again for the next step; SPLIT: the second of the two blocks that share it does that
 		uint32_t* done = a.cursor_done + ly * a.max_chunks + c;
@@ -1530,7 +1559,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	} else {
 		typedef typename BinVal<F>::type val_t;
 		val_t* gt = (val_t*)((__half*)a.grid_grad_ + ((size_t)offset + (dense ? (size_t)c : ((size_t)c << CL2))) * F);
-		const uint32_t n_local = dense ? (hs > c ? (hs - c + (1u << NCH_LOG2) - 1u) >> NCH_LOG2 : 0u) : E; // dense: entries c, c + NCH, c + 2 NCH, ... < hs
+		const uint32_t n_local = n_entries;
 		if constexpr (ADAM) if (!dense) {
 			// Fused optimizer step for this chunk (k_optimizer's arithmetic, entry by entry): the gradient the sweep would read is the half-rounded sum -- formed here the
 			// same way and used from registers.  Only a list that overflowed has gradient mass in the table (k_grad_bin's fallback atomics): read and cleared then.
@@ -2426,6 +2455,8 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_train_fwd_bwd(EncTrainArgs a)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	h8* fw = (h8*)smem;
 	h8* bw = fw + N_FW_FRAGS * 64;
+	__shared__ uint4 s_lct[16];
+	fill_level_table_nd<D>(s_lct, a.gm);
 	load_frags_to_lds(fw, a.fw_frags, N_FW_FRAGS);
 	load_frags_to_lds(bw, a.bw_frags, N_BW_FRAGS);
 	__syncthreads();
@@ -2447,7 +2478,7 @@ __global__ void __launch_bounds__(256, 3) k_encmlp_train_fwd_bwd(EncTrainArgs a)
 			h8 e;
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
-				const h2 f = level_features2<D>(a.table, a.gm, (uint32_t)(8 * s + 4 * (q >> 1) + 2 * hi + (q & 1)), x);
+				const h2 f = level_features2_lds<D>(a.table, s_lct, (uint32_t)(8 * s + 4 * (q >> 1) + 2 * hi + (q & 1)), x);
 				e[2 * q] = f[0]; e[2 * q + 1] = f[1];
 			}
 			st.rin[0][s] = e;
@@ -2640,16 +2671,18 @@ k_encmlp_wgrad(const ngp_half* __restrict__ fw_frags, const ngp_half* __restrict
 		for (int i = threadIdx.x; i < 4 * 16 * 64; i += blockDim.x) dstp[half * 4 * 16 * 64 + i] = red[i];
 	}
 }
-__global__ void __launch_bounds__(256) k_encmlp_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
-	__shared__ float sm[4][64];
+// (16 wavefronts per 64 elements, each summing every 16th partial, then a fixed-order tree -- the shape of k_wgrad_reduce; round 6: four wavefronts walked 64 dependent loads each, 17 us)
+__global__ void __launch_bounds__(1024) k_encmlp_wgrad_reduce(const float* __restrict__ partials, uint32_t n_partials, __half* __restrict__ mlp_grad) {
+	__shared__ float sm[16][64];
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	const uint32_t e = blockIdx.x * 64 + lane; // element of [tile][r][lane]
 	float s = 0.f;
-	for (uint32_t g = wid; g < n_partials; g += 4) s += partials[(size_t)g * (N_EDW_TILES * 16 * 64) + e];
+	for (uint32_t g = wid; g < n_partials; g += 16) s += partials[(size_t)g * (N_EDW_TILES * 16 * 64) + e];
 	sm[wid][lane] = s;
 	__syncthreads();
 	if (wid != 0) return;
-	s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+	s = (((sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane])) + ((sm[4][lane] + sm[5][lane]) + (sm[6][lane] + sm[7][lane])))
+	  + (((sm[8][lane] + sm[9][lane]) + (sm[10][lane] + sm[11][lane])) + ((sm[12][lane] + sm[13][lane]) + (sm[14][lane] + sm[15][lane])));
 	const int t = e / (16 * 64), r = (e / 64) % 16;
 	int layer_off, R, C, it, kt;
 	if (t < 2) { layer_off = 0; R = 64; C = 32; it = t; kt = 0; }
@@ -2828,7 +2861,7 @@ void launch_encmlp_train(hipStream_t s, const EncTrainArgs& a, uint32_t n_pos_di
 		else hipLaunchKernelGGL((k_encmlp_train_fwd_bwd<3, false>), dim3(grid_dim), dim3(256), lds, s, a);
 	}
 	hipLaunchKernelGGL(k_encmlp_wgrad, dim3(n_partials), dim3(256), lds, s, a.fw_frags, a.bw_frags, a.n, (const uint2*)a.dy_stash, (const uint4*)a.enc_stash, wgrad_partials);
-	hipLaunchKernelGGL(k_encmlp_wgrad_reduce, dim3(N_EDW_TILES * 16), dim3(256), 0, s, wgrad_partials, n_partials, (__half*)mlp_grad);
+	hipLaunchKernelGGL(k_encmlp_wgrad_reduce, dim3(N_EDW_TILES * 16), dim3(1024), 0, s, wgrad_partials, n_partials, (__half*)mlp_grad);
 }
 void launch_encode_only(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* pos, uint32_t stride, uint32_t n, ngp_half* out, uint32_t F) {
 	if (n == 0) return;
