@@ -428,11 +428,15 @@ int ngp_allreduce_counters(ngp_nerf*, void* stream);
  *     sums the MLP gradients [0, n_mlp) over all ranks and each rank's pieces over all ranks (reduce-scatter), calls finish_sharded(phase 0) = the local Adam step,
  *     all-gathers the half parameters of the pieces, and calls finish_sharded(phase 1) = foreign EMA + the rest of ngp_nerf_train_finish.
  *   ngp_nerf_dp_gather_state: COLLECTIVE -- the fp32 master parameters, Adam moments and step counters of every rank's own pieces to all ranks (only the half parameters
- *     and the inference copy are kept current everywhere); call on every rank before reading parameters / serialising a sharded run. */
+ *     and the inference copy are kept current everywhere); call on every rank before reading parameters / serialising a sharded run.  Until then
+ *     ngp_nerf_dp_state_stale() is 1 and ngp_model_get_params_host / ngp_model_serialize_host FAIL (they would hand out stale numbers for the foreign pieces); leaving the
+ *     sharded step (ngp_nerf_dp_set_sharded(t, 0), ngp_comm_destroy -- called on every rank) gathers first. */
 int ngp_nerf_dp_set_sharded(ngp_nerf*, int on);
 int ngp_nerf_dp_layout(ngp_nerf*, uint64_t begin[2], uint64_t end[2]);
 int ngp_nerf_train_finish_sharded(ngp_nerf*, void* stream, int phase);
 int ngp_nerf_dp_gather_state(ngp_nerf*, void* stream);
+int ngp_nerf_dp_state_stale(const ngp_nerf*);
+int ngp_nerf_dp_state_gathered(ngp_nerf*); /* callers that run their own collectives (ngp_nerf_train_finish_sharded): the optimizer state of every piece has been exchanged */
 /* Three uint32 {measured_before_compaction, measured, this rank's loss sum in units of 2^-24} to all-reduce(sum) across ranks (8e):
  * every rank then derives the same next rays_per_batch and reports the loss of the union batch. */
 int ngp_nerf_counter_ptrs(ngp_nerf*, uint32_t** counters3);

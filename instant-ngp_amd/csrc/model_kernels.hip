@@ -546,66 +546,8 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 	}
 }
 
-// ---------------------------------------------------------------------------------------------
-// Level-per-XCD encoding of the round-0 tiles (round 4).  K2 is bound by what one CU can keep in flight beyond its L1: every 8-byte entry of a fine hashed level arrives
-// as a 128-byte line, a wavefront's gathers are ~300 such lines, and with all eight levels behind every XCD's 4 MiB L2 (23 MB of tables) they are served by the fabric
-// (Infinity Cache / HBM latency): 3.1 M lines per step at the rate the L1s can hold misses open.  Here ONE level is gathered per XCD: a workgroup reads the id of the XCD
-// it runs on (HW_REG_XCC_ID) and takes chunks of tiles of THAT XCD's level from the level's work counter, so the level's 4 MB table becomes resident in the XCD's own L2 and
-// the same misses are L2 hits at a quarter of the latency.  The two finest levels get two XCDs each... (see XCD_LEVEL).  A workgroup whose level is exhausted steals
-// chunks of the other levels (dense ones first: their tables are small), so the result never depends on where the dispatcher puts workgroups -- placement is a matter of
-// speed only.  Output: LEVEL-MAJOR, 8 bytes at [level][sample] -- a tile's 16 samples of one level are one 128-byte line written by one wavefront (the sample-major stash
-// layout would have eight XCDs write 8-byte pieces of every line: measured 0.16 ms for this kernel, profiles/r04_microbench_k2_xcd_encode.log); the lazy K2 then LOADS the
-// first tile of every ray (nearly all evaluated samples: a ray ends after ~10 compacted samples) with four coalesced 8-byte loads per lane and gathers only continuation
-// tiles itself.
-// Same level_features4 arithmetic (corner order, half fma chain): bit-identical encodings.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t XCD_CHUNK_TILES = 64; // tiles per work item (<= 1024 samples at 16 samples per tile)
-__constant__ uint32_t XCD_LEVEL[8] = {7, 6, 5, 4, 7, 6, 5, 3}; // preferred level of XCD x for L = 8 (block b usually runs on XCD b % 8): the three finest levels on two XCDs each
-template <uint32_t TW>
-__global__ void __launch_bounds__(256) k_encode_tiles_xcd(const GridMeta* __restrict__ gm, const __half* __restrict__ table, const float* __restrict__ in, uint32_t in_stride,
-		const uint4* __restrict__ tiles, const uint32_t* __restrict__ n_tiles_ptr, uint32_t tile_cap, uint2* __restrict__ enc_lv /* [level][sample] */, size_t enc_lv_stride /* samples per level */,
-		uint32_t* __restrict__ work /* [n_levels] chunk counters + [16] = exit ticket; all zero */, uint32_t n_levels, uint32_t by_block_index) {
-	__shared__ uint32_t s_chunk;
-	uint32_t xcc;
-	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-	xcc = by_block_index ? blockIdx.x & 7u : xcc & 7u;
-	const uint32_t n_tiles = min(*n_tiles_ptr, tile_cap);
-	const uint32_t n_chunks = (n_tiles + XCD_CHUNK_TILES - 1) / XCD_CHUNK_TILES;
-	const uint32_t pref = n_levels == 8 ? XCD_LEVEL[xcc] : xcc % n_levels;
-	// order in which this workgroup serves the levels: its own, then the coarse (cheap) ones, then the rest from fine to coarse
-	for (uint32_t k = 0; k < n_levels; ++k) {
-		uint32_t level;
-		if (k == 0) level = pref;
-		else { // k-th level of the sequence 0, 1, 2, ..., n_levels - 1 with `pref` removed
-			level = k - 1; if (level >= pref) ++level;
-		}
-		const LevelConst lc = level_const_uniform(gm, level);
-		uint2* __restrict__ dst = enc_lv + (size_t)level * enc_lv_stride;
-		for (;;) {
-			__syncthreads();
-			if (threadIdx.x == 0) s_chunk = atomicAdd(&work[level], 1u);
-			__syncthreads();
-			const uint32_t chunk = s_chunk;
-			if (chunk >= n_chunks) break;
-			for (uint32_t q = 0; q < XCD_CHUNK_TILES * TW / 256u; ++q) {
-				const uint32_t p = q * 256u + threadIdx.x, tile = chunk * XCD_CHUNK_TILES + p / TW, j = p % TW;
-				if (tile >= n_tiles) continue;
-				const uint4 d = tiles[tile];
-				if (j >= d.y) continue;
-				const uint32_t sample = d.x + j;
-				const float* pp = in + (size_t)sample * in_stride;
-				const h4 f = level_features4<false>(table, lc, pp[0], pp[1], pp[2], (int)(threadIdx.x & 63u));
-				dst[sample] = __builtin_bit_cast(uint2, f);
-			}
-		}
-	}
-	// the last workgroup to leave zeroes the counters for the next step (no memset launch)
-	__syncthreads();
-	// (thread 0's last -- failing -- chunk request of every level has RETURNED before its ticket is issued, and the counters are only ever touched by device-scope atomics:
-	// no fence needed; an agent-scope release per workgroup would cost ~25 us here, MI355X_MICROARCH.md)
-	if (threadIdx.x == 0 && atomicAdd(&work[16], 1u) == gridDim.x - 1u) { for (uint32_t l = 0; l < n_levels; ++l) atomicExch(&work[l], 0u); atomicExch(&work[16], 0u); }
-}
-
+// (Round 4's level-per-XCD encoding stage in front of the lazy K2 -- k_encode_tiles_xcd: one hash-grid level per XCD, so that its 4 MB table stays in that XCD's L2 -- was
+// measured at 0.105 ms against 0.120 ms for the whole fused K2, profiles/r04_microbench_k2_xcd_encode.log, and removed in round 6; git history has the kernel.)
 // ---------------------------------------------------------------------------------------------
 // Lazy (front-to-back) K2.  The reference evaluates the network on EVERY marched sample and then discards all samples behind
 // the point where a ray's transmittance drops below 1e-4 (compute_loss_kernel_train_nerf: `if (T < EPSILON) break`).  Samples
@@ -674,13 +616,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		if (__ballot(valid) == 0ull) break;
 		FwdState<1> st;
 		const float* p = in + (size_t)sample * in_stride;
-		if (F == 4 && la.enc_pre && first_tile) { // the round-0 tiles were encoded level by level on the XCDs (k_encode_tiles_xcd): four coalesced 8-byte loads instead of 32 gathers
-			uint2 q[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) q[u] = valid ? la.enc_lv[(size_t)(2 * u + hi) * la.enc_lv_stride + sample] : make_uint2(0u, 0u); // levels hi, 2 + hi (k-step 0), 4 + hi, 6 + hi (k-step 1)
-			st.enc[0][0] = __builtin_bit_cast(h8, make_uint4(q[0].x, q[0].y, q[1].x, q[1].y));
-			st.enc[0][1] = __builtin_bit_cast(h8, make_uint4(q[2].x, q[2].y, q[3].x, q[3].y));
-		} else if constexpr (DEPTH != 0 && F == 4) encode_sample_lds<DEPTH>(s_lct, table, p[0], p[1], p[2], hi, st.enc[0]);
+		if constexpr (DEPTH != 0 && F == 4) encode_sample_lds<DEPTH>(s_lct, table, p[0], p[1], p[2], hi, st.enc[0]);
 		else encode_sample<F, false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
 		if (la.enc_out && valid) { // for T1 (EncStashIn): this lane's half of the sample's encoding, 32 contiguous bytes
 			uint4* e = la.enc_out + (size_t)sample * 4 + (uint32_t)hi * 2;
@@ -2803,14 +2739,6 @@ void launch_inference(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, co
 		else { if (occ4) NGP_LAUNCH_INF(false, false, 4, N_FW_FRAGS * 1024, 4, 2); else NGP_LAUNCH_INF(false, false, 3, N_FW_FRAGS * 1024, 4, 2); }
 	}
 #undef NGP_LAUNCH_INF
-}
-void launch_encode_tiles_xcd(hipStream_t s, const GridMeta* gm, const ngp_half* grid, const float* in, uint32_t in_stride, const uint4* tiles, const uint32_t* n_tiles_ptr, uint32_t tile_cap,
-		uint32_t tile_w, uint2* enc_lv, size_t enc_lv_stride, uint32_t* work, uint32_t n_levels) {
-	static const uint32_t bpc = getenv("NGP_XCD_ENCODE_BLOCKS_PER_CU") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_XCD_ENCODE_BLOCKS_PER_CU")), 1), 8) : 2u;
-	static const uint32_t by_index = getenv("NGP_XCD_ENCODE_BY_BLOCK_INDEX") && atoi(getenv("NGP_XCD_ENCODE_BY_BLOCK_INDEX")) != 0; // ablation: level from blockIdx % 8 instead of the XCC id
-	const uint32_t g = (uint32_t)num_cus() * bpc;
-	if (tile_w == 16) hipLaunchKernelGGL((k_encode_tiles_xcd<16>), dim3(g), dim3(256), 0, s, gm, (const __half*)grid, in, in_stride, tiles, n_tiles_ptr, tile_cap, enc_lv, enc_lv_stride, work, n_levels, by_index);
-	else hipLaunchKernelGGL((k_encode_tiles_xcd<32>), dim3(g), dim3(256), 0, s, gm, (const __half*)grid, in, in_stride, tiles, n_tiles_ptr, tile_cap, enc_lv, enc_lv_stride, work, n_levels, by_index);
 }
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
 		ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la_in, uint32_t F) {

@@ -268,6 +268,10 @@ struct ngp_model {
 	bool adam_fused_pending = false; uint64_t adam_sweep_end = 0, last_sweep_params = 0; // this step's k_grad_accumulate has already applied the optimizer to the hashed levels: the sweep covers [0, adam_sweep_end) only
 	float* dextra_out = nullptr; // this training step also leaves dL/d(extra dims) per sample here (n x n_extra_dims floats; set by the callers that want it)
 	bool grads_clean = true; // the hash-grid part of `grads` is all zero (after creation / after an optimizer sweep that zeroed it)
+	// sharded data-parallel step: this rank's fp32 masters / Adam moments / step counters of the pieces OTHER ranks own are out of date (only the half parameters and the
+	// inference copy travel each step).  Set by the sharded optimizer step, cleared by ngp_nerf_dp_gather_state (a collective); while set, the calls that would hand out or
+	// continue from those arrays fail instead of returning stale numbers
+	bool dp_state_stale = false;
 };
 
 // pcg32(initstate, initseq = 1) [tcnn pcg32.h]
@@ -432,8 +436,10 @@ extern "C" int ngp_model_set_params_host(ngp_model* m, const float* p, uint64_t 
 	HIPCHK(hipDeviceSynchronize());
 	return 0;
 }
+static const char* kStaleMsg = "the sharded data-parallel step leaves this rank's fp32 masters / Adam state of the other ranks' pieces out of date: call ngp_nerf_dp_gather_state (Testbed.dp_gather_state) on EVERY rank first";
 extern "C" int ngp_model_get_params_host(ngp_model* m, float* p, uint64_t n) {
 	REQUIRE(n == m->n_params, "get_params: size mismatch");
+	REQUIRE(!m->dp_state_stale, kStaleMsg);
 	HIPCHK(hipMemcpy(p, m->master, n * 4, hipMemcpyDeviceToHost));
 	return 0;
 }
@@ -1270,6 +1276,7 @@ extern "C" uint64_t ngp_model_serialized_size(const ngp_model* m, int with_optim
 }
 extern "C" int ngp_model_serialize_host(ngp_model* m, void* buf, uint64_t size, int with_optimizer) {
 	REQUIRE(size >= ngp_model_serialized_size(m, with_optimizer), "serialize: buffer too small");
+	REQUIRE(!m->dp_state_stale, kStaleMsg);
 	SerHeader h = {0x4E475031u, 1, m->n_params, m->step, (uint32_t)(with_optimizer != 0), m->lr, 0};
 	char* p = (char*)buf;
 	memcpy(p, &h, sizeof(h)); p += sizeof(h);
@@ -1513,7 +1520,6 @@ struct ngp_nerf {
 	uint32_t k2_rounds = 1, k2_tile_w = 16; // rounds 1 = one launch, every wavefront follows its rays front to back (default); 2..8 = list-driven rounds (round r < last evaluates samples [r w, r w + w) of the rays that are still transparent, the last round the rest).  Tile width 16: two rays per wavefront, 383k instead of 556k evaluations per step.  Measured per step (profiles/r02_microbench_k2.log, r02_microbench_final.log): 3 rounds x 32 = 0.171 ms, 1 x 32 = 0.131 ms, 1 x 16 = 0.112 ms.  NGP_K2_ROUNDS / NGP_K2_TILE override.
 	float* k2_T = nullptr; uint4* k2_tiles = nullptr; uint32_t k2_tile_cap = 0; // lazy K2 round B tile descriptors
 	float* ray_targets = nullptr; // per active ray: {rgbtarget, background} from k1_setup for K3
-	bool k2_xcd_encode = false; uint32_t* xcd_work = nullptr; uint2* k2_enc_lv = nullptr; // k_encode_tiles_xcd: work counters (zero between launches), level-major encodings of the round-0 tiles
 	uint4* k2_enc = nullptr; uint32_t* src_index = nullptr; bool k2_enc_valid = false; // K2's per-sample encodings and K3's row -> sample map for T1 (EncStashIn); valid: written by this step's K2 / K3
 	float* coords = nullptr; ngp_half* mlp_out = nullptr; float* coords_compacted = nullptr; ngp_half* dloss = nullptr;
 	RenderRay* r_rays = nullptr; uint64_t* r_masks = nullptr; uint32_t* r_alive = nullptr; uint32_t* r_n_alive = nullptr; uint32_t* r_n_inf = nullptr; float* r_coords = nullptr; ngp_half* r_out = nullptr;
@@ -1560,7 +1566,6 @@ extern "C" int ngp_nerf_create(ngp_model* model, const ngp_nerf_options* o, ngp_
 	t->density_grid_rng = make_rng(t->rng.next_uint()); // testbed.cu:4178
 	const uint32_t n_cells = GRID_N_CELLS * (o->max_cascade + 1);
 	const uint32_t B = o->target_batch_size, max_samples = B * 16;
-	if (const char* e = getenv("NGP_K2_XCD_ENCODE")) t->k2_xcd_encode = atoi(e) != 0;
 	if (const char* e = getenv("NGP_K2_ROUNDS")) t->k2_rounds = std::min<uint32_t>(std::max<int>(atoi(e), 1), K2_ROUNDS);
 	if (const char* e = getenv("NGP_K2_TILE")) t->k2_tile_w = atoi(e) == 32 ? 32u : atoi(e) == 8 ? 8u : 16u;
 	if (t->k2_tile_w == 8) t->k2_rounds = 1;
@@ -1613,7 +1618,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->xcd_work, (void*)t->k2_enc_lv, (void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v, (void*)t->extra_iter, (void*)t->dextra}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->error_map, (void*)t->cdf_x_cond_y, (void*)t->cdf_y, (void*)t->cdf_img, (void*)t->k2_enc, (void*)t->src_index, (void*)t->extra_dims, (void*)t->extra_grad, (void*)t->extra_m, (void*)t->extra_v, (void*)t->extra_iter, (void*)t->dextra}) if (p) (void)hipFree(p);
 	for (void* p : t->owned_pixels) (void)hipFree(p);
 	delete t;
 }
@@ -1872,16 +1877,6 @@ static int nerf_step_impl(ngp_nerf* t, void* stream, int phase, bool global_coun
 		const bool two_pass_k3 = (g_debug_flags & DBG_K3_TWO_PASS) && !(o.depth_supervision_lambda > 0.f) && !error_map_wanted(t) && !t->error_cycle_open;
 		t->k2_enc_valid = t->model->gm.F == 4 && t->model->cfg.n_hidden_layers_rgb == 2 && !(g_debug_flags & DBG_T1_NO_K2_STASH) && !two_pass_k3;
 		la.enc_out = t->k2_enc_valid ? t->k2_enc : nullptr;
-		// ABLATION (off by default; NGP_K2_XCD_ENCODE=1 when the trainer is created): level-per-XCD encoding of the first tile of every ray (nearly all evaluated samples),
-		// then K2 loads instead of gathering them.  Built and measured in round 4 (VERDICT r3 item 4 i): the encoding stage alone takes 0.105 ms against 0.120 ms for the
-		// whole fused K2 -- a 4 MB level does not stay resident in a 4 MiB L2 next to the streamed coordinates (TCC hit rate 66 %, still 1 M fabric lines per launch),
-		// profiles/r04_microbench_k2_xcd_encode.log.  Same encodings bit for bit (tests/test_gpu_train.py::test_xcd_encode_ablation_is_bit_identical).
-		if (t->k2_xcd_encode && t->model->gm.F == 4 && t->k2_rounds == 1 && (t->k2_tile_w == 16 || t->k2_tile_w == 32) && t->model->gm.n_levels <= 16) {
-			if (!t->xcd_work) { if (dev_alloc(&t->xcd_work, 32) || dev_alloc(&t->k2_enc_lv, (size_t)t->model->gm.n_levels * max_samples)) return 1; HIPCHK(hipMemsetAsync(t->xcd_work, 0, 32 * 4, s)); }
-			ProfScope ps2(P_K2_ENCODE_XCD, s);
-			launch_encode_tiles_xcd(s, t->model->gm_dev, model_ptrs(t->model, false).grid, t->coords, 7, t->k2_tiles, &c->ray_counter, t->k2_tile_cap, t->k2_tile_w, t->k2_enc_lv, max_samples, t->xcd_work, t->model->gm.n_levels);
-			la.enc_pre = 1; la.enc_lv = t->k2_enc_lv; la.enc_lv_stride = max_samples;
-		}
 		launch_inference_lazy(s, t->model->gm_dev, model_ptrs(t->model, false), t->coords, 7, t->max_rays, max_samples, t->mlp_out, 4, 4, la, t->model->gm.F);
 	  } else {
 	  t->k2_enc_valid = false; // eager K2 (ablation): T1 gathers
@@ -2038,8 +2033,10 @@ constexpr int kNcclUint32 = 3, kNcclHalf = 6, kNcclSum = 0; // ncclDataType_t / 
 // Same bytes on the wire as the all-reduce (a ring all-reduce IS reduce-scatter + all-gather), less of them exposed, 1/G of the Adam state touched per rank.
 // Per-rank optimizer state (fp32 master, Adam moments, step counters) of the FOREIGN pieces goes stale: ngp_nerf_dp_gather_state (collective) refreshes it before a
 // snapshot / parameter read-back.
+extern "C" int ngp_nerf_dp_gather_state(ngp_nerf* t, void* stream);
 static int dp_setup_sharded(ngp_nerf* t, bool on) {
 	ngp_model* m = t->model;
+	if (m->dp_state_stale && t->dp_sharded && t->comm) { if (ngp_nerf_dp_gather_state(t, nullptr)) return 1; } // leaving (or re-planning) the sharded step continues from every rank's masters: a collective, like the calls that get here (ngp_comm_init / _destroy, ngp_nerf_dp_set_sharded on every rank)
 	t->dp_sharded = false; m->dp_split_level = 0;
 	if (!on) return 0;
 	const uint32_t W = t->opt.world_size, L = m->gm.n_levels, F = m->gm.F;
@@ -2068,10 +2065,12 @@ extern "C" int ngp_nerf_dp_layout(ngp_nerf* t, uint64_t begin[2], uint64_t end[2
 // this step's Adam on the replicated MLP and on this rank's pieces (their summed gradients are in place)
 static int dp_optimizer_local(ngp_nerf* t, hipStream_t s) {
 	ngp_model* m = t->model;
+	// (checked BEFORE the step counter moves: a refused step must not skew the EMA debiasing / the decay schedule of the steps behind it)
+	REQUIRE(65535.0f * std::log(m->cfg.beta1) < -18.f && 65535.0f * std::log(m->cfg.beta2) < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
 	++m->step;
 	AdamArgs a = make_adam_args(m, t->opt.loss_scale, m->step);
-	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
 	t->dp_adam = a;
+	if (t->opt.world_size > 1) m->dp_state_stale = true;
 	ProfScope ps(P_OPTIMIZER, s);
 	a.range_begin = 0; a.n_params = m->n_mlp; launch_optimizer_step(s, a);
 	for (int b = 0; b < 2; ++b) {
@@ -2212,8 +2211,12 @@ extern "C" int ngp_nerf_dp_gather_state(ngp_nerf* t, void* stream) {
 	}
 	RCCLCHK(g_rccl.GroupEnd());
 	HIPCHK(hipStreamSynchronize(s));
+	m->dp_state_stale = false;
 	return 0;
 }
+extern "C" int ngp_nerf_dp_state_stale(const ngp_nerf* t) { return t && t->model && t->model->dp_state_stale ? 1 : 0; }
+// for callers that run the collectives themselves (ngp_nerf_train_finish_sharded): they have all-gathered master / Adam m / v / step counters of every piece (ngp_model_param_ptrs + the layout)
+extern "C" int ngp_nerf_dp_state_gathered(ngp_nerf* t) { REQUIRE(t, "null trainer"); t->model->dp_state_stale = false; return 0; }
 
 static int error_map_allreduce(ngp_nerf* t, hipStream_t s, size_t n) {
 	REQUIRE(t->comm, "error-proportional sampling under data parallelism needs the in-library communicator (ngp_comm_init): the ranks' error maps are summed before the CDFs are built");

@@ -184,13 +184,8 @@ struct K2LazyArgs {
 	int density_activation; float dt_unwarp_scale, dt_unwarp_offset; // dt = warped * scale + offset (unwarp_dt)
 	uint32_t round, n_rounds;
 	uint32_t tile_w;                // samples per tile: 16 (two rays' tiles per wavefront) or 32
-	uint32_t enc_pre = 0;           // enc_lv holds the encodings of the round-0 tiles (launch_encode_tiles_xcd), level-major: K2 loads them instead of gathering
-	const uint2* enc_lv = nullptr; size_t enc_lv_stride = 0;
 	uint4* enc_out = nullptr;       // optional: the encoding of every evaluated sample, 4 x 16 bytes per sample at [sample][hi][k-step] (the B-operand registers of its two lanes), for T1
 };
-// level-per-XCD encoding of K1's round-0 tile list into a level-major buffer [level][sample] of 8-byte entries (model_kernels.hip k_encode_tiles_xcd); `work`: 17 zeroed words, left zeroed
-void launch_encode_tiles_xcd(hipStream_t s, const GridMeta* gm_dev, const ngp_half* grid, const float* in, uint32_t in_stride, const uint4* tiles, const uint32_t* n_tiles_ptr, uint32_t tile_cap,
-	uint32_t tile_w, uint2* enc_lv, size_t enc_lv_stride, uint32_t* work, uint32_t n_levels);
 void launch_inference_lazy(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t max_rays, uint32_t max_samples,
 	ngp_half* out, uint32_t out_stride, uint32_t dir_offset, const K2LazyArgs& la, uint32_t n_features = 4);
 void launch_inference(hipStream_t s, const GridMeta* gm_dev, const ModelPtrs& mp, const float* in, uint32_t in_stride, uint32_t n_max, const uint32_t* n_ptr,

@@ -200,12 +200,17 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("light_dir", &Nerf::light_dir)                                                                                                      // testbed.h:871 (the reference sets it from its GUI only; bound here so that scripts can relight)
 		.def("set_rendering_extra_dims_from_training_view", [](Nerf& n, int v) { n.rendering_extra_dims_from_training_view = v; })                           // :735-737
 		.def("set_rendering_extra_dims", [](Nerf& n, const std::vector<float>& v) { n.rendering_extra_dims = v; n.rendering_extra_dims_from_training_view = -1; }) // :739
-		.def("get_rendering_extra_dims", [](Nerf& n) {                                                                                                     // :741
-				if (n.rendering_extra_dims_from_training_view >= 0) return n.training.owner->get_extra_dims(n.rendering_extra_dims_from_training_view);
-				if (!n.rendering_extra_dims.empty()) return n.rendering_extra_dims;
+		.def("get_rendering_extra_dims", [](Nerf& n) {                                                                                                     // :741 -> get_rendering_extra_dims_cpu, testbed_nerf.cu:3750
 				if (n.training.dataset.n_extra_dims() == 0) return std::vector<float>{};
-				(void)n.training.owner->get_extra_dims(0);            // (creates the trainer, which runs reset_extra_dims)
-				return n.rendering_extra_dims_default; })               // the copy of image 0's INITIAL dims (testbed_nerf.cu:3679-3682), not its trained ones
+				std::vector<float> v;
+				if (n.rendering_extra_dims_from_training_view >= 0) v = n.training.owner->get_extra_dims(n.rendering_extra_dims_from_training_view);
+				else if (!n.rendering_extra_dims.empty()) v = n.rendering_extra_dims;
+				else { (void)n.training.owner->get_extra_dims(0); v = n.rendering_extra_dims_default; } // (creates the trainer, which runs reset_extra_dims); the copy of image 0's INITIAL dims (testbed_nerf.cu:3679-3682), not its trained ones
+				if (n.training.dataset.has_light_dirs) { // testbed_nerf.cu:3697-3706: with light directions the first three dims are warp_direction(normalize(light_dir)) -- what the renderer uses
+					const float len = std::sqrt(n.light_dir[0] * n.light_dir[0] + n.light_dir[1] * n.light_dir[1] + n.light_dir[2] * n.light_dir[2]);
+					for (size_t k = 0; k < 3 && k < v.size(); ++k) v[k] = (n.light_dir[k] / len + 1.0f) * 0.5f;
+				}
+				return v; })
 		.def("find_closest_training_view", [](Nerf& n, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
 				if (a.size() < 12) throw std::runtime_error{"find_closest_training_view expects a 3x4 matrix"};
 				std::array<float, 12> mm; for (int k = 0; k < 12; ++k) mm[k] = a.data()[k];
@@ -237,6 +242,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("reset", &Testbed::reset_network).def("reset_network", &Testbed::reset_network)
 		.def("load_snapshot", &Testbed::load_snapshot).def("_nerf_dataset_to_json", &Testbed::nerf_dataset_to_json_text)       // test hooks: snapshot["nerf"]["dataset"] as JSON text (json_binding.h to_json / from_json), host only
 		.def("_nerf_dataset_from_json", &Testbed::nerf_dataset_from_json_text)
+		.def("dp_gather_state", &Testbed::dp_gather_state, "data parallel (sharded step): gather every rank's optimizer state on all ranks -- a collective, call on every rank before save_snapshot(path, True)")
 		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())
 		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>())

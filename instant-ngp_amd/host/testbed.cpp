@@ -1344,11 +1344,19 @@ mini_json::Value Testbed::dataset_to_json() const {
 	return jd;
 }
 
+void Testbed::dp_gather_state() { // COLLECTIVE (every rank): the optimizer state of every rank's own pieces to all ranks -- before save_snapshot(path, True) / parameter read-backs of a sharded run
+	ensure_trainer();
+	NGP_CHECK(ngp_nerf_dp_gather_state(m_nerf, nullptr));
+}
+
 void Testbed::save_snapshot(const std::string& path, bool include_optimizer_state) {
 	ensure_trainer();
 	// data parallel (sharded step): the fp32 master parameters / Adam state of the other ranks' pieces are gathered first -- a COLLECTIVE: with an optimizer state every rank
 	// calls save_snapshot (each may write its own file); the half / inference parameters (all a snapshot without optimizer state holds) are current on every rank anyway
-	if (m_world_size > 1 && m_comm_up && include_optimizer_state) NGP_CHECK(ngp_nerf_dp_gather_state(m_nerf, nullptr));
+	// (round 6: no longer gathered implicitly -- rank 0 saving alone, the usual pattern, would block forever in the all-gather; the caller makes the collective explicit)
+	if (include_optimizer_state && ngp_nerf_dp_state_stale(m_nerf))
+		throw std::runtime_error{"save_snapshot with optimizer state under the sharded data-parallel step: this rank holds stale fp32 masters / Adam moments for the other ranks' pieces. "
+			"Call testbed.dp_gather_state() on EVERY rank first (a collective), then save on the ranks that should write a file."};
 	Value root = m_network_config.type == Value::Object ? m_network_config : jobj();
 	Value snap = jobj();
 	// ---- tcnn Trainer::serialize ----

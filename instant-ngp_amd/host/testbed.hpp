@@ -158,6 +158,7 @@ public:
 	const mini_json::Value& network_config() const { return m_network_config; }
 	void reset_network();                                           // testbed.cu:4160
 	void load_snapshot(const std::string& path);                    // testbed.cu:5357
+	void dp_gather_state();
 	void save_snapshot(const std::string& path, bool include_optimizer_state = false); // testbed.cu:5288
 	bool frame();                                                   // testbed.cu:3908 (headless: train one step)
 	void train(uint32_t batch_size);                                // testbed.cu:4561

@@ -162,6 +162,20 @@ def scene_aabb(aabb_scale=1):
 _lib = None
 
 
+_hooks = None
+
+
+def load_testhooks():
+    """dlopen libngp_hip_testhooks.so: the device code's leaf functions compiled for the host (include/ngp_hip_host_hooks.h) -- test infrastructure, not part of the product library"""
+    global _hooks
+    if _hooks is None:
+        path = os.path.join(HERE, "libngp_hip_testhooks.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _hooks = C.CDLL(path)
+    return _hooks
+
+
 def load_hip():
     """dlopen libngp_hip.so (built in-tree by __graft_entry__.build()). Raises if it is missing."""
     global _lib

@@ -76,6 +76,9 @@ API void ora_read_rgba_byte(const float* uv, const int32_t* res, const void* pix
 API float ora_read_depth(const float* uv, const int32_t* res, const float* depth) { return read_depth({uv[0], uv[1]}, res, depth); }
 
 // ---- model -----------------------------------------------------------------------------------
+API void ora_set_mlp_half_accumulate(int on) { mlp_half_accumulate() = on; }
+API int ora_get_mlp_half_accumulate() { return mlp_half_accumulate(); }
+API float ora_mlp_dot(uint32_t n, const uint16_t* a, const uint16_t* b) { return mlp_dot(n, [&](uint32_t k) { return h2f(a[k]); }, [&](uint32_t k) { return h2f(b[k]); }); } // test hook: the accumulator switch's arithmetic
 API int ora_model_create(const ngp_model_config* cfg, uint64_t seed, void** out) { TRY(*out = new Model(*cfg, seed)) }
 API void ora_model_destroy(void* m) { delete (Model*)m; }
 API uint64_t ora_model_n_params(void* m) { return ((Model*)m)->n_params; }

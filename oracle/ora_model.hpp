@@ -135,6 +135,26 @@ struct MlpShape {
 	uint32_t n_params() const { return offset(n_layers()); }
 };
 
+// Appendix-A switch: the precision of the matrix-multiply ACCUMULATOR.
+//   0 (default): fp32 accumulation over the whole contraction, one rounding to half per output -- what this repository's MFMA kernels do (v_mfma_f32_*_f16);
+//   1: tcnn's FullyFusedMLP keeps its WMMA accumulator fragments in __half (wmma::fragment<accumulator, 16, 16, 16, __half>): every 16-wide k-step is one
+//      mma_sync whose result is rounded to half -- modelled as acc = half(float(acc) + sum of the step's 16 products in fp32).
+// tcnn's source is absent from this mount, so which one the CUDA build runs cannot be settled here; the switch puts a number on the difference
+// (tools/ab_half_accumulate.py): it is a process-wide test switch of the ORACLE only (ora_set_mlp_half_accumulate / ORA_MLP_HALF_ACCUMULATE).
+inline int& mlp_half_accumulate() { static int v = [] { const char* e = getenv("ORA_MLP_HALF_ACCUMULATE"); return e ? atoi(e) : 0; }(); return v; }
+// dot product of `n` half pairs under the selected accumulator precision (n a multiple of 16 in every layer of the models here; a tail is one more step)
+template <typename FA, typename FB>
+inline float mlp_dot(uint32_t n, FA a, FB b) {
+	if (!mlp_half_accumulate()) { float acc = 0.f; for (uint32_t k = 0; k < n; ++k) acc += a(k) * b(k); return acc; }
+	float acc = 0.f;
+	for (uint32_t k0 = 0; k0 < n; k0 += 16) {
+		float part = 0.f;
+		for (uint32_t k = k0; k < n && k < k0 + 16; ++k) part += a(k) * b(k);
+		acc = h2f(f2h(acc + part));
+	}
+	return acc;
+}
+
 // forward: acts[l] (l < n_hidden) = half(relu(W_l x)), out = half(W_last h)
 inline void mlp_forward(const MlpShape& s, const uint16_t* w, const uint16_t* x, uint16_t* acts /* n_hidden*width */, uint16_t* out) {
 	const uint16_t* in = x;
@@ -143,8 +163,7 @@ inline void mlp_forward(const MlpShape& s, const uint16_t* w, const uint16_t* x,
 		uint32_t R = s.rows(l), C = s.cols(l);
 		uint16_t* dst = (l == s.n_hidden) ? out : acts + l * s.width;
 		for (uint32_t i = 0; i < R; ++i) {
-			float acc = 0.f;
-			for (uint32_t k = 0; k < C; ++k) acc += h2f(W[i * C + k]) * h2f(in[k]);
+			float acc = mlp_dot(C, [&](uint32_t k) { return h2f(W[i * C + k]); }, [&](uint32_t k) { return h2f(in[k]); });
 			if (l != s.n_hidden) acc = acc > 0.f ? acc : 0.f;
 			dst[i] = f2h(acc);
 		}
@@ -169,8 +188,7 @@ inline void mlp_backward(const MlpShape& s, const uint16_t* w, const uint16_t* x
 		if (l == 0 && !dL_dx) break;
 		dnext.assign(C, 0);
 		for (uint32_t k = 0; k < C; ++k) {
-			float acc = 0.f;
-			for (uint32_t i = 0; i < R; ++i) acc += h2f(W[i * C + k]) * h2f(dcur[i]);
+			float acc = mlp_dot(R, [&](uint32_t i) { return h2f(W[i * C + k]); }, [&](uint32_t i) { return h2f(dcur[i]); }); // (the dgrad chain is the same fused kernel in tcnn: same accumulator type)
 			if (l > 0) { // ReLU backward through the stored forward activation
 				if (!(h2f(in[k]) > 0.f)) acc = 0.f;
 			}

@@ -299,6 +299,17 @@ def _sharded_worker(rank, world, port, q):
     assert (ma[~own] != ms[~own]).any(), "the foreign pieces' fp32 state is NOT maintained by the sharded step (that is the saving)"
     g = sh["grads"].cpu().numpy().view(np.uint16)
     assert not g[n_mlp:].any(), "every grid gradient is cleared for the next step's scatter, foreign pieces included"
+    # ... and the library says so: parameter read-backs / serialisation of the sharded trainer FAIL until the optimizer state has been gathered (they used to
+    # return the stale foreign pieces silently), the all-reduce trainer's do not
+    assert lib.ngp_nerf_dp_state_stale(sh["t"]) == 1 and lib.ngp_nerf_dp_state_stale(tr["allreduce"]["t"]) == 0
+    buf = np.empty(ps.n, np.float32)
+    assert lib.ngp_model_get_params_host(ps.h, buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size)) != 0 and b"ngp_nerf_dp_gather_state" in lib.ngp_last_error()
+    lib.ngp_model_serialized_size.restype = C.c_uint64
+    blob = np.empty(int(lib.ngp_model_serialized_size(ps.h, 1)), np.uint8)
+    assert lib.ngp_model_serialize_host(ps.h, blob.ctypes.data_as(C.c_void_p), C.c_uint64(blob.size), 1) != 0
+    A.check(lib, lib.ngp_model_get_params_host(pa.h, buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size)))
+    A.check(lib, lib.ngp_nerf_dp_state_gathered(sh["t"]))   # (what a caller with its own collectives says after exchanging the state; here only the flag is exercised)
+    A.check(lib, lib.ngp_model_get_params_host(ps.h, buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size)))
     print(f"rank {rank}: sharded == all-reduce step, {n_steps} steps, loss {ss.loss:.6f}; pieces {pieces}")
     q.put("ok")
     dist.barrier()

@@ -181,11 +181,17 @@ def test_short_training_run(hip, name):
     A.check(hip, hip.ngp_nerf_create(hm.h, C.byref(opts), A.scene_aabb(1), C.byref(t)))
     pix = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
     A.check(hip, hip.ngp_nerf_set_dataset_host(t, len(imgs), M, X, pix))
-    losses = []
-    for _ in range(6):
-        A.check(hip, hip.ngp_nerf_train(t, None, 25))
-        st = A.NerfStats(); A.check(hip, hip.ngp_nerf_get_stats(t, None, C.byref(st)))
-        losses.append(float(st.loss))
+    # deterministic compaction (DBG_K3_TWO_PASS: the production K3 orders the batch rows by atomic arrival, so two runs differ in the last bits and this loss ratio
+    # scattered around its bar -- a flake of the round-5 final tier): with slot-ordered rows the run is the same every time and the round-3 bar (a factor 3 in 150 steps) is back
+    hip.ngp_debug_set_flags(1048576)
+    try:
+        losses = []
+        for _ in range(6):
+            A.check(hip, hip.ngp_nerf_train(t, None, 25))
+            st = A.NerfStats(); A.check(hip, hip.ngp_nerf_get_stats(t, None, C.byref(st)))
+            losses.append(float(st.loss))
+    finally:
+        hip.ngp_debug_set_flags(0)
     print(name, [f"{l:.5f}" for l in losses])
-    assert np.isfinite(losses).all() and losses[-1] < losses[0] / 2 and st.measured_batch_size > 0
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] / 3 and st.measured_batch_size > 0
     hip.ngp_nerf_destroy(t)

@@ -656,34 +656,3 @@ def test_fused_optimizer_epilogue_is_the_separate_sweep(ora, hip):
         bad = np.flatnonzero(blobs[0][k] != blobs[1][k])
         assert bad.size == 0, (name, bad.size, bad[:8].tolist(), blobs[0][k][bad[:8]].tolist(), blobs[1][k][bad[:8]].tolist())
     assert np.array_equal(blobs[0][0][:hdr], blobs[1][0][:hdr])
-
-
-def test_xcd_encode_ablation_is_bit_identical(hip, ora):
-    """Ablation NGP_K2_XCD_ENCODE=1 (one hash-grid level per XCD encodes the first tile of every ray into a level-major buffer, the lazy K2 loads those encodings instead
-    of gathering: model_kernels.hip k_encode_tiles_xcd; measured slower than the fused gathers, profiles/r04_microbench_k2_xcd_encode.log, hence off).  Same level_features4
-    arithmetic => with the deterministic K3 compaction (DBG_K3_TWO_PASS, which also makes T1 gather its own encodings) the two trainers hold IDENTICAL master parameters
-    and Adam state after 30 steps."""
-    import os
-    B = 1 << 16
-    blobs, stats = [], []
-    for xcd in ("0", "1"):
-        os.environ["NGP_K2_XCD_ENCODE"] = xcd
-        hip.ngp_debug_set_flags(1048576)  # DBG_K3_TWO_PASS
-        try:
-            s = _make(ora, hip, B, n_images=8, res=64)
-            os.environ.pop("NGP_K2_XCD_ENCODE", None)
-            A.check(hip, hip.ngp_nerf_train(s["t"], None, 30))
-            st = _stats(hip, s["t"])
-            size = hip.ngp_model_serialized_size; size.restype = C.c_uint64
-            nbytes = size(s["hm"].h, 1)
-            buf = np.zeros(nbytes, np.uint8)
-            A.check(hip, hip.ngp_model_serialize_host(s["hm"].h, ptr(buf), C.c_uint64(nbytes), 1))
-            blobs.append(buf); stats.append((st.training_step, st.rays_per_batch, st.measured_batch_size, st.network_evaluations))
-            hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
-        finally:
-            os.environ.pop("NGP_K2_XCD_ENCODE", None)
-            hip.ngp_debug_set_flags(0)
-    print("xcd-encode ablation (off, on):", stats)
-    assert stats[0] == stats[1] and stats[0][0] == 30 and stats[0][3] > 0
-    bad = np.flatnonzero(blobs[0] != blobs[1])
-    assert bad.size == 0, (bad.size, bad[:8].tolist())

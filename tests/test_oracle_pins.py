@@ -423,3 +423,43 @@ def test_grid_sizing_matches_the_reference_log(ora):
     assert ora.ora_encmlp_create(C.byref(ec), C.c_uint64(1337), C.byref(e)) == 0, ora.ora_last_error()
     ora.ora_encmlp_n_params.restype = C.c_uint64
     assert ora.ora_encmlp_n_params(e) - (64 * 32 + 64 * 64 + 16 * 64) == REFERENCE_LOG_TOTAL_ENCODING_PARAMS
+
+
+def test_mlp_accumulator_switch(ora):
+    """Appendix-A switch `mlp_half_accumulate` (oracle only): off = fp32 accumulation over the whole contraction (the product's MFMA arithmetic and the
+    oracle's default, unchanged by the switch's existence); on = tcnn's __half WMMA accumulator fragments, modelled as one rounding to half per 16-wide k-step.  The two are
+    pinned here against an independent numpy statement, and the network outputs under the switch stay within a few half ulps of the default."""
+    import ctypes as C
+    ora.ora_mlp_dot.restype = C.c_float
+    ora.ora_mlp_dot.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+    ora.ora_set_mlp_half_accumulate.argtypes = [C.c_int]
+    rng = np.random.default_rng(11)
+    try:
+        for n in (16, 32, 48, 64):
+            a = rng.normal(size=n).astype(np.float16); b = rng.normal(size=n).astype(np.float16)
+            af, bf = a.astype(np.float32), b.astype(np.float32)
+            seq = np.float32(0)
+            for k in range(n):
+                seq = np.float32(seq + af[k] * bf[k])
+            stepped = np.float32(0)
+            for k0 in range(0, n, 16):
+                part = np.float32(0)
+                for k in range(k0, k0 + 16):
+                    part = np.float32(part + af[k] * bf[k])
+                stepped = np.float32(np.float16(np.float32(stepped + part)))
+            ora.ora_set_mlp_half_accumulate(0)
+            assert ora.ora_mlp_dot(n, a.ctypes.data, b.ctypes.data) == float(seq)
+            ora.ora_set_mlp_half_accumulate(1)
+            assert ora.ora_mlp_dot(n, a.ctypes.data, b.ctypes.data) == float(stepped)
+        from common import OraModel, random_coords, half_to_f32
+        import ngp_abi as A
+        om = OraModel(ora, A.base_model_config(1))
+        p = om.params_fp
+        p[: om.n_mlp] = rng.uniform(-0.3, 0.3, om.n_mlp).astype(np.float32); p[om.n_mlp:] = rng.uniform(-1, 1, om.n - om.n_mlp).astype(np.float32)
+        ora.ora_model_sync_half(om.h)
+        c = random_coords(512, seed=2, ray_coherent=True)
+        ora.ora_set_mlp_half_accumulate(0); o0 = half_to_f32(om.inference(c))
+        ora.ora_set_mlp_half_accumulate(1); o1 = half_to_f32(om.inference(c))
+        assert not np.array_equal(o0, o1) and np.abs(o0 - o1).max() <= 2e-2 * max(np.abs(o0).max(), 1.0)
+    finally:
+        ora.ora_set_mlp_half_accumulate(0)

@@ -47,16 +47,16 @@ FLOAT_FNS = ("calc_dt", "advance_n_steps", "to_stepping_space", "from_stepping_s
 
 
 class _ProductOnTheHost:
-    """`ora_<name>` -> `ngp_host_<name>` of libngp_hip.so (include/ngp_hip_host_hooks.h): the product's device source evaluated on the host, in the oracle's place"""
+    """`ora_<name>` -> `ngp_host_<name>` of libngp_hip_testhooks.so (include/ngp_hip_host_hooks.h): the product's device source evaluated on the host, in the oracle's place"""
 
-    def __init__(self, lib, ora):
-        self._lib, self._ora = lib, ora
+    def __init__(self, lib, ora, api):
+        self._lib, self._ora, self._api = lib, ora, api
         for n in FLOAT_FNS:
             getattr(lib, "ngp_host_" + n).restype = F
         lib.ngp_host_sobol.restype = C.c_uint32; lib.ngp_host_image_idx_cdf.restype = C.c_uint32
 
     def __getattr__(self, name):
-        lib = self._lib
+        lib = self._api if name in ("ora_uv_to_ray", "ora_pos_to_uv") else self._lib  # (the camera hooks are entries of the C-ABI, include/ngp_hip.h)
         if name == "ora_uv_to_ray":  # (the camera hooks predate this file and take the metadata first)
             return lambda uv, m, x, o3, d3: lib.ngp_host_uv_to_ray(m, x, uv, o3, d3)
         if name == "ora_pos_to_uv":
@@ -74,7 +74,7 @@ def o(request, ora):
             getattr(ora, "ora_" + n).restype = F
         ora.ora_sobol.restype = C.c_uint32; ora.ora_image_idx_cdf.restype = C.c_uint32
         return ora
-    return _ProductOnTheHost(A.load_hip(), ora)
+    return _ProductOnTheHost(A.load_testhooks(), ora, A.load_hip())
 
 
 CONES = (0.0, 1.0 / 256.0, 1.0 / 128.0, 0.01)
