@@ -84,6 +84,9 @@ DEV h8 to_frag_masked(const f16v& d, int q, uint32_t mask16) {
 // hash grid: one level for one sample.  [tcnn grid.h kernel_grid / grid_index / pos_fract]
 // ---------------------------------------------------------------------------------------------
 struct LevelConst { float scale; uint32_t res, hs, offset; bool hashed; };
+// pieces of a NerfCoordinate (28-byte records: 4-byte aligned only) as ONE 16- / 12-byte access instead of dwords at a 28-byte stride
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f3u_t __attribute__((ext_vector_type(3), aligned(4)));
 // the lane's level is one of two compile-time levels, selected by hi (= lane >> 5): a select between two uniform values
 DEV LevelConst level_const2(const GridMeta* __restrict__ gmp, int lvl_lo, int lvl_hi, int hi) {
 	const GridMeta& gm = *gmp;
@@ -559,16 +562,21 @@ __global__ void __launch_bounds__(256, MINW) k_inference(const GridMeta* __restr
 // ---------------------------------------------------------------------------------------------
 // TW = tile width in samples: 32 (one tile per wavefront) or 16 (two tiles of two different rays share the wavefront's 32 MFMA
 // columns -- rays end after ~12 compacted samples, so 16-wide tiles evaluate fewer samples behind the cut and fill the columns).
-template <uint32_t TW, int F = 4, int NR = 2, int DEPTH = 0 /* F = 4: 0 = level constants from GridMeta (rounds 1-5), 1 | 2 = from the LDS table, with one | two levels' gathers in flight */>
+template <uint32_t TW, int F = 4, int NR = 2, int DEPTH = 0 /* F = 4: 0 = level constants from GridMeta (rounds 1-5), 1 | 2 = from the LDS table, with one | two levels' gathers in flight */,
+	bool DYN = false /* a workgroup owns a contiguous range of tile pairs and its wavefronts take them as they finish (LDS counter) instead of every n_waves-th pair: rays need 1 .. 60+ tiles */>
 __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __restrict__ gm, ModelPtrs mp, const float* __restrict__ in, uint32_t in_stride,
 		K2LazyArgs la, __half* __restrict__ out, uint32_t out_stride, uint32_t dir_offset) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr uint32_t TPW = 32u / TW; // tiles per wavefront
 	const uint32_t r = la.round;
 	const uint32_t n_tiles = min(r == 0 ? *la.n_rays_ptr : la.n_tiles_ptr[r], la.tile_cap);
-	if (blockIdx.x * 4 * TPW >= n_tiles) return; // uniform: late rounds are small
 	h8* fw = (h8*)smem;
 	__shared__ uint4 s_lct[16];
+	__shared__ uint32_t s_next_wt;
+	const uint32_t n_wt = (n_tiles + TPW - 1u) / TPW; // tile pairs (TW = 16) / tiles
+	const uint32_t wt_begin = DYN ? (uint32_t)(((uint64_t)n_wt * blockIdx.x) / gridDim.x) : 0u, wt_end = DYN ? (uint32_t)(((uint64_t)n_wt * (blockIdx.x + 1u)) / gridDim.x) : n_wt;
+	if (DYN ? wt_begin >= wt_end : blockIdx.x * 4 * TPW >= n_tiles) return; // uniform: nothing for this workgroup (late rounds / the first training steps are small)
+	if (DYN && threadIdx.x == 0) s_next_wt = wt_begin + (blockDim.x >> 6);
 	if constexpr (DEPTH != 0) fill_level_table(s_lct, gm);
 	load_frags_to_lds(fw, mp.fw_frags, n_fw(NR));
 	__syncthreads();
@@ -603,7 +611,10 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 			if (off + j < la.tile_cap) next[off + j] = make_uint4(first + TW * j, min(TW, n - TW * j), ray, rest - min(rest, TW * (j + 1u)));
 		n_pend = 0;
 	};
-	for (uint32_t wt = wave; wt * TPW < n_tiles; wt += n_waves) {
+	for (uint32_t wt = DYN ? wt_begin + wid : wave; wt < wt_end; ) {
+		const uint32_t wt_cur = wt;
+		if constexpr (DYN) { uint32_t nx = 0u; if (lane == 0) nx = atomicAdd(&s_next_wt, 1u); wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx); } else wt += n_waves;
+		{ const uint32_t wt = wt_cur; // (the body below names the current pair `wt`)
 		const uint32_t tile = wt * TPW + slot;
 		uint4 d = make_uint4(0u, 0u, 0u, 0u);
 		if (tile < n_tiles) d = tiles[tile];
@@ -616,14 +627,16 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 		if (__ballot(valid) == 0ull) break;
 		FwdState<1> st;
 		const float* p = in + (size_t)sample * in_stride;
-		if constexpr (DEPTH != 0 && F == 4) encode_sample_lds<DEPTH>(s_lct, table, p[0], p[1], p[2], hi, st.enc[0]);
-		else encode_sample<F, false>(gm, table, p[0], p[1], p[2], hi, st.enc[0]);
+		const f4u_t pc = *(const f4u_t*)p;                 // position + warped dt
+		const f3u_t pd = *(const f3u_t*)(p + dir_offset);  // direction
+		if constexpr (DEPTH != 0 && F == 4) encode_sample_lds<DEPTH>(s_lct, table, pc[0], pc[1], pc[2], hi, st.enc[0]);
+		else encode_sample<F, false>(gm, table, pc[0], pc[1], pc[2], hi, st.enc[0]);
 		if (la.enc_out && valid) { // for T1 (EncStashIn): this lane's half of the sample's encoding, 32 contiguous bytes
 			uint4* e = la.enc_out + (size_t)sample * 4 + (uint32_t)hi * 2;
 			e[0] = __builtin_bit_cast(uint4, st.enc[0][0]); e[1] = __builtin_bit_cast(uint4, st.enc[0][1]);
 		}
 		first_tile = false;
-		st.rin[0][1] = sh4_frag(p[dir_offset], p[dir_offset + 1], p[dir_offset + 2], hi);
+		st.rin[0][1] = sh4_frag(pd[0], pd[1], pd[2], hi);
 		fwd_density_l1<1>(fw, lane, st);
 		fwd_density_l2<1>(fw, lane, st);
 		fwd_rgb_hidden<1, NR>(fw, lane, st);
@@ -645,7 +658,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 				const float x = st.sigma[0];
 				const float sg = la.density_activation == NGP_ACT_NONE ? x : la.density_activation == NGP_ACT_RELU ? fmaxf(x, 0.f)
 					: la.density_activation == NGP_ACT_LOGISTIC ? 1.f / (1.f + __expf(-x)) : __expf(x);
-				od = sg * (p[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
+				od = sg * (pc[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
 			}
 #pragma unroll
 			for (int dd = (int)TW / 2; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64); // sum over the tile's TW lanes (hi == 0 half)
@@ -666,7 +679,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 				const float x = st.sigma[0];
 				const float sg = la.density_activation == NGP_ACT_NONE ? x : la.density_activation == NGP_ACT_RELU ? fmaxf(x, 0.f)
 					: la.density_activation == NGP_ACT_LOGISTIC ? 1.f / (1.f + __expf(-x)) : __expf(x);
-				od = sg * (p[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
+				od = sg * (pc[3] * la.dt_unwarp_scale + la.dt_unwarp_offset);
 			}
 #pragma unroll
 			for (int dd = (int)TW / 2; dd >= 1; dd >>= 1) od += __shfl_xor(od, dd, 64); // sum over the tile's TW lanes (hi == 0 half)
@@ -686,6 +699,7 @@ __global__ void __launch_bounds__(256, 3) k_inference_tiles(const GridMeta* __re
 			}
 		}
 		break;
+		}
 		}
 	}
 	if (n_pend) flush();
@@ -1244,7 +1258,8 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 			const float* p = a.in + (size_t)sc * a.in_stride;
 			if constexpr (D == 3) {
 				Corners c3;
-				level_corners(lc, p[0], p[1], p[2], c3);
+				const f3u_t p3 = *(const f3u_t*)p;
+				level_corners(lc, p3[0], p3[1], p3[2], c3);
 #pragma unroll
 				for (int k = 0; k < NC; ++k) { cr.idx[k] = c3.idx[k]; cr.w[k] = c3.w[k]; }
 				cr.cell_xy = c3.cell_xy; cr.cell_z = c3.cell_z;
@@ -2757,6 +2772,8 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	static const int k2_depth = getenv("NGP_K2_DEPTH") ? atoi(getenv("NGP_K2_DEPTH")) : 2; // 0: level constants from GridMeta (rounds 1-5, ablation); 1 / 2: from the LDS table (profiles/r06_ab_k2_level_table.txt)
 	for (uint32_t r = 0; r < la.n_rounds; ++r) {
 		la.round = r;
+		static const bool k2_dyn = !(getenv("NGP_K2_STATIC") && atoi(getenv("NGP_K2_STATIC")) != 0) && la.n_rounds == 1;
+		if (k2_depth == 2 && F == 4 && nr == 2 && la.tile_w == 16 && k2_dyn) { hipLaunchKernelGGL((k_inference_tiles<16, 4, 2, 2, true>), dim3(grid), dim3(256), n_fw(2) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset); continue; }
 		if (k2_depth == 2 && F == 4 && nr == 2 && la.tile_w == 16) { hipLaunchKernelGGL((k_inference_tiles<16, 4, 2, 2>), dim3(grid), dim3(256), n_fw(2) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset); continue; }
 		if (k2_depth == 1 && F == 4 && nr == 2 && la.tile_w == 16) { hipLaunchKernelGGL((k_inference_tiles<16, 4, 2, 1>), dim3(grid), dim3(256), n_fw(2) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset); continue; }
 		if (F == 2) { if (nr == 1) NGP_LAUNCH_TILES_W(2, 1); else if (nr == 3) NGP_LAUNCH_TILES_W(2, 3); else NGP_LAUNCH_TILES_W(2, 2); }

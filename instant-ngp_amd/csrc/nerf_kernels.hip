@@ -173,6 +173,9 @@ __global__ void __launch_bounds__(128) k_generate_training_samples(K1Args a) {
 // rounding of (n + k1) + k2 vs n + (k1 + k2) and of fl(fl(x*M)/M): the great majority of rays are
 // bit-identical, the rest carry <= 2-ulp offsets in t (tests/test_gpu_nerf.py quantifies both).
 // ------------------------------------------------------------------------------------------------
+// the seven floats of a NerfCoordinate (a 28-byte record: 4-byte aligned only) as one 16-byte and one 12-byte access instead of seven 4-byte ones at a 28-byte stride
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f3u_t __attribute__((ext_vector_type(3), aligned(4)));
 constexpr uint32_t LAT_MAX_CHUNKS = 32;   // 2048 lattice points per ray
 constexpr uint32_t LAT_MAX_POINTS = LAT_MAX_CHUNKS * 64;
 constexpr uint32_t SCAN_BLOCK = 1024;     // elements per scan block (256 threads x 4)
@@ -565,6 +568,7 @@ __global__ void __launch_bounds__(64 * NW) k1_count_segments(K1Args a, RaySetup*
 	__shared__ uint64_t s_tot[NW];
 	__shared__ uint64_t s_scan[NW];
 	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_next; // next slot of the workgroup's range to hand out: a ray costs between nothing (misses the box) and hundreds of lattice points, so the wavefronts take rays as they finish (round 6) instead of every NW-th one
 	__shared__ uint8_t s_seg[NW][K1_MAX_SEGS]; // per wavefront: the segments of its ray that passed the prepass, in lattice order
 	extern __shared__ uint32_t s_pre[];       // [COARSE_WORDS coarse of cascade 0][MID_WORDS dilated mid grid]
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
@@ -572,6 +576,7 @@ __global__ void __launch_bounds__(64 * NW) k1_count_segments(K1Args a, RaySetup*
 	const uint32_t ray_end = (uint32_t)(((uint64_t)n_rays * (a.rank + 1)) / a.world_size);
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint32_t li_begin, li_end; k1_slot_range(ray_end - ray_begin, blockIdx.x, gridDim.x, li_begin, li_end);
+	if (threadIdx.x == 0) s_next = li_begin + NW; // (the first NW rays are taken by wavefront index)
 	if (li_begin < li_end) { // 36 KiB per workgroup: all 16-byte loads of a thread in flight before the first LDS store
 		static_assert(COARSE_WORDS == 4 * 256 && MID_WORDS == 8 * 4 * 256, "one + eight uint4 per thread of a 256-thread workgroup");
 		const uint4* src_c = (const uint4*)a.bitfield_coarse; const uint4* src_m = (const uint4*)(a.bitfield_coarse + (size_t)a.n_mips * COARSE_WORDS);
@@ -588,7 +593,7 @@ __global__ void __launch_bounds__(64 * NW) k1_count_segments(K1Args a, RaySetup*
 	__syncthreads();
 	const uint32_t* s_mid = s_pre + COARSE_WORDS;
 	uint64_t wave_total = 0ull;
-	for (uint32_t li = li_begin + wid; li < li_end; li += NW) {
+	for (uint32_t li = li_begin + wid; li < li_end; ) {
 		const RaySetup& r = rs[li];
 		const uint32_t n_in = r.flags; // lattice points inside the box: [0, n_in)
 		uint32_t cnt = 0;
@@ -634,6 +639,9 @@ __global__ void __launch_bounds__(64 * NW) k1_count_segments(K1Args a, RaySetup*
 		}
 		if (lane == 0) rs[li].count = cnt;
 		wave_total += (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
+		uint32_t nxt = 0u;
+		if (lane == 0) nxt = atomicAdd(&s_next, 1u);
+		li = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
 	}
 	k1_publish_and_scan<NW>(a, wave_total, partial, done, s_tot, s_scan, s_ticket);
 }
@@ -647,7 +655,6 @@ __global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* _
 	__shared__ uint64_t s_scan[4];
 	__shared__ uint32_t s_base[K1_MAX_RANGE + 1]; // exclusive prefix of the range's sample counts (relative to the range's first sample)
 	__shared__ uint32_t s_cut;                    // first sample (relative) of the first ray that does not fit under the sample cap
-	__shared__ float s_stage[4][64 * 7];
 	const uint32_t n_rays = a.n_rays_ptr ? *a.n_rays_ptr : a.n_rays;
 	const uint32_t max_samples = a.max_samples_ptr ? min(*a.max_samples_ptr, a.max_samples) : a.max_samples;
 	const uint32_t ray_begin = (uint32_t)(((uint64_t)n_rays * a.rank) / a.world_size);
@@ -693,7 +700,6 @@ __global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* _
 	}
 	// samples past the cap's cut are not written (dropped rays form a suffix of the slot order: the span base is monotone)
 	const uint32_t n_total = min(s_base[n_slots], s_cut);
-	float* st = s_stage[wid];
 	for (uint32_t e0 = (part * 4u + wid) * 64u; e0 < n_total; e0 += K1_WRITE_SPLIT * 4u * 64u) {
 		const uint32_t e = min(e0 + lane, n_total - 1u), n = min(n_total - e0, 64u);
 		// the sample's slot: the last one whose span starts at or before e (empty slots share their successor's offset and lose against it)
@@ -715,13 +721,13 @@ __global__ void __launch_bounds__(256) k1_write_list(K1Args a, const RaySetup* _
 			}
 			continue;
 		}
-		float* c = st + lane * 7u;
-		c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
-		__builtin_amdgcn_wave_barrier();
-		float* co = a.coords_out + ((size_t)(uint32_t)range_off + e0) * 7;
-#pragma unroll
-		for (uint32_t q = 0; q < 7; ++q) { const uint32_t x = q * 64u + lane; if (x < n * 7u) co[x] = st[x]; }
-		__builtin_amdgcn_wave_barrier();
+		// the lane's 28-byte record as one 16-byte and one 12-byte store (the wavefront's 1792 bytes are contiguous: the L2 merges the pieces).  Rounds 4-5 transposed the
+		// records through LDS for seven coalesced dword stores: measured equal (tools/batches/r06_p.sh), removed.
+		if (lane < n) {
+			float* co = a.coords_out + ((size_t)(uint32_t)range_off + e0 + lane) * 7;
+			const f4u_t va = {wp.x, wp.y, wp.z, warp_dt(dt)}; const f3u_t vb = {wd.x, wd.y, wd.z};
+			*(f4u_t*)co = va; *(f3u_t*)(co + 4) = vb;
+		}
 	}
 }
 
@@ -1019,7 +1025,8 @@ __global__ void __launch_bounds__(64 * WPB, MINW) k_compute_loss_v2(K3Args a) {
 	float T_final = 1.f;
 	float depth_ray = 0.f, target_depth = -1.f; // depth supervision (depth_lambda > 0, wave-uniform)
 	// the first LPR samples of the ray stay in registers for the adjoint pass (most rays keep fewer)
-	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f, k_cc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	// (the NerfCoordinate as two VECTOR values, never an array: the 7-float array of rounds 3-5 lived in scratch -- a store in pass 1, a load in pass 2, 32 bytes per lane)
+	float k_l0 = 0.f, k_l1 = 0.f, k_l2 = 0.f, k_l3 = 0.f; f4u_t k_ca = {0.f, 0.f, 0.f, 0.f}; f3u_t k_cb = {0.f, 0.f, 0.f};
 	const bool vec_out = a.output_stride == 4, vec_dl = a.dloss_stride == 4;
 	auto load_out = [&](const __half* lo, float& l0, float& l1, float& l2, float& l3) {
 		if (vec_out) {
@@ -1079,10 +1086,9 @@ __global__ void __launch_bounds__(64 * WPB, MINW) k_compute_loss_v2(K3Args a) {
 				load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
 				if (c0 == 0) {
 					const float* ci = cin + (size_t)s * cs;
-#pragma unroll
-					for (int k = 0; k < 7; ++k) k_cc[k] = ci[k];
+					k_ca = *(const f4u_t*)ci; k_cb = *(const f3u_t*)(ci + 4);
 					k_l0 = l0; k_l1 = l1; k_l2 = l2; k_l3 = l3;
-					dtw = k_cc[3];
+					dtw = k_ca[3];
 				} else dtw = cin[(size_t)s * cs + 3];
 				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
 				const float dt = unwarp_dt(dtw);
@@ -1162,22 +1168,20 @@ __global__ void __launch_bounds__(64 * WPB, MINW) k_compute_loss_v2(K3Args a) {
 			const bool valid = s < compacted;
 			float alpha = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, dt = 0.f, depth = 0.f;
 			f3 rgb = mk3(0.f);
-			float cc[7];
+			f4u_t ca = {0.f, 0.f, 0.f, 0.f}; f3u_t cb = {0.f, 0.f, 0.f};
 			if (valid) {
 				if (c0 == 0) {
-#pragma unroll
-					for (int k = 0; k < 7; ++k) cc[k] = k_cc[k];
+					ca = k_ca; cb = k_cb;
 					l0 = k_l0; l1 = k_l1; l2 = k_l2; l3 = k_l3;
 				} else {
 					const float* ci = cin + (size_t)s * cs;
-#pragma unroll
-					for (int k = 0; k < 7; ++k) cc[k] = ci[k];
+					ca = *(const f4u_t*)ci; cb = *(const f3u_t*)(ci + 4);
 					load_out(no + (size_t)s * a.output_stride, l0, l1, l2, l3);
 				}
 				rgb = mk3(act_rgb(l0, a.rgb_activation), act_rgb(l1, a.rgb_activation), act_rgb(l2, a.rgb_activation));
-				dt = unwarp_dt(cc[3]);
+				dt = unwarp_dt(ca[3]);
 				alpha = 1.f - __expf(-act_density(l3, a.density_activation) * dt);
-				depth = dist3(unwarp_position(mk3(cc[0], cc[1], cc[2]), aabb), ray_o);
+				depth = dist3(unwarp_position(mk3(ca[0], ca[1], ca[2]), aabb), ray_o);
 			}
 			const float incl = seg_prod(1.f - alpha);
 			float excl = __shfl_up(incl, 1, 64);
@@ -1194,8 +1198,7 @@ __global__ void __launch_bounds__(64 * WPB, MINW) k_compute_loss_v2(K3Args a) {
 			}
 			if (valid) {
 				float* cj = cout + (size_t)s * cs;
-#pragma unroll
-				for (int k = 0; k < 7; ++k) cj[k] = cc[k];
+				*(f4u_t*)cj = ca; *(f3u_t*)(cj + 4) = cb;
 				for (uint32_t k = 7; k < cs; ++k) cj[k] = cin[(size_t)s * cs + k];
 				if (a.src_index_out) a.src_index_out[compacted_base + s] = base + s; // which K2 sample this batch row is (EncStashIn)
 				const f3 suffix = rgb_ray - ray2;
@@ -1853,7 +1856,8 @@ void launch_compute_loss(hipStream_t s, const K3Args& a, uint32_t max_rays) {
 			// 4-wavefront workgroups double the span atomics once more and are 20 - 35 us SLOWER: one counter word retires ~100 returning atomics per microsecond)
 			static const bool wg16 = getenv("NGP_K3_WG16") && atoi(getenv("NGP_K3_WG16")) != 0; // the round-3..5 shape (ablation)
 			if (wg16) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true>), g2, dim3(1024), 0, s, a);
-			else hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true, 8, 5>), dim3(std::min<uint32_t>(blocks(max_rays, 16), 256u * 2u)), dim3(512), 0, s, a);
+			// (79 registers since the coordinate lives in vector registers: three 8-wavefront workgroups per CU; two -- NGP_K3_OCC=5 in tools/batches/r06_p.sh -- measured the same)
+			else hipLaunchKernelGGL((k_compute_loss_v2<2, false, true, true, 8, 6>), dim3(std::min<uint32_t>(blocks(max_rays, 16), 256u * 3u)), dim3(512), 0, s, a);
 		}
 		else if (plain) hipLaunchKernelGGL((k_compute_loss_v2<2, false, true>), g2, dim3(1024), 0, s, a);
 		else hipLaunchKernelGGL((k_compute_loss_v2<2, false, false>), g2, dim3(1024), 0, s, a);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 6, call o: K3 with the NerfCoordinate in vector registers (96 registers + 32 B scratch -> 79 + 0: three 8-wavefront workgroups per CU), k1_write_list storing 28-byte records directly,
+# k1_count_segments / lazy K2 handing rays / tile pairs out dynamically inside a workgroup, 16- / 12-byte coordinate loads in K2 and k_grad_bin.  Parity tests, then the A/B per knob and against
+# the previous commit's library.
+R=$PWD; O=gpurun_out/r06o; mkdir -p $O; . tools/batches/ab_lib.sh
+timeout 900 python -m pytest tests/test_gpu_nerf.py tests/test_gpu_train.py tests/test_gpu_model.py -q -x -m gpu -p no:cacheprovider > $O/pytest.log 2>&1; tail -3 $O/pytest.log | cut -c1-300
+for pass in 1 2; do
+  ab_run prev_p$pass NGP_HIP_LIB=$R/gpurun_in/libngp_hip_prev.so
+  ab_run new_p$pass NGP_X=1
+  ab_run k3occ5_p$pass NGP_K3_OCC=5
+  ab_run k1writelds_p$pass NGP_K1_WRITE_LDS=1
+  ab_run k2static_p$pass NGP_K2_STATIC=1
+done
