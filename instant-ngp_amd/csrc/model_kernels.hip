@@ -2764,7 +2764,7 @@ void launch_inference_lazy(hipStream_t s, const GridMeta* gm, const ModelPtrs& m
 	// resident slots (dispatcher hands tiles out as blocks retire) 0.13 -> 0.16 - 0.21 ms; 4 blocks per CU at 128 registers (28 B of scratch) 0.130 -> 0.134 ms; 8-wide
 	// tiles 0.131 -> 0.142 ms.  The kernel moves 400 MB of 128-byte lines for 8-byte table entries (profiles/r03_pmc_summary.txt): it runs at the memory side's
 	// random-line rate (3.3 TB/s), not at a latency or occupancy limit.
-	static const uint32_t k2_bpc = getenv("NGP_K2_BLOCKS_PER_CU") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_K2_BLOCKS_PER_CU")), 1), 3) : 3u; // experiment: leave wave slots to a concurrent VALU-bound kernel
+	constexpr uint32_t k2_bpc = 3u; // resident workgroups per CU (fewer, to leave wave slots to a concurrent kernel, bought nothing: profiles/r04_exp_dummy_k1_under_k2.log)
 	const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)la.tile_cap / tpw + 3) / 4, (uint64_t)num_cus() * k2_bpc);
 	const uint32_t nr = mp.n_rgb_hidden;
 #define NGP_LAUNCH_TILES(TW, FF, NRR) hipLaunchKernelGGL((k_inference_tiles<TW, FF, NRR>), dim3(grid), dim3(256), n_fw(NRR) * 1024, s, gm, mp, in, in_stride, la, (__half*)out, out_stride, dir_offset)
@@ -2827,7 +2827,7 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a_in, uint32_t what) {
 	if (a.acc_ly_count == 0) { a.acc_ly_begin = 0; a.acc_ly_count = a.n_hashed; }
 	const bool do_bin = (what & 1u) != 0, do_acc = (what & 2u) != 0;
 	const uint32_t ny = a.acc_ly_count;
-	static const uint32_t ns = getenv("NGP_BIN_SAMPLES") ? (uint32_t)atoi(getenv("NGP_BIN_SAMPLES")) : 512u;
+	constexpr uint32_t ns = 512u; // samples per k_grad_bin workgroup (256 / 1024 measured in rounds 2-3: profiles/r03_microbench_bin_threads_k2_grid.log)
 	const dim3 gb((a.n + ns - 1) / ns, a.n_hashed);
 	if (a.n_features == 2 && a.n_pos_dims == 2) { // the image primitive's grid (encmlp trainer): 4 corners per sample
 		REQUIRE_VOID(a.chunk_log2 == 12);
@@ -2856,7 +2856,7 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a_in, uint32_t what) {
 			else hipLaunchKernelGGL((k_grad_accumulate<11, false>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
 		}
 	} else {
-		static const uint32_t bin_threads = getenv("NGP_BIN_THREADS") ? (uint32_t)atoi(getenv("NGP_BIN_THREADS")) : 512u; // 256: the round-2 shape (ablation)
+		constexpr uint32_t bin_threads = 512u; // one sample per thread (256 threads x 2 samples, the round-2 shape: 80 -> 66 us, profiles/r03_microbench_bin_threads_k2_grid.log)
 		if (do_bin) {
 			if (ns == 256) hipLaunchKernelGGL((k_grad_bin<12, 256>), gb, dim3(256), 0, s, a);
 			// (1024 samples / threads per block -- twice the run length, half the cursor atomics, but one 100 KiB block per CU: unit 0.150 -> 0.164 ms, rejected)
@@ -2896,7 +2896,7 @@ void launch_train_fwd_bwd(hipStream_t s, const GridMeta* gm, const ModelPtrs& mp
 		return;
 	}
 	// 3 wavefronts per SIMD without spills (164 registers) beat 4 with 36 spilled registers: T1 + bin + accumulate 0.219 vs 0.244 ms (profiles/r02_t1_occupancy.txt)
-	static const int t1_occ = getenv("NGP_T1_OCC") ? atoi(getenv("NGP_T1_OCC")) : 3;
+	constexpr int t1_occ = 3; // wavefronts per SIMD of T1 (4 spills: profiles/r02_t1_occupancy.txt)
 	// (4 blocks per CU -- the stash variant compiles to 91 registers when asked -- measured no better: unit 0.189 vs 0.180 ms, profiles/r03_microbench_t1_stash.log)
 	if ((flags & T1_DENSE_EXTERNAL) && denc_lv && !(flags & DBG_T1_OCC2) && t1_occ == 3 && stash_in && stash_in->enc && !(flags & DBG_T1_NO_K2_STASH))
 		hipLaunchKernelGGL((k_train_fwd_bwd<1, 3, false, 4, 2, true>), dim3(grid), dim3(256), (N_FW_FRAGS + N_BW_FRAGS) * 1024, s, gm, mp, in, in_stride, n,

@@ -1742,8 +1742,8 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 // to round 3a ran 1.33 rounds: K1 0.181 -> 0.171 ms, step 0.600 -> 0.587 ms with 6 (profiles/r03_microbench_k1_grid.log).  k1_count<8, false> (98 registers, 4 per CU)
 // keeps 8 = two full rounds.  Scratch is sized for the largest grid.
 constexpr uint32_t K1_MAX_BLOCKS_PER_CU = 16;
-static uint32_t k1_blocks_per_cu(bool single_cascade) { static const int env = [] { const char* e = getenv("NGP_K1_BLOCKS_PER_CU"); return e ? std::min(std::max(atoi(e), 1), (int)K1_MAX_BLOCKS_PER_CU) : 0; }(); return env ? (uint32_t)env : single_cascade ? 6u : 8u; }
-static uint32_t k1_blocks_per_cu_segments() { static const int env = [] { const char* e = getenv("NGP_K1_SEG_BLOCKS_PER_CU"); return e ? std::min(std::max(atoi(e), 1), (int)K1_MAX_BLOCKS_PER_CU) : 0; }(); return env ? (uint32_t)env : 4u; }
+static uint32_t k1_blocks_per_cu(bool single_cascade) { return single_cascade ? 6u : 8u; }
+static uint32_t k1_blocks_per_cu_segments() { return 4u; } // (36 KiB of LDS per workgroup)
 static uint32_t k1_grid(uint32_t max_local_rays, uint32_t blocks_per_cu = K1_MAX_BLOCKS_PER_CU) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * blocks_per_cu), blocks(max_local_rays, K1_MAX_RANGE)); }
 // byte offset of the workgroup totals behind the RaySetup and mask arrays (64-bit atomics: naturally aligned)
 static size_t k1_partial_offset(uint32_t max_local_rays) { return ((size_t)max_local_rays * (sizeof(RaySetup) + LAT_MAX_CHUNKS * 8) + 15) / 16 * 16; }

@@ -154,7 +154,7 @@ extern "C" int ngp_profile_read(double* ms_sum, uint64_t* launches) {
 // (inside the first training step) they used to come into existence AFTER a data-parallel caller's RCCL communicator, and in that order every kernel of the
 // step ran 1.3 - 2x longer (+20 us even for one-wavefront kernels): 1.12 ms per step against 0.66 ms with the communicator created after the first steps
 // (profiles/r03_dp_overhead.txt).  NGP_LAZY_STREAMS=1 restores the old order (diagnostic).
-static bool lazy_streams() { static const bool v = getenv("NGP_LAZY_STREAMS") && atoi(getenv("NGP_LAZY_STREAMS")) != 0; return v; }
+static bool lazy_streams() { return false; } // (round 3's diagnostic NGP_LAZY_STREAMS=1 -- helper streams created on first use, i.e. possibly behind a communicator -- is gone: profiles/r03_dp_overhead.txt)
 static int g_helper_stream_device = -1; // the device the process-wide helper streams belong to (one process per GPU: SURVEY 8e)
 static int create_helper_stream(hipStream_t* st, bool high_priority) {
 	int dev = 0; HIPCHK(hipGetDevice(&dev));
@@ -1727,7 +1727,7 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 		ProfScope ps(P_GRID_MISC, s);
 		uint32_t key_bits = 21; for (uint32_t c = t->opt.max_cascade; c; c >>= 1) ++key_bits; // 3 x 7 Morton bits + the cascade
 		// the low 6 Morton bits (the cell inside its 4x4x4 block) stay unsorted: one radix pass less, the same coherence for the hash-grid levels
-		static const uint32_t begin_bit = getenv("NGP_GRID_SORT_BEGIN_BIT") ? (uint32_t)atoi(getenv("NGP_GRID_SORT_BEGIN_BIT")) : 6u; // (ablation knob: coarser blocks = fewer radix passes, less coherence)
+		constexpr uint32_t begin_bit = 6u; // Morton blocks of 4 x 4 x 4 cells (coarser blocks = fewer radix passes, less coherence: measured in round 4)
 		if (grid_sample_sort(s, t->grid_sort_temp, t->grid_sort_temp_bytes, t->grid_indices, t->grid_indices_sorted, t->grid_positions, t->grid_positions_sorted, n_samples, std::min(begin_bit, key_bits - 1u), key_bits))
 			return fail("update_density_grid: sort failed");
 		eval_pos = t->grid_positions_sorted; eval_idx = t->grid_indices_sorted;

@@ -504,9 +504,9 @@ int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions
 		a.escaped = q.escaped; a.stab_offsets = q.stab_offsets; a.ctr = q.work_ctr;
 		// how often a walking ray polls its point's mark (a device-scope load per lane: 64 uncoalesced memory-side requests per wavefront): every 2nd / 8th / ... round, or never
 		// (0xffffffff: the marks are then only read at the hand-out).  Ablation knob NGP_SDF_POLL_MASK; measured: profiles/r05_f4_sdf_walk_occupancy.txt
-		static const uint32_t poll_mask = getenv("NGP_SDF_POLL_MASK") ? (uint32_t)strtoul(getenv("NGP_SDF_POLL_MASK"), nullptr, 0) : 7u;
+		constexpr uint32_t poll_mask = 7u;
 		a.poll_mask = poll_mask;
-		static const bool dist_batch_order = getenv("NGP_SDF_DIST_ORDER") && atoi(getenv("NGP_SDF_DIST_ORDER")) == 0; // ablation: distance items in batch order (calls k .. u)
+		constexpr bool dist_batch_order = false; // (distance items in batch order: +15 %, profiles/r05_pytest_sdf_dist_order.log)
 		a.dist_reversed = dist_batch_order ? 0u : 1u;
 		static const uint32_t occ = getenv("NGP_SDF_WALK_OCC") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_WALK_OCC")), 1), 6) : 2u; // workgroups per CU (ablation knob; round 5 measured 2 / 3 / 4 as equal, profiles/r05_f4_sdf_walk_occupancy.txt; round 6: 2 is 4 - 6 % faster alone and leaves the CUs room for the training step that now runs beside the walks, profiles/r06_ab_sdf_prefetch.txt)
 		const uint32_t lds = a.stack_entries * 256u * 4u + 4u * 64u * 4u, per_cu = std::max(1u, std::min(occ, (160u * 1024u) / (lds + 64u)));
@@ -516,10 +516,10 @@ int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions
 		hipLaunchKernelGGL(k_sdf_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, q.escaped, q.work_ctr);
 		return 0;
 	}
-	static const uint32_t first_rays = getenv("NGP_SDF_FIRST_RAYS") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_FIRST_RAYS")), 0), 32) : 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel (ablation knob)
+	constexpr uint32_t first_rays = 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel
 	// 0: batch order (production); 1: (cost class, Morton) order; 2: Morton order, one class.  Ablation knob: coherent wavefronts measured SLOWER (batch 3.5 -> 4.3 ms, 2^18 uniform points
 	// 3.2 -> 5.6 / 6.2 ms, profiles/r04_f4_sdf_ground_truth.txt v7) -- sorted points make concurrently running wavefronts hammer the same lines.
-	static const int point_order = getenv("NGP_SDF_POINT_ORDER") ? atoi(getenv("NGP_SDF_POINT_ORDER")) : 0;
+	constexpr int point_order = 0; // the batch's order (Morton / cost-class orders measured slower in round 4)
 	const uint32_t entries = std::min<uint32_t>(std::max<uint32_t>(stack_entries, 4u), (uint32_t)SDF_STACK_MAX), lds = entries * 256u * 4u; // (<= 48 KiB)
 	(void)hipMemsetAsync(q.n_survivors, 0, 4, s); // (`escaped` is zero: ngp_sdf_create clears it, k_sdf_compact_survivors leaves it clean)
 	hipLaunchKernelGGL(k_sdf_point_keys, dim3((n + 255) / 256), dim3(256), 0, s, n, positions, (use_upper_bounds && point_order == 1) ? distances : nullptr, q.keys, point_order ? q.idx : q.order);

@@ -257,7 +257,8 @@ def test_flow_snapshot_written_elsewhere_continues_training(trained, scene_dir):
     # (it failed once in the round-5 final tier at 3.4e-4 against 1.7e-4).  A cold optimizer -- zero moments, step-1 debiasing -- takes lr-sized steps and lands at 1e-2.
     # Both continuations run with the deterministic K3 compaction (DBG_K3_TWO_PASS, process-wide: the flags live in libngp_hip.so, which pyngp and ctypes share): the same state
     # then sees the same batches in the same row order, and the re-encoded snapshot (half parameters cast up, uniform step counters) must stay within 1.5 x of the exact one --
-    # the relative yardstick of round 5 with its factor tightened, plus the round-4 absolute bar (3 x the fixture's recorded loss) on the MEDIAN instead of the maximum.
+    # the relative yardstick of round 5 with its factor tightened (2 -> 1.5 on the maximum), plus the same on the MEDIAN (the round-4 absolute bar, 3 x the ONE loss value the
+    # fixture recorded at step 400, measures that sample's luck: the per-step loss of this small scene scatters between 2e-5 and 5e-4, profiles/r06_final_pytest_gpu_first.log).
     import ctypes
     import ngp_abi
     lib = ngp_abi.load_hip()
@@ -269,7 +270,7 @@ def test_flow_snapshot_written_elsewhere_continues_training(trained, scene_dir):
         lib.ngp_debug_set_flags(0)
     print(f"trained loss {trained['loss']:.5f}; continued 40 steps: own snapshot max {max(native):.5f}, re-encoded snapshot first {losses[0]:.5f}, last {losses[-1]:.5f}, max {max(losses):.5f}")
     assert max(losses) < 1.5 * max(native) + 1e-4, "a cold optimizer (zero moments, step 1 debiasing) or mis-read state makes the first steps jump"
-    assert float(np.median(losses)) < 3.0 * trained["loss"] + 1e-4
+    assert float(np.median(losses)) < 1.25 * float(np.median(native)) + 1e-5   # (deterministic compaction: the two continuations see the same batches, so their medians are comparable to a quarter)
     snap2 = os.path.join(os.path.dirname(path), "again.ingp")
     t2.save_snapshot(snap2, True)
     a2 = msgpack.unpackb(zlib.decompress(open(snap2, "rb").read()), raw=False)["snapshot"]["optimizer"]["nested"]["nested"]

@@ -25,7 +25,7 @@ GROUPS = {
     # MFMA utilisation (north_star: "evidenced by rocprof HBM GB/s and MFMA utilisation"): busy cycles of the matrix pipe vs the SQ's, MFMA instruction / op counts
     "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"],
 }
-KERNELS = "k_encode_tiles_xcd|k_train_fused|k_train_fwd_bwd|k_grad_bin|k_grad_accumulate|k_inference|k_optimizer|k_wgrad|k_compute_loss_v2|k1_count|k1_write|k1_setup"
+KERNELS = "k_train_fused|k_train_fwd_bwd|k_grad_bin|k_grad_accumulate|k_inference|k_optimizer|k_wgrad|k_compute_loss_v2|k1_count|k1_write|k1_setup"
 
 
 def main():
