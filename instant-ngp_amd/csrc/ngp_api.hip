@@ -136,7 +136,9 @@ struct FlagScope {
 // (split = 0) or per (chunk, feature pair) (split = 1), and a list-capacity override (0 = twice the mean; small values force the
 // overflow path of k_grad_bin).  NGP_BIN_CHUNK_LOG2 / NGP_BIN_SPLIT / NGP_BIN_CAP in the environment set the defaults.
 static uint32_t env_u32(const char* name, uint32_t dflt) { const char* e = getenv(name); return e ? (uint32_t)strtoul(e, nullptr, 0) : dflt; }
-static uint32_t g_bin_chunk_log2 = env_u32("NGP_BIN_CHUNK_LOG2", 12) == 11 ? 11 : 12, g_bin_split = env_u32("NGP_BIN_SPLIT", 0) ? 1 : 0, g_bin_cap_override = env_u32("NGP_BIN_CAP", 0);
+// chunk = 2^11 table entries since round 6 (64 KiB of accumulators per k_grad_accumulate block, two per CU): the kernels' own times equal those of 2^12 (one 128 KiB block per CU),
+// but the step is 8-10 us shorter -- the next step's K1 (36 KiB of LDS per workgroup) then fits beside the accumulate blocks (profiles/r06_ab_bin_chunk_2048.txt; NGP_BIN_CHUNK_LOG2=12: rounds 2-5)
+static uint32_t g_bin_chunk_log2 = env_u32("NGP_BIN_CHUNK_LOG2", 11) == 12 ? 12 : 11, g_bin_split = env_u32("NGP_BIN_SPLIT", 0) ? 1 : 0, g_bin_cap_override = env_u32("NGP_BIN_CAP", 0);
 extern "C" int ngp_debug_set_bin_params(uint32_t chunk_log2, uint32_t split, uint32_t cap_override) {
 	if (chunk_log2 != 11 && chunk_log2 != 12) { g_err = "ngp_debug_set_bin_params: chunk_log2 must be 11 or 12"; return 1; }
 	g_bin_chunk_log2 = chunk_log2; g_bin_split = split ? 1 : 0; g_bin_cap_override = cap_override;

@@ -319,7 +319,7 @@ def test_training_step_gradients_full_batch_and_bin_layouts(ora, hip):
                 else:
                     assert report_true[k] < 2.0 * noise[k] + GRID_TRUE_TOL, (name, k, report_true[k], noise[k])    # half atomics: the reference's own kind of error
     finally:
-        A.check(hip, hip.ngp_debug_set_bin_params(12, 0, 0)); hip.ngp_debug_set_flags(0)
+        A.check(hip, hip.ngp_debug_set_bin_params(11, 0, 0)); hip.ngp_debug_set_flags(0)  # (11: the library default since round 6)
     # Bit-identical sums within one instantiation of T1 (the layouts with one block per chunk run the T1 without scatter code, the split ones
     # the T1 that issues the dense levels' atomics: the compiler contracts the MLP's fp operations differently in the two, so dL/d(enc)
     # differs in the last bit between them); in the one-block-per-chunk layouts the DENSE levels are exact sums as well.

@@ -162,7 +162,7 @@ def test_training_step_gradients_all_scatter_layouts(ora, hip, name):
             if res[l] ** 3 > offs[l + 1] - offs[l] and (1 << 12) <= offs[l + 1] - offs[l] <= (1 << 19):  # hashed and within the lists' table sizes
                 assert np.array_equal(got["chunk12"][lo:hi_], got["chunk11"][lo:hi_]), (name, "chunk11 != chunk12", l)
     finally:
-        A.check(hip, hip.ngp_debug_set_bin_params(12, 0, 0)); hip.ngp_debug_set_flags(0)
+        A.check(hip, hip.ngp_debug_set_bin_params(11, 0, 0)); hip.ngp_debug_set_flags(0)  # (11: the library default since round 6)
 
 
 @pytest.mark.parametrize("name", ["l16f2_t19", "l8f4_t15", "l8f4_t21", "l16f2_t15", "l8f4_rgb1", "l8f4_rgb3", "l16f2_rgb3_t15"])

@@ -14,7 +14,7 @@ import synth_scene
 
 # name: (debug flags, (bin chunk log2, split, cap), (k2 rounds, k2 tile width))
 VARIANTS = [
-    ("default", 0, (12, 0, 0), (1, 16)),
+    ("default", 0, (11, 0, 0), (1, 16)),   # 2048-entry chunks: the library default since round 6
     ("bin_no_dense_merge", 16777216, (12, 0, 0), (1, 16)),   # dense levels in the bin lists without run merging
     ("t1_dense_atomics", 8388608, (12, 0, 0), (1, 16)),   # dense levels as half atomics from T1 instead of through the bin lists
     ("grid_no_sort", 4194304, (12, 0, 0), (1, 16)),   # occupancy-grid update in generation order
@@ -29,13 +29,13 @@ VARIANTS = [
     ("separate_grad_memset", 131072, (12, 0, 0), (1, 16)),
     ("round1_backward", 32768 | 131072, (12, 1, 0), (1, 16)),
     ("bin_chunk12_split", 0, (12, 1, 0), (1, 16)),   # round-1 layout
-    ("bin_chunk11", 0, (11, 0, 0), (1, 16)),
+    ("bin_chunk12", 0, (12, 0, 0), (1, 16)),   # rounds 2-5: 4096-entry chunks, one 128 KiB accumulate block per CU
     ("k2_tile16_r4", 0, (12, 0, 0), (4, 16)),
     ("k2_eager", 8192, (12, 0, 0), (1, 16)),
     ("k1_no_first_point_skip", 268435456, (12, 0, 0), (1, 16)),   # k1_count evaluates the chunks behind the ray's exit as well (rounds 1-2)
     ("k3_one_ray_per_wave", 134217728, (12, 0, 0), (1, 16)),   # K3 with a whole wavefront per ray (rounds 1-2)
     ("k1_independent_lattice", 16384, (12, 0, 0), (1, 16)),
-    ("default_again", 0, (12, 0, 0), (1, 16)),
+    ("default_again", 0, (11, 0, 0), (1, 16)),
     ("t1_no_binning", 2048, (12, 0, 0), (1, 16)),
     ("t1_no_scatter", 2, (12, 0, 0), (1, 16)),
 ]
@@ -89,7 +89,7 @@ def main():
         r["_rays_per_batch"] = s.rays_per_batch; r["_rays_hit"] = s.n_rays_last; r["_before"] = s.measured_batch_size_before_compaction
         r["_k2_evals"] = s.network_evaluations; r["_loss"] = s.loss
         print(name, json.dumps(r), flush=True)
-    lib.ngp_debug_set_flags(0); lib.ngp_debug_set_bin_params(12, 0, 0)
+    lib.ngp_debug_set_flags(0); lib.ngp_debug_set_bin_params(11, 0, 0)
 
 
 if __name__ == "__main__":
