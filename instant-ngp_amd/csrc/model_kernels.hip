@@ -231,6 +231,9 @@ DEV void level_features4_x2(const __half* __restrict__ table, const LevelConst& 
 	ra = h4{a0[0], a0[1], a1[0], a1[1]}; rb = h4{b0[0], b0[1], b1[0], b1[1]};
 	__builtin_amdgcn_sched_barrier(0);
 }
+// (Round 6 also tried x-adjacent corner pairs as ONE 16-byte gather per lane where the table makes them neighbours -- always on dense levels, for even x on hashed ones --
+// with an exec-masked 8-byte load for the rest: 168 registers + 228 B of scratch and K2 106 -> 193 us, profiles/r06_ab_k2_pair_gathers_slower.txt.  Not kept; rounds 1 and 5
+// had measured the lane-pair + shuffle form and the L1-resident case with the same verdict.)
 // The level constants from a 16-byte-per-level LDS table {scale, resolution | hashed << 31, hashmap_size, offset} (fill_level_table) instead of from GridMeta in global memory:
 // level_const's `hi ? gm.x[l + 1] : gm.x[l]` compiles to four VECTOR global loads per level (the address depends on the lane), i.e. a second memory round trip in front
 // of every level's gathers -- the lazy K2 paid eight dependent round trips per tile where four are needed (round 6).
