@@ -101,8 +101,8 @@ def main():
                 rp.camera[k] = float(xf[k])
             rp.lens_mode = 0; rp.spp_index = 0; rp.snap_to_pixel_centers = 1; rp.min_transmittance = 1e-4; rp.near_distance = 0.0; rp.use_inference_params = 0
             rp.render_aabb = A.scene_aabb(1)
-            f = np.zeros((args.res * args.res, 4), np.float32)
-            assert ora.ora_nerf_render(ot, C.byref(rp), ptr(f), None) == 0
+            f = np.zeros((args.res * args.res, 4), np.float32); dep = np.zeros(args.res * args.res, np.float32)
+            assert ora.ora_nerf_render(ot, C.byref(rp), ptr(f), ptr(dep)) == 0
             out.append(srgb(f[:, :3]))
         return out
 
