@@ -2850,8 +2850,9 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a_in, uint32_t what) {
 	}
 	if (a.chunk_log2 == 11) {
 		if (do_bin) {
-			if (ns == 256) hipLaunchKernelGGL((k_grad_bin<11, 256>), gb, dim3(256), 0, s, a);
-			else hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
+			static const bool bin256 = getenv("NGP_BIN_THREADS_256") && atoi(getenv("NGP_BIN_THREADS_256")) != 0; // ablation: two samples per thread (what 2048-entry chunks ran until this commit)
+			if (bin256) hipLaunchKernelGGL((k_grad_bin<11, 512>), gb, dim3(256), 0, s, a);
+			else hipLaunchKernelGGL((k_grad_bin<11, 512, 4, 512>), gb, dim3(512), 0, s, a); // one sample per thread, as with 4096-entry chunks (round 3: 80 -> 66 us)
 		}
 		if (do_acc) {
 			if (a.fuse_adam && !a.split) hipLaunchKernelGGL((k_grad_accumulate<11, false, 4, true>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
