@@ -1288,7 +1288,8 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 		const uint32_t key_xy = cr.cell_xy, key_z = cr.cell_z;
 		const uint32_t pxy = (uint32_t)__shfl_up((int)key_xy, 1, 64), pz = (uint32_t)__shfl_up((int)key_z, 1, 64);
 		const bool pvalid = __shfl_up((int)valid[u], 1, 64) != 0;
-		const bool head = lane == 0 || key_xy != pxy || key_z != pz || !valid[u] || !pvalid;
+		// (runs are cut at the 16-lane DPP rows -- lanes 0, 16, 32, 48 are heads -- so that the reduction below stays inside a row: round 6)
+		const bool head = (lane & 15u) == 0u || key_xy != pxy || key_z != pz || !valid[u] || !pvalid;
 		const uint64_t hm = __ballot(head);
 		const bool merge = D == 3 && (a.merge_runs || (dense && !a.no_dense_merge)) && __popcll(hm) <= 48; // dense (coarse) levels: most lanes are followers
 		bool emit = valid[u];
@@ -1300,15 +1301,23 @@ __global__ void __launch_bounds__(THREADS) k_grad_bin(GradBinArgs a) {
 			for (int k = 0; k < NC; ++k) { const float w = cr.w[k];
 #pragma unroll
 				for (int f = 0; f < F; ++f) v[k][f] = g[f] * w; }
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
+			// segmented suffix sums by doubling, through DPP row shifts (v_mov_b32 row_shl:d: lane i reads lane i + d of its 16-lane row, 0 past the row's end) instead of
+			// __shfl_down = ds_bpermute_b32: 32 values x up to 4 steps were 128 LDS-pipe instructions per thread of a kernel that is VALU / LDS-issue bound (round 6).  A run never
+			// crosses a row (forced heads above), so a lane that takes never reads past its row.
+			auto step = [&](auto dconst) {
+				constexpr int d = decltype(dconst)::value;
 				const bool take = run_right >= (uint32_t)d;
-				if (__ballot(take) == 0ull) break; // no run reaches this far (wave-uniform): runs are a ray's samples in one cell, rarely longer than 8 - 16
+				if (__ballot(take) == 0ull) return false; // no run reaches this far (wave-uniform): runs are a ray's samples in one cell
 #pragma unroll
 				for (int k = 0; k < NC; ++k)
 #pragma unroll
-					for (int f = 0; f < F; ++f) { const float t = __shfl_down(v[k][f], d, 64); if (take) v[k][f] += t; }
-			}
+					for (int f = 0; f < F; ++f) {
+						const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k][f]), 0x100 + d, 0xf, 0xf, true));
+						v[k][f] += take ? t : 0.f;
+					}
+				return true;
+			};
+			if (step(std::integral_constant<int, 1>{}) && step(std::integral_constant<int, 2>{}) && step(std::integral_constant<int, 4>{})) (void)step(std::integral_constant<int, 8>{});
 			emit = valid[u] && head;
 #pragma unroll
 			for (int k = 0; k < NC; ++k) val[u][k] = pack_halfs<F>(v[k]);
