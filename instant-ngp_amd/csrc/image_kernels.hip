@@ -39,6 +39,7 @@ static __device__ __forceinline__ void eval_image_and_snap(const ImageBatchArgs&
 // generate_random_uniform [tcnn: element e <- draw e of the pcg32 stream] + stratify2_kernel + eval_image_kernel_and_snap
 __global__ void __launch_bounds__(256) k_image_generate_batch(ImageBatchArgs a) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0 && a.zero_word) *a.zero_word = 0.f;
 	if (i >= a.n) return;
 	Rng rng(a.rng);
 	rng.advance((uint64_t)i * 2ull);

@@ -1439,8 +1439,10 @@ DEV long long half_bits_to_fixed(uint32_t hbits) {
 //                  every record byte is fetched once;
 //   SPLIT = true:  one block = one chunk x one feature pair (round-1 layout: half the LDS, but both blocks fetch every record).
 // The block also empties its list for the next step (no separate reset launch).
-template <uint32_t CL2, bool SPLIT, int F = 4, bool ADAM = false>
-__global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
+// THREADS: 1024 (NeRF: lists of ~13 k records, 4096-entry epilogues) or 256 (the image primitive: 2048 blocks whose lists hold ~2 k records and whose chunks own a few hundred entries --
+// sixteen wavefronts per block were mostly launch and barrier cost there; round 6)
+template <uint32_t CL2, bool SPLIT, int F = 4, bool ADAM = false, uint32_t THREADS = 1024>
+__global__ void __launch_bounds__(THREADS) k_grad_accumulate(GradBinArgs a) {
 	static_assert(F == 4 || !SPLIT, "the split layout exists for F = 4 only");
 	static_assert(!ADAM || (F == 4 && !SPLIT), "the fused optimizer epilogue exists for the production layout (F = 4, one block per chunk)");
 	constexpr uint32_t E = 1u << CL2, NF = SPLIT ? 2u : (uint32_t)F;
@@ -1458,7 +1460,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	// launch 2048 blocks for 7 10^5 entries), not 2^CL2
 	const uint32_t n_entries = dense ? (hs > c ? (hs - c + (1u << NCH_LOG2) - 1u) >> NCH_LOG2 : 0u) : E;
 	if (n_raw == 0u && !(ADAM && !dense)) return; // nothing listed: the gradients stay what they are (zero: cleared by the optimizer sweep / the step's memset); the cursor is zero already
-	for (uint32_t f = 0; f < NF; ++f) for (uint32_t i = tid; i < n_entries; i += 1024) acc[f * E + i] = 0ull;
+	for (uint32_t f = 0; f < NF; ++f) for (uint32_t i = tid; i < n_entries; i += THREADS) acc[f * E + i] = 0ull;
 	__syncthreads(); // every thread has read the cursor
 	if (tid == 0) { // the list is empty again for the next step; SPLIT: the second of the two blocks that share it does that
 		uint32_t* done = a.cursor_done + ly * a.max_chunks + c;
@@ -1470,26 +1472,26 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	constexpr int U = 8; // records per thread in flight
 	if constexpr (SPLIT) {
 		const uint32_t* vals32 = (const uint32_t*)((const uint2*)a.vals + base) + fp; // this block's half2 of every 8-byte record
-		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+		for (uint32_t i0 = tid; i0 < n; i0 += U * THREADS) {
 			uint32_t v[U], id[U];
 #pragma unroll
-			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals32[(size_t)i * 2]; id[u] = idxs[i]; } }
+			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * THREADS; if (i < n) { v[u] = vals32[(size_t)i * 2]; id[u] = idxs[i]; } }
 #pragma unroll
 			for (int u = 0; u < U; ++u) {
-				if (i0 + u * 1024 >= n) break;
+				if (i0 + u * THREADS >= n) break;
 				atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u] & 0xffffu));
 				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
 			}
 		}
 	} else if constexpr (F == 4) {
 		const uint2* vals = (const uint2*)a.vals + base;
-		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+		for (uint32_t i0 = tid; i0 < n; i0 += U * THREADS) {
 			uint2 v[U]; uint32_t id[U];
 #pragma unroll
-			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals[i]; id[u] = idxs[i]; } }
+			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * THREADS; if (i < n) { v[u] = vals[i]; id[u] = idxs[i]; } }
 #pragma unroll
 			for (int u = 0; u < U; ++u) {
-				if (i0 + u * 1024 >= n) break;
+				if (i0 + u * THREADS >= n) break;
 				atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u].x & 0xffffu));
 				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u].x >> 16));
 				atomicAdd(&acc[2 * E + id[u]], (unsigned long long)half_bits_to_fixed(v[u].y & 0xffffu));
@@ -1498,13 +1500,13 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 		}
 	} else {
 		const uint32_t* vals = (const uint32_t*)a.vals + base;
-		for (uint32_t i0 = tid; i0 < n; i0 += U * 1024) {
+		for (uint32_t i0 = tid; i0 < n; i0 += U * THREADS) {
 			uint32_t v[U], id[U];
 #pragma unroll
-			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 1024; if (i < n) { v[u] = vals[i]; id[u] = idxs[i]; } }
+			for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * THREADS; if (i < n) { v[u] = vals[i]; id[u] = idxs[i]; } }
 #pragma unroll
 			for (int u = 0; u < U; ++u) {
-				if (i0 + u * 1024 >= n) break;
+				if (i0 + u * THREADS >= n) break;
 				atomicAdd(&acc[id[u]], (unsigned long long)half_bits_to_fixed(v[u] & 0xffffu));
 				atomicAdd(&acc[E + id[u]], (unsigned long long)half_bits_to_fixed(v[u] >> 16));
 			}
@@ -1513,7 +1515,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 	__syncthreads();
 	if constexpr (SPLIT) {
 		h2* gt = (h2*)((__half*)a.grid_grad_ + ((size_t)offset + ((size_t)c << CL2)) * 4) + fp;
-		for (uint32_t e = tid; e < E; e += 1024) {
+		for (uint32_t e = tid; e < E; e += THREADS) {
 			const h2 old = gt[(size_t)e * 2]; // zero unless a list overflowed
 			const float s0 = (float)(long long)acc[e] * 0x1p-24f, s1 = (float)(long long)acc[E + e] * 0x1p-24f;
 			const h2 r = {(_Float16)((float)old[0] + s0), (_Float16)((float)old[1] + s1)};
@@ -1529,7 +1531,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 			const AdamArgs& o = a.adam;
 			const bool overflow = n_raw > a.cap;
 			const uint64_t i4_0 = o.n_mlp / 4 + (uint64_t)offset + ((uint64_t)c << CL2); // index in 4-parameter units (= table entries behind the MLP block)
-			for (uint32_t e = tid; e < E; e += 1024) {
+			for (uint32_t e = tid; e < E; e += THREADS) {
 				const uint64_t i4 = i4_0 + e;
 				float r[4];
 #pragma unroll
@@ -1582,7 +1584,7 @@ __global__ void __launch_bounds__(1024) k_grad_accumulate(GradBinArgs a) {
 			}
 			return;
 		}
-		for (uint32_t e = tid; e < n_local; e += 1024) {
+		for (uint32_t e = tid; e < n_local; e += THREADS) {
 			const size_t o = dense ? ((size_t)e << NCH_LOG2) : (size_t)e;
 			const val_t oldv = gt[o]; // zero unless a list overflowed
 			const _Float16* old = (const _Float16*)&oldv;
@@ -2844,7 +2846,7 @@ void launch_grad_bin(hipStream_t s, const GradBinArgs& a_in, uint32_t what) {
 	if (a.n_features == 2 && a.n_pos_dims == 2) { // the image primitive's grid (encmlp trainer): 4 corners per sample
 		REQUIRE_VOID(a.chunk_log2 == 12);
 		if (do_bin) hipLaunchKernelGGL((k_grad_bin<12, 512, 2, 256, 2>), dim3((a.n + 511) / 512, a.n_hashed), dim3(256), 0, s, a);
-		if (do_acc) hipLaunchKernelGGL((k_grad_accumulate<12, false, 2>), dim3(a.max_chunks, ny, 1), dim3(1024), 0, s, a);
+		if (do_acc) hipLaunchKernelGGL((k_grad_accumulate<12, false, 2, false, 256>), dim3(a.max_chunks, ny, 1), dim3(256), 0, s, a);
 		return;
 	}
 	if (a.n_features == 2) { // L = 16, F = 2: one block per chunk, both features (4-byte record values)

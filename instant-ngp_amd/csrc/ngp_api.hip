@@ -654,6 +654,7 @@ struct ngp_encmlp {
 	float* wgrad_partials = nullptr; uint32_t n_partials = 0;
 	uint32_t step = 0; float lr = 1e-2f;
 	bool train_network = true, train_encoding = true;
+	bool grads_clean = false; // the grid part of `grads` is all zero (the optimizer sweep zeroed what it consumed): the next training step needs no memset launch
 	// scatter through the record lists (k_grad_bin / k_grad_accumulate, as in ngp_model): level-major dL/d(enc) + one list per (level, 4096-entry chunk)
 	void* denc_lv = nullptr; void* bin_vals = nullptr; void* bin_idxs = nullptr; uint32_t* bin_cursors = nullptr; uint32_t bin_n = 0, bin_cap = 0, bin_lists = 0;
 };
@@ -749,7 +750,9 @@ extern "C" void ngp_encmlp_destroy(ngp_encmlp* m) {
 }
 extern "C" int ngp_encmlp_n_params(const ngp_encmlp* m, uint64_t* n_params, uint64_t* n_mlp) { if (n_params) *n_params = m->n_params; if (n_mlp) *n_mlp = m->n_mlp; return 0; }
 extern "C" int ngp_encmlp_param_ptrs(ngp_encmlp* m, float** master, ngp_half** params, ngp_half** inf, ngp_half** grads) {
-	if (master) *master = m->master; if (params) *params = m->params; if (inf) *inf = m->params_inf; if (grads) *grads = m->grads; return 0;
+	if (master) *master = m->master; if (params) *params = m->params; if (inf) *inf = m->params_inf;
+	if (grads) { *grads = m->grads; m->grads_clean = false; } // (a caller that holds the pointer may write: the next training step clears the table itself again)
+	return 0;
 }
 extern "C" int ngp_encmlp_set_params_host(ngp_encmlp* m, const float* p, uint64_t n) {
 	REQUIRE(n == m->n_params, "encmlp set_params: size mismatch");
@@ -777,7 +780,7 @@ extern "C" int ngp_encmlp_inference(ngp_encmlp* m, void* stream, const float* in
 // Trainer::training_step(stream, input, target) (testbed_image.cu:289, testbed_sdf.cu:1557): forward, loss [tcnn l2 / mape / relative_l2 / l1],
 // backward, gradients overwritten.  `external`: dL/dy is given instead of targets (parity tests / callers with their own loss).
 static int encmlp_training_step(ngp_encmlp* m, hipStream_t s, const float* in, uint32_t in_stride, uint32_t n, const float* target, uint32_t target_stride,
-		int loss_type, float loss_scale, const ngp_half* dy, uint32_t dy_stride, float* loss_sum_dev, ngp_half* pred_out, uint32_t pred_stride) {
+		int loss_type, float loss_scale, const ngp_half* dy, uint32_t dy_stride, float* loss_sum_dev, ngp_half* pred_out, uint32_t pred_stride, bool loss_sum_is_zero = false) {
 	REQUIRE(m->cfg.n_output_dims <= 4, "encmlp training: at most 4 output dims (image: 3, SDF: 1)");
 	REQUIRE(in_stride >= m->cfg.n_pos_dims, "encmlp training: in_stride too small");
 	if (n > m->stash_n) {
@@ -788,8 +791,9 @@ static int encmlp_training_step(ngp_encmlp* m, hipStream_t s, const float* in, u
 		HIPCHK(hipMalloc(&m->dy_stash, (size_t)((n + 31) / 32) * 32 * 8));
 		m->stash_n = n;
 	}
-	HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); // GradientMode::Overwrite
-	if (loss_sum_dev) HIPCHK(hipMemsetAsync(loss_sum_dev, 0, 4, s));
+	if (!m->grads_clean) HIPCHK(hipMemsetAsync(m->grads + m->n_mlp, 0, (m->n_params - m->n_mlp) * 2, s)); // GradientMode::Overwrite (the optimizer sweep leaves the table zeroed: no launch then)
+	m->grads_clean = false;
+	if (loss_sum_dev && !loss_sum_is_zero) HIPCHK(hipMemsetAsync(loss_sum_dev, 0, 4, s));
 	// The encoding's backward pass through the record lists (round 4; rounds 2-3: atomicAdd(__half2) from the fused kernel, 2.2 ms per 2^18 SDF samples -- the memory side
 	// retires ~15 G atomic operations per second): every level -- hashed ones by 4096-entry chunk, dense ones interleaved over the 128 chunks -- is counting-sorted by
 	// k_grad_bin and summed exactly in LDS by k_grad_accumulate.  Needs base.json's table size (T = 2^19: all lists share one capacity); other sizes keep the atomics.
@@ -858,7 +862,7 @@ extern "C" int ngp_encmlp_optimizer_step(ngp_encmlp* m, void* stream, float loss
 	a.beta1 = m->opt.beta1; a.beta2 = m->opt.beta2; a.eps = m->opt.epsilon; a.l2_reg = m->opt.l2_reg;
 	a.log_beta1 = std::log(m->opt.beta1); a.log_beta2 = std::log(m->opt.beta2);
 	REQUIRE(65535.0f * a.log_beta1 < -18.f && 65535.0f * a.log_beta2 < -18.f, "Adam: beta too close to 1 for the 16-bit saturating per-parameter step counters (1 - beta^65535 must round to 1)");
-	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding; a.zero_grid_grads = 0;
+	a.optimize_matrix = m->train_network; a.optimize_non_matrix = m->train_encoding; a.zero_grid_grads = 1; // (the sweep clears the grid gradients it consumed, as in the NeRF model)
 	const float d = m->opt.ema_decay; // 0 without an Ema wrapper: the inference parameters then equal the parameters
 	a.ema_decay = d;
 	a.ema_debias_old = 1 - std::pow(d, (float)(m->step - 1));
@@ -868,6 +872,7 @@ extern "C" int ngp_encmlp_optimizer_step(ngp_encmlp* m, void* stream, float loss
 	a.fw_perm = m->fw_perm; a.bw_perm = m->bw_perm; a.fw_frags = m->fw_frags; a.bw_frags = m->bw_frags; a.fw_frags_inf = m->fw_frags_inf;
 	launch_optimizer_step((hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
+	m->grads_clean = true;
 	if (m->opt.decay_interval > 0 && m->step >= m->opt.decay_start && m->step % m->opt.decay_interval == 0) m->lr *= m->opt.decay_base;
 	return 0;
 }
@@ -923,9 +928,10 @@ extern "C" int ngp_image_train(ngp_image* t, void* stream, uint32_t n_steps) {
 			uint32_t l2 = 0; while ((1u << l2) < n) ++l2;
 			if ((1u << l2) == n && l2 % 2 == 0) a.stratify_log2 = l2;
 		}
+		a.zero_word = t->loss_sum; // (the step's loss sum starts from zero without a memset launch)
 		launch_image_generate_batch(s, a);
 		t->rng.advance((uint64_t)n * 2ull); // generate_random_uniform advances the generator by the number of elements [tcnn]
-		if (encmlp_training_step(t->model, s, t->positions, 2, n, t->targets, 3, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
+		if (encmlp_training_step(t->model, s, t->positions, 2, n, t->targets, 3, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0, true)) return 1;
 		if (ngp_encmlp_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 		++t->training_step;
 	}

@@ -272,6 +272,7 @@ struct ImageBatchArgs {
 	uint32_t n; ngp_pcg32 rng; uint32_t stratify_log2; // 0 = plain uniform positions
 	int snap_to_pixel_centers, linear_colors;
 	float* positions; float* targets; // vec2 / vec3 per sample
+	float* zero_word = nullptr;       // optional: one word this launch clears (the trainer's loss sum of the step that follows: no memset launch)
 };
 void launch_image_generate_batch(hipStream_t s, const ImageBatchArgs& a);
 void launch_image_pixel_batch(hipStream_t s, const ImageBatchArgs& a, uint32_t offset);
