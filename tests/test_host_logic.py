@@ -547,3 +547,34 @@ def test_image_mode_loads_bin_jpeg_png_natively(tmp_path):
             assert got.shape == (20, 31, 4) and np.abs(got - lin).max() < 1e-6, name
     finally:
         ngp._set_image_decoder(ngp._pil_decoder)
+
+
+def test_state_blob_layout_api():
+    """ngp_model_state_header / ngp_model_state_offset (round 6): the layout of ngp_model_serialize_host's payload for hosts that translate it into tcnn's per-optimizer
+    snapshot keys -- no caller carries a copy of the header struct.  Pure host functions: no GPU needed."""
+    lib = A.load_hip()
+    n = 1234
+    off = [int(lib.ngp_model_state_offset(C.c_uint64(n), k)) for k in range(6)]
+    assert off[0] > 0 and all(off[k + 1] - off[k] == 4 * n for k in range(5))     # a header, then sections of n_params x 4 bytes: master, Adam m, v, steps (u32), EMA
+    buf = (C.c_uint8 * off[5])()
+    npar, step, lr, wo = C.c_uint64(n), C.c_uint32(77), C.c_float(0.0033), C.c_uint32(1)
+    assert lib.ngp_model_state_header(buf, C.c_uint64(off[5]), 1, C.byref(npar), C.byref(step), C.byref(lr), C.byref(wo)) == 0
+    a, b, c, d = C.c_uint64(), C.c_uint32(), C.c_float(), C.c_uint32()
+    assert lib.ngp_model_state_header(buf, C.c_uint64(off[5]), 0, C.byref(a), C.byref(b), C.byref(c), C.byref(d)) == 0
+    assert (a.value, b.value, d.value) == (n, 77, 1) and abs(c.value - 0.0033) < 1e-9
+    buf[0] = 0  # a damaged magic is refused
+    assert lib.ngp_model_state_header(buf, C.c_uint64(off[5]), 0, C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0
+    assert lib.ngp_model_state_header(buf, C.c_uint64(4), 0, C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0  # truncated
+
+
+def test_config_from_json_reads_the_ema_kernel_switch():
+    """tcnn's EmaOptimizer hyperparameter "full_precision" (default false = ema_step_half_precision) -> ngp_model_config::ema_full_precision"""
+    lib = A.load_hip()
+    base = open(os.path.join(ROOT, "instant-ngp_amd", "configs", "nerf", "base.json")).read()
+    cfg = A.ModelConfig()
+    assert lib.ngp_model_config_from_json(base.encode(), 1, 0, C.byref(cfg)) == 0 and cfg.ema_full_precision == 0 and abs(cfg.ema_decay - 0.95) < 1e-7
+    import json as _json
+    import re as _re
+    j = _json.loads(_re.sub(r"//.*", "", base))
+    j["optimizer"]["full_precision"] = True
+    assert lib.ngp_model_config_from_json(_json.dumps(j).encode(), 1, 0, C.byref(cfg)) == 0 and cfg.ema_full_precision == 1
