@@ -56,7 +56,7 @@ def test_scene_from_a_nerf_synthetic_layout(tmp_path, monkeypatch):
     args = types.SimpleNamespace(scene="auto", images=6, res=64, eval_views=2, eval_res=64, eval_spp=1, batch=1 << 14)
     sc = bench.load_scene(args)
     assert sc["which"] == "lego" and sc["n"] == 6 and sc["aabb_scale"] == 1 and len(sc["eval"]) == 2
-    assert "held-out" in sc["eval_kind"] and sc["metric_scene"] == "nerf_synthetic/lego" and "synthetic" not in sc["data"].split()[0]
+    assert "held-out" in sc["eval_kind"] and sc["metric_scene"] == "nerf_synthetic/lego" and sc["data"].startswith("nerf_synthetic/lego") and sc["data"] != "synthetic"
     gt, rp = sc["eval"][0]
     assert tuple(gt.shape) == (64, 64, 4) and rp.resolution[0] == 64 and gt.is_cuda
     # the held-out cameras are NOT training cameras
