@@ -964,6 +964,7 @@ extern "C" int ngp_image_batch_ptrs(ngp_image* t, float** positions, float** tar
 // SDF trainer: Testbed::m_sdf, load_mesh (testbed_sdf.cu:1363-1447), generate_training_samples_sdf (:1449-1544), train_sdf (:1580-1622),
 // calculate_iou (:1636-1680); TriangleBvh::build (triangle_bvh.cu:757-840) as a binary tree
 // ------------------------------------------------------------------------------------------------
+static uint32_t sdf_default_batches_ahead();
 struct ngp_sdf {
 	ngp_encmlp* model = nullptr;
 	ngp_sdf_options opt{};
@@ -976,8 +977,12 @@ struct ngp_sdf {
 	void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
 	SdfQueryScratch query() const { return {stab_list, stab_list + cap, stab_count, stab_list + 2 * (size_t)cap, stab_list + 3 * (size_t)cap, stab_list + 4 * (size_t)cap, stab_list + 5 * (size_t)cap, sort_temp, sort_temp_bytes, stab_offsets, stab_count + 1}; }
 	Rng rng; uint32_t training_step = 0;
-	// batch n + 1 is generated (positions + ground truth: it depends on no parameter) on a side stream while batch n trains: a second batch-sized buffer pair and two events (round 6)
-	float* positions2 = nullptr; float* distances2 = nullptr; hipEvent_t ev_free = nullptr, ev_batch = nullptr;
+	// The batches ahead (positions + ground truth: they depend on the rng stream and the mesh, on no parameter) are generated on a side stream while the current ones train, a
+	// GROUP of batches per ground-truth launch (round 6): two group-sized buffer pairs and two events.  `start` = the rng state a group's first batch was drawn at: a group serves
+	// the trainer only while the trainer's own rng stands where the group's next batch begins (anything else that draws in between -- calculate_iou -- invalidates what was
+	// generated ahead; it is then generated again).
+	struct Group { float* positions = nullptr; float* distances = nullptr; uint32_t count = 0, next = 0; Rng start; bool in_flight = false; } group[2];
+	uint32_t cur_group = 0, group_cap = 0, batches_ahead = 0 /* ngp_sdf_set_batches_ahead; 0 = serial loop */; hipEvent_t ev_free = nullptr, ev_batch = nullptr;
 	float* batch_positions = nullptr; float* batch_distances = nullptr; // where the last trained batch lies (null: positions / distances)
 };
 // load_mesh's normalisation (testbed_sdf.cu:1380-1410): raw box inflated by 0.5 % of its diagonal, scaled by its largest extent and centred in the unit cube
@@ -1107,6 +1112,7 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 	ngp_sdf* t = new ngp_sdf();
 	t->model = model; t->opt = *o; t->aabb = aabb; t->n_triangles = n_triangles;
 	t->rng = make_rng(o->seed);
+	t->batches_ahead = sdf_default_batches_ahead();
 	std::vector<SdfTriangle> tris(n_triangles);
 	memcpy(tris.data(), triangles_host, (size_t)n_triangles * sizeof(SdfTriangle));
 	std::vector<SdfBvhNode> nodes;
@@ -1138,59 +1144,108 @@ extern "C" int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, ui
 extern "C" void ngp_sdf_destroy(ngp_sdf* t) {
 	if (!t) return;
 	(void)hipDeviceSynchronize();
-	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, (void*)t->stab_offsets, t->sort_temp, (void*)t->positions2, (void*)t->distances2}) if (p) (void)hipFree(p);
+	for (void* p : {(void*)t->tris, (void*)t->nodes, (void*)t->cdf, (void*)t->positions, (void*)t->distances, (void*)t->pred, (void*)t->loss_sum, (void*)t->iou_counters, (void*)t->stab_list, (void*)t->stab_count, (void*)t->stab_offsets, t->sort_temp, (void*)t->group[0].positions, (void*)t->group[0].distances, (void*)t->group[1].positions, (void*)t->group[1].distances}) if (p) (void)hipFree(p);
 	if (t->ev_free) (void)hipEventDestroy(t->ev_free);
 	if (t->ev_batch) (void)hipEventDestroy(t->ev_batch);
 	delete t;
 }
-// generate_training_samples_sdf: fills positions / distances for `n` samples and advances m_rng like the reference
-static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only, float* positions = nullptr, float* distances = nullptr) {
-	if (!positions) { positions = t->positions; distances = t->distances; }
+// generate_training_samples_sdf for `count` consecutive batches of `n` samples drawn from `rng` on (batch k at positions + k * n * 3 / distances + k * n); the ground truth of all
+// of them in one launch.  Returns the rng draws one batch consumes through *draws_per_batch; the caller's rng is not touched.
+static int sdf_generate_batches(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only, Rng rng, uint32_t count, float* positions, float* distances, uint64_t* draws_per_batch = nullptr) {
 	const uint32_t base = n / 8;
 	SdfSampleArgs a;
 	a.n = n; a.n_exact = uniform_only ? 0 : base * 4; a.n_surface = uniform_only ? 0 : base * 7;
-	a.rng = pod(t->rng);
 	a.stddev = std::sqrt(0.75f) / 1024.0f * t->opt.surface_offset_scale; // m_bounding_radius = length(vec3(0.5)) (testbed_sdf.cu:1424)
 	a.aabb = t->aabb;
 	for (int k = 0; k < 3; ++k) { a.aabb.min[k] -= t->opt.zero_offset; a.aabb.max[k] += t->opt.zero_offset; } // sdf_aabb.inflate(zero_offset)
-	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris; a.positions = positions; a.distances = distances;
-	launch_sdf_generate_positions(s, a);
-	t->rng.advance((uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull); // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
-	if (launch_sdf_signed_distance(s, n - a.n_exact, positions + (size_t)a.n_exact * 3, distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->query())) return fail("sdf ground truth: point sort failed");
+	a.cdf = t->cdf; a.n_triangles = t->n_triangles; a.triangles = t->tris;
+	const uint64_t draws = (uint64_t)n * 3ull + (uint64_t)(a.n_surface - a.n_exact) * 3ull; // generate_random_uniform(n * 3) + generate_random_logistic(n_offset * 3)
+	if (draws_per_batch) *draws_per_batch = draws;
+	REQUIRE((uint64_t)count * (n - a.n_exact) <= t->cap, "sdf ground truth: more points in one launch than the scratch holds");
+	for (uint32_t k = 0; k < count; ++k) {
+		a.rng = pod(rng); a.positions = positions + (size_t)k * n * 3; a.distances = distances + (size_t)k * n;
+		launch_sdf_generate_positions(s, a);
+		rng.advance(draws);
+	}
+	if (launch_sdf_signed_distance(s, n - a.n_exact, positions + (size_t)a.n_exact * 3, distances + a.n_exact, t->nodes, t->root, t->stack_entries, t->tris, 1, t->query(), count, n)) return fail("sdf ground truth: point sort failed");
 	HIPCHK(hipGetLastError());
+	return 0;
+}
+// one batch into the trainer's own buffers, advancing m_rng like the reference (calculate_iou's uniform points)
+static int sdf_generate(ngp_sdf* t, hipStream_t s, uint32_t n, bool uniform_only) {
+	// the ground-truth scratch is shared with whatever was generated ahead on the side stream
+	for (auto& g : t->group) if (g.in_flight) { HIPCHK(hipStreamSynchronize(g_side_stream)); g.in_flight = false; }
+	uint64_t draws = 0;
+	if (sdf_generate_batches(t, s, n, uniform_only, t->rng, 1, t->positions, t->distances, &draws)) return 1;
+	t->rng.advance(draws);
+	return 0;
+}
+static uint32_t sdf_default_batches_ahead() { // batches per ground-truth launch (NGP_SDF_GROUP; 1 = one batch ahead, round 6's first form; NGP_SDF_NO_PREFETCH=1: the serial loop)
+	static const bool no_prefetch = getenv("NGP_SDF_NO_PREFETCH") && atoi(getenv("NGP_SDF_NO_PREFETCH")) != 0;
+	static const uint32_t g = getenv("NGP_SDF_GROUP") ? (uint32_t)std::min(std::max(atoi(getenv("NGP_SDF_GROUP")), 1), 16) : 8u;
+	return no_prefetch ? 0u : g;
+}
+extern "C" int ngp_sdf_set_batches_ahead(ngp_sdf* t, uint32_t batches) {
+	REQUIRE(t && batches <= 16, "ngp_sdf_set_batches_ahead: 0 (serial loop) .. 16 batches per ground-truth launch");
+	t->batches_ahead = batches;
 	return 0;
 }
 extern "C" int ngp_sdf_train(ngp_sdf* t, void* stream, uint32_t n_steps) {
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n = t->opt.batch_size;
-	// The ground truth of a batch (BVH distance + stab rays: 2.6 ms, a launch as long as its longest walk with most lanes idle) depends on the rng stream and the mesh only, the
-	// training part (0.7 ms) on the batch: inside one call, batch i + 1 is generated on a side stream into the second buffer pair while batch i trains.  Same rng positions, same
-	// batches, same order of the training steps as the serial loop (NGP_SDF_NO_PREFETCH=1); nothing is pending when the call returns, so rng consumers between calls
-	// (calculate_iou) see the reference's order.
-	static const bool no_prefetch = getenv("NGP_SDF_NO_PREFETCH") && atoi(getenv("NGP_SDF_NO_PREFETCH")) != 0;
-	const bool prefetch = !no_prefetch && n_steps > 1 && !g_prof_on;
+	// The ground truth of a batch (BVH distance + stab rays) is a launch as long as its longest walk with most lanes idle: 2.2 ms for one batch, 2.6 for two, 4.0 for four; the step: serial loop 2.96 ms, 1 / 2 / 4 / 8 batches ahead 2.65 / 1.80 / 1.43 / 1.2 ms (profiles/r06_ab_sdf_batches_ahead.txt)
+	// (profiles/r06_exp_sdf_multibatch.jsonl), and it depends on the rng stream and the mesh only; the training part (0.5 - 0.7 ms) depends on the batch.  So the batches are
+	// generated a GROUP at a time, group k + 1 on a side stream while group k trains -- also across calls (the Testbed trains one step per call).  Same rng positions, same
+	// batches, same order of the training steps as the serial loop (ngp_sdf_set_batches_ahead(t, 0) / NGP_SDF_NO_PREFETCH=1).  The trainer's rng advances as batches are CONSUMED: a draw in between (calculate_iou)
+	// sees the reference's order, and what was generated ahead from a state that is not the trainer's any more is dropped.
+	const bool prefetch = t->batches_ahead > 0 && !g_prof_on;
+	const uint32_t n_bvh = n - n / 8 * 4;
+	const uint32_t G = prefetch ? std::max(1u, std::min(t->batches_ahead, t->cap / std::max(n_bvh, 1u))) : 1u;
+	if (t->group_cap < G) {
+		for (auto& g : t->group) {
+			if (g.in_flight) { HIPCHK(hipStreamSynchronize(g_side_stream)); g.in_flight = false; }
+			if (g.positions) (void)hipFree(g.positions);
+			if (g.distances) (void)hipFree(g.distances);
+			g.positions = nullptr; g.distances = nullptr; g.count = g.next = 0;
+			if (dev_alloc(&g.positions, (size_t)G * n * 3) || dev_alloc(&g.distances, (size_t)G * n)) return 1;
+		}
+		t->group_cap = G;
+	}
 	if (prefetch) {
-		if (!t->positions2 && (dev_alloc(&t->positions2, (size_t)n * 3) || dev_alloc(&t->distances2, n))) return 1;
 		if (create_helper_stream(&g_side_stream, false)) return 1;
 		if (!t->ev_free) { HIPCHK(hipEventCreateWithFlags(&t->ev_free, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_batch, hipEventDisableTiming)); }
 	}
-	float* pos[2] = {t->positions, t->positions2}; float* dst[2] = {t->distances, t->distances2};
-	uint32_t cur = 0;
-	bool have = false; // batch i is already in pos[cur] / dst[cur] (generated on the side stream during step i - 1)
+	uint64_t draws = 0;
+	{ const uint32_t base = n / 8; draws = (uint64_t)n * 3ull + (uint64_t)(base * 3) * 3ull; }
+	auto begins_at = [&](const ngp_sdf::Group& g, uint32_t k) { Rng r = g.start; r.advance(draws * k); return r.state == t->rng.state && r.inc == t->rng.inc; };
 	for (uint32_t i = 0; i < n_steps; ++i) {
-		if (!have && sdf_generate(t, s, n, false, pos[cur], dst[cur])) return 1; // training_prep_sdf with generate_sdf_data_online (the shuffle of train_sdf permutes a full batch: no effect on its sum)
-		const bool next = prefetch && i + 1 < n_steps;
-		if (next) { // the other pair was last read by step i - 1, the ground-truth scratch by batch i: both are behind this point of the caller's stream
-			HIPCHK(hipEventRecord(t->ev_free, s)); HIPCHK(hipStreamWaitEvent(g_side_stream, t->ev_free, 0));
-			if (sdf_generate(t, g_side_stream, n, false, pos[cur ^ 1u], dst[cur ^ 1u])) return 1;
-			HIPCHK(hipEventRecord(t->ev_batch, g_side_stream));
+		ngp_sdf::Group* g = &t->group[t->cur_group];
+		if (!(g->next < g->count && begins_at(*g, g->next))) {
+			ngp_sdf::Group* h = &t->group[t->cur_group ^ 1u];
+			if (h->count > 0 && h->next == 0 && begins_at(*h, 0)) { // the group generated ahead is the one that comes now
+				if (h->in_flight) { HIPCHK(hipStreamWaitEvent(s, t->ev_batch, 0)); h->in_flight = false; }
+			} else { // nothing usable ahead (first call, or somebody else drew from the rng): this step waits for its ground truth
+				if (h->in_flight) { HIPCHK(hipStreamWaitEvent(s, t->ev_batch, 0)); h->in_flight = false; } // (one scratch for every ground-truth launch)
+				h->count = std::min(G, n_steps - i); h->next = 0; h->start = t->rng;
+				if (sdf_generate_batches(t, s, n, false, h->start, h->count, h->positions, h->distances)) return 1; // training_prep_sdf with generate_sdf_data_online (the shuffle of train_sdf permutes a full batch: no effect on its sum)
+			}
+			t->cur_group ^= 1u; g = h;
+			if (prefetch) { // the next group into the pair that has just been used up: it was last read by the steps before this point of the caller's stream, and so was the scratch
+				ngp_sdf::Group* f = &t->group[t->cur_group ^ 1u];
+				f->count = G; f->next = 0; f->start = g->start; f->start.advance(draws * g->count);
+				HIPCHK(hipEventRecord(t->ev_free, s)); HIPCHK(hipStreamWaitEvent(g_side_stream, t->ev_free, 0));
+				if (sdf_generate_batches(t, g_side_stream, n, false, f->start, f->count, f->positions, f->distances)) return 1;
+				HIPCHK(hipEventRecord(t->ev_batch, g_side_stream));
+				f->in_flight = true;
+			}
 		}
-		if (encmlp_training_step(t->model, s, pos[cur], 3, n, dst[cur], 1, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
+		float* pos = g->positions + (size_t)g->next * n * 3; float* dst = g->distances + (size_t)g->next * n;
+		++g->next;
+		t->rng.advance(draws);
+		if (encmlp_training_step(t->model, s, pos, 3, n, dst, 1, t->opt.loss_type, t->opt.loss_scale, nullptr, 0, t->loss_sum, nullptr, 0)) return 1;
 		if (ngp_encmlp_optimizer_step(t->model, stream, t->opt.loss_scale)) return 1;
 		++t->training_step;
-		t->batch_positions = pos[cur]; t->batch_distances = dst[cur]; // ngp_sdf_batch_ptrs: the last trained batch
-		have = next;
-		if (next) { HIPCHK(hipStreamWaitEvent(s, t->ev_batch, 0)); cur ^= 1u; }
+		t->batch_positions = pos; t->batch_distances = dst; // ngp_sdf_batch_ptrs: the last trained batch
 	}
 	return 0;
 }
@@ -1220,6 +1275,7 @@ extern "C" int ngp_sdf_batch_ptrs(ngp_sdf* t, float** positions, float** distanc
 }
 extern "C" int ngp_sdf_signed_distance(ngp_sdf* t, void* stream, const float* positions, uint32_t n, float* out) {
 	REQUIRE(t && (n == 0 || (positions && out)), "ngp_sdf_signed_distance: null argument");
+	for (auto& g : t->group) if (g.in_flight) { HIPCHK(hipStreamSynchronize(g_side_stream)); g.in_flight = false; } // one scratch for every ground-truth launch
 	for (uint32_t done = 0; done < n; done += t->cap) // the survivor list of the stab rays holds t->cap points
 		if (launch_sdf_signed_distance((hipStream_t)stream, std::min(n - done, t->cap), positions + (size_t)done * 3, out + done, t->nodes, t->root, t->stack_entries, t->tris, 0, t->query())) return fail("sdf ground truth: point sort failed");
 	HIPCHK(hipGetLastError());

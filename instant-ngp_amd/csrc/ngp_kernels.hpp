@@ -306,7 +306,7 @@ size_t sdf_point_sort_temp_bytes(uint32_t n);
 void launch_sdf_stab_offsets(hipStream_t s, uint32_t n, float* offsets);
 int sdf_point_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n);
 int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries /* 3 * depth + 1 */,
-		const SdfTriangle* tris, int use_upper_bounds, const SdfQueryScratch& q);
+		const SdfTriangle* tris, int use_upper_bounds, const SdfQueryScratch& q, uint32_t groups = 1 /* the launch covers `groups` x n points: point j of group b at element b * group_stride + j */, uint32_t group_stride = 0);
 void host_sdf_signed_distance(uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, const SdfTriangle* tris, int use_upper_bounds); // test hook, host
 void launch_sdf_compare_signs(hipStream_t s, uint32_t n, const float* ref, const ngp_half* model, uint32_t model_stride, uint32_t* counters);
 

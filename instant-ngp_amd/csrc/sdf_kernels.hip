@@ -344,6 +344,7 @@ constexpr uint32_t SDF_REFILL_MIN = 16;   // idle lanes that make a wavefront lo
 constexpr uint32_t SDF_INNER_STEPS = 8;   // inner-node steps per round
 struct SdfWalkArgs {
 	uint32_t n, n_pad, stack_entries, poll_mask, dist_reversed; int root, use_upper_bounds; // poll_mask: a walking ray looks at its point's mark in the rounds with (round & poll_mask) == poll_mask
+	uint32_t m, groups, group_stride; // n = groups x m points: point j of group b lies at element b * group_stride + j of positions / distances, its lattice offset is stab_offsets[j] (round 6: the ground truth of several training batches in one launch)
 	const float* positions; float* distances; const SdfBvhNode4* nodes; const SdfTriangle* tris;
 	uint32_t* escaped; const float* stab_offsets; uint32_t* ctr; // ctr[0]: distance items reserved, ctr[1]: ray items reserved (zero on entry; k_sdf_finalize clears them)
 };
@@ -394,7 +395,8 @@ template <bool RAYS>
 static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLdsStack& st, uint32_t* s_pick) {
 	SdfFetch f;
 	bool busy = false, found = false;
-	uint32_t i = 0, round = 0;
+	uint32_t i = 0, round = 0; // i: the point's number in the launch (its mark), mi: its element in positions / distances
+	size_t mi = 0;
 	int ref = SDF_DONE, sp = 0;
 	f3 p = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f), inv = mk3(0.f, 0.f, 0.f);
 	float best = 0.f;
@@ -406,11 +408,16 @@ static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLd
 				busy = true; sp = 0; ref = a.root; round = 0;
 				const uint32_t r = RAYS ? item / a.n_pad : 0u;
 				// distance items from the END of the batch first: the launch is as long as its longest dependent chain, and the long distance walks (the uniform points, whose upper
-				// bound is the box diagonal: 163 rounds on average, up to ~530) sit behind the near-surface points in a training batch -- they must not start last
-				i = RAYS ? item - r * a.n_pad : (a.dist_reversed ? a.n - 1u - item : item);
-				p = mk3(a.positions[(size_t)i * 3], a.positions[(size_t)i * 3 + 1], a.positions[(size_t)i * 3 + 2]);
-				if (RAYS) { d = fibonacci_dir32(r, a.stab_offsets[2 * i], a.stab_offsets[2 * i + 1]); inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
-				else { const float md = a.use_upper_bounds ? a.distances[i] : SDF_MAX_DIST; best = md * md; found = false; }
+				// bound is the box diagonal: 163 rounds on average, up to ~530) sit behind the near-surface points in a training batch -- they must not start last.  With several
+				// batches in the launch the items interleave them (item -> batch item % groups, point m - 1 - item / groups), so that every batch's tail comes first.
+				uint32_t b, j;
+				if (RAYS) { i = item - r * a.n_pad; b = i / a.m; j = i - b * a.m; }
+				else if (a.dist_reversed) { const uint32_t q = item / a.groups; b = item - q * a.groups; j = a.m - 1u - q; i = b * a.m + j; }
+				else { i = item; b = i / a.m; j = i - b * a.m; }
+				mi = (size_t)b * a.group_stride + j;
+				p = mk3(a.positions[mi * 3], a.positions[mi * 3 + 1], a.positions[mi * 3 + 2]);
+				if (RAYS) { d = fibonacci_dir32(r, a.stab_offsets[2 * j], a.stab_offsets[2 * j + 1]); inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+				else { const float md = a.use_upper_bounds ? a.distances[mi] : SDF_MAX_DIST; best = md * md; found = false; }
 			}
 		}
 		if (!__ballot(busy)) break; // (the hand-out gives every idle lane an item unless the list is exhausted)
@@ -450,7 +457,7 @@ static __device__ __forceinline__ void sdf_walk_list(const SdfWalkArgs& a, SdfLd
 		}
 		if (busy && ref == SDF_DONE) {                         // nothing left to visit
 			if (RAYS) sdf_mark_set(a.escaped + i);             // the ray escaped: the point is outside
-			else a.distances[i] = found ? sqrtf(best) : 0.0f;  // "No closest triangle found": 0, as the reference (triangle_bvh.cu:562-566)
+			else a.distances[mi] = found ? sqrtf(best) : 0.0f; // "No closest triangle found": 0, as the reference (triangle_bvh.cu:562-566)
 			busy = false;
 		}
 	}
@@ -466,9 +473,9 @@ __global__ void __launch_bounds__(256, OCC) k_sdf_walks(SdfWalkArgs a) {
 	if ((blockIdx.x & 7u) == 0u) { sdf_walk_list<false>(a, st, s_pick); sdf_walk_list<true>(a, st, s_pick); }
 	else { sdf_walk_list<true>(a, st, s_pick); sdf_walk_list<false>(a, st, s_pick); }
 }
-__global__ void __launch_bounds__(256) k_sdf_finalize(uint32_t n, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ ctr) {
+__global__ void __launch_bounds__(256) k_sdf_finalize(uint32_t n, uint32_t m, uint32_t group_stride, float* __restrict__ distances, uint32_t* __restrict__ escaped, uint32_t* __restrict__ ctr) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) { if (escaped[i] == 0u) distances[i] = -distances[i]; escaped[i] = 0u; } // clean for the next call
+	if (i < n) { const uint32_t b = i / m; const size_t mi = (size_t)b * group_stride + (i - b * m); if (escaped[i] == 0u) distances[mi] = -distances[mi]; escaped[i] = 0u; } // clean for the next call
 	if (i == 0) { ctr[0] = 0u; ctr[1] = 0u; }
 }
 // the same functions on the host (test hook; the product never calls it)
@@ -494,11 +501,12 @@ __global__ void __launch_bounds__(256) k_sdf_compare_signs(uint32_t n, const flo
 void launch_sdf_stab_offsets(hipStream_t s, uint32_t n, float* offsets) { if (n) hipLaunchKernelGGL(k_sdf_stab_offsets, dim3((n + 255) / 256), dim3(256), 0, s, n, offsets); }
 void launch_sdf_generate_positions(hipStream_t s, const SdfSampleArgs& a) { if (a.n) hipLaunchKernelGGL(k_sdf_generate_positions, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions, float* distances, const SdfBvhNode4* nodes, int root, uint32_t stack_entries, const SdfTriangle* tris,
-		int use_upper_bounds, const SdfQueryScratch& q) {
-	if (!n) return 0;
+		int use_upper_bounds, const SdfQueryScratch& q, uint32_t groups, uint32_t group_stride) {
+	if (!n || !groups) return 0;
 	static const bool persistent = !(getenv("NGP_SDF_PERSISTENT") && atoi(getenv("NGP_SDF_PERSISTENT")) == 0); // 0: the round-4 three-launch path (ablation)
-	if (persistent) {
+	if (persistent || groups > 1) {
 		SdfWalkArgs a;
+		a.m = n; a.groups = groups; a.group_stride = groups > 1 ? group_stride : n; n *= groups; // n: points of the launch from here on
 		a.n = n; a.n_pad = (n + SDF_FETCH_CHUNK - 1u) / SDF_FETCH_CHUNK * SDF_FETCH_CHUNK; a.stack_entries = std::min<uint32_t>(std::max<uint32_t>(stack_entries, 4u), (uint32_t)SDF_STACK_MAX);
 		a.root = root; a.use_upper_bounds = use_upper_bounds; a.positions = positions; a.distances = distances; a.nodes = nodes; a.tris = tris;
 		a.escaped = q.escaped; a.stab_offsets = q.stab_offsets; a.ctr = q.work_ctr;
@@ -513,7 +521,7 @@ int launch_sdf_signed_distance(hipStream_t s, uint32_t n, const float* positions
 		// a grid of resident workgroups (no more than there are reservations to make)
 		const uint32_t grid = std::min<uint32_t>(256u * per_cu, (uint32_t)(((uint64_t)33u * a.n_pad / SDF_FETCH_CHUNK + 3u) / 4u) + 8u);
 		if (per_cu > 4u) hipLaunchKernelGGL(k_sdf_walks<6>, dim3(grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(k_sdf_walks<4>, dim3(grid), dim3(256), lds, s, a);
-		hipLaunchKernelGGL(k_sdf_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, distances, q.escaped, q.work_ctr);
+		hipLaunchKernelGGL(k_sdf_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, a.m, a.group_stride, distances, q.escaped, q.work_ctr);
 		return 0;
 	}
 	constexpr uint32_t first_rays = 4u; // stab rays walked next to the distance query before a point goes to the 32-lane kernel

@@ -139,3 +139,54 @@ def test_sdf_trainer_learns_the_mesh(hip):
     print(f"{name} ({len(tn)} triangles): IoU {iou0.value:.3f} -> {iou.value:.4f} after 500 steps, MAPE {loss.value:.4f}, {490 * o.batch_size / dt / 1e6:.1f} M samples/s ({dt / 490 * 1e3:.2f} ms/step incl. sample generation)")
     assert np.isfinite(loss.value) and iou.value > 0.95
     hip.ngp_sdf_destroy(t); hip.ngp_encmlp_destroy(hh)
+
+
+@pytest.mark.gpu
+def test_sdf_batches_ahead_equal_the_serial_loop(hip):
+    """ngp_sdf_train generates the batches a group at a time on a side stream, ahead of the training steps and across calls (one ground-truth launch per group); the batches, their
+    order and the rng positions other consumers see (calculate_iou) must be the serial loop's (generate -> train, testbed_sdf.cu:1580-1635): last trained batch bit-identical after
+    every call, for group sizes 1 / 3 / 4, with one-step calls, calls longer than a group and an IoU evaluation (which draws from the trainer's rng) in between."""
+    import torch
+    tris, name = _mesh()
+    verts = tris.reshape(-1, 3).copy()
+    box = A.Aabb(); scale = C.c_float()
+    A.check(hip, hip.ngp_sdf_normalize_mesh_host(ptr(verts), C.c_uint64(len(verts)), C.byref(box), C.byref(scale)))
+    tn = np.ascontiguousarray(verts.reshape(-1, 3, 3))
+    B = 1 << 13
+    calls = [3, 1, 1, 5, "iou", 2, 1, "sd", 4, 9]
+
+    def run(ahead):
+        cfg = A.sdf_encmlp_config()
+        hh = C.c_void_p(); A.check(hip, hip.ngp_encmlp_create(C.byref(cfg), C.c_uint64(1337), C.byref(hh)))
+        o = A.default_sdf_options(batch_size=B)
+        t = C.c_void_p(); A.check(hip, hip.ngp_sdf_create(hh, ptr(tn), len(tn), box, C.byref(o), C.byref(t)))
+        A.check(hip, hip.ngp_sdf_set_batches_ahead(t, ahead))
+        seen = []
+        for c in calls:
+            if c == "iou":
+                iou = C.c_double(); A.check(hip, hip.ngp_sdf_iou(t, 1 << 14, C.byref(iou))); seen.append(("iou", iou.value))
+            elif c == "sd":  # a ground-truth query of the caller's own points shares the scratch with what is generated ahead
+                p = torch.from_numpy(np.random.default_rng(5).uniform(0.2, 0.8, (777, 3)).astype(np.float32)).cuda(); d = torch.zeros(777, device="cuda")
+                A.check(hip, hip.ngp_sdf_signed_distance(t, None, C.c_void_p(p.data_ptr()), 777, C.c_void_p(d.data_ptr()))); torch.cuda.synchronize()
+                seen.append(("sd", d.cpu().numpy()))
+            else:
+                A.check(hip, hip.ngp_sdf_train(t, None, c)); torch.cuda.synchronize()
+                pp, dp = C.c_void_p(), C.c_void_p(); hip.ngp_sdf_batch_ptrs(t, C.byref(pp), C.byref(dp))
+                seen.append(("batch", _dev_read(pp.value, B * 3, np.uint32), _dev_read(dp.value, B, np.uint32)))
+        loss = C.c_float(); A.check(hip, hip.ngp_sdf_loss(t, None, C.byref(loss)))
+        hip.ngp_sdf_destroy(t); hip.ngp_encmlp_destroy(hh)
+        return seen, loss.value
+
+    ref, ref_loss = run(0)
+    assert any(np.any(a[2][B // 2:] != b[2][B // 2:]) for a, b in zip([r for r in ref if r[0] == "batch"][:-1], [r for r in ref if r[0] == "batch"][1:]))  # (the batches do differ from one another)
+    for ahead in (1, 3, 4):
+        got, loss = run(ahead)
+        for k, (r, g) in enumerate(zip(ref, got)):
+            if r[0] == "batch":
+                assert np.array_equal(r[1], g[1]) and np.array_equal(r[2], g[2]), f"{name}: batches_ahead {ahead}: the batch after call {k} ({calls[k]} steps) differs from the serial loop's"
+            elif r[0] == "sd":
+                assert np.array_equal(r[1], g[1])
+            else:
+                assert abs(r[1] - g[1]) < 0.02, (ahead, r[1], g[1])
+        assert abs(loss - ref_loss) <= 0.05 * abs(ref_loss) + 1e-4, (ahead, loss, ref_loss)
+        print(f"{name}: batches_ahead {ahead}: {sum(1 for r in ref if r[0] == 'batch')} batches bit-identical to the serial loop's, loss {loss:.5f} vs {ref_loss:.5f}")
