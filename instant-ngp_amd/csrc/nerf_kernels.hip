@@ -368,20 +368,40 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	}
 	__syncthreads();
 	uint64_t wave_total = 0ull; // packed {samples (low 32), rays with samples (high 32)} of this wavefront's rays
-	for (uint32_t li = li_begin + (threadIdx.x >> 6); li < li_end; li += 4) {
-	const RaySetup r = rs[li];
-	uint32_t cnt = 0, n_chunks = 0;
+	// Round 6: the workgroup marches FOUR rays at a time in two phases.  A ray's chunks used to be one wavefront's serial work -- and a launch lasts as long as its longest ray: on
+	// fox (aabb_scale 4: ~4.3 k rays per step, ~7 chunks on average, 32 at most) 8192 wavefronts held one ray or none and the kernel took 125 us for 12 us of average work.
+	//   phase A: the 4 x 4 (ray, group of eight chunks) evaluations of the batch, spread over the four wavefronts so that ONE ray's groups run side by side (task (k, g) -> wavefront
+	//            (k + g) mod 4); the chunk records {occupied mask, inside mask, mip, uniform?, per-point skip length} go to LDS;
+	//   phase B: wavefront k replays ray k's exit tests / exact-skip orbit over the records in chunk order -- the loop that used to follow each group's evaluation, word for word,
+	//            so masks, counts and n_chunks are those of the one-wavefront-per-ray kernel.
+	const uint32_t wid = threadIdx.x >> 6;
+	const uint32_t coarse_words = prefilter ? (SINGLE_CASCADE ? 1u : a.n_mips) * COARSE_WORDS : 0u;
+	uint64_t* s_m = (uint64_t*)(s_coarse + coarse_words);               // [4][LAT_MAX_CHUNKS]
+	uint64_t* s_in = s_m + 4 * LAT_MAX_CHUNKS;                          // [4][LAT_MAX_CHUNKS]
+	uint16_t* s_skip = (uint16_t*)(s_in + 4 * LAT_MAX_CHUNKS);          // [4][LAT_MAX_CHUNKS][64]
+	uint8_t* s_mip0 = (uint8_t*)(s_skip + 4 * LAT_MAX_CHUNKS * 64);     // [4][LAT_MAX_CHUNKS]: the chunk's mip (of its first point) | 0x80 if every inside point shares it
+	uint8_t* s_mark = s_mip0 + 4 * LAT_MAX_CHUNKS + wid * 64u;          // [4][64]: this wavefront's visited marks of the chunk it walks (phase B)
 	// The reference's skip rule differs from "every lattice point on its own" only where the mip changes along a skipped voxel, and the
 	// mip of a lattice point depends on dt only when cone_angle > 0 (mip_from_dt): with cone_angle == 0 both are the same algorithm.
 	const bool exact_skip = a.exact_skip != 0 && a.cone_angle_constant > 1e-5f;
-	if (r.flags) {
-		const Box aabb(a.aabb);
+	const Box aabb(a.aabb);
+	static_assert(LAT_MAX_CHUNKS == 4 * K1_GROUP, "k1_count: four groups of K1_GROUP chunks per ray, one per wavefront");
+	for (uint32_t lb = li_begin; lb < li_end; lb += 4) {
+	// ---- phase A ----
+#pragma unroll 1
+	for (uint32_t k = 0; k < 4; ++k) {
+		const uint32_t li = lb + k, g = (wid + 4u - k) & 3u, ch0 = g * K1_GROUP;
+		if (li >= li_end) break;
+		const RaySetup& r = rs[li];
+		if (!r.flags) continue; // the march starts outside the box (k1_setup): no record is read
 		const f3 ro = ld3(r.o), rdn = normalize3(ld3(r.d));
 		const f3 idir = mk3(1.0f) / rdn;
+		const float startt = r.startt, nprime = r.nprime;
+		auto lat_t = [&](uint32_t j) { return j == 0 ? startt : from_stepping_space(nprime + (float)j, a.cone_angle_constant); }; // lattice_t
 		// one lattice point per lane: inside the box? occupied at its own mip? (64 consecutive lattice points span ~14 voxels: the byte
 		// loads of a wavefront coalesce into a few L1/L2 lines, and thousands of resident wavefronts hide their latency)
 		auto eval_point = [&](uint32_t j, bool want_skip, bool& inside, bool& occ, uint32_t& mip, uint32_t& skip) {
-			const float t = lattice_t(r, j, a.cone_angle_constant);
+			const float t = lat_t(j);
 			const f3 pos = ro + t * rdn;
 			inside = aabb.contains(pos);
 			occ = false; mip = 0u; skip = 1u;
@@ -400,9 +420,34 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 				}
 			}
 		};
-		// Eight chunks are tested per iteration so that eight independent occupancy loads are in flight (the loop is a
-		// chain of dependent ~1 us loads otherwise); the exit tests are then replayed in chunk order, so masks, counts
-		// and n_chunks are exactly those of the one-chunk-at-a-time loop.
+		// The in-box lattice points of a ray are a contiguous range (every coordinate of ro + t * rdn is monotonic in t, in fp32 as well, and so is t in
+		// j), so a chunk whose FIRST point is outside the box lies wholly outside: one test per chunk (lane u = chunk u of the group) instead of 64 point
+		// evaluations (same masks: a chunk evaluated outside the box yields exactly these values).
+		const uint32_t first_in = (uint32_t)(__ballot(lane < K1_GROUP && aabb.contains(ro + lat_t((ch0 + (lane < K1_GROUP ? lane : 0u)) * 64u) * rdn)) & ((1ull << K1_GROUP) - 1ull));
+		// Eight chunks per task so that eight independent occupancy loads are in flight (a chain of dependent ~1 us loads otherwise)
+#pragma unroll
+		for (uint32_t u = 0; u < K1_GROUP; ++u) {
+			uint64_t m = 0ull, in = 0ull; uint32_t mip0 = 0u; bool uni = true; uint32_t skip = 1u;
+			if (((first_in >> u) & 1u) || a.no_first_point_skip) {
+				bool inside, occ; uint32_t mip;
+				eval_point((ch0 + u) * 64 + lane, exact_skip, inside, occ, mip, skip);
+				m = __ballot(occ);
+				in = __ballot(inside);
+				mip0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mip);
+				uni = __ballot(inside && mip != mip0) == 0ull;
+			}
+			const uint32_t rec = k * LAT_MAX_CHUNKS + ch0 + u;
+			if (lane == 0) { s_m[rec] = m; s_in[rec] = in; s_mip0[rec] = (uint8_t)(mip0 | (uni ? 0x80u : 0u)); }
+			if (exact_skip) s_skip[rec * 64u + lane] = (uint16_t)min(skip, 0xffffu); // (a jump past the lattice's 2048 points ends the march whatever its length)
+		}
+	}
+	__syncthreads();
+	// ---- phase B ----
+	if (lb + wid < li_end) {
+	const uint32_t li = lb + wid;
+	const uint32_t ray_flags = rs[li].flags;
+	uint32_t cnt = 0, n_chunks = 0;
+	if (ray_flags) {
 		bool done = false, prev_walked = false;
 		uint32_t jnext = 0;        // exact skip: next lattice point the reference's loop visits (valid while prev_walked)
 		uint32_t prev_mip = 0xffu; // mip of the previous chunk if it was uniform
@@ -413,21 +458,13 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		for (uint32_t ch0 = 0; ch0 < LAT_MAX_CHUNKS && !done; ch0 += K1_GROUP) {
 			uint64_t m[K1_GROUP], in[K1_GROUP];
 			uint32_t mip0[K1_GROUP]; bool uni[K1_GROUP]; // exact skip: the chunk's mip (of its first point) / is it the same for all points inside the box?
-			// The in-box lattice points of a ray are a contiguous range (every coordinate of ro + t * rdn is monotonic in t, in fp32 as well, and so is t in
-			// j), so a chunk whose FIRST point is outside the box lies wholly outside: one test per chunk (lane u = chunk u of the group) instead of 64 point
-			// evaluations.  A ray crosses ~9 chunks, the groups are 8 wide: this skips the ~6 chunks behind the exit that the last group used to evaluate
-			// (same masks: a chunk evaluated outside the box yields exactly these values).
-			const uint32_t first_in = (uint32_t)(__ballot(lane < K1_GROUP && aabb.contains(ro + lattice_t(r, (ch0 + (lane < K1_GROUP ? lane : 0u)) * 64u, a.cone_angle_constant) * rdn)) & ((1ull << K1_GROUP) - 1ull));
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
-				if (!((first_in >> u) & 1u) && !a.no_first_point_skip) { m[u] = 0ull; in[u] = 0ull; mip0[u] = 0u; uni[u] = true; continue; }
-				bool inside, occ; uint32_t mip, skip;
-				eval_point((ch0 + u) * 64 + lane, false, inside, occ, mip, skip);
-				m[u] = __ballot(occ);
-				in[u] = __ballot(inside);
-				mip0[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)mip);
-				uni[u] = __ballot(inside && mip != mip0[u]) == 0ull;
+				const uint32_t rec = wid * LAT_MAX_CHUNKS + ch0 + u;
+				m[u] = s_m[rec]; in[u] = s_in[rec];
+				const uint32_t q = s_mip0[rec]; mip0[u] = q & 0x7fu; uni[u] = (q & 0x80u) != 0u;
 			}
+			// the exit tests are replayed in chunk order, so masks, counts and n_chunks are exactly those of the one-chunk-at-a-time loop
 #pragma unroll
 			for (uint32_t u = 0; u < K1_GROUP; ++u) {
 				if (done || cnt >= N_STEPS) { done = true; break; }
@@ -440,22 +477,35 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 					const bool next_same = u + 1 < K1_GROUP && (in[u + 1 < K1_GROUP ? u + 1 : u] == 0ull || (uni[u + 1 < K1_GROUP ? u + 1 : u] && mip0[u + 1 < K1_GROUP ? u + 1 : u] == mip0[u]));
 					const bool plain = uni[u] && prev_mip == mip0[u] && next_same;
 					if (!plain) {
-						bool inside, occ; uint32_t mip, skip;
-						eval_point((ch0 + u) * 64 + lane, true, inside, occ, mip, skip);
+						// The orbit of the reference's update rule through the chunk: an occupied point goes to its successor, an empty one jumps by its skip length, a point
+						// outside the box ends the march.  One scalar step per visited point (~100 cycles each) made a far chunk -- step ~ voxel, every jump one or two points
+						// long -- cost ~5 us, and a fox ray has thirty of them: the kernel's critical path.  Here the orbit is marked by pointer doubling over the 64 lanes
+						// (round k: the visited set, a prefix of the orbit of length 2^k, is joined by its image under next^(2^k)): <= 6 rounds of three LDS operations,
+						// ended as soon as a round adds nothing.
+						const uint32_t skip = s_skip[(size_t)(wid * LAT_MAX_CHUNKS + ch0 + u) * 64u + lane]; // the jump lengths of the chunk's points (phase A), one per lane
 						const uint32_t base = (ch0 + u) * 64;
-						sm = 0ull;
-						uint32_t j = (prev_walked && jnext > base) ? jnext - base : 0u; // behind a plain chunk of the same mip the entry point is immaterial
-						while (j < 64u) {
-							if (!((in[u] >> j) & 1ull)) { done = true; break; } // the march left the box
-							const uint64_t rest = ~(m[u] >> j); // bit 0 = 1 <=> point j is empty
-							const uint32_t run = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
-							if (run) {
-								const uint32_t len = min(run, 64u - j);
-								sm |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << j;
-								j += len;
-							} else j += (uint32_t)__builtin_amdgcn_readlane((int)skip, (int)__builtin_amdgcn_readfirstlane((int)j));
-						}
-						jnext = base + j;
+						const uint32_t j0 = (prev_walked && jnext > base) ? jnext - base : 0u; // behind a plain chunk of the same mip the entry point is immaterial
+						const uint32_t nxt = ((m[u] >> lane) & 1ull) ? lane + 1u : ((in[u] >> lane) & 1ull) ? lane + skip : 0x10000u;
+						uint64_t V = j0 < 64u ? 1ull << j0 : 0ull;
+						if (V) {
+							uint32_t J = nxt;
+							s_mark[lane] = 0;
+#pragma unroll 1
+							for (int k = 0; k < 6; ++k) {
+								if (((V >> lane) & 1ull) && J < 64u) s_mark[J] = 1;
+								__builtin_amdgcn_wave_barrier(); // (a wavefront's LDS operations complete in order)
+								const uint64_t Vn = V | __ballot(s_mark[lane] != 0);
+								if (Vn == V) break;
+								V = Vn;
+								const uint32_t Jn = (uint32_t)__shfl((int)J, (int)(J & 63u), 64);
+								J = J < 64u ? Jn : J;
+							}
+							__builtin_amdgcn_wave_barrier();
+							sm = V & m[u];
+							if (V & ~in[u]) done = true; // the march left the box
+							const uint32_t jlast = 63u - (uint32_t)__builtin_clzll(V);
+							jnext = base + (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)jlast);
+						} else { sm = 0ull; jnext = base + j0; }
 					}
 					prev_walked = !plain;
 					prev_mip = uni[u] ? mip0[u] : 0xffu;
@@ -473,6 +523,8 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 		rs[li].flags = n_chunks;
 	}
 	wave_total += (uint64_t)cnt | ((uint64_t)(cnt > 0 ? 1u : 0u) << 32);
+	}
+	__syncthreads(); // the records are rewritten by the next batch (and rs[].flags, which phase A reads, by this phase)
 	}
 	k1_publish_and_scan(a, wave_total, partial, done, s_tot, s_scan, s_ticket);
 }
@@ -1739,10 +1791,10 @@ void launch_generate_training_samples(hipStream_t s, const K1Args& a, uint32_t m
 // persistent grid: up to 8 workgroups of 4 wavefronts per CU; every workgroup owns at most K1_MAX_RANGE consecutive slots
 // The marcher's grid must equal the number of RESIDENT workgroups: every workgroup owns a contiguous slot range, so workgroups that start only when others retire
 // are a second round at partial occupancy.  k1_count<8, true> (one cascade) holds 77 registers = 6 workgroups of 4 wavefronts per CU -- the grid of 8 per CU used up
-// to round 3a ran 1.33 rounds: K1 0.181 -> 0.171 ms, step 0.600 -> 0.587 ms with 6 (profiles/r03_microbench_k1_grid.log).  k1_count<8, false> (98 registers, 4 per CU)
-// keeps 8 = two full rounds.  Scratch is sized for the largest grid.
+// to round 3a ran 1.33 rounds: K1 0.181 -> 0.171 ms, step 0.600 -> 0.587 ms with 6 (profiles/r03_microbench_k1_grid.log).  k1_count<8, false>: one round as well since
+// round 6 (its critical path is a workgroup's batches of four rays).  Scratch is sized for the largest grid.
 constexpr uint32_t K1_MAX_BLOCKS_PER_CU = 16;
-static uint32_t k1_blocks_per_cu(bool single_cascade) { return single_cascade ? 6u : 8u; }
+static uint32_t k1_blocks_per_cu(bool single_cascade) { return single_cascade ? 6u : 4u; } // (multi-cascade, two-phase kernel with ~50 KiB of LDS: fox step 556 / 525 / 525 / 528 us at 8 / 4 / 3 / 2, profiles/r06_ab_k1_count_two_phase.txt)
 static uint32_t k1_blocks_per_cu_segments() { return 4u; } // (36 KiB of LDS per workgroup)
 static uint32_t k1_grid(uint32_t max_local_rays, uint32_t blocks_per_cu = K1_MAX_BLOCKS_PER_CU) { return std::max(std::min<uint32_t>(blocks(max_local_rays, 4), 256u * blocks_per_cu), blocks(max_local_rays, K1_MAX_RANGE)); }
 // byte offset of the workgroup totals behind the RaySetup and mask arrays (64-bit atomics: naturally aligned)
@@ -1790,8 +1842,10 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 		return;
 	}
 	// 8 chunks (512 lattice points) in flight per iteration; 16 measured slower (143 -> 159 us: SGPR pressure, profiles/r02_k1_experiments.txt)
-	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
-	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), a.bitfield_coarse ? a.n_mips * COARSE_WORDS * 4 : 0, s, a, rs, masks, partial, done);
+	constexpr uint32_t rec_bytes = 4u * LAT_MAX_CHUNKS * (8u + 8u + 64u * 2u + 1u) + 4u * 64u; // k1_count's chunk records of four rays: masks, skip lengths, mip; the walk's marks
+	const bool prefilter = a.bitfield_coarse != nullptr && a.bitfield_linear != nullptr;
+	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), (prefilter ? COARSE_WORDS * 4 : 0) + rec_bytes, s, a, rs, masks, partial, done);
+	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), (prefilter ? a.n_mips * COARSE_WORDS * 4 : 0) + rec_bytes, s, a, rs, masks, partial, done);
 	if (!count_only) hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {
