@@ -247,10 +247,10 @@ def test_flow_snapshot_written_elsewhere_continues_training(trained, scene_dir):
         assert t.training_step == 400
         t.shall_train = True
         losses = []
-        for _ in range(40):
+        for _ in range(96): # (Testbed::train reads the loss back every 16th step: 96 frames = six loss samples, 40 were three)
             t.frame()
             losses.append(t.loss)
-        assert t.training_step == 440 and np.isfinite(losses).all()
+        assert t.training_step == 496 and np.isfinite(losses).all()
         return t, losses
     # The yardstick is the SAME continuation from this library's own snapshot (fp32 masters and per-parameter counters included): on this small scene the loss of a
     # 2^16-sample batch scatters between 2e-5 and 4e-4 from step to step, so a bound against the one value the fixture happened to record at step 400 is a coin toss
@@ -268,13 +268,16 @@ def test_flow_snapshot_written_elsewhere_continues_training(trained, scene_dir):
         t2, losses = continue_from(path)
     finally:
         lib.ngp_debug_set_flags(0)
-    print(f"trained loss {trained['loss']:.5f}; continued 40 steps: own snapshot max {max(native):.5f}, re-encoded snapshot first {losses[0]:.5f}, last {losses[-1]:.5f}, max {max(losses):.5f}")
+    print(f"trained loss {trained['loss']:.5f}; continued 96 steps: own snapshot max {max(native):.5f}, re-encoded snapshot first {losses[0]:.5f}, last {losses[-1]:.5f}, max {max(losses):.5f}")
     assert max(losses) < 1.5 * max(native) + 1e-4, "a cold optimizer (zero moments, step 1 debiasing) or mis-read state makes the first steps jump"
-    assert float(np.median(losses)) < 1.25 * float(np.median(native)) + 1e-5   # (deterministic compaction: the two continuations see the same batches, so their medians are comparable to a quarter)
+    # (deterministic compaction: the two continuations draw the same rays; their parameters differ by the masters' low bits, so the per-batch losses -- six read-backs each, scattering
+    # between 2e-5 and 5e-4 on this scene -- agree in the mean, not sample by sample: the round's 1.25 x bar on the median of THREE samples failed once by 9 %,
+    # profiles/r06_s2_pytest_gpu.log.  What the bar separates is a cold or mis-read optimizer: 1e-2, fifty times the trained level.)
+    assert float(np.mean(losses)) < 1.5 * float(np.mean(native)) + 5e-5
     snap2 = os.path.join(os.path.dirname(path), "again.ingp")
     t2.save_snapshot(snap2, True)
     a2 = msgpack.unpackb(zlib.decompress(open(snap2, "rb").read()), raw=False)["snapshot"]["optimizer"]["nested"]["nested"]
-    assert a2["current_step"] == 440 and np.frombuffer(a2["param_steps_binary"], np.uint32)[:10240].min() == 440
+    assert a2["current_step"] == 496 and np.frombuffer(a2["param_steps_binary"], np.uint32)[:10240].min() == 496
 
 
 @pytest.mark.gpu
