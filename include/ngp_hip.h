@@ -457,6 +457,10 @@ int ngp_nerf_get_stats(ngp_nerf*, void* stream, ngp_nerf_stats* out_host);
 int ngp_nerf_update_density_grid(ngp_nerf*, void* stream, float decay, uint32_t n_uniform, uint32_t n_nonuniform);
 /* device pointers: density grid (float, 128^3*(max_cascade+1)), bitfield (128^3/8*8), mean (1 float) */
 int ngp_nerf_density_grid_ptrs(ngp_nerf*, float** grid, uint8_t** bitfield, float** mean);
+/* Diagnostic / test hook.  update_density_grid_nerf's samples (generate_grid_samples_nerf_nonuniform x 2, testbed_nerf.cu:2525-2557) depend on the grid rng, the EMA step and the grid
+ * as the previous update left it -- on no parameter: the trainer draws and sorts the NEXT update's samples on a side stream while the steps in between train, and uses them if
+ * nothing they were derived from has changed by then.  Returns how many updates found their samples ready.  (DBG2 bit 4 / NGP_GRID_NO_AHEAD=1: inside the update, as before.) */
+uint32_t ngp_nerf_grid_ahead_hits(ngp_nerf*);
 int ngp_nerf_set_density_grid_host(ngp_nerf*, void* stream, const float* grid_host, uint64_t n);
 /* m_training_step restored by load_snapshot (testbed.cu:5400-5403). */
 int ngp_nerf_set_training_step(ngp_nerf*, uint32_t step);
@@ -562,7 +566,7 @@ int ngp_host_sdf_signed_distance(const float* triangles_host, uint32_t n_triangl
 int ngp_debug_set_flags(uint32_t flags);
 /* The switches in effect (NGP_DEBUG_FLAGS_OR from the environment included); 0 = the production path. */
 uint32_t ngp_debug_get_flags(void);
-/* second word of ablation switches (DBG2_* of csrc/ngp_kernels.hpp; NGP_DEBUG_FLAGS2_OR): 1 = the backward pass as T1 + W, two kernels (round 4), instead of k_train_fused */
+/* second word of ablation switches (DBG2_* of csrc/ngp_kernels.hpp; NGP_DEBUG_FLAGS2_OR): 1 = the backward pass as T1 + W, two kernels (round 4), instead of k_train_fused; 4 = the occupancy-grid update draws its samples itself */
 int ngp_debug_set_flags2(uint32_t flags);
 uint32_t ngp_debug_get_flags2(void);
 /* The same switches PER HANDLE: a handle with an override (on != 0) runs its calls (training step, inference, rendering, grid update, optimizer) under `flags` / `flags2`

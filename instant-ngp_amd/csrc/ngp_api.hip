@@ -177,6 +177,8 @@ static int create_helper_stream(hipStream_t* st, bool high_priority) {
 // neither adds hardware queues -- two trainers with their own streams ran the second one at 1.17 instead of 0.78 ms per step,
 // profiles/r03_bench_n1_slow_box.json -- nor creates streams behind a communicator that exists by then.  ngp_init() creates them explicitly for hosts
 // that set up communication before their first model.
+// (Three helper streams + the caller's = the four hardware queues HIP maps streams onto by default.  A FIFTH stream shares a queue with another one: measured with one more helper stream
+// merely created and used once per 16 steps -- every step 445 -> 660 us, all of it gaps between kernels whose own times did not change, profiles/r06_ab_grid_samples_ahead.txt.)
 static hipStream_t g_side_stream = nullptr, g_side2_stream = nullptr, g_k1_stream = nullptr, g_comm_stream = nullptr;
 static int ensure_helper_streams() { return create_helper_stream(&g_side_stream, false) || create_helper_stream(&g_k1_stream, true) || create_helper_stream(&g_comm_stream, true); }
 extern "C" int ngp_init(void) {
@@ -1606,6 +1608,10 @@ struct ngp_nerf {
 	// host-side deterministic state (no device read-back needed)
 	Rng rng, density_grid_rng;
 	uint32_t training_step = 0, prep_skip_counter = 0, ema_step = 0;
+	// the NEXT occupancy-grid update's samples (generation + sort: they depend on the grid rng, the EMA step and the grid as the last update left it -- on no parameter), drawn on a
+	// side stream while the steps in between train; used if nothing they were derived from has changed by then (grid_ahead_matches), dropped otherwise
+	struct GridAhead { bool valid = false, in_flight = false, sorted = false; uint32_t n_uniform = 0, n_nonuniform = 0, ema_step = 0; Rng rng; uint64_t state_version = 0; } grid_ahead;
+	hipEvent_t ev_grid_free = nullptr, ev_grid_ahead = nullptr; uint32_t grid_ahead_hits = 0;
 	uint32_t max_rays = 1u << 18;
 	// extra (latent / light-direction) dims, testbed.h Nerf::Training::extra_dims_gpu / extra_dims_opt / rendering_extra_dims: n_extra floats per image (+ one slot behind them
 	// for the dims a rendering uses), their gradient, the per-image VarAdamOptimizer state (adam_optimizer.h:27-47; one iteration count: every image steps every time)
@@ -1679,6 +1685,8 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (t->k1_prelaunched && t->k1_stream) (void)hipStreamSynchronize(t->k1_stream); // (process-wide stream: not destroyed with the trainer)
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
+	if (t->ev_grid_free) (void)hipEventDestroy(t->ev_grid_free);
+	if (t->ev_grid_ahead) (void)hipEventDestroy(t->ev_grid_ahead);
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
 		t->grid_mlp_out, t->counters, t->ray_indices, t->rays, t->numsteps, t->ray_targets, t->k2_tiles, t->k2_T, t->coords, t->mlp_out, t->coords_compacted, t->dloss, t->sync2, t->bitfield_linear, t->bitfield_coarse, t->k1_scratch, t->k3_scratch, t->r_rays, t->r_masks, t->r_alive, t->r_n_alive, t->r_coords, t->r_out};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1762,12 +1770,43 @@ extern "C" int ngp_nerf_set_dataset_device(ngp_nerf* t, uint32_t n, const ngp_im
 	return set_dataset_common(t, n, m, xforms);
 }
 
+// the samples of one occupancy-grid update (testbed_nerf.cu:2525-2557): uniform + non-uniform generation from `rng` (not advanced here) and their sort into (cascade, Morton block)
+// order; generate = false: they lie in the buffers already (drawn ahead), only the pointers are returned
+static int grid_update_samples(ngp_nerf* t, hipStream_t s, const Rng* rng, uint32_t n_uniform, uint32_t n_nonuniform, bool sorted, bool generate, const float** eval_pos, const uint32_t** eval_idx) {
+	const uint32_t n_samples = n_uniform + n_nonuniform;
+	if (generate) {
+		ProfScope ps(P_GRID_MISC, s);
+		Rng r = *rng;
+		launch_generate_grid_samples(s, n_uniform, pod(r), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions, t->grid_indices,
+			t->opt.max_cascade + 1, -0.01f);
+		r.advance(1ull << 32);
+		launch_generate_grid_samples(s, n_nonuniform, pod(r), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions + (size_t)n_uniform * 3,
+			t->grid_indices + n_uniform, t->opt.max_cascade + 1, MIN_OPTICAL_THICKNESS);
+	}
+	// evaluation order = (cascade, Morton cell) order: spatially coherent like the samples of a ray (sort_util.hip); the result is order independent
+	*eval_pos = t->grid_positions; *eval_idx = t->grid_indices;
+	if (sorted) {
+		if (generate) {
+			ProfScope ps(P_GRID_MISC, s);
+			uint32_t key_bits = 21; for (uint32_t c = t->opt.max_cascade; c; c >>= 1) ++key_bits; // 3 x 7 Morton bits + the cascade
+			// the low 6 Morton bits (the cell inside its 4x4x4 block) stay unsorted: one radix pass less, the same coherence for the hash-grid levels
+			constexpr uint32_t begin_bit = 6u; // Morton blocks of 4 x 4 x 4 cells (coarser blocks = fewer radix passes, less coherence: measured in round 4)
+			if (grid_sample_sort(s, t->grid_sort_temp, t->grid_sort_temp_bytes, t->grid_indices, t->grid_indices_sorted, t->grid_positions, t->grid_positions_sorted, n_samples, std::min(begin_bit, key_bits - 1u), key_bits))
+				return fail("update_density_grid: sort failed");
+		}
+		*eval_pos = t->grid_positions_sorted; *eval_idx = t->grid_indices_sorted;
+	}
+	return 0;
+}
 // update_density_grid_nerf, testbed_nerf.cu:2476-2592
 extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float decay, uint32_t n_uniform, uint32_t n_nonuniform) {
 	FlagScope flag_scope_(t->dbg);
+	const uint64_t version_on_entry = t->state_version;
 	invalidate_k1(t);
 	REQUIRE(t->n_images > 0, "update_density_grid: no dataset");
 	hipStream_t s = (hipStream_t)stream;
+	bool marked = false;
+	if (t->grid_ahead.in_flight) { HIPCHK(hipStreamWaitEvent(s, t->ev_grid_ahead, 0)); t->grid_ahead.in_flight = false; } // used or not: the sample buffers (and the grid it reads) are the side stream's until then
 	const uint32_t n_elements = GRID_N_CELLS * (t->opt.max_cascade + 1);
 	const uint32_t n_samples = n_uniform + n_nonuniform;
 	REQUIRE(n_samples <= t->grid_sample_cap, "update_density_grid: too many samples");
@@ -1775,27 +1814,19 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 		t->n_images_marked = t->n_images;                             // (a streaming client raising n_images_for_training): cells only the new cameras see become trainable
 		if (t->training_step == 0) t->ema_step = 0;
 		launch_mark_untrained(s, n_elements, t->density_grid, t->n_images, t->meta_dev, t->xforms_dev, t->training_step == 0 ? 1 : 0);
+		marked = true; // the grid the samples ahead were thresholded against has changed
 	}
+	const bool want_sorted = !(g_debug_flags & DBG_GRID_NO_SORT);
+	ngp_nerf::GridAhead& ga = t->grid_ahead;
+	const bool ahead_hit = ga.valid && !marked && ga.state_version == version_on_entry && ga.n_uniform == n_uniform && ga.n_nonuniform == n_nonuniform && ga.ema_step == t->ema_step &&
+		ga.rng.state == t->density_grid_rng.state && ga.rng.inc == t->density_grid_rng.inc && ga.sorted == want_sorted;
+	ga.valid = false;
+	if (ahead_hit) ++t->grid_ahead_hits;
 	{ ProfScope ps(P_GRID_MISC, s);
-	HIPCHK(hipMemsetAsync(t->density_grid_tmp, 0, (size_t)n_elements * 4, s));
-	launch_generate_grid_samples(s, n_uniform, pod(t->density_grid_rng), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions, t->grid_indices,
-		t->opt.max_cascade + 1, -0.01f);
-	t->density_grid_rng.advance(1ull << 32);
-	launch_generate_grid_samples(s, n_nonuniform, pod(t->density_grid_rng), nullptr, t->ema_step, t->aabb, t->density_grid, t->grid_positions + (size_t)n_uniform * 3,
-		t->grid_indices + n_uniform, t->opt.max_cascade + 1, MIN_OPTICAL_THICKNESS);
-	t->density_grid_rng.advance(1ull << 32);
-	}
-	// evaluation order = (cascade, Morton cell) order: spatially coherent like the samples of a ray (sort_util.hip); the result is order independent
-	const float* eval_pos = t->grid_positions; const uint32_t* eval_idx = t->grid_indices;
-	if (!(g_debug_flags & DBG_GRID_NO_SORT)) {
-		ProfScope ps(P_GRID_MISC, s);
-		uint32_t key_bits = 21; for (uint32_t c = t->opt.max_cascade; c; c >>= 1) ++key_bits; // 3 x 7 Morton bits + the cascade
-		// the low 6 Morton bits (the cell inside its 4x4x4 block) stay unsorted: one radix pass less, the same coherence for the hash-grid levels
-		constexpr uint32_t begin_bit = 6u; // Morton blocks of 4 x 4 x 4 cells (coarser blocks = fewer radix passes, less coherence: measured in round 4)
-		if (grid_sample_sort(s, t->grid_sort_temp, t->grid_sort_temp_bytes, t->grid_indices, t->grid_indices_sorted, t->grid_positions, t->grid_positions_sorted, n_samples, std::min(begin_bit, key_bits - 1u), key_bits))
-			return fail("update_density_grid: sort failed");
-		eval_pos = t->grid_positions_sorted; eval_idx = t->grid_indices_sorted;
-	}
+	HIPCHK(hipMemsetAsync(t->density_grid_tmp, 0, (size_t)n_elements * 4, s)); }
+	const float* eval_pos = nullptr; const uint32_t* eval_idx = nullptr;
+	if (grid_update_samples(t, s, ahead_hit ? nullptr : &t->density_grid_rng, n_uniform, n_nonuniform, want_sorted, !ahead_hit, &eval_pos, &eval_idx)) return 1;
+	t->density_grid_rng.advance(1ull << 32); t->density_grid_rng.advance(1ull << 32); // (one advance per generation launch, testbed_nerf.cu:2541, 2557)
 	// NerfNetwork::density with the TRAINING params (use_inference_params = false, testbed_nerf.cu:2570)
 	{ ProfScope ps(P_GRID_DENSITY, s);
 	  launch_inference(s, t->model->gm_dev, model_ptrs(t->model, false), eval_pos, 3, n_samples, nullptr, t->grid_mlp_out, 1, true, 0, t->model->gm.F); }
@@ -1807,6 +1838,23 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	launch_grid_to_bitfield(s, t->density_grid, t->opt.max_cascade, t->bitfield, t->mean);
 	launch_build_linear_bitfield(s, t->bitfield, t->bitfield_linear, N_CASCADES, t->bitfield_coarse); // all pooled levels: the march may ask for one above max_cascade (mip_from_dt)
 	HIPCHK(hipGetLastError());
+	// The next update's samples, now: everything they depend on is final (the grid after this EMA, the grid rng, the EMA step).  Steady state only (the sample counts change at
+	// step 256), not under the per-kernel profile (its events time the caller's stream).
+	static const bool no_ahead = getenv("NGP_GRID_NO_AHEAD") && atoi(getenv("NGP_GRID_NO_AHEAD")) != 0;
+	// They run on the communication stream, which a trainer without communicator leaves idle (with one, its collectives must not queue behind them: drawn inside the update then).
+	if (!no_ahead && !(g_debug_flags2 & DBG2_GRID_NO_AHEAD) && !g_prof_on && t->training_step >= 256 + 16 && n_nonuniform > 0 && !t->comm && t->opt.world_size <= 1) {
+		hipStream_t g_grid_stream = nullptr;
+		if (create_helper_stream(&g_comm_stream, true)) return 1;
+		g_grid_stream = g_comm_stream;
+		if (!t->ev_grid_free) { HIPCHK(hipEventCreateWithFlags(&t->ev_grid_free, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&t->ev_grid_ahead, hipEventDisableTiming)); }
+		HIPCHK(hipEventRecord(t->ev_grid_free, s)); HIPCHK(hipStreamWaitEvent(g_grid_stream, t->ev_grid_free, 0));
+		Rng r = t->density_grid_rng;
+		const float* p_; const uint32_t* i_;
+		if (grid_update_samples(t, g_grid_stream, &r, n_uniform, n_nonuniform, want_sorted, true, &p_, &i_)) return 1;
+		HIPCHK(hipEventRecord(t->ev_grid_ahead, g_grid_stream));
+		ga.valid = true; ga.in_flight = true; ga.sorted = want_sorted; ga.n_uniform = n_uniform; ga.n_nonuniform = n_nonuniform; ga.ema_step = t->ema_step; ga.rng = t->density_grid_rng;
+		ga.state_version = t->state_version;
+	}
 	return 0;
 }
 
@@ -2361,6 +2409,7 @@ extern "C" int ngp_nerf_get_stats(ngp_nerf* t, void* stream, ngp_nerf_stats* out
 	out->network_evaluations = c.k2_samples_last ? c.k2_samples_last : c.measured_batch_size_before_compaction; out->reserved = 0;
 	return 0;
 }
+extern "C" uint32_t ngp_nerf_grid_ahead_hits(ngp_nerf* t) { return t ? t->grid_ahead_hits : 0u; }
 extern "C" int ngp_nerf_density_grid_ptrs(ngp_nerf* t, float** grid, uint8_t** bitfield, float** mean) {
 	if (grid) *grid = t->density_grid; if (bitfield) *bitfield = t->bitfield; if (mean) *mean = t->mean; return 0;
 }

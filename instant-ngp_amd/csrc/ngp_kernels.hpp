@@ -12,6 +12,7 @@ extern uint32_t g_debug_flags2; // second word of ablation switches (ngp_debug_s
 enum : uint32_t {
 	DBG2_NO_FUSED_T1W = 1,      // round-4 backward pass: T1 (k_train_fwd_bwd) and W (k_wgrad2) as two kernels instead of k_train_fused
 	DBG2_K1_SETUP_GENERAL = 2,  // k1_setup's general instance (seven lens models, rolling shutter, three pixel formats, CDF samplers) also for plain datasets
+	DBG2_GRID_NO_AHEAD = 4,     // occupancy-grid update: samples drawn and sorted inside the update (rounds 1-6a) instead of ahead of it on a side stream
 };
 enum : uint32_t { DBG_K1_REFERENCE_LAYOUT = 1 /* thread-per-ray sequential march, exact reference recurrence */, DBG_T1_NO_SCATTER = 2, DBG_T1_NO_COARSE_LEVELS = 4, DBG_T1_NO_FINE_LEVELS = 8, DBG_T1_NO_MERGE = 16, DBG_T1_NO_PAIR_HALVES = 64, DBG_T1_NO_QUADS = 128, DBG_FWD_PAIR_LOADS = 256, DBG_FWD_OCC4 = 512, DBG_T1_OCC2 = 1024, DBG_T1_NO_BINNING = 2048 /* hashed levels through global atomics as well */, DBG_NO_STREAM_OVERLAP = 4096, DBG_K2_EAGER = 8192 /* evaluate every marched sample like the reference */, DBG_K3_THREAD_PER_RAY = 32 /* the reference's sequential per-ray loops */,
 	DBG_BIN_NO_HASHED_MERGE = 65536 /* k_grad_bin sums same-cell runs before the sort on the dense levels only (hashed levels: one record per sample and corner): bin + accumulate 150 -> 161 us (profiles/r02_microbench_bin_merge.log) */, DBG_NO_GRAD_ZERO_IN_OPTIMIZER = 131072 /* separate gradient memset per step */,

@@ -334,6 +334,49 @@ def test_sharded_step_equals_allreduce_step_world2_shared_gpu():
     assert q.get(timeout=5) == "ok" and q.get(timeout=5) == "ok"
 
 
+def test_grid_samples_drawn_ahead_are_the_updates_own(hip):
+    """The occupancy-grid update's samples (generate_grid_samples_nerf_nonuniform twice + their sort, testbed_nerf.cu:2525-2557) are drawn on a side stream right after the PREVIOUS
+    update, while the steps in between train: they depend on the grid rng, the EMA step and the grid as that update left it, on no parameter.  Asserted as what it must be: 340
+    deterministic training steps (DBG_K3_TWO_PASS, see test_rccl_in_library_world1) with the samples drawn ahead vs inside the update (DBG2 bit 4): BIT-IDENTICAL density grid,
+    bitfield, parameters and EMA parameters -- including an update whose samples ahead must be dropped (the dataset is set again in between: the grid may have been re-marked)."""
+    import ngp_abi as A
+    K3_TWO_PASS = 1048576
+    GRID_NO_AHEAD = 4
+    def run(flags2, reset_at):
+        hip.ngp_debug_set_flags(K3_TWO_PASS); hip.ngp_debug_set_flags2(flags2)
+        try:
+            hm, t, keep = _setup(A, hip, 0, 1, 1 << 16)
+            for k in range(17):
+                A.check(hip, hip.ngp_nerf_train(t, None, 20))
+                if k == reset_at:
+                    imgs, M, X, pix = keep
+                    A.check(hip, hip.ngp_nerf_set_dataset_host(t, len(imgs), M, X, pix))
+            torch.cuda.synchronize()
+            g, b, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            A.check(hip, hip.ngp_nerf_density_grid_ptrs(t, C.byref(g), C.byref(b), C.byref(m)))
+            grid = torch.as_tensor(_View(g.value, 128 ** 3, "<i4"), device="cuda").cpu().numpy().copy()
+            bits = torch.as_tensor(_View(b.value, 128 ** 3 // 8 // 4, "<i4"), device="cuda").cpu().numpy().copy()
+            st = A.NerfStats(); A.check(hip, hip.ngp_nerf_get_stats(t, None, C.byref(st)))
+            hip.ngp_nerf_grid_ahead_hits.restype = C.c_uint32
+            out = dict(grid=grid, bits=bits, master=hm.read("master", torch), inference=hm.read("inference", torch), hits=int(hip.ngp_nerf_grid_ahead_hits(t)), step=st.training_step,
+                       rays=st.rays_per_batch, batch=st.measured_batch_size)
+            hip.ngp_nerf_destroy(t)
+            return out
+        finally:
+            hip.ngp_debug_set_flags(0); hip.ngp_debug_set_flags2(0)
+    ref = run(GRID_NO_AHEAD, 15)
+    got = run(0, 15)
+    assert ref["hits"] == 0 and ref["step"] == got["step"] == 340
+    # updates every 16 steps from step 256 on; the first ones are drawn from step 272 on; the one after the dataset was set again (step 320) must not use what was drawn before it
+    print(f"grid samples ahead: {got['hits']} updates found their samples ready; rays per batch {got['rays']} vs {ref['rays']}")
+    assert 2 <= got["hits"] <= 4, got["hits"]
+    assert (got["rays"], got["batch"]) == (ref["rays"], ref["batch"])
+    for k in ("grid", "bits", "master", "inference"):
+        a, b = ref[k], got[k]
+        n_diff = int((a.view(np.uint32) != b.view(np.uint32)).sum()) if a.dtype.itemsize == 4 else int((a != b).sum())
+        assert n_diff == 0, f"{k}: {n_diff} of {a.size} words differ between the samples drawn ahead and the samples drawn inside the update"
+
+
 def test_rccl_in_library_world1(hip):
     """ngp_comm_unique_id / ngp_comm_init / the all-reduces inside ngp_nerf_train with a communicator of ONE rank: the collectives are identities, so training IS the plain
     single-rank run -- asserted as what an identity is: the same ray / sample counters on every step checked and BIT-IDENTICAL parameters after 30 steps.  (The data-parallel
