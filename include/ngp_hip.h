@@ -459,7 +459,7 @@ int ngp_nerf_update_density_grid(ngp_nerf*, void* stream, float decay, uint32_t 
 int ngp_nerf_density_grid_ptrs(ngp_nerf*, float** grid, uint8_t** bitfield, float** mean);
 /* Diagnostic / test hook.  update_density_grid_nerf's samples (generate_grid_samples_nerf_nonuniform x 2, testbed_nerf.cu:2525-2557) depend on the grid rng, the EMA step and the grid
  * as the previous update left it -- on no parameter: the trainer draws and sorts the NEXT update's samples on a side stream while the steps in between train, and uses them if
- * nothing they were derived from has changed by then.  Returns how many updates found their samples ready.  (DBG2 bit 4 / NGP_GRID_NO_AHEAD=1: inside the update, as before.) */
+ * nothing they were derived from has changed by then.  Returns how many updates found their samples ready.  (ngp_debug_set_flags2 bit 4 / NGP_DEBUG_FLAGS2_OR=4: inside the update, as before.) */
 uint32_t ngp_nerf_grid_ahead_hits(ngp_nerf*);
 int ngp_nerf_set_density_grid_host(ngp_nerf*, void* stream, const float* grid_host, uint64_t n);
 /* m_training_step restored by load_snapshot (testbed.cu:5400-5403). */

@@ -1840,9 +1840,8 @@ extern "C" int ngp_nerf_update_density_grid(ngp_nerf* t, void* stream, float dec
 	HIPCHK(hipGetLastError());
 	// The next update's samples, now: everything they depend on is final (the grid after this EMA, the grid rng, the EMA step).  Steady state only (the sample counts change at
 	// step 256), not under the per-kernel profile (its events time the caller's stream).
-	static const bool no_ahead = getenv("NGP_GRID_NO_AHEAD") && atoi(getenv("NGP_GRID_NO_AHEAD")) != 0;
 	// They run on the communication stream, which a trainer without communicator leaves idle (with one, its collectives must not queue behind them: drawn inside the update then).
-	if (!no_ahead && !(g_debug_flags2 & DBG2_GRID_NO_AHEAD) && !g_prof_on && t->training_step >= 256 + 16 && n_nonuniform > 0 && !t->comm && t->opt.world_size <= 1) {
+	if (!(g_debug_flags2 & DBG2_GRID_NO_AHEAD) && !g_prof_on && t->training_step >= 256 + 16 && n_nonuniform > 0 && !t->comm && t->opt.world_size <= 1) {
 		hipStream_t g_grid_stream = nullptr;
 		if (create_helper_stream(&g_comm_stream, true)) return 1;
 		g_grid_stream = g_comm_stream;
