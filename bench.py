@@ -424,7 +424,7 @@ def run_image_leg(lib):
 def run_sdf_leg(lib):
     """BASELINE.json config 4 (testbed_sdf.cu:1578-1631 train_sdf, :1449-1520 generate_training_samples_sdf, triangle_bvh.cu:631-660 the ray-stab ground truth): data/sdf/armadillo.obj
     (99,976 triangles, staged under _ref_data/), configs/sdf/base.json (3-D HashGrid L = 16 F = 2 T = 2^19, MLP 2 x 64, MAPE), batch 2^18 points per step.  Untimed: OBJ parse, BVH build,
-    50 steps.  Timed: 7 x 20 whole steps (sample generation + ground truth + forward / backward + optimizer; the ground truth is generated 8 batches per launch ahead of the steps, on a side stream:
+    50 steps.  Timed: 7 x 20 whole steps (sample generation + ground truth + forward / backward + optimizer; the ground truth is generated 16 batches per launch ahead of the steps, on a side stream:
     140 timed steps consume 140 batches and generate 140), and -- on its own -- the ground truth of the half batch that goes through the BVH as one launch."""
     obj = os.path.join(ROOT, "_ref_data", "data", "sdf", "armadillo.obj")
     if not os.path.exists(obj):
@@ -458,7 +458,7 @@ def run_sdf_leg(lib):
     out = {"workload": f"SDF data/sdf/armadillo.obj ({len(tn)} triangles), configs/sdf/base.json (3-D HashGrid L=16 F=2 T=2^19 + MLP 2x64, MAPE), batch {B} points per step (BASELINE.json configs[4])",
            "steps": 7 * n, "ms_per_step": round(ms, 4), "samples_per_s": B / ms * 1e3,
            "ms_ground_truth_alone": round(ms_gt, 4), "ground_truth_points": n_bvh, "inside_fraction": round(float((dist_out < 0).float().mean().item()), 4),
-           "batches_ahead": int(os.environ.get("NGP_SDF_GROUP", "8")) if not int(os.environ.get("NGP_SDF_NO_PREFETCH", "0") or 0) else 0,
+           "batches_ahead": int(os.environ.get("NGP_SDF_GROUP", "16")) if not int(os.environ.get("NGP_SDF_NO_PREFETCH", "0") or 0) else 0,
            "split_note": "ground truth = unsigned BVH distance + up to 32 stab rays for the near-surface and uniform half of a batch, timed on its own on the last batch's points as ONE launch (without the trainer's upper bounds, which only prune more).  The trainer generates samples + ground truth of `batches_ahead` batches per launch on a side stream, ahead of the steps that train on them (a launch lasts as long as its longest walk: 1 / 2 / 4 batches 2.2 / 2.6 / 4.0 ms, profiles/r06_exp_sdf_multibatch.jsonl); every timed step still consumes one freshly generated batch, so ms_per_step holds sample generation + ground truth + forward / backward + scatter + optimizer",
            "n_params": int(n_params.value), "algorithmic_bytes_per_step": int(step_bytes), "achieved_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
            "frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss_mape": loss.value, "iou_after_190_steps": round(iou.value, 4)}

@@ -318,7 +318,7 @@ int ngp_sdf_normalize_mesh_host(float* vertices_inout_host, uint64_t n_vertices,
 int ngp_sdf_create(ngp_encmlp* model, const float* triangles_host, uint32_t n_triangles, ngp_aabb aabb, const ngp_sdf_options* opts_host, ngp_sdf** out);
 void ngp_sdf_destroy(ngp_sdf*);
 int ngp_sdf_train(ngp_sdf*, void* stream, uint32_t n_steps);                 /* training_prep_sdf + train_sdf + optimizer_step, n times */
-/* Batches whose samples + ground truth are generated ahead of the training steps, per ground-truth launch, on a side stream (default 8; 0 = the reference's serial loop
+/* Batches whose samples + ground truth are generated ahead of the training steps, per ground-truth launch, on a side stream (default 16; 0 = the reference's serial loop
  * generate -> train, testbed_sdf.cu:1580-1635 training_prep_sdf / train_sdf).  The batches, their order and the rng positions are the serial loop's either way. */
 int ngp_sdf_set_batches_ahead(ngp_sdf*, uint32_t batches);
 int ngp_sdf_loss(ngp_sdf*, void* stream, float* loss_host);

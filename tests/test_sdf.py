@@ -145,7 +145,7 @@ def test_sdf_trainer_learns_the_mesh(hip):
 def test_sdf_batches_ahead_equal_the_serial_loop(hip):
     """ngp_sdf_train generates the batches a group at a time on a side stream, ahead of the training steps and across calls (one ground-truth launch per group); the batches, their
     order and the rng positions other consumers see (calculate_iou) must be the serial loop's (generate -> train, testbed_sdf.cu:1580-1635): last trained batch bit-identical after
-    every call, for group sizes 1 / 3 / 4, with one-step calls, calls longer than a group and an IoU evaluation (which draws from the trainer's rng) in between."""
+    every call, for group sizes 1 / 3 / 4 / 16, with one-step calls, calls longer than a group and an IoU evaluation (which draws from the trainer's rng) in between."""
     import torch
     tris, name = _mesh()
     verts = tris.reshape(-1, 3).copy()
@@ -179,7 +179,7 @@ def test_sdf_batches_ahead_equal_the_serial_loop(hip):
 
     ref, ref_loss = run(0)
     assert any(np.any(a[2][B // 2:] != b[2][B // 2:]) for a, b in zip([r for r in ref if r[0] == "batch"][:-1], [r for r in ref if r[0] == "batch"][1:]))  # (the batches do differ from one another)
-    for ahead in (1, 3, 4):
+    for ahead in (1, 3, 4, 16):
         got, loss = run(ahead)
         for k, (r, g) in enumerate(zip(ref, got)):
             if r[0] == "batch":
