@@ -424,8 +424,8 @@ def run_image_leg(lib):
 def run_sdf_leg(lib):
     """BASELINE.json config 4 (testbed_sdf.cu:1578-1631 train_sdf, :1449-1520 generate_training_samples_sdf, triangle_bvh.cu:631-660 the ray-stab ground truth): data/sdf/armadillo.obj
     (99,976 triangles, staged under _ref_data/), configs/sdf/base.json (3-D HashGrid L = 16 F = 2 T = 2^19, MLP 2 x 64, MAPE), batch 2^18 points per step.  Untimed: OBJ parse, BVH build,
-    50 steps.  Timed: 7 x 20 whole steps (sample generation + ground truth + forward / backward + optimizer; the ground truth is generated 16 batches per launch ahead of the steps, on a side stream:
-    140 timed steps consume 140 batches and generate 140), and -- on its own -- the ground truth of the half batch that goes through the BVH as one launch."""
+    50 steps.  Timed: 16 x 20 whole steps in ONE host-clock window between two device synchronisations (sample generation + ground truth + forward / backward + optimizer; the ground truth is
+    generated 16 batches per launch ahead of the steps, on a side stream: 320 timed steps consume 320 batches and generate 320), and -- on its own -- the ground truth of the half batch that goes through the BVH as one launch."""
     obj = os.path.join(ROOT, "_ref_data", "data", "sdf", "armadillo.obj")
     if not os.path.exists(obj):
         return {"skipped": "_ref_data/data/sdf/armadillo.obj not staged (tools/stage_reference_data.py copies it from /root/reference at build time)"}
@@ -443,8 +443,14 @@ def run_sdf_leg(lib):
     t = C.c_void_p(); A.check(lib, lib.ngp_sdf_create(hh, ptr(tn), len(tn), box, C.byref(o), C.byref(t)))
     B = int(o.batch_size)
     A.check(lib, lib.ngp_sdf_train(t, None, 50)); torch.cuda.synchronize()
-    n = 20
-    ms = _median_ms(lambda: A.check(lib, lib.ngp_sdf_train(t, None, n))) / n
+    # One CONTINUOUS window, host clock from a synchronised start to a synchronised end: the batches are generated ahead on a side stream, so an event pair on the caller's stream
+    # around a short call would leave part of that work outside the window (it runs on while the host synchronises between repetitions).  Here the window opens with one group
+    # generated before it and closes with one generated but not consumed: what lies between is the work of exactly the steps timed.
+    n, reps = 20, 16
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        A.check(lib, lib.ngp_sdf_train(t, None, n))
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / (n * reps)
     loss = C.c_float(); A.check(lib, lib.ngp_sdf_loss(t, None, C.byref(loss)))
     # the ground truth alone: the near-surface 3/8 + uniform 1/8 of the last batch are the points generate_training_samples_sdf hands to the BVH (the 4/8 on the surface have distance 0)
     pp, dp = C.c_void_p(), C.c_void_p(); lib.ngp_sdf_batch_ptrs(t, C.byref(pp), C.byref(dp))
@@ -456,12 +462,12 @@ def run_sdf_leg(lib):
     iou = C.c_double(); A.check(lib, lib.ngp_sdf_iou(t, 1 << 18, C.byref(iou)))
     step_bytes = B * (12 + 512 + 1024 + 4) + BYTES_PER_PARAM_OPT * n_params.value   # per point 12 (position) + 16 levels x 8 corners x 4 B gathered + RMW scatter + 4 (distance); 38 per parameter
     out = {"workload": f"SDF data/sdf/armadillo.obj ({len(tn)} triangles), configs/sdf/base.json (3-D HashGrid L=16 F=2 T=2^19 + MLP 2x64, MAPE), batch {B} points per step (BASELINE.json configs[4])",
-           "steps": 7 * n, "ms_per_step": round(ms, 4), "samples_per_s": B / ms * 1e3,
+           "steps": reps * n, "ms_per_step": round(ms, 4), "samples_per_s": B / ms * 1e3,
            "ms_ground_truth_alone": round(ms_gt, 4), "ground_truth_points": n_bvh, "inside_fraction": round(float((dist_out < 0).float().mean().item()), 4),
            "batches_ahead": int(os.environ.get("NGP_SDF_GROUP", "16")) if not int(os.environ.get("NGP_SDF_NO_PREFETCH", "0") or 0) else 0,
            "split_note": "ground truth = unsigned BVH distance + up to 32 stab rays for the near-surface and uniform half of a batch, timed on its own on the last batch's points as ONE launch (without the trainer's upper bounds, which only prune more).  The trainer generates samples + ground truth of `batches_ahead` batches per launch on a side stream, ahead of the steps that train on them (a launch lasts as long as its longest walk: 1 / 2 / 4 batches 2.2 / 2.6 / 4.0 ms, profiles/r06_exp_sdf_multibatch.jsonl); every timed step still consumes one freshly generated batch, so ms_per_step holds sample generation + ground truth + forward / backward + scatter + optimizer",
            "n_params": int(n_params.value), "algorithmic_bytes_per_step": int(step_bytes), "achieved_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
-           "frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss_mape": loss.value, "iou_after_190_steps": round(iou.value, 4)}
+           "frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss_mape": loss.value, "iou_after_370_steps": round(iou.value, 4)}
     lib.ngp_sdf_destroy(t); lib.ngp_encmlp_destroy(hh)
     return out
 

@@ -1195,7 +1195,7 @@ extern "C" int ngp_sdf_set_batches_ahead(ngp_sdf* t, uint32_t batches) {
 extern "C" int ngp_sdf_train(ngp_sdf* t, void* stream, uint32_t n_steps) {
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n = t->opt.batch_size;
-	// The ground truth of a batch (BVH distance + stab rays) is a launch as long as its longest walk with most lanes idle: 2.2 ms for one batch, 2.6 for two, 4.0 for four; the step: serial loop 2.96 ms, 1 / 2 / 4 / 8 / 16 batches ahead 2.65 / 1.80 / 1.43 / 1.2 / 1.12 ms (profiles/r06_ab_sdf_batches_ahead.txt)
+	// The ground truth of a batch (BVH distance + stab rays) is a launch as long as its longest walk with most lanes idle: 2.2 ms for one batch, 2.6 for two, 4.0 for four; the step in a continuous 320-step window: serial loop 2.97 ms, 4 / 8 / 12 / 16 batches ahead 1.50 / 1.36 / 1.30 / 1.29 ms (profiles/r06_ab_sdf_batches_ahead.txt)
 	// (profiles/r06_exp_sdf_multibatch.jsonl), and it depends on the rng stream and the mesh only; the training part (0.5 - 0.7 ms) depends on the batch.  So the batches are
 	// generated a GROUP at a time, group k + 1 on a side stream while group k trains -- also across calls (the Testbed trains one step per call).  Same rng positions, same
 	// batches, same order of the training steps as the serial loop (ngp_sdf_set_batches_ahead(t, 0) / NGP_SDF_NO_PREFETCH=1).  The trainer's rng advances as batches are CONSUMED: a draw in between (calculate_iou)

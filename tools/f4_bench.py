@@ -69,7 +69,13 @@ def sdf_cases(lib):
     t = C.c_void_p(); A.check(lib, lib.ngp_sdf_create(hh, ptr(tn), len(tn), box, C.byref(o), C.byref(t)))
     B = o.batch_size
     A.check(lib, lib.ngp_sdf_train(t, None, 50)); torch.cuda.synchronize()
-    ms_step = timed(lambda: A.check(lib, lib.ngp_sdf_train(t, None, 20))) / 20
+    # one continuous host-clock window between two synchronisations (the batches are generated ahead on a side stream: an event pair around a short call would leave part of that
+    # work outside the window -- it runs on while the host synchronises between repetitions)
+    import time
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(16):
+        A.check(lib, lib.ngp_sdf_train(t, None, 20))
+    torch.cuda.synchronize(); ms_step = (time.perf_counter() - t0) * 1e3 / 320
     print(json.dumps({"op": "sdf training step (samples + BVH ground truth + fwd / bwd + optimizer)", "mesh": name, "triangles": len(tn), "batch": B, "ms": round(ms_step, 4), "samples_per_s": B / ms_step * 1e3}), flush=True)
     # the ground truth alone on the points a batch hands to the BVH (near-surface 3/8 + uniform 1/8 of the batch), without the upper bounds (an upper bound only prunes more)
     pp, dp = C.c_void_p(), C.c_void_p(); lib.ngp_sdf_batch_ptrs(t, C.byref(pp), C.byref(dp))
