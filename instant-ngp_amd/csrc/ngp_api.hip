@@ -1195,11 +1195,12 @@ extern "C" int ngp_sdf_set_batches_ahead(ngp_sdf* t, uint32_t batches) {
 extern "C" int ngp_sdf_train(ngp_sdf* t, void* stream, uint32_t n_steps) {
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n = t->opt.batch_size;
-	// The ground truth of a batch (BVH distance + stab rays) is a launch as long as its longest walk with most lanes idle: 2.2 ms for one batch, 2.6 for two, 4.0 for four; the step in a continuous 320-step window: serial loop 2.97 ms, 4 / 8 / 12 / 16 batches ahead 1.50 / 1.36 / 1.30 / 1.29 ms (profiles/r06_ab_sdf_batches_ahead.txt)
+	// The ground truth of a batch (BVH distance + stab rays) is a launch as long as its longest walk with most lanes idle: 2.2 ms for one batch, 2.6 for two, 4.0 for four
 	// (profiles/r06_exp_sdf_multibatch.jsonl), and it depends on the rng stream and the mesh only; the training part (0.5 - 0.7 ms) depends on the batch.  So the batches are
 	// generated a GROUP at a time, group k + 1 on a side stream while group k trains -- also across calls (the Testbed trains one step per call).  Same rng positions, same
-	// batches, same order of the training steps as the serial loop (ngp_sdf_set_batches_ahead(t, 0) / NGP_SDF_NO_PREFETCH=1).  The trainer's rng advances as batches are CONSUMED: a draw in between (calculate_iou)
-	// sees the reference's order, and what was generated ahead from a state that is not the trainer's any more is dropped.
+	// batches, same order of the training steps as the serial loop (ngp_sdf_set_batches_ahead(t, 0) / NGP_SDF_NO_PREFETCH=1).  The trainer's rng advances as batches are
+	// CONSUMED: a draw in between (calculate_iou) sees the reference's order, and what was generated ahead from a state that is not the trainer's any more is dropped.
+	// The step in a continuous 320-step window: serial loop 2.97 ms, 4 / 8 / 12 / 16 batches ahead 1.50 / 1.36 / 1.30 / 1.29 ms (profiles/r06_ab_sdf_batches_ahead.txt).
 	const bool prefetch = t->batches_ahead > 0 && !g_prof_on;
 	const uint32_t n_bvh = n - n / 8 * 4;
 	const uint32_t G = prefetch ? std::max(1u, std::min(t->batches_ahead, t->cap / std::max(n_bvh, 1u))) : 1u;
