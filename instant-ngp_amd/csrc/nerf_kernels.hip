@@ -363,7 +363,9 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	const bool prefilter = a.bitfield_coarse != nullptr && a.bitfield_linear != nullptr;
 	if (prefilter && li_begin < li_end) {
 		// every level the march can ask for: mip_from_dt returns max(mip_from_pos, exponent of the step), which exceeds max_mip for long steps (pooled levels)
-		const uint32_t n_words = (SINGLE_CASCADE ? 1u : a.n_mips) * COARSE_WORDS;
+		// (in LDS: the first n_mips_lds levels -- the dataset's cascades and the next pooled ones, where nearly every point falls; a point of a higher level reads the coarse bit from
+		// memory: 4 KiB of LDS per level decide how many workgroups a CU holds)
+		const uint32_t n_words = (SINGLE_CASCADE ? 1u : a.n_mips_lds) * COARSE_WORDS;
 		for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) s_coarse[w] = a.bitfield_coarse[w];
 	}
 	__syncthreads();
@@ -375,7 +377,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 	//   phase B: wavefront k replays ray k's exit tests / exact-skip orbit over the records in chunk order -- the loop that used to follow each group's evaluation, word for word,
 	//            so masks, counts and n_chunks are those of the one-wavefront-per-ray kernel.
 	const uint32_t wid = threadIdx.x >> 6;
-	const uint32_t coarse_words = prefilter ? (SINGLE_CASCADE ? 1u : a.n_mips) * COARSE_WORDS : 0u;
+	const uint32_t coarse_words = prefilter ? (SINGLE_CASCADE ? 1u : a.n_mips_lds) * COARSE_WORDS : 0u;
 	uint64_t* s_m = (uint64_t*)(s_coarse + coarse_words);               // [4][LAT_MAX_CHUNKS]
 	uint64_t* s_in = s_m + 4 * LAT_MAX_CHUNKS;                          // [4][LAT_MAX_CHUNKS]
 	uint16_t* s_skip = (uint16_t*)(s_in + 4 * LAT_MAX_CHUNKS);          // [4][LAT_MAX_CHUNKS][64]
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(256) k1_count(K1Args a, RaySetup* __restrict__
 					const float dt = calc_dt(t, a.cone_angle_constant);
 					mip = k1_mip(a, dt, pos);
 				}
-				occ = prefilter ? occupied_at_linear_prefiltered(pos, a.bitfield_linear, s_coarse, mip)
+				occ = prefilter ? ((SINGLE_CASCADE || mip < a.n_mips_lds) ? occupied_at_linear_prefiltered(pos, a.bitfield_linear, s_coarse, mip) : occupied_at_linear_prefiltered(pos, a.bitfield_linear, a.bitfield_coarse, mip))
 					: a.bitfield_linear ? occupied_at_linear(pos, a.bitfield_linear, mip) : occupied_at(pos, a.bitfield, mip);
 				if (want_skip && !occ) {
 					// advance_to_next_voxel (nerf_device.cuh:431-441) lands on lattice point j + ceil(max(to(t_target) - to(t), 0.5))
@@ -1845,7 +1847,11 @@ void launch_generate_training_samples_lattice(hipStream_t s, const K1Args& a, ui
 	constexpr uint32_t rec_bytes = 4u * LAT_MAX_CHUNKS * (8u + 8u + 64u * 2u + 1u) + 4u * 64u; // k1_count's chunk records of four rays: masks, skip lengths, mip; the walk's marks
 	const bool prefilter = a.bitfield_coarse != nullptr && a.bitfield_linear != nullptr;
 	if (single) hipLaunchKernelGGL((k1_count<8, true>), dim3(ray_grid), dim3(256), (prefilter ? COARSE_WORDS * 4 : 0) + rec_bytes, s, a, rs, masks, partial, done);
-	else hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), (prefilter ? a.n_mips * COARSE_WORDS * 4 : 0) + rec_bytes, s, a, rs, masks, partial, done);
+	else {
+		K1Args a2 = a;
+		a2.n_mips_lds = std::min<uint32_t>(a.n_mips, std::max<uint32_t>(a.max_mip + 2u, 4u)); // fox (max_mip 2): 4 levels = 16 KiB + 18.6 KiB of records: four workgroups per CU (all eight levels: three)
+		hipLaunchKernelGGL((k1_count<8, false>), dim3(ray_grid), dim3(256), (prefilter ? a2.n_mips_lds * COARSE_WORDS * 4 : 0) + rec_bytes, s, a2, rs, masks, partial, done);
+	}
 	if (!count_only) hipLaunchKernelGGL(k1_write, dim3(ray_grid), dim3(256), 0, s, a, rs, masks, partial);
 }
 void launch_build_linear_bitfield(hipStream_t s, const uint8_t* bitfield, uint8_t* linear, uint32_t n_cascades, uint32_t* coarse) {

@@ -71,6 +71,7 @@ struct K1Args {
 	const uint8_t* bitfield; uint32_t max_mip;
 	const uint8_t* bitfield_linear; // optional x-major copy (launch_build_linear_bitfield) for the lattice marcher
 	uint32_t clamp_min_max = 0;                // ablation DBG_K1_MIP_CLAMP_MIN_MAX
+	uint32_t n_mips_lds = 1; // k1_count: levels of bitfield_coarse it keeps in LDS (set by the launcher)
 	uint32_t n_mips = 1; // bitfield levels present in bitfield_linear / bitfield_coarse (N_CASCADES: mip_from_dt may ask for a pooled level above max_mip, nerf_device.cuh:459)
 	const uint32_t* bitfield_coarse = nullptr; // optional: k1_prefilter_words(n_mips) words from launch_build_linear_bitfield: one bit per 4x4x4 cells of every level of the x-major copy, then the dilated mid grid of level 0 (2x2x2 cells per bit): the marchers' LDS prefilters
 	uint32_t no_first_point_skip = 0;          // ablation DBG_K1_NO_FIRST_POINT_SKIP: k1_count evaluates every chunk of a group, also those behind the ray's exit from the box (rounds 1-2)
