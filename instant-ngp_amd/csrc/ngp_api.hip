@@ -1613,6 +1613,7 @@ struct ngp_nerf {
 	// side stream while the steps in between train; used if nothing they were derived from has changed by then (grid_ahead_matches), dropped otherwise
 	struct GridAhead { bool valid = false, in_flight = false, sorted = false; uint32_t n_uniform = 0, n_nonuniform = 0, ema_step = 0; Rng rng; uint64_t state_version = 0; } grid_ahead;
 	hipEvent_t ev_grid_free = nullptr, ev_grid_ahead = nullptr; uint32_t grid_ahead_hits = 0;
+	TrainCounters* stats_host = nullptr; // pinned: ngp_nerf_get_stats
 	uint32_t max_rays = 1u << 18;
 	// extra (latent / light-direction) dims, testbed.h Nerf::Training::extra_dims_gpu / extra_dims_opt / rendering_extra_dims: n_extra floats per image (+ one slot behind them
 	// for the dims a rendering uses), their gradient, the per-image VarAdamOptimizer state (adam_optimizer.h:27-47; one iteration count: every image steps every time)
@@ -1686,6 +1687,7 @@ extern "C" void ngp_nerf_destroy(ngp_nerf* t) {
 	if (t->k1_prelaunched && t->k1_stream) (void)hipStreamSynchronize(t->k1_stream); // (process-wide stream: not destroyed with the trainer)
 	if (t->ev_ctl) (void)hipEventDestroy(t->ev_ctl);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
+	if (t->stats_host) (void)hipHostFree(t->stats_host);
 	if (t->ev_grid_free) (void)hipEventDestroy(t->ev_grid_free);
 	if (t->ev_grid_ahead) (void)hipEventDestroy(t->ev_grid_ahead);
 	void* ptrs[] = {t->meta_dev, t->xforms_dev, t->density_grid, t->density_grid_tmp, t->bitfield, t->mean, t->mean_partial, t->grid_positions, t->grid_indices, t->grid_positions_sorted, t->grid_indices_sorted, t->grid_sort_temp,
@@ -2400,9 +2402,12 @@ extern "C" int ngp_nerf_counter_ptrs(ngp_nerf* t, uint32_t** counters2) { *count
 extern "C" int ngp_nerf_uses_k2_stash(ngp_nerf* t) { return t && t->k2_enc_valid ? 1 : 0; }
 extern "C" uint64_t ngp_model_last_sweep_params(const ngp_model* m) { return m ? m->last_sweep_params : 0; }
 extern "C" int ngp_nerf_get_stats(ngp_nerf* t, void* stream, ngp_nerf_stats* out) {
-	TrainCounters c;
-	HIPCHK(hipMemcpyAsync(&c, t->counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	// (pinned staging buffer: a device-to-host copy into pageable memory goes through the runtime's own staging and costs a few hundred microseconds of an idle GPU per call --
+	// Testbed::train reads the loss every 16 steps like the reference, testbed.cu:4625: 0.471 -> see profiles/r06_pyngp_frame_rate.txt)
+	if (!t->stats_host) HIPCHK(hipHostMalloc((void**)&t->stats_host, sizeof(TrainCounters), hipHostMallocDefault));
+	HIPCHK(hipMemcpyAsync(t->stats_host, t->counters, sizeof(TrainCounters), hipMemcpyDeviceToHost, (hipStream_t)stream));
 	HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+	const TrainCounters c = *t->stats_host;
 	out->training_step = c.training_step; out->rays_per_batch = c.rays_per_batch; out->n_rays_last = c.n_rays_last;
 	out->measured_batch_size = c.measured_batch_size; out->measured_batch_size_before_compaction = c.measured_batch_size_before_compaction;
 	out->loss = c.loss_scalar; out->total_rays = c.total_rays; out->total_samples = c.total_samples;
