@@ -358,7 +358,9 @@ def test_render_matches_oracle(ora, hip, scene):
 #   depth the same max-weight sample (|delta| < 1e-4) on 99.90 - 99.92 % of the hit pixels, 99th percentile 8e-7 .. 2e-6; the rest picked another sample of nearly equal
 #         weight (any distance along the ray); alpha-0.2 classification: 0 mismatches.
 RENDER_TOL = {
-    "synthetic_aabb1": dict(rgba_q99=1e-4, rgba_outliers=1e-3, rgba_max=2e-2, depth_same_sample=0.997, depth_q99=1e-4),
+    # (rgba_max: 2 x the 2.6e-2 above.  It stood at 2e-2 -- BELOW the measured maximum -- until the last GPU tier of round 6 drew a 2.11e-2 pixel: the maximum over 40,000 pixels of a
+    # freshly trained model is one voxel-face sample appearing or not; what the test holds tight are the 99th percentile and the fraction of pixels off by more than 2e-3.)
+    "synthetic_aabb1": dict(rgba_q99=1e-4, rgba_outliers=1e-3, rgba_max=5.2e-2, depth_same_sample=0.997, depth_q99=1e-4),
     "fox_small_aabb4": dict(rgba_q99=1.5e-4, rgba_outliers=1e-3, rgba_max=8e-2, depth_same_sample=0.997, depth_q99=1e-4),
 }
 
