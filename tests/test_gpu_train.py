@@ -159,6 +159,7 @@ def test_lazy_k2_matches_eager(ora, hip):
     rng, grng = A.Pcg32(), A.Pcg32()
     hip.ngp_nerf_get_rng(s["t"], C.byref(rng), C.byref(grng))
     rays = min(st.rays_per_batch, 12000)  # far below K1's sample cap and K3's batch clamp (both order dependent)
+    K3_TWO_PASS = 1048576
     res = {}
     for name, flags in (("lazy", 0), ("lazy_rounds", 0), ("lazy_tile16", 0), ("lazy_tile32", 0), ("lazy_tile8", 0), ("eager", 8192)):
         c = _make(ora, hip, B, n_images=12, res=96)
@@ -174,7 +175,10 @@ def test_lazy_k2_matches_eager(ora, hip):
         A.check(hip, hip.ngp_nerf_set_density_grid_host(c["t"], None, ptr(grid), C.c_uint64(n_cells)))
         hip.ngp_nerf_set_rng(c["t"], C.byref(rng))
         A.check(hip, hip.ngp_nerf_set_rays_per_batch(c["t"], rays))
-        hip.ngp_debug_set_flags(flags)
+        # Every variant runs K3 as the deterministic two-pass kernel (DBG_K3_TWO_PASS: slot-ordered compaction): fill_rollover duplicates the FIRST B - n compacted samples (here
+        # ~15 % of the batch), and with the production K3 which ones come first depends on the order of its span atomics -- two runs of the SAME path then differ by a few per
+        # cent, occasionally by 10 % (the last tier run of round 6 drew 0.1008 against the 0.1 bar below).  With the slot order the variants see the same batch rows.
+        hip.ngp_debug_set_flags(flags | K3_TWO_PASS)
         try:
             A.check(hip, hip.ngp_nerf_train_forward_backward(c["t"], None))
         finally:
@@ -200,9 +204,7 @@ def test_lazy_k2_matches_eager(ora, hip):
     assert cl[1] < 0.7 * cl[0]  # the cut is active in this state
     err = np.linalg.norm(gl - ge) / np.linalg.norm(ge)
     print("relative gradient difference", err)
-    # fill_rollover duplicates the FIRST B - n compacted samples (here ~15 % of the batch) and which ones come first depends on the
-    # order of K3's span atomics, so two runs of the SAME path differ by a few per cent as well
-    assert err < 0.1
+    assert err < 0.1  # (measured with the slot-ordered compaction: see the printed value)
     hip.ngp_nerf_destroy(s["t"]); ora.ora_nerf_destroy(s["ot"])
 
 
